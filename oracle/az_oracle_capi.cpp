@@ -1,0 +1,283 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see az_rng.hpp header for the usage rule).
+// extern "C" surface over the restatement so tests/ (ctypes) and bench.py's
+// cpu_baseline leg can drive it.  Builds to oracle/liboracle.so (oracle/Makefile).
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "az_games.hpp"
+#include "az_mcts.hpp"
+#include "az_playmanager.hpp"
+#include "az_rng.hpp"
+#include "az_tafl.hpp"
+
+using namespace orc;
+
+namespace {
+std::unique_ptr<Game> make_game(int game_id) {
+  switch (game_id) {
+    case 0: return std::make_unique<Connect4>();
+    case 1: return std::make_unique<Tawlbwrdd>();
+    default: throw std::runtime_error("unknown game id");
+  }
+}
+struct MctsBox {
+  Pcg32 rng;
+  std::unique_ptr<Mcts> m;
+  std::unique_ptr<Game> leaf;
+};
+struct PmBox {
+  std::unique_ptr<PlayManager> pm;
+};
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------- RNG layer
+void orc_pcg32_outputs(uint64_t seed, uint32_t n, uint32_t* out) {
+  Pcg32 g; g.seed(seed);
+  for (uint32_t i = 0; i < n; ++i) out[i] = g.next();
+}
+// shuffles {0..n-1} `reps` times in a row from one seeded stream; out[reps*n]
+void orc_shuffle_iota(uint64_t seed, uint32_t n, uint32_t reps, uint32_t* out) {
+  Pcg32 g; g.seed(seed);
+  for (uint32_t r = 0; r < reps; ++r) {
+    for (uint32_t i = 0; i < n; ++i) out[r * n + i] = i;
+    shuffle(out + r * n, n, g);
+  }
+}
+void orc_uniform01(uint64_t seed, uint32_t n, float* out) {
+  Pcg32 g; g.seed(seed);
+  for (uint32_t i = 0; i < n; ++i) out[i] = uniform01(g);
+}
+// fresh_each != 0: a new distribution object per draw (shaped-Dirichlet pattern, mcts.cc:430)
+void orc_gamma(uint64_t seed, float alpha, float beta, uint32_t n, int fresh_each, float* out) {
+  Pcg32 g; g.seed(seed);
+  Gamma dist(alpha, beta);
+  for (uint32_t i = 0; i < n; ++i) {
+    if (fresh_each) { Gamma d2(alpha, beta); out[i] = d2(g); }
+    else out[i] = dist(g);
+  }
+}
+void orc_gumbel(uint64_t seed, uint32_t n, float* out) {
+  Pcg32 g; g.seed(seed);
+  for (uint32_t i = 0; i < n; ++i) out[i] = gumbel01(g);
+}
+
+// ---------------------------------------------------------------- games
+void* orc_game_new(int game_id) { try { return make_game(game_id).release(); } catch (...) { return nullptr; } }
+void* orc_c4_from_board(const int8_t* board, int8_t player, int32_t turn) {
+  return new Connect4(board, player, turn);
+}
+void* orc_game_copy(void* g) { return static_cast<Game*>(g)->copy().release(); }
+void orc_game_free(void* g) { delete static_cast<Game*>(g); }
+int orc_game_play(void* g, uint32_t m) {
+  try { static_cast<Game*>(g)->play_move(m); return 0; } catch (...) { return -1; }
+}
+uint32_t orc_game_num_moves(void* g) { return static_cast<Game*>(g)->num_moves(); }
+uint32_t orc_game_num_players(void* g) { return static_cast<Game*>(g)->num_players(); }
+uint32_t orc_game_player(void* g) { return static_cast<Game*>(g)->current_player(); }
+uint32_t orc_game_turn(void* g) { return static_cast<Game*>(g)->current_turn(); }
+void orc_game_valid(void* g, uint8_t* out) { static_cast<Game*>(g)->valid_moves(out); }
+int orc_game_scores(void* g, float* out) { return static_cast<Game*>(g)->scores(out) ? 1 : 0; }
+void orc_game_canonical_shape(void* g, int* chw) {
+  static_cast<Game*>(g)->canonical_shape(chw, chw + 1, chw + 2);
+}
+void orc_game_canonical(void* g, float* out) { static_cast<Game*>(g)->canonicalized(out); }
+uint64_t orc_game_key(void* g) { return static_cast<Game*>(g)->key(); }
+
+// ---------------------------------------------------------------- single tree
+struct OrcMctsCfg {
+  float cpuct;
+  uint32_t num_players, num_moves;
+  float epsilon, root_policy_temp, fpu_reduction;
+  int32_t relative_values, root_fpu_zero, shaped_dirichlet;
+};
+void* orc_mcts_new(const OrcMctsCfg* c, uint64_t seed) {
+  auto* b = new MctsBox();
+  b->rng.seed(seed);
+  MctsConfig mc;
+  mc.cpuct = c->cpuct; mc.num_players = c->num_players; mc.num_moves = c->num_moves;
+  mc.epsilon = c->epsilon; mc.root_policy_temp = c->root_policy_temp; mc.fpu_reduction = c->fpu_reduction;
+  mc.relative_values = c->relative_values != 0; mc.root_fpu_zero = c->root_fpu_zero != 0;
+  mc.shaped_dirichlet = c->shaped_dirichlet != 0;
+  b->m = std::make_unique<Mcts>(mc, &b->rng);
+  return b;
+}
+void orc_mcts_free(void* h) { delete static_cast<MctsBox*>(h); }
+// find_leaf; the leaf state is kept inside the box (orc_mcts_leaf to borrow it)
+void orc_mcts_find_leaf(void* h, void* game) {
+  auto* b = static_cast<MctsBox*>(h);
+  b->leaf = b->m->find_leaf(*static_cast<Game*>(game));
+}
+void* orc_mcts_leaf(void* h) { return static_cast<MctsBox*>(h)->leaf.get(); }
+void orc_mcts_process_result(void* h, float* value, const float* pi, int noise) {
+  static_cast<MctsBox*>(h)->m->process_result(value, pi, noise != 0);
+}
+// `sims` x (find_leaf, dumb_eval, process_result) — mcts_test.cc:41-72 pattern
+void orc_mcts_search_dumb(void* h, void* game, uint32_t sims, int noise) {
+  auto* b = static_cast<MctsBox*>(h);
+  Game* gs = static_cast<Game*>(game);
+  std::vector<float> v(gs->num_players() + 1), pi(gs->num_moves());
+  for (uint32_t s = 0; s < sims; ++s) {
+    auto leaf = b->m->find_leaf(*gs);
+    dumb_eval(*leaf, v.data(), pi.data());
+    b->m->process_result(v.data(), pi.data(), noise != 0);
+  }
+}
+int orc_mcts_update_root(void* h, void* game, uint32_t move) {
+  try { static_cast<MctsBox*>(h)->m->update_root(*static_cast<Game*>(game), move); return 0; }
+  catch (...) { return -1; }
+}
+void orc_mcts_counts(void* h, uint32_t* out) {
+  auto c = static_cast<MctsBox*>(h)->m->counts();
+  std::memcpy(out, c.data(), c.size() * sizeof(uint32_t));
+}
+void orc_mcts_root_q(void* h, float* out) {
+  auto c = static_cast<MctsBox*>(h)->m->root_q_values();
+  std::memcpy(out, c.data(), c.size() * sizeof(float));
+}
+void orc_mcts_probs(void* h, float temp, int pruned, float* out) {
+  auto* m = static_cast<MctsBox*>(h)->m.get();
+  auto p = pruned ? m->probs_pruned(temp) : m->probs(temp);
+  std::memcpy(out, p.data(), p.size() * sizeof(float));
+}
+uint32_t orc_mcts_pick_move(void* h, const float* p, uint32_t n) {
+  auto* b = static_cast<MctsBox*>(h);
+  return Mcts::pick_move(std::vector<float>(p, p + n), b->rng);
+}
+uint32_t orc_mcts_depth(void* h) { return static_cast<MctsBox*>(h)->m->depth(); }
+uint32_t orc_mcts_root_n(void* h) { return static_cast<MctsBox*>(h)->m->root_n(); }
+float orc_mcts_avg_leaf_depth(void* h) { return static_cast<MctsBox*>(h)->m->avg_leaf_depth(); }
+float orc_mcts_entropy(void* h) { return static_cast<MctsBox*>(h)->m->normalized_root_entropy(); }
+void orc_mcts_root_value(void* h, float* wld) { static_cast<MctsBox*>(h)->m->root_value(wld); }
+void orc_mcts_add_root_noise(void* h) { static_cast<MctsBox*>(h)->m->add_root_noise(); }
+void orc_mcts_apply_root_policy_temp(void* h) { static_cast<MctsBox*>(h)->m->apply_root_policy_temp(); }
+// root children in stored order: moves[k], policy[k], n[k], q[k]; returns k
+uint32_t orc_mcts_root_children(void* h, uint32_t* moves, float* policy, uint32_t* n, float* q) {
+  auto* m = static_cast<MctsBox*>(h)->m.get();
+  const Node& r = m->root();
+  for (uint32_t i = 0; i < r.nchild; ++i) {
+    const Node& c = m->node(r.child0 + i);
+    moves[i] = c.move; policy[i] = c.policy; n[i] = c.n; q[i] = c.q;
+  }
+  return r.nchild;
+}
+// Node::uct on explicit numbers (mcts_test.cc:14-38 known answers)
+float orc_node_uct(float q, float policy, uint32_t n, float sqrt_parent_n, float cpuct, float fpu) {
+  Node c; c.q = q; c.policy = policy; c.n = n;
+  return Mcts::uct(c, sqrt_parent_n, cpuct, fpu);
+}
+
+// ---------------------------------------------------------------- PlayManager
+struct OrcPlayParams {
+  uint32_t games_to_play, concurrent_games, max_batch_size, max_cache_size, cache_shards;
+  uint32_t mcts_visits[4];
+  float cpuct, start_temp, final_temp, temp_decay_half_life;
+  int32_t history_enabled, tree_reuse;
+  float epsilon, mcts_root_temp;
+  int32_t playout_cap_randomization;
+  uint32_t playout_cap_depth;
+  float playout_cap_percent, fpu_reduction;
+  int32_t root_fpu_zero, shaped_dirichlet, policy_target_pruning;
+  float resign_percent, resign_playthrough_percent;
+  int32_t eval_type[4];  // -1 = unset (all NN)
+};
+typedef void (*orc_eval_fn)(const float* canonical, uint32_t n, float* v, float* pi, void* user);
+
+void* orc_pm_new(int game_id, const OrcPlayParams* c, uint64_t seed, int per_slot_rng, int record_moves) {
+  try {
+    auto base = make_game(game_id);
+    const uint32_t P = base->num_players();
+    PlayParams p;
+    p.games_to_play = c->games_to_play; p.concurrent_games = c->concurrent_games;
+    p.max_batch_size = c->max_batch_size; p.max_cache_size = c->max_cache_size;
+    p.cache_shards = c->cache_shards ? c->cache_shards : 1;
+    p.mcts_visits.assign(c->mcts_visits, c->mcts_visits + P);
+    p.cpuct = c->cpuct; p.start_temp = c->start_temp; p.final_temp = c->final_temp;
+    p.temp_decay_half_life = c->temp_decay_half_life;
+    p.history_enabled = c->history_enabled != 0; p.tree_reuse = c->tree_reuse != 0;
+    p.epsilon = c->epsilon; p.mcts_root_temp = c->mcts_root_temp;
+    p.playout_cap_randomization = c->playout_cap_randomization != 0;
+    p.playout_cap_depth = c->playout_cap_depth; p.playout_cap_percent = c->playout_cap_percent;
+    p.fpu_reduction = c->fpu_reduction; p.root_fpu_zero = c->root_fpu_zero != 0;
+    p.shaped_dirichlet = c->shaped_dirichlet != 0; p.policy_target_pruning = c->policy_target_pruning != 0;
+    p.resign_percent = c->resign_percent; p.resign_playthrough_percent = c->resign_playthrough_percent;
+    if (c->eval_type[0] >= 0)
+      for (uint32_t i = 0; i < P; ++i) p.eval_type.push_back(static_cast<EvalType>(c->eval_type[i]));
+    auto* b = new PmBox();
+    b->pm = std::make_unique<PlayManager>(std::move(base), p, seed, per_slot_rng != 0);
+    b->pm->record_moves = record_moves != 0;
+    return b;
+  } catch (...) { return nullptr; }
+}
+void orc_pm_free(void* h) { delete static_cast<PmBox*>(h); }
+int orc_pm_run(void* h, orc_eval_fn fn, void* user) {
+  try {
+    static_cast<PmBox*>(h)->pm->run([fn, user](const float* c, uint32_t n, float* v, float* pi) {
+      if (!fn) throw std::runtime_error("NN evaluator needed but none supplied");
+      fn(c, n, v, pi, user);
+    });
+    return 0;
+  } catch (...) { return -1; }
+}
+void orc_pm_scores(void* h, float* out) {
+  auto& s = static_cast<PmBox*>(h)->pm->scores();
+  std::memcpy(out, s.data(), s.size() * sizeof(float));
+}
+void orc_pm_resign_scores(void* h, float* out) {
+  auto& s = static_cast<PmBox*>(h)->pm->resign_scores();
+  std::memcpy(out, s.data(), s.size() * sizeof(float));
+}
+uint32_t orc_pm_games_completed(void* h) { return static_cast<PmBox*>(h)->pm->games_completed(); }
+// stats[0..6] = avg_game_length, avg_leaf_depth, avg_search_entropy, fast_avg_leaf_depth,
+//               fast_avg_search_entropy, avg_moves_per_turn, avg_valid_moves
+void orc_pm_stats(void* h, float* out) {
+  auto* pm = static_cast<PmBox*>(h)->pm.get();
+  out[0] = pm->avg_game_length(); out[1] = pm->avg_leaf_depth(); out[2] = pm->avg_search_entropy();
+  out[3] = pm->fast_avg_leaf_depth(); out[4] = pm->fast_avg_search_entropy();
+  out[5] = pm->avg_moves_per_turn(); out[6] = pm->avg_valid_moves();
+}
+// counters[0..4] = sims, nn_evals, cache_hits, cache_misses, hist_count
+void orc_pm_counters(void* h, uint64_t* out) {
+  auto* pm = static_cast<PmBox*>(h)->pm.get();
+  out[0] = pm->sims(); out[1] = pm->nn_evals(); out[2] = pm->cache_hits(); out[3] = pm->cache_misses();
+  out[4] = pm->hist_count();
+}
+uint64_t orc_pm_hist_count(void* h) { return static_cast<PmBox*>(h)->pm->hist_count(); }
+void orc_pm_history(void* h, float* canonical, float* v, float* pi) {
+  auto& hist = static_cast<PmBox*>(h)->pm->history();
+  size_t co = 0, vo = 0, po = 0;
+  for (auto& r : hist) {
+    std::memcpy(canonical + co, r.canonical.data(), r.canonical.size() * 4); co += r.canonical.size();
+    std::memcpy(v + vo, r.v.data(), r.v.size() * 4); vo += r.v.size();
+    std::memcpy(pi + po, r.pi.data(), r.pi.size() * 4); po += r.pi.size();
+  }
+}
+uint64_t orc_pm_move_count(void* h) { return static_cast<PmBox*>(h)->pm->moves().size(); }
+// rows of 6 u32: slot, game_in_slot, move, turn, player, capped; counts[num_moves] per row
+void orc_pm_moves(void* h, uint32_t* rows, uint32_t* counts, uint32_t num_moves) {
+  auto& mv = static_cast<PmBox*>(h)->pm->moves();
+  for (size_t i = 0; i < mv.size(); ++i) {
+    rows[i * 6 + 0] = mv[i].slot; rows[i * 6 + 1] = mv[i].game_in_slot; rows[i * 6 + 2] = mv[i].move;
+    rows[i * 6 + 3] = mv[i].turn; rows[i * 6 + 4] = mv[i].player; rows[i * 6 + 5] = mv[i].capped;
+    if (counts) std::memcpy(counts + i * num_moves, mv[i].counts.data(), num_moves * sizeof(uint32_t));
+  }
+}
+
+// ---------------------------------------------------------------- S3-FIFO
+void* orc_cache_new(uint32_t max_size, uint32_t shards, uint32_t ghost, uint32_t np, uint32_t nv) {
+  return new ShardedS3Fifo(max_size, shards, ghost, np, nv);
+}
+void orc_cache_free(void* c) { delete static_cast<ShardedS3Fifo*>(c); }
+int orc_cache_find(void* c, uint64_t h, float* p, float* v) { return static_cast<ShardedS3Fifo*>(c)->find(h, p, v); }
+void orc_cache_insert(void* c, uint64_t h, const float* p, const float* v) { static_cast<ShardedS3Fifo*>(c)->insert(h, p, v); }
+// out[0..5] = hits, misses, evictions, reinserts, size, max_size
+void orc_cache_stats(void* c, uint64_t* out) {
+  auto* s = static_cast<ShardedS3Fifo*>(c);
+  out[0] = s->hits(); out[1] = s->misses(); out[2] = s->evictions(); out[3] = s->reinserts();
+  out[4] = s->size(); out[5] = s->max_size();
+}
+
+}  // extern "C"

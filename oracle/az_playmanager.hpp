@@ -1,0 +1,414 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see az_rng.hpp header for the usage rule).
+// CPU restatement of PlayManager (play_manager.h:159-441, play_manager.cc) as a
+// single-threaded, fully deterministic state machine.
+//
+// Determinism contract (SURVEY §8c tiers T1/T2, R12, R15):
+//  * the reference keeps ONE `thread_local pcg32` per worker thread, shared by
+//    every tree that thread touches (mcts.cc:19).  `per_slot_rng=false` restates
+//    exactly that for one worker thread (one stream, FIFO queue order).
+//    `per_slot_rng=true` gives every game slot its own stream seeded
+//    slot_seed(seed, slot); with concurrent_games == 1 both modes coincide, which
+//    is how a many-slot device run is compared slot by slot.
+//  * the playout-cap / resign-playthrough coins come from an UNSEEDABLE
+//    thread_local std::default_random_engine in the reference
+//    (play_manager.cc:261-262).  Here they come from a second pcg32 per stream
+//    ("coin stream", seeded seed ^ kCoinSalt) through uniform01 — build-defined.
+//  * NN evaluation order: the mcts queue is drained, then every waiting slot is
+//    evaluated in FIFO order in batches of max_batch_size (py_wrapper.cc:449-504
+//    + play_manager.cc:619-642), then pushed back in batch order.
+#pragma once
+#include <deque>
+#include <functional>
+#include <memory>
+#include <optional>
+#include <vector>
+
+#include "az_mcts.hpp"
+#include "az_s3fifo.hpp"
+
+namespace orc {
+
+enum class EvalType : uint8_t { NN = 0, RANDOM = 1, PLAYOUT = 2 };  // play_manager.h:20
+
+constexpr uint64_t kCoinSalt = 0x5851F42D4C957F2DULL;
+inline uint64_t slot_seed(uint64_t seed, uint32_t slot) {
+  return mix64(seed + 0x9E3779B97F4A7C15ULL * (static_cast<uint64_t>(slot) + 1));
+}
+
+struct PlayParams {  // play_manager.h:60-154 (fields the path implements)
+  uint32_t games_to_play = 0;
+  uint32_t concurrent_games = 0;
+  uint32_t max_batch_size = 1;
+  uint32_t max_cache_size = 0;
+  uint32_t cache_shards = 1;
+  std::vector<uint32_t> mcts_visits;
+  float cpuct = 2.0f;
+  float start_temp = 1.0f;
+  float final_temp = 1.0f;
+  float temp_decay_half_life = 0;
+  bool history_enabled = false;
+  bool self_play = false;
+  bool tree_reuse = true;
+  float epsilon = 0.0f;
+  float mcts_root_temp = 1.0f;
+  bool playout_cap_randomization = false;
+  uint32_t playout_cap_depth = 25;
+  float playout_cap_percent = 0.75f;
+  float fpu_reduction = 0.0f;
+  bool root_fpu_zero = false;
+  bool shaped_dirichlet = false;
+  bool policy_target_pruning = false;
+  float resign_percent = 0.0f;
+  float resign_playthrough_percent = 0.0f;
+  std::vector<EvalType> eval_type;  // per player; empty = all NN
+};
+
+struct HistoryRow {  // game_state.h:16-20
+  std::vector<float> canonical, v, pi;
+};
+
+struct MoveRecord {  // test hook: one entry per played move
+  uint32_t slot, game_in_slot, move, turn;
+  uint8_t player;
+  bool capped;
+  std::vector<uint32_t> counts;  // root counts() right before the move
+};
+
+class PlayManager {
+ public:
+  using Evaluator = std::function<void(const float* canonical, uint32_t n, float* v, float* pi)>;
+
+  PlayManager(std::unique_ptr<Game> base, PlayParams p, uint64_t seed, bool per_slot_rng)
+      : base_(std::move(base)), params_(std::move(p)), per_slot_rng_(per_slot_rng) {
+    const uint32_t P = base_->num_players();
+    if (params_.mcts_visits.size() != P)
+      throw std::runtime_error("You must specify MCTS visits for each player");  // play_manager.cc:20-22
+    games_started_ = params_.concurrent_games;
+    const uint32_t nstreams = per_slot_rng_ ? params_.concurrent_games : 1;
+    tree_rng_.resize(nstreams);
+    coin_rng_.resize(nstreams);
+    for (uint32_t s = 0; s < nstreams; ++s) {
+      const uint64_t sd = per_slot_rng_ ? slot_seed(seed, s) : seed;
+      tree_rng_[s].seed(sd);
+      coin_rng_[s].seed(sd ^ kCoinSalt);
+    }
+    if (params_.max_cache_size > 0) {  // play_manager.cc:195-203 (one model group)
+      const uint32_t per_group = params_.max_cache_size;
+      cache_ = std::make_unique<ShardedS3Fifo>(per_group, params_.cache_shards, per_group * 9 / 10,
+                                               base_->num_moves(), P + 1);
+    }
+    scores_.assign(P + 1, 0.0f);
+    resign_scores_.assign(P + 1, 0.0f);
+    slots_.resize(params_.concurrent_games);
+    for (uint32_t i = 0; i < params_.concurrent_games; ++i) {  // play_manager.cc:214-230
+      Slot& g = slots_[i];
+      g.gs = base_->copy();
+      g.gs->randomize_start();
+      for (uint32_t j = 0; j < P; ++j) g.mcts.push_back(make_mcts(i));
+      g.canonical.assign(base_->canonical_size(), 0.0f);
+      g.v.assign(P + 1, 0.0f);
+      g.pi.assign(base_->num_moves(), 0.0f);
+      awaiting_mcts_.push_back(i);
+    }
+  }
+
+  // Single-threaded equivalent of N x play() + the GameRunner eval pipeline.
+  void run(const Evaluator& nn) {
+    while (games_completed_ < params_.games_to_play) {
+      while (!awaiting_mcts_.empty() && games_completed_ < params_.games_to_play) {
+        const uint32_t i = awaiting_mcts_.front();
+        awaiting_mcts_.pop_front();
+        step(i);
+      }
+      if (games_completed_ >= params_.games_to_play) break;
+      if (awaiting_inference_.empty()) break;  // nothing left to do (all slots retired)
+      flush_inference(nn);
+    }
+  }
+
+  // ---- stats getters, play_manager.h:173-366 -------------------------------------
+  const std::vector<float>& scores() const { return scores_; }
+  const std::vector<float>& resign_scores() const { return resign_scores_; }
+  uint32_t games_completed() const { return games_completed_; }
+  float avg_game_length() const {
+    return static_cast<float>(game_length_) / static_cast<float>(games_completed_);
+  }
+  float avg_leaf_depth() const {
+    if (full_move_count_ == 0) return 0;
+    return static_cast<float>(total_avg_leaf_depth_ / static_cast<double>(full_move_count_));
+  }
+  float avg_search_entropy() const {
+    if (full_move_count_ == 0) return 0;
+    return static_cast<float>(total_search_entropy_ / static_cast<double>(full_move_count_));
+  }
+  float fast_avg_leaf_depth() const {
+    if (fast_move_count_ == 0) return 0;
+    return static_cast<float>(fast_total_avg_leaf_depth_ / static_cast<double>(fast_move_count_));
+  }
+  float fast_avg_search_entropy() const {
+    if (fast_move_count_ == 0) return 0;
+    return static_cast<float>(fast_total_search_entropy_ / static_cast<double>(fast_move_count_));
+  }
+  float avg_moves_per_turn() const {
+    if (game_length_ == 0) return 0;
+    return static_cast<float>(total_move_count_) / static_cast<float>(game_length_);
+  }
+  float avg_valid_moves() const {
+    if (total_move_count_ == 0) return 0;
+    return static_cast<float>(total_valid_moves_ / static_cast<double>(total_move_count_));
+  }
+  size_t hist_count() const { return history_.size(); }
+  const std::vector<HistoryRow>& history() const { return history_; }
+  const std::vector<MoveRecord>& moves() const { return moves_; }
+  uint64_t sims() const { return sims_; }
+  uint64_t nn_evals() const { return nn_evals_; }
+  uint64_t cache_hits() const { return cache_ ? cache_->hits() : 0; }
+  uint64_t cache_misses() const { return cache_ ? cache_->misses() : 0; }
+  bool record_moves = false;
+
+ private:
+  struct Pending {  // play_manager.h:28-31
+    HistoryRow ph;
+    uint8_t player;
+  };
+  struct Slot {  // GameData, play_manager.h:33-58
+    std::unique_ptr<Game> gs;
+    uint64_t leaf_hash = 0;
+    std::vector<Mcts> mcts;
+    std::vector<float> canonical, v, pi;
+    std::vector<Pending> partial_history;
+    bool initialized = false, capped = false, playthrough = false;
+    double total_avg_leaf_depth = 0, total_search_entropy = 0;
+    double fast_total_avg_leaf_depth = 0, fast_total_search_entropy = 0;
+    double total_valid_moves = 0;
+    uint32_t move_count = 0, full_move_count = 0, fast_move_count = 0;
+    uint32_t games_played = 0;
+  };
+
+  Pcg32& tree_rng(uint32_t slot) { return tree_rng_[per_slot_rng_ ? slot : 0]; }
+  Pcg32& coin_rng(uint32_t slot) { return coin_rng_[per_slot_rng_ ? slot : 0]; }
+
+  Mcts make_mcts(uint32_t slot) {  // play_manager.cc:602-617 (single perm, global settings)
+    MctsConfig c;
+    c.cpuct = params_.cpuct;
+    c.num_players = base_->num_players();
+    c.num_moves = base_->num_moves();
+    c.epsilon = params_.epsilon;
+    c.root_policy_temp = params_.mcts_root_temp;
+    c.fpu_reduction = params_.fpu_reduction;
+    c.relative_values = base_->relative_values();
+    c.root_fpu_zero = params_.root_fpu_zero;
+    c.shaped_dirichlet = params_.shaped_dirichlet;
+    return Mcts(c, &tree_rng(slot));
+  }
+
+  EvalType eval_type_for(uint8_t player) const {
+    return params_.eval_type.empty() ? EvalType::NN : params_.eval_type[player];
+  }
+
+  // One iteration of the worker loop body, play_manager.cc:277-599.
+  void step(uint32_t i) {
+    Slot& game = slots_[i];
+    const uint32_t P = base_->num_players();
+    if (game.initialized) {
+      const uint8_t cp = game.gs->current_player();
+      Mcts& mcts = game.mcts[cp];
+      mcts.process_result(game.v.data(), game.pi.data(), params_.epsilon > 0 && !game.capped);
+      ++sims_;
+      const uint32_t goal_depth = game.capped ? params_.playout_cap_depth : params_.mcts_visits[cp];
+      if (mcts.depth() >= goal_depth) {
+        float temp = params_.start_temp;
+        const float half_life = params_.temp_decay_half_life;
+        if (half_life != 0) {  // play_manager.cc:297-304, ln2 hard-coded as 0.693
+          const uint32_t t = game.gs->current_turn();
+          constexpr float ln2 = 0.693;
+          const float lambda = ln2 / half_life;
+          temp -= params_.final_temp;
+          temp *= az_expf(-lambda * t);
+          temp += params_.final_temp;
+        }
+        std::optional<std::vector<float>> resign_score;
+        if (params_.resign_percent > 0 && !game.playthrough) {  // play_manager.cc:306-334
+          if (P != 2) throw std::runtime_error("Resigning only works in 2 player games");
+          float pred[3];
+          mcts.root_value(pred);
+          const float w = pred[0], l = pred[1], d = pred[2];
+          const double resign_val = 1.0 - params_.resign_percent;
+          std::vector<float> tmp(P + 1, 0.0f);
+          if (w > resign_val) tmp[cp] = 1.0;
+          else if (l > resign_val) tmp[(cp + 1) % 2] = 1.0;
+          else if (d > resign_val) tmp[P] = 1.0;
+          float tsum = 0;
+          for (float x : tmp) tsum += x;
+          if (tsum > 0) {
+            if (uniform01(coin_rng(i)) < params_.resign_playthrough_percent) game.playthrough = true;
+            else resign_score = tmp;
+          }
+        }
+        // move choice, play_manager.cc:403-406 (PUCT branch)
+        const std::vector<float> pi_play = mcts.probs(temp);
+        const uint32_t chosen_m = Mcts::pick_move(pi_play, tree_rng(i));
+        if (record_moves) {
+          MoveRecord mr;
+          mr.slot = i; mr.game_in_slot = game.games_played; mr.move = chosen_m;
+          mr.turn = game.gs->current_turn(); mr.player = cp; mr.capped = game.capped;
+          mr.counts = mcts.counts();
+          moves_.push_back(std::move(mr));
+        }
+        if (params_.history_enabled && !game.capped) {  // play_manager.cc:407-424
+          Pending pd;
+          pd.ph.canonical.assign(base_->canonical_size(), 0.0f);
+          game.gs->canonicalized(pd.ph.canonical.data());
+          pd.ph.v.assign(game.v.size(), 0.0f);
+          pd.ph.pi = (params_.policy_target_pruning && params_.epsilon > 0) ? mcts.probs_pruned(1.0)
+                                                                            : mcts.probs(1.0);
+          pd.player = game.gs->current_player();
+          game.partial_history.push_back(std::move(pd));
+        }
+        if (!game.capped) {  // play_manager.cc:425-435
+          game.total_avg_leaf_depth += mcts.avg_leaf_depth();
+          game.total_search_entropy += mcts.normalized_root_entropy();
+          ++game.full_move_count;
+        } else {
+          game.fast_total_avg_leaf_depth += mcts.avg_leaf_depth();
+          game.fast_total_search_entropy += mcts.normalized_root_entropy();
+          ++game.fast_move_count;
+        }
+        game.total_valid_moves += mcts.num_root_children();
+        ++game.move_count;
+        for (auto& m : game.mcts) m.update_root(*game.gs, chosen_m);  // player order
+        game.gs->play_move(chosen_m);
+        float sc[kMaxValue];
+        bool over = game.gs->scores(sc);
+        std::vector<float> scores;
+        if (over) scores.assign(sc, sc + P + 1);
+        if (!over && resign_score.has_value()) {
+          scores = *resign_score;
+          over = true;
+        } else {
+          resign_score.reset();
+        }
+        if (over) {
+          if (params_.history_enabled) {  // play_manager.cc:448-461
+            while (!game.partial_history.empty()) {
+              Pending& pending = game.partial_history.back();
+              if (base_->relative_values()) {
+                std::vector<float> rel(P + 1);
+                for (uint32_t k = 0; k < P; ++k) rel[k] = scores[(pending.player + k) % P];
+                rel[P] = scores[P];
+                pending.ph.v = rel;
+              } else {
+                pending.ph.v = scores;
+              }
+              history_.push_back(std::move(pending.ph));
+              game.partial_history.pop_back();
+            }
+          }
+          // play_manager.cc:463-514
+          for (uint32_t k = 0; k <= P; ++k) scores_[k] += scores[k];
+          if (resign_score.has_value())
+            for (uint32_t k = 0; k <= P; ++k) resign_scores_[k] += (*resign_score)[k];
+          ++games_completed_;
+          game_length_ += game.gs->current_turn();
+          total_avg_leaf_depth_ += game.total_avg_leaf_depth;
+          total_search_entropy_ += game.total_search_entropy;
+          fast_total_avg_leaf_depth_ += game.fast_total_avg_leaf_depth;
+          fast_total_search_entropy_ += game.fast_total_search_entropy;
+          total_valid_moves_ += game.total_valid_moves;
+          total_move_count_ += game.move_count;
+          full_move_count_ += game.full_move_count;
+          fast_move_count_ += game.fast_move_count;
+          game.total_avg_leaf_depth = game.total_search_entropy = 0;
+          game.fast_total_avg_leaf_depth = game.fast_total_search_entropy = 0;
+          game.total_valid_moves = 0;
+          game.move_count = game.full_move_count = game.fast_move_count = 0;
+          ++game.games_played;
+          if (games_started_ >= params_.games_to_play) return;  // slot retires
+          ++games_started_;
+          game.gs = base_->copy();
+          game.gs->randomize_start();
+          for (uint32_t j = 0; j < P; ++j) game.mcts[j] = make_mcts(i);
+        }
+        // play_manager.cc:522-555
+        game.capped = params_.playout_cap_randomization &&
+                      (uniform01(coin_rng(i)) < params_.playout_cap_percent);
+        if (!params_.tree_reuse) {
+          for (uint32_t j = 0; j < P; ++j) game.mcts[j] = make_mcts(i);
+        } else {
+          const uint8_t next_cp = game.gs->current_player();
+          Mcts& next = game.mcts[next_cp];
+          if (next.root_n() > 0) {
+            next.apply_root_policy_temp();
+            if (params_.epsilon > 0 && !game.capped) next.add_root_noise();
+          }
+        }
+      }
+    } else {  // play_manager.cc:557-571
+      game.initialized = true;
+      game.capped = params_.playout_cap_randomization &&
+                    (uniform01(coin_rng(i)) < params_.playout_cap_percent);
+    }
+    // play_manager.cc:572-598
+    const uint8_t cp = game.gs->current_player();
+    Mcts& mcts = game.mcts[cp];
+    auto leaf = mcts.find_leaf(*game.gs);
+    const EvalType et = eval_type_for(cp);
+    if (et != EvalType::NN) {
+      if (et == EvalType::PLAYOUT) throw std::runtime_error("PLAYOUT eval is not restated");
+      dumb_eval(*leaf, game.v.data(), game.pi.data());
+      awaiting_mcts_.push_back(i);
+      return;
+    }
+    leaf->canonicalized(game.canonical.data());
+    game.leaf_hash = leaf->key();
+    if (cache_ && cache_->find(game.leaf_hash, game.pi.data(), game.v.data())) {
+      awaiting_mcts_.push_back(i);
+      return;
+    }
+    awaiting_inference_.push_back(i);
+  }
+
+  void flush_inference(const Evaluator& nn) {
+    const uint32_t P = base_->num_players();
+    const uint32_t M = base_->num_moves();
+    const size_t csz = base_->canonical_size();
+    while (!awaiting_inference_.empty()) {
+      const uint32_t n = static_cast<uint32_t>(
+          std::min<size_t>(awaiting_inference_.size(), std::max<uint32_t>(1, params_.max_batch_size)));
+      std::vector<uint32_t> idx(awaiting_inference_.begin(), awaiting_inference_.begin() + n);
+      awaiting_inference_.erase(awaiting_inference_.begin(), awaiting_inference_.begin() + n);
+      std::vector<float> batch(n * csz), v(n * (P + 1)), pi(static_cast<size_t>(n) * M);
+      for (uint32_t r = 0; r < n; ++r)
+        std::copy(slots_[idx[r]].canonical.begin(), slots_[idx[r]].canonical.end(), batch.begin() + r * csz);
+      nn(batch.data(), n, v.data(), pi.data());
+      nn_evals_ += n;
+      for (uint32_t r = 0; r < n; ++r) {  // update_inferences, play_manager.cc:619-642
+        Slot& g = slots_[idx[r]];
+        std::copy(v.begin() + r * (P + 1), v.begin() + (r + 1) * (P + 1), g.v.begin());
+        std::copy(pi.begin() + static_cast<size_t>(r) * M, pi.begin() + static_cast<size_t>(r + 1) * M, g.pi.begin());
+        if (cache_) cache_->insert(g.leaf_hash, g.pi.data(), g.v.data());
+      }
+      for (uint32_t r = 0; r < n; ++r) awaiting_mcts_.push_back(idx[r]);
+    }
+  }
+
+  std::unique_ptr<Game> base_;
+  PlayParams params_;
+  bool per_slot_rng_;
+  std::vector<Pcg32> tree_rng_, coin_rng_;
+  std::vector<Slot> slots_;
+  std::deque<uint32_t> awaiting_mcts_, awaiting_inference_;
+  std::unique_ptr<ShardedS3Fifo> cache_;
+  std::vector<HistoryRow> history_;
+  std::vector<MoveRecord> moves_;
+  std::vector<float> scores_, resign_scores_;
+  uint32_t games_started_ = 0, games_completed_ = 0;
+  uint64_t game_length_ = 0;
+  double total_avg_leaf_depth_ = 0, total_search_entropy_ = 0;
+  double fast_total_avg_leaf_depth_ = 0, fast_total_search_entropy_ = 0;
+  double total_valid_moves_ = 0;
+  uint64_t total_move_count_ = 0, full_move_count_ = 0, fast_move_count_ = 0;
+  uint64_t sims_ = 0, nn_evals_ = 0;
+};
+
+}  // namespace orc
