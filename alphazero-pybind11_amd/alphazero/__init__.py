@@ -1,0 +1,396 @@
+"""`alphazero` — host-side mirror of the reference's pybind11 module
+(/root/reference/src/py_wrapper.cc:108-788) for the self-play hot path, backed by
+the MI355X engine in libazmi.so (include/azmi.h).
+
+Same names, argument meaning and error behaviour as the reference for
+PlayParams / EvalType / PlayManager and the game classes' static facts, so
+`game_runner.py`-style callers work unchanged; plus the device fast path the
+reference lacks (`PlayManager.round`, `io_tensors`).
+
+Put the directory that contains this package on sys.path:
+    sys.path.insert(0, "<repo>/alphazero-pybind11_amd"); import alphazero
+"""
+import ctypes as C
+import enum
+
+import numpy as np
+
+from . import _capi
+from ._capi import lib, check
+
+__all__ = [
+    "EvalType", "PlayParams", "PlayManager", "GameState", "Connect4GS",
+    "tracy_is_enabled", "tracy_frame_mark",
+]
+
+
+class EvalType(enum.IntEnum):  # py_wrapper.cc:290-293
+    NN = 0
+    RANDOM = 1
+    PLAYOUT = 2
+
+
+class PlayParams:
+    """py_wrapper.cc:295-349 / play_manager.h:60-154 — same field names and defaults."""
+
+    def __init__(self):
+        self.games_to_play = 0
+        self.concurrent_games = 0
+        self.max_batch_size = 1
+        self.max_cache_size = 0
+        self.cache_shards = 1
+        self.queue_shards = 1
+        self.eval_pipelines = 1
+        self.mcts_visits = []
+        self.cpuct = 2.0
+        self.start_temp = 1.0
+        self.final_temp = 1.0
+        self.temp_decay_half_life = 0.0
+        self.temp_decay_half_life_by_variant = []
+        self.history_enabled = False
+        self.self_play = False
+        self.tree_reuse = True
+        self.epsilon = 0.0
+        self.mcts_root_temp = 1.0
+        self.playout_cap_randomization = False
+        self.playout_cap_depth = 25
+        self.playout_cap_percent = 0.75
+        self.fpu_reduction = 0.0
+        self.root_fpu_zero = False
+        self.shaped_dirichlet = False
+        self.policy_target_pruning = False
+        self.gumbel_enabled = False
+        self.gumbel_m = 16
+        self.gumbel_c_visit = 50.0
+        self.gumbel_c_scale = 1.0
+        self.gumbel_full = False
+        self.fast_search_uses_gumbel = False
+        self.resign_percent = 0.0
+        self.resign_playthrough_percent = 0.0
+        self.eval_type = []
+        self.model_groups = []
+        self.seat_perms = []
+        self.seat_visits = []
+        self.seat_cap_visits = []
+        self.seat_epsilon = []
+        self.seat_mcts_root_temp = []
+        self.seat_root_fpu_zero = []
+        self.seat_gumbel_enabled = []
+        self.seat_gumbel_m = []
+        self.seat_gumbel_c_visit = []
+        self.seat_gumbel_c_scale = []
+        self.seat_gumbel_full = []
+        self.seat_gumbel_use_improved_policy = []
+        self.seat_resign_threshold = []
+        self.seat_resign_consecutive = []
+
+    # fields the device engine does not implement yet: anything but the default is an error
+    _UNSUPPORTED = (
+        "temp_decay_half_life_by_variant", "gumbel_enabled", "seat_perms", "seat_visits", "seat_cap_visits",
+        "seat_epsilon", "seat_mcts_root_temp", "seat_root_fpu_zero", "seat_gumbel_enabled", "seat_gumbel_m",
+        "seat_gumbel_c_visit", "seat_gumbel_c_scale", "seat_gumbel_full", "seat_gumbel_use_improved_policy",
+        "seat_resign_threshold", "seat_resign_consecutive",
+    )
+
+    def _to_c(self, num_players):
+        c = _capi.PlayParamsC()
+        lib.azmi_play_params_default(C.byref(c))
+        for name in self._UNSUPPORTED:
+            if getattr(self, name):
+                raise RuntimeError(f"PlayParams.{name} is not supported by the MI355X engine yet")
+        groups = list(self.model_groups)
+        if groups and len(set(groups)) > 1:
+            raise RuntimeError("more than one model group is not supported by the MI355X engine yet")
+        c.games_to_play = int(self.games_to_play)
+        c.concurrent_games = int(self.concurrent_games)
+        c.max_batch_size = int(self.max_batch_size)
+        c.max_cache_size = int(self.max_cache_size)
+        c.cache_shards = int(self.cache_shards)
+        visits = list(self.mcts_visits)
+        if len(visits) > _capi.AZMI_MAX_PLAYERS:
+            raise RuntimeError("You must specify MCTS visits for each player")
+        c.num_mcts_visits = len(visits)
+        for i, v in enumerate(visits):
+            c.mcts_visits[i] = int(v)
+        c.cpuct = self.cpuct
+        c.start_temp = self.start_temp
+        c.final_temp = self.final_temp
+        c.temp_decay_half_life = self.temp_decay_half_life
+        c.history_enabled = int(bool(self.history_enabled))
+        c.self_play = int(bool(self.self_play))
+        c.tree_reuse = int(bool(self.tree_reuse))
+        c.epsilon = self.epsilon
+        c.mcts_root_temp = self.mcts_root_temp
+        c.playout_cap_randomization = int(bool(self.playout_cap_randomization))
+        c.playout_cap_depth = int(self.playout_cap_depth)
+        c.playout_cap_percent = self.playout_cap_percent
+        c.fpu_reduction = self.fpu_reduction
+        c.root_fpu_zero = int(bool(self.root_fpu_zero))
+        c.shaped_dirichlet = int(bool(self.shaped_dirichlet))
+        c.policy_target_pruning = int(bool(self.policy_target_pruning))
+        c.resign_percent = self.resign_percent
+        c.resign_playthrough_percent = self.resign_playthrough_percent
+        ets = list(self.eval_type)
+        c.num_eval_type = len(ets)
+        for i, e in enumerate(ets[: _capi.AZMI_MAX_PLAYERS]):
+            c.eval_type[i] = int(e)
+        return c
+
+
+class GameState:
+    """Static facts of a game class (py_wrapper.cc:157-189, 562-580)."""
+
+    GAME_ID = -1
+
+    @classmethod
+    def _info(cls):
+        p, m = C.c_uint32(), C.c_uint32()
+        chw = (C.c_uint32 * 3)()
+        check(lib.azmi_game_info(cls.GAME_ID, C.byref(p), C.byref(m), chw))
+        return p.value, m.value, tuple(chw)
+
+    @classmethod
+    def NUM_PLAYERS(cls):
+        return cls._info()[0]
+
+    @classmethod
+    def NUM_MOVES(cls):
+        return cls._info()[1]
+
+    @classmethod
+    def CANONICAL_SHAPE(cls):
+        return cls._info()[2]
+
+    def num_players(self):
+        return self.NUM_PLAYERS()
+
+    def num_moves(self):
+        return self.NUM_MOVES()
+
+
+class Connect4GS(GameState):  # py_wrapper.cc:562-580
+    GAME_ID = 0
+
+    @staticmethod
+    def NUM_SYMMETRIES():
+        return 2
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class PlayManager:
+    """py_wrapper.cc:351-504 over libazmi.
+
+    Reference methods: play, build_batch, update_inferences, build_history_batch, scores,
+    resign_scores, games_completed, remaining_games, params, avg_* getters, hist_count.
+    Device fast path (no reference counterpart): round(), io_tensors(), poll().
+    """
+
+    def __init__(self, gs, params, seed=None, device=0, max_inline=0, log_moves=False, history_capacity=0):
+        if gs is None:
+            raise TypeError("PlayManager(): gs must not be None")  # py::arg().none(false)
+        game_id = gs.GAME_ID
+        nplayers = type(gs).NUM_PLAYERS() if not isinstance(gs, type) else gs.NUM_PLAYERS()
+        self._game = gs if isinstance(gs, type) else type(gs)
+        self._params = params
+        cparams = params._to_c(nplayers)
+        opts = _capi.EngineOptsC()
+        lib.azmi_engine_opts_default(C.byref(opts))
+        if seed is not None:
+            opts.seed = int(seed)
+        opts.device = int(device)
+        opts.max_inline = int(max_inline)
+        opts.log_moves = int(bool(log_moves))
+        opts.history_capacity = int(history_capacity)
+        h = C.c_void_p()
+        check(lib.azmi_pm_create(game_id, C.byref(cparams), C.byref(opts), C.byref(h)))
+        self._h = h
+        self._P, self._M, self._chw = self._game._info()
+        self._S = int(params.concurrent_games)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.azmi_pm_destroy(h)
+            self._h = None
+
+    # ---- reference surface --------------------------------------------------------------
+    def params(self):
+        return self._params
+
+    def play(self):
+        """PlayManager::play (play_manager.cc:258-600) for RANDOM-eval seats: runs to completion."""
+        check(lib.azmi_pm_play(self._h, None))
+
+    def games_completed(self):
+        done, live = C.c_uint32(), C.c_uint32()
+        check(lib.azmi_pm_poll(self._h, None, C.byref(done), C.byref(live)))
+        return done.value
+
+    def remaining_games(self):
+        done, live = C.c_uint32(), C.c_uint32()
+        check(lib.azmi_pm_poll(self._h, None, C.byref(done), C.byref(live)))
+        if live.value == 0:
+            return 0
+        return max(0, int(self._params.games_to_play) - done.value)
+
+    def scores(self):
+        out = np.zeros(self._P + 1, np.float32)
+        check(lib.azmi_pm_scores(self._h, out.ctypes.data))
+        return out
+
+    def resign_scores(self):
+        out = np.zeros(self._P + 1, np.float32)
+        check(lib.azmi_pm_resign_scores(self._h, out.ctypes.data))
+        return out
+
+    def _stats(self):
+        out = np.zeros(7, np.float32)
+        check(lib.azmi_pm_stats(self._h, out.ctypes.data))
+        return out
+
+    def avg_game_length(self): return float(self._stats()[0])
+    def avg_leaf_depth(self): return float(self._stats()[1])
+    def avg_search_entropy(self): return float(self._stats()[2])
+    def fast_avg_leaf_depth(self): return float(self._stats()[3])
+    def fast_avg_search_entropy(self): return float(self._stats()[4])
+    def avg_moves_per_turn(self): return float(self._stats()[5])
+    def avg_valid_moves(self): return float(self._stats()[6])
+
+    def counters(self):
+        out = np.zeros(6, np.uint64)
+        check(lib.azmi_pm_counters(self._h, out.ctypes.data))
+        return dict(zip(("sims", "evals", "cache_hits", "cache_misses", "hist_rows", "rounds"), (int(x) for x in out)))
+
+    def hist_count(self):
+        return self.counters()["hist_rows"]
+
+    def cache_hits(self): return self.counters()["cache_hits"]
+    def cache_misses(self): return self.counters()["cache_misses"]
+    def num_model_groups(self): return 1
+    def num_seat_perms(self): return 1
+
+    def build_batch(self, group, batch, shard=0):
+        """py_wrapper.cc:449-504: fills the caller's [max_batch, C, H, W] float32 array, returns slot ids."""
+        arr = np.asarray(batch) if not hasattr(batch, "numpy") else batch.numpy()
+        if arr.ndim != 4 or tuple(arr.shape[1:]) != tuple(self._chw) or arr.dtype != np.float32 or not arr.flags.c_contiguous:
+            raise RuntimeError("Improper batch size")
+        idx = np.zeros(arr.shape[0], np.uint32)
+        n = C.c_uint32()
+        cap = min(arr.shape[0], int(self._params.max_batch_size)) if self._params.max_batch_size else arr.shape[0]
+        check(lib.azmi_pm_build_batch(self._h, arr.ctypes.data, cap, idx.ctypes.data, C.byref(n)))
+        return [int(i) for i in idx[: n.value]]
+
+    def update_inferences(self, group, indices, v, pi):
+        idx = np.ascontiguousarray(indices, dtype=np.uint32)
+        v = _f32(v); pi = _f32(pi)
+        if v.shape != (len(idx), self._P + 1) or pi.shape != (len(idx), self._M):
+            raise RuntimeError("Eigen is angry!!!")  # shapes.h:4-6 bounds assertion
+        check(lib.azmi_pm_update_inferences(self._h, idx.ctypes.data, len(idx), v.ctypes.data, pi.ctypes.data))
+
+    def build_history_batch(self, canonical, v, pi):
+        """py_wrapper.cc:393-424: fills the caller arrays with finished samples, returns rows written."""
+        c = np.asarray(canonical); vv = np.asarray(v); p = np.asarray(pi)
+        for a in (c, vv, p):
+            if a.dtype != np.float32 or not a.flags.c_contiguous:
+                raise RuntimeError("history buffers must be C-contiguous float32")
+        n = C.c_uint32()
+        check(lib.azmi_pm_pop_history(self._h, c.ctypes.data, vv.ctypes.data, p.ctypes.data, c.shape[0], C.byref(n)))
+        return n.value
+
+    # ---- device fast path ------------------------------------------------------------------
+    def round(self, stream=None):
+        """One engine round on `stream` (a hipStream_t as int, e.g. torch.cuda.current_stream().cuda_stream)."""
+        check(lib.azmi_pm_round(self._h, C.c_void_p(stream) if stream else None))
+
+    def poll(self, stream=None):
+        done, live = C.c_uint32(), C.c_uint32()
+        check(lib.azmi_pm_poll(self._h, C.c_void_p(stream) if stream else None, C.byref(done), C.byref(live)))
+        return done.value, live.value
+
+    def io_pointers(self):
+        c, v, p = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(lib.azmi_pm_io_buffers(self._h, C.byref(c), C.byref(v), C.byref(p)))
+        return c.value, v.value, p.value
+
+    def io_tensors(self):
+        """torch views (no copy) of the slot-indexed canonical / v / pi buffers in HBM."""
+        import torch
+        from ._torch_view import device_tensor
+        c, v, p = self.io_pointers()
+        S = self._S
+        dev = torch.device("cuda", torch.cuda.current_device())
+        return (device_tensor(c, (S,) + tuple(self._chw), torch.float32, dev),
+                device_tensor(v, (S, self._P + 1), torch.float32, dev),
+                device_tensor(p, (S, self._M), torch.float32, dev))
+
+    def move_log(self):
+        cap = (int(self._params.games_to_play) + self._S) * 512
+        rows = np.zeros((cap, 8), np.uint32)
+        counts = np.zeros((cap, self._M), np.uint32)
+        n = C.c_uint32()
+        check(lib.azmi_pm_move_log(self._h, rows.ctypes.data, counts.ctypes.data, cap, C.byref(n)))
+        return rows[: n.value].copy(), counts[: n.value].copy()
+
+    def slot_games(self):
+        out = np.zeros(self._S, np.uint32)
+        check(lib.azmi_pm_slot_games(self._h, out.ctypes.data))
+        return out
+
+    def history(self):
+        """All finished samples not yet popped, as numpy arrays (canonical, v, pi)."""
+        n = self.hist_count()
+        c = np.zeros((n,) + tuple(self._chw), np.float32)
+        v = np.zeros((n, self._P + 1), np.float32)
+        p = np.zeros((n, self._M), np.float32)
+        got = self.build_history_batch(c, v, p) if n else 0
+        return c[:got], v[:got], p[:got]
+
+
+def game_replay(game_cls, moves, device=0):
+    """Batched rules replay on the device (azmi_game_replay): moves [n, len] int32, -1 padded."""
+    moves = np.ascontiguousarray(moves, dtype=np.int32)
+    n, ln = moves.shape
+    P, M, chw = game_cls._info()
+    out = dict(
+        valid=np.zeros((n, M), np.uint8), scores=np.zeros((n, P + 1), np.float32),
+        canonical=np.zeros((n,) + tuple(chw), np.float32), player=np.zeros(n, np.uint32),
+        turn=np.zeros(n, np.uint32), key=np.zeros(n, np.uint64), status=np.zeros(n, np.int32),
+    )
+    check(lib.azmi_game_replay(game_cls.GAME_ID, device, moves.ctypes.data, n, ln, out["valid"].ctypes.data,
+                               out["scores"].ctypes.data, out["canonical"].ctypes.data, out["player"].ctypes.data,
+                               out["turn"].ctypes.data, out["key"].ctypes.data, out["status"].ctypes.data))
+    return out
+
+
+def rng_probe(kind, seed, n, param=0.0, reps=1, device=0):
+    """azmi_rng_probe: kind in {"pcg32","shuffle","uniform","gamma","gamma_fresh"}."""
+    kinds = {"pcg32": 0, "shuffle": 1, "uniform": 2, "gamma": 3, "gamma_fresh": 4}
+    k = kinds[kind]
+    dtype = np.uint32 if k < 2 else np.float32
+    out = np.zeros(n * (reps if k == 1 else 1), dtype)
+    check(lib.azmi_rng_probe(device, k, seed, param, n, reps, out.ctypes.data))
+    return out.reshape(reps, n) if k == 1 else out
+
+
+# Tracy stubs — py_wrapper.cc:772-787: must exist even as no-ops
+def tracy_is_enabled():
+    return False
+
+
+def tracy_frame_mark():
+    return None
+
+
+def _tracy_zone_begin(name, file, line):
+    return None
+
+
+def _tracy_zone_end():
+    return None
+
+
+def _tracy_set_thread_name(name):
+    return None

@@ -1,0 +1,109 @@
+"""ctypes binding of libazmi.so (include/azmi.h).
+
+The library is the product: if it is missing this module raises ImportError —
+there is no Python/CPU fallback for any compute entry point.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libazmi.so")
+
+AZMI_MAX_PLAYERS = 4
+
+
+class PlayParamsC(C.Structure):
+    _fields_ = [
+        ("games_to_play", C.c_uint32),
+        ("concurrent_games", C.c_uint32),
+        ("max_batch_size", C.c_uint32),
+        ("max_cache_size", C.c_uint32),
+        ("cache_shards", C.c_uint32),
+        ("num_mcts_visits", C.c_uint32),
+        ("mcts_visits", C.c_uint32 * AZMI_MAX_PLAYERS),
+        ("cpuct", C.c_float),
+        ("start_temp", C.c_float),
+        ("final_temp", C.c_float),
+        ("temp_decay_half_life", C.c_float),
+        ("history_enabled", C.c_int32),
+        ("self_play", C.c_int32),
+        ("tree_reuse", C.c_int32),
+        ("epsilon", C.c_float),
+        ("mcts_root_temp", C.c_float),
+        ("playout_cap_randomization", C.c_int32),
+        ("playout_cap_depth", C.c_uint32),
+        ("playout_cap_percent", C.c_float),
+        ("fpu_reduction", C.c_float),
+        ("root_fpu_zero", C.c_int32),
+        ("shaped_dirichlet", C.c_int32),
+        ("policy_target_pruning", C.c_int32),
+        ("resign_percent", C.c_float),
+        ("resign_playthrough_percent", C.c_float),
+        ("num_eval_type", C.c_uint32),
+        ("eval_type", C.c_int32 * AZMI_MAX_PLAYERS),
+    ]
+
+
+class EngineOptsC(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint64),
+        ("device", C.c_int32),
+        ("max_inline", C.c_uint32),
+        ("history_capacity", C.c_uint32),
+        ("log_moves", C.c_int32),
+        ("move_log_capacity", C.c_uint32),
+    ]
+
+
+# every symbol include/azmi.h declares: name -> (restype, argtypes)
+_VP = C.c_void_p
+_PP = C.POINTER
+SYMBOLS = {
+    "azmi_play_params_default": (None, [_PP(PlayParamsC)]),
+    "azmi_engine_opts_default": (None, [_PP(EngineOptsC)]),
+    "azmi_last_error": (C.c_char_p, []),
+    "azmi_abi_version": (C.c_int, []),
+    "azmi_device_count": (C.c_int, []),
+    "azmi_game_info": (C.c_int, [C.c_int, _PP(C.c_uint32), _PP(C.c_uint32), _PP(C.c_uint32)]),
+    "azmi_pm_create": (C.c_int, [C.c_int, _PP(PlayParamsC), _PP(EngineOptsC), _PP(_VP)]),
+    "azmi_pm_destroy": (None, [_VP]),
+    "azmi_pm_round": (C.c_int, [_VP, _VP]),
+    "azmi_pm_io_buffers": (C.c_int, [_VP, _PP(_VP), _PP(_VP), _PP(_VP)]),
+    "azmi_pm_play": (C.c_int, [_VP, _VP]),
+    "azmi_pm_poll": (C.c_int, [_VP, _VP, _PP(C.c_uint32), _PP(C.c_uint32)]),
+    "azmi_pm_scores": (C.c_int, [_VP, _VP]),
+    "azmi_pm_resign_scores": (C.c_int, [_VP, _VP]),
+    "azmi_pm_stats": (C.c_int, [_VP, _VP]),
+    "azmi_pm_counters": (C.c_int, [_VP, _VP]),
+    "azmi_pm_pop_history": (C.c_int, [_VP, _VP, _VP, _VP, C.c_uint32, _PP(C.c_uint32)]),
+    "azmi_pm_history_device": (C.c_int, [_VP, _PP(_VP), _PP(_VP), _PP(_VP), _PP(_VP), _PP(C.c_uint32)]),
+    "azmi_pm_move_log": (C.c_int, [_VP, _VP, _VP, C.c_uint32, _PP(C.c_uint32)]),
+    "azmi_pm_slot_games": (C.c_int, [_VP, _VP]),
+    "azmi_pm_build_batch": (C.c_int, [_VP, _VP, C.c_uint32, _VP, _PP(C.c_uint32)]),
+    "azmi_pm_update_inferences": (C.c_int, [_VP, _VP, C.c_uint32, _VP, _VP]),
+    "azmi_rng_probe": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_float, C.c_uint32, C.c_uint32, _VP]),
+    "azmi_game_replay": (C.c_int, [C.c_int, C.c_int, _VP, C.c_uint32, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+}
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = load()
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib.azmi_last_error().decode("utf-8", "replace")
+        raise RuntimeError(msg or f"azmi error {rc}")

@@ -1,0 +1,629 @@
+// Host side of libazmi.so: owns the HBM arrays of one PlayManager, launches the
+// round kernels, and implements the C ABI declared in include/azmi.h.
+// There is deliberately no CPU code path: every entry point that computes
+// requires a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <vector>
+
+#include "../../include/azmi.h"
+#include "engine_kernels.h"
+
+using namespace azmi;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIP_TRY(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(e_ == hipErrorOutOfMemory ? AZMI_ERR_OOM : AZMI_ERR_NO_DEVICE, "%s: %s", #expr, \
+                  hipGetErrorString(e_));                                                 \
+  } while (0)
+
+struct GameInfo {
+  uint32_t P, M, C, H, W, maxk, max_turns, state_words;
+};
+bool game_info(int game, GameInfo* gi) {
+  switch (game) {
+    case AZMI_GAME_CONNECT4:
+      *gi = GameInfo{Connect4::P, Connect4::M, Connect4::C, Connect4::H, Connect4::W, Connect4::MAXK,
+                     Connect4::MAX_TURNS, 3};
+      return true;
+    default:
+      return false;
+  }
+}
+
+}  // namespace
+
+struct azmi_pm {
+  int game = 0;
+  int device = 0;
+  GameInfo gi{};
+  azmi_play_params params{};
+  EngineParams ep{};
+  EngineArrays ar{};
+  std::vector<void*> allocs;
+  size_t bytes = 0;
+  hipStream_t stream = nullptr;  // engine-owned stream for result queries
+  uint32_t hist_read = 0;
+  // host-buffer compatibility path
+  std::deque<uint32_t> pending;        // slots whose leaf waits for the net
+  std::vector<float> host_v, host_pi;  // mirrors of the slot-indexed rows
+  uint32_t outstanding = 0;
+
+  template <class T>
+  int alloc(T*& p, size_t n, bool zero) {
+    void* q = nullptr;
+    const size_t sz = std::max<size_t>(n, 1) * sizeof(T);
+    HIP_TRY(hipMalloc(&q, sz));
+    allocs.push_back(q);
+    bytes += sz;
+    if (zero) HIP_TRY(hipMemset(q, 0, sz));
+    p = static_cast<T*>(q);
+    return AZMI_OK;
+  }
+  ~azmi_pm() {
+    for (void* q : allocs) (void)hipFree(q);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace {
+
+__global__ void k_seed(EngineArrays ar, uint32_t S, uint64_t seed) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  Pcg32 g;
+  const uint64_t sd = slot_seed(seed, s);
+  g.seed(sd);
+  ar.rng[s] = g.state;
+  g.seed(sd ^ kCoinSalt);
+  ar.coin[s] = g.state;
+}
+
+int launch_round(azmi_pm* pm, hipStream_t st) {
+  k_assign<<<1, 256, 0, st>>>(pm->ep, pm->ar, 1u);
+  const uint32_t threads = 256;
+  switch (pm->game) {
+    case AZMI_GAME_CONNECT4: {
+      const uint32_t slots_per_block = threads / Connect4::GROUP;
+      const uint32_t blocks = (pm->ep.S + slots_per_block - 1) / slots_per_block;
+      k_round<Connect4><<<blocks, threads, 0, st>>>(pm->ep, pm->ar);
+      break;
+    }
+    default:
+      return fail(AZMI_ERR_INVALID, "game %d has no device kernels", pm->game);
+  }
+  HIP_TRY(hipGetLastError());
+  return AZMI_OK;
+}
+
+int read_ctl(azmi_pm* pm, hipStream_t st, Control* out, bool settle) {
+  if (settle) k_assign<<<1, 256, 0, st>>>(pm->ep, pm->ar, 0u);
+  HIP_TRY(hipMemcpyAsync(out, pm->ar.ctl, sizeof(Control), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (out->overflow)
+    return fail(AZMI_ERR_OVERFLOW, "device engine stopped: overflow mask 0x%x (1 tree arena, 2 history, 4 move log, "
+                "8 path/children, 16 pick_move, 32 unknown move, 64 illegal move)", out->overflow);
+  return AZMI_OK;
+}
+
+template <class T>
+int d2h(std::vector<T>& dst, const T* src, size_t n, hipStream_t st) {
+  dst.resize(n);
+  HIP_TRY(hipMemcpyAsync(dst.data(), src, n * sizeof(T), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return AZMI_OK;
+}
+
+// ---- batched rules replay (parity tier T0) --------------------------------------------------------
+template <class GM>
+__global__ void k_replay(const int32_t* moves, uint32_t n, uint32_t len, uint8_t* valid, float* scores,
+                         float* canonical, uint32_t* player, uint32_t* turn, uint64_t* key, int32_t* status) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  typename GM::State s = GM::initial();
+  int32_t stt = 0;
+  for (uint32_t i = 0; i < len; ++i) {
+    const int32_t mv = moves[static_cast<size_t>(g) * len + i];
+    if (mv < 0) break;
+    if (mv >= GM::M || !((GM::valid_mask(s) >> mv) & 1u) || !GM::play(s, static_cast<uint32_t>(mv))) { stt = -1; break; }
+  }
+  if (status) status[g] = stt;
+  if (valid) for (int m = 0; m < GM::M; ++m) valid[static_cast<size_t>(g) * GM::M + m] = (GM::valid_mask(s) >> m) & 1u;
+  if (scores) {
+    const uint32_t t = GM::terminal(s);
+    for (int i = 0; i <= GM::P; ++i)
+      scores[static_cast<size_t>(g) * (GM::P + 1) + i] = t == 0 ? -1.0f : (static_cast<int>(t) - 1 == i ? 1.0f : 0.0f);
+  }
+  if (canonical) for (int e = 0; e < GM::CANON; ++e) canonical[static_cast<size_t>(g) * GM::CANON + e] = GM::canonical_at(s, e);
+  if (player) player[g] = s.player;
+  if (turn) turn[g] = s.turn;
+  if (key) key[g] = GM::key(s);
+}
+
+// ---- RNG probe: the device RNG layer on its own (parity tier "RNG") -------------------------------
+__global__ void k_rng_probe(int kind, uint64_t seed, float param, uint32_t n, uint32_t reps, uint32_t* out_u, float* out_f) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  Pcg32 g;
+  g.seed(seed);
+  if (kind == 0) {
+    for (uint32_t i = 0; i < n; ++i) out_u[i] = g.next();
+  } else if (kind == 1) {  // std::shuffle of iota(n), `reps` times from one stream (one lane, plain arrays)
+    for (uint32_t r = 0; r < reps; ++r) {
+      uint32_t* a = out_u + static_cast<size_t>(r) * n;
+      for (uint32_t i = 0; i < n; ++i) a[i] = i;
+      if (n > 1) {
+        uint32_t i = 1;
+        if ((n & 1u) == 0) { const uint32_t j = lemire_below(g, 2); const uint32_t t = a[i]; a[i] = a[j]; a[j] = t; ++i; }
+        while (i != n) {
+          const uint32_t sr = i + 1, b1 = sr + 1;
+          const uint32_t x = lemire_below(g, sr * b1);
+          const uint32_t p0 = x / b1, p1 = x % b1;
+          uint32_t t = a[i]; a[i] = a[p0]; a[p0] = t; ++i;
+          t = a[i]; a[i] = a[p1]; a[p1] = t; ++i;
+        }
+      }
+    }
+  } else if (kind == 2) {
+    for (uint32_t i = 0; i < n; ++i) out_f[i] = canonical01(g) * 1.0f + 0.0f;
+  } else if (kind == 3) {  // one gamma object across draws (mcts.cc:435-440)
+    Gamma d(param);
+    for (uint32_t i = 0; i < n; ++i) out_f[i] = d.draw(g);
+  } else if (kind == 4) {  // fresh gamma object per draw (mcts.cc:430)
+    for (uint32_t i = 0; i < n; ++i) { Gamma d(param); out_f[i] = d.draw(g); }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int azmi_rng_probe(int device, int kind, uint64_t seed, float param, uint32_t n, uint32_t reps, void* out) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(AZMI_ERR_NO_DEVICE, "no HIP device: libazmi has no CPU path");
+  if (kind < 0 || kind > 4 || !out) return fail(AZMI_ERR_INVALID, "bad rng probe arguments");
+  HIP_TRY(hipSetDevice(device));
+  const size_t count = static_cast<size_t>(n) * (kind == 1 ? std::max(reps, 1u) : 1u);
+  void* d = nullptr;
+  HIP_TRY(hipMalloc(&d, std::max<size_t>(count, 1) * 4));
+  k_rng_probe<<<1, 64>>>(kind, seed, param, n, std::max(reps, 1u), static_cast<uint32_t*>(d), static_cast<float*>(d));
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(out, d, count * 4, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(AZMI_ERR_NO_DEVICE, "rng probe: %s", hipGetErrorString(e));
+  return AZMI_OK;
+}
+
+const char* azmi_last_error(void) { return g_err.c_str(); }
+int azmi_abi_version(void) { return AZMI_ABI_VERSION; }
+int azmi_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void azmi_play_params_default(azmi_play_params* p) {  // play_manager.h:60-154
+  std::memset(p, 0, sizeof(*p));
+  p->max_batch_size = 1;
+  p->cache_shards = 1;
+  p->cpuct = 2.0f;
+  p->start_temp = 1.0f;
+  p->final_temp = 1.0f;
+  p->tree_reuse = 1;
+  p->mcts_root_temp = 1.0f;
+  p->playout_cap_depth = 25;
+  p->playout_cap_percent = 0.75f;
+}
+void azmi_engine_opts_default(azmi_engine_opts* o) {
+  std::memset(o, 0, sizeof(*o));
+  o->seed = 20240601ULL;  // mcts_test.cc:515
+}
+
+int azmi_game_info(int game, uint32_t* num_players, uint32_t* num_moves, uint32_t chw[3]) {
+  GameInfo gi;
+  if (!game_info(game, &gi)) return fail(AZMI_ERR_INVALID, "unknown game id %d", game);
+  if (num_players) *num_players = gi.P;
+  if (num_moves) *num_moves = gi.M;
+  if (chw) { chw[0] = gi.C; chw[1] = gi.H; chw[2] = gi.W; }
+  return AZMI_OK;
+}
+
+int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_opts* opts_in, azmi_pm** out) {
+  if (!params || !out) return fail(AZMI_ERR_INVALID, "null argument");
+  GameInfo gi;
+  if (!game_info(game, &gi)) return fail(AZMI_ERR_INVALID, "unknown game id %d", game);
+  azmi_engine_opts opts;
+  if (opts_in) opts = *opts_in; else azmi_engine_opts_default(&opts);
+  // play_manager.cc:20-22
+  if (params->num_mcts_visits != gi.P) return fail(AZMI_ERR_INVALID, "You must specify MCTS visits for each player");
+  if (params->concurrent_games == 0) return fail(AZMI_ERR_INVALID, "concurrent_games must be > 0");
+  if (params->num_eval_type != 0 && params->num_eval_type != gi.P)
+    return fail(AZMI_ERR_INVALID, "eval_type must be empty or have one entry per player");
+  for (uint32_t i = 0; i < params->num_eval_type; ++i)
+    if (params->eval_type[i] == AZMI_EVAL_PLAYOUT) return fail(AZMI_ERR_INVALID, "EvalType::PLAYOUT is not implemented on the device");
+  if (params->resign_percent > 0 && gi.P != 2) return fail(AZMI_ERR_INVALID, "Resigning only works in 2 player games");
+  if (params->max_cache_size != 0) return fail(AZMI_ERR_INVALID, "device position cache is not available in this build; set max_cache_size=0");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(AZMI_ERR_NO_DEVICE, "no HIP device: libazmi has no CPU path");
+  if (opts.device < 0 || opts.device >= ndev) return fail(AZMI_ERR_INVALID, "device %d out of range", opts.device);
+  HIP_TRY(hipSetDevice(opts.device));
+
+  auto pm = new azmi_pm();
+  pm->game = game; pm->device = opts.device; pm->gi = gi; pm->params = *params;
+  EngineParams& ep = pm->ep;
+  ep.S = params->concurrent_games;
+  ep.games_to_play = params->games_to_play;
+  uint32_t max_visits = params->playout_cap_randomization ? params->playout_cap_depth : 0;
+  for (uint32_t i = 0; i < gi.P; ++i) { ep.visits[i] = params->mcts_visits[i]; max_visits = std::max(max_visits, ep.visits[i]); }
+  ep.cap_visits = params->playout_cap_depth;
+  ep.cpuct = params->cpuct; ep.start_temp = params->start_temp; ep.final_temp = params->final_temp;
+  ep.half_life = params->temp_decay_half_life;
+  ep.epsilon = params->epsilon; ep.root_temp = params->mcts_root_temp; ep.fpu_reduction = params->fpu_reduction;
+  ep.cap_percent = params->playout_cap_percent; ep.resign_percent = params->resign_percent;
+  ep.resign_playthrough = params->resign_playthrough_percent;
+  ep.history = params->history_enabled != 0; ep.tree_reuse = params->tree_reuse != 0;
+  ep.cap_rand = params->playout_cap_randomization != 0; ep.root_fpu_zero = params->root_fpu_zero != 0;
+  ep.shaped = params->shaped_dirichlet != 0; ep.pruning = params->policy_target_pruning != 0;
+  for (uint32_t i = 0; i < gi.P; ++i)
+    ep.eval_random[i] = params->num_eval_type ? (params->eval_type[i] == AZMI_EVAL_RANDOM) : 0;
+  ep.max_inline = opts.max_inline ? opts.max_inline : 4;
+  ep.max_hist_rows = gi.max_turns;
+  ep.max_depth = gi.max_turns + 2;
+  // every search expands at most one node (<= maxk children) per simulation and a tree is
+  // searched on at most ceil(max_turns/2) turns; re-rooting an empty tree expands once more.
+  const uint64_t cap64 = (static_cast<uint64_t>((gi.max_turns + 1) / 2) * max_visits + gi.max_turns) * gi.maxk + 8;
+  if (cap64 > 0xFFFFFFF0ULL) { delete pm; return fail(AZMI_ERR_INVALID, "tree arena too large"); }
+  ep.cap = static_cast<uint32_t>(cap64);
+  ep.log_moves = opts.log_moves != 0;
+  ep.log_cap = ep.log_moves ? (opts.move_log_capacity ? opts.move_log_capacity
+                                                       : (params->games_to_play + ep.S) * gi.max_turns) : 0;
+  ep.hist_cap = ep.history ? (opts.history_capacity ? opts.history_capacity
+                                                    : (params->games_to_play + ep.S) * gi.max_turns) : 0;
+
+  const uint32_t S = ep.S, P = gi.P, M = gi.M, CANON = gi.C * gi.H * gi.W;
+  const size_t T = static_cast<size_t>(S) * P, NODES = T * ep.cap;
+  EngineArrays& ar = pm->ar;
+  int rc = AZMI_OK;
+#define A(field, count, zero) if (rc == AZMI_OK) rc = pm->alloc(ar.field, (count), (zero))
+  A(ctl, 1, true);
+  A(ended_list, S, true);
+  A(gs_words, static_cast<size_t>(gi.state_words) * S, true);
+  A(rng, S, true); A(coin, S, true);
+  A(sstate, S, true); A(flags, S, true);
+  A(cur, S, true); A(plen, S, true);
+  A(path, static_cast<size_t>(S) * ep.max_depth, true);
+  A(slot_games, S, true);
+  A(g_dsum, 5 * static_cast<size_t>(S), true); A(g_cnt, 3 * static_cast<size_t>(S), true);
+  A(a_scores, static_cast<size_t>(S) * (P + 1), true); A(a_resign, static_cast<size_t>(S) * (P + 1), true);
+  A(a_len, S, true); A(a_dsum, 5 * static_cast<size_t>(S), true); A(a_cnt, 3 * static_cast<size_t>(S), true);
+  A(c_sims, S, true); A(c_evals, S, true);
+  A(ph_count, S, true);
+  A(ph_canon, ep.history ? static_cast<size_t>(S) * ep.max_hist_rows * CANON : 0, false);
+  A(ph_pi, ep.history ? static_cast<size_t>(S) * ep.max_hist_rows * M : 0, false);
+  A(ph_meta, ep.history ? static_cast<size_t>(S) * ep.max_hist_rows * 2 : 0, false);
+  A(root, T, true); A(bump, T, true); A(depth, T, true); A(tld, T, true);
+  A(N, NODES, false); A(Q, NODES, false); A(Pr, NODES, false); A(D, NODES, false); A(V, NODES, false);
+  A(META, NODES, false);
+  A(canon, static_cast<size_t>(S) * CANON, true);
+  A(v, static_cast<size_t>(S) * (P + 1), true);
+  A(pi, static_cast<size_t>(S) * M, true);
+  A(leaf_key, S, true);
+  A(h_canon, static_cast<size_t>(ep.hist_cap) * CANON, false);
+  A(h_v, static_cast<size_t>(ep.hist_cap) * (P + 1), false);
+  A(h_pi, static_cast<size_t>(ep.hist_cap) * M, false);
+  A(h_meta, static_cast<size_t>(ep.hist_cap) * 4, false);
+  A(log_rows, static_cast<size_t>(ep.log_cap) * 8, false);
+  A(log_counts, static_cast<size_t>(ep.log_cap) * M, false);
+  ep.trace_slot = getenv("AZMI_TRACE_SLOT") ? static_cast<uint32_t>(atoi(getenv("AZMI_TRACE_SLOT"))) : 0xFFFFFFFFu;
+  ep.trace_cap = ep.trace_slot != 0xFFFFFFFFu ? (1u << 16) : 1u;
+  A(trace, 2 * static_cast<size_t>(ep.trace_cap), true);
+#undef A
+  if (rc != AZMI_OK) { delete pm; return rc; }
+  if (hipStreamCreateWithFlags(&pm->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete pm;
+    return fail(AZMI_ERR_NO_DEVICE, "hipStreamCreate failed");
+  }
+  Control c{};
+  c.games_started = S;  // play_manager.cc:15
+  c.live_slots = S;
+  if (hipMemcpy(ar.ctl, &c, sizeof(c), hipMemcpyHostToDevice) != hipSuccess) { delete pm; return fail(AZMI_ERR_NO_DEVICE, "ctl init failed"); }
+  k_seed<<<(S + 255) / 256, 256, 0, pm->stream>>>(ar, S, opts.seed);
+  if (hipStreamSynchronize(pm->stream) != hipSuccess) { delete pm; return fail(AZMI_ERR_NO_DEVICE, "seed kernel failed"); }
+  pm->host_v.assign(static_cast<size_t>(S) * (P + 1), 0.0f);
+  pm->host_pi.assign(static_cast<size_t>(S) * M, 0.0f);
+  *out = pm;
+  return AZMI_OK;
+}
+
+void azmi_pm_destroy(azmi_pm* pm) {
+  if (!pm) return;
+  (void)hipSetDevice(pm->device);
+  (void)hipDeviceSynchronize();
+  delete pm;
+}
+
+int azmi_pm_round(azmi_pm* pm, void* stream) {
+  if (!pm) return fail(AZMI_ERR_INVALID, "null pm");
+  return launch_round(pm, stream ? static_cast<hipStream_t>(stream) : pm->stream);
+}
+
+int azmi_pm_io_buffers(azmi_pm* pm, float** dev_canonical, float** dev_v, float** dev_pi) {
+  if (!pm) return fail(AZMI_ERR_INVALID, "null pm");
+  if (dev_canonical) *dev_canonical = pm->ar.canon;
+  if (dev_v) *dev_v = pm->ar.v;
+  if (dev_pi) *dev_pi = pm->ar.pi;
+  return AZMI_OK;
+}
+
+int azmi_pm_poll(azmi_pm* pm, void* stream, uint32_t* games_completed, uint32_t* live_slots) {
+  if (!pm) return fail(AZMI_ERR_INVALID, "null pm");
+  Control c;
+  const int rc = read_ctl(pm, stream ? static_cast<hipStream_t>(stream) : pm->stream, &c, true);
+  if (rc != AZMI_OK) return rc;
+  if (games_completed) *games_completed = c.games_completed;
+  if (live_slots) *live_slots = c.stop ? 0u : c.live_slots;
+  return AZMI_OK;
+}
+
+int azmi_pm_play(azmi_pm* pm, void* stream) {
+  if (!pm) return fail(AZMI_ERR_INVALID, "null pm");
+  for (uint32_t i = 0; i < pm->gi.P; ++i)
+    if (!pm->ep.eval_random[i]) return fail(AZMI_ERR_STATE, "azmi_pm_play needs EvalType::RANDOM on every seat; drive NN seats with azmi_pm_round");
+  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : pm->stream;
+  for (;;) {
+    for (int r = 0; r < 32; ++r) {
+      const int rc = launch_round(pm, st);
+      if (rc != AZMI_OK) return rc;
+    }
+    Control c;
+    const int rc = read_ctl(pm, st, &c, true);
+    if (rc != AZMI_OK) return rc;
+    if (c.stop) return AZMI_OK;
+  }
+}
+
+int azmi_pm_scores(azmi_pm* pm, float* out) {
+  if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");
+  std::vector<float> a;
+  const uint32_t V = pm->gi.P + 1;
+  const int rc = d2h(a, pm->ar.a_scores, static_cast<size_t>(pm->ep.S) * V, pm->stream);
+  if (rc != AZMI_OK) return rc;
+  for (uint32_t i = 0; i < V; ++i) out[i] = 0.0f;
+  for (uint32_t s = 0; s < pm->ep.S; ++s) for (uint32_t i = 0; i < V; ++i) out[i] += a[static_cast<size_t>(s) * V + i];
+  return AZMI_OK;
+}
+int azmi_pm_resign_scores(azmi_pm* pm, float* out) {
+  if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");
+  std::vector<float> a;
+  const uint32_t V = pm->gi.P + 1;
+  const int rc = d2h(a, pm->ar.a_resign, static_cast<size_t>(pm->ep.S) * V, pm->stream);
+  if (rc != AZMI_OK) return rc;
+  for (uint32_t i = 0; i < V; ++i) out[i] = 0.0f;
+  for (uint32_t s = 0; s < pm->ep.S; ++s) for (uint32_t i = 0; i < V; ++i) out[i] += a[static_cast<size_t>(s) * V + i];
+  return AZMI_OK;
+}
+
+int azmi_pm_stats(azmi_pm* pm, float* out) {  // play_manager.h:288-315
+  if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");
+  const uint32_t S = pm->ep.S;
+  std::vector<uint64_t> len, cnt; std::vector<double> ds; std::vector<uint32_t> games;
+  int rc = d2h(len, pm->ar.a_len, S, pm->stream); if (rc) return rc;
+  rc = d2h(cnt, pm->ar.a_cnt, 3 * static_cast<size_t>(S), pm->stream); if (rc) return rc;
+  rc = d2h(ds, pm->ar.a_dsum, 5 * static_cast<size_t>(S), pm->stream); if (rc) return rc;
+  rc = d2h(games, pm->ar.slot_games, S, pm->stream); if (rc) return rc;
+  uint64_t game_length = 0, mc[3] = {0, 0, 0}, completed = 0; double d[5] = {0, 0, 0, 0, 0};
+  for (uint32_t s = 0; s < S; ++s) {
+    game_length += len[s]; completed += games[s];
+    for (int j = 0; j < 3; ++j) mc[j] += cnt[static_cast<size_t>(j) * S + s];
+    for (int j = 0; j < 5; ++j) d[j] += ds[static_cast<size_t>(j) * S + s];
+  }
+  out[0] = static_cast<float>(game_length) / static_cast<float>(completed);
+  out[1] = mc[1] == 0 ? 0.0f : static_cast<float>(d[0] / static_cast<double>(mc[1]));
+  out[2] = mc[1] == 0 ? 0.0f : static_cast<float>(d[1] / static_cast<double>(mc[1]));
+  out[3] = mc[2] == 0 ? 0.0f : static_cast<float>(d[2] / static_cast<double>(mc[2]));
+  out[4] = mc[2] == 0 ? 0.0f : static_cast<float>(d[3] / static_cast<double>(mc[2]));
+  out[5] = game_length == 0 ? 0.0f : static_cast<float>(mc[0]) / static_cast<float>(game_length);
+  out[6] = mc[0] == 0 ? 0.0f : static_cast<float>(d[4] / static_cast<double>(mc[0]));
+  return AZMI_OK;
+}
+
+int azmi_pm_counters(azmi_pm* pm, uint64_t* out) {
+  if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");
+  const uint32_t S = pm->ep.S;
+  std::vector<uint64_t> sims, evals;
+  int rc = d2h(sims, pm->ar.c_sims, S, pm->stream); if (rc) return rc;
+  rc = d2h(evals, pm->ar.c_evals, S, pm->stream); if (rc) return rc;
+  Control c;
+  rc = read_ctl(pm, pm->stream, &c, true); if (rc) return rc;
+  out[0] = out[1] = 0;
+  for (uint32_t s = 0; s < S; ++s) { out[0] += sims[s]; out[1] += evals[s]; }
+  out[2] = 0; out[3] = 0;
+  out[4] = std::min(c.hist_rows, pm->ep.hist_cap) - pm->hist_read;
+  out[5] = c.rounds;
+  return AZMI_OK;
+}
+
+int azmi_pm_pop_history(azmi_pm* pm, float* canonical, float* v, float* pi, uint32_t cap, uint32_t* n) {
+  if (!pm || !n) return fail(AZMI_ERR_INVALID, "null argument");
+  Control c;
+  int rc = read_ctl(pm, pm->stream, &c, true); if (rc) return rc;
+  const uint32_t avail = std::min(c.hist_rows, pm->ep.hist_cap) - pm->hist_read;
+  const uint32_t take = std::min(avail, cap);
+  const uint32_t CANON = pm->gi.C * pm->gi.H * pm->gi.W, V = pm->gi.P + 1, M = pm->gi.M;
+  const size_t r0 = pm->hist_read;
+  if (take) {
+    HIP_TRY(hipMemcpy(canonical, pm->ar.h_canon + r0 * CANON, static_cast<size_t>(take) * CANON * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(v, pm->ar.h_v + r0 * V, static_cast<size_t>(take) * V * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pi, pm->ar.h_pi + r0 * M, static_cast<size_t>(take) * M * 4, hipMemcpyDeviceToHost));
+  }
+  pm->hist_read += take;
+  *n = take;
+  return AZMI_OK;
+}
+
+int azmi_pm_history_device(azmi_pm* pm, float** dev_canonical, float** dev_v, float** dev_pi, uint32_t** dev_meta,
+                           uint32_t* rows) {
+  if (!pm) return fail(AZMI_ERR_INVALID, "null argument");
+  Control c;
+  int rc = read_ctl(pm, pm->stream, &c, true); if (rc) return rc;
+  if (dev_canonical) *dev_canonical = pm->ar.h_canon;
+  if (dev_v) *dev_v = pm->ar.h_v;
+  if (dev_pi) *dev_pi = pm->ar.h_pi;
+  if (dev_meta) *dev_meta = pm->ar.h_meta;
+  if (rows) *rows = std::min(c.hist_rows, pm->ep.hist_cap);
+  return AZMI_OK;
+}
+
+int azmi_pm_move_log(azmi_pm* pm, uint32_t* rows, uint32_t* counts, uint32_t cap, uint32_t* n) {
+  if (!pm || !n) return fail(AZMI_ERR_INVALID, "null argument");
+  if (!pm->ep.log_moves) return fail(AZMI_ERR_STATE, "move log was not enabled (azmi_engine_opts.log_moves)");
+  Control c;
+  int rc = read_ctl(pm, pm->stream, &c, true); if (rc) return rc;
+  const uint32_t take = std::min(std::min(c.log_rows, pm->ep.log_cap), cap);
+  if (take && rows) HIP_TRY(hipMemcpy(rows, pm->ar.log_rows, static_cast<size_t>(take) * 8 * 4, hipMemcpyDeviceToHost));
+  if (take && counts) HIP_TRY(hipMemcpy(counts, pm->ar.log_counts, static_cast<size_t>(take) * pm->gi.M * 4, hipMemcpyDeviceToHost));
+  *n = take;
+  return AZMI_OK;
+}
+
+int azmi_debug_trace(azmi_pm* pm, uint64_t* out, uint32_t cap, uint32_t* n) {
+  std::vector<uint64_t> t;
+  const int rc = d2h(t, pm->ar.trace, 2 * static_cast<size_t>(pm->ep.trace_cap), pm->stream);
+  if (rc) return rc;
+  const uint32_t cnt = static_cast<uint32_t>(std::min<uint64_t>(t[0], cap));
+  std::memcpy(out, t.data() + 2, static_cast<size_t>(cnt) * 16);
+  *n = cnt;
+  return AZMI_OK;
+}
+
+int azmi_pm_slot_games(azmi_pm* pm, uint32_t* out) {
+  if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");
+  std::vector<uint32_t> g;
+  const int rc = d2h(g, pm->ar.slot_games, pm->ep.S, pm->stream);
+  if (rc) return rc;
+  std::memcpy(out, g.data(), g.size() * 4);
+  return AZMI_OK;
+}
+
+// ---- host-buffer compatibility path ------------------------------------------------------------------
+int azmi_pm_build_batch(azmi_pm* pm, float* batch, uint32_t cap, uint32_t* indices, uint32_t* n) {
+  if (!pm || !batch || !indices || !n) return fail(AZMI_ERR_INVALID, "null argument");
+  *n = 0;
+  if (cap == 0) return AZMI_OK;
+  const uint32_t S = pm->ep.S, CANON = pm->gi.C * pm->gi.H * pm->gi.W;
+  hipStream_t st = pm->stream;
+  int guard = 0;
+  while (pm->pending.empty()) {
+    if (pm->outstanding != 0) return AZMI_OK;  // rows handed out, answers not back yet
+    Control c;
+    int rc = read_ctl(pm, st, &c, true); if (rc) return rc;
+    if (c.stop) return AZMI_OK;
+    rc = launch_round(pm, st); if (rc) return rc;
+    std::vector<uint8_t> ss, fl;
+    rc = d2h(ss, pm->ar.sstate, S, st); if (rc) return rc;
+    rc = d2h(fl, pm->ar.flags, S, st); if (rc) return rc;
+    for (uint32_t s = 0; s < S; ++s)
+      if (ss[s] == kSlotWaitEval && (fl[s] & kFlagLeafNeedsNet)) pm->pending.push_back(s);
+    if (++guard > (1 << 20)) return fail(AZMI_ERR_STATE, "build_batch made no progress");
+  }
+  const uint32_t take = std::min<uint32_t>(cap, static_cast<uint32_t>(pm->pending.size()));
+  for (uint32_t r = 0; r < take; ++r) {
+    const uint32_t s = pm->pending.front();
+    pm->pending.pop_front();
+    indices[r] = s;
+    HIP_TRY(hipMemcpyAsync(batch + static_cast<size_t>(r) * CANON, pm->ar.canon + static_cast<size_t>(s) * CANON,
+                           CANON * 4, hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  pm->outstanding += take;
+  *n = take;
+  return AZMI_OK;
+}
+
+int azmi_pm_update_inferences(azmi_pm* pm, const uint32_t* indices, uint32_t n, const float* v, const float* pi) {
+  if (!pm || (n && (!indices || !v || !pi))) return fail(AZMI_ERR_INVALID, "null argument");
+  const uint32_t S = pm->ep.S, V = pm->gi.P + 1, M = pm->gi.M;
+  if (n > pm->outstanding) return fail(AZMI_ERR_STATE, "update_inferences: more rows than build_batch handed out");
+  for (uint32_t r = 0; r < n; ++r) {
+    if (indices[r] >= S) return fail(AZMI_ERR_INVALID, "slot index out of range");
+    std::memcpy(&pm->host_v[static_cast<size_t>(indices[r]) * V], v + static_cast<size_t>(r) * V, V * 4);
+    std::memcpy(&pm->host_pi[static_cast<size_t>(indices[r]) * M], pi + static_cast<size_t>(r) * M, M * 4);
+  }
+  pm->outstanding -= n;
+  if (pm->outstanding == 0 && pm->pending.empty()) {
+    HIP_TRY(hipMemcpyAsync(pm->ar.v, pm->host_v.data(), pm->host_v.size() * 4, hipMemcpyHostToDevice, pm->stream));
+    HIP_TRY(hipMemcpyAsync(pm->ar.pi, pm->host_pi.data(), pm->host_pi.size() * 4, hipMemcpyHostToDevice, pm->stream));
+    HIP_TRY(hipStreamSynchronize(pm->stream));
+  }
+  return AZMI_OK;
+}
+
+int azmi_game_replay(int game, int device, const int32_t* moves, uint32_t n, uint32_t len, uint8_t* valid,
+                     float* scores, float* canonical, uint32_t* player, uint32_t* turn, uint64_t* key,
+                     int32_t* status) {
+  GameInfo gi;
+  if (!game_info(game, &gi)) return fail(AZMI_ERR_INVALID, "unknown game id %d", game);
+  if (!moves && n * len) return fail(AZMI_ERR_INVALID, "null moves");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(AZMI_ERR_NO_DEVICE, "no HIP device: libazmi has no CPU path");
+  HIP_TRY(hipSetDevice(device));
+  const uint32_t CANON = gi.C * gi.H * gi.W, V = gi.P + 1;
+  int32_t* d_moves = nullptr; uint8_t* d_valid = nullptr; float *d_scores = nullptr, *d_canon = nullptr;
+  uint32_t *d_player = nullptr, *d_turn = nullptr; uint64_t* d_key = nullptr; int32_t* d_status = nullptr;
+  std::vector<void*> tmp;
+  auto dalloc = [&](void** p, size_t bytes) { hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 4)); if (e == hipSuccess) tmp.push_back(*p); return e; };
+  auto cleanup = [&]() { for (void* q : tmp) (void)hipFree(q); };
+#define TRY2(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(AZMI_ERR_NO_DEVICE, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
+  TRY2(dalloc(reinterpret_cast<void**>(&d_moves), static_cast<size_t>(n) * len * 4));
+  TRY2(hipMemcpy(d_moves, moves, static_cast<size_t>(n) * len * 4, hipMemcpyHostToDevice));
+  if (valid) TRY2(dalloc(reinterpret_cast<void**>(&d_valid), static_cast<size_t>(n) * gi.M));
+  if (scores) TRY2(dalloc(reinterpret_cast<void**>(&d_scores), static_cast<size_t>(n) * V * 4));
+  if (canonical) TRY2(dalloc(reinterpret_cast<void**>(&d_canon), static_cast<size_t>(n) * CANON * 4));
+  if (player) TRY2(dalloc(reinterpret_cast<void**>(&d_player), static_cast<size_t>(n) * 4));
+  if (turn) TRY2(dalloc(reinterpret_cast<void**>(&d_turn), static_cast<size_t>(n) * 4));
+  if (key) TRY2(dalloc(reinterpret_cast<void**>(&d_key), static_cast<size_t>(n) * 8));
+  if (status) TRY2(dalloc(reinterpret_cast<void**>(&d_status), static_cast<size_t>(n) * 4));
+  if (n) {
+    switch (game) {
+      case AZMI_GAME_CONNECT4:
+        k_replay<Connect4><<<(n + 255) / 256, 256>>>(d_moves, n, len, d_valid, d_scores, d_canon, d_player, d_turn, d_key, d_status);
+        break;
+      default: cleanup(); return fail(AZMI_ERR_INVALID, "game %d has no device kernels", game);
+    }
+    TRY2(hipGetLastError());
+    TRY2(hipDeviceSynchronize());
+  }
+  if (valid) TRY2(hipMemcpy(valid, d_valid, static_cast<size_t>(n) * gi.M, hipMemcpyDeviceToHost));
+  if (scores) TRY2(hipMemcpy(scores, d_scores, static_cast<size_t>(n) * V * 4, hipMemcpyDeviceToHost));
+  if (canonical) TRY2(hipMemcpy(canonical, d_canon, static_cast<size_t>(n) * CANON * 4, hipMemcpyDeviceToHost));
+  if (player) TRY2(hipMemcpy(player, d_player, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost));
+  if (turn) TRY2(hipMemcpy(turn, d_turn, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost));
+  if (key) TRY2(hipMemcpy(key, d_key, static_cast<size_t>(n) * 8, hipMemcpyDeviceToHost));
+  if (status) TRY2(hipMemcpy(status, d_status, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost));
+#undef TRY2
+  cleanup();
+  return AZMI_OK;
+}
+
+}  // extern "C"

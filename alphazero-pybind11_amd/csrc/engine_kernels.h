@@ -1,0 +1,740 @@
+// Tree + game-step kernels of the self-play engine (gfx950, wave64).
+//
+// One lane-group of GM::GROUP lanes owns one game slot; 64/GROUP slots share a
+// wavefront.  Per-child work (the N/Q/P walk of PUCT select, prior
+// normalisation, expansion, backup levels) is spread over the group's lanes so
+// that consecutive lanes touch consecutive children of the SoA node arrays
+// (coalesced HBM reads); per-slot scalars (bitboards, pcg32 state) are computed
+// redundantly by every lane of the group, which keeps them group-uniform
+// without any cross-lane traffic.  Order-sensitive float reductions (the
+// reference sums priors in child order) are done by an in-order lane sweep with
+// DPP/bpermute shuffles; arg-max uses a butterfly with a (score, index) key so
+// the first index wins ties exactly like the reference's strict `>` scan.
+//
+// Reference behaviour restated here (file:line under /root/reference/src):
+//   Node::add_children        mcts.cc:93-101      -> expand_node
+//   Node::set_policy_normalized mcts.cc:109-121   -> process_result (priors)
+//   Node::uct / best_child    mcts.cc:123-149     -> select_child
+//   MCTS::update_root         mcts.cc:151-173     -> update_root
+//   MCTS::add_root_noise      mcts.cc:403-446     -> add_root_noise
+//   MCTS::apply_root_policy_temp mcts.cc:448-460  -> apply_root_policy_temp
+//   MCTS::find_leaf           mcts.cc:462-498     -> find_leaf
+//   MCTS::process_result      mcts.cc:500-555     -> process_result
+//   MCTS::probs/probs_pruned/pick_move/root_value/normalized_root_entropy
+//                             mcts.cc:575-674,717-750, mcts.h:78-100
+//   PlayManager::play         play_manager.cc:258-600 -> k_round (one worker-loop
+//                             iteration per slot per round) + k_assign
+//   dumb_eval                 game_state.h:160-173 -> synthesised in process_result
+// Build with -ffp-contract=off: the float expressions keep the reference's
+// operand order and must not be fused.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dev_games.h"
+#include "dev_rng.h"
+#include "engine_types.h"
+
+namespace azmi {
+
+constexpr float kNoiseAlphaRatio = 10.83f;  // mcts.cc:14
+
+template <class GM>
+struct SlotCtx {
+  static constexpr int G = GM::GROUP;
+  static constexpr int P = GM::P;
+  static constexpr int M = GM::M;
+  static_assert(GM::MAXK <= G, "single-chunk child handling needs MAXK <= GROUP");
+  static_assert(GM::M <= G, "lane-dense move vectors need M <= GROUP");
+
+  const EngineParams& ep;
+  const EngineArrays& ar;
+  uint32_t slot, lane;
+  Pcg32 rng, coin;
+  typename GM::State gs;
+  uint8_t flags;
+  // per-tree scalars, held identically by every lane of the group for the whole round
+  // (MCTS::root_, arena bump pointer, MCTS::depth_, MCTS::total_leaf_depth_)
+  uint32_t t_root[P], t_bump[P], t_depth[P];
+  uint64_t t_tld[P];
+  uint32_t cur, plen;  // MCTS::current_, MCTS::path_.size() of the pending simulation
+  uint32_t ph_rows;    // GameData::partial_history.size()
+
+  __device__ SlotCtx(const EngineParams& e, const EngineArrays& a, uint32_t s, uint32_t l)
+      : ep(e), ar(a), slot(s), lane(l) {}
+
+  // ---- group primitives ---------------------------------------------------------
+  template <class T>
+  __device__ __forceinline__ T bcast(T v, int src) const { return __shfl(v, src, G); }
+  __device__ __forceinline__ float seqsum(float x, uint32_t n) const {  // x_0 + x_1 + ... in lane order
+    float s = 0.0f;
+    for (uint32_t i = 0; i < n; ++i) s += bcast(x, i);
+    return s;
+  }
+  __device__ __forceinline__ size_t tree_base(uint32_t seat) const {
+    return (static_cast<size_t>(slot) * P + seat) * ep.cap;
+  }
+  __device__ __forceinline__ uint32_t tree_id(uint32_t seat) const { return slot * P + seat; }
+  __device__ __forceinline__ void raise(uint32_t bit) const {
+    if (lane == 0) { atomicOr(&ar.ctl->overflow, bit); ar.ctl->stop = 1; }
+  }
+  // Lanes of a group hand node data to each other through HBM (e.g. backup writes N/Q by
+  // level-lane, select reads them by child-lane).  A workgroup-scope fence makes those stores
+  // visible to the other lanes and stops the compiler from forwarding a lane's own stale value.
+  __device__ __forceinline__ void sync_lanes() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+  __device__ __forceinline__ void trace(uint64_t tag) const {
+    if (slot != ep.trace_slot || lane != 0) return;
+    const uint64_t n = ar.trace[0];
+    if (n + 1 < ep.trace_cap) { ar.trace[2 * (n + 1)] = tag; ar.trace[2 * (n + 1) + 1] = rng.state; ar.trace[0] = n + 1; }
+  }
+#define AZMI_SEL(arr, seat) ((seat) == 0 ? arr[0] : arr[P > 1 ? 1 : 0])
+
+  // ---- state load / store ----------------------------------------------------------
+  __device__ void load() {
+    rng.state = ar.rng[slot];
+    coin.state = ar.coin[slot];
+    flags = ar.flags[slot];
+    const uint64_t w0 = ar.gs_words[0 * ep.S + slot], w1 = ar.gs_words[1 * ep.S + slot],
+                   w2 = ar.gs_words[2 * ep.S + slot];
+    gs.bb[0] = w0; gs.bb[1] = w1;
+    gs.turn = static_cast<uint32_t>(w2); gs.player = static_cast<uint32_t>(w2 >> 32);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const uint32_t t = slot * P + p;
+      t_root[p] = ar.root[t]; t_bump[p] = ar.bump[t]; t_depth[p] = ar.depth[t]; t_tld[p] = ar.tld[t];
+    }
+    cur = ar.cur[slot]; plen = ar.plen[slot]; ph_rows = ar.ph_count[slot];
+  }
+  __device__ void store(uint8_t sstate) const {
+    if (lane != 0) return;
+    ar.rng[slot] = rng.state;
+    ar.coin[slot] = coin.state;
+    ar.flags[slot] = flags;
+    ar.sstate[slot] = sstate;
+    ar.gs_words[0 * ep.S + slot] = gs.bb[0];
+    ar.gs_words[1 * ep.S + slot] = gs.bb[1];
+    ar.gs_words[2 * ep.S + slot] = static_cast<uint64_t>(gs.turn) | (static_cast<uint64_t>(gs.player) << 32);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const uint32_t t = slot * P + p;
+      ar.root[t] = t_root[p]; ar.bump[t] = t_bump[p]; ar.depth[t] = t_depth[p]; ar.tld[t] = t_tld[p];
+    }
+    ar.cur[slot] = cur; ar.plen[slot] = plen; ar.ph_count[slot] = ph_rows;
+  }
+
+  // ---- tree reset: MCTS{...} construction, play_manager.cc:602-617 --------------------
+  __device__ void reset_tree(uint32_t seat) {
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+      if (static_cast<uint32_t>(p) == seat) { t_root[p] = 0; t_bump[p] = 1; t_depth[p] = 0; t_tld[p] = 0; }
+    const size_t tb = tree_base(seat);
+    if (lane == 0) { ar.N[tb] = 0; ar.Q[tb] = 0; ar.Pr[tb] = 0; ar.D[tb] = 0; ar.V[tb] = 0; ar.META[tb] = 0; }
+  }
+
+  // ---- Node::add_children: legal moves ascending, std::shuffle, append to the arena ----
+  // Returns false when the arena is full.  `meta_keep` supplies move/player/term of `node`.
+  __device__ bool expand_node(uint32_t seat, uint32_t node, const typename GM::State& st, uint64_t meta_keep,
+                              uint32_t& c0_out, uint32_t& k_out) {
+    const size_t tb = tree_base(seat);
+    const uint32_t k = GM::num_valid(st);
+    uint32_t mv = lane < k ? GM::nth_valid(st, lane) : 0u;
+    // std::shuffle (stl_algo.h:3729-3792): element `lane` of the array lives in lane `lane`
+    if (k > 1) {
+      uint32_t i = 1;
+      if ((k & 1u) == 0) {
+        const uint32_t j = lemire_below(rng, 2);
+        const uint32_t vi = bcast(mv, i), vj = bcast(mv, j);
+        if (lane == i) mv = vj;
+        if (lane == j) mv = vi;
+        ++i;
+      }
+      while (i != k) {
+        const uint32_t swap_range = i + 1, b1 = swap_range + 1;
+        const uint32_t x = lemire_below(rng, swap_range * b1);
+        const uint32_t p0 = x / b1, p1 = x % b1;
+        uint32_t vi = bcast(mv, i), vj = bcast(mv, p0);
+        if (lane == i) mv = vj;
+        if (lane == p0) mv = vi;
+        ++i;
+        vi = bcast(mv, i); vj = bcast(mv, p1);
+        if (lane == i) mv = vj;
+        if (lane == p1) mv = vi;
+        ++i;
+      }
+    }
+    const uint32_t c0 = AZMI_SEL(t_bump, seat);
+    if (c0 + k > ep.cap) { raise(1u); return false; }
+    if (lane < k) {
+      const size_t ci = tb + c0 + lane;
+      ar.N[ci] = 0; ar.Q[ci] = 0.0f; ar.Pr[ci] = 0.0f; ar.D[ci] = 0.0f; ar.V[ci] = 0.0f;
+      ar.META[ci] = meta_pack(0, 0, mv, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == seat) t_bump[p] = c0 + k;
+    if (lane == 0)
+      ar.META[tb + node] = meta_pack(c0, k, meta_mv(meta_keep), meta_player(meta_keep), meta_term(meta_keep));
+    c0_out = c0;
+    k_out = k;
+    return true;
+  }
+
+  // ---- Node::best_child ------------------------------------------------------------------
+  // children live in lanes [0,k): n_l, q_l, p_l.  Returns the winning lane.
+  __device__ uint32_t select_child(uint32_t k, uint32_t n_l, float q_l, float p_l, float v_parent,
+                                   uint32_t n_parent, float fpu_reduction) const {
+    float seen = 0.0f;
+    for (uint32_t i = 0; i < k; ++i) {
+      const uint32_t ni = bcast(n_l, i);
+      const float pi = bcast(p_l, i);
+      if (ni > 0) seen += pi;
+    }
+    const float fpu_value = v_parent - fpu_reduction * sqrtf(seen);
+    const float sqrt_n = sqrtf(static_cast<float>(n_parent));
+    float u = (n_l == 0 ? fpu_value : q_l) + ep.cpuct * p_l * sqrt_n / static_cast<float>(n_l + 1);
+    // a strict `>` scan never replaces the incumbent with a NaN and never leaves a NaN at
+    // index 0: map NaN to +inf at lane 0 and -inf elsewhere, then butterfly (score, index)
+    if (u != u) u = (lane == 0) ? __builtin_inff() : -__builtin_inff();
+    if (lane >= k) u = -__builtin_inff();
+    uint32_t idx = lane < k ? lane : 0xFFFFu;
+    for (int off = 1; off < G; off <<= 1) {
+      const float ou = __shfl_xor(u, off, G);
+      const uint32_t oi = __shfl_xor(idx, off, G);
+      if (ou > u || (ou == u && oi < idx)) { u = ou; idx = oi; }
+    }
+    return idx;
+  }
+
+  // ---- MCTS::find_leaf ---------------------------------------------------------------------
+  // Descends from the root of `seat`'s tree, expands an unvisited node.  Outputs the leaf
+  // state and its terminal code; stores MCTS::current_ / path_ for process_result.
+  __device__ bool find_leaf(uint32_t seat, typename GM::State& leaf, uint32_t& term) {
+    sync_lanes();
+    const size_t tb = tree_base(seat);
+    const uint32_t root = AZMI_SEL(t_root, seat);
+    cur = root; plen = 0;
+    leaf = gs;
+    uint64_t meta = ar.META[tb + cur];
+    uint32_t n = ar.N[tb + cur];
+    uint32_t* path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
+    while (n > 0 && meta_term(meta) == 0) {
+      if (plen >= ep.max_depth) { raise(8u); return false; }
+      if (lane == 0) path[plen] = cur;
+      ++plen;
+      const uint32_t k = meta_nch(meta), c0 = meta_ch0(meta);
+      if (k == 0) { raise(8u); return false; }  // reference: children.at(0) throws
+      const size_t ci = tb + c0 + lane;
+      uint32_t n_l = 0; float q_l = 0.0f, p_l = 0.0f; uint64_t m_l = 0;
+      if (lane < k) { n_l = ar.N[ci]; q_l = ar.Q[ci]; p_l = ar.Pr[ci]; m_l = ar.META[ci]; }
+      const float fpu = (cur == root && ep.root_fpu_zero) ? 0.0f : ep.fpu_reduction;
+      const float v_parent = ar.V[tb + cur];
+      const uint32_t best = select_child(k, n_l, q_l, p_l, v_parent, n, fpu);
+      cur = c0 + best;
+      n = bcast(n_l, best);
+      meta = bcast(m_l, best);
+      GM::play(leaf, meta_mv(meta));
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == seat) t_tld[p] += plen;
+    term = meta_term(meta);
+    if (n == 0) {
+      term = GM::terminal(leaf);
+      const uint64_t keep = meta_pack(0, 0, meta_mv(meta), leaf.player, term);
+      uint32_t c0, k;
+      if (!expand_node(seat, cur, leaf, keep, c0, k)) return false;
+    }
+    return true;
+  }
+
+  // ---- MCTS::add_root_noise: children in lanes [0,k), priors p_l -----------------------------
+  __device__ float add_root_noise(uint32_t k, float p_l) {
+    float noise_l = 0.0f;
+    double sum = 0.0;
+    if (ep.shaped && k > 1) {
+      const float Nf = static_cast<float>(k);
+      const float lp_l = lane < k ? az_logf(fminf(p_l, 0.01f) + 1e-20f) : 0.0f;
+      const float log_sum = seqsum(lp_l, k);
+      const float log_mean = log_sum / Nf;
+      const float sh_l = lane < k ? fmaxf(0.0f, lp_l - log_mean) : 0.0f;
+      const float shaped_sum = seqsum(sh_l, k);
+      const float uniform = 1.0f / Nf;
+      for (uint32_t i = 0; i < k; ++i) {
+        const float shaped = bcast(sh_l, i);
+        float alpha_prop = (shaped_sum > 0) ? 0.5f * (shaped / shaped_sum + uniform) : uniform;
+        alpha_prop = fmaxf(alpha_prop, 1e-6f);
+        Gamma dist(kNoiseAlphaRatio * alpha_prop);  // fresh object per child (mcts.cc:430)
+        const float g = dist.draw(rng);
+        if (lane == i) noise_l = g;
+        sum += g;
+      }
+    } else {
+      Gamma dist(kNoiseAlphaRatio / static_cast<float>(k));  // one object, normal cache carries
+      for (uint32_t i = 0; i < k; ++i) {
+        const float g = dist.draw(rng);
+        if (lane == i) noise_l = g;
+        sum += g;
+      }
+    }
+    return p_l * (1 - ep.epsilon) + ep.epsilon * noise_l / static_cast<float>(sum);
+  }
+
+  // ---- MCTS::process_result -------------------------------------------------------------------
+  // from_net: read (v, pi) rows written by the net; otherwise synthesise dumb_eval.
+  __device__ void process_result(uint32_t seat, bool from_net, bool root_noise) {
+    sync_lanes();
+    const size_t tb = tree_base(seat);
+    const uint32_t root = AZMI_SEL(t_root, seat);
+    const uint64_t meta = ar.META[tb + cur];
+    const uint32_t term = meta_term(meta);
+    float val[P + 1];
+    if (term != 0) {
+#pragma unroll
+      for (int i = 0; i <= P; ++i) val[i] = (static_cast<int>(term) - 1 == i) ? 1.0f : 0.0f;
+    } else {
+      const uint32_t k = meta_nch(meta), c0 = meta_ch0(meta);
+      const size_t ci = tb + c0 + lane;
+      float p = 0.0f;
+      if (from_net) {
+#pragma unroll
+        for (int i = 0; i <= P; ++i) val[i] = ar.v[static_cast<size_t>(slot) * (P + 1) + i];
+        if (lane < k) p = ar.pi[static_cast<size_t>(slot) * M + meta_mv(ar.META[ci])];
+      } else {  // dumb_eval: uniform over legal moves, u8 sum wraps (game_state.h:160-173)
+#pragma unroll
+        for (int i = 0; i <= P; ++i) val[i] = static_cast<float>(1.0 / (P + 1));
+        const float ksum = static_cast<float>(k & 0xFFu);
+        if (lane < k) p = (ksum == 0.0f) ? 0.0f : 1.0f / ksum;
+      }
+      const bool is_root = cur == root;
+      if (is_root && ep.root_temp != 1.0f && lane < k) p = az_powf(p, 1.0f / ep.root_temp);
+      const float sum = seqsum(lane < k ? p : 0.0f, k);
+      p = p / sum;
+      if (is_root && root_noise) { trace(1 | (static_cast<uint64_t>(k) << 8)); p = add_root_noise(k, p); trace(2); }
+      if (lane < k) ar.Pr[ci] = p;
+    }
+    // backup: level i updates node_i (child of path[i]); levels are independent -> one lane each
+    const uint32_t* path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
+    const float draw_share = val[P] / static_cast<int32_t>(P);
+    for (uint32_t base = 0; base < plen; base += G) {
+      const uint32_t i = base + lane;
+      if (i < plen) {
+        const uint32_t node = (i == plen - 1) ? cur : path[i + 1];
+        const uint32_t parent = path[i];
+        const uint32_t pp = meta_player(ar.META[tb + parent]);
+        const size_t ni = tb + node;
+        float vv = (pp == 0) ? val[0] : val[1];
+        if (P > 2) vv = val[pp];
+        vv += draw_share;
+        const uint32_t nn = ar.N[ni];
+        const float q = ar.Q[ni], d = ar.D[ni];
+        ar.Q[ni] = (q * static_cast<float>(nn) + vv) / static_cast<float>(nn + 1);
+        ar.D[ni] = (d * static_cast<float>(nn) + val[P]) / static_cast<float>(nn + 1);
+        if (nn == 0) {
+          const uint32_t np = meta_player(ar.META[ni]);
+          ar.V[ni] = ((np == 0) ? val[0] : val[1]) + draw_share;
+        }
+        ar.N[ni] = nn + 1;
+      }
+    }
+    if (lane == 0) {
+      const size_t ri = tb + root;
+      const uint32_t rn = ar.N[ri];
+      if (rn == 0) {
+        const uint32_t rp = meta_player(ar.META[ri]);
+        ar.V[ri] = ((rp == 0) ? val[0] : val[1]) + draw_share;
+        ar.D[ri] = val[P];
+      }
+      ar.N[ri] = rn + 1;
+      ar.c_sims[slot] += 1;
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == seat) t_depth[p] += 1;
+    sync_lanes();
+  }
+
+  // ---- lane-dense [M] vector helpers (lane m holds entry m) ------------------------------------
+  template <class T>
+  __device__ __forceinline__ T scatter_by_move(uint32_t k, uint32_t mv_l, T x_l) const {
+    T out = T(0);
+    for (uint32_t i = 0; i < k; ++i) {
+      const uint32_t mi = bcast(mv_l, i);
+      const T xi = bcast(x_l, i);
+      if (lane == mi) out = xi;
+    }
+    return out;
+  }
+  __device__ __forceinline__ float pow_entry(float x, float e) const { return e == 1.0f ? x : az_powf(x, e); }
+
+  // MCTS::probs — cnt_m / pol_m are the dense root counts and priors
+  __device__ float probs(float temp, uint32_t cnt_m, float pol_m) const {
+    const bool in = lane < M;
+    const float count_sum = seqsum(in ? static_cast<float>(cnt_m) : 0.0f, M);
+    if (count_sum == 0) {
+      float p = in ? pol_m : 0.0f;
+      if (temp != 0.0f) p = in ? pow_entry(p, 1.0f / temp) : 0.0f;
+      return p / seqsum(p, M);
+    }
+    if (temp == 0) {
+      uint32_t best = in ? cnt_m : 0u;
+      for (int off = 1; off < G; off <<= 1) best = max(best, __shfl_xor(best, off, G));
+      const bool is_best = in && cnt_m == best;
+      uint32_t nbest = is_best ? 1u : 0u;
+      for (int off = 1; off < G; off <<= 1) nbest += __shfl_xor(nbest, off, G);
+      return is_best ? static_cast<float>(1.0 / static_cast<double>(nbest)) : 0.0f;
+    }
+    float p = in ? static_cast<float>(cnt_m) : 0.0f;
+    p = p / seqsum(p, M);
+    p = in ? pow_entry(p, 1 / temp) : 0.0f;
+    return p / seqsum(p, M);
+  }
+
+  // MCTS::probs_pruned — children in lanes, returns the dense vector
+  __device__ float probs_pruned(float temp, uint32_t root_n, uint32_t k, uint32_t mv_l, uint32_t n_l, float q_l,
+                                float p_l, uint32_t cnt_m, float pol_m) const {
+    if (root_n <= 1) return probs(temp, cnt_m, pol_m);
+    const float explore_scaling = ep.cpuct * sqrtf(static_cast<float>(root_n));
+    float best_sel = -1e30f;
+    for (uint32_t i = 0; i < k; ++i) {
+      const uint32_t ni = bcast(n_l, i);
+      const float sel = bcast(q_l, i) + explore_scaling * bcast(p_l, i) / static_cast<float>(ni + 1);
+      if (ni != 0 && sel > best_sel) best_sel = sel;
+    }
+    float pr_l = 0.0f;
+    if (lane < k && n_l != 0) {
+      const float gap = best_sel - q_l;
+      const float nf = static_cast<float>(n_l);
+      const float desired = (gap <= 0) ? nf : explore_scaling * p_l / gap - 1.0f;
+      const float lo = (0.0f < desired) ? desired : 0.0f;  // std::max(0.0f, desired)
+      pr_l = (lo < nf) ? lo : nf;                          // std::min(n, .)
+    }
+    float pruned = scatter_by_move<float>(k, mv_l, pr_l);
+    const bool in = lane < M;
+    const float total = seqsum(in ? pruned : 0.0f, M);
+    if (total == 0) return probs(temp, cnt_m, pol_m);
+    if (temp == 0) {
+      float best_val = bcast(pruned, 0);
+      for (uint32_t m = 1; m < static_cast<uint32_t>(M); ++m) {
+        const float o = bcast(pruned, m);
+        best_val = (best_val < o) ? o : best_val;
+      }
+      const bool is_best = in && pruned == best_val;
+      uint32_t cnt = is_best ? 1u : 0u;
+      for (int off = 1; off < G; off <<= 1) cnt += __shfl_xor(cnt, off, G);
+      return is_best ? 1.0f / static_cast<int32_t>(cnt) : 0.0f;
+    }
+    pruned = in ? pruned / total : 0.0f;
+    if (temp != 1.0f) {
+      pruned = in ? pow_entry(pruned, 1.0f / temp) : 0.0f;
+      pruned = pruned / seqsum(pruned, M);
+    }
+    return pruned;
+  }
+
+  // MCTS::pick_move — one uniform draw, first m with running sum > choice
+  __device__ uint32_t pick_move(float p_m) {
+    const float choice = canonical01(rng) * 1.0f + 0.0f;
+    float sum = 0.0f;
+    for (uint32_t m = 0; m < static_cast<uint32_t>(M); ++m) {
+      sum += bcast(p_m, m);
+      if (sum > choice) return m;
+    }
+    for (int m = M - 1; m >= 0; --m)
+      if (bcast(p_m, m) > 0) return static_cast<uint32_t>(m);
+    raise(16u);  // reference throws "this shouldn't be possible."
+    return 0;
+  }
+
+  // ---- MCTS::update_root ----------------------------------------------------------------------------
+  __device__ bool update_root(uint32_t seat, uint32_t move) {
+    sync_lanes();
+    const size_t tb = tree_base(seat);
+    const uint32_t root = AZMI_SEL(t_root, seat);
+    const uint64_t meta = ar.META[tb + root];
+    uint32_t k = meta_nch(meta), c0 = meta_ch0(meta);
+    if (k == 0 && !expand_node(seat, root, gs, meta, c0, k)) return false;
+    uint32_t hit = 0xFFFFu;
+    if (lane < k && meta_mv(ar.META[tb + c0 + lane]) == move) hit = lane;
+    for (int off = 1; off < G; off <<= 1) hit = min(hit, __shfl_xor(hit, off, G));
+    if (hit == 0xFFFFu) { raise(32u); return false; }  // "ahh, what is this move"
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+      if (static_cast<uint32_t>(p) == seat) { t_root[p] = c0 + hit; t_depth[p] = 0; t_tld[p] = 0; }
+    return true;
+  }
+
+  // ---- MCTS::apply_root_policy_temp + add_root_noise on a reused subtree (play_manager.cc:541-555) ---
+  __device__ void reapply_root_prior(uint32_t seat, bool noise) {
+    sync_lanes();
+    const size_t tb = tree_base(seat);
+    const uint32_t root = AZMI_SEL(t_root, seat);
+    if (ar.N[tb + root] == 0) return;
+    const uint64_t meta = ar.META[tb + root];
+    const uint32_t k = meta_nch(meta), c0 = meta_ch0(meta);
+    const size_t ci = tb + c0 + lane;
+    float p = lane < k ? ar.Pr[ci] : 0.0f;
+    bool dirty = false;
+    if (ep.root_temp != 1.0f) {
+      if (lane < k) p = az_powf(p, 1.0f / ep.root_temp);
+      const float sum = seqsum(lane < k ? p : 0.0f, k);
+      if (sum > 0.0f) p = p / sum;
+      dirty = true;
+    }
+    if (noise && k > 0) { trace(3 | (static_cast<uint64_t>(k) << 8)); p = add_root_noise(k, p); trace(4); dirty = true; }
+    if (dirty && lane < k) ar.Pr[ci] = p;
+  }
+
+  // ---- new game: GameData reset + fresh trees (play_manager.cc:214-230, 515-520) ------------------------
+  __device__ void start_game() {
+    gs = GM::initial();
+    for (uint32_t s = 0; s < static_cast<uint32_t>(P); ++s) reset_tree(s);
+    ph_rows = 0;
+  }
+  __device__ void draw_capped() {  // play_manager.cc:523-524 / 559-560
+    const bool capped = ep.cap_rand && (canonical01(coin) < ep.cap_percent);
+    flags = capped ? (flags | kFlagCapped) : (flags & ~kFlagCapped);
+  }
+
+  // ---- the "actually play a move" block, play_manager.cc:286-556.  Returns true if the game ended. ------
+  __device__ bool make_move(uint32_t cp) {
+    sync_lanes();
+    const size_t tb = tree_base(cp);
+    const bool capped = flags & kFlagCapped;
+    const uint32_t root = AZMI_SEL(t_root, cp);
+    const uint64_t rmeta = ar.META[tb + root];
+    const uint32_t k = meta_nch(rmeta), c0 = meta_ch0(rmeta);
+    const uint32_t root_n = ar.N[tb + root];
+    const size_t ci = tb + c0 + lane;
+    uint32_t n_l = 0, mv_l = 0; float q_l = 0, p_l = 0, d_l = 0;
+    if (lane < k) { n_l = ar.N[ci]; q_l = ar.Q[ci]; p_l = ar.Pr[ci]; d_l = ar.D[ci]; mv_l = meta_mv(ar.META[ci]); }
+    const uint32_t cnt_m = scatter_by_move<uint32_t>(k, mv_l, n_l);
+    const float pol_m = scatter_by_move<float>(k, mv_l, p_l);
+
+    float temp = ep.start_temp;
+    if (ep.half_life != 0) {  // play_manager.cc:297-304; ln2 is the literal 0.693
+      const float lambda = 0.693f / ep.half_life;
+      temp -= ep.final_temp;
+      temp *= az_expf(-lambda * gs.turn);
+      temp += ep.final_temp;
+    }
+    // resign, play_manager.cc:305-334
+    int resign_entry = -1;
+    if (ep.resign_percent > 0 && !(flags & kFlagPlaythrough)) {
+      float q = 0, d = 0; bool found = false;  // MCTS::root_value, mcts.h:78-100
+      for (uint32_t i = 0; i < k; ++i) {
+        const uint32_t ni = bcast(n_l, i); const float qi = bcast(q_l, i), di = bcast(d_l, i);
+        if (ni > 0 && qi > q) { q = qi; d = di; found = true; }
+      }
+      if (!found && root_n > 0) { q = ar.V[tb + root]; d = ar.D[tb + root]; }
+      const float w = q - d / static_cast<int32_t>(P);
+      const float l = static_cast<float>(1.0 - static_cast<double>(w) - static_cast<double>(d));
+      const double resign_val = 1.0 - static_cast<double>(ep.resign_percent);
+      int entry = -1;
+      if (w > resign_val) entry = static_cast<int>(cp);
+      else if (l > resign_val) entry = static_cast<int>((cp + 1) % 2);
+      else if (d > resign_val) entry = P;
+      if (entry >= 0) {
+        if (canonical01(coin) < ep.resign_playthrough) flags |= kFlagPlaythrough;
+        else resign_entry = entry;
+      }
+    }
+    // move choice, play_manager.cc:403-406
+    const float play_p = probs(temp, cnt_m, pol_m);
+    const uint64_t rng_before = rng.state;
+    const uint32_t chosen = pick_move(play_p);
+    trace(5 | (static_cast<uint64_t>(chosen) << 8));
+
+    if (ep.log_moves) {
+      uint32_t row = 0;
+      if (lane == 0) row = atomicAdd(&ar.ctl->log_rows, 1u);
+      row = bcast(row, 0);
+      if (row < ep.log_cap) {
+        if (lane == 0) {
+          uint32_t* r = ar.log_rows + static_cast<size_t>(row) * 8;
+          r[0] = slot; r[1] = ar.slot_games[slot]; r[2] = chosen; r[3] = gs.turn; r[4] = cp; r[5] = capped ? 1u : 0u;
+          r[6] = static_cast<uint32_t>(rng_before); r[7] = static_cast<uint32_t>(rng_before >> 32);
+        }
+        if (lane < static_cast<uint32_t>(M)) ar.log_counts[static_cast<size_t>(row) * M + lane] = cnt_m;
+      } else {
+        raise(4u);
+      }
+    }
+    // history sample, play_manager.cc:407-424
+    if (ep.history && !capped) {
+      const float target = (ep.pruning && ep.epsilon > 0)
+                               ? probs_pruned(1.0f, root_n, k, mv_l, n_l, q_l, p_l, cnt_m, pol_m)
+                               : probs(1.0f, cnt_m, pol_m);
+      const uint32_t r = ph_rows;
+      if (r < ep.max_hist_rows) {
+        float* crow = ar.ph_canon + (static_cast<size_t>(slot) * ep.max_hist_rows + r) * GM::CANON;
+        for (uint32_t e = lane; e < static_cast<uint32_t>(GM::CANON); e += G) crow[e] = GM::canonical_at(gs, e);
+        if (lane < static_cast<uint32_t>(M)) ar.ph_pi[(static_cast<size_t>(slot) * ep.max_hist_rows + r) * M + lane] = target;
+        if (lane == 0) {
+          uint32_t* pm = ar.ph_meta + (static_cast<size_t>(slot) * ep.max_hist_rows + r) * 2;
+          pm[0] = gs.player; pm[1] = gs.turn;
+        }
+        ph_rows = r + 1;
+      } else {
+        raise(2u);
+      }
+    }
+    // stats, play_manager.cc:425-435
+    {
+      const uint32_t dep = AZMI_SEL(t_depth, cp);
+      const float ald = dep == 0 ? 0.0f : static_cast<float>(AZMI_SEL(t_tld, cp)) / static_cast<float>(dep);
+      float ent = 0.0f;  // MCTS::normalized_root_entropy, mcts.cc:737-750
+      const float kf = static_cast<float>(k);
+      if (!(kf <= 1 || root_n <= 1)) {
+        const float log_k = az_logf(kf);
+        const float total_n = static_cast<float>(root_n);
+        float term_l = 0.0f;
+        if (lane < k && n_l > 0) { const float p = static_cast<float>(n_l) / total_n; term_l = p * az_logf(p); }
+        float e = 0.0f;
+        for (uint32_t i = 0; i < k; ++i) { const uint32_t ni = bcast(n_l, i); const float ti = bcast(term_l, i); if (ni > 0) e -= ti; }
+        ent = e / log_k;
+      }
+      if (lane == 0) {
+        const uint32_t S = ep.S;
+        if (!capped) { ar.g_dsum[0 * S + slot] += ald; ar.g_dsum[1 * S + slot] += ent; ar.g_cnt[1 * S + slot] += 1; }
+        else { ar.g_dsum[2 * S + slot] += ald; ar.g_dsum[3 * S + slot] += ent; ar.g_cnt[2 * S + slot] += 1; }
+        ar.g_dsum[4 * S + slot] += k;
+        ar.g_cnt[0 * S + slot] += 1;
+      }
+    }
+    // re-root every seat's tree in seat order, then play the move (play_manager.cc:436-439)
+    for (uint32_t s = 0; s < static_cast<uint32_t>(P); ++s)
+      { if (!update_root(s, chosen)) return true; trace(6); }
+    if (!GM::play(gs, chosen)) { raise(64u); return true; }
+    uint32_t term = GM::terminal(gs);
+    bool resigned = false;
+    if (term == 0 && resign_entry >= 0) { term = static_cast<uint32_t>(resign_entry) + 1; resigned = true; }
+    if (term != 0) {
+      end_game(term, resigned);
+      return true;
+    }
+    // play_manager.cc:522-555
+    draw_capped();
+    if (!ep.tree_reuse) {
+      for (uint32_t s = 0; s < static_cast<uint32_t>(P); ++s) reset_tree(s);
+    } else {
+      reapply_root_prior(gs.player, ep.epsilon > 0 && !(flags & kFlagCapped));
+    }
+    return false;
+  }
+
+  // ---- game end: flush history with the final scores, commit totals (play_manager.cc:446-505) -----------
+  __device__ void end_game(uint32_t term, bool resigned) {
+    const uint32_t S = ep.S;
+    sync_lanes();
+    const uint32_t rows = ep.history ? ph_rows : 0u;
+    if (rows > 0) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&ar.ctl->hist_rows, rows);
+      base = bcast(base, 0);
+      if (base + rows <= ep.hist_cap) {
+        const uint32_t game_idx = ar.slot_games[slot];
+        for (uint32_t r = 0; r < rows; ++r) {
+          const size_t src = static_cast<size_t>(slot) * ep.max_hist_rows + r;
+          const size_t dst = static_cast<size_t>(base) + r;
+          for (uint32_t e = lane; e < static_cast<uint32_t>(GM::CANON); e += G)
+            ar.h_canon[dst * GM::CANON + e] = ar.ph_canon[src * GM::CANON + e];
+          if (lane < static_cast<uint32_t>(M)) ar.h_pi[dst * M + lane] = ar.ph_pi[src * M + lane];
+          if (lane <= static_cast<uint32_t>(P)) ar.h_v[dst * (P + 1) + lane] = (lane == term - 1) ? 1.0f : 0.0f;
+          if (lane == 0) {
+            uint32_t* hm = ar.h_meta + dst * 4;
+            hm[0] = slot; hm[1] = game_idx; hm[2] = ar.ph_meta[src * 2 + 1]; hm[3] = ar.ph_meta[src * 2 + 0];
+          }
+        }
+      } else {
+        raise(2u);
+      }
+    }
+    ph_rows = 0;
+    if (lane == 0) {
+      ar.a_scores[static_cast<size_t>(slot) * (P + 1) + (term - 1)] += 1.0f;
+      if (resigned) ar.a_resign[static_cast<size_t>(slot) * (P + 1) + (term - 1)] += 1.0f;
+      ar.a_len[slot] += gs.turn;
+      for (int j = 0; j < 5; ++j) { ar.a_dsum[j * S + slot] += ar.g_dsum[j * S + slot]; ar.g_dsum[j * S + slot] = 0.0; }
+      for (int j = 0; j < 3; ++j) { ar.a_cnt[j * S + slot] += ar.g_cnt[j * S + slot]; ar.g_cnt[j * S + slot] = 0; }
+      ar.slot_games[slot] += 1;
+      const uint32_t pos = atomicAdd(&ar.ctl->ended_count, 1u);
+      ar.ended_list[pos] = slot;
+    }
+  }
+
+  // ---- leaf hand-off to the net: canonical planes + position key (play_manager.cc:589-598) ----------------
+  __device__ void emit_leaf(const typename GM::State& leaf) const {
+    float* row = ar.canon + static_cast<size_t>(slot) * GM::CANON;
+    for (uint32_t e = lane; e < static_cast<uint32_t>(GM::CANON); e += G) row[e] = GM::canonical_at(leaf, e);
+    if (lane == 0) { ar.leaf_key[slot] = GM::key(leaf); ar.c_evals[slot] += 1; }
+  }
+};
+
+// One round of PlayManager::play for every slot (play_manager.cc:272-599).
+template <class GM>
+__global__ __launch_bounds__(256) void k_round(EngineParams ep, EngineArrays ar) {
+  constexpr int G = GM::GROUP;
+  constexpr int P = GM::P;
+  const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t slot = gtid / G, lane = gtid % G;
+  if (slot >= ep.S) return;
+  if (ar.ctl->stop) return;
+  const uint8_t st = ar.sstate[slot];
+  if (st == kSlotDone || st == kSlotEnded) return;
+  SlotCtx<GM> c(ep, ar, slot, lane);
+  c.load();
+  uint32_t inline_sims = 0;
+  bool need_process = (st == kSlotWaitEval);
+  if (!need_process) {  // kSlotFresh / kSlotRestart
+    c.start_game();
+    c.draw_capped();
+  }
+  for (;;) {
+    if (need_process) {
+      const uint32_t cp = c.gs.player;
+      const bool noise = ep.epsilon > 0 && !(c.flags & kFlagCapped);
+      c.process_result(cp, (c.flags & kFlagLeafNeedsNet) != 0, noise);
+      const uint32_t goal = (c.flags & kFlagCapped) ? ep.cap_visits : ep.visits[cp];
+      if (AZMI_SEL(c.t_depth, cp) >= goal) {
+        if (c.make_move(cp)) { c.store(kSlotEnded); return; }
+      }
+    }
+    const uint32_t cp = c.gs.player;
+    typename GM::State leaf;
+    uint32_t term = 0;
+    if (!c.find_leaf(cp, leaf, term)) { c.store(kSlotDone); return; }
+    const bool needs_net = term == 0 && !ep.eval_random[cp];
+    c.flags = needs_net ? (c.flags | kFlagLeafNeedsNet) : (c.flags & ~kFlagLeafNeedsNet);
+    if (needs_net) { c.emit_leaf(leaf); break; }
+    need_process = true;
+    if (++inline_sims >= ep.max_inline) break;
+  }
+  c.store(kSlotWaitEval);
+}
+
+// Deterministic restart / retire of the slots whose game ended in the previous round:
+// slots are served in slot order against games_started (play_manager.cc:506-513).
+__global__ void k_assign(EngineParams ep, EngineArrays ar, uint32_t count_round) {
+  Control* ctl = ar.ctl;
+  __shared__ uint32_t s_n, s_base;
+  if (threadIdx.x == 0) { s_n = ctl->ended_count; s_base = ctl->games_started; }
+  __syncthreads();
+  const uint32_t n = s_n, base = s_base;
+  if (threadIdx.x == 0 && count_round) ctl->rounds += 1;
+  if (n == 0) return;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint32_t s = ar.ended_list[i];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < n; ++j) rank += (ar.ended_list[j] < s) ? 1u : 0u;
+    ar.sstate[s] = (base + rank < ep.games_to_play) ? kSlotRestart : kSlotDone;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t room = base < ep.games_to_play ? ep.games_to_play - base : 0u;
+    const uint32_t restarted = n < room ? n : room;
+    ctl->games_started = base + restarted;
+    ctl->games_completed += n;
+    ctl->live_slots -= (n - restarted);
+    ctl->ended_count = 0;
+    if (ctl->games_completed >= ep.games_to_play || ctl->live_slots == 0) ctl->stop = 1;
+  }
+}
+
+}  // namespace azmi

@@ -1,0 +1,121 @@
+// Plain-data views shared by the host side (engine.hip) and the kernels
+// (engine_kernels.h).  Everything the engine owns lives in HBM as
+// structure-of-arrays; these structs only carry the base pointers.
+#pragma once
+#include <stdint.h>
+
+namespace azmi {
+
+// slot life cycle
+enum SlotState : uint8_t {
+  kSlotFresh = 0,    // no game started yet (PlayManager ctor, play_manager.cc:214-230)
+  kSlotWaitEval = 1, // a leaf is pending: next round starts with process_result
+  kSlotEnded = 2,    // game finished this round; k_assign decides restart / retire
+  kSlotRestart = 3,  // start the next game at the beginning of the round
+  kSlotDone = 4      // retired (games_started >= games_to_play, play_manager.cc:507-509)
+};
+
+enum SlotFlags : uint8_t { kFlagCapped = 1, kFlagPlaythrough = 2, kFlagLeafNeedsNet = 4 };
+
+// node META word: [31:0] first child (tree-relative), [43:32] child count,
+// [55:44] move, [56] player to move at the node, [59:57] terminal code
+// (0 = not terminal, 1 + index of the winning entry of the one-hot score vector)
+__host__ __device__ inline uint64_t meta_pack(uint32_t ch0, uint32_t nch, uint32_t mv, uint32_t player, uint32_t term) {
+  return static_cast<uint64_t>(ch0) | (static_cast<uint64_t>(nch) << 32) | (static_cast<uint64_t>(mv) << 44) |
+         (static_cast<uint64_t>(player) << 56) | (static_cast<uint64_t>(term) << 57);
+}
+__host__ __device__ inline uint32_t meta_ch0(uint64_t m) { return static_cast<uint32_t>(m); }
+__host__ __device__ inline uint32_t meta_nch(uint64_t m) { return static_cast<uint32_t>(m >> 32) & 0xFFFu; }
+__host__ __device__ inline uint32_t meta_mv(uint64_t m) { return static_cast<uint32_t>(m >> 44) & 0xFFFu; }
+__host__ __device__ inline uint32_t meta_player(uint64_t m) { return static_cast<uint32_t>(m >> 56) & 1u; }
+__host__ __device__ inline uint32_t meta_term(uint64_t m) { return static_cast<uint32_t>(m >> 57) & 7u; }
+
+struct EngineParams {  // run constants (PlayParams, play_manager.h:60-154, after ctor normalisation)
+  uint32_t S;              // concurrent_games
+  uint32_t cap;            // nodes per tree arena
+  uint32_t games_to_play;
+  uint32_t visits[4];      // per seat (single seat permutation)
+  uint32_t cap_visits;     // playout_cap_depth
+  float cpuct, start_temp, final_temp, half_life;
+  float epsilon, root_temp, fpu_reduction;
+  float cap_percent, resign_percent, resign_playthrough;
+  uint32_t history, tree_reuse, cap_rand, root_fpu_zero, shaped, pruning;
+  uint32_t eval_random[4]; // seat uses EvalType::RANDOM (dumb_eval) instead of the net
+  uint32_t max_inline;
+  uint32_t hist_cap, log_cap, log_moves;
+  uint32_t max_hist_rows;  // pending history rows per slot (= max moves of one game)
+  uint32_t max_depth;      // path capacity per slot
+  uint32_t trace_slot;     // debug: slot whose RNG events are traced (0xFFFFFFFF = off)
+  uint32_t trace_cap;
+};
+
+struct Control {  // small device control block, copied back by azmi_pm_poll
+  uint32_t games_started;
+  uint32_t games_completed;
+  uint32_t stop;
+  uint32_t ended_count;
+  uint32_t hist_rows;
+  uint32_t log_rows;
+  uint32_t overflow;      // bit0 tree arena, bit1 history, bit2 move log, bit3 path
+  uint32_t live_slots;
+  uint64_t rounds;
+};
+
+struct EngineArrays {
+  Control* ctl;
+  uint32_t* ended_list;   // [S]
+  // ---- per slot -----------------------------------------------------------------
+  uint64_t* gs_words;     // [STATE_WORDS][S] game state, SoA
+  uint64_t* rng;          // [S] tree stream   (mcts.cc:19)
+  uint64_t* coin;         // [S] coin stream   (play_manager.cc:261-262)
+  uint8_t* sstate;        // [S]
+  uint8_t* flags;         // [S]
+  uint32_t* cur;          // [S] leaf node of the pending simulation (MCTS::current_)
+  uint32_t* plen;         // [S] MCTS::path_.size()
+  uint32_t* path;         // [S][max_depth]
+  uint32_t* slot_games;   // [S] games completed by the slot
+  // running totals of the slot's current game (GameData, play_manager.h:46-53)
+  double* g_dsum;         // [5][S]: leaf depth, entropy, fast leaf depth, fast entropy, valid moves
+  uint32_t* g_cnt;        // [3][S]: move_count, full_move_count, fast_move_count
+  // committed totals over the slot's finished games (play_manager.cc:463-497)
+  float* a_scores;        // [S][P+1]
+  float* a_resign;        // [S][P+1]
+  uint64_t* a_len;        // [S] sum of game lengths
+  double* a_dsum;         // [5][S]
+  uint64_t* a_cnt;        // [3][S]
+  uint64_t* c_sims;       // [S] simulations finished
+  uint64_t* c_evals;      // [S] leaves sent to the net
+  // pending history rows of the running game (GameData::partial_history)
+  uint32_t* ph_count;     // [S]
+  float* ph_canon;        // [S][max_hist_rows][CANON]
+  float* ph_pi;           // [S][max_hist_rows][M]
+  uint32_t* ph_meta;      // [S][max_hist_rows][2]: player, turn
+  // ---- per tree (slot * P + seat) -------------------------------------------------
+  uint32_t* root;         // MCTS::root_
+  uint32_t* bump;         // next free node of the arena
+  uint32_t* depth;        // MCTS::depth_
+  uint64_t* tld;          // MCTS::total_leaf_depth_
+  // ---- node arrays, [trees * cap] ---------------------------------------------------
+  uint32_t* N;            // Node::n
+  float* Q;               // Node::q
+  float* Pr;              // Node::policy
+  float* D;               // Node::d
+  float* V;               // Node::v
+  uint64_t* META;         // children range, move, player, terminal code
+  // ---- slot-indexed evaluation I/O ---------------------------------------------------
+  float* canon;           // [S][CANON]   leaf planes for the net
+  float* v;               // [S][P+1]     net value  (probabilities)
+  float* pi;              // [S][M]       net policy (probabilities)
+  uint64_t* leaf_key;     // [S]          position key of the pending leaf
+  // ---- finished samples (PlayHistory rows) ---------------------------------------------
+  float* h_canon;         // [hist_cap][CANON]
+  float* h_v;             // [hist_cap][P+1]
+  float* h_pi;            // [hist_cap][M]
+  uint32_t* h_meta;       // [hist_cap][4]: slot, game_in_slot, turn, player
+  // ---- move log (parity hook) -------------------------------------------------------------
+  uint32_t* log_rows;     // [log_cap][8]
+  uint32_t* log_counts;   // [log_cap][M]
+  uint64_t* trace;        // debug [trace_cap][2]: tag, rng state; trace[0] = event count
+};
+
+}  // namespace azmi

@@ -1,0 +1,168 @@
+/* azmi.h — C ABI of the MI355X-native self-play engine (libazmi.so).
+ *
+ * Drop-in boundary for the reference's PlayManager/MCTS hot path.  Every entry
+ * point below replaces one member of the reference's pybind11 surface
+ * (/root/reference/src/py_wrapper.cc) or of the C++ class behind it; the
+ * reference file:line each one stands in for is cited next to it.  Plain
+ * pointers and sizes only: no torch, pybind11 or HIP types cross this line
+ * (`stream` is a hipStream_t passed as void*; `dev_*` pointers are HIP device
+ * addresses, e.g. torch.Tensor.data_ptr()).
+ *
+ * All functions return 0 on success or a negative azmi_status; the message of
+ * the last error on the calling thread is available from azmi_last_error().
+ * The library has NO CPU fallback: without a HIP device azmi_pm_create fails
+ * with AZMI_ERR_NO_DEVICE.
+ */
+#ifndef AZMI_H_
+#define AZMI_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AZMI_ABI_VERSION 1
+
+typedef enum azmi_status {
+  AZMI_OK = 0,
+  AZMI_ERR_INVALID = -1,   /* bad argument (reference: std::runtime_error -> RuntimeError) */
+  AZMI_ERR_NO_DEVICE = -2, /* no HIP device / HIP runtime error */
+  AZMI_ERR_OOM = -3,
+  AZMI_ERR_OVERFLOW = -4,  /* a device-side arena / history ring ran out of room */
+  AZMI_ERR_STATE = -5
+} azmi_status;
+
+/* game ids (reference GAME_REGISTRY, config.py:17-35) */
+typedef enum azmi_game { AZMI_GAME_CONNECT4 = 0, AZMI_GAME_TAWLBWRDD = 1 } azmi_game;
+
+/* EvalType, play_manager.h:20 */
+typedef enum azmi_eval_type { AZMI_EVAL_NN = 0, AZMI_EVAL_RANDOM = 1, AZMI_EVAL_PLAYOUT = 2 } azmi_eval_type;
+
+#define AZMI_MAX_PLAYERS 4
+
+/* POD mirror of struct PlayParams (play_manager.h:60-154): same names, same
+ * meaning, same defaults (azmi_play_params_default).  Vectors become fixed
+ * arrays + a count. */
+typedef struct azmi_play_params {
+  uint32_t games_to_play;
+  uint32_t concurrent_games;
+  uint32_t max_batch_size;
+  uint32_t max_cache_size;
+  uint32_t cache_shards;
+  uint32_t num_mcts_visits;                 /* must equal num_players (play_manager.cc:20-22) */
+  uint32_t mcts_visits[AZMI_MAX_PLAYERS];
+  float cpuct;
+  float start_temp;
+  float final_temp;
+  float temp_decay_half_life;
+  int32_t history_enabled;
+  int32_t self_play;
+  int32_t tree_reuse;
+  float epsilon;
+  float mcts_root_temp;
+  int32_t playout_cap_randomization;
+  uint32_t playout_cap_depth;
+  float playout_cap_percent;
+  float fpu_reduction;
+  int32_t root_fpu_zero;
+  int32_t shaped_dirichlet;
+  int32_t policy_target_pruning;
+  float resign_percent;
+  float resign_playthrough_percent;
+  uint32_t num_eval_type;                   /* 0 = all NN */
+  int32_t eval_type[AZMI_MAX_PLAYERS];
+} azmi_play_params;
+
+/* engine-only knobs that have no reference counterpart */
+typedef struct azmi_engine_opts {
+  uint64_t seed;          /* slot s uses pcg32 stream slot_seed(seed, s) */
+  int32_t device;         /* HIP device ordinal */
+  uint32_t max_inline;    /* simulations a slot may finish inside one round without the net
+                             (terminal leaves, RANDOM eval, cache hits); 0 = default */
+  uint32_t history_capacity; /* rows of the device history buffer; 0 = sized from params */
+  int32_t log_moves;      /* keep a per-move log (parity tests) */
+  uint32_t move_log_capacity;
+} azmi_engine_opts;
+
+typedef struct azmi_pm azmi_pm;
+
+void azmi_play_params_default(azmi_play_params* p);      /* PlayParams{} defaults, play_manager.h:60-154 */
+void azmi_engine_opts_default(azmi_engine_opts* o);
+const char* azmi_last_error(void);
+int azmi_abi_version(void);
+int azmi_device_count(void);
+
+/* static game facts: GameState::num_moves/num_players + CANONICAL_SHAPE (py_wrapper.cc:157-189, 562-580) */
+int azmi_game_info(int game, uint32_t* num_players, uint32_t* num_moves, uint32_t chw[3]);
+
+/* PlayManager(gs, params) — py_wrapper.cc:352-354, play_manager.cc:12-256 */
+int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_opts* opts, azmi_pm** out);
+void azmi_pm_destroy(azmi_pm* pm);
+
+/* ---- device fast path (what PlayManager::play + GameRunner's batcher/result_worker do,
+ *      play_manager.cc:258-600 + game_runner.py:651-726, without leaving HBM) ---------------
+ * One round = every live slot: consume its (v, pi) row -> backup -> maybe play a move ->
+ * descend to the next leaf -> write that leaf's canonical planes into row `slot` of the
+ * leaf batch.  Rows are slot-indexed, so the batch shape is always
+ * [concurrent_games, C, H, W] and a round needs no host round-trip. */
+int azmi_pm_round(azmi_pm* pm, void* stream);
+/* device pointers of the slot-indexed buffers: canonical [S,C,H,W] (engine writes, net reads),
+ * v [S,P+1] and pi [S,M] (net writes probabilities, engine reads) — replaces
+ * build_batch / update_inferences, py_wrapper.cc:449-504 / play_manager.cc:619-642 */
+int azmi_pm_io_buffers(azmi_pm* pm, float** dev_canonical, float** dev_v, float** dev_pi);
+/* play() for EvalType::RANDOM on every seat: rounds until games_completed >= games_to_play */
+int azmi_pm_play(azmi_pm* pm, void* stream);
+/* copies the small control block back (sync on `stream`); mirrors remaining_games()/games_completed() */
+int azmi_pm_poll(azmi_pm* pm, void* stream, uint32_t* games_completed, uint32_t* live_slots);
+
+/* ---- results (all synchronise on the engine's stream first) -------------------------------- */
+int azmi_pm_scores(azmi_pm* pm, float* out /* [P+1] */);          /* scores(), play_manager.h:173 */
+int azmi_pm_resign_scores(azmi_pm* pm, float* out /* [P+1] */);   /* resign_scores(), :174 */
+/* out[7] = avg_game_length, avg_leaf_depth, avg_search_entropy, fast_avg_leaf_depth,
+ *          fast_avg_search_entropy, avg_moves_per_turn, avg_valid_moves (play_manager.h:288-315) */
+int azmi_pm_stats(azmi_pm* pm, float* out);
+/* out[6] = simulations, leaf evaluations requested from the net, cache hits, cache misses,
+ *          history rows available, rounds */
+int azmi_pm_counters(azmi_pm* pm, uint64_t* out);
+/* build_history_batch, py_wrapper.cc:393-424: copies up to `cap` finished rows to HOST arrays
+ * canonical [cap,C,H,W], v [cap,P+1], pi [cap,M]; returns rows written in *n */
+int azmi_pm_pop_history(azmi_pm* pm, float* canonical, float* v, float* pi, uint32_t cap, uint32_t* n);
+/* same rows, left in HBM: device pointers + row count (for the RCCL sample gather) */
+int azmi_pm_history_device(azmi_pm* pm, float** dev_canonical, float** dev_v, float** dev_pi,
+                           uint32_t** dev_meta, uint32_t* rows);
+/* per-move log (opts.log_moves): rows [n,8] = slot, game_in_slot, move, turn, player, capped,
+ * pcg32 state (lo, hi) of the slot's tree stream right before pick_move's draw;
+ * counts [n,M] = root counts() right before the move.  Parity-test hook. */
+int azmi_pm_move_log(azmi_pm* pm, uint32_t* rows, uint32_t* counts, uint32_t cap, uint32_t* n);
+/* games each slot has completed, [S] */
+int azmi_pm_slot_games(azmi_pm* pm, uint32_t* out);
+
+/* ---- host-buffer compatibility path (exact reference signatures) ---------------------------
+ * build_batch(group, batch) — py_wrapper.cc:449-504: runs rounds until a leaf batch is
+ * pending, copies the live rows to the HOST array batch[cap,C,H,W], returns their slot ids. */
+int azmi_pm_build_batch(azmi_pm* pm, float* batch, uint32_t cap, uint32_t* indices, uint32_t* n);
+/* update_inferences(group, indices, v, pi) — play_manager.cc:619-642, HOST arrays */
+int azmi_pm_update_inferences(azmi_pm* pm, const uint32_t* indices, uint32_t n, const float* v, const float* pi);
+
+/* ---- GameState / MCTS single-object surface on the device (py_wrapper.cc:157-220) ----------
+ * Batched over `n` independent states so one launch covers many objects. Used by the
+ * parity tests of the rules kernels (SURVEY tier T0). `moves` is [n, len] row-major; a
+ * negative entry stops that game early.  Outputs (any may be NULL):
+ *   valid [n,M] u8, scores [n,P+1] f32 (all -1 if not over), canonical [n,C,H,W] f32,
+ *   player [n] u32, turn [n] u32, key [n] u64, status [n] i32 (0 ok, -1 illegal move). */
+int azmi_game_replay(int game, int device, const int32_t* moves, uint32_t n, uint32_t len,
+                     uint8_t* valid, float* scores, float* canonical, uint32_t* player,
+                     uint32_t* turn, uint64_t* key, int32_t* status);
+
+/* The device RNG layer on its own (parity tier "RNG"): runs `thread_local pcg32 re` + the
+ * libstdc++ algorithm the reference applies to it (mcts.cc:19,100,430-440,718) on the GPU.
+ * kind 0: n raw pcg32 outputs (u32)      1: std::shuffle of iota(n), reps times (u32 [reps,n])
+ *      2: n uniform_real<float>(0,1)      3: n gamma_distribution<float>(param,1), one object
+ *      4: same, a fresh object per draw.  `out` is a HOST array of n (kind 1: reps*n) 4-byte items. */
+int azmi_rng_probe(int device, int kind, uint64_t seed, float param, uint32_t n, uint32_t reps, void* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AZMI_H_ */

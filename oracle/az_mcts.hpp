@@ -160,7 +160,7 @@ class Mcts {
       if (current_ == root_) {
         set_policy_normalized(current_, pi, cfg_.root_policy_temp != 1.0f,
                               1.0f / cfg_.root_policy_temp);
-        if (root_noise_enabled && !cfg_.gumbel_enabled) add_root_noise();
+        if (root_noise_enabled && !cfg_.gumbel_enabled) { tr(1); add_root_noise(); tr(2); }
       } else {
         set_policy_normalized(current_, pi, false, 1.0f);
       }
@@ -422,6 +422,8 @@ class Mcts {
     return pv;
   }
 
+  std::vector<std::pair<uint64_t, uint64_t>>* trace = nullptr;  // debug: (tag, rng state)
+  void tr(uint64_t tag) { if (trace) trace->push_back({tag, re_->state}); }
   uint32_t depth() const { return depth_; }
   float avg_leaf_depth() const {  // mcts.h:112-114
     return depth_ == 0 ? 0.0f : static_cast<float>(total_leaf_depth_) / static_cast<float>(depth_);

@@ -60,6 +60,12 @@ void orc_gamma(uint64_t seed, float alpha, float beta, uint32_t n, int fresh_eac
     else out[i] = dist(g);
   }
 }
+uint64_t orc_gamma_raw(uint64_t state, float alpha, uint32_t n, float* out) {
+  Pcg32 g; g.state = state;
+  Gamma dist(alpha, 1.0f);
+  for (uint32_t i = 0; i < n; ++i) out[i] = dist(g);
+  return g.state;
+}
 void orc_gumbel(uint64_t seed, uint32_t n, float* out) {
   Pcg32 g; g.seed(seed);
   for (uint32_t i = 0; i < n; ++i) out[i] = gumbel01(g);
@@ -208,9 +214,16 @@ void* orc_pm_new(int game_id, const OrcPlayParams* c, uint64_t seed, int per_slo
       for (uint32_t i = 0; i < P; ++i) p.eval_type.push_back(static_cast<EvalType>(c->eval_type[i]));
     auto* b = new PmBox();
     b->pm = std::make_unique<PlayManager>(std::move(base), p, seed, per_slot_rng != 0);
-    b->pm->record_moves = record_moves != 0;
+    b->pm->record_moves = (record_moves & 1) != 0;
+    b->pm->trace_on = (record_moves & 2) != 0;
     return b;
   } catch (...) { return nullptr; }
+}
+uint64_t orc_pm_trace(void* h, uint64_t* out, uint64_t cap) {
+  auto& t = static_cast<PmBox*>(h)->pm->trace;
+  uint64_t n = std::min<uint64_t>(cap, t.size());
+  for (uint64_t i = 0; i < n; ++i) { out[2 * i] = t[i].first; out[2 * i + 1] = t[i].second; }
+  return n;
 }
 void orc_pm_free(void* h) { delete static_cast<PmBox*>(h); }
 int orc_pm_run(void* h, orc_eval_fn fn, void* user) {
@@ -256,12 +269,14 @@ void orc_pm_history(void* h, float* canonical, float* v, float* pi) {
   }
 }
 uint64_t orc_pm_move_count(void* h) { return static_cast<PmBox*>(h)->pm->moves().size(); }
-// rows of 6 u32: slot, game_in_slot, move, turn, player, capped; counts[num_moves] per row
+// rows of 8 u32: slot, game_in_slot, move, turn, player, capped, rng state lo, hi;
+// counts[num_moves] per row
 void orc_pm_moves(void* h, uint32_t* rows, uint32_t* counts, uint32_t num_moves) {
   auto& mv = static_cast<PmBox*>(h)->pm->moves();
   for (size_t i = 0; i < mv.size(); ++i) {
-    rows[i * 6 + 0] = mv[i].slot; rows[i * 6 + 1] = mv[i].game_in_slot; rows[i * 6 + 2] = mv[i].move;
-    rows[i * 6 + 3] = mv[i].turn; rows[i * 6 + 4] = mv[i].player; rows[i * 6 + 5] = mv[i].capped;
+    rows[i * 8 + 0] = mv[i].slot; rows[i * 8 + 1] = mv[i].game_in_slot; rows[i * 8 + 2] = mv[i].move;
+    rows[i * 8 + 3] = mv[i].turn; rows[i * 8 + 4] = mv[i].player; rows[i * 8 + 5] = mv[i].capped;
+    rows[i * 8 + 6] = static_cast<uint32_t>(mv[i].rng_state); rows[i * 8 + 7] = static_cast<uint32_t>(mv[i].rng_state >> 32);
     if (counts) std::memcpy(counts + i * num_moves, mv[i].counts.data(), num_moves * sizeof(uint32_t));
   }
 }

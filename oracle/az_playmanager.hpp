@@ -71,6 +71,7 @@ struct MoveRecord {  // test hook: one entry per played move
   uint32_t slot, game_in_slot, move, turn;
   uint8_t player;
   bool capped;
+  uint64_t rng_state;            // tree stream position right before pick_move's draw
   std::vector<uint32_t> counts;  // root counts() right before the move
 };
 
@@ -165,6 +166,8 @@ class PlayManager {
   uint64_t cache_hits() const { return cache_ ? cache_->hits() : 0; }
   uint64_t cache_misses() const { return cache_ ? cache_->misses() : 0; }
   bool record_moves = false;
+  bool trace_on = false;
+  std::vector<std::pair<uint64_t, uint64_t>> trace;
 
  private:
   struct Pending {  // play_manager.h:28-31
@@ -199,7 +202,9 @@ class PlayManager {
     c.relative_values = base_->relative_values();
     c.root_fpu_zero = params_.root_fpu_zero;
     c.shaped_dirichlet = params_.shaped_dirichlet;
-    return Mcts(c, &tree_rng(slot));
+    Mcts m(c, &tree_rng(slot));
+    if (trace_on) m.trace = &trace;
+    return m;
   }
 
   EvalType eval_type_for(uint8_t player) const {
@@ -247,11 +252,14 @@ class PlayManager {
         }
         // move choice, play_manager.cc:403-406 (PUCT branch)
         const std::vector<float> pi_play = mcts.probs(temp);
+        const uint64_t rng_before = tree_rng(i).state;
         const uint32_t chosen_m = Mcts::pick_move(pi_play, tree_rng(i));
+        if (trace_on) trace.push_back({5 | (static_cast<uint64_t>(chosen_m) << 8), tree_rng(i).state});
         if (record_moves) {
           MoveRecord mr;
           mr.slot = i; mr.game_in_slot = game.games_played; mr.move = chosen_m;
           mr.turn = game.gs->current_turn(); mr.player = cp; mr.capped = game.capped;
+          mr.rng_state = rng_before;
           mr.counts = mcts.counts();
           moves_.push_back(std::move(mr));
         }
@@ -276,7 +284,7 @@ class PlayManager {
         }
         game.total_valid_moves += mcts.num_root_children();
         ++game.move_count;
-        for (auto& m : game.mcts) m.update_root(*game.gs, chosen_m);  // player order
+        for (auto& m : game.mcts) { m.update_root(*game.gs, chosen_m); if (trace_on) trace.push_back({6, tree_rng(i).state}); }  // player order
         game.gs->play_move(chosen_m);
         float sc[kMaxValue];
         bool over = game.gs->scores(sc);
@@ -339,7 +347,7 @@ class PlayManager {
           Mcts& next = game.mcts[next_cp];
           if (next.root_n() > 0) {
             next.apply_root_policy_temp();
-            if (params_.epsilon > 0 && !game.capped) next.add_root_noise();
+            if (params_.epsilon > 0 && !game.capped) { if (trace_on) trace.push_back({3 | (static_cast<uint64_t>(next.num_root_children()) << 8), tree_rng(i).state}); next.add_root_noise(); if (trace_on) trace.push_back({4, tree_rng(i).state}); }
           }
         }
       }

@@ -1,0 +1,51 @@
+"""CPU: the C-ABI library loads and exports every symbol include/azmi.h declares; without a GPU the
+compute entry points fail loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "azmi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(azmi_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    lib = C.CDLL(os.path.join(ROOT, "alphazero-pybind11_amd", "libazmi.so"))
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), n
+    from alphazero import _capi
+    assert set(names) <= set(_capi.SYMBOLS) | {"azmi_debug_trace"}
+    assert lib.azmi_abi_version() == 1
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import alphazero as az
+    pp = az.PlayParams()
+    pp.games_to_play, pp.concurrent_games, pp.mcts_visits = 1, 1, [10, 10]
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        az.PlayManager(az.Connect4GS(), pp)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        az.rng_probe("pcg32", 1, 4)
+
+
+def test_host_side_validation_matches_reference_messages():
+    import alphazero as az
+    pp = az.PlayParams()
+    assert pp.cpuct == 2.0 and pp.tree_reuse is True and pp.playout_cap_depth == 25  # play_manager.h:60-154
+    assert int(az.EvalType.NN) == 0 and int(az.EvalType.RANDOM) == 1 and int(az.EvalType.PLAYOUT) == 2
+    assert az.Connect4GS.NUM_PLAYERS() == 2 and az.Connect4GS.NUM_MOVES() == 7
+    assert az.Connect4GS.CANONICAL_SHAPE() == (4, 6, 7)
+    assert az.tracy_is_enabled() is False

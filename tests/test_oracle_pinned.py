@@ -1,0 +1,203 @@
+"""CPU: pins the oracle (oracle/) against the reference's known answers.
+
+Sources: tests/golden/known_answers.json (outputs of the reference itself recorded in SURVEY §8c and
+the known-answer assertions of the reference's own gtest files) and, when built, the real libstdc++ +
+reference pcg header (oracle/_ref/librngref.so).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KA = json.load(open(os.path.join(HERE, "golden", "known_answers.json")))
+
+
+def test_rng_known_answers(oracle):
+    assert oracle.pcg32_outputs(12345, 4).tolist() == KA["pcg32_seed_12345_first4"]
+    assert oracle.shuffle_iota(12345, 7)[0].tolist() == KA["shuffle_iota7_seed_12345"]
+    assert np.allclose(oracle.uniform01(12345, 2), KA["uniform_real_float_seed_12345_first2"], rtol=1e-7)
+    assert np.array_equal(oracle.uniform01(12345, 1), np.float32([1411482639 / 2 ** 32]))
+    assert np.allclose(oracle.gamma(12345, np.float32(10.83) / np.float32(7), 2), KA["gamma_10.83_over_7_seed_12345_first2"], rtol=1e-7)
+    assert np.allclose(oracle.gumbel(12345, 2), KA["extreme_value_seed_12345_first2"], rtol=1e-6)
+
+
+def test_rng_against_real_libstdcxx(oracle):
+    """Integer paths are bit-exact; gamma / gumbel differ from glibc's float libm by a few ulp in < 0.2 % / 2 % of draws."""
+    ref = oracle.ref_rng()
+    if ref is None:
+        pytest.skip("oracle/_ref/librngref.so not built (reference tree absent)")
+    assert np.array_equal(oracle.pcg32_outputs(7, 100000), oracle.pcg32_outputs(7, 100000, which=ref))
+    for n in (1, 2, 3, 4, 5, 6, 7, 8, 33, 112, 113, 250, 1000):
+        assert np.array_equal(oracle.shuffle_iota(99 + n, n, 100), oracle.shuffle_iota(99 + n, n, 100, which=ref)), n
+    assert np.array_equal(oracle.uniform01(5, 500000), oracle.uniform01(5, 500000, which=ref))
+    for alpha in (10.83 / 7, 10.83 / 2, 0.3, 0.77, 5.0):
+        for fresh in (False, True):
+            a = oracle.gamma(77, alpha, 100000, fresh)
+            b = oracle.gamma(77, alpha, 100000, fresh, which=ref)
+            assert (a != b).mean() < 2e-3, (alpha, fresh)
+            assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-30)) < 2e-6
+    a, b = oracle.gumbel(77, 100000), oracle.gumbel(77, 100000, which=ref)
+    assert (a != b).mean() < 0.03 and np.max(np.abs(a - b)) < 1e-5
+
+
+def test_node_uct_known_answers(oracle):
+    ka = KA["node_uct"]
+    for n, sqrt_n, fpu, want in ka["cases"]:
+        got = oracle.node_uct(0.0, ka["policy"], n, sqrt_n, ka["cpuct"], fpu)
+        assert np.float32(got) == pytest.approx(want, rel=4e-7)  # EXPECT_FLOAT_EQ = 4 ulp
+
+
+def test_node_best_child_known_answer(oracle):
+    """mcts_test.cc:14-38: priors [.1,1.2,.3,.4,.5,.6,.7], root.n = 1 -> best child is move 1."""
+    m = oracle.Mcts(2.0, 2, 7, seed=1)
+    g = oracle.Game(oracle.GAME_CONNECT4)
+    m.find_leaf(g)
+    # raw (un-normalised) priors are what update_policy sets; normalisation keeps the argmax
+    m.process_result([1 / 3, 1 / 3, 1 / 3], [0.1, 1.2, 0.3, 0.4, 0.5, 0.6, 0.7])
+    m.find_leaf(g)
+    m.process_result([1 / 3, 1 / 3, 1 / 3], [1 / 7] * 7)
+    assert int(np.argmax(m.counts())) == 1
+
+
+def test_mcts_known_answers(oracle):
+    ka = KA["mcts_connect4"]
+    g = oracle.Game(oracle.GAME_CONNECT4)
+    for mv in ka["moves"]:
+        g.play(mv)
+    m = oracle.Mcts(ka["cpuct"], 2, 7, seed=ka["seed"])
+    m.search_dumb(g, ka["sims"])
+    assert m.counts().tolist() == ka["counts"]
+    assert m.pick_move(m.probs(0.0)) == ka["pick_move_probs0"]
+    kb = KA["mcts_connect4_second_position"]
+    for seed in (1, 2, 3, 20240601):
+        g = oracle.Game(oracle.GAME_CONNECT4)
+        for mv in kb["moves"]:
+            g.play(mv)
+        m = oracle.Mcts(kb["cpuct"], 2, 7, seed=seed)
+        m.search_dumb(g, kb["sims"])
+        assert m.pick_move(m.probs(0.0)) == kb["pick_move_probs0"]
+
+
+def _pm(oracle, game, ka):
+    import types
+    pp = types.SimpleNamespace(
+        games_to_play=ka["games_to_play"], concurrent_games=ka["concurrent_games"], max_batch_size=1, max_cache_size=0,
+        cache_shards=1, mcts_visits=ka["mcts_visits"], cpuct=2.0, start_temp=1.0, final_temp=1.0, temp_decay_half_life=0.0,
+        history_enabled=True, tree_reuse=True, epsilon=0.0, mcts_root_temp=1.0, playout_cap_randomization=False,
+        playout_cap_depth=25, playout_cap_percent=0.75, fpu_reduction=0.0, root_fpu_zero=False, shaped_dirichlet=False,
+        policy_target_pruning=False, resign_percent=0.0, resign_playthrough_percent=0.0, eval_type=[1, 1])
+    pm = oracle.PlayManager(game, pp, ka["seed"], per_slot_rng=False)
+    pm.run()
+    return pm
+
+
+def test_playmanager_known_answers(oracle):
+    ka = KA["playmanager_connect4"]
+    pm = _pm(oracle, oracle.GAME_CONNECT4, ka)
+    assert pm.scores().tolist() == ka["scores"]
+    st = pm.stats()
+    assert st[0] == ka["avg_game_length"]
+    assert st[1] == pytest.approx(ka["avg_leaf_depth"], abs=5e-6)
+    assert pm.counters()["hist_rows"] == ka["hist_count"]
+    kt = KA["playmanager_tawlbwrdd"]
+    pm = _pm(oracle, oracle.GAME_TAWLBWRDD, kt)
+    assert pm.scores().tolist() == kt["scores"]
+    st = pm.stats()
+    assert st[0] == kt["game_length"]
+    assert st[1] == pytest.approx(kt["avg_leaf_depth"], abs=5e-7)
+
+
+# ---- connect4_gs_test.cc, re-expressed -------------------------------------------------------------
+def _board(cells):
+    b = np.zeros((2, 6, 7), np.int8)
+    for p, h, w in cells:
+        b[p, h, w] = 1
+    return b
+
+
+def test_connect4_valid_moves(oracle):  # connect4_gs_test.cc:54-72
+    g = oracle.Game(oracle.GAME_CONNECT4)
+    assert g.valid().tolist() == [1] * 7
+    g = oracle.Game.connect4_from_board(_board([(0, 0, 3), (1, 0, 5)]), 0, 0)
+    assert g.valid().tolist() == [1, 1, 1, 0, 1, 0, 1]
+
+
+def test_connect4_play_move_stacks(oracle):  # connect4_gs_test.cc:75-101
+    g = oracle.Game(oracle.GAME_CONNECT4)
+    for i in range(6):
+        g.play(3)
+        c = g.canonical()
+        assert c[i % 2, 5 - i, 3] == 1 and g.turn() == i + 1 and g.player() == (i + 1) % 2
+    with pytest.raises(RuntimeError, match="Invalid move: You have a bug in your code."):
+        g.play(3)
+
+
+def test_connect4_win_states(oracle):  # connect4_gs_test.cc:104-171
+    F = oracle.Game.connect4_from_board
+    assert oracle.Game(oracle.GAME_CONNECT4).scores() is None
+    row = [(0, 3, 0), (0, 3, 1), (0, 3, 2), (0, 3, 3)]
+    assert F(_board(row), 0, 0).scores().tolist() == [1, 0, 0]
+    assert F(_board(row[:2] + row[3:]), 0, 0).scores() is None
+    col = [(1, 1, 2), (1, 2, 2), (1, 3, 2), (1, 4, 2)]
+    base = row[:2] + row[3:]
+    assert F(_board(base + col), 0, 0).scores().tolist() == [0, 1, 0]
+    assert F(_board(base + [c for c in col if c != (1, 2, 2)]), 0, 0).scores() is None
+    d1 = [(0, 1, 1), (0, 2, 2), (0, 3, 3), (0, 4, 4)]
+    assert F(_board(d1), 0, 0).scores().tolist() == [1, 0, 0]
+    assert F(_board([c for c in d1 if c != (0, 2, 2)]), 0, 0).scores() is None
+    d2 = [(1, 1, 3), (1, 2, 2), (1, 3, 1), (1, 4, 0)]
+    assert F(_board(d2), 0, 0).scores().tolist() == [0, 1, 0]
+    assert F(_board([c for c in d2 if c != (1, 2, 2)]), 0, 0).scores() is None
+    full_top = [(w % 2, 0, w) for w in range(7)]
+    assert F(_board(full_top), 0, 0).scores().tolist() == [0, 0, 1]
+
+
+def test_connect4_canonical(oracle):  # connect4_gs_test.cc:174-225
+    g = oracle.Game(oracle.GAME_CONNECT4)
+    want = np.zeros((4, 6, 7), np.float32); want[2] = 1
+    assert np.array_equal(g.canonical(), want)
+    g.play(0)
+    want = np.zeros((4, 6, 7), np.float32); want[0, 5, 0] = 1; want[3] = 1
+    assert np.array_equal(g.canonical(), want)
+    g.play(0)
+    want = np.zeros((4, 6, 7), np.float32); want[0, 5, 0] = 1; want[1, 4, 0] = 1; want[2] = 1
+    assert np.array_equal(g.canonical(), want)
+
+
+def test_tawlbwrdd_threefold_repetition(oracle):
+    """tawlbwrdd_gs_test.cc:9-53: shuffling a piece back and forth -> third repetition ends the game,
+    the side to move is credited (tawlbwrdd_gs.cc:350-364)."""
+    g = oracle.Game(oracle.GAME_TAWLBWRDD)
+    W = 11
+
+    def mv(fh, fw, th, tw):
+        base = (fh * W + fw) * 22
+        return base + (W + th if fw == tw else tw)
+
+    seq = [mv(0, 4, 0, 3), mv(2, 5, 2, 4), mv(0, 3, 0, 4), mv(2, 4, 2, 5)]
+    for rep in range(2):
+        for m in seq:
+            assert g.scores() is None
+            g.play(m)
+    assert g.scores() is not None and g.scores().tolist() == [1, 0, 0]
+
+
+def test_s3fifo_reference_behaviour(oracle):
+    """s3fifo_cache_test.cc: promotion S->M on re-reference, ghost re-admission to Main, 2-bit freq cap."""
+    c = oracle.Cache(4, 1, 4, 2, 1)
+    for k in range(1, 5):
+        c.insert(k, [k, k], [k])
+    assert c.find(1) is not None        # freq(1) = 1
+    c.insert(5, [5, 5], [5])            # evicts from Small: 1 is promoted to Main, 2 is evicted -> ghost
+    assert c.find(2) is None and c.find(1) is not None and c.stats()["evictions"] == 1
+    assert c.stats()["reinserts"] == 1  # the miss on 2 hit the ghost list
+    c.insert(2, [2, 2], [2])            # ghost hit -> admitted to Main
+    assert c.find(2)[0].tolist() == [2, 2]
+    z = oracle.Cache(0, 1, 0, 2, 1)     # capacity 0: inserts are ignored
+    z.insert(1, [1, 1], [1])
+    assert z.find(1) is None and z.stats()["size"] == 0
+    for _ in range(10):
+        c.find(1)
+    assert c.stats()["hits"] >= 10
