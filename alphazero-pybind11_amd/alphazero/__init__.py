@@ -18,6 +18,13 @@ import numpy as np
 from . import _capi
 from ._capi import lib, check
 
+
+def __getattr__(name):  # torch-dependent pieces are imported on first use
+    if name == "HipLeafNet":
+        from .hip_net import HipLeafNet
+        return HipLeafNet
+    raise AttributeError(name)
+
 __all__ = [
     "EvalType", "PlayParams", "PlayManager", "GameState", "Connect4GS",
     "tracy_is_enabled", "tracy_frame_mark",
@@ -325,6 +332,23 @@ class PlayManager:
         return (device_tensor(c, (S,) + tuple(self._chw), torch.float32, dev),
                 device_tensor(v, (S, self._P + 1), torch.float32, dev),
                 device_tensor(p, (S, self._M), torch.float32, dev))
+
+    def history_device_tensors(self, dev=None):
+        """Finished samples left in HBM as torch views: canonical [n,C,H,W], v [n,P+1], pi [n,M], meta [n,4] u32."""
+        import torch
+        from ._torch_view import device_tensor
+        c, v, p, m = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        rows = C.c_uint32()
+        check(lib.azmi_pm_history_device(self._h, C.byref(c), C.byref(v), C.byref(p), C.byref(m), C.byref(rows)))
+        n = rows.value
+        dev = dev or torch.device("cuda", torch.cuda.current_device())
+        if n == 0:
+            z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+            return z(0, *self._chw), z(0, self._P + 1), z(0, self._M), torch.zeros((0, 4), dtype=torch.int32, device=dev)
+        return (device_tensor(c.value, (n,) + tuple(self._chw), torch.float32, dev),
+                device_tensor(v.value, (n, self._P + 1), torch.float32, dev),
+                device_tensor(p.value, (n, self._M), torch.float32, dev),
+                device_tensor(m.value, (n, 4), torch.int32, dev))
 
     def move_log(self):
         cap = (int(self._params.games_to_play) + self._S) * 512

@@ -81,6 +81,11 @@ SYMBOLS = {
     "azmi_pm_slot_games": (C.c_int, [_VP, _VP]),
     "azmi_pm_build_batch": (C.c_int, [_VP, _VP, C.c_uint32, _VP, _PP(C.c_uint32)]),
     "azmi_pm_update_inferences": (C.c_int, [_VP, _VP, C.c_uint32, _VP, _VP]),
+    "azmi_net_blob_bytes": (C.c_size_t, None),
+    "azmi_net_create": (C.c_int, None),
+    "azmi_net_destroy": (None, None),
+    "azmi_net_forward": (C.c_int, None),
+    "azmi_net_last_error": (C.c_char_p, None),
     "azmi_rng_probe": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_float, C.c_uint32, C.c_uint32, _VP]),
     "azmi_game_replay": (C.c_int, [C.c_int, C.c_int, _VP, C.c_uint32, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
 }
@@ -96,7 +101,8 @@ def load():
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
         fn.restype = res
-        fn.argtypes = args
+        if args is not None:
+            fn.argtypes = args
     return lib
 
 

@@ -1,0 +1,128 @@
+"""Host side of the fused MFMA leaf net (csrc/leafnet.hip): BatchNorm folding, bf16 conversion and
+the MFMA-fragment weight layout, plus the ctypes wrapper `HipLeafNet`.
+
+Weight blob layout (little-endian, in this order; `frag` = [k-step][m-tile][lane 0..63][8 bf16] where
+element j of lane l is  W[co = 16*mt + (l & 15)][k = 32*ks + 8*(l >> 4) + j]):
+  stem    frag[2][4]   W[co][k = tap*C_in + ci] (k >= 9*C_in zero)      + bias[64] f32   (bn1 folded)
+  block i a1[64] b1[64] c1[64] f32 | conv1 frag[18][4] (bn2 folded, k = tap*64 + ci) | conv2 frag[18][4]
+  heads   frag[2][4]   rows 0-31 = v_conv * v_bn, rows 32-63 = pi_conv * pi_bn + bias[64] f32
+  v_fc1 W[hidden][32] b[hidden] | v_fc2 W[P+1][hidden] b[P+1] | pi_fc1 W[M][32*H*W] b[M]   (all f32)
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import lib
+from .torch_net import bn_affine
+
+
+class NetDescC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("in_channels", "height", "width", "channels", "depth", "kernel_size",
+                                         "head_channels", "v_hidden", "num_moves", "num_players")]
+
+
+lib.azmi_net_blob_bytes.restype = C.c_size_t
+lib.azmi_net_blob_bytes.argtypes = [C.POINTER(NetDescC)]
+lib.azmi_net_create.restype = C.c_int
+lib.azmi_net_create.argtypes = [C.POINTER(NetDescC), C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
+lib.azmi_net_destroy.restype = None
+lib.azmi_net_destroy.argtypes = [C.c_void_p]
+lib.azmi_net_forward.restype = C.c_int
+lib.azmi_net_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+lib.azmi_net_last_error.restype = C.c_char_p
+
+
+def _bf16_bits(x):
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32).to(torch.bfloat16).view(torch.int16).numpy()
+
+
+def _frags(wmat):
+    """wmat [64][K] float -> bf16 fragments [K/32][4][64][8] as bytes."""
+    co, K = wmat.shape
+    assert co == 64 and K % 32 == 0
+    lanes = np.arange(64)
+    out = np.zeros((K // 32, 4, 64, 8), np.int16)
+    bits = _bf16_bits(wmat)
+    for ks in range(K // 32):
+        for mt in range(4):
+            rows = 16 * mt + (lanes & 15)
+            cols = 32 * ks + 8 * (lanes >> 4)
+            out[ks, mt] = np.stack([bits[rows, cols + j] for j in range(8)], axis=1)
+    return out.tobytes()
+
+
+def _f32(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float64).astype(np.float32)).tobytes()
+
+
+def fold(net):
+    """LeafNet (reference NNArch parameter names) -> (NetDescC, blob bytes)."""
+    spec = net.spec
+    Cin, H, W = spec.in_shape
+    assert spec.num_channels == 64 and spec.head_channels == 32 and spec.kernel_size == 3
+    assert spec.policy_shape is None and spec.head_pool and spec.v_head_convs == 0 and spec.pi_head_convs == 0
+    assert spec.v_fc_layers == 1 and 9 * Cin <= 64
+    sd = {k: v.detach().double().cpu() for k, v in net.state_dict().items()}
+    blob = bytearray()
+    # stem: conv1 * bn1
+    a, b = bn_affine(net.bn1)
+    a, b = a.cpu(), b.cpu()
+    w = sd["conv1.weight"] * a[:, None, None, None]                  # [64][Cin][3][3]
+    wm = np.zeros((64, 64))
+    wm[:, : 9 * Cin] = w.permute(0, 2, 3, 1).reshape(64, 9 * Cin).numpy()  # k = tap*Cin + ci
+    blob += _frags(wm) + _f32(b)
+    for i, blk in enumerate(net.conv_layers):
+        a1, b1 = (t.cpu() for t in bn_affine(blk.bn1))
+        a2, b2 = (t.cpu() for t in bn_affine(blk.bn2))
+        w1 = sd[f"conv_layers.{i}.conv1.weight"] * a2[:, None, None, None]
+        w2 = sd[f"conv_layers.{i}.conv2.weight"]
+        blob += _f32(a1) + _f32(b1) + _f32(b2)
+        blob += _frags(w1.permute(0, 2, 3, 1).reshape(64, 576).numpy())   # k = tap*64 + ci
+        blob += _frags(w2.permute(0, 2, 3, 1).reshape(64, 576).numpy())
+    av, bv = (t.cpu() for t in bn_affine(net.v_bn))
+    ap, bp = (t.cpu() for t in bn_affine(net.pi_bn))
+    wh = torch.cat([sd["v_conv.weight"][:, :, 0, 0] * av[:, None], sd["pi_conv.weight"][:, :, 0, 0] * ap[:, None]], 0)
+    blob += _frags(wh.numpy()) + _f32(torch.cat([bv, bp]))
+    blob += _f32(sd["v_fc1.weight"]) + _f32(sd["v_fc1.bias"])
+    blob += _f32(sd["v_fc2.weight"]) + _f32(sd["v_fc2.bias"])
+    blob += _f32(sd["pi_fc1.weight"]) + _f32(sd["pi_fc1.bias"])
+    desc = NetDescC(Cin, H, W, 64, spec.depth, 3, 32, spec.v_fc_hidden, spec.num_moves, spec.num_players)
+    assert len(blob) == lib.azmi_net_blob_bytes(C.byref(desc)), (len(blob), lib.azmi_net_blob_bytes(C.byref(desc)))
+    return desc, bytes(blob)
+
+
+class HipLeafNet:
+    """The fused MFMA kernel as an evaluator: forward(canonical, v_out, pi_out) on device tensors."""
+
+    def __init__(self, net, spec=None, max_batch=None, device=0):
+        self.desc, blob = fold(net)
+        self._blob = blob
+        h = C.c_void_p()
+        rc = lib.azmi_net_create(C.byref(self.desc), blob, len(blob), int(device), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(lib.azmi_net_last_error().decode())
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.azmi_net_destroy(self._h)
+            self._h = None
+
+    def forward(self, canonical, v_out, pi_out, stream=None):
+        n = canonical.shape[0]
+        assert canonical.dtype == torch.float32 and canonical.is_contiguous() and v_out.is_contiguous() and pi_out.is_contiguous()
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        rc = lib.azmi_net_forward(self._h, canonical.data_ptr(), v_out.data_ptr(), pi_out.data_ptr(), n, C.c_void_p(stream))
+        if rc != 0:
+            raise RuntimeError(lib.azmi_net_last_error().decode())
+
+    def process(self, canonical):
+        """NNWrapper.process signature: returns (v, pi) probabilities as new float32 tensors."""
+        n = canonical.shape[0]
+        v = torch.empty((n, self.desc.num_players + 1), dtype=torch.float32, device=canonical.device)
+        pi = torch.empty((n, self.desc.num_moves), dtype=torch.float32, device=canonical.device)
+        self.forward(canonical.contiguous().float(), v, pi)
+        return v, pi

@@ -16,6 +16,7 @@
 #ifndef AZMI_H_
 #define AZMI_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -154,6 +155,25 @@ int azmi_pm_update_inferences(azmi_pm* pm, const uint32_t* indices, uint32_t n, 
 int azmi_game_replay(int game, int device, const int32_t* moves, uint32_t n, uint32_t len,
                      uint8_t* valid, float* scores, float* canonical, uint32_t* player,
                      uint32_t* turn, uint64_t* key, int32_t* status);
+
+/* ---- leaf policy/value network (the reference's NNArch forward + NNWrapper.process,
+ *      neural_net.py:448-510, 800-823) as one fused MFMA kernel ---------------------------------
+ * `blob` is the BatchNorm-folded, MFMA-fragment-ordered weight image produced by
+ * alphazero/hip_net.py::fold() (layout documented there and in DESIGN.md); it is copied to HBM.
+ * forward(): canonical [batch,C,H,W] f32 -> v [batch,P+1], pi [batch,M] f32 probabilities, all
+ * device pointers, asynchronous on `stream`. */
+typedef struct azmi_net_desc {
+  int32_t in_channels, height, width;   /* CANONICAL_SHAPE */
+  int32_t channels, depth, kernel_size; /* NNArgs.num_channels / depth / kernel_size */
+  int32_t head_channels, v_hidden;      /* NNArgs.head_channels / v_fc_hidden */
+  int32_t num_moves, num_players;
+} azmi_net_desc;
+typedef struct azmi_net azmi_net;
+size_t azmi_net_blob_bytes(const azmi_net_desc* desc);
+int azmi_net_create(const azmi_net_desc* desc, const void* blob, size_t blob_bytes, int device, azmi_net** out);
+void azmi_net_destroy(azmi_net* net);
+int azmi_net_forward(azmi_net* net, const float* dev_canonical, float* dev_v, float* dev_pi, uint32_t batch, void* stream);
+const char* azmi_net_last_error(void);
 
 /* The device RNG layer on its own (parity tier "RNG"): runs `thread_local pcg32 re` + the
  * libstdc++ algorithm the reference applies to it (mcts.cc:19,100,430-440,718) on the GPU.

@@ -1,0 +1,88 @@
+"""Generates tests/golden/nn_connect4_6b64c.npz by importing the REFERENCE's own neural_net.py
+(/root/reference/src/neural_net.py) in this container.  The reference cannot travel to the GPU box,
+so only data is committed: the random-init state_dict (torch.manual_seed(0), BatchNorm statistics
+randomised so folding is exercised), 64 canonical Connect4 inputs and the reference's outputs
+(NNArch in eval mode, fp32, CPU; probabilities = exp(log_softmax) as NNWrapper.process returns).
+
+`alphazero` and `zstandard` are absent from this image; neural_net.py imports them at module level
+only for Tracy hooks / checkpoint compression, so they are stubbed in sys.modules for the import.
+Run:  python tests/golden/make_nn_fixture.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/src"
+
+stub = types.ModuleType("alphazero")
+stub.tracy_is_enabled = lambda: False
+stub._tracy_zone_begin = lambda *a: None
+stub._tracy_zone_end = lambda: None
+stub.tracy_frame_mark = lambda: None
+stub._tracy_set_thread_name = lambda n: None
+sys.modules["alphazero"] = stub
+sys.modules["zstandard"] = types.ModuleType("zstandard")
+sys.path.insert(0, REF)
+import neural_net as ref_nn  # noqa: E402
+
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_api as orc  # noqa: E402  (only to produce realistic canonical inputs)
+
+
+class C4:  # the static surface NNArch reads from a game class
+    @staticmethod
+    def CANONICAL_SHAPE(): return (4, 6, 7)
+    @staticmethod
+    def NUM_PLAYERS(): return 2
+    @staticmethod
+    def NUM_MOVES(): return 7
+
+
+def main():
+    args = ref_nn.NNArgs(num_channels=64, depth=6, kernel_size=3, dense_net=False, head_channels=32)
+    torch.manual_seed(0)
+    net = ref_nn.NNArch(C4, args)
+    g = torch.Generator().manual_seed(1)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.2)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) * 1.0 + 0.5)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) * 0.8 + 0.6)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    net.eval()
+    rng = np.random.default_rng(3)
+    xs = []
+    while len(xs) < 64:
+        game = orc.Game(orc.GAME_CONNECT4)
+        for _ in range(int(rng.integers(0, 30))):
+            if game.scores() is not None:
+                break
+            game.play(int(rng.choice(np.flatnonzero(game.valid()))))
+        xs.append(game.canonical())
+    x = torch.from_numpy(np.stack(xs))
+    with torch.no_grad():
+        v, pi = net(x)
+        v, pi = torch.exp(v), torch.exp(pi)
+    out = {"input": x.numpy(), "v": v.numpy(), "pi": pi.numpy()}
+    for k, t in net.state_dict().items():
+        out["sd." + k] = t.numpy()
+    path = os.path.join(HERE, "nn_connect4_6b64c.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes;", sum(p.numel() for p in net.parameters()), "params")
+    # the package's own LeafNet must accept this state_dict and reproduce the reference bit for bit
+    sys.modules.pop("alphazero")
+    sys.path.insert(0, os.path.join(ROOT, "alphazero-pybind11_amd"))
+    from alphazero import torch_net
+    mine = torch_net.LeafNet(torch_net.connect4_spec())
+    mine.load_state_dict(net.state_dict())
+    v2, pi2 = mine.process(x)
+    print("LeafNet vs reference NNArch: max |dv| =", float((v2 - v).abs().max()), " max |dpi| =", float((pi2 - pi).abs().max()))
+
+
+if __name__ == "__main__":
+    main()
