@@ -183,6 +183,9 @@ class Connect4GS(GameState):  # py_wrapper.cc:562-580
         return 2
 
 
+_ENGINE_STREAM = C.c_void_p(-1)  # AZMI_STREAM_ENGINE
+
+
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
@@ -216,6 +219,7 @@ class PlayManager:
         self._h = h
         self._P, self._M, self._chw = self._game._info()
         self._S = int(params.concurrent_games)
+        self._last_stream = _ENGINE_STREAM
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -229,16 +233,16 @@ class PlayManager:
 
     def play(self):
         """PlayManager::play (play_manager.cc:258-600) for RANDOM-eval seats: runs to completion."""
-        check(lib.azmi_pm_play(self._h, None))
+        check(lib.azmi_pm_play(self._h, _ENGINE_STREAM))
 
     def games_completed(self):
         done, live = C.c_uint32(), C.c_uint32()
-        check(lib.azmi_pm_poll(self._h, None, C.byref(done), C.byref(live)))
+        check(lib.azmi_pm_poll(self._h, self._stream_arg(None), C.byref(done), C.byref(live)))
         return done.value
 
     def remaining_games(self):
         done, live = C.c_uint32(), C.c_uint32()
-        check(lib.azmi_pm_poll(self._h, None, C.byref(done), C.byref(live)))
+        check(lib.azmi_pm_poll(self._h, self._stream_arg(None), C.byref(done), C.byref(live)))
         if live.value == 0:
             return 0
         return max(0, int(self._params.games_to_play) - done.value)
@@ -308,13 +312,21 @@ class PlayManager:
         return n.value
 
     # ---- device fast path ------------------------------------------------------------------
+    def _stream_arg(self, stream):
+        """None -> the stream of the previous call (initially the engine's own); an int (0 included, the HIP
+        null stream) -> that hipStream_t."""
+        if stream is None:
+            return self._last_stream
+        self._last_stream = C.c_void_p(int(stream))
+        return self._last_stream
+
     def round(self, stream=None):
         """One engine round on `stream` (a hipStream_t as int, e.g. torch.cuda.current_stream().cuda_stream)."""
-        check(lib.azmi_pm_round(self._h, C.c_void_p(stream) if stream else None))
+        check(lib.azmi_pm_round(self._h, self._stream_arg(stream)))
 
     def poll(self, stream=None):
         done, live = C.c_uint32(), C.c_uint32()
-        check(lib.azmi_pm_poll(self._h, C.c_void_p(stream) if stream else None, C.byref(done), C.byref(live)))
+        check(lib.azmi_pm_poll(self._h, self._stream_arg(stream), C.byref(done), C.byref(live)))
         return done.value, live.value
 
     def io_pointers(self):

@@ -52,7 +52,8 @@ struct Connect4 {
     const int cnt = __builtin_popcountll((s.bb[0] | s.bb[1]) & col);
     if (cnt >= H) return false;
     const int h = H - 1 - cnt;
-    s.bb[s.player] |= 1ULL << (h * W + mv);
+    const uint64_t bit = 1ULL << (h * W + mv);
+    if (s.player == 0) s.bb[0] |= bit; else s.bb[1] |= bit;  // no runtime index: keeps State in registers
     s.player = (s.player + 1) & 1;
     ++s.turn;
     return true;
@@ -91,7 +92,7 @@ struct Connect4 {
   // connect4_gs.cc:131-149 — element e of the [4,6,7] canonical tensor
   __host__ __device__ static float canonical_at(const State& s, uint32_t e) {
     const uint32_t plane = e / (H * W), cell = e % (H * W);
-    if (plane < 2) return static_cast<float>((s.bb[plane] >> cell) & 1ULL);
+    if (plane < 2) return static_cast<float>(((plane == 0 ? s.bb[0] : s.bb[1]) >> cell) & 1ULL);
     return (plane - 2 == s.player) ? 1.0f : 0.0f;
   }
 };

@@ -76,7 +76,7 @@ struct Normal01 {
   // encoded as a NaN in the float itself rather than a separate bool: a bool member became an
   // i1 lane mask that hipcc (ROCm 7.2) mis-tracked across divergent groups of one wavefront.
   float saved = __builtin_nanf("");
-  __device__ float draw(Pcg32& g) {
+  __device__ __forceinline__ float draw(Pcg32& g) {
     const float cached = saved;
     if (cached == cached) {
       saved = __builtin_nanf("");
@@ -97,12 +97,12 @@ struct Normal01 {
 struct Gamma {
   float alpha, malpha, a2;
   Normal01 nd;
-  __device__ explicit Gamma(float a) : alpha(a) {
+  __device__ __forceinline__ explicit Gamma(float a) : alpha(a) {
     malpha = alpha < 1.0f ? alpha + 1.0f : alpha;
     const float a1 = malpha - 1.0f / 3.0f;
     a2 = 1.0f / sqrtf(9.0f * a1);
   }
-  __device__ float draw(Pcg32& g) {  // beta == 1
+  __device__ __forceinline__ float draw(Pcg32& g) {  // beta == 1
     float u, v, n;
     const float a1 = malpha - 1.0f / 3.0f;
     for (;;) {

@@ -63,7 +63,9 @@ struct azmi_pm {
   EngineArrays ar{};
   std::vector<void*> allocs;
   size_t bytes = 0;
-  hipStream_t stream = nullptr;  // engine-owned stream for result queries
+  hipStream_t stream = nullptr;  // engine-owned stream (AZMI_STREAM_ENGINE)
+  hipStream_t last = nullptr;    // stream of the most recent round: result queries order themselves behind it
+  hipStream_t pick(void* s) { last = (s == AZMI_STREAM_ENGINE) ? stream : static_cast<hipStream_t>(s); return last; }
   uint32_t hist_read = 0;
   // host-buffer compatibility path
   std::deque<uint32_t> pending;        // slots whose leaf waits for the net
@@ -340,6 +342,7 @@ int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_o
   A(trace, 2 * static_cast<size_t>(ep.trace_cap), true);
 #undef A
   if (rc != AZMI_OK) { delete pm; return rc; }
+  if (hipDeviceSynchronize() != hipSuccess) { delete pm; return fail(AZMI_ERR_NO_DEVICE, "device sync failed"); }
   if (hipStreamCreateWithFlags(&pm->stream, hipStreamNonBlocking) != hipSuccess) {
     delete pm;
     return fail(AZMI_ERR_NO_DEVICE, "hipStreamCreate failed");
@@ -352,6 +355,7 @@ int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_o
   if (hipStreamSynchronize(pm->stream) != hipSuccess) { delete pm; return fail(AZMI_ERR_NO_DEVICE, "seed kernel failed"); }
   pm->host_v.assign(static_cast<size_t>(S) * (P + 1), 0.0f);
   pm->host_pi.assign(static_cast<size_t>(S) * M, 0.0f);
+  pm->last = pm->stream;
   *out = pm;
   return AZMI_OK;
 }
@@ -365,7 +369,7 @@ void azmi_pm_destroy(azmi_pm* pm) {
 
 int azmi_pm_round(azmi_pm* pm, void* stream) {
   if (!pm) return fail(AZMI_ERR_INVALID, "null pm");
-  return launch_round(pm, stream ? static_cast<hipStream_t>(stream) : pm->stream);
+  return launch_round(pm, pm->pick(stream));
 }
 
 int azmi_pm_io_buffers(azmi_pm* pm, float** dev_canonical, float** dev_v, float** dev_pi) {
@@ -379,7 +383,7 @@ int azmi_pm_io_buffers(azmi_pm* pm, float** dev_canonical, float** dev_v, float*
 int azmi_pm_poll(azmi_pm* pm, void* stream, uint32_t* games_completed, uint32_t* live_slots) {
   if (!pm) return fail(AZMI_ERR_INVALID, "null pm");
   Control c;
-  const int rc = read_ctl(pm, stream ? static_cast<hipStream_t>(stream) : pm->stream, &c, true);
+  const int rc = read_ctl(pm, pm->pick(stream), &c, true);
   if (rc != AZMI_OK) return rc;
   if (games_completed) *games_completed = c.games_completed;
   if (live_slots) *live_slots = c.stop ? 0u : c.live_slots;
@@ -390,7 +394,7 @@ int azmi_pm_play(azmi_pm* pm, void* stream) {
   if (!pm) return fail(AZMI_ERR_INVALID, "null pm");
   for (uint32_t i = 0; i < pm->gi.P; ++i)
     if (!pm->ep.eval_random[i]) return fail(AZMI_ERR_STATE, "azmi_pm_play needs EvalType::RANDOM on every seat; drive NN seats with azmi_pm_round");
-  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : pm->stream;
+  hipStream_t st = pm->pick(stream);
   for (;;) {
     for (int r = 0; r < 32; ++r) {
       const int rc = launch_round(pm, st);
@@ -407,7 +411,7 @@ int azmi_pm_scores(azmi_pm* pm, float* out) {
   if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");
   std::vector<float> a;
   const uint32_t V = pm->gi.P + 1;
-  const int rc = d2h(a, pm->ar.a_scores, static_cast<size_t>(pm->ep.S) * V, pm->stream);
+  const int rc = d2h(a, pm->ar.a_scores, static_cast<size_t>(pm->ep.S) * V, pm->last);
   if (rc != AZMI_OK) return rc;
   for (uint32_t i = 0; i < V; ++i) out[i] = 0.0f;
   for (uint32_t s = 0; s < pm->ep.S; ++s) for (uint32_t i = 0; i < V; ++i) out[i] += a[static_cast<size_t>(s) * V + i];
@@ -417,7 +421,7 @@ int azmi_pm_resign_scores(azmi_pm* pm, float* out) {
   if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");
   std::vector<float> a;
   const uint32_t V = pm->gi.P + 1;
-  const int rc = d2h(a, pm->ar.a_resign, static_cast<size_t>(pm->ep.S) * V, pm->stream);
+  const int rc = d2h(a, pm->ar.a_resign, static_cast<size_t>(pm->ep.S) * V, pm->last);
   if (rc != AZMI_OK) return rc;
   for (uint32_t i = 0; i < V; ++i) out[i] = 0.0f;
   for (uint32_t s = 0; s < pm->ep.S; ++s) for (uint32_t i = 0; i < V; ++i) out[i] += a[static_cast<size_t>(s) * V + i];
@@ -428,10 +432,10 @@ int azmi_pm_stats(azmi_pm* pm, float* out) {  // play_manager.h:288-315
   if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");
   const uint32_t S = pm->ep.S;
   std::vector<uint64_t> len, cnt; std::vector<double> ds; std::vector<uint32_t> games;
-  int rc = d2h(len, pm->ar.a_len, S, pm->stream); if (rc) return rc;
-  rc = d2h(cnt, pm->ar.a_cnt, 3 * static_cast<size_t>(S), pm->stream); if (rc) return rc;
-  rc = d2h(ds, pm->ar.a_dsum, 5 * static_cast<size_t>(S), pm->stream); if (rc) return rc;
-  rc = d2h(games, pm->ar.slot_games, S, pm->stream); if (rc) return rc;
+  int rc = d2h(len, pm->ar.a_len, S, pm->last); if (rc) return rc;
+  rc = d2h(cnt, pm->ar.a_cnt, 3 * static_cast<size_t>(S), pm->last); if (rc) return rc;
+  rc = d2h(ds, pm->ar.a_dsum, 5 * static_cast<size_t>(S), pm->last); if (rc) return rc;
+  rc = d2h(games, pm->ar.slot_games, S, pm->last); if (rc) return rc;
   uint64_t game_length = 0, mc[3] = {0, 0, 0}, completed = 0; double d[5] = {0, 0, 0, 0, 0};
   for (uint32_t s = 0; s < S; ++s) {
     game_length += len[s]; completed += games[s];
@@ -452,10 +456,10 @@ int azmi_pm_counters(azmi_pm* pm, uint64_t* out) {
   if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");
   const uint32_t S = pm->ep.S;
   std::vector<uint64_t> sims, evals;
-  int rc = d2h(sims, pm->ar.c_sims, S, pm->stream); if (rc) return rc;
-  rc = d2h(evals, pm->ar.c_evals, S, pm->stream); if (rc) return rc;
+  int rc = d2h(sims, pm->ar.c_sims, S, pm->last); if (rc) return rc;
+  rc = d2h(evals, pm->ar.c_evals, S, pm->last); if (rc) return rc;
   Control c;
-  rc = read_ctl(pm, pm->stream, &c, true); if (rc) return rc;
+  rc = read_ctl(pm, pm->last, &c, true); if (rc) return rc;
   out[0] = out[1] = 0;
   for (uint32_t s = 0; s < S; ++s) { out[0] += sims[s]; out[1] += evals[s]; }
   out[2] = 0; out[3] = 0;
@@ -467,7 +471,7 @@ int azmi_pm_counters(azmi_pm* pm, uint64_t* out) {
 int azmi_pm_pop_history(azmi_pm* pm, float* canonical, float* v, float* pi, uint32_t cap, uint32_t* n) {
   if (!pm || !n) return fail(AZMI_ERR_INVALID, "null argument");
   Control c;
-  int rc = read_ctl(pm, pm->stream, &c, true); if (rc) return rc;
+  int rc = read_ctl(pm, pm->last, &c, true); if (rc) return rc;
   const uint32_t avail = std::min(c.hist_rows, pm->ep.hist_cap) - pm->hist_read;
   const uint32_t take = std::min(avail, cap);
   const uint32_t CANON = pm->gi.C * pm->gi.H * pm->gi.W, V = pm->gi.P + 1, M = pm->gi.M;
@@ -486,7 +490,7 @@ int azmi_pm_history_device(azmi_pm* pm, float** dev_canonical, float** dev_v, fl
                            uint32_t* rows) {
   if (!pm) return fail(AZMI_ERR_INVALID, "null argument");
   Control c;
-  int rc = read_ctl(pm, pm->stream, &c, true); if (rc) return rc;
+  int rc = read_ctl(pm, pm->last, &c, true); if (rc) return rc;
   if (dev_canonical) *dev_canonical = pm->ar.h_canon;
   if (dev_v) *dev_v = pm->ar.h_v;
   if (dev_pi) *dev_pi = pm->ar.h_pi;
@@ -499,7 +503,7 @@ int azmi_pm_move_log(azmi_pm* pm, uint32_t* rows, uint32_t* counts, uint32_t cap
   if (!pm || !n) return fail(AZMI_ERR_INVALID, "null argument");
   if (!pm->ep.log_moves) return fail(AZMI_ERR_STATE, "move log was not enabled (azmi_engine_opts.log_moves)");
   Control c;
-  int rc = read_ctl(pm, pm->stream, &c, true); if (rc) return rc;
+  int rc = read_ctl(pm, pm->last, &c, true); if (rc) return rc;
   const uint32_t take = std::min(std::min(c.log_rows, pm->ep.log_cap), cap);
   if (take && rows) HIP_TRY(hipMemcpy(rows, pm->ar.log_rows, static_cast<size_t>(take) * 8 * 4, hipMemcpyDeviceToHost));
   if (take && counts) HIP_TRY(hipMemcpy(counts, pm->ar.log_counts, static_cast<size_t>(take) * pm->gi.M * 4, hipMemcpyDeviceToHost));
@@ -509,7 +513,7 @@ int azmi_pm_move_log(azmi_pm* pm, uint32_t* rows, uint32_t* counts, uint32_t cap
 
 int azmi_debug_trace(azmi_pm* pm, uint64_t* out, uint32_t cap, uint32_t* n) {
   std::vector<uint64_t> t;
-  const int rc = d2h(t, pm->ar.trace, 2 * static_cast<size_t>(pm->ep.trace_cap), pm->stream);
+  const int rc = d2h(t, pm->ar.trace, 2 * static_cast<size_t>(pm->ep.trace_cap), pm->last);
   if (rc) return rc;
   const uint32_t cnt = static_cast<uint32_t>(std::min<uint64_t>(t[0], cap));
   std::memcpy(out, t.data() + 2, static_cast<size_t>(cnt) * 16);
@@ -520,7 +524,7 @@ int azmi_debug_trace(azmi_pm* pm, uint64_t* out, uint32_t cap, uint32_t* n) {
 int azmi_pm_slot_games(azmi_pm* pm, uint32_t* out) {
   if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");
   std::vector<uint32_t> g;
-  const int rc = d2h(g, pm->ar.slot_games, pm->ep.S, pm->stream);
+  const int rc = d2h(g, pm->ar.slot_games, pm->ep.S, pm->last);
   if (rc) return rc;
   std::memcpy(out, g.data(), g.size() * 4);
   return AZMI_OK;
@@ -532,7 +536,7 @@ int azmi_pm_build_batch(azmi_pm* pm, float* batch, uint32_t cap, uint32_t* indic
   *n = 0;
   if (cap == 0) return AZMI_OK;
   const uint32_t S = pm->ep.S, CANON = pm->gi.C * pm->gi.H * pm->gi.W;
-  hipStream_t st = pm->stream;
+  hipStream_t st = pm->pick(AZMI_STREAM_ENGINE);
   int guard = 0;
   while (pm->pending.empty()) {
     if (pm->outstanding != 0) return AZMI_OK;  // rows handed out, answers not back yet

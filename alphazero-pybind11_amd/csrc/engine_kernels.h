@@ -39,6 +39,12 @@ namespace azmi {
 
 constexpr float kNoiseAlphaRatio = 10.83f;  // mcts.cc:14
 
+// per-seat parameter without a dynamically indexed load: a runtime index into a by-value kernel
+// argument forces the whole argument block into scratch memory (every ar.X then costs a load)
+__device__ __forceinline__ uint32_t seat_param(const uint32_t (&a)[4], uint32_t seat) {
+  return seat == 0 ? a[0] : seat == 1 ? a[1] : seat == 2 ? a[2] : a[3];
+}
+
 template <class GM>
 struct SlotCtx {
   static constexpr int G = GM::GROUP;
@@ -60,7 +66,7 @@ struct SlotCtx {
   uint32_t cur, plen;  // MCTS::current_, MCTS::path_.size() of the pending simulation
   uint32_t ph_rows;    // GameData::partial_history.size()
 
-  __device__ SlotCtx(const EngineParams& e, const EngineArrays& a, uint32_t s, uint32_t l)
+  __device__ __forceinline__ SlotCtx(const EngineParams& e, const EngineArrays& a, uint32_t s, uint32_t l)
       : ep(e), ar(a), slot(s), lane(l) {}
 
   // ---- group primitives ---------------------------------------------------------
@@ -90,7 +96,7 @@ struct SlotCtx {
 #define AZMI_SEL(arr, seat) ((seat) == 0 ? arr[0] : arr[P > 1 ? 1 : 0])
 
   // ---- state load / store ----------------------------------------------------------
-  __device__ void load() {
+  __device__ __forceinline__ void load() {
     rng.state = ar.rng[slot];
     coin.state = ar.coin[slot];
     flags = ar.flags[slot];
@@ -105,7 +111,7 @@ struct SlotCtx {
     }
     cur = ar.cur[slot]; plen = ar.plen[slot]; ph_rows = ar.ph_count[slot];
   }
-  __device__ void store(uint8_t sstate) const {
+  __device__ __forceinline__ void store(uint8_t sstate) const {
     if (lane != 0) return;
     ar.rng[slot] = rng.state;
     ar.coin[slot] = coin.state;
@@ -123,7 +129,7 @@ struct SlotCtx {
   }
 
   // ---- tree reset: MCTS{...} construction, play_manager.cc:602-617 --------------------
-  __device__ void reset_tree(uint32_t seat) {
+  __device__ __forceinline__ void reset_tree(uint32_t seat) {
 #pragma unroll
     for (int p = 0; p < P; ++p)
       if (static_cast<uint32_t>(p) == seat) { t_root[p] = 0; t_bump[p] = 1; t_depth[p] = 0; t_tld[p] = 0; }
@@ -133,7 +139,7 @@ struct SlotCtx {
 
   // ---- Node::add_children: legal moves ascending, std::shuffle, append to the arena ----
   // Returns false when the arena is full.  `meta_keep` supplies move/player/term of `node`.
-  __device__ bool expand_node(uint32_t seat, uint32_t node, const typename GM::State& st, uint64_t meta_keep,
+  __device__ __forceinline__ bool expand_node(uint32_t seat, uint32_t node, const typename GM::State& st, uint64_t meta_keep,
                               uint32_t& c0_out, uint32_t& k_out) {
     const size_t tb = tree_base(seat);
     const uint32_t k = GM::num_valid(st);
@@ -180,7 +186,7 @@ struct SlotCtx {
 
   // ---- Node::best_child ------------------------------------------------------------------
   // children live in lanes [0,k): n_l, q_l, p_l.  Returns the winning lane.
-  __device__ uint32_t select_child(uint32_t k, uint32_t n_l, float q_l, float p_l, float v_parent,
+  __device__ __forceinline__ uint32_t select_child(uint32_t k, uint32_t n_l, float q_l, float p_l, float v_parent,
                                    uint32_t n_parent, float fpu_reduction) const {
     float seen = 0.0f;
     for (uint32_t i = 0; i < k; ++i) {
@@ -207,7 +213,7 @@ struct SlotCtx {
   // ---- MCTS::find_leaf ---------------------------------------------------------------------
   // Descends from the root of `seat`'s tree, expands an unvisited node.  Outputs the leaf
   // state and its terminal code; stores MCTS::current_ / path_ for process_result.
-  __device__ bool find_leaf(uint32_t seat, typename GM::State& leaf, uint32_t& term) {
+  __device__ __forceinline__ bool find_leaf(uint32_t seat, typename GM::State& leaf, uint32_t& term) {
     sync_lanes();
     const size_t tb = tree_base(seat);
     const uint32_t root = AZMI_SEL(t_root, seat);
@@ -246,7 +252,7 @@ struct SlotCtx {
   }
 
   // ---- MCTS::add_root_noise: children in lanes [0,k), priors p_l -----------------------------
-  __device__ float add_root_noise(uint32_t k, float p_l) {
+  __device__ __forceinline__ float add_root_noise(uint32_t k, float p_l) {
     float noise_l = 0.0f;
     double sum = 0.0;
     if (ep.shaped && k > 1) {
@@ -279,7 +285,7 @@ struct SlotCtx {
 
   // ---- MCTS::process_result -------------------------------------------------------------------
   // from_net: read (v, pi) rows written by the net; otherwise synthesise dumb_eval.
-  __device__ void process_result(uint32_t seat, bool from_net, bool root_noise) {
+  __device__ __forceinline__ void process_result(uint32_t seat, bool from_net, bool root_noise) {
     sync_lanes();
     const size_t tb = tree_base(seat);
     const uint32_t root = AZMI_SEL(t_root, seat);
@@ -364,7 +370,7 @@ struct SlotCtx {
   __device__ __forceinline__ float pow_entry(float x, float e) const { return e == 1.0f ? x : az_powf(x, e); }
 
   // MCTS::probs — cnt_m / pol_m are the dense root counts and priors
-  __device__ float probs(float temp, uint32_t cnt_m, float pol_m) const {
+  __device__ __forceinline__ float probs(float temp, uint32_t cnt_m, float pol_m) const {
     const bool in = lane < M;
     const float count_sum = seqsum(in ? static_cast<float>(cnt_m) : 0.0f, M);
     if (count_sum == 0) {
@@ -387,7 +393,7 @@ struct SlotCtx {
   }
 
   // MCTS::probs_pruned — children in lanes, returns the dense vector
-  __device__ float probs_pruned(float temp, uint32_t root_n, uint32_t k, uint32_t mv_l, uint32_t n_l, float q_l,
+  __device__ __forceinline__ float probs_pruned(float temp, uint32_t root_n, uint32_t k, uint32_t mv_l, uint32_t n_l, float q_l,
                                 float p_l, uint32_t cnt_m, float pol_m) const {
     if (root_n <= 1) return probs(temp, cnt_m, pol_m);
     const float explore_scaling = ep.cpuct * sqrtf(static_cast<float>(root_n));
@@ -429,7 +435,7 @@ struct SlotCtx {
   }
 
   // MCTS::pick_move — one uniform draw, first m with running sum > choice
-  __device__ uint32_t pick_move(float p_m) {
+  __device__ __forceinline__ uint32_t pick_move(float p_m) {
     const float choice = canonical01(rng) * 1.0f + 0.0f;
     float sum = 0.0f;
     for (uint32_t m = 0; m < static_cast<uint32_t>(M); ++m) {
@@ -443,7 +449,7 @@ struct SlotCtx {
   }
 
   // ---- MCTS::update_root ----------------------------------------------------------------------------
-  __device__ bool update_root(uint32_t seat, uint32_t move) {
+  __device__ __forceinline__ bool update_root(uint32_t seat, uint32_t move) {
     sync_lanes();
     const size_t tb = tree_base(seat);
     const uint32_t root = AZMI_SEL(t_root, seat);
@@ -461,7 +467,7 @@ struct SlotCtx {
   }
 
   // ---- MCTS::apply_root_policy_temp + add_root_noise on a reused subtree (play_manager.cc:541-555) ---
-  __device__ void reapply_root_prior(uint32_t seat, bool noise) {
+  __device__ __forceinline__ void reapply_root_prior(uint32_t seat, bool noise) {
     sync_lanes();
     const size_t tb = tree_base(seat);
     const uint32_t root = AZMI_SEL(t_root, seat);
@@ -482,18 +488,18 @@ struct SlotCtx {
   }
 
   // ---- new game: GameData reset + fresh trees (play_manager.cc:214-230, 515-520) ------------------------
-  __device__ void start_game() {
+  __device__ __forceinline__ void start_game() {
     gs = GM::initial();
     for (uint32_t s = 0; s < static_cast<uint32_t>(P); ++s) reset_tree(s);
     ph_rows = 0;
   }
-  __device__ void draw_capped() {  // play_manager.cc:523-524 / 559-560
+  __device__ __forceinline__ void draw_capped() {  // play_manager.cc:523-524 / 559-560
     const bool capped = ep.cap_rand && (canonical01(coin) < ep.cap_percent);
     flags = capped ? (flags | kFlagCapped) : (flags & ~kFlagCapped);
   }
 
   // ---- the "actually play a move" block, play_manager.cc:286-556.  Returns true if the game ended. ------
-  __device__ bool make_move(uint32_t cp) {
+  __device__ __forceinline__ bool make_move(uint32_t cp) {
     sync_lanes();
     const size_t tb = tree_base(cp);
     const bool capped = flags & kFlagCapped;
@@ -620,7 +626,7 @@ struct SlotCtx {
   }
 
   // ---- game end: flush history with the final scores, commit totals (play_manager.cc:446-505) -----------
-  __device__ void end_game(uint32_t term, bool resigned) {
+  __device__ __forceinline__ void end_game(uint32_t term, bool resigned) {
     const uint32_t S = ep.S;
     sync_lanes();
     const uint32_t rows = ep.history ? ph_rows : 0u;
@@ -660,7 +666,7 @@ struct SlotCtx {
   }
 
   // ---- leaf hand-off to the net: canonical planes + position key (play_manager.cc:589-598) ----------------
-  __device__ void emit_leaf(const typename GM::State& leaf) const {
+  __device__ __forceinline__ void emit_leaf(const typename GM::State& leaf) const {
     float* row = ar.canon + static_cast<size_t>(slot) * GM::CANON;
     for (uint32_t e = lane; e < static_cast<uint32_t>(GM::CANON); e += G) row[e] = GM::canonical_at(leaf, e);
     if (lane == 0) { ar.leaf_key[slot] = GM::key(leaf); ar.c_evals[slot] += 1; }
@@ -669,7 +675,7 @@ struct SlotCtx {
 
 // One round of PlayManager::play for every slot (play_manager.cc:272-599).
 template <class GM>
-__global__ __launch_bounds__(256) void k_round(EngineParams ep, EngineArrays ar) {
+__global__ __launch_bounds__(256, 1) void k_round(EngineParams ep, EngineArrays ar) {
   constexpr int G = GM::GROUP;
   constexpr int P = GM::P;
   const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -691,7 +697,7 @@ __global__ __launch_bounds__(256) void k_round(EngineParams ep, EngineArrays ar)
       const uint32_t cp = c.gs.player;
       const bool noise = ep.epsilon > 0 && !(c.flags & kFlagCapped);
       c.process_result(cp, (c.flags & kFlagLeafNeedsNet) != 0, noise);
-      const uint32_t goal = (c.flags & kFlagCapped) ? ep.cap_visits : ep.visits[cp];
+      const uint32_t goal = (c.flags & kFlagCapped) ? ep.cap_visits : seat_param(ep.visits, cp);
       if (AZMI_SEL(c.t_depth, cp) >= goal) {
         if (c.make_move(cp)) { c.store(kSlotEnded); return; }
       }
@@ -700,7 +706,7 @@ __global__ __launch_bounds__(256) void k_round(EngineParams ep, EngineArrays ar)
     typename GM::State leaf;
     uint32_t term = 0;
     if (!c.find_leaf(cp, leaf, term)) { c.store(kSlotDone); return; }
-    const bool needs_net = term == 0 && !ep.eval_random[cp];
+    const bool needs_net = term == 0 && !seat_param(ep.eval_random, cp);
     c.flags = needs_net ? (c.flags | kFlagLeafNeedsNet) : (c.flags & ~kFlagLeafNeedsNet);
     if (needs_net) { c.emit_leaf(leaf); break; }
     need_process = true;

@@ -88,6 +88,11 @@ typedef struct azmi_engine_opts {
 
 typedef struct azmi_pm azmi_pm;
 
+/* `stream` arguments are hipStream_t values used as given (NULL is the HIP null stream);
+ * AZMI_STREAM_ENGINE selects the engine's own non-blocking stream. Result queries order
+ * themselves behind the stream of the most recent round/play/poll call. */
+#define AZMI_STREAM_ENGINE ((void*)(intptr_t)-1)
+
 void azmi_play_params_default(azmi_play_params* p);      /* PlayParams{} defaults, play_manager.h:60-154 */
 void azmi_engine_opts_default(azmi_engine_opts* o);
 const char* azmi_last_error(void);
