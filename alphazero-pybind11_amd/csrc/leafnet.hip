@@ -12,24 +12,28 @@
 //     heads  h  = relu(conv1x1(s) + bh)                   (v_bn / pi_bn folded; 32 + 32 channels)
 //            v  = softmax(W2 relu(W1 avgpool(h_v) + b1) + b2),  pi = softmax(Wp flatten(h_pi) + bp)
 //
-// One workgroup (4 waves, one per SIMD) carries a tile of TB = 8 boards through the WHOLE tower:
+// One workgroup (8 waves, two per SIMD) carries a tile of TB = 8 boards through the WHOLE tower:
 //   * the residual stream s stays in fp32 MFMA accumulators for the entire kernel (conv2's
 //     accumulator is the stream itself: C-in = s, C-out = s + conv(u));
-//   * activations that feed a convolution live in LDS as bf16 [board][padded cell][64 ch]
-//     with a zero halo ring, so the 9 taps of the implicit GEMM are plain shifted reads;
+//   * activations that feed a convolution live in LDS as bf16 in eight 8-channel planes of
+//     [pixel][16 B] (bank-conflict-free fragment reads); out-of-board taps of the implicit GEMM
+//     are redirected to a shared all-zero cell, in-board taps are plain shifted reads;
 //   * each convolution is D[co][pixel] = sum_k W[co][k] * X[k][pixel] on
 //     v_mfma_f32_16x16x32_bf16 with A = weights (4 m-tiles = 64 output channels) and
 //     B = activations (n-tiles of 16 pixels), which leaves every lane holding 4 consecutive
 //     channels of one pixel — exactly the 8-byte store the LDS activation layout wants;
+//   * waves that own fewer n-tiles than the busiest one run the spare tile slot on dummy data
+//     (branch-free MFMA stream; the spare accumulators are never stored);
 //   * the next convolution's 72 KB of weights are prefetched from L2 into registers while the
 //     current one runs on the matrix cores, and dropped into LDS between the two barriers
 //     that separate convolutions (weights are pre-swizzled on the host into MFMA fragment
 //     order, so both the global load and the LDS read are flat 16 B-per-lane streams).
-// LDS: 82,944 B activations + 73,728 B weights = 156,672 B of the CU's 160 KB (head scratch reuses it).
+// LDS: 45,056 B activations + 73,728 B weights = 118,784 B (head scratch reuses it).
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -46,7 +50,8 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 constexpr int CH = 64;            // trunk channels
 constexpr int HC = 32;            // head channels (value / policy each)
 constexpr int TB = 8;             // boards per workgroup
-constexpr int CELL_BYTES = 144;   // 64 bf16 + 16 B pad (bank spread for the b128 reads)
+constexpr int NTHREADS = 512;     // 8 waves: two per SIMD, so one wave's LDS latency hides under the other's MFMAs
+constexpr int NWAVES = NTHREADS / 64;
 constexpr int WFRAG_BYTES = 1024; // one MFMA A-fragment: 64 lanes x 16 B
 constexpr int MT = 4;             // m-tiles (16 output channels each)
 
@@ -60,25 +65,33 @@ struct NetPtrs {           // device pointers into the folded weight blob
   const uint8_t* blocks;   // per block: a1[64] b1[64] c1[64] (fp32) | conv1 frags | conv2 frags
   const uint8_t* head_w;   // [2 ks][4 mt] fragments (rows 0-31 value conv, 32-63 policy conv)
   const float* head_b;     // [64]
-  const float* v_fc1_w;    // [v_hidden][32]
+  const float* v_fc1_w;    // [32][v_hidden]  (transposed on the host)
   const float* v_fc1_b;    // [v_hidden]
   const float* v_fc2_w;    // [P+1][v_hidden]
   const float* v_fc2_b;    // [P+1]
-  const float* pi_fc_w;    // [M][32*H*W]
+  const float* pi_fc_w;    // [H*W*32][16]  transposed, rows padded to 16; feature order k' = p*32 + c
   const float* pi_fc_b;    // [M]
 };
 
+// LDS activation layout: 8 planes (one per 8-channel chunk), each [pixel slot][8 bf16 = 16 B].
+// Pixel slots 0..NPIX-1 are the tile's real pixels in (board, h, w) order; slots NPIX..NPIX+15 are
+// all-zero cells: an out-of-board tap is redirected to the zero cell with the SAME slot residue
+// mod 16 it would have had, so the redirect never collides with another lane's bank (no halo ring).  With a plane stride that is a
+// multiple of 256 B, the 16 lanes of every ds_read_b128 lane-group land on 16 distinct 16-byte
+// bank slots (consecutive pixels), so fragment reads are conflict-free.
 template <int H, int W>
 struct Geo {
   static constexpr int PIX = H * W;                 // 42
-  static constexpr int PH = H + 2, PW = W + 2;      // padded 8 x 9
-  static constexpr int CELLS = PH * PW;             // 72
   static constexpr int NPIX = TB * PIX;             // 336 GEMM columns
   static constexpr int NT = (NPIX + 15) / 16;       // 21 n-tiles
-  static constexpr int NT_W = (NT + 3) / 4;         // n-tiles per wave (6)
-  static constexpr int ACT_BYTES = TB * CELLS * CELL_BYTES;  // 82,944
+  static constexpr int NT_W = (NT + NWAVES - 1) / NWAVES;  // n-tiles per wave (3)
+  static constexpr int SLOTS = ((NPIX + 1 + 15) / 16) * 16;  // 352
+  static constexpr int PLANE = SLOTS * 16;          // 5632 B, multiple of 256
+  static constexpr int ZERO_OFF = NPIX * 16;        // 16 zero cells (slots NPIX..NPIX+15) inside every plane
+  static constexpr int ACT_BYTES = 8 * PLANE;       // 45,056
   static constexpr int KS3 = 9 * CH / 32;           // 18 k-steps of a 3x3 conv
   static constexpr int WCONV_BYTES = KS3 * MT * WFRAG_BYTES;  // 73,728
+  static constexpr int WREG = WCONV_BYTES / (NTHREADS * 16);  // 9 x 16 B of weights per thread
 };
 
 __device__ __forceinline__ bf16x8 lds_read_frag(const uint8_t* p) {
@@ -86,67 +99,70 @@ __device__ __forceinline__ bf16x8 lds_read_frag(const uint8_t* p) {
 }
 
 template <int H, int W, int MAXP1, int MAXM>
-__global__ __launch_bounds__(256, 1) void k_leafnet(NetDesc nd, NetPtrs np, const float* __restrict__ canon,
-                                                     float* __restrict__ v_out, float* __restrict__ pi_out,
-                                                     uint32_t batch) {
+__global__ __launch_bounds__(NTHREADS, 2) void k_leafnet(NetDesc nd, NetPtrs np, const float* __restrict__ canon,
+                                                          float* __restrict__ v_out, float* __restrict__ pi_out,
+                                                          uint32_t batch, uint32_t dbg) {
   using G = Geo<H, W>;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  uint8_t* act = lds;                                   // activation cells
+  uint8_t* act = lds;                                   // activation planes
   uint8_t* wbuf = lds + G::ACT_BYTES;                   // weights of the running convolution
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int col = lane & 15, quad = lane >> 4;
   const uint32_t board0 = blockIdx.x * TB;
 
-  // ---- per-lane pixel geometry of the wave's n-tiles: tile t = wave + 4 j ----------------------
-  int cell_off[G::NT_W];   // byte offset of the lane's pixel cell inside `act`
+  // ---- per-lane pixel geometry of the wave's n-tiles: tile t = wave + NWAVES * j ------------------
+  int pix_off[G::NT_W];      // byte offset (inside a plane) of the lane's pixel
+  uint32_t tap_ok[G::NT_W];  // bit tap: the 3x3 neighbour (tap/3-1, tap%3-1) is on the board
   bool tile_on[G::NT_W];
 #pragma unroll
   for (int j = 0; j < G::NT_W; ++j) {
-    const int t = wave + 4 * j;
+    const int t = wave + NWAVES * j;
     const int n = t * 16 + col;
-    tile_on[j] = t < G::NT;
-    const int nn = (t < G::NT && n < G::NPIX) ? n : 0;
-    const int b = nn / G::PIX, p = nn % G::PIX;
-    const int h = p / W, w = p % W;
-    cell_off[j] = (b * G::CELLS + (h + 1) * G::PW + (w + 1)) * CELL_BYTES;
+    tile_on[j] = __builtin_amdgcn_readfirstlane(t) < G::NT;
+    const bool real = t < G::NT && n < G::NPIX;
+    const int nn = real ? n : 0;
+    const int p = nn % G::PIX, h = p / W, w = p % W;
+    pix_off[j] = nn * 16;
+    uint32_t m = 0;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
+      if (real && hh >= 0 && hh < H && ww >= 0 && ww < W) m |= 1u << tap;
+    }
+    tap_ok[j] = m;
   }
 
-  // ---- zero the activation buffer once (the halo ring stays zero for the whole kernel) -----------
-  for (int i = tid * 16; i < G::ACT_BYTES; i += 256 * 16) *reinterpret_cast<u32x4*>(act + i) = u32x4{0, 0, 0, 0};
+  // ---- zero the activation planes once (covers the zero cells) ---------------------------------------
+  if (!(dbg & 16))
+    for (int i = tid * 16; i < G::ACT_BYTES; i += NTHREADS * 16) *reinterpret_cast<u32x4*>(act + i) = u32x4{0, 0, 0, 0};
 
-  // ---- stem: im2col of the C_in input planes into act as [pixel][k = tap*C_in + ci] (k < 64) ----
-  // staged through `wbuf` as raw fp32 planes first
-  float* raw = reinterpret_cast<float*>(wbuf + 16384);  // [TB][C_in][H][W]
+  // ---- stem: im2col of the C_in input planes: B[k = tap*C_in + ci][pixel], k < 64 ---------------------
+  float* raw = reinterpret_cast<float*>(wbuf + 16384);  // [TB][C_in][H][W] staged in the weight area
   const int plane_sz = nd.C_in * G::PIX;
-  for (int i = tid; i < TB * plane_sz; i += 256) {
+  for (int i = tid; i < TB * plane_sz; i += NTHREADS) {
     const uint32_t b = board0 + i / plane_sz;
     raw[i] = b < batch ? canon[static_cast<size_t>(b) * plane_sz + (i % plane_sz)] : 0.0f;
   }
-  // stem weights: 2 k-steps x 4 m-tiles = 8 KB
-  for (int i = tid * 16; i < 2 * MT * WFRAG_BYTES; i += 256 * 16)
+  for (int i = tid * 16; i < 2 * MT * WFRAG_BYTES; i += NTHREADS * 16)
     *reinterpret_cast<u32x4*>(wbuf + i) = *reinterpret_cast<const u32x4*>(np.stem_w + i);
   __syncthreads();
-  {
-    // the stem's B operand is laid out like a 1x1 conv input: one 128 B row per pixel, stored in the
-    // pixel's own (interior) cell; the halo is not involved because the taps are already unrolled in k
-    const int kdim = 9 * nd.C_in;  // <= 64
-    for (int i = tid; i < G::NPIX * 64; i += 256) {
-      const int n = i >> 6, k = i & 63;
-      const int b = n / G::PIX, p = n % G::PIX, h = p / W, w = p % W;
-      float val = 0.0f;
-      if (k < kdim) {
-        const int tap = k / nd.C_in, ci = k % nd.C_in;
-        const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
-        if (hh >= 0 && hh < H && ww >= 0 && ww < W) val = raw[(b * nd.C_in + ci) * G::PIX + hh * W + ww];
+  if (tid < G::NPIX && !(dbg & 1)) {  // one thread per pixel: k = tap*C_in + ci, written as bf16 into the chunk planes
+    const int n = tid, b = n / G::PIX, p = n % G::PIX, h = p / W, w = p % W;
+    const float* rb = raw + b * plane_sz;
+    for (int tap = 0; tap < 9; ++tap) {
+      const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
+      const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+      for (int ci = 0; ci < nd.C_in; ++ci) {
+        const int k = tap * nd.C_in + ci;
+        const float val = ok ? rb[ci * G::PIX + hh * W + ww] : 0.0f;
+        *reinterpret_cast<__bf16*>(act + (k >> 3) * G::PLANE + n * 16 + (k & 7) * 2) = static_cast<__bf16>(val);
       }
-      const int off = (b * G::CELLS + (h + 1) * G::PW + (w + 1)) * CELL_BYTES + k * 2;
-      *reinterpret_cast<__bf16*>(act + off) = static_cast<__bf16>(val);
     }
   }
   __syncthreads();
 
-  // ---- residual stream: accumulators s[j][mt] (fp32), kept for the whole kernel -------------------
+  // ---- residual stream: accumulators s[j][mt] (fp32), kept for the whole kernel -----------------------
   f32x4 s[G::NT_W][MT];
   {
     f32x4 bias[MT];
@@ -163,36 +179,41 @@ __global__ __launch_bounds__(256, 1) void k_leafnet(NetDesc nd, NetPtrs np, cons
       for (int mt = 0; mt < MT; ++mt) a[mt] = lds_read_frag(wbuf + (ks * MT + mt) * WFRAG_BYTES + lane * 16);
 #pragma unroll
       for (int j = 0; j < G::NT_W; ++j) {
-        if (!tile_on[j]) continue;
-        const bf16x8 b = lds_read_frag(act + cell_off[j] + ks * 64 + quad * 16);
+        const bf16x8 b = lds_read_frag(act + (ks * 4 + quad) * G::PLANE + pix_off[j]);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) s[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, s[j][mt], 0, 0, 0);
       }
     }
   }
 
-  // weight prefetch registers: this thread's 288 B slice of the next convolution (18 x 16 B)
-  u32x4 wnext[G::KS3];
+  // weight prefetch registers: this thread's 144 B slice of the next convolution (9 x 16 B)
+  u32x4 wnext[G::WREG];
   auto prefetch = [&](const uint8_t* src) {
 #pragma unroll
-    for (int i = 0; i < G::KS3; ++i) wnext[i] = *reinterpret_cast<const u32x4*>(src + (i * 256 + tid) * 16);
+    for (int i = 0; i < G::WREG; ++i) wnext[i] = *reinterpret_cast<const u32x4*>(src + (i * NTHREADS + tid) * 16);
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int i = 0; i < G::KS3; ++i) *reinterpret_cast<u32x4*>(wbuf + (i * 256 + tid) * 16) = wnext[i];
+    for (int i = 0; i < G::WREG; ++i) *reinterpret_cast<u32x4*>(wbuf + (i * NTHREADS + tid) * 16) = wnext[i];
   };
-  // epilogue helper: store one accumulator tile as bf16 into the lane's pixel cell
+  // epilogue helper: 4 consecutive channels (mt*16 + quad*4 ..) of the lane's pixel, as bf16
   auto store_tile = [&](int j, int mt, f32x4 val) {
     bf16x4 o;
     o[0] = static_cast<__bf16>(val[0]); o[1] = static_cast<__bf16>(val[1]);
     o[2] = static_cast<__bf16>(val[2]); o[3] = static_cast<__bf16>(val[3]);
-    *reinterpret_cast<bf16x4*>(act + cell_off[j] + (mt * 16 + quad * 4) * 2) = o;
+    *reinterpret_cast<bf16x4*>(act + (mt * 2 + (quad >> 1)) * G::PLANE + pix_off[j] + (quad & 1) * 8) = o;
   };
   // one 3x3 convolution over `act` with the weights in `wbuf`, accumulating into acc[][]
   auto conv3x3 = [&](f32x4 (&acc)[G::NT_W][MT]) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int tap_off = ((tap / 3 - 1) * G::PW + (tap % 3 - 1)) * CELL_BYTES;
+      const int tap_off = ((tap / 3 - 1) * W + (tap % 3 - 1)) * 16;
+      int src[G::NT_W];
+#pragma unroll
+      for (int j = 0; j < G::NT_W; ++j) {
+        const int shifted = pix_off[j] + tap_off;
+        src[j] = ((tap_ok[j] >> tap) & 1u) ? shifted : G::ZERO_OFF + (shifted & 0xF0);
+      }
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int ks = tap * 2 + half;
@@ -201,8 +222,7 @@ __global__ __launch_bounds__(256, 1) void k_leafnet(NetDesc nd, NetPtrs np, cons
         for (int mt = 0; mt < MT; ++mt) a[mt] = lds_read_frag(wbuf + (ks * MT + mt) * WFRAG_BYTES + lane * 16);
 #pragma unroll
         for (int j = 0; j < G::NT_W; ++j) {
-          if (!tile_on[j]) continue;
-          const bf16x8 b = lds_read_frag(act + cell_off[j] + tap_off + half * 64 + quad * 16);
+          const bf16x8 b = lds_read_frag(act + (half * 4 + quad) * G::PLANE + src[j]);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, acc[j][mt], 0, 0, 0);
         }
@@ -256,19 +276,19 @@ __global__ __launch_bounds__(256, 1) void k_leafnet(NetDesc nd, NetPtrs np, cons
       }
     commit();
     __syncthreads();
-    // s = s + conv2(u); meanwhile fetch the next block's conv1 weights (or the head conv)
+    // s = s + conv2(u); meanwhile fetch the next block's conv1 weights
     if (blk + 1 < nd.depth) prefetch(bp + block_stride + 3 * CH * sizeof(float));
     conv3x3(s);
     __syncthreads();
   }
 
-  // ---- heads: h = relu(conv1x1(s) + bh), 64 rows = 32 value + 32 policy channels -------------------
+  // ---- heads: h = relu(conv1x1(s) + bh), 64 rows = 32 value + 32 policy channels -----------------------
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int j = 0; j < G::NT_W; ++j)
       if (tile_on[j]) store_tile(j, mt, s[j][mt]);
-  for (int i = tid * 16; i < 2 * MT * WFRAG_BYTES; i += 256 * 16)
+  for (int i = tid * 16; i < 2 * MT * WFRAG_BYTES; i += NTHREADS * 16)
     *reinterpret_cast<u32x4*>(wbuf + i) = *reinterpret_cast<const u32x4*>(np.head_w + i);
   __syncthreads();
   f32x4 hacc[G::NT_W][MT];
@@ -285,78 +305,111 @@ __global__ __launch_bounds__(256, 1) void k_leafnet(NetDesc nd, NetPtrs np, cons
     for (int mt = 0; mt < MT; ++mt) a[mt] = lds_read_frag(wbuf + (ks * MT + mt) * WFRAG_BYTES + lane * 16);
 #pragma unroll
     for (int j = 0; j < G::NT_W; ++j) {
-      if (!tile_on[j]) continue;
-      const bf16x8 b = lds_read_frag(act + cell_off[j] + ks * 64 + quad * 16);
+      const bf16x8 b = lds_read_frag(act + (ks * 4 + quad) * G::PLANE + pix_off[j]);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) hacc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, hacc[j][mt], 0, 0, 0);
     }
   }
   __syncthreads();
-  // head activations as fp32 [pixel][64] over the (now free) act + wbuf region
-  float* hbuf = reinterpret_cast<float*>(lds);
+  // head activations over the (now free) act + wbuf region, fp32:
+  //   vbuf [pixel][32]            value channels, for the average pool
+  //   pbuf [p*32 + c][8 boards]   policy channels in the FC's k order, board-minor (conflict-free B reads)
+  float* vbuf = reinterpret_cast<float*>(lds);
+  float* pbuf = vbuf + G::NPIX * HC;
+  float* part = pbuf + G::PIX * HC * TB;   // [NWAVES][16 moves][16 boards] partial policy logits
+  float* vpool = part + NWAVES * 256;      // [TB][32]
+  float* vh = vpool + TB * HC;             // [TB][v_hidden]   (v_hidden <= 256)
+  float* logits = vh + TB * 256;           // [TB][MAXP1 + MAXM]
+  const int P1 = nd.num_players + 1, M = nd.num_moves;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int j = 0; j < G::NT_W; ++j) {
-      const int t = wave + 4 * j, n = t * 16 + col;
+      const int t = wave + NWAVES * j, n = t * 16 + col;
       if (t < G::NT && n < G::NPIX) {
         f32x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = fmaxf(hacc[j][mt][r], 0.0f);
-        *reinterpret_cast<f32x4*>(hbuf + n * 64 + mt * 16 + quad * 4) = o;
+        if (mt < 2) {
+          *reinterpret_cast<f32x4*>(vbuf + n * HC + mt * 16 + quad * 4) = o;
+        } else {
+          const int b = n / G::PIX, p = n % G::PIX, c0 = (mt - 2) * 16 + quad * 4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pbuf[(p * HC + c0 + r) * TB + b] = o[r];
+        }
       }
     }
   __syncthreads();
-
-  // ---- value head: avgpool -> fc1 -> relu -> fc2 -> softmax (fp32 VALU) --------------------------------
-  float* vpool = hbuf + G::NPIX * 64;   // [TB][32]  (LDS behind hbuf, still inside act + wbuf)
-  float* vh = vpool + TB * HC;          // [TB][v_hidden]   (v_hidden <= 256)
-  float* logits = vh + TB * 256;        // [TB][MAXP1 + MAXM]
-  {
-    const int b = tid >> 5, c = tid & 31;  // 8 boards x 32 channels = 256 threads
+  if (tid < TB * HC && !(dbg & 8)) {
+    const int b = tid >> 5, c = tid & 31;
     float acc = 0.0f;
-    for (int p = 0; p < G::PIX; ++p) acc += hbuf[(b * G::PIX + p) * 64 + c];
+    for (int p = 0; p < G::PIX; ++p) acc += vbuf[(b * G::PIX + p) * HC + c];
     vpool[b * HC + c] = acc / static_cast<float>(G::PIX);
   }
-  __syncthreads();
-  for (int o = tid; o < nd.v_hidden; o += 256) {
-    float wrow[HC];
-#pragma unroll
-    for (int i = 0; i < HC; ++i) wrow[i] = np.v_fc1_w[o * HC + i];
-    const float bias = np.v_fc1_b[o];
-    for (int b = 0; b < TB; ++b) {
-      float acc = bias;
-#pragma unroll
-      for (int i = 0; i < HC; ++i) acc += wrow[i] * vpool[b * HC + i];
-      vh[b * 256 + o] = fmaxf(acc, 0.0f);
+  // policy logits = W[16 x K] * pbuf[K x 16] on the exact-fp32 matrix pipe (v_mfma_f32_16x16x4_f32),
+  // K = 32*H*W split over the 8 waves; A = host-transposed weights [k][16 rows, zero padded] (one coalesced
+  // 256 B load per MFMA), B = pbuf rows (boards 8..15 of the tile do not exist -> 0).
+  if (!(dbg & 2)) {
+    constexpr int KSTEPS = HC * G::PIX / 4;           // 336
+    static_assert(KSTEPS % NWAVES == 0, "policy k-steps must split evenly over the waves");
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 14
+    for (int i = 0; i < KSTEPS / NWAVES; ++i) {
+      const int k = (i * NWAVES + wave) * 4 + quad;
+      const float a = np.pi_fc_w[k * 16 + col];
+      const float bval = col < TB ? pbuf[k * TB + col] : 0.0f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bval, acc, 0, 0, 0);
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[(wave * 16 + quad * 4 + r) * 16 + col] = acc[r];
   }
   __syncthreads();
-  const int P1 = nd.num_players + 1, M = nd.num_moves;
-  // value logits: (board, output) pairs, one wave-quarter (16 lanes) each
-  {
-    const int pair = tid >> 4, sub = tid & 15;  // 16 pairs per pass
-    for (int q = pair; q < TB * P1; q += 16) {
-      const int b = q / P1, o = q % P1;
-      float acc = 0.0f;
-      for (int i = sub; i < nd.v_hidden; i += 16) acc += np.v_fc2_w[o * nd.v_hidden + i] * vh[b * 256 + i];
-      for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 16);
-      if (sub == 0) logits[b * (MAXP1 + MAXM) + o] = acc + np.v_fc2_b[o];
-    }
+  if (tid < TB * M) {
+    const int b = tid / M, m = tid % M;
+    float a = np.pi_fc_b[m];
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) a += part[(w * 16 + m) * 16 + b];
+    logits[b * (MAXP1 + MAXM) + MAXP1 + m] = a;
   }
-  // policy logits: flatten order (c, h, w) of the 32 policy channels -> index c * PIX + p
+  __syncthreads();
+  // value fc1 (weights transposed on the host: [32][v_hidden] -> coalesced over outputs); 2 threads per output
   {
-    const int pair = tid >> 5, sub = tid & 31;  // 8 pairs per pass, 32 lanes each
-    const int feat = HC * G::PIX;
-    for (int q = pair; q < TB * M; q += 8) {
-      const int b = q / M, m = q % M;
-      float acc = 0.0f;
-      for (int i = sub; i < feat; i += 32) {
-        const int c = i / G::PIX, p = i % G::PIX;
-        acc += np.pi_fc_w[static_cast<size_t>(m) * feat + i] * hbuf[(b * G::PIX + p) * 64 + HC + c];
+    const int o = tid % 256, bh = tid / 256;  // bh: boards 0-3 / 4-7
+    if (o < nd.v_hidden && !(dbg & 4)) {
+      float acc[TB / 2];
+      const float bias = np.v_fc1_b[o];
+#pragma unroll
+      for (int b = 0; b < TB / 2; ++b) acc[b] = bias;
+#pragma unroll
+      for (int i = 0; i < HC; ++i) {
+        const float wv = np.v_fc1_w[i * nd.v_hidden + o];
+#pragma unroll
+        for (int b = 0; b < TB / 2; ++b) acc[b] += wv * vpool[(bh * (TB / 2) + b) * HC + i];
       }
-      for (int off = 16; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 32);
-      if (sub == 0) logits[b * (MAXP1 + MAXM) + MAXP1 + m] = acc + np.pi_fc_b[m];
+#pragma unroll
+      for (int b = 0; b < TB / 2; ++b) vh[(bh * (TB / 2) + b) * 256 + o] = fmaxf(acc[b], 0.0f);
+    }
+  }
+  __syncthreads();
+  {  // value fc2: wave b owns board b
+    const int b = wave;
+    float acc[MAXP1];
+#pragma unroll
+    for (int o = 0; o < MAXP1; ++o) acc[o] = 0.0f;
+#pragma unroll 4
+    for (int i = lane; i < nd.v_hidden; i += 64) {
+      const float x = vh[b * 256 + i];
+#pragma unroll
+      for (int o = 0; o < MAXP1; ++o)
+        if (o < P1) acc[o] += np.v_fc2_w[o * nd.v_hidden + i] * x;
+    }
+#pragma unroll
+    for (int o = 0; o < MAXP1; ++o) {
+      if (o < P1) {
+        float a = acc[o];
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+        if (lane == 0) logits[b * (MAXP1 + MAXM) + o] = a + np.v_fc2_b[o];
+      }
     }
   }
   __syncthreads();
@@ -413,7 +466,7 @@ size_t azmi_net_blob_bytes(const azmi_net_desc* d) {
   n += wsmall + CH * 4;
   n += (static_cast<size_t>(d->v_hidden) * HC + d->v_hidden) * 4;
   n += (static_cast<size_t>(d->num_players + 1) * d->v_hidden + d->num_players + 1) * 4;
-  n += (static_cast<size_t>(d->num_moves) * HC * d->height * d->width + d->num_moves) * 4;
+  n += (static_cast<size_t>(16) * HC * d->height * d->width + d->num_moves) * 4;
   return n;
 }
 
@@ -446,11 +499,12 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
   np.v_fc1_b = reinterpret_cast<const float*>(p); p += static_cast<size_t>(d->v_hidden) * 4;
   np.v_fc2_w = reinterpret_cast<const float*>(p); p += static_cast<size_t>(d->num_players + 1) * d->v_hidden * 4;
   np.v_fc2_b = reinterpret_cast<const float*>(p); p += static_cast<size_t>(d->num_players + 1) * 4;
-  np.pi_fc_w = reinterpret_cast<const float*>(p); p += static_cast<size_t>(d->num_moves) * HC * d->height * d->width * 4;
+  np.pi_fc_w = reinterpret_cast<const float*>(p); p += static_cast<size_t>(16) * HC * d->height * d->width * 4;
   np.pi_fc_b = reinterpret_cast<const float*>(p); p += static_cast<size_t>(d->num_moves) * 4;
   using G = Geo<6, 7>;
   net->lds_bytes = G::ACT_BYTES + G::WCONV_BYTES;
-  static_assert(G::NPIX * 64 * 4 + (TB * HC + TB * 256 + TB * (4 + 16)) * 4 <= G::ACT_BYTES + G::WCONV_BYTES, "head scratch must fit");
+  static_assert(NWAVES == TB, "head maps one wave to one board");
+  static_assert(G::NPIX * 64 * 4 + (NWAVES * 256 + TB * HC + TB * 256 + TB * (4 + 16)) * 4 <= G::ACT_BYTES + G::WCONV_BYTES, "head scratch must fit");
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_leafnet<6, 7, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           static_cast<int>(net->lds_bytes)) != hipSuccess) {
     (void)hipFree(net->blob); delete net;
@@ -471,7 +525,7 @@ int azmi_net_forward(azmi_net* net, const float* dev_canonical, float* dev_v, fl
   if (!net || !dev_canonical || !dev_v || !dev_pi) return nfail(AZMI_ERR_INVALID, "null argument");
   if (batch == 0) return AZMI_OK;
   const uint32_t tiles = (batch + TB - 1) / TB;
-  k_leafnet<6, 7, 4, 16><<<tiles, 256, net->lds_bytes, static_cast<hipStream_t>(stream)>>>(net->nd, net->np, dev_canonical, dev_v, dev_pi, batch);
+  k_leafnet<6, 7, 4, 16><<<tiles, NTHREADS, net->lds_bytes, static_cast<hipStream_t>(stream)>>>(net->nd, net->np, dev_canonical, dev_v, dev_pi, batch, getenv("AZMI_NET_DEBUG") ? static_cast<uint32_t>(atoi(getenv("AZMI_NET_DEBUG"))) : 0u);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nfail(AZMI_ERR_NO_DEVICE, "k_leafnet launch: %s", hipGetErrorString(e));
   return AZMI_OK;
