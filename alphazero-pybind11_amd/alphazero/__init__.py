@@ -385,6 +385,16 @@ class PlayManager:
         return c[:got], v[:got], p[:got]
 
 
+def run_rounds(pms, net, rounds, streams):
+    """azmi_run_rounds: native round driver over several engines (one stream each) sharing one HipLeafNet."""
+    k = len(pms)
+    arr_pm = (C.c_void_p * k)(*[pm._h for pm in pms])
+    arr_st = (C.c_void_p * k)(*[C.c_void_p(int(s)) for s in streams])
+    for pm, s in zip(pms, streams):
+        pm._last_stream = C.c_void_p(int(s))
+    check(lib.azmi_run_rounds(arr_pm, net._h, k, int(rounds), arr_st))
+
+
 def game_replay(game_cls, moves, device=0):
     """Batched rules replay on the device (azmi_game_replay): moves [n, len] int32, -1 padded."""
     moves = np.ascontiguousarray(moves, dtype=np.int32)

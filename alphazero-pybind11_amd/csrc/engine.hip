@@ -372,6 +372,21 @@ int azmi_pm_round(azmi_pm* pm, void* stream) {
   return launch_round(pm, pm->pick(stream));
 }
 
+int azmi_run_rounds(azmi_pm* const* pms, azmi_net* net, uint32_t k, uint32_t rounds, void* const* streams) {
+  if (!pms || !net || !streams || k == 0) return fail(AZMI_ERR_INVALID, "null argument");
+  for (uint32_t r = 0; r < rounds; ++r) {
+    for (uint32_t i = 0; i < k; ++i) {
+      azmi_pm* pm = pms[i];
+      hipStream_t st = pm->pick(streams[i]);
+      int rc = launch_round(pm, st);
+      if (rc != AZMI_OK) return rc;
+      rc = azmi_net_forward(net, pm->ar.canon, pm->ar.v, pm->ar.pi, pm->ep.S, st);
+      if (rc != AZMI_OK) return fail(rc, "%s", azmi_net_last_error());
+    }
+  }
+  return AZMI_OK;
+}
+
 int azmi_pm_io_buffers(azmi_pm* pm, float** dev_canonical, float** dev_v, float** dev_pi) {
   if (!pm) return fail(AZMI_ERR_INVALID, "null pm");
   if (dev_canonical) *dev_canonical = pm->ar.canon;

@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=36000)
     ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
     ap.add_argument("--sims", type=int, default=800)
+    ap.add_argument("--engines", type=int, default=4, help="engine shards (HIP streams) per GPU")
     ap.add_argument("--net", choices=["hip", "torch"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -103,65 +104,94 @@ def main():
     import alphazero as az
     from alphazero import torch_net
 
-    S, sims = args.games, args.sims
-    total_rounds = args.warmup + args.steps
-    stream_games = max(S, 8 * S)  # stream pool, play_manager_bench.cc:171-181
-    pp = selfplay_params(az, S, sims, stream_games)
-    pm = az.PlayManager(az.Connect4GS(), pp, seed=20240601 + 7919 * rank, device=local_rank)
-    canon, v_buf, pi_buf = pm.io_tensors()
+    S, sims, K = args.games, args.sims, args.engines
+    assert S % K == 0
+    Se = S // K                       # slots per engine shard
+    stream_games = max(Se, 8 * Se)    # stream pool, play_manager_bench.cc:171-181
+    # K engine shards of S/K slots, one HIP stream each: while one shard's leaf batch is on the matrix
+    # cores another shard's tree kernel runs on the CUs the net leaves free.
+    pms, streams = [], []
+    for i in range(K):
+        pp = selfplay_params(az, Se, sims, stream_games)
+        pms.append(az.PlayManager(az.Connect4GS(), pp, seed=20240601 + 7919 * rank + 104729 * i, device=local_rank))
+        streams.append(torch.cuda.Stream(device=dev))
+    sps = [st.cuda_stream for st in streams]
+    io = [pm.io_tensors() for pm in pms]
 
     spec = torch_net.connect4_spec()
     net = torch_net.random_init(spec, seed=0).to(dev)
     net_kind = args.net or "hip"
-    if net_kind == "hip":
-        hip_net = az.HipLeafNet(net, spec, max_batch=S, device=local_rank)
-
-        def evaluate(stream_ptr):
-            hip_net.forward(canon, v_buf, pi_buf, stream_ptr)
-    else:
+    hip_net = az.HipLeafNet(net, spec, device=local_rank) if net_kind == "hip" else None
+    if net_kind == "torch":
         net = net.to(memory_format=torch.channels_last)
 
-        def evaluate(stream_ptr):
-            v, pi = net.process(canon, amp_dtype=torch.bfloat16)
-            v_buf.copy_(v)
-            pi_buf.copy_(pi)
-
-    stream = torch.cuda.current_stream()
-    sp = stream.cuda_stream
+    def evaluate(i):
+        canon, v_buf, pi_buf = io[i]
+        if hip_net is not None:
+            hip_net.forward(canon, v_buf, pi_buf, sps[i])
+        else:
+            with torch.cuda.stream(streams[i]):
+                v, pi = net.process(canon, amp_dtype=torch.bfloat16)
+                v_buf.copy_(v)
+                pi_buf.copy_(pi)
 
     def run_rounds(n, ev=None):
-        for i in range(n):
-            if ev is not None and (i & 15) == 0:
+        """n rounds of every shard. With the HIP net the loop is the native driver (azmi_run_rounds);
+        every 64th round is launched from here with HIP events around the two kernels of shard 0."""
+        done = 0
+        while done < n:
+            if ev is not None:
                 e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-                e0.record(stream); pm.round(sp); e1.record(stream); evaluate(sp); e2.record(stream)
+                for i in range(K):
+                    if i == 0:
+                        e0.record(streams[0])
+                    pms[i].round(sps[i])
+                    if i == 0:
+                        e1.record(streams[0])
+                    evaluate(i)
+                    if i == 0:
+                        e2.record(streams[0])
                 ev.append((e0, e1, e2))
+                done += 1
+            chunk = min(63 if ev is not None else 256, n - done)
+            if chunk <= 0:
+                continue
+            if hip_net is not None:
+                az.run_rounds(pms, hip_net, chunk, sps)
             else:
-                pm.round(sp)
-                evaluate(sp)
+                for _ in range(chunk):
+                    for i in range(K):
+                        pms[i].round(sps[i])
+                        evaluate(i)
+            done += chunk
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def totals():
+        done = sum(pm.poll()[0] for pm in pms)
+        cs = [pm.counters() for pm in pms]
+        return done, sum(c["sims"] for c in cs), sum(c["evals"] for c in cs)
+
     run_rounds(args.warmup)
     barrier()
-    done0, _ = pm.poll(sp)
-    c0 = pm.counters()
+    done0, sims0, evals0 = totals()
     events = []
     t0 = time.perf_counter()
     run_rounds(args.steps, events)
     # the one exchange step: finished samples of this window go to rank 0 over RCCL/xGMI
-    done1, live = pm.poll(sp)
+    done1, sims1, evals1 = totals()
     gathered_rows = 0
     if world > 1:
         from alphazero import gather
-        gathered_rows = gather.gather_history_to_rank0(pm, dev, rank, world)
+        for pm in pms:
+            gathered_rows += gather.gather_history_to_rank0(pm, dev, rank, world)
     barrier()
     dt = time.perf_counter() - t0
-    c1 = pm.counters()
     tmax = torch.tensor([dt], device=dev)
-    games = torch.tensor([float(done1 - done0), float(c1["sims"] - c0["sims"]), float(c1["evals"] - c0["evals"])], device=dev)
+    games = torch.tensor([float(done1 - done0), float(sims1 - sims0), float(evals1 - evals0)], device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(games, op=dist.ReduceOp.SUM)
@@ -171,8 +201,13 @@ def main():
     if rank == 0:
         tree_ms = sum(a.elapsed_time(b) for a, b, _ in events) / max(1, len(events))
         nn_ms = sum(b.elapsed_time(c) for _, b, c in events) / max(1, len(events))
-        flops = FLOP_PER_EVAL * S  # the net evaluates all S slot rows every round (fixed-shape batch)
-        achieved = flops / (nn_ms * 1e-3) / 1e12 if nn_ms > 0 else 0.0
+        # k_leafnet evaluates the Se rows of one shard per launch; K launches (one per shard) are in flight
+        # at once and share the chip with each other and with the tree kernels, so a per-launch event
+        # interval double-counts shared CUs.  `achieved` is therefore the algorithmic FLOPs of ALL net
+        # launches of the timed region / the region's wall time (a lower bound on the kernel's own rate);
+        # the per-launch HIP-event interval is reported next to it.
+        launches = args.steps * K
+        achieved = FLOP_PER_EVAL * Se * launches / dt / 1e12
         out = {
             "metric": "self-play games/sec (whole node), Connect4 @ 800 MCTS sims",
             "value": n_games / dt,
@@ -189,7 +224,7 @@ def main():
             "config": {
                 "workload": f"Connect4, {S} concurrent games/GPU, {sims} sims/move, 6-block/64-ch ResNet (k3, 32 head ch), "
                             f"self-play flags of game_runner.py:2018-2041 with playout-cap off, random-init weights",
-                "concurrent_games_per_gpu": S, "sims_per_move": sims, "net": net_kind,
+                "concurrent_games_per_gpu": S, "engine_shards": K, "sims_per_move": sims, "net": net_kind,
                 "sims_per_s": n_sims / dt, "leaf_evals_per_s": n_evals / dt,
                 "tree_kernel_ms": tree_ms, "net_ms": nn_ms, "samples_gathered": gathered_rows,
                 "games_in_window": n_games,
@@ -197,7 +232,8 @@ def main():
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
-                "kernel": "leaf-net forward, %d positions x %.1f MFLOP per launch" % (S, FLOP_PER_EVAL / 1e6),
+                "kernel": "k_leafnet: %d positions x %.1f MFLOP per launch, %d overlapping launches per round" % (Se, FLOP_PER_EVAL / 1e6, K),
+                "per_launch_event_ms": nn_ms, "definition": "sum of algorithmic FLOPs of all k_leafnet launches in the timed region / wall time of the region",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -180,6 +180,14 @@ void azmi_net_destroy(azmi_net* net);
 int azmi_net_forward(azmi_net* net, const float* dev_canonical, float* dev_v, float* dev_pi, uint32_t batch, void* stream);
 const char* azmi_net_last_error(void);
 
+/* ---- native round driver (the counterpart of GameRunner's batcher / gpu_loop / result_worker
+ *      threads, game_runner.py:483-552, 651-726): `rounds` times, for each of the `k` engines in turn:
+ *      one round on streams[i], then the net on that engine's slot-indexed leaf batch on the same
+ *      stream.  Engines on different streams overlap: while one engine's leaf batch is on the matrix
+ *      cores, another engine's tree kernel runs on the CUs the net leaves free.  Launch-only
+ *      (asynchronous); poll with azmi_pm_poll. */
+int azmi_run_rounds(azmi_pm* const* pms, azmi_net* net, uint32_t k, uint32_t rounds, void* const* streams);
+
 /* The device RNG layer on its own (parity tier "RNG"): runs `thread_local pcg32 re` + the
  * libstdc++ algorithm the reference applies to it (mcts.cc:19,100,430-440,718) on the GPU.
  * kind 0: n raw pcg32 outputs (u32)      1: std::shuffle of iota(n), reps times (u32 [reps,n])
