@@ -26,7 +26,7 @@ def __getattr__(name):  # torch-dependent pieces are imported on first use
     raise AttributeError(name)
 
 __all__ = [
-    "EvalType", "PlayParams", "PlayManager", "GameState", "Connect4GS",
+    "EvalType", "PlayParams", "PlayManager", "GameState", "Connect4GS", "S3FIFOCache", "ShardedS3FIFOCache",
     "tracy_is_enabled", "tracy_frame_mark",
 ]
 
@@ -383,6 +383,62 @@ class PlayManager:
         p = np.zeros((n, self._M), np.float32)
         got = self.build_history_batch(c, v, p) if n else 0
         return c[:got], v[:got], p[:got]
+
+
+class ShardedS3FIFOCache:
+    """py_wrapper.cc:250-259 + find/insert of S3FIFOCache (:222-248), on the device (azmi_cache_*)."""
+
+    def __init__(self, max_size, shards, ghost_size, num_policy, num_value, device=0):
+        h = C.c_void_p()
+        rc = lib.azmi_cache_create(max_size, shards, ghost_size, num_policy, num_value, device, C.byref(h))
+        if rc != 0:
+            raise RuntimeError(lib.azmi_cache_last_error().decode())
+        self._h, self._np, self._nv = h, num_policy, num_value
+
+    def __del__(self):
+        if getattr(self, "_h", None) and lib is not None:
+            lib.azmi_cache_destroy(self._h)
+            self._h = None
+
+    def insert_many(self, hashes, policies, values):
+        h = np.ascontiguousarray(hashes, np.uint64)
+        p = np.ascontiguousarray(policies, np.float32).reshape(len(h), self._np)
+        v = np.ascontiguousarray(values, np.float32).reshape(len(h), self._nv)
+        if lib.azmi_cache_insert_many(self._h, h.ctypes.data, p.ctypes.data, v.ctypes.data, len(h)) != 0:
+            raise RuntimeError(lib.azmi_cache_last_error().decode())
+
+    def insert(self, hash, policy, value):
+        self.insert_many([hash], [policy], [value])
+
+    def find_many(self, hashes):
+        h = np.ascontiguousarray(hashes, np.uint64)
+        hit = np.zeros(len(h), np.uint8)
+        p = np.zeros((len(h), self._np), np.float32)
+        v = np.zeros((len(h), self._nv), np.float32)
+        if lib.azmi_cache_find_many(self._h, h.ctypes.data, len(h), hit.ctypes.data, p.ctypes.data, v.ctypes.data) != 0:
+            raise RuntimeError(lib.azmi_cache_last_error().decode())
+        return hit.astype(bool), p, v
+
+    def find(self, hash, num_policy=None, num_value=None):
+        hit, p, v = self.find_many([hash])
+        return (p[0], v[0]) if hit[0] else None
+
+    def _stats(self):
+        out = np.zeros(6, np.uint64)
+        lib.azmi_cache_stats(self._h, out.ctypes.data)
+        return [int(x) for x in out]
+
+    def hits(self): return self._stats()[0]
+    def misses(self): return self._stats()[1]
+    def evictions(self): return self._stats()[2]
+    def reinserts(self): return self._stats()[3]
+    def size(self): return self._stats()[4]
+    def max_size(self): return self._stats()[5]
+
+
+def S3FIFOCache(max_size, ghost_size, num_policy, num_value, device=0):
+    """py_wrapper.cc:222-248 — the single-shard cache."""
+    return ShardedS3FIFOCache(max_size, 1, ghost_size, num_policy, num_value, device)
 
 
 def run_rounds(pms, net, rounds, streams):

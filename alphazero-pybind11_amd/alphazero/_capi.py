@@ -86,6 +86,12 @@ SYMBOLS = {
     "azmi_net_destroy": (None, None),
     "azmi_net_forward": (C.c_int, None),
     "azmi_net_last_error": (C.c_char_p, None),
+    "azmi_cache_create": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _PP(_VP)]),
+    "azmi_cache_destroy": (None, [_VP]),
+    "azmi_cache_insert_many": (C.c_int, [_VP, _VP, _VP, _VP, C.c_uint32]),
+    "azmi_cache_find_many": (C.c_int, [_VP, _VP, C.c_uint32, _VP, _VP, _VP]),
+    "azmi_cache_stats": (C.c_int, [_VP, _VP]),
+    "azmi_cache_last_error": (C.c_char_p, []),
     "azmi_run_rounds": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, _VP]),
     "azmi_rng_probe": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_float, C.c_uint32, C.c_uint32, _VP]),
     "azmi_game_replay": (C.c_int, [C.c_int, C.c_int, _VP, C.c_uint32, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),

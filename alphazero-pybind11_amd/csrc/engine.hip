@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/azmi.h"
+#include "cache_host.h"
 #include "engine_kernels.h"
 
 using namespace azmi;
@@ -67,6 +68,12 @@ struct azmi_pm {
   hipStream_t last = nullptr;    // stream of the most recent round: result queries order themselves behind it
   hipStream_t pick(void* s) { last = (s == AZMI_STREAM_ENGINE) ? stream : static_cast<hipStream_t>(s); return last; }
   uint32_t hist_read = 0;
+  uint32_t cache_shards = 0;
+  // hipGraph of kGraphRounds x (round kernels + net) for azmi_run_rounds: one graph launch instead of
+  // ~5 kernel launches per round keeps the host ahead of the GPU
+  hipGraphExec_t graph_exec = nullptr;
+  hipStream_t graph_stream = nullptr;
+  azmi_net* graph_net = nullptr;
   // host-buffer compatibility path
   std::deque<uint32_t> pending;        // slots whose leaf waits for the net
   std::vector<float> host_v, host_pi;  // mirrors of the slot-indexed rows
@@ -84,6 +91,7 @@ struct azmi_pm {
     return AZMI_OK;
   }
   ~azmi_pm() {
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     for (void* q : allocs) (void)hipFree(q);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -107,6 +115,13 @@ int launch_round(azmi_pm* pm, hipStream_t st) {
   const uint32_t threads = 256;
   switch (pm->game) {
     case AZMI_GAME_CONNECT4: {
+      if (pm->ep.cache_on) {
+        k_cache_keys<Connect4><<<(pm->ep.S + 255) / 256, 256, 0, st>>>(pm->ep, pm->ar, pm->ar.cache_keys);
+        for (uint32_t off = 0; off < pm->ep.S; off += kApplyMax) {
+          const uint32_t m = std::min<uint32_t>(kApplyMax, pm->ep.S - off);
+          k_cache_insert<Connect4><<<(m + 3) / 4, 256, 0, st>>>(pm->ep, pm->ar, pm->ar.cache_keys, off, m);
+        }
+      }
       const uint32_t slots_per_block = threads / Connect4::GROUP;
       const uint32_t blocks = (pm->ep.S + slots_per_block - 1) / slots_per_block;
       k_round<Connect4><<<blocks, threads, 0, st>>>(pm->ep, pm->ar);
@@ -264,7 +279,6 @@ int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_o
   for (uint32_t i = 0; i < params->num_eval_type; ++i)
     if (params->eval_type[i] == AZMI_EVAL_PLAYOUT) return fail(AZMI_ERR_INVALID, "EvalType::PLAYOUT is not implemented on the device");
   if (params->resign_percent > 0 && gi.P != 2) return fail(AZMI_ERR_INVALID, "Resigning only works in 2 player games");
-  if (params->max_cache_size != 0) return fail(AZMI_ERR_INVALID, "device position cache is not available in this build; set max_cache_size=0");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(AZMI_ERR_NO_DEVICE, "no HIP device: libazmi has no CPU path");
@@ -337,6 +351,20 @@ int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_o
   A(h_meta, static_cast<size_t>(ep.hist_cap) * 4, false);
   A(log_rows, static_cast<size_t>(ep.log_cap) * 8, false);
   A(log_counts, static_cast<size_t>(ep.log_cap) * M, false);
+  // position cache: play_manager.cc:195-203 (one model group): ghost = 9/10 of the capacity.  The
+  // reference's cache_shards (<= 255) exists to spread a mutex; here a shard is one wavefront's worth
+  // of entries (64) and the unit of parallelism of the insert kernel.
+  ep.cache_on = params->max_cache_size > 0;
+  if (ep.cache_on) {
+    // wave-resident shards: 64 entries each (dev_cache.h); max_cache_size is rounded down to a multiple of 64
+    const uint32_t shards = std::max<uint32_t>(1, params->max_cache_size / kWaveCap);
+    pm->cache_shards = shards;
+    A(cache_keys, S, true);
+    if (rc != AZMI_OK || cache_alloc(ar.cache, pm->allocs, shards * kWaveCap, shards, static_cast<uint32_t>(static_cast<uint64_t>(shards) * kWaveCap * 9 / 10), M, P + 1) != hipSuccess) {
+      delete pm;
+      return fail(AZMI_ERR_OOM, "position cache allocation failed");
+    }
+  }
   ep.trace_slot = getenv("AZMI_TRACE_SLOT") ? static_cast<uint32_t>(atoi(getenv("AZMI_TRACE_SLOT"))) : 0xFFFFFFFFu;
   ep.trace_cap = ep.trace_slot != 0xFFFFFFFFu ? (1u << 16) : 1u;
   A(trace, 2 * static_cast<size_t>(ep.trace_cap), true);
@@ -372,18 +400,51 @@ int azmi_pm_round(azmi_pm* pm, void* stream) {
   return launch_round(pm, pm->pick(stream));
 }
 
+namespace {
+constexpr uint32_t kGraphRounds = 16;
+int one_round_with_net(azmi_pm* pm, azmi_net* net, hipStream_t st) {
+  int rc = launch_round(pm, st);
+  if (rc != AZMI_OK) return rc;
+  rc = azmi_net_forward(net, pm->ar.canon, pm->ar.v, pm->ar.pi, pm->ep.S, st);
+  if (rc != AZMI_OK) return fail(rc, "%s", azmi_net_last_error());
+  return AZMI_OK;
+}
+int ensure_graph(azmi_pm* pm, azmi_net* net, hipStream_t st) {
+  if (pm->graph_exec && pm->graph_stream == st && pm->graph_net == net) return AZMI_OK;
+  if (pm->graph_exec) { (void)hipGraphExecDestroy(pm->graph_exec); pm->graph_exec = nullptr; }
+  hipGraph_t graph = nullptr;
+  HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  int rc = AZMI_OK;
+  for (uint32_t r = 0; r < kGraphRounds && rc == AZMI_OK; ++r) rc = one_round_with_net(pm, net, st);
+  const hipError_t e = hipStreamEndCapture(st, &graph);
+  if (rc != AZMI_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  if (e != hipSuccess) return fail(AZMI_ERR_NO_DEVICE, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  const hipError_t e2 = hipGraphInstantiate(&pm->graph_exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e2 != hipSuccess) { pm->graph_exec = nullptr; return fail(AZMI_ERR_NO_DEVICE, "hipGraphInstantiate: %s", hipGetErrorString(e2)); }
+  pm->graph_stream = st;
+  pm->graph_net = net;
+  return AZMI_OK;
+}
+}  // namespace
+
 int azmi_run_rounds(azmi_pm* const* pms, azmi_net* net, uint32_t k, uint32_t rounds, void* const* streams) {
   if (!pms || !net || !streams || k == 0) return fail(AZMI_ERR_INVALID, "null argument");
-  for (uint32_t r = 0; r < rounds; ++r) {
+  const bool use_graph = getenv("AZMI_NO_GRAPH") == nullptr;
+  uint32_t done = 0;
+  if (use_graph) {
     for (uint32_t i = 0; i < k; ++i) {
-      azmi_pm* pm = pms[i];
-      hipStream_t st = pm->pick(streams[i]);
-      int rc = launch_round(pm, st);
+      const int rc = ensure_graph(pms[i], net, pms[i]->pick(streams[i]));
       if (rc != AZMI_OK) return rc;
-      rc = azmi_net_forward(net, pm->ar.canon, pm->ar.v, pm->ar.pi, pm->ep.S, st);
-      if (rc != AZMI_OK) return fail(rc, "%s", azmi_net_last_error());
     }
+    for (; done + kGraphRounds <= rounds; done += kGraphRounds)
+      for (uint32_t i = 0; i < k; ++i) HIP_TRY(hipGraphLaunch(pms[i]->graph_exec, pms[i]->graph_stream));
   }
+  for (; done < rounds; ++done)
+    for (uint32_t i = 0; i < k; ++i) {
+      const int rc = one_round_with_net(pms[i], net, pms[i]->pick(streams[i]));
+      if (rc != AZMI_OK) return rc;
+    }
   return AZMI_OK;
 }
 
@@ -478,6 +539,11 @@ int azmi_pm_counters(azmi_pm* pm, uint64_t* out) {
   out[0] = out[1] = 0;
   for (uint32_t s = 0; s < S; ++s) { out[0] += sims[s]; out[1] += evals[s]; }
   out[2] = 0; out[3] = 0;
+  if (pm->ep.cache_on) {
+    std::vector<unsigned long long> st;
+    rc = d2h(st, pm->ar.cache.stats, static_cast<size_t>(pm->ar.cache.shards) * 4, pm->last); if (rc) return rc;
+    for (uint32_t s = 0; s < pm->ar.cache.shards; ++s) { out[2] += st[static_cast<size_t>(s) * 4]; out[3] += st[static_cast<size_t>(s) * 4 + 1]; }
+  }
   out[4] = std::min(c.hist_rows, pm->ep.hist_cap) - pm->hist_read;
   out[5] = c.rounds;
   return AZMI_OK;

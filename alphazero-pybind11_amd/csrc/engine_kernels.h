@@ -666,10 +666,33 @@ struct SlotCtx {
   }
 
   // ---- leaf hand-off to the net: canonical planes + position key (play_manager.cc:589-598) ----------------
-  __device__ __forceinline__ void emit_leaf(const typename GM::State& leaf) const {
+  __device__ __forceinline__ uint64_t emit_leaf(const typename GM::State& leaf) const {
     float* row = ar.canon + static_cast<size_t>(slot) * GM::CANON;
     for (uint32_t e = lane; e < static_cast<uint32_t>(GM::CANON); e += G) row[e] = GM::canonical_at(leaf, e);
-    if (lane == 0) { ar.leaf_key[slot] = GM::key(leaf); ar.c_evals[slot] += 1; }
+    const uint64_t key = GM::key(leaf);
+    if (lane == 0) ar.leaf_key[slot] = key;
+    return key;
+  }
+  // position-cache probe (play_manager.cc:592-597): on a hit the cached (pi, v) land in the slot's rows
+  __device__ __forceinline__ bool cache_lookup(uint64_t key) const {
+    uint32_t sh;
+    const int cslot = wave_shard_find<G>(ar.cache, key, lane, &sh);
+    if (lane == 0) {  // hits / misses / freq; the ghost "reinserts" statistic is not kept for in-round probes
+      unsigned long long* st = ar.cache.stats + static_cast<size_t>(sh) * 4;
+      if (cslot < 0) {
+        atomicAdd(&st[1], 1ULL);
+      } else {
+        atomicAdd(&st[0], 1ULL);
+        uint32_t* f = ar.cache.freq + static_cast<size_t>(sh) * kWaveCap + cslot;
+        if (atomicAdd(f, 1u) >= 3u) atomicSub(f, 1u);
+      }
+    }
+    if (cslot < 0) return false;
+    const float* sp = ar.cache.policy + (static_cast<size_t>(sh) * ar.cache.cap + cslot) * M;
+    const float* sv = ar.cache.value + (static_cast<size_t>(sh) * ar.cache.cap + cslot) * (P + 1);
+    for (uint32_t e = lane; e < static_cast<uint32_t>(M); e += G) ar.pi[static_cast<size_t>(slot) * M + e] = sp[e];
+    if (lane <= static_cast<uint32_t>(P)) ar.v[static_cast<size_t>(slot) * (P + 1) + lane] = sv[lane];
+    return true;
   }
 };
 
@@ -708,11 +731,34 @@ __global__ __launch_bounds__(256, 1) void k_round(EngineParams ep, EngineArrays 
     if (!c.find_leaf(cp, leaf, term)) { c.store(kSlotDone); return; }
     const bool needs_net = term == 0 && !seat_param(ep.eval_random, cp);
     c.flags = needs_net ? (c.flags | kFlagLeafNeedsNet) : (c.flags & ~kFlagLeafNeedsNet);
-    if (needs_net) { c.emit_leaf(leaf); break; }
+    if (needs_net) {
+      const uint64_t key = c.emit_leaf(leaf);
+      const bool hit = ep.cache_on && c.cache_lookup(key);
+      if (!hit) {
+        if (lane == 0) ar.c_evals[slot] += 1;
+        break;
+      }
+    }
     need_process = true;
     if (++inline_sims >= ep.max_inline) break;
   }
   c.store(kSlotWaitEval);
+}
+
+// Inserts the leaves the net evaluated in the previous round into the position cache
+// (PlayManager::update_inferences -> insert_many, play_manager.cc:631-640): one lane per shard,
+// slots in slot order.
+template <class GM>
+__global__ __launch_bounds__(256) void k_cache_keys(EngineParams ep, EngineArrays ar, uint64_t* keys) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ep.S) return;
+  const bool on = !ar.ctl->stop && ar.sstate[s] == kSlotWaitEval && (ar.flags[s] & kFlagLeafNeedsNet);
+  keys[s] = on ? cache_key(ar.leaf_key[s]) : 0;
+}
+template <class GM>
+__global__ __launch_bounds__(256) void k_cache_insert(EngineParams ep, EngineArrays ar, const uint64_t* keys, uint32_t off, uint32_t n) {
+  __shared__ uint32_t s_sid[kApplyMax];
+  cache_apply_batch(ar.cache, keys + off, ar.pi + static_cast<size_t>(off) * GM::M, ar.v + static_cast<size_t>(off) * (GM::P + 1), n, s_sid);
 }
 
 // Deterministic restart / retire of the slots whose game ended in the previous round:

@@ -4,6 +4,8 @@
 #pragma once
 #include <stdint.h>
 
+#include "dev_cache.h"
+
 namespace azmi {
 
 // slot life cycle
@@ -45,6 +47,7 @@ struct EngineParams {  // run constants (PlayParams, play_manager.h:60-154, afte
   uint32_t hist_cap, log_cap, log_moves;
   uint32_t max_hist_rows;  // pending history rows per slot (= max moves of one game)
   uint32_t max_depth;      // path capacity per slot
+  uint32_t cache_on;       // device S3-FIFO position cache enabled (max_cache_size > 0)
   uint32_t trace_slot;     // debug: slot whose RNG events are traced (0xFFFFFFFF = off)
   uint32_t trace_cap;
 };
@@ -115,6 +118,8 @@ struct EngineArrays {
   // ---- move log (parity hook) -------------------------------------------------------------
   uint32_t* log_rows;     // [log_cap][8]
   uint32_t* log_counts;   // [log_cap][M]
+  uint64_t* cache_keys;   // [S] scratch: keys to insert this round (0 = none)
+  CacheView cache;        // position cache (s3fifo_cache.h), see dev_cache.h
   uint64_t* trace;        // debug [trace_cap][2]: tag, rng state; trace[0] = event count
 };
 

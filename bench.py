@@ -35,13 +35,16 @@ def parse():
     ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
     ap.add_argument("--sims", type=int, default=800)
     ap.add_argument("--engines", type=int, default=4, help="engine shards (HIP streams) per GPU")
+    ap.add_argument("--cache", type=int, default=32_000_000,
+                    help="max_cache_size per GPU (reference default 200000, config.py:197; sized up for 288 GB of HBM)")
+    ap.add_argument("--inline", type=int, default=0, help="max simulations finished per slot per round without the net (0 = engine default)")
     ap.add_argument("--net", choices=["hip", "torch"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
 
-def selfplay_params(az, games, sims, stream_games):
+def selfplay_params(az, games, sims, stream_games, cache=0):
     """self_play() settings, game_runner.py:2018-2041 with TrainConfig defaults (config.py:79-139,235-236);
     playout-cap randomisation is OFF so that every move is a full 800-simulation search."""
     pp = az.PlayParams()
@@ -65,6 +68,7 @@ def selfplay_params(az, games, sims, stream_games):
     pp.playout_cap_randomization = False
     pp.resign_percent = 0.02
     pp.resign_playthrough_percent = 0.20
+    pp.max_cache_size = cache
     return pp
 
 
@@ -112,8 +116,8 @@ def main():
     # cores another shard's tree kernel runs on the CUs the net leaves free.
     pms, streams = [], []
     for i in range(K):
-        pp = selfplay_params(az, Se, sims, stream_games)
-        pms.append(az.PlayManager(az.Connect4GS(), pp, seed=20240601 + 7919 * rank + 104729 * i, device=local_rank))
+        pp = selfplay_params(az, Se, sims, stream_games, cache=args.cache // K)
+        pms.append(az.PlayManager(az.Connect4GS(), pp, seed=20240601 + 7919 * rank + 104729 * i, device=local_rank, max_inline=args.inline))
         streams.append(torch.cuda.Stream(device=dev))
     sps = [st.cuda_stream for st in streams]
     io = [pm.io_tensors() for pm in pms]
@@ -153,7 +157,7 @@ def main():
                         e2.record(streams[0])
                 ev.append((e0, e1, e2))
                 done += 1
-            chunk = min(63 if ev is not None else 256, n - done)
+            chunk = min(64 if ev is not None else 256, n - done)
             if chunk <= 0:
                 continue
             if hip_net is not None:
@@ -173,16 +177,17 @@ def main():
     def totals():
         done = sum(pm.poll()[0] for pm in pms)
         cs = [pm.counters() for pm in pms]
-        return done, sum(c["sims"] for c in cs), sum(c["evals"] for c in cs)
+        return done, sum(c["sims"] for c in cs), sum(c["evals"] for c in cs), sum(c["cache_hits"] for c in cs), sum(c["cache_misses"] for c in cs)
 
     run_rounds(args.warmup)
     barrier()
-    done0, sims0, evals0 = totals()
+    done0, sims0, evals0, h0, m0 = totals()
     events = []
     t0 = time.perf_counter()
     run_rounds(args.steps, events)
     # the one exchange step: finished samples of this window go to rank 0 over RCCL/xGMI
-    done1, sims1, evals1 = totals()
+    done1, sims1, evals1, h1, m1 = totals()
+    hit_rate = (h1 - h0) / max(1, (h1 - h0) + (m1 - m0))
     gathered_rows = 0
     if world > 1:
         from alphazero import gather
@@ -225,6 +230,7 @@ def main():
                 "workload": f"Connect4, {S} concurrent games/GPU, {sims} sims/move, 6-block/64-ch ResNet (k3, 32 head ch), "
                             f"self-play flags of game_runner.py:2018-2041 with playout-cap off, random-init weights",
                 "concurrent_games_per_gpu": S, "engine_shards": K, "sims_per_move": sims, "net": net_kind,
+                "max_cache_size": args.cache, "cache_hit_rate": hit_rate,
                 "sims_per_s": n_sims / dt, "leaf_evals_per_s": n_evals / dt,
                 "tree_kernel_ms": tree_ms, "net_ms": nn_ms, "samples_gathered": gathered_rows,
                 "games_in_window": n_games,

@@ -180,6 +180,20 @@ void azmi_net_destroy(azmi_net* net);
 int azmi_net_forward(azmi_net* net, const float* dev_canonical, float* dev_v, float* dev_pi, uint32_t batch, void* stream);
 const char* azmi_net_last_error(void);
 
+/* ---- device position cache on its own: S3FIFOCache / ShardedS3FIFOCache (s3fifo_cache.h:15-318,
+ *      Python classes at py_wrapper.cc:222-259).  max_size / ghost_size are totals over `shards`;
+ *      shard = hash % shards.  insert_many keeps batch order inside a shard (eviction order is the
+ *      reference's); the finds of one call are concurrent.  All pointers are HOST arrays.
+ *      stats out[6] = hits, misses, evictions, reinserts, size, max_size. */
+typedef struct azmi_cache azmi_cache;
+int azmi_cache_create(uint32_t max_size, uint32_t shards, uint32_t ghost_size, uint32_t num_policy, uint32_t num_value,
+                      int device, azmi_cache** out);
+void azmi_cache_destroy(azmi_cache* cache);
+int azmi_cache_insert_many(azmi_cache* cache, const uint64_t* hashes, const float* policy, const float* value, uint32_t n);
+int azmi_cache_find_many(azmi_cache* cache, const uint64_t* hashes, uint32_t n, uint8_t* hit, float* policy, float* value);
+int azmi_cache_stats(azmi_cache* cache, uint64_t out[6]);
+const char* azmi_cache_last_error(void);
+
 /* ---- native round driver (the counterpart of GameRunner's batcher / gpu_loop / result_worker
  *      threads, game_runner.py:483-552, 651-726): `rounds` times, for each of the `k` engines in turn:
  *      one round on streams[i], then the net on that engine's slot-indexed leaf batch on the same

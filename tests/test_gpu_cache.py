@@ -1,0 +1,97 @@
+"""-m gpu: the device S3-FIFO cache against the oracle's restatement of s3fifo_cache.h, op by op, and the
+engine with the cache switched on (search results must not depend on the cache)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pv(key, np_=7, nv=3):
+    r = np.random.default_rng(int(key) & 0xFFFFFFFF)
+    return r.random(np_, dtype=np.float32), r.random(nv, dtype=np.float32)
+
+
+@pytest.mark.parametrize("max_size,shards,ghost", [(16, 1, 14), (64, 4, 56), (4, 1, 4), (1, 1, 1), (0, 1, 0), (256, 8, 0), (96, 3, 80),
+                                                    (64, 1, 57), (256, 4, 228), (128, 2, 0), (640, 10, 570)])  # last four: 64-entry wave-resident shards
+def test_device_cache_matches_oracle_op_by_op(oracle, max_size, shards, ghost):
+    """Random interleaving of insert batches and find batches over a small key universe, so that
+    promotion S->M, ghost re-admission, second-chance sweeps and the 2-bit frequency cap all occur
+    (s3fifo_cache_test.cc:28-600 behaviours).  Finds inside one batch use distinct keys (concurrent
+    finds of one key are order-free on the device and serial in the oracle)."""
+    import alphazero as az
+    dev = az.ShardedS3FIFOCache(max_size, shards, ghost, 7, 3)
+    orc = oracle.Cache(max_size, shards, ghost, 7, 3)
+    rng = np.random.default_rng(max_size * 1000 + shards)
+    universe = rng.integers(1, 2 ** 63, size=max(16, 3 * max_size + 8), dtype=np.uint64)
+    for step in range(200):
+        if rng.random() < 0.5:
+            keys = rng.choice(universe, size=rng.integers(1, 12))
+            pol = np.stack([_pv(k)[0] for k in keys]); val = np.stack([_pv(k)[1] for k in keys])
+            dev.insert_many(keys, pol, val)
+            for k, p, v in zip(keys, pol, val):
+                orc.insert(int(k), p, v)
+        else:
+            keys = rng.choice(universe, size=rng.integers(1, 12), replace=False)
+            hit, p, v = dev.find_many(keys)
+            for i, k in enumerate(keys):
+                want = orc.find(int(k))
+                assert bool(hit[i]) == (want is not None), (step, i, int(k))
+                if want is not None:
+                    assert np.array_equal(p[i], want[0]) and np.array_equal(v[i], want[1])
+        st = orc.stats()
+        got = dict(hits=dev.hits(), misses=dev.misses(), evictions=dev.evictions(), reinserts=dev.reinserts(), size=dev.size(), max_size=dev.max_size())
+        assert got == st, (step, got, st)
+
+
+def test_reference_python_surface():
+    """S3FIFOCache(max_size, ghost_size, num_policy, num_value).find/insert (py_wrapper.cc:222-248)."""
+    import alphazero as az
+    c = az.S3FIFOCache(4, 4, 2, 1)
+    assert c.find(123, 2, 1) is None and c.misses() == 1
+    c.insert(123, [0.25, 0.75], [0.5])
+    p, v = c.find(123, 2, 1)
+    assert p.tolist() == [0.25, 0.75] and v.tolist() == [0.5] and c.hits() == 1 and c.size() == 1 and c.max_size() == 4
+
+
+def _evaluator(canon):
+    n = canon.shape[0]
+    flat = canon.reshape(n, -1)
+    w = np.linspace(0.5, 1.5, flat.shape[1], dtype=np.float32)
+    s = flat @ w
+    v = np.stack([0.3 + 0.1 * np.sin(s), 0.3 - 0.1 * np.sin(s), np.full(n, 0.4)], 1).astype(np.float32)
+    pi = np.abs(np.sin(s[:, None] * np.arange(1, 8, dtype=np.float32))) + 0.05
+    return v, (pi / pi.sum(1, keepdims=True)).astype(np.float32)
+
+
+def test_engine_with_cache_is_transparent(oracle):
+    """With a deterministic evaluator the cache changes which leaves are evaluated, never the search:
+    moves / visit counts / RNG positions equal the oracle run WITHOUT a cache, and hits happen."""
+    import alphazero as az
+    pp = az.PlayParams()
+    pp.games_to_play, pp.concurrent_games, pp.max_batch_size = 12, 12, 12
+    pp.mcts_visits = [40, 40]
+    pp.cpuct, pp.fpu_reduction = 1.25, 0.25
+    pp.history_enabled = True
+    pp.max_cache_size = 4096
+    seed = 31
+    pm = az.PlayManager(az.Connect4GS(), pp, seed=seed, log_moves=True)
+    batch = np.zeros((12, 4, 6, 7), np.float32)
+    while pm.remaining_games() > 0:
+        idx = pm.build_batch(0, batch)
+        if not idx:
+            continue
+        v, pi = _evaluator(batch[: len(idx)])
+        pm.update_inferences(0, idx, v, pi)
+    rows, counts = pm.move_log()
+    c = pm.counters()
+    assert c["cache_hits"] > 0 and c["cache_misses"] > 0
+    assert c["evals"] < c["sims"]
+    for s in range(12):
+        one = az.PlayParams(); one.__dict__.update(pp.__dict__)
+        one.games_to_play, one.concurrent_games, one.max_cache_size = 1, 1, 0
+        o = oracle.PlayManager(oracle.GAME_CONNECT4, one, oracle.slot_seed(seed, s), per_slot_rng=False)
+        o.run(_evaluator)
+        orows, ocounts = o.moves()
+        sel = rows[:, 0] == s
+        assert np.array_equal(rows[sel][:, 2:], orows[:, 2:]), s
+        assert np.array_equal(counts[sel], ocounts), s
