@@ -26,7 +26,7 @@ def __getattr__(name):  # torch-dependent pieces are imported on first use
     raise AttributeError(name)
 
 __all__ = [
-    "EvalType", "PlayParams", "PlayManager", "GameState", "Connect4GS", "S3FIFOCache", "ShardedS3FIFOCache",
+    "EvalType", "PlayParams", "PlayManager", "GameState", "Connect4GS", "TawlbwrddGS", "S3FIFOCache", "ShardedS3FIFOCache",
     "tracy_is_enabled", "tracy_frame_mark",
 ]
 
@@ -184,6 +184,22 @@ class Connect4GS(GameState):  # py_wrapper.cc:562-580
 
 
 _ENGINE_STREAM = C.c_void_p(-1)  # AZMI_STREAM_ENGINE
+
+
+class TawlbwrddGS(GameState):  # py_wrapper.cc:549-551
+    GAME_ID = 1
+
+    def __init__(self, max_turns=400):
+        if max_turns != 400:
+            raise RuntimeError("the MI355X engine implements Tawlbwrdd with the default max_turns = 400")
+
+    @staticmethod
+    def NUM_SYMMETRIES():
+        return 8
+
+    @staticmethod
+    def POLICY_SHAPE():
+        return (22, 11, 11)
 
 
 def _f32(a):

@@ -98,3 +98,154 @@ struct Connect4 {
 };
 
 }  // namespace azmi
+
+// =====================================================================================================
+// Tawlbwrdd — 11x11 tafl (reference tawlbwrdd_gs.h:31-240, tawlbwrdd_gs.cc), on 121-bit bitboards.
+// Square index sq = h*11 + w; layer bitboards for defenders and attackers (2 x u64 each), the king
+// as a square index.  Move index = sq_from*22 + (column move ? 11 + new_h : new_w)
+// (tawlbwrdd_gs.cc:176-214, tafl_helper.h:7-14).
+//
+// Repetition (tawlbwrdd_gs.cc:253-259, 286-331): the reference keeps a map (board, player) -> count
+// that is cleared by every capture.  Here it is the LIST of 64-bit position keys since the last
+// capture; count(new position) = 1 + number of equal keys in the list (a 64-bit key collision would
+// be needed to differ from the reference's exact board comparison).
+// =====================================================================================================
+namespace azmi {
+
+struct Tawlbwrdd {
+  static constexpr int kGameId = 1;
+  static constexpr int P = 2;
+  static constexpr int W = 11, H = 11, SQ = 121;
+  static constexpr int M = SQ * (W + H);       // 2662
+  static constexpr int C = 7;
+  static constexpr int CANON = C * SQ;          // 847
+  static constexpr int MAXK = 512;              // children per node (hard cap; > any reachable position)
+  static constexpr int MAX_TURNS = 400;         // DEFAULT_MAX_TURNS, tawlbwrdd_gs.h:20
+  static constexpr int GROUP = 64;              // one wavefront per game slot
+  static constexpr uint32_t kNoKing = 127;
+  static constexpr int STATE_WORDS = 5;
+
+  struct State {
+    uint64_t def[2], atk[2];
+    uint32_t king;     // square of the king or kNoKing
+    uint32_t turn, player, rep;  // rep = current_repetition_count_
+  };
+
+  __host__ __device__ static bool bit(const uint64_t (&b)[2], uint32_t sq) { return ((sq < 64 ? b[0] : b[1]) >> (sq & 63)) & 1ULL; }
+  __host__ __device__ static void setb(uint64_t (&b)[2], uint32_t sq) { if (sq < 64) b[0] |= 1ULL << sq; else b[1] |= 1ULL << (sq - 64); }
+  __host__ __device__ static void clrb(uint64_t (&b)[2], uint32_t sq) { if (sq < 64) b[0] &= ~(1ULL << sq); else b[1] &= ~(1ULL << (sq - 64)); }
+
+  __host__ __device__ static State initial() {  // Lewis cross, tawlbwrdd_gs.h:91-135
+    State s{};
+    s.king = 5 * W + 5;
+    const int defs[12][2] = {{2,5},{3,5},{4,5},{5,4},{5,3},{5,2},{6,5},{7,5},{8,5},{5,6},{5,7},{5,8}};
+    for (auto& d : defs) setb(s.def, d[0] * W + d[1]);
+    const int atks[24][2] = {{0,4},{0,5},{0,6},{1,4},{1,5},{1,6},{9,4},{9,5},{9,6},{10,4},{10,5},{10,6},
+                             {4,0},{5,0},{6,0},{4,1},{5,1},{6,1},{4,9},{5,9},{6,9},{4,10},{5,10},{6,10}};
+    for (auto& a : atks) setb(s.atk, a[0] * W + a[1]);
+    s.turn = 0; s.player = 0; s.rep = 1;
+    return s;
+  }
+  __host__ __device__ static bool occupied(const State& s, uint32_t sq) { return bit(s.def, sq) || bit(s.atk, sq) || s.king == sq; }
+  // player 0 = attackers, player 1 = king side (tawlbwrdd_gs.h:26-29)
+  __host__ __device__ static bool own_piece(const State& s, uint32_t p, uint32_t sq) {
+    return p == 0 ? bit(s.atk, sq) : (bit(s.def, sq) || s.king == sq);
+  }
+  __host__ __device__ static bool empty_at(const State& s, int h, int w) {  // is_valid_square, tawlbwrdd_gs.cc:132-140
+    if (w < 0 || w >= W || h < 0 || h >= H) return false;
+    return !occupied(s, h * W + w);
+  }
+  // 22-bit target mask of the piece on sq: bits 0..10 = new_w (row slides), bits 11..21 = new_h
+  __host__ __device__ static uint32_t slide_mask(const State& s, uint32_t sq) {
+    const int h = sq / W, w = sq % W;
+    uint32_t m = 0;
+    for (int t = w + 1; empty_at(s, h, t); ++t) m |= 1u << t;
+    for (int t = w - 1; empty_at(s, h, t); --t) m |= 1u << t;
+    for (int t = h + 1; empty_at(s, t, w); ++t) m |= 1u << (W + t);
+    for (int t = h - 1; empty_at(s, t, w); --t) m |= 1u << (W + t);
+    return m;
+  }
+  __host__ __device__ static bool has_valid_moves(const State& s) {  // tawlbwrdd_gs.cc:142-174
+    for (uint32_t sq = 0; sq < SQ; ++sq) {
+      if (!own_piece(s, s.player, sq)) continue;
+      const int h = sq / W, w = sq % W;
+      if (empty_at(s, h, w + 1) || empty_at(s, h, w - 1) || empty_at(s, h + 1, w) || empty_at(s, h - 1, w)) return true;
+    }
+    return false;
+  }
+  __host__ __device__ static void remove_at(State& s, uint32_t sq) {
+    clrb(s.def, sq); clrb(s.atk, sq);
+    if (s.king == sq) s.king = kNoKing;
+  }
+  // custodial capture test, tawlbwrdd_gs.cc:222-244: mover on (fh,fw), victim one step along (dh,dw)
+  __host__ __device__ static bool captured(const State& s, uint32_t mover, int fh, int fw, int dh, int dw) {
+    const int th = fh + dh, tw = fw + dw;
+    if (tw < 0 || tw >= W || th < 0 || th >= H) return false;
+    if (!own_piece(s, mover ^ 1u, th * W + tw)) return false;
+    const int zh = th + dh, zw = tw + dw;
+    if (zw < 0 || zw >= W || zh < 0 || zh >= H) return false;
+    return own_piece(s, mover, zh * W + zw);
+  }
+  // tawlbwrdd_gs.cc:246-321 without the repetition bookkeeping; *captured_any tells the caller to clear it.
+  // Returns false on an illegal move (empty source or non-slide).
+  __host__ __device__ static bool apply_move(State& s, uint32_t mv, bool* captured_any) {
+    *captured_any = false;
+    if (mv >= static_cast<uint32_t>(M)) return false;
+    uint32_t new_loc = mv % (W + H);
+    const bool height_move = new_loc >= static_cast<uint32_t>(W);
+    if (height_move) new_loc -= W;
+    const uint32_t from = mv / (W + H);
+    const int ph = from / W, pw = from % W;
+    const int nh = height_move ? static_cast<int>(new_loc) : ph, nw = height_move ? pw : static_cast<int>(new_loc);
+    const uint32_t to = nh * W + nw;
+    const uint32_t mover = s.player;
+    if (!own_piece(s, mover, from)) return false;
+    if (s.king == from) s.king = to;
+    else if (bit(s.def, from)) { clrb(s.def, from); setb(s.def, to); }
+    else { clrb(s.atk, from); setb(s.atk, to); }
+    if (captured(s, mover, nh, nw, -1, 0)) { remove_at(s, (nh - 1) * W + nw); *captured_any = true; }
+    if (captured(s, mover, nh, nw, 1, 0)) { remove_at(s, (nh + 1) * W + nw); *captured_any = true; }
+    if (captured(s, mover, nh, nw, 0, -1)) { remove_at(s, nh * W + nw - 1); *captured_any = true; }
+    if (captured(s, mover, nh, nw, 0, 1)) { remove_at(s, nh * W + nw + 1); *captured_any = true; }
+    s.player ^= 1u;
+    ++s.turn;
+    return true;
+  }
+  // key of (board, player) — what the repetition map is keyed on (tawlbwrdd_gs.h:57-87)
+  __host__ __device__ static uint64_t rep_key(const State& s) {
+    uint64_t k = mix64(s.def[0] ^ 0x7A77ULL);
+    k = mix64(k ^ s.def[1]); k = mix64(k ^ s.atk[0]); k = mix64(k ^ s.atk[1]);
+    return mix64(k ^ (static_cast<uint64_t>(s.king) | (static_cast<uint64_t>(s.player) << 8)));
+  }
+  // position key for the evaluation cache: board, player and repetition count (tawlbwrdd_gs.cc:99-103)
+  __host__ __device__ static uint64_t key(const State& s) { return mix64(rep_key(s) ^ (static_cast<uint64_t>(s.rep) << 32)); }
+
+  // tawlbwrdd_gs.cc:345-397 — 0 running, else 1 + index of the winning score entry
+  __host__ __device__ static uint32_t terminal(const State& s) {
+    if (s.rep >= 3) return 1 + s.player;                     // the side to move is credited
+    if (s.king != kNoKing) {
+      const int h = s.king / W, w = s.king % W;
+      if (h == 0 || h == H - 1 || w == 0 || w == W - 1) return 2;  // king on an edge: defenders
+    } else {
+      return 1;                                              // no king: attackers
+    }
+    if (!has_valid_moves(s)) return 1 + (s.player ^ 1u);
+    if (s.turn >= static_cast<uint32_t>(MAX_TURNS)) return 3;
+    return 0;
+  }
+  // tawlbwrdd_gs.cc:399-453
+  __host__ __device__ static float canonical_at(const State& s, uint32_t e) {
+    const uint32_t plane = e / SQ, sq = e % SQ;
+    switch (plane) {
+      case 0: return s.king == sq ? 1.0f : 0.0f;
+      case 1: return bit(s.def, sq) ? 1.0f : 0.0f;
+      case 2: return bit(s.atk, sq) ? 1.0f : 0.0f;
+      case 3: return s.player == 0 ? 1.0f : 0.0f;
+      case 4: return s.player == 1 ? 1.0f : 0.0f;
+      case 5: return (s.rep == 1 || s.rep > 2) ? 1.0f : 0.0f;
+      default: return s.rep >= 2 ? 1.0f : 0.0f;
+    }
+  }
+};
+
+}  // namespace azmi

@@ -48,6 +48,10 @@ bool game_info(int game, GameInfo* gi) {
       *gi = GameInfo{Connect4::P, Connect4::M, Connect4::C, Connect4::H, Connect4::W, Connect4::MAXK,
                      Connect4::MAX_TURNS, 3};
       return true;
+    case AZMI_GAME_TAWLBWRDD:
+      *gi = GameInfo{Tawlbwrdd::P, Tawlbwrdd::M, Tawlbwrdd::C, Tawlbwrdd::H, Tawlbwrdd::W, Tawlbwrdd::MAXK,
+                     Tawlbwrdd::MAX_TURNS, Tawlbwrdd::STATE_WORDS};
+      return true;
     default:
       return false;
   }
@@ -167,6 +171,57 @@ __global__ void k_replay(const int32_t* moves, uint32_t n, uint32_t len, uint8_t
   }
   if (status) status[g] = stt;
   if (valid) for (int m = 0; m < GM::M; ++m) valid[static_cast<size_t>(g) * GM::M + m] = (GM::valid_mask(s) >> m) & 1u;
+  if (scores) {
+    const uint32_t t = GM::terminal(s);
+    for (int i = 0; i <= GM::P; ++i)
+      scores[static_cast<size_t>(g) * (GM::P + 1) + i] = t == 0 ? -1.0f : (static_cast<int>(t) - 1 == i ? 1.0f : 0.0f);
+  }
+  if (canonical) for (int e = 0; e < GM::CANON; ++e) canonical[static_cast<size_t>(g) * GM::CANON + e] = GM::canonical_at(s, e);
+  if (player) player[g] = s.player;
+  if (turn) turn[g] = s.turn;
+  if (key) key[g] = GM::key(s);
+}
+
+// Tawlbwrdd replay: one thread per game, repetition list in a global scratch row per game
+__global__ void k_replay_tafl(const int32_t* moves, uint32_t n, uint32_t len, uint64_t* rep_scratch, uint32_t rep_stride,
+                              uint8_t* valid, float* scores, float* canonical, uint32_t* player, uint32_t* turn,
+                              uint64_t* key, int32_t* status) {
+  using GM = Tawlbwrdd;
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  GM::State s = GM::initial();
+  uint64_t* reps = rep_scratch + static_cast<size_t>(g) * rep_stride;
+  uint32_t nrep = 0;
+  int32_t stt = 0;
+  for (uint32_t i = 0; i < len; ++i) {
+    const int32_t mv = moves[static_cast<size_t>(g) * len + i];
+    if (mv < 0) break;
+    bool legal = mv < GM::M;
+    if (legal) {
+      const uint32_t from = static_cast<uint32_t>(mv) / 22, tgt = static_cast<uint32_t>(mv) % 22;
+      legal = GM::own_piece(s, s.player, from) && ((GM::slide_mask(s, from) >> tgt) & 1u);
+    }
+    if (!legal) { stt = -1; break; }
+    if (s.turn == 0) { reps[0] = GM::rep_key(s); nrep = 1; }   // tawlbwrdd_gs.cc:253-259
+    bool cap = false;
+    GM::apply_move(s, static_cast<uint32_t>(mv), &cap);
+    if (cap) nrep = 0;
+    const uint64_t k = GM::rep_key(s);
+    uint32_t cnt = 1;
+    for (uint32_t j = 0; j < nrep; ++j) cnt += reps[j] == k;
+    if (nrep < rep_stride) reps[nrep++] = k;
+    s.rep = cnt;
+  }
+  if (status) status[g] = stt;
+  if (valid) {
+    uint8_t* vr = valid + static_cast<size_t>(g) * GM::M;
+    for (int m = 0; m < GM::M; ++m) vr[m] = 0;
+    for (uint32_t sq = 0; sq < static_cast<uint32_t>(GM::SQ); ++sq) {
+      if (!GM::own_piece(s, s.player, sq)) continue;
+      const uint32_t mask = GM::slide_mask(s, sq);
+      for (int b = 0; b < 22; ++b) if ((mask >> b) & 1u) vr[sq * 22 + b] = 1;
+    }
+  }
   if (scores) {
     const uint32_t t = GM::terminal(s);
     for (int i = 0; i <= GM::P; ++i)
@@ -694,6 +749,13 @@ int azmi_game_replay(int game, int device, const int32_t* moves, uint32_t n, uin
       case AZMI_GAME_CONNECT4:
         k_replay<Connect4><<<(n + 255) / 256, 256>>>(d_moves, n, len, d_valid, d_scores, d_canon, d_player, d_turn, d_key, d_status);
         break;
+      case AZMI_GAME_TAWLBWRDD: {
+        uint64_t* d_rep = nullptr;
+        const uint32_t stride = len + 2;
+        TRY2(dalloc(reinterpret_cast<void**>(&d_rep), static_cast<size_t>(n) * stride * 8));
+        k_replay_tafl<<<(n + 63) / 64, 64>>>(d_moves, n, len, d_rep, stride, d_valid, d_scores, d_canon, d_player, d_turn, d_key, d_status);
+        break;
+      }
       default: cleanup(); return fail(AZMI_ERR_INVALID, "game %d has no device kernels", game);
     }
     TRY2(hipGetLastError());
