@@ -16,6 +16,7 @@
 #include "../../include/azmi.h"
 #include "cache_host.h"
 #include "engine_kernels.h"
+#include "engine_kernels_big.h"
 
 using namespace azmi;
 
@@ -41,16 +42,17 @@ int fail(int code, const char* fmt, ...) {
 
 struct GameInfo {
   uint32_t P, M, C, H, W, maxk, max_turns, state_words;
+  uint32_t cap_branch;  // children per expansion the tree arena is sized for (== maxk when that is affordable)
 };
 bool game_info(int game, GameInfo* gi) {
   switch (game) {
     case AZMI_GAME_CONNECT4:
       *gi = GameInfo{Connect4::P, Connect4::M, Connect4::C, Connect4::H, Connect4::W, Connect4::MAXK,
-                     Connect4::MAX_TURNS, 3};
+                     Connect4::MAX_TURNS, 3, Connect4::MAXK};
       return true;
     case AZMI_GAME_TAWLBWRDD:
       *gi = GameInfo{Tawlbwrdd::P, Tawlbwrdd::M, Tawlbwrdd::C, Tawlbwrdd::H, Tawlbwrdd::W, Tawlbwrdd::MAXK,
-                     Tawlbwrdd::MAX_TURNS, Tawlbwrdd::STATE_WORDS};
+                     Tawlbwrdd::MAX_TURNS, Tawlbwrdd::STATE_WORDS, 160};
       return true;
     default:
       return false;
@@ -131,6 +133,9 @@ int launch_round(azmi_pm* pm, hipStream_t st) {
       k_round<Connect4><<<blocks, threads, 0, st>>>(pm->ep, pm->ar);
       break;
     }
+    case AZMI_GAME_TAWLBWRDD:
+      k_round_big<Tawlbwrdd><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
+      break;
     default:
       return fail(AZMI_ERR_INVALID, "game %d has no device kernels", pm->game);
   }
@@ -363,8 +368,12 @@ int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_o
   ep.max_depth = gi.max_turns + 2;
   // every search expands at most one node (<= maxk children) per simulation and a tree is
   // searched on at most ceil(max_turns/2) turns; re-rooting an empty tree expands once more.
-  const uint64_t cap64 = (static_cast<uint64_t>((gi.max_turns + 1) / 2) * max_visits + gi.max_turns) * gi.maxk + 8;
+  // Connect4: cap_branch == maxk, a hard bound.  Wide games: sized for the average branching factor and
+  // capped at 16 M nodes per tree; running out raises overflow bit 1 (arena compaction is the next step).
+  uint64_t cap64 = (static_cast<uint64_t>((gi.max_turns + 1) / 2) * max_visits + gi.max_turns) * gi.cap_branch + 8;
+  if (gi.cap_branch != gi.maxk) cap64 = std::min<uint64_t>(cap64, 16u << 20);
   if (cap64 > 0xFFFFFFF0ULL) { delete pm; return fail(AZMI_ERR_INVALID, "tree arena too large"); }
+  if (game != AZMI_GAME_CONNECT4 && params->max_cache_size != 0) { delete pm; return fail(AZMI_ERR_INVALID, "the device position cache is wired for Connect4 only in this build; set max_cache_size=0"); }
   ep.cap = static_cast<uint32_t>(cap64);
   ep.log_moves = opts.log_moves != 0;
   ep.log_cap = ep.log_moves ? (opts.move_log_capacity ? opts.move_log_capacity
@@ -385,6 +394,8 @@ int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_o
   A(cur, S, true); A(plen, S, true);
   A(path, static_cast<size_t>(S) * ep.max_depth, true);
   A(slot_games, S, true);
+  A(rep_list, game == AZMI_GAME_TAWLBWRDD ? static_cast<size_t>(S) * (gi.max_turns + 2) : 0, true);
+  A(rep_len, S, true);
   A(g_dsum, 5 * static_cast<size_t>(S), true); A(g_cnt, 3 * static_cast<size_t>(S), true);
   A(a_scores, static_cast<size_t>(S) * (P + 1), true); A(a_resign, static_cast<size_t>(S) * (P + 1), true);
   A(a_len, S, true); A(a_dsum, 5 * static_cast<size_t>(S), true); A(a_cnt, 3 * static_cast<size_t>(S), true);

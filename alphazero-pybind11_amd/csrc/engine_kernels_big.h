@@ -1,0 +1,758 @@
+// Tree + game-step kernel for games with wide nodes and a large action space (the Tafl family:
+// ~113 children per node on average, 2662 moves).  Same algorithm and the same reference citations as
+// engine_kernels.h; what changes is the mapping:
+//   * ONE WAVEFRONT PER GAME SLOT (workgroup = 64 lanes): control flow is wave-uniform, children are
+//     walked in chunks of 64 (consecutive lanes -> consecutive children of the SoA node arrays),
+//   * child scores / priors / visit counts are staged in LDS (per-wave scratch) so that the
+//     order-sensitive reductions of the reference (sums in child order, sums over the dense
+//     [num_moves] vector in move order) are plain in-order LDS sweeps,
+//   * legal moves are generated straight from the bitboards by all lanes (one or two squares per
+//     lane, wave prefix-sum for the ascending move order the reference's dense mask implies),
+//   * the repetition list of the game (keys since the last capture) is staged in LDS once per round;
+//     positions along the descent are appended to a path-local list, exactly the effect of the
+//     reference's per-simulation gs.copy() of the repetition map (tawlbwrdd_gs.cc:74-78).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dev_games.h"
+#include "dev_rng.h"
+#include "engine_kernels.h"
+#include "engine_types.h"
+
+namespace azmi {
+
+template <class GM>
+struct BigScratch {  // per-wave LDS
+  uint16_t moves[GM::MAXK];
+  float f0[GM::MAXK], f1[GM::MAXK], f2[GM::MAXK];
+  uint32_t n[GM::MAXK];
+  float dense[GM::M];
+  uint64_t glist[GM::MAX_TURNS + 2];  // game repetition list (since the last capture)
+  uint64_t plist[GM::MAX_TURNS + 2];  // path-local repetition list of the running descent
+};
+
+template <class GM>
+struct BigSlot {
+  static constexpr int G = 64, P = GM::P, M = GM::M, MAXK = GM::MAXK;
+  const EngineParams& ep;
+  const EngineArrays& ar;
+  BigScratch<GM>& sm;
+  uint32_t slot, lane;
+  Pcg32 rng, coin;
+  typename GM::State gs;
+  uint8_t flags;
+  uint32_t t_root[P], t_bump[P], t_depth[P];
+  uint64_t t_tld[P];
+  uint32_t cur, plen, ph_rows, glen;
+
+  __device__ BigSlot(const EngineParams& e, const EngineArrays& a, BigScratch<GM>& s, uint32_t sl, uint32_t l)
+      : ep(e), ar(a), sm(s), slot(sl), lane(l) {}
+
+  __device__ __forceinline__ size_t tree_base(uint32_t seat) const { return (static_cast<size_t>(slot) * P + seat) * ep.cap; }
+  __device__ __forceinline__ void raise(uint32_t bit) const { if (lane == 0) { atomicOr(&ar.ctl->overflow, bit); ar.ctl->stop = 1; } }
+  __device__ __forceinline__ void sync() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __syncthreads(); }
+#define AZB_SEL(arr, seat) ((seat) == 0 ? arr[0] : arr[P > 1 ? 1 : 0])
+  __device__ __forceinline__ void set_seat(uint32_t (&arr)[P], uint32_t seat, uint32_t v) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == seat) arr[p] = v;
+  }
+  template <class T>
+  __device__ __forceinline__ T wave_sum(T v) const {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+  }
+
+  // ---- load / store -----------------------------------------------------------------------------------
+  __device__ void load() {
+    rng.state = ar.rng[slot]; coin.state = ar.coin[slot]; flags = ar.flags[slot];
+    const uint32_t S = ep.S;
+    const uint64_t w0 = ar.gs_words[0 * S + slot], w1 = ar.gs_words[1 * S + slot], w2 = ar.gs_words[2 * S + slot],
+                   w3 = ar.gs_words[3 * S + slot], w4 = ar.gs_words[4 * S + slot];
+    gs.def[0] = w0; gs.def[1] = w1; gs.atk[0] = w2; gs.atk[1] = w3;
+    gs.king = static_cast<uint32_t>(w4) & 0x7Fu; gs.turn = static_cast<uint32_t>(w4 >> 8) & 0xFFFFu;
+    gs.player = static_cast<uint32_t>(w4 >> 24) & 1u; gs.rep = static_cast<uint32_t>(w4 >> 32) & 0xFFu;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const uint32_t t = slot * P + p;
+      t_root[p] = ar.root[t]; t_bump[p] = ar.bump[t]; t_depth[p] = ar.depth[t]; t_tld[p] = ar.tld[t];
+    }
+    cur = ar.cur[slot]; plen = ar.plen[slot]; ph_rows = ar.ph_count[slot]; glen = ar.rep_len[slot];
+    const uint64_t* gl = ar.rep_list + static_cast<size_t>(slot) * (GM::MAX_TURNS + 2);
+    for (uint32_t i = lane; i < glen; i += G) sm.glist[i] = gl[i];
+    sync();
+  }
+  __device__ void store(uint8_t sstate) const {
+    if (lane != 0) return;
+    ar.rng[slot] = rng.state; ar.coin[slot] = coin.state; ar.flags[slot] = flags; ar.sstate[slot] = sstate;
+    const uint32_t S = ep.S;
+    ar.gs_words[0 * S + slot] = gs.def[0]; ar.gs_words[1 * S + slot] = gs.def[1];
+    ar.gs_words[2 * S + slot] = gs.atk[0]; ar.gs_words[3 * S + slot] = gs.atk[1];
+    ar.gs_words[4 * S + slot] = static_cast<uint64_t>(gs.king) | (static_cast<uint64_t>(gs.turn) << 8) |
+                                (static_cast<uint64_t>(gs.player) << 24) | (static_cast<uint64_t>(gs.rep) << 32);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const uint32_t t = slot * P + p;
+      ar.root[t] = t_root[p]; ar.bump[t] = t_bump[p]; ar.depth[t] = t_depth[p]; ar.tld[t] = t_tld[p];
+    }
+    ar.cur[slot] = cur; ar.plen[slot] = plen; ar.ph_count[slot] = ph_rows; ar.rep_len[slot] = glen;
+  }
+  __device__ void reset_tree(uint32_t seat) {
+    set_seat(t_root, seat, 0); set_seat(t_bump, seat, 1); set_seat(t_depth, seat, 0);
+#pragma unroll
+    for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == seat) t_tld[p] = 0;
+    const size_t tb = tree_base(seat);
+    if (lane == 0) { ar.N[tb] = 0; ar.Q[tb] = 0; ar.Pr[tb] = 0; ar.D[tb] = 0; ar.V[tb] = 0; ar.META[tb] = 0; }
+  }
+
+  // ---- repetition-aware move on a state; `list`/`len` is the list the new position is appended to --------
+  // base list = glist[0, glen) unless a capture cleared it (tawlbwrdd_gs.cc:246-332)
+  __device__ bool step_state(typename GM::State& st, uint32_t mv, uint64_t* list, uint32_t& len, bool& base_valid,
+                             uint32_t base_len) {
+    if (st.turn == 0) {  // the start position enters the map with count 1 at the first move
+      if (lane == 0) list[len] = GM::rep_key(st);
+      ++len;
+      sync();
+    }
+    bool cap = false;
+    if (!GM::apply_move(st, mv, &cap)) return false;
+    if (cap) { len = 0; base_valid = false; }
+    const uint64_t k = GM::rep_key(st);
+    uint32_t cnt = 0;
+    for (uint32_t i = lane; i < len; i += G) cnt += list[i] == k;
+    if (base_valid && list != sm.glist)
+      for (uint32_t i = lane; i < base_len; i += G) cnt += sm.glist[i] == k;
+    cnt = wave_sum(cnt) + 1;
+    sync();
+    if (lane == 0) list[len] = k;
+    ++len;
+    st.rep = cnt;
+    sync();
+    return true;
+  }
+
+  // ---- Node::add_children: legal moves ascending (from the bitboards), std::shuffle, append -------------
+  __device__ bool expand_node(uint32_t seat, uint32_t node, const typename GM::State& st, uint64_t meta_keep,
+                              uint32_t& c0_out, uint32_t& k_out) {
+    const size_t tb = tree_base(seat);
+    // move generation: lane handles squares lane and lane + 64
+    uint32_t base = 0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const uint32_t sq = half * 64 + lane;
+      uint32_t mask = 0;
+      if (sq < static_cast<uint32_t>(GM::SQ) && GM::own_piece(st, st.player, sq)) mask = GM::slide_mask(st, sq);
+      const uint32_t cnt = __builtin_popcount(mask);
+      uint32_t incl = cnt;  // inclusive wave scan
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if (lane >= static_cast<uint32_t>(off)) incl += o;
+      }
+      uint32_t pos = base + incl - cnt;
+      const uint32_t total = __shfl(incl, 63, 64);
+      if (base + total > static_cast<uint32_t>(MAXK)) { raise(8u); return false; }
+      uint32_t m = mask;
+      while (m) {
+        const uint32_t b = __builtin_ctz(m);
+        m &= m - 1;
+        sm.moves[pos++] = static_cast<uint16_t>(sq * 22 + b);
+      }
+      base += total;
+    }
+    const uint32_t k = base;
+    sync();
+    // std::shuffle (stl_algo.h:3729-3792), sequential on lane 0's copy of the stream
+    if (k > 1) {
+      if (lane == 0) {
+        uint32_t i = 1;
+        if ((k & 1u) == 0) {
+          const uint32_t j = lemire_below(rng, 2);
+          const uint16_t t = sm.moves[i]; sm.moves[i] = sm.moves[j]; sm.moves[j] = t;
+          ++i;
+        }
+        while (i != k) {
+          const uint32_t sr = i + 1, b1 = sr + 1;
+          const uint32_t x = lemire_below(rng, sr * b1);
+          const uint32_t p0 = x / b1, p1 = x % b1;
+          uint16_t t = sm.moves[i]; sm.moves[i] = sm.moves[p0]; sm.moves[p0] = t; ++i;
+          t = sm.moves[i]; sm.moves[i] = sm.moves[p1]; sm.moves[p1] = t; ++i;
+        }
+      }
+      const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(rng.state)));
+      const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(rng.state >> 32)));
+      rng.state = static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32);
+      sync();
+    }
+    const uint32_t c0 = AZB_SEL(t_bump, seat);
+    if (c0 + k > ep.cap) { raise(1u); return false; }
+    for (uint32_t i = lane; i < k; i += G) {
+      const size_t ci = tb + c0 + i;
+      ar.N[ci] = 0; ar.Q[ci] = 0.0f; ar.Pr[ci] = 0.0f; ar.D[ci] = 0.0f; ar.V[ci] = 0.0f;
+      ar.META[ci] = meta_pack(0, 0, sm.moves[i], 0, 0);
+    }
+    set_seat(t_bump, seat, c0 + k);
+    if (lane == 0) ar.META[tb + node] = meta_pack(c0, k, meta_mv(meta_keep), meta_player(meta_keep), meta_term(meta_keep));
+    c0_out = c0; k_out = k;
+    sync();
+    return true;
+  }
+
+  // in-order sum of sm.f0[0..k): every lane walks the same LDS words (broadcast reads), result uniform
+  __device__ __forceinline__ float seq_sum_f0(uint32_t k) const {
+    float s = 0.0f;
+    for (uint32_t i = 0; i < k; ++i) s += sm.f0[i];
+    return s;
+  }
+
+  // ---- Node::best_child over k children starting at c0 -------------------------------------------------------
+  __device__ uint32_t select_child(size_t tb, uint32_t c0, uint32_t k, float v_parent, uint32_t n_parent, float fpu_reduction) {
+    for (uint32_t i = lane; i < k; i += G) {
+      const size_t ci = tb + c0 + i;
+      const uint32_t n = ar.N[ci];
+      const float p = ar.Pr[ci];
+      sm.n[i] = n; sm.f1[i] = ar.Q[ci]; sm.f2[i] = p;
+      sm.f0[i] = n > 0 ? p : 0.0f;
+    }
+    sync();
+    // reference: seen_policy += c.policy only for visited children, in child order; adding the 0.0f of an
+    // unvisited child leaves the running sum unchanged, so the masked in-order sum is identical
+    const float seen = seq_sum_f0(k);
+    const float fpu_value = v_parent - fpu_reduction * sqrtf(seen);
+    const float sqrt_n = sqrtf(static_cast<float>(n_parent));
+    float best_u = -__builtin_inff();
+    uint32_t best_i = 0xFFFFFFFFu;
+    for (uint32_t i = lane; i < k; i += G) {
+      const uint32_t n = sm.n[i];
+      float u = (n == 0 ? fpu_value : sm.f1[i]) + ep.cpuct * sm.f2[i] * sqrt_n / static_cast<float>(n + 1);
+      if (u != u) u = (i == 0) ? __builtin_inff() : -__builtin_inff();
+      if (u > best_u || best_i == 0xFFFFFFFFu) { best_u = u; best_i = i; }
+    }
+    for (int off = 1; off < 64; off <<= 1) {
+      const float ou = __shfl_xor(best_u, off, 64);
+      const uint32_t oi = __shfl_xor(best_i, off, 64);
+      if (oi != 0xFFFFFFFFu && (best_i == 0xFFFFFFFFu || ou > best_u || (ou == best_u && oi < best_i))) { best_u = ou; best_i = oi; }
+    }
+    sync();
+    return best_i;
+  }
+
+  // ---- MCTS::find_leaf ------------------------------------------------------------------------------------------
+  __device__ bool find_leaf(uint32_t seat, typename GM::State& leaf, uint32_t& term) {
+    sync();
+    const size_t tb = tree_base(seat);
+    const uint32_t root = AZB_SEL(t_root, seat);
+    cur = root; plen = 0;
+    leaf = gs;
+    uint32_t path_len = 0;
+    bool base_valid = true;
+    uint64_t meta = ar.META[tb + cur];
+    uint32_t n = ar.N[tb + cur];
+    uint32_t* path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
+    while (n > 0 && meta_term(meta) == 0) {
+      if (plen >= ep.max_depth) { raise(8u); return false; }
+      if (lane == 0) path[plen] = cur;
+      ++plen;
+      const uint32_t k = meta_nch(meta), c0 = meta_ch0(meta);
+      if (k == 0) { raise(8u); return false; }
+      const float fpu = (cur == root && ep.root_fpu_zero) ? 0.0f : ep.fpu_reduction;
+      const uint32_t best = select_child(tb, c0, k, ar.V[tb + cur], n, fpu);
+      cur = c0 + best;
+      n = ar.N[tb + cur];
+      meta = ar.META[tb + cur];
+      if (!step_state(leaf, meta_mv(meta), sm.plist, path_len, base_valid, glen)) { raise(64u); return false; }
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == seat) t_tld[p] += plen;
+    term = meta_term(meta);
+    if (n == 0) {
+      term = GM::terminal(leaf);
+      const uint64_t keep = meta_pack(0, 0, meta_mv(meta), leaf.player, term);
+      uint32_t c0, k;
+      if (!expand_node(seat, cur, leaf, keep, c0, k)) return false;
+    }
+    return true;
+  }
+
+  // ---- MCTS::add_root_noise over the children whose priors sit in sm.f0[0..k) --------------------------------------
+  __device__ void add_root_noise(uint32_t k) {
+    double sum = 0.0;
+    if (ep.shaped && k > 1) {
+      const float Nf = static_cast<float>(k);
+      for (uint32_t i = lane; i < k; i += G) sm.f1[i] = az_logf(fminf(sm.f0[i], 0.01f) + 1e-20f);
+      sync();
+      float log_sum = 0.0f;
+      for (uint32_t i = 0; i < k; ++i) log_sum += sm.f1[i];
+      const float log_mean = log_sum / Nf;
+      sync();
+      for (uint32_t i = lane; i < k; i += G) sm.f1[i] = fmaxf(0.0f, sm.f1[i] - log_mean);
+      sync();
+      float shaped_sum = 0.0f;
+      for (uint32_t i = 0; i < k; ++i) shaped_sum += sm.f1[i];
+      const float uniform = 1.0f / Nf;
+      for (uint32_t i = 0; i < k; ++i) {
+        const float shaped = sm.f1[i];
+        float alpha_prop = (shaped_sum > 0) ? 0.5f * (shaped / shaped_sum + uniform) : uniform;
+        alpha_prop = fmaxf(alpha_prop, 1e-6f);
+        Gamma dist(kNoiseAlphaRatio * alpha_prop);
+        const float g = dist.draw(rng);
+        if (lane == 0) sm.f2[i] = g;
+        sum += g;
+      }
+    } else {
+      Gamma dist(kNoiseAlphaRatio / static_cast<float>(k));
+      for (uint32_t i = 0; i < k; ++i) {
+        const float g = dist.draw(rng);
+        if (lane == 0) sm.f2[i] = g;
+        sum += g;
+      }
+    }
+    sync();
+    for (uint32_t i = lane; i < k; i += G)
+      sm.f0[i] = sm.f0[i] * (1 - ep.epsilon) + ep.epsilon * sm.f2[i] / static_cast<float>(sum);
+    sync();
+  }
+
+  // ---- MCTS::process_result --------------------------------------------------------------------------------------------
+  __device__ void process_result(uint32_t seat, bool from_net, bool root_noise) {
+    sync();
+    const size_t tb = tree_base(seat);
+    const uint32_t root = AZB_SEL(t_root, seat);
+    const uint64_t meta = ar.META[tb + cur];
+    const uint32_t term = meta_term(meta);
+    float val[P + 1];
+    if (term != 0) {
+#pragma unroll
+      for (int i = 0; i <= P; ++i) val[i] = (static_cast<int>(term) - 1 == i) ? 1.0f : 0.0f;
+    } else {
+      const uint32_t k = meta_nch(meta), c0 = meta_ch0(meta);
+      if (from_net) {
+#pragma unroll
+        for (int i = 0; i <= P; ++i) val[i] = ar.v[static_cast<size_t>(slot) * (P + 1) + i];
+      } else {
+#pragma unroll
+        for (int i = 0; i <= P; ++i) val[i] = static_cast<float>(1.0 / (P + 1));
+      }
+      const float ksum = static_cast<float>(k & 0xFFu);  // dumb_eval: u8 sum wraps (game_state.h:167, shapes.h:14)
+      const bool is_root = cur == root;
+      const bool root_pow = is_root && ep.root_temp != 1.0f;
+      for (uint32_t i = lane; i < k; i += G) {
+        float p;
+        if (from_net) p = ar.pi[static_cast<size_t>(slot) * M + meta_mv(ar.META[tb + c0 + i])];
+        else p = (ksum == 0.0f) ? 0.0f : 1.0f / ksum;
+        if (root_pow) p = az_powf(p, 1.0f / ep.root_temp);
+        sm.f0[i] = p;
+      }
+      sync();
+      const float sum = seq_sum_f0(k);
+      sync();
+      for (uint32_t i = lane; i < k; i += G) sm.f0[i] = sm.f0[i] / sum;
+      sync();
+      if (is_root && root_noise) add_root_noise(k);
+      for (uint32_t i = lane; i < k; i += G) ar.Pr[tb + c0 + i] = sm.f0[i];
+    }
+    const uint32_t* path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
+    const float draw_share = val[P] / static_cast<int32_t>(P);
+    for (uint32_t base = 0; base < plen; base += G) {
+      const uint32_t i = base + lane;
+      if (i < plen) {
+        const uint32_t node = (i == plen - 1) ? cur : path[i + 1];
+        const uint32_t pp = meta_player(ar.META[tb + path[i]]);
+        const size_t ni = tb + node;
+        const float vv = ((pp == 0) ? val[0] : val[1]) + draw_share;
+        const uint32_t nn = ar.N[ni];
+        const float q = ar.Q[ni], d = ar.D[ni];
+        ar.Q[ni] = (q * static_cast<float>(nn) + vv) / static_cast<float>(nn + 1);
+        ar.D[ni] = (d * static_cast<float>(nn) + val[P]) / static_cast<float>(nn + 1);
+        if (nn == 0) ar.V[ni] = ((meta_player(ar.META[ni]) == 0) ? val[0] : val[1]) + draw_share;
+        ar.N[ni] = nn + 1;
+      }
+    }
+    if (lane == 0) {
+      const size_t ri = tb + root;
+      const uint32_t rn = ar.N[ri];
+      if (rn == 0) {
+        ar.V[ri] = ((meta_player(ar.META[ri]) == 0) ? val[0] : val[1]) + draw_share;
+        ar.D[ri] = val[P];
+      }
+      ar.N[ri] = rn + 1;
+      ar.c_sims[slot] += 1;
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == seat) t_depth[p] += 1;
+    sync();
+  }
+
+  // ---- dense [M] helpers on sm.dense ------------------------------------------------------------------------------------
+  __device__ __forceinline__ float dense_seq_sum() const {
+    float s = 0.0f;
+    for (uint32_t m = 0; m < static_cast<uint32_t>(M); ++m) s += sm.dense[m];
+    return s;
+  }
+  __device__ void dense_zero() { for (uint32_t m = lane; m < static_cast<uint32_t>(M); m += G) sm.dense[m] = 0.0f; sync(); }
+  __device__ void dense_div(float s) { for (uint32_t m = lane; m < static_cast<uint32_t>(M); m += G) sm.dense[m] = sm.dense[m] / s; sync(); }
+  __device__ void dense_pow(float e) {
+    if (e == 1.0f) return;
+    for (uint32_t m = lane; m < static_cast<uint32_t>(M); m += G) sm.dense[m] = az_powf(sm.dense[m], e);
+    sync();
+  }
+  // root children staged in LDS: moves, n (sm.n), q (f1), p (f2)
+  __device__ void stage_root(size_t tb, uint32_t c0, uint32_t k) {
+    for (uint32_t i = lane; i < k; i += G) {
+      const size_t ci = tb + c0 + i;
+      sm.moves[i] = static_cast<uint16_t>(meta_mv(ar.META[ci]));
+      sm.n[i] = ar.N[ci]; sm.f1[i] = ar.Q[ci]; sm.f2[i] = ar.Pr[ci];
+    }
+    sync();
+  }
+  // MCTS::probs into sm.dense (mcts.cc:575-618)
+  __device__ void probs(float temp, uint32_t k) {
+    dense_zero();
+    for (uint32_t i = lane; i < k; i += G) sm.dense[sm.moves[i]] = static_cast<float>(sm.n[i]);
+    sync();
+    const float count_sum = dense_seq_sum();
+    if (count_sum == 0) {
+      sync();
+      for (uint32_t i = lane; i < k; i += G) sm.dense[sm.moves[i]] = sm.f2[i];
+      sync();
+      if (temp != 0.0f) dense_pow(1.0f / temp);
+      dense_div(dense_seq_sum());
+      return;
+    }
+    if (temp == 0) {
+      float best = 0.0f;
+      for (uint32_t m = lane; m < static_cast<uint32_t>(M); m += G) best = fmaxf(best, sm.dense[m]);
+      for (int off = 32; off > 0; off >>= 1) best = fmaxf(best, __shfl_xor(best, off, 64));
+      uint32_t nb = 0;
+      for (uint32_t m = lane; m < static_cast<uint32_t>(M); m += G) nb += sm.dense[m] == best;
+      nb = wave_sum(nb);
+      const float pv = static_cast<float>(1.0 / static_cast<double>(nb));
+      sync();
+      for (uint32_t m = lane; m < static_cast<uint32_t>(M); m += G) sm.dense[m] = (sm.dense[m] == best) ? pv : 0.0f;
+      sync();
+      return;
+    }
+    dense_div(count_sum);
+    dense_pow(1 / temp);
+    dense_div(dense_seq_sum());
+  }
+  // MCTS::probs_pruned into sm.dense (mcts.cc:620-674), temp == 1 or general
+  __device__ void probs_pruned(float temp, uint32_t root_n, uint32_t k) {
+    if (root_n <= 1) { probs(temp, k); return; }
+    const float explore_scaling = ep.cpuct * sqrtf(static_cast<float>(root_n));
+    float best_sel = -1e30f;
+    for (uint32_t i = lane; i < k; i += G)
+      if (sm.n[i] != 0) {
+        const float sel = sm.f1[i] + explore_scaling * sm.f2[i] / static_cast<float>(sm.n[i] + 1);
+        if (sel > best_sel) best_sel = sel;
+      }
+    for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(best_sel, off, 64); if (o > best_sel) best_sel = o; }
+    dense_zero();
+    for (uint32_t i = lane; i < k; i += G) {
+      if (sm.n[i] == 0) continue;
+      const float gap = best_sel - sm.f1[i];
+      const float nf = static_cast<float>(sm.n[i]);
+      const float desired = (gap <= 0) ? nf : explore_scaling * sm.f2[i] / gap - 1.0f;
+      const float lo = (0.0f < desired) ? desired : 0.0f;
+      sm.dense[sm.moves[i]] = (lo < nf) ? lo : nf;
+    }
+    sync();
+    const float total = dense_seq_sum();
+    if (total == 0) { sync(); probs(temp, k); return; }
+    if (temp == 0) {
+      float best = sm.dense[0];
+      for (uint32_t m = 1; m < static_cast<uint32_t>(M); ++m) best = (best < sm.dense[m]) ? sm.dense[m] : best;
+      uint32_t cnt = 0;
+      for (uint32_t m = lane; m < static_cast<uint32_t>(M); m += G) cnt += sm.dense[m] == best;
+      cnt = wave_sum(cnt);
+      sync();
+      for (uint32_t m = lane; m < static_cast<uint32_t>(M); m += G) sm.dense[m] = (sm.dense[m] == best) ? 1.0f / static_cast<int32_t>(cnt) : 0.0f;
+      sync();
+      return;
+    }
+    dense_div(total);
+    if (temp != 1.0f) { dense_pow(1.0f / temp); dense_div(dense_seq_sum()); }
+  }
+  __device__ uint32_t pick_move() {  // mcts.cc:717-735 on sm.dense
+    const float choice = canonical01(rng) * 1.0f + 0.0f;
+    float sum = 0.0f;
+    for (uint32_t m = 0; m < static_cast<uint32_t>(M); ++m) {
+      sum += sm.dense[m];
+      if (sum > choice) return m;
+    }
+    for (int m = M - 1; m >= 0; --m)
+      if (sm.dense[m] > 0) return static_cast<uint32_t>(m);
+    raise(16u);
+    return 0;
+  }
+
+  __device__ bool update_root(uint32_t seat, uint32_t move) {
+    sync();
+    const size_t tb = tree_base(seat);
+    const uint32_t root = AZB_SEL(t_root, seat);
+    const uint64_t meta = ar.META[tb + root];
+    uint32_t k = meta_nch(meta), c0 = meta_ch0(meta);
+    if (k == 0 && !expand_node(seat, root, gs, meta, c0, k)) return false;
+    uint32_t hit = 0xFFFFFFFFu;
+    for (uint32_t i = lane; i < k; i += G)
+      if (meta_mv(ar.META[tb + c0 + i]) == move) hit = i;
+    for (int off = 32; off > 0; off >>= 1) hit = min(hit, __shfl_xor(hit, off, 64));
+    if (hit == 0xFFFFFFFFu) { raise(32u); return false; }
+    set_seat(t_root, seat, c0 + hit); set_seat(t_depth, seat, 0);
+#pragma unroll
+    for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == seat) t_tld[p] = 0;
+    return true;
+  }
+
+  __device__ void reapply_root_prior(uint32_t seat, bool noise) {
+    sync();
+    const size_t tb = tree_base(seat);
+    const uint32_t root = AZB_SEL(t_root, seat);
+    if (ar.N[tb + root] == 0) return;
+    const uint64_t meta = ar.META[tb + root];
+    const uint32_t k = meta_nch(meta), c0 = meta_ch0(meta);
+    const bool do_temp = ep.root_temp != 1.0f;
+    if (!do_temp && !(noise && k > 0)) return;
+    for (uint32_t i = lane; i < k; i += G) {
+      float p = ar.Pr[tb + c0 + i];
+      if (do_temp) p = az_powf(p, 1.0f / ep.root_temp);
+      sm.f0[i] = p;
+    }
+    sync();
+    if (do_temp) {
+      const float sum = seq_sum_f0(k);
+      sync();
+      if (sum > 0.0f) for (uint32_t i = lane; i < k; i += G) sm.f0[i] = sm.f0[i] / sum;
+      sync();
+    }
+    if (noise && k > 0) add_root_noise(k);
+    for (uint32_t i = lane; i < k; i += G) ar.Pr[tb + c0 + i] = sm.f0[i];
+    sync();
+  }
+
+  __device__ void start_game() {
+    gs = GM::initial();
+    for (uint32_t s = 0; s < static_cast<uint32_t>(P); ++s) reset_tree(s);
+    ph_rows = 0;
+    glen = 0;
+  }
+  __device__ void draw_capped() {
+    const bool capped = ep.cap_rand && (canonical01(coin) < ep.cap_percent);
+    flags = capped ? (flags | kFlagCapped) : (flags & ~kFlagCapped);
+  }
+
+  __device__ bool make_move(uint32_t cp) {
+    sync();
+    const size_t tb = tree_base(cp);
+    const bool capped = flags & kFlagCapped;
+    const uint32_t root = AZB_SEL(t_root, cp);
+    const uint64_t rmeta = ar.META[tb + root];
+    const uint32_t k = meta_nch(rmeta), c0 = meta_ch0(rmeta);
+    const uint32_t root_n = ar.N[tb + root];
+    stage_root(tb, c0, k);
+
+    float temp = ep.start_temp;
+    if (ep.half_life != 0) {
+      const float lambda = 0.693f / ep.half_life;
+      temp -= ep.final_temp;
+      temp *= az_expf(-lambda * gs.turn);
+      temp += ep.final_temp;
+    }
+    int resign_entry = -1;
+    if (ep.resign_percent > 0 && !(flags & kFlagPlaythrough)) {
+      float q = 0, d = 0; bool found = false;  // MCTS::root_value: in-order scan, strict >
+      for (uint32_t i = 0; i < k; ++i) {
+        const float qi = sm.f1[i];
+        if (sm.n[i] > 0 && qi > q) { q = qi; d = ar.D[tb + c0 + i]; found = true; }
+      }
+      if (!found && root_n > 0) { q = ar.V[tb + root]; d = ar.D[tb + root]; }
+      const float w = q - d / static_cast<int32_t>(P);
+      const float l = static_cast<float>(1.0 - static_cast<double>(w) - static_cast<double>(d));
+      const double resign_val = 1.0 - static_cast<double>(ep.resign_percent);
+      int entry = -1;
+      if (w > resign_val) entry = static_cast<int>(cp);
+      else if (l > resign_val) entry = static_cast<int>((cp + 1) % 2);
+      else if (d > resign_val) entry = P;
+      if (entry >= 0) {
+        if (canonical01(coin) < ep.resign_playthrough) flags |= kFlagPlaythrough;
+        else resign_entry = entry;
+      }
+    }
+    probs(temp, k);
+    const uint64_t rng_before = rng.state;
+    const uint32_t chosen = pick_move();
+    sync();
+
+    if (ep.log_moves) {
+      uint32_t row = 0;
+      if (lane == 0) row = atomicAdd(&ar.ctl->log_rows, 1u);
+      row = __shfl(row, 0, 64);
+      if (row < ep.log_cap) {
+        if (lane == 0) {
+          uint32_t* r = ar.log_rows + static_cast<size_t>(row) * 8;
+          r[0] = slot; r[1] = ar.slot_games[slot]; r[2] = chosen; r[3] = gs.turn; r[4] = cp; r[5] = capped ? 1u : 0u;
+          r[6] = static_cast<uint32_t>(rng_before); r[7] = static_cast<uint32_t>(rng_before >> 32);
+        }
+        uint32_t* cr = ar.log_counts + static_cast<size_t>(row) * M;
+        for (uint32_t m = lane; m < static_cast<uint32_t>(M); m += G) cr[m] = 0;
+        sync();
+        for (uint32_t i = lane; i < k; i += G) cr[sm.moves[i]] = sm.n[i];
+      } else {
+        raise(4u);
+      }
+    }
+    if (ep.history && !capped) {
+      if (ep.pruning && ep.epsilon > 0) probs_pruned(1.0f, root_n, k); else probs(1.0f, k);
+      const uint32_t r = ph_rows;
+      if (r < ep.max_hist_rows) {
+        float* crow = ar.ph_canon + (static_cast<size_t>(slot) * ep.max_hist_rows + r) * GM::CANON;
+        for (uint32_t e = lane; e < static_cast<uint32_t>(GM::CANON); e += G) crow[e] = GM::canonical_at(gs, e);
+        float* prow = ar.ph_pi + (static_cast<size_t>(slot) * ep.max_hist_rows + r) * M;
+        for (uint32_t m = lane; m < static_cast<uint32_t>(M); m += G) prow[m] = sm.dense[m];
+        if (lane == 0) {
+          uint32_t* pm = ar.ph_meta + (static_cast<size_t>(slot) * ep.max_hist_rows + r) * 2;
+          pm[0] = gs.player; pm[1] = gs.turn;
+        }
+        ph_rows = r + 1;
+      } else {
+        raise(2u);
+      }
+      sync();
+    }
+    {
+      const uint32_t dep = AZB_SEL(t_depth, cp);
+      const float ald = dep == 0 ? 0.0f : static_cast<float>(AZB_SEL(t_tld, cp)) / static_cast<float>(dep);
+      float ent = 0.0f;
+      const float kf = static_cast<float>(k);
+      if (!(kf <= 1 || root_n <= 1)) {
+        const float log_k = az_logf(kf);
+        const float total_n = static_cast<float>(root_n);
+        for (uint32_t i = lane; i < k; i += G) {
+          float t = 0.0f;
+          if (sm.n[i] > 0) { const float p = static_cast<float>(sm.n[i]) / total_n; t = p * az_logf(p); }
+          sm.f0[i] = t;
+        }
+        sync();
+        float e = 0.0f;
+        for (uint32_t i = 0; i < k; ++i) if (sm.n[i] > 0) e -= sm.f0[i];
+        ent = e / log_k;
+        sync();
+      }
+      if (lane == 0) {
+        const uint32_t S = ep.S;
+        if (!capped) { ar.g_dsum[0 * S + slot] += ald; ar.g_dsum[1 * S + slot] += ent; ar.g_cnt[1 * S + slot] += 1; }
+        else { ar.g_dsum[2 * S + slot] += ald; ar.g_dsum[3 * S + slot] += ent; ar.g_cnt[2 * S + slot] += 1; }
+        ar.g_dsum[4 * S + slot] += k;
+        ar.g_cnt[0 * S + slot] += 1;
+      }
+    }
+    for (uint32_t s = 0; s < static_cast<uint32_t>(P); ++s)
+      if (!update_root(s, chosen)) return true;
+    {
+      bool base_valid = true;
+      if (!step_state(gs, chosen, sm.glist, glen, base_valid, 0)) { raise(64u); return true; }
+      // persist the game's repetition list (whole list: a capture may have cleared it)
+      uint64_t* gl = ar.rep_list + static_cast<size_t>(slot) * (GM::MAX_TURNS + 2);
+      for (uint32_t i = lane; i < glen; i += G) gl[i] = sm.glist[i];
+    }
+    uint32_t term = GM::terminal(gs);
+    bool resigned = false;
+    if (term == 0 && resign_entry >= 0) { term = static_cast<uint32_t>(resign_entry) + 1; resigned = true; }
+    if (term != 0) { end_game(term, resigned); return true; }
+    draw_capped();
+    if (!ep.tree_reuse) {
+      for (uint32_t s = 0; s < static_cast<uint32_t>(P); ++s) reset_tree(s);
+    } else {
+      reapply_root_prior(gs.player, ep.epsilon > 0 && !(flags & kFlagCapped));
+    }
+    return false;
+  }
+
+  __device__ void end_game(uint32_t term, bool resigned) {
+    sync();
+    const uint32_t S = ep.S;
+    const uint32_t rows = ep.history ? ph_rows : 0u;
+    if (rows > 0) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&ar.ctl->hist_rows, rows);
+      base = __shfl(base, 0, 64);
+      if (base + rows <= ep.hist_cap) {
+        const uint32_t game_idx = ar.slot_games[slot];
+        for (uint32_t r = 0; r < rows; ++r) {
+          const size_t src = static_cast<size_t>(slot) * ep.max_hist_rows + r;
+          const size_t dst = static_cast<size_t>(base) + r;
+          for (uint32_t e = lane; e < static_cast<uint32_t>(GM::CANON); e += G) ar.h_canon[dst * GM::CANON + e] = ar.ph_canon[src * GM::CANON + e];
+          for (uint32_t m = lane; m < static_cast<uint32_t>(M); m += G) ar.h_pi[dst * M + m] = ar.ph_pi[src * M + m];
+          if (lane <= static_cast<uint32_t>(P)) ar.h_v[dst * (P + 1) + lane] = (lane == term - 1) ? 1.0f : 0.0f;
+          if (lane == 0) {
+            uint32_t* hm = ar.h_meta + dst * 4;
+            hm[0] = slot; hm[1] = game_idx; hm[2] = ar.ph_meta[src * 2 + 1]; hm[3] = ar.ph_meta[src * 2 + 0];
+          }
+        }
+      } else {
+        raise(2u);
+      }
+    }
+    ph_rows = 0;
+    if (lane == 0) {
+      ar.a_scores[static_cast<size_t>(slot) * (P + 1) + (term - 1)] += 1.0f;
+      if (resigned) ar.a_resign[static_cast<size_t>(slot) * (P + 1) + (term - 1)] += 1.0f;
+      ar.a_len[slot] += gs.turn;
+      for (int j = 0; j < 5; ++j) { ar.a_dsum[j * S + slot] += ar.g_dsum[j * S + slot]; ar.g_dsum[j * S + slot] = 0.0; }
+      for (int j = 0; j < 3; ++j) { ar.a_cnt[j * S + slot] += ar.g_cnt[j * S + slot]; ar.g_cnt[j * S + slot] = 0; }
+      ar.slot_games[slot] += 1;
+      const uint32_t pos = atomicAdd(&ar.ctl->ended_count, 1u);
+      ar.ended_list[pos] = slot;
+    }
+  }
+
+  __device__ uint64_t emit_leaf(const typename GM::State& leaf) const {
+    float* row = ar.canon + static_cast<size_t>(slot) * GM::CANON;
+    for (uint32_t e = lane; e < static_cast<uint32_t>(GM::CANON); e += G) row[e] = GM::canonical_at(leaf, e);
+    const uint64_t key = GM::key(leaf);
+    if (lane == 0) ar.leaf_key[slot] = key;
+    return key;
+  }
+};
+
+// One round for every slot of a wide-node game: one wavefront (= one workgroup) per slot.
+template <class GM>
+__global__ __launch_bounds__(64) void k_round_big(EngineParams ep, EngineArrays ar) {
+  __shared__ BigScratch<GM> sm;
+  const uint32_t slot = blockIdx.x, lane = threadIdx.x;
+  if (slot >= ep.S) return;
+  if (ar.ctl->stop) return;
+  const uint8_t st = ar.sstate[slot];
+  if (st == kSlotDone || st == kSlotEnded) return;
+  BigSlot<GM> c(ep, ar, sm, slot, lane);
+  c.load();
+  uint32_t inline_sims = 0;
+  bool need_process = (st == kSlotWaitEval);
+  if (!need_process) { c.start_game(); c.draw_capped(); }
+  for (;;) {
+    if (need_process) {
+      const uint32_t cp = c.gs.player;
+      const bool noise = ep.epsilon > 0 && !(c.flags & kFlagCapped);
+      c.process_result(cp, (c.flags & kFlagLeafNeedsNet) != 0, noise);
+      const uint32_t goal = (c.flags & kFlagCapped) ? ep.cap_visits : seat_param(ep.visits, cp);
+      if (((cp == 0) ? c.t_depth[0] : c.t_depth[GM::P > 1 ? 1 : 0]) >= goal) {
+        if (c.make_move(cp)) { c.store(kSlotEnded); return; }
+      }
+    }
+    const uint32_t cp = c.gs.player;
+    typename GM::State leaf;
+    uint32_t term = 0;
+    if (!c.find_leaf(cp, leaf, term)) { c.store(kSlotDone); return; }
+    const bool needs_net = term == 0 && !seat_param(ep.eval_random, cp);
+    c.flags = needs_net ? (c.flags | kFlagLeafNeedsNet) : (c.flags & ~kFlagLeafNeedsNet);
+    if (needs_net) {
+      c.emit_leaf(leaf);
+      if (lane == 0) ar.c_evals[slot] += 1;
+      break;
+    }
+    need_process = true;
+    if (++inline_sims >= ep.max_inline) break;
+  }
+  c.store(kSlotWaitEval);
+}
+
+}  // namespace azmi

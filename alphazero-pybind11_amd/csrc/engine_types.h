@@ -77,6 +77,8 @@ struct EngineArrays {
   uint32_t* plen;         // [S] MCTS::path_.size()
   uint32_t* path;         // [S][max_depth]
   uint32_t* slot_games;   // [S] games completed by the slot
+  uint64_t* rep_list;     // [S][max_turns + 2] repetition keys since the last capture (Tafl family)
+  uint32_t* rep_len;      // [S]
   // running totals of the slot's current game (GameData, play_manager.h:46-53)
   double* g_dsum;         // [5][S]: leaf depth, entropy, fast leaf depth, fast entropy, valid moves
   uint32_t* g_cnt;        // [3][S]: move_count, full_move_count, fast_move_count
