@@ -144,11 +144,94 @@ class PlayParams:
         return c
 
 
+class PlayHistory:
+    """One training sample (game_state.h:31-35, py_wrapper.cc:111-155): canonical [C,H,W], v [P+1], pi [M]."""
+
+    def __init__(self, canonical, v, pi):
+        if canonical is None or v is None or pi is None:
+            raise TypeError("PlayHistory(canonical, v, pi): arguments must not be None")
+        self._c = np.array(canonical, dtype=np.float32, order="C")
+        self._v = np.array(v, dtype=np.float32).reshape(-1)
+        self._pi = np.array(pi, dtype=np.float32).reshape(-1)
+        if self._c.ndim != 3:
+            raise RuntimeError("PlayHistory: canonical must have 3 dimensions")
+
+    def canonical(self):
+        return memoryview(self._c)
+
+    def v(self):
+        return self._v
+
+    def pi(self):
+        return self._pi
+
+
+def symmetries_batch(game_cls, canonical, v, pi, device=0, stream=None):
+    """All NUM_SYMMETRIES images of a batch of samples in one launch (azmi_symmetries).
+    numpy in -> numpy out ([n, NS, ...]); torch CUDA tensors in -> torch CUDA tensors out, no host copy."""
+    ns = game_cls.NUM_SYMMETRIES()
+    P, M, chw = game_cls._info()
+    if hasattr(canonical, "is_cuda"):
+        import torch
+        if not (canonical.is_cuda and v.is_cuda and pi.is_cuda):
+            raise RuntimeError("symmetries_batch: torch inputs must be CUDA tensors (numpy arrays take the staged path)")
+        c = canonical.contiguous().float(); vv = v.contiguous().float(); pp = pi.contiguous().float()
+        n = c.shape[0]
+        if tuple(c.shape[1:]) != tuple(chw) or tuple(vv.shape) != (n, P + 1) or tuple(pp.shape) != (n, M):
+            raise RuntimeError("Improper sample shapes")
+        oc = torch.empty((n, ns) + tuple(chw), dtype=torch.float32, device=c.device)
+        ov = torch.empty((n, ns, P + 1), dtype=torch.float32, device=c.device)
+        op = torch.empty((n, ns, M), dtype=torch.float32, device=c.device)
+        st = torch.cuda.current_stream(c.device).cuda_stream if stream is None else stream
+        rc = lib.azmi_symmetries(game_cls.GAME_ID, c.device.index, n, c.data_ptr(), vv.data_ptr(), pp.data_ptr(),
+                                 oc.data_ptr(), ov.data_ptr(), op.data_ptr(), 0, C.c_void_p(st))
+        if rc:
+            raise RuntimeError(lib.azmi_symmetries_last_error().decode())
+        return oc, ov, op
+    c = np.ascontiguousarray(canonical, np.float32); vv = np.ascontiguousarray(v, np.float32)
+    pp = np.ascontiguousarray(pi, np.float32)
+    n = c.shape[0]
+    if tuple(c.shape[1:]) != tuple(chw) or vv.shape != (n, P + 1) or pp.shape != (n, M):
+        raise RuntimeError("Improper sample shapes")
+    oc = np.zeros((n, ns) + tuple(chw), np.float32); ov = np.zeros((n, ns, P + 1), np.float32)
+    op = np.zeros((n, ns, M), np.float32)
+    rc = lib.azmi_symmetries(game_cls.GAME_ID, device, n, c.ctypes.data, vv.ctypes.data, pp.ctypes.data,
+                             oc.ctypes.data, ov.ctypes.data, op.ctypes.data, 1, None)
+    if rc:
+        raise RuntimeError(lib.azmi_symmetries_last_error().decode())
+    return oc, ov, op
+
+
+def tafl_symmetries(board, canonical, v, pi, device=0):
+    """eightSym for any square Tafl board (azmi_tafl_symmetries), numpy [n,...] in/out."""
+    c = np.ascontiguousarray(canonical, np.float32); vv = np.ascontiguousarray(v, np.float32)
+    pp = np.ascontiguousarray(pi, np.float32)
+    n, ch = c.shape[0], c.shape[1]
+    oc = np.zeros((n, 8) + c.shape[1:], np.float32); ov = np.zeros((n, 8, vv.shape[1]), np.float32)
+    op = np.zeros((n, 8, pp.shape[1]), np.float32)
+    if c.shape[2:] != (board, board) or pp.shape[1] != board * board * 2 * board:
+        raise RuntimeError("Improper sample shapes")
+    rc = lib.azmi_tafl_symmetries(board, ch, vv.shape[1], device, n, c.ctypes.data, vv.ctypes.data, pp.ctypes.data,
+                                  oc.ctypes.data, ov.ctypes.data, op.ctypes.data, 1, None)
+    if rc:
+        raise RuntimeError(lib.azmi_symmetries_last_error().decode())
+    return oc, ov, op
+
+
 class GameState:
-    """Static facts of a game class (py_wrapper.cc:157-189, 562-580)."""
+    """A game position (py_wrapper.cc:157-189).  The object is a start position plus the moves played
+    from it; every query (valid_moves, scores, canonicalized, ...) is answered by the device rules
+    kernels (azmi_game_replay_from) and memoised until the next play_move()."""
 
     GAME_ID = -1
 
+    def __init__(self):
+        self._init = None      # serialized start position (reference pickle image) or None = initial()
+        self._moves = []
+        self._snap = None
+        self._device = 0
+
+    # ---- statics ---------------------------------------------------------------------------
     @classmethod
     def _info(cls):
         p, m = C.c_uint32(), C.c_uint32()
@@ -168,28 +251,142 @@ class GameState:
     def CANONICAL_SHAPE(cls):
         return cls._info()[2]
 
+    # ---- instance surface ------------------------------------------------------------------
+    def _state(self):
+        if self._snap is None:
+            P, M, chw = self._info()
+            mv = np.array([self._moves + [-1]], dtype=np.int32)
+            out = dict(valid=np.zeros((1, M), np.uint8), scores=np.zeros((1, P + 1), np.float32),
+                       canonical=np.zeros((1,) + tuple(chw), np.float32), player=np.zeros(1, np.uint32),
+                       turn=np.zeros(1, np.uint32), key=np.zeros(1, np.uint64), status=np.zeros(1, np.int32))
+            init = None if self._init is None else np.frombuffer(self._init, np.uint8)
+            check(lib.azmi_game_replay_from(self.GAME_ID, self._device, None if init is None else init.ctypes.data,
+                                            0 if init is None else init.size, mv.ctypes.data, 1, mv.shape[1],
+                                            out["valid"].ctypes.data, out["scores"].ctypes.data, out["canonical"].ctypes.data,
+                                            out["player"].ctypes.data, out["turn"].ctypes.data, out["key"].ctypes.data,
+                                            out["status"].ctypes.data))
+            if out["status"][0] != 0:
+                raise RuntimeError("illegal move in the game record")
+            self._snap = out
+        return self._snap
+
+    def copy(self):
+        g = self.__class__.__new__(self.__class__)
+        g.__dict__.update(self.__dict__)
+        g._moves = list(self._moves)
+        return g
+
+    def __eq__(self, other):
+        if not isinstance(other, GameState) or other.GAME_ID != self.GAME_ID:
+            return False
+        a, b = self._state(), other._state()
+        return bool(a["player"][0] == b["player"][0] and a["turn"][0] == b["turn"][0]
+                    and np.array_equal(a["canonical"], b["canonical"]))
+
+    __hash__ = None
+
+    def current_turn(self):
+        return int(self._state()["turn"][0])
+
+    def current_player(self):
+        return int(self._state()["player"][0])
+
     def num_players(self):
         return self.NUM_PLAYERS()
 
     def num_moves(self):
         return self.NUM_MOVES()
 
+    def num_symmetries(self):
+        return self.NUM_SYMMETRIES()
 
-class Connect4GS(GameState):  # py_wrapper.cc:562-580
+    def relative_values(self):   # game_state.h:114
+        return False
+
+    def randomize_start(self):   # game_state.h:73 — no-op for both games
+        return None
+
+    def num_variants(self):      # game_state.h:76
+        return 0
+
+    def get_variant_id(self):    # game_state.h:79
+        return -1
+
+    def valid_moves(self):
+        return self._state()["valid"][0].copy()
+
+    def play_move(self, move):
+        move = int(move)
+        if not 0 <= move < self.NUM_MOVES():
+            raise RuntimeError(f"move {move} out of range")
+        self._moves.append(move)
+        self._snap = None
+
+    def scores(self):
+        sc = self._state()["scores"][0]
+        return None if sc[0] < 0 else sc.copy()
+
+    def canonicalized(self):
+        return self._state()["canonical"][0].copy()
+
+    def symmetries(self, base):
+        """GameState::symmetries(PlayHistory) -> list of NUM_SYMMETRIES PlayHistory (device gather)."""
+        oc, ov, op = symmetries_batch(self.__class__, base._c[None], base._v[None], base._pi[None], device=self._device)
+        return [PlayHistory(oc[0, i], ov[0, i], op[0, i]) for i in range(oc.shape[1])]
+
+
+class Connect4GS(GameState):  # py_wrapper.cc:562-586
     GAME_ID = 0
+
+    def __init__(self, board=None, player=0, turn=0):
+        super().__init__()
+        if board is not None:
+            b = np.ascontiguousarray(board, dtype=np.int8)
+            if b.shape != (2, 6, 7):
+                raise RuntimeError("Improper connect 4 board shape")
+            self._init = b.tobytes() + np.int8(player).tobytes() + np.int32(turn).tobytes()
 
     @staticmethod
     def NUM_SYMMETRIES():
         return 2
 
+    def to_bytes(self):          # connect4_gs.cc:172-178
+        st = self._state()
+        board = (st["canonical"][0, :2] != 0).astype(np.int8)
+        return board.tobytes() + np.int8(st["player"][0]).tobytes() + np.int32(st["turn"][0]).tobytes()
+
+    @classmethod
+    def from_bytes(cls, data):   # connect4_gs.cc:180-190
+        if len(data) != 89:
+            raise ValueError("Connect4GS::from_bytes: wrong size")
+        g = cls()
+        g._init = bytes(data)
+        return g
+
+    def __reduce__(self):        # ADD_GS_PICKLE, py_wrapper.cc:77-83
+        return (_c4_from_bytes, (self.to_bytes(),))
+
+    def __str__(self):           # connect4_gs.cc:192-208
+        st = self._state()
+        out = "Current Player: %d\n" % st["player"][0]
+        for h in range(6):
+            out += "".join("X" if st["canonical"][0, 0, h, w] == 1 else "O" if st["canonical"][0, 1, h, w] == 1 else "."
+                           for w in range(7)) + "\n"
+        return out + "\n"
+
+
+def _c4_from_bytes(data):
+    return Connect4GS.from_bytes(data)
+
 
 _ENGINE_STREAM = C.c_void_p(-1)  # AZMI_STREAM_ENGINE
 
 
-class TawlbwrddGS(GameState):  # py_wrapper.cc:549-551
+class TawlbwrddGS(GameState):  # py_wrapper.cc:549-560
     GAME_ID = 1
 
     def __init__(self, max_turns=400):
+        super().__init__()
         if max_turns != 400:
             raise RuntimeError("the MI355X engine implements Tawlbwrdd with the default max_turns = 400")
 
@@ -200,6 +397,16 @@ class TawlbwrddGS(GameState):  # py_wrapper.cc:549-551
     @staticmethod
     def POLICY_SHAPE():
         return (22, 11, 11)
+
+    def __str__(self):           # tawlbwrdd_gs.cc:460-484
+        st = self._state()
+        c = st["canonical"][0]
+        rep = 3 if (c[5, 0, 0] and c[6, 0, 0] and st["turn"][0] > 0) else 2 if c[6, 0, 0] else 1 if c[5, 0, 0] else 0
+        out = "Current Player: %d\nCurrent Turn: %d out of 400\nCurrent Repetition Count: %d\n" % (st["player"][0], st["turn"][0], rep)
+        for h in range(11):
+            out += "".join("@" if c[0, h, w] == 1 else "O" if c[1, h, w] == 1 else "X" if c[2, h, w] == 1 else "."
+                           for w in range(11)) + "\n"
+        return out + "\n"
 
 
 def _f32(a):
@@ -218,6 +425,8 @@ class PlayManager:
         if gs is None:
             raise TypeError("PlayManager(): gs must not be None")  # py::arg().none(false)
         game_id = gs.GAME_ID
+        if not isinstance(gs, type) and (gs._moves or gs._init is not None):
+            raise RuntimeError("the MI355X PlayManager starts every game from the game's initial position")
         nplayers = type(gs).NUM_PLAYERS() if not isinstance(gs, type) else gs.NUM_PLAYERS()
         self._game = gs if isinstance(gs, type) else type(gs)
         self._params = params

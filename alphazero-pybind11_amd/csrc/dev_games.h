@@ -34,6 +34,18 @@ struct Connect4 {
 
   __host__ __device__ static State initial() { return State{{0, 0}, 0, 0}; }
 
+  // Connect4GS::to_bytes image (connect4_gs.cc:172-190): int8 board[2][6][7], int8 player, int32 turn (LE)
+  static constexpr uint32_t SERIALIZED = 89;
+  __host__ __device__ static State from_bytes(const uint8_t* b) {
+    State s{{0, 0}, 0, 0};
+    for (uint32_t p = 0; p < 2; ++p)
+      for (uint32_t i = 0; i < 42; ++i)
+        if (b[p * 42 + i]) { if (p == 0) s.bb[0] |= 1ULL << i; else s.bb[1] |= 1ULL << i; }
+    s.player = b[84] & 1u;
+    s.turn = uint32_t(b[85]) | uint32_t(b[86]) << 8 | uint32_t(b[87]) << 16 | uint32_t(b[88]) << 24;
+    return s;
+  }
+
   // connect4_gs.cc:39-46 — bit w set iff column w's top cell is empty
   __host__ __device__ static uint32_t valid_mask(const State& s) {
     return static_cast<uint32_t>(~(s.bb[0] | s.bb[1]) & kTop);

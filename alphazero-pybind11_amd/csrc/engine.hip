@@ -163,11 +163,12 @@ int d2h(std::vector<T>& dst, const T* src, size_t n, hipStream_t st) {
 
 // ---- batched rules replay (parity tier T0) --------------------------------------------------------
 template <class GM>
-__global__ void k_replay(const int32_t* moves, uint32_t n, uint32_t len, uint8_t* valid, float* scores,
+__global__ void k_replay(const uint8_t* init, const int32_t* moves, uint32_t n, uint32_t len, uint8_t* valid, float* scores,
                          float* canonical, uint32_t* player, uint32_t* turn, uint64_t* key, int32_t* status) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
   typename GM::State s = GM::initial();
+  if (init) s = GM::from_bytes(init + static_cast<size_t>(g) * GM::SERIALIZED);
   int32_t stt = 0;
   for (uint32_t i = 0; i < len; ++i) {
     const int32_t mv = moves[static_cast<size_t>(g) * len + i];
@@ -733,9 +734,17 @@ int azmi_pm_update_inferences(azmi_pm* pm, const uint32_t* indices, uint32_t n, 
 int azmi_game_replay(int game, int device, const int32_t* moves, uint32_t n, uint32_t len, uint8_t* valid,
                      float* scores, float* canonical, uint32_t* player, uint32_t* turn, uint64_t* key,
                      int32_t* status) {
+  return azmi_game_replay_from(game, device, nullptr, 0, moves, n, len, valid, scores, canonical, player, turn, key, status);
+}
+
+int azmi_game_replay_from(int game, int device, const uint8_t* init, uint32_t init_stride, const int32_t* moves,
+                          uint32_t n, uint32_t len, uint8_t* valid, float* scores, float* canonical,
+                          uint32_t* player, uint32_t* turn, uint64_t* key, int32_t* status) {
   GameInfo gi;
   if (!game_info(game, &gi)) return fail(AZMI_ERR_INVALID, "unknown game id %d", game);
   if (!moves && n * len) return fail(AZMI_ERR_INVALID, "null moves");
+  if (init && (game != AZMI_GAME_CONNECT4 || init_stride != Connect4::SERIALIZED))
+    return fail(AZMI_ERR_INVALID, "start positions: Connect4 only, %u bytes per state (connect4_gs.cc:172-178)", unsigned(Connect4::SERIALIZED));
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(AZMI_ERR_NO_DEVICE, "no HIP device: libazmi has no CPU path");
   HIP_TRY(hipSetDevice(device));
@@ -748,6 +757,11 @@ int azmi_game_replay(int game, int device, const int32_t* moves, uint32_t n, uin
 #define TRY2(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(AZMI_ERR_NO_DEVICE, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
   TRY2(dalloc(reinterpret_cast<void**>(&d_moves), static_cast<size_t>(n) * len * 4));
   TRY2(hipMemcpy(d_moves, moves, static_cast<size_t>(n) * len * 4, hipMemcpyHostToDevice));
+  uint8_t* d_init = nullptr;
+  if (init && n) {
+    TRY2(dalloc(reinterpret_cast<void**>(&d_init), static_cast<size_t>(n) * init_stride));
+    TRY2(hipMemcpy(d_init, init, static_cast<size_t>(n) * init_stride, hipMemcpyHostToDevice));
+  }
   if (valid) TRY2(dalloc(reinterpret_cast<void**>(&d_valid), static_cast<size_t>(n) * gi.M));
   if (scores) TRY2(dalloc(reinterpret_cast<void**>(&d_scores), static_cast<size_t>(n) * V * 4));
   if (canonical) TRY2(dalloc(reinterpret_cast<void**>(&d_canon), static_cast<size_t>(n) * CANON * 4));
@@ -758,7 +772,7 @@ int azmi_game_replay(int game, int device, const int32_t* moves, uint32_t n, uin
   if (n) {
     switch (game) {
       case AZMI_GAME_CONNECT4:
-        k_replay<Connect4><<<(n + 255) / 256, 256>>>(d_moves, n, len, d_valid, d_scores, d_canon, d_player, d_turn, d_key, d_status);
+        k_replay<Connect4><<<(n + 255) / 256, 256>>>(d_init, d_moves, n, len, d_valid, d_scores, d_canon, d_player, d_turn, d_key, d_status);
         break;
       case AZMI_GAME_TAWLBWRDD: {
         uint64_t* d_rep = nullptr;

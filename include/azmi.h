@@ -160,6 +160,29 @@ int azmi_pm_update_inferences(azmi_pm* pm, const uint32_t* indices, uint32_t n, 
 int azmi_game_replay(int game, int device, const int32_t* moves, uint32_t n, uint32_t len,
                      uint8_t* valid, float* scores, float* canonical, uint32_t* player,
                      uint32_t* turn, uint64_t* key, int32_t* status);
+/* the same from given start positions: `init` is [n, init_stride] bytes, one serialized state per
+ * game in the reference's pickle image (Connect4GS::to_bytes, connect4_gs.cc:172-190: int8
+ * board[2][6][7], int8 player, int32 turn = 89 bytes; Connect4GS(board, player, turn) ctor,
+ * py_wrapper.cc:563-581). NULL = the game's initial position. Connect4 only in this round. */
+int azmi_game_replay_from(int game, int device, const uint8_t* init, uint32_t init_stride, const int32_t* moves,
+                          uint32_t n, uint32_t len, uint8_t* valid, float* scores, float* canonical,
+                          uint32_t* player, uint32_t* turn, uint64_t* key, int32_t* status);
+
+/* ---- training-sample symmetries (GameState::symmetries(PlayHistory), py_wrapper.cc:178;
+ *      connect4_gs.cc:151-170, tafl_helper.h:16-149, tawlbwrdd_gs.cc:455-458) ------------------
+ * `count` samples in: canon [count,C,H,W], v [count,P+1], pi [count,M]; out: the NUM_SYMMETRIES
+ * images of every sample, sample-major, in the reference's order (Connect4 {base, mirror}; Tafl
+ * {base, r, r^2, r^3, m(base), m(r), m(r^2), m(r^3)}): out_canon [count,NS,C,H,W], out_v
+ * [count,NS,P+1], out_pi [count,NS,M].  Pointers are DEVICE pointers (asynchronous on `stream`)
+ * unless host_buffers != 0 (then HOST arrays, staged through HBM, synchronous). */
+uint32_t azmi_num_symmetries(int game);
+int azmi_symmetries(int game, int device, uint32_t count, const float* canon, const float* v, const float* pi,
+                    float* out_canon, float* out_v, float* out_pi, int host_buffers, void* stream);
+/* the same for any square Tafl board (Brandubh 7, Tawlbwrdd 11, OpenTafl 11 share tafl_helper.h) */
+int azmi_tafl_symmetries(uint32_t board, uint32_t channels, uint32_t num_values, int device, uint32_t count,
+                         const float* canon, const float* v, const float* pi, float* out_canon, float* out_v,
+                         float* out_pi, int host_buffers, void* stream);
+const char* azmi_symmetries_last_error(void);
 
 /* ---- leaf policy/value network (the reference's NNArch forward + NNWrapper.process,
  *      neural_net.py:448-510, 800-823) as one fused MFMA kernel ---------------------------------

@@ -10,6 +10,7 @@
 #include "az_mcts.hpp"
 #include "az_playmanager.hpp"
 #include "az_rng.hpp"
+#include "az_symmetries.hpp"
 #include "az_tafl.hpp"
 
 using namespace orc;
@@ -293,6 +294,33 @@ void orc_cache_stats(void* c, uint64_t* out) {
   auto* s = static_cast<ShardedS3Fifo*>(c);
   out[0] = s->hits(); out[1] = s->misses(); out[2] = s->evictions(); out[3] = s->reinserts();
   out[4] = s->size(); out[5] = s->max_size();
+}
+
+// ---------------------------------------------------------------- symmetries
+// kind 0: Connect4 {base, mirror}; 1: tafl eightSym; 2: tafl mirrorWidth only; 3: tafl rot90Clockwise only.
+// canon [C][H][W], pi [num_moves], v [nv]; outputs are [nsym][...]; returns nsym.
+uint32_t orc_symmetries(int kind, int channels, int height, int width, uint32_t num_moves, uint32_t nv,
+                        const float* canon, const float* v, const float* pi,
+                        float* out_canon, float* out_v, float* out_pi) {
+  Sample b;
+  b.channels = channels; b.height = height; b.width = width;
+  b.canonical.assign(canon, canon + size_t(channels) * height * width);
+  b.v.assign(v, v + nv);
+  b.pi.assign(pi, pi + num_moves);
+  std::vector<Sample> syms;
+  switch (kind) {
+    case 0: syms = connect4_symmetries(b); break;
+    case 1: syms = eight_sym(b); break;
+    case 2: syms = {mirror_width(b)}; break;
+    case 3: syms = {rot90_clockwise(b)}; break;
+    default: return 0;
+  }
+  for (size_t s = 0; s < syms.size(); ++s) {
+    std::memcpy(out_canon + s * b.canonical.size(), syms[s].canonical.data(), b.canonical.size() * sizeof(float));
+    std::memcpy(out_v + s * nv, syms[s].v.data(), nv * sizeof(float));
+    std::memcpy(out_pi + s * num_moves, syms[s].pi.data(), size_t(num_moves) * sizeof(float));
+  }
+  return uint32_t(syms.size());
 }
 
 }  // extern "C"

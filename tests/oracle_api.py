@@ -325,3 +325,22 @@ class Cache:
     def stats(self):
         out = np.zeros(6, np.uint64); lib.orc_cache_stats(self.h, _p(out))
         return dict(zip(("hits", "misses", "evictions", "reinserts", "size", "max_size"), (int(x) for x in out)))
+
+
+# ------------------------------------------------------------------ symmetries
+SYM_CONNECT4, SYM_TAFL_EIGHT, SYM_TAFL_MIRROR, SYM_TAFL_ROT90 = 0, 1, 2, 3
+
+
+def symmetries(kind, canon, v, pi):
+    """orc::connect4_symmetries / eight_sym / mirror_width / rot90_clockwise on ONE sample.
+    canon [C,H,W], v [nv], pi [M] -> (canon [ns,C,H,W], v [ns,nv], pi [ns,M])."""
+    canon = np.ascontiguousarray(canon, np.float32); v = np.ascontiguousarray(v, np.float32)
+    pi = np.ascontiguousarray(pi, np.float32)
+    ns = {SYM_CONNECT4: 2, SYM_TAFL_EIGHT: 8}.get(kind, 1)
+    oc = np.zeros((ns,) + canon.shape, np.float32); ov = np.zeros((ns, v.size), np.float32)
+    op = np.zeros((ns, pi.size), np.float32)
+    lib.orc_symmetries.restype = C.c_uint32
+    got = lib.orc_symmetries(C.c_int(kind), C.c_int(canon.shape[0]), C.c_int(canon.shape[1]), C.c_int(canon.shape[2]),
+                             C.c_uint32(pi.size), C.c_uint32(v.size), _p(canon), _p(v), _p(pi), _p(oc), _p(ov), _p(op))
+    assert got == ns
+    return oc, ov, op

@@ -1,0 +1,83 @@
+"""GPU: the GameState object surface (py_wrapper.cc:157-189, 562-586) answered by the device rules
+kernels, against the oracle and the reference's connect4_gs_test.cc cases."""
+import pickle
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def az():
+    import alphazero
+    return alphazero
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    import oracle_api
+    return oracle_api
+
+
+def test_connect4_object_walk_matches_oracle(az, oracle):
+    rng = np.random.default_rng(7)
+    for game in range(6):
+        gs = az.Connect4GS(); og = oracle.Game(oracle.GAME_CONNECT4)
+        while gs.scores() is None:
+            assert gs.current_player() == og.player() and gs.current_turn() == og.turn()
+            vm = gs.valid_moves()
+            assert np.array_equal(vm, og.valid())
+            assert np.array_equal(gs.canonicalized(), og.canonical())
+            assert og.scores() is None
+            mv = int(rng.choice(np.flatnonzero(vm)))
+            gs.play_move(mv); og.play(mv)
+        assert np.array_equal(gs.scores(), og.scores())
+
+
+def test_connect4_from_board_ctor_and_pickle(az, oracle):
+    # connect4_gs_test.cc:104-171 style: a hand-built board, player to move wins by dropping in column 3
+    board = np.zeros((2, 6, 7), np.int8)
+    board[0, 5, 0] = board[0, 5, 1] = board[0, 5, 2] = 1
+    board[1, 4, 0] = board[1, 4, 1] = board[1, 4, 2] = 1
+    gs = az.Connect4GS(board, 0, 6)
+    assert gs.current_player() == 0 and gs.current_turn() == 6 and gs.scores() is None
+    assert np.array_equal(gs.valid_moves(), np.ones(7, np.uint8))
+    assert np.array_equal(gs.canonicalized()[:2], board.astype(np.float32))
+    twin = gs.copy()
+    assert twin == gs
+    gs.play_move(3)
+    assert twin != gs
+    assert np.array_equal(gs.scores(), np.array([1, 0, 0], np.float32))
+    assert twin.scores() is None
+    blob = pickle.dumps(gs)
+    back = pickle.loads(blob)
+    assert back == gs and back.to_bytes() == gs.to_bytes() and len(gs.to_bytes()) == 89
+    assert str(gs).startswith("Current Player: 1\n") and str(gs).count("\n") == 8
+    with pytest.raises(RuntimeError):
+        az.Connect4GS(np.zeros((2, 6, 6), np.int8), 0, 0)
+    full = az.Connect4GS()
+    for _ in range(6):
+        full.play_move(0)
+    assert full.valid_moves()[0] == 0
+    full.play_move(0)
+    with pytest.raises(RuntimeError):
+        full.valid_moves()
+
+
+def test_tawlbwrdd_object_walk_matches_oracle(az, oracle):
+    rng = np.random.default_rng(8)
+    gs = az.TawlbwrddGS(); og = oracle.Game(oracle.GAME_TAWLBWRDD)
+    assert gs.num_symmetries() == 8 and gs.num_moves() == 2662 and gs.num_players() == 2
+    assert gs.relative_values() is False and gs.num_variants() == 0 and gs.get_variant_id() == -1
+    for ply in range(40):
+        if gs.scores() is not None:
+            break
+        vm = gs.valid_moves()
+        assert np.array_equal(vm, og.valid())
+        assert np.array_equal(gs.canonicalized(), og.canonical())
+        mv = int(rng.choice(np.flatnonzero(vm)))
+        gs.play_move(mv); og.play(mv)
+    assert gs.current_turn() == og.turn() and gs.current_player() == og.player()
+    s = str(gs)
+    assert s.startswith("Current Player:") and "@" in s

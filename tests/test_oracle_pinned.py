@@ -201,3 +201,100 @@ def test_s3fifo_reference_behaviour(oracle):
     for _ in range(10):
         c.find(1)
     assert c.stats()["hits"] >= 10
+
+
+# ---------------------------------------------------------------- symmetries (tafl_helper_test.cc)
+def _ploc(n, fh, fw, height_move, new_loc):  # tafl_helper.h:7-14
+    return (fh * n + fw) * (2 * n) + (n if height_move else 0) + new_loc
+
+
+def _spot_base():  # the 5x5 sample of TEST(TaflHelper, Mirror / Rot90), tafl_helper_test.cc:76-103
+    n = 5
+    canon = np.zeros((3, n, n), np.float32); pi = np.zeros(n * n * 2 * n, np.float32)
+    canon[0, 2, 1] = 1; canon[1, 2, 3] = 1; canon[1, 4, 1] = 1; canon[2, 2, 2] = 1
+    for hm, loc in ((False, 0), (False, 2), (True, 0), (True, 1), (True, 3)):
+        pi[_ploc(n, 2, 1, hm, loc)] = 1
+    for hm, loc in ((False, 1), (False, 4), (True, 0), (True, 3)):
+        pi[_ploc(n, 2, 2, hm, loc)] = 1
+    return n, canon, np.array([0.25, -0.5, 0.125], np.float32), pi
+
+
+def _expect(n, canon_cells, width_moves, height_moves):
+    canon = np.zeros((3, n, n), np.float32); pi = np.zeros(n * n * 2 * n, np.float32)
+    for c in canon_cells:
+        canon[c] = 1
+    for (fh, fw), locs in width_moves.items():
+        for x in locs:
+            pi[_ploc(n, fh, fw, False, x)] = 1
+    for (fh, fw), locs in height_moves.items():
+        for y in locs:
+            pi[_ploc(n, fh, fw, True, y)] = 1
+    return canon, pi
+
+
+def test_symmetry_mirror_known_answer(oracle):  # tafl_helper_test.cc:73-157
+    n, canon, v, pi = _spot_base()
+    oc, ov, op = oracle.symmetries(oracle.SYM_TAFL_MIRROR, canon, v, pi)
+    ec, ep = _expect(n, [(0, 2, 3), (1, 2, 1), (1, 4, 3), (2, 2, 2)],
+                     {(2, 3): (2, 4), (2, 2): (0, 3)}, {(2, 3): (0, 1, 3), (2, 2): (0, 3)})
+    assert np.array_equal(oc[0], ec) and np.array_equal(op[0], ep) and np.array_equal(ov[0], v)
+
+
+def test_symmetry_rot90_known_answer(oracle):  # tafl_helper_test.cc:159-241
+    n, canon, v, pi = _spot_base()
+    oc, ov, op = oracle.symmetries(oracle.SYM_TAFL_ROT90, canon, v, pi)
+    ec, ep = _expect(n, [(0, 1, 2), (1, 3, 2), (1, 1, 0), (2, 2, 2)],
+                     {(1, 2): (1, 3, 4), (2, 2): (1, 4)}, {(1, 2): (0, 2), (2, 2): (1, 4)})
+    assert np.array_equal(oc[0], ec) and np.array_equal(op[0], ep) and np.array_equal(ov[0], v)
+
+
+def _distinct(n):  # MakeDistinct, tafl_helper_test.cc:16-37
+    pi = np.arange(1, n * n * 2 * n + 1, dtype=np.float32)
+    canon = np.arange(1, 3 * n * n + 1, dtype=np.float32).reshape(3, n, n)
+    return canon, np.array([0.1, 0.2, 0.3], np.float32), pi
+
+
+def _equivariant(n, out_pi, base_pi, xf):  # ExpectGeometricEquivariance, tafl_helper_test.cc:328-353
+    span = 2 * n
+    for m in range(n * n * span):
+        nl = m % span; hm = nl >= n; nl -= n if hm else 0
+        fh, fw = divmod(m // span, n)
+        th, tw = (nl, fw) if hm else (fh, nl)
+        nf, nt = xf(fh, fw), xf(th, tw)
+        if nf == nt:
+            continue
+        nm = _ploc(n, nf[0], nf[1], False, nt[1]) if nf[0] == nt[0] else _ploc(n, nf[0], nf[1], True, nt[0])
+        assert out_pi[nm] == base_pi[m], (n, m)
+
+
+def test_symmetry_group_properties(oracle):  # tafl_helper_test.cc:268-326, 355-375
+    for n in (5, 7, 11):
+        canon, v, pi = _distinct(n)
+        rc, rv, rp = oracle.symmetries(oracle.SYM_TAFL_ROT90, canon, v, pi)
+        assert np.array_equal(np.sort(rp[0]), np.sort(pi)) and np.array_equal(rv[0], v)
+        c4, p4 = rc[0], rp[0]
+        for _ in range(3):
+            c4, _, p4 = oracle.symmetries(oracle.SYM_TAFL_ROT90, c4, v, p4); c4, p4 = c4[0], p4[0]
+        assert np.array_equal(c4, canon) and np.array_equal(p4, pi)
+        _equivariant(n, rp[0], pi, lambda h, w: (w, n - 1 - h))
+        mc, mv, mp = oracle.symmetries(oracle.SYM_TAFL_MIRROR, canon, v, pi)
+        assert np.array_equal(np.sort(mp[0]), np.sort(pi))
+        m2c, _, m2p = oracle.symmetries(oracle.SYM_TAFL_MIRROR, mc[0], v, mp[0])
+        assert np.array_equal(m2c[0], canon) and np.array_equal(m2p[0], pi)
+        _equivariant(n, mp[0], pi, lambda h, w: (h, n - 1 - w))
+    canon, v, pi = _distinct(7)
+    ec, ev, ep = oracle.symmetries(oracle.SYM_TAFL_EIGHT, canon, v, pi)
+    assert ec.shape[0] == 8 and np.array_equal(ec[0], canon) and np.array_equal(ep[0], pi)
+    for i in range(8):
+        assert np.array_equal(np.sort(ep[i]), np.sort(pi)) and np.array_equal(ev[i], v)
+        for j in range(i + 1, 8):
+            assert not np.array_equal(ep[i], ep[j])
+
+
+def test_symmetry_connect4(oracle):  # connect4_gs.cc:151-170
+    rng = np.random.default_rng(3)
+    canon = rng.random((4, 6, 7), dtype=np.float32); pi = rng.random(7, dtype=np.float32)
+    v = np.array([1, 0, 0], np.float32)
+    oc, ov, op = oracle.symmetries(oracle.SYM_CONNECT4, canon, v, pi)
+    assert np.array_equal(oc[0], canon) and np.array_equal(op[0], pi)
+    assert np.array_equal(oc[1], canon[:, :, ::-1]) and np.array_equal(op[1], pi[::-1]) and np.array_equal(ov[1], v)
