@@ -448,7 +448,7 @@ class PlayManager:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and lib is not None:   # `lib` is already None while the interpreter shuts down
             lib.azmi_pm_destroy(h)
             self._h = None
 

@@ -111,7 +111,7 @@ class HipLeafNet:
         self._h = h
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             lib.azmi_net_destroy(self._h)
             self._h = None
 

@@ -38,13 +38,16 @@ def parse():
     ap.add_argument("--cache", type=int, default=32_000_000,
                     help="max_cache_size per GPU (reference default 200000, config.py:197; sized up for 288 GB of HBM)")
     ap.add_argument("--inline", type=int, default=0, help="max simulations finished per slot per round without the net (0 = engine default)")
+    ap.add_argument("--hwq", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (0 = leave the runtime default of 4)")
+    ap.add_argument("--playout-cap", action="store_true", help="playout-cap randomisation at the TrainConfig defaults (config.py:86,100)")
     ap.add_argument("--net", choices=["hip", "torch"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short playout-cap-on measurement reported in config")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
 
-def selfplay_params(az, games, sims, stream_games, cache=0):
+def selfplay_params(az, games, sims, stream_games, cache=0, playout_cap=False):
     """self_play() settings, game_runner.py:2018-2041 with TrainConfig defaults (config.py:79-139,235-236);
     playout-cap randomisation is OFF so that every move is a full 800-simulation search."""
     pp = az.PlayParams()
@@ -65,7 +68,10 @@ def selfplay_params(az, games, sims, stream_games, cache=0):
     pp.root_fpu_zero = True
     pp.shaped_dirichlet = True
     pp.policy_target_pruning = True
-    pp.playout_cap_randomization = False
+    pp.playout_cap_randomization = bool(playout_cap)
+    if playout_cap:                      # config.py:86,100 and game_runner.py:2018-2041
+        pp.playout_cap_depth = 25
+        pp.playout_cap_percent = 0.75
     pp.resign_percent = 0.02
     pp.resign_playthrough_percent = 0.20
     pp.max_cache_size = cache
@@ -95,6 +101,8 @@ def cpu_baseline(az, sims, seconds):
 
 def main():
     args = parse()
+    if args.hwq:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(args.hwq)   # must be set before the HIP runtime starts
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -111,12 +119,15 @@ def main():
     S, sims, K = args.games, args.sims, args.engines
     assert S % K == 0
     Se = S // K                       # slots per engine shard
-    stream_games = max(Se, 8 * Se)    # stream pool, play_manager_bench.cc:171-181
+    # stream pool (play_manager_bench.cc:171-181: games_to_play = 8 x concurrent), widened when the run is
+    # long enough that a slot could finish more than 8 games: a dry stream would idle slots and void the number
+    rounds_per_game = 1000 if args.playout_cap else 4000        # conservative lower bounds (measured 2900 / 13000)
+    stream_games = Se * max(8, -(-(args.warmup + args.steps) // rounds_per_game))
     # K engine shards of S/K slots, one HIP stream each: while one shard's leaf batch is on the matrix
     # cores another shard's tree kernel runs on the CUs the net leaves free.
     pms, streams = [], []
     for i in range(K):
-        pp = selfplay_params(az, Se, sims, stream_games, cache=args.cache // K)
+        pp = selfplay_params(az, Se, sims, stream_games, cache=args.cache // K, playout_cap=args.playout_cap)
         pms.append(az.PlayManager(az.Connect4GS(), pp, seed=20240601 + 7919 * rank + 104729 * i, device=local_rank, max_inline=args.inline))
         streams.append(torch.cuda.Stream(device=dev))
     sps = [st.cuda_stream for st in streams]
@@ -187,6 +198,9 @@ def main():
     run_rounds(args.steps, events)
     # the one exchange step: finished samples of this window go to rank 0 over RCCL/xGMI
     done1, sims1, evals1, h1, m1 = totals()
+    live = sum(pm.poll()[1] for pm in pms)
+    if live != S:
+        raise RuntimeError(f"game stream ran dry inside the timed region ({live} of {S} slots live): raise stream_games")
     hit_rate = (h1 - h0) / max(1, (h1 - h0) + (m1 - m0))
     gathered_rows = 0
     if world > 1:
@@ -228,7 +242,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"Connect4, {S} concurrent games/GPU, {sims} sims/move, 6-block/64-ch ResNet (k3, 32 head ch), "
-                            f"self-play flags of game_runner.py:2018-2041 with playout-cap off, random-init weights",
+                            f"self-play flags of game_runner.py:2018-2041 with playout-cap {'ON (25 sims on 75% of moves)' if args.playout_cap else 'off'}, random-init weights",
                 "concurrent_games_per_gpu": S, "engine_shards": K, "sims_per_move": sims, "net": net_kind,
                 "max_cache_size": args.cache, "cache_hit_rate": hit_rate,
                 "sims_per_s": n_sims / dt, "leaf_evals_per_s": n_evals / dt,
@@ -242,6 +256,26 @@ def main():
                 "per_launch_event_ms": nn_ms, "definition": "sum of algorithmic FLOPs of all k_leafnet launches in the timed region / wall time of the region",
             },
         }
+        if world == 1 and hip_net is not None and not args.playout_cap and not args.no_secondary:
+            # the same workload with playout-cap randomisation at the reference's self-play defaults
+            # (fast_mcts_visits 25 on 75 % of moves, config.py:86,100): reported beside the headline, never as it
+            w2, k2 = 12000, 6000
+            pms2 = []
+            for i in range(K):
+                pp = selfplay_params(az, Se, sims, Se * 32, cache=args.cache // K, playout_cap=True)
+                pms2.append(az.PlayManager(az.Connect4GS(), pp, seed=977 + i, device=local_rank, max_inline=args.inline))
+            az.run_rounds(pms2, hip_net, w2, sps)
+            torch.cuda.synchronize()
+            d0 = sum(pm.poll()[0] for pm in pms2); s0 = sum(pm.counters()["sims"] for pm in pms2)
+            t2 = time.perf_counter()
+            az.run_rounds(pms2, hip_net, k2, sps)
+            d1 = sum(pm.poll()[0] for pm in pms2); s1 = sum(pm.counters()["sims"] for pm in pms2)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t2
+            live2 = sum(pm.poll()[1] for pm in pms2)
+            out["config"]["playout_cap_on"] = {"games_per_s": (d1 - d0) / dt2, "sims_per_s": (s1 - s0) / dt2, "steps": k2, "warmup": w2,
+                                               "live_slots": live2, "note": "25 sims on 75% of moves, 800 on the rest; secondary figure"}
+            del pms2
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(az, sims, args.cpu_seconds)
         print(json.dumps(out))
