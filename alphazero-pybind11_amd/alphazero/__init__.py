@@ -93,7 +93,7 @@ class PlayParams:
 
     # fields the device engine does not implement yet: anything but the default is an error
     _UNSUPPORTED = (
-        "temp_decay_half_life_by_variant", "gumbel_enabled", "seat_perms", "seat_visits", "seat_cap_visits",
+        "temp_decay_half_life_by_variant", "seat_perms", "seat_visits", "seat_cap_visits",
         "seat_epsilon", "seat_mcts_root_temp", "seat_root_fpu_zero", "seat_gumbel_enabled", "seat_gumbel_m",
         "seat_gumbel_c_visit", "seat_gumbel_c_scale", "seat_gumbel_full", "seat_gumbel_use_improved_policy",
         "seat_resign_threshold", "seat_resign_consecutive",
@@ -137,6 +137,12 @@ class PlayParams:
         c.policy_target_pruning = int(bool(self.policy_target_pruning))
         c.resign_percent = self.resign_percent
         c.resign_playthrough_percent = self.resign_playthrough_percent
+        c.gumbel_enabled = int(bool(self.gumbel_enabled))
+        c.gumbel_m = int(self.gumbel_m)
+        c.gumbel_c_visit = float(self.gumbel_c_visit)
+        c.gumbel_c_scale = float(self.gumbel_c_scale)
+        c.gumbel_full = int(bool(self.gumbel_full))
+        c.fast_search_uses_gumbel = int(bool(self.fast_search_uses_gumbel))
         ets = list(self.eval_type)
         c.num_eval_type = len(ets)
         for i, e in enumerate(ets[: _capi.AZMI_MAX_PLAYERS]):

@@ -41,6 +41,12 @@ class PlayParamsC(C.Structure):
         ("resign_playthrough_percent", C.c_float),
         ("num_eval_type", C.c_uint32),
         ("eval_type", C.c_int32 * AZMI_MAX_PLAYERS),
+        ("gumbel_enabled", C.c_int32),
+        ("gumbel_m", C.c_uint32),
+        ("gumbel_c_visit", C.c_float),
+        ("gumbel_c_scale", C.c_float),
+        ("gumbel_full", C.c_int32),
+        ("fast_search_uses_gumbel", C.c_int32),
     ]
 
 

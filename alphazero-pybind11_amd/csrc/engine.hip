@@ -311,6 +311,9 @@ void azmi_play_params_default(azmi_play_params* p) {  // play_manager.h:60-154
   p->mcts_root_temp = 1.0f;
   p->playout_cap_depth = 25;
   p->playout_cap_percent = 0.75f;
+  p->gumbel_m = 16;
+  p->gumbel_c_visit = 50.0f;
+  p->gumbel_c_scale = 1.0f;
 }
 void azmi_engine_opts_default(azmi_engine_opts* o) {
   std::memset(o, 0, sizeof(*o));
@@ -340,6 +343,10 @@ int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_o
   for (uint32_t i = 0; i < params->num_eval_type; ++i)
     if (params->eval_type[i] == AZMI_EVAL_PLAYOUT) return fail(AZMI_ERR_INVALID, "EvalType::PLAYOUT is not implemented on the device");
   if (params->resign_percent > 0 && gi.P != 2) return fail(AZMI_ERR_INVALID, "Resigning only works in 2 player games");
+  if (params->gumbel_enabled && game != AZMI_GAME_CONNECT4)
+    return fail(AZMI_ERR_INVALID, "gumbel_enabled: only the Connect4 engine implements Gumbel search in this round");
+  if (params->gumbel_enabled && params->gumbel_m > kGumMaxM)
+    return fail(AZMI_ERR_INVALID, "gumbel_m %u exceeds the engine limit %u", params->gumbel_m, kGumMaxM);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(AZMI_ERR_NO_DEVICE, "no HIP device: libazmi has no CPU path");
@@ -364,6 +371,11 @@ int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_o
   ep.shaped = params->shaped_dirichlet != 0; ep.pruning = params->policy_target_pruning != 0;
   for (uint32_t i = 0; i < gi.P; ++i)
     ep.eval_random[i] = params->num_eval_type ? (params->eval_type[i] == AZMI_EVAL_RANDOM) : 0;
+  ep.gumbel_on = params->gumbel_enabled != 0;
+  ep.gumbel_m = params->gumbel_m; ep.gumbel_full = params->gumbel_full != 0;
+  ep.fast_gumbel = params->fast_search_uses_gumbel != 0;
+  ep.gumbel_c_visit = params->gumbel_c_visit; ep.gumbel_c_scale = params->gumbel_c_scale;
+  ep.gum_stride = gi.maxk;
   ep.max_inline = opts.max_inline ? opts.max_inline : 4;
   ep.max_hist_rows = gi.max_turns;
   ep.max_depth = gi.max_turns + 2;
@@ -435,6 +447,11 @@ int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_o
   ep.trace_slot = getenv("AZMI_TRACE_SLOT") ? static_cast<uint32_t>(atoi(getenv("AZMI_TRACE_SLOT"))) : 0xFFFFFFFFu;
   ep.trace_cap = ep.trace_slot != 0xFFFFFFFFu ? (1u << 16) : 1u;
   A(trace, 2 * static_cast<size_t>(ep.trace_cap), true);
+  if (ep.gumbel_on) {
+    A(gum_state, static_cast<size_t>(S) * P * 8, true);
+    A(gum_g, static_cast<size_t>(S) * P * ep.gum_stride, true);
+    A(gum_surv, static_cast<size_t>(S) * P * kGumMaxM, true);
+  }
 #undef A
   if (rc != AZMI_OK) { delete pm; return rc; }
   if (hipDeviceSynchronize() != hipSuccess) { delete pm; return fail(AZMI_ERR_NO_DEVICE, "device sync failed"); }

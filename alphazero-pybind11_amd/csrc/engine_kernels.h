@@ -135,6 +135,201 @@ struct SlotCtx {
       if (static_cast<uint32_t>(p) == seat) { t_root[p] = 0; t_bump[p] = 1; t_depth[p] = 0; t_tld[p] = 0; }
     const size_t tb = tree_base(seat);
     if (lane == 0) { ar.N[tb] = 0; ar.Q[tb] = 0; ar.Pr[tb] = 0; ar.D[tb] = 0; ar.V[tb] = 0; ar.META[tb] = 0; }
+    if (ep.gumbel_on) set_gumbel_num_sims(seat, 0);   // a new MCTS object: target 0, nothing initialised
+  }
+
+  // ======================= Gumbel AlphaZero (mcts.cc:24-401) =========================================
+  // Per-tree record in HBM; every lane of the group computes the same scalars, lane 0 stores them.
+  enum { kGumTarget = 0, kGumInit = 1, kGumNSurv = 2, kGumPhase = 3, kGumSims = 4, kGumMEff = 5, kGumRemain = 6 };
+  __device__ __forceinline__ uint32_t* gum_state(uint32_t seat) const { return ar.gum_state + static_cast<size_t>(tree_id(seat)) * 8; }
+  __device__ __forceinline__ float* gum_g(uint32_t seat) const { return ar.gum_g + static_cast<size_t>(tree_id(seat)) * ep.gum_stride; }
+  __device__ __forceinline__ uint16_t* gum_surv(uint32_t seat) const { return ar.gum_surv + static_cast<size_t>(tree_id(seat)) * kGumMaxM; }
+
+  __device__ __forceinline__ void reset_gumbel_state(uint32_t seat) const {  // mcts.cc:180-188
+    if (lane != 0) return;
+    uint32_t* st = gum_state(seat);
+    st[kGumInit] = 0; st[kGumNSurv] = 0; st[kGumPhase] = 0; st[kGumSims] = 0; st[kGumMEff] = 0; st[kGumRemain] = 0;
+  }
+  __device__ __forceinline__ void set_gumbel_num_sims(uint32_t seat, uint32_t n) const {  // mcts.cc:175-178
+    if (lane == 0) gum_state(seat)[kGumTarget] = n;
+    reset_gumbel_state(seat);
+  }
+  // play_manager.cc:525-539 / 561-570: the search of the player to move is Gumbel only when it is a
+  // full search (or fast_search_uses_gumbel)
+  __device__ __forceinline__ void set_gumbel_target() const {
+    if (!ep.gumbel_on) return;
+    const uint32_t cp = gs.player;
+    const uint32_t target = (flags & kFlagCapped) ? (ep.fast_gumbel ? ep.cap_visits : 0u) : seat_param(ep.visits, cp);
+    set_gumbel_num_sims(cp, target);
+  }
+  // seq_halving_phase_plan, mcts.cc:28-66: returns the number of phases; (num_c, v_per) of phase `want`
+  __device__ __forceinline__ static uint32_t gum_plan(uint32_t m, uint32_t n, uint32_t want, uint32_t& num_c_out, uint32_t& v_per_out) {
+    num_c_out = 0; v_per_out = 0;
+    if (m <= 1) { if (want == 0) { num_c_out = 1; v_per_out = n; } return 1; }
+    uint32_t log2m = 0;
+    for (uint32_t v = m - 1; v > 0; v >>= 1) ++log2m;
+    if (log2m == 0) log2m = 1;
+    const uint32_t d0 = n / (log2m * m);
+    const uint32_t base_v = d0 > 1u ? d0 : 1u;
+    uint32_t sims_used = 0, num_c = m, count = 0;
+    for (uint32_t phase_idx = 0; phase_idx < log2m; ++phase_idx) {
+      if (sims_used >= n) break;
+      const uint32_t remaining = n - sims_used;
+      const bool is_final = (phase_idx == log2m - 1);
+      const uint32_t fin = remaining / num_c;
+      uint32_t v_per = is_final ? (fin > 1u ? fin : 1u) : base_v * (1u << phase_idx);
+      if (num_c * v_per > remaining) {
+        v_per = remaining / num_c;
+        if (v_per == 0) { num_c = remaining; v_per = 1; }
+      }
+      if (count == want) { num_c_out = num_c; v_per_out = v_per; }
+      ++count;
+      sims_used += num_c * v_per;
+      num_c = (num_c / 2) > 1u ? (num_c / 2) : 1u;
+    }
+    return count;
+  }
+  __device__ __forceinline__ float gumbel01() {  // extreme_value_distribution<float>{0,1}, random.tcc:2581-2590
+    return 0.0f - 1.0f * az_logf(-az_logf(1.0f - canonical01(rng)));
+  }
+  __device__ __forceinline__ uint32_t group_max(uint32_t x) const {
+    for (int off = 1; off < G; off <<= 1) x = max(x, __shfl_xor(x, off, G));
+    return x;
+  }
+  // init_gumbel_state, mcts.cc:190-227; root children (priors p_l) in lanes [0,k)
+  __device__ __forceinline__ void init_gumbel_state(uint32_t seat, uint32_t k, float p_l) {
+    if (k == 0) return;
+    uint32_t* st = gum_state(seat);
+    const uint32_t target = st[kGumTarget], depth = AZMI_SEL(t_depth, seat);
+    const uint32_t remaining = depth < target ? target - depth : 0u;
+    if (remaining == 0) return;
+    uint32_t m_eff = ep.gumbel_m < k ? ep.gumbel_m : k;
+    m_eff = m_eff < remaining ? m_eff : remaining;
+    m_eff = m_eff > 1u ? m_eff : 1u;
+    float g_l = 0.0f;
+    for (uint32_t i = 0; i < k; ++i) { const float gi = gumbel01(); if (lane == i) g_l = gi; }
+    const float score_l = g_l + az_logf(p_l + 1e-20f);
+    uint32_t rank_l = 0;  // position in the descending order of g + log(prior) (partial_sort, mcts.cc:214-221)
+    for (uint32_t j = 0; j < k; ++j) {
+      const float sj = bcast(score_l, j);
+      if (sj > score_l || (sj == score_l && j < lane)) ++rank_l;
+    }
+    if (lane < k) {
+      gum_g(seat)[lane] = g_l;
+      if (rank_l < m_eff) gum_surv(seat)[rank_l] = static_cast<uint16_t>(lane);
+    }
+    if (lane == 0) {
+      st[kGumInit] = 1; st[kGumNSurv] = m_eff; st[kGumPhase] = 0; st[kGumSims] = 0; st[kGumMEff] = m_eff; st[kGumRemain] = remaining;
+    }
+    sync_lanes();
+  }
+  // gumbel_next_root_child (mcts.cc:266-283) with gumbel_advance_phase (mcts.cc:229-264) inlined
+  __device__ __forceinline__ uint32_t gumbel_next_root_child(uint32_t seat, uint32_t k, uint32_t n_l, float q_l, float p_l) {
+    sync_lanes();
+    uint32_t* st = gum_state(seat);
+    uint16_t* surv = gum_surv(seat);
+    uint32_t nsurv = st[kGumNSurv], phase = st[kGumPhase], sims = st[kGumSims];
+    const uint32_t m_eff = st[kGumMEff], remain = st[kGumRemain];
+    uint32_t num_c, v_per;
+    const uint32_t nph = gum_plan(m_eff, remain, phase, num_c, v_per);
+    if (phase < nph && sims >= num_c * v_per && phase + 1 < nph) {
+      uint32_t next_c, next_v;
+      gum_plan(m_eff, remain, phase + 1, next_c, next_v);
+      if (next_c < nsurv) {
+        uint32_t pos_l = 0xFFFFu;
+        for (uint32_t i = 0; i < nsurv; ++i) if (surv[i] == lane) pos_l = i;
+        const bool is_s = pos_l != 0xFFFFu;
+        const uint32_t max_visit = group_max(is_s ? n_l : 0u);
+        const float sigma_scale = (ep.gumbel_c_visit + static_cast<float>(max_visit)) * ep.gumbel_c_scale;
+        const float g_l = lane < k ? gum_g(seat)[lane] : 0.0f;
+        const float score_l = g_l + az_logf(p_l + 1e-20f) + sigma_scale * (n_l > 0 ? q_l : 0.0f);
+        uint32_t rank_l = 0;
+        for (uint32_t j = 0; j < k; ++j) {
+          const float sj = bcast(score_l, j);
+          const uint32_t pj = bcast(pos_l, j);
+          if (pj != 0xFFFFu && (sj > score_l || (sj == score_l && pj < pos_l))) ++rank_l;
+        }
+        sync_lanes();
+        if (is_s && rank_l < next_c) surv[rank_l] = static_cast<uint16_t>(lane);
+        sync_lanes();
+        nsurv = next_c;
+      }
+      ++phase; sims = 0;
+    }
+    uint32_t child = 0;
+    if (nsurv != 0) { child = surv[sims % nsurv]; ++sims; }
+    if (lane == 0) { st[kGumNSurv] = nsurv; st[kGumPhase] = phase; st[kGumSims] = sims; }
+    return child;
+  }
+  // softmax(log prior + sigma * completedQ) over the children in lanes [0,k) (mcts.cc:285-373); returns this
+  // lane's exp term, the sum in z_sum
+  __device__ __forceinline__ float gumbel_pi_prime(uint32_t k, uint32_t n_l, float q_l, float p_l, float node_v, float& z_sum) const {
+    float sum_visits = 0.0f, sum_priors_visited = 0.0f, weighted_num = 0.0f;   // compute_v_mix_from_children, mcts.cc:71-89
+    for (uint32_t i = 0; i < k; ++i) {
+      const uint32_t ni = bcast(n_l, i); const float qi = bcast(q_l, i), pi = bcast(p_l, i);
+      sum_visits += static_cast<float>(ni);
+      if (ni > 0) { sum_priors_visited += pi; weighted_num += pi * qi; }
+    }
+    float v_mix = node_v;
+    if (!(sum_priors_visited <= 0.0f)) {
+      const float weighted_q = weighted_num / sum_priors_visited;
+      v_mix = (node_v + sum_visits * weighted_q) / (sum_visits + 1.0f);
+    }
+    const uint32_t max_visit = group_max(lane < k ? n_l : 0u);
+    const float sigma_scale = (ep.gumbel_c_visit + static_cast<float>(max_visit)) * ep.gumbel_c_scale;
+    float z = lane < k ? az_logf(p_l + 1e-20f) + sigma_scale * (n_l > 0 ? q_l : v_mix) : -__builtin_inff();
+    float z_max = -__builtin_inff();
+    for (uint32_t i = 0; i < k; ++i) { const float zi = bcast(z, i); if (zi > z_max) z_max = zi; }
+    z = lane < k ? az_expf(z - z_max) : 0.0f;
+    z_sum = seqsum(z, k);
+    return z;
+  }
+  // gumbel_interior_select, mcts.cc:285-334
+  __device__ __forceinline__ uint32_t gumbel_interior_select(uint32_t k, uint32_t n_l, float q_l, float p_l, float node_v) const {
+    float z_sum;
+    const float z = gumbel_pi_prime(k, n_l, q_l, p_l, node_v, z_sum);
+    uint32_t sum_visits = lane < k ? n_l : 0u;
+    for (int off = 1; off < G; off <<= 1) sum_visits += __shfl_xor(sum_visits, off, G);
+    const float inv = z_sum > 0 ? (1.0f / z_sum) : 0.0f;
+    const float denom = 1.0f + static_cast<float>(sum_visits);
+    float score = z * inv - static_cast<float>(n_l) / denom;
+    if (score != score || lane >= k) score = -__builtin_inff();   // `score > best_score` never picks a NaN
+    uint32_t idx = lane < k ? lane : 0xFFFFu;
+    for (int off = 1; off < G; off <<= 1) {
+      const float os = __shfl_xor(score, off, G);
+      const uint32_t oi = __shfl_xor(idx, off, G);
+      if (os > score || (os == score && oi < idx)) { score = os; idx = oi; }
+    }
+    return idx;
+  }
+  // gumbel_improved_policy, mcts.cc:336-373: dense [M] vector, lane m holds entry m
+  __device__ __forceinline__ float gumbel_improved_policy(uint32_t k, uint32_t mv_l, uint32_t n_l, float q_l, float p_l, float root_v) const {
+    if (k == 0) return 0.0f;
+    float z_sum;
+    const float z = gumbel_pi_prime(k, n_l, q_l, p_l, root_v, z_sum);
+    if (z_sum <= 0) return 0.0f;
+    return scatter_by_move<float>(k, mv_l, z / z_sum);
+  }
+  // gumbel_final_action, mcts.cc:375-401; returns the move
+  __device__ __forceinline__ uint32_t gumbel_final_action(uint32_t seat, uint32_t k, uint32_t mv_l, uint32_t n_l, float q_l, float p_l,
+                                                          uint32_t cnt_m, float pol_m) {
+    sync_lanes();
+    const uint32_t* st = gum_state(seat);
+    const uint32_t nsurv = st[kGumNSurv];
+    if (!st[kGumInit] || nsurv == 0) return pick_move(probs(0.0f, cnt_m, pol_m));
+    const uint16_t* surv = gum_surv(seat);
+    const uint32_t max_visit = group_max(lane < k ? n_l : 0u);
+    const float sigma_scale = (ep.gumbel_c_visit + static_cast<float>(max_visit)) * ep.gumbel_c_scale;
+    const float g_l = lane < k ? gum_g(seat)[lane] : 0.0f;
+    const float score_l = g_l + az_logf(p_l + 1e-20f) + sigma_scale * (n_l > 0 ? q_l : 0.0f);
+    uint32_t best = surv[0];
+    float best_score = -__builtin_inff();
+    for (uint32_t i = 0; i < nsurv; ++i) {
+      const uint32_t ci = surv[i];
+      const float sc = bcast(score_l, ci);
+      if (sc > best_score) { best_score = sc; best = ci; }
+    }
+    return bcast(mv_l, best);
   }
 
   // ---- Node::add_children: legal moves ascending, std::shuffle, append to the arena ----
@@ -222,6 +417,17 @@ struct SlotCtx {
     uint64_t meta = ar.META[tb + cur];
     uint32_t n = ar.N[tb + cur];
     uint32_t* path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
+    uint32_t gum_active = 0;   // (uint32_t: a bool carried across the descent loop is mis-tracked by hipcc in divergent groups)
+    if (ep.gumbel_on) {  // lazy init, mcts.cc:465-472
+      const uint32_t* st = gum_state(seat);
+      gum_active = st[kGumInit];
+      if (!gum_active && st[kGumTarget] > 0 && n > 0 && meta_nch(meta) != 0) {
+        const uint32_t k0 = meta_nch(meta);
+        const float p0 = lane < k0 ? ar.Pr[tb + meta_ch0(meta) + lane] : 0.0f;
+        init_gumbel_state(seat, k0, p0);
+        gum_active = gum_state(seat)[kGumInit];
+      }
+    }
     while (n > 0 && meta_term(meta) == 0) {
       if (plen >= ep.max_depth) { raise(8u); return false; }
       if (lane == 0) path[plen] = cur;
@@ -233,7 +439,10 @@ struct SlotCtx {
       if (lane < k) { n_l = ar.N[ci]; q_l = ar.Q[ci]; p_l = ar.Pr[ci]; m_l = ar.META[ci]; }
       const float fpu = (cur == root && ep.root_fpu_zero) ? 0.0f : ep.fpu_reduction;
       const float v_parent = ar.V[tb + cur];
-      const uint32_t best = select_child(k, n_l, q_l, p_l, v_parent, n, fpu);
+      uint32_t best;
+      if (gum_active && cur == root) best = gumbel_next_root_child(seat, k, n_l, q_l, p_l);
+      else if (gum_active && ep.gumbel_full) best = gumbel_interior_select(k, n_l, q_l, p_l, v_parent);
+      else best = select_child(k, n_l, q_l, p_l, v_parent, n, fpu);
       cur = c0 + best;
       n = bcast(n_l, best);
       meta = bcast(m_l, best);
@@ -313,7 +522,7 @@ struct SlotCtx {
       if (is_root && ep.root_temp != 1.0f && lane < k) p = az_powf(p, 1.0f / ep.root_temp);
       const float sum = seqsum(lane < k ? p : 0.0f, k);
       p = p / sum;
-      if (is_root && root_noise) { trace(1 | (static_cast<uint64_t>(k) << 8)); p = add_root_noise(k, p); trace(2); }
+      if (is_root && root_noise && !ep.gumbel_on) { trace(1 | (static_cast<uint64_t>(k) << 8)); p = add_root_noise(k, p); trace(2); }
       if (lane < k) ar.Pr[ci] = p;
     }
     // backup: level i updates node_i (child of path[i]); levels are independent -> one lane each
@@ -463,6 +672,7 @@ struct SlotCtx {
 #pragma unroll
     for (int p = 0; p < P; ++p)
       if (static_cast<uint32_t>(p) == seat) { t_root[p] = c0 + hit; t_depth[p] = 0; t_tld[p] = 0; }
+    if (ep.gumbel_on) reset_gumbel_state(seat);  // mcts.cc:172
     return true;
   }
 
@@ -542,9 +752,10 @@ struct SlotCtx {
       }
     }
     // move choice, play_manager.cc:403-406
-    const float play_p = probs(temp, cnt_m, pol_m);
     const uint64_t rng_before = rng.state;
-    const uint32_t chosen = pick_move(play_p);
+    uint32_t chosen;
+    if (ep.gumbel_on && !capped) chosen = gumbel_final_action(cp, k, mv_l, n_l, q_l, p_l, cnt_m, pol_m);  // play_manager.cc:367-381
+    else chosen = pick_move(probs(temp, cnt_m, pol_m));
     trace(5 | (static_cast<uint64_t>(chosen) << 8));
 
     if (ep.log_moves) {
@@ -564,7 +775,8 @@ struct SlotCtx {
     }
     // history sample, play_manager.cc:407-424
     if (ep.history && !capped) {
-      const float target = (ep.pruning && ep.epsilon > 0)
+      const float target = ep.gumbel_on ? gumbel_improved_policy(k, mv_l, n_l, q_l, p_l, ar.V[tb + root])  // play_manager.cc:411-417
+                           : (ep.pruning && ep.epsilon > 0)
                                ? probs_pruned(1.0f, root_n, k, mv_l, n_l, q_l, p_l, cnt_m, pol_m)
                                : probs(1.0f, cnt_m, pol_m);
       const uint32_t r = ph_rows;
@@ -617,6 +829,7 @@ struct SlotCtx {
     }
     // play_manager.cc:522-555
     draw_capped();
+    set_gumbel_target();
     if (!ep.tree_reuse) {
       for (uint32_t s = 0; s < static_cast<uint32_t>(P); ++s) reset_tree(s);
     } else {
@@ -714,6 +927,10 @@ __global__ __launch_bounds__(256, 1) void k_round(EngineParams ep, EngineArrays 
   if (!need_process) {  // kSlotFresh / kSlotRestart
     c.start_game();
     c.draw_capped();
+    c.set_gumbel_target();
+    // a game restarted in a slot goes through play_manager.cc:522-546: with tree_reuse off the trees are
+    // rebuilt AFTER set_gumbel_num_sims, so the first search of that game has no Gumbel target
+    if (ep.gumbel_on && st == kSlotRestart && !ep.tree_reuse) c.set_gumbel_num_sims(c.gs.player, 0);
   }
   for (;;) {
     if (need_process) {

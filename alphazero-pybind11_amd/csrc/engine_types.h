@@ -50,6 +50,10 @@ struct EngineParams {  // run constants (PlayParams, play_manager.h:60-154, afte
   uint32_t cache_on;       // device S3-FIFO position cache enabled (max_cache_size > 0)
   uint32_t trace_slot;     // debug: slot whose RNG events are traced (0xFFFFFFFF = off)
   uint32_t trace_cap;
+  // Gumbel AlphaZero (play_manager.h:103-116)
+  uint32_t gumbel_on, gumbel_m, gumbel_full, fast_gumbel;
+  float gumbel_c_visit, gumbel_c_scale;
+  uint32_t gum_stride;     // floats per tree in gum_g (>= max children of a root)
 };
 
 struct Control {  // small device control block, copied back by azmi_pm_poll
@@ -63,6 +67,8 @@ struct Control {  // small device control block, copied back by azmi_pm_poll
   uint32_t live_slots;
   uint64_t rounds;
 };
+
+constexpr uint32_t kGumMaxM = 64;   // cap on PlayParams.gumbel_m (reference default 16)
 
 struct EngineArrays {
   Control* ctl;
@@ -123,6 +129,10 @@ struct EngineArrays {
   uint64_t* cache_keys;   // [S] scratch: keys to insert this round (0 = none)
   CacheView cache;        // position cache (s3fifo_cache.h), see dev_cache.h
   uint64_t* trace;        // debug [trace_cap][2]: tag, rng state; trace[0] = event count
+  // ---- Gumbel AlphaZero per-tree search state (mcts.h:179-191) ---------------------------------
+  uint32_t* gum_state;    // [trees][8]: target, initialized, n_survivors, phase_idx, sims_in_phase, m_eff, remaining
+  float* gum_g;           // [trees][gum_stride] Gumbel(0,1) sample per root child
+  uint16_t* gum_surv;     // [trees][kGumMaxM] surviving root-child indices, best first
 };
 
 }  // namespace azmi

@@ -73,6 +73,15 @@ typedef struct azmi_play_params {
   float resign_playthrough_percent;
   uint32_t num_eval_type;                   /* 0 = all NN */
   int32_t eval_type[AZMI_MAX_PLAYERS];
+  /* Gumbel AlphaZero (play_manager.h:103-116; mcts.cc:24-401): full searches use Gumbel-Top-k +
+   * sequential halving at the root, the improved policy as the training target and the
+   * deterministic final action; capped searches stay PUCT unless fast_search_uses_gumbel. */
+  int32_t gumbel_enabled;
+  uint32_t gumbel_m;                        /* default 16, at most 64 here */
+  float gumbel_c_visit;                     /* default 50 */
+  float gumbel_c_scale;                     /* default 1 */
+  int32_t gumbel_full;
+  int32_t fast_search_uses_gumbel;
 } azmi_play_params;
 
 /* engine-only knobs that have no reference counterpart */

@@ -122,16 +122,27 @@ class Mcts {
     if (found == UINT32_MAX)
       throw std::runtime_error("ahh, what is this move: " + std::to_string(move));
     root_ = found;  // the reference moves the subtree into root_ and frees the rest
+    reset_gumbel_state();  // mcts.cc:172
   }
 
-  // ---- MCTS::find_leaf, mcts.cc:462-498 (PUCT branch) ----------------------
+  // ---- MCTS::find_leaf, mcts.cc:462-498 ------------------------------------
   std::unique_ptr<Game> find_leaf(const Game& gs) {
     current_ = root_;
     auto leaf = gs.copy();
+    if (cfg_.gumbel_enabled && !gumbel_initialized_ && gumbel_num_sims_target_ > 0 && pool_[root_].n > 0 &&
+        pool_[root_].nchild != 0) {
+      init_gumbel_state();  // lazy init, mcts.cc:465-472
+    }
     while (pool_[current_].n > 0 && !pool_[current_].terminal) {
       path_.push_back(current_);
-      const float fpu = (current_ == root_ && cfg_.root_fpu_zero) ? 0.0f : cfg_.fpu_reduction;
-      current_ = best_child(current_, cfg_.cpuct, fpu);
+      if (cfg_.gumbel_enabled && gumbel_initialized_ && current_ == root_) {
+        current_ = pool_[root_].child0 + static_cast<uint32_t>(gumbel_next_root_child());
+      } else if (cfg_.gumbel_enabled && gumbel_initialized_ && cfg_.gumbel_full) {
+        current_ = pool_[current_].child0 + static_cast<uint32_t>(gumbel_interior_select(current_));
+      } else {
+        const float fpu = (current_ == root_ && cfg_.root_fpu_zero) ? 0.0f : cfg_.fpu_reduction;
+        current_ = best_child(current_, cfg_.cpuct, fpu);
+      }
       leaf->play_move(pool_[current_].move);
     }
     total_leaf_depth_ += path_.size();
@@ -405,14 +416,22 @@ class Mcts {
     return entropy / log_k;
   }
 
-  // ---- MCTS::principal_variation, mcts.cc:676-715 (PUCT branch) -------------------
-  std::vector<uint32_t> principal_variation(uint32_t depth) const {
+  // ---- MCTS::principal_variation, mcts.cc:676-715 -----------------------------------
+  // NB: with Gumbel on and no Gumbel state the reference's root step calls pick_move(probs(0)),
+  // which draws from the shared stream; `re` is that stream.
+  std::vector<uint32_t> principal_variation(uint32_t depth) {
     std::vector<uint32_t> pv;
     uint32_t node = root_;
     for (uint32_t i = 0; i < depth; ++i) {
       const Node& nd = pool_[node];
       if (nd.nchild == 0) break;
       uint32_t best = UINT32_MAX, best_n = 0;
+      if (i == 0 && cfg_.gumbel_enabled) {
+        const uint32_t mv = gumbel_final_action();
+        for (uint32_t j = 0; j < nd.nchild; ++j)
+          if (pool_[nd.child0 + j].move == mv) { best = nd.child0 + j; break; }
+      }
+      if (best == UINT32_MAX)
       for (uint32_t j = 0; j < nd.nchild; ++j)
         if (pool_[nd.child0 + j].n > best_n) { best_n = pool_[nd.child0 + j].n; best = nd.child0 + j; }
       if (best == UINT32_MAX || pool_[best].n == 0) break;
@@ -420,6 +439,189 @@ class Mcts {
       node = best;
     }
     return pv;
+  }
+
+
+  // ======================= Gumbel AlphaZero, mcts.cc:24-401 =========================
+  static constexpr float kGumbelLogFloor = 1e-20f;  // mcts.cc:18
+
+  // seq_halving_phase_plan, mcts.cc:28-66: (num_candidates, visits_per_candidate) per phase
+  static std::vector<std::pair<uint32_t, uint32_t>> seq_halving_phase_plan(uint32_t m, uint32_t n) {
+    std::vector<std::pair<uint32_t, uint32_t>> phases;
+    if (m <= 1) { phases.emplace_back(1u, n); return phases; }
+    uint32_t log2m = 0;
+    for (uint32_t v = m - 1; v > 0; v >>= 1) ++log2m;
+    if (log2m == 0) log2m = 1;
+    const uint32_t base_v = std::max<uint32_t>(1u, n / (log2m * m));
+    uint32_t sims_used = 0, num_c = m;
+    for (uint32_t phase_idx = 0; phase_idx < log2m; ++phase_idx) {
+      if (sims_used >= n) break;
+      const uint32_t remaining = n - sims_used;
+      const bool is_final = (phase_idx == log2m - 1);
+      uint32_t v_per = is_final ? std::max<uint32_t>(1u, remaining / num_c) : base_v * (1u << phase_idx);
+      if (num_c * v_per > remaining) {
+        v_per = remaining / num_c;
+        if (v_per == 0) { num_c = remaining; v_per = 1; }
+      }
+      phases.emplace_back(num_c, v_per);
+      sims_used += num_c * v_per;
+      num_c = std::max<uint32_t>(1u, num_c / 2);
+    }
+    return phases;
+  }
+
+  // compute_v_mix_from_children, mcts.cc:71-89
+  static float v_mix_from_children(float raw_v, const std::vector<float>& qs, const std::vector<uint32_t>& ns,
+                                   const std::vector<float>& priors) {
+    float sum_visits = 0.0f, sum_priors_visited = 0.0f, weighted_num = 0.0f;
+    for (size_t i = 0; i < qs.size(); ++i) {
+      sum_visits += static_cast<float>(ns[i]);
+      if (ns[i] > 0) { sum_priors_visited += priors[i]; weighted_num += priors[i] * qs[i]; }
+    }
+    if (sum_priors_visited <= 0.0f) return raw_v;
+    const float weighted_q = weighted_num / sum_priors_visited;
+    return (raw_v + sum_visits * weighted_q) / (sum_visits + 1.0f);
+  }
+
+  void set_gumbel_num_sims(uint32_t n) { gumbel_num_sims_target_ = n; reset_gumbel_state(); }  // mcts.cc:175-178
+  bool gumbel_enabled() const { return cfg_.gumbel_enabled; }
+  bool gumbel_initialized() const { return gumbel_initialized_; }
+  const std::vector<size_t>& gumbel_survivors() const { return gumbel_survivors_; }
+  const std::vector<float>& gumbel_g() const { return gumbel_g_; }
+
+  void reset_gumbel_state() {  // mcts.cc:180-188
+    gumbel_initialized_ = false;
+    gumbel_effective_m_ = 0;
+    gumbel_g_.clear(); gumbel_survivors_.clear(); gumbel_phases_.clear();
+    gumbel_phase_idx_ = 0; gumbel_sims_in_phase_ = 0;
+  }
+
+  void init_gumbel_state() {  // mcts.cc:190-227
+    const Node& r = pool_[root_];
+    const uint32_t num_legal = r.nchild;
+    if (num_legal == 0) return;
+    const uint32_t remaining = depth_ < gumbel_num_sims_target_ ? gumbel_num_sims_target_ - depth_ : 0;
+    if (remaining == 0) return;
+    gumbel_effective_m_ = std::max<uint32_t>(1u, std::min({cfg_.gumbel_m, num_legal, remaining}));
+    gumbel_g_.resize(num_legal);
+    for (uint32_t i = 0; i < num_legal; ++i) gumbel_g_[i] = gumbel01(*re_);
+    std::vector<size_t> idx(num_legal);
+    for (uint32_t i = 0; i < num_legal; ++i) idx[i] = i;
+    std::partial_sort(idx.begin(), idx.begin() + gumbel_effective_m_, idx.end(), [this, &r](size_t a, size_t b) {
+      const float la = az_logf(pool_[r.child0 + a].policy + kGumbelLogFloor);
+      const float lb = az_logf(pool_[r.child0 + b].policy + kGumbelLogFloor);
+      return gumbel_g_[a] + la > gumbel_g_[b] + lb;
+    });
+    gumbel_survivors_.assign(idx.begin(), idx.begin() + gumbel_effective_m_);
+    gumbel_phases_ = seq_halving_phase_plan(gumbel_effective_m_, remaining);
+    gumbel_phase_idx_ = 0;
+    gumbel_sims_in_phase_ = 0;
+    gumbel_initialized_ = true;
+  }
+
+  void gumbel_advance_phase() {  // mcts.cc:229-264
+    if (gumbel_phase_idx_ + 1 >= gumbel_phases_.size()) return;
+    const uint32_t next_num_c = gumbel_phases_[gumbel_phase_idx_ + 1].first;
+    if (next_num_c >= gumbel_survivors_.size()) { ++gumbel_phase_idx_; gumbel_sims_in_phase_ = 0; return; }
+    const Node& r = pool_[root_];
+    uint32_t max_visit = 0;
+    for (size_t ci : gumbel_survivors_) max_visit = std::max(max_visit, pool_[r.child0 + ci].n);
+    const float sigma_scale = (cfg_.gumbel_c_visit + static_cast<float>(max_visit)) * cfg_.gumbel_c_scale;
+    std::vector<std::pair<float, size_t>> scored;
+    for (size_t ci : gumbel_survivors_) {
+      const Node& c = pool_[r.child0 + ci];
+      const float logit = az_logf(c.policy + kGumbelLogFloor);
+      const float q_hat = c.n > 0 ? c.q : 0.0f;
+      scored.emplace_back(gumbel_g_[ci] + logit + sigma_scale * q_hat, ci);
+    }
+    std::partial_sort(scored.begin(), scored.begin() + next_num_c, scored.end(),
+                      [](const auto& a, const auto& b) { return a.first > b.first; });
+    gumbel_survivors_.resize(next_num_c);
+    for (size_t i = 0; i < next_num_c; ++i) gumbel_survivors_[i] = scored[i].second;
+    ++gumbel_phase_idx_;
+    gumbel_sims_in_phase_ = 0;
+  }
+
+  size_t gumbel_next_root_child() {  // mcts.cc:266-283
+    if (gumbel_phase_idx_ < gumbel_phases_.size()) {
+      const auto& ph = gumbel_phases_[gumbel_phase_idx_];
+      if (gumbel_sims_in_phase_ >= ph.first * ph.second) gumbel_advance_phase();
+    }
+    if (gumbel_survivors_.empty()) return 0;
+    const size_t pick = gumbel_sims_in_phase_ % gumbel_survivors_.size();
+    ++gumbel_sims_in_phase_;
+    return gumbel_survivors_[pick];
+  }
+
+  // softmax(log(prior) + sigma * completedQ) over the children of `node`; shared by
+  // gumbel_interior_select (mcts.cc:285-334) and gumbel_improved_policy (mcts.cc:336-373)
+  void gumbel_pi_prime(uint32_t node, std::vector<float>& z, float& z_sum, std::vector<uint32_t>& ns) const {
+    const Node& nd = pool_[node];
+    const uint32_t k = nd.nchild;
+    uint32_t max_visit = 0;
+    std::vector<float> qs(k), priors(k);
+    ns.assign(k, 0);
+    for (uint32_t i = 0; i < k; ++i) {
+      const Node& c = pool_[nd.child0 + i];
+      max_visit = std::max(max_visit, c.n);
+      qs[i] = c.q; ns[i] = c.n; priors[i] = c.policy;
+    }
+    const float v_mix = v_mix_from_children(nd.v, qs, ns, priors);
+    const float sigma_scale = (cfg_.gumbel_c_visit + static_cast<float>(max_visit)) * cfg_.gumbel_c_scale;
+    z.assign(k, 0.0f);
+    float z_max = -std::numeric_limits<float>::infinity();
+    for (uint32_t i = 0; i < k; ++i) {
+      const float completed_q = ns[i] > 0 ? qs[i] : v_mix;
+      z[i] = az_logf(priors[i] + kGumbelLogFloor) + sigma_scale * completed_q;
+      if (z[i] > z_max) z_max = z[i];
+    }
+    z_sum = 0.0f;
+    for (uint32_t i = 0; i < k; ++i) { z[i] = az_expf(z[i] - z_max); z_sum += z[i]; }
+  }
+
+  size_t gumbel_interior_select(uint32_t node) const {  // mcts.cc:285-334
+    std::vector<float> z; std::vector<uint32_t> ns; float z_sum;
+    gumbel_pi_prime(node, z, z_sum, ns);
+    uint32_t sum_visits = 0;
+    for (uint32_t n : ns) sum_visits += n;
+    const float inv = z_sum > 0 ? (1.0f / z_sum) : 0.0f;
+    const float denom = 1.0f + static_cast<float>(sum_visits);
+    size_t best = 0;
+    float best_score = -std::numeric_limits<float>::infinity();
+    for (size_t i = 0; i < z.size(); ++i) {
+      const float score = z[i] * inv - static_cast<float>(ns[i]) / denom;
+      if (score > best_score) { best_score = score; best = i; }
+    }
+    return best;
+  }
+
+  std::vector<float> gumbel_improved_policy() const {  // mcts.cc:336-373
+    std::vector<float> out(cfg_.num_moves, 0.0f);
+    const Node& r = pool_[root_];
+    if (r.nchild == 0) return out;
+    std::vector<float> z; std::vector<uint32_t> ns; float z_sum;
+    gumbel_pi_prime(root_, z, z_sum, ns);
+    if (z_sum <= 0) return out;
+    for (uint32_t i = 0; i < r.nchild; ++i) out[pool_[r.child0 + i].move] = z[i] / z_sum;
+    return out;
+  }
+
+  uint32_t gumbel_final_action() {  // mcts.cc:375-401
+    if (!gumbel_initialized_ || gumbel_survivors_.empty()) return pick_move(probs(0.0f), *re_);
+    const Node& r = pool_[root_];
+    uint32_t max_visit = 0;
+    for (uint32_t i = 0; i < r.nchild; ++i) max_visit = std::max(max_visit, pool_[r.child0 + i].n);
+    const float sigma_scale = (cfg_.gumbel_c_visit + static_cast<float>(max_visit)) * cfg_.gumbel_c_scale;
+    size_t best = gumbel_survivors_[0];
+    float best_score = -std::numeric_limits<float>::infinity();
+    for (size_t ci : gumbel_survivors_) {
+      const Node& c = pool_[r.child0 + ci];
+      const float logit = az_logf(c.policy + kGumbelLogFloor);
+      const float q_hat = c.n > 0 ? c.q : 0.0f;
+      const float score = gumbel_g_[ci] + logit + sigma_scale * q_hat;
+      if (score > best_score) { best_score = score; best = ci; }
+    }
+    return pool_[r.child0 + best].move;
   }
 
   std::vector<std::pair<uint64_t, uint64_t>>* trace = nullptr;  // debug: (tag, rng state)
@@ -451,6 +653,13 @@ class Mcts {
   std::vector<uint32_t> path_;
   uint32_t depth_ = 0;
   uint64_t total_leaf_depth_ = 0;
+  // per-search Gumbel state, mcts.h:179-191
+  bool gumbel_initialized_ = false;
+  uint32_t gumbel_num_sims_target_ = 0, gumbel_effective_m_ = 0;
+  std::vector<float> gumbel_g_;
+  std::vector<size_t> gumbel_survivors_;
+  std::vector<std::pair<uint32_t, uint32_t>> gumbel_phases_;
+  uint32_t gumbel_phase_idx_ = 0, gumbel_sims_in_phase_ = 0;
 };
 
 // game_state.h:160-173 — the deterministic evaluator of the parity tiers.

@@ -100,6 +100,7 @@ struct OrcMctsCfg {
   uint32_t num_players, num_moves;
   float epsilon, root_policy_temp, fpu_reduction;
   int32_t relative_values, root_fpu_zero, shaped_dirichlet;
+  int32_t gumbel_enabled; uint32_t gumbel_m; float gumbel_c_visit, gumbel_c_scale; int32_t gumbel_full;
 };
 void* orc_mcts_new(const OrcMctsCfg* c, uint64_t seed) {
   auto* b = new MctsBox();
@@ -109,10 +110,38 @@ void* orc_mcts_new(const OrcMctsCfg* c, uint64_t seed) {
   mc.epsilon = c->epsilon; mc.root_policy_temp = c->root_policy_temp; mc.fpu_reduction = c->fpu_reduction;
   mc.relative_values = c->relative_values != 0; mc.root_fpu_zero = c->root_fpu_zero != 0;
   mc.shaped_dirichlet = c->shaped_dirichlet != 0;
+  mc.gumbel_enabled = c->gumbel_enabled != 0; mc.gumbel_m = c->gumbel_m;
+  mc.gumbel_c_visit = c->gumbel_c_visit; mc.gumbel_c_scale = c->gumbel_c_scale; mc.gumbel_full = c->gumbel_full != 0;
   b->m = std::make_unique<Mcts>(mc, &b->rng);
   return b;
 }
 void orc_mcts_free(void* h) { delete static_cast<MctsBox*>(h); }
+// ---- Gumbel hooks (mcts.cc:24-401)
+void orc_mcts_set_gumbel_num_sims(void* h, uint32_t n) { static_cast<MctsBox*>(h)->m->set_gumbel_num_sims(n); }
+void orc_mcts_gumbel_improved_policy(void* h, float* out) {
+  auto v = static_cast<MctsBox*>(h)->m->gumbel_improved_policy();
+  std::memcpy(out, v.data(), v.size() * sizeof(float));
+}
+uint32_t orc_mcts_gumbel_final_action(void* h) { return static_cast<MctsBox*>(h)->m->gumbel_final_action(); }
+// survivors as root-child indices, g per root child; returns #survivors (0 if not initialised)
+uint32_t orc_mcts_gumbel_state(void* h, uint32_t* survivors, float* g, uint32_t cap) {
+  auto& m = *static_cast<MctsBox*>(h)->m;
+  if (!m.gumbel_initialized()) return 0;
+  const auto& sv = m.gumbel_survivors(); const auto& gg = m.gumbel_g();
+  for (uint32_t i = 0; i < sv.size() && i < cap; ++i) survivors[i] = static_cast<uint32_t>(sv[i]);
+  for (uint32_t i = 0; i < gg.size() && i < cap; ++i) g[i] = gg[i];
+  return static_cast<uint32_t>(sv.size());
+}
+// seq_halving_phase_plan(m, n) -> out[2*i] = num_c, out[2*i+1] = v_per; returns #phases
+uint32_t orc_seq_halving_phase_plan(uint32_t m, uint32_t n, uint32_t* out, uint32_t cap) {
+  auto ph = Mcts::seq_halving_phase_plan(m, n);
+  for (uint32_t i = 0; i < ph.size() && i < cap; ++i) { out[2 * i] = ph[i].first; out[2 * i + 1] = ph[i].second; }
+  return static_cast<uint32_t>(ph.size());
+}
+float orc_v_mix(float raw_v, const float* q, const uint32_t* n, const float* prior, uint32_t k) {
+  return Mcts::v_mix_from_children(raw_v, std::vector<float>(q, q + k), std::vector<uint32_t>(n, n + k),
+                                   std::vector<float>(prior, prior + k));
+}
 // find_leaf; the leaf state is kept inside the box (orc_mcts_leaf to borrow it)
 void orc_mcts_find_leaf(void* h, void* game) {
   auto* b = static_cast<MctsBox*>(h);
@@ -190,6 +219,8 @@ struct OrcPlayParams {
   int32_t root_fpu_zero, shaped_dirichlet, policy_target_pruning;
   float resign_percent, resign_playthrough_percent;
   int32_t eval_type[4];  // -1 = unset (all NN)
+  int32_t gumbel_enabled; uint32_t gumbel_m; float gumbel_c_visit, gumbel_c_scale;
+  int32_t gumbel_full, fast_search_uses_gumbel;
 };
 typedef void (*orc_eval_fn)(const float* canonical, uint32_t n, float* v, float* pi, void* user);
 
@@ -211,6 +242,9 @@ void* orc_pm_new(int game_id, const OrcPlayParams* c, uint64_t seed, int per_slo
     p.fpu_reduction = c->fpu_reduction; p.root_fpu_zero = c->root_fpu_zero != 0;
     p.shaped_dirichlet = c->shaped_dirichlet != 0; p.policy_target_pruning = c->policy_target_pruning != 0;
     p.resign_percent = c->resign_percent; p.resign_playthrough_percent = c->resign_playthrough_percent;
+    p.gumbel_enabled = c->gumbel_enabled != 0; p.gumbel_m = c->gumbel_m;
+    p.gumbel_c_visit = c->gumbel_c_visit; p.gumbel_c_scale = c->gumbel_c_scale;
+    p.gumbel_full = c->gumbel_full != 0; p.fast_search_uses_gumbel = c->fast_search_uses_gumbel != 0;
     if (c->eval_type[0] >= 0)
       for (uint32_t i = 0; i < P; ++i) p.eval_type.push_back(static_cast<EvalType>(c->eval_type[i]));
     auto* b = new PmBox();

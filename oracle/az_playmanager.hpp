@@ -58,6 +58,11 @@ struct PlayParams {  // play_manager.h:60-154 (fields the path implements)
   bool root_fpu_zero = false;
   bool shaped_dirichlet = false;
   bool policy_target_pruning = false;
+  bool gumbel_enabled = false;             // play_manager.h:103-116
+  uint32_t gumbel_m = 16;
+  float gumbel_c_visit = 50.0f, gumbel_c_scale = 1.0f;
+  bool gumbel_full = false;
+  bool fast_search_uses_gumbel = false;
   float resign_percent = 0.0f;
   float resign_playthrough_percent = 0.0f;
   std::vector<EvalType> eval_type;  // per player; empty = all NN
@@ -202,9 +207,23 @@ class PlayManager {
     c.relative_values = base_->relative_values();
     c.root_fpu_zero = params_.root_fpu_zero;
     c.shaped_dirichlet = params_.shaped_dirichlet;
+    c.gumbel_enabled = params_.gumbel_enabled;   // play_manager.cc:612-616
+    c.gumbel_m = params_.gumbel_m;
+    c.gumbel_c_visit = params_.gumbel_c_visit;
+    c.gumbel_c_scale = params_.gumbel_c_scale;
+    c.gumbel_full = params_.gumbel_full;
     Mcts m(c, &tree_rng(slot));
     if (trace_on) m.trace = &trace;
     return m;
+  }
+
+  // capped searches fall back to PUCT (target 0) unless fast_search_uses_gumbel
+  template <class SlotT>
+  void set_gumbel_target(SlotT& game) {
+    const uint8_t cp = game.gs->current_player();
+    const uint32_t target = game.capped ? (params_.fast_search_uses_gumbel ? params_.playout_cap_depth : 0u)
+                                        : params_.mcts_visits[cp];
+    game.mcts[cp].set_gumbel_num_sims(target);
   }
 
   EvalType eval_type_for(uint8_t player) const {
@@ -250,10 +269,16 @@ class PlayManager {
             else resign_score = tmp;
           }
         }
-        // move choice, play_manager.cc:403-406 (PUCT branch)
-        const std::vector<float> pi_play = mcts.probs(temp);
+        // move choice, play_manager.cc:367-406 (G1 Gumbel acting or PUCT sampling; the opt-in G3
+        // branch, seat_gumbel_use_improved_policy, is not restated)
         const uint64_t rng_before = tree_rng(i).state;
-        const uint32_t chosen_m = Mcts::pick_move(pi_play, tree_rng(i));
+        uint32_t chosen_m;
+        if (mcts.gumbel_enabled() && !game.capped) {
+          chosen_m = mcts.gumbel_final_action();
+        } else {
+          const std::vector<float> pi_play = mcts.probs(temp);
+          chosen_m = Mcts::pick_move(pi_play, tree_rng(i));
+        }
         if (trace_on) trace.push_back({5 | (static_cast<uint64_t>(chosen_m) << 8), tree_rng(i).state});
         if (record_moves) {
           MoveRecord mr;
@@ -268,8 +293,9 @@ class PlayManager {
           pd.ph.canonical.assign(base_->canonical_size(), 0.0f);
           game.gs->canonicalized(pd.ph.canonical.data());
           pd.ph.v.assign(game.v.size(), 0.0f);
-          pd.ph.pi = (params_.policy_target_pruning && params_.epsilon > 0) ? mcts.probs_pruned(1.0)
-                                                                            : mcts.probs(1.0);
+          pd.ph.pi = params_.gumbel_enabled ? mcts.gumbel_improved_policy()   // play_manager.cc:411-417
+                     : (params_.policy_target_pruning && params_.epsilon > 0) ? mcts.probs_pruned(1.0)
+                                                                              : mcts.probs(1.0);
           pd.player = game.gs->current_player();
           game.partial_history.push_back(std::move(pd));
         }
@@ -340,6 +366,7 @@ class PlayManager {
         // play_manager.cc:522-555
         game.capped = params_.playout_cap_randomization &&
                       (uniform01(coin_rng(i)) < params_.playout_cap_percent);
+        set_gumbel_target(game);  // play_manager.cc:525-539
         if (!params_.tree_reuse) {
           for (uint32_t j = 0; j < P; ++j) game.mcts[j] = make_mcts(i);
         } else {
@@ -355,6 +382,7 @@ class PlayManager {
       game.initialized = true;
       game.capped = params_.playout_cap_randomization &&
                     (uniform01(coin_rng(i)) < params_.playout_cap_percent);
+      set_gumbel_target(game);  // play_manager.cc:561-570
     }
     // play_manager.cc:572-598
     const uint8_t cp = game.gs->current_player();

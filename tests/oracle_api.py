@@ -127,14 +127,18 @@ class Game:
 class MctsCfg(C.Structure):
     _fields_ = [("cpuct", C.c_float), ("num_players", C.c_uint32), ("num_moves", C.c_uint32), ("epsilon", C.c_float),
                 ("root_policy_temp", C.c_float), ("fpu_reduction", C.c_float), ("relative_values", C.c_int32),
-                ("root_fpu_zero", C.c_int32), ("shaped_dirichlet", C.c_int32)]
+                ("root_fpu_zero", C.c_int32), ("shaped_dirichlet", C.c_int32), ("gumbel_enabled", C.c_int32),
+                ("gumbel_m", C.c_uint32), ("gumbel_c_visit", C.c_float), ("gumbel_c_scale", C.c_float),
+                ("gumbel_full", C.c_int32)]
 
 
 class Mcts:
     def __init__(self, cpuct, num_players, num_moves, epsilon=0.0, root_policy_temp=1.0, fpu_reduction=0.0,
-                 relative_values=False, root_fpu_zero=False, shaped_dirichlet=False, seed=0):
+                 relative_values=False, root_fpu_zero=False, shaped_dirichlet=False, gumbel_enabled=False, gumbel_m=16,
+                 gumbel_c_visit=50.0, gumbel_c_scale=1.0, gumbel_full=False, seed=0):
         cfg = MctsCfg(cpuct, num_players, num_moves, epsilon, root_policy_temp, fpu_reduction, int(relative_values),
-                      int(root_fpu_zero), int(shaped_dirichlet))
+                      int(root_fpu_zero), int(shaped_dirichlet), int(gumbel_enabled), gumbel_m, gumbel_c_visit,
+                      gumbel_c_scale, int(gumbel_full))
         self.h = C.c_void_p(lib.orc_mcts_new(C.byref(cfg), C.c_uint64(seed)))
         self.P, self.M = num_players, num_moves
 
@@ -142,6 +146,20 @@ class Mcts:
         if self.h:
             lib.orc_mcts_free(self.h)
             self.h = None
+
+    def set_gumbel_num_sims(self, n):
+        lib.orc_mcts_set_gumbel_num_sims(self.h, C.c_uint32(n))
+
+    def gumbel_improved_policy(self):
+        out = np.zeros(self.M, np.float32); lib.orc_mcts_gumbel_improved_policy(self.h, _p(out)); return out
+
+    def gumbel_final_action(self):
+        return int(lib.orc_mcts_gumbel_final_action(self.h))
+
+    def gumbel_state(self):
+        sv = np.zeros(512, np.uint32); g = np.zeros(512, np.float32)
+        n = lib.orc_mcts_gumbel_state(self.h, _p(sv), _p(g), C.c_uint32(512))
+        return sv[:n].copy(), g
 
     def search_dumb(self, game, sims, noise=False):
         lib.orc_mcts_search_dumb(self.h, game.h, C.c_uint32(sims), C.c_int(int(noise)))
@@ -202,7 +220,9 @@ class OrcPlayParams(C.Structure):
                 ("epsilon", C.c_float), ("mcts_root_temp", C.c_float), ("playout_cap_randomization", C.c_int32),
                 ("playout_cap_depth", C.c_uint32), ("playout_cap_percent", C.c_float), ("fpu_reduction", C.c_float),
                 ("root_fpu_zero", C.c_int32), ("shaped_dirichlet", C.c_int32), ("policy_target_pruning", C.c_int32),
-                ("resign_percent", C.c_float), ("resign_playthrough_percent", C.c_float), ("eval_type", C.c_int32 * 4)]
+                ("resign_percent", C.c_float), ("resign_playthrough_percent", C.c_float), ("eval_type", C.c_int32 * 4),
+                ("gumbel_enabled", C.c_int32), ("gumbel_m", C.c_uint32), ("gumbel_c_visit", C.c_float),
+                ("gumbel_c_scale", C.c_float), ("gumbel_full", C.c_int32), ("fast_search_uses_gumbel", C.c_int32)]
 
 
 EVAL_FN = C.CFUNCTYPE(None, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p)
@@ -222,6 +242,12 @@ def params_from(pp, num_players):
         setattr(c, name, int(bool(getattr(pp, name))))
     for i, v in enumerate(pp.mcts_visits):
         c.mcts_visits[i] = int(v)
+    c.gumbel_enabled = int(bool(getattr(pp, "gumbel_enabled", False)))
+    c.gumbel_m = int(getattr(pp, "gumbel_m", 16))
+    c.gumbel_c_visit = float(getattr(pp, "gumbel_c_visit", 50.0))
+    c.gumbel_c_scale = float(getattr(pp, "gumbel_c_scale", 1.0))
+    c.gumbel_full = int(bool(getattr(pp, "gumbel_full", False)))
+    c.fast_search_uses_gumbel = int(bool(getattr(pp, "fast_search_uses_gumbel", False)))
     for i in range(4):
         c.eval_type[i] = -1
     for i, e in enumerate(pp.eval_type):
@@ -290,6 +316,19 @@ class PlayManager:
         if n:
             lib.orc_pm_moves(self.h, _p(rows), _p(counts), C.c_uint32(self.M))
         return rows, counts
+
+
+def seq_halving_phase_plan(m, n):
+    out = np.zeros(64, np.uint32)
+    lib.orc_seq_halving_phase_plan.restype = C.c_uint32
+    k = lib.orc_seq_halving_phase_plan(C.c_uint32(m), C.c_uint32(n), _p(out), C.c_uint32(32))
+    return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(k)]
+
+
+def v_mix(raw_v, q, n, prior):
+    q = np.ascontiguousarray(q, np.float32); n = np.ascontiguousarray(n, np.uint32); prior = np.ascontiguousarray(prior, np.float32)
+    lib.orc_v_mix.restype = C.c_float
+    return float(lib.orc_v_mix(C.c_float(raw_v), _p(q), _p(n), _p(prior), C.c_uint32(len(q))))
 
 
 def slot_seed(seed, slot):

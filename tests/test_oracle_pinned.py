@@ -298,3 +298,65 @@ def test_symmetry_connect4(oracle):  # connect4_gs.cc:151-170
     oc, ov, op = oracle.symmetries(oracle.SYM_CONNECT4, canon, v, pi)
     assert np.array_equal(oc[0], canon) and np.array_equal(op[0], pi)
     assert np.array_equal(oc[1], canon[:, :, ::-1]) and np.array_equal(op[1], pi[::-1]) and np.array_equal(ov[1], v)
+
+
+# ---------------------------------------------------------------- Gumbel (test_gumbel.py, mcts_test.cc:706-900)
+def test_gumbel_phase_plan_known_answers(oracle):
+    # test_gumbel.py:250-256 (paper figure 1) and :268-296
+    ph = oracle.seq_halving_phase_plan(16, 200)
+    assert ph == [(16, 3), (8, 6), (4, 12), (2, 28)]
+    assert sum(c * v for c, v in ph) == 200 and sum(v for _, v in ph) == 49
+    assert oracle.seq_halving_phase_plan(1, 10) == [(1, 10)]
+    assert oracle.seq_halving_phase_plan(4, 12) == [(4, 1), (2, 4)]          # mcts_test.cc:802-805
+    assert sum(c * v for c, v in oracle.seq_halving_phase_plan(8, 8)) == 8
+    for m in (2, 3, 4, 5, 7, 8, 16, 32):
+        for n in (m, m + 1, 2 * m, 50, 200, 800):
+            ph = oracle.seq_halving_phase_plan(m, n)
+            tot = sum(c * v for c, v in ph)
+            assert n - ph[-1][0] <= tot <= n, (m, n, ph)
+
+
+def test_gumbel_v_mix_known_answers(oracle):  # test_gumbel.py:170-195
+    pr = [0.25] * 4
+    assert oracle.v_mix(0.7, [0, 0, 0, 0], [0, 0, 0, 0], pr) == pytest.approx(0.7)
+    assert oracle.v_mix(0.5, [0, 0, 0.8, 0], [0, 0, 1, 0], pr) == pytest.approx(0.65)
+    assert oracle.v_mix(0.1, [0.9] * 4, [100] * 4, pr) == pytest.approx(0.898, abs=0.005)
+
+
+def _gumbel_mcts(oracle, m, full=False, seed=1):  # make_gumbel_mcts, mcts_test.cc:713-729
+    return oracle.Mcts(2.0, 2, 7, gumbel_enabled=True, gumbel_m=m, gumbel_full=full, seed=seed)
+
+
+def test_gumbel_mcts_known_answers(oracle):
+    gs = oracle.Game(oracle.GAME_CONNECT4)
+    # SequentialHalvingVisitDistribution, mcts_test.cc:801-822
+    for seed in (1, 2, 3, 12345):
+        m = _gumbel_mcts(oracle, 4, seed=seed)
+        m.set_gumbel_num_sims(13)
+        m.search_dumb(gs, 13)
+        cnt = m.counts()
+        assert sorted((int(c) for c in cnt if c > 0), reverse=True) == [5, 5, 1, 1] and cnt.sum() == 12
+    # RunsCleanlyAtLowVisits / ImprovedPolicySumsToOne / FinalActionIsValidMove, mcts_test.cc:744-853
+    for n in (4, 8, 16, 32):
+        m = _gumbel_mcts(oracle, 16, seed=n)
+        m.set_gumbel_num_sims(n)
+        m.search_dumb(gs, n)
+        assert np.isfinite(m.root_q()).all()
+        pi = m.gumbel_improved_policy()
+        assert abs(pi.sum() - 1.0) < 1e-4 and (pi >= 0).all()
+        assert 0 <= m.gumbel_final_action() < 7
+    # SkipsDirichletNoise, mcts_test.cc:768-798: first eval with noise requested keeps the uniform prior
+    m = _gumbel_mcts(oracle, 16)
+    m.set_gumbel_num_sims(64)
+    leaf = m.find_leaf(gs)
+    m.process_result(np.full(3, 1 / 3, np.float32), np.full(7, 1 / 7, np.float32), noise=True)
+    assert np.allclose(m.gumbel_improved_policy(), 1 / 7, atol=1e-5)
+    # FallbackToPuctWhenSimsTargetZero, mcts_test.cc:886-900: target 0 -> plain PUCT, same tree as a PUCT search
+    a = _gumbel_mcts(oracle, 16, seed=9); a.set_gumbel_num_sims(0); a.search_dumb(gs, 100)
+    b = oracle.Mcts(2.0, 2, 7, seed=9); b.search_dumb(gs, 100)
+    assert np.array_equal(a.counts(), b.counts())
+    sv, _ = a.gumbel_state()
+    assert len(sv) == 0
+    # gumbel_full (interior pi'-matching) runs and keeps the root schedule
+    f = _gumbel_mcts(oracle, 4, full=True, seed=5); f.set_gumbel_num_sims(13); f.search_dumb(gs, 13)
+    assert sorted((int(c) for c in f.counts() if c > 0), reverse=True) == [5, 5, 1, 1]
