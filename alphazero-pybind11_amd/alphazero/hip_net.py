@@ -20,7 +20,8 @@ from .torch_net import bn_affine
 
 class NetDescC(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("in_channels", "height", "width", "channels", "depth", "kernel_size",
-                                         "head_channels", "v_hidden", "num_moves", "num_players")]
+                                         "head_channels", "v_hidden", "num_moves", "num_players", "v_head_convs",
+                                         "pi_head_convs", "v_fc_layers", "policy_channels")]
 
 
 lib.azmi_net_blob_bytes.restype = C.c_size_t
@@ -39,14 +40,15 @@ def _bf16_bits(x):
 
 
 def _frags(wmat):
-    """wmat [64][K] float -> bf16 fragments [K/32][4][64][8] as bytes."""
+    """wmat [16*MT][K] float -> bf16 fragments [K/32][MT][64][8] as bytes."""
     co, K = wmat.shape
-    assert co == 64 and K % 32 == 0
+    assert co % 16 == 0 and K % 32 == 0
+    nmt = co // 16
     lanes = np.arange(64)
-    out = np.zeros((K // 32, 4, 64, 8), np.int16)
+    out = np.zeros((K // 32, nmt, 64, 8), np.int16)
     bits = _bf16_bits(wmat)
     for ks in range(K // 32):
-        for mt in range(4):
+        for mt in range(nmt):
             rows = 16 * mt + (lanes & 15)
             cols = 32 * ks + 8 * (lanes >> 4)
             out[ks, mt] = np.stack([bits[rows, cols + j] for j in range(8)], axis=1)
@@ -57,9 +59,67 @@ def _f32(x):
     return np.ascontiguousarray(np.asarray(x, dtype=np.float64).astype(np.float32)).tobytes()
 
 
+def _fold_trunk(net, sd, Cin):
+    blob = bytearray()
+    a, b = (t.cpu() for t in bn_affine(net.bn1))
+    w = sd["conv1.weight"] * a[:, None, None, None]
+    wm = np.zeros((64, 64))
+    wm[:, : 9 * Cin] = w.permute(0, 2, 3, 1).reshape(64, 9 * Cin).numpy()
+    blob += _frags(wm) + _f32(b)
+    for i, blk in enumerate(net.conv_layers):
+        a1, b1 = (t.cpu() for t in bn_affine(blk.bn1))
+        a2, b2 = (t.cpu() for t in bn_affine(blk.bn2))
+        w1 = sd[f"conv_layers.{i}.conv1.weight"] * a2[:, None, None, None]
+        w2 = sd[f"conv_layers.{i}.conv2.weight"]
+        blob += _f32(a1) + _f32(b1) + _f32(b2)
+        blob += _frags(w1.permute(0, 2, 3, 1).reshape(64, 576).numpy())
+        blob += _frags(w2.permute(0, 2, 3, 1).reshape(64, 576).numpy())
+    return blob
+
+
+def fold_spatial(net):
+    """Spatial-policy-head nets (Tafl family: head_channels 64, one extra conv per head, v_fc_layers >= 1).
+    Blob: stem | blocks | head frag[2][8] + b[128] | v_extra frag[18][4] + b[64] | pi_extra frag[18][4] + b[64] |
+    policy 1x1 frag[2][2] + b[32] | fc1 W^T[64][Hd] b | extra FC (W^T[Hd][Hd])* then (b[Hd])* | fc2 W^T[Hd][16] b[16]."""
+    spec = net.spec
+    Cin, H, W = spec.in_shape
+    assert spec.num_channels == 64 and spec.head_channels == 64 and spec.kernel_size == 3 and spec.head_pool
+    assert spec.v_head_convs == 1 and spec.pi_head_convs == 1 and 9 * Cin <= 64
+    pc = spec.policy_shape[0]
+    Hd, L, P1 = spec.v_fc_hidden, spec.v_fc_layers, spec.num_players + 1
+    sd = {k: v.detach().double().cpu() for k, v in net.state_dict().items()}
+    blob = _fold_trunk(net, sd, Cin)
+    av, bv = (t.cpu() for t in bn_affine(net.v_bn))
+    ap, bp = (t.cpu() for t in bn_affine(net.pi_bn))
+    wh = torch.cat([sd["v_conv.weight"][:, :, 0, 0] * av[:, None], sd["pi_conv.weight"][:, :, 0, 0] * ap[:, None]], 0)
+    blob += _frags(wh.numpy()) + _f32(torch.cat([bv, bp]))
+    for seq, name in ((net.v_extra_convs, "v_extra_convs"), (net.pi_extra_convs, "pi_extra_convs")):
+        a, b = (t.cpu() for t in bn_affine(seq[1]))
+        w = sd[f"{name}.0.weight"] * a[:, None, None, None]
+        blob += _frags(w.permute(0, 2, 3, 1).reshape(64, 576).numpy()) + _f32(b)
+    a2, b2 = (t.cpu() for t in bn_affine(net.pi_bn2))
+    wpol = torch.zeros((32, 64), dtype=torch.float64)
+    wpol[:pc] = sd["pi_conv2.weight"][:, :, 0, 0] * a2[:, None]
+    bpol = torch.zeros(32, dtype=torch.float64); bpol[:pc] = b2
+    blob += _frags(wpol.numpy()) + _f32(bpol)
+    blob += _f32(sd["v_fc1.weight"].t().contiguous()) + _f32(sd["v_fc1.bias"])
+    for l in range(L - 1):
+        blob += _f32(sd[f"v_fc_extra.{2 * l}.weight"].t().contiguous())
+    for l in range(L - 1):
+        blob += _f32(sd[f"v_fc_extra.{2 * l}.bias"])
+    w2 = torch.zeros((Hd, 16), dtype=torch.float64); w2[:, :P1] = sd["v_fc2.weight"].t()
+    b2f = torch.zeros(16, dtype=torch.float64); b2f[:P1] = sd["v_fc2.bias"]
+    blob += _f32(w2) + _f32(b2f)
+    desc = NetDescC(Cin, H, W, 64, spec.depth, 3, 64, Hd, spec.num_moves, spec.num_players, 1, 1, L, pc)
+    assert len(blob) == lib.azmi_net_blob_bytes(C.byref(desc)), (len(blob), lib.azmi_net_blob_bytes(C.byref(desc)))
+    return desc, bytes(blob)
+
+
 def fold(net):
     """LeafNet (reference NNArch parameter names) -> (NetDescC, blob bytes)."""
     spec = net.spec
+    if spec.policy_shape is not None:
+        return fold_spatial(net)
     Cin, H, W = spec.in_shape
     assert spec.num_channels == 64 and spec.head_channels == 32 and spec.kernel_size == 3
     assert spec.policy_shape is None and spec.head_pool and spec.v_head_convs == 0 and spec.pi_head_convs == 0
@@ -93,7 +153,7 @@ def fold(net):
     wt = torch.zeros((wp.shape[1], 16), dtype=torch.float64)
     wt[:, : spec.num_moves] = wp.t()
     blob += _f32(wt) + _f32(sd["pi_fc1.bias"])
-    desc = NetDescC(Cin, H, W, 64, spec.depth, 3, 32, spec.v_fc_hidden, spec.num_moves, spec.num_players)
+    desc = NetDescC(Cin, H, W, 64, spec.depth, 3, 32, spec.v_fc_hidden, spec.num_moves, spec.num_players, 0, 0, 1, 0)
     assert len(blob) == lib.azmi_net_blob_bytes(C.byref(desc)), (len(blob), lib.azmi_net_blob_bytes(C.byref(desc)))
     return desc, bytes(blob)
 

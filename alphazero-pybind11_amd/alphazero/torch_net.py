@@ -142,6 +142,13 @@ def connect4_spec(depth=6, channels=64, kernel_size=3, head_channels=32):
                    kernel_size=kernel_size, head_channels=head_channels)
 
 
+def tawlbwrdd_spec(depth=4):
+    """BASELINE config 3 / configs/tawlbwrdd.yaml:6-16: 4 blocks x 64 channels, k=3, head_channels 64,
+    one extra conv per head, two value FC layers, spatial policy head (POLICY_SHAPE 22 x 11 x 11)."""
+    return NetSpec(in_shape=(7, 11, 11), num_moves=2662, num_players=2, num_channels=64, depth=depth, kernel_size=3,
+                   head_channels=64, v_head_convs=1, pi_head_convs=1, v_fc_layers=2, policy_shape=(22, 11, 11))
+
+
 def random_init(spec, seed=0, randomize_bn=True):
     """Random-init net of the named architecture (no checkpoint / dataset is reachable here).
     BatchNorm statistics and affine parameters are randomised too so that BN folding is exercised."""

@@ -79,15 +79,16 @@ struct NetPtrs {           // device pointers into the folded weight blob
 // mod 16 it would have had, so the redirect never collides with another lane's bank (no halo ring).  With a plane stride that is a
 // multiple of 256 B, the 16 lanes of every ds_read_b128 lane-group land on 16 distinct 16-byte
 // bank slots (consecutive pixels), so fragment reads are conflict-free.
-template <int H, int W>
+template <int H, int W, int TBG = TB>
 struct Geo {
   static constexpr int PIX = H * W;                 // 42
-  static constexpr int NPIX = TB * PIX;             // 336 GEMM columns
+  static constexpr int NPIX = TBG * PIX;            // 336 GEMM columns
   static constexpr int NT = (NPIX + 15) / 16;       // 21 n-tiles
   static constexpr int NT_W = (NT + NWAVES - 1) / NWAVES;  // n-tiles per wave (3)
-  static constexpr int SLOTS = ((NPIX + 1 + 15) / 16) * 16;  // 352
+  static constexpr int ZSLOT = NT * 16;             // first zero cell: a multiple of 16, so residues line up
+  static constexpr int SLOTS = ZSLOT + 16;          // 352
   static constexpr int PLANE = SLOTS * 16;          // 5632 B, multiple of 256
-  static constexpr int ZERO_OFF = NPIX * 16;        // 16 zero cells (slots NPIX..NPIX+15) inside every plane
+  static constexpr int ZERO_OFF = ZSLOT * 16;       // 16 zero cells (slots ZSLOT..ZSLOT+15) inside every plane
   static constexpr int ACT_BYTES = 8 * PLANE;       // 45,056
   static constexpr int KS3 = 9 * CH / 32;           // 18 k-steps of a 3x3 conv
   static constexpr int WCONV_BYTES = KS3 * MT * WFRAG_BYTES;  // 73,728
@@ -432,6 +433,412 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_leafnet(NetDesc nd, NetPtrs np,
   }
 }
 
+// =====================================================================================================
+// Spatial-policy-head variant (Tafl family, configs/tawlbwrdd.yaml: 4b64c k3, head_channels 64,
+// v_head_convs 1, pi_head_convs 1, v_fc_layers 2, spatial policy; neural_net.py:341-427, 448-494):
+//     heads  hv = relu(conv1x1_v(s) + b)          hp = relu(conv1x1_pi(s) + b)         (v_bn / pi_bn folded)
+//            v2 = relu(conv3x3(hv) + b)           p2 = relu(conv3x3(hp) + b)           (extra head convs, BN folded)
+//            pooled = avgpool(v2)  -> k_value_fc  logits[h][w][c] = conv1x1(p2) + b    (pi_conv2 * pi_bn2 folded)
+//            pi = softmax over all H*W*C logits of a board (index (h*W + w)*C + c = the game's move index)
+// Same implicit-GEMM tower as k_leafnet with TBS = 3 boards per workgroup (3 * 121 = 363 pixels = 23 n-tiles,
+// 3 per wave); the value head's FC stack runs batched in k_value_fc on the exact-fp32 matrix pipe.
+constexpr int TBS = 3;
+constexpr int HCS = 64;
+
+struct SpatialDesc {
+  int C_in, H, W, depth, num_moves, num_players, v_hidden, v_fc_layers, pol_ch;
+};
+struct SpatialPtrs {
+  const uint8_t* stem_w; const float* stem_b; const uint8_t* blocks;
+  const uint8_t* head_w;   // frag[2 ks][8 mt]: rows 0-63 v_conv*v_bn, rows 64-127 pi_conv*pi_bn
+  const float* head_b;     // [128]
+  const uint8_t* vx_w; const float* vx_b;   // value-head extra conv frag[18][4] + bias[64]
+  const uint8_t* px_w; const float* px_b;   // policy-head extra conv
+  const uint8_t* pol_w;    // frag[2 ks][2 mt]: rows 0..pol_ch-1 = pi_conv2*pi_bn2, zero padded to 32
+  const float* pol_b;      // [32]
+  const float* fc1_w;      // W^T [64][v_hidden]
+  const float* fc1_b;
+  const float* fcx_w;      // (v_fc_layers-1) x W^T [v_hidden][v_hidden]
+  const float* fcx_b;      // (v_fc_layers-1) x [v_hidden]
+  const float* fc2_w;      // W^T [v_hidden][16], columns >= P+1 zero
+  const float* fc2_b;      // [16]
+};
+
+template <int H, int W>
+__global__ __launch_bounds__(NTHREADS, 2) void k_leafnet_spatial(SpatialDesc nd, SpatialPtrs np, const float* __restrict__ canon,
+                                                                  float* __restrict__ vpool_out, float* __restrict__ pi_out,
+                                                                  uint32_t batch) {
+  using G = Geo<H, W, TBS>;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  uint8_t* act = lds;
+  uint8_t* wbuf = lds + G::ACT_BYTES;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int col = lane & 15, quad = lane >> 4;
+  const uint32_t board0 = blockIdx.x * TBS;
+
+  int pix_off[G::NT_W];
+  uint32_t tap_ok[G::NT_W];
+  bool tile_on[G::NT_W];
+  uint32_t real_m = 0;       // bit j: this lane's column of tile j is a real pixel (the last tile is partial)
+#pragma unroll
+  for (int j = 0; j < G::NT_W; ++j) {
+    const int t = wave + NWAVES * j;
+    const int n = t * 16 + col;
+    tile_on[j] = __builtin_amdgcn_readfirstlane(t) < G::NT;
+    const bool real = t < G::NT && n < G::NPIX;
+    if (real) real_m |= 1u << j;
+    const int nn = real ? n : 0;
+    const int p = nn % G::PIX, h = p / W, w = p % W;
+    pix_off[j] = nn * 16;
+    uint32_t m = 0;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
+      if (real && hh >= 0 && hh < H && ww >= 0 && ww < W) m |= 1u << tap;
+    }
+    tap_ok[j] = m;
+  }
+
+  for (int i = tid * 16; i < G::ACT_BYTES; i += NTHREADS * 16) *reinterpret_cast<u32x4*>(act + i) = u32x4{0, 0, 0, 0};
+
+  // ---- stem ---------------------------------------------------------------------------------------------
+  float* raw = reinterpret_cast<float*>(wbuf + 16384);
+  const int plane_sz = nd.C_in * G::PIX;
+  for (int i = tid; i < TBS * plane_sz; i += NTHREADS) {
+    const uint32_t b = board0 + i / plane_sz;
+    raw[i] = b < batch ? canon[static_cast<size_t>(b) * plane_sz + (i % plane_sz)] : 0.0f;
+  }
+  for (int i = tid * 16; i < 2 * MT * WFRAG_BYTES; i += NTHREADS * 16)
+    *reinterpret_cast<u32x4*>(wbuf + i) = *reinterpret_cast<const u32x4*>(np.stem_w + i);
+  __syncthreads();
+  if (tid < G::NPIX) {
+    const int n = tid, b = n / G::PIX, p = n % G::PIX, h = p / W, w = p % W;
+    const float* rb = raw + b * plane_sz;
+    for (int tap = 0; tap < 9; ++tap) {
+      const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
+      const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+      for (int ci = 0; ci < nd.C_in; ++ci) {
+        const int k = tap * nd.C_in + ci;
+        const float val = ok ? rb[ci * G::PIX + hh * W + ww] : 0.0f;
+        *reinterpret_cast<__bf16*>(act + (k >> 3) * G::PLANE + n * 16 + (k & 7) * 2) = static_cast<__bf16>(val);
+      }
+    }
+  }
+  __syncthreads();
+
+  f32x4 s[G::NT_W][MT];
+  {
+    f32x4 bias[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) bias[mt] = *reinterpret_cast<const f32x4*>(np.stem_b + mt * 16 + quad * 4);
+#pragma unroll
+    for (int j = 0; j < G::NT_W; ++j)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) s[j][mt] = bias[mt];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = lds_read_frag(wbuf + (ks * MT + mt) * WFRAG_BYTES + lane * 16);
+#pragma unroll
+      for (int j = 0; j < G::NT_W; ++j) {
+        const bf16x8 b = lds_read_frag(act + (ks * 4 + quad) * G::PLANE + pix_off[j]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) s[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, s[j][mt], 0, 0, 0);
+      }
+    }
+  }
+
+  u32x4 wnext[G::WREG];
+  auto prefetch = [&](const uint8_t* src) {
+#pragma unroll
+    for (int i = 0; i < G::WREG; ++i) wnext[i] = *reinterpret_cast<const u32x4*>(src + (i * NTHREADS + tid) * 16);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < G::WREG; ++i) *reinterpret_cast<u32x4*>(wbuf + (i * NTHREADS + tid) * 16) = wnext[i];
+  };
+  auto store_tile = [&](int j, int mt, f32x4 val) {   // real lanes only: the partial tile's spare columns own no slot
+    if (!((real_m >> j) & 1u)) return;
+    bf16x4 o;
+    o[0] = static_cast<__bf16>(val[0]); o[1] = static_cast<__bf16>(val[1]);
+    o[2] = static_cast<__bf16>(val[2]); o[3] = static_cast<__bf16>(val[3]);
+    *reinterpret_cast<bf16x4*>(act + (mt * 2 + (quad >> 1)) * G::PLANE + pix_off[j] + (quad & 1) * 8) = o;
+  };
+  auto store_relu = [&](f32x4 (&x)[G::NT_W][MT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < G::NT_W; ++j) {
+        if (!tile_on[j]) continue;
+        f32x4 t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = fmaxf(x[j][mt][r], 0.0f);
+        store_tile(j, mt, t);
+      }
+  };
+  auto set_bias = [&](f32x4 (&x)[G::NT_W][MT], const float* bias) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const f32x4 c = *reinterpret_cast<const f32x4*>(bias + mt * 16 + quad * 4);
+#pragma unroll
+      for (int j = 0; j < G::NT_W; ++j) x[j][mt] = c;
+    }
+  };
+  auto conv3x3 = [&](f32x4 (&acc)[G::NT_W][MT]) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int tap_off = ((tap / 3 - 1) * W + (tap % 3 - 1)) * 16;
+      int src[G::NT_W];
+#pragma unroll
+      for (int j = 0; j < G::NT_W; ++j) {
+        const int shifted = pix_off[j] + tap_off;
+        src[j] = ((tap_ok[j] >> tap) & 1u) ? shifted : G::ZERO_OFF + (shifted & 0xF0);
+      }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int ks = tap * 2 + half;
+        bf16x8 a[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = lds_read_frag(wbuf + (ks * MT + mt) * WFRAG_BYTES + lane * 16);
+#pragma unroll
+        for (int j = 0; j < G::NT_W; ++j) {
+          const bf16x8 b = lds_read_frag(act + (half * 4 + quad) * G::PLANE + src[j]);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, acc[j][mt], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  const size_t block_stride = 3 * CH * sizeof(float) + 2 * static_cast<size_t>(G::WCONV_BYTES);
+  prefetch(np.blocks + 3 * CH * sizeof(float));
+  __syncthreads();
+
+  for (int blk = 0; blk < nd.depth; ++blk) {
+    const uint8_t* bp = np.blocks + blk * block_stride;
+    const float* affine = reinterpret_cast<const float*>(bp);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(affine + mt * 16 + quad * 4);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(affine + CH + mt * 16 + quad * 4);
+#pragma unroll
+      for (int j = 0; j < G::NT_W; ++j) {
+        if (!tile_on[j]) continue;
+        f32x4 t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = fmaxf(a1[r] * s[j][mt][r] + b1[r], 0.0f);
+        store_tile(j, mt, t);
+      }
+    }
+    commit();
+    __syncthreads();
+    prefetch(bp + 3 * CH * sizeof(float) + G::WCONV_BYTES);
+    f32x4 u[G::NT_W][MT];
+    set_bias(u, affine + 2 * CH);
+    conv3x3(u);
+    __syncthreads();
+    store_relu(u);
+    commit();
+    __syncthreads();
+    if (blk + 1 < nd.depth) prefetch(bp + block_stride + 3 * CH * sizeof(float));
+    else prefetch(np.vx_w);                       // value-head extra conv rides behind the last trunk conv
+    conv3x3(s);
+    __syncthreads();
+  }
+
+  // ---- head 1x1 convs: 128 rows over the raw stream ---------------------------------------------------------
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int j = 0; j < G::NT_W; ++j)
+      if (tile_on[j]) store_tile(j, mt, s[j][mt]);
+  for (int i = tid * 16; i < 2 * 8 * WFRAG_BYTES; i += NTHREADS * 16)
+    *reinterpret_cast<u32x4*>(wbuf + i) = *reinterpret_cast<const u32x4*>(np.head_w + i);
+  __syncthreads();
+  f32x4 hv[G::NT_W][MT], hp[G::NT_W][MT];
+  set_bias(hv, np.head_b);
+  set_bias(hp, np.head_b + HCS);
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int hsel = 0; hsel < 2; ++hsel) {
+      bf16x8 a[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = lds_read_frag(wbuf + (ks * 8 + hsel * 4 + mt) * WFRAG_BYTES + lane * 16);
+#pragma unroll
+      for (int j = 0; j < G::NT_W; ++j) {
+        const bf16x8 b = lds_read_frag(act + (ks * 4 + quad) * G::PLANE + pix_off[j]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          if (hsel == 0) hv[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, hv[j][mt], 0, 0, 0);
+          else hp[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, hp[j][mt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- value head: extra conv, average pool -------------------------------------------------------------------
+  store_relu(hv);
+  commit();                        // vx weights
+  __syncthreads();
+  prefetch(np.px_w);
+  set_bias(hv, np.vx_b);
+  conv3x3(hv);
+  __syncthreads();
+  {
+    float* pool_buf = reinterpret_cast<float*>(act);          // [NPIX][32] fp32, one half of the channels at a time
+    float* psum = reinterpret_cast<float*>(wbuf);             // [TBS][64][4] partial sums (vx weights are dead)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int j = 0; j < G::NT_W; ++j) {
+        if (!((real_m >> j) & 1u)) continue;
+        const int n = (wave + NWAVES * j) * 16 + col;
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2) {
+          f32x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = fmaxf(hv[j][half * 2 + m2][r], 0.0f);
+          *reinterpret_cast<f32x4*>(pool_buf + n * 32 + m2 * 16 + quad * 4) = o;
+        }
+      }
+      __syncthreads();
+      if (tid < TBS * 128) {
+        const int b = tid / 128, r = tid % 128, c = r % 32, part = r / 32;
+        constexpr int per = (G::PIX + 3) / 4;
+        const int p0 = part * per, p1 = (p0 + per < G::PIX) ? p0 + per : G::PIX;
+        float acc = 0.0f;
+        for (int p = p0; p < p1; ++p) acc += pool_buf[(b * G::PIX + p) * 32 + c];
+        psum[(b * 64 + half * 32 + c) * 4 + part] = acc;
+      }
+      __syncthreads();
+    }
+    if (tid < TBS * 64) {
+      const int b = tid / 64, c = tid % 64;
+      const float* q = psum + (b * 64 + c) * 4;
+      if (board0 + b < batch) vpool_out[static_cast<size_t>(board0 + b) * 64 + c] = (((q[0] + q[1]) + q[2]) + q[3]) / static_cast<float>(G::PIX);
+    }
+  }
+  __syncthreads();
+  // ---- policy head: extra conv, 1x1 to the policy channels, softmax over the board -----------------------------
+  if (tid < 8 * 16) {              // the pooling scratch ran over the zero cells of the activation planes
+    const int pl = tid / 16, c = tid % 16;
+    *reinterpret_cast<u32x4*>(act + pl * G::PLANE + G::ZERO_OFF + c * 16) = u32x4{0, 0, 0, 0};
+  }
+  store_relu(hp);
+  commit();                        // px weights
+  __syncthreads();
+  set_bias(hp, np.px_b);
+  conv3x3(hp);
+  __syncthreads();
+  store_relu(hp);
+  for (int i = tid * 16; i < 2 * 2 * WFRAG_BYTES; i += NTHREADS * 16)
+    *reinterpret_cast<u32x4*>(wbuf + i) = *reinterpret_cast<const u32x4*>(np.pol_w + i);
+  __syncthreads();
+  float* lg = reinterpret_cast<float*>(wbuf + 8192);           // [NPIX][pol_ch] logits, = [board][move]
+  {
+    f32x4 pl[G::NT_W][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const f32x4 c = *reinterpret_cast<const f32x4*>(np.pol_b + mt * 16 + quad * 4);
+#pragma unroll
+      for (int j = 0; j < G::NT_W; ++j) pl[j][mt] = c;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) a[mt] = lds_read_frag(wbuf + (ks * 2 + mt) * WFRAG_BYTES + lane * 16);
+#pragma unroll
+      for (int j = 0; j < G::NT_W; ++j) {
+        const bf16x8 b = lds_read_frag(act + (ks * 4 + quad) * G::PLANE + pix_off[j]);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) pl[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, pl[j][mt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < G::NT_W; ++j) {
+      if (!((real_m >> j) & 1u)) continue;
+      const int n = (wave + NWAVES * j) * 16 + col;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = mt * 16 + quad * 4 + r;
+          if (c < nd.pol_ch) lg[n * nd.pol_ch + c] = pl[j][mt][r];
+        }
+    }
+  }
+  __syncthreads();
+  if (wave < TBS && board0 + wave < batch) {   // one wave per board: softmax = exp(log_softmax), neural_net.py:494,816
+    const int M = nd.num_moves;
+    const float* row = lg + wave * M;
+    float mx = -__builtin_inff();
+    for (int e = lane; e < M; e += 64) mx = fmaxf(mx, row[e]);
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    float sum = 0.0f;
+    for (int e = lane; e < M; e += 64) sum += expf(row[e] - mx);
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    float* out = pi_out + static_cast<size_t>(board0 + wave) * M;
+    for (int e = lane; e < M; e += 64) out[e] = expf(row[e] - mx) / sum;
+  }
+}
+
+// Value-head FC stack over the whole batch on the exact-fp32 matrix pipe (v_mfma_f32_16x16x4_f32):
+// x0 = pooled [b][64]; x = relu(W x + b) for fc1 and the extra layers; v = softmax(W2 x + b2).
+// One workgroup = 16 boards; activations live in LDS as [k][16 boards]; weights stream from L2 transposed
+// ([k][out]), 16 outputs x 4 k per MFMA.
+constexpr int VFC_THREADS = 256;
+__global__ __launch_bounds__(VFC_THREADS) void k_value_fc(SpatialDesc nd, SpatialPtrs np, const float* __restrict__ vpool,
+                                                         float* __restrict__ v_out, uint32_t batch) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  float* xa = reinterpret_cast<float*>(lds);                  // [v_hidden][16]
+  float* xb = xa + nd.v_hidden * 16;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 15, quad = lane >> 4;
+  const uint32_t b0 = blockIdx.x * 16;
+  for (int i = tid; i < 64 * 16; i += VFC_THREADS) {
+    const int k = i / 16, b = i % 16;
+    xa[i] = (b0 + b < batch) ? vpool[static_cast<size_t>(b0 + b) * 64 + k] : 0.0f;
+  }
+  __syncthreads();
+  auto layer = [&](const float* wt, const float* bias, int K, int N, const float* xin, float* xout, bool relu) {
+    for (int ot = wave; ot * 16 < N; ot += VFC_THREADS / 64) {
+      f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 8
+      for (int k = 0; k < K; k += 4) {
+        const float a = wt[static_cast<size_t>(k + quad) * N + ot * 16 + col];
+        const float b = xin[(k + quad) * 16 + col];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = ot * 16 + quad * 4 + r;
+        const float y = acc[r] + bias[o];
+        xout[o * 16 + col] = relu ? fmaxf(y, 0.0f) : y;
+      }
+    }
+    __syncthreads();
+  };
+  const int Hd = nd.v_hidden;
+  layer(np.fc1_w, np.fc1_b, 64, Hd, xa, xb, true);
+  float *cur = xb, *nxt = xa;
+  for (int l = 0; l + 1 < nd.v_fc_layers; ++l) {
+    layer(np.fcx_w + static_cast<size_t>(l) * Hd * Hd, np.fcx_b + l * Hd, Hd, Hd, cur, nxt, true);
+    float* t = cur; cur = nxt; nxt = t;
+  }
+  layer(np.fc2_w, np.fc2_b, Hd, 16, cur, nxt, false);
+  if (tid < 16 && b0 + tid < batch) {
+    const int P1 = nd.num_players + 1;
+    float mx = nxt[0 * 16 + tid];
+    for (int i = 1; i < P1; ++i) mx = fmaxf(mx, nxt[i * 16 + tid]);
+    float sum = 0.0f;
+    for (int i = 0; i < P1; ++i) sum += expf(nxt[i * 16 + tid] - mx);
+    for (int i = 0; i < P1; ++i) v_out[static_cast<size_t>(b0 + tid) * P1 + i] = expf(nxt[i * 16 + tid] - mx) / sum;
+  }
+}
+
 thread_local std::string g_net_err;
 int nfail(int code, const char* fmt, ...) {
   char buf[512];
@@ -448,11 +855,32 @@ int nfail(int code, const char* fmt, ...) {
 struct azmi_net {
   NetDesc nd{};
   NetPtrs np{};
+  bool spatial = false;      // spatial policy head (Tafl family): k_leafnet_spatial + k_value_fc
+  SpatialDesc sd{};
+  SpatialPtrs sp{};
+  float* vpool = nullptr;    // [vpool_rows][64] pooled value-head features between the two kernels
+  uint32_t vpool_rows = 0;
+  size_t vfc_lds = 0;
   void* blob = nullptr;
   size_t blob_bytes = 0;
   int device = 0;
   size_t lds_bytes = 0;
 };
+
+namespace {
+bool is_spatial(const azmi_net_desc* d) { return d->policy_channels > 0; }
+size_t spatial_blob_bytes(const azmi_net_desc* d) {
+  const size_t wconv = 18 * MT * WFRAG_BYTES, wsmall = 2 * MT * WFRAG_BYTES;
+  const size_t Hd = d->v_hidden, L = d->v_fc_layers;
+  size_t n = wsmall + CH * 4;                                         // stem
+  n += static_cast<size_t>(d->depth) * (3 * CH * 4 + 2 * wconv);      // trunk
+  n += 2 * 8 * WFRAG_BYTES + 128 * 4;                                 // head 1x1 convs
+  n += 2 * (wconv + 64 * 4);                                          // extra head convs
+  n += 2 * 2 * WFRAG_BYTES + 32 * 4;                                  // policy 1x1
+  n += (64 * Hd + Hd) * 4 + (L - 1) * (Hd * Hd + Hd) * 4 + (Hd * 16 + 16) * 4;
+  return n;
+}
+}  // namespace
 
 extern "C" {
 
@@ -460,6 +888,7 @@ const char* azmi_net_last_error(void) { return g_net_err.c_str(); }
 
 size_t azmi_net_blob_bytes(const azmi_net_desc* d) {
   if (!d) return 0;
+  if (is_spatial(d)) return spatial_blob_bytes(d);
   const size_t wconv = 18 * MT * WFRAG_BYTES, wsmall = 2 * MT * WFRAG_BYTES;
   size_t n = wsmall + CH * 4;
   n += static_cast<size_t>(d->depth) * (3 * CH * 4 + 2 * wconv);
@@ -472,6 +901,54 @@ size_t azmi_net_blob_bytes(const azmi_net_desc* d) {
 
 int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes, int device, azmi_net** out) {
   if (!d || !blob || !out) return nfail(AZMI_ERR_INVALID, "null argument");
+  if (is_spatial(d)) {
+    if (d->channels != CH || d->head_channels != HCS || d->kernel_size != 3 || d->v_head_convs != 1 || d->pi_head_convs != 1)
+      return nfail(AZMI_ERR_INVALID, "spatial leaf net kernel covers 64 trunk / 64 head channels, 3x3 convs, one extra conv per head");
+    if (!(d->height == 11 && d->width == 11)) return nfail(AZMI_ERR_INVALID, "spatial leaf net kernel: board %dx%d not instantiated", d->height, d->width);
+    if (9 * d->in_channels > 64 || d->policy_channels > 32 || d->policy_channels * d->height * d->width != d->num_moves)
+      return nfail(AZMI_ERR_INVALID, "spatial head: 9*C_in <= 64, policy channels <= 32, no global actions");
+    if (d->v_hidden > 512 || d->v_hidden % 16 || d->v_fc_layers < 1 || d->num_players + 1 > 16) return nfail(AZMI_ERR_INVALID, "value head sizes out of range");
+    if (blob_bytes != spatial_blob_bytes(d)) return nfail(AZMI_ERR_INVALID, "weight blob is %zu bytes, expected %zu", blob_bytes, spatial_blob_bytes(d));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return nfail(AZMI_ERR_NO_DEVICE, "no HIP device: libazmi has no CPU path");
+    if (hipSetDevice(device) != hipSuccess) return nfail(AZMI_ERR_NO_DEVICE, "hipSetDevice failed");
+    auto net = new azmi_net();
+    net->device = device; net->spatial = true;
+    net->sd = SpatialDesc{d->in_channels, d->height, d->width, d->depth, d->num_moves, d->num_players, d->v_hidden, d->v_fc_layers, d->policy_channels};
+    if (hipMalloc(&net->blob, blob_bytes) != hipSuccess) { delete net; return nfail(AZMI_ERR_OOM, "hipMalloc(weights) failed"); }
+    if (hipMemcpy(net->blob, blob, blob_bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(net->blob); delete net; return nfail(AZMI_ERR_NO_DEVICE, "weight upload failed"); }
+    net->blob_bytes = blob_bytes;
+    const uint8_t* p = static_cast<const uint8_t*>(net->blob);
+    const size_t wconv = 18 * MT * WFRAG_BYTES, wsmall = 2 * MT * WFRAG_BYTES;
+    const size_t Hd = d->v_hidden, L = d->v_fc_layers;
+    SpatialPtrs& sp = net->sp;
+    auto f32p = [&](size_t count) { const float* q = reinterpret_cast<const float*>(p); p += count * 4; return q; };
+    sp.stem_w = p; p += wsmall; sp.stem_b = f32p(CH);
+    sp.blocks = p; p += static_cast<size_t>(d->depth) * (3 * CH * 4 + 2 * wconv);
+    sp.head_w = p; p += 2 * 8 * WFRAG_BYTES; sp.head_b = f32p(128);
+    sp.vx_w = p; p += wconv; sp.vx_b = f32p(64);
+    sp.px_w = p; p += wconv; sp.px_b = f32p(64);
+    sp.pol_w = p; p += 2 * 2 * WFRAG_BYTES; sp.pol_b = f32p(32);
+    sp.fc1_w = f32p(64 * Hd); sp.fc1_b = f32p(Hd);
+    sp.fcx_w = f32p((L - 1) * Hd * Hd); sp.fcx_b = f32p((L - 1) * Hd);
+    sp.fc2_w = f32p(Hd * 16); sp.fc2_b = f32p(16);
+    using GS = Geo<11, 11, TBS>;
+    net->lds_bytes = GS::ACT_BYTES + GS::WCONV_BYTES;
+    static_assert(GS::NPIX <= NTHREADS, "stem im2col maps one thread to one pixel");
+    static_assert(GS::NPIX * 32 * 4 <= GS::ACT_BYTES, "pooling scratch must fit the activation planes");
+    static_assert(8192 + GS::NPIX * 32 * 4 <= GS::WCONV_BYTES, "policy logits must fit the weight area");
+    static_assert(16384 + TBS * 64 * GS::PIX * 4 / 7 <= GS::WCONV_BYTES, "input staging must fit");
+    net->vfc_lds = 2 * Hd * 16 * sizeof(float);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_leafnet_spatial<11, 11>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(net->lds_bytes)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_value_fc), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(net->vfc_lds)) != hipSuccess) {
+      (void)hipFree(net->blob); delete net;
+      return nfail(AZMI_ERR_NO_DEVICE, "cannot reserve LDS for the spatial leaf net");
+    }
+    *out = net;
+    return AZMI_OK;
+  }
   if (d->channels != CH || d->head_channels != HC || d->kernel_size != 3)
     return nfail(AZMI_ERR_INVALID, "leaf net kernel covers 64 trunk channels, 32 head channels, 3x3 convs");
   if (!(d->height == 6 && d->width == 7)) return nfail(AZMI_ERR_INVALID, "leaf net kernel: board %dx%d not instantiated", d->height, d->width);
@@ -518,12 +995,28 @@ void azmi_net_destroy(azmi_net* net) {
   if (!net) return;
   (void)hipSetDevice(net->device);
   (void)hipFree(net->blob);
+  if (net->vpool) (void)hipFree(net->vpool);
   delete net;
 }
 
 int azmi_net_forward(azmi_net* net, const float* dev_canonical, float* dev_v, float* dev_pi, uint32_t batch, void* stream) {
   if (!net || !dev_canonical || !dev_v || !dev_pi) return nfail(AZMI_ERR_INVALID, "null argument");
   if (batch == 0) return AZMI_OK;
+  if (net->spatial) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (batch > net->vpool_rows) {   // grows on first use / larger batches only (synchronous, outside steady state)
+      (void)hipSetDevice(net->device);
+      if (net->vpool) { (void)hipDeviceSynchronize(); (void)hipFree(net->vpool); net->vpool = nullptr; net->vpool_rows = 0; }
+      if (hipMalloc(reinterpret_cast<void**>(&net->vpool), static_cast<size_t>(batch) * 64 * sizeof(float)) != hipSuccess)
+        return nfail(AZMI_ERR_OOM, "hipMalloc(value-head scratch) failed");
+      net->vpool_rows = batch;
+    }
+    k_leafnet_spatial<11, 11><<<(batch + TBS - 1) / TBS, NTHREADS, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, net->vpool, dev_pi, batch);
+    k_value_fc<<<(batch + 15) / 16, VFC_THREADS, net->vfc_lds, st>>>(net->sd, net->sp, net->vpool, dev_v, batch);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return nfail(AZMI_ERR_NO_DEVICE, "k_leafnet_spatial launch: %s", hipGetErrorString(e));
+    return AZMI_OK;
+  }
   const uint32_t tiles = (batch + TB - 1) / TB;
   k_leafnet<6, 7, 4, 16><<<tiles, NTHREADS, net->lds_bytes, static_cast<hipStream_t>(stream)>>>(net->nd, net->np, dev_canonical, dev_v, dev_pi, batch, getenv("AZMI_NET_DEBUG") ? static_cast<uint32_t>(atoi(getenv("AZMI_NET_DEBUG"))) : 0u);
   const hipError_t e = hipGetLastError();

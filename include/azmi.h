@@ -204,6 +204,9 @@ typedef struct azmi_net_desc {
   int32_t channels, depth, kernel_size; /* NNArgs.num_channels / depth / kernel_size */
   int32_t head_channels, v_hidden;      /* NNArgs.head_channels / v_fc_hidden */
   int32_t num_moves, num_players;
+  /* head options (neural_net.py:56-75, 341-427). policy_channels > 0 selects the spatial policy head
+   * (POLICY_SHAPE[0]; Tafl family 22) and its kernel; 0 = flat FC policy head. */
+  int32_t v_head_convs, pi_head_convs, v_fc_layers, policy_channels;
 } azmi_net_desc;
 typedef struct azmi_net azmi_net;
 size_t azmi_net_blob_bytes(const azmi_net_desc* desc);

@@ -84,5 +84,62 @@ def main():
     print("LeafNet vs reference NNArch: max |dv| =", float((v2 - v).abs().max()), " max |dpi| =", float((pi2 - pi).abs().max()))
 
 
+class Tw:  # TawlbwrddGS statics (py_wrapper.cc:549-560); POLICY_SHAPE switches the spatial head on
+    @staticmethod
+    def CANONICAL_SHAPE(): return (7, 11, 11)
+    @staticmethod
+    def NUM_PLAYERS(): return 2
+    @staticmethod
+    def NUM_MOVES(): return 2662
+    @staticmethod
+    def POLICY_SHAPE(): return (22, 11, 11)
+
+
+def main_tawlbwrdd():
+    """configs/tawlbwrdd.yaml:6-16: 4 blocks x 64 ch, k3, head_channels 64, one extra conv per head,
+    v_fc_layers 2, spatial policy head.  16 positions from oracle random playouts."""
+    args = ref_nn.NNArgs(num_channels=64, depth=4, kernel_size=3, dense_net=False, head_channels=64,
+                         v_head_convs=1, pi_head_convs=1, v_fc_layers=2, spatial_policy="on")
+    torch.manual_seed(0)
+    net = ref_nn.NNArch(Tw, args)
+    g = torch.Generator().manual_seed(1)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.2)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) * 1.0 + 0.5)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) * 0.8 + 0.6)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    net.eval()
+    rng = np.random.default_rng(4)
+    xs = []
+    while len(xs) < 16:
+        game = orc.Game(orc.GAME_TAWLBWRDD)
+        for _ in range(int(rng.integers(0, 60))):
+            if game.scores() is not None:
+                break
+            game.play(int(rng.choice(np.flatnonzero(game.valid()))))
+        xs.append(game.canonical())
+    x = torch.from_numpy(np.stack(xs))
+    with torch.no_grad():
+        v, pi = net(x)
+        v, pi = torch.exp(v), torch.exp(pi)
+    out = {"input": x.numpy(), "v": v.numpy(), "pi": pi.numpy()}
+    for k, t in net.state_dict().items():
+        out["sd." + k] = t.numpy()
+    path = os.path.join(HERE, "nn_tawlbwrdd_4b64c.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes;", sum(p.numel() for p in net.parameters()), "params")
+    sys.modules.pop("alphazero", None)
+    sys.path.insert(0, os.path.join(ROOT, "alphazero-pybind11_amd"))
+    from alphazero import torch_net
+    mine = torch_net.LeafNet(torch_net.tawlbwrdd_spec())
+    mine.load_state_dict(net.state_dict())
+    v2, pi2 = mine.process(x)
+    print("LeafNet vs reference NNArch (tawlbwrdd): max |dv| =", float((v2 - v).abs().max()), " max |dpi| =", float((pi2 - pi).abs().max()))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "tawlbwrdd":
+        main_tawlbwrdd()
+    else:
+        main()

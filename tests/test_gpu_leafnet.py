@@ -65,3 +65,54 @@ def test_batch_shapes_and_batch_invariance(batch):
     with torch.no_grad():
         vr, pr = net.to(dev).process(x)
     assert (v - vr).abs().max().item() <= TOL and (pi - pr).abs().max().item() <= TOL
+
+
+# ---------------------------------------------------------------- spatial policy head (Tafl family)
+def _tafl_fixture_net():
+    from alphazero import torch_net
+    fx = np.load(os.path.join(HERE, "golden", "nn_tawlbwrdd_4b64c.npz"))
+    net = torch_net.LeafNet(torch_net.tawlbwrdd_spec())
+    net.load_state_dict({k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("sd.")})
+    return fx, net.eval()
+
+
+def test_spatial_net_matches_reference_nnarch_fixture():
+    """configs/tawlbwrdd.yaml net (4b64c, head 64, extra head convs, 2 value FC layers, spatial policy head):
+    the two-kernel HIP path vs the reference NNArch's fp32 outputs (fixture), same bf16 tolerance."""
+    import alphazero as az
+    fx, net = _tafl_fixture_net()
+    dev = torch.device("cuda:0")
+    hip = az.HipLeafNet(net)
+    x = torch.from_numpy(fx["input"]).to(dev)
+    v, pi = hip.process(x)
+    torch.cuda.synchronize()
+    dv = np.abs(v.cpu().numpy() - fx["v"]).max()
+    dpi = np.abs(pi.cpu().numpy() - fx["pi"]).max()
+    print("spatial hip vs reference fp32: max|dv| %.3e max|dpi| %.3e" % (dv, dpi))
+    assert dv <= TOL and dpi <= TOL, (dv, dpi)
+    assert np.allclose(v.sum(1).cpu().numpy(), 1, atol=1e-5) and np.allclose(pi.sum(1).cpu().numpy(), 1, atol=1e-4)
+    net_dev = net.to(dev)
+    v16, pi16 = net_dev.process(x, amp_dtype=torch.bfloat16)
+    e16 = max(np.abs(v16.cpu().numpy() - fx["v"]).max(), np.abs(pi16.cpu().numpy() - fx["pi"]).max())
+    print("torch bf16 autocast vs reference fp32: %.3e" % e16)
+    assert max(dv, dpi) <= max(2 * e16, 5e-3), (dv, dpi, e16)
+
+
+@pytest.mark.parametrize("batch", [1, 2, 3, 4, 50, 2048])
+def test_spatial_batch_shapes_and_invariance(batch):
+    """Ragged batches (not a multiple of the 3-board tile / the 16-board FC tile) and row invariance."""
+    import alphazero as az
+    from alphazero import torch_net
+    dev = torch.device("cuda:0")
+    net = torch_net.random_init(torch_net.tawlbwrdd_spec(), seed=5)
+    hip = az.HipLeafNet(net)
+    g = torch.Generator().manual_seed(batch)
+    x = (torch.rand((batch, 7, 11, 11), generator=g) < 0.2).float().to(dev)
+    v, pi = hip.process(x)
+    v1, pi1 = hip.process(x[:1].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(v[:1], v1) and torch.equal(pi[:1], pi1)
+    with torch.no_grad():
+        vr, pr = net.to(dev).process(x)
+    assert (v - vr).abs().max().item() <= TOL and (pi - pr).abs().max().item() <= TOL
+    assert torch.isfinite(pi).all() and torch.isfinite(v).all()
