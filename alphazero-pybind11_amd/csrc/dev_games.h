@@ -143,6 +143,11 @@ struct Tawlbwrdd {
     uint32_t turn, player, rep;  // rep = current_repetition_count_
   };
 
+  // engine state words (engine_kernels_big.h load/store): word 4 = king | turn << 8 | player << 24 | rep << 32
+  __host__ __device__ static uint32_t player_from_words(const uint64_t* words, uint32_t S, uint32_t slot) {
+    return static_cast<uint32_t>(words[4 * static_cast<size_t>(S) + slot] >> 24) & 1u;
+  }
+
   __host__ __device__ static bool bit(const uint64_t (&b)[2], uint32_t sq) { return ((sq < 64 ? b[0] : b[1]) >> (sq & 63)) & 1ULL; }
   __host__ __device__ static void setb(uint64_t (&b)[2], uint32_t sq) { if (sq < 64) b[0] |= 1ULL << sq; else b[1] |= 1ULL << (sq - 64); }
   __host__ __device__ static void clrb(uint64_t (&b)[2], uint32_t sq) { if (sq < 64) b[0] &= ~(1ULL << sq); else b[1] &= ~(1ULL << (sq - 64)); }

@@ -135,6 +135,7 @@ int launch_round(azmi_pm* pm, hipStream_t st) {
     }
     case AZMI_GAME_TAWLBWRDD:
       k_round_big<Tawlbwrdd><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
+      if (pm->ep.half_nodes) k_compact<Tawlbwrdd><<<pm->ep.S * pm->gi.P, 256, 0, st>>>(pm->ep, pm->ar);
       break;
     default:
       return fail(AZMI_ERR_INVALID, "game %d has no device kernels", pm->game);
@@ -384,7 +385,17 @@ int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_o
   // Connect4: cap_branch == maxk, a hard bound.  Wide games: sized for the average branching factor and
   // capped at 16 M nodes per tree; running out raises overflow bit 1 (arena compaction is the next step).
   uint64_t cap64 = (static_cast<uint64_t>((gi.max_turns + 1) / 2) * max_visits + gi.max_turns) * gi.cap_branch + 8;
-  if (gi.cap_branch != gi.maxk) cap64 = std::min<uint64_t>(cap64, 16u << 20);
+  ep.half_nodes = 0; ep.compact_above = 0;
+  if (gi.cap_branch != gi.maxk) {
+    // wide games: two halves of 4 searches' worth of nodes each; the live subtree is copied into the idle
+    // half (k_compact) when a move leaves less than one search of room in the active one
+    const uint64_t growth = (static_cast<uint64_t>(max_visits) + 12 + (opts.max_inline ? opts.max_inline : 4)) * (gi.cap_branch * 3 / 2);
+    const uint64_t half = std::min<uint64_t>(std::max<uint64_t>(4 * growth, 64u << 10), 8u << 20);
+    ep.half_nodes = static_cast<uint32_t>(half);
+    ep.compact_above = static_cast<uint32_t>(half > growth ? half - growth : half / 2);
+    cap64 = 2 * half;
+    if (const char* e = getenv("AZMI_COMPACT_ABOVE")) ep.compact_above = static_cast<uint32_t>(atoi(e));  // test hook: 0 = compact after every move
+  }
   if (cap64 > 0xFFFFFFF0ULL) { delete pm; return fail(AZMI_ERR_INVALID, "tree arena too large"); }
   if (game != AZMI_GAME_CONNECT4 && params->max_cache_size != 0) { delete pm; return fail(AZMI_ERR_INVALID, "the device position cache is wired for Connect4 only in this build; set max_cache_size=0"); }
   ep.cap = static_cast<uint32_t>(cap64);
@@ -447,6 +458,7 @@ int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_o
   ep.trace_slot = getenv("AZMI_TRACE_SLOT") ? static_cast<uint32_t>(atoi(getenv("AZMI_TRACE_SLOT"))) : 0xFFFFFFFFu;
   ep.trace_cap = ep.trace_slot != 0xFFFFFFFFu ? (1u << 16) : 1u;
   A(trace, 2 * static_cast<size_t>(ep.trace_cap), true);
+  if (ep.half_nodes) A(compact_flag, T, true);
   if (ep.gumbel_on) {
     A(gum_state, static_cast<size_t>(S) * P * 8, true);
     A(gum_g, static_cast<size_t>(S) * P * ep.gum_stride, true);

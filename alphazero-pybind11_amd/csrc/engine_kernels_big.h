@@ -184,7 +184,9 @@ struct BigSlot {
       sync();
     }
     const uint32_t c0 = AZB_SEL(t_bump, seat);
-    if (c0 + k > ep.cap) { raise(1u); return false; }
+    // the bump pointer lives in one half of the arena (k_compact ping-pongs between them)
+    const uint32_t limit = ep.half_nodes ? ((c0 - 1) / ep.half_nodes + 1) * ep.half_nodes : ep.cap;
+    if (c0 + k > limit) { raise(1u); return false; }
     for (uint32_t i = lane; i < k; i += G) {
       const size_t ci = tb + c0 + i;
       ar.N[ci] = 0; ar.Q[ci] = 0.0f; ar.Pr[ci] = 0.0f; ar.D[ci] = 0.0f; ar.V[ci] = 0.0f;
@@ -664,6 +666,14 @@ struct BigSlot {
     } else {
       reapply_root_prior(gs.player, ep.epsilon > 0 && !(flags & kFlagCapped));
     }
+    if (ep.half_nodes && lane == 0) {   // ask k_compact to move a tree whose active half is filling up
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const uint32_t b = t_bump[p];
+        const uint32_t used = b - ((b - 1) / ep.half_nodes) * ep.half_nodes;
+        if (used > ep.compact_above) ar.compact_flag[slot * P + p] = 1;
+      }
+    }
     return false;
   }
 
@@ -753,6 +763,77 @@ __global__ __launch_bounds__(64) void k_round_big(EngineParams ep, EngineArrays 
     if (++inline_sims >= ep.max_inline) break;
   }
   c.store(kSlotWaitEval);
+}
+
+// Arena compaction for wide games: copies the subtree under the current root into the idle half of the
+// tree's arena in breadth-first order (children of a node stay contiguous and keep their order, so the
+// search is unchanged), leaves a forwarding index in the old copy and re-points the slot's pending
+// simulation (MCTS::current_ / path_).  One workgroup per flagged tree; HBM-bound: 28 B read + 28 B
+// written per live node.
+template <class GM>
+__global__ __launch_bounds__(256) void k_compact(EngineParams ep, EngineArrays ar) {
+  constexpr int P = GM::P;
+  const uint32_t t = blockIdx.x, tid = threadIdx.x;
+  if (ar.ctl->stop || !ar.compact_flag[t]) return;
+  const uint32_t slot = t / P, seat = t % P;
+  const uint32_t H = ep.half_nodes;
+  const size_t tb = static_cast<size_t>(t) * ep.cap;
+  uint32_t* N = ar.N + tb; float* Q = ar.Q + tb; float* Pr = ar.Pr + tb; float* D = ar.D + tb; float* V = ar.V + tb;
+  uint64_t* META = ar.META + tb;
+  const uint32_t old_root = ar.root[t], old_bump = ar.bump[t];
+  const uint32_t dst0 = (((old_bump - 1) / H) ^ 1u) * H;
+  __shared__ uint32_t s_off[256], s_oldc0[256], s_scan[256];
+  if (tid == 0) {
+    N[dst0] = N[old_root]; Q[dst0] = Q[old_root]; Pr[dst0] = Pr[old_root]; D[dst0] = D[old_root]; V[dst0] = V[old_root];
+    META[dst0] = META[old_root];
+    META[old_root] = dst0;   // forwarding index
+  }
+  __syncthreads();
+  uint32_t lo = dst0, hi = dst0 + 1, bump = dst0 + 1;
+  bool overflow = false;
+  while (lo < hi && !overflow) {
+    for (uint32_t base = lo; base < hi && !overflow; base += 256) {
+      const uint32_t i = base + tid;
+      uint32_t k = 0, oc0 = 0;
+      uint64_t m = 0;
+      if (i < hi) { m = META[i]; k = meta_nch(m); oc0 = meta_ch0(m); }
+      s_scan[tid] = k;
+      __syncthreads();
+      for (uint32_t d = 1; d < 256; d <<= 1) {   // inclusive Hillis-Steele scan
+        const uint32_t v = tid >= d ? s_scan[tid - d] : 0u;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+      }
+      const uint32_t total = s_scan[255], off = s_scan[tid] - k;
+      if (bump + total > dst0 + H) { overflow = true; break; }   // uniform: total and bump are block-wide values
+      if (k > 0) META[i] = (m & ~0xFFFFFFFFull) | static_cast<uint64_t>(bump + off);
+      s_off[tid] = off; s_oldc0[tid] = oc0;
+      __syncthreads();
+      for (uint32_t e = tid; e < total; e += 256) {
+        uint32_t a = 0, b = 256;                    // last j with s_off[j] <= e
+        while (b - a > 1) { const uint32_t mid = (a + b) >> 1; if (s_off[mid] <= e) a = mid; else b = mid; }
+        const uint32_t src = s_oldc0[a] + (e - s_off[a]), dst = bump + e;
+        N[dst] = N[src]; Q[dst] = Q[src]; Pr[dst] = Pr[src]; D[dst] = D[src]; V[dst] = V[src];
+        META[dst] = META[src];
+        META[src] = dst;
+      }
+      bump += total;
+      __syncthreads();
+    }
+    lo = hi; hi = bump;
+  }
+  if (overflow) { if (tid == 0) { atomicOr(&ar.ctl->overflow, 1u); ar.ctl->stop = 1; } return; }
+  if (tid == 0) {
+    // the slot's pending simulation runs in the tree of the player to move
+    if (ar.sstate[slot] == kSlotWaitEval && GM::player_from_words(ar.gs_words, ep.S, slot) == seat) {
+      uint32_t* path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
+      const uint32_t plen = ar.plen[slot];
+      for (uint32_t i = 0; i < plen; ++i) path[i] = static_cast<uint32_t>(META[path[i]]);
+      ar.cur[slot] = static_cast<uint32_t>(META[ar.cur[slot]]);
+    }
+    ar.root[t] = dst0; ar.bump[t] = bump; ar.compact_flag[t] = 0;
+  }
 }
 
 }  // namespace azmi

@@ -54,6 +54,9 @@ struct EngineParams {  // run constants (PlayParams, play_manager.h:60-154, afte
   uint32_t gumbel_on, gumbel_m, gumbel_full, fast_gumbel;
   float gumbel_c_visit, gumbel_c_scale;
   uint32_t gum_stride;     // floats per tree in gum_g (>= max children of a root)
+  // wide games: the arena is two halves of `half_nodes`; the live subtree is copied into the idle half
+  // (k_compact) once the active half holds more than `compact_above` nodes after a move. 0 = one flat arena.
+  uint32_t half_nodes, compact_above;
 };
 
 struct Control {  // small device control block, copied back by azmi_pm_poll
@@ -133,6 +136,7 @@ struct EngineArrays {
   uint32_t* gum_state;    // [trees][8]: target, initialized, n_survivors, phase_idx, sims_in_phase, m_eff, remaining
   float* gum_g;           // [trees][gum_stride] Gumbel(0,1) sample per root child
   uint16_t* gum_surv;     // [trees][kGumMaxM] surviving root-child indices, best first
+  uint32_t* compact_flag; // [trees] set by make_move, consumed by k_compact
 };
 
 }  // namespace azmi

@@ -141,3 +141,30 @@ def test_playmanager_option_tiers(oracle, cfg):
     for k, v in cfg.items():
         setattr(pp, k, v)
     _compare(az, oracle, pp, seed=31337, S=4)
+
+
+def test_arena_compaction_is_invisible_to_the_search(oracle, monkeypatch):
+    """k_compact (ping-pong arena halves) forced after EVERY move (AZMI_COMPACT_ABOVE=0): the games must still
+    equal the oracle's move for move, count for count — the copy keeps child order and re-points the pending path."""
+    import alphazero as az
+    monkeypatch.setenv("AZMI_COMPACT_ABOVE", "0")
+    pp = az.PlayParams()
+    pp.eval_type = [az.EvalType.RANDOM, az.EvalType.RANDOM]
+    pp.history_enabled = True
+    pp.games_to_play, pp.concurrent_games, pp.mcts_visits = 6, 6, [40, 40]
+    pp.cpuct, pp.fpu_reduction, pp.epsilon, pp.shaped_dirichlet = 1.25, 0.25, 0.25, True
+    seed = 31
+    pm = az.PlayManager(az.TawlbwrddGS(), pp, seed=seed, log_moves=True)
+    pm.play()
+    rows, counts = pm.move_log()
+    games = pm.slot_games()
+    assert int(games.sum()) == 6
+    for s in range(6):
+        one = az.PlayParams(); one.__dict__.update(pp.__dict__)
+        one.games_to_play, one.concurrent_games = 1, 1
+        o = oracle.PlayManager(oracle.GAME_TAWLBWRDD, one, oracle.slot_seed(seed, s), per_slot_rng=False)
+        o.run()
+        orows, ocounts = o.moves()
+        sel = rows[:, 0] == s
+        assert np.array_equal(rows[sel][:, 1:], orows[:, 1:]), s
+        assert np.array_equal(counts[sel], ocounts), s
