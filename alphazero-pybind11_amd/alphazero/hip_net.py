@@ -59,6 +59,22 @@ def _f32(x):
     return np.ascontiguousarray(np.asarray(x, dtype=np.float64).astype(np.float32)).tobytes()
 
 
+def _f32_frags(w):
+    """w [N][K] (rows = outputs, N % 16 == 0, K % 16 == 0) -> f32 MFMA A-fragments [N/16][K/16][64 lanes][4]:
+    element j of lane l = w[16*tile + (l & 15)][16*group + 4*j + (l >> 4)] (v_mfma_f32_16x16x4_f32, k-step j)."""
+    w = np.asarray(w, dtype=np.float64)
+    N, K = w.shape
+    assert N % 16 == 0 and K % 16 == 0
+    lanes = np.arange(64)
+    out = np.zeros((N // 16, K // 16, 64, 4), np.float32)
+    for t in range(N // 16):
+        rows = 16 * t + (lanes & 15)
+        for g in range(K // 16):
+            for j in range(4):
+                out[t, g, :, j] = w[rows, 16 * g + 4 * j + (lanes >> 4)]
+    return out.tobytes()
+
+
 def _fold_trunk(net, sd, Cin):
     blob = bytearray()
     a, b = (t.cpu() for t in bn_affine(net.bn1))
@@ -80,7 +96,7 @@ def _fold_trunk(net, sd, Cin):
 def fold_spatial(net):
     """Spatial-policy-head nets (Tafl family: head_channels 64, one extra conv per head, v_fc_layers >= 1).
     Blob: stem | blocks | head frag[2][8] + b[128] | v_extra frag[18][4] + b[64] | pi_extra frag[18][4] + b[64] |
-    policy 1x1 frag[2][2] + b[32] | fc1 W^T[64][Hd] b | extra FC (W^T[Hd][Hd])* then (b[Hd])* | fc2 W^T[Hd][16] b[16]."""
+    policy 1x1 frag[2][2] + b[32] | fc1 f32-frag[Hd/16][4] b | extra FC (f32-frag[Hd/16][Hd/16])* then (b[Hd])* | fc2 f32-frag[1][Hd/16] b[16]."""
     spec = net.spec
     Cin, H, W = spec.in_shape
     assert spec.num_channels == 64 and spec.head_channels == 64 and spec.kernel_size == 3 and spec.head_pool
@@ -102,14 +118,14 @@ def fold_spatial(net):
     wpol[:pc] = sd["pi_conv2.weight"][:, :, 0, 0] * a2[:, None]
     bpol = torch.zeros(32, dtype=torch.float64); bpol[:pc] = b2
     blob += _frags(wpol.numpy()) + _f32(bpol)
-    blob += _f32(sd["v_fc1.weight"].t().contiguous()) + _f32(sd["v_fc1.bias"])
+    blob += _f32_frags(sd["v_fc1.weight"].numpy()) + _f32(sd["v_fc1.bias"])
     for l in range(L - 1):
-        blob += _f32(sd[f"v_fc_extra.{2 * l}.weight"].t().contiguous())
+        blob += _f32_frags(sd[f"v_fc_extra.{2 * l}.weight"].numpy())
     for l in range(L - 1):
         blob += _f32(sd[f"v_fc_extra.{2 * l}.bias"])
-    w2 = torch.zeros((Hd, 16), dtype=torch.float64); w2[:, :P1] = sd["v_fc2.weight"].t()
+    w2 = np.zeros((16, Hd)); w2[:P1] = sd["v_fc2.weight"].numpy()
     b2f = torch.zeros(16, dtype=torch.float64); b2f[:P1] = sd["v_fc2.bias"]
-    blob += _f32(w2) + _f32(b2f)
+    blob += _f32_frags(w2) + _f32(b2f)
     desc = NetDescC(Cin, H, W, 64, spec.depth, 3, 64, Hd, spec.num_moves, spec.num_players, 1, 1, L, pc)
     assert len(blob) == lib.azmi_net_blob_bytes(C.byref(desc)), (len(blob), lib.azmi_net_blob_bytes(C.byref(desc)))
     return desc, bytes(blob)

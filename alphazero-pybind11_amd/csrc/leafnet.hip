@@ -456,11 +456,11 @@ struct SpatialPtrs {
   const uint8_t* px_w; const float* px_b;   // policy-head extra conv
   const uint8_t* pol_w;    // frag[2 ks][2 mt]: rows 0..pol_ch-1 = pi_conv2*pi_bn2, zero padded to 32
   const float* pol_b;      // [32]
-  const float* fc1_w;      // W^T [64][v_hidden]
+  const float* fc1_w;      // f32 A-fragments [v_hidden/16 tiles][64/16 groups][64 lanes][4]
   const float* fc1_b;
-  const float* fcx_w;      // (v_fc_layers-1) x W^T [v_hidden][v_hidden]
+  const float* fcx_w;      // (v_fc_layers-1) x fragments [v_hidden/16][v_hidden/16][64][4]
   const float* fcx_b;      // (v_fc_layers-1) x [v_hidden]
-  const float* fc2_w;      // W^T [v_hidden][16], columns >= P+1 zero
+  const float* fc2_w;      // fragments [1][v_hidden/16][64][4], rows >= P+1 zero
   const float* fc2_b;      // [16]
 };
 
@@ -790,12 +790,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_leafnet_spatial(SpatialDesc nd,
 // x0 = pooled [b][64]; x = relu(W x + b) for fc1 and the extra layers; v = softmax(W2 x + b2).
 // One workgroup = 16 boards; activations live in LDS as [k][16 boards]; weights stream from L2 transposed
 // ([k][out]), 16 outputs x 4 k per MFMA.
-constexpr int VFC_THREADS = 256;
+constexpr int VFC_THREADS = 1024;
+constexpr int VFC_WAVES = VFC_THREADS / 64;
 __global__ __launch_bounds__(VFC_THREADS) void k_value_fc(SpatialDesc nd, SpatialPtrs np, const float* __restrict__ vpool,
                                                          float* __restrict__ v_out, uint32_t batch) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   float* xa = reinterpret_cast<float*>(lds);                  // [v_hidden][16]
   float* xb = xa + nd.v_hidden * 16;
+  float* part = xb + nd.v_hidden * 16;                        // [VFC_WAVES][16 outputs][16 boards]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 15, quad = lane >> 4;
   const uint32_t b0 = blockIdx.x * 16;
   for (int i = tid; i < 64 * 16; i += VFC_THREADS) {
@@ -803,39 +805,71 @@ __global__ __launch_bounds__(VFC_THREADS) void k_value_fc(SpatialDesc nd, Spatia
     xa[i] = (b0 + b < batch) ? vpool[static_cast<size_t>(b0 + b) * 64 + k] : 0.0f;
   }
   __syncthreads();
-  auto layer = [&](const float* wt, const float* bias, int K, int N, const float* xin, float* xout, bool relu) {
-    for (int ot = wave; ot * 16 < N; ot += VFC_THREADS / 64) {
-      f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 8
-      for (int k = 0; k < K; k += 4) {
-        const float a = wt[static_cast<size_t>(k + quad) * N + ot * 16 + col];
-        const float b = xin[(k + quad) * 16 + col];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+  // hidden layers: a wave owns output tiles {wave, wave + 16, ...} two at a time, so 16 weight loads are in flight
+  // per wave (the loop is bound by L2 latency, not by the matrix pipe)
+  // Weights are stored on the host in MFMA A-fragment order: frag[out tile][k group of 16][lane][4], element j of lane l
+  // = W[16*tile + (l & 15)][16*group + 4*j + (l >> 4)], so one 16-byte load feeds four k-steps.  A wave owns output
+  // tiles {wave, wave + 16} together: the loop is bound by L2 latency, not by the matrix pipe.
+  auto layer = [&](const float* wt, const float* bias, int K, int N, const float* xin, float* xout) {
+    const int ntiles = N / 16, kgroups = K / 16;
+    for (int t0 = wave; t0 < ntiles; t0 += 2 * VFC_WAVES) {
+      const int t1 = t0 + VFC_WAVES;
+      const bool two = t1 < ntiles;
+      const f32x4* w0 = reinterpret_cast<const f32x4*>(wt) + static_cast<size_t>(t0) * kgroups * 64 + lane;
+      const f32x4* w1 = reinterpret_cast<const f32x4*>(wt) + static_cast<size_t>(two ? t1 : t0) * kgroups * 64 + lane;
+      f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+      for (int kg = 0; kg < kgroups; ++kg) {
+        const f32x4 a0 = w0[kg * 64], a1 = w1[kg * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float b = xin[(kg * 16 + j * 4 + quad) * 16 + col];
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b, acc1, 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int o = ot * 16 + quad * 4 + r;
-        const float y = acc[r] + bias[o];
-        xout[o * 16 + col] = relu ? fmaxf(y, 0.0f) : y;
+        const int o0 = t0 * 16 + quad * 4 + r;
+        xout[o0 * 16 + col] = fmaxf(acc0[r] + bias[o0], 0.0f);
+        if (two) { const int o1 = t1 * 16 + quad * 4 + r; xout[o1 * 16 + col] = fmaxf(acc1[r] + bias[o1], 0.0f); }
       }
     }
     __syncthreads();
   };
   const int Hd = nd.v_hidden;
-  layer(np.fc1_w, np.fc1_b, 64, Hd, xa, xb, true);
+  layer(np.fc1_w, np.fc1_b, 64, Hd, xa, xb);
   float *cur = xb, *nxt = xa;
   for (int l = 0; l + 1 < nd.v_fc_layers; ++l) {
-    layer(np.fcx_w + static_cast<size_t>(l) * Hd * Hd, np.fcx_b + l * Hd, Hd, Hd, cur, nxt, true);
+    layer(np.fcx_w + static_cast<size_t>(l) * Hd * Hd, np.fcx_b + l * Hd, Hd, Hd, cur, nxt);
     float* t = cur; cur = nxt; nxt = t;
   }
-  layer(np.fc2_w, np.fc2_b, Hd, 16, cur, nxt, false);
+  {  // output layer (one tile of 16 padded rows): k groups split over the waves, partial tiles summed in wave order
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int gper = Hd / 16 / VFC_WAVES;
+    const f32x4* w = reinterpret_cast<const f32x4*>(np.fc2_w) + lane;
+    for (int kg = wave * gper; kg < (wave + 1) * gper; ++kg) {
+      const f32x4 a = w[kg * 64];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], cur[(kg * 16 + j * 4 + quad) * 16 + col], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[(wave * 16 + quad * 4 + r) * 16 + col] = acc[r];
+  }
+  __syncthreads();
   if (tid < 16 && b0 + tid < batch) {
     const int P1 = nd.num_players + 1;
-    float mx = nxt[0 * 16 + tid];
-    for (int i = 1; i < P1; ++i) mx = fmaxf(mx, nxt[i * 16 + tid]);
+    float lg[16];
+    for (int i = 0; i < P1; ++i) {
+      float a = np.fc2_b[i];
+      for (int w = 0; w < VFC_WAVES; ++w) a += part[(w * 16 + i) * 16 + tid];
+      lg[i] = a;
+    }
+    float mx = lg[0];
+    for (int i = 1; i < P1; ++i) mx = fmaxf(mx, lg[i]);
     float sum = 0.0f;
-    for (int i = 0; i < P1; ++i) sum += expf(nxt[i * 16 + tid] - mx);
-    for (int i = 0; i < P1; ++i) v_out[static_cast<size_t>(b0 + tid) * P1 + i] = expf(nxt[i * 16 + tid] - mx) / sum;
+    for (int i = 0; i < P1; ++i) sum += expf(lg[i] - mx);
+    for (int i = 0; i < P1; ++i) v_out[static_cast<size_t>(b0 + tid) * P1 + i] = expf(lg[i] - mx) / sum;
   }
 }
 
@@ -907,7 +941,7 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
     if (!(d->height == 11 && d->width == 11)) return nfail(AZMI_ERR_INVALID, "spatial leaf net kernel: board %dx%d not instantiated", d->height, d->width);
     if (9 * d->in_channels > 64 || d->policy_channels > 32 || d->policy_channels * d->height * d->width != d->num_moves)
       return nfail(AZMI_ERR_INVALID, "spatial head: 9*C_in <= 64, policy channels <= 32, no global actions");
-    if (d->v_hidden > 512 || d->v_hidden % 16 || d->v_fc_layers < 1 || d->num_players + 1 > 16) return nfail(AZMI_ERR_INVALID, "value head sizes out of range");
+    if (d->v_hidden > 512 || d->v_hidden % 256 || d->v_fc_layers < 1 || d->num_players + 1 > 16) return nfail(AZMI_ERR_INVALID, "value head sizes out of range");
     if (blob_bytes != spatial_blob_bytes(d)) return nfail(AZMI_ERR_INVALID, "weight blob is %zu bytes, expected %zu", blob_bytes, spatial_blob_bytes(d));
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return nfail(AZMI_ERR_NO_DEVICE, "no HIP device: libazmi has no CPU path");
@@ -938,7 +972,13 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
     static_assert(GS::NPIX * 32 * 4 <= GS::ACT_BYTES, "pooling scratch must fit the activation planes");
     static_assert(8192 + GS::NPIX * 32 * 4 <= GS::WCONV_BYTES, "policy logits must fit the weight area");
     static_assert(16384 + TBS * 64 * GS::PIX * 4 / 7 <= GS::WCONV_BYTES, "input staging must fit");
-    net->vfc_lds = 2 * Hd * 16 * sizeof(float);
+    net->vfc_lds = (2 * Hd * 16 + VFC_WAVES * 256) * sizeof(float);
+    // scratch for 16384 positions up front: forward() may run under stream capture, where hipMalloc is not allowed
+    net->vpool_rows = 16384;
+    if (hipMalloc(reinterpret_cast<void**>(&net->vpool), static_cast<size_t>(net->vpool_rows) * 64 * sizeof(float)) != hipSuccess) {
+      (void)hipFree(net->blob); delete net;
+      return nfail(AZMI_ERR_OOM, "hipMalloc(value-head scratch) failed");
+    }
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_leafnet_spatial<11, 11>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             static_cast<int>(net->lds_bytes)) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_value_fc), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -32,10 +32,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12000)
     ap.add_argument("--warmup", type=int, default=36000)
-    ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
-    ap.add_argument("--sims", type=int, default=800)
-    ap.add_argument("--engines", type=int, default=4, help="engine shards (HIP streams) per GPU")
-    ap.add_argument("--cache", type=int, default=32_000_000,
+    ap.add_argument("--game", choices=["connect4", "tawlbwrdd"], default="connect4",
+                    help="connect4 = BASELINE configs[1] (the headline); tawlbwrdd = configs[2] (2048 games, 400 sims, YAML net)")
+    ap.add_argument("--games", type=int, default=None, help="concurrent games per GPU (4096 / 2048)")
+    ap.add_argument("--sims", type=int, default=None, help="simulations per move (800 / 400)")
+    ap.add_argument("--engines", type=int, default=None, help="engine shards (HIP streams) per GPU (4 / 2)")
+    ap.add_argument("--cache", type=int, default=None,
                     help="max_cache_size per GPU (reference default 200000, config.py:197; sized up for 288 GB of HBM)")
     ap.add_argument("--inline", type=int, default=0, help="max simulations finished per slot per round without the net (0 = engine default)")
     ap.add_argument("--hwq", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (0 = leave the runtime default of 4)")
@@ -116,24 +118,33 @@ def main():
     import alphazero as az
     from alphazero import torch_net
 
+    tafl = args.game == "tawlbwrdd"
+    if args.games is None: args.games = 2048 if tafl else 4096
+    if args.sims is None: args.sims = 400 if tafl else 800
+    if args.engines is None: args.engines = 2 if tafl else 4
+    if args.cache is None: args.cache = 0 if tafl else 32_000_000      # the device cache is wired for Connect4 only
+    Game = az.TawlbwrddGS if tafl else az.Connect4GS
+    flop_per_eval = 93.1e6 if tafl else FLOP_PER_EVAL
     S, sims, K = args.games, args.sims, args.engines
     assert S % K == 0
     Se = S // K                       # slots per engine shard
     # stream pool (play_manager_bench.cc:171-181: games_to_play = 8 x concurrent), widened when the run is
     # long enough that a slot could finish more than 8 games: a dry stream would idle slots and void the number
     rounds_per_game = 1000 if args.playout_cap else 4000        # conservative lower bounds (measured 2900 / 13000)
+    if tafl: rounds_per_game = 8000
     stream_games = Se * max(8, -(-(args.warmup + args.steps) // rounds_per_game))
     # K engine shards of S/K slots, one HIP stream each: while one shard's leaf batch is on the matrix
     # cores another shard's tree kernel runs on the CUs the net leaves free.
     pms, streams = [], []
     for i in range(K):
         pp = selfplay_params(az, Se, sims, stream_games, cache=args.cache // K, playout_cap=args.playout_cap)
-        pms.append(az.PlayManager(az.Connect4GS(), pp, seed=20240601 + 7919 * rank + 104729 * i, device=local_rank, max_inline=args.inline))
+        pms.append(az.PlayManager(Game(), pp, seed=20240601 + 7919 * rank + 104729 * i, device=local_rank, max_inline=args.inline,
+                                  history_capacity=(400_000 // K if tafl else 0)))
         streams.append(torch.cuda.Stream(device=dev))
     sps = [st.cuda_stream for st in streams]
     io = [pm.io_tensors() for pm in pms]
 
-    spec = torch_net.connect4_spec()
+    spec = torch_net.tawlbwrdd_spec() if tafl else torch_net.connect4_spec()
     net = torch_net.random_init(spec, seed=0).to(dev)
     net_kind = args.net or "hip"
     hip_net = az.HipLeafNet(net, spec, device=local_rank) if net_kind == "hip" else None
@@ -226,9 +237,9 @@ def main():
         # launches of the timed region / the region's wall time (a lower bound on the kernel's own rate);
         # the per-launch HIP-event interval is reported next to it.
         launches = args.steps * K
-        achieved = FLOP_PER_EVAL * Se * launches / dt / 1e12
+        achieved = flop_per_eval * Se * launches / dt / 1e12
         out = {
-            "metric": "self-play games/sec (whole node), Connect4 @ 800 MCTS sims",
+            "metric": "self-play games/sec (whole node), Connect4 @ 800 MCTS sims" if not tafl else f"self-play games/sec (whole node), Tawlbwrdd @ {sims} MCTS sims",
             "value": n_games / dt,
             "unit": "games/s",
             "n_gpus": world,
@@ -241,8 +252,9 @@ def main():
             "dtype": "bf16",
             "data": "synthetic",
             "config": {
-                "workload": f"Connect4, {S} concurrent games/GPU, {sims} sims/move, 6-block/64-ch ResNet (k3, 32 head ch), "
-                            f"self-play flags of game_runner.py:2018-2041 with playout-cap {'ON (25 sims on 75% of moves)' if args.playout_cap else 'off'}, random-init weights",
+                "workload": (f"Tawlbwrdd 11x11, {S} concurrent games/GPU, {sims} sims/move, 4-block/64-ch ResNet (configs/tawlbwrdd.yaml net, spatial head), PUCT, "
+                             if tafl else f"Connect4, {S} concurrent games/GPU, {sims} sims/move, 6-block/64-ch ResNet (k3, 32 head ch), ")
+                            + f"self-play flags of game_runner.py:2018-2041 with playout-cap {'ON (25 sims on 75% of moves)' if args.playout_cap else 'off'}, random-init weights",
                 "concurrent_games_per_gpu": S, "engine_shards": K, "sims_per_move": sims, "net": net_kind,
                 "max_cache_size": args.cache, "cache_hit_rate": hit_rate,
                 "sims_per_s": n_sims / dt, "leaf_evals_per_s": n_evals / dt,
@@ -252,11 +264,11 @@ def main():
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
-                "kernel": "k_leafnet: %d positions x %.1f MFLOP per launch, %d overlapping launches per round" % (Se, FLOP_PER_EVAL / 1e6, K),
+                "kernel": "%s: %d positions x %.1f MFLOP per launch, %d overlapping launches per round" % ("k_leafnet_spatial" if tafl else "k_leafnet", Se, flop_per_eval / 1e6, K),
                 "per_launch_event_ms": nn_ms, "definition": "sum of algorithmic FLOPs of all k_leafnet launches in the timed region / wall time of the region",
             },
         }
-        if world == 1 and hip_net is not None and not args.playout_cap and not args.no_secondary:
+        if world == 1 and hip_net is not None and not args.playout_cap and not args.no_secondary and not tafl:
             # the same workload with playout-cap randomisation at the reference's self-play defaults
             # (fast_mcts_visits 25 on 75 % of moves, config.py:86,100): reported beside the headline, never as it
             w2, k2 = 12000, 6000
@@ -276,7 +288,7 @@ def main():
             out["config"]["playout_cap_on"] = {"games_per_s": (d1 - d0) / dt2, "sims_per_s": (s1 - s0) / dt2, "steps": k2, "warmup": w2,
                                                "live_slots": live2, "note": "25 sims on 75% of moves, 800 on the rest; secondary figure"}
             del pms2
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not tafl:
             out["cpu_baseline"] = cpu_baseline(az, sims, args.cpu_seconds)
         print(json.dumps(out))
     if world > 1:
