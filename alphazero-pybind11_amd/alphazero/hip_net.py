@@ -21,7 +21,7 @@ from .torch_net import bn_affine
 class NetDescC(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("in_channels", "height", "width", "channels", "depth", "kernel_size",
                                          "head_channels", "v_hidden", "num_moves", "num_players", "v_head_convs",
-                                         "pi_head_convs", "v_fc_layers", "policy_channels")]
+                                         "pi_head_convs", "v_fc_layers", "policy_channels", "precision")]
 
 
 lib.azmi_net_blob_bytes.restype = C.c_size_t
@@ -126,13 +126,53 @@ def fold_spatial(net):
     w2 = np.zeros((16, Hd)); w2[:P1] = sd["v_fc2.weight"].numpy()
     b2f = torch.zeros(16, dtype=torch.float64); b2f[:P1] = sd["v_fc2.bias"]
     blob += _f32_frags(w2) + _f32(b2f)
-    desc = NetDescC(Cin, H, W, 64, spec.depth, 3, 64, Hd, spec.num_moves, spec.num_players, 1, 1, L, pc)
+    desc = NetDescC(Cin, H, W, 64, spec.depth, 3, 64, Hd, spec.num_moves, spec.num_players, 1, 1, L, pc, 0)
     assert len(blob) == lib.azmi_net_blob_bytes(C.byref(desc)), (len(blob), lib.azmi_net_blob_bytes(C.byref(desc)))
     return desc, bytes(blob)
 
 
-def fold(net):
+def fold_fp32(net):
+    """fp32 path (csrc/leafnet_f32.hip): torch layouts, BatchNorms folded in double, no bf16 anywhere."""
+    spec = net.spec
+    Cin, H, W = spec.in_shape
+    assert spec.num_channels == 64 and spec.kernel_size == 3 and spec.head_pool
+    sd = {k: v.detach().double().cpu() for k, v in net.state_dict().items()}
+    blob = bytearray()
+
+    def conv_bn(wname, bn):
+        a, b = (t.cpu() for t in bn_affine(bn))
+        return _f32(sd[wname] * a[:, None, None, None]) + _f32(b)
+
+    blob += conv_bn("conv1.weight", net.bn1)
+    for i, blk in enumerate(net.conv_layers):
+        a1, b1 = (t.cpu() for t in bn_affine(blk.bn1))
+        blob += _f32(a1) + _f32(b1) + conv_bn(f"conv_layers.{i}.conv1.weight", blk.bn2) + _f32(sd[f"conv_layers.{i}.conv2.weight"])
+    blob += conv_bn("v_conv.weight", net.v_bn)
+    for i in range(spec.v_head_convs):
+        blob += conv_bn(f"v_extra_convs.{3 * i}.weight", net.v_extra_convs[3 * i + 1])
+    blob += _f32(sd["v_fc1.weight"]) + _f32(sd["v_fc1.bias"])
+    for l in range(spec.v_fc_layers - 1):
+        blob += _f32(sd[f"v_fc_extra.{2 * l}.weight"]) + _f32(sd[f"v_fc_extra.{2 * l}.bias"])
+    blob += _f32(sd["v_fc2.weight"]) + _f32(sd["v_fc2.bias"])
+    blob += conv_bn("pi_conv.weight", net.pi_bn)
+    for i in range(spec.pi_head_convs):
+        blob += conv_bn(f"pi_extra_convs.{3 * i}.weight", net.pi_extra_convs[3 * i + 1])
+    pc = 0
+    if spec.policy_shape is not None:
+        pc = spec.policy_shape[0]
+        blob += conv_bn("pi_conv2.weight", net.pi_bn2)
+    else:
+        blob += _f32(sd["pi_fc1.weight"]) + _f32(sd["pi_fc1.bias"])
+    desc = NetDescC(Cin, H, W, 64, spec.depth, 3, spec.head_channels, spec.v_fc_hidden, spec.num_moves, spec.num_players,
+                    spec.v_head_convs, spec.pi_head_convs, spec.v_fc_layers, pc, 1)
+    assert len(blob) == lib.azmi_net_blob_bytes(C.byref(desc)), (len(blob), lib.azmi_net_blob_bytes(C.byref(desc)))
+    return desc, bytes(blob)
+
+
+def fold(net, precision="bf16"):
     """LeafNet (reference NNArch parameter names) -> (NetDescC, blob bytes)."""
+    if precision == "fp32":
+        return fold_fp32(net)
     spec = net.spec
     if spec.policy_shape is not None:
         return fold_spatial(net)
@@ -169,7 +209,7 @@ def fold(net):
     wt = torch.zeros((wp.shape[1], 16), dtype=torch.float64)
     wt[:, : spec.num_moves] = wp.t()
     blob += _f32(wt) + _f32(sd["pi_fc1.bias"])
-    desc = NetDescC(Cin, H, W, 64, spec.depth, 3, 32, spec.v_fc_hidden, spec.num_moves, spec.num_players, 0, 0, 1, 0)
+    desc = NetDescC(Cin, H, W, 64, spec.depth, 3, 32, spec.v_fc_hidden, spec.num_moves, spec.num_players, 0, 0, 1, 0, 0)
     assert len(blob) == lib.azmi_net_blob_bytes(C.byref(desc)), (len(blob), lib.azmi_net_blob_bytes(C.byref(desc)))
     return desc, bytes(blob)
 
@@ -177,8 +217,10 @@ def fold(net):
 class HipLeafNet:
     """The fused MFMA kernel as an evaluator: forward(canonical, v_out, pi_out) on device tensors."""
 
-    def __init__(self, net, spec=None, max_batch=None, device=0):
-        self.desc, blob = fold(net)
+    def __init__(self, net, spec=None, max_batch=None, device=0, precision="bf16"):
+        """precision: "bf16" = MFMA fast path (bf16 operands, fp32 accumulate); "fp32" = plain fp32 path for the
+        1e-5 parity tier."""
+        self.desc, blob = fold(net, precision)
         self._blob = blob
         h = C.c_void_p()
         rc = lib.azmi_net_create(C.byref(self.desc), blob, len(blob), int(device), C.byref(h))

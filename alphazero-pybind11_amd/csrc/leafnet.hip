@@ -39,6 +39,7 @@
 #include <vector>
 
 #include "../../include/azmi.h"
+#include "leafnet_f32.h"
 
 namespace {
 
@@ -889,6 +890,7 @@ int nfail(int code, const char* fmt, ...) {
 struct azmi_net {
   NetDesc nd{};
   NetPtrs np{};
+  void* f32 = nullptr;       // precision = 1: the fp32 path (leafnet_f32.hip) owns everything
   bool spatial = false;      // spatial policy head (Tafl family): k_leafnet_spatial + k_value_fc
   SpatialDesc sd{};
   SpatialPtrs sp{};
@@ -922,6 +924,7 @@ const char* azmi_net_last_error(void) { return g_net_err.c_str(); }
 
 size_t azmi_net_blob_bytes(const azmi_net_desc* d) {
   if (!d) return 0;
+  if (d->precision == 1) return azmi_f32::blob_bytes(d);
   if (is_spatial(d)) return spatial_blob_bytes(d);
   const size_t wconv = 18 * MT * WFRAG_BYTES, wsmall = 2 * MT * WFRAG_BYTES;
   size_t n = wsmall + CH * 4;
@@ -935,6 +938,17 @@ size_t azmi_net_blob_bytes(const azmi_net_desc* d) {
 
 int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes, int device, azmi_net** out) {
   if (!d || !blob || !out) return nfail(AZMI_ERR_INVALID, "null argument");
+  if (d->precision == 1) {
+    const char* msg = "";
+    void* impl = nullptr;
+    const int rc = azmi_f32::create(d, blob, blob_bytes, device, &impl, &msg);
+    if (rc != AZMI_OK) return nfail(rc, "%s", msg);
+    auto net = new azmi_net();
+    net->device = device; net->f32 = impl;
+    *out = net;
+    return AZMI_OK;
+  }
+  if (d->precision != 0) return nfail(AZMI_ERR_INVALID, "precision must be 0 (bf16 MFMA) or 1 (fp32)");
   if (is_spatial(d)) {
     if (d->channels != CH || d->head_channels != HCS || d->kernel_size != 3 || d->v_head_convs != 1 || d->pi_head_convs != 1)
       return nfail(AZMI_ERR_INVALID, "spatial leaf net kernel covers 64 trunk / 64 head channels, 3x3 convs, one extra conv per head");
@@ -1033,6 +1047,7 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
 
 void azmi_net_destroy(azmi_net* net) {
   if (!net) return;
+  if (net->f32) { azmi_f32::destroy(net->f32); delete net; return; }
   (void)hipSetDevice(net->device);
   (void)hipFree(net->blob);
   if (net->vpool) (void)hipFree(net->vpool);
@@ -1042,6 +1057,11 @@ void azmi_net_destroy(azmi_net* net) {
 int azmi_net_forward(azmi_net* net, const float* dev_canonical, float* dev_v, float* dev_pi, uint32_t batch, void* stream) {
   if (!net || !dev_canonical || !dev_v || !dev_pi) return nfail(AZMI_ERR_INVALID, "null argument");
   if (batch == 0) return AZMI_OK;
+  if (net->f32) {
+    const char* msg = "";
+    const int rc = azmi_f32::forward(net->f32, dev_canonical, dev_v, dev_pi, batch, stream, &msg);
+    return rc == AZMI_OK ? rc : nfail(rc, "%s", msg);
+  }
   if (net->spatial) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (batch > net->vpool_rows) {   // grows on first use / larger batches only (synchronous, outside steady state)

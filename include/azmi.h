@@ -207,6 +207,10 @@ typedef struct azmi_net_desc {
   /* head options (neural_net.py:56-75, 341-427). policy_channels > 0 selects the spatial policy head
    * (POLICY_SHAPE[0]; Tafl family 22) and its kernel; 0 = flat FC policy head. */
   int32_t v_head_convs, pi_head_convs, v_fc_layers, policy_channels;
+  /* 0 = bf16 operands on the matrix cores, fp32 accumulation (what the reference runs under autocast,
+   * neural_net.py:811-813) — the throughput path.  1 = plain fp32 arithmetic, layer by layer: the precision
+   * the 1e-5 parity tier refers to; blob layout in csrc/leafnet_f32.hip. */
+  int32_t precision;
 } azmi_net_desc;
 typedef struct azmi_net azmi_net;
 size_t azmi_net_blob_bytes(const azmi_net_desc* desc);

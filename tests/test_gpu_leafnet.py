@@ -116,3 +116,40 @@ def test_spatial_batch_shapes_and_invariance(batch):
         vr, pr = net.to(dev).process(x)
     assert (v - vr).abs().max().item() <= TOL and (pi - pr).abs().max().item() <= TOL
     assert torch.isfinite(pi).all() and torch.isfinite(v).all()
+
+
+# ---------------------------------------------------------------- fp32 path: the north star's 1e-5 tier
+TOL_F32 = 1e-5   # BASELINE.json north_star: "1e-5 on policy/value tensors" (SURVEY §8c tier T3)
+
+
+@pytest.mark.parametrize("which", ["connect4", "tawlbwrdd"])
+def test_fp32_path_matches_reference_nnarch_within_1e5(which):
+    """precision="fp32" (csrc/leafnet_f32.hip, plain fp32 arithmetic on the GPU) against the reference NNArch's own
+    fp32 outputs (fixtures generated by tests/golden/make_nn_fixture.py from /root/reference/src/neural_net.py)."""
+    import alphazero as az
+    fx, net = _fixture_net() if which == "connect4" else _tafl_fixture_net()
+    dev = torch.device("cuda:0")
+    hip = az.HipLeafNet(net, precision="fp32")
+    x = torch.from_numpy(fx["input"]).to(dev)
+    v, pi = hip.process(x)
+    torch.cuda.synchronize()
+    dv = np.abs(v.cpu().numpy() - fx["v"]).max()
+    dpi = np.abs(pi.cpu().numpy() - fx["pi"]).max()
+    print("%s fp32 hip vs reference fp32: max|dv| %.3e max|dpi| %.3e" % (which, dv, dpi))
+    assert dv <= TOL_F32 and dpi <= TOL_F32, (dv, dpi)
+    # relative check too: small probabilities must be right, not just small
+    rel = np.abs(pi.cpu().numpy() - fx["pi"]) / np.maximum(fx["pi"], 1e-12)
+    assert rel.max() <= 1e-3, rel.max()
+
+
+def test_fp32_path_batch_larger_than_reservation():
+    import alphazero as az
+    from alphazero import torch_net
+    dev = torch.device("cuda:0")
+    net = torch_net.random_init(torch_net.connect4_spec(), seed=8)
+    hip = az.HipLeafNet(net, precision="fp32")
+    x = (torch.rand((5000, 4, 6, 7), generator=torch.Generator().manual_seed(1)) < 0.3).float().to(dev)
+    v, pi = hip.process(x)
+    with torch.no_grad():
+        vr, pr = net.to(dev).process(x)
+    assert (v - vr).abs().max().item() <= TOL_F32 and (pi - pr).abs().max().item() <= TOL_F32
