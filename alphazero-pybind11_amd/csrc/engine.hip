@@ -344,8 +344,6 @@ int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_o
   for (uint32_t i = 0; i < params->num_eval_type; ++i)
     if (params->eval_type[i] == AZMI_EVAL_PLAYOUT) return fail(AZMI_ERR_INVALID, "EvalType::PLAYOUT is not implemented on the device");
   if (params->resign_percent > 0 && gi.P != 2) return fail(AZMI_ERR_INVALID, "Resigning only works in 2 player games");
-  if (params->gumbel_enabled && game != AZMI_GAME_CONNECT4)
-    return fail(AZMI_ERR_INVALID, "gumbel_enabled: only the Connect4 engine implements Gumbel search in this round");
   if (params->gumbel_enabled && params->gumbel_m > kGumMaxM)
     return fail(AZMI_ERR_INVALID, "gumbel_m %u exceeds the engine limit %u", params->gumbel_m, kGumMaxM);
   int ndev = 0;

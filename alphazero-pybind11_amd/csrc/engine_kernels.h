@@ -45,6 +45,34 @@ __device__ __forceinline__ uint32_t seat_param(const uint32_t (&a)[4], uint32_t 
   return seat == 0 ? a[0] : seat == 1 ? a[1] : seat == 2 ? a[2] : a[3];
 }
 
+// seq_halving_phase_plan, mcts.cc:28-66: returns the number of phases; (num_c, v_per) of phase `want`
+__device__ __forceinline__ uint32_t gum_plan(uint32_t m, uint32_t n, uint32_t want, uint32_t& num_c_out, uint32_t& v_per_out) {
+  num_c_out = 0; v_per_out = 0;
+  if (m <= 1) { if (want == 0) { num_c_out = 1; v_per_out = n; } return 1; }
+  uint32_t log2m = 0;
+  for (uint32_t v = m - 1; v > 0; v >>= 1) ++log2m;
+  if (log2m == 0) log2m = 1;
+  const uint32_t d0 = n / (log2m * m);
+  const uint32_t base_v = d0 > 1u ? d0 : 1u;
+  uint32_t sims_used = 0, num_c = m, count = 0;
+  for (uint32_t phase_idx = 0; phase_idx < log2m; ++phase_idx) {
+    if (sims_used >= n) break;
+    const uint32_t remaining = n - sims_used;
+    const bool is_final = (phase_idx == log2m - 1);
+    const uint32_t fin = remaining / num_c;
+    uint32_t v_per = is_final ? (fin > 1u ? fin : 1u) : base_v * (1u << phase_idx);
+    if (num_c * v_per > remaining) {
+      v_per = remaining / num_c;
+      if (v_per == 0) { num_c = remaining; v_per = 1; }
+    }
+    if (count == want) { num_c_out = num_c; v_per_out = v_per; }
+    ++count;
+    sims_used += num_c * v_per;
+    num_c = (num_c / 2) > 1u ? (num_c / 2) : 1u;
+  }
+  return count;
+}
+
 template <class GM>
 struct SlotCtx {
   static constexpr int G = GM::GROUP;
@@ -161,33 +189,6 @@ struct SlotCtx {
     const uint32_t cp = gs.player;
     const uint32_t target = (flags & kFlagCapped) ? (ep.fast_gumbel ? ep.cap_visits : 0u) : seat_param(ep.visits, cp);
     set_gumbel_num_sims(cp, target);
-  }
-  // seq_halving_phase_plan, mcts.cc:28-66: returns the number of phases; (num_c, v_per) of phase `want`
-  __device__ __forceinline__ static uint32_t gum_plan(uint32_t m, uint32_t n, uint32_t want, uint32_t& num_c_out, uint32_t& v_per_out) {
-    num_c_out = 0; v_per_out = 0;
-    if (m <= 1) { if (want == 0) { num_c_out = 1; v_per_out = n; } return 1; }
-    uint32_t log2m = 0;
-    for (uint32_t v = m - 1; v > 0; v >>= 1) ++log2m;
-    if (log2m == 0) log2m = 1;
-    const uint32_t d0 = n / (log2m * m);
-    const uint32_t base_v = d0 > 1u ? d0 : 1u;
-    uint32_t sims_used = 0, num_c = m, count = 0;
-    for (uint32_t phase_idx = 0; phase_idx < log2m; ++phase_idx) {
-      if (sims_used >= n) break;
-      const uint32_t remaining = n - sims_used;
-      const bool is_final = (phase_idx == log2m - 1);
-      const uint32_t fin = remaining / num_c;
-      uint32_t v_per = is_final ? (fin > 1u ? fin : 1u) : base_v * (1u << phase_idx);
-      if (num_c * v_per > remaining) {
-        v_per = remaining / num_c;
-        if (v_per == 0) { num_c = remaining; v_per = 1; }
-      }
-      if (count == want) { num_c_out = num_c; v_per_out = v_per; }
-      ++count;
-      sims_used += num_c * v_per;
-      num_c = (num_c / 2) > 1u ? (num_c / 2) : 1u;
-    }
-    return count;
   }
   __device__ __forceinline__ float gumbel01() {  // extreme_value_distribution<float>{0,1}, random.tcc:2581-2590
     return 0.0f - 1.0f * az_logf(-az_logf(1.0f - canonical01(rng)));

@@ -103,6 +103,7 @@ struct BigSlot {
     for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == seat) t_tld[p] = 0;
     const size_t tb = tree_base(seat);
     if (lane == 0) { ar.N[tb] = 0; ar.Q[tb] = 0; ar.Pr[tb] = 0; ar.D[tb] = 0; ar.V[tb] = 0; ar.META[tb] = 0; }
+    if (ep.gumbel_on) set_gumbel_num_sims(seat, 0);
   }
 
   // ---- repetition-aware move on a state; `list`/`len` is the list the new position is appended to --------
@@ -206,6 +207,196 @@ struct BigSlot {
     return s;
   }
 
+  // ======================= Gumbel AlphaZero (mcts.cc:24-401), wide-game form ===============================
+  // Same per-tree record as SlotCtx (engine_kernels.h); children are walked in chunks of 64 through LDS, the
+  // (<= 64) surviving root candidates of the sequential halving are lane-resident.
+  enum { kGumTarget = 0, kGumInit = 1, kGumNSurv = 2, kGumPhase = 3, kGumSims = 4, kGumMEff = 5, kGumRemain = 6 };
+  __device__ __forceinline__ uint32_t* gum_state(uint32_t seat) const { return ar.gum_state + (static_cast<size_t>(slot) * P + seat) * 8; }
+  __device__ __forceinline__ float* gum_g(uint32_t seat) const { return ar.gum_g + (static_cast<size_t>(slot) * P + seat) * ep.gum_stride; }
+  __device__ __forceinline__ uint16_t* gum_surv(uint32_t seat) const { return ar.gum_surv + (static_cast<size_t>(slot) * P + seat) * kGumMaxM; }
+  __device__ void reset_gumbel_state(uint32_t seat) const {
+    if (lane != 0) return;
+    uint32_t* st = gum_state(seat);
+    st[kGumInit] = 0; st[kGumNSurv] = 0; st[kGumPhase] = 0; st[kGumSims] = 0; st[kGumMEff] = 0; st[kGumRemain] = 0;
+  }
+  __device__ void set_gumbel_num_sims(uint32_t seat, uint32_t n) const {
+    if (lane == 0) gum_state(seat)[kGumTarget] = n;
+    reset_gumbel_state(seat);
+  }
+  __device__ void set_gumbel_target() const {   // play_manager.cc:525-539 / 561-570
+    if (!ep.gumbel_on) return;
+    const uint32_t cp = gs.player;
+    const uint32_t target = (flags & kFlagCapped) ? (ep.fast_gumbel ? ep.cap_visits : 0u) : seat_param(ep.visits, cp);
+    set_gumbel_num_sims(cp, target);
+  }
+  __device__ __forceinline__ float gumbel01() { return 0.0f - 1.0f * az_logf(-az_logf(1.0f - canonical01(rng))); }
+  __device__ __forceinline__ uint32_t wave_max(uint32_t x) const {
+    for (int off = 32; off > 0; off >>= 1) x = max(x, __shfl_xor(x, off, 64));
+    return x;
+  }
+  // init_gumbel_state, mcts.cc:190-227
+  __device__ void init_gumbel_state(uint32_t seat, size_t tb, uint32_t c0, uint32_t k) {
+    if (k == 0) return;
+    uint32_t* st = gum_state(seat);
+    const uint32_t target = st[kGumTarget], depth = AZB_SEL(t_depth, seat);
+    const uint32_t remaining = depth < target ? target - depth : 0u;
+    if (remaining == 0) return;
+    uint32_t m_eff = ep.gumbel_m < k ? ep.gumbel_m : k;
+    m_eff = m_eff < remaining ? m_eff : remaining;
+    m_eff = m_eff > 1u ? m_eff : 1u;
+    for (uint32_t i = lane; i < k; i += G) sm.f2[i] = ar.Pr[tb + c0 + i];
+    sync();
+    float* gg = gum_g(seat);
+    for (uint32_t i = 0; i < k; ++i) {           // k draws in child order from the slot's stream
+      const float g = gumbel01();
+      if (lane == 0) { gg[i] = g; sm.f0[i] = g + az_logf(sm.f2[i] + 1e-20f); }
+    }
+    sync();
+    uint16_t* surv = gum_surv(seat);
+    for (uint32_t i = lane; i < k; i += G) {     // rank in the descending order of g + log(prior), mcts.cc:214-221
+      const float s = sm.f0[i];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < k; ++j) { const float sj = sm.f0[j]; rank += (sj > s || (sj == s && j < i)) ? 1u : 0u; }
+      if (rank < m_eff) surv[rank] = static_cast<uint16_t>(i);
+    }
+    if (lane == 0) {
+      st[kGumInit] = 1; st[kGumNSurv] = m_eff; st[kGumPhase] = 0; st[kGumSims] = 0; st[kGumMEff] = m_eff; st[kGumRemain] = remaining;
+    }
+    sync();
+  }
+  // score g + log(prior) + sigma * q_hat of survivor `lane` (mcts.cc:241-253, 385-397); lanes >= nsurv get -inf
+  __device__ float survivor_score(uint32_t seat, size_t tb, uint32_t c0, uint32_t nsurv, uint32_t max_visit, uint32_t& ci) const {
+    ci = 0;
+    if (lane >= nsurv) return -__builtin_inff();
+    ci = gum_surv(seat)[lane];
+    const size_t idx = tb + c0 + ci;
+    const uint32_t n = ar.N[idx];
+    const float sigma_scale = (ep.gumbel_c_visit + static_cast<float>(max_visit)) * ep.gumbel_c_scale;
+    const float sc = gum_g(seat)[ci] + az_logf(ar.Pr[idx] + 1e-20f) + sigma_scale * (n > 0 ? ar.Q[idx] : 0.0f);
+    return sc != sc ? -__builtin_inff() : sc;
+  }
+  // gumbel_next_root_child (mcts.cc:266-283) with gumbel_advance_phase (mcts.cc:229-264) inlined
+  __device__ uint32_t gumbel_next_root_child(uint32_t seat, size_t tb, uint32_t c0) {
+    sync();
+    uint32_t* st = gum_state(seat);
+    uint16_t* surv = gum_surv(seat);
+    uint32_t nsurv = st[kGumNSurv], phase = st[kGumPhase], sims = st[kGumSims];
+    const uint32_t m_eff = st[kGumMEff], remain = st[kGumRemain];
+    uint32_t num_c, v_per;
+    const uint32_t nph = gum_plan(m_eff, remain, phase, num_c, v_per);
+    if (phase < nph && sims >= num_c * v_per && phase + 1 < nph) {
+      uint32_t next_c, next_v;
+      gum_plan(m_eff, remain, phase + 1, next_c, next_v);
+      if (next_c < nsurv) {
+        const uint32_t my = lane < nsurv ? ar.N[tb + c0 + surv[lane]] : 0u;
+        const uint32_t max_visit = wave_max(my);
+        uint32_t ci;
+        const float score = survivor_score(seat, tb, c0, nsurv, max_visit, ci);
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < nsurv; ++j) {
+          const float sj = __shfl(score, static_cast<int>(j), 64);
+          rank += (sj > score || (sj == score && j < lane)) ? 1u : 0u;
+        }
+        sync();
+        if (lane < nsurv && rank < next_c) surv[rank] = static_cast<uint16_t>(ci);
+        sync();
+        nsurv = next_c;
+      }
+      ++phase; sims = 0;
+    }
+    uint32_t child = 0;
+    if (nsurv != 0) { child = surv[sims % nsurv]; ++sims; }
+    if (lane == 0) { st[kGumNSurv] = nsurv; st[kGumPhase] = phase; st[kGumSims] = sims; }
+    return child;
+  }
+  // exp terms of softmax(log prior + sigma * completedQ) over the children staged in LDS (n: sm.n, q: f1, p: f2)
+  // -> sm.f0[0..k); returns their in-order sum (mcts.cc:285-373 share this)
+  __device__ float gumbel_pi_prime(uint32_t k, float node_v) {
+    float sum_visits = 0.0f, sum_priors_visited = 0.0f, weighted_num = 0.0f;   // compute_v_mix_from_children, mcts.cc:71-89
+    for (uint32_t i = 0; i < k; ++i) {
+      const uint32_t ni = sm.n[i];
+      sum_visits += static_cast<float>(ni);
+      if (ni > 0) { sum_priors_visited += sm.f2[i]; weighted_num += sm.f2[i] * sm.f1[i]; }
+    }
+    float v_mix = node_v;
+    if (!(sum_priors_visited <= 0.0f)) {
+      const float weighted_q = weighted_num / sum_priors_visited;
+      v_mix = (node_v + sum_visits * weighted_q) / (sum_visits + 1.0f);
+    }
+    uint32_t mv = 0;
+    for (uint32_t i = lane; i < k; i += G) mv = max(mv, sm.n[i]);
+    const uint32_t max_visit = wave_max(mv);
+    const float sigma_scale = (ep.gumbel_c_visit + static_cast<float>(max_visit)) * ep.gumbel_c_scale;
+    float z_max = -__builtin_inff();
+    for (uint32_t i = lane; i < k; i += G) {
+      const float z = az_logf(sm.f2[i] + 1e-20f) + sigma_scale * (sm.n[i] > 0 ? sm.f1[i] : v_mix);
+      sm.f0[i] = z;
+      if (z > z_max) z_max = z;
+    }
+    for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(z_max, off, 64); if (o > z_max) z_max = o; }
+    sync();
+    for (uint32_t i = lane; i < k; i += G) sm.f0[i] = az_expf(sm.f0[i] - z_max);
+    sync();
+    return seq_sum_f0(k);
+  }
+  // gumbel_interior_select, mcts.cc:285-334
+  __device__ uint32_t gumbel_interior_select(size_t tb, uint32_t c0, uint32_t k, float node_v) {
+    for (uint32_t i = lane; i < k; i += G) {
+      const size_t ci = tb + c0 + i;
+      sm.n[i] = ar.N[ci]; sm.f1[i] = ar.Q[ci]; sm.f2[i] = ar.Pr[ci];
+    }
+    sync();
+    const float z_sum = gumbel_pi_prime(k, node_v);
+    uint32_t sv = 0;
+    for (uint32_t i = lane; i < k; i += G) sv += sm.n[i];
+    const uint32_t sum_visits = wave_sum(sv);
+    const float inv = z_sum > 0 ? (1.0f / z_sum) : 0.0f;
+    const float denom = 1.0f + static_cast<float>(sum_visits);
+    float best_s = -__builtin_inff();
+    uint32_t best_i = 0xFFFFFFFFu;
+    for (uint32_t i = lane; i < k; i += G) {
+      float sc = sm.f0[i] * inv - static_cast<float>(sm.n[i]) / denom;
+      if (sc != sc) sc = -__builtin_inff();
+      if (sc > best_s || best_i == 0xFFFFFFFFu) { best_s = sc; best_i = i; }
+    }
+    for (int off = 1; off < 64; off <<= 1) {
+      const float os = __shfl_xor(best_s, off, 64);
+      const uint32_t oi = __shfl_xor(best_i, off, 64);
+      if (oi != 0xFFFFFFFFu && (best_i == 0xFFFFFFFFu || os > best_s || (os == best_s && oi < best_i))) { best_s = os; best_i = oi; }
+    }
+    sync();
+    return best_i;
+  }
+  // gumbel_improved_policy into sm.dense (mcts.cc:336-373); the root must be staged (stage_root)
+  __device__ void gumbel_improved_policy(uint32_t k, float root_v) {
+    dense_zero();
+    if (k == 0) return;
+    const float z_sum = gumbel_pi_prime(k, root_v);
+    if (z_sum <= 0) return;
+    for (uint32_t i = lane; i < k; i += G) sm.dense[sm.moves[i]] = sm.f0[i] / z_sum;
+    sync();
+  }
+  // gumbel_final_action (mcts.cc:375-401); the root must be staged; returns the move
+  __device__ uint32_t gumbel_final_action(uint32_t seat, size_t tb, uint32_t c0, uint32_t k) {
+    sync();
+    const uint32_t* st = gum_state(seat);
+    const uint32_t nsurv = st[kGumNSurv];
+    if (!st[kGumInit] || nsurv == 0) { probs(0.0f, k); return pick_move(); }
+    uint32_t mv = 0;
+    for (uint32_t i = lane; i < k; i += G) mv = max(mv, sm.n[i]);
+    const uint32_t max_visit = wave_max(mv);
+    uint32_t ci;
+    float score = survivor_score(seat, tb, c0, nsurv, max_visit, ci);
+    uint32_t pos = lane < nsurv ? lane : 0xFFFFu;
+    for (int off = 1; off < 64; off <<= 1) {     // first survivor with the strictly largest score
+      const float os = __shfl_xor(score, off, 64);
+      const uint32_t op = __shfl_xor(pos, off, 64);
+      const uint32_t oc = __shfl_xor(ci, off, 64);
+      if (op != 0xFFFFu && (pos == 0xFFFFu || os > score || (os == score && op < pos))) { score = os; pos = op; ci = oc; }
+    }
+    return sm.moves[ci];
+  }
+
   // ---- Node::best_child over k children starting at c0 -------------------------------------------------------
   __device__ uint32_t select_child(size_t tb, uint32_t c0, uint32_t k, float v_parent, uint32_t n_parent, float fpu_reduction) {
     for (uint32_t i = lane; i < k; i += G) {
@@ -250,6 +441,14 @@ struct BigSlot {
     uint64_t meta = ar.META[tb + cur];
     uint32_t n = ar.N[tb + cur];
     uint32_t* path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
+    uint32_t gum_active = 0;
+    if (ep.gumbel_on) {  // lazy init, mcts.cc:465-472
+      gum_active = gum_state(seat)[kGumInit];
+      if (!gum_active && gum_state(seat)[kGumTarget] > 0 && n > 0 && meta_nch(meta) != 0) {
+        init_gumbel_state(seat, tb, meta_ch0(meta), meta_nch(meta));
+        gum_active = gum_state(seat)[kGumInit];
+      }
+    }
     while (n > 0 && meta_term(meta) == 0) {
       if (plen >= ep.max_depth) { raise(8u); return false; }
       if (lane == 0) path[plen] = cur;
@@ -257,7 +456,10 @@ struct BigSlot {
       const uint32_t k = meta_nch(meta), c0 = meta_ch0(meta);
       if (k == 0) { raise(8u); return false; }
       const float fpu = (cur == root && ep.root_fpu_zero) ? 0.0f : ep.fpu_reduction;
-      const uint32_t best = select_child(tb, c0, k, ar.V[tb + cur], n, fpu);
+      uint32_t best;
+      if (gum_active && cur == root) best = gumbel_next_root_child(seat, tb, c0);
+      else if (gum_active && ep.gumbel_full) best = gumbel_interior_select(tb, c0, k, ar.V[tb + cur]);
+      else best = select_child(tb, c0, k, ar.V[tb + cur], n, fpu);
       cur = c0 + best;
       n = ar.N[tb + cur];
       meta = ar.META[tb + cur];
@@ -349,7 +551,7 @@ struct BigSlot {
       sync();
       for (uint32_t i = lane; i < k; i += G) sm.f0[i] = sm.f0[i] / sum;
       sync();
-      if (is_root && root_noise) add_root_noise(k);
+      if (is_root && root_noise && !ep.gumbel_on) add_root_noise(k);
       for (uint32_t i = lane; i < k; i += G) ar.Pr[tb + c0 + i] = sm.f0[i];
     }
     const uint32_t* path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
@@ -502,6 +704,7 @@ struct BigSlot {
     set_seat(t_root, seat, c0 + hit); set_seat(t_depth, seat, 0);
 #pragma unroll
     for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == seat) t_tld[p] = 0;
+    if (ep.gumbel_on) reset_gumbel_state(seat);  // mcts.cc:172
     return true;
   }
 
@@ -579,9 +782,14 @@ struct BigSlot {
         else resign_entry = entry;
       }
     }
-    probs(temp, k);
     const uint64_t rng_before = rng.state;
-    const uint32_t chosen = pick_move();
+    uint32_t chosen;
+    if (ep.gumbel_on && !capped) {          // play_manager.cc:367-381 (G1 acting)
+      chosen = gumbel_final_action(cp, tb, c0, k);
+    } else {
+      probs(temp, k);
+      chosen = pick_move();
+    }
     sync();
 
     if (ep.log_moves) {
@@ -603,7 +811,8 @@ struct BigSlot {
       }
     }
     if (ep.history && !capped) {
-      if (ep.pruning && ep.epsilon > 0) probs_pruned(1.0f, root_n, k); else probs(1.0f, k);
+      if (ep.gumbel_on) gumbel_improved_policy(k, ar.V[tb + root]);   // play_manager.cc:411-417
+      else if (ep.pruning && ep.epsilon > 0) probs_pruned(1.0f, root_n, k); else probs(1.0f, k);
       const uint32_t r = ph_rows;
       if (r < ep.max_hist_rows) {
         float* crow = ar.ph_canon + (static_cast<size_t>(slot) * ep.max_hist_rows + r) * GM::CANON;
@@ -661,6 +870,7 @@ struct BigSlot {
     if (term == 0 && resign_entry >= 0) { term = static_cast<uint32_t>(resign_entry) + 1; resigned = true; }
     if (term != 0) { end_game(term, resigned); return true; }
     draw_capped();
+    set_gumbel_target();
     if (!ep.tree_reuse) {
       for (uint32_t s = 0; s < static_cast<uint32_t>(P); ++s) reset_tree(s);
     } else {
@@ -737,7 +947,10 @@ __global__ __launch_bounds__(64) void k_round_big(EngineParams ep, EngineArrays 
   c.load();
   uint32_t inline_sims = 0;
   bool need_process = (st == kSlotWaitEval);
-  if (!need_process) { c.start_game(); c.draw_capped(); }
+  if (!need_process) {
+    c.start_game(); c.draw_capped(); c.set_gumbel_target();
+    if (ep.gumbel_on && st == kSlotRestart && !ep.tree_reuse) c.set_gumbel_num_sims(c.gs.player, 0);   // see k_round
+  }
   for (;;) {
     if (need_process) {
       const uint32_t cp = c.gs.player;

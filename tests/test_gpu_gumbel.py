@@ -65,13 +65,46 @@ def test_gumbel_visit_schedule_on_device(oracle):
         assert sorted((int(x) for x in c if x > 0), reverse=True) == [5, 5, 1, 1] and c.sum() == 12
 
 
-def test_gumbel_rejected_where_not_implemented():
+def test_gumbel_m_limit():
     az = _az()
     pp = az.PlayParams()
     pp.games_to_play, pp.concurrent_games, pp.mcts_visits = 1, 1, [10, 10]
     pp.gumbel_enabled, pp.gumbel_m = True, 65
     with pytest.raises(RuntimeError, match="gumbel_m"):
         az.PlayManager(az.Connect4GS(), pp)
-    pp.gumbel_m = 16
-    with pytest.raises(RuntimeError, match="Gumbel"):
-        az.PlayManager(az.TawlbwrddGS(), pp)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(),                                                        # configs/tawlbwrdd.yaml:24-25: gumbel on, capped searches PUCT
+    dict(gumbel_m=8, gumbel_full=True),
+    dict(playout_cap_randomization=True, playout_cap_depth=8, playout_cap_percent=0.5, epsilon=0.25, shaped_dirichlet=True),
+    dict(playout_cap_randomization=True, playout_cap_depth=8, playout_cap_percent=0.5, fast_search_uses_gumbel=True),
+])
+def test_gumbel_tawlbwrdd_tiers(oracle, cfg):
+    """Gumbel on the wide-game engine (one wave per slot, lane-resident survivors): moves, visit counts, RNG
+    position and pi' history rows equal the oracle's."""
+    az = _az()
+    pp = az.PlayParams()
+    pp.eval_type = [az.EvalType.RANDOM, az.EvalType.RANDOM]
+    pp.history_enabled = True
+    pp.games_to_play, pp.concurrent_games, pp.mcts_visits = 4, 4, [24, 24]
+    pp.cpuct, pp.fpu_reduction, pp.gumbel_enabled = 1.25, 0.25, True
+    for k, v in cfg.items():
+        setattr(pp, k, v)
+    seed = 99
+    pm = az.PlayManager(az.TawlbwrddGS(), pp, seed=seed, log_moves=True)
+    pm.play()
+    rows, counts = pm.move_log()
+    hist = pm.history()
+    rows_orc = []
+    for s in range(4):
+        one = az.PlayParams(); one.__dict__.update(pp.__dict__)
+        one.games_to_play, one.concurrent_games = 1, 1
+        o = oracle.PlayManager(oracle.GAME_TAWLBWRDD, one, oracle.slot_seed(seed, s), per_slot_rng=False)
+        o.run()
+        orows, ocounts = o.moves()
+        sel = rows[:, 0] == s
+        assert np.array_equal(rows[sel][:, 1:], orows[:, 1:]), s
+        assert np.array_equal(counts[sel], ocounts), s
+        rows_orc += _history_multiset(*o.history())
+    assert _history_multiset(*hist) == sorted(rows_orc)
