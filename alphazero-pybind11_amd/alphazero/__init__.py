@@ -555,6 +555,11 @@ class PlayManager:
         """One engine round on `stream` (a hipStream_t as int, e.g. torch.cuda.current_stream().cuda_stream)."""
         check(lib.azmi_pm_round(self._h, self._stream_arg(stream)))
 
+    def net_forward(self, net, stream=None):
+        """The HIP leaf net on this engine's leaf batch, restricted to the rows the last round listed as needing
+        an evaluation (azmi_pm_net_forward); `net` is a HipLeafNet."""
+        check(lib.azmi_pm_net_forward(self._h, net._h, self._stream_arg(stream)))
+
     def poll(self, stream=None):
         done, live = C.c_uint32(), C.c_uint32()
         check(lib.azmi_pm_poll(self._h, self._stream_arg(stream), C.byref(done), C.byref(live)))

@@ -117,15 +117,16 @@ __global__ void k_seed(EngineArrays ar, uint32_t S, uint64_t seed) {
 }
 
 int launch_round(azmi_pm* pm, hipStream_t st) {
-  k_assign<<<1, 256, 0, st>>>(pm->ep, pm->ar, 1u);
   const uint32_t threads = 256;
+  if (!(pm->game == AZMI_GAME_CONNECT4 && pm->ep.cache_on)) k_assign<<<1, 256, 0, st>>>(pm->ep, pm->ar, 1u);
   switch (pm->game) {
     case AZMI_GAME_CONNECT4: {
-      if (pm->ep.cache_on) {
-        k_cache_keys<Connect4><<<(pm->ep.S + 255) / 256, 256, 0, st>>>(pm->ep, pm->ar, pm->ar.cache_keys);
+      if (pm->ep.cache_on) {   // cache insert of last round's leaves + the restart/retire bookkeeping in one launch
         for (uint32_t off = 0; off < pm->ep.S; off += kApplyMax) {
           const uint32_t m = std::min<uint32_t>(kApplyMax, pm->ep.S - off);
-          k_cache_insert<Connect4><<<(m + 3) / 4, 256, 0, st>>>(pm->ep, pm->ar, pm->ar.cache_keys, off, m);
+          const uint32_t nb = (m + 3) / 4;
+          k_cache_insert<Connect4><<<nb + (off == 0 ? 1u : 0u), 256, 0, st>>>(pm->ep, pm->ar, pm->ar.cache_keys, off, m,
+                                                                              off == 0 ? nb : 0xFFFFFFFFu, 1u);
         }
       }
       const uint32_t slots_per_block = threads / Connect4::GROUP;
@@ -410,6 +411,7 @@ int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_o
 #define A(field, count, zero) if (rc == AZMI_OK) rc = pm->alloc(ar.field, (count), (zero))
   A(ctl, 1, true);
   A(ended_list, S, true);
+  A(eval_list, S, true);
   A(gs_words, static_cast<size_t>(gi.state_words) * S, true);
   A(rng, S, true); A(coin, S, true);
   A(sstate, S, true); A(flags, S, true);
@@ -496,12 +498,20 @@ int azmi_pm_round(azmi_pm* pm, void* stream) {
 
 namespace {
 constexpr uint32_t kGraphRounds = 16;
+// the net on this engine's leaf batch: only the rows k_round listed (Connect4 engine), else the whole batch
+int pm_net_forward(azmi_pm* pm, azmi_net* net, hipStream_t st) {
+  int rc;
+  if (pm->game == AZMI_GAME_CONNECT4)
+    rc = azmi_net_forward_rows(net, pm->ar.canon, pm->ar.v, pm->ar.pi, pm->ar.eval_list, &pm->ar.ctl->eval_count, pm->ep.S, st);
+  else
+    rc = azmi_net_forward(net, pm->ar.canon, pm->ar.v, pm->ar.pi, pm->ep.S, st);
+  if (rc != AZMI_OK) return fail(rc, "%s", azmi_net_last_error());
+  return AZMI_OK;
+}
 int one_round_with_net(azmi_pm* pm, azmi_net* net, hipStream_t st) {
   int rc = launch_round(pm, st);
   if (rc != AZMI_OK) return rc;
-  rc = azmi_net_forward(net, pm->ar.canon, pm->ar.v, pm->ar.pi, pm->ep.S, st);
-  if (rc != AZMI_OK) return fail(rc, "%s", azmi_net_last_error());
-  return AZMI_OK;
+  return pm_net_forward(pm, net, st);
 }
 int ensure_graph(azmi_pm* pm, azmi_net* net, hipStream_t st) {
   if (pm->graph_exec && pm->graph_stream == st && pm->graph_net == net) return AZMI_OK;
@@ -540,6 +550,11 @@ int azmi_run_rounds(azmi_pm* const* pms, azmi_net* net, uint32_t k, uint32_t rou
       if (rc != AZMI_OK) return rc;
     }
   return AZMI_OK;
+}
+
+int azmi_pm_net_forward(azmi_pm* pm, azmi_net* net, void* stream) {
+  if (!pm || !net) return fail(AZMI_ERR_INVALID, "null argument");
+  return pm_net_forward(pm, net, pm->pick(stream));
 }
 
 int azmi_pm_io_buffers(azmi_pm* pm, float** dev_canonical, float** dev_v, float** dev_pi) {

@@ -920,10 +920,12 @@ __global__ __launch_bounds__(256, 1) void k_round(EngineParams ep, EngineArrays 
   if (slot >= ep.S) return;
   if (ar.ctl->stop) return;
   const uint8_t st = ar.sstate[slot];
-  if (st == kSlotDone || st == kSlotEnded) return;
+  // cache_keys[slot] = key of the leaf this slot sends to the net this round (0 = none): the next round's
+  // k_cache_insert stores the net's answer under it (PlayManager::update_inferences -> insert_many)
+  if (st == kSlotDone || st == kSlotEnded) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; return; }
   SlotCtx<GM> c(ep, ar, slot, lane);
   c.load();
-  uint32_t inline_sims = 0;
+  uint32_t inline_sims = 0, insert_key_set = 0;
   bool need_process = (st == kSlotWaitEval);
   if (!need_process) {  // kSlotFresh / kSlotRestart
     c.start_game();
@@ -940,54 +942,44 @@ __global__ __launch_bounds__(256, 1) void k_round(EngineParams ep, EngineArrays 
       c.process_result(cp, (c.flags & kFlagLeafNeedsNet) != 0, noise);
       const uint32_t goal = (c.flags & kFlagCapped) ? ep.cap_visits : seat_param(ep.visits, cp);
       if (AZMI_SEL(c.t_depth, cp) >= goal) {
-        if (c.make_move(cp)) { c.store(kSlotEnded); return; }
+        if (c.make_move(cp)) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; c.store(kSlotEnded); return; }
       }
     }
     const uint32_t cp = c.gs.player;
     typename GM::State leaf;
     uint32_t term = 0;
-    if (!c.find_leaf(cp, leaf, term)) { c.store(kSlotDone); return; }
+    if (!c.find_leaf(cp, leaf, term)) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; c.store(kSlotDone); return; }
     const bool needs_net = term == 0 && !seat_param(ep.eval_random, cp);
     c.flags = needs_net ? (c.flags | kFlagLeafNeedsNet) : (c.flags & ~kFlagLeafNeedsNet);
     if (needs_net) {
       const uint64_t key = c.emit_leaf(leaf);
       const bool hit = ep.cache_on && c.cache_lookup(key);
       if (!hit) {
-        if (lane == 0) ar.c_evals[slot] += 1;
+        if (lane == 0) {
+          ar.c_evals[slot] += 1;
+          if (ep.cache_on) ar.cache_keys[slot] = cache_key(key);
+          ar.eval_list[atomicAdd(&ar.ctl->eval_count, 1u)] = slot;
+        }
+        insert_key_set = 1;
         break;
       }
     }
     need_process = true;
     if (++inline_sims >= ep.max_inline) break;
   }
+  if (ep.cache_on && !insert_key_set && lane == 0) ar.cache_keys[slot] = 0;
   c.store(kSlotWaitEval);
-}
-
-// Inserts the leaves the net evaluated in the previous round into the position cache
-// (PlayManager::update_inferences -> insert_many, play_manager.cc:631-640): one lane per shard,
-// slots in slot order.
-template <class GM>
-__global__ __launch_bounds__(256) void k_cache_keys(EngineParams ep, EngineArrays ar, uint64_t* keys) {
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= ep.S) return;
-  const bool on = !ar.ctl->stop && ar.sstate[s] == kSlotWaitEval && (ar.flags[s] & kFlagLeafNeedsNet);
-  keys[s] = on ? cache_key(ar.leaf_key[s]) : 0;
-}
-template <class GM>
-__global__ __launch_bounds__(256) void k_cache_insert(EngineParams ep, EngineArrays ar, const uint64_t* keys, uint32_t off, uint32_t n) {
-  __shared__ uint32_t s_sid[kApplyMax];
-  cache_apply_batch(ar.cache, keys + off, ar.pi + static_cast<size_t>(off) * GM::M, ar.v + static_cast<size_t>(off) * (GM::P + 1), n, s_sid);
 }
 
 // Deterministic restart / retire of the slots whose game ended in the previous round:
 // slots are served in slot order against games_started (play_manager.cc:506-513).
-__global__ void k_assign(EngineParams ep, EngineArrays ar, uint32_t count_round) {
+__device__ __forceinline__ void assign_body(const EngineParams& ep, const EngineArrays& ar, uint32_t count_round) {
   Control* ctl = ar.ctl;
   __shared__ uint32_t s_n, s_base;
   if (threadIdx.x == 0) { s_n = ctl->ended_count; s_base = ctl->games_started; }
   __syncthreads();
   const uint32_t n = s_n, base = s_base;
-  if (threadIdx.x == 0 && count_round) ctl->rounds += 1;
+  if (threadIdx.x == 0 && count_round) { ctl->rounds += 1; ctl->eval_count = 0; }
   if (n == 0) return;
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     const uint32_t s = ar.ended_list[i];
@@ -1005,6 +997,20 @@ __global__ void k_assign(EngineParams ep, EngineArrays ar, uint32_t count_round)
     ctl->ended_count = 0;
     if (ctl->games_completed >= ep.games_to_play || ctl->live_slots == 0) ctl->stop = 1;
   }
+}
+
+__global__ void k_assign(EngineParams ep, EngineArrays ar, uint32_t count_round) { assign_body(ep, ar, count_round); }
+
+// Start of a round with the position cache on: the leaves the net evaluated in the previous round go into
+// the cache (PlayManager::update_inferences -> insert_many, play_manager.cc:631-640; one wave per leaf, batch
+// order per shard, keys left by k_round), and — in the same launch, they are independent — the extra last block
+// does the restart / retire bookkeeping.
+template <class GM>
+__global__ __launch_bounds__(256) void k_cache_insert(EngineParams ep, EngineArrays ar, const uint64_t* keys, uint32_t off, uint32_t n,
+                                                      uint32_t assign_block, uint32_t count_round) {
+  if (blockIdx.x == assign_block) { assign_body(ep, ar, count_round); return; }
+  __shared__ uint32_t s_sid[kApplyMax];
+  cache_apply_batch(ar.cache, keys + off, ar.pi + static_cast<size_t>(off) * GM::M, ar.v + static_cast<size_t>(off) * (GM::P + 1), n, s_sid);
 }
 
 }  // namespace azmi

@@ -69,6 +69,8 @@ struct Control {  // small device control block, copied back by azmi_pm_poll
   uint32_t overflow;      // bit0 tree arena, bit1 history, bit2 move log, bit3 path
   uint32_t live_slots;
   uint64_t rounds;
+  uint32_t eval_count;    // entries of eval_list written by this round's k_round
+  uint32_t pad_;
 };
 
 constexpr uint32_t kGumMaxM = 64;   // cap on PlayParams.gumbel_m (reference default 16)
@@ -137,6 +139,7 @@ struct EngineArrays {
   float* gum_g;           // [trees][gum_stride] Gumbel(0,1) sample per root child
   uint16_t* gum_surv;     // [trees][kGumMaxM] surviving root-child indices, best first
   uint32_t* compact_flag; // [trees] set by make_move, consumed by k_compact
+  uint32_t* eval_list;    // [S] slots whose pending leaf needs the net this round (unordered; ctl->eval_count entries)
 };
 
 }  // namespace azmi

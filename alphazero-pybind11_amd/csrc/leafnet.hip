@@ -103,8 +103,15 @@ __device__ __forceinline__ bf16x8 lds_read_frag(const uint8_t* p) {
 template <int H, int W, int MAXP1, int MAXM>
 __global__ __launch_bounds__(NTHREADS, 2) void k_leafnet(NetDesc nd, NetPtrs np, const float* __restrict__ canon,
                                                           float* __restrict__ v_out, float* __restrict__ pi_out,
-                                                          uint32_t batch, uint32_t dbg) {
+                                                          uint32_t batch, uint32_t dbg, const uint32_t* __restrict__ rows,
+                                                          const uint32_t* __restrict__ row_count) {
   using G = Geo<H, W>;
+  // rows != nullptr: evaluate only the rows listed in rows[0 .. *row_count) (the engine's eval list: slots whose
+  // pending leaf really needs the net); workgroups past the end of the list leave at once
+  if (rows) {
+    batch = *row_count;
+    if (blockIdx.x * TB >= batch) return;
+  }
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   uint8_t* act = lds;                                   // activation planes
   uint8_t* wbuf = lds + G::ACT_BYTES;                   // weights of the running convolution
@@ -144,7 +151,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_leafnet(NetDesc nd, NetPtrs np,
   const int plane_sz = nd.C_in * G::PIX;
   for (int i = tid; i < TB * plane_sz; i += NTHREADS) {
     const uint32_t b = board0 + i / plane_sz;
-    raw[i] = b < batch ? canon[static_cast<size_t>(b) * plane_sz + (i % plane_sz)] : 0.0f;
+    const uint32_t src = (rows && b < batch) ? rows[b] : b;
+    raw[i] = b < batch ? canon[static_cast<size_t>(src) * plane_sz + (i % plane_sz)] : 0.0f;
   }
   for (int i = tid * 16; i < 2 * MT * WFRAG_BYTES; i += NTHREADS * 16)
     *reinterpret_cast<u32x4*>(wbuf + i) = *reinterpret_cast<const u32x4*>(np.stem_w + i);
@@ -416,8 +424,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_leafnet(NetDesc nd, NetPtrs np,
   }
   __syncthreads();
   if (tid < TB) {  // softmax = exp(log_softmax), neural_net.py:468,508,816
-    const uint32_t b = board0 + tid;
+    uint32_t b = board0 + tid;
     if (b < batch) {
+      if (rows) b = rows[b];
       const float* lg = logits + tid * (MAXP1 + MAXM);
       float mx = lg[0];
       for (int i = 1; i < P1; ++i) mx = fmaxf(mx, lg[i]);
@@ -1078,7 +1087,20 @@ int azmi_net_forward(azmi_net* net, const float* dev_canonical, float* dev_v, fl
     return AZMI_OK;
   }
   const uint32_t tiles = (batch + TB - 1) / TB;
-  k_leafnet<6, 7, 4, 16><<<tiles, NTHREADS, net->lds_bytes, static_cast<hipStream_t>(stream)>>>(net->nd, net->np, dev_canonical, dev_v, dev_pi, batch, getenv("AZMI_NET_DEBUG") ? static_cast<uint32_t>(atoi(getenv("AZMI_NET_DEBUG"))) : 0u);
+  k_leafnet<6, 7, 4, 16><<<tiles, NTHREADS, net->lds_bytes, static_cast<hipStream_t>(stream)>>>(net->nd, net->np, dev_canonical, dev_v, dev_pi, batch, getenv("AZMI_NET_DEBUG") ? static_cast<uint32_t>(atoi(getenv("AZMI_NET_DEBUG"))) : 0u, nullptr, nullptr);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return nfail(AZMI_ERR_NO_DEVICE, "k_leafnet launch: %s", hipGetErrorString(e));
+  return AZMI_OK;
+}
+
+int azmi_net_forward_rows(azmi_net* net, const float* dev_canonical, float* dev_v, float* dev_pi, const uint32_t* dev_rows,
+                          const uint32_t* dev_row_count, uint32_t max_rows, void* stream) {
+  if (!net || !dev_canonical || !dev_v || !dev_pi || !dev_rows || !dev_row_count) return nfail(AZMI_ERR_INVALID, "null argument");
+  if (max_rows == 0) return AZMI_OK;
+  if (net->f32 || net->spatial)   // those paths evaluate the whole slot-indexed batch (rows not listed keep valid rows too)
+    return azmi_net_forward(net, dev_canonical, dev_v, dev_pi, max_rows, stream);
+  const uint32_t tiles = (max_rows + TB - 1) / TB;
+  k_leafnet<6, 7, 4, 16><<<tiles, NTHREADS, net->lds_bytes, static_cast<hipStream_t>(stream)>>>(net->nd, net->np, dev_canonical, dev_v, dev_pi, max_rows, 0u, dev_rows, dev_row_count);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nfail(AZMI_ERR_NO_DEVICE, "k_leafnet launch: %s", hipGetErrorString(e));
   return AZMI_OK;

@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--inline", type=int, default=0, help="max simulations finished per slot per round without the net (0 = engine default)")
     ap.add_argument("--hwq", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (0 = leave the runtime default of 4)")
     ap.add_argument("--playout-cap", action="store_true", help="playout-cap randomisation at the TrainConfig defaults (config.py:86,100)")
+    ap.add_argument("--gumbel", action="store_true", help="Gumbel AlphaZero search (configs/tawlbwrdd.yaml:24-25: gumbel_enabled, capped searches PUCT)")
     ap.add_argument("--net", choices=["hip", "torch"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short playout-cap-on measurement reported in config")
@@ -49,7 +50,7 @@ def parse():
     return ap.parse_args()
 
 
-def selfplay_params(az, games, sims, stream_games, cache=0, playout_cap=False):
+def selfplay_params(az, games, sims, stream_games, cache=0, playout_cap=False, gumbel=False):
     """self_play() settings, game_runner.py:2018-2041 with TrainConfig defaults (config.py:79-139,235-236);
     playout-cap randomisation is OFF so that every move is a full 800-simulation search."""
     pp = az.PlayParams()
@@ -77,6 +78,7 @@ def selfplay_params(az, games, sims, stream_games, cache=0, playout_cap=False):
     pp.resign_percent = 0.02
     pp.resign_playthrough_percent = 0.20
     pp.max_cache_size = cache
+    pp.gumbel_enabled = bool(gumbel)
     return pp
 
 
@@ -137,7 +139,7 @@ def main():
     # cores another shard's tree kernel runs on the CUs the net leaves free.
     pms, streams = [], []
     for i in range(K):
-        pp = selfplay_params(az, Se, sims, stream_games, cache=args.cache // K, playout_cap=args.playout_cap)
+        pp = selfplay_params(az, Se, sims, stream_games, cache=args.cache // K, playout_cap=args.playout_cap, gumbel=args.gumbel)
         pms.append(az.PlayManager(Game(), pp, seed=20240601 + 7919 * rank + 104729 * i, device=local_rank, max_inline=args.inline,
                                   history_capacity=(400_000 // K if tafl else 0)))
         streams.append(torch.cuda.Stream(device=dev))
@@ -154,7 +156,7 @@ def main():
     def evaluate(i):
         canon, v_buf, pi_buf = io[i]
         if hip_net is not None:
-            hip_net.forward(canon, v_buf, pi_buf, sps[i])
+            pms[i].net_forward(hip_net, sps[i])
         else:
             with torch.cuda.stream(streams[i]):
                 v, pi = net.process(canon, amp_dtype=torch.bfloat16)
@@ -237,7 +239,10 @@ def main():
         # launches of the timed region / the region's wall time (a lower bound on the kernel's own rate);
         # the per-launch HIP-event interval is reported next to it.
         launches = args.steps * K
-        achieved = flop_per_eval * Se * launches / dt / 1e12
+        # Connect4 + HIP net: a launch evaluates only the rows of the engine's eval list (leaves that missed the
+        # cache and are not terminal) = the `evals` counter; other paths evaluate the whole slot-indexed batch
+        rows_evaluated = n_evals if (hip_net is not None and not tafl) else float(Se) * launches
+        achieved = flop_per_eval * rows_evaluated / dt / 1e12
         out = {
             "metric": "self-play games/sec (whole node), Connect4 @ 800 MCTS sims" if not tafl else f"self-play games/sec (whole node), Tawlbwrdd @ {sims} MCTS sims",
             "value": n_games / dt,
@@ -252,7 +257,7 @@ def main():
             "dtype": "bf16",
             "data": "synthetic",
             "config": {
-                "workload": (f"Tawlbwrdd 11x11, {S} concurrent games/GPU, {sims} sims/move, 4-block/64-ch ResNet (configs/tawlbwrdd.yaml net, spatial head), PUCT, "
+                "workload": (f"Tawlbwrdd 11x11, {S} concurrent games/GPU, {sims} sims/move, 4-block/64-ch ResNet (configs/tawlbwrdd.yaml net, spatial head), {'Gumbel' if args.gumbel else 'PUCT'}, "
                              if tafl else f"Connect4, {S} concurrent games/GPU, {sims} sims/move, 6-block/64-ch ResNet (k3, 32 head ch), ")
                             + f"self-play flags of game_runner.py:2018-2041 with playout-cap {'ON (25 sims on 75% of moves)' if args.playout_cap else 'off'}, random-init weights",
                 "concurrent_games_per_gpu": S, "engine_shards": K, "sims_per_move": sims, "net": net_kind,
@@ -264,7 +269,7 @@ def main():
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
-                "kernel": "%s: %d positions x %.1f MFLOP per launch, %d overlapping launches per round" % ("k_leafnet_spatial" if tafl else "k_leafnet", Se, flop_per_eval / 1e6, K),
+                "kernel": "%s: %.0f positions (avg) x %.1f MFLOP per launch, %d overlapping launches per round" % ("k_leafnet_spatial" if tafl else "k_leafnet", rows_evaluated / launches, flop_per_eval / 1e6, K),
                 "per_launch_event_ms": nn_ms, "definition": "sum of algorithmic FLOPs of all k_leafnet launches in the timed region / wall time of the region",
             },
         }

@@ -217,6 +217,13 @@ size_t azmi_net_blob_bytes(const azmi_net_desc* desc);
 int azmi_net_create(const azmi_net_desc* desc, const void* blob, size_t blob_bytes, int device, azmi_net** out);
 void azmi_net_destroy(azmi_net* net);
 int azmi_net_forward(azmi_net* net, const float* dev_canonical, float* dev_v, float* dev_pi, uint32_t batch, void* stream);
+/* the same on a subset of the rows: dev_rows[0 .. *dev_row_count) (device memory, read when the kernel runs) are
+ * the row indices to evaluate; rows not listed are left untouched.  The engine lists the slots whose pending
+ * leaf really needs the net (cache hits, terminal leaves and retired slots do not). */
+int azmi_net_forward_rows(azmi_net* net, const float* dev_canonical, float* dev_v, float* dev_pi, const uint32_t* dev_rows,
+                          const uint32_t* dev_row_count, uint32_t max_rows, void* stream);
+/* azmi_net_forward_rows on an engine's own leaf batch and eval list (what azmi_run_rounds does after each round) */
+int azmi_pm_net_forward(azmi_pm* pm, azmi_net* net, void* stream);
 const char* azmi_net_last_error(void);
 
 /* ---- device position cache on its own: S3FIFOCache / ShardedS3FIFOCache (s3fifo_cache.h:15-318,
