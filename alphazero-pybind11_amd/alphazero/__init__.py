@@ -230,6 +230,7 @@ class GameState:
     kernels (azmi_game_replay_from) and memoised until the next play_move()."""
 
     GAME_ID = -1
+    _REPLAY_FLAGS = 0          # bit 0: reference-style unchecked play_move (Brandubh / OpenTafl objects)
 
     def __init__(self):
         self._init = None      # serialized start position (reference pickle image) or None = initial()
@@ -266,11 +267,11 @@ class GameState:
                        canonical=np.zeros((1,) + tuple(chw), np.float32), player=np.zeros(1, np.uint32),
                        turn=np.zeros(1, np.uint32), key=np.zeros(1, np.uint64), status=np.zeros(1, np.int32))
             init = None if self._init is None else np.frombuffer(self._init, np.uint8)
-            check(lib.azmi_game_replay_from(self.GAME_ID, self._device, None if init is None else init.ctypes.data,
-                                            0 if init is None else init.size, mv.ctypes.data, 1, mv.shape[1],
-                                            out["valid"].ctypes.data, out["scores"].ctypes.data, out["canonical"].ctypes.data,
-                                            out["player"].ctypes.data, out["turn"].ctypes.data, out["key"].ctypes.data,
-                                            out["status"].ctypes.data))
+            check(lib.azmi_game_replay_ex(self.GAME_ID, self._device, None if init is None else init.ctypes.data,
+                                          0 if init is None else init.size, mv.ctypes.data, 1, mv.shape[1],
+                                          out["valid"].ctypes.data, out["scores"].ctypes.data, out["canonical"].ctypes.data,
+                                          out["player"].ctypes.data, out["turn"].ctypes.data, out["key"].ctypes.data,
+                                          out["status"].ctypes.data, self._REPLAY_FLAGS))
             if out["status"][0] != 0:
                 raise RuntimeError("illegal move in the game record")
             self._snap = out
@@ -413,6 +414,57 @@ class TawlbwrddGS(GameState):  # py_wrapper.cc:549-560
             out += "".join("@" if c[0, h, w] == 1 else "O" if c[1, h, w] == 1 else "X" if c[2, h, w] == 1 else "."
                            for w in range(11)) + "\n"
         return out + "\n"
+
+
+class _TaflBoardGS(GameState):
+    """Brandubh / OpenTafl objects: optional start position as the reference's board tensor
+    (int8 [3, N, N] = king, defenders, attackers) with an empty repetition map."""
+    BOARD = 0
+    MAX_TURNS = 0
+    _REPLAY_FLAGS = 1          # play_move like the reference: no ownership / slide check (valid_moves is the validator)
+
+    def __init__(self, max_turns=None):
+        super().__init__()
+        if max_turns is not None and max_turns != self.MAX_TURNS:
+            raise RuntimeError(f"the MI355X engine implements {type(self).__name__} with the default max_turns = {self.MAX_TURNS}")
+
+    @classmethod
+    def from_board(cls, board, player, turn=0):
+        b = np.ascontiguousarray(board, dtype=np.int8)
+        if b.shape != (3, cls.BOARD, cls.BOARD):
+            raise RuntimeError("Improper tafl board shape")
+        g = cls()
+        g._init = b.tobytes() + np.int8(player).tobytes() + np.int32(turn).tobytes()
+        return g
+
+    @staticmethod
+    def NUM_SYMMETRIES():
+        return 8
+
+    @classmethod
+    def POLICY_SHAPE(cls):
+        return (2 * cls.BOARD, cls.BOARD, cls.BOARD)
+
+    def __str__(self):           # brandubh_gs.cc:547-581 / opentafl_gs.cc:589-623 without the colour escapes
+        st = self._state()
+        c = st["canonical"][0]
+        out = "Current Player: %d\nCurrent Turn: %d out of %d\n" % (st["player"][0], st["turn"][0], self.MAX_TURNS)
+        for h in range(self.BOARD):
+            out += "".join("@" if c[0, h, w] == 1 else "O" if c[1, h, w] == 1 else "X" if c[2, h, w] == 1 else "."
+                           for w in range(self.BOARD)) + "\n"
+        return out + "\n"
+
+
+class BrandubhGS(_TaflBoardGS):  # py_wrapper.cc:527-536
+    GAME_ID = 2
+    BOARD = 7
+    MAX_TURNS = 150
+
+
+class OpenTaflGS(_TaflBoardGS):  # py_wrapper.cc:538-547
+    GAME_ID = 3
+    BOARD = 11
+    MAX_TURNS = 400
 
 
 def _f32(a):

@@ -106,6 +106,7 @@ SYMBOLS = {
     "azmi_symmetries_last_error": (C.c_char_p, []),
     "azmi_pm_net_forward": (C.c_int, [_VP, _VP, _VP]),
     "azmi_net_forward_rows": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_uint32, _VP]),
+    "azmi_game_replay_ex": (C.c_int, [C.c_int, C.c_int, _VP, C.c_uint32, _VP, C.c_uint32, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_uint32]),
     "azmi_game_replay_from": (C.c_int, [C.c_int, C.c_int, _VP, C.c_uint32, _VP, C.c_uint32, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "azmi_game_replay": (C.c_int, [C.c_int, C.c_int, _VP, C.c_uint32, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
 }

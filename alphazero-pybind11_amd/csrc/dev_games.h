@@ -265,4 +265,226 @@ struct Tawlbwrdd {
   }
 };
 
+// =====================================================================================================
+// Brandubh (7x7) and OpenTafl (11x11): the Tawlbwrdd skeleton plus special squares
+// (/root/reference/src/brandubh_gs.cc:118-520, opentafl_gs.cc:99-585).  Corners are king-only and hostile to
+// everyone; non-king pieces pass through the empty throne but cannot land on it; the throne is hostile to
+// attackers always and to defenders when the king is not on it; the king wins on a CORNER.  Brandubh's
+// king is captured like any piece; OpenTafl's needs four hostile sides and is safe on an edge, attackers also
+// win by encirclement (flood fill from the rim), the position key includes the turn and canonical plane 7
+// is turn / max_turns.  Same state record and interface as Tawlbwrdd, so the wide-game engine
+// (engine_kernels_big.h) is instantiated unchanged.
+// =====================================================================================================
+template <int VARIANT>   // 0 = Brandubh, 1 = OpenTafl
+struct TaflX {
+  static constexpr bool kOpen = VARIANT == 1;
+  static constexpr int kGameId = 2 + VARIANT;
+  static constexpr int P = 2;
+  static constexpr int N = kOpen ? 11 : 7;
+  static constexpr int W = N, H = N, SQ = N * N, T = N / 2;
+  static constexpr int M = SQ * (W + H);
+  static constexpr int C = kOpen ? 8 : 7;
+  static constexpr int CANON = C * SQ;
+  static constexpr int MAXK = kOpen ? 512 : 256;
+  static constexpr int MAX_TURNS = kOpen ? 400 : 150;   // opentafl_gs.h:18, brandubh_gs.h:35
+  static constexpr int GROUP = 64;
+  static constexpr uint32_t kNoKing = 127;
+  static constexpr int STATE_WORDS = 5;
+  using State = Tawlbwrdd::State;
+
+  __host__ __device__ static uint32_t player_from_words(const uint64_t* words, uint32_t S, uint32_t slot) {
+    return static_cast<uint32_t>(words[4 * static_cast<size_t>(S) + slot] >> 24) & 1u;
+  }
+  __host__ __device__ static bool bit(const uint64_t (&b)[2], uint32_t sq) { return ((sq < 64 ? b[0] : b[1]) >> (sq & 63)) & 1ULL; }
+  __host__ __device__ static void setb(uint64_t (&b)[2], uint32_t sq) { if (sq < 64) b[0] |= 1ULL << sq; else b[1] |= 1ULL << (sq - 64); }
+  __host__ __device__ static void clrb(uint64_t (&b)[2], uint32_t sq) { if (sq < 64) b[0] &= ~(1ULL << sq); else b[1] &= ~(1ULL << (sq - 64)); }
+
+  __host__ __device__ static State initial() {
+    State s{};
+    s.king = T * W + T;
+    if (kOpen) {  // opentafl_gs.h:90-135
+      const int defs[12][2] = {{3,5},{4,5},{5,4},{5,3},{6,5},{7,5},{5,6},{5,7},{4,4},{4,6},{6,4},{6,6}};
+      for (auto& d : defs) setb(s.def, d[0] * W + d[1]);
+      const int atks[24][2] = {{0,3},{0,4},{0,5},{0,6},{0,7},{1,5},{10,3},{10,4},{10,5},{10,6},{10,7},{9,5},
+                               {3,0},{4,0},{5,0},{6,0},{7,0},{5,1},{3,10},{4,10},{5,10},{6,10},{7,10},{5,9}};
+      for (auto& a : atks) setb(s.atk, a[0] * W + a[1]);
+    } else {      // brandubh_gs.h:92-111
+      const int defs[4][2] = {{2,3},{3,2},{4,3},{3,4}};
+      for (auto& d : defs) setb(s.def, d[0] * W + d[1]);
+      const int atks[8][2] = {{1,3},{0,3},{3,1},{3,0},{5,3},{6,3},{3,5},{3,6}};
+      for (auto& a : atks) setb(s.atk, a[0] * W + a[1]);
+    }
+    s.turn = 0; s.player = 0; s.rep = 1;
+    return s;
+  }
+  // a position given as the reference's board tensor: int8 [3][N][N] (king, defenders, attackers) + player + turn
+  // (the test helper MakeGS, opentafl_gs_test.cc:97-101: empty repetition map, count 1)
+  __host__ __device__ static State from_board(const uint8_t* b, uint32_t player, uint32_t turn) {
+    State s{};
+    s.king = kNoKing;
+    for (uint32_t sq = 0; sq < static_cast<uint32_t>(SQ); ++sq) {
+      if (b[sq]) s.king = sq;
+      if (b[SQ + sq]) setb(s.def, sq);
+      if (b[2 * SQ + sq]) setb(s.atk, sq);
+    }
+    s.turn = turn; s.player = player & 1u; s.rep = 1;
+    return s;
+  }
+  __host__ __device__ static bool corner(int h, int w) { return (h == 0 || h == H - 1) && (w == 0 || w == W - 1); }
+  __host__ __device__ static bool occupied(const State& s, uint32_t sq) { return bit(s.def, sq) || bit(s.atk, sq) || s.king == sq; }
+  __host__ __device__ static bool own_piece(const State& s, uint32_t p, uint32_t sq) {
+    return p == 0 ? bit(s.atk, sq) : (bit(s.def, sq) || s.king == sq);
+  }
+  // is_valid_square, brandubh_gs.cc:138-154 / opentafl_gs.cc:137-153
+  __host__ __device__ static bool valid_square(const State& s, bool is_king, int h, int w) {
+    if (w < 0 || w >= W || h < 0 || h >= H) return false;
+    if (corner(h, w)) return is_king;
+    return !occupied(s, h * W + w);
+  }
+  // 2N-bit target mask of the piece on sq: bits 0..N-1 = new_w (row slides), bits N..2N-1 = new_h
+  __host__ __device__ static uint32_t slide_mask(const State& s, uint32_t sq) {
+    const int h = sq / W, w = sq % W;
+    const bool k = s.king == sq;
+    uint32_t m = 0;
+    for (int t = w + 1; valid_square(s, k, h, t); ++t) { if (h == T && t == T && !k) continue; m |= 1u << t; }
+    for (int t = w - 1; valid_square(s, k, h, t); --t) { if (h == T && t == T && !k) continue; m |= 1u << t; }
+    for (int t = h + 1; valid_square(s, k, t, w); ++t) { if (t == T && w == T && !k) continue; m |= 1u << (W + t); }
+    for (int t = h - 1; valid_square(s, k, t, w); --t) { if (t == T && w == T && !k) continue; m |= 1u << (W + t); }
+    return m;
+  }
+  __host__ __device__ static bool has_valid_moves(const State& s) {  // brandubh_gs.cc:156-213 / opentafl_gs.cc:155-212
+    for (uint32_t sq = 0; sq < static_cast<uint32_t>(SQ); ++sq)
+      if (own_piece(s, s.player, sq) && slide_mask(s, sq) != 0) return true;
+    return false;
+  }
+  __host__ __device__ static void remove_at(State& s, uint32_t sq) {
+    clrb(s.def, sq); clrb(s.atk, sq);
+    if (s.king == sq) s.king = kNoKing;
+  }
+  // is_hostile_to, brandubh_gs.cc:278-305 / opentafl_gs.cc:277-297: is (h, w) hostile to a piece of player p
+  __host__ __device__ static bool hostile_to(const State& s, uint32_t p, int h, int w) {
+    if (corner(h, w)) return true;
+    if (h == T && w == T) return p == 1 ? s.king != static_cast<uint32_t>(T * W + T) : true;
+    return own_piece(s, p ^ 1u, h * W + w);
+  }
+  // captured(), brandubh_gs.cc:307-340 / opentafl_gs.cc:299-334: mover sits on (fh, fw), victim one step along (dh, dw)
+  __host__ __device__ static bool captured(const State& s, uint32_t mover, int fh, int fw, int dh, int dw) {
+    const int th = fh + dh, tw = fw + dw;
+    if (tw < 0 || tw >= W || th < 0 || th >= H) return false;
+    const uint32_t tsq = th * W + tw;
+    if (kOpen && s.king == tsq) {
+      if (th == 0 || th == H - 1 || tw == 0 || tw == W - 1) return false;
+      return hostile_to(s, 1, th - 1, tw) && hostile_to(s, 1, th + 1, tw) && hostile_to(s, 1, th, tw - 1) && hostile_to(s, 1, th, tw + 1);
+    }
+    if (!own_piece(s, mover ^ 1u, tsq)) return false;
+    const int zh = th + dh, zw = tw + dw;
+    if (zw < 0 || zw >= W || zh < 0 || zh >= H) return false;
+    return hostile_to(s, mover ^ 1u, zh, zw);
+  }
+  __host__ __device__ static bool apply_move(State& s, uint32_t mv, bool* captured_any, bool unchecked = false) {
+    *captured_any = false;
+    if (mv >= static_cast<uint32_t>(M)) return false;
+    uint32_t new_loc = mv % (W + H);
+    const bool height_move = new_loc >= static_cast<uint32_t>(W);
+    if (height_move) new_loc -= W;
+    const uint32_t from = mv / (W + H);
+    const int ph = from / W, pw = from % W;
+    const int nh = height_move ? static_cast<int>(new_loc) : ph, nw = height_move ? pw : static_cast<int>(new_loc);
+    const uint32_t to = nh * W + nw;
+    // `unchecked`: the reference's play_move moves whatever stands on the square and never checks the slide
+    // (its own tests rely on that, brandubh_gs_test.cc:10-23, opentafl_gs_test.cc:408-420); captures are judged
+    // from the moved piece's side (piece_to_player of the new square).  The engine always plays checked moves.
+    uint32_t mover = s.player;
+    if (unchecked) {
+      if (!occupied(s, from) || (to != from && occupied(s, to))) return false;
+      mover = bit(s.atk, from) ? 0u : 1u;
+    } else if (!own_piece(s, mover, from)) {
+      return false;
+    }
+    if (s.king == from) s.king = to;
+    else if (bit(s.def, from)) { clrb(s.def, from); setb(s.def, to); }
+    else { clrb(s.atk, from); setb(s.atk, to); }
+    if (captured(s, mover, nh, nw, -1, 0)) { remove_at(s, (nh - 1) * W + nw); *captured_any = true; }
+    if (captured(s, mover, nh, nw, 1, 0)) { remove_at(s, (nh + 1) * W + nw); *captured_any = true; }
+    if (captured(s, mover, nh, nw, 0, -1)) { remove_at(s, nh * W + nw - 1); *captured_any = true; }
+    if (captured(s, mover, nh, nw, 0, 1)) { remove_at(s, nh * W + nw + 1); *captured_any = true; }
+    s.player ^= 1u;
+    ++s.turn;
+    return true;
+  }
+  __host__ __device__ static uint64_t rep_key(const State& s) {
+    uint64_t k = mix64(s.def[0] ^ (kOpen ? 0x0F7AULL : 0xB7A0ULL));
+    k = mix64(k ^ s.def[1]); k = mix64(k ^ s.atk[0]); k = mix64(k ^ s.atk[1]);
+    return mix64(k ^ (static_cast<uint64_t>(s.king) | (static_cast<uint64_t>(s.player) << 8)));
+  }
+  // evaluation-cache key: board, player, repetition count (+ turn for OpenTafl, opentafl_gs.cc:102-108)
+  __host__ __device__ static uint64_t key(const State& s) {
+    const uint64_t k = mix64(rep_key(s) ^ (static_cast<uint64_t>(s.rep) << 32));
+    return kOpen ? mix64(k ^ (static_cast<uint64_t>(s.turn) << 16)) : k;
+  }
+  // ---- encirclement (opentafl_gs.cc:466-506): flood fill from the rim over squares without attackers; the
+  // defenders can still reach the edge iff the filled region meets a defender or the king.  121-bit boards.
+  struct B128 { uint64_t lo, hi; };
+  __host__ __device__ static B128 shl(B128 x, int n) { return B128{x.lo << n, (x.hi << n) | (x.lo >> (64 - n))}; }
+  __host__ __device__ static B128 shr(B128 x, int n) { return B128{(x.lo >> n) | (x.hi << (64 - n)), x.hi >> n}; }
+  __host__ __device__ static B128 band(B128 a, B128 b) { return B128{a.lo & b.lo, a.hi & b.hi}; }
+  __host__ __device__ static B128 bor(B128 a, B128 b) { return B128{a.lo | b.lo, a.hi | b.hi}; }
+  __host__ __device__ static B128 column(int w) {
+    B128 m{0, 0};
+    for (int h = 0; h < H; ++h) { const int sq = h * W + w; if (sq < 64) m.lo |= 1ULL << sq; else m.hi |= 1ULL << (sq - 64); }
+    return m;
+  }
+  __host__ __device__ static bool encircled(const State& s) {
+    constexpr uint64_t hi_mask = SQ > 64 ? ((1ULL << ((SQ > 64 ? SQ : 65) - 64)) - 1) : 0ULL;
+    constexpr uint64_t lo_mask = SQ >= 64 ? ~0ULL : ((1ULL << (SQ < 64 ? SQ : 0)) - 1);
+    const B128 all{lo_mask, hi_mask};
+    const B128 free_sq{all.lo & ~s.atk[0], all.hi & ~s.atk[1]};
+    const B128 col0 = column(0), colN = column(W - 1);
+    B128 rim = bor(col0, colN);
+    for (int w = 0; w < W; ++w) { const int a = w, b = (H - 1) * W + w;
+      if (a < 64) rim.lo |= 1ULL << a; else rim.hi |= 1ULL << (a - 64);
+      if (b < 64) rim.lo |= 1ULL << b; else rim.hi |= 1ULL << (b - 64); }
+    B128 reach = band(rim, free_sq);
+    for (int it = 0; it < SQ; ++it) {
+      const B128 left = band(shr(reach, 1), B128{~colN.lo, ~colN.hi});    // sq - 1 (never wraps into column N-1)
+      const B128 right = band(shl(reach, 1), B128{~col0.lo, ~col0.hi});   // sq + 1
+      const B128 up = shr(reach, W), down = band(shl(reach, W), all);
+      const B128 next = bor(reach, band(bor(bor(left, right), bor(up, down)), free_sq));
+      if (next.lo == reach.lo && next.hi == reach.hi) break;
+      reach = next;
+    }
+    uint64_t dlo = s.def[0], dhi = s.def[1];
+    if (s.king != kNoKing) { if (s.king < 64) dlo |= 1ULL << s.king; else dhi |= 1ULL << (s.king - 64); }
+    return ((reach.lo & dlo) | (reach.hi & dhi)) == 0;
+  }
+  // scores(), brandubh_gs.cc:441-488 / opentafl_gs.cc:430-520 — 0 running, else 1 + index of the winning entry
+  __host__ __device__ static uint32_t terminal(const State& s) {
+    if (s.rep >= 3) return 1 + s.player;
+    if (s.king != kNoKing) {
+      if (corner(s.king / W, s.king % W)) return 2;
+    } else {
+      return 1;
+    }
+    if (kOpen && encircled(s)) return 1;
+    if (!has_valid_moves(s)) return 1 + (s.player ^ 1u);
+    if (s.turn >= static_cast<uint32_t>(MAX_TURNS)) return 3;
+    return 0;
+  }
+  __host__ __device__ static float canonical_at(const State& s, uint32_t e) {
+    const uint32_t plane = e / SQ, sq = e % SQ;
+    switch (plane) {
+      case 0: return s.king == sq ? 1.0f : 0.0f;
+      case 1: return bit(s.def, sq) ? 1.0f : 0.0f;
+      case 2: return bit(s.atk, sq) ? 1.0f : 0.0f;
+      case 3: return s.player == 0 ? 1.0f : 0.0f;
+      case 4: return s.player == 1 ? 1.0f : 0.0f;
+      case 5: return (s.rep == 1 || s.rep > 2) ? 1.0f : 0.0f;
+      case 6: return s.rep >= 2 ? 1.0f : 0.0f;
+      default: return static_cast<float>(s.turn) / static_cast<float>(MAX_TURNS);   // opentafl_gs.cc:574-579
+    }
+  }
+};
+using Brandubh = TaflX<0>;
+using OpenTafl = TaflX<1>;
+
 }  // namespace azmi

@@ -54,6 +54,14 @@ bool game_info(int game, GameInfo* gi) {
       *gi = GameInfo{Tawlbwrdd::P, Tawlbwrdd::M, Tawlbwrdd::C, Tawlbwrdd::H, Tawlbwrdd::W, Tawlbwrdd::MAXK,
                      Tawlbwrdd::MAX_TURNS, Tawlbwrdd::STATE_WORDS, 160};
       return true;
+    case AZMI_GAME_BRANDUBH:
+      *gi = GameInfo{Brandubh::P, Brandubh::M, Brandubh::C, Brandubh::H, Brandubh::W, Brandubh::MAXK,
+                     Brandubh::MAX_TURNS, Brandubh::STATE_WORDS, 48};
+      return true;
+    case AZMI_GAME_OPENTAFL:
+      *gi = GameInfo{OpenTafl::P, OpenTafl::M, OpenTafl::C, OpenTafl::H, OpenTafl::W, OpenTafl::MAXK,
+                     OpenTafl::MAX_TURNS, OpenTafl::STATE_WORDS, 160};
+      return true;
     default:
       return false;
   }
@@ -138,6 +146,14 @@ int launch_round(azmi_pm* pm, hipStream_t st) {
       k_round_big<Tawlbwrdd><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
       if (pm->ep.half_nodes) k_compact<Tawlbwrdd><<<pm->ep.S * pm->gi.P, 256, 0, st>>>(pm->ep, pm->ar);
       break;
+    case AZMI_GAME_BRANDUBH:
+      k_round_big<Brandubh><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
+      if (pm->ep.half_nodes) k_compact<Brandubh><<<pm->ep.S * pm->gi.P, 256, 0, st>>>(pm->ep, pm->ar);
+      break;
+    case AZMI_GAME_OPENTAFL:
+      k_round_big<OpenTafl><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
+      if (pm->ep.half_nodes) k_compact<OpenTafl><<<pm->ep.S * pm->gi.P, 256, 0, st>>>(pm->ep, pm->ar);
+      break;
     default:
       return fail(AZMI_ERR_INVALID, "game %d has no device kernels", pm->game);
   }
@@ -190,14 +206,28 @@ __global__ void k_replay(const uint8_t* init, const int32_t* moves, uint32_t n, 
   if (key) key[g] = GM::key(s);
 }
 
-// Tawlbwrdd replay: one thread per game, repetition list in a global scratch row per game
-__global__ void k_replay_tafl(const int32_t* moves, uint32_t n, uint32_t len, uint64_t* rep_scratch, uint32_t rep_stride,
+// Tafl-family replay: one thread per game, repetition list in a global scratch row per game
+template <class GM>
+__device__ typename GM::State tafl_start(const uint8_t* init, uint32_t stride, uint32_t g) {
+  if constexpr (GM::kGameId == Tawlbwrdd::kGameId) {
+    return GM::initial();
+  } else {
+    if (!init) return GM::initial();
+    const uint8_t* b = init + static_cast<size_t>(g) * stride;
+    const uint8_t* t = b + 3 * GM::SQ + 1;
+    return GM::from_board(b, b[3 * GM::SQ], uint32_t(t[0]) | uint32_t(t[1]) << 8 | uint32_t(t[2]) << 16 | uint32_t(t[3]) << 24);
+  }
+}
+template <class GM>
+__global__ void k_replay_tafl(const uint8_t* init, uint32_t init_stride, const int32_t* moves, uint32_t n, uint32_t len,
+                              uint64_t* rep_scratch, uint32_t rep_stride,
                               uint8_t* valid, float* scores, float* canonical, uint32_t* player, uint32_t* turn,
-                              uint64_t* key, int32_t* status) {
-  using GM = Tawlbwrdd;
+                              uint64_t* key, int32_t* status, uint32_t flags) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
-  GM::State s = GM::initial();
+  typename GM::State s = tafl_start<GM>(init, init_stride, g);
+  const bool unchecked = (flags & 1u) && GM::kGameId != Tawlbwrdd::kGameId;
+  constexpr uint32_t SPAN = GM::W + GM::H;
   uint64_t* reps = rep_scratch + static_cast<size_t>(g) * rep_stride;
   uint32_t nrep = 0;
   int32_t stt = 0;
@@ -205,14 +235,18 @@ __global__ void k_replay_tafl(const int32_t* moves, uint32_t n, uint32_t len, ui
     const int32_t mv = moves[static_cast<size_t>(g) * len + i];
     if (mv < 0) break;
     bool legal = mv < GM::M;
-    if (legal) {
-      const uint32_t from = static_cast<uint32_t>(mv) / 22, tgt = static_cast<uint32_t>(mv) % 22;
+    if (legal && !unchecked) {
+      const uint32_t from = static_cast<uint32_t>(mv) / SPAN, tgt = static_cast<uint32_t>(mv) % SPAN;
       legal = GM::own_piece(s, s.player, from) && ((GM::slide_mask(s, from) >> tgt) & 1u);
     }
     if (!legal) { stt = -1; break; }
-    if (s.turn == 0) { reps[0] = GM::rep_key(s); nrep = 1; }   // tawlbwrdd_gs.cc:253-259
+    typename GM::State before = s;
     bool cap = false;
-    GM::apply_move(s, static_cast<uint32_t>(mv), &cap);
+    bool ok;
+    if constexpr (GM::kGameId == Tawlbwrdd::kGameId) ok = GM::apply_move(s, static_cast<uint32_t>(mv), &cap);
+    else ok = GM::apply_move(s, static_cast<uint32_t>(mv), &cap, unchecked);
+    if (!ok) { stt = -1; break; }
+    if (before.turn == 0) { reps[0] = GM::rep_key(before); nrep = 1; }   // tawlbwrdd_gs.cc:253-259
     if (cap) nrep = 0;
     const uint64_t k = GM::rep_key(s);
     uint32_t cnt = 1;
@@ -227,7 +261,7 @@ __global__ void k_replay_tafl(const int32_t* moves, uint32_t n, uint32_t len, ui
     for (uint32_t sq = 0; sq < static_cast<uint32_t>(GM::SQ); ++sq) {
       if (!GM::own_piece(s, s.player, sq)) continue;
       const uint32_t mask = GM::slide_mask(s, sq);
-      for (int b = 0; b < 22; ++b) if ((mask >> b) & 1u) vr[sq * 22 + b] = 1;
+      for (uint32_t b = 0; b < SPAN; ++b) if ((mask >> b) & 1u) vr[sq * SPAN + b] = 1;
     }
   }
   if (scores) {
@@ -418,7 +452,7 @@ int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_o
   A(cur, S, true); A(plen, S, true);
   A(path, static_cast<size_t>(S) * ep.max_depth, true);
   A(slot_games, S, true);
-  A(rep_list, game == AZMI_GAME_TAWLBWRDD ? static_cast<size_t>(S) * (gi.max_turns + 2) : 0, true);
+  A(rep_list, game != AZMI_GAME_CONNECT4 ? static_cast<size_t>(S) * (gi.max_turns + 2) : 0, true);
   A(rep_len, S, true);
   A(g_dsum, 5 * static_cast<size_t>(S), true); A(g_cnt, 3 * static_cast<size_t>(S), true);
   A(a_scores, static_cast<size_t>(S) * (P + 1), true); A(a_resign, static_cast<size_t>(S) * (P + 1), true);
@@ -782,11 +816,21 @@ int azmi_game_replay(int game, int device, const int32_t* moves, uint32_t n, uin
 int azmi_game_replay_from(int game, int device, const uint8_t* init, uint32_t init_stride, const int32_t* moves,
                           uint32_t n, uint32_t len, uint8_t* valid, float* scores, float* canonical,
                           uint32_t* player, uint32_t* turn, uint64_t* key, int32_t* status) {
+  return azmi_game_replay_ex(game, device, init, init_stride, moves, n, len, valid, scores, canonical, player, turn, key, status, 0u);
+}
+
+int azmi_game_replay_ex(int game, int device, const uint8_t* init, uint32_t init_stride, const int32_t* moves,
+                        uint32_t n, uint32_t len, uint8_t* valid, float* scores, float* canonical,
+                        uint32_t* player, uint32_t* turn, uint64_t* key, int32_t* status, uint32_t flags) {
   GameInfo gi;
   if (!game_info(game, &gi)) return fail(AZMI_ERR_INVALID, "unknown game id %d", game);
   if (!moves && n * len) return fail(AZMI_ERR_INVALID, "null moves");
-  if (init && (game != AZMI_GAME_CONNECT4 || init_stride != Connect4::SERIALIZED))
-    return fail(AZMI_ERR_INVALID, "start positions: Connect4 only, %u bytes per state (connect4_gs.cc:172-178)", unsigned(Connect4::SERIALIZED));
+  if (init) {
+    const uint32_t want = game == AZMI_GAME_CONNECT4 ? Connect4::SERIALIZED : game == AZMI_GAME_BRANDUBH ? 3u * Brandubh::SQ + 5u
+                        : game == AZMI_GAME_OPENTAFL ? 3u * OpenTafl::SQ + 5u : 0u;
+    if (want == 0 || init_stride != want)
+      return fail(AZMI_ERR_INVALID, "start positions: Connect4 (89 bytes), Brandubh (152) and OpenTafl (368) only; got stride %u for game %d", init_stride, game);
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(AZMI_ERR_NO_DEVICE, "no HIP device: libazmi has no CPU path");
   HIP_TRY(hipSetDevice(device));
@@ -816,11 +860,18 @@ int azmi_game_replay_from(int game, int device, const uint8_t* init, uint32_t in
       case AZMI_GAME_CONNECT4:
         k_replay<Connect4><<<(n + 255) / 256, 256>>>(d_init, d_moves, n, len, d_valid, d_scores, d_canon, d_player, d_turn, d_key, d_status);
         break;
-      case AZMI_GAME_TAWLBWRDD: {
+      case AZMI_GAME_TAWLBWRDD:
+      case AZMI_GAME_BRANDUBH:
+      case AZMI_GAME_OPENTAFL: {
         uint64_t* d_rep = nullptr;
         const uint32_t stride = len + 2;
         TRY2(dalloc(reinterpret_cast<void**>(&d_rep), static_cast<size_t>(n) * stride * 8));
-        k_replay_tafl<<<(n + 63) / 64, 64>>>(d_moves, n, len, d_rep, stride, d_valid, d_scores, d_canon, d_player, d_turn, d_key, d_status);
+        if (game == AZMI_GAME_TAWLBWRDD)
+          k_replay_tafl<Tawlbwrdd><<<(n + 63) / 64, 64>>>(d_init, init_stride, d_moves, n, len, d_rep, stride, d_valid, d_scores, d_canon, d_player, d_turn, d_key, d_status, flags);
+        else if (game == AZMI_GAME_BRANDUBH)
+          k_replay_tafl<Brandubh><<<(n + 63) / 64, 64>>>(d_init, init_stride, d_moves, n, len, d_rep, stride, d_valid, d_scores, d_canon, d_player, d_turn, d_key, d_status, flags);
+        else
+          k_replay_tafl<OpenTafl><<<(n + 63) / 64, 64>>>(d_init, init_stride, d_moves, n, len, d_rep, stride, d_valid, d_scores, d_canon, d_player, d_turn, d_key, d_status, flags);
         break;
       }
       default: cleanup(); return fail(AZMI_ERR_INVALID, "game %d has no device kernels", game);

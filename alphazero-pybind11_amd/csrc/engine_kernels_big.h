@@ -156,7 +156,7 @@ struct BigSlot {
       while (m) {
         const uint32_t b = __builtin_ctz(m);
         m &= m - 1;
-        sm.moves[pos++] = static_cast<uint16_t>(sq * 22 + b);
+        sm.moves[pos++] = static_cast<uint16_t>(sq * (GM::W + GM::H) + b);
       }
       base += total;
     }

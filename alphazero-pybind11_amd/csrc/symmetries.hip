@@ -131,13 +131,17 @@ extern "C" {
 
 const char* azmi_symmetries_last_error(void) { return g_sym_err.c_str(); }
 
-uint32_t azmi_num_symmetries(int game) { return game == AZMI_GAME_CONNECT4 ? 2u : game == AZMI_GAME_TAWLBWRDD ? 8u : 0u; }
+uint32_t azmi_num_symmetries(int game) {
+  return game == AZMI_GAME_CONNECT4 ? 2u : (game == AZMI_GAME_TAWLBWRDD || game == AZMI_GAME_BRANDUBH || game == AZMI_GAME_OPENTAFL) ? 8u : 0u;
+}
 
 int azmi_symmetries(int game, int device, uint32_t count, const float* canon, const float* v, const float* pi,
                     float* out_canon, float* out_v, float* out_pi, int host_buffers, void* stream) {
   SymGeo g;
   if (game == AZMI_GAME_CONNECT4) g = SymGeo{0, 4, 6, 7, 7, 3, 2};
   else if (game == AZMI_GAME_TAWLBWRDD) g = SymGeo{1, 7, 11, 11, 11 * 11 * 22, 3, 8};
+  else if (game == AZMI_GAME_BRANDUBH) g = SymGeo{1, 7, 7, 7, 7 * 7 * 14, 3, 8};
+  else if (game == AZMI_GAME_OPENTAFL) g = SymGeo{1, 8, 11, 11, 11 * 11 * 22, 3, 8};
   else { g_sym_err = "azmi_symmetries: unknown game"; return AZMI_ERR_INVALID; }
   return run(g, device, count, canon, v, pi, out_canon, out_v, out_pi, host_buffers, stream);
 }

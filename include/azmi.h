@@ -35,7 +35,7 @@ typedef enum azmi_status {
 } azmi_status;
 
 /* game ids (reference GAME_REGISTRY, config.py:17-35) */
-typedef enum azmi_game { AZMI_GAME_CONNECT4 = 0, AZMI_GAME_TAWLBWRDD = 1 } azmi_game;
+typedef enum azmi_game { AZMI_GAME_CONNECT4 = 0, AZMI_GAME_TAWLBWRDD = 1, AZMI_GAME_BRANDUBH = 2, AZMI_GAME_OPENTAFL = 3 } azmi_game;
 
 /* EvalType, play_manager.h:20 */
 typedef enum azmi_eval_type { AZMI_EVAL_NN = 0, AZMI_EVAL_RANDOM = 1, AZMI_EVAL_PLAYOUT = 2 } azmi_eval_type;
@@ -172,10 +172,18 @@ int azmi_game_replay(int game, int device, const int32_t* moves, uint32_t n, uin
 /* the same from given start positions: `init` is [n, init_stride] bytes, one serialized state per
  * game in the reference's pickle image (Connect4GS::to_bytes, connect4_gs.cc:172-190: int8
  * board[2][6][7], int8 player, int32 turn = 89 bytes; Connect4GS(board, player, turn) ctor,
- * py_wrapper.cc:563-581). NULL = the game's initial position. Connect4 only in this round. */
+ * py_wrapper.cc:563-581).  Brandubh / OpenTafl: int8 board[3][N][N] (king, defenders, attackers), int8 player,
+ * int32 turn = 3*N*N + 5 bytes, with an empty repetition map (the reference tests' MakeGS helper,
+ * opentafl_gs_test.cc:97-101).  NULL = the game's initial position. */
 int azmi_game_replay_from(int game, int device, const uint8_t* init, uint32_t init_stride, const int32_t* moves,
                           uint32_t n, uint32_t len, uint8_t* valid, float* scores, float* canonical,
                           uint32_t* player, uint32_t* turn, uint64_t* key, int32_t* status);
+/* flags bit 0 (Brandubh / OpenTafl): apply moves the way the reference's play_move does — no ownership or slide
+ * check, captures judged from the moved piece's side (brandubh_gs.cc:342-427; the reference's own tests rely on
+ * it).  Without the flag a move that valid_moves() does not list ends the game record with status -1. */
+int azmi_game_replay_ex(int game, int device, const uint8_t* init, uint32_t init_stride, const int32_t* moves,
+                        uint32_t n, uint32_t len, uint8_t* valid, float* scores, float* canonical,
+                        uint32_t* player, uint32_t* turn, uint64_t* key, int32_t* status, uint32_t flags);
 
 /* ---- training-sample symmetries (GameState::symmetries(PlayHistory), py_wrapper.cc:178;
  *      connect4_gs.cc:151-170, tafl_helper.h:16-149, tawlbwrdd_gs.cc:455-458) ------------------

@@ -12,6 +12,7 @@
 #include "az_rng.hpp"
 #include "az_symmetries.hpp"
 #include "az_tafl.hpp"
+#include "az_tafl_family.hpp"
 
 using namespace orc;
 
@@ -20,6 +21,8 @@ std::unique_ptr<Game> make_game(int game_id) {
   switch (game_id) {
     case 0: return std::make_unique<Connect4>();
     case 1: return std::make_unique<Tawlbwrdd>();
+    case 2: return std::make_unique<Brandubh>();
+    case 3: return std::make_unique<OpenTafl>();
     default: throw std::runtime_error("unknown game id");
   }
 }
@@ -76,6 +79,16 @@ void orc_gumbel(uint64_t seed, uint32_t n, float* out) {
 void* orc_game_new(int game_id) { try { return make_game(game_id).release(); } catch (...) { return nullptr; } }
 void* orc_c4_from_board(const int8_t* board, int8_t player, int32_t turn) {
   return new Connect4(board, player, turn);
+}
+// Tafl family from a given board (test helper MakeGS, opentafl_gs_test.cc:97-101): int8 board[3][N][N]
+void* orc_tafl_from_board(int game_id, const int8_t* board, int8_t player, uint32_t turn, uint32_t max_turns) {
+  try {
+    switch (game_id) {
+      case 2: return new Brandubh(board, player, static_cast<uint16_t>(turn), static_cast<uint16_t>(max_turns));
+      case 3: return new OpenTafl(board, player, static_cast<uint16_t>(turn), static_cast<uint16_t>(max_turns));
+      default: return nullptr;
+    }
+  } catch (...) { return nullptr; }
 }
 void* orc_game_copy(void* g) { return static_cast<Game*>(g)->copy().release(); }
 void orc_game_free(void* g) { delete static_cast<Game*>(g); }

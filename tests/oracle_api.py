@@ -13,7 +13,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB = os.path.join(ORACLE_DIR, "liboracle.so")
 REF_RNG = os.path.join(ORACLE_DIR, "_ref", "librngref.so")
 
-GAME_CONNECT4, GAME_TAWLBWRDD = 0, 1
+GAME_CONNECT4, GAME_TAWLBWRDD, GAME_BRANDUBH, GAME_OPENTAFL = 0, 1, 2, 3
 
 
 def build():
@@ -25,7 +25,7 @@ def build():
 
 build()
 lib = C.CDLL(LIB)
-for name in ("orc_game_new", "orc_c4_from_board", "orc_game_copy", "orc_mcts_new", "orc_mcts_leaf", "orc_pm_new",
+for name in ("orc_game_new", "orc_c4_from_board", "orc_tafl_from_board", "orc_game_copy", "orc_mcts_new", "orc_mcts_leaf", "orc_pm_new",
              "orc_cache_new"):
     getattr(lib, name).restype = C.c_void_p
 lib.orc_game_key.restype = C.c_uint64
@@ -87,6 +87,14 @@ class Game:
         b = np.ascontiguousarray(board, dtype=np.int8)
         assert b.shape == (2, 6, 7)
         return cls(handle=lib.orc_c4_from_board(_p(b), C.c_int8(player), C.c_int32(turn)))
+
+    @classmethod
+    def tafl_from_board(cls, game_id, board, player, turn=10, max_turns=400):
+        """MakeGS of opentafl_gs_test.cc:97-101: int8 board [3,N,N], empty repetition map, count 1."""
+        b = np.ascontiguousarray(board, dtype=np.int8)
+        h = lib.orc_tafl_from_board(C.c_int(game_id), _p(b), C.c_int8(player), C.c_uint32(turn), C.c_uint32(max_turns))
+        assert h
+        return cls(handle=h)
 
     def __del__(self):
         if getattr(self, "owned", False) and self.h:

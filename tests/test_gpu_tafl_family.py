@@ -1,0 +1,141 @@
+"""-m gpu: Brandubh and OpenTafl on the device (rules kernels + the wide-game engine) against the reference's own
+rule tests (opentafl_gs_test.cc / brandubh_gs_test.cc, as data in tafl_cases.py) and the oracle."""
+import numpy as np
+import pytest
+
+import tafl_cases as tc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def az():
+    import alphazero
+    return alphazero
+
+
+class _DevGame:
+    """adapter: alphazero GameState object -> the tiny interface tafl_cases.check_case uses"""
+    def __init__(self, gs): self.gs = gs
+    def play(self, m): self.gs.play_move(m)
+    def valid(self): return self.gs.valid_moves()
+    def scores(self): return self.gs.scores()
+    def canonical(self): return self.gs.canonicalized()
+
+
+def test_opentafl_reference_rule_cases_on_device(az):
+    for case in tc.OPENTAFL_CASES:
+        name, pieces, player, turn, move, exp = case
+        gs = az.OpenTaflGS.from_board(tc.board(pieces), player, turn)
+        tc.check_case(_DevGame(gs), case)
+    rep = az.OpenTaflGS()                      # RepetitionCount, opentafl_gs_test.cc:10-78
+    for m in tc.OPENTAFL_REPETITION:
+        rep.play_move(m)
+    assert np.array_equal(rep.scores(), [1, 0, 0]) and np.allclose(rep.canonicalized()[7], 8 / 400)
+    gs = az.OpenTaflGS()
+    c = gs.canonicalized()
+    assert gs.current_player() == 0 and c[0].sum() == 1 and c[1].sum() == 12 and c[2].sum() == 24 and c[0, 5, 5] == 1
+    assert gs.num_moves() == 2662 and az.OpenTaflGS.CANONICAL_SHAPE() == (8, 11, 11) and az.OpenTaflGS.POLICY_SHAPE() == (22, 11, 11)
+
+
+def test_brandubh_cases_on_device(az):
+    rep = az.BrandubhGS()                      # RepetitionCount, brandubh_gs_test.cc:10-55 (moves a piece of either side)
+    for m in tc.BRANDUBH_REPETITION:
+        rep.play_move(m)
+    assert np.array_equal(rep.scores(), [1, 0, 0])
+    gs = az.BrandubhGS()
+    c = gs.canonicalized()
+    assert c.shape == (7, 7, 7) and c[0, 3, 3] == 1 and c[1].sum() == 4 and c[2].sum() == 8 and gs.num_moves() == 686
+    b = tc.board([(tc.A, 3, 1), (tc.K, 6, 5)], n=7)
+    v = az.BrandubhGS.from_board(b, 0, 4).valid_moves()
+    assert v[tc.mv(3, 1, False, 3, n=7)] == 0 and v[tc.mv(3, 1, False, 4, n=7)] == 1
+    g = az.BrandubhGS.from_board(b, 1, 4); g.play_move(tc.mv(6, 5, False, 6, n=7))
+    assert np.array_equal(g.scores(), [0, 1, 0])
+    b = tc.board([(tc.K, 2, 2), (tc.A, 2, 1), (tc.A, 2, 5)], n=7)
+    g = az.BrandubhGS.from_board(b, 0, 4); g.play_move(tc.mv(2, 5, False, 3, n=7))
+    assert np.array_equal(g.scores(), [1, 0, 0])
+
+
+@pytest.mark.parametrize("name", ["BrandubhGS", "OpenTaflGS"])
+def test_rules_random_walks_match_oracle(az, oracle, name):
+    """T0: valid_moves / scores / canonicalized / player / turn along seeded random legal walks, batched replay."""
+    Game = getattr(az, name)
+    gid = oracle.GAME_BRANDUBH if name == "BrandubhGS" else oracle.GAME_OPENTAFL
+    rng = np.random.default_rng(17)
+    n, L = 300, 120
+    moves = -np.ones((n, L), np.int32)
+    finals = []
+    for g in range(n):
+        game = oracle.Game(gid)
+        for i in range(int(rng.integers(0, L + 1))):
+            if game.scores() is not None:
+                break
+            m = int(rng.choice(np.flatnonzero(game.valid())))
+            game.play(m); moves[g, i] = m
+        finals.append(game)
+    out = az.game_replay(Game, moves)
+    assert (out["status"] == 0).all()
+    ended = 0
+    for g, game in enumerate(finals):
+        assert np.array_equal(out["valid"][g], game.valid()), g
+        sc = game.scores()
+        if sc is None:
+            assert (out["scores"][g] == -1).all(), g
+        else:
+            ended += 1
+            assert np.array_equal(out["scores"][g], sc), g
+        assert np.array_equal(out["canonical"][g], game.canonical()), g
+        assert out["player"][g] == game.player() and out["turn"][g] == game.turn(), g
+    assert ended > 0
+
+
+@pytest.mark.parametrize("name,cfg", [
+    ("BrandubhGS", dict()),
+    ("BrandubhGS", dict(epsilon=0.25, shaped_dirichlet=True, mcts_root_temp=1.25, policy_target_pruning=True)),
+    ("BrandubhGS", dict(gumbel_enabled=True, gumbel_m=8)),
+    ("OpenTaflGS", dict()),
+    ("OpenTaflGS", dict(playout_cap_randomization=True, playout_cap_depth=8, playout_cap_percent=0.5, epsilon=0.25)),
+])
+def test_playmanager_parity(az, oracle, name, cfg):
+    """T2 on the wide-game engine instantiated for Brandubh / OpenTafl: moves, visit counts, RNG position, history rows."""
+    Game = getattr(az, name)
+    gid = oracle.GAME_BRANDUBH if name == "BrandubhGS" else oracle.GAME_OPENTAFL
+    pp = az.PlayParams()
+    pp.eval_type = [az.EvalType.RANDOM, az.EvalType.RANDOM]
+    pp.history_enabled = True
+    pp.games_to_play, pp.concurrent_games, pp.mcts_visits = 6, 6, [24, 24]
+    pp.cpuct, pp.fpu_reduction = 1.25, 0.25
+    for k, v in cfg.items():
+        setattr(pp, k, v)
+    seed = 404
+    pm = az.PlayManager(Game(), pp, seed=seed, log_moves=True)
+    pm.play()
+    rows, counts = pm.move_log()
+    hc, hv, hp = pm.history()
+    tot = np.zeros(3, np.float32)
+    rows_orc = []
+    for s in range(6):
+        one = az.PlayParams(); one.__dict__.update(pp.__dict__)
+        one.games_to_play, one.concurrent_games = 1, 1
+        o = oracle.PlayManager(gid, one, oracle.slot_seed(seed, s), per_slot_rng=False)
+        o.run()
+        orows, ocounts = o.moves()
+        sel = rows[:, 0] == s
+        assert np.array_equal(rows[sel][:, 1:], orows[:, 1:]), s
+        assert np.array_equal(counts[sel], ocounts), s
+        tot += o.scores()
+        c, v, p = o.history()
+        rows_orc += [(a.tobytes(), b.tobytes(), d.tobytes()) for a, b, d in zip(c, v, p)]
+    assert np.array_equal(pm.scores(), tot)
+    assert sorted((a.tobytes(), b.tobytes(), d.tobytes()) for a, b, d in zip(hc, hv, hp)) == sorted(rows_orc)
+
+
+def test_symmetries_match_oracle(az, oracle):
+    rng = np.random.default_rng(2)
+    for Game, n, C in ((az.BrandubhGS, 7, 7), (az.OpenTaflGS, 11, 8)):
+        c = rng.random((3, C, n, n), dtype=np.float32); v = rng.random((3, 3), dtype=np.float32)
+        pi = rng.random((3, n * n * 2 * n), dtype=np.float32)
+        oc, ov, op = az.symmetries_batch(Game, c, v, pi)
+        for i in range(3):
+            ec, ev, ep = oracle.symmetries(oracle.SYM_TAFL_EIGHT, c[i], v[i], pi[i])
+            assert np.array_equal(oc[i], ec) and np.array_equal(op[i], ep) and np.array_equal(ov[i], ev)

@@ -360,3 +360,43 @@ def test_gumbel_mcts_known_answers(oracle):
     # gumbel_full (interior pi'-matching) runs and keeps the root schedule
     f = _gumbel_mcts(oracle, 4, full=True, seed=5); f.set_gumbel_num_sims(13); f.search_dumb(gs, 13)
     assert sorted((int(c) for c in f.counts() if c > 0), reverse=True) == [5, 5, 1, 1]
+
+
+# ---------------------------------------------------------------- Brandubh / OpenTafl (opentafl_gs_test.cc, brandubh_gs_test.cc)
+def test_opentafl_rule_known_answers(oracle):
+    import tafl_cases as tc
+    for case in tc.OPENTAFL_CASES:
+        name, pieces, player, turn, move, exp = case
+        g = oracle.Game.tafl_from_board(oracle.GAME_OPENTAFL, tc.board(pieces), player, turn=turn, max_turns=400)
+        tc.check_case(g, case)
+    g = oracle.Game(oracle.GAME_OPENTAFL)       # StartingPosition, opentafl_gs_test.cc:295-312
+    c = g.canonical()
+    assert g.player() == 0 and c[0].sum() == 1 and c[1].sum() == 12 and c[2].sum() == 24 and c[0, 5, 5] == 1
+    assert c.shape == (8, 11, 11) and (c[7] == 0).all()
+    for m in tc.OPENTAFL_REPETITION:            # RepetitionCount, opentafl_gs_test.cc:10-78
+        g.play(m)
+    assert np.array_equal(g.scores(), [1, 0, 0])
+    assert np.allclose(g.canonical()[7], 8 / 400)
+
+
+def test_brandubh_known_answers(oracle):
+    import tafl_cases as tc
+    g = oracle.Game(oracle.GAME_BRANDUBH)
+    c = g.canonical()
+    assert c.shape == (7, 7, 7) and c[0, 3, 3] == 1 and c[1].sum() == 4 and c[2].sum() == 8
+    for m in tc.BRANDUBH_REPETITION:            # brandubh_gs_test.cc:10-55 (the test moves one piece back and forth
+        g.play(m)                               # for both sides: play_move does not check ownership)
+    assert np.array_equal(g.scores(), [1, 0, 0])
+    # rules shared with OpenTafl, on the 7x7 board: corner king-only, throne pass-through, king escapes to a corner
+    b = tc.board([(tc.A, 3, 1), (tc.K, 6, 5)], n=7)
+    g = oracle.Game.tafl_from_board(oracle.GAME_BRANDUBH, b, 0, turn=4, max_turns=150)
+    v = g.valid()
+    assert v[tc.mv(3, 1, False, 3, n=7)] == 0 and v[tc.mv(3, 1, False, 4, n=7)] == 1
+    g = oracle.Game.tafl_from_board(oracle.GAME_BRANDUBH, b, 1, turn=4, max_turns=150)
+    g.play(tc.mv(6, 5, False, 6, n=7))
+    assert np.array_equal(g.scores(), [0, 1, 0])
+    # Brandubh king is captured custodially (no 4-side rule): brandubh_gs.cc:309-340
+    b = tc.board([(tc.K, 2, 2), (tc.A, 2, 1), (tc.A, 2, 5)], n=7)
+    g = oracle.Game.tafl_from_board(oracle.GAME_BRANDUBH, b, 0, turn=4, max_turns=150)
+    g.play(tc.mv(2, 5, False, 3, n=7))
+    assert np.array_equal(g.scores(), [1, 0, 0])
