@@ -345,10 +345,11 @@ __device__ inline void wave_shard_find_account(const CacheView& c, uint64_t hash
 // (row strides np / nv floats) are the payload.  Launch: <<<ceil(n / 4), 256>>>, n <= kApplyMax.
 constexpr uint32_t kApplyMax = 8192;
 __device__ __forceinline__ void cache_apply_batch(const CacheView& c, const uint64_t* keys, const float* policy,
-                                                   const float* value, uint32_t n, uint32_t* s_sid) {
+                                                   const float* value, uint32_t n, uint32_t* s_sid,
+                                                   const uint8_t* groups = nullptr, uint32_t group = 0) {
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   for (uint32_t j = tid; j < n; j += blockDim.x) {
-    const uint64_t k = keys[j];
+    const uint64_t k = (groups && groups[j] != group) ? 0 : keys[j];   // elements of another model group are not ours
     s_sid[j] = k ? static_cast<uint32_t>(k % c.shards) : 0xFFFFFFFFu;
   }
   __syncthreads();

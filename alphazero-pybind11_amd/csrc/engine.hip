@@ -83,6 +83,9 @@ struct azmi_pm {
   hipStream_t pick(void* s) { last = (s == AZMI_STREAM_ENGINE) ? stream : static_cast<hipStream_t>(s); return last; }
   uint32_t hist_read = 0;
   uint32_t cache_shards = 0;
+  std::vector<CacheView> group_caches;   // host copies of the per-model-group cache views
+  bool all_random = false;               // every model group uses EvalType::RANDOM
+  std::vector<std::deque<uint32_t>> pending_g;   // host-buffer path: pending leaves per model group
   // hipGraph of kGraphRounds x (round kernels + net) for azmi_run_rounds: one graph launch instead of
   // ~5 kernel launches per round keeps the host ahead of the GPU
   hipGraphExec_t graph_exec = nullptr;
@@ -130,12 +133,14 @@ int launch_round(azmi_pm* pm, hipStream_t st) {
   switch (pm->game) {
     case AZMI_GAME_CONNECT4: {
       if (pm->ep.cache_on) {   // cache insert of last round's leaves + the restart/retire bookkeeping in one launch
-        for (uint32_t off = 0; off < pm->ep.S; off += kApplyMax) {
-          const uint32_t m = std::min<uint32_t>(kApplyMax, pm->ep.S - off);
-          const uint32_t nb = (m + 3) / 4;
-          k_cache_insert<Connect4><<<nb + (off == 0 ? 1u : 0u), 256, 0, st>>>(pm->ep, pm->ar, pm->ar.cache_keys, off, m,
-                                                                              off == 0 ? nb : 0xFFFFFFFFu, 1u);
-        }
+        for (uint32_t g = 0; g < pm->ep.num_groups; ++g)
+          for (uint32_t off = 0; off < pm->ep.S; off += kApplyMax) {
+            const uint32_t m = std::min<uint32_t>(kApplyMax, pm->ep.S - off);
+            const uint32_t nb = (m + 3) / 4;
+            const bool with_assign = g == 0 && off == 0;
+            k_cache_insert<Connect4><<<nb + (with_assign ? 1u : 0u), 256, 0, st>>>(pm->ep, pm->ar, pm->ar.cache_keys, off, m,
+                                                                                  with_assign ? nb : 0xFFFFFFFFu, 1u, g);
+          }
       }
       const uint32_t slots_per_block = threads / Connect4::GROUP;
       const uint32_t blocks = (pm->ep.S + slots_per_block - 1) / slots_per_block;
@@ -365,6 +370,67 @@ int azmi_game_info(int game, uint32_t* num_players, uint32_t* num_moves, uint32_
   return AZMI_OK;
 }
 
+namespace {
+// PlayManager ctor normalisation of model groups, seat permutations and the per-seat override matrices
+// (play_manager.cc:24-113): mcts_visits / eval_type are given per PLAYER, folded per model group (the last player
+// of a group wins), then expanded per (permutation, seat).
+struct SeatTables {
+  uint32_t num_groups = 1, num_perms = 1, max_visits = 0;
+  bool all_random = true, any_random = false;
+  std::vector<uint32_t> words;   // [perm][seat][kSeatWords]
+};
+int build_seat_tables(const azmi_play_params* p, uint32_t P, SeatTables* out) {
+  uint8_t groups[AZMI_MAX_PLAYERS];
+  if (p->num_model_groups_given == 0) for (uint32_t i = 0; i < P; ++i) groups[i] = static_cast<uint8_t>(i);
+  else {
+    if (p->num_model_groups_given != P) return fail(AZMI_ERR_INVALID, "model_groups must be empty or have one entry per player");
+    for (uint32_t i = 0; i < P; ++i) groups[i] = p->model_groups[i];
+  }
+  uint32_t ng = 0;
+  for (uint32_t i = 0; i < P; ++i) ng = std::max<uint32_t>(ng, groups[i] + 1u);
+  if (ng > AZMI_MAX_GROUPS) return fail(AZMI_ERR_INVALID, "at most %d model groups", AZMI_MAX_GROUPS);
+  uint32_t visits_g[AZMI_MAX_GROUPS] = {0, 0, 0, 0};
+  int32_t eval_g[AZMI_MAX_GROUPS] = {AZMI_EVAL_NN, AZMI_EVAL_NN, AZMI_EVAL_NN, AZMI_EVAL_NN};
+  for (uint32_t i = 0; i < P; ++i) {
+    visits_g[groups[i]] = p->mcts_visits[i];
+    if (p->num_eval_type) eval_g[groups[i]] = p->eval_type[i];
+  }
+  uint32_t np = p->num_seat_perms;
+  uint8_t perms[AZMI_MAX_PERMS][AZMI_MAX_PLAYERS];
+  if (np == 0) { np = 1; for (uint32_t s = 0; s < P; ++s) perms[0][s] = groups[s]; }
+  else {
+    if (np > AZMI_MAX_PERMS) return fail(AZMI_ERR_INVALID, "at most %d seat permutations", AZMI_MAX_PERMS);
+    for (uint32_t q = 0; q < np; ++q)
+      for (uint32_t s = 0; s < P; ++s) {
+        if (p->seat_perms[q][s] >= ng) return fail(AZMI_ERR_INVALID, "seat_perms refers to model group %u but there are %u", unsigned(p->seat_perms[q][s]), ng);
+        perms[q][s] = p->seat_perms[q][s];
+      }
+  }
+  out->num_groups = ng; out->num_perms = np;
+  out->words.assign(static_cast<size_t>(np) * P * kSeatWords, 0u);
+  out->max_visits = p->playout_cap_randomization ? p->playout_cap_depth : 0;
+  for (uint32_t q = 0; q < np; ++q)
+    for (uint32_t s = 0; s < P; ++s) {
+      const uint32_t g = perms[q][s];
+      const uint32_t visits = p->has_seat_visits ? p->seat_visits[q][s] : visits_g[g];
+      const uint32_t capv = p->has_seat_cap_visits ? p->seat_cap_visits[q][s] : p->playout_cap_depth;
+      const float eps = p->has_seat_epsilon ? p->seat_epsilon[q][s] : p->epsilon;
+      const float rt = p->has_seat_mcts_root_temp ? p->seat_mcts_root_temp[q][s] : p->mcts_root_temp;
+      const uint32_t fz = p->has_seat_root_fpu_zero ? (p->seat_root_fpu_zero[q][s] != 0) : (p->root_fpu_zero != 0);
+      const bool rnd = eval_g[g] == AZMI_EVAL_RANDOM;
+      if (eval_g[g] == AZMI_EVAL_PLAYOUT) return fail(AZMI_ERR_INVALID, "EvalType::PLAYOUT is not implemented on the device");
+      if (capv > 0xFFFFFFu) return fail(AZMI_ERR_INVALID, "seat_cap_visits too large");
+      out->all_random = out->all_random && rnd; out->any_random = out->any_random || rnd;
+      out->max_visits = std::max(out->max_visits, visits);
+      if (p->playout_cap_randomization) out->max_visits = std::max(out->max_visits, capv);
+      uint32_t* w = &out->words[(static_cast<size_t>(q) * P + s) * kSeatWords];
+      w[0] = visits; w[1] = seat_w1_pack(capv, fz, rnd ? 1u : 0u, g);
+      std::memcpy(&w[2], &eps, 4); std::memcpy(&w[3], &rt, 4);
+    }
+  return AZMI_OK;
+}
+}  // namespace
+
 int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_opts* opts_in, azmi_pm** out) {
   if (!params || !out) return fail(AZMI_ERR_INVALID, "null argument");
   GameInfo gi;
@@ -376,8 +442,8 @@ int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_o
   if (params->concurrent_games == 0) return fail(AZMI_ERR_INVALID, "concurrent_games must be > 0");
   if (params->num_eval_type != 0 && params->num_eval_type != gi.P)
     return fail(AZMI_ERR_INVALID, "eval_type must be empty or have one entry per player");
-  for (uint32_t i = 0; i < params->num_eval_type; ++i)
-    if (params->eval_type[i] == AZMI_EVAL_PLAYOUT) return fail(AZMI_ERR_INVALID, "EvalType::PLAYOUT is not implemented on the device");
+  SeatTables seats;
+  { const int rc_seats = build_seat_tables(params, gi.P, &seats); if (rc_seats != AZMI_OK) return rc_seats; }
   if (params->resign_percent > 0 && gi.P != 2) return fail(AZMI_ERR_INVALID, "Resigning only works in 2 player games");
   if (params->gumbel_enabled && params->gumbel_m > kGumMaxM)
     return fail(AZMI_ERR_INVALID, "gumbel_m %u exceeds the engine limit %u", params->gumbel_m, kGumMaxM);
@@ -392,9 +458,11 @@ int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_o
   EngineParams& ep = pm->ep;
   ep.S = params->concurrent_games;
   ep.games_to_play = params->games_to_play;
-  uint32_t max_visits = params->playout_cap_randomization ? params->playout_cap_depth : 0;
-  for (uint32_t i = 0; i < gi.P; ++i) { ep.visits[i] = params->mcts_visits[i]; max_visits = std::max(max_visits, ep.visits[i]); }
+  const uint32_t max_visits = seats.max_visits;
+  for (uint32_t i = 0; i < gi.P; ++i) ep.visits[i] = params->mcts_visits[i];   // kept for reference; kernels read ar.seat_tab
   ep.cap_visits = params->playout_cap_depth;
+  ep.num_perms = seats.num_perms; ep.num_groups = seats.num_groups;
+  pm->all_random = seats.all_random;
   ep.cpuct = params->cpuct; ep.start_temp = params->start_temp; ep.final_temp = params->final_temp;
   ep.half_life = params->temp_decay_half_life;
   ep.epsilon = params->epsilon; ep.root_temp = params->mcts_root_temp; ep.fpu_reduction = params->fpu_reduction;
@@ -403,8 +471,7 @@ int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_o
   ep.history = params->history_enabled != 0; ep.tree_reuse = params->tree_reuse != 0;
   ep.cap_rand = params->playout_cap_randomization != 0; ep.root_fpu_zero = params->root_fpu_zero != 0;
   ep.shaped = params->shaped_dirichlet != 0; ep.pruning = params->policy_target_pruning != 0;
-  for (uint32_t i = 0; i < gi.P; ++i)
-    ep.eval_random[i] = params->num_eval_type ? (params->eval_type[i] == AZMI_EVAL_RANDOM) : 0;
+  for (uint32_t i = 0; i < gi.P; ++i) ep.eval_random[i] = 0;
   ep.gumbel_on = params->gumbel_enabled != 0;
   ep.gumbel_m = params->gumbel_m; ep.gumbel_full = params->gumbel_full != 0;
   ep.fast_gumbel = params->fast_search_uses_gumbel != 0;
@@ -445,7 +512,12 @@ int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_o
 #define A(field, count, zero) if (rc == AZMI_OK) rc = pm->alloc(ar.field, (count), (zero))
   A(ctl, 1, true);
   A(ended_list, S, true);
-  A(eval_list, S, true);
+  A(eval_list, static_cast<size_t>(S) * ep.num_groups, true);
+  A(seat_tab, seats.words.size(), false);
+  A(perm, S, true);
+  A(leaf_group, S, true);
+  A(a_perm_scores, static_cast<size_t>(S) * ep.num_perms * (P + 1), true);
+  A(a_perm_games, static_cast<size_t>(S) * ep.num_perms, true);
   A(gs_words, static_cast<size_t>(gi.state_words) * S, true);
   A(rng, S, true); A(coin, S, true);
   A(sstate, S, true); A(flags, S, true);
@@ -481,12 +553,22 @@ int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_o
   ep.cache_on = params->max_cache_size > 0;
   if (ep.cache_on) {
     // wave-resident shards: 64 entries each (dev_cache.h); max_cache_size is rounded down to a multiple of 64
-    const uint32_t shards = std::max<uint32_t>(1, params->max_cache_size / kWaveCap);
+    // one cache per model group, max_cache_size / num_model_groups entries each (play_manager.cc:195-203)
+    const uint32_t shards = std::max<uint32_t>(1, params->max_cache_size / ep.num_groups / kWaveCap);
     pm->cache_shards = shards;
     A(cache_keys, S, true);
-    if (rc != AZMI_OK || cache_alloc(ar.cache, pm->allocs, shards * kWaveCap, shards, static_cast<uint32_t>(static_cast<uint64_t>(shards) * kWaveCap * 9 / 10), M, P + 1) != hipSuccess) {
-      delete pm;
-      return fail(AZMI_ERR_OOM, "position cache allocation failed");
+    pm->group_caches.resize(ep.num_groups);
+    for (uint32_t g = 0; g < ep.num_groups && rc == AZMI_OK; ++g)
+      if (cache_alloc(pm->group_caches[g], pm->allocs, shards * kWaveCap, shards, static_cast<uint32_t>(static_cast<uint64_t>(shards) * kWaveCap * 9 / 10), M, P + 1) != hipSuccess) {
+        delete pm;
+        return fail(AZMI_ERR_OOM, "position cache allocation failed");
+      }
+    if (rc == AZMI_OK) {
+      ar.cache = pm->group_caches[0];
+      CacheView* dev_views = nullptr;
+      rc = pm->alloc(dev_views, ep.num_groups, false);
+      if (rc == AZMI_OK && hipMemcpy(dev_views, pm->group_caches.data(), sizeof(CacheView) * ep.num_groups, hipMemcpyHostToDevice) != hipSuccess) rc = AZMI_ERR_NO_DEVICE;
+      ar.caches = dev_views;
     }
   }
   ep.trace_slot = getenv("AZMI_TRACE_SLOT") ? static_cast<uint32_t>(atoi(getenv("AZMI_TRACE_SLOT"))) : 0xFFFFFFFFu;
@@ -509,6 +591,13 @@ int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_o
   c.games_started = S;  // play_manager.cc:15
   c.live_slots = S;
   if (hipMemcpy(ar.ctl, &c, sizeof(c), hipMemcpyHostToDevice) != hipSuccess) { delete pm; return fail(AZMI_ERR_NO_DEVICE, "ctl init failed"); }
+  if (hipMemcpy(ar.seat_tab, seats.words.data(), seats.words.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { delete pm; return fail(AZMI_ERR_NO_DEVICE, "seat table upload failed"); }
+  {
+    std::vector<uint32_t> perm0(S);
+    for (uint32_t i = 0; i < S; ++i) perm0[i] = i % ep.num_perms;   // gd.perm_index = i % seat_perms_.size(), play_manager.cc:218
+    if (hipMemcpy(ar.perm, perm0.data(), S * 4, hipMemcpyHostToDevice) != hipSuccess) { delete pm; return fail(AZMI_ERR_NO_DEVICE, "perm init failed"); }
+  }
+  pm->pending_g.resize(ep.num_groups);
   k_seed<<<(S + 255) / 256, 256, 0, pm->stream>>>(ar, S, opts.seed);
   if (hipStreamSynchronize(pm->stream) != hipSuccess) { delete pm; return fail(AZMI_ERR_NO_DEVICE, "seed kernel failed"); }
   pm->host_v.assign(static_cast<size_t>(S) * (P + 1), 0.0f);
@@ -533,10 +622,11 @@ int azmi_pm_round(azmi_pm* pm, void* stream) {
 namespace {
 constexpr uint32_t kGraphRounds = 16;
 // the net on this engine's leaf batch: only the rows k_round listed (Connect4 engine), else the whole batch
-int pm_net_forward(azmi_pm* pm, azmi_net* net, hipStream_t st) {
+int pm_net_forward(azmi_pm* pm, uint32_t group, azmi_net* net, hipStream_t st) {
   int rc;
-  if (pm->game == AZMI_GAME_CONNECT4)
-    rc = azmi_net_forward_rows(net, pm->ar.canon, pm->ar.v, pm->ar.pi, pm->ar.eval_list, &pm->ar.ctl->eval_count, pm->ep.S, st);
+  if (pm->game == AZMI_GAME_CONNECT4 || pm->ep.num_groups > 1)
+    rc = azmi_net_forward_rows(net, pm->ar.canon, pm->ar.v, pm->ar.pi, pm->ar.eval_list + static_cast<size_t>(group) * pm->ep.S,
+                               &pm->ar.ctl->eval_count[group], pm->ep.S, st);
   else
     rc = azmi_net_forward(net, pm->ar.canon, pm->ar.v, pm->ar.pi, pm->ep.S, st);
   if (rc != AZMI_OK) return fail(rc, "%s", azmi_net_last_error());
@@ -545,7 +635,8 @@ int pm_net_forward(azmi_pm* pm, azmi_net* net, hipStream_t st) {
 int one_round_with_net(azmi_pm* pm, azmi_net* net, hipStream_t st) {
   int rc = launch_round(pm, st);
   if (rc != AZMI_OK) return rc;
-  return pm_net_forward(pm, net, st);
+  if (pm->ep.num_groups != 1) return fail(AZMI_ERR_STATE, "this engine has %u model groups: evaluate each with azmi_pm_net_forward_group", pm->ep.num_groups);
+  return pm_net_forward(pm, 0, net, st);
 }
 int ensure_graph(azmi_pm* pm, azmi_net* net, hipStream_t st) {
   if (pm->graph_exec && pm->graph_stream == st && pm->graph_net == net) return AZMI_OK;
@@ -588,7 +679,36 @@ int azmi_run_rounds(azmi_pm* const* pms, azmi_net* net, uint32_t k, uint32_t rou
 
 int azmi_pm_net_forward(azmi_pm* pm, azmi_net* net, void* stream) {
   if (!pm || !net) return fail(AZMI_ERR_INVALID, "null argument");
-  return pm_net_forward(pm, net, pm->pick(stream));
+  if (pm->ep.num_groups != 1) return fail(AZMI_ERR_STATE, "this engine has %u model groups: use azmi_pm_net_forward_group", pm->ep.num_groups);
+  return pm_net_forward(pm, 0, net, pm->pick(stream));
+}
+
+int azmi_pm_net_forward_group(azmi_pm* pm, uint32_t group, azmi_net* net, void* stream) {
+  if (!pm || !net) return fail(AZMI_ERR_INVALID, "null argument");
+  if (group >= pm->ep.num_groups) return fail(AZMI_ERR_INVALID, "model group %u out of range", group);
+  return pm_net_forward(pm, group, net, pm->pick(stream));
+}
+
+int azmi_pm_groups(azmi_pm* pm, uint32_t* num_model_groups, uint32_t* num_seat_perms) {
+  if (!pm) return fail(AZMI_ERR_INVALID, "null pm");
+  if (num_model_groups) *num_model_groups = pm->ep.num_groups;
+  if (num_seat_perms) *num_seat_perms = pm->ep.num_perms;
+  return AZMI_OK;
+}
+
+int azmi_pm_perm_scores(azmi_pm* pm, uint32_t perm, float* out_scores, uint32_t* games_completed) {
+  if (!pm) return fail(AZMI_ERR_INVALID, "null pm");
+  if (perm >= pm->ep.num_perms) return fail(AZMI_ERR_INVALID, "seat permutation %u out of range", perm);
+  const uint32_t S = pm->ep.S, V = pm->gi.P + 1, NP = pm->ep.num_perms;
+  std::vector<float> a; std::vector<uint32_t> g;
+  int rc = d2h(a, pm->ar.a_perm_scores, static_cast<size_t>(S) * NP * V, pm->last); if (rc) return rc;
+  rc = d2h(g, pm->ar.a_perm_games, static_cast<size_t>(S) * NP, pm->last); if (rc) return rc;
+  if (out_scores) {
+    for (uint32_t i = 0; i < V; ++i) out_scores[i] = 0.0f;
+    for (uint32_t s = 0; s < S; ++s) for (uint32_t i = 0; i < V; ++i) out_scores[i] += a[(static_cast<size_t>(s) * NP + perm) * V + i];
+  }
+  if (games_completed) { uint32_t n = 0; for (uint32_t s = 0; s < S; ++s) n += g[static_cast<size_t>(s) * NP + perm]; *games_completed = n; }
+  return AZMI_OK;
 }
 
 int azmi_pm_io_buffers(azmi_pm* pm, float** dev_canonical, float** dev_v, float** dev_pi) {
@@ -611,8 +731,7 @@ int azmi_pm_poll(azmi_pm* pm, void* stream, uint32_t* games_completed, uint32_t*
 
 int azmi_pm_play(azmi_pm* pm, void* stream) {
   if (!pm) return fail(AZMI_ERR_INVALID, "null pm");
-  for (uint32_t i = 0; i < pm->gi.P; ++i)
-    if (!pm->ep.eval_random[i]) return fail(AZMI_ERR_STATE, "azmi_pm_play needs EvalType::RANDOM on every seat; drive NN seats with azmi_pm_round");
+  if (!pm->all_random) return fail(AZMI_ERR_STATE, "azmi_pm_play needs EvalType::RANDOM on every seat; drive NN seats with azmi_pm_round");
   hipStream_t st = pm->pick(stream);
   for (;;) {
     for (int r = 0; r < 32; ++r) {
@@ -756,29 +875,44 @@ int azmi_pm_slot_games(azmi_pm* pm, uint32_t* out) {
 
 // ---- host-buffer compatibility path ------------------------------------------------------------------
 int azmi_pm_build_batch(azmi_pm* pm, float* batch, uint32_t cap, uint32_t* indices, uint32_t* n) {
+  return azmi_pm_build_batch_group(pm, 0xFFFFFFFFu, batch, cap, indices, n);
+}
+
+// group == 0xFFFFFFFF: leaves of any model group (single-evaluator callers)
+int azmi_pm_build_batch_group(azmi_pm* pm, uint32_t group, float* batch, uint32_t cap, uint32_t* indices, uint32_t* n) {
   if (!pm || !batch || !indices || !n) return fail(AZMI_ERR_INVALID, "null argument");
   *n = 0;
   if (cap == 0) return AZMI_OK;
+  if (group != 0xFFFFFFFFu && group >= pm->ep.num_groups) return fail(AZMI_ERR_INVALID, "model group %u out of range", group);
   const uint32_t S = pm->ep.S, CANON = pm->gi.C * pm->gi.H * pm->gi.W;
   hipStream_t st = pm->pick(AZMI_STREAM_ENGINE);
   int guard = 0;
-  while (pm->pending.empty()) {
+  auto any_pending = [&]() { for (auto& q : pm->pending_g) if (!q.empty()) return true; return false; };
+  auto mine = [&]() -> std::deque<uint32_t>* {
+    if (group != 0xFFFFFFFFu) return pm->pending_g[group].empty() ? nullptr : &pm->pending_g[group];
+    for (auto& q : pm->pending_g) if (!q.empty()) return &q;
+    return nullptr;
+  };
+  while (!any_pending()) {
     if (pm->outstanding != 0) return AZMI_OK;  // rows handed out, answers not back yet
     Control c;
     int rc = read_ctl(pm, st, &c, true); if (rc) return rc;
     if (c.stop) return AZMI_OK;
     rc = launch_round(pm, st); if (rc) return rc;
-    std::vector<uint8_t> ss, fl;
+    std::vector<uint8_t> ss, fl, lg;
     rc = d2h(ss, pm->ar.sstate, S, st); if (rc) return rc;
     rc = d2h(fl, pm->ar.flags, S, st); if (rc) return rc;
+    rc = d2h(lg, pm->ar.leaf_group, S, st); if (rc) return rc;
     for (uint32_t s = 0; s < S; ++s)
-      if (ss[s] == kSlotWaitEval && (fl[s] & kFlagLeafNeedsNet)) pm->pending.push_back(s);
+      if (ss[s] == kSlotWaitEval && (fl[s] & kFlagLeafNeedsNet)) pm->pending_g[lg[s] < pm->ep.num_groups ? lg[s] : 0].push_back(s);
     if (++guard > (1 << 20)) return fail(AZMI_ERR_STATE, "build_batch made no progress");
   }
-  const uint32_t take = std::min<uint32_t>(cap, static_cast<uint32_t>(pm->pending.size()));
+  std::deque<uint32_t>* q = mine();
+  if (!q) return AZMI_OK;   // other groups have pending leaves, this one has none right now
+  const uint32_t take = std::min<uint32_t>(cap, static_cast<uint32_t>(q->size()));
   for (uint32_t r = 0; r < take; ++r) {
-    const uint32_t s = pm->pending.front();
-    pm->pending.pop_front();
+    const uint32_t s = q->front();
+    q->pop_front();
     indices[r] = s;
     HIP_TRY(hipMemcpyAsync(batch + static_cast<size_t>(r) * CANON, pm->ar.canon + static_cast<size_t>(s) * CANON,
                            CANON * 4, hipMemcpyDeviceToHost, st));
@@ -799,7 +933,9 @@ int azmi_pm_update_inferences(azmi_pm* pm, const uint32_t* indices, uint32_t n, 
     std::memcpy(&pm->host_pi[static_cast<size_t>(indices[r]) * M], pi + static_cast<size_t>(r) * M, M * 4);
   }
   pm->outstanding -= n;
-  if (pm->outstanding == 0 && pm->pending.empty()) {
+  bool any_left = false;
+  for (auto& q : pm->pending_g) any_left = any_left || !q.empty();
+  if (pm->outstanding == 0 && !any_left) {
     HIP_TRY(hipMemcpyAsync(pm->ar.v, pm->host_v.data(), pm->host_v.size() * 4, hipMemcpyHostToDevice, pm->stream));
     HIP_TRY(hipMemcpyAsync(pm->ar.pi, pm->host_pi.data(), pm->host_pi.size() * 4, hipMemcpyHostToDevice, pm->stream));
     HIP_TRY(hipStreamSynchronize(pm->stream));

@@ -73,6 +73,7 @@ __device__ __forceinline__ uint32_t gum_plan(uint32_t m, uint32_t n, uint32_t wa
   return count;
 }
 
+#define AZMI_SEL(arr, seat) ((seat) == 0 ? arr[0] : arr[P > 1 ? 1 : 0])
 template <class GM>
 struct SlotCtx {
   static constexpr int G = GM::GROUP;
@@ -93,6 +94,17 @@ struct SlotCtx {
   uint64_t t_tld[P];
   uint32_t cur, plen;  // MCTS::current_, MCTS::path_.size() of the pending simulation
   uint32_t ph_rows;    // GameData::partial_history.size()
+  // per-seat search settings of this game's seat permutation (seat_visits_, seat_cap_visits_, seat_epsilon_,
+  // seat_mcts_root_temp_, seat_root_fpu_zero_, seat_perm -> model group / eval type; play_manager.cc:57-113)
+  uint32_t perm, sv_w0[P], sv_w1[P];
+  float sv_eps[P], sv_rt[P];
+  __device__ __forceinline__ uint32_t seat_visits(uint32_t seat) const { return AZMI_SEL(sv_w0, seat); }
+  __device__ __forceinline__ uint32_t seat_cap_visits(uint32_t seat) const { return AZMI_SEL(sv_w1, seat) & 0xFFFFFFu; }
+  __device__ __forceinline__ bool seat_fpu_zero(uint32_t seat) const { return (AZMI_SEL(sv_w1, seat) >> 24) & 1u; }
+  __device__ __forceinline__ bool seat_eval_random(uint32_t seat) const { return (AZMI_SEL(sv_w1, seat) >> 25) & 1u; }
+  __device__ __forceinline__ uint32_t seat_group(uint32_t seat) const { return (AZMI_SEL(sv_w1, seat) >> 26) & 3u; }
+  __device__ __forceinline__ float seat_eps(uint32_t seat) const { return AZMI_SEL(sv_eps, seat); }
+  __device__ __forceinline__ float seat_root_temp(uint32_t seat) const { return AZMI_SEL(sv_rt, seat); }
 
   __device__ __forceinline__ SlotCtx(const EngineParams& e, const EngineArrays& a, uint32_t s, uint32_t l)
       : ep(e), ar(a), slot(s), lane(l) {}
@@ -121,7 +133,6 @@ struct SlotCtx {
     const uint64_t n = ar.trace[0];
     if (n + 1 < ep.trace_cap) { ar.trace[2 * (n + 1)] = tag; ar.trace[2 * (n + 1) + 1] = rng.state; ar.trace[0] = n + 1; }
   }
-#define AZMI_SEL(arr, seat) ((seat) == 0 ? arr[0] : arr[P > 1 ? 1 : 0])
 
   // ---- state load / store ----------------------------------------------------------
   __device__ __forceinline__ void load() {
@@ -138,6 +149,12 @@ struct SlotCtx {
       t_root[p] = ar.root[t]; t_bump[p] = ar.bump[t]; t_depth[p] = ar.depth[t]; t_tld[p] = ar.tld[t];
     }
     cur = ar.cur[slot]; plen = ar.plen[slot]; ph_rows = ar.ph_count[slot];
+    perm = ar.perm[slot];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const uint32_t* rec = ar.seat_tab + (static_cast<size_t>(perm) * P + p) * kSeatWords;
+      sv_w0[p] = rec[0]; sv_w1[p] = rec[1]; sv_eps[p] = __uint_as_float(rec[2]); sv_rt[p] = __uint_as_float(rec[3]);
+    }
   }
   __device__ __forceinline__ void store(uint8_t sstate) const {
     if (lane != 0) return;
@@ -187,7 +204,7 @@ struct SlotCtx {
   __device__ __forceinline__ void set_gumbel_target() const {
     if (!ep.gumbel_on) return;
     const uint32_t cp = gs.player;
-    const uint32_t target = (flags & kFlagCapped) ? (ep.fast_gumbel ? ep.cap_visits : 0u) : seat_param(ep.visits, cp);
+    const uint32_t target = (flags & kFlagCapped) ? (ep.fast_gumbel ? seat_cap_visits(cp) : 0u) : seat_visits(cp);
     set_gumbel_num_sims(cp, target);
   }
   __device__ __forceinline__ float gumbel01() {  // extreme_value_distribution<float>{0,1}, random.tcc:2581-2590
@@ -438,7 +455,7 @@ struct SlotCtx {
       const size_t ci = tb + c0 + lane;
       uint32_t n_l = 0; float q_l = 0.0f, p_l = 0.0f; uint64_t m_l = 0;
       if (lane < k) { n_l = ar.N[ci]; q_l = ar.Q[ci]; p_l = ar.Pr[ci]; m_l = ar.META[ci]; }
-      const float fpu = (cur == root && ep.root_fpu_zero) ? 0.0f : ep.fpu_reduction;
+      const float fpu = (cur == root && seat_fpu_zero(seat)) ? 0.0f : ep.fpu_reduction;
       const float v_parent = ar.V[tb + cur];
       uint32_t best;
       if (gum_active && cur == root) best = gumbel_next_root_child(seat, k, n_l, q_l, p_l);
@@ -462,7 +479,7 @@ struct SlotCtx {
   }
 
   // ---- MCTS::add_root_noise: children in lanes [0,k), priors p_l -----------------------------
-  __device__ __forceinline__ float add_root_noise(uint32_t k, float p_l) {
+  __device__ __forceinline__ float add_root_noise(uint32_t k, float p_l, float eps) {
     float noise_l = 0.0f;
     double sum = 0.0;
     if (ep.shaped && k > 1) {
@@ -490,7 +507,7 @@ struct SlotCtx {
         sum += g;
       }
     }
-    return p_l * (1 - ep.epsilon) + ep.epsilon * noise_l / static_cast<float>(sum);
+    return p_l * (1 - eps) + eps * noise_l / static_cast<float>(sum);
   }
 
   // ---- MCTS::process_result -------------------------------------------------------------------
@@ -520,10 +537,11 @@ struct SlotCtx {
         if (lane < k) p = (ksum == 0.0f) ? 0.0f : 1.0f / ksum;
       }
       const bool is_root = cur == root;
-      if (is_root && ep.root_temp != 1.0f && lane < k) p = az_powf(p, 1.0f / ep.root_temp);
+      const float root_temp = seat_root_temp(seat);
+      if (is_root && root_temp != 1.0f && lane < k) p = az_powf(p, 1.0f / root_temp);
       const float sum = seqsum(lane < k ? p : 0.0f, k);
       p = p / sum;
-      if (is_root && root_noise && !ep.gumbel_on) { trace(1 | (static_cast<uint64_t>(k) << 8)); p = add_root_noise(k, p); trace(2); }
+      if (is_root && root_noise && !ep.gumbel_on) { trace(1 | (static_cast<uint64_t>(k) << 8)); p = add_root_noise(k, p, seat_eps(seat)); trace(2); }
       if (lane < k) ar.Pr[ci] = p;
     }
     // backup: level i updates node_i (child of path[i]); levels are independent -> one lane each
@@ -688,13 +706,14 @@ struct SlotCtx {
     const size_t ci = tb + c0 + lane;
     float p = lane < k ? ar.Pr[ci] : 0.0f;
     bool dirty = false;
-    if (ep.root_temp != 1.0f) {
-      if (lane < k) p = az_powf(p, 1.0f / ep.root_temp);
+    const float root_temp = seat_root_temp(seat);
+    if (root_temp != 1.0f) {
+      if (lane < k) p = az_powf(p, 1.0f / root_temp);
       const float sum = seqsum(lane < k ? p : 0.0f, k);
       if (sum > 0.0f) p = p / sum;
       dirty = true;
     }
-    if (noise && k > 0) { trace(3 | (static_cast<uint64_t>(k) << 8)); p = add_root_noise(k, p); trace(4); dirty = true; }
+    if (noise && k > 0) { trace(3 | (static_cast<uint64_t>(k) << 8)); p = add_root_noise(k, p, seat_eps(seat)); trace(4); dirty = true; }
     if (dirty && lane < k) ar.Pr[ci] = p;
   }
 
@@ -777,7 +796,7 @@ struct SlotCtx {
     // history sample, play_manager.cc:407-424
     if (ep.history && !capped) {
       const float target = ep.gumbel_on ? gumbel_improved_policy(k, mv_l, n_l, q_l, p_l, ar.V[tb + root])  // play_manager.cc:411-417
-                           : (ep.pruning && ep.epsilon > 0)
+                           : (ep.pruning && seat_eps(cp) > 0)
                                ? probs_pruned(1.0f, root_n, k, mv_l, n_l, q_l, p_l, cnt_m, pol_m)
                                : probs(1.0f, cnt_m, pol_m);
       const uint32_t r = ph_rows;
@@ -834,7 +853,7 @@ struct SlotCtx {
     if (!ep.tree_reuse) {
       for (uint32_t s = 0; s < static_cast<uint32_t>(P); ++s) reset_tree(s);
     } else {
-      reapply_root_prior(gs.player, ep.epsilon > 0 && !(flags & kFlagCapped));
+      reapply_root_prior(gs.player, seat_eps(gs.player) > 0 && !(flags & kFlagCapped));
     }
     return false;
   }
@@ -870,6 +889,8 @@ struct SlotCtx {
     if (lane == 0) {
       ar.a_scores[static_cast<size_t>(slot) * (P + 1) + (term - 1)] += 1.0f;
       if (resigned) ar.a_resign[static_cast<size_t>(slot) * (P + 1) + (term - 1)] += 1.0f;
+      ar.a_perm_scores[(static_cast<size_t>(slot) * ep.num_perms + perm) * (P + 1) + (term - 1)] += 1.0f;   // play_manager.cc:466-467
+      ar.a_perm_games[static_cast<size_t>(slot) * ep.num_perms + perm] += 1;
       ar.a_len[slot] += gs.turn;
       for (int j = 0; j < 5; ++j) { ar.a_dsum[j * S + slot] += ar.g_dsum[j * S + slot]; ar.g_dsum[j * S + slot] = 0.0; }
       for (int j = 0; j < 3; ++j) { ar.a_cnt[j * S + slot] += ar.g_cnt[j * S + slot]; ar.g_cnt[j * S + slot] = 0; }
@@ -888,22 +909,23 @@ struct SlotCtx {
     return key;
   }
   // position-cache probe (play_manager.cc:592-597): on a hit the cached (pi, v) land in the slot's rows
-  __device__ __forceinline__ bool cache_lookup(uint64_t key) const {
+  __device__ __forceinline__ bool cache_lookup(uint64_t key, uint32_t group) const {
     uint32_t sh;
-    const int cslot = wave_shard_find<G>(ar.cache, key, lane, &sh);
+    const CacheView cache = ep.num_groups == 1 ? ar.cache : ar.caches[group];   // one cache per model group
+    const int cslot = wave_shard_find<G>(cache, key, lane, &sh);
     if (lane == 0) {  // hits / misses / freq; the ghost "reinserts" statistic is not kept for in-round probes
-      unsigned long long* st = ar.cache.stats + static_cast<size_t>(sh) * 4;
+      unsigned long long* st = cache.stats + static_cast<size_t>(sh) * 4;
       if (cslot < 0) {
         atomicAdd(&st[1], 1ULL);
       } else {
         atomicAdd(&st[0], 1ULL);
-        uint32_t* f = ar.cache.freq + static_cast<size_t>(sh) * kWaveCap + cslot;
+        uint32_t* f = cache.freq + static_cast<size_t>(sh) * kWaveCap + cslot;
         if (atomicAdd(f, 1u) >= 3u) atomicSub(f, 1u);
       }
     }
     if (cslot < 0) return false;
-    const float* sp = ar.cache.policy + (static_cast<size_t>(sh) * ar.cache.cap + cslot) * M;
-    const float* sv = ar.cache.value + (static_cast<size_t>(sh) * ar.cache.cap + cslot) * (P + 1);
+    const float* sp = cache.policy + (static_cast<size_t>(sh) * cache.cap + cslot) * M;
+    const float* sv = cache.value + (static_cast<size_t>(sh) * cache.cap + cslot) * (P + 1);
     for (uint32_t e = lane; e < static_cast<uint32_t>(M); e += G) ar.pi[static_cast<size_t>(slot) * M + e] = sp[e];
     if (lane <= static_cast<uint32_t>(P)) ar.v[static_cast<size_t>(slot) * (P + 1) + lane] = sv[lane];
     return true;
@@ -938,9 +960,9 @@ __global__ __launch_bounds__(256, 1) void k_round(EngineParams ep, EngineArrays 
   for (;;) {
     if (need_process) {
       const uint32_t cp = c.gs.player;
-      const bool noise = ep.epsilon > 0 && !(c.flags & kFlagCapped);
+      const bool noise = c.seat_eps(cp) > 0 && !(c.flags & kFlagCapped);
       c.process_result(cp, (c.flags & kFlagLeafNeedsNet) != 0, noise);
-      const uint32_t goal = (c.flags & kFlagCapped) ? ep.cap_visits : seat_param(ep.visits, cp);
+      const uint32_t goal = (c.flags & kFlagCapped) ? c.seat_cap_visits(cp) : c.seat_visits(cp);
       if (AZMI_SEL(c.t_depth, cp) >= goal) {
         if (c.make_move(cp)) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; c.store(kSlotEnded); return; }
       }
@@ -949,16 +971,18 @@ __global__ __launch_bounds__(256, 1) void k_round(EngineParams ep, EngineArrays 
     typename GM::State leaf;
     uint32_t term = 0;
     if (!c.find_leaf(cp, leaf, term)) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; c.store(kSlotDone); return; }
-    const bool needs_net = term == 0 && !seat_param(ep.eval_random, cp);
+    const bool needs_net = term == 0 && !c.seat_eval_random(cp);
+    const uint32_t group = c.seat_group(cp);
     c.flags = needs_net ? (c.flags | kFlagLeafNeedsNet) : (c.flags & ~kFlagLeafNeedsNet);
     if (needs_net) {
       const uint64_t key = c.emit_leaf(leaf);
-      const bool hit = ep.cache_on && c.cache_lookup(key);
+      const bool hit = ep.cache_on && c.cache_lookup(key, group);
       if (!hit) {
         if (lane == 0) {
           ar.c_evals[slot] += 1;
           if (ep.cache_on) ar.cache_keys[slot] = cache_key(key);
-          ar.eval_list[atomicAdd(&ar.ctl->eval_count, 1u)] = slot;
+          ar.leaf_group[slot] = static_cast<uint8_t>(group);
+          ar.eval_list[static_cast<size_t>(group) * ep.S + atomicAdd(&ar.ctl->eval_count[group], 1u)] = slot;
         }
         insert_key_set = 1;
         break;
@@ -979,13 +1003,17 @@ __device__ __forceinline__ void assign_body(const EngineParams& ep, const Engine
   if (threadIdx.x == 0) { s_n = ctl->ended_count; s_base = ctl->games_started; }
   __syncthreads();
   const uint32_t n = s_n, base = s_base;
-  if (threadIdx.x == 0 && count_round) { ctl->rounds += 1; ctl->eval_count = 0; }
+  if (threadIdx.x == 0 && count_round) {
+    ctl->rounds += 1;
+    ctl->eval_count[0] = 0; ctl->eval_count[1] = 0; ctl->eval_count[2] = 0; ctl->eval_count[3] = 0;
+  }
   if (n == 0) return;
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     const uint32_t s = ar.ended_list[i];
     uint32_t rank = 0;
     for (uint32_t j = 0; j < n; ++j) rank += (ar.ended_list[j] < s) ? 1u : 0u;
     ar.sstate[s] = (base + rank < ep.games_to_play) ? kSlotRestart : kSlotDone;
+    ar.perm[s] = (base + rank) % ep.num_perms;   // game.perm_index = games_started_ % seat_perms_.size(), play_manager.cc:511
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1007,10 +1035,12 @@ __global__ void k_assign(EngineParams ep, EngineArrays ar, uint32_t count_round)
 // does the restart / retire bookkeeping.
 template <class GM>
 __global__ __launch_bounds__(256) void k_cache_insert(EngineParams ep, EngineArrays ar, const uint64_t* keys, uint32_t off, uint32_t n,
-                                                      uint32_t assign_block, uint32_t count_round) {
+                                                      uint32_t assign_block, uint32_t count_round, uint32_t group) {
   if (blockIdx.x == assign_block) { assign_body(ep, ar, count_round); return; }
   __shared__ uint32_t s_sid[kApplyMax];
-  cache_apply_batch(ar.cache, keys + off, ar.pi + static_cast<size_t>(off) * GM::M, ar.v + static_cast<size_t>(off) * (GM::P + 1), n, s_sid);
+  const CacheView cache = ep.num_groups == 1 ? ar.cache : ar.caches[group];
+  cache_apply_batch(cache, keys + off, ar.pi + static_cast<size_t>(off) * GM::M, ar.v + static_cast<size_t>(off) * (GM::P + 1), n, s_sid,
+                    ep.num_groups == 1 ? nullptr : ar.leaf_group + off, group);
 }
 
 }  // namespace azmi

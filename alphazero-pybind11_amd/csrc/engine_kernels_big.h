@@ -32,6 +32,7 @@ struct BigScratch {  // per-wave LDS
   uint64_t plist[GM::MAX_TURNS + 2];  // path-local repetition list of the running descent
 };
 
+#define AZB_SEL(arr, seat) ((seat) == 0 ? arr[0] : arr[P > 1 ? 1 : 0])
 template <class GM>
 struct BigSlot {
   static constexpr int G = 64, P = GM::P, M = GM::M, MAXK = GM::MAXK;
@@ -45,6 +46,16 @@ struct BigSlot {
   uint32_t t_root[P], t_bump[P], t_depth[P];
   uint64_t t_tld[P];
   uint32_t cur, plen, ph_rows, glen;
+  // per-seat search settings of this game's seat permutation (see SlotCtx)
+  uint32_t perm, sv_w0[P], sv_w1[P];
+  float sv_eps[P], sv_rt[P];
+  __device__ __forceinline__ uint32_t seat_visits(uint32_t seat) const { return AZB_SEL(sv_w0, seat); }
+  __device__ __forceinline__ uint32_t seat_cap_visits(uint32_t seat) const { return AZB_SEL(sv_w1, seat) & 0xFFFFFFu; }
+  __device__ __forceinline__ bool seat_fpu_zero(uint32_t seat) const { return (AZB_SEL(sv_w1, seat) >> 24) & 1u; }
+  __device__ __forceinline__ bool seat_eval_random(uint32_t seat) const { return (AZB_SEL(sv_w1, seat) >> 25) & 1u; }
+  __device__ __forceinline__ uint32_t seat_group(uint32_t seat) const { return (AZB_SEL(sv_w1, seat) >> 26) & 3u; }
+  __device__ __forceinline__ float seat_eps(uint32_t seat) const { return AZB_SEL(sv_eps, seat); }
+  __device__ __forceinline__ float seat_root_temp(uint32_t seat) const { return AZB_SEL(sv_rt, seat); }
 
   __device__ BigSlot(const EngineParams& e, const EngineArrays& a, BigScratch<GM>& s, uint32_t sl, uint32_t l)
       : ep(e), ar(a), sm(s), slot(sl), lane(l) {}
@@ -52,7 +63,6 @@ struct BigSlot {
   __device__ __forceinline__ size_t tree_base(uint32_t seat) const { return (static_cast<size_t>(slot) * P + seat) * ep.cap; }
   __device__ __forceinline__ void raise(uint32_t bit) const { if (lane == 0) { atomicOr(&ar.ctl->overflow, bit); ar.ctl->stop = 1; } }
   __device__ __forceinline__ void sync() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __syncthreads(); }
-#define AZB_SEL(arr, seat) ((seat) == 0 ? arr[0] : arr[P > 1 ? 1 : 0])
   __device__ __forceinline__ void set_seat(uint32_t (&arr)[P], uint32_t seat, uint32_t v) {
 #pragma unroll
     for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == seat) arr[p] = v;
@@ -78,6 +88,12 @@ struct BigSlot {
       t_root[p] = ar.root[t]; t_bump[p] = ar.bump[t]; t_depth[p] = ar.depth[t]; t_tld[p] = ar.tld[t];
     }
     cur = ar.cur[slot]; plen = ar.plen[slot]; ph_rows = ar.ph_count[slot]; glen = ar.rep_len[slot];
+    perm = ar.perm[slot];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const uint32_t* rec = ar.seat_tab + (static_cast<size_t>(perm) * P + p) * kSeatWords;
+      sv_w0[p] = rec[0]; sv_w1[p] = rec[1]; sv_eps[p] = __uint_as_float(rec[2]); sv_rt[p] = __uint_as_float(rec[3]);
+    }
     const uint64_t* gl = ar.rep_list + static_cast<size_t>(slot) * (GM::MAX_TURNS + 2);
     for (uint32_t i = lane; i < glen; i += G) sm.glist[i] = gl[i];
     sync();
@@ -226,7 +242,7 @@ struct BigSlot {
   __device__ void set_gumbel_target() const {   // play_manager.cc:525-539 / 561-570
     if (!ep.gumbel_on) return;
     const uint32_t cp = gs.player;
-    const uint32_t target = (flags & kFlagCapped) ? (ep.fast_gumbel ? ep.cap_visits : 0u) : seat_param(ep.visits, cp);
+    const uint32_t target = (flags & kFlagCapped) ? (ep.fast_gumbel ? seat_cap_visits(cp) : 0u) : seat_visits(cp);
     set_gumbel_num_sims(cp, target);
   }
   __device__ __forceinline__ float gumbel01() { return 0.0f - 1.0f * az_logf(-az_logf(1.0f - canonical01(rng))); }
@@ -455,7 +471,7 @@ struct BigSlot {
       ++plen;
       const uint32_t k = meta_nch(meta), c0 = meta_ch0(meta);
       if (k == 0) { raise(8u); return false; }
-      const float fpu = (cur == root && ep.root_fpu_zero) ? 0.0f : ep.fpu_reduction;
+      const float fpu = (cur == root && seat_fpu_zero(seat)) ? 0.0f : ep.fpu_reduction;
       uint32_t best;
       if (gum_active && cur == root) best = gumbel_next_root_child(seat, tb, c0);
       else if (gum_active && ep.gumbel_full) best = gumbel_interior_select(tb, c0, k, ar.V[tb + cur]);
@@ -478,7 +494,7 @@ struct BigSlot {
   }
 
   // ---- MCTS::add_root_noise over the children whose priors sit in sm.f0[0..k) --------------------------------------
-  __device__ void add_root_noise(uint32_t k) {
+  __device__ void add_root_noise(uint32_t k, float eps) {
     double sum = 0.0;
     if (ep.shaped && k > 1) {
       const float Nf = static_cast<float>(k);
@@ -512,7 +528,7 @@ struct BigSlot {
     }
     sync();
     for (uint32_t i = lane; i < k; i += G)
-      sm.f0[i] = sm.f0[i] * (1 - ep.epsilon) + ep.epsilon * sm.f2[i] / static_cast<float>(sum);
+      sm.f0[i] = sm.f0[i] * (1 - eps) + eps * sm.f2[i] / static_cast<float>(sum);
     sync();
   }
 
@@ -538,12 +554,13 @@ struct BigSlot {
       }
       const float ksum = static_cast<float>(k & 0xFFu);  // dumb_eval: u8 sum wraps (game_state.h:167, shapes.h:14)
       const bool is_root = cur == root;
-      const bool root_pow = is_root && ep.root_temp != 1.0f;
+      const float root_temp = seat_root_temp(seat);
+      const bool root_pow = is_root && root_temp != 1.0f;
       for (uint32_t i = lane; i < k; i += G) {
         float p;
         if (from_net) p = ar.pi[static_cast<size_t>(slot) * M + meta_mv(ar.META[tb + c0 + i])];
         else p = (ksum == 0.0f) ? 0.0f : 1.0f / ksum;
-        if (root_pow) p = az_powf(p, 1.0f / ep.root_temp);
+        if (root_pow) p = az_powf(p, 1.0f / root_temp);
         sm.f0[i] = p;
       }
       sync();
@@ -551,7 +568,7 @@ struct BigSlot {
       sync();
       for (uint32_t i = lane; i < k; i += G) sm.f0[i] = sm.f0[i] / sum;
       sync();
-      if (is_root && root_noise && !ep.gumbel_on) add_root_noise(k);
+      if (is_root && root_noise && !ep.gumbel_on) add_root_noise(k, seat_eps(seat));
       for (uint32_t i = lane; i < k; i += G) ar.Pr[tb + c0 + i] = sm.f0[i];
     }
     const uint32_t* path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
@@ -715,11 +732,12 @@ struct BigSlot {
     if (ar.N[tb + root] == 0) return;
     const uint64_t meta = ar.META[tb + root];
     const uint32_t k = meta_nch(meta), c0 = meta_ch0(meta);
-    const bool do_temp = ep.root_temp != 1.0f;
+    const float root_temp = seat_root_temp(seat);
+    const bool do_temp = root_temp != 1.0f;
     if (!do_temp && !(noise && k > 0)) return;
     for (uint32_t i = lane; i < k; i += G) {
       float p = ar.Pr[tb + c0 + i];
-      if (do_temp) p = az_powf(p, 1.0f / ep.root_temp);
+      if (do_temp) p = az_powf(p, 1.0f / root_temp);
       sm.f0[i] = p;
     }
     sync();
@@ -729,7 +747,7 @@ struct BigSlot {
       if (sum > 0.0f) for (uint32_t i = lane; i < k; i += G) sm.f0[i] = sm.f0[i] / sum;
       sync();
     }
-    if (noise && k > 0) add_root_noise(k);
+    if (noise && k > 0) add_root_noise(k, seat_eps(seat));
     for (uint32_t i = lane; i < k; i += G) ar.Pr[tb + c0 + i] = sm.f0[i];
     sync();
   }
@@ -812,7 +830,7 @@ struct BigSlot {
     }
     if (ep.history && !capped) {
       if (ep.gumbel_on) gumbel_improved_policy(k, ar.V[tb + root]);   // play_manager.cc:411-417
-      else if (ep.pruning && ep.epsilon > 0) probs_pruned(1.0f, root_n, k); else probs(1.0f, k);
+      else if (ep.pruning && seat_eps(cp) > 0) probs_pruned(1.0f, root_n, k); else probs(1.0f, k);
       const uint32_t r = ph_rows;
       if (r < ep.max_hist_rows) {
         float* crow = ar.ph_canon + (static_cast<size_t>(slot) * ep.max_hist_rows + r) * GM::CANON;
@@ -874,7 +892,7 @@ struct BigSlot {
     if (!ep.tree_reuse) {
       for (uint32_t s = 0; s < static_cast<uint32_t>(P); ++s) reset_tree(s);
     } else {
-      reapply_root_prior(gs.player, ep.epsilon > 0 && !(flags & kFlagCapped));
+      reapply_root_prior(gs.player, seat_eps(gs.player) > 0 && !(flags & kFlagCapped));
     }
     if (ep.half_nodes && lane == 0) {   // ask k_compact to move a tree whose active half is filling up
 #pragma unroll
@@ -916,6 +934,8 @@ struct BigSlot {
     if (lane == 0) {
       ar.a_scores[static_cast<size_t>(slot) * (P + 1) + (term - 1)] += 1.0f;
       if (resigned) ar.a_resign[static_cast<size_t>(slot) * (P + 1) + (term - 1)] += 1.0f;
+      ar.a_perm_scores[(static_cast<size_t>(slot) * ep.num_perms + perm) * (P + 1) + (term - 1)] += 1.0f;
+      ar.a_perm_games[static_cast<size_t>(slot) * ep.num_perms + perm] += 1;
       ar.a_len[slot] += gs.turn;
       for (int j = 0; j < 5; ++j) { ar.a_dsum[j * S + slot] += ar.g_dsum[j * S + slot]; ar.g_dsum[j * S + slot] = 0.0; }
       for (int j = 0; j < 3; ++j) { ar.a_cnt[j * S + slot] += ar.g_cnt[j * S + slot]; ar.g_cnt[j * S + slot] = 0; }
@@ -954,9 +974,9 @@ __global__ __launch_bounds__(64) void k_round_big(EngineParams ep, EngineArrays 
   for (;;) {
     if (need_process) {
       const uint32_t cp = c.gs.player;
-      const bool noise = ep.epsilon > 0 && !(c.flags & kFlagCapped);
+      const bool noise = c.seat_eps(cp) > 0 && !(c.flags & kFlagCapped);
       c.process_result(cp, (c.flags & kFlagLeafNeedsNet) != 0, noise);
-      const uint32_t goal = (c.flags & kFlagCapped) ? ep.cap_visits : seat_param(ep.visits, cp);
+      const uint32_t goal = (c.flags & kFlagCapped) ? c.seat_cap_visits(cp) : c.seat_visits(cp);
       if (((cp == 0) ? c.t_depth[0] : c.t_depth[GM::P > 1 ? 1 : 0]) >= goal) {
         if (c.make_move(cp)) { c.store(kSlotEnded); return; }
       }
@@ -965,11 +985,16 @@ __global__ __launch_bounds__(64) void k_round_big(EngineParams ep, EngineArrays 
     typename GM::State leaf;
     uint32_t term = 0;
     if (!c.find_leaf(cp, leaf, term)) { c.store(kSlotDone); return; }
-    const bool needs_net = term == 0 && !seat_param(ep.eval_random, cp);
+    const bool needs_net = term == 0 && !c.seat_eval_random(cp);
     c.flags = needs_net ? (c.flags | kFlagLeafNeedsNet) : (c.flags & ~kFlagLeafNeedsNet);
     if (needs_net) {
       c.emit_leaf(leaf);
-      if (lane == 0) ar.c_evals[slot] += 1;
+      if (lane == 0) {
+        const uint32_t group = c.seat_group(cp);
+        ar.c_evals[slot] += 1;
+        ar.leaf_group[slot] = static_cast<uint8_t>(group);
+        ar.eval_list[static_cast<size_t>(group) * ep.S + atomicAdd(&ar.ctl->eval_count[group], 1u)] = slot;
+      }
       break;
     }
     need_process = true;

@@ -57,7 +57,14 @@ struct EngineParams {  // run constants (PlayParams, play_manager.h:60-154, afte
   // wide games: the arena is two halves of `half_nodes`; the live subtree is copied into the idle half
   // (k_compact) once the active half holds more than `compact_above` nodes after a move. 0 = one flat arena.
   uint32_t half_nodes, compact_above;
+  uint32_t num_perms, num_groups;   // seat permutations / model groups (play_manager.cc:24-113)
 };
+
+// per (permutation, seat) record of ar.seat_tab, 4 words: visits | cap_visits + flags | epsilon | root temp
+constexpr uint32_t kSeatWords = 4;
+__host__ __device__ inline uint32_t seat_w1_pack(uint32_t cap_visits, uint32_t fpu_zero, uint32_t eval_random, uint32_t group) {
+  return (cap_visits & 0xFFFFFFu) | (fpu_zero << 24) | (eval_random << 25) | (group << 26);
+}
 
 struct Control {  // small device control block, copied back by azmi_pm_poll
   uint32_t games_started;
@@ -69,8 +76,7 @@ struct Control {  // small device control block, copied back by azmi_pm_poll
   uint32_t overflow;      // bit0 tree arena, bit1 history, bit2 move log, bit3 path
   uint32_t live_slots;
   uint64_t rounds;
-  uint32_t eval_count;    // entries of eval_list written by this round's k_round
-  uint32_t pad_;
+  uint32_t eval_count[4]; // per model group: entries of eval_list[g] written by this round's k_round
 };
 
 constexpr uint32_t kGumMaxM = 64;   // cap on PlayParams.gumbel_m (reference default 16)
@@ -139,7 +145,13 @@ struct EngineArrays {
   float* gum_g;           // [trees][gum_stride] Gumbel(0,1) sample per root child
   uint16_t* gum_surv;     // [trees][kGumMaxM] surviving root-child indices, best first
   uint32_t* compact_flag; // [trees] set by make_move, consumed by k_compact
-  uint32_t* eval_list;    // [S] slots whose pending leaf needs the net this round (unordered; ctl->eval_count entries)
+  uint32_t* eval_list;    // [groups][S] slots whose pending leaf needs group g's net this round (unordered)
+  uint32_t* seat_tab;     // [perms][P][kSeatWords] per-seat search settings after the reference's normalisation
+  uint32_t* perm;         // [S] GameData::perm_index
+  uint8_t* leaf_group;    // [S] model group of the pending leaf
+  float* a_perm_scores;   // [S][perms][P+1] committed scores per permutation
+  uint32_t* a_perm_games; // [S][perms]
+  const CacheView* caches;  // [groups] one S3-FIFO per model group (play_manager.cc:195-203); `cache` = caches[0]
 };
 
 }  // namespace azmi

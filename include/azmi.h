@@ -41,6 +41,8 @@ typedef enum azmi_game { AZMI_GAME_CONNECT4 = 0, AZMI_GAME_TAWLBWRDD = 1, AZMI_G
 typedef enum azmi_eval_type { AZMI_EVAL_NN = 0, AZMI_EVAL_RANDOM = 1, AZMI_EVAL_PLAYOUT = 2 } azmi_eval_type;
 
 #define AZMI_MAX_PLAYERS 4
+#define AZMI_MAX_PERMS 8    /* seat permutations (2 players: 2; the reference cycles or enumerates them, game_runner.py:2208-2231) */
+#define AZMI_MAX_GROUPS 4   /* model groups = distinct networks in one PlayManager */
 
 /* POD mirror of struct PlayParams (play_manager.h:60-154): same names, same
  * meaning, same defaults (azmi_play_params_default).  Vectors become fixed
@@ -82,6 +84,22 @@ typedef struct azmi_play_params {
   float gumbel_c_scale;                     /* default 1 */
   int32_t gumbel_full;
   int32_t fast_search_uses_gumbel;
+  /* model groups and seat permutations (play_manager.h:118-154; normalised as play_manager.cc:24-113 does):
+   * model_groups[player] = network index (0 entries = identity, i.e. one group per player);
+   * seat_perms[perm][seat] = model group sitting in that seat for games with perm_index == perm
+   * (0 perms = one permutation equal to model_groups); game i starts with perm i % num_seat_perms.
+   * mcts_visits / eval_type are per PLAYER and become per-group (last player of a group wins), then per seat. */
+  uint32_t num_model_groups_given;
+  uint8_t model_groups[AZMI_MAX_PLAYERS];
+  uint32_t num_seat_perms;
+  uint8_t seat_perms[AZMI_MAX_PERMS][AZMI_MAX_PLAYERS];
+  /* per-permutation x per-seat overrides [num_seat_perms][num_players]; has_* = 0 -> filled from the globals */
+  int32_t has_seat_visits, has_seat_cap_visits, has_seat_epsilon, has_seat_mcts_root_temp, has_seat_root_fpu_zero;
+  uint32_t seat_visits[AZMI_MAX_PERMS][AZMI_MAX_PLAYERS];
+  uint32_t seat_cap_visits[AZMI_MAX_PERMS][AZMI_MAX_PLAYERS];
+  float seat_epsilon[AZMI_MAX_PERMS][AZMI_MAX_PLAYERS];
+  float seat_mcts_root_temp[AZMI_MAX_PERMS][AZMI_MAX_PLAYERS];
+  uint8_t seat_root_fpu_zero[AZMI_MAX_PERMS][AZMI_MAX_PLAYERS];
 } azmi_play_params;
 
 /* engine-only knobs that have no reference counterpart */
@@ -232,6 +250,14 @@ int azmi_net_forward_rows(azmi_net* net, const float* dev_canonical, float* dev_
                           const uint32_t* dev_row_count, uint32_t max_rows, void* stream);
 /* azmi_net_forward_rows on an engine's own leaf batch and eval list (what azmi_run_rounds does after each round) */
 int azmi_pm_net_forward(azmi_pm* pm, azmi_net* net, void* stream);
+/* the same for one model group: only the leaves whose seat belongs to `group` (play_manager.cc:577, 597) */
+int azmi_pm_net_forward_group(azmi_pm* pm, uint32_t group, azmi_net* net, void* stream);
+/* num_model_groups() / num_seat_perms(), play_manager.h:210-211 */
+int azmi_pm_groups(azmi_pm* pm, uint32_t* num_model_groups, uint32_t* num_seat_perms);
+/* perm_scores(idx) / perm_games_completed(idx), play_manager.h:212-217: out_scores [P+1] */
+int azmi_pm_perm_scores(azmi_pm* pm, uint32_t perm, float* out_scores, uint32_t* games_completed);
+/* build_batch / update_inferences restricted to one model group (py_wrapper.cc:449-504, play_manager.cc:619-642) */
+int azmi_pm_build_batch_group(azmi_pm* pm, uint32_t group, float* batch, uint32_t cap, uint32_t* indices, uint32_t* n);
 const char* azmi_net_last_error(void);
 
 /* ---- device position cache on its own: S3FIFOCache / ShardedS3FIFOCache (s3fifo_cache.h:15-318,
