@@ -93,8 +93,7 @@ class PlayParams:
 
     # fields the device engine does not implement yet: anything but the default is an error
     _UNSUPPORTED = (
-        "temp_decay_half_life_by_variant", "seat_perms", "seat_visits", "seat_cap_visits",
-        "seat_epsilon", "seat_mcts_root_temp", "seat_root_fpu_zero", "seat_gumbel_enabled", "seat_gumbel_m",
+        "temp_decay_half_life_by_variant", "seat_gumbel_enabled", "seat_gumbel_m",
         "seat_gumbel_c_visit", "seat_gumbel_c_scale", "seat_gumbel_full", "seat_gumbel_use_improved_policy",
         "seat_resign_threshold", "seat_resign_consecutive",
     )
@@ -105,9 +104,36 @@ class PlayParams:
         for name in self._UNSUPPORTED:
             if getattr(self, name):
                 raise RuntimeError(f"PlayParams.{name} is not supported by the MI355X engine yet")
-        groups = list(self.model_groups)
-        if groups and len(set(groups)) > 1:
-            raise RuntimeError("more than one model group is not supported by the MI355X engine yet")
+        # model groups / seat permutations / per-seat matrices: same validation messages as play_manager.cc:57-113
+        groups = [int(g) for g in self.model_groups]
+        if groups and len(groups) != num_players:
+            raise RuntimeError("model_groups must be empty or have one entry per player")
+        perms = [[int(g) for g in row] for row in self.seat_perms]
+        if len(perms) > _capi.AZMI_MAX_PERMS:
+            raise RuntimeError(f"at most {_capi.AZMI_MAX_PERMS} seat permutations")
+        n_perms = len(perms) if perms else 1
+        c.num_model_groups_given = len(groups)
+        for i, g in enumerate(groups):
+            c.model_groups[i] = g
+        c.num_seat_perms = len(perms)
+        for q, row in enumerate(perms):
+            if len(row) != num_players:
+                raise RuntimeError("seat_perms inner dimension must match number of players")
+            for sidx, g in enumerate(row):
+                c.seat_perms[q][sidx] = g
+        for name, cast in (("seat_visits", int), ("seat_cap_visits", int), ("seat_epsilon", float),
+                           ("seat_mcts_root_temp", float), ("seat_root_fpu_zero", int)):
+            mat = [list(row) for row in getattr(self, name)]
+            setattr(c, "has_" + name, int(bool(mat)))
+            if not mat:
+                continue
+            if len(mat) != n_perms:
+                raise RuntimeError(f"{name} outer dimension must match number of seat permutations")
+            for q, row in enumerate(mat):
+                if len(row) != num_players:
+                    raise RuntimeError(f"{name} inner dimension must match number of players")
+                for sidx, x in enumerate(row):
+                    getattr(c, name)[q][sidx] = cast(x)
         c.games_to_play = int(self.games_to_play)
         c.concurrent_games = int(self.concurrent_games)
         c.max_batch_size = int(self.max_batch_size)
@@ -563,8 +589,23 @@ class PlayManager:
 
     def cache_hits(self): return self.counters()["cache_hits"]
     def cache_misses(self): return self.counters()["cache_misses"]
-    def num_model_groups(self): return 1
-    def num_seat_perms(self): return 1
+    def _groups(self):
+        g, p = C.c_uint32(), C.c_uint32()
+        check(lib.azmi_pm_groups(self._h, C.byref(g), C.byref(p)))
+        return g.value, p.value
+
+    def num_model_groups(self): return self._groups()[0]   # play_manager.h:210
+    def num_seat_perms(self): return self._groups()[1]     # play_manager.h:211
+
+    def perm_scores(self, idx):                            # play_manager.h:212-214
+        out = np.zeros(self._P + 1, np.float32)
+        check(lib.azmi_pm_perm_scores(self._h, int(idx), out.ctypes.data, None))
+        return out
+
+    def perm_games_completed(self, idx):                   # play_manager.h:215-217
+        n = C.c_uint32()
+        check(lib.azmi_pm_perm_scores(self._h, int(idx), None, C.byref(n)))
+        return n.value
 
     def build_batch(self, group, batch, shard=0):
         """py_wrapper.cc:449-504: fills the caller's [max_batch, C, H, W] float32 array, returns slot ids."""
@@ -574,7 +615,7 @@ class PlayManager:
         idx = np.zeros(arr.shape[0], np.uint32)
         n = C.c_uint32()
         cap = min(arr.shape[0], int(self._params.max_batch_size)) if self._params.max_batch_size else arr.shape[0]
-        check(lib.azmi_pm_build_batch(self._h, arr.ctypes.data, cap, idx.ctypes.data, C.byref(n)))
+        check(lib.azmi_pm_build_batch_group(self._h, int(group), arr.ctypes.data, cap, idx.ctypes.data, C.byref(n)))
         return [int(i) for i in idx[: n.value]]
 
     def update_inferences(self, group, indices, v, pi):
@@ -610,7 +651,11 @@ class PlayManager:
     def net_forward(self, net, stream=None):
         """The HIP leaf net on this engine's leaf batch, restricted to the rows the last round listed as needing
         an evaluation (azmi_pm_net_forward); `net` is a HipLeafNet."""
-        check(lib.azmi_pm_net_forward(self._h, net._h, self._stream_arg(stream)))
+        if isinstance(net, (list, tuple)):     # one HipLeafNet per model group
+            for g, one in enumerate(net):
+                check(lib.azmi_pm_net_forward_group(self._h, g, one._h, self._stream_arg(stream)))
+        else:
+            check(lib.azmi_pm_net_forward(self._h, net._h, self._stream_arg(stream)))
 
     def poll(self, stream=None):
         done, live = C.c_uint32(), C.c_uint32()

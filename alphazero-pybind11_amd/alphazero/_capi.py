@@ -10,6 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libazmi.so")
 
 AZMI_MAX_PLAYERS = 4
+AZMI_MAX_PERMS = 8
+AZMI_MAX_GROUPS = 4
 
 
 class PlayParamsC(C.Structure):
@@ -47,6 +49,20 @@ class PlayParamsC(C.Structure):
         ("gumbel_c_scale", C.c_float),
         ("gumbel_full", C.c_int32),
         ("fast_search_uses_gumbel", C.c_int32),
+        ("num_model_groups_given", C.c_uint32),
+        ("model_groups", C.c_uint8 * AZMI_MAX_PLAYERS),
+        ("num_seat_perms", C.c_uint32),
+        ("seat_perms", (C.c_uint8 * AZMI_MAX_PLAYERS) * AZMI_MAX_PERMS),
+        ("has_seat_visits", C.c_int32),
+        ("has_seat_cap_visits", C.c_int32),
+        ("has_seat_epsilon", C.c_int32),
+        ("has_seat_mcts_root_temp", C.c_int32),
+        ("has_seat_root_fpu_zero", C.c_int32),
+        ("seat_visits", (C.c_uint32 * AZMI_MAX_PLAYERS) * AZMI_MAX_PERMS),
+        ("seat_cap_visits", (C.c_uint32 * AZMI_MAX_PLAYERS) * AZMI_MAX_PERMS),
+        ("seat_epsilon", (C.c_float * AZMI_MAX_PLAYERS) * AZMI_MAX_PERMS),
+        ("seat_mcts_root_temp", (C.c_float * AZMI_MAX_PLAYERS) * AZMI_MAX_PERMS),
+        ("seat_root_fpu_zero", (C.c_uint8 * AZMI_MAX_PLAYERS) * AZMI_MAX_PERMS),
     ]
 
 
@@ -105,6 +121,10 @@ SYMBOLS = {
     "azmi_tafl_symmetries": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int, _VP]),
     "azmi_symmetries_last_error": (C.c_char_p, []),
     "azmi_pm_net_forward": (C.c_int, [_VP, _VP, _VP]),
+    "azmi_pm_net_forward_group": (C.c_int, [_VP, C.c_uint32, _VP, _VP]),
+    "azmi_pm_groups": (C.c_int, [_VP, _PP(C.c_uint32), _PP(C.c_uint32)]),
+    "azmi_pm_perm_scores": (C.c_int, [_VP, C.c_uint32, _VP, _PP(C.c_uint32)]),
+    "azmi_pm_build_batch_group": (C.c_int, [_VP, C.c_uint32, _VP, C.c_uint32, _VP, _PP(C.c_uint32)]),
     "azmi_net_forward_rows": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_uint32, _VP]),
     "azmi_game_replay_ex": (C.c_int, [C.c_int, C.c_int, _VP, C.c_uint32, _VP, C.c_uint32, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_uint32]),
     "azmi_game_replay_from": (C.c_int, [C.c_int, C.c_int, _VP, C.c_uint32, _VP, C.c_uint32, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),

@@ -635,8 +635,11 @@ int pm_net_forward(azmi_pm* pm, uint32_t group, azmi_net* net, hipStream_t st) {
 int one_round_with_net(azmi_pm* pm, azmi_net* net, hipStream_t st) {
   int rc = launch_round(pm, st);
   if (rc != AZMI_OK) return rc;
-  if (pm->ep.num_groups != 1) return fail(AZMI_ERR_STATE, "this engine has %u model groups: evaluate each with azmi_pm_net_forward_group", pm->ep.num_groups);
-  return pm_net_forward(pm, 0, net, st);
+  for (uint32_t g = 0; g < pm->ep.num_groups; ++g) {   // one net given: it serves every model group
+    rc = pm_net_forward(pm, g, net, st);
+    if (rc != AZMI_OK) return rc;
+  }
+  return AZMI_OK;
 }
 int ensure_graph(azmi_pm* pm, azmi_net* net, hipStream_t st) {
   if (pm->graph_exec && pm->graph_stream == st && pm->graph_net == net) return AZMI_OK;
@@ -679,8 +682,11 @@ int azmi_run_rounds(azmi_pm* const* pms, azmi_net* net, uint32_t k, uint32_t rou
 
 int azmi_pm_net_forward(azmi_pm* pm, azmi_net* net, void* stream) {
   if (!pm || !net) return fail(AZMI_ERR_INVALID, "null argument");
-  if (pm->ep.num_groups != 1) return fail(AZMI_ERR_STATE, "this engine has %u model groups: use azmi_pm_net_forward_group", pm->ep.num_groups);
-  return pm_net_forward(pm, 0, net, pm->pick(stream));
+  for (uint32_t g = 0; g < pm->ep.num_groups; ++g) {   // the same net for every model group
+    const int rc = pm_net_forward(pm, g, net, pm->pick(stream));
+    if (rc != AZMI_OK) return rc;
+  }
+  return AZMI_OK;
 }
 
 int azmi_pm_net_forward_group(azmi_pm* pm, uint32_t group, azmi_net* net, void* stream) {
@@ -899,12 +905,18 @@ int azmi_pm_build_batch_group(azmi_pm* pm, uint32_t group, float* batch, uint32_
     int rc = read_ctl(pm, st, &c, true); if (rc) return rc;
     if (c.stop) return AZMI_OK;
     rc = launch_round(pm, st); if (rc) return rc;
-    std::vector<uint8_t> ss, fl, lg;
-    rc = d2h(ss, pm->ar.sstate, S, st); if (rc) return rc;
-    rc = d2h(fl, pm->ar.flags, S, st); if (rc) return rc;
-    rc = d2h(lg, pm->ar.leaf_group, S, st); if (rc) return rc;
-    for (uint32_t s = 0; s < S; ++s)
-      if (ss[s] == kSlotWaitEval && (fl[s] & kFlagLeafNeedsNet)) pm->pending_g[lg[s] < pm->ep.num_groups ? lg[s] : 0].push_back(s);
+    // the round's eval lists name exactly the leaves that need a network answer, per model group (a slot whose
+    // last leaf was a cache hit or terminal is not listed); sorted so the hand-out order is deterministic
+    Control c2;
+    rc = read_ctl(pm, st, &c2, false); if (rc) return rc;
+    for (uint32_t g = 0; g < pm->ep.num_groups; ++g) {
+      const uint32_t cnt = std::min<uint32_t>(c2.eval_count[g], S);
+      if (cnt == 0) continue;
+      std::vector<uint32_t> lst;
+      rc = d2h(lst, pm->ar.eval_list + static_cast<size_t>(g) * S, cnt, st); if (rc) return rc;
+      std::sort(lst.begin(), lst.end());
+      for (uint32_t sidx : lst) pm->pending_g[g].push_back(sidx);
+    }
     if (++guard > (1 << 20)) return fail(AZMI_ERR_STATE, "build_batch made no progress");
   }
   std::deque<uint32_t>* q = mine();
@@ -927,19 +939,15 @@ int azmi_pm_update_inferences(azmi_pm* pm, const uint32_t* indices, uint32_t n, 
   if (!pm || (n && (!indices || !v || !pi))) return fail(AZMI_ERR_INVALID, "null argument");
   const uint32_t S = pm->ep.S, V = pm->gi.P + 1, M = pm->gi.M;
   if (n > pm->outstanding) return fail(AZMI_ERR_STATE, "update_inferences: more rows than build_batch handed out");
+  // rows go straight to the slot-indexed device buffers: rows of other slots (cache hits written by the round
+  // kernel) must not be touched, so there is no whole-buffer mirror upload
   for (uint32_t r = 0; r < n; ++r) {
     if (indices[r] >= S) return fail(AZMI_ERR_INVALID, "slot index out of range");
-    std::memcpy(&pm->host_v[static_cast<size_t>(indices[r]) * V], v + static_cast<size_t>(r) * V, V * 4);
-    std::memcpy(&pm->host_pi[static_cast<size_t>(indices[r]) * M], pi + static_cast<size_t>(r) * M, M * 4);
+    HIP_TRY(hipMemcpyAsync(pm->ar.v + static_cast<size_t>(indices[r]) * V, v + static_cast<size_t>(r) * V, V * 4, hipMemcpyHostToDevice, pm->stream));
+    HIP_TRY(hipMemcpyAsync(pm->ar.pi + static_cast<size_t>(indices[r]) * M, pi + static_cast<size_t>(r) * M, M * 4, hipMemcpyHostToDevice, pm->stream));
   }
+  HIP_TRY(hipStreamSynchronize(pm->stream));
   pm->outstanding -= n;
-  bool any_left = false;
-  for (auto& q : pm->pending_g) any_left = any_left || !q.empty();
-  if (pm->outstanding == 0 && !any_left) {
-    HIP_TRY(hipMemcpyAsync(pm->ar.v, pm->host_v.data(), pm->host_v.size() * 4, hipMemcpyHostToDevice, pm->stream));
-    HIP_TRY(hipMemcpyAsync(pm->ar.pi, pm->host_pi.data(), pm->host_pi.size() * 4, hipMemcpyHostToDevice, pm->stream));
-    HIP_TRY(hipStreamSynchronize(pm->stream));
-  }
   return AZMI_OK;
 }
 

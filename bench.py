@@ -79,6 +79,7 @@ def selfplay_params(az, games, sims, stream_games, cache=0, playout_cap=False, g
     pp.resign_playthrough_percent = 0.20
     pp.max_cache_size = cache
     pp.gumbel_enabled = bool(gumbel)
+    pp.model_groups = [0, 0]      # one network on both seats: set_model_groups(), game_runner.py:773-787, 2054
     return pp
 
 

@@ -234,7 +234,16 @@ struct OrcPlayParams {
   int32_t eval_type[4];  // -1 = unset (all NN)
   int32_t gumbel_enabled; uint32_t gumbel_m; float gumbel_c_visit, gumbel_c_scale;
   int32_t gumbel_full, fast_search_uses_gumbel;
+  // model groups / seat permutations / per-seat overrides (0 counts = not given)
+  uint32_t num_model_groups_given; uint8_t model_groups[4];
+  uint32_t num_seat_perms; uint8_t seat_perms[8][4];
+  int32_t has_seat_visits, has_seat_cap_visits, has_seat_epsilon, has_seat_mcts_root_temp, has_seat_root_fpu_zero;
+  uint32_t seat_visits[8][4], seat_cap_visits[8][4];
+  float seat_epsilon[8][4], seat_mcts_root_temp[8][4];
+  uint8_t seat_root_fpu_zero[8][4];
+  uint32_t perm_base;
 };
+typedef void (*orc_group_eval_fn)(uint32_t group, const float* canonical, uint32_t n, float* v, float* pi, void* user);
 typedef void (*orc_eval_fn)(const float* canonical, uint32_t n, float* v, float* pi, void* user);
 
 void* orc_pm_new(int game_id, const OrcPlayParams* c, uint64_t seed, int per_slot_rng, int record_moves) {
@@ -260,8 +269,19 @@ void* orc_pm_new(int game_id, const OrcPlayParams* c, uint64_t seed, int per_slo
     p.gumbel_full = c->gumbel_full != 0; p.fast_search_uses_gumbel = c->fast_search_uses_gumbel != 0;
     if (c->eval_type[0] >= 0)
       for (uint32_t i = 0; i < P; ++i) p.eval_type.push_back(static_cast<EvalType>(c->eval_type[i]));
+    for (uint32_t i = 0; i < c->num_model_groups_given; ++i) p.model_groups.push_back(c->model_groups[i]);
+    const uint32_t np = c->num_seat_perms;
+    for (uint32_t q = 0; q < np; ++q) p.seat_perms.emplace_back(c->seat_perms[q], c->seat_perms[q] + P);
+    const uint32_t rows = np ? np : 1;
+    for (uint32_t q = 0; q < rows; ++q) {
+      if (c->has_seat_visits) p.seat_visits.emplace_back(c->seat_visits[q], c->seat_visits[q] + P);
+      if (c->has_seat_cap_visits) p.seat_cap_visits.emplace_back(c->seat_cap_visits[q], c->seat_cap_visits[q] + P);
+      if (c->has_seat_epsilon) p.seat_epsilon.emplace_back(c->seat_epsilon[q], c->seat_epsilon[q] + P);
+      if (c->has_seat_mcts_root_temp) p.seat_mcts_root_temp.emplace_back(c->seat_mcts_root_temp[q], c->seat_mcts_root_temp[q] + P);
+      if (c->has_seat_root_fpu_zero) p.seat_root_fpu_zero.emplace_back(c->seat_root_fpu_zero[q], c->seat_root_fpu_zero[q] + P);
+    }
     auto* b = new PmBox();
-    b->pm = std::make_unique<PlayManager>(std::move(base), p, seed, per_slot_rng != 0);
+    b->pm = std::make_unique<PlayManager>(std::move(base), p, seed, per_slot_rng != 0, c->perm_base);
     b->pm->record_moves = (record_moves & 1) != 0;
     b->pm->trace_on = (record_moves & 2) != 0;
     return b;
@@ -274,6 +294,23 @@ uint64_t orc_pm_trace(void* h, uint64_t* out, uint64_t cap) {
   return n;
 }
 void orc_pm_free(void* h) { delete static_cast<PmBox*>(h); }
+int orc_pm_run_groups(void* h, orc_group_eval_fn fn, void* user) {
+  try {
+    static_cast<PmBox*>(h)->pm->run_groups([fn, user](uint32_t g, const float* c, uint32_t n, float* v, float* pi) {
+      if (!fn) throw std::runtime_error("NN evaluator needed but none supplied");
+      fn(g, c, n, v, pi, user);
+    });
+    return 0;
+  } catch (...) { return -1; }
+}
+uint32_t orc_pm_num_groups(void* h) { return static_cast<PmBox*>(h)->pm->num_model_groups(); }
+uint32_t orc_pm_num_perms(void* h) { return static_cast<PmBox*>(h)->pm->num_seat_perms(); }
+uint32_t orc_pm_perm_scores(void* h, uint32_t perm, float* out) {
+  auto& pm = *static_cast<PmBox*>(h)->pm;
+  const auto& sc = pm.perm_scores(perm);
+  for (size_t i = 0; i < sc.size(); ++i) out[i] = sc[i];
+  return pm.perm_games_completed(perm);
+}
 int orc_pm_run(void* h, orc_eval_fn fn, void* user) {
   try {
     static_cast<PmBox*>(h)->pm->run([fn, user](const float* c, uint32_t n, float* v, float* pi) {

@@ -66,6 +66,12 @@ struct PlayParams {  // play_manager.h:60-154 (fields the path implements)
   float resign_percent = 0.0f;
   float resign_playthrough_percent = 0.0f;
   std::vector<EvalType> eval_type;  // per player; empty = all NN
+  // model groups / seat permutations / per-seat overrides, play_manager.h:118-154
+  std::vector<uint8_t> model_groups;                    // player -> model group (empty = identity)
+  std::vector<std::vector<uint8_t>> seat_perms;         // [perm][seat] -> model group (empty = {model_groups})
+  std::vector<std::vector<uint32_t>> seat_visits, seat_cap_visits;
+  std::vector<std::vector<float>> seat_epsilon, seat_mcts_root_temp;
+  std::vector<std::vector<uint8_t>> seat_root_fpu_zero;
 };
 
 struct HistoryRow {  // game_state.h:16-20
@@ -83,12 +89,16 @@ struct MoveRecord {  // test hook: one entry per played move
 class PlayManager {
  public:
   using Evaluator = std::function<void(const float* canonical, uint32_t n, float* v, float* pi)>;
+  using GroupEvaluator = std::function<void(uint32_t group, const float* canonical, uint32_t n, float* v, float* pi)>;
 
-  PlayManager(std::unique_ptr<Game> base, PlayParams p, uint64_t seed, bool per_slot_rng)
+  // perm_base: index of this manager's first game in a larger run (test hook: a one-slot manager standing in for
+  // slot s of an S-slot run starts with perm (s % perms), play_manager.cc:218)
+  PlayManager(std::unique_ptr<Game> base, PlayParams p, uint64_t seed, bool per_slot_rng, uint32_t perm_base = 0)
       : base_(std::move(base)), params_(std::move(p)), per_slot_rng_(per_slot_rng) {
     const uint32_t P = base_->num_players();
     if (params_.mcts_visits.size() != P)
       throw std::runtime_error("You must specify MCTS visits for each player");  // play_manager.cc:20-22
+    normalise(P);
     games_started_ = params_.concurrent_games;
     const uint32_t nstreams = per_slot_rng_ ? params_.concurrent_games : 1;
     tree_rng_.resize(nstreams);
@@ -98,11 +108,15 @@ class PlayManager {
       tree_rng_[s].seed(sd);
       coin_rng_[s].seed(sd ^ kCoinSalt);
     }
-    if (params_.max_cache_size > 0) {  // play_manager.cc:195-203 (one model group)
-      const uint32_t per_group = params_.max_cache_size;
-      cache_ = std::make_unique<ShardedS3Fifo>(per_group, params_.cache_shards, per_group * 9 / 10,
-                                               base_->num_moves(), P + 1);
+    if (params_.max_cache_size > 0) {  // play_manager.cc:195-203: one cache per model group
+      const uint32_t per_group = params_.max_cache_size / num_model_groups_;
+      for (uint32_t g = 0; g < num_model_groups_; ++g)
+        caches_.push_back(std::make_unique<ShardedS3Fifo>(per_group, params_.cache_shards, per_group * 9 / 10,
+                                                          base_->num_moves(), P + 1));
     }
+    perm_scores_.assign(seat_perms_.size(), std::vector<float>(P + 1, 0.0f));
+    perm_games_.assign(seat_perms_.size(), 0u);
+    awaiting_inference_.resize(num_model_groups_);
     scores_.assign(P + 1, 0.0f);
     resign_scores_.assign(P + 1, 0.0f);
     slots_.resize(params_.concurrent_games);
@@ -110,7 +124,8 @@ class PlayManager {
       Slot& g = slots_[i];
       g.gs = base_->copy();
       g.gs->randomize_start();
-      for (uint32_t j = 0; j < P; ++j) g.mcts.push_back(make_mcts(i));
+      g.perm_index = static_cast<uint8_t>((perm_base + i) % seat_perms_.size());   // play_manager.cc:218
+      for (uint32_t j = 0; j < P; ++j) g.mcts.push_back(make_mcts(i, g.perm_index, j));
       g.canonical.assign(base_->canonical_size(), 0.0f);
       g.v.assign(P + 1, 0.0f);
       g.pi.assign(base_->num_moves(), 0.0f);
@@ -120,6 +135,9 @@ class PlayManager {
 
   // Single-threaded equivalent of N x play() + the GameRunner eval pipeline.
   void run(const Evaluator& nn) {
+    run_groups([&nn](uint32_t, const float* c, uint32_t n, float* v, float* pi) { nn(c, n, v, pi); });
+  }
+  void run_groups(const GroupEvaluator& nn) {
     while (games_completed_ < params_.games_to_play) {
       while (!awaiting_mcts_.empty() && games_completed_ < params_.games_to_play) {
         const uint32_t i = awaiting_mcts_.front();
@@ -127,10 +145,16 @@ class PlayManager {
         step(i);
       }
       if (games_completed_ >= params_.games_to_play) break;
-      if (awaiting_inference_.empty()) break;  // nothing left to do (all slots retired)
-      flush_inference(nn);
+      bool any = false;
+      for (auto& q : awaiting_inference_) any = any || !q.empty();
+      if (!any) break;  // nothing left to do (all slots retired)
+      for (uint32_t g = 0; g < num_model_groups_; ++g) flush_inference(g, nn);
     }
   }
+  uint32_t num_model_groups() const { return num_model_groups_; }
+  uint32_t num_seat_perms() const { return static_cast<uint32_t>(seat_perms_.size()); }
+  const std::vector<float>& perm_scores(uint32_t i) const { return perm_scores_[i]; }
+  uint32_t perm_games_completed(uint32_t i) const { return perm_games_[i]; }
 
   // ---- stats getters, play_manager.h:173-366 -------------------------------------
   const std::vector<float>& scores() const { return scores_; }
@@ -168,8 +192,8 @@ class PlayManager {
   const std::vector<MoveRecord>& moves() const { return moves_; }
   uint64_t sims() const { return sims_; }
   uint64_t nn_evals() const { return nn_evals_; }
-  uint64_t cache_hits() const { return cache_ ? cache_->hits() : 0; }
-  uint64_t cache_misses() const { return cache_ ? cache_->misses() : 0; }
+  uint64_t cache_hits() const { uint64_t n = 0; for (auto& c : caches_) n += c->hits(); return n; }
+  uint64_t cache_misses() const { uint64_t n = 0; for (auto& c : caches_) n += c->misses(); return n; }
   bool record_moves = false;
   bool trace_on = false;
   std::vector<std::pair<uint64_t, uint64_t>> trace;
@@ -186,6 +210,7 @@ class PlayManager {
     std::vector<float> canonical, v, pi;
     std::vector<Pending> partial_history;
     bool initialized = false, capped = false, playthrough = false;
+    uint8_t perm_index = 0;   // GameData::perm_index; seat_perm = seat_perms_[perm_index]
     double total_avg_leaf_depth = 0, total_search_entropy = 0;
     double fast_total_avg_leaf_depth = 0, fast_total_search_entropy = 0;
     double total_valid_moves = 0;
@@ -196,16 +221,49 @@ class PlayManager {
   Pcg32& tree_rng(uint32_t slot) { return tree_rng_[per_slot_rng_ ? slot : 0]; }
   Pcg32& coin_rng(uint32_t slot) { return coin_rng_[per_slot_rng_ ? slot : 0]; }
 
-  Mcts make_mcts(uint32_t slot) {  // play_manager.cc:602-617 (single perm, global settings)
+  // ctor steps 1-5, play_manager.cc:24-113
+  void normalise(uint32_t P) {
+    std::vector<uint8_t> groups = params_.model_groups;
+    if (groups.empty()) for (uint32_t i = 0; i < P; ++i) groups.push_back(static_cast<uint8_t>(i));
+    num_model_groups_ = 0;
+    for (uint8_t g : groups) num_model_groups_ = std::max<uint32_t>(num_model_groups_, g + 1u);
+    std::vector<uint32_t> visits_g(num_model_groups_, 0);
+    for (uint32_t i = 0; i < P; ++i) visits_g[groups[i]] = params_.mcts_visits[i];
+    if (!params_.eval_type.empty()) {
+      eval_types_.assign(num_model_groups_, EvalType::NN);
+      for (uint32_t i = 0; i < P; ++i) eval_types_[groups[i]] = params_.eval_type[i];
+    }
+    seat_perms_ = params_.seat_perms;
+    if (seat_perms_.empty()) seat_perms_.push_back(groups);
+    const size_t np = seat_perms_.size();
+    auto check = [&](size_t outer, const char* name) {
+      if (outer != np) throw std::runtime_error(std::string(name) + " outer dimension must match number of seat permutations");
+    };
+    auto fill = [&](auto& dst, const auto& given, auto deflt, const char* name) {
+      if (given.empty()) { dst.resize(np); for (size_t q = 0; q < np; ++q) { dst[q].clear(); for (uint32_t sidx = 0; sidx < P; ++sidx) dst[q].push_back(deflt(q, sidx)); } }
+      else {
+        check(given.size(), name);
+        for (auto& row : given) if (row.size() != P) throw std::runtime_error(std::string(name) + " inner dimension must match number of players");
+        dst = given;
+      }
+    };
+    fill(seat_visits_, params_.seat_visits, [&](size_t q, uint32_t sidx) { return visits_g[seat_perms_[q][sidx]]; }, "seat_visits");
+    fill(seat_cap_visits_, params_.seat_cap_visits, [&](size_t, uint32_t) { return params_.playout_cap_depth; }, "seat_cap_visits");
+    fill(seat_epsilon_, params_.seat_epsilon, [&](size_t, uint32_t) { return params_.epsilon; }, "seat_epsilon");
+    fill(seat_root_temp_, params_.seat_mcts_root_temp, [&](size_t, uint32_t) { return params_.mcts_root_temp; }, "seat_mcts_root_temp");
+    fill(seat_fpu_zero_, params_.seat_root_fpu_zero, [&](size_t, uint32_t) { return static_cast<uint8_t>(params_.root_fpu_zero ? 1 : 0); }, "seat_root_fpu_zero");
+  }
+
+  Mcts make_mcts(uint32_t slot, uint8_t perm, uint32_t player) {  // play_manager.cc:602-617
     MctsConfig c;
     c.cpuct = params_.cpuct;
     c.num_players = base_->num_players();
     c.num_moves = base_->num_moves();
-    c.epsilon = params_.epsilon;
-    c.root_policy_temp = params_.mcts_root_temp;
+    c.epsilon = seat_epsilon_[perm][player];
+    c.root_policy_temp = seat_root_temp_[perm][player];
     c.fpu_reduction = params_.fpu_reduction;
     c.relative_values = base_->relative_values();
-    c.root_fpu_zero = params_.root_fpu_zero;
+    c.root_fpu_zero = seat_fpu_zero_[perm][player] != 0;
     c.shaped_dirichlet = params_.shaped_dirichlet;
     c.gumbel_enabled = params_.gumbel_enabled;   // play_manager.cc:612-616
     c.gumbel_m = params_.gumbel_m;
@@ -221,13 +279,13 @@ class PlayManager {
   template <class SlotT>
   void set_gumbel_target(SlotT& game) {
     const uint8_t cp = game.gs->current_player();
-    const uint32_t target = game.capped ? (params_.fast_search_uses_gumbel ? params_.playout_cap_depth : 0u)
-                                        : params_.mcts_visits[cp];
+    const uint32_t target = game.capped ? (params_.fast_search_uses_gumbel ? seat_cap_visits_[game.perm_index][cp] : 0u)
+                                        : seat_visits_[game.perm_index][cp];
     game.mcts[cp].set_gumbel_num_sims(target);
   }
 
-  EvalType eval_type_for(uint8_t player) const {
-    return params_.eval_type.empty() ? EvalType::NN : params_.eval_type[player];
+  EvalType eval_type_for_group(uint32_t group) const {
+    return eval_types_.empty() ? EvalType::NN : eval_types_[group];
   }
 
   // One iteration of the worker loop body, play_manager.cc:277-599.
@@ -237,9 +295,9 @@ class PlayManager {
     if (game.initialized) {
       const uint8_t cp = game.gs->current_player();
       Mcts& mcts = game.mcts[cp];
-      mcts.process_result(game.v.data(), game.pi.data(), params_.epsilon > 0 && !game.capped);
+      mcts.process_result(game.v.data(), game.pi.data(), seat_epsilon_[game.perm_index][cp] > 0 && !game.capped);
       ++sims_;
-      const uint32_t goal_depth = game.capped ? params_.playout_cap_depth : params_.mcts_visits[cp];
+      const uint32_t goal_depth = game.capped ? seat_cap_visits_[game.perm_index][cp] : seat_visits_[game.perm_index][cp];
       if (mcts.depth() >= goal_depth) {
         float temp = params_.start_temp;
         const float half_life = params_.temp_decay_half_life;
@@ -294,7 +352,7 @@ class PlayManager {
           game.gs->canonicalized(pd.ph.canonical.data());
           pd.ph.v.assign(game.v.size(), 0.0f);
           pd.ph.pi = params_.gumbel_enabled ? mcts.gumbel_improved_policy()   // play_manager.cc:411-417
-                     : (params_.policy_target_pruning && params_.epsilon > 0) ? mcts.probs_pruned(1.0)
+                     : (params_.policy_target_pruning && seat_epsilon_[game.perm_index][cp] > 0) ? mcts.probs_pruned(1.0)
                                                                               : mcts.probs(1.0);
           pd.player = game.gs->current_player();
           game.partial_history.push_back(std::move(pd));
@@ -340,6 +398,8 @@ class PlayManager {
           }
           // play_manager.cc:463-514
           for (uint32_t k = 0; k <= P; ++k) scores_[k] += scores[k];
+          for (uint32_t k = 0; k <= P; ++k) perm_scores_[game.perm_index][k] += scores[k];   // play_manager.cc:466-467
+          ++perm_games_[game.perm_index];
           if (resign_score.has_value())
             for (uint32_t k = 0; k <= P; ++k) resign_scores_[k] += (*resign_score)[k];
           ++games_completed_;
@@ -358,23 +418,24 @@ class PlayManager {
           game.move_count = game.full_move_count = game.fast_move_count = 0;
           ++game.games_played;
           if (games_started_ >= params_.games_to_play) return;  // slot retires
+          game.perm_index = static_cast<uint8_t>(games_started_ % seat_perms_.size());   // play_manager.cc:511
           ++games_started_;
           game.gs = base_->copy();
           game.gs->randomize_start();
-          for (uint32_t j = 0; j < P; ++j) game.mcts[j] = make_mcts(i);
+          for (uint32_t j = 0; j < P; ++j) game.mcts[j] = make_mcts(i, game.perm_index, j);
         }
         // play_manager.cc:522-555
         game.capped = params_.playout_cap_randomization &&
                       (uniform01(coin_rng(i)) < params_.playout_cap_percent);
         set_gumbel_target(game);  // play_manager.cc:525-539
         if (!params_.tree_reuse) {
-          for (uint32_t j = 0; j < P; ++j) game.mcts[j] = make_mcts(i);
+          for (uint32_t j = 0; j < P; ++j) game.mcts[j] = make_mcts(i, game.perm_index, j);
         } else {
           const uint8_t next_cp = game.gs->current_player();
           Mcts& next = game.mcts[next_cp];
           if (next.root_n() > 0) {
             next.apply_root_policy_temp();
-            if (params_.epsilon > 0 && !game.capped) { if (trace_on) trace.push_back({3 | (static_cast<uint64_t>(next.num_root_children()) << 8), tree_rng(i).state}); next.add_root_noise(); if (trace_on) trace.push_back({4, tree_rng(i).state}); }
+            if (seat_epsilon_[game.perm_index][next_cp] > 0 && !game.capped) { if (trace_on) trace.push_back({3 | (static_cast<uint64_t>(next.num_root_children()) << 8), tree_rng(i).state}); next.add_root_noise(); if (trace_on) trace.push_back({4, tree_rng(i).state}); }
           }
         }
       }
@@ -388,7 +449,8 @@ class PlayManager {
     const uint8_t cp = game.gs->current_player();
     Mcts& mcts = game.mcts[cp];
     auto leaf = mcts.find_leaf(*game.gs);
-    const EvalType et = eval_type_for(cp);
+    const uint32_t group = seat_perms_[game.perm_index][cp];   // play_manager.cc:577
+    const EvalType et = eval_type_for_group(group);
     if (et != EvalType::NN) {
       if (et == EvalType::PLAYOUT) throw std::runtime_error("PLAYOUT eval is not restated");
       dumb_eval(*leaf, game.v.data(), game.pi.data());
@@ -397,32 +459,33 @@ class PlayManager {
     }
     leaf->canonicalized(game.canonical.data());
     game.leaf_hash = leaf->key();
-    if (cache_ && cache_->find(game.leaf_hash, game.pi.data(), game.v.data())) {
+    if (!caches_.empty() && caches_[group]->find(game.leaf_hash, game.pi.data(), game.v.data())) {
       awaiting_mcts_.push_back(i);
       return;
     }
-    awaiting_inference_.push_back(i);
+    awaiting_inference_[group].push_back(i);
   }
 
-  void flush_inference(const Evaluator& nn) {
+  void flush_inference(uint32_t group, const GroupEvaluator& nn) {
+    std::deque<uint32_t>& queue = awaiting_inference_[group];
     const uint32_t P = base_->num_players();
     const uint32_t M = base_->num_moves();
     const size_t csz = base_->canonical_size();
-    while (!awaiting_inference_.empty()) {
+    while (!queue.empty()) {
       const uint32_t n = static_cast<uint32_t>(
-          std::min<size_t>(awaiting_inference_.size(), std::max<uint32_t>(1, params_.max_batch_size)));
-      std::vector<uint32_t> idx(awaiting_inference_.begin(), awaiting_inference_.begin() + n);
-      awaiting_inference_.erase(awaiting_inference_.begin(), awaiting_inference_.begin() + n);
+          std::min<size_t>(queue.size(), std::max<uint32_t>(1, params_.max_batch_size)));
+      std::vector<uint32_t> idx(queue.begin(), queue.begin() + n);
+      queue.erase(queue.begin(), queue.begin() + n);
       std::vector<float> batch(n * csz), v(n * (P + 1)), pi(static_cast<size_t>(n) * M);
       for (uint32_t r = 0; r < n; ++r)
         std::copy(slots_[idx[r]].canonical.begin(), slots_[idx[r]].canonical.end(), batch.begin() + r * csz);
-      nn(batch.data(), n, v.data(), pi.data());
+      nn(group, batch.data(), n, v.data(), pi.data());
       nn_evals_ += n;
       for (uint32_t r = 0; r < n; ++r) {  // update_inferences, play_manager.cc:619-642
         Slot& g = slots_[idx[r]];
         std::copy(v.begin() + r * (P + 1), v.begin() + (r + 1) * (P + 1), g.v.begin());
         std::copy(pi.begin() + static_cast<size_t>(r) * M, pi.begin() + static_cast<size_t>(r + 1) * M, g.pi.begin());
-        if (cache_) cache_->insert(g.leaf_hash, g.pi.data(), g.v.data());
+        if (!caches_.empty()) caches_[group]->insert(g.leaf_hash, g.pi.data(), g.v.data());
       }
       for (uint32_t r = 0; r < n; ++r) awaiting_mcts_.push_back(idx[r]);
     }
@@ -433,8 +496,16 @@ class PlayManager {
   bool per_slot_rng_;
   std::vector<Pcg32> tree_rng_, coin_rng_;
   std::vector<Slot> slots_;
-  std::deque<uint32_t> awaiting_mcts_, awaiting_inference_;
-  std::unique_ptr<ShardedS3Fifo> cache_;
+  std::deque<uint32_t> awaiting_mcts_;
+  std::vector<std::deque<uint32_t>> awaiting_inference_;   // one queue per model group
+  std::vector<std::unique_ptr<ShardedS3Fifo>> caches_;
+  uint32_t num_model_groups_ = 1;
+  std::vector<EvalType> eval_types_;                       // per model group
+  std::vector<std::vector<uint8_t>> seat_perms_, seat_fpu_zero_;
+  std::vector<std::vector<uint32_t>> seat_visits_, seat_cap_visits_;
+  std::vector<std::vector<float>> seat_epsilon_, seat_root_temp_;
+  std::vector<std::vector<float>> perm_scores_;
+  std::vector<uint32_t> perm_games_;
   std::vector<HistoryRow> history_;
   std::vector<MoveRecord> moves_;
   std::vector<float> scores_, resign_scores_;

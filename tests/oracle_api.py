@@ -230,7 +230,38 @@ class OrcPlayParams(C.Structure):
                 ("root_fpu_zero", C.c_int32), ("shaped_dirichlet", C.c_int32), ("policy_target_pruning", C.c_int32),
                 ("resign_percent", C.c_float), ("resign_playthrough_percent", C.c_float), ("eval_type", C.c_int32 * 4),
                 ("gumbel_enabled", C.c_int32), ("gumbel_m", C.c_uint32), ("gumbel_c_visit", C.c_float),
-                ("gumbel_c_scale", C.c_float), ("gumbel_full", C.c_int32), ("fast_search_uses_gumbel", C.c_int32)]
+                ("gumbel_c_scale", C.c_float), ("gumbel_full", C.c_int32), ("fast_search_uses_gumbel", C.c_int32),
+                ("num_model_groups_given", C.c_uint32), ("model_groups", C.c_uint8 * 4),
+                ("num_seat_perms", C.c_uint32), ("seat_perms", (C.c_uint8 * 4) * 8),
+                ("has_seat_visits", C.c_int32), ("has_seat_cap_visits", C.c_int32), ("has_seat_epsilon", C.c_int32),
+                ("has_seat_mcts_root_temp", C.c_int32), ("has_seat_root_fpu_zero", C.c_int32),
+                ("seat_visits", (C.c_uint32 * 4) * 8), ("seat_cap_visits", (C.c_uint32 * 4) * 8),
+                ("seat_epsilon", (C.c_float * 4) * 8), ("seat_mcts_root_temp", (C.c_float * 4) * 8),
+                ("seat_root_fpu_zero", (C.c_uint8 * 4) * 8), ("perm_base", C.c_uint32)]
+
+
+GROUP_EVAL_FN = C.CFUNCTYPE(None, C.c_uint32, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p)
+
+
+def fill_seat_fields(c, pp):
+    """model_groups / seat_perms / seat_* matrices of a PlayParams-shaped object into a ctypes params struct
+    (shared by the oracle and, through alphazero._capi, the engine: same field names)."""
+    groups = list(getattr(pp, "model_groups", []) or [])
+    c.num_model_groups_given = len(groups)
+    for i, g in enumerate(groups):
+        c.model_groups[i] = int(g)
+    perms = [list(p) for p in (getattr(pp, "seat_perms", []) or [])]
+    c.num_seat_perms = len(perms)
+    for q, row in enumerate(perms):
+        for sidx, g in enumerate(row):
+            c.seat_perms[q][sidx] = int(g)
+    for name, cast in (("seat_visits", int), ("seat_cap_visits", int), ("seat_epsilon", float), ("seat_mcts_root_temp", float),
+                       ("seat_root_fpu_zero", int)):
+        mat = getattr(pp, name, []) or []
+        setattr(c, "has_" + name, int(bool(mat)))
+        for q, row in enumerate(mat):
+            for sidx, x in enumerate(row):
+                getattr(c, name)[q][sidx] = cast(x)
 
 
 EVAL_FN = C.CFUNCTYPE(None, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p)
@@ -260,12 +291,14 @@ def params_from(pp, num_players):
         c.eval_type[i] = -1
     for i, e in enumerate(pp.eval_type):
         c.eval_type[i] = int(e)
+    fill_seat_fields(c, pp)
     return c
 
 
 class PlayManager:
-    def __init__(self, game_id, pp, seed, per_slot_rng=True, record_moves=True, num_players=2):
+    def __init__(self, game_id, pp, seed, per_slot_rng=True, record_moves=True, num_players=2, perm_base=0):
         self.c = params_from(pp, num_players)
+        self.c.perm_base = int(perm_base)
         self.h = C.c_void_p(lib.orc_pm_new(game_id, C.byref(self.c), C.c_uint64(seed), int(per_slot_rng), int(record_moves)))
         if not self.h.value:
             raise RuntimeError("oracle PlayManager construction failed")
@@ -295,6 +328,28 @@ class PlayManager:
             rc = lib.orc_pm_run(self.h, self._cb, None)
         if rc != 0:
             raise RuntimeError("oracle PlayManager.run failed")
+
+    def run_groups(self, evaluator):
+        """evaluator(group, canonical[n,C,H,W]) -> (v, pi): one evaluator per model group (play_manager.cc:577-597)."""
+        chw, P, M = self.chw, self.P, self.M
+
+        def cb(group, canon, n, v, pi, _user):
+            x = np.ctypeslib.as_array(canon, shape=(n,) + tuple(chw))
+            vv, pp = evaluator(int(group), x.copy())
+            np.ctypeslib.as_array(v, shape=(n, P + 1))[:] = vv
+            np.ctypeslib.as_array(pi, shape=(n, M))[:] = pp
+
+        self._gcb = GROUP_EVAL_FN(cb)
+        if lib.orc_pm_run_groups(self.h, self._gcb, None) != 0:
+            raise RuntimeError("oracle PlayManager.run_groups failed")
+
+    def num_model_groups(self): return int(lib.orc_pm_num_groups(self.h))
+    def num_seat_perms(self): return int(lib.orc_pm_num_perms(self.h))
+
+    def perm_scores(self, perm):
+        out = np.zeros(self.P + 1, np.float32)
+        n = lib.orc_pm_perm_scores(self.h, C.c_uint32(perm), _p(out))
+        return out, int(n)
 
     def scores(self):
         out = np.zeros(self.P + 1, np.float32); lib.orc_pm_scores(self.h, _p(out)); return out

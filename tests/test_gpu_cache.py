@@ -69,6 +69,7 @@ def test_engine_with_cache_is_transparent(oracle):
     import alphazero as az
     pp = az.PlayParams()
     pp.games_to_play, pp.concurrent_games, pp.max_batch_size = 12, 12, 12
+    pp.model_groups = [0, 0]
     pp.mcts_visits = [40, 40]
     pp.cpuct, pp.fpu_reduction = 1.25, 0.25
     pp.history_enabled = True

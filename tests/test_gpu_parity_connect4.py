@@ -201,6 +201,7 @@ def test_host_buffer_path_matches_device_path(oracle):
 
     pp = az.PlayParams()
     pp.games_to_play, pp.concurrent_games, pp.max_batch_size = 6, 6, 4
+    pp.model_groups = [0, 0]     # one evaluator for both seats (game_runner.set_model_groups)
     pp.mcts_visits = [30, 30]
     pp.cpuct, pp.fpu_reduction = 1.25, 0.25
     pp.history_enabled = True
