@@ -292,14 +292,14 @@ struct TaflX {
   static constexpr int STATE_WORDS = 5;
   using State = Tawlbwrdd::State;
 
-  __host__ __device__ static uint32_t player_from_words(const uint64_t* words, uint32_t S, uint32_t slot) {
+  __host__ __device__ __forceinline__ static uint32_t player_from_words(const uint64_t* words, uint32_t S, uint32_t slot) {
     return static_cast<uint32_t>(words[4 * static_cast<size_t>(S) + slot] >> 24) & 1u;
   }
-  __host__ __device__ static bool bit(const uint64_t (&b)[2], uint32_t sq) { return ((sq < 64 ? b[0] : b[1]) >> (sq & 63)) & 1ULL; }
-  __host__ __device__ static void setb(uint64_t (&b)[2], uint32_t sq) { if (sq < 64) b[0] |= 1ULL << sq; else b[1] |= 1ULL << (sq - 64); }
-  __host__ __device__ static void clrb(uint64_t (&b)[2], uint32_t sq) { if (sq < 64) b[0] &= ~(1ULL << sq); else b[1] &= ~(1ULL << (sq - 64)); }
+  __host__ __device__ __forceinline__ static bool bit(const uint64_t (&b)[2], uint32_t sq) { return ((sq < 64 ? b[0] : b[1]) >> (sq & 63)) & 1ULL; }
+  __host__ __device__ __forceinline__ static void setb(uint64_t (&b)[2], uint32_t sq) { if (sq < 64) b[0] |= 1ULL << sq; else b[1] |= 1ULL << (sq - 64); }
+  __host__ __device__ __forceinline__ static void clrb(uint64_t (&b)[2], uint32_t sq) { if (sq < 64) b[0] &= ~(1ULL << sq); else b[1] &= ~(1ULL << (sq - 64)); }
 
-  __host__ __device__ static State initial() {
+  __host__ __device__ __forceinline__ static State initial() {
     State s{};
     s.king = T * W + T;
     if (kOpen) {  // opentafl_gs.h:90-135
@@ -319,7 +319,7 @@ struct TaflX {
   }
   // a position given as the reference's board tensor: int8 [3][N][N] (king, defenders, attackers) + player + turn
   // (the test helper MakeGS, opentafl_gs_test.cc:97-101: empty repetition map, count 1)
-  __host__ __device__ static State from_board(const uint8_t* b, uint32_t player, uint32_t turn) {
+  __host__ __device__ __forceinline__ static State from_board(const uint8_t* b, uint32_t player, uint32_t turn) {
     State s{};
     s.king = kNoKing;
     for (uint32_t sq = 0; sq < static_cast<uint32_t>(SQ); ++sq) {
@@ -330,19 +330,19 @@ struct TaflX {
     s.turn = turn; s.player = player & 1u; s.rep = 1;
     return s;
   }
-  __host__ __device__ static bool corner(int h, int w) { return (h == 0 || h == H - 1) && (w == 0 || w == W - 1); }
-  __host__ __device__ static bool occupied(const State& s, uint32_t sq) { return bit(s.def, sq) || bit(s.atk, sq) || s.king == sq; }
-  __host__ __device__ static bool own_piece(const State& s, uint32_t p, uint32_t sq) {
+  __host__ __device__ __forceinline__ static bool corner(int h, int w) { return (h == 0 || h == H - 1) && (w == 0 || w == W - 1); }
+  __host__ __device__ __forceinline__ static bool occupied(const State& s, uint32_t sq) { return bit(s.def, sq) || bit(s.atk, sq) || s.king == sq; }
+  __host__ __device__ __forceinline__ static bool own_piece(const State& s, uint32_t p, uint32_t sq) {
     return p == 0 ? bit(s.atk, sq) : (bit(s.def, sq) || s.king == sq);
   }
   // is_valid_square, brandubh_gs.cc:138-154 / opentafl_gs.cc:137-153
-  __host__ __device__ static bool valid_square(const State& s, bool is_king, int h, int w) {
+  __host__ __device__ __forceinline__ static bool valid_square(const State& s, bool is_king, int h, int w) {
     if (w < 0 || w >= W || h < 0 || h >= H) return false;
     if (corner(h, w)) return is_king;
     return !occupied(s, h * W + w);
   }
   // 2N-bit target mask of the piece on sq: bits 0..N-1 = new_w (row slides), bits N..2N-1 = new_h
-  __host__ __device__ static uint32_t slide_mask(const State& s, uint32_t sq) {
+  __host__ __device__ __forceinline__ static uint32_t slide_mask(const State& s, uint32_t sq) {
     const int h = sq / W, w = sq % W;
     const bool k = s.king == sq;
     uint32_t m = 0;
@@ -352,23 +352,23 @@ struct TaflX {
     for (int t = h - 1; valid_square(s, k, t, w); --t) { if (t == T && w == T && !k) continue; m |= 1u << (W + t); }
     return m;
   }
-  __host__ __device__ static bool has_valid_moves(const State& s) {  // brandubh_gs.cc:156-213 / opentafl_gs.cc:155-212
+  __host__ __device__ __forceinline__ static bool has_valid_moves(const State& s) {  // brandubh_gs.cc:156-213 / opentafl_gs.cc:155-212
     for (uint32_t sq = 0; sq < static_cast<uint32_t>(SQ); ++sq)
       if (own_piece(s, s.player, sq) && slide_mask(s, sq) != 0) return true;
     return false;
   }
-  __host__ __device__ static void remove_at(State& s, uint32_t sq) {
+  __host__ __device__ __forceinline__ static void remove_at(State& s, uint32_t sq) {
     clrb(s.def, sq); clrb(s.atk, sq);
     if (s.king == sq) s.king = kNoKing;
   }
   // is_hostile_to, brandubh_gs.cc:278-305 / opentafl_gs.cc:277-297: is (h, w) hostile to a piece of player p
-  __host__ __device__ static bool hostile_to(const State& s, uint32_t p, int h, int w) {
+  __host__ __device__ __forceinline__ static bool hostile_to(const State& s, uint32_t p, int h, int w) {
     if (corner(h, w)) return true;
     if (h == T && w == T) return p == 1 ? s.king != static_cast<uint32_t>(T * W + T) : true;
     return own_piece(s, p ^ 1u, h * W + w);
   }
   // captured(), brandubh_gs.cc:307-340 / opentafl_gs.cc:299-334: mover sits on (fh, fw), victim one step along (dh, dw)
-  __host__ __device__ static bool captured(const State& s, uint32_t mover, int fh, int fw, int dh, int dw) {
+  __host__ __device__ __forceinline__ static bool captured(const State& s, uint32_t mover, int fh, int fw, int dh, int dw) {
     const int th = fh + dh, tw = fw + dw;
     if (tw < 0 || tw >= W || th < 0 || th >= H) return false;
     const uint32_t tsq = th * W + tw;
@@ -381,7 +381,7 @@ struct TaflX {
     if (zw < 0 || zw >= W || zh < 0 || zh >= H) return false;
     return hostile_to(s, mover ^ 1u, zh, zw);
   }
-  __host__ __device__ static bool apply_move(State& s, uint32_t mv, bool* captured_any, bool unchecked = false) {
+  __host__ __device__ __forceinline__ static bool apply_move(State& s, uint32_t mv, bool* captured_any, bool unchecked = false) {
     *captured_any = false;
     if (mv >= static_cast<uint32_t>(M)) return false;
     uint32_t new_loc = mv % (W + H);
@@ -412,29 +412,29 @@ struct TaflX {
     ++s.turn;
     return true;
   }
-  __host__ __device__ static uint64_t rep_key(const State& s) {
+  __host__ __device__ __forceinline__ static uint64_t rep_key(const State& s) {
     uint64_t k = mix64(s.def[0] ^ (kOpen ? 0x0F7AULL : 0xB7A0ULL));
     k = mix64(k ^ s.def[1]); k = mix64(k ^ s.atk[0]); k = mix64(k ^ s.atk[1]);
     return mix64(k ^ (static_cast<uint64_t>(s.king) | (static_cast<uint64_t>(s.player) << 8)));
   }
   // evaluation-cache key: board, player, repetition count (+ turn for OpenTafl, opentafl_gs.cc:102-108)
-  __host__ __device__ static uint64_t key(const State& s) {
+  __host__ __device__ __forceinline__ static uint64_t key(const State& s) {
     const uint64_t k = mix64(rep_key(s) ^ (static_cast<uint64_t>(s.rep) << 32));
     return kOpen ? mix64(k ^ (static_cast<uint64_t>(s.turn) << 16)) : k;
   }
   // ---- encirclement (opentafl_gs.cc:466-506): flood fill from the rim over squares without attackers; the
   // defenders can still reach the edge iff the filled region meets a defender or the king.  121-bit boards.
   struct B128 { uint64_t lo, hi; };
-  __host__ __device__ static B128 shl(B128 x, int n) { return B128{x.lo << n, (x.hi << n) | (x.lo >> (64 - n))}; }
-  __host__ __device__ static B128 shr(B128 x, int n) { return B128{(x.lo >> n) | (x.hi << (64 - n)), x.hi >> n}; }
-  __host__ __device__ static B128 band(B128 a, B128 b) { return B128{a.lo & b.lo, a.hi & b.hi}; }
-  __host__ __device__ static B128 bor(B128 a, B128 b) { return B128{a.lo | b.lo, a.hi | b.hi}; }
-  __host__ __device__ static B128 column(int w) {
+  __host__ __device__ __forceinline__ static B128 shl(B128 x, int n) { return B128{x.lo << n, (x.hi << n) | (x.lo >> (64 - n))}; }
+  __host__ __device__ __forceinline__ static B128 shr(B128 x, int n) { return B128{(x.lo >> n) | (x.hi << (64 - n)), x.hi >> n}; }
+  __host__ __device__ __forceinline__ static B128 band(B128 a, B128 b) { return B128{a.lo & b.lo, a.hi & b.hi}; }
+  __host__ __device__ __forceinline__ static B128 bor(B128 a, B128 b) { return B128{a.lo | b.lo, a.hi | b.hi}; }
+  __host__ __device__ __forceinline__ static B128 column(int w) {
     B128 m{0, 0};
     for (int h = 0; h < H; ++h) { const int sq = h * W + w; if (sq < 64) m.lo |= 1ULL << sq; else m.hi |= 1ULL << (sq - 64); }
     return m;
   }
-  __host__ __device__ static bool encircled(const State& s) {
+  __host__ __device__ __forceinline__ static bool encircled(const State& s) {
     constexpr uint64_t hi_mask = SQ > 64 ? ((1ULL << ((SQ > 64 ? SQ : 65) - 64)) - 1) : 0ULL;
     constexpr uint64_t lo_mask = SQ >= 64 ? ~0ULL : ((1ULL << (SQ < 64 ? SQ : 0)) - 1);
     const B128 all{lo_mask, hi_mask};
@@ -458,7 +458,7 @@ struct TaflX {
     return ((reach.lo & dlo) | (reach.hi & dhi)) == 0;
   }
   // scores(), brandubh_gs.cc:441-488 / opentafl_gs.cc:430-520 — 0 running, else 1 + index of the winning entry
-  __host__ __device__ static uint32_t terminal(const State& s) {
+  __host__ __device__ __forceinline__ static uint32_t terminal(const State& s) {
     if (s.rep >= 3) return 1 + s.player;
     if (s.king != kNoKing) {
       if (corner(s.king / W, s.king % W)) return 2;
@@ -470,7 +470,7 @@ struct TaflX {
     if (s.turn >= static_cast<uint32_t>(MAX_TURNS)) return 3;
     return 0;
   }
-  __host__ __device__ static float canonical_at(const State& s, uint32_t e) {
+  __host__ __device__ __forceinline__ static float canonical_at(const State& s, uint32_t e) {
     const uint32_t plane = e / SQ, sq = e % SQ;
     switch (plane) {
       case 0: return s.king == sq ? 1.0f : 0.0f;

@@ -57,7 +57,7 @@ struct BigSlot {
   __device__ __forceinline__ float seat_eps(uint32_t seat) const { return AZB_SEL(sv_eps, seat); }
   __device__ __forceinline__ float seat_root_temp(uint32_t seat) const { return AZB_SEL(sv_rt, seat); }
 
-  __device__ BigSlot(const EngineParams& e, const EngineArrays& a, BigScratch<GM>& s, uint32_t sl, uint32_t l)
+  __device__ __forceinline__ BigSlot(const EngineParams& e, const EngineArrays& a, BigScratch<GM>& s, uint32_t sl, uint32_t l)
       : ep(e), ar(a), sm(s), slot(sl), lane(l) {}
 
   __device__ __forceinline__ size_t tree_base(uint32_t seat) const { return (static_cast<size_t>(slot) * P + seat) * ep.cap; }
@@ -74,7 +74,7 @@ struct BigSlot {
   }
 
   // ---- load / store -----------------------------------------------------------------------------------
-  __device__ void load() {
+  __device__ __forceinline__ void load() {
     rng.state = ar.rng[slot]; coin.state = ar.coin[slot]; flags = ar.flags[slot];
     const uint32_t S = ep.S;
     const uint64_t w0 = ar.gs_words[0 * S + slot], w1 = ar.gs_words[1 * S + slot], w2 = ar.gs_words[2 * S + slot],
@@ -98,7 +98,7 @@ struct BigSlot {
     for (uint32_t i = lane; i < glen; i += G) sm.glist[i] = gl[i];
     sync();
   }
-  __device__ void store(uint8_t sstate) const {
+  __device__ __forceinline__ void store(uint8_t sstate) const {
     if (lane != 0) return;
     ar.rng[slot] = rng.state; ar.coin[slot] = coin.state; ar.flags[slot] = flags; ar.sstate[slot] = sstate;
     const uint32_t S = ep.S;
@@ -113,7 +113,7 @@ struct BigSlot {
     }
     ar.cur[slot] = cur; ar.plen[slot] = plen; ar.ph_count[slot] = ph_rows; ar.rep_len[slot] = glen;
   }
-  __device__ void reset_tree(uint32_t seat) {
+  __device__ __forceinline__ void reset_tree(uint32_t seat) {
     set_seat(t_root, seat, 0); set_seat(t_bump, seat, 1); set_seat(t_depth, seat, 0);
 #pragma unroll
     for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == seat) t_tld[p] = 0;
@@ -124,7 +124,7 @@ struct BigSlot {
 
   // ---- repetition-aware move on a state; `list`/`len` is the list the new position is appended to --------
   // base list = glist[0, glen) unless a capture cleared it (tawlbwrdd_gs.cc:246-332)
-  __device__ bool step_state(typename GM::State& st, uint32_t mv, uint64_t* list, uint32_t& len, bool& base_valid,
+  __device__ __forceinline__ bool step_state(typename GM::State& st, uint32_t mv, uint64_t* list, uint32_t& len, bool& base_valid,
                              uint32_t base_len) {
     if (st.turn == 0) {  // the start position enters the map with count 1 at the first move
       if (lane == 0) list[len] = GM::rep_key(st);
@@ -149,7 +149,7 @@ struct BigSlot {
   }
 
   // ---- Node::add_children: legal moves ascending (from the bitboards), std::shuffle, append -------------
-  __device__ bool expand_node(uint32_t seat, uint32_t node, const typename GM::State& st, uint64_t meta_keep,
+  __device__ __forceinline__ bool expand_node(uint32_t seat, uint32_t node, const typename GM::State& st, uint64_t meta_keep,
                               uint32_t& c0_out, uint32_t& k_out) {
     const size_t tb = tree_base(seat);
     // move generation: lane handles squares lane and lane + 64
@@ -230,16 +230,16 @@ struct BigSlot {
   __device__ __forceinline__ uint32_t* gum_state(uint32_t seat) const { return ar.gum_state + (static_cast<size_t>(slot) * P + seat) * 8; }
   __device__ __forceinline__ float* gum_g(uint32_t seat) const { return ar.gum_g + (static_cast<size_t>(slot) * P + seat) * ep.gum_stride; }
   __device__ __forceinline__ uint16_t* gum_surv(uint32_t seat) const { return ar.gum_surv + (static_cast<size_t>(slot) * P + seat) * kGumMaxM; }
-  __device__ void reset_gumbel_state(uint32_t seat) const {
+  __device__ __forceinline__ void reset_gumbel_state(uint32_t seat) const {
     if (lane != 0) return;
     uint32_t* st = gum_state(seat);
     st[kGumInit] = 0; st[kGumNSurv] = 0; st[kGumPhase] = 0; st[kGumSims] = 0; st[kGumMEff] = 0; st[kGumRemain] = 0;
   }
-  __device__ void set_gumbel_num_sims(uint32_t seat, uint32_t n) const {
+  __device__ __forceinline__ void set_gumbel_num_sims(uint32_t seat, uint32_t n) const {
     if (lane == 0) gum_state(seat)[kGumTarget] = n;
     reset_gumbel_state(seat);
   }
-  __device__ void set_gumbel_target() const {   // play_manager.cc:525-539 / 561-570
+  __device__ __forceinline__ void set_gumbel_target() const {   // play_manager.cc:525-539 / 561-570
     if (!ep.gumbel_on) return;
     const uint32_t cp = gs.player;
     const uint32_t target = (flags & kFlagCapped) ? (ep.fast_gumbel ? seat_cap_visits(cp) : 0u) : seat_visits(cp);
@@ -251,7 +251,7 @@ struct BigSlot {
     return x;
   }
   // init_gumbel_state, mcts.cc:190-227
-  __device__ void init_gumbel_state(uint32_t seat, size_t tb, uint32_t c0, uint32_t k) {
+  __device__ __forceinline__ void init_gumbel_state(uint32_t seat, size_t tb, uint32_t c0, uint32_t k) {
     if (k == 0) return;
     uint32_t* st = gum_state(seat);
     const uint32_t target = st[kGumTarget], depth = AZB_SEL(t_depth, seat);
@@ -281,7 +281,7 @@ struct BigSlot {
     sync();
   }
   // score g + log(prior) + sigma * q_hat of survivor `lane` (mcts.cc:241-253, 385-397); lanes >= nsurv get -inf
-  __device__ float survivor_score(uint32_t seat, size_t tb, uint32_t c0, uint32_t nsurv, uint32_t max_visit, uint32_t& ci) const {
+  __device__ __forceinline__ float survivor_score(uint32_t seat, size_t tb, uint32_t c0, uint32_t nsurv, uint32_t max_visit, uint32_t& ci) const {
     ci = 0;
     if (lane >= nsurv) return -__builtin_inff();
     ci = gum_surv(seat)[lane];
@@ -292,7 +292,7 @@ struct BigSlot {
     return sc != sc ? -__builtin_inff() : sc;
   }
   // gumbel_next_root_child (mcts.cc:266-283) with gumbel_advance_phase (mcts.cc:229-264) inlined
-  __device__ uint32_t gumbel_next_root_child(uint32_t seat, size_t tb, uint32_t c0) {
+  __device__ __forceinline__ uint32_t gumbel_next_root_child(uint32_t seat, size_t tb, uint32_t c0) {
     sync();
     uint32_t* st = gum_state(seat);
     uint16_t* surv = gum_surv(seat);
@@ -327,7 +327,7 @@ struct BigSlot {
   }
   // exp terms of softmax(log prior + sigma * completedQ) over the children staged in LDS (n: sm.n, q: f1, p: f2)
   // -> sm.f0[0..k); returns their in-order sum (mcts.cc:285-373 share this)
-  __device__ float gumbel_pi_prime(uint32_t k, float node_v) {
+  __device__ __forceinline__ float gumbel_pi_prime(uint32_t k, float node_v) {
     float sum_visits = 0.0f, sum_priors_visited = 0.0f, weighted_num = 0.0f;   // compute_v_mix_from_children, mcts.cc:71-89
     for (uint32_t i = 0; i < k; ++i) {
       const uint32_t ni = sm.n[i];
@@ -356,7 +356,7 @@ struct BigSlot {
     return seq_sum_f0(k);
   }
   // gumbel_interior_select, mcts.cc:285-334
-  __device__ uint32_t gumbel_interior_select(size_t tb, uint32_t c0, uint32_t k, float node_v) {
+  __device__ __forceinline__ uint32_t gumbel_interior_select(size_t tb, uint32_t c0, uint32_t k, float node_v) {
     for (uint32_t i = lane; i < k; i += G) {
       const size_t ci = tb + c0 + i;
       sm.n[i] = ar.N[ci]; sm.f1[i] = ar.Q[ci]; sm.f2[i] = ar.Pr[ci];
@@ -384,7 +384,7 @@ struct BigSlot {
     return best_i;
   }
   // gumbel_improved_policy into sm.dense (mcts.cc:336-373); the root must be staged (stage_root)
-  __device__ void gumbel_improved_policy(uint32_t k, float root_v) {
+  __device__ __forceinline__ void gumbel_improved_policy(uint32_t k, float root_v) {
     dense_zero();
     if (k == 0) return;
     const float z_sum = gumbel_pi_prime(k, root_v);
@@ -393,7 +393,7 @@ struct BigSlot {
     sync();
   }
   // gumbel_final_action (mcts.cc:375-401); the root must be staged; returns the move
-  __device__ uint32_t gumbel_final_action(uint32_t seat, size_t tb, uint32_t c0, uint32_t k) {
+  __device__ __forceinline__ uint32_t gumbel_final_action(uint32_t seat, size_t tb, uint32_t c0, uint32_t k) {
     sync();
     const uint32_t* st = gum_state(seat);
     const uint32_t nsurv = st[kGumNSurv];
@@ -414,7 +414,7 @@ struct BigSlot {
   }
 
   // ---- Node::best_child over k children starting at c0 -------------------------------------------------------
-  __device__ uint32_t select_child(size_t tb, uint32_t c0, uint32_t k, float v_parent, uint32_t n_parent, float fpu_reduction) {
+  __device__ __forceinline__ uint32_t select_child(size_t tb, uint32_t c0, uint32_t k, float v_parent, uint32_t n_parent, float fpu_reduction) {
     for (uint32_t i = lane; i < k; i += G) {
       const size_t ci = tb + c0 + i;
       const uint32_t n = ar.N[ci];
@@ -446,7 +446,7 @@ struct BigSlot {
   }
 
   // ---- MCTS::find_leaf ------------------------------------------------------------------------------------------
-  __device__ bool find_leaf(uint32_t seat, typename GM::State& leaf, uint32_t& term) {
+  __device__ __forceinline__ bool find_leaf(uint32_t seat, typename GM::State& leaf, uint32_t& term) {
     sync();
     const size_t tb = tree_base(seat);
     const uint32_t root = AZB_SEL(t_root, seat);
@@ -494,7 +494,7 @@ struct BigSlot {
   }
 
   // ---- MCTS::add_root_noise over the children whose priors sit in sm.f0[0..k) --------------------------------------
-  __device__ void add_root_noise(uint32_t k, float eps) {
+  __device__ __forceinline__ void add_root_noise(uint32_t k, float eps) {
     double sum = 0.0;
     if (ep.shaped && k > 1) {
       const float Nf = static_cast<float>(k);
@@ -533,7 +533,7 @@ struct BigSlot {
   }
 
   // ---- MCTS::process_result --------------------------------------------------------------------------------------------
-  __device__ void process_result(uint32_t seat, bool from_net, bool root_noise) {
+  __device__ __forceinline__ void process_result(uint32_t seat, bool from_net, bool root_noise) {
     sync();
     const size_t tb = tree_base(seat);
     const uint32_t root = AZB_SEL(t_root, seat);
@@ -609,15 +609,15 @@ struct BigSlot {
     for (uint32_t m = 0; m < static_cast<uint32_t>(M); ++m) s += sm.dense[m];
     return s;
   }
-  __device__ void dense_zero() { for (uint32_t m = lane; m < static_cast<uint32_t>(M); m += G) sm.dense[m] = 0.0f; sync(); }
-  __device__ void dense_div(float s) { for (uint32_t m = lane; m < static_cast<uint32_t>(M); m += G) sm.dense[m] = sm.dense[m] / s; sync(); }
-  __device__ void dense_pow(float e) {
+  __device__ __forceinline__ void dense_zero() { for (uint32_t m = lane; m < static_cast<uint32_t>(M); m += G) sm.dense[m] = 0.0f; sync(); }
+  __device__ __forceinline__ void dense_div(float s) { for (uint32_t m = lane; m < static_cast<uint32_t>(M); m += G) sm.dense[m] = sm.dense[m] / s; sync(); }
+  __device__ __forceinline__ void dense_pow(float e) {
     if (e == 1.0f) return;
     for (uint32_t m = lane; m < static_cast<uint32_t>(M); m += G) sm.dense[m] = az_powf(sm.dense[m], e);
     sync();
   }
   // root children staged in LDS: moves, n (sm.n), q (f1), p (f2)
-  __device__ void stage_root(size_t tb, uint32_t c0, uint32_t k) {
+  __device__ __forceinline__ void stage_root(size_t tb, uint32_t c0, uint32_t k) {
     for (uint32_t i = lane; i < k; i += G) {
       const size_t ci = tb + c0 + i;
       sm.moves[i] = static_cast<uint16_t>(meta_mv(ar.META[ci]));
@@ -626,7 +626,7 @@ struct BigSlot {
     sync();
   }
   // MCTS::probs into sm.dense (mcts.cc:575-618)
-  __device__ void probs(float temp, uint32_t k) {
+  __device__ __forceinline__ void probs(float temp, uint32_t k) {
     dense_zero();
     for (uint32_t i = lane; i < k; i += G) sm.dense[sm.moves[i]] = static_cast<float>(sm.n[i]);
     sync();
@@ -657,7 +657,7 @@ struct BigSlot {
     dense_div(dense_seq_sum());
   }
   // MCTS::probs_pruned into sm.dense (mcts.cc:620-674), temp == 1 or general
-  __device__ void probs_pruned(float temp, uint32_t root_n, uint32_t k) {
+  __device__ __forceinline__ void probs_pruned(float temp, uint32_t root_n, uint32_t k) {
     if (root_n <= 1) { probs(temp, k); return; }
     const float explore_scaling = ep.cpuct * sqrtf(static_cast<float>(root_n));
     float best_sel = -1e30f;
@@ -693,7 +693,7 @@ struct BigSlot {
     dense_div(total);
     if (temp != 1.0f) { dense_pow(1.0f / temp); dense_div(dense_seq_sum()); }
   }
-  __device__ uint32_t pick_move() {  // mcts.cc:717-735 on sm.dense
+  __device__ __forceinline__ uint32_t pick_move() {  // mcts.cc:717-735 on sm.dense
     const float choice = canonical01(rng) * 1.0f + 0.0f;
     float sum = 0.0f;
     for (uint32_t m = 0; m < static_cast<uint32_t>(M); ++m) {
@@ -706,7 +706,7 @@ struct BigSlot {
     return 0;
   }
 
-  __device__ bool update_root(uint32_t seat, uint32_t move) {
+  __device__ __forceinline__ bool update_root(uint32_t seat, uint32_t move) {
     sync();
     const size_t tb = tree_base(seat);
     const uint32_t root = AZB_SEL(t_root, seat);
@@ -725,7 +725,7 @@ struct BigSlot {
     return true;
   }
 
-  __device__ void reapply_root_prior(uint32_t seat, bool noise) {
+  __device__ __forceinline__ void reapply_root_prior(uint32_t seat, bool noise) {
     sync();
     const size_t tb = tree_base(seat);
     const uint32_t root = AZB_SEL(t_root, seat);
@@ -752,18 +752,18 @@ struct BigSlot {
     sync();
   }
 
-  __device__ void start_game() {
+  __device__ __forceinline__ void start_game() {
     gs = GM::initial();
     for (uint32_t s = 0; s < static_cast<uint32_t>(P); ++s) reset_tree(s);
     ph_rows = 0;
     glen = 0;
   }
-  __device__ void draw_capped() {
+  __device__ __forceinline__ void draw_capped() {
     const bool capped = ep.cap_rand && (canonical01(coin) < ep.cap_percent);
     flags = capped ? (flags | kFlagCapped) : (flags & ~kFlagCapped);
   }
 
-  __device__ bool make_move(uint32_t cp) {
+  __device__ __forceinline__ bool make_move(uint32_t cp) {
     sync();
     const size_t tb = tree_base(cp);
     const bool capped = flags & kFlagCapped;
@@ -905,7 +905,7 @@ struct BigSlot {
     return false;
   }
 
-  __device__ void end_game(uint32_t term, bool resigned) {
+  __device__ __forceinline__ void end_game(uint32_t term, bool resigned) {
     sync();
     const uint32_t S = ep.S;
     const uint32_t rows = ep.history ? ph_rows : 0u;
@@ -945,7 +945,7 @@ struct BigSlot {
     }
   }
 
-  __device__ uint64_t emit_leaf(const typename GM::State& leaf) const {
+  __device__ __forceinline__ uint64_t emit_leaf(const typename GM::State& leaf) const {
     float* row = ar.canon + static_cast<size_t>(slot) * GM::CANON;
     for (uint32_t e = lane; e < static_cast<uint32_t>(GM::CANON); e += G) row[e] = GM::canonical_at(leaf, e);
     const uint64_t key = GM::key(leaf);
