@@ -274,6 +274,18 @@ def main():
                 "per_launch_event_ms": nn_ms, "definition": "sum of algorithmic FLOPs of all k_leafnet launches in the timed region / wall time of the region",
             },
         }
+        # HBM-side traffic of the dominant kernel: not measurable from inside the process; taken from the committed
+        # rocprofv3 --pmc summary of this same command (scripts/gpu_pmc.sh -> profiles/r1_pmc_traffic.csv), per launch,
+        # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on gfx950
+        pmc = os.path.join(ROOT, "profiles", "r1_pmc_traffic.csv")
+        if not tafl and hip_net is not None and os.path.exists(pmc):
+            for line in open(pmc):
+                if line.startswith("k_leafnet"):
+                    f = line.strip().split(",")
+                    out["roofline"]["traffic"] = (2.0 * float(f[-2]) + float(f[-1])) * 1024.0
+                    out["roofline"]["traffic_note"] = ("bytes per k_leafnet launch at the L2-to-fabric counters (2 x FETCH_SIZE + WRITE_SIZE, "
+                                                       "profiles/r1_pmc_traffic.csv); ~8 x the 0.94 MB weight image: each of the 8 XCD L2s "
+                                                       "fetches it once per launch, served from Infinity Cache")
         if world == 1 and hip_net is not None and not args.playout_cap and not args.no_secondary and not tafl:
             # the same workload with playout-cap randomisation at the reference's self-play defaults
             # (fast_mcts_visits 25 on 75 % of moves, config.py:86,100): reported beside the headline, never as it
