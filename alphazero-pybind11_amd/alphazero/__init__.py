@@ -442,6 +442,113 @@ class TawlbwrddGS(GameState):  # py_wrapper.cc:549-560
         return out + "\n"
 
 
+class MCTS:
+    """The stand-alone search tree (py_wrapper.cc:192-220, mcts.h:50-200) on the device: find_leaf / process_result /
+    update_root and the read-outs, call by call.  Connect4 in this round.  `seed` seeds the object's pcg32 stream (the
+    reference shares one unseedable-from-Python thread_local stream; its C++ tests call MCTS::seed_thread_rng)."""
+
+    def __init__(self, cpuct, num_players, num_moves, epsilon=0.0, root_policy_temp=1.0, fpu_reduction=0.0,
+                 relative_values=False, root_fpu_zero=False, shaped_dirichlet=False, gumbel_enabled=False, gumbel_m=16,
+                 gumbel_c_visit=50.0, gumbel_c_scale=1.0, gumbel_full=False, *, game=None, seed=None, device=0,
+                 max_simulations=0):
+        game = Connect4GS if game is None else (game if isinstance(game, type) else type(game))
+        cfg = _capi.MctsConfigC(cpuct, num_players, num_moves, epsilon, root_policy_temp, fpu_reduction, int(relative_values),
+                                int(root_fpu_zero), int(shaped_dirichlet), int(gumbel_enabled), gumbel_m, gumbel_c_visit,
+                                gumbel_c_scale, int(gumbel_full), int(max_simulations))
+        if seed is None:
+            seed = int.from_bytes(__import__("os").urandom(8), "little")     # std::random_device, mcts.cc:19
+        h = C.c_void_p()
+        check(lib.azmi_mcts_create(game.GAME_ID, C.byref(cfg), C.c_uint64(seed), int(device), C.byref(h)))
+        self._h, self._game, self._P, self._M = h, game, num_players, num_moves
+        self._gumbel = bool(gumbel_enabled)
+        self._vec = max(num_moves, 64)
+
+    def __del__(self):
+        if getattr(self, "_h", None) and lib is not None:
+            lib.azmi_mcts_destroy(self._h)
+            self._h = None
+
+    @staticmethod
+    def _gs_args(gs):
+        init = None if gs._init is None else np.frombuffer(gs._init, np.uint8)
+        mv = np.array(gs._moves, dtype=np.int32)
+        return init, mv
+
+    def find_leaf(self, gs):
+        init, mv = self._gs_args(gs)
+        out = np.zeros(512, np.int32)
+        n = C.c_uint32()
+        check(lib.azmi_mcts_find_leaf(self._h, None if init is None else init.ctypes.data, 0 if init is None else init.size,
+                                      mv.ctypes.data if mv.size else None, mv.size, out.ctypes.data, out.size, C.byref(n)))
+        leaf = gs.copy()
+        for m in out[: n.value]:
+            leaf._moves.append(int(m))
+        leaf._snap = None
+        return leaf
+
+    def process_result(self, gs, value, pi, root_noise_enabled=False):
+        """value is updated in place like the reference's by-reference argument (terminal leaves: the cached scores)."""
+        v = np.ascontiguousarray(value, dtype=np.float32); p = np.ascontiguousarray(pi, dtype=np.float32)
+        if v.shape != (self._P + 1,) or p.shape != (self._M,):
+            raise RuntimeError("process_result: value must be [num_players + 1] and pi [num_moves]")
+        out = np.zeros(self._P + 1, np.float32)
+        check(lib.azmi_mcts_process_result(self._h, v.ctypes.data, p.ctypes.data, int(bool(root_noise_enabled)), out.ctypes.data))
+        if isinstance(value, np.ndarray) and value.dtype == np.float32:
+            value[...] = out
+        return out
+
+    def update_root(self, gs, move):
+        init, mv = self._gs_args(gs)
+        check(lib.azmi_mcts_update_root(self._h, None if init is None else init.ctypes.data, 0 if init is None else init.size,
+                                        mv.ctypes.data if mv.size else None, mv.size, int(move)))
+
+    def _query(self, kind, temp=0.0, arg=0, in_f=None):
+        f = np.zeros(self._vec, np.float32); u = np.zeros(self._vec + 64, np.uint32)
+        inp = None if in_f is None else np.ascontiguousarray(in_f, dtype=np.float32)
+        check(lib.azmi_mcts_query(self._h, kind, float(temp), int(arg), None if inp is None else inp.ctypes.data, f.ctypes.data, u.ctypes.data))
+        return f, u
+
+    def counts(self): return self._query(0)[1][: self._M].copy()
+    def probs(self, temp): return self._query(1, temp)[0][: self._M].copy()
+    def probs_pruned(self, temp): return self._query(2, temp)[0][: self._M].copy()
+    def root_value(self): return self._query(3)[0][:3].copy()
+    def root_q_values(self): return self._query(4)[0][: self._M].copy()
+    def depth(self): return int(self._query(5)[1][0])
+    def root_n(self): return int(self._query(5)[1][1])
+    def avg_leaf_depth(self): return float(self._query(5)[0][0])
+    def normalized_root_entropy(self): return float(self._query(5)[0][1])
+    def gumbel_enabled(self): return self._gumbel
+    def gumbel_improved_policy(self): return self._query(6)[0][: self._M].copy()
+    def gumbel_final_action(self): return int(self._query(7)[1][0])
+    def add_root_noise(self): self._query(8)
+    def apply_root_policy_temp(self): self._query(9)
+    def set_gumbel_num_sims(self, n): self._query(12, arg=n)
+
+    def principal_variation(self, depth=5):
+        u = self._query(11, arg=depth)[1]
+        return u[1: 1 + int(u[0])].copy()
+
+    def pick_move(self, pi):
+        """MCTS::pick_move (static in the reference, drawing from the thread's stream): draws from this object's stream."""
+        return int(self._query(10, in_f=pi)[1][0])
+
+    # the WU-UCT batched API (mcts.cc:752-851) is not implemented on the device
+    def find_leaf_batched(self, *a, **k): raise RuntimeError("find_leaf_batched is not implemented by the MI355X engine yet")
+    def process_result_batched(self, *a, **k): raise RuntimeError("process_result_batched is not implemented by the MI355X engine yet")
+    def in_flight_count(self): return 0
+    def reset_batch(self): return None
+
+
+def dumb_eval(gs):
+    """game_state.h:160-173: uniform policy over the legal moves (u8 sum wraps), value 1/(P+1) each."""
+    valids = gs.valid_moves()
+    P = gs.num_players()
+    v = np.full(P + 1, np.float32(1.0 / (P + 1)), np.float32)
+    ssum = np.float32(int(valids.sum()) & 0xFF)
+    pi = np.zeros(valids.size, np.float32) if ssum == 0 else (valids.astype(np.float32) / ssum)
+    return v, pi
+
+
 class _TaflBoardGS(GameState):
     """Brandubh / OpenTafl objects: optional start position as the reference's board tensor
     (int8 [3, N, N] = king, defenders, attackers) with an empty repetition map."""

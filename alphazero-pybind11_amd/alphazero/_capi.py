@@ -66,6 +66,14 @@ class PlayParamsC(C.Structure):
     ]
 
 
+class MctsConfigC(C.Structure):
+    _fields_ = [("cpuct", C.c_float), ("num_players", C.c_uint32), ("num_moves", C.c_uint32), ("epsilon", C.c_float),
+                ("root_policy_temp", C.c_float), ("fpu_reduction", C.c_float), ("relative_values", C.c_int32),
+                ("root_fpu_zero", C.c_int32), ("shaped_dirichlet", C.c_int32), ("gumbel_enabled", C.c_int32),
+                ("gumbel_m", C.c_uint32), ("gumbel_c_visit", C.c_float), ("gumbel_c_scale", C.c_float),
+                ("gumbel_full", C.c_int32), ("max_simulations", C.c_uint32)]
+
+
 class EngineOptsC(C.Structure):
     _fields_ = [
         ("seed", C.c_uint64),
@@ -126,6 +134,12 @@ SYMBOLS = {
     "azmi_pm_perm_scores": (C.c_int, [_VP, C.c_uint32, _VP, _PP(C.c_uint32)]),
     "azmi_pm_build_batch_group": (C.c_int, [_VP, C.c_uint32, _VP, C.c_uint32, _VP, _PP(C.c_uint32)]),
     "azmi_net_forward_rows": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_uint32, _VP]),
+    "azmi_mcts_create": (C.c_int, [C.c_int, _VP, C.c_uint64, C.c_int, _PP(C.c_void_p)]),
+    "azmi_mcts_destroy": (None, [_VP]),
+    "azmi_mcts_find_leaf": (C.c_int, [_VP, _VP, C.c_uint32, _VP, C.c_uint32, _VP, C.c_uint32, _PP(C.c_uint32)]),
+    "azmi_mcts_process_result": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP]),
+    "azmi_mcts_update_root": (C.c_int, [_VP, _VP, C.c_uint32, _VP, C.c_uint32, C.c_uint32]),
+    "azmi_mcts_query": (C.c_int, [_VP, C.c_uint32, C.c_float, C.c_uint32, _VP, _VP, _VP]),
     "azmi_game_replay_ex": (C.c_int, [C.c_int, C.c_int, _VP, C.c_uint32, _VP, C.c_uint32, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_uint32]),
     "azmi_game_replay_from": (C.c_int, [C.c_int, C.c_int, _VP, C.c_uint32, _VP, C.c_uint32, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "azmi_game_replay": (C.c_int, [C.c_int, C.c_int, _VP, C.c_uint32, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),

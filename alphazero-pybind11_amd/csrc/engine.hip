@@ -17,6 +17,7 @@
 #include "cache_host.h"
 #include "engine_kernels.h"
 #include "engine_kernels_big.h"
+#include "mcts_object_kernels.h"
 
 using namespace azmi;
 
@@ -1033,6 +1034,147 @@ int azmi_game_replay_ex(int game, int device, const uint8_t* init, uint32_t init
 #undef TRY2
   cleanup();
   return AZMI_OK;
+}
+
+// ---- stand-alone MCTS object (py_wrapper.cc:192-220) on a one-slot engine -------------------------------------
+struct azmi_mcts {
+  azmi_pm* pm = nullptr;
+  uint8_t* d_init = nullptr; int32_t* d_moves = nullptr; int32_t* d_out_moves = nullptr;
+  uint32_t* d_len = nullptr; int32_t* d_status = nullptr; float* d_f = nullptr; uint32_t* d_u = nullptr;
+  uint32_t moves_cap = 0, vec = 0;
+};
+
+int azmi_mcts_create(int game, const azmi_mcts_config* cfg, uint64_t seed, int device, azmi_mcts** out) {
+  if (!cfg || !out) return fail(AZMI_ERR_INVALID, "null argument");
+  if (game != AZMI_GAME_CONNECT4) return fail(AZMI_ERR_INVALID, "the stand-alone MCTS class is implemented for Connect4 in this round");
+  GameInfo gi;
+  game_info(game, &gi);
+  if (cfg->num_players != gi.P || cfg->num_moves != gi.M) return fail(AZMI_ERR_INVALID, "MCTS(num_players, num_moves) do not match the game");
+  if (cfg->relative_values) return fail(AZMI_ERR_INVALID, "relative_values games are not implemented");
+  azmi_play_params p;
+  azmi_play_params_default(&p);
+  p.games_to_play = 1; p.concurrent_games = 1; p.max_batch_size = 1;
+  p.num_mcts_visits = gi.P;
+  const uint32_t sims = cfg->max_simulations ? cfg->max_simulations : 50000u;
+  for (uint32_t i = 0; i < gi.P; ++i) p.mcts_visits[i] = (sims + 20) / 21;   // arena = (21 * visits + 42) * 7 nodes >= sims * 7
+  p.cpuct = cfg->cpuct; p.epsilon = cfg->epsilon; p.mcts_root_temp = cfg->root_policy_temp; p.fpu_reduction = cfg->fpu_reduction;
+  p.root_fpu_zero = cfg->root_fpu_zero; p.shaped_dirichlet = cfg->shaped_dirichlet;
+  p.gumbel_enabled = cfg->gumbel_enabled; p.gumbel_m = cfg->gumbel_m; p.gumbel_c_visit = cfg->gumbel_c_visit;
+  p.gumbel_c_scale = cfg->gumbel_c_scale; p.gumbel_full = cfg->gumbel_full;
+  p.num_model_groups_given = gi.P;
+  for (uint32_t i = 0; i < gi.P; ++i) p.model_groups[i] = 0;
+  azmi_engine_opts o;
+  azmi_engine_opts_default(&o);
+  o.seed = seed; o.device = device;
+  auto m = new azmi_mcts();
+  int rc = azmi_pm_create(game, &p, &o, &m->pm);
+  if (rc != AZMI_OK) { delete m; return rc; }
+  // the slot's stream is the object's stream; seed it directly (not through slot_seed) so that `seed` means what
+  // MCTS::seed_thread_rng(seed) means in the reference tests
+  {
+    Pcg32 g; g.seed(seed);
+    const uint64_t st = g.state;
+    if (hipMemcpy(m->pm->ar.rng, &st, 8, hipMemcpyHostToDevice) != hipSuccess) { azmi_pm_destroy(m->pm); delete m; return fail(AZMI_ERR_NO_DEVICE, "rng init failed"); }
+  }
+  m->moves_cap = gi.max_turns + 8;
+  m->vec = std::max<uint32_t>(gi.M, 64u);
+  auto A = [&](auto*& ptr, size_t n) { return m->pm->alloc(ptr, n, true); };
+  rc = A(m->d_init, 512); if (rc == AZMI_OK) rc = A(m->d_moves, m->moves_cap); if (rc == AZMI_OK) rc = A(m->d_out_moves, m->moves_cap);
+  if (rc == AZMI_OK) rc = A(m->d_len, 1); if (rc == AZMI_OK) rc = A(m->d_status, 1);
+  if (rc == AZMI_OK) rc = A(m->d_f, m->vec); if (rc == AZMI_OK) rc = A(m->d_u, m->vec + 64);
+  if (rc != AZMI_OK) { azmi_pm_destroy(m->pm); delete m; return rc; }
+  *out = m;
+  return AZMI_OK;
+}
+
+void azmi_mcts_destroy(azmi_mcts* m) {
+  if (!m) return;
+  azmi_pm_destroy(m->pm);
+  delete m;
+}
+
+namespace {
+int mcts_upload_state(azmi_mcts* m, const uint8_t* init, uint32_t init_bytes, const int32_t* moves, uint32_t len, hipStream_t st) {
+  if (len > m->moves_cap) return fail(AZMI_ERR_INVALID, "game record too long");
+  if (init && init_bytes != Connect4::SERIALIZED) return fail(AZMI_ERR_INVALID, "start position must be %u bytes", unsigned(Connect4::SERIALIZED));
+  if (init) HIP_TRY(hipMemcpyAsync(m->d_init, init, init_bytes, hipMemcpyHostToDevice, st));
+  if (len) HIP_TRY(hipMemcpyAsync(m->d_moves, moves, static_cast<size_t>(len) * 4, hipMemcpyHostToDevice, st));
+  return AZMI_OK;
+}
+int mcts_check(azmi_mcts* m, hipStream_t st) {
+  Control c;
+  return read_ctl(m->pm, st, &c, false);
+}
+}  // namespace
+
+int azmi_mcts_find_leaf(azmi_mcts* m, const uint8_t* init, uint32_t init_bytes, const int32_t* moves, uint32_t len,
+                        int32_t* leaf_moves, uint32_t cap, uint32_t* leaf_len) {
+  if (!m || !leaf_len || (len && !moves)) return fail(AZMI_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(m->pm->device));
+  hipStream_t st = m->pm->stream;
+  int rc = mcts_upload_state(m, init, init_bytes, moves, len, st); if (rc) return rc;
+  k_mcts_find_leaf<Connect4><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, init ? m->d_init : nullptr, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status);
+  int32_t status = 0; uint32_t n = 0;
+  HIP_TRY(hipMemcpyAsync(&status, m->d_status, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(&n, m->d_len, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (status == -1) return fail(AZMI_ERR_INVALID, "illegal move in the game record");
+  rc = mcts_check(m, st); if (rc) return rc;
+  if (status != 0) return fail(AZMI_ERR_OVERFLOW, "find_leaf failed (tree arena or path capacity)");
+  if (n > cap) return fail(AZMI_ERR_INVALID, "leaf_moves too small");
+  if (n && leaf_moves) HIP_TRY(hipMemcpy(leaf_moves, m->d_out_moves, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost));
+  *leaf_len = n;
+  return AZMI_OK;
+}
+
+int azmi_mcts_process_result(azmi_mcts* m, const float* value, const float* pi, int root_noise_enabled, float* value_out) {
+  if (!m || !value || !pi) return fail(AZMI_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(m->pm->device));
+  hipStream_t st = m->pm->stream;
+  const uint32_t V = m->pm->gi.P + 1, M = m->pm->gi.M;
+  HIP_TRY(hipMemcpyAsync(m->pm->ar.v, value, V * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(m->pm->ar.pi, pi, M * 4, hipMemcpyHostToDevice, st));
+  k_mcts_process_result<Connect4><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, root_noise_enabled ? 1u : 0u, m->d_f);
+  float tmp[8];
+  HIP_TRY(hipMemcpyAsync(tmp, m->d_f, V * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (value_out) std::memcpy(value_out, tmp, V * 4);
+  return mcts_check(m, st);
+}
+
+int azmi_mcts_update_root(azmi_mcts* m, const uint8_t* init, uint32_t init_bytes, const int32_t* moves, uint32_t len, uint32_t move) {
+  if (!m || (len && !moves)) return fail(AZMI_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(m->pm->device));
+  hipStream_t st = m->pm->stream;
+  int rc = mcts_upload_state(m, init, init_bytes, moves, len, st); if (rc) return rc;
+  k_mcts_update_root<Connect4><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, init ? m->d_init : nullptr, m->d_moves, len, move, m->d_status);
+  int32_t status = 0;
+  HIP_TRY(hipMemcpyAsync(&status, m->d_status, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (status == -1) return fail(AZMI_ERR_INVALID, "illegal move in the game record");
+  if (status == -3) {   // the device raised its "unknown move" bit; clear it so the object stays usable
+    Control c; HIP_TRY(hipMemcpy(&c, m->pm->ar.ctl, sizeof(c), hipMemcpyDeviceToHost));
+    c.overflow &= ~32u; if (!c.overflow) c.stop = 0;
+    HIP_TRY(hipMemcpy(m->pm->ar.ctl, &c, sizeof(c), hipMemcpyHostToDevice));
+    return fail(AZMI_ERR_INVALID, "ahh, what is this move: %u", move);
+  }
+  return mcts_check(m, st);
+}
+
+int azmi_mcts_query(azmi_mcts* m, uint32_t kind, float temp, uint32_t arg, const float* in_f, float* out_f, uint32_t* out_u) {
+  if (!m) return fail(AZMI_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(m->pm->device));
+  hipStream_t st = m->pm->stream;
+  if (kind == kQPickMove) {
+    if (!in_f) return fail(AZMI_ERR_INVALID, "pick_move needs a probability vector");
+    HIP_TRY(hipMemcpyAsync(m->d_f, in_f, static_cast<size_t>(m->pm->gi.M) * 4, hipMemcpyHostToDevice, st));
+  }
+  if (kind == kQPrincipalVariation && arg > 60) arg = 60;
+  k_mcts_query<Connect4><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, kind, temp, arg, m->d_f, m->d_u);
+  if (out_f) HIP_TRY(hipMemcpyAsync(out_f, m->d_f, static_cast<size_t>(m->vec) * 4, hipMemcpyDeviceToHost, st));
+  if (out_u) HIP_TRY(hipMemcpyAsync(out_u, m->d_u, static_cast<size_t>(m->vec) * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return mcts_check(m, st);
 }
 
 }  // extern "C"

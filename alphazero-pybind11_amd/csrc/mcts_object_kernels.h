@@ -1,0 +1,201 @@
+// The reference's stand-alone `MCTS` class (py_wrapper.cc:192-220, mcts.h:50-200) on the device: one tree driven
+// call by call (find_leaf / process_result / update_root / queries), built from the same SlotCtx member functions
+// the PlayManager round kernel uses, on a one-slot engine (seat 0's tree).  Connect4 (lane-group engine).
+#pragma once
+#include "engine_kernels.h"
+
+namespace azmi {
+
+// the root GameState of a call = start position (optional serialized state) + move list
+template <class GM>
+__device__ __forceinline__ bool mcts_replay_state(const uint8_t* init, const int32_t* moves, uint32_t len, typename GM::State& s) {
+  s = init ? GM::from_bytes(init) : GM::initial();
+  for (uint32_t i = 0; i < len; ++i) {
+    const int32_t mv = moves[i];
+    if (mv < 0) break;
+    if (mv >= GM::M || !((GM::valid_mask(s) >> mv) & 1u) || !GM::play(s, static_cast<uint32_t>(mv))) return false;
+  }
+  return true;
+}
+
+// MCTS::find_leaf(gs): out_moves[0 .. *out_len) = the moves from gs to the leaf (the leaf GameState is gs + those)
+template <class GM>
+__global__ void k_mcts_find_leaf(EngineParams ep, EngineArrays ar, const uint8_t* init, const int32_t* moves, uint32_t len,
+                                 int32_t* out_moves, uint32_t* out_len, int32_t* status) {
+  constexpr int G = GM::GROUP;
+  const uint32_t lane = threadIdx.x;
+  if (lane >= static_cast<uint32_t>(G)) return;
+  SlotCtx<GM> c(ep, ar, 0, lane);
+  c.load();
+  if (ar.sstate[0] == kSlotFresh) c.start_game();   // first call: empty tree (root = node 0, arena bump = 1)
+  typename GM::State st;
+  if (!mcts_replay_state<GM>(init, moves, len, st)) { if (lane == 0) *status = -1; return; }
+  c.gs = st;
+  typename GM::State leaf;
+  uint32_t term = 0;
+  const bool ok = c.find_leaf(0, leaf, term);
+  if (lane == 0) {
+    const size_t tb = c.tree_base(0);
+    const uint32_t* path = ar.path;
+    for (uint32_t i = 0; i < c.plen; ++i) {
+      const uint32_t node = (i + 1 < c.plen) ? path[i + 1] : c.cur;
+      out_moves[i] = static_cast<int32_t>(meta_mv(ar.META[tb + node]));
+    }
+    *out_len = c.plen;
+    *status = ok ? 0 : -2;
+  }
+  c.store(kSlotWaitEval);
+}
+
+// MCTS::process_result(gs, value, pi, root_noise_enabled): value / pi are row 0 of ar.v / ar.pi; value_out receives the
+// vector the reference leaves in its by-reference `value` (the cached terminal scores for a terminal leaf)
+template <class GM>
+__global__ void k_mcts_process_result(EngineParams ep, EngineArrays ar, uint32_t root_noise, float* value_out) {
+  constexpr int G = GM::GROUP;
+  constexpr int P = GM::P;
+  const uint32_t lane = threadIdx.x;
+  if (lane >= static_cast<uint32_t>(G)) return;
+  SlotCtx<GM> c(ep, ar, 0, lane);
+  c.load();
+  if (ar.sstate[0] == kSlotFresh) c.start_game();   // first call: empty tree (root = node 0, arena bump = 1)
+  const uint32_t term = meta_term(ar.META[c.tree_base(0) + c.cur]);
+  c.process_result(0, true, root_noise != 0);
+  if (lane == 0)
+    for (int i = 0; i <= P; ++i) value_out[i] = term ? ((static_cast<int>(term) - 1 == i) ? 1.0f : 0.0f) : ar.v[i];
+  c.store(kSlotWaitEval);
+}
+
+template <class GM>
+__global__ void k_mcts_update_root(EngineParams ep, EngineArrays ar, const uint8_t* init, const int32_t* moves, uint32_t len,
+                                   uint32_t move, int32_t* status) {
+  constexpr int G = GM::GROUP;
+  const uint32_t lane = threadIdx.x;
+  if (lane >= static_cast<uint32_t>(G)) return;
+  SlotCtx<GM> c(ep, ar, 0, lane);
+  c.load();
+  if (ar.sstate[0] == kSlotFresh) c.start_game();   // first call: empty tree (root = node 0, arena bump = 1)
+  typename GM::State st;
+  if (!mcts_replay_state<GM>(init, moves, len, st)) { if (lane == 0) *status = -1; return; }
+  c.gs = st;
+  const bool ok = c.update_root(0, move);
+  if (lane == 0) *status = ok ? 0 : -3;   // -3: "ahh, what is this move"
+  c.store(kSlotWaitEval);
+}
+
+enum MctsQuery : uint32_t {
+  kQCounts = 0, kQProbs = 1, kQProbsPruned = 2, kQRootValue = 3, kQRootQ = 4, kQScalars = 5, kQGumbelPolicy = 6,
+  kQGumbelFinal = 7, kQAddRootNoise = 8, kQApplyRootTemp = 9, kQPickMove = 10, kQPrincipalVariation = 11, kQSetGumbelSims = 12, kQRootChildren = 13
+};
+
+// every read-out / small mutation of the root: dense [M] vectors go to out_f / out_u (lane m writes entry m)
+template <class GM>
+__global__ void k_mcts_query(EngineParams ep, EngineArrays ar, uint32_t kind, float temp, uint32_t arg, float* out_f, uint32_t* out_u) {
+  constexpr int G = GM::GROUP;
+  constexpr int P = GM::P;
+  constexpr int M = GM::M;
+  const uint32_t lane = threadIdx.x;
+  if (lane >= static_cast<uint32_t>(G)) return;
+  SlotCtx<GM> c(ep, ar, 0, lane);
+  c.load();
+  if (ar.sstate[0] == kSlotFresh) c.start_game();   // first call: empty tree (root = node 0, arena bump = 1)
+  c.sync_lanes();
+  const size_t tb = c.tree_base(0);
+  const uint32_t root = c.t_root[0];
+  const uint64_t rmeta = ar.META[tb + root];
+  const uint32_t k = meta_nch(rmeta), c0 = meta_ch0(rmeta), root_n = ar.N[tb + root];
+  const size_t ci = tb + c0 + lane;
+  uint32_t n_l = 0, mv_l = 0; float q_l = 0, p_l = 0, d_l = 0;
+  if (lane < k) { n_l = ar.N[ci]; q_l = ar.Q[ci]; p_l = ar.Pr[ci]; d_l = ar.D[ci]; mv_l = meta_mv(ar.META[ci]); }
+  const uint32_t cnt_m = c.template scatter_by_move<uint32_t>(k, mv_l, n_l);
+  const float pol_m = c.template scatter_by_move<float>(k, mv_l, p_l);
+  const bool in = lane < static_cast<uint32_t>(M);
+  switch (kind) {
+    case kQCounts: if (in) out_u[lane] = cnt_m; break;                                                  // mcts.cc:557-564
+    case kQProbs: { const float p = c.probs(temp, cnt_m, pol_m); if (in) out_f[lane] = p; break; }        // mcts.cc:575-618
+    case kQProbsPruned: { const float p = c.probs_pruned(temp, root_n, k, mv_l, n_l, q_l, p_l, cnt_m, pol_m); if (in) out_f[lane] = p; break; }
+    case kQRootValue: {                                                                                  // mcts.h:78-100
+      float q = 0, d = 0; bool found = false;
+      for (uint32_t i = 0; i < k; ++i) {
+        const uint32_t ni = c.bcast(n_l, i); const float qi = c.bcast(q_l, i), di = c.bcast(d_l, i);
+        if (ni > 0 && qi > q) { q = qi; d = di; found = true; }
+      }
+      if (!found && root_n > 0) { q = ar.V[tb + root]; d = ar.D[tb + root]; }
+      const float w = q - d / static_cast<int32_t>(P);
+      const float l = static_cast<float>(1.0 - static_cast<double>(w) - static_cast<double>(d));
+      if (lane == 0) { out_f[0] = w; out_f[1] = l; out_f[2] = d; }
+      break;
+    }
+    case kQRootQ: { const float qm = c.template scatter_by_move<float>(k, mv_l, q_l); if (in) out_f[lane] = qm; break; }   // mcts.cc:566-573
+    case kQScalars: {   // depth(), root_n(), avg_leaf_depth(), normalized_root_entropy(), number of root children
+      const uint32_t dep = c.t_depth[0];
+      float ent = 0.0f;
+      const float kf = static_cast<float>(k);
+      if (!(kf <= 1 || root_n <= 1)) {
+        const float log_k = az_logf(kf), total_n = static_cast<float>(root_n);
+        float term_l = 0.0f;
+        if (lane < k && n_l > 0) { const float p = static_cast<float>(n_l) / total_n; term_l = p * az_logf(p); }
+        float e = 0.0f;
+        for (uint32_t i = 0; i < k; ++i) { const uint32_t ni = c.bcast(n_l, i); const float ti = c.bcast(term_l, i); if (ni > 0) e -= ti; }
+        ent = e / log_k;
+      }
+      if (lane == 0) {
+        out_u[0] = dep; out_u[1] = root_n; out_u[2] = k;
+        out_f[0] = dep == 0 ? 0.0f : static_cast<float>(c.t_tld[0]) / static_cast<float>(dep);
+        out_f[1] = ent;
+      }
+      break;
+    }
+    case kQGumbelPolicy: { const float p = c.gumbel_improved_policy(k, mv_l, n_l, q_l, p_l, ar.V[tb + root]); if (in) out_f[lane] = p; break; }
+    case kQGumbelFinal: { const uint32_t a = c.gumbel_final_action(0, k, mv_l, n_l, q_l, p_l, cnt_m, pol_m); if (lane == 0) out_u[0] = a; break; }
+    case kQAddRootNoise: {   // MCTS::add_root_noise on the current root priors
+      if (k > 0) { const float p = c.add_root_noise(k, p_l, c.seat_eps(0)); if (lane < k) ar.Pr[ci] = p; }
+      break;
+    }
+    case kQApplyRootTemp: {  // MCTS::apply_root_policy_temp, mcts.cc:448-460
+      const float rt = c.seat_root_temp(0);
+      if (rt != 1.0f && k > 0) {
+        float p = lane < k ? az_powf(p_l, 1.0f / rt) : 0.0f;
+        const float sum = c.seqsum(p, k);
+        if (sum > 0.0f) p = p / sum;
+        if (lane < k) ar.Pr[ci] = p;
+      }
+      break;
+    }
+    case kQPickMove: { const float p = in ? out_f[lane] : 0.0f; const uint32_t m = c.pick_move(p); if (lane == 0) out_u[0] = m; break; }   // mcts.cc:717-735
+    case kQPrincipalVariation: {   // mcts.cc:676-715: most-visited child per ply (root: the Gumbel final action when Gumbel is on)
+      uint32_t node = root, len = 0;
+      for (uint32_t ply = 0; ply < arg; ++ply) {
+        const uint64_t m = ar.META[tb + node];
+        const uint32_t kk = meta_nch(m), cc0 = meta_ch0(m);
+        if (kk == 0) break;
+        uint32_t nn = 0, mm = 0;
+        if (lane < kk) { nn = ar.N[tb + cc0 + lane]; mm = meta_mv(ar.META[tb + cc0 + lane]); }
+        uint32_t best = 0xFFFFu;
+        if (ply == 0 && ep.gumbel_on) {
+          const uint32_t a = c.gumbel_final_action(0, k, mv_l, n_l, q_l, p_l, cnt_m, pol_m);
+          for (uint32_t i = 0; i < kk; ++i) if (c.bcast(mm, i) == a) { best = i; break; }
+        }
+        if (best == 0xFFFFu) {
+          uint32_t best_n = 0;
+          for (uint32_t i = 0; i < kk; ++i) { const uint32_t ni = c.bcast(nn, i); if (ni > best_n) { best_n = ni; best = i; } }
+        }
+        if (best == 0xFFFFu || c.bcast(nn, best) == 0) break;
+        const uint32_t best_mv = c.bcast(mm, best);
+        if (lane == 0) out_u[1 + len] = best_mv;
+        ++len;
+        node = cc0 + best;
+      }
+      if (lane == 0) out_u[0] = len;
+      break;
+    }
+    case kQSetGumbelSims: if (ep.gumbel_on) c.set_gumbel_num_sims(0, arg); break;
+    case kQRootChildren:   // test hook: root children in stored (shuffled) order + the stream position
+      if (lane < k) { out_u[4 + lane] = mv_l; out_f[lane] = p_l; }
+      if (lane == 0) { out_u[0] = k; out_u[1] = static_cast<uint32_t>(c.rng.state); out_u[2] = static_cast<uint32_t>(c.rng.state >> 32); }
+      break;
+    default: break;
+  }
+  c.store(kSlotWaitEval);
+}
+
+}  // namespace azmi

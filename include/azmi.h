@@ -219,6 +219,34 @@ int azmi_tafl_symmetries(uint32_t board, uint32_t channels, uint32_t num_values,
                          float* out_pi, int host_buffers, void* stream);
 const char* azmi_symmetries_last_error(void);
 
+/* ---- the stand-alone MCTS class (py_wrapper.cc:192-220, mcts.h:50-200): one search tree driven call by call.
+ * Connect4 in this round.  A GameState argument is passed as start position (`init`, NULL = initial position, else the
+ * game's serialized image as in azmi_game_replay_from) + the moves played from it.  The object owns one pcg32
+ * stream (the reference shares a thread_local one across all trees of a thread). */
+typedef struct azmi_mcts azmi_mcts;
+typedef struct azmi_mcts_config {   /* ctor arguments, mcts.h:52-72 */
+  float cpuct; uint32_t num_players, num_moves;
+  float epsilon, root_policy_temp, fpu_reduction;
+  int32_t relative_values, root_fpu_zero, shaped_dirichlet, gumbel_enabled;
+  uint32_t gumbel_m; float gumbel_c_visit, gumbel_c_scale; int32_t gumbel_full;
+  uint32_t max_simulations;         /* arena size: simulations over the object's lifetime (0 = 50000) */
+} azmi_mcts_config;
+int azmi_mcts_create(int game, const azmi_mcts_config* cfg, uint64_t seed, int device, azmi_mcts** out);
+void azmi_mcts_destroy(azmi_mcts* m);
+/* find_leaf(gs): leaf_moves[0 .. *leaf_len) are the moves from gs to the leaf (leaf GameState = gs + those moves) */
+int azmi_mcts_find_leaf(azmi_mcts* m, const uint8_t* init, uint32_t init_bytes, const int32_t* moves, uint32_t len,
+                        int32_t* leaf_moves, uint32_t cap, uint32_t* leaf_len);
+/* process_result(gs, value, pi, root_noise_enabled); value_out [P+1] = the reference's in-out `value` afterwards */
+int azmi_mcts_process_result(azmi_mcts* m, const float* value, const float* pi, int root_noise_enabled, float* value_out);
+/* update_root(gs, move); returns AZMI_ERR_INVALID with "ahh, what is this move" for a move the root does not have */
+int azmi_mcts_update_root(azmi_mcts* m, const uint8_t* init, uint32_t init_bytes, const int32_t* moves, uint32_t len, uint32_t move);
+/* read-outs and small mutations, kind: 0 counts (u32 [M]) 1 probs(temp) 2 probs_pruned(temp) (f32 [M]) 3 root_value (f32 [3])
+ * 4 root_q_values (f32 [M]) 5 scalars: u = {depth, root_n, root children}, f = {avg_leaf_depth, normalized_root_entropy}
+ * 6 gumbel_improved_policy (f32 [M]) 7 gumbel_final_action (u[0]) 8 add_root_noise 9 apply_root_policy_temp
+ * 10 pick_move: in_f = pi [M], u[0] = move 11 principal_variation(depth = arg): u[0] = length, u[1..] = moves
+ * 12 set_gumbel_num_sims(arg).  out_f / out_u are HOST arrays of at least max(M, 64) entries (may be NULL if unused). */
+int azmi_mcts_query(azmi_mcts* m, uint32_t kind, float temp, uint32_t arg, const float* in_f, float* out_f, uint32_t* out_u);
+
 /* ---- leaf policy/value network (the reference's NNArch forward + NNWrapper.process,
  *      neural_net.py:448-510, 800-823) as one fused MFMA kernel ---------------------------------
  * `blob` is the BatchNorm-folded, MFMA-fragment-ordered weight image produced by

@@ -201,6 +201,11 @@ uint32_t orc_mcts_root_n(void* h) { return static_cast<MctsBox*>(h)->m->root_n()
 float orc_mcts_avg_leaf_depth(void* h) { return static_cast<MctsBox*>(h)->m->avg_leaf_depth(); }
 float orc_mcts_entropy(void* h) { return static_cast<MctsBox*>(h)->m->normalized_root_entropy(); }
 void orc_mcts_root_value(void* h, float* wld) { static_cast<MctsBox*>(h)->m->root_value(wld); }
+uint32_t orc_mcts_principal_variation(void* h, uint32_t depth, uint32_t* out) {
+  auto pv = static_cast<MctsBox*>(h)->m->principal_variation(depth);
+  for (size_t i = 0; i < pv.size(); ++i) out[i] = pv[i];
+  return static_cast<uint32_t>(pv.size());
+}
 void orc_mcts_add_root_noise(void* h) { static_cast<MctsBox*>(h)->m->add_root_noise(); }
 void orc_mcts_apply_root_policy_temp(void* h) { static_cast<MctsBox*>(h)->m->apply_root_policy_temp(); }
 // root children in stored order: moves[k], policy[k], n[k], q[k]; returns k

@@ -209,6 +209,14 @@ class Mcts:
     def root_value(self):
         out = np.zeros(3, np.float32); lib.orc_mcts_root_value(self.h, _p(out)); return out
 
+    def add_root_noise(self): lib.orc_mcts_add_root_noise(self.h)
+    def apply_root_policy_temp(self): lib.orc_mcts_apply_root_policy_temp(self.h)
+
+    def principal_variation(self, depth=5):
+        out = np.zeros(max(depth, 1), np.uint32)
+        n = lib.orc_mcts_principal_variation(self.h, C.c_uint32(depth), _p(out))
+        return out[:n].copy()
+
     def root_children(self):
         mv = np.zeros(4096, np.uint32); pol = np.zeros(4096, np.float32); n = np.zeros(4096, np.uint32); q = np.zeros(4096, np.float32)
         k = lib.orc_mcts_root_children(self.h, _p(mv), _p(pol), _p(n), _p(q))
