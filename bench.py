@@ -30,8 +30,8 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12000)
-    ap.add_argument("--warmup", type=int, default=36000)
+    ap.add_argument("--steps", type=int, default=30000, help="timed rounds; the default spans > 2 game lengths (13 k rounds each) so that the opening/endgame phase mix of the initially synchronised games averages out")
+    ap.add_argument("--warmup", type=int, default=30000)
     ap.add_argument("--game", choices=["connect4", "tawlbwrdd"], default="connect4",
                     help="connect4 = BASELINE configs[1] (the headline); tawlbwrdd = configs[2] (2048 games, 400 sims, YAML net)")
     ap.add_argument("--games", type=int, default=None, help="concurrent games per GPU (4096 / 2048)")
