@@ -128,35 +128,42 @@ __global__ void k_seed(EngineArrays ar, uint32_t S, uint64_t seed) {
   ar.coin[s] = g.state;
 }
 
+// start of a round: cache insert of last round's leaves + the restart/retire bookkeeping in one launch
+template <class GM>
+void launch_pre_round(azmi_pm* pm, hipStream_t st) {
+  if (!pm->ep.cache_on) { k_assign<<<1, 256, 0, st>>>(pm->ep, pm->ar, 1u); return; }
+  for (uint32_t g = 0; g < pm->ep.num_groups; ++g)
+    for (uint32_t off = 0; off < pm->ep.S; off += kApplyMax) {
+      const uint32_t m = std::min<uint32_t>(kApplyMax, pm->ep.S - off);
+      const uint32_t nb = (m + 3) / 4;
+      const bool with_assign = g == 0 && off == 0;
+      k_cache_insert<GM><<<nb + (with_assign ? 1u : 0u), 256, 0, st>>>(pm->ep, pm->ar, pm->ar.cache_keys, off, m,
+                                                                      with_assign ? nb : 0xFFFFFFFFu, 1u, g);
+    }
+}
+
 int launch_round(azmi_pm* pm, hipStream_t st) {
   const uint32_t threads = 256;
-  if (!(pm->game == AZMI_GAME_CONNECT4 && pm->ep.cache_on)) k_assign<<<1, 256, 0, st>>>(pm->ep, pm->ar, 1u);
   switch (pm->game) {
     case AZMI_GAME_CONNECT4: {
-      if (pm->ep.cache_on) {   // cache insert of last round's leaves + the restart/retire bookkeeping in one launch
-        for (uint32_t g = 0; g < pm->ep.num_groups; ++g)
-          for (uint32_t off = 0; off < pm->ep.S; off += kApplyMax) {
-            const uint32_t m = std::min<uint32_t>(kApplyMax, pm->ep.S - off);
-            const uint32_t nb = (m + 3) / 4;
-            const bool with_assign = g == 0 && off == 0;
-            k_cache_insert<Connect4><<<nb + (with_assign ? 1u : 0u), 256, 0, st>>>(pm->ep, pm->ar, pm->ar.cache_keys, off, m,
-                                                                                  with_assign ? nb : 0xFFFFFFFFu, 1u, g);
-          }
-      }
+      launch_pre_round<Connect4>(pm, st);
       const uint32_t slots_per_block = threads / Connect4::GROUP;
       const uint32_t blocks = (pm->ep.S + slots_per_block - 1) / slots_per_block;
       k_round<Connect4><<<blocks, threads, 0, st>>>(pm->ep, pm->ar);
       break;
     }
     case AZMI_GAME_TAWLBWRDD:
+      launch_pre_round<Tawlbwrdd>(pm, st);
       k_round_big<Tawlbwrdd><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
       if (pm->ep.half_nodes) k_compact<Tawlbwrdd><<<pm->ep.S * pm->gi.P, 256, 0, st>>>(pm->ep, pm->ar);
       break;
     case AZMI_GAME_BRANDUBH:
+      launch_pre_round<Brandubh>(pm, st);
       k_round_big<Brandubh><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
       if (pm->ep.half_nodes) k_compact<Brandubh><<<pm->ep.S * pm->gi.P, 256, 0, st>>>(pm->ep, pm->ar);
       break;
     case AZMI_GAME_OPENTAFL:
+      launch_pre_round<OpenTafl>(pm, st);
       k_round_big<OpenTafl><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
       if (pm->ep.half_nodes) k_compact<OpenTafl><<<pm->ep.S * pm->gi.P, 256, 0, st>>>(pm->ep, pm->ar);
       break;
@@ -498,7 +505,6 @@ int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_o
     if (const char* e = getenv("AZMI_COMPACT_ABOVE")) ep.compact_above = static_cast<uint32_t>(atoi(e));  // test hook: 0 = compact after every move
   }
   if (cap64 > 0xFFFFFFF0ULL) { delete pm; return fail(AZMI_ERR_INVALID, "tree arena too large"); }
-  if (game != AZMI_GAME_CONNECT4 && params->max_cache_size != 0) { delete pm; return fail(AZMI_ERR_INVALID, "the device position cache is wired for Connect4 only in this build; set max_cache_size=0"); }
   ep.cap = static_cast<uint32_t>(cap64);
   ep.log_moves = opts.log_moves != 0;
   ep.log_cap = ep.log_moves ? (opts.move_log_capacity ? opts.move_log_capacity
@@ -625,7 +631,7 @@ constexpr uint32_t kGraphRounds = 16;
 // the net on this engine's leaf batch: only the rows k_round listed (Connect4 engine), else the whole batch
 int pm_net_forward(azmi_pm* pm, uint32_t group, azmi_net* net, hipStream_t st) {
   int rc;
-  if (pm->game == AZMI_GAME_CONNECT4 || pm->ep.num_groups > 1)
+  if (pm->game == AZMI_GAME_CONNECT4 || pm->ep.num_groups > 1 || pm->ep.cache_on)
     rc = azmi_net_forward_rows(net, pm->ar.canon, pm->ar.v, pm->ar.pi, pm->ar.eval_list + static_cast<size_t>(group) * pm->ep.S,
                                &pm->ar.ctl->eval_count[group], pm->ep.S, st);
   else

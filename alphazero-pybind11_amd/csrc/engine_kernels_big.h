@@ -952,6 +952,30 @@ struct BigSlot {
     if (lane == 0) ar.leaf_key[slot] = key;
     return key;
   }
+  // position-cache probe (play_manager.cc:592-597) by the slot's wavefront: one lane per entry of the 64-entry shard;
+  // on a hit the cached (pi[M], v) are copied into the slot's rows
+  __device__ __forceinline__ bool cache_lookup(uint64_t key, uint32_t group) const {
+    uint32_t sh;
+    const CacheView cache = ep.num_groups == 1 ? ar.cache : ar.caches[group];
+    const int cslot = wave_shard_find<64>(cache, key, lane, &sh);
+    if (lane == 0) {
+      unsigned long long* st = cache.stats + static_cast<size_t>(sh) * 4;
+      if (cslot < 0) {
+        atomicAdd(&st[1], 1ULL);
+      } else {
+        atomicAdd(&st[0], 1ULL);
+        uint32_t* f = cache.freq + static_cast<size_t>(sh) * kWaveCap + cslot;
+        if (atomicAdd(f, 1u) >= 3u) atomicSub(f, 1u);
+      }
+    }
+    if (cslot < 0) return false;
+    const float* sp = cache.policy + (static_cast<size_t>(sh) * cache.cap + cslot) * M;
+    const float* sv = cache.value + (static_cast<size_t>(sh) * cache.cap + cslot) * (P + 1);
+    for (uint32_t e = lane; e < static_cast<uint32_t>(M); e += G) ar.pi[static_cast<size_t>(slot) * M + e] = sp[e];
+    if (lane <= static_cast<uint32_t>(P)) ar.v[static_cast<size_t>(slot) * (P + 1) + lane] = sv[lane];
+    sync();
+    return true;
+  }
 };
 
 // One round for every slot of a wide-node game: one wavefront (= one workgroup) per slot.
@@ -962,10 +986,10 @@ __global__ __launch_bounds__(64) void k_round_big(EngineParams ep, EngineArrays 
   if (slot >= ep.S) return;
   if (ar.ctl->stop) return;
   const uint8_t st = ar.sstate[slot];
-  if (st == kSlotDone || st == kSlotEnded) return;
+  if (st == kSlotDone || st == kSlotEnded) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; return; }
   BigSlot<GM> c(ep, ar, sm, slot, lane);
   c.load();
-  uint32_t inline_sims = 0;
+  uint32_t inline_sims = 0, insert_key_set = 0;
   bool need_process = (st == kSlotWaitEval);
   if (!need_process) {
     c.start_game(); c.draw_capped(); c.set_gumbel_target();
@@ -978,28 +1002,34 @@ __global__ __launch_bounds__(64) void k_round_big(EngineParams ep, EngineArrays 
       c.process_result(cp, (c.flags & kFlagLeafNeedsNet) != 0, noise);
       const uint32_t goal = (c.flags & kFlagCapped) ? c.seat_cap_visits(cp) : c.seat_visits(cp);
       if (((cp == 0) ? c.t_depth[0] : c.t_depth[GM::P > 1 ? 1 : 0]) >= goal) {
-        if (c.make_move(cp)) { c.store(kSlotEnded); return; }
+        if (c.make_move(cp)) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; c.store(kSlotEnded); return; }
       }
     }
     const uint32_t cp = c.gs.player;
     typename GM::State leaf;
     uint32_t term = 0;
-    if (!c.find_leaf(cp, leaf, term)) { c.store(kSlotDone); return; }
+    if (!c.find_leaf(cp, leaf, term)) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; c.store(kSlotDone); return; }
     const bool needs_net = term == 0 && !c.seat_eval_random(cp);
     c.flags = needs_net ? (c.flags | kFlagLeafNeedsNet) : (c.flags & ~kFlagLeafNeedsNet);
     if (needs_net) {
-      c.emit_leaf(leaf);
-      if (lane == 0) {
-        const uint32_t group = c.seat_group(cp);
-        ar.c_evals[slot] += 1;
-        ar.leaf_group[slot] = static_cast<uint8_t>(group);
-        ar.eval_list[static_cast<size_t>(group) * ep.S + atomicAdd(&ar.ctl->eval_count[group], 1u)] = slot;
+      const uint64_t key = c.emit_leaf(leaf);
+      const uint32_t group = c.seat_group(cp);
+      const bool hit = ep.cache_on && c.cache_lookup(key, group);
+      if (!hit) {
+        if (lane == 0) {
+          ar.c_evals[slot] += 1;
+          if (ep.cache_on) ar.cache_keys[slot] = cache_key(key);
+          ar.leaf_group[slot] = static_cast<uint8_t>(group);
+          ar.eval_list[static_cast<size_t>(group) * ep.S + atomicAdd(&ar.ctl->eval_count[group], 1u)] = slot;
+        }
+        insert_key_set = 1;
+        break;
       }
-      break;
     }
     need_process = true;
     if (++inline_sims >= ep.max_inline) break;
   }
+  if (ep.cache_on && !insert_key_set && lane == 0) ar.cache_keys[slot] = 0;
   c.store(kSlotWaitEval);
 }
 

@@ -96,3 +96,48 @@ def test_engine_with_cache_is_transparent(oracle):
         sel = rows[:, 0] == s
         assert np.array_equal(rows[sel][:, 2:], orows[:, 2:]), s
         assert np.array_equal(counts[sel], ocounts), s
+
+
+def test_wide_game_engine_with_cache_is_transparent(oracle):
+    """Tawlbwrdd (one wavefront per slot, 10.6 KB of policy per cache entry): with a deterministic evaluator the cache
+    changes which leaves are evaluated, never the search."""
+    import alphazero as az
+
+    def evaluator(canon):
+        n = canon.shape[0]
+        flat = canon.reshape(n, -1)
+        # batch-invariant by construction (a BLAS float32 gemv may sum in a batch-size dependent order, and a cached
+        # answer must equal a recomputed one bit for bit): accumulate in float64, round once
+        w = np.linspace(0.5, 1.5, flat.shape[1], dtype=np.float64)
+        s = (flat.astype(np.float64) * w).sum(1).astype(np.float32)
+        v = np.stack([0.3 + 0.1 * np.sin(s), 0.3 - 0.1 * np.sin(s), np.full(n, 0.4)], 1).astype(np.float32)
+        pi = np.abs(np.sin(s[:, None] * np.float32(0.01) * np.arange(1, 2663, dtype=np.float32))) + np.float32(0.05)
+        return v, (pi / pi.sum(1, keepdims=True)).astype(np.float32)
+
+    pp = az.PlayParams()
+    pp.games_to_play, pp.concurrent_games, pp.max_batch_size = 3, 3, 3
+    pp.model_groups = [0, 0]
+    pp.mcts_visits = [24, 24]
+    pp.cpuct, pp.fpu_reduction = 1.25, 0.25
+    pp.max_cache_size = 2048
+    seed = 37
+    pm = az.PlayManager(az.TawlbwrddGS(), pp, seed=seed, log_moves=True)
+    batch = np.zeros((3, 7, 11, 11), np.float32)
+    while pm.remaining_games() > 0:
+        idx = pm.build_batch(0, batch)
+        if not idx:
+            continue
+        v, pi = evaluator(batch[: len(idx)])
+        pm.update_inferences(0, idx, v, pi)
+    rows, counts = pm.move_log()
+    c = pm.counters()
+    assert c["cache_hits"] > 0 and c["cache_misses"] > 0 and c["evals"] < c["sims"]
+    for s in range(3):
+        one = az.PlayParams(); one.__dict__.update(pp.__dict__)
+        one.games_to_play, one.concurrent_games, one.max_cache_size = 1, 1, 0
+        o = oracle.PlayManager(oracle.GAME_TAWLBWRDD, one, oracle.slot_seed(seed, s), per_slot_rng=False)
+        o.run(evaluator)
+        orows, ocounts = o.moves()
+        sel = rows[:, 0] == s
+        assert np.array_equal(rows[sel][:, 2:], orows[:, 2:]), s
+        assert np.array_equal(counts[sel], ocounts), s
