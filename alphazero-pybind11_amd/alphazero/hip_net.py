@@ -99,8 +99,10 @@ def fold_spatial(net):
     policy 1x1 frag[2][2] + b[32] | fc1 f32-frag[Hd/16][4] b | extra FC (f32-frag[Hd/16][Hd/16])* then (b[Hd])* | fc2 f32-frag[1][Hd/16] b[16]."""
     spec = net.spec
     Cin, H, W = spec.in_shape
-    assert spec.num_channels == 64 and spec.head_channels == 64 and spec.kernel_size == 3 and spec.head_pool
-    assert spec.v_head_convs == 1 and spec.pi_head_convs == 1 and 9 * Cin <= 64
+    if not (spec.num_channels == 64 and spec.head_channels == 64 and spec.kernel_size == 3 and spec.head_pool
+            and spec.v_head_convs == 1 and spec.pi_head_convs == 1 and 9 * Cin <= 64 and (H, W) == (11, 11)):
+        raise RuntimeError("the bf16 MFMA spatial-head kernel covers the configs/tawlbwrdd.yaml net (11x11, 64 trunk / 64 head "
+                           "channels, one extra conv per head, 9*C_in <= 64); use precision='fp32' for other shapes")
     pc = spec.policy_shape[0]
     Hd, L, P1 = spec.v_fc_hidden, spec.v_fc_layers, spec.num_players + 1
     sd = {k: v.detach().double().cpu() for k, v in net.state_dict().items()}
@@ -135,7 +137,7 @@ def fold_fp32(net):
     """fp32 path (csrc/leafnet_f32.hip): torch layouts, BatchNorms folded in double, no bf16 anywhere."""
     spec = net.spec
     Cin, H, W = spec.in_shape
-    assert spec.num_channels == 64 and spec.kernel_size == 3 and spec.head_pool
+    assert spec.kernel_size == 3 and spec.head_pool
     sd = {k: v.detach().double().cpu() for k, v in net.state_dict().items()}
     blob = bytearray()
 
@@ -163,7 +165,7 @@ def fold_fp32(net):
         blob += conv_bn("pi_conv2.weight", net.pi_bn2)
     else:
         blob += _f32(sd["pi_fc1.weight"]) + _f32(sd["pi_fc1.bias"])
-    desc = NetDescC(Cin, H, W, 64, spec.depth, 3, spec.head_channels, spec.v_fc_hidden, spec.num_moves, spec.num_players,
+    desc = NetDescC(Cin, H, W, spec.num_channels, spec.depth, 3, spec.head_channels, spec.v_fc_hidden, spec.num_moves, spec.num_players,
                     spec.v_head_convs, spec.pi_head_convs, spec.v_fc_layers, pc, 1)
     assert len(blob) == lib.azmi_net_blob_bytes(C.byref(desc)), (len(blob), lib.azmi_net_blob_bytes(C.byref(desc)))
     return desc, bytes(blob)
@@ -177,9 +179,11 @@ def fold(net, precision="bf16"):
     if spec.policy_shape is not None:
         return fold_spatial(net)
     Cin, H, W = spec.in_shape
-    assert spec.num_channels == 64 and spec.head_channels == 32 and spec.kernel_size == 3
-    assert spec.policy_shape is None and spec.head_pool and spec.v_head_convs == 0 and spec.pi_head_convs == 0
-    assert spec.v_fc_layers == 1 and 9 * Cin <= 64
+    if not (spec.num_channels == 64 and spec.head_channels == 32 and spec.kernel_size == 3 and spec.policy_shape is None
+            and spec.head_pool and spec.v_head_convs == 0 and spec.pi_head_convs == 0 and spec.v_fc_layers == 1
+            and 9 * Cin <= 64 and (H, W) == (6, 7)):
+        raise RuntimeError("the bf16 MFMA flat-head kernel covers the Connect4 net family (6x7, 64 trunk / 32 head channels, "
+                           "flat policy head); use precision='fp32' for other shapes")
     sd = {k: v.detach().double().cpu() for k, v in net.state_dict().items()}
     blob = bytearray()
     # stem: conv1 * bn1

@@ -149,6 +149,18 @@ def tawlbwrdd_spec(depth=4):
                    head_channels=64, v_head_convs=1, pi_head_convs=1, v_fc_layers=2, policy_shape=(22, 11, 11))
 
 
+def brandubh_spec():
+    """configs/brandubh.yaml: 4 blocks x 32 channels, head_channels 32, extra head convs, two value FC layers, spatial head."""
+    return NetSpec(in_shape=(7, 7, 7), num_moves=686, num_players=2, num_channels=32, depth=4, kernel_size=3, head_channels=32,
+                   v_head_convs=1, pi_head_convs=1, v_fc_layers=2, policy_shape=(14, 7, 7))
+
+
+def opentafl_spec(depth=4, channels=64, head_channels=64):
+    """OpenTafl: 8 canonical planes (plane 7 = turn / max_turns), 11x11, spatial head (the Tawlbwrdd YAML shape)."""
+    return NetSpec(in_shape=(8, 11, 11), num_moves=2662, num_players=2, num_channels=channels, depth=depth, kernel_size=3,
+                   head_channels=head_channels, v_head_convs=1, pi_head_convs=1, v_fc_layers=2, policy_shape=(22, 11, 11))
+
+
 def random_init(spec, seed=0, randomize_bn=True):
     """Random-init net of the named architecture (no checkpoint / dataset is reachable here).
     BatchNorm statistics and affine parameters are randomised too so that BN folding is exercised."""

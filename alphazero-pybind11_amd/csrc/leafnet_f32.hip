@@ -5,11 +5,11 @@
 // Throughput is not the point here (VALU FMAs, activations round-trip through HBM between layers).
 //
 // Weight blob (all f32, torch layouts, inference BatchNorms folded on the host in double):
-//   stem    W[64][Cin][3][3] b[64]
-//   block i a1[64] b1[64] | W1[64][64][3][3] c1[64] | W2[64][64][3][3]
-//   value   Wv[HC][64] bv[HC] | v_head_convs x (W[HC][HC][3][3] b[HC]) | fc1 W[Hd][HC] b[Hd] |
+//   stem    W[CH][Cin][3][3] b[CH]                                  (CH = NNArgs.num_channels, any width)
+//   block i a1[CH] b1[CH] | W1[CH][CH][3][3] c1[CH] | W2[CH][CH][3][3]
+//   value   Wv[HC][CH] bv[HC] | v_head_convs x (W[HC][HC][3][3] b[HC]) | fc1 W[Hd][HC] b[Hd] |
 //           (v_fc_layers-1) x (W[Hd][Hd] b[Hd]) | fc2 W[P+1][Hd] b[P+1]
-//   policy  Wp[HC][64] bp[HC] | pi_head_convs x (W[HC][HC][3][3] b[HC]) |
+//   policy  Wp[HC][CH] bp[HC] | pi_head_convs x (W[HC][HC][3][3] b[HC]) |
 //           flat: Wfc[M][HC*H*W] b[M]      spatial: Wpol[PC][HC] bpol[PC]
 #include <hip/hip_runtime.h>
 
@@ -22,7 +22,6 @@
 
 namespace {
 
-constexpr int CH = 64;
 thread_local std::string g_err;
 int fail(const char** err, int code, const char* what, hipError_t e = hipSuccess) {
   char buf[256];
@@ -113,6 +112,7 @@ struct Net {
 };
 
 size_t count_floats(const azmi_net_desc* d) {
+  const size_t CH = d->channels;
   const size_t HW = static_cast<size_t>(d->height) * d->width, HC = d->head_channels, Hd = d->v_hidden, P1 = d->num_players + 1;
   size_t n = static_cast<size_t>(CH) * d->in_channels * 9 + CH;
   n += static_cast<size_t>(d->depth) * (2 * CH + static_cast<size_t>(CH) * CH * 9 + CH + static_cast<size_t>(CH) * CH * 9);
@@ -149,6 +149,7 @@ int reserve(void* impl, uint32_t batch, const char** err) {
   for (float*& p : n->small) { if (p) (void)hipFree(p); p = nullptr; }
   n->rows = 0;
   const size_t HW = static_cast<size_t>(n->d.height) * n->d.width;
+  const size_t CH = std::max<size_t>(n->d.channels, n->d.head_channels);
   const size_t wide = std::max<size_t>(std::max<size_t>(n->d.v_hidden, n->d.num_moves), n->d.head_channels);
   for (float*& p : n->buf)
     if (hipMalloc(reinterpret_cast<void**>(&p), static_cast<size_t>(batch) * CH * HW * sizeof(float)) != hipSuccess)
@@ -161,8 +162,8 @@ int reserve(void* impl, uint32_t batch, const char** err) {
 }
 
 int create(const azmi_net_desc* d, const void* blob, size_t bytes, int device, void** impl, const char** err) {
-  if (d->channels != CH || d->kernel_size != 3) return fail(err, AZMI_ERR_INVALID, "fp32 leaf net: 64 trunk channels, 3x3 convolutions");
-  if (d->head_channels > CH || d->v_fc_layers < 1 || d->v_head_convs < 0 || d->pi_head_convs < 0)
+  if (d->channels < 1 || d->kernel_size != 3) return fail(err, AZMI_ERR_INVALID, "fp32 leaf net: 3x3 convolutions only");
+  if (d->head_channels < 1 || d->v_fc_layers < 1 || d->v_head_convs < 0 || d->pi_head_convs < 0)
     return fail(err, AZMI_ERR_INVALID, "fp32 leaf net: head sizes out of range");
   if (d->policy_channels > 0 && d->policy_channels * d->height * d->width != d->num_moves)
     return fail(err, AZMI_ERR_INVALID, "fp32 leaf net: spatial head with global actions is not supported");
@@ -187,6 +188,7 @@ int forward(void* impl, const float* canon, float* v_out, float* pi_out, uint32_
   if (B > n->rows) { const int rc = reserve(n, B, err); if (rc != AZMI_OK) return rc; }
   const azmi_net_desc& d = n->d;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const int CH = d.channels;
   const int H = d.height, W = d.width, HW = H * W, HC = d.head_channels, Hd = d.v_hidden, P1 = d.num_players + 1, M = d.num_moves;
   const float* p = n->blob;
   auto take = [&](size_t count) { const float* q = p; p += count; return q; };

@@ -153,3 +153,22 @@ def test_fp32_path_batch_larger_than_reservation():
     with torch.no_grad():
         vr, pr = net.to(dev).process(x)
     assert (v - vr).abs().max().item() <= TOL_F32 and (pi - pr).abs().max().item() <= TOL_F32
+
+
+@pytest.mark.parametrize("which", ["brandubh", "opentafl"])
+def test_fp32_path_other_tafl_nets(which):
+    """configs/brandubh.yaml (32 channels, 7x7) and an 8-plane OpenTafl net run on the library's fp32 path
+    (the MFMA kernels cover the two BASELINE nets); equality with a PyTorch fp32 forward of the same weights."""
+    import alphazero as az
+    from alphazero import torch_net
+    dev = torch.device("cuda:0")
+    spec = torch_net.brandubh_spec() if which == "brandubh" else torch_net.opentafl_spec(depth=2)
+    net = torch_net.random_init(spec, seed=11)
+    hip = az.HipLeafNet(net, precision="fp32")
+    x = torch.rand((37,) + tuple(spec.in_shape), generator=torch.Generator().manual_seed(2)).to(dev)
+    v, pi = hip.process(x)
+    with torch.no_grad():
+        vr, pr = net.to(dev).process(x)
+    assert (v - vr).abs().max().item() <= TOL_F32 and (pi - pr).abs().max().item() <= TOL_F32
+    with pytest.raises(RuntimeError):
+        az.HipLeafNet(net)          # the bf16 MFMA kernels are instantiated for the BASELINE nets only: loud failure
