@@ -1,5 +1,6 @@
 import sys, time
-sys.path.insert(0, "alphazero-pybind11_amd")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "alphazero-pybind11_amd"))
 import torch, alphazero as az
 from alphazero import torch_net
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
