@@ -444,7 +444,7 @@ class TawlbwrddGS(GameState):  # py_wrapper.cc:549-560
 
 class MCTS:
     """The stand-alone search tree (py_wrapper.cc:192-220, mcts.h:50-200) on the device: find_leaf / process_result /
-    update_root and the read-outs, call by call.  Connect4 in this round.  `seed` seeds the object's pcg32 stream (the
+    update_root and the read-outs, call by call; pass game=<GS class> for anything but Connect4.  `seed` seeds the object's pcg32 stream (the
     reference shares one unseedable-from-Python thread_local stream; its C++ tests call MCTS::seed_thread_rng)."""
 
     def __init__(self, cpuct, num_players, num_moves, epsilon=0.0, root_policy_temp=1.0, fpu_reduction=0.0,

@@ -1052,9 +1052,8 @@ struct azmi_mcts {
 
 int azmi_mcts_create(int game, const azmi_mcts_config* cfg, uint64_t seed, int device, azmi_mcts** out) {
   if (!cfg || !out) return fail(AZMI_ERR_INVALID, "null argument");
-  if (game != AZMI_GAME_CONNECT4) return fail(AZMI_ERR_INVALID, "the stand-alone MCTS class is implemented for Connect4 in this round");
   GameInfo gi;
-  game_info(game, &gi);
+  if (!game_info(game, &gi)) return fail(AZMI_ERR_INVALID, "unknown game id %d", game);
   if (cfg->num_players != gi.P || cfg->num_moves != gi.M) return fail(AZMI_ERR_INVALID, "MCTS(num_players, num_moves) do not match the game");
   if (cfg->relative_values) return fail(AZMI_ERR_INVALID, "relative_values games are not implemented");
   azmi_play_params p;
@@ -1062,7 +1061,9 @@ int azmi_mcts_create(int game, const azmi_mcts_config* cfg, uint64_t seed, int d
   p.games_to_play = 1; p.concurrent_games = 1; p.max_batch_size = 1;
   p.num_mcts_visits = gi.P;
   const uint32_t sims = cfg->max_simulations ? cfg->max_simulations : 50000u;
-  for (uint32_t i = 0; i < gi.P; ++i) p.mcts_visits[i] = (sims + 20) / 21;   // arena = (21 * visits + 42) * 7 nodes >= sims * 7
+  // Connect4: arena = (21 * visits + 42) * 7 nodes >= sims * 7.  Wide games: two halves of 4 x (visits + 16) x 240 nodes,
+  // compacted after update_root when the active half fills up
+  for (uint32_t i = 0; i < gi.P; ++i) p.mcts_visits[i] = game == AZMI_GAME_CONNECT4 ? (sims + 20) / 21 : std::min<uint32_t>(sims, 8000u);
   p.cpuct = cfg->cpuct; p.epsilon = cfg->epsilon; p.mcts_root_temp = cfg->root_policy_temp; p.fpu_reduction = cfg->fpu_reduction;
   p.root_fpu_zero = cfg->root_fpu_zero; p.shaped_dirichlet = cfg->shaped_dirichlet;
   p.gumbel_enabled = cfg->gumbel_enabled; p.gumbel_m = cfg->gumbel_m; p.gumbel_c_visit = cfg->gumbel_c_visit;
@@ -1085,7 +1086,7 @@ int azmi_mcts_create(int game, const azmi_mcts_config* cfg, uint64_t seed, int d
   m->moves_cap = gi.max_turns + 8;
   m->vec = std::max<uint32_t>(gi.M, 64u);
   auto A = [&](auto*& ptr, size_t n) { return m->pm->alloc(ptr, n, true); };
-  rc = A(m->d_init, 512); if (rc == AZMI_OK) rc = A(m->d_moves, m->moves_cap); if (rc == AZMI_OK) rc = A(m->d_out_moves, m->moves_cap);
+  rc = A(m->d_init, 1024); if (rc == AZMI_OK) rc = A(m->d_moves, m->moves_cap); if (rc == AZMI_OK) rc = A(m->d_out_moves, m->moves_cap);
   if (rc == AZMI_OK) rc = A(m->d_len, 1); if (rc == AZMI_OK) rc = A(m->d_status, 1);
   if (rc == AZMI_OK) rc = A(m->d_f, m->vec); if (rc == AZMI_OK) rc = A(m->d_u, m->vec + 64);
   if (rc != AZMI_OK) { azmi_pm_destroy(m->pm); delete m; return rc; }
@@ -1100,9 +1101,14 @@ void azmi_mcts_destroy(azmi_mcts* m) {
 }
 
 namespace {
+uint32_t mcts_init_bytes(int game) {
+  return game == AZMI_GAME_CONNECT4 ? Connect4::SERIALIZED : game == AZMI_GAME_BRANDUBH ? 3u * Brandubh::SQ + 5u
+       : game == AZMI_GAME_OPENTAFL ? 3u * OpenTafl::SQ + 5u : 0u;
+}
 int mcts_upload_state(azmi_mcts* m, const uint8_t* init, uint32_t init_bytes, const int32_t* moves, uint32_t len, hipStream_t st) {
   if (len > m->moves_cap) return fail(AZMI_ERR_INVALID, "game record too long");
-  if (init && init_bytes != Connect4::SERIALIZED) return fail(AZMI_ERR_INVALID, "start position must be %u bytes", unsigned(Connect4::SERIALIZED));
+  if (init && (mcts_init_bytes(m->pm->game) == 0 || init_bytes != mcts_init_bytes(m->pm->game)))
+    return fail(AZMI_ERR_INVALID, "start position: %u bytes expected for this game", mcts_init_bytes(m->pm->game));
   if (init) HIP_TRY(hipMemcpyAsync(m->d_init, init, init_bytes, hipMemcpyHostToDevice, st));
   if (len) HIP_TRY(hipMemcpyAsync(m->d_moves, moves, static_cast<size_t>(len) * 4, hipMemcpyHostToDevice, st));
   return AZMI_OK;
@@ -1119,7 +1125,13 @@ int azmi_mcts_find_leaf(azmi_mcts* m, const uint8_t* init, uint32_t init_bytes, 
   HIP_TRY(hipSetDevice(m->pm->device));
   hipStream_t st = m->pm->stream;
   int rc = mcts_upload_state(m, init, init_bytes, moves, len, st); if (rc) return rc;
-  k_mcts_find_leaf<Connect4><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, init ? m->d_init : nullptr, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status);
+  const uint8_t* di = init ? m->d_init : nullptr;
+  switch (m->pm->game) {
+    case AZMI_GAME_CONNECT4: k_mcts_find_leaf<Connect4><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, di, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
+    case AZMI_GAME_TAWLBWRDD: k_mcts_big_find_leaf<Tawlbwrdd><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, di, init_bytes, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
+    case AZMI_GAME_BRANDUBH: k_mcts_big_find_leaf<Brandubh><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, di, init_bytes, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
+    default: k_mcts_big_find_leaf<OpenTafl><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, di, init_bytes, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
+  }
   int32_t status = 0; uint32_t n = 0;
   HIP_TRY(hipMemcpyAsync(&status, m->d_status, 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(&n, m->d_len, 4, hipMemcpyDeviceToHost, st));
@@ -1140,7 +1152,13 @@ int azmi_mcts_process_result(azmi_mcts* m, const float* value, const float* pi, 
   const uint32_t V = m->pm->gi.P + 1, M = m->pm->gi.M;
   HIP_TRY(hipMemcpyAsync(m->pm->ar.v, value, V * 4, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(m->pm->ar.pi, pi, M * 4, hipMemcpyHostToDevice, st));
-  k_mcts_process_result<Connect4><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, root_noise_enabled ? 1u : 0u, m->d_f);
+  const uint32_t rn = root_noise_enabled ? 1u : 0u;
+  switch (m->pm->game) {
+    case AZMI_GAME_CONNECT4: k_mcts_process_result<Connect4><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, rn, m->d_f); break;
+    case AZMI_GAME_TAWLBWRDD: k_mcts_big_process_result<Tawlbwrdd><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, rn, m->d_f); break;
+    case AZMI_GAME_BRANDUBH: k_mcts_big_process_result<Brandubh><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, rn, m->d_f); break;
+    default: k_mcts_big_process_result<OpenTafl><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, rn, m->d_f); break;
+  }
   float tmp[8];
   HIP_TRY(hipMemcpyAsync(tmp, m->d_f, V * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
@@ -1153,7 +1171,23 @@ int azmi_mcts_update_root(azmi_mcts* m, const uint8_t* init, uint32_t init_bytes
   HIP_TRY(hipSetDevice(m->pm->device));
   hipStream_t st = m->pm->stream;
   int rc = mcts_upload_state(m, init, init_bytes, moves, len, st); if (rc) return rc;
-  k_mcts_update_root<Connect4><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, init ? m->d_init : nullptr, m->d_moves, len, move, m->d_status);
+  const uint8_t* di = init ? m->d_init : nullptr;
+  const uint32_t trees = m->pm->gi.P;
+  switch (m->pm->game) {
+    case AZMI_GAME_CONNECT4: k_mcts_update_root<Connect4><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, di, m->d_moves, len, move, m->d_status); break;
+    case AZMI_GAME_TAWLBWRDD:
+      k_mcts_big_update_root<Tawlbwrdd><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, di, init_bytes, m->d_moves, len, move, m->d_status);
+      if (m->pm->ep.half_nodes) k_compact<Tawlbwrdd><<<trees, 256, 0, st>>>(m->pm->ep, m->pm->ar);
+      break;
+    case AZMI_GAME_BRANDUBH:
+      k_mcts_big_update_root<Brandubh><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, di, init_bytes, m->d_moves, len, move, m->d_status);
+      if (m->pm->ep.half_nodes) k_compact<Brandubh><<<trees, 256, 0, st>>>(m->pm->ep, m->pm->ar);
+      break;
+    default:
+      k_mcts_big_update_root<OpenTafl><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, di, init_bytes, m->d_moves, len, move, m->d_status);
+      if (m->pm->ep.half_nodes) k_compact<OpenTafl><<<trees, 256, 0, st>>>(m->pm->ep, m->pm->ar);
+      break;
+  }
   int32_t status = 0;
   HIP_TRY(hipMemcpyAsync(&status, m->d_status, 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
@@ -1176,7 +1210,12 @@ int azmi_mcts_query(azmi_mcts* m, uint32_t kind, float temp, uint32_t arg, const
     HIP_TRY(hipMemcpyAsync(m->d_f, in_f, static_cast<size_t>(m->pm->gi.M) * 4, hipMemcpyHostToDevice, st));
   }
   if (kind == kQPrincipalVariation && arg > 60) arg = 60;
-  k_mcts_query<Connect4><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, kind, temp, arg, m->d_f, m->d_u);
+  switch (m->pm->game) {
+    case AZMI_GAME_CONNECT4: k_mcts_query<Connect4><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, kind, temp, arg, m->d_f, m->d_u); break;
+    case AZMI_GAME_TAWLBWRDD: k_mcts_big_query<Tawlbwrdd><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, kind, temp, arg, m->d_f, m->d_u); break;
+    case AZMI_GAME_BRANDUBH: k_mcts_big_query<Brandubh><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, kind, temp, arg, m->d_f, m->d_u); break;
+    default: k_mcts_big_query<OpenTafl><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, kind, temp, arg, m->d_f, m->d_u); break;
+  }
   if (out_f) HIP_TRY(hipMemcpyAsync(out_f, m->d_f, static_cast<size_t>(m->vec) * 4, hipMemcpyDeviceToHost, st));
   if (out_u) HIP_TRY(hipMemcpyAsync(out_u, m->d_u, static_cast<size_t>(m->vec) * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));

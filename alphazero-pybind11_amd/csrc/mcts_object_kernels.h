@@ -199,3 +199,218 @@ __global__ void k_mcts_query(EngineParams ep, EngineArrays ar, uint32_t kind, fl
 }
 
 }  // namespace azmi
+
+// =====================================================================================================
+// The same object on the wide-game engine (Tafl family): one wavefront, BigSlot member functions.
+// The root GameState is rebuilt from its move list with the repetition list (step_state), exactly like
+// the engine's own game state.
+// =====================================================================================================
+#include "engine_kernels_big.h"
+
+namespace azmi {
+
+template <class GM>
+__device__ __forceinline__ bool mcts_big_replay(BigSlot<GM>& c, const uint8_t* init, uint32_t init_stride, const int32_t* moves, uint32_t len) {
+  if constexpr (GM::kGameId == Tawlbwrdd::kGameId) {
+    c.gs = GM::initial();
+  } else {
+    if (init) {
+      const uint8_t* t = init + 3 * GM::SQ + 1;
+      c.gs = GM::from_board(init, init[3 * GM::SQ], uint32_t(t[0]) | uint32_t(t[1]) << 8 | uint32_t(t[2]) << 16 | uint32_t(t[3]) << 24);
+    } else {
+      c.gs = GM::initial();
+    }
+  }
+  c.glen = 0;
+  constexpr uint32_t SPAN = GM::W + GM::H;
+  for (uint32_t i = 0; i < len; ++i) {
+    const int32_t mv = moves[i];
+    if (mv < 0) break;
+    if (mv >= GM::M) return false;
+    const uint32_t from = static_cast<uint32_t>(mv) / SPAN, tgt = static_cast<uint32_t>(mv) % SPAN;
+    if (!GM::own_piece(c.gs, c.gs.player, from) || !((GM::slide_mask(c.gs, from) >> tgt) & 1u)) return false;
+    bool base_valid = true;
+    if (!c.step_state(c.gs, static_cast<uint32_t>(mv), c.sm.glist, c.glen, base_valid, 0)) return false;
+  }
+  return true;
+}
+
+template <class GM>
+__global__ __launch_bounds__(64) void k_mcts_big_find_leaf(EngineParams ep, EngineArrays ar, const uint8_t* init, uint32_t init_stride,
+                                                           const int32_t* moves, uint32_t len, int32_t* out_moves, uint32_t* out_len, int32_t* status) {
+  __shared__ BigScratch<GM> sm;
+  const uint32_t lane = threadIdx.x;
+  BigSlot<GM> c(ep, ar, sm, 0, lane);
+  c.load();
+  if (ar.sstate[0] == kSlotFresh) c.start_game();
+  if (!mcts_big_replay<GM>(c, init, init_stride, moves, len)) { if (lane == 0) *status = -1; return; }
+  typename GM::State leaf;
+  uint32_t term = 0;
+  const bool ok = c.find_leaf(0, leaf, term);
+  if (lane == 0) {
+    const size_t tb = c.tree_base(0);
+    for (uint32_t i = 0; i < c.plen; ++i) {
+      const uint32_t node = (i + 1 < c.plen) ? ar.path[i + 1] : c.cur;
+      out_moves[i] = static_cast<int32_t>(meta_mv(ar.META[tb + node]));
+    }
+    *out_len = c.plen;
+    *status = ok ? 0 : -2;
+  }
+  c.store(kSlotWaitEval);
+}
+
+template <class GM>
+__global__ __launch_bounds__(64) void k_mcts_big_process_result(EngineParams ep, EngineArrays ar, uint32_t root_noise, float* value_out) {
+  __shared__ BigScratch<GM> sm;
+  constexpr int P = GM::P;
+  const uint32_t lane = threadIdx.x;
+  BigSlot<GM> c(ep, ar, sm, 0, lane);
+  c.load();
+  const uint32_t term = meta_term(ar.META[c.tree_base(0) + c.cur]);
+  c.process_result(0, true, root_noise != 0);
+  if (lane == 0)
+    for (int i = 0; i <= P; ++i) value_out[i] = term ? ((static_cast<int>(term) - 1 == i) ? 1.0f : 0.0f) : ar.v[i];
+  c.store(kSlotWaitEval);
+}
+
+template <class GM>
+__global__ __launch_bounds__(64) void k_mcts_big_update_root(EngineParams ep, EngineArrays ar, const uint8_t* init, uint32_t init_stride,
+                                                             const int32_t* moves, uint32_t len, uint32_t move, int32_t* status) {
+  __shared__ BigScratch<GM> sm;
+  const uint32_t lane = threadIdx.x;
+  BigSlot<GM> c(ep, ar, sm, 0, lane);
+  c.load();
+  if (ar.sstate[0] == kSlotFresh) c.start_game();
+  if (!mcts_big_replay<GM>(c, init, init_stride, moves, len)) { if (lane == 0) *status = -1; return; }
+  const bool ok = c.update_root(0, move);
+  // a long-lived object needs the arena compaction the engine does between rounds
+  if (ok && ep.half_nodes && lane == 0) {
+    const uint32_t b = c.t_bump[0];
+    if (b - ((b - 1) / ep.half_nodes) * ep.half_nodes > ep.compact_above) ar.compact_flag[0] = 1;
+  }
+  if (lane == 0) *status = ok ? 0 : -3;
+  c.store(kSlotFresh + 1);   // kSlotWaitEval, but with no pending simulation to re-point: plen is reset below
+  if (lane == 0) ar.plen[0] = 0;
+}
+
+template <class GM>
+__global__ __launch_bounds__(64) void k_mcts_big_query(EngineParams ep, EngineArrays ar, uint32_t kind, float temp, uint32_t arg, float* out_f, uint32_t* out_u) {
+  __shared__ BigScratch<GM> sm;
+  constexpr int P = GM::P;
+  constexpr uint32_t M = GM::M;
+  const uint32_t lane = threadIdx.x;
+  BigSlot<GM> c(ep, ar, sm, 0, lane);
+  c.load();
+  if (ar.sstate[0] == kSlotFresh) c.start_game();
+  const size_t tb = c.tree_base(0);
+  const uint32_t root = c.t_root[0];
+  const uint64_t rmeta = ar.META[tb + root];
+  const uint32_t k = meta_nch(rmeta), c0 = meta_ch0(rmeta), root_n = ar.N[tb + root];
+  c.stage_root(tb, c0, k);
+  auto dense_out = [&]() { for (uint32_t m = lane; m < M; m += 64) out_f[m] = sm.dense[m]; };
+  switch (kind) {
+    case kQCounts:
+      for (uint32_t m = lane; m < M; m += 64) out_u[m] = 0;
+      c.sync();
+      for (uint32_t i = lane; i < k; i += 64) out_u[sm.moves[i]] = sm.n[i];
+      break;
+    case kQProbs: c.probs(temp, k); dense_out(); break;
+    case kQProbsPruned: c.probs_pruned(temp, root_n, k); dense_out(); break;
+    case kQRootValue: {
+      float q = 0, d = 0; bool found = false;
+      for (uint32_t i = 0; i < k; ++i) { const float qi = sm.f1[i]; if (sm.n[i] > 0 && qi > q) { q = qi; d = ar.D[tb + c0 + i]; found = true; } }
+      if (!found && root_n > 0) { q = ar.V[tb + root]; d = ar.D[tb + root]; }
+      const float w = q - d / static_cast<int32_t>(P);
+      const float l = static_cast<float>(1.0 - static_cast<double>(w) - static_cast<double>(d));
+      if (lane == 0) { out_f[0] = w; out_f[1] = l; out_f[2] = d; }
+      break;
+    }
+    case kQRootQ:
+      for (uint32_t m = lane; m < M; m += 64) out_f[m] = 0.0f;
+      c.sync();
+      for (uint32_t i = lane; i < k; i += 64) out_f[sm.moves[i]] = sm.f1[i];
+      break;
+    case kQScalars: {
+      const uint32_t dep = c.t_depth[0];
+      float ent = 0.0f;
+      const float kf = static_cast<float>(k);
+      if (!(kf <= 1 || root_n <= 1)) {
+        const float log_k = az_logf(kf), total_n = static_cast<float>(root_n);
+        for (uint32_t i = lane; i < k; i += 64) {
+          float t = 0.0f;
+          if (sm.n[i] > 0) { const float p = static_cast<float>(sm.n[i]) / total_n; t = p * az_logf(p); }
+          sm.f0[i] = t;
+        }
+        c.sync();
+        float e = 0.0f;
+        for (uint32_t i = 0; i < k; ++i) if (sm.n[i] > 0) e -= sm.f0[i];
+        ent = e / log_k;
+      }
+      if (lane == 0) {
+        out_u[0] = dep; out_u[1] = root_n; out_u[2] = k;
+        out_f[0] = dep == 0 ? 0.0f : static_cast<float>(c.t_tld[0]) / static_cast<float>(dep);
+        out_f[1] = ent;
+      }
+      break;
+    }
+    case kQGumbelPolicy: c.gumbel_improved_policy(k, ar.V[tb + root]); dense_out(); break;
+    case kQGumbelFinal: { const uint32_t a = c.gumbel_final_action(0, tb, c0, k); if (lane == 0) out_u[0] = a; break; }
+    case kQAddRootNoise:
+      if (k > 0) {
+        for (uint32_t i = lane; i < k; i += 64) sm.f0[i] = sm.f2[i];
+        c.sync();
+        c.add_root_noise(k, c.seat_eps(0));
+        for (uint32_t i = lane; i < k; i += 64) ar.Pr[tb + c0 + i] = sm.f0[i];
+      }
+      break;
+    case kQApplyRootTemp: c.reapply_root_prior(0, false); break;
+    case kQPickMove: {
+      for (uint32_t m = lane; m < M; m += 64) sm.dense[m] = out_f[m];
+      c.sync();
+      const uint32_t mv = c.pick_move();
+      if (lane == 0) out_u[0] = mv;
+      break;
+    }
+    case kQPrincipalVariation: {
+      uint32_t node = root, len = 0;
+      for (uint32_t ply = 0; ply < arg; ++ply) {
+        const uint64_t m = ar.META[tb + node];
+        const uint32_t kk = meta_nch(m), cc0 = meta_ch0(m);
+        if (kk == 0) break;
+        uint32_t best = 0xFFFFFFFFu;
+        if (ply == 0 && ep.gumbel_on) {
+          const uint32_t a = c.gumbel_final_action(0, tb, c0, k);
+          uint32_t hit = 0xFFFFFFFFu;
+          for (uint32_t i = lane; i < kk; i += 64) if (meta_mv(ar.META[tb + cc0 + i]) == a) hit = i;
+          for (int off = 32; off > 0; off >>= 1) hit = min(hit, __shfl_xor(hit, off, 64));
+          best = hit;
+        }
+        if (best == 0xFFFFFFFFu) {   // first child with the strictly largest visit count
+          uint32_t bn = 0, bi = 0xFFFFFFFFu;
+          for (uint32_t i = lane; i < kk; i += 64) { const uint32_t ni = ar.N[tb + cc0 + i]; if (ni > bn) { bn = ni; bi = i; } }
+          for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t on = __shfl_xor(bn, off, 64), oi = __shfl_xor(bi, off, 64);
+            if (on > bn || (on == bn && oi < bi)) { bn = on; bi = oi; }
+          }
+          best = bn == 0 ? 0xFFFFFFFFu : bi;
+        }
+        if (best == 0xFFFFFFFFu || ar.N[tb + cc0 + best] == 0) break;
+        if (lane == 0) out_u[1 + len] = meta_mv(ar.META[tb + cc0 + best]);
+        ++len;
+        node = cc0 + best;
+      }
+      if (lane == 0) out_u[0] = len;
+      break;
+    }
+    case kQSetGumbelSims: if (ep.gumbel_on) c.set_gumbel_num_sims(0, arg); break;
+    case kQRootChildren:
+      for (uint32_t i = lane; i < k && i < 60; i += 64) { out_u[4 + i] = sm.moves[i]; out_f[i] = sm.f2[i]; }
+      if (lane == 0) { out_u[0] = k; out_u[1] = static_cast<uint32_t>(c.rng.state); out_u[2] = static_cast<uint32_t>(c.rng.state >> 32); }
+      break;
+    default: break;
+  }
+  c.sync();
+  c.store(kSlotWaitEval);
+}
+
+}  // namespace azmi

@@ -220,7 +220,7 @@ int azmi_tafl_symmetries(uint32_t board, uint32_t channels, uint32_t num_values,
 const char* azmi_symmetries_last_error(void);
 
 /* ---- the stand-alone MCTS class (py_wrapper.cc:192-220, mcts.h:50-200): one search tree driven call by call.
- * Connect4 in this round.  A GameState argument is passed as start position (`init`, NULL = initial position, else the
+ * All four games.  A GameState argument is passed as start position (`init`, NULL = initial position, else the
  * game's serialized image as in azmi_game_replay_from) + the moves played from it.  The object owns one pcg32
  * stream (the reference shares a thread_local one across all trees of a thread). */
 typedef struct azmi_mcts azmi_mcts;
