@@ -867,6 +867,19 @@ int azmi_pm_move_log(azmi_pm* pm, uint32_t* rows, uint32_t* counts, uint32_t cap
   return AZMI_OK;
 }
 
+// debug: keys of the leaves the last round sent to the net (0 = none), one per slot
+int azmi_debug_eval_keys(azmi_pm* pm, uint64_t* out, uint32_t cap, uint32_t* n) {
+  if (!pm || !out || !n) return fail(AZMI_ERR_INVALID, "null argument");
+  if (!pm->ep.cache_on) return fail(AZMI_ERR_STATE, "cache is off");
+  std::vector<uint64_t> k;
+  const int rc = d2h(k, pm->ar.cache_keys, pm->ep.S, pm->last);
+  if (rc) return rc;
+  const uint32_t cnt = std::min<uint32_t>(cap, pm->ep.S);
+  std::memcpy(out, k.data(), static_cast<size_t>(cnt) * 8);
+  *n = cnt;
+  return AZMI_OK;
+}
+
 int azmi_debug_trace(azmi_pm* pm, uint64_t* out, uint32_t cap, uint32_t* n) {
   std::vector<uint64_t> t;
   const int rc = d2h(t, pm->ar.trace, 2 * static_cast<size_t>(pm->ep.trace_cap), pm->last);
