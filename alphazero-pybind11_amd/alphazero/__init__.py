@@ -532,11 +532,37 @@ class MCTS:
         """MCTS::pick_move (static in the reference, drawing from the thread's stream): draws from this object's stream."""
         return int(self._query(10, in_f=pi)[1][0])
 
-    # the WU-UCT batched API (mcts.cc:752-851) is not implemented on the device
-    def find_leaf_batched(self, *a, **k): raise RuntimeError("find_leaf_batched is not implemented by the MI355X engine yet")
-    def process_result_batched(self, *a, **k): raise RuntimeError("process_result_batched is not implemented by the MI355X engine yet")
-    def in_flight_count(self): return 0
-    def reset_batch(self): return None
+    # ---- WU-UCT batched API (py_wrapper.cc:212-215, mcts.cc:752-851) ----
+    def find_leaf_batched(self, gs):
+        init, mv = self._gs_args(gs)
+        out = np.zeros(512, np.int32)
+        n = C.c_uint32()
+        check(lib.azmi_mcts_find_leaf_batched(self._h, None if init is None else init.ctypes.data, 0 if init is None else init.size,
+                                              mv.ctypes.data if mv.size else None, mv.size, out.ctypes.data, out.size, C.byref(n)))
+        leaf = gs.copy()
+        for m in out[: n.value]:
+            leaf._moves.append(int(m))
+        leaf._snap = None
+        return leaf
+
+    def process_result_batched(self, gs, leaf_index, value, pi, root_noise_enabled=False):
+        v = np.ascontiguousarray(value, dtype=np.float32); p = np.ascontiguousarray(pi, dtype=np.float32)
+        if v.shape != (self._P + 1,) or p.shape != (self._M,):
+            raise RuntimeError("process_result_batched: value must be [num_players + 1] and pi [num_moves]")
+        out = np.zeros(self._P + 1, np.float32)
+        check(lib.azmi_mcts_process_result_batched(self._h, int(leaf_index), v.ctypes.data, p.ctypes.data, int(bool(root_noise_enabled)),
+                                                   out.ctypes.data))
+        if isinstance(value, np.ndarray) and value.dtype == np.float32:
+            value[...] = out
+        return out
+
+    def in_flight_count(self):
+        n = C.c_uint32()
+        check(lib.azmi_mcts_in_flight_count(self._h, C.byref(n)))
+        return n.value
+
+    def reset_batch(self):
+        check(lib.azmi_mcts_reset_batch(self._h))
 
 
 def dumb_eval(gs):

@@ -138,6 +138,10 @@ SYMBOLS = {
     "azmi_mcts_destroy": (None, [_VP]),
     "azmi_mcts_find_leaf": (C.c_int, [_VP, _VP, C.c_uint32, _VP, C.c_uint32, _VP, C.c_uint32, _PP(C.c_uint32)]),
     "azmi_mcts_process_result": (C.c_int, [_VP, _VP, _VP, C.c_int, _VP]),
+    "azmi_mcts_find_leaf_batched": (C.c_int, [_VP, _VP, C.c_uint32, _VP, C.c_uint32, _VP, C.c_uint32, _PP(C.c_uint32)]),
+    "azmi_mcts_process_result_batched": (C.c_int, [_VP, C.c_uint32, _VP, _VP, C.c_int, _VP]),
+    "azmi_mcts_in_flight_count": (C.c_int, [_VP, _PP(C.c_uint32)]),
+    "azmi_mcts_reset_batch": (C.c_int, [_VP]),
     "azmi_mcts_update_root": (C.c_int, [_VP, _VP, C.c_uint32, _VP, C.c_uint32, C.c_uint32]),
     "azmi_mcts_query": (C.c_int, [_VP, C.c_uint32, C.c_float, C.c_uint32, _VP, _VP, _VP]),
     "azmi_game_replay_ex": (C.c_int, [C.c_int, C.c_int, _VP, C.c_uint32, _VP, C.c_uint32, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_uint32]),
@@ -167,4 +171,6 @@ lib = load()
 def check(rc):
     if rc != 0:
         msg = lib.azmi_last_error().decode("utf-8", "replace")
+        if rc == -6:   # AZMI_ERR_RANGE: the reference's std::out_of_range, which pybind11 maps to IndexError
+            raise IndexError(msg or "index out of range")
         raise RuntimeError(msg or f"azmi error {rc}")

@@ -1061,6 +1061,8 @@ struct azmi_mcts {
   uint8_t* d_init = nullptr; int32_t* d_moves = nullptr; int32_t* d_out_moves = nullptr;
   uint32_t* d_len = nullptr; int32_t* d_status = nullptr; float* d_f = nullptr; uint32_t* d_u = nullptr;
   uint32_t moves_cap = 0, vec = 0;
+  WuArrays wu{};                         // Node::n_in_flight + MCTS::in_flight_ (mcts.h:24,171)
+  uint32_t ifl_count = 0, ifl_cap = 0;
 };
 
 int azmi_mcts_create(int game, const azmi_mcts_config* cfg, uint64_t seed, int device, azmi_mcts** out) {
@@ -1102,6 +1104,10 @@ int azmi_mcts_create(int game, const azmi_mcts_config* cfg, uint64_t seed, int d
   rc = A(m->d_init, 1024); if (rc == AZMI_OK) rc = A(m->d_moves, m->moves_cap); if (rc == AZMI_OK) rc = A(m->d_out_moves, m->moves_cap);
   if (rc == AZMI_OK) rc = A(m->d_len, 1); if (rc == AZMI_OK) rc = A(m->d_status, 1);
   if (rc == AZMI_OK) rc = A(m->d_f, m->vec); if (rc == AZMI_OK) rc = A(m->d_u, m->vec + 64);
+  m->ifl_cap = 1024;
+  if (rc == AZMI_OK) rc = A(m->wu.nif, static_cast<size_t>(gi.P) * m->pm->ep.cap);
+  if (rc == AZMI_OK) rc = A(m->wu.ifl_path, static_cast<size_t>(m->ifl_cap) * m->pm->ep.max_depth);
+  if (rc == AZMI_OK) rc = A(m->wu.ifl_plen, m->ifl_cap); if (rc == AZMI_OK) rc = A(m->wu.ifl_cur, m->ifl_cap);
   if (rc != AZMI_OK) { azmi_pm_destroy(m->pm); delete m; return rc; }
   *out = m;
   return AZMI_OK;
@@ -1140,10 +1146,10 @@ int azmi_mcts_find_leaf(azmi_mcts* m, const uint8_t* init, uint32_t init_bytes, 
   int rc = mcts_upload_state(m, init, init_bytes, moves, len, st); if (rc) return rc;
   const uint8_t* di = init ? m->d_init : nullptr;
   switch (m->pm->game) {
-    case AZMI_GAME_CONNECT4: k_mcts_find_leaf<Connect4><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, di, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
-    case AZMI_GAME_TAWLBWRDD: k_mcts_big_find_leaf<Tawlbwrdd><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, di, init_bytes, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
-    case AZMI_GAME_BRANDUBH: k_mcts_big_find_leaf<Brandubh><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, di, init_bytes, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
-    default: k_mcts_big_find_leaf<OpenTafl><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, di, init_bytes, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
+    case AZMI_GAME_CONNECT4: k_mcts_find_leaf<Connect4><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif, di, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
+    case AZMI_GAME_TAWLBWRDD: k_mcts_big_find_leaf<Tawlbwrdd><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif, di, init_bytes, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
+    case AZMI_GAME_BRANDUBH: k_mcts_big_find_leaf<Brandubh><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif, di, init_bytes, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
+    default: k_mcts_big_find_leaf<OpenTafl><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif, di, init_bytes, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
   }
   int32_t status = 0; uint32_t n = 0;
   HIP_TRY(hipMemcpyAsync(&status, m->d_status, 4, hipMemcpyDeviceToHost, st));
@@ -1179,6 +1185,71 @@ int azmi_mcts_process_result(azmi_mcts* m, const float* value, const float* pi, 
   return mcts_check(m, st);
 }
 
+// ---- WU-UCT batched API, mcts.cc:752-851 -----------------------------------------------------------------------
+int azmi_mcts_find_leaf_batched(azmi_mcts* m, const uint8_t* init, uint32_t init_bytes, const int32_t* moves, uint32_t len,
+                                int32_t* leaf_moves, uint32_t cap, uint32_t* leaf_len) {
+  if (!m || !leaf_len || (len && !moves)) return fail(AZMI_ERR_INVALID, "null argument");
+  if (m->ifl_count >= m->ifl_cap) return fail(AZMI_ERR_OVERFLOW, "%u leaves in flight: call reset_batch", m->ifl_count);
+  HIP_TRY(hipSetDevice(m->pm->device));
+  hipStream_t st = m->pm->stream;
+  int rc = mcts_upload_state(m, init, init_bytes, moves, len, st); if (rc) return rc;
+  const uint8_t* di = init ? m->d_init : nullptr;
+  const uint32_t idx = m->ifl_count;
+  switch (m->pm->game) {
+    case AZMI_GAME_CONNECT4: k_mcts_find_leaf_batched<Connect4><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu, idx, di, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
+    case AZMI_GAME_TAWLBWRDD: k_mcts_big_find_leaf_batched<Tawlbwrdd><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu, idx, di, init_bytes, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
+    case AZMI_GAME_BRANDUBH: k_mcts_big_find_leaf_batched<Brandubh><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu, idx, di, init_bytes, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
+    default: k_mcts_big_find_leaf_batched<OpenTafl><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu, idx, di, init_bytes, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
+  }
+  int32_t status = 0; uint32_t n = 0;
+  HIP_TRY(hipMemcpyAsync(&status, m->d_status, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(&n, m->d_len, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (status == -1) return fail(AZMI_ERR_INVALID, "illegal move in the game record");
+  rc = mcts_check(m, st); if (rc) return rc;
+  if (status != 0) return fail(AZMI_ERR_OVERFLOW, "find_leaf_batched failed (tree arena or path capacity)");
+  if (n > cap) return fail(AZMI_ERR_INVALID, "leaf_moves too small");
+  if (n && leaf_moves) HIP_TRY(hipMemcpy(leaf_moves, m->d_out_moves, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost));
+  *leaf_len = n;
+  ++m->ifl_count;
+  return AZMI_OK;
+}
+
+int azmi_mcts_process_result_batched(azmi_mcts* m, uint32_t leaf_index, const float* value, const float* pi, int root_noise_enabled,
+                                     float* value_out) {
+  if (!m || !value || !pi) return fail(AZMI_ERR_INVALID, "null argument");
+  if (leaf_index >= m->ifl_count) return fail(AZMI_ERR_RANGE, "leaf_index %u out of range (%u in flight)", leaf_index, m->ifl_count);
+  HIP_TRY(hipSetDevice(m->pm->device));
+  hipStream_t st = m->pm->stream;
+  const uint32_t V = m->pm->gi.P + 1, M = m->pm->gi.M;
+  HIP_TRY(hipMemcpyAsync(m->pm->ar.v, value, V * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(m->pm->ar.pi, pi, M * 4, hipMemcpyHostToDevice, st));
+  const uint32_t rn = root_noise_enabled ? 1u : 0u;
+  switch (m->pm->game) {
+    case AZMI_GAME_CONNECT4: k_mcts_process_result_batched<Connect4><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu, leaf_index, rn, m->d_f); break;
+    case AZMI_GAME_TAWLBWRDD: k_mcts_big_process_result_batched<Tawlbwrdd><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu, leaf_index, rn, m->d_f); break;
+    case AZMI_GAME_BRANDUBH: k_mcts_big_process_result_batched<Brandubh><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu, leaf_index, rn, m->d_f); break;
+    default: k_mcts_big_process_result_batched<OpenTafl><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu, leaf_index, rn, m->d_f); break;
+  }
+  float tmp[8];
+  HIP_TRY(hipMemcpyAsync(tmp, m->d_f, V * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (value_out) std::memcpy(value_out, tmp, V * 4);
+  return mcts_check(m, st);
+}
+
+int azmi_mcts_in_flight_count(const azmi_mcts* m, uint32_t* out) {
+  if (!m || !out) return fail(AZMI_ERR_INVALID, "null argument");
+  *out = m->ifl_count;
+  return AZMI_OK;
+}
+
+int azmi_mcts_reset_batch(azmi_mcts* m) {
+  if (!m) return fail(AZMI_ERR_INVALID, "null argument");
+  m->ifl_count = 0;
+  return AZMI_OK;
+}
+
 int azmi_mcts_update_root(azmi_mcts* m, const uint8_t* init, uint32_t init_bytes, const int32_t* moves, uint32_t len, uint32_t move) {
   if (!m || (len && !moves)) return fail(AZMI_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(m->pm->device));
@@ -1187,18 +1258,18 @@ int azmi_mcts_update_root(azmi_mcts* m, const uint8_t* init, uint32_t init_bytes
   const uint8_t* di = init ? m->d_init : nullptr;
   const uint32_t trees = m->pm->gi.P;
   switch (m->pm->game) {
-    case AZMI_GAME_CONNECT4: k_mcts_update_root<Connect4><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, di, m->d_moves, len, move, m->d_status); break;
+    case AZMI_GAME_CONNECT4: k_mcts_update_root<Connect4><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif, di, m->d_moves, len, move, m->d_status); break;
     case AZMI_GAME_TAWLBWRDD:
-      k_mcts_big_update_root<Tawlbwrdd><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, di, init_bytes, m->d_moves, len, move, m->d_status);
-      if (m->pm->ep.half_nodes) k_compact<Tawlbwrdd><<<trees, 256, 0, st>>>(m->pm->ep, m->pm->ar);
+      k_mcts_big_update_root<Tawlbwrdd><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif, di, init_bytes, m->d_moves, len, move, m->d_status);
+      if (m->pm->ep.half_nodes) k_compact<Tawlbwrdd><<<trees, 256, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif);
       break;
     case AZMI_GAME_BRANDUBH:
-      k_mcts_big_update_root<Brandubh><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, di, init_bytes, m->d_moves, len, move, m->d_status);
-      if (m->pm->ep.half_nodes) k_compact<Brandubh><<<trees, 256, 0, st>>>(m->pm->ep, m->pm->ar);
+      k_mcts_big_update_root<Brandubh><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif, di, init_bytes, m->d_moves, len, move, m->d_status);
+      if (m->pm->ep.half_nodes) k_compact<Brandubh><<<trees, 256, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif);
       break;
     default:
-      k_mcts_big_update_root<OpenTafl><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, di, init_bytes, m->d_moves, len, move, m->d_status);
-      if (m->pm->ep.half_nodes) k_compact<OpenTafl><<<trees, 256, 0, st>>>(m->pm->ep, m->pm->ar);
+      k_mcts_big_update_root<OpenTafl><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif, di, init_bytes, m->d_moves, len, move, m->d_status);
+      if (m->pm->ep.half_nodes) k_compact<OpenTafl><<<trees, 256, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif);
       break;
   }
   int32_t status = 0;

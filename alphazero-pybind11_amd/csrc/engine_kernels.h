@@ -399,8 +399,9 @@ struct SlotCtx {
 
   // ---- Node::best_child ------------------------------------------------------------------
   // children live in lanes [0,k): n_l, q_l, p_l.  Returns the winning lane.
+  // (`if_l` = Node::n_in_flight of the child, `n_parent` includes the parent's: only the WU-UCT batched API has them non-zero)
   __device__ __forceinline__ uint32_t select_child(uint32_t k, uint32_t n_l, float q_l, float p_l, float v_parent,
-                                   uint32_t n_parent, float fpu_reduction) const {
+                                   uint32_t n_parent, float fpu_reduction, uint32_t if_l = 0) const {
     float seen = 0.0f;
     for (uint32_t i = 0; i < k; ++i) {
       const uint32_t ni = bcast(n_l, i);
@@ -409,7 +410,7 @@ struct SlotCtx {
     }
     const float fpu_value = v_parent - fpu_reduction * sqrtf(seen);
     const float sqrt_n = sqrtf(static_cast<float>(n_parent));
-    float u = (n_l == 0 ? fpu_value : q_l) + ep.cpuct * p_l * sqrt_n / static_cast<float>(n_l + 1);
+    float u = (n_l == 0 ? fpu_value : q_l) + ep.cpuct * p_l * sqrt_n / static_cast<float>(n_l + if_l + 1);
     // a strict `>` scan never replaces the incumbent with a NaN and never leaves a NaN at
     // index 0: map NaN to +inf at lane 0 and -inf elsewhere, then butterfly (score, index)
     if (u != u) u = (lane == 0) ? __builtin_inff() : -__builtin_inff();
@@ -421,6 +422,51 @@ struct SlotCtx {
       if (ou > u || (ou == u && oi < idx)) { u = ou; idx = oi; }
     }
     return idx;
+  }
+
+  // ---- MCTS::find_leaf_batched (WU-UCT), mcts.cc:752-784 ----------------------------------------
+  // `nif` = Node::n_in_flight per arena node of this tree.  Walks through visited nodes AND nodes with an
+  // evaluation in flight, marks every node of the path after selecting below it, expands only a node
+  // nobody expanded yet.  No Gumbel branch: the reference's batched descent is plain PUCT.
+  __device__ __forceinline__ bool find_leaf_wu(uint32_t seat, typename GM::State& leaf, uint32_t& term, uint32_t* nif) {
+    sync_lanes();
+    const size_t tb = tree_base(seat);
+    const uint32_t root = AZMI_SEL(t_root, seat);
+    cur = root; plen = 0;
+    leaf = gs;
+    uint64_t meta = ar.META[tb + cur];
+    uint32_t n = ar.N[tb + cur], nf = nif[cur];
+    uint32_t* path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
+    while ((n > 0 || nf > 0) && meta_nch(meta) != 0 && meta_term(meta) == 0) {
+      if (plen >= ep.max_depth) { raise(8u); return false; }
+      if (lane == 0) path[plen] = cur;
+      ++plen;
+      const uint32_t k = meta_nch(meta), c0 = meta_ch0(meta);
+      const size_t ci = tb + c0 + lane;
+      uint32_t n_l = 0, if_l = 0; float q_l = 0.0f, p_l = 0.0f; uint64_t m_l = 0;
+      if (lane < k) { n_l = ar.N[ci]; q_l = ar.Q[ci]; p_l = ar.Pr[ci]; m_l = ar.META[ci]; if_l = nif[c0 + lane]; }
+      const float fpu = (cur == root && seat_fpu_zero(seat)) ? 0.0f : ep.fpu_reduction;
+      const uint32_t best = select_child(k, n_l, q_l, p_l, ar.V[tb + cur], n + nf, fpu, if_l);
+      if (lane == 0) nif[cur] = nf + 1;
+      cur = c0 + best;
+      n = bcast(n_l, best);
+      nf = bcast(if_l, best);
+      meta = bcast(m_l, best);
+      GM::play(leaf, meta_mv(meta));
+    }
+    if (lane == 0) nif[cur] = nf + 1;
+#pragma unroll
+    for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == seat) t_tld[p] += plen;
+    term = meta_term(meta);
+    if (n == 0 && meta_nch(meta) == 0) {
+      term = GM::terminal(leaf);
+      const uint64_t keep = meta_pack(0, 0, meta_mv(meta), leaf.player, term);
+      uint32_t c0, k;
+      if (!expand_node(seat, cur, leaf, keep, c0, k)) return false;
+      if (lane < k) nif[c0 + lane] = 0;
+    }
+    sync_lanes();
+    return true;
   }
 
   // ---- MCTS::find_leaf ---------------------------------------------------------------------

@@ -414,7 +414,9 @@ struct BigSlot {
   }
 
   // ---- Node::best_child over k children starting at c0 -------------------------------------------------------
-  __device__ __forceinline__ uint32_t select_child(size_t tb, uint32_t c0, uint32_t k, float v_parent, uint32_t n_parent, float fpu_reduction) {
+  // (`nif` = Node::n_in_flight per arena node, only given by the WU-UCT batched API; `n_parent` then includes the parent's)
+  __device__ __forceinline__ uint32_t select_child(size_t tb, uint32_t c0, uint32_t k, float v_parent, uint32_t n_parent, float fpu_reduction,
+                                                   const uint32_t* nif = nullptr) {
     for (uint32_t i = lane; i < k; i += G) {
       const size_t ci = tb + c0 + i;
       const uint32_t n = ar.N[ci];
@@ -432,7 +434,8 @@ struct BigSlot {
     uint32_t best_i = 0xFFFFFFFFu;
     for (uint32_t i = lane; i < k; i += G) {
       const uint32_t n = sm.n[i];
-      float u = (n == 0 ? fpu_value : sm.f1[i]) + ep.cpuct * sm.f2[i] * sqrt_n / static_cast<float>(n + 1);
+      const uint32_t fl = nif ? nif[c0 + i] : 0u;
+      float u = (n == 0 ? fpu_value : sm.f1[i]) + ep.cpuct * sm.f2[i] * sqrt_n / static_cast<float>(n + fl + 1);
       if (u != u) u = (i == 0) ? __builtin_inff() : -__builtin_inff();
       if (u > best_u || best_i == 0xFFFFFFFFu) { best_u = u; best_i = i; }
     }
@@ -490,6 +493,47 @@ struct BigSlot {
       uint32_t c0, k;
       if (!expand_node(seat, cur, leaf, keep, c0, k)) return false;
     }
+    return true;
+  }
+
+  // ---- MCTS::find_leaf_batched (WU-UCT), mcts.cc:752-784; see SlotCtx::find_leaf_wu ---------------------------------
+  __device__ __forceinline__ bool find_leaf_wu(uint32_t seat, typename GM::State& leaf, uint32_t& term, uint32_t* nif) {
+    sync();
+    const size_t tb = tree_base(seat);
+    const uint32_t root = AZB_SEL(t_root, seat);
+    cur = root; plen = 0;
+    leaf = gs;
+    uint32_t path_len = 0;
+    bool base_valid = true;
+    uint64_t meta = ar.META[tb + cur];
+    uint32_t n = ar.N[tb + cur], nf = nif[cur];
+    uint32_t* path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
+    while ((n > 0 || nf > 0) && meta_nch(meta) != 0 && meta_term(meta) == 0) {
+      if (plen >= ep.max_depth) { raise(8u); return false; }
+      if (lane == 0) path[plen] = cur;
+      ++plen;
+      const uint32_t k = meta_nch(meta), c0 = meta_ch0(meta);
+      const float fpu = (cur == root && seat_fpu_zero(seat)) ? 0.0f : ep.fpu_reduction;
+      const uint32_t best = select_child(tb, c0, k, ar.V[tb + cur], n + nf, fpu, nif);
+      if (lane == 0) nif[cur] = nf + 1;
+      cur = c0 + best;
+      n = ar.N[tb + cur];
+      nf = nif[cur];
+      meta = ar.META[tb + cur];
+      if (!step_state(leaf, meta_mv(meta), sm.plist, path_len, base_valid, glen)) { raise(64u); return false; }
+    }
+    if (lane == 0) nif[cur] = nf + 1;
+#pragma unroll
+    for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == seat) t_tld[p] += plen;
+    term = meta_term(meta);
+    if (n == 0 && meta_nch(meta) == 0) {
+      term = GM::terminal(leaf);
+      const uint64_t keep = meta_pack(0, 0, meta_mv(meta), leaf.player, term);
+      uint32_t c0, k;
+      if (!expand_node(seat, cur, leaf, keep, c0, k)) return false;
+      for (uint32_t i = lane; i < k; i += G) nif[c0 + i] = 0;
+    }
+    sync();
     return true;
   }
 
@@ -1039,7 +1083,7 @@ __global__ __launch_bounds__(64) void k_round_big(EngineParams ep, EngineArrays 
 // simulation (MCTS::current_ / path_).  One workgroup per flagged tree; HBM-bound: 28 B read + 28 B
 // written per live node.
 template <class GM>
-__global__ __launch_bounds__(256) void k_compact(EngineParams ep, EngineArrays ar) {
+__global__ __launch_bounds__(256) void k_compact(EngineParams ep, EngineArrays ar, uint32_t* nif = nullptr) {
   constexpr int P = GM::P;
   const uint32_t t = blockIdx.x, tid = threadIdx.x;
   if (ar.ctl->stop || !ar.compact_flag[t]) return;
@@ -1055,6 +1099,7 @@ __global__ __launch_bounds__(256) void k_compact(EngineParams ep, EngineArrays a
     N[dst0] = N[old_root]; Q[dst0] = Q[old_root]; Pr[dst0] = Pr[old_root]; D[dst0] = D[old_root]; V[dst0] = V[old_root];
     META[dst0] = META[old_root];
     META[old_root] = dst0;   // forwarding index
+    if (nif) nif[tb + dst0] = nif[tb + old_root];
   }
   __syncthreads();
   uint32_t lo = dst0, hi = dst0 + 1, bump = dst0 + 1;
@@ -1085,6 +1130,7 @@ __global__ __launch_bounds__(256) void k_compact(EngineParams ep, EngineArrays a
         N[dst] = N[src]; Q[dst] = Q[src]; Pr[dst] = Pr[src]; D[dst] = D[src]; V[dst] = V[src];
         META[dst] = META[src];
         META[src] = dst;
+        if (nif) nif[tb + dst] = nif[tb + src];
       }
       bump += total;
       __syncthreads();

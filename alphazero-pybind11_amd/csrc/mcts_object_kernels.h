@@ -6,6 +6,15 @@
 
 namespace azmi {
 
+// WU-UCT batched API state (mcts.cc:752-851): Node::n_in_flight per arena node + the in_flight_ list.  Every kernel of the
+// object that can create nodes clears the marks of the nodes it created, so the array always describes live nodes.
+struct WuArrays {
+  uint32_t* nif;        // [trees * cap] Node::n_in_flight
+  uint32_t* ifl_path;   // [ifl_cap][max_depth] InFlightLeaf::path
+  uint32_t* ifl_plen;   // [ifl_cap]
+  uint32_t* ifl_cur;    // [ifl_cap] InFlightLeaf::leaf
+};
+
 // the root GameState of a call = start position (optional serialized state) + move list
 template <class GM>
 __device__ __forceinline__ bool mcts_replay_state(const uint8_t* init, const int32_t* moves, uint32_t len, typename GM::State& s) {
@@ -20,7 +29,7 @@ __device__ __forceinline__ bool mcts_replay_state(const uint8_t* init, const int
 
 // MCTS::find_leaf(gs): out_moves[0 .. *out_len) = the moves from gs to the leaf (the leaf GameState is gs + those)
 template <class GM>
-__global__ void k_mcts_find_leaf(EngineParams ep, EngineArrays ar, const uint8_t* init, const int32_t* moves, uint32_t len,
+__global__ void k_mcts_find_leaf(EngineParams ep, EngineArrays ar, uint32_t* nif, const uint8_t* init, const int32_t* moves, uint32_t len,
                                  int32_t* out_moves, uint32_t* out_len, int32_t* status) {
   constexpr int G = GM::GROUP;
   const uint32_t lane = threadIdx.x;
@@ -33,7 +42,9 @@ __global__ void k_mcts_find_leaf(EngineParams ep, EngineArrays ar, const uint8_t
   c.gs = st;
   typename GM::State leaf;
   uint32_t term = 0;
+  const uint32_t bump0 = c.t_bump[0];
   const bool ok = c.find_leaf(0, leaf, term);
+  for (uint32_t i = bump0 + lane; i < c.t_bump[0]; i += G) nif[c.tree_base(0) + i] = 0;
   if (lane == 0) {
     const size_t tb = c.tree_base(0);
     const uint32_t* path = ar.path;
@@ -66,7 +77,7 @@ __global__ void k_mcts_process_result(EngineParams ep, EngineArrays ar, uint32_t
 }
 
 template <class GM>
-__global__ void k_mcts_update_root(EngineParams ep, EngineArrays ar, const uint8_t* init, const int32_t* moves, uint32_t len,
+__global__ void k_mcts_update_root(EngineParams ep, EngineArrays ar, uint32_t* nif, const uint8_t* init, const int32_t* moves, uint32_t len,
                                    uint32_t move, int32_t* status) {
   constexpr int G = GM::GROUP;
   const uint32_t lane = threadIdx.x;
@@ -77,8 +88,64 @@ __global__ void k_mcts_update_root(EngineParams ep, EngineArrays ar, const uint8
   typename GM::State st;
   if (!mcts_replay_state<GM>(init, moves, len, st)) { if (lane == 0) *status = -1; return; }
   c.gs = st;
+  const uint32_t bump0 = c.t_bump[0];
   const bool ok = c.update_root(0, move);
+  for (uint32_t i = bump0 + lane; i < c.t_bump[0]; i += G) nif[c.tree_base(0) + i] = 0;
   if (lane == 0) *status = ok ? 0 : -3;   // -3: "ahh, what is this move"
+  c.store(kSlotWaitEval);
+}
+
+// ---- WU-UCT batched API (mcts.cc:752-851) kernels ----------------------------------------------------------------
+template <class GM>
+__global__ void k_mcts_find_leaf_batched(EngineParams ep, EngineArrays ar, WuArrays wu, uint32_t index, const uint8_t* init,
+                                         const int32_t* moves, uint32_t len, int32_t* out_moves, uint32_t* out_len, int32_t* status) {
+  constexpr int G = GM::GROUP;
+  const uint32_t lane = threadIdx.x;
+  if (lane >= static_cast<uint32_t>(G)) return;
+  SlotCtx<GM> c(ep, ar, 0, lane);
+  c.load();
+  if (ar.sstate[0] == kSlotFresh) c.start_game();
+  typename GM::State st;
+  if (!mcts_replay_state<GM>(init, moves, len, st)) { if (lane == 0) *status = -1; return; }
+  c.gs = st;
+  typename GM::State leaf;
+  uint32_t term = 0;
+  const bool ok = c.find_leaf_wu(0, leaf, term, wu.nif + c.tree_base(0));
+  if (lane == 0) {
+    const size_t tb = c.tree_base(0);
+    uint32_t* rec = wu.ifl_path + static_cast<size_t>(index) * ep.max_depth;
+    for (uint32_t i = 0; i < c.plen; ++i) {
+      rec[i] = ar.path[i];
+      const uint32_t node = (i + 1 < c.plen) ? ar.path[i + 1] : c.cur;
+      out_moves[i] = static_cast<int32_t>(meta_mv(ar.META[tb + node]));
+    }
+    wu.ifl_plen[index] = c.plen; wu.ifl_cur[index] = c.cur;
+    *out_len = c.plen;
+    *status = ok ? 0 : -2;
+  }
+  c.store(kSlotWaitEval);
+}
+
+template <class GM>
+__global__ void k_mcts_process_result_batched(EngineParams ep, EngineArrays ar, WuArrays wu, uint32_t index, uint32_t root_noise, float* value_out) {
+  constexpr int G = GM::GROUP;
+  constexpr int P = GM::P;
+  const uint32_t lane = threadIdx.x;
+  if (lane >= static_cast<uint32_t>(G)) return;
+  SlotCtx<GM> c(ep, ar, 0, lane);
+  c.load();
+  uint32_t* nif = wu.nif + c.tree_base(0);
+  c.cur = wu.ifl_cur[index]; c.plen = wu.ifl_plen[index];
+  if (lane == 0) {
+    const uint32_t* rec = wu.ifl_path + static_cast<size_t>(index) * ep.max_depth;
+    --nif[c.cur];
+    for (uint32_t i = 0; i < c.plen; ++i) { ar.path[i] = rec[i]; --nif[rec[i]]; }
+  }
+  c.sync_lanes();
+  const uint32_t term = meta_term(ar.META[c.tree_base(0) + c.cur]);
+  c.process_result(0, true, root_noise != 0);
+  if (lane == 0)
+    for (int i = 0; i <= P; ++i) value_out[i] = term ? ((static_cast<int>(term) - 1 == i) ? 1.0f : 0.0f) : ar.v[i];
   c.store(kSlotWaitEval);
 }
 
@@ -236,7 +303,7 @@ __device__ __forceinline__ bool mcts_big_replay(BigSlot<GM>& c, const uint8_t* i
 }
 
 template <class GM>
-__global__ __launch_bounds__(64) void k_mcts_big_find_leaf(EngineParams ep, EngineArrays ar, const uint8_t* init, uint32_t init_stride,
+__global__ __launch_bounds__(64) void k_mcts_big_find_leaf(EngineParams ep, EngineArrays ar, uint32_t* nif, const uint8_t* init, uint32_t init_stride,
                                                            const int32_t* moves, uint32_t len, int32_t* out_moves, uint32_t* out_len, int32_t* status) {
   __shared__ BigScratch<GM> sm;
   const uint32_t lane = threadIdx.x;
@@ -246,7 +313,9 @@ __global__ __launch_bounds__(64) void k_mcts_big_find_leaf(EngineParams ep, Engi
   if (!mcts_big_replay<GM>(c, init, init_stride, moves, len)) { if (lane == 0) *status = -1; return; }
   typename GM::State leaf;
   uint32_t term = 0;
+  const uint32_t bump0 = c.t_bump[0];
   const bool ok = c.find_leaf(0, leaf, term);
+  for (uint32_t i = bump0 + lane; i < c.t_bump[0]; i += 64) nif[c.tree_base(0) + i] = 0;
   if (lane == 0) {
     const size_t tb = c.tree_base(0);
     for (uint32_t i = 0; i < c.plen; ++i) {
@@ -274,7 +343,58 @@ __global__ __launch_bounds__(64) void k_mcts_big_process_result(EngineParams ep,
 }
 
 template <class GM>
-__global__ __launch_bounds__(64) void k_mcts_big_update_root(EngineParams ep, EngineArrays ar, const uint8_t* init, uint32_t init_stride,
+__global__ __launch_bounds__(64) void k_mcts_big_find_leaf_batched(EngineParams ep, EngineArrays ar, WuArrays wu, uint32_t index, const uint8_t* init,
+                                                                   uint32_t init_stride, const int32_t* moves, uint32_t len, int32_t* out_moves,
+                                                                   uint32_t* out_len, int32_t* status) {
+  __shared__ BigScratch<GM> sm;
+  const uint32_t lane = threadIdx.x;
+  BigSlot<GM> c(ep, ar, sm, 0, lane);
+  c.load();
+  if (ar.sstate[0] == kSlotFresh) c.start_game();
+  if (!mcts_big_replay<GM>(c, init, init_stride, moves, len)) { if (lane == 0) *status = -1; return; }
+  typename GM::State leaf;
+  uint32_t term = 0;
+  const bool ok = c.find_leaf_wu(0, leaf, term, wu.nif + c.tree_base(0));
+  if (lane == 0) {
+    const size_t tb = c.tree_base(0);
+    uint32_t* rec = wu.ifl_path + static_cast<size_t>(index) * ep.max_depth;
+    for (uint32_t i = 0; i < c.plen; ++i) {
+      rec[i] = ar.path[i];
+      const uint32_t node = (i + 1 < c.plen) ? ar.path[i + 1] : c.cur;
+      out_moves[i] = static_cast<int32_t>(meta_mv(ar.META[tb + node]));
+    }
+    wu.ifl_plen[index] = c.plen; wu.ifl_cur[index] = c.cur;
+    *out_len = c.plen;
+    *status = ok ? 0 : -2;
+  }
+  c.store(kSlotWaitEval);
+}
+
+template <class GM>
+__global__ __launch_bounds__(64) void k_mcts_big_process_result_batched(EngineParams ep, EngineArrays ar, WuArrays wu, uint32_t index,
+                                                                        uint32_t root_noise, float* value_out) {
+  __shared__ BigScratch<GM> sm;
+  constexpr int P = GM::P;
+  const uint32_t lane = threadIdx.x;
+  BigSlot<GM> c(ep, ar, sm, 0, lane);
+  c.load();
+  uint32_t* nif = wu.nif + c.tree_base(0);
+  c.cur = wu.ifl_cur[index]; c.plen = wu.ifl_plen[index];
+  if (lane == 0) {
+    const uint32_t* rec = wu.ifl_path + static_cast<size_t>(index) * ep.max_depth;
+    --nif[c.cur];
+    for (uint32_t i = 0; i < c.plen; ++i) { ar.path[i] = rec[i]; --nif[rec[i]]; }
+  }
+  c.sync();
+  const uint32_t term = meta_term(ar.META[c.tree_base(0) + c.cur]);
+  c.process_result(0, true, root_noise != 0);
+  if (lane == 0)
+    for (int i = 0; i <= P; ++i) value_out[i] = term ? ((static_cast<int>(term) - 1 == i) ? 1.0f : 0.0f) : ar.v[i];
+  c.store(kSlotWaitEval);
+}
+
+template <class GM>
+__global__ __launch_bounds__(64) void k_mcts_big_update_root(EngineParams ep, EngineArrays ar, uint32_t* nif, const uint8_t* init, uint32_t init_stride,
                                                              const int32_t* moves, uint32_t len, uint32_t move, int32_t* status) {
   __shared__ BigScratch<GM> sm;
   const uint32_t lane = threadIdx.x;
@@ -282,7 +402,9 @@ __global__ __launch_bounds__(64) void k_mcts_big_update_root(EngineParams ep, En
   c.load();
   if (ar.sstate[0] == kSlotFresh) c.start_game();
   if (!mcts_big_replay<GM>(c, init, init_stride, moves, len)) { if (lane == 0) *status = -1; return; }
+  const uint32_t bump0 = c.t_bump[0];
   const bool ok = c.update_root(0, move);
+  for (uint32_t i = bump0 + lane; i < c.t_bump[0]; i += 64) nif[c.tree_base(0) + i] = 0;
   // a long-lived object needs the arena compaction the engine does between rounds
   if (ok && ep.half_nodes && lane == 0) {
     const uint32_t b = c.t_bump[0];

@@ -31,7 +31,8 @@ typedef enum azmi_status {
   AZMI_ERR_NO_DEVICE = -2, /* no HIP device / HIP runtime error */
   AZMI_ERR_OOM = -3,
   AZMI_ERR_OVERFLOW = -4,  /* a device-side arena / history ring ran out of room */
-  AZMI_ERR_STATE = -5
+  AZMI_ERR_STATE = -5,
+  AZMI_ERR_RANGE = -6      /* index out of range (reference: std::out_of_range -> IndexError) */
 } azmi_status;
 
 /* game ids (reference GAME_REGISTRY, config.py:17-35) */
@@ -240,6 +241,17 @@ int azmi_mcts_find_leaf(azmi_mcts* m, const uint8_t* init, uint32_t init_bytes, 
 int azmi_mcts_process_result(azmi_mcts* m, const float* value, const float* pi, int root_noise_enabled, float* value_out);
 /* update_root(gs, move); returns AZMI_ERR_INVALID with "ahh, what is this move" for a move the root does not have */
 int azmi_mcts_update_root(azmi_mcts* m, const uint8_t* init, uint32_t init_bytes, const int32_t* moves, uint32_t len, uint32_t move);
+/* WU-UCT batched search (mcts.h:124-129, mcts.cc:752-851; Python: py_wrapper.cc:212-215).  find_leaf_batched descends with the
+ * in-flight penalty (Node::n_in_flight in PUCT's denominator and parent count), appends an entry to the in-flight list and returns
+ * the leaf like find_leaf; the entry's index is in_flight_count() - 1.  process_result_batched(leaf_index, ...) backs one entry up
+ * (AZMI_ERR_RANGE for an index that is not in the list: the reference's in_flight_.at() -> IndexError); reset_batch() clears the
+ * list (at most 1024 entries between resets).  The batched descent is plain PUCT also when Gumbel is enabled, like the reference. */
+int azmi_mcts_find_leaf_batched(azmi_mcts* m, const uint8_t* init, uint32_t init_bytes, const int32_t* moves, uint32_t len,
+                                int32_t* leaf_moves, uint32_t cap, uint32_t* leaf_len);
+int azmi_mcts_process_result_batched(azmi_mcts* m, uint32_t leaf_index, const float* value, const float* pi, int root_noise_enabled,
+                                     float* value_out);
+int azmi_mcts_in_flight_count(const azmi_mcts* m, uint32_t* out);
+int azmi_mcts_reset_batch(azmi_mcts* m);
 /* read-outs and small mutations, kind: 0 counts (u32 [M]) 1 probs(temp) 2 probs_pruned(temp) (f32 [M]) 3 root_value (f32 [3])
  * 4 root_q_values (f32 [M]) 5 scalars: u = {depth, root_n, root children}, f = {avg_leaf_depth, normalized_root_entropy}
  * 6 gumbel_improved_policy (f32 [M]) 7 gumbel_final_action (u[0]) 8 add_root_noise 9 apply_root_policy_temp

@@ -210,6 +210,51 @@ class Mcts {
     ++r.n;
   }
 
+  // ---- WU-UCT batched search, mcts.cc:752-851 -------------------------------
+  // find_leaf_batched: descend through nodes that are visited OR have an evaluation in flight, add the
+  // in-flight penalty after each selection, expand only a node nobody expanded yet.
+  std::unique_ptr<Game> find_leaf_batched(const Game& gs) {
+    InFlight ifl;
+    uint32_t cur = root_;
+    auto leaf = gs.copy();
+    while ((pool_[cur].n > 0 || pool_[cur].n_in_flight > 0) && pool_[cur].nchild != 0 && !pool_[cur].terminal) {
+      ifl.path.push_back(cur);
+      const float fpu = (cur == root_ && cfg_.root_fpu_zero) ? 0.0f : cfg_.fpu_reduction;
+      const uint32_t selected = best_child(cur, cfg_.cpuct, fpu);
+      ++pool_[cur].n_in_flight;
+      cur = selected;
+      leaf->play_move(pool_[cur].move);
+    }
+    ++pool_[cur].n_in_flight;
+    total_leaf_depth_ += ifl.path.size();
+    if (pool_[cur].n == 0 && pool_[cur].nchild == 0) {
+      pool_[cur].player = static_cast<int8_t>(leaf->current_player());
+      float s[kMaxValue];
+      if (leaf->scores(s)) {
+        pool_[cur].terminal = true;
+        for (uint32_t i = 0; i <= cfg_.num_players; ++i) pool_[cur].scores[i] = s[i];
+      }
+      std::vector<uint8_t> valids(leaf->num_moves());
+      leaf->valid_moves(valids.data());
+      add_children(cur, valids.data(), leaf->num_moves());
+    }
+    ifl.leaf = cur;
+    in_flight_.push_back(std::move(ifl));
+    return leaf;
+  }
+  // process_result_batched, mcts.cc:786-845: the same backup as process_result over the stored path,
+  // releasing the in-flight marks on the way
+  void process_result_batched(uint32_t leaf_index, float* value, const float* pi, bool root_noise_enabled) {
+    const InFlight& ifl = in_flight_.at(leaf_index);
+    path_ = ifl.path;
+    current_ = ifl.leaf;
+    --pool_[current_].n_in_flight;
+    for (uint32_t node : path_) --pool_[node].n_in_flight;
+    process_result(value, pi, root_noise_enabled);
+  }
+  uint32_t in_flight_count() const { return static_cast<uint32_t>(in_flight_.size()); }
+  void reset_batch() { in_flight_.clear(); }
+
   // ---- MCTS::add_root_noise, mcts.cc:403-446 --------------------------------
   void add_root_noise() {
     Node& r = pool_[root_];
@@ -651,6 +696,8 @@ class Mcts {
   uint32_t root_ = 0;
   uint32_t current_ = 0;
   std::vector<uint32_t> path_;
+  struct InFlight { std::vector<uint32_t> path; uint32_t leaf = 0; };  // mcts.h InFlightLeaf
+  std::vector<InFlight> in_flight_;
   uint32_t depth_ = 0;
   uint64_t total_leaf_depth_ = 0;
   // per-search Gumbel state, mcts.h:179-191

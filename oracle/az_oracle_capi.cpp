@@ -164,6 +164,19 @@ void* orc_mcts_leaf(void* h) { return static_cast<MctsBox*>(h)->leaf.get(); }
 void orc_mcts_process_result(void* h, float* value, const float* pi, int noise) {
   static_cast<MctsBox*>(h)->m->process_result(value, pi, noise != 0);
 }
+// dumb_eval(gs), game_state.h:160-173
+void orc_dumb_eval(void* game, float* v, float* pi) { dumb_eval(*static_cast<Game*>(game), v, pi); }
+// WU-UCT batched API (mcts.cc:752-851)
+void orc_mcts_find_leaf_batched(void* h, void* game) {
+  auto* b = static_cast<MctsBox*>(h);
+  b->leaf = b->m->find_leaf_batched(*static_cast<Game*>(game));
+}
+int orc_mcts_process_result_batched(void* h, uint32_t leaf_index, float* value, const float* pi, int noise) {
+  try { static_cast<MctsBox*>(h)->m->process_result_batched(leaf_index, value, pi, noise != 0); return 0; }
+  catch (const std::out_of_range&) { return -1; }
+}
+uint32_t orc_mcts_in_flight_count(void* h) { return static_cast<MctsBox*>(h)->m->in_flight_count(); }
+void orc_mcts_reset_batch(void* h) { static_cast<MctsBox*>(h)->m->reset_batch(); }
 // `sims` x (find_leaf, dumb_eval, process_result) — mcts_test.cc:41-72 pattern
 void orc_mcts_search_dumb(void* h, void* game, uint32_t sims, int noise) {
   auto* b = static_cast<MctsBox*>(h);

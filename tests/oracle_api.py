@@ -182,6 +182,20 @@ class Mcts:
         lib.orc_mcts_process_result(self.h, _p(v), _p(p), C.c_int(int(noise)))
         return v
 
+    def find_leaf_batched(self, game):
+        lib.orc_mcts_find_leaf_batched(self.h, game.h)
+        return Game(handle=lib.orc_mcts_leaf(self.h), owned=False)
+
+    def process_result_batched(self, leaf_index, value, pi, noise=False):
+        v = np.ascontiguousarray(value, np.float32).copy()
+        p = np.ascontiguousarray(pi, np.float32)
+        if lib.orc_mcts_process_result_batched(self.h, C.c_uint32(leaf_index), _p(v), _p(p), C.c_int(int(noise))) != 0:
+            raise IndexError("leaf_index out of range")
+        return v
+
+    def in_flight_count(self): return lib.orc_mcts_in_flight_count(self.h)
+    def reset_batch(self): lib.orc_mcts_reset_batch(self.h)
+
     def update_root(self, game, move):
         if lib.orc_mcts_update_root(self.h, game.h, C.c_uint32(move)) != 0:
             raise RuntimeError("ahh, what is this move")
@@ -221,6 +235,13 @@ class Mcts:
         mv = np.zeros(4096, np.uint32); pol = np.zeros(4096, np.float32); n = np.zeros(4096, np.uint32); q = np.zeros(4096, np.float32)
         k = lib.orc_mcts_root_children(self.h, _p(mv), _p(pol), _p(n), _p(q))
         return mv[:k], pol[:k], n[:k], q[:k]
+
+
+def dumb_eval(game):
+    """dumb_eval(gs) -> (value [P+1], pi [M]), game_state.h:160-173"""
+    v = np.zeros(game.num_players() + 1, np.float32); pi = np.zeros(game.num_moves(), np.float32)
+    lib.orc_dumb_eval(game.h, _p(v), _p(pi))
+    return v, pi
 
 
 def node_uct(q, policy, n, sqrt_parent_n, cpuct, fpu):

@@ -90,8 +90,9 @@ def test_errors(az):
     m.update_root(gs, 3)           # the object is still usable afterwards
     with pytest.raises(RuntimeError):
         az.MCTS(2.0, 2, 8, seed=1)
-    with pytest.raises(RuntimeError, match="not implemented"):
-        m.find_leaf_batched(gs, 4)
+    with pytest.raises(IndexError):          # in_flight_.at(leaf_index), mcts.cc:789
+        v, pi = az.dumb_eval(gs)
+        m.process_result_batched(gs, 0, v, pi)
 
 
 @pytest.mark.parametrize("name,cfg", [
@@ -137,3 +138,108 @@ def test_tafl_family_call_by_call_parity(az, oracle, name, cfg):
             m.apply_root_policy_temp(); o.apply_root_policy_temp()
             if m.root_n() > 0:
                 m.add_root_noise(); o.add_root_noise()
+
+
+# ---- WU-UCT batched API (mcts.cc:752-851; reference tests mcts_test.cc:572-697) ----------------------------------
+def _batched_search(az, m, gs, total, batch):
+    sims = 0
+    while sims < total:
+        b = min(batch, total - sims)
+        for i in range(b):
+            leaf = m.find_leaf_batched(gs)
+            assert m.in_flight_count() == i + 1
+            v, pi = az.dumb_eval(leaf)
+            m.process_result_batched(gs, i, v, pi)
+        m.reset_batch()
+        assert m.in_flight_count() == 0
+        sims += b
+
+
+def test_batched_basic_and_terminal(az):
+    """mcts_test.cc BatchedBasic (:572-596) and BatchedTerminal (:599-626)."""
+    gs = az.Connect4GS()
+    for mv in (1, 6, 3, 6):
+        gs.play_move(mv)
+    m = az.MCTS(2.0, 2, 7, seed=3)
+    _batched_search(az, m, gs, 800, 8)
+    assert m.pick_move(m.probs(0.0)) == 2 and int(m.counts().sum()) == 799
+    gs = az.Connect4GS()
+    for mv in (3, 0, 3, 0, 3, 1):
+        gs.play_move(mv)
+    m = az.MCTS(2.0, 2, 7, seed=3)
+    _batched_search(az, m, gs, 100, 4)
+    assert m.pick_move(m.probs(0.0)) == 3
+
+
+def test_batched_single_equals_unbatched(az):
+    """mcts_test.cc BatchedSingleEquivalent (:629-667); with one seed the two are the same search, bit for bit."""
+    gs = az.Connect4GS()
+    for mv in (1, 6, 3, 6):
+        gs.play_move(mv)
+    a = az.MCTS(2.0, 2, 7, seed=12345); b = az.MCTS(2.0, 2, 7, seed=12345)
+    _search(az, a, gs, 800)
+    _batched_search(az, b, gs, 800, 1)
+    assert a.counts().tolist() == b.counts().tolist() == [62, 21, 631, 21, 22, 21, 21]
+    assert np.array_equal(a.root_q_values(), b.root_q_values())
+
+
+def test_wu_uct_diversity(az):
+    """mcts_test.cc WUUCTDiversity (:670-702): four leaves found in one batch explore different children."""
+    gs = az.Connect4GS()
+    m = az.MCTS(2.0, 2, 7, seed=5)
+    _search(az, m, gs, 1)
+    leaves = [m.find_leaf_batched(gs) for _ in range(4)]
+    for i in range(4):
+        v, pi = az.dumb_eval(gs)
+        m.process_result_batched(gs, i, v, pi)
+    m.reset_batch()
+    assert len({str(l) for l in leaves}) >= 3
+
+
+@pytest.mark.parametrize("name,batch,cfg", [
+    ("Connect4GS", 8, dict(cpuct=1.25, fpu_reduction=0.25)),
+    ("Connect4GS", 5, dict(cpuct=1.25, fpu_reduction=0.25, epsilon=0.25, root_policy_temp=1.25, root_fpu_zero=True, shaped_dirichlet=True)),
+    ("TawlbwrddGS", 4, dict(cpuct=1.25, fpu_reduction=0.25)),
+    ("BrandubhGS", 6, dict(cpuct=2.0, root_fpu_zero=True)),
+])
+def test_batched_parity_with_oracle(az, oracle, name, batch, cfg):
+    """find all leaves of a batch first, then back them up in a scrambled order: every leaf, every returned value vector and
+    every root read-out equals the oracle's, over several moves with update_root in between."""
+    Game = getattr(az, name)
+    gid = {"Connect4GS": oracle.GAME_CONNECT4, "TawlbwrddGS": oracle.GAME_TAWLBWRDD, "BrandubhGS": oracle.GAME_BRANDUBH}[name]
+    M = Game.NUM_MOVES()
+    noise = cfg.get("epsilon", 0) > 0
+    kw = dict(cfg); cpuct = kw.pop("cpuct")
+    extra = {} if name == "Connect4GS" else dict(game=Game, max_simulations=400)
+    m = az.MCTS(cpuct, 2, M, seed=17, **extra, **kw)
+    o = oracle.Mcts(cpuct, 2, M, seed=17, **kw)
+    gs = Game(); og = oracle.Game(gid)
+    rng = np.random.default_rng(8)
+    rounds = 10 if name == "Connect4GS" else 5
+    for ply in range(4):
+        for _ in range(rounds):
+            evals = []
+            for i in range(batch):
+                leaf = m.find_leaf_batched(gs); oleaf = o.find_leaf_batched(og)
+                assert np.array_equal(leaf.canonicalized(), oleaf.canonical())
+                v, pi = az.dumb_eval(leaf)
+                w = (1 + 0.3 * np.sin(np.arange(M) * 0.37 + i)).astype(np.float32)
+                pi = (pi * w).astype(np.float32); pi /= max(pi.sum(), 1e-30)
+                evals.append((v, pi))
+            assert m.in_flight_count() == o.in_flight_count() == batch
+            for i in rng.permutation(batch):
+                v, pi = evals[i]
+                assert np.array_equal(m.process_result_batched(gs, int(i), v.copy(), pi, noise),
+                                      o.process_result_batched(int(i), v.copy(), pi, noise))
+            m.reset_batch(); o.reset_batch()
+        assert np.array_equal(m.counts(), o.counts())
+        assert np.array_equal(m.root_q_values(), o.root_q())
+        assert np.array_equal(m.probs(1.0), o.probs(1.0))
+        assert np.array_equal(m.root_value(), o.root_value())
+        assert m.depth() == o.depth() and m.root_n() == o.root_n()
+        assert m.avg_leaf_depth() == pytest.approx(o.avg_leaf_depth(), rel=1e-6)
+        move = m.pick_move(m.probs(1.0)); assert move == o.pick_move(o.probs(1.0))
+        m.update_root(gs, move); o.update_root(og, move)
+        gs.play_move(move); og.play(move)
+        if gs.scores() is not None:
+            break

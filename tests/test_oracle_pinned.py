@@ -400,3 +400,49 @@ def test_brandubh_known_answers(oracle):
     g = oracle.Game.tafl_from_board(oracle.GAME_BRANDUBH, b, 0, turn=4, max_turns=150)
     g.play(tc.mv(2, 5, False, 3, n=7))
     assert np.array_equal(g.scores(), [1, 0, 0])
+
+
+# ---- WU-UCT batched search: the reference's own four tests (mcts_test.cc:572-702) on the restatement --------------
+def _orc_batched(orc, m, g, total, batch):
+    sims = 0
+    while sims < total:
+        b = min(batch, total - sims)
+        for i in range(b):
+            leaf = m.find_leaf_batched(g)
+            v, pi = orc.dumb_eval(leaf)
+            m.process_result_batched(i, v, pi)
+        m.reset_batch()
+        sims += b
+
+
+def test_batched_search_reference_cases():
+    import oracle_api as orc
+    g = orc.Game(orc.GAME_CONNECT4)
+    for mv in (1, 6, 3, 6):
+        g.play(mv)
+    m = orc.Mcts(2.0, 2, 7, seed=3)
+    _orc_batched(orc, m, g, 800, 8)
+    assert m.pick_move(m.probs(0.0)) == 2                     # BatchedBasic
+    g2 = orc.Game(orc.GAME_CONNECT4)
+    for mv in (3, 0, 3, 0, 3, 1):
+        g2.play(mv)
+    m = orc.Mcts(2.0, 2, 7, seed=3)
+    _orc_batched(orc, m, g2, 100, 4)
+    assert m.pick_move(m.probs(0.0)) == 3                     # BatchedTerminal
+    a = orc.Mcts(2.0, 2, 7, seed=12345); b = orc.Mcts(2.0, 2, 7, seed=12345)
+    a.search_dumb(g, 800)
+    _orc_batched(orc, b, g, 800, 1)
+    assert a.counts().tolist() == b.counts().tolist() == [62, 21, 631, 21, 22, 21, 21]   # BatchedSingleEquivalent (+ the SURVEY §8c answer)
+    g0 = orc.Game(orc.GAME_CONNECT4)
+    m = orc.Mcts(2.0, 2, 7, seed=5)
+    m.search_dumb(g0, 1)
+    keys = []
+    for _ in range(4):
+        keys.append(m.find_leaf_batched(g0).canonical().tobytes())
+    v, pi = orc.dumb_eval(g0)
+    for i in range(4):
+        m.process_result_batched(i, v, pi)
+    with pytest.raises(IndexError):
+        m.process_result_batched(4, v, pi)
+    m.reset_batch()
+    assert m.in_flight_count() == 0 and len(set(keys)) >= 3   # WUUCTDiversity
