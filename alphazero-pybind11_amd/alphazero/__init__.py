@@ -630,6 +630,52 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+class GameData:
+    """GameData (py_wrapper.cc:265-288) of one slot: gs(), valid_moves(), canonical() read the device state; v() and pi()
+    are the host rows push_inference(i) hands to the engine."""
+
+    def __init__(self, pm, i):
+        self._pm, self._i = pm, i
+        self._v = np.zeros(pm._P + 1, np.float32)
+        self._pi = np.zeros(pm._M, np.float32)
+
+    def v(self): return self._v
+    def pi(self): return self._pi
+
+    def canonical(self):
+        out = np.zeros(tuple(self._pm._chw), np.float32)
+        check(lib.azmi_pm_slot_canonical(self._pm._h, self._i, out.ctypes.data))
+        return out
+
+    def gs(self):
+        pm = self._pm
+        w = np.zeros(8, np.uint64); n = C.c_uint32()
+        check(lib.azmi_pm_slot_state(pm._h, self._i, w.ctypes.data, 8, C.byref(n)))
+        game = pm._game
+        if game is Connect4GS:
+            board = np.zeros((2, 6, 7), np.int8)
+            for p in range(2):
+                bits = int(w[p])
+                for c in range(42):
+                    board[p].flat[c] = (bits >> c) & 1
+            return Connect4GS(board, int(w[2]) >> 32, int(w[2]) & 0xFFFFFFFF)
+        if issubclass(game, _TaflBoardGS):
+            sq = game.BOARD * game.BOARD
+            d = int(w[0]) | (int(w[1]) << 64); a = int(w[2]) | (int(w[3]) << 64)
+            king = int(w[4]) & 0xFF
+            board = np.zeros((3, game.BOARD, game.BOARD), np.int8)
+            for c in range(sq):
+                board[1].flat[c] = (d >> c) & 1
+                board[2].flat[c] = (a >> c) & 1
+            if king < sq:
+                board[0].flat[king] = 1
+            return game.from_board(board, (int(w[4]) >> 24) & 0xFF, (int(w[4]) >> 8) & 0xFFFF)
+        raise RuntimeError("game_data(i).gs() is not available for this game (its state carries a repetition history)")
+
+    def valid_moves(self):
+        return self.gs().valid_moves()
+
+
 class PlayManager:
     """py_wrapper.cc:351-504 over libazmi.
 
@@ -638,7 +684,7 @@ class PlayManager:
     Device fast path (no reference counterpart): round(), io_tensors(), poll().
     """
 
-    def __init__(self, gs, params, seed=None, device=0, max_inline=0, log_moves=False, history_capacity=0):
+    def __init__(self, gs, params, caches=None, seed=None, device=0, max_inline=0, log_moves=False, history_capacity=0):
         if gs is None:
             raise TypeError("PlayManager(): gs must not be None")  # py::arg().none(false)
         game_id = gs.GAME_ID
@@ -657,8 +703,20 @@ class PlayManager:
         opts.log_moves = int(bool(log_moves))
         opts.history_capacity = int(history_capacity)
         h = C.c_void_p()
-        check(lib.azmi_pm_create(game_id, C.byref(cparams), C.byref(opts), C.byref(h)))
+        self._caches = None
+        if caches is None:
+            check(lib.azmi_pm_create(game_id, C.byref(cparams), C.byref(opts), C.byref(h)))
+        else:   # PlayManager(gs, params, caches): py_wrapper.cc:355-360, one (possibly None) cache per model group
+            self._caches = list(caches)     # the engine borrows them: keep them alive as long as the engine
+            arr = (C.c_void_p * max(1, len(self._caches)))()
+            for i, c in enumerate(self._caches):
+                if c is not None and not isinstance(c, ShardedS3FIFOCache):
+                    raise TypeError("caches must hold ShardedS3FIFOCache objects or None")
+                arr[i] = None if c is None else c._h
+            check(lib.azmi_pm_create_with_caches(game_id, C.byref(cparams), C.byref(opts), arr, len(self._caches), C.byref(h)))
         self._h = h
+        self._eager = False
+        self._slot_rows = {}
         self._P, self._M, self._chw = self._game._info()
         self._S = int(params.concurrent_games)
         self._last_stream = _ENGINE_STREAM
@@ -682,7 +740,30 @@ class PlayManager:
         check(lib.azmi_pm_poll(self._h, self._stream_arg(None), C.byref(done), C.byref(live)))
         return done.value
 
+    def stop(self):                                        # play_manager.h:177
+        check(lib.azmi_pm_stop(self._h))
+
+    def stopped(self):                                     # play_manager.h:178
+        f = C.c_int()
+        check(lib.azmi_pm_stopped(self._h, C.byref(f)))
+        return bool(f.value)
+
+    def set_eager(self, e):
+        """play_manager.h:277: the reference's batcher hands over partial batches while this is set; the engine's
+        build_batch never waits for a batch to fill, so the flag is only remembered."""
+        self._eager = bool(e)
+
+    def _queue_counts(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        check(lib.azmi_pm_queue_counts(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def awaiting_inference_count(self): return self._queue_counts()[0]    # play_manager.h:317-323
+    def awaiting_mcts_count(self): return self._queue_counts()[1]         # play_manager.h:316
+
     def remaining_games(self):
+        if self.stopped():                                 # play_manager.h:179-182
+            return 0
         done, live = C.c_uint32(), C.c_uint32()
         check(lib.azmi_pm_poll(self._h, self._stream_arg(None), C.byref(done), C.byref(live)))
         if live.value == 0:
@@ -720,8 +801,51 @@ class PlayManager:
     def hist_count(self):
         return self.counters()["hist_rows"]
 
-    def cache_hits(self): return self.counters()["cache_hits"]
-    def cache_misses(self): return self.counters()["cache_misses"]
+    def _cache_stats(self):
+        out = np.zeros(6, np.uint64)
+        check(lib.azmi_pm_cache_stats(self._h, out.ctypes.data))
+        return [int(x) for x in out]
+
+    # play_manager.h:325-366: sums over the model groups' caches
+    def cache_hits(self): return self._cache_stats()[0]
+    def cache_misses(self): return self._cache_stats()[1]
+    def cache_evictions(self): return self._cache_stats()[2]
+    def cache_reinserts(self): return self._cache_stats()[3]
+    def cache_size(self): return self._cache_stats()[4]
+    def cache_max_size(self): return self._cache_stats()[5]
+
+    # per-variant tables (play_manager.h:218-275) exist only for multi-variant games; none of the device games has variants
+    def num_tracked_variants(self): return 0
+    def _no_variant(self, *a):
+        raise IndexError("this game tracks no variants (num_tracked_variants() == 0)")
+    variant_scores = variant_games_completed = variant_perm_scores = variant_perm_games_completed = _no_variant
+    variant_avg_game_length = variant_avg_leaf_depth = variant_avg_search_entropy = _no_variant
+    variant_fast_avg_leaf_depth = variant_fast_avg_search_entropy = variant_avg_moves_per_turn = variant_avg_valid_moves = _no_variant
+
+    # ---- the raw queue interface (play_manager.h:186-192, 285-286): pop leaf indices, read the slot through
+    # game_data(i), write its v() / pi() rows, push_inference(i)
+    def pop_games_upto(self, group, n):
+        idx = np.zeros(max(int(n), 1), np.uint32)
+        cnt = C.c_uint32()
+        check(lib.azmi_pm_build_batch_group(self._h, int(group), None, int(n), idx.ctypes.data, C.byref(cnt)))
+        return [int(i) for i in idx[: cnt.value]]
+
+    def pop_game(self, group):
+        got = self.pop_games_upto(group, 1)
+        return got[0] if got else None
+
+    def game_data(self, i):
+        i = int(i)
+        if not 0 <= i < self._S:
+            raise IndexError("game index out of range")
+        gd = self._slot_rows.get(i)
+        if gd is None:
+            gd = self._slot_rows[i] = GameData(self, i)
+        return gd
+
+    def push_inference(self, i):
+        gd = self.game_data(i)
+        self.update_inferences(0, [int(i)], gd._v[None, :], gd._pi[None, :])
     def _groups(self):
         g, p = C.c_uint32(), C.c_uint32()
         check(lib.azmi_pm_groups(self._h, C.byref(g), C.byref(p)))
@@ -866,6 +990,13 @@ class ShardedS3FIFOCache:
             lib.azmi_cache_destroy(self._h)
             self._h = None
 
+    @classmethod
+    def for_engine(cls, max_size, num_policy, num_value, device=0):
+        """A cache in the layout the engine probes (64-entry shards, ghost = 9/10 like play_manager.cc:195-203), to be
+        passed as PlayManager(gs, params, caches=[...]) and kept from one PlayManager to the next."""
+        shards = max(1, int(max_size) // 64)
+        return cls(shards * 64, shards, shards * 64 * 9 // 10, num_policy, num_value, device)
+
     def insert_many(self, hashes, policies, values):
         h = np.ascontiguousarray(hashes, np.uint64)
         p = np.ascontiguousarray(policies, np.float32).reshape(len(h), self._np)
@@ -900,6 +1031,13 @@ class ShardedS3FIFOCache:
     def reinserts(self): return self._stats()[3]
     def size(self): return self._stats()[4]
     def max_size(self): return self._stats()[5]
+
+
+def hash_game_state(gs):
+    """hash_game_state(gs), game_state.h:141-156 / py_wrapper.cc:260-263: the 64-bit position key the caches use.  absl's
+    hash is salted per process, so only equality semantics are contract; this is the engine's deterministic key over
+    the same fields."""
+    return int(gs._state()["key"][0])
 
 
 def S3FIFOCache(max_size, ghost_size, num_policy, num_value, device=0):

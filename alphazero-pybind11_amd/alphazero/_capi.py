@@ -5,6 +5,7 @@ there is no Python/CPU fallback for any compute entry point.
 """
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libazmi.so")
@@ -96,6 +97,13 @@ SYMBOLS = {
     "azmi_device_count": (C.c_int, []),
     "azmi_game_info": (C.c_int, [C.c_int, _PP(C.c_uint32), _PP(C.c_uint32), _PP(C.c_uint32)]),
     "azmi_pm_create": (C.c_int, [C.c_int, _PP(PlayParamsC), _PP(EngineOptsC), _PP(_VP)]),
+    "azmi_pm_create_with_caches": (C.c_int, [C.c_int, _PP(PlayParamsC), _PP(EngineOptsC), _PP(_VP), C.c_uint32, _PP(_VP)]),
+    "azmi_pm_stop": (C.c_int, [_VP]),
+    "azmi_pm_stopped": (C.c_int, [_VP, _PP(C.c_int)]),
+    "azmi_pm_queue_counts": (C.c_int, [_VP, _PP(C.c_uint32), _PP(C.c_uint32)]),
+    "azmi_pm_slot_state": (C.c_int, [_VP, C.c_uint32, _VP, C.c_uint32, _PP(C.c_uint32)]),
+    "azmi_pm_cache_stats": (C.c_int, [_VP, _VP]),
+    "azmi_pm_slot_canonical": (C.c_int, [_VP, C.c_uint32, _VP]),
     "azmi_pm_destroy": (None, [_VP]),
     "azmi_pm_round": (C.c_int, [_VP, _VP]),
     "azmi_pm_io_buffers": (C.c_int, [_VP, _PP(_VP), _PP(_VP), _PP(_VP)]),
@@ -150,12 +158,37 @@ SYMBOLS = {
 }
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64 and looks them up by file
+    name, so if libazmi.so pulled in /opt/rocm's copies first, a later `import torch` would load a second runtime whose
+    device enumeration fails ("No HIP GPUs are available").  Loading torch's copies first (without importing torch)
+    makes libazmi.so bind to them by SONAME, whichever of the two is used first."""
+    import importlib.util
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return          # keep the system runtime; torch must then be imported before this package
+
+
 def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback."
         )
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete

@@ -79,13 +79,6 @@ __global__ void k_cache_find_many(CacheView c, const uint64_t* hashes, uint32_t 
 }
 }  // namespace
 
-struct azmi_cache {
-  CacheView c{};
-  std::vector<void*> allocs;
-  int device = 0;
-  uint32_t max_size = 0;
-  ~azmi_cache() { for (void* p : allocs) (void)hipFree(p); }
-};
 
 extern "C" {
 

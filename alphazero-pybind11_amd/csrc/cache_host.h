@@ -39,3 +39,13 @@ inline hipError_t cache_alloc(CacheView& c, std::vector<void*>& allocs, uint32_t
 }
 
 }  // namespace azmi
+
+// the C-ABI cache object (azmi_cache_create, include/azmi.h): shared with the engine, which can run on caches it does
+// not own (PlayManager(gs, params, caches), play_manager.cc:644-649)
+struct azmi_cache {
+  azmi::CacheView c{};
+  std::vector<void*> allocs;
+  int device = 0;
+  uint32_t max_size = 0;
+  ~azmi_cache() { for (void* p : allocs) (void)hipFree(p); }
+};

@@ -14,6 +14,8 @@
 #include <vector>
 
 #include "../../include/azmi.h"
+#include <atomic>
+
 #include "cache_host.h"
 #include "engine_kernels.h"
 #include "engine_kernels_big.h"
@@ -85,6 +87,7 @@ struct azmi_pm {
   uint32_t hist_read = 0;
   uint32_t cache_shards = 0;
   std::vector<CacheView> group_caches;   // host copies of the per-model-group cache views
+  std::vector<uint8_t> group_cache_counted;  // 0: stand-in for a `None` entry of an external cache list (not in the statistics)
   bool all_random = false;               // every model group uses EvalType::RANDOM
   std::vector<std::deque<uint32_t>> pending_g;   // host-buffer path: pending leaves per model group
   // hipGraph of kGraphRounds x (round kernels + net) for azmi_run_rounds: one graph launch instead of
@@ -96,6 +99,7 @@ struct azmi_pm {
   std::deque<uint32_t> pending;        // slots whose leaf waits for the net
   std::vector<float> host_v, host_pi;  // mirrors of the slot-indexed rows
   uint32_t outstanding = 0;
+  std::atomic<bool> stopped{false};    // PlayManager::stop(), play_manager.h:177 (may be set from another thread)
 
   template <class T>
   int alloc(T*& p, size_t n, bool zero) {
@@ -439,7 +443,22 @@ int build_seat_tables(const azmi_play_params* p, uint32_t P, SeatTables* out) {
 }
 }  // namespace
 
+namespace {
+int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_opts* opts_in, azmi_cache* const* ext_caches,
+                   uint32_t num_ext, bool use_ext, azmi_pm** out);
+}
 int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_opts* opts_in, azmi_pm** out) {
+  return pm_create_impl(game, params, opts_in, nullptr, 0, false, out);
+}
+// PlayManager(gs, params, caches), play_manager.cc:644-649: max_cache_size is forced to 0 and the given caches are used
+int azmi_pm_create_with_caches(int game, const azmi_play_params* params, const azmi_engine_opts* opts_in, azmi_cache* const* caches,
+                               uint32_t num_caches, azmi_pm** out) {
+  if (num_caches && !caches) return fail(AZMI_ERR_INVALID, "null argument");
+  return pm_create_impl(game, params, opts_in, caches, num_caches, true, out);
+}
+namespace {
+int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_opts* opts_in, azmi_cache* const* ext_caches,
+                   uint32_t num_ext, bool use_ext, azmi_pm** out) {
   if (!params || !out) return fail(AZMI_ERR_INVALID, "null argument");
   GameInfo gi;
   if (!game_info(game, &gi)) return fail(AZMI_ERR_INVALID, "unknown game id %d", game);
@@ -557,19 +576,41 @@ int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_o
   // position cache: play_manager.cc:195-203 (one model group): ghost = 9/10 of the capacity.  The
   // reference's cache_shards (<= 255) exists to spread a mutex; here a shard is one wavefront's worth
   // of entries (64) and the unit of parallelism of the insert kernel.
-  ep.cache_on = params->max_cache_size > 0;
+  bool any_ext = false;
+  if (use_ext) {
+    // caches_[group] is indexed by model group (play_manager.cc:619-642): the list must cover every group; None entries
+    // (groups that never reach the net) are allowed
+    if (num_ext != 0 && num_ext < ep.num_groups) { delete pm; return fail(AZMI_ERR_INVALID, "caches: %u entries for %u model groups", num_ext, ep.num_groups); }
+    for (uint32_t g = 0; g < std::min<uint32_t>(num_ext, ep.num_groups); ++g) {
+      const azmi_cache* c = ext_caches[g];
+      if (!c) continue;
+      any_ext = true;
+      if (c->device != opts.device) { delete pm; return fail(AZMI_ERR_INVALID, "caches[%u] lives on another device", g); }
+      if (c->c.np != M || c->c.nv != P + 1) { delete pm; return fail(AZMI_ERR_INVALID, "caches[%u]: num_policy / num_value do not match the game", g); }
+      if (c->c.cap != kWaveCap) {
+        delete pm;
+        return fail(AZMI_ERR_INVALID, "caches[%u]: the engine probes 64-entry shards; create the cache with shards = max_size / 64 "
+                    "(ShardedS3FIFOCache.for_engine)", g);
+      }
+    }
+  }
+  ep.cache_on = use_ext ? any_ext : params->max_cache_size > 0;
   if (ep.cache_on) {
     // wave-resident shards: 64 entries each (dev_cache.h); max_cache_size is rounded down to a multiple of 64
     // one cache per model group, max_cache_size / num_model_groups entries each (play_manager.cc:195-203)
-    const uint32_t shards = std::max<uint32_t>(1, params->max_cache_size / ep.num_groups / kWaveCap);
+    const uint32_t shards = use_ext ? 1u : std::max<uint32_t>(1, params->max_cache_size / ep.num_groups / kWaveCap);
     pm->cache_shards = shards;
     A(cache_keys, S, true);
     pm->group_caches.resize(ep.num_groups);
-    for (uint32_t g = 0; g < ep.num_groups && rc == AZMI_OK; ++g)
+    pm->group_cache_counted.assign(ep.num_groups, 1);
+    for (uint32_t g = 0; g < ep.num_groups && rc == AZMI_OK; ++g) {
+      if (use_ext && g < num_ext && ext_caches[g]) { pm->group_caches[g] = ext_caches[g]->c; continue; }
+      if (use_ext) pm->group_cache_counted[g] = 0;   // a None entry: one private 64-entry shard stands in, outside the statistics
       if (cache_alloc(pm->group_caches[g], pm->allocs, shards * kWaveCap, shards, static_cast<uint32_t>(static_cast<uint64_t>(shards) * kWaveCap * 9 / 10), M, P + 1) != hipSuccess) {
         delete pm;
         return fail(AZMI_ERR_OOM, "position cache allocation failed");
       }
+    }
     if (rc == AZMI_OK) {
       ar.cache = pm->group_caches[0];
       CacheView* dev_views = nullptr;
@@ -613,6 +654,7 @@ int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_o
   *out = pm;
   return AZMI_OK;
 }
+}  // namespace
 
 void azmi_pm_destroy(azmi_pm* pm) {
   if (!pm) return;
@@ -742,11 +784,61 @@ int azmi_pm_poll(azmi_pm* pm, void* stream, uint32_t* games_completed, uint32_t*
   return AZMI_OK;
 }
 
+// ---- PlayManager::stop / stopped / queue sizes / one slot's GameState (play_manager.h:177-186, 285-324) ----------
+int azmi_pm_stop(azmi_pm* pm) {
+  if (!pm) return fail(AZMI_ERR_INVALID, "null pm");
+  pm->stopped.store(true, std::memory_order_relaxed);
+  return AZMI_OK;
+}
+int azmi_pm_stopped(azmi_pm* pm, int* out) {
+  if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");
+  *out = pm->stopped.load(std::memory_order_relaxed) ? 1 : 0;
+  return AZMI_OK;
+}
+// awaiting_inference_count(): leaves waiting to be handed out by build_batch / pop_games; awaiting_mcts_count(): live
+// slots that hold their answer (or need none) and wait for the next round
+int azmi_pm_queue_counts(azmi_pm* pm, uint32_t* awaiting_inference, uint32_t* awaiting_mcts) {
+  if (!pm) return fail(AZMI_ERR_INVALID, "null pm");
+  Control c;
+  const int rc = read_ctl(pm, pm->last, &c, true);
+  if (rc != AZMI_OK) return rc;
+  uint32_t pend = 0;
+  for (auto& q : pm->pending_g) pend += static_cast<uint32_t>(q.size());
+  const uint32_t live = c.stop ? 0u : c.live_slots;
+  if (awaiting_inference) *awaiting_inference = pend;
+  if (awaiting_mcts) *awaiting_mcts = live > pend + pm->outstanding ? live - pend - pm->outstanding : 0u;
+  return AZMI_OK;
+}
+// game_data(i).gs: the packed state words of slot `slot` (Connect4: stones of player 0, stones of player 1,
+// turn | player << 32; Tafl family: defenders lo/hi, attackers lo/hi, king | turn << 8 | player << 24 | repetitions << 32)
+int azmi_pm_slot_state(azmi_pm* pm, uint32_t slot, uint64_t* words, uint32_t cap, uint32_t* n) {
+  if (!pm || !words || !n) return fail(AZMI_ERR_INVALID, "null argument");
+  if (slot >= pm->ep.S) return fail(AZMI_ERR_RANGE, "game index %u out of range", slot);
+  const uint32_t W = pm->gi.state_words;
+  if (cap < W) return fail(AZMI_ERR_INVALID, "words too small");
+  HIP_TRY(hipStreamSynchronize(pm->last));
+  for (uint32_t w = 0; w < W; ++w)
+    HIP_TRY(hipMemcpy(words + w, pm->ar.gs_words + static_cast<size_t>(w) * pm->ep.S + slot, 8, hipMemcpyDeviceToHost));
+  *n = W;
+  return AZMI_OK;
+}
+
+// game_data(i).canonical(): the planes of the leaf slot `slot` is waiting on (host array [C,H,W])
+int azmi_pm_slot_canonical(azmi_pm* pm, uint32_t slot, float* out) {
+  if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");
+  if (slot >= pm->ep.S) return fail(AZMI_ERR_RANGE, "game index %u out of range", slot);
+  const size_t CANON = static_cast<size_t>(pm->gi.C) * pm->gi.H * pm->gi.W;
+  HIP_TRY(hipStreamSynchronize(pm->last));
+  HIP_TRY(hipMemcpy(out, pm->ar.canon + slot * CANON, CANON * 4, hipMemcpyDeviceToHost));
+  return AZMI_OK;
+}
+
 int azmi_pm_play(azmi_pm* pm, void* stream) {
   if (!pm) return fail(AZMI_ERR_INVALID, "null pm");
   if (!pm->all_random) return fail(AZMI_ERR_STATE, "azmi_pm_play needs EvalType::RANDOM on every seat; drive NN seats with azmi_pm_round");
   hipStream_t st = pm->pick(stream);
   for (;;) {
+    if (pm->stopped.load(std::memory_order_relaxed)) return AZMI_OK;   // play_manager.cc:272
     for (int r = 0; r < 32; ++r) {
       const int rc = launch_round(pm, st);
       if (rc != AZMI_OK) return rc;
@@ -803,6 +895,26 @@ int azmi_pm_stats(azmi_pm* pm, float* out) {  // play_manager.h:288-315
   return AZMI_OK;
 }
 
+// cache_hits / misses / evictions / reinserts / size / max_size summed over the model groups' caches (play_manager.h:325-366)
+int azmi_pm_cache_stats(azmi_pm* pm, uint64_t out[6]) {
+  if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");
+  for (int i = 0; i < 6; ++i) out[i] = 0;
+  if (!pm->ep.cache_on) return AZMI_OK;
+  for (uint32_t g = 0; g < pm->ep.num_groups; ++g) {
+    if (!pm->group_cache_counted[g]) continue;
+    const CacheView& c = pm->group_caches[g];
+    std::vector<unsigned long long> st; std::vector<uint32_t> state;
+    int rc = d2h(st, c.stats, static_cast<size_t>(c.shards) * 4, pm->last); if (rc) return rc;
+    rc = d2h(state, c.state, static_cast<size_t>(c.shards) * 8, pm->last); if (rc) return rc;
+    for (uint32_t s = 0; s < c.shards; ++s) {
+      for (int j = 0; j < 4; ++j) out[j] += st[static_cast<size_t>(s) * 4 + j];
+      out[4] += state[static_cast<size_t>(s) * 8 + kSize];
+    }
+    out[5] += static_cast<uint64_t>(c.cap) * c.shards;
+  }
+  return AZMI_OK;
+}
+
 int azmi_pm_counters(azmi_pm* pm, uint64_t* out) {
   if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");
   const uint32_t S = pm->ep.S;
@@ -813,12 +925,9 @@ int azmi_pm_counters(azmi_pm* pm, uint64_t* out) {
   rc = read_ctl(pm, pm->last, &c, true); if (rc) return rc;
   out[0] = out[1] = 0;
   for (uint32_t s = 0; s < S; ++s) { out[0] += sims[s]; out[1] += evals[s]; }
-  out[2] = 0; out[3] = 0;
-  if (pm->ep.cache_on) {
-    std::vector<unsigned long long> st;
-    rc = d2h(st, pm->ar.cache.stats, static_cast<size_t>(pm->ar.cache.shards) * 4, pm->last); if (rc) return rc;
-    for (uint32_t s = 0; s < pm->ar.cache.shards; ++s) { out[2] += st[static_cast<size_t>(s) * 4]; out[3] += st[static_cast<size_t>(s) * 4 + 1]; }
-  }
+  uint64_t cs[6];
+  rc = azmi_pm_cache_stats(pm, cs); if (rc) return rc;
+  out[2] = cs[0]; out[3] = cs[1];
   out[4] = std::min(c.hist_rows, pm->ep.hist_cap) - pm->hist_read;
   out[5] = c.rounds;
   return AZMI_OK;
@@ -906,9 +1015,9 @@ int azmi_pm_build_batch(azmi_pm* pm, float* batch, uint32_t cap, uint32_t* indic
 
 // group == 0xFFFFFFFF: leaves of any model group (single-evaluator callers)
 int azmi_pm_build_batch_group(azmi_pm* pm, uint32_t group, float* batch, uint32_t cap, uint32_t* indices, uint32_t* n) {
-  if (!pm || !batch || !indices || !n) return fail(AZMI_ERR_INVALID, "null argument");
+  if (!pm || !indices || !n) return fail(AZMI_ERR_INVALID, "null argument");   // batch == NULL: pop_games_upto (indices only)
   *n = 0;
-  if (cap == 0) return AZMI_OK;
+  if (cap == 0 || pm->stopped.load(std::memory_order_relaxed)) return AZMI_OK;
   if (group != 0xFFFFFFFFu && group >= pm->ep.num_groups) return fail(AZMI_ERR_INVALID, "model group %u out of range", group);
   const uint32_t S = pm->ep.S, CANON = pm->gi.C * pm->gi.H * pm->gi.W;
   hipStream_t st = pm->pick(AZMI_STREAM_ENGINE);
@@ -946,7 +1055,7 @@ int azmi_pm_build_batch_group(azmi_pm* pm, uint32_t group, float* batch, uint32_
     const uint32_t s = q->front();
     q->pop_front();
     indices[r] = s;
-    HIP_TRY(hipMemcpyAsync(batch + static_cast<size_t>(r) * CANON, pm->ar.canon + static_cast<size_t>(s) * CANON,
+    if (batch) HIP_TRY(hipMemcpyAsync(batch + static_cast<size_t>(r) * CANON, pm->ar.canon + static_cast<size_t>(s) * CANON,
                            CANON * 4, hipMemcpyDeviceToHost, st));
   }
   HIP_TRY(hipStreamSynchronize(st));

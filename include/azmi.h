@@ -132,6 +132,13 @@ int azmi_game_info(int game, uint32_t* num_players, uint32_t* num_moves, uint32_
 
 /* PlayManager(gs, params) — py_wrapper.cc:352-354, play_manager.cc:12-256 */
 int azmi_pm_create(int game, const azmi_play_params* params, const azmi_engine_opts* opts, azmi_pm** out);
+/* PlayManager(gs, params, caches) — py_wrapper.cc:355-360, play_manager.cc:644-649: params.max_cache_size is ignored and model
+ * group g uses caches[g] (an azmi_cache from azmi_cache_create, see below; NULL entries = no cache for that group).  The
+ * caches are not owned: they must outlive the engine, and they keep their contents from one engine to the next.  The engine
+ * probes 64-entry shards, so a cache must have been created with shards = max_size / 64. */
+typedef struct azmi_cache azmi_cache;
+int azmi_pm_create_with_caches(int game, const azmi_play_params* params, const azmi_engine_opts* opts, azmi_cache* const* caches,
+                               uint32_t num_caches, azmi_pm** out);
 void azmi_pm_destroy(azmi_pm* pm);
 
 /* ---- device fast path (what PlayManager::play + GameRunner's batcher/result_worker do,
@@ -150,6 +157,18 @@ int azmi_pm_play(azmi_pm* pm, void* stream);
 /* copies the small control block back (sync on `stream`); mirrors remaining_games()/games_completed() */
 int azmi_pm_poll(azmi_pm* pm, void* stream, uint32_t* games_completed, uint32_t* live_slots);
 
+/* stop() / stopped(), play_manager.h:177-178: play() and build_batch return at their next check; may be called from another thread */
+int azmi_pm_stop(azmi_pm* pm);
+int azmi_pm_stopped(azmi_pm* pm, int* out);
+/* awaiting_inference_count() / awaiting_mcts_count(), play_manager.h:316-323 */
+int azmi_pm_queue_counts(azmi_pm* pm, uint32_t* awaiting_inference, uint32_t* awaiting_mcts);
+/* game_data(i).gs, play_manager.h:286: the packed state of the game in slot i.  Connect4: words = {stones of player 0, stones
+ * of player 1 (bit h*7+w), turn | player << 32}; Tafl family: {defenders lo, hi, attackers lo, hi (bit = square),
+ * king square | turn << 8 | player << 24 | repetition count << 32}.  AZMI_ERR_RANGE for a bad index. */
+int azmi_pm_slot_state(azmi_pm* pm, uint32_t slot, uint64_t* words, uint32_t cap, uint32_t* n);
+/* game_data(i).canonical(), py_wrapper.cc:279-288: the leaf planes slot i is waiting on, to a HOST array [C,H,W] */
+int azmi_pm_slot_canonical(azmi_pm* pm, uint32_t slot, float* out);
+
 /* ---- results (all synchronise on the engine's stream first) -------------------------------- */
 int azmi_pm_scores(azmi_pm* pm, float* out /* [P+1] */);          /* scores(), play_manager.h:173 */
 int azmi_pm_resign_scores(azmi_pm* pm, float* out /* [P+1] */);   /* resign_scores(), :174 */
@@ -159,6 +178,9 @@ int azmi_pm_stats(azmi_pm* pm, float* out);
 /* out[6] = simulations, leaf evaluations requested from the net, cache hits, cache misses,
  *          history rows available, rounds */
 int azmi_pm_counters(azmi_pm* pm, uint64_t* out);
+/* out[6] = cache_hits, cache_misses, cache_evictions, cache_reinserts, cache_size, cache_max_size summed over the model
+ *          groups' caches (play_manager.h:325-366) */
+int azmi_pm_cache_stats(azmi_pm* pm, uint64_t out[6]);
 /* build_history_batch, py_wrapper.cc:393-424: copies up to `cap` finished rows to HOST arrays
  * canonical [cap,C,H,W], v [cap,P+1], pi [cap,M]; returns rows written in *n */
 int azmi_pm_pop_history(azmi_pm* pm, float* canonical, float* v, float* pi, uint32_t cap, uint32_t* n);
@@ -174,7 +196,8 @@ int azmi_pm_slot_games(azmi_pm* pm, uint32_t* out);
 
 /* ---- host-buffer compatibility path (exact reference signatures) ---------------------------
  * build_batch(group, batch) — py_wrapper.cc:449-504: runs rounds until a leaf batch is
- * pending, copies the live rows to the HOST array batch[cap,C,H,W], returns their slot ids. */
+ * pending, copies the live rows to the HOST array batch[cap,C,H,W], returns their slot ids.
+ * batch == NULL hands out the indices only: pop_game / pop_games_upto (play_manager.h:186-192). */
 int azmi_pm_build_batch(azmi_pm* pm, float* batch, uint32_t cap, uint32_t* indices, uint32_t* n);
 /* update_inferences(group, indices, v, pi) — play_manager.cc:619-642, HOST arrays */
 int azmi_pm_update_inferences(azmi_pm* pm, const uint32_t* indices, uint32_t n, const float* v, const float* pi);
@@ -305,7 +328,6 @@ const char* azmi_net_last_error(void);
  *      shard = hash % shards.  insert_many keeps batch order inside a shard (eviction order is the
  *      reference's); the finds of one call are concurrent.  All pointers are HOST arrays.
  *      stats out[6] = hits, misses, evictions, reinserts, size, max_size. */
-typedef struct azmi_cache azmi_cache;
 int azmi_cache_create(uint32_t max_size, uint32_t shards, uint32_t ghost_size, uint32_t num_policy, uint32_t num_value,
                       int device, azmi_cache** out);
 void azmi_cache_destroy(azmi_cache* cache);

@@ -141,3 +141,90 @@ def test_wide_game_engine_with_cache_is_transparent(oracle):
         sel = rows[:, 0] == s
         assert np.array_equal(rows[sel][:, 2:], orows[:, 2:]), s
         assert np.array_equal(counts[sel], ocounts), s
+
+
+# ---- PlayManager(gs, params, caches=[...]) — py_wrapper.cc:355-360, play_manager.cc:644-649; reference tests
+# test_cache.py:385-470 ------------------------------------------------------------------------------------------
+def _play_with_evaluator(az, pp, caches, seed, log=True):
+    pm = az.PlayManager(az.Connect4GS(), pp, caches=caches, seed=seed, log_moves=log)
+    batch = np.zeros((int(pp.concurrent_games), 4, 6, 7), np.float32)
+    while pm.remaining_games() > 0:
+        idx = pm.build_batch(0, batch)
+        if not idx:
+            continue
+        v, pi = _evaluator(batch[: len(idx)])
+        pm.update_inferences(0, idx, v, pi)
+    return pm
+
+
+def _c4_params(az, games=8, visits=30):
+    pp = az.PlayParams()
+    pp.games_to_play, pp.concurrent_games, pp.max_batch_size = games, games, games
+    pp.model_groups = [0, 0]
+    pp.mcts_visits = [visits, visits]
+    pp.cpuct, pp.fpu_reduction = 1.25, 0.25
+    return pp
+
+
+def test_playmanager_cache_counters_and_no_cache():
+    """test_cache.py:385-411: the internal cache reports max_size / size; no cache reports zeros."""
+    import alphazero as az
+    pp = _c4_params(az); pp.max_cache_size = 1024
+    pm = _play_with_evaluator(az, pp, None, 5)
+    assert pm.cache_max_size() == 1024 and 0 < pm.cache_size() <= 1024
+    assert pm.cache_hits() > 0 and pm.cache_misses() > 0
+    assert pm.cache_hits() == pm.counters()["cache_hits"]
+    pp = _c4_params(az); pp.max_cache_size = 0
+    pm = _play_with_evaluator(az, pp, None, 5)
+    assert (pm.cache_max_size(), pm.cache_hits(), pm.cache_misses(), pm.cache_size(), pm.cache_evictions(), pm.cache_reinserts()) == (0,) * 6
+
+
+def test_playmanager_external_cache_is_used_and_transparent():
+    """test_cache.py:414-431 + the transparency property: the same games as a run with the engine's own cache."""
+    import alphazero as az
+    pp = _c4_params(az); pp.max_cache_size = 0
+    ext = az.ShardedS3FIFOCache.for_engine(4096, 7, 3)
+    pm = _play_with_evaluator(az, pp, [ext], 9)
+    assert pm.cache_max_size() == 4096 and ext.size() > 0 and ext.misses() > 0
+    assert pm.cache_size() == ext.size() and pm.cache_hits() == ext.hits()
+    pp2 = _c4_params(az); pp2.max_cache_size = 4096
+    own = _play_with_evaluator(az, pp2, None, 9)
+    assert np.array_equal(pm.move_log()[0], own.move_log()[0]) and np.array_equal(pm.move_log()[1], own.move_log()[1])
+    assert (pm.cache_hits(), pm.cache_misses()) == (own.cache_hits(), own.cache_misses())
+
+
+def test_playmanager_external_cache_shared_across_instances():
+    """test_cache.py:434-460: a second PlayManager on the same cache starts warm."""
+    import alphazero as az
+    shared = az.ShardedS3FIFOCache.for_engine(8192, 7, 3)
+    pp = _c4_params(az)
+    a = _play_with_evaluator(az, pp, [shared], 11)
+    size1, hits1, evals1 = shared.size(), shared.hits(), a.counters()["evals"]
+    assert size1 > 0
+    b = _play_with_evaluator(az, pp, [shared], 11)       # the same games again: every leaf is already cached
+    assert shared.hits() > hits1
+    assert b.counters()["evals"] < evals1
+    def by_slot(pm):    # log rows are in time order, which depends on how many leaves hit the cache: order them per slot
+        rows = pm.move_log()[0]
+        return rows[np.lexsort((rows[:, 3], rows[:, 1], rows[:, 0]))][:, :5]
+    assert np.array_equal(by_slot(a), by_slot(b))
+    del a, b
+    assert shared.size() >= size1                        # the cache outlives the engines that borrowed it
+
+
+def test_playmanager_external_cache_none_entries_and_errors():
+    """test_cache.py:463-476 (None entries for groups that never reach a net) + argument checks."""
+    import alphazero as az
+    pp = _c4_params(az)
+    pp.model_groups = [0, 1]
+    pp.eval_type = [az.EvalType.RANDOM, az.EvalType.RANDOM]
+    nn_cache = az.ShardedS3FIFOCache.for_engine(1024, 7, 3)
+    pm = az.PlayManager(az.Connect4GS(), pp, caches=[nn_cache, None], seed=3)
+    pm.play()
+    assert pm.games_completed() == 8 and pm.cache_max_size() == 1024
+    with pytest.raises(RuntimeError, match="64-entry shards"):
+        az.PlayManager(az.Connect4GS(), pp, caches=[az.ShardedS3FIFOCache(1000, 1, 900, 7, 3), None])
+    with pytest.raises(RuntimeError, match="num_policy"):
+        az.PlayManager(az.Connect4GS(), pp, caches=[az.ShardedS3FIFOCache.for_engine(1024, 9, 3), None])
+    with pytest.raises(RuntimeError, match="model groups"):
+        az.PlayManager(az.Connect4GS(), pp, caches=[nn_cache])

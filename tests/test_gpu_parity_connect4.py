@@ -239,3 +239,100 @@ def test_error_behaviour():
         pm.build_batch(0, np.zeros((2, 3, 6, 7), np.float32))
     with pytest.raises(TypeError):
         az.PlayManager(None, pp)
+
+
+def test_control_surface_stop_queues_variants():
+    """stop / stopped / remaining_games (play_manager.h:177-182), awaiting_* counts, set_eager, the variant accessors."""
+    import alphazero as az
+    pp = az.PlayParams()
+    pp.games_to_play, pp.concurrent_games, pp.max_batch_size = 1000, 16, 16
+    pp.mcts_visits = [20, 20]
+    pp.model_groups = [0, 0]
+    pm = az.PlayManager(az.Connect4GS(), pp, seed=2)
+    assert not pm.stopped() and pm.remaining_games() == 1000
+    assert pm.awaiting_inference_count() == 0 and pm.awaiting_mcts_count() == 16
+    batch = np.zeros((16, 4, 6, 7), np.float32)
+    idx = pm.build_batch(0, batch[:5])
+    assert len(idx) == 5 and pm.awaiting_inference_count() == 11 and pm.awaiting_mcts_count() == 0
+    pm.set_eager(True); pm.set_eager(False)
+    assert pm.num_tracked_variants() == 0
+    with pytest.raises(IndexError):
+        pm.variant_scores(0)
+    pm.stop()
+    assert pm.stopped() and pm.remaining_games() == 0
+    assert pm.build_batch(0, batch) == []
+    # stop() ends a running play() (RANDOM seats) from another thread
+    import threading
+    pp.eval_type = [az.EvalType.RANDOM, az.EvalType.RANDOM]
+    pp.games_to_play = 10 ** 9
+    pm2 = az.PlayManager(az.Connect4GS(), pp, seed=2)
+    t = threading.Thread(target=pm2.play)
+    t.start()
+    import time
+    time.sleep(0.3)
+    pm2.stop()
+    t.join(timeout=20)
+    assert not t.is_alive() and pm2.games_completed() > 0
+
+
+def test_raw_queue_interface_matches_build_batch(oracle):
+    """pop_games_upto / game_data(i) / push_inference(i) (play_manager.h:186-192, 285-286; py_wrapper.cc:265-288) drive
+    the same games as build_batch / update_inferences; game_data(i).gs() is the game in slot i."""
+    import alphazero as az
+
+    def evaluator(canon):
+        n = canon.shape[0]
+        s = (canon.reshape(n, -1).astype(np.float64) * np.linspace(0.5, 1.5, 168)).sum(1).astype(np.float32)
+        v = np.stack([0.3 + 0.1 * np.sin(s), 0.3 - 0.1 * np.sin(s), np.full(n, 0.4)], 1).astype(np.float32)
+        pi = np.abs(np.sin(s[:, None] * np.arange(1, 8, dtype=np.float32))) + 0.05
+        return v, (pi / pi.sum(1, keepdims=True)).astype(np.float32)
+
+    def params():
+        pp = az.PlayParams()
+        pp.games_to_play, pp.concurrent_games, pp.max_batch_size = 6, 6, 6
+        pp.mcts_visits = [25, 25]
+        pp.model_groups = [0, 0]
+        pp.cpuct, pp.fpu_reduction = 1.25, 0.25
+        return pp
+
+    a = az.PlayManager(az.Connect4GS(), params(), seed=13, log_moves=True)
+    batch = np.zeros((6, 4, 6, 7), np.float32)
+    while a.remaining_games() > 0:
+        idx = a.build_batch(0, batch)
+        if idx:
+            v, pi = evaluator(batch[: len(idx)])
+            a.update_inferences(0, idx, v, pi)
+    b = az.PlayManager(az.Connect4GS(), params(), seed=13, log_moves=True)
+    checked_gs = False
+    while b.remaining_games() > 0:
+        idx = b.pop_games_upto(0, 4)
+        if not idx:
+            continue
+        for i in idx:
+            gd = b.game_data(i)
+            canon = gd.canonical()
+            if not checked_gs:                      # the slot's own game: stones on the board = its turn counter
+                g = gd.gs()
+                assert int(np.asarray(g.canonicalized())[:2].sum()) == g.current_turn()
+                assert np.array_equal(gd.valid_moves(), g.valid_moves())
+                checked_gs = True
+            v, pi = evaluator(canon[None])
+            gd.v()[:] = v[0]; gd.pi()[:] = pi[0]
+            b.push_inference(i)
+    assert b.pop_game(0) is None
+    assert np.array_equal(a.move_log()[0], b.move_log()[0]) and np.array_equal(a.move_log()[1], b.move_log()[1])
+    with pytest.raises(IndexError):
+        b.game_data(6)
+
+
+def test_hash_game_state_equality_semantics():
+    """hash_game_state (game_state.h:141-156): equal states hash equal, transpositions too, different states differ."""
+    import alphazero as az
+    a = az.Connect4GS(); b = az.Connect4GS()
+    for m in (3, 4, 2, 5):
+        a.play_move(m)
+    for m in (2, 5, 3, 4):
+        b.play_move(m)
+    c = az.Connect4GS(); c.play_move(3)
+    assert az.hash_game_state(a) == az.hash_game_state(b) == az.hash_game_state(a.copy())
+    assert az.hash_game_state(a) != az.hash_game_state(c)
