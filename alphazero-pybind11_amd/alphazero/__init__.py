@@ -92,11 +92,7 @@ class PlayParams:
         self.seat_resign_consecutive = []
 
     # fields the device engine does not implement yet: anything but the default is an error
-    _UNSUPPORTED = (
-        "temp_decay_half_life_by_variant", "seat_gumbel_enabled", "seat_gumbel_m",
-        "seat_gumbel_c_visit", "seat_gumbel_c_scale", "seat_gumbel_full", "seat_gumbel_use_improved_policy",
-        "seat_resign_threshold", "seat_resign_consecutive",
-    )
+    _UNSUPPORTED = ("temp_decay_half_life_by_variant",)    # indexed by get_variant_id(): no device game has variants
 
     def _to_c(self, num_players):
         c = _capi.PlayParamsC()
@@ -122,7 +118,10 @@ class PlayParams:
             for sidx, g in enumerate(row):
                 c.seat_perms[q][sidx] = g
         for name, cast in (("seat_visits", int), ("seat_cap_visits", int), ("seat_epsilon", float),
-                           ("seat_mcts_root_temp", float), ("seat_root_fpu_zero", int)):
+                           ("seat_mcts_root_temp", float), ("seat_root_fpu_zero", int),
+                           ("seat_gumbel_enabled", int), ("seat_gumbel_m", int), ("seat_gumbel_c_visit", float),
+                           ("seat_gumbel_c_scale", float), ("seat_gumbel_full", int), ("seat_gumbel_use_improved_policy", int),
+                           ("seat_resign_threshold", float), ("seat_resign_consecutive", int)):
             mat = [list(row) for row in getattr(self, name)]
             setattr(c, "has_" + name, int(bool(mat)))
             if not mat:

@@ -64,6 +64,22 @@ class PlayParamsC(C.Structure):
         ("seat_epsilon", (C.c_float * AZMI_MAX_PLAYERS) * AZMI_MAX_PERMS),
         ("seat_mcts_root_temp", (C.c_float * AZMI_MAX_PLAYERS) * AZMI_MAX_PERMS),
         ("seat_root_fpu_zero", (C.c_uint8 * AZMI_MAX_PLAYERS) * AZMI_MAX_PERMS),
+        ("has_seat_gumbel_enabled", C.c_int32),
+        ("has_seat_gumbel_m", C.c_int32),
+        ("has_seat_gumbel_c_visit", C.c_int32),
+        ("has_seat_gumbel_c_scale", C.c_int32),
+        ("has_seat_gumbel_full", C.c_int32),
+        ("has_seat_gumbel_use_improved_policy", C.c_int32),
+        ("has_seat_resign_threshold", C.c_int32),
+        ("has_seat_resign_consecutive", C.c_int32),
+        ("seat_gumbel_enabled", (C.c_uint8 * AZMI_MAX_PLAYERS) * AZMI_MAX_PERMS),
+        ("seat_gumbel_full", (C.c_uint8 * AZMI_MAX_PLAYERS) * AZMI_MAX_PERMS),
+        ("seat_gumbel_use_improved_policy", (C.c_uint8 * AZMI_MAX_PLAYERS) * AZMI_MAX_PERMS),
+        ("seat_gumbel_m", (C.c_uint32 * AZMI_MAX_PLAYERS) * AZMI_MAX_PERMS),
+        ("seat_resign_consecutive", (C.c_uint32 * AZMI_MAX_PLAYERS) * AZMI_MAX_PERMS),
+        ("seat_gumbel_c_visit", (C.c_float * AZMI_MAX_PLAYERS) * AZMI_MAX_PERMS),
+        ("seat_gumbel_c_scale", (C.c_float * AZMI_MAX_PLAYERS) * AZMI_MAX_PERMS),
+        ("seat_resign_threshold", (C.c_float * AZMI_MAX_PLAYERS) * AZMI_MAX_PERMS),
     ]
 
 

@@ -389,6 +389,7 @@ namespace {
 struct SeatTables {
   uint32_t num_groups = 1, num_perms = 1, max_visits = 0;
   bool all_random = true, any_random = false;
+  bool any_gumbel = false, any_seat_resign = false;
   std::vector<uint32_t> words;   // [perm][seat][kSeatWords]
 };
 int build_seat_tables(const azmi_play_params* p, uint32_t P, SeatTables* out) {
@@ -435,9 +436,25 @@ int build_seat_tables(const azmi_play_params* p, uint32_t P, SeatTables* out) {
       out->all_random = out->all_random && rnd; out->any_random = out->any_random || rnd;
       out->max_visits = std::max(out->max_visits, visits);
       if (p->playout_cap_randomization) out->max_visits = std::max(out->max_visits, capv);
+      // per-seat Gumbel / resign overrides, play_manager.cc:116-176
+      const uint32_t gum = p->has_seat_gumbel_enabled ? (p->seat_gumbel_enabled[q][s] != 0) : (p->gumbel_enabled != 0);
+      const uint32_t gfull = p->has_seat_gumbel_full ? (p->seat_gumbel_full[q][s] != 0) : (p->gumbel_full != 0);
+      const uint32_t g3 = p->has_seat_gumbel_use_improved_policy ? (p->seat_gumbel_use_improved_policy[q][s] != 0) : 0u;
+      const uint32_t gm = p->has_seat_gumbel_m ? p->seat_gumbel_m[q][s] : p->gumbel_m;
+      const float gcv = p->has_seat_gumbel_c_visit ? p->seat_gumbel_c_visit[q][s] : p->gumbel_c_visit;
+      const float gcs = p->has_seat_gumbel_c_scale ? p->seat_gumbel_c_scale[q][s] : p->gumbel_c_scale;
+      const float rth = p->has_seat_resign_threshold ? p->seat_resign_threshold[q][s] : -2.0f;
+      const uint32_t rneed = std::max<uint32_t>(1u, p->has_seat_resign_consecutive ? p->seat_resign_consecutive[q][s] : 1u);
+      if (gum && gm > kGumMaxM) return fail(AZMI_ERR_INVALID, "gumbel_m %u exceeds the engine limit %u", gm, kGumMaxM);
+      if (rneed > 255u) return fail(AZMI_ERR_INVALID, "seat_resign_consecutive %u exceeds the engine limit 255", rneed);
+      if (rth > -2.0f && P != 2) return fail(AZMI_ERR_INVALID, "Per-seat resign only works in 2 player games");
+      out->any_gumbel = out->any_gumbel || gum;
+      out->any_seat_resign = out->any_seat_resign || rth > -2.0f;
       uint32_t* w = &out->words[(static_cast<size_t>(q) * P + s) * kSeatWords];
       w[0] = visits; w[1] = seat_w1_pack(capv, fz, rnd ? 1u : 0u, g);
       std::memcpy(&w[2], &eps, 4); std::memcpy(&w[3], &rt, 4);
+      w[4] = seat_gum_pack(gum, gfull, g3, gm, rneed);
+      std::memcpy(&w[5], &gcv, 4); std::memcpy(&w[6], &gcs, 4); std::memcpy(&w[7], &rth, 4);
     }
   return AZMI_OK;
 }
@@ -472,8 +489,6 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
   SeatTables seats;
   { const int rc_seats = build_seat_tables(params, gi.P, &seats); if (rc_seats != AZMI_OK) return rc_seats; }
   if (params->resign_percent > 0 && gi.P != 2) return fail(AZMI_ERR_INVALID, "Resigning only works in 2 player games");
-  if (params->gumbel_enabled && params->gumbel_m > kGumMaxM)
-    return fail(AZMI_ERR_INVALID, "gumbel_m %u exceeds the engine limit %u", params->gumbel_m, kGumMaxM);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(AZMI_ERR_NO_DEVICE, "no HIP device: libazmi has no CPU path");
@@ -499,10 +514,10 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
   ep.cap_rand = params->playout_cap_randomization != 0; ep.root_fpu_zero = params->root_fpu_zero != 0;
   ep.shaped = params->shaped_dirichlet != 0; ep.pruning = params->policy_target_pruning != 0;
   for (uint32_t i = 0; i < gi.P; ++i) ep.eval_random[i] = 0;
-  ep.gumbel_on = params->gumbel_enabled != 0;
-  ep.gumbel_m = params->gumbel_m; ep.gumbel_full = params->gumbel_full != 0;
+  ep.gumbel_on = seats.any_gumbel ? 1u : 0u;
+  ep.gumbel_hist = params->gumbel_enabled != 0;
   ep.fast_gumbel = params->fast_search_uses_gumbel != 0;
-  ep.gumbel_c_visit = params->gumbel_c_visit; ep.gumbel_c_scale = params->gumbel_c_scale;
+  ep.seat_resign = seats.any_seat_resign ? 1u : 0u;
   ep.gum_stride = gi.maxk;
   ep.max_inline = opts.max_inline ? opts.max_inline : 4;
   ep.max_hist_rows = gi.max_turns;
@@ -628,6 +643,7 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
     A(gum_g, static_cast<size_t>(S) * P * ep.gum_stride, true);
     A(gum_surv, static_cast<size_t>(S) * P * kGumMaxM, true);
   }
+  A(resign_streak, static_cast<size_t>(S) * P, true);
 #undef A
   if (rc != AZMI_OK) { delete pm; return rc; }
   if (hipDeviceSynchronize() != hipSuccess) { delete pm; return fail(AZMI_ERR_NO_DEVICE, "device sync failed"); }

@@ -105,6 +105,18 @@ struct SlotCtx {
   __device__ __forceinline__ uint32_t seat_group(uint32_t seat) const { return (AZMI_SEL(sv_w1, seat) >> 26) & 3u; }
   __device__ __forceinline__ float seat_eps(uint32_t seat) const { return AZMI_SEL(sv_eps, seat); }
   __device__ __forceinline__ float seat_root_temp(uint32_t seat) const { return AZMI_SEL(sv_rt, seat); }
+  // per-seat Gumbel / resign settings (words 4-7 of the seat record): read on demand, they are off the PUCT path
+  __device__ __forceinline__ const uint32_t* seat_rec(uint32_t seat) const { return ar.seat_tab + (static_cast<size_t>(perm) * P + seat) * kSeatWords; }
+  __device__ __forceinline__ bool seat_gumbel(uint32_t seat) const { return ep.gumbel_on && (seat_rec(seat)[4] & 1u); }
+  __device__ __forceinline__ bool seat_gumbel_full(uint32_t seat) const { return (seat_rec(seat)[4] >> 1) & 1u; }
+  __device__ __forceinline__ bool seat_gumbel_g3(uint32_t seat) const { return (seat_rec(seat)[4] >> 2) & 1u; }
+  __device__ __forceinline__ uint32_t seat_gumbel_m(uint32_t seat) const { return (seat_rec(seat)[4] >> 8) & 0xFFFFu; }
+  __device__ __forceinline__ uint32_t seat_resign_need(uint32_t seat) const { return seat_rec(seat)[4] >> 24; }
+  __device__ __forceinline__ float seat_sigma_scale(uint32_t seat, uint32_t max_visit) const {   // (c_visit + max N) * c_scale
+    const uint32_t* r = seat_rec(seat);
+    return (__uint_as_float(r[5]) + static_cast<float>(max_visit)) * __uint_as_float(r[6]);
+  }
+  __device__ __forceinline__ float seat_resign_threshold(uint32_t seat) const { return __uint_as_float(seat_rec(seat)[7]); }
 
   __device__ __forceinline__ SlotCtx(const EngineParams& e, const EngineArrays& a, uint32_t s, uint32_t l)
       : ep(e), ar(a), slot(s), lane(l) {}
@@ -221,7 +233,8 @@ struct SlotCtx {
     const uint32_t target = st[kGumTarget], depth = AZMI_SEL(t_depth, seat);
     const uint32_t remaining = depth < target ? target - depth : 0u;
     if (remaining == 0) return;
-    uint32_t m_eff = ep.gumbel_m < k ? ep.gumbel_m : k;
+    const uint32_t gm = seat_gumbel_m(seat);
+    uint32_t m_eff = gm < k ? gm : k;
     m_eff = m_eff < remaining ? m_eff : remaining;
     m_eff = m_eff > 1u ? m_eff : 1u;
     float g_l = 0.0f;
@@ -258,7 +271,7 @@ struct SlotCtx {
         for (uint32_t i = 0; i < nsurv; ++i) if (surv[i] == lane) pos_l = i;
         const bool is_s = pos_l != 0xFFFFu;
         const uint32_t max_visit = group_max(is_s ? n_l : 0u);
-        const float sigma_scale = (ep.gumbel_c_visit + static_cast<float>(max_visit)) * ep.gumbel_c_scale;
+        const float sigma_scale = seat_sigma_scale(seat, max_visit);
         const float g_l = lane < k ? gum_g(seat)[lane] : 0.0f;
         const float score_l = g_l + az_logf(p_l + 1e-20f) + sigma_scale * (n_l > 0 ? q_l : 0.0f);
         uint32_t rank_l = 0;
@@ -281,7 +294,7 @@ struct SlotCtx {
   }
   // softmax(log prior + sigma * completedQ) over the children in lanes [0,k) (mcts.cc:285-373); returns this
   // lane's exp term, the sum in z_sum
-  __device__ __forceinline__ float gumbel_pi_prime(uint32_t k, uint32_t n_l, float q_l, float p_l, float node_v, float& z_sum) const {
+  __device__ __forceinline__ float gumbel_pi_prime(uint32_t seat, uint32_t k, uint32_t n_l, float q_l, float p_l, float node_v, float& z_sum) const {
     float sum_visits = 0.0f, sum_priors_visited = 0.0f, weighted_num = 0.0f;   // compute_v_mix_from_children, mcts.cc:71-89
     for (uint32_t i = 0; i < k; ++i) {
       const uint32_t ni = bcast(n_l, i); const float qi = bcast(q_l, i), pi = bcast(p_l, i);
@@ -294,7 +307,7 @@ struct SlotCtx {
       v_mix = (node_v + sum_visits * weighted_q) / (sum_visits + 1.0f);
     }
     const uint32_t max_visit = group_max(lane < k ? n_l : 0u);
-    const float sigma_scale = (ep.gumbel_c_visit + static_cast<float>(max_visit)) * ep.gumbel_c_scale;
+    const float sigma_scale = seat_sigma_scale(seat, max_visit);
     float z = lane < k ? az_logf(p_l + 1e-20f) + sigma_scale * (n_l > 0 ? q_l : v_mix) : -__builtin_inff();
     float z_max = -__builtin_inff();
     for (uint32_t i = 0; i < k; ++i) { const float zi = bcast(z, i); if (zi > z_max) z_max = zi; }
@@ -303,9 +316,9 @@ struct SlotCtx {
     return z;
   }
   // gumbel_interior_select, mcts.cc:285-334
-  __device__ __forceinline__ uint32_t gumbel_interior_select(uint32_t k, uint32_t n_l, float q_l, float p_l, float node_v) const {
+  __device__ __forceinline__ uint32_t gumbel_interior_select(uint32_t seat, uint32_t k, uint32_t n_l, float q_l, float p_l, float node_v) const {
     float z_sum;
-    const float z = gumbel_pi_prime(k, n_l, q_l, p_l, node_v, z_sum);
+    const float z = gumbel_pi_prime(seat, k, n_l, q_l, p_l, node_v, z_sum);
     uint32_t sum_visits = lane < k ? n_l : 0u;
     for (int off = 1; off < G; off <<= 1) sum_visits += __shfl_xor(sum_visits, off, G);
     const float inv = z_sum > 0 ? (1.0f / z_sum) : 0.0f;
@@ -321,10 +334,10 @@ struct SlotCtx {
     return idx;
   }
   // gumbel_improved_policy, mcts.cc:336-373: dense [M] vector, lane m holds entry m
-  __device__ __forceinline__ float gumbel_improved_policy(uint32_t k, uint32_t mv_l, uint32_t n_l, float q_l, float p_l, float root_v) const {
+  __device__ __forceinline__ float gumbel_improved_policy(uint32_t seat, uint32_t k, uint32_t mv_l, uint32_t n_l, float q_l, float p_l, float root_v) const {
     if (k == 0) return 0.0f;
     float z_sum;
-    const float z = gumbel_pi_prime(k, n_l, q_l, p_l, root_v, z_sum);
+    const float z = gumbel_pi_prime(seat, k, n_l, q_l, p_l, root_v, z_sum);
     if (z_sum <= 0) return 0.0f;
     return scatter_by_move<float>(k, mv_l, z / z_sum);
   }
@@ -337,7 +350,7 @@ struct SlotCtx {
     if (!st[kGumInit] || nsurv == 0) return pick_move(probs(0.0f, cnt_m, pol_m));
     const uint16_t* surv = gum_surv(seat);
     const uint32_t max_visit = group_max(lane < k ? n_l : 0u);
-    const float sigma_scale = (ep.gumbel_c_visit + static_cast<float>(max_visit)) * ep.gumbel_c_scale;
+    const float sigma_scale = seat_sigma_scale(seat, max_visit);
     const float g_l = lane < k ? gum_g(seat)[lane] : 0.0f;
     const float score_l = g_l + az_logf(p_l + 1e-20f) + sigma_scale * (n_l > 0 ? q_l : 0.0f);
     uint32_t best = surv[0];
@@ -482,7 +495,7 @@ struct SlotCtx {
     uint32_t n = ar.N[tb + cur];
     uint32_t* path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
     uint32_t gum_active = 0;   // (uint32_t: a bool carried across the descent loop is mis-tracked by hipcc in divergent groups)
-    if (ep.gumbel_on) {  // lazy init, mcts.cc:465-472
+    if (seat_gumbel(seat)) {  // lazy init, mcts.cc:465-472 (MCTS::gumbel_enabled_ of this seat's tree)
       const uint32_t* st = gum_state(seat);
       gum_active = st[kGumInit];
       if (!gum_active && st[kGumTarget] > 0 && n > 0 && meta_nch(meta) != 0) {
@@ -505,7 +518,7 @@ struct SlotCtx {
       const float v_parent = ar.V[tb + cur];
       uint32_t best;
       if (gum_active && cur == root) best = gumbel_next_root_child(seat, k, n_l, q_l, p_l);
-      else if (gum_active && ep.gumbel_full) best = gumbel_interior_select(k, n_l, q_l, p_l, v_parent);
+      else if (gum_active && seat_gumbel_full(seat)) best = gumbel_interior_select(seat, k, n_l, q_l, p_l, v_parent);
       else best = select_child(k, n_l, q_l, p_l, v_parent, n, fpu);
       cur = c0 + best;
       n = bcast(n_l, best);
@@ -587,7 +600,7 @@ struct SlotCtx {
       if (is_root && root_temp != 1.0f && lane < k) p = az_powf(p, 1.0f / root_temp);
       const float sum = seqsum(lane < k ? p : 0.0f, k);
       p = p / sum;
-      if (is_root && root_noise && !ep.gumbel_on) { trace(1 | (static_cast<uint64_t>(k) << 8)); p = add_root_noise(k, p, seat_eps(seat)); trace(2); }
+      if (is_root && root_noise && !seat_gumbel(seat)) { trace(1 | (static_cast<uint64_t>(k) << 8)); p = add_root_noise(k, p, seat_eps(seat)); trace(2); }
       if (lane < k) ar.Pr[ci] = p;
     }
     // backup: level i updates node_i (child of path[i]); levels are independent -> one lane each
@@ -817,11 +830,54 @@ struct SlotCtx {
         else resign_entry = entry;
       }
     }
-    // move choice, play_manager.cc:403-406
+    // per-seat opt-in resign, play_manager.cc:335-366
+    if (ep.seat_resign && resign_entry < 0 && !(flags & kFlagPlaythrough)) {
+      const float seat_thresh = seat_resign_threshold(cp);
+      if (seat_thresh > -2.0f) {
+        float q = 0, d = 0; bool found = false;  // MCTS::root_value, mcts.h:78-100
+        for (uint32_t i = 0; i < k; ++i) {
+          const uint32_t ni = bcast(n_l, i); const float qi = bcast(q_l, i), di = bcast(d_l, i);
+          if (ni > 0 && qi > q) { q = qi; d = di; found = true; }
+        }
+        if (!found && root_n > 0) { q = ar.V[tb + root]; d = ar.D[tb + root]; }
+        const float w = q - d / static_cast<int32_t>(P);
+        const float l = static_cast<float>(1.0 - static_cast<double>(w) - static_cast<double>(d));
+        const float v_self = w - l;
+        uint32_t* streak = ar.resign_streak + static_cast<size_t>(slot) * P + cp;
+        const uint32_t now = v_self <= seat_thresh ? *streak + 1u : 0u;
+        sync_lanes();
+        if (lane == 0) *streak = now;
+        if (now >= seat_resign_need(cp)) resign_entry = static_cast<int>((cp + 1) % 2);
+      }
+    }
+    // move choice, play_manager.cc:367-406
     const uint64_t rng_before = rng.state;
     uint32_t chosen;
-    if (ep.gumbel_on && !capped) chosen = gumbel_final_action(cp, k, mv_l, n_l, q_l, p_l, cnt_m, pol_m);  // play_manager.cc:367-381
-    else chosen = pick_move(probs(temp, cnt_m, pol_m));
+    if (seat_gumbel(cp) && !capped) {
+      if (!seat_gumbel_g3(cp)) {
+        chosen = gumbel_final_action(cp, k, mv_l, n_l, q_l, p_l, cnt_m, pol_m);   // G1 acting
+      } else {   // G3 opt-in: sample from improved policy ^ (1 / temp)
+        const bool in = lane < static_cast<uint32_t>(M);
+        float pg = gumbel_improved_policy(cp, k, mv_l, n_l, q_l, p_l, ar.V[tb + root]);
+        if (temp != 1.0f && temp > 0.0f) {
+          pg = in ? az_powf(pg, 1.0f / temp) : 0.0f;
+          const float sg = seqsum(pg, M);
+          if (sg > 0) pg = pg / sg;
+        } else if (temp <= 0.0f) {   // arg-max of pi' (first maximum), as a one-hot vector
+          float bv = in ? pg : -__builtin_inff(); uint32_t bi = in ? lane : 0xFFFFu;
+          for (int off = 1; off < G; off <<= 1) {
+            const float ov = __shfl_xor(bv, off, G); const uint32_t oi = __shfl_xor(bi, off, G);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+          }
+          pg = (lane == bi) ? 1.0f : 0.0f;
+        }
+        const float sg = seqsum(in ? pg : 0.0f, M);
+        if (sg > 0) chosen = pick_move(pg);
+        else chosen = gumbel_final_action(cp, k, mv_l, n_l, q_l, p_l, cnt_m, pol_m);
+      }
+    } else {
+      chosen = pick_move(probs(temp, cnt_m, pol_m));
+    }
     trace(5 | (static_cast<uint64_t>(chosen) << 8));
 
     if (ep.log_moves) {
@@ -841,7 +897,7 @@ struct SlotCtx {
     }
     // history sample, play_manager.cc:407-424
     if (ep.history && !capped) {
-      const float target = ep.gumbel_on ? gumbel_improved_policy(k, mv_l, n_l, q_l, p_l, ar.V[tb + root])  // play_manager.cc:411-417
+      const float target = ep.gumbel_hist ? gumbel_improved_policy(cp, k, mv_l, n_l, q_l, p_l, ar.V[tb + root])  // play_manager.cc:411-417
                            : (ep.pruning && seat_eps(cp) > 0)
                                ? probs_pruned(1.0f, root_n, k, mv_l, n_l, q_l, p_l, cnt_m, pol_m)
                                : probs(1.0f, cnt_m, pol_m);

@@ -56,6 +56,18 @@ struct BigSlot {
   __device__ __forceinline__ uint32_t seat_group(uint32_t seat) const { return (AZB_SEL(sv_w1, seat) >> 26) & 3u; }
   __device__ __forceinline__ float seat_eps(uint32_t seat) const { return AZB_SEL(sv_eps, seat); }
   __device__ __forceinline__ float seat_root_temp(uint32_t seat) const { return AZB_SEL(sv_rt, seat); }
+  // per-seat Gumbel / resign settings (words 4-7 of the seat record), read on demand
+  __device__ __forceinline__ const uint32_t* seat_rec(uint32_t seat) const { return ar.seat_tab + (static_cast<size_t>(perm) * P + seat) * kSeatWords; }
+  __device__ __forceinline__ bool seat_gumbel(uint32_t seat) const { return ep.gumbel_on && (seat_rec(seat)[4] & 1u); }
+  __device__ __forceinline__ bool seat_gumbel_full(uint32_t seat) const { return (seat_rec(seat)[4] >> 1) & 1u; }
+  __device__ __forceinline__ bool seat_gumbel_g3(uint32_t seat) const { return (seat_rec(seat)[4] >> 2) & 1u; }
+  __device__ __forceinline__ uint32_t seat_gumbel_m(uint32_t seat) const { return (seat_rec(seat)[4] >> 8) & 0xFFFFu; }
+  __device__ __forceinline__ uint32_t seat_resign_need(uint32_t seat) const { return seat_rec(seat)[4] >> 24; }
+  __device__ __forceinline__ float seat_sigma_scale(uint32_t seat, uint32_t max_visit) const {   // (c_visit + max N) * c_scale
+    const uint32_t* r = seat_rec(seat);
+    return (__uint_as_float(r[5]) + static_cast<float>(max_visit)) * __uint_as_float(r[6]);
+  }
+  __device__ __forceinline__ float seat_resign_threshold(uint32_t seat) const { return __uint_as_float(seat_rec(seat)[7]); }
 
   __device__ __forceinline__ BigSlot(const EngineParams& e, const EngineArrays& a, BigScratch<GM>& s, uint32_t sl, uint32_t l)
       : ep(e), ar(a), sm(s), slot(sl), lane(l) {}
@@ -257,7 +269,8 @@ struct BigSlot {
     const uint32_t target = st[kGumTarget], depth = AZB_SEL(t_depth, seat);
     const uint32_t remaining = depth < target ? target - depth : 0u;
     if (remaining == 0) return;
-    uint32_t m_eff = ep.gumbel_m < k ? ep.gumbel_m : k;
+    const uint32_t gm = seat_gumbel_m(seat);
+    uint32_t m_eff = gm < k ? gm : k;
     m_eff = m_eff < remaining ? m_eff : remaining;
     m_eff = m_eff > 1u ? m_eff : 1u;
     for (uint32_t i = lane; i < k; i += G) sm.f2[i] = ar.Pr[tb + c0 + i];
@@ -287,7 +300,7 @@ struct BigSlot {
     ci = gum_surv(seat)[lane];
     const size_t idx = tb + c0 + ci;
     const uint32_t n = ar.N[idx];
-    const float sigma_scale = (ep.gumbel_c_visit + static_cast<float>(max_visit)) * ep.gumbel_c_scale;
+    const float sigma_scale = seat_sigma_scale(seat, max_visit);
     const float sc = gum_g(seat)[ci] + az_logf(ar.Pr[idx] + 1e-20f) + sigma_scale * (n > 0 ? ar.Q[idx] : 0.0f);
     return sc != sc ? -__builtin_inff() : sc;
   }
@@ -327,7 +340,7 @@ struct BigSlot {
   }
   // exp terms of softmax(log prior + sigma * completedQ) over the children staged in LDS (n: sm.n, q: f1, p: f2)
   // -> sm.f0[0..k); returns their in-order sum (mcts.cc:285-373 share this)
-  __device__ __forceinline__ float gumbel_pi_prime(uint32_t k, float node_v) {
+  __device__ __forceinline__ float gumbel_pi_prime(uint32_t seat, uint32_t k, float node_v) {
     float sum_visits = 0.0f, sum_priors_visited = 0.0f, weighted_num = 0.0f;   // compute_v_mix_from_children, mcts.cc:71-89
     for (uint32_t i = 0; i < k; ++i) {
       const uint32_t ni = sm.n[i];
@@ -342,7 +355,7 @@ struct BigSlot {
     uint32_t mv = 0;
     for (uint32_t i = lane; i < k; i += G) mv = max(mv, sm.n[i]);
     const uint32_t max_visit = wave_max(mv);
-    const float sigma_scale = (ep.gumbel_c_visit + static_cast<float>(max_visit)) * ep.gumbel_c_scale;
+    const float sigma_scale = seat_sigma_scale(seat, max_visit);
     float z_max = -__builtin_inff();
     for (uint32_t i = lane; i < k; i += G) {
       const float z = az_logf(sm.f2[i] + 1e-20f) + sigma_scale * (sm.n[i] > 0 ? sm.f1[i] : v_mix);
@@ -356,13 +369,13 @@ struct BigSlot {
     return seq_sum_f0(k);
   }
   // gumbel_interior_select, mcts.cc:285-334
-  __device__ __forceinline__ uint32_t gumbel_interior_select(size_t tb, uint32_t c0, uint32_t k, float node_v) {
+  __device__ __forceinline__ uint32_t gumbel_interior_select(uint32_t seat, size_t tb, uint32_t c0, uint32_t k, float node_v) {
     for (uint32_t i = lane; i < k; i += G) {
       const size_t ci = tb + c0 + i;
       sm.n[i] = ar.N[ci]; sm.f1[i] = ar.Q[ci]; sm.f2[i] = ar.Pr[ci];
     }
     sync();
-    const float z_sum = gumbel_pi_prime(k, node_v);
+    const float z_sum = gumbel_pi_prime(seat, k, node_v);
     uint32_t sv = 0;
     for (uint32_t i = lane; i < k; i += G) sv += sm.n[i];
     const uint32_t sum_visits = wave_sum(sv);
@@ -384,10 +397,10 @@ struct BigSlot {
     return best_i;
   }
   // gumbel_improved_policy into sm.dense (mcts.cc:336-373); the root must be staged (stage_root)
-  __device__ __forceinline__ void gumbel_improved_policy(uint32_t k, float root_v) {
+  __device__ __forceinline__ void gumbel_improved_policy(uint32_t seat, uint32_t k, float root_v) {
     dense_zero();
     if (k == 0) return;
-    const float z_sum = gumbel_pi_prime(k, root_v);
+    const float z_sum = gumbel_pi_prime(seat, k, root_v);
     if (z_sum <= 0) return;
     for (uint32_t i = lane; i < k; i += G) sm.dense[sm.moves[i]] = sm.f0[i] / z_sum;
     sync();
@@ -461,7 +474,7 @@ struct BigSlot {
     uint32_t n = ar.N[tb + cur];
     uint32_t* path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
     uint32_t gum_active = 0;
-    if (ep.gumbel_on) {  // lazy init, mcts.cc:465-472
+    if (seat_gumbel(seat)) {  // lazy init, mcts.cc:465-472 (MCTS::gumbel_enabled_ of this seat's tree)
       gum_active = gum_state(seat)[kGumInit];
       if (!gum_active && gum_state(seat)[kGumTarget] > 0 && n > 0 && meta_nch(meta) != 0) {
         init_gumbel_state(seat, tb, meta_ch0(meta), meta_nch(meta));
@@ -477,7 +490,7 @@ struct BigSlot {
       const float fpu = (cur == root && seat_fpu_zero(seat)) ? 0.0f : ep.fpu_reduction;
       uint32_t best;
       if (gum_active && cur == root) best = gumbel_next_root_child(seat, tb, c0);
-      else if (gum_active && ep.gumbel_full) best = gumbel_interior_select(tb, c0, k, ar.V[tb + cur]);
+      else if (gum_active && seat_gumbel_full(seat)) best = gumbel_interior_select(seat, tb, c0, k, ar.V[tb + cur]);
       else best = select_child(tb, c0, k, ar.V[tb + cur], n, fpu);
       cur = c0 + best;
       n = ar.N[tb + cur];
@@ -612,7 +625,7 @@ struct BigSlot {
       sync();
       for (uint32_t i = lane; i < k; i += G) sm.f0[i] = sm.f0[i] / sum;
       sync();
-      if (is_root && root_noise && !ep.gumbel_on) add_root_noise(k, seat_eps(seat));
+      if (is_root && root_noise && !seat_gumbel(seat)) add_root_noise(k, seat_eps(seat));
       for (uint32_t i = lane; i < k; i += G) ar.Pr[tb + c0 + i] = sm.f0[i];
     }
     const uint32_t* path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
@@ -844,10 +857,52 @@ struct BigSlot {
         else resign_entry = entry;
       }
     }
+    // per-seat opt-in resign, play_manager.cc:335-366
+    if (ep.seat_resign && resign_entry < 0 && !(flags & kFlagPlaythrough)) {
+      const float seat_thresh = seat_resign_threshold(cp);
+      if (seat_thresh > -2.0f) {
+        float q = 0, d = 0; bool found = false;  // MCTS::root_value
+        for (uint32_t i = 0; i < k; ++i) {
+          const float qi = sm.f1[i];
+          if (sm.n[i] > 0 && qi > q) { q = qi; d = ar.D[tb + c0 + i]; found = true; }
+        }
+        if (!found && root_n > 0) { q = ar.V[tb + root]; d = ar.D[tb + root]; }
+        const float w = q - d / static_cast<int32_t>(P);
+        const float l = static_cast<float>(1.0 - static_cast<double>(w) - static_cast<double>(d));
+        const float v_self = w - l;
+        uint32_t* streak = ar.resign_streak + static_cast<size_t>(slot) * P + cp;
+        const uint32_t now = v_self <= seat_thresh ? *streak + 1u : 0u;
+        sync();
+        if (lane == 0) *streak = now;
+        if (now >= seat_resign_need(cp)) resign_entry = static_cast<int>((cp + 1) % 2);
+      }
+    }
     const uint64_t rng_before = rng.state;
     uint32_t chosen;
-    if (ep.gumbel_on && !capped) {          // play_manager.cc:367-381 (G1 acting)
-      chosen = gumbel_final_action(cp, tb, c0, k);
+    if (seat_gumbel(cp) && !capped) {          // play_manager.cc:367-402
+      if (!seat_gumbel_g3(cp)) {
+        chosen = gumbel_final_action(cp, tb, c0, k);   // G1 acting
+      } else {   // G3 opt-in: sample from improved policy ^ (1 / temp)
+        gumbel_improved_policy(cp, k, ar.V[tb + root]);
+        if (temp != 1.0f && temp > 0.0f) {
+          dense_pow(1.0f / temp);
+          const float sg = dense_seq_sum();
+          if (sg > 0) dense_div(sg);
+        } else if (temp <= 0.0f) {   // arg-max of pi' (first maximum), as a one-hot vector
+          float bv = -__builtin_inff(); uint32_t bi = 0xFFFFFFFFu;
+          for (uint32_t m = lane; m < static_cast<uint32_t>(M); m += G) { const float x = sm.dense[m]; if (x > bv) { bv = x; bi = m; } }
+          for (int off = 1; off < 64; off <<= 1) {
+            const float ov = __shfl_xor(bv, off, 64); const uint32_t oi = __shfl_xor(bi, off, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+          }
+          sync();
+          dense_zero();
+          if (lane == 0 && bi != 0xFFFFFFFFu) sm.dense[bi] = 1.0f;
+          sync();
+        }
+        if (dense_seq_sum() > 0) chosen = pick_move();
+        else { stage_root(tb, c0, k); chosen = gumbel_final_action(cp, tb, c0, k); }
+      }
     } else {
       probs(temp, k);
       chosen = pick_move();
@@ -873,7 +928,7 @@ struct BigSlot {
       }
     }
     if (ep.history && !capped) {
-      if (ep.gumbel_on) gumbel_improved_policy(k, ar.V[tb + root]);   // play_manager.cc:411-417
+      if (ep.gumbel_hist) gumbel_improved_policy(cp, k, ar.V[tb + root]);   // play_manager.cc:411-417
       else if (ep.pruning && seat_eps(cp) > 0) probs_pruned(1.0f, root_n, k); else probs(1.0f, k);
       const uint32_t r = ph_rows;
       if (r < ep.max_hist_rows) {

@@ -51,8 +51,10 @@ struct EngineParams {  // run constants (PlayParams, play_manager.h:60-154, afte
   uint32_t trace_slot;     // debug: slot whose RNG events are traced (0xFFFFFFFF = off)
   uint32_t trace_cap;
   // Gumbel AlphaZero (play_manager.h:103-116)
-  uint32_t gumbel_on, gumbel_m, gumbel_full, fast_gumbel;
-  float gumbel_c_visit, gumbel_c_scale;
+  uint32_t gumbel_on;     // some seat searches with Gumbel (the per-seat settings are in seat_tab)
+  uint32_t gumbel_hist;   // PlayParams::gumbel_enabled: history rows carry the improved policy (play_manager.cc:411-417)
+  uint32_t fast_gumbel;
+  uint32_t seat_resign;   // some seat has a resign threshold (seat_resign_threshold > -2)
   uint32_t gum_stride;     // floats per tree in gum_g (>= max children of a root)
   // wide games: the arena is two halves of `half_nodes`; the live subtree is copied into the idle half
   // (k_compact) once the active half holds more than `compact_above` nodes after a move. 0 = one flat arena.
@@ -60,8 +62,14 @@ struct EngineParams {  // run constants (PlayParams, play_manager.h:60-154, afte
   uint32_t num_perms, num_groups;   // seat permutations / model groups (play_manager.cc:24-113)
 };
 
-// per (permutation, seat) record of ar.seat_tab, 4 words: visits | cap_visits + flags | epsilon | root temp
-constexpr uint32_t kSeatWords = 4;
+// per (permutation, seat) record of ar.seat_tab, 8 words: visits | cap_visits + flags | epsilon | root temp |
+// Gumbel word (seat_gum_pack) | gumbel_c_visit | gumbel_c_scale | seat_resign_threshold
+constexpr uint32_t kSeatWords = 8;
+// bit 0 seat_gumbel_enabled, 1 seat_gumbel_full, 2 seat_gumbel_use_improved_policy; bits 8-23 seat_gumbel_m;
+// bits 24-31 max(1, seat_resign_consecutive)
+__host__ __device__ inline uint32_t seat_gum_pack(uint32_t enabled, uint32_t full, uint32_t g3, uint32_t m, uint32_t resign_need) {
+  return (enabled & 1u) | ((full & 1u) << 1) | ((g3 & 1u) << 2) | ((m & 0xFFFFu) << 8) | ((resign_need & 0xFFu) << 24);
+}
 __host__ __device__ inline uint32_t seat_w1_pack(uint32_t cap_visits, uint32_t fpu_zero, uint32_t eval_random, uint32_t group) {
   return (cap_visits & 0xFFFFFFu) | (fpu_zero << 24) | (eval_random << 25) | (group << 26);
 }
@@ -151,6 +159,7 @@ struct EngineArrays {
   uint8_t* leaf_group;    // [S] model group of the pending leaf
   float* a_perm_scores;   // [S][perms][P+1] committed scores per permutation
   uint32_t* a_perm_games; // [S][perms]
+  uint32_t* resign_streak;  // [S][P] GameData::resign_streak (kept from one game of the slot to the next, like the reference)
   const CacheView* caches;  // [groups] one S3-FIFO per model group (play_manager.cc:195-203); `cache` = caches[0]
 };
 

@@ -212,7 +212,7 @@ __global__ void k_mcts_query(EngineParams ep, EngineArrays ar, uint32_t kind, fl
       }
       break;
     }
-    case kQGumbelPolicy: { const float p = c.gumbel_improved_policy(k, mv_l, n_l, q_l, p_l, ar.V[tb + root]); if (in) out_f[lane] = p; break; }
+    case kQGumbelPolicy: { const float p = c.gumbel_improved_policy(0, k, mv_l, n_l, q_l, p_l, ar.V[tb + root]); if (in) out_f[lane] = p; break; }
     case kQGumbelFinal: { const uint32_t a = c.gumbel_final_action(0, k, mv_l, n_l, q_l, p_l, cnt_m, pol_m); if (lane == 0) out_u[0] = a; break; }
     case kQAddRootNoise: {   // MCTS::add_root_noise on the current root priors
       if (k > 0) { const float p = c.add_root_noise(k, p_l, c.seat_eps(0)); if (lane < k) ar.Pr[ci] = p; }
@@ -238,7 +238,7 @@ __global__ void k_mcts_query(EngineParams ep, EngineArrays ar, uint32_t kind, fl
         uint32_t nn = 0, mm = 0;
         if (lane < kk) { nn = ar.N[tb + cc0 + lane]; mm = meta_mv(ar.META[tb + cc0 + lane]); }
         uint32_t best = 0xFFFFu;
-        if (ply == 0 && ep.gumbel_on) {
+        if (ply == 0 && c.seat_gumbel(0)) {
           const uint32_t a = c.gumbel_final_action(0, k, mv_l, n_l, q_l, p_l, cnt_m, pol_m);
           for (uint32_t i = 0; i < kk; ++i) if (c.bcast(mm, i) == a) { best = i; break; }
         }
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(64) void k_mcts_big_query(EngineParams ep, EngineAr
       }
       break;
     }
-    case kQGumbelPolicy: c.gumbel_improved_policy(k, ar.V[tb + root]); dense_out(); break;
+    case kQGumbelPolicy: c.gumbel_improved_policy(0, k, ar.V[tb + root]); dense_out(); break;
     case kQGumbelFinal: { const uint32_t a = c.gumbel_final_action(0, tb, c0, k); if (lane == 0) out_u[0] = a; break; }
     case kQAddRootNoise:
       if (k > 0) {
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(64) void k_mcts_big_query(EngineParams ep, EngineAr
         const uint32_t kk = meta_nch(m), cc0 = meta_ch0(m);
         if (kk == 0) break;
         uint32_t best = 0xFFFFFFFFu;
-        if (ply == 0 && ep.gumbel_on) {
+        if (ply == 0 && c.seat_gumbel(0)) {
           const uint32_t a = c.gumbel_final_action(0, tb, c0, k);
           uint32_t hit = 0xFFFFFFFFu;
           for (uint32_t i = lane; i < kk; i += 64) if (meta_mv(ar.META[tb + cc0 + i]) == a) hit = i;

@@ -101,6 +101,18 @@ typedef struct azmi_play_params {
   float seat_epsilon[AZMI_MAX_PERMS][AZMI_MAX_PLAYERS];
   float seat_mcts_root_temp[AZMI_MAX_PERMS][AZMI_MAX_PLAYERS];
   uint8_t seat_root_fpu_zero[AZMI_MAX_PERMS][AZMI_MAX_PLAYERS];
+  /* per-seat Gumbel and resign overrides, play_manager.h:126-153 / play_manager.cc:116-176 (same has_* convention; defaults:
+   * the global gumbel_* fields, use_improved_policy 0, resign threshold -2 = off, consecutive 1) */
+  int32_t has_seat_gumbel_enabled, has_seat_gumbel_m, has_seat_gumbel_c_visit, has_seat_gumbel_c_scale, has_seat_gumbel_full,
+          has_seat_gumbel_use_improved_policy, has_seat_resign_threshold, has_seat_resign_consecutive;
+  uint8_t seat_gumbel_enabled[AZMI_MAX_PERMS][AZMI_MAX_PLAYERS];
+  uint8_t seat_gumbel_full[AZMI_MAX_PERMS][AZMI_MAX_PLAYERS];
+  uint8_t seat_gumbel_use_improved_policy[AZMI_MAX_PERMS][AZMI_MAX_PLAYERS];
+  uint32_t seat_gumbel_m[AZMI_MAX_PERMS][AZMI_MAX_PLAYERS];
+  uint32_t seat_resign_consecutive[AZMI_MAX_PERMS][AZMI_MAX_PLAYERS];
+  float seat_gumbel_c_visit[AZMI_MAX_PERMS][AZMI_MAX_PLAYERS];
+  float seat_gumbel_c_scale[AZMI_MAX_PERMS][AZMI_MAX_PLAYERS];
+  float seat_resign_threshold[AZMI_MAX_PERMS][AZMI_MAX_PLAYERS];
 } azmi_play_params;
 
 /* engine-only knobs that have no reference counterpart */

@@ -260,6 +260,11 @@ struct OrcPlayParams {
   float seat_epsilon[8][4], seat_mcts_root_temp[8][4];
   uint8_t seat_root_fpu_zero[8][4];
   uint32_t perm_base;
+  int32_t has_seat_gumbel_enabled, has_seat_gumbel_m, has_seat_gumbel_c_visit, has_seat_gumbel_c_scale, has_seat_gumbel_full,
+          has_seat_gumbel_use_improved_policy, has_seat_resign_threshold, has_seat_resign_consecutive;
+  uint8_t seat_gumbel_enabled[8][4], seat_gumbel_full[8][4], seat_gumbel_use_improved_policy[8][4];
+  uint32_t seat_gumbel_m[8][4], seat_resign_consecutive[8][4];
+  float seat_gumbel_c_visit[8][4], seat_gumbel_c_scale[8][4], seat_resign_threshold[8][4];
 };
 typedef void (*orc_group_eval_fn)(uint32_t group, const float* canonical, uint32_t n, float* v, float* pi, void* user);
 typedef void (*orc_eval_fn)(const float* canonical, uint32_t n, float* v, float* pi, void* user);
@@ -297,6 +302,11 @@ void* orc_pm_new(int game_id, const OrcPlayParams* c, uint64_t seed, int per_slo
       if (c->has_seat_epsilon) p.seat_epsilon.emplace_back(c->seat_epsilon[q], c->seat_epsilon[q] + P);
       if (c->has_seat_mcts_root_temp) p.seat_mcts_root_temp.emplace_back(c->seat_mcts_root_temp[q], c->seat_mcts_root_temp[q] + P);
       if (c->has_seat_root_fpu_zero) p.seat_root_fpu_zero.emplace_back(c->seat_root_fpu_zero[q], c->seat_root_fpu_zero[q] + P);
+#define ORC_SEAT(name) if (c->has_##name) p.name.emplace_back(c->name[q], c->name[q] + P)
+      ORC_SEAT(seat_gumbel_enabled); ORC_SEAT(seat_gumbel_m); ORC_SEAT(seat_gumbel_c_visit); ORC_SEAT(seat_gumbel_c_scale);
+      ORC_SEAT(seat_gumbel_full); ORC_SEAT(seat_gumbel_use_improved_policy); ORC_SEAT(seat_resign_threshold);
+      ORC_SEAT(seat_resign_consecutive);
+#undef ORC_SEAT
     }
     auto* b = new PmBox();
     b->pm = std::make_unique<PlayManager>(std::move(base), p, seed, per_slot_rng != 0, c->perm_base);

@@ -72,6 +72,10 @@ struct PlayParams {  // play_manager.h:60-154 (fields the path implements)
   std::vector<std::vector<uint32_t>> seat_visits, seat_cap_visits;
   std::vector<std::vector<float>> seat_epsilon, seat_mcts_root_temp;
   std::vector<std::vector<uint8_t>> seat_root_fpu_zero;
+  // per-seat Gumbel / resign overrides, play_manager.h:126-153
+  std::vector<std::vector<uint8_t>> seat_gumbel_enabled, seat_gumbel_full, seat_gumbel_use_improved_policy;
+  std::vector<std::vector<uint32_t>> seat_gumbel_m, seat_resign_consecutive;
+  std::vector<std::vector<float>> seat_gumbel_c_visit, seat_gumbel_c_scale, seat_resign_threshold;
 };
 
 struct HistoryRow {  // game_state.h:16-20
@@ -216,6 +220,7 @@ class PlayManager {
     double total_valid_moves = 0;
     uint32_t move_count = 0, full_move_count = 0, fast_move_count = 0;
     uint32_t games_played = 0;
+    std::vector<uint32_t> resign_streak;   // GameData::resign_streak, play_manager.h:54-57 (not cleared between games)
   };
 
   Pcg32& tree_rng(uint32_t slot) { return tree_rng_[per_slot_rng_ ? slot : 0]; }
@@ -252,6 +257,15 @@ class PlayManager {
     fill(seat_epsilon_, params_.seat_epsilon, [&](size_t, uint32_t) { return params_.epsilon; }, "seat_epsilon");
     fill(seat_root_temp_, params_.seat_mcts_root_temp, [&](size_t, uint32_t) { return params_.mcts_root_temp; }, "seat_mcts_root_temp");
     fill(seat_fpu_zero_, params_.seat_root_fpu_zero, [&](size_t, uint32_t) { return static_cast<uint8_t>(params_.root_fpu_zero ? 1 : 0); }, "seat_root_fpu_zero");
+    // play_manager.cc:116-176
+    fill(seat_gumbel_enabled_, params_.seat_gumbel_enabled, [&](size_t, uint32_t) { return static_cast<uint8_t>(params_.gumbel_enabled ? 1 : 0); }, "seat_gumbel_enabled");
+    fill(seat_gumbel_m_, params_.seat_gumbel_m, [&](size_t, uint32_t) { return params_.gumbel_m; }, "seat_gumbel_m");
+    fill(seat_gumbel_c_visit_, params_.seat_gumbel_c_visit, [&](size_t, uint32_t) { return params_.gumbel_c_visit; }, "seat_gumbel_c_visit");
+    fill(seat_gumbel_c_scale_, params_.seat_gumbel_c_scale, [&](size_t, uint32_t) { return params_.gumbel_c_scale; }, "seat_gumbel_c_scale");
+    fill(seat_gumbel_full_, params_.seat_gumbel_full, [&](size_t, uint32_t) { return static_cast<uint8_t>(params_.gumbel_full ? 1 : 0); }, "seat_gumbel_full");
+    fill(seat_gumbel_g3_, params_.seat_gumbel_use_improved_policy, [&](size_t, uint32_t) { return static_cast<uint8_t>(0); }, "seat_gumbel_use_improved_policy");
+    fill(seat_resign_threshold_, params_.seat_resign_threshold, [&](size_t, uint32_t) { return -2.0f; }, "seat_resign_threshold");
+    fill(seat_resign_consecutive_, params_.seat_resign_consecutive, [&](size_t, uint32_t) { return 1u; }, "seat_resign_consecutive");
   }
 
   Mcts make_mcts(uint32_t slot, uint8_t perm, uint32_t player) {  // play_manager.cc:602-617
@@ -265,11 +279,11 @@ class PlayManager {
     c.relative_values = base_->relative_values();
     c.root_fpu_zero = seat_fpu_zero_[perm][player] != 0;
     c.shaped_dirichlet = params_.shaped_dirichlet;
-    c.gumbel_enabled = params_.gumbel_enabled;   // play_manager.cc:612-616
-    c.gumbel_m = params_.gumbel_m;
-    c.gumbel_c_visit = params_.gumbel_c_visit;
-    c.gumbel_c_scale = params_.gumbel_c_scale;
-    c.gumbel_full = params_.gumbel_full;
+    c.gumbel_enabled = seat_gumbel_enabled_[perm][player] != 0;   // play_manager.cc:612-616
+    c.gumbel_m = seat_gumbel_m_[perm][player];
+    c.gumbel_c_visit = seat_gumbel_c_visit_[perm][player];
+    c.gumbel_c_scale = seat_gumbel_c_scale_[perm][player];
+    c.gumbel_full = seat_gumbel_full_[perm][player] != 0;
     Mcts m(c, &tree_rng(slot));
     if (trace_on) m.trace = &trace;
     return m;
@@ -327,12 +341,51 @@ class PlayManager {
             else resign_score = tmp;
           }
         }
-        // move choice, play_manager.cc:367-406 (G1 Gumbel acting or PUCT sampling; the opt-in G3
-        // branch, seat_gumbel_use_improved_policy, is not restated)
+        // per-seat opt-in resign, play_manager.cc:335-366: W - L of the seat at or below its threshold for
+        // `consecutive` own moves in a row
+        if (!resign_score.has_value() && !game.playthrough) {
+          const float seat_thresh = seat_resign_threshold_[game.perm_index][cp];
+          if (seat_thresh > -2.0f) {
+            if (P != 2) throw std::runtime_error("Per-seat resign only works in 2 player games");
+            if (game.resign_streak.empty()) game.resign_streak.assign(P, 0u);
+            float pred[3];
+            mcts.root_value(pred);
+            const float v_self = pred[0] - pred[1];
+            if (v_self <= seat_thresh) ++game.resign_streak[cp];
+            else game.resign_streak[cp] = 0;
+            const uint32_t need = std::max(1u, seat_resign_consecutive_[game.perm_index][cp]);
+            if (game.resign_streak[cp] >= need) {
+              std::vector<float> tmp(P + 1, 0.0f);
+              tmp[(cp + 1) % 2] = 1.0;
+              resign_score = tmp;
+            }
+          }
+        }
+        // move choice, play_manager.cc:367-406: G1 Gumbel acting, the opt-in G3 acting
+        // (seat_gumbel_use_improved_policy) or PUCT sampling
         const uint64_t rng_before = tree_rng(i).state;
         uint32_t chosen_m;
         if (mcts.gumbel_enabled() && !game.capped) {
-          chosen_m = mcts.gumbel_final_action();
+          if (!seat_gumbel_g3_[game.perm_index][cp]) {
+            chosen_m = mcts.gumbel_final_action();
+          } else {
+            std::vector<float> pi_g = mcts.gumbel_improved_policy();
+            if (temp != 1.0f && temp > 0.0f) {
+              float sg = 0.0f;
+              for (float& x : pi_g) { x = az_powf(x, 1.0f / temp); }
+              for (float x : pi_g) sg += x;
+              if (sg > 0) for (float& x : pi_g) x /= sg;
+            } else if (temp <= 0.0f) {
+              uint32_t arg = 0;
+              for (uint32_t m = 1; m < pi_g.size(); ++m) if (pi_g[m] > pi_g[arg]) arg = m;
+              std::fill(pi_g.begin(), pi_g.end(), 0.0f);
+              pi_g[arg] = 1.0f;
+            }
+            float sg = 0.0f;
+            for (float x : pi_g) sg += x;
+            if (sg > 0) chosen_m = Mcts::pick_move(pi_g, tree_rng(i));
+            else chosen_m = mcts.gumbel_final_action();
+          }
         } else {
           const std::vector<float> pi_play = mcts.probs(temp);
           chosen_m = Mcts::pick_move(pi_play, tree_rng(i));
@@ -502,6 +555,9 @@ class PlayManager {
   uint32_t num_model_groups_ = 1;
   std::vector<EvalType> eval_types_;                       // per model group
   std::vector<std::vector<uint8_t>> seat_perms_, seat_fpu_zero_;
+  std::vector<std::vector<uint8_t>> seat_gumbel_enabled_, seat_gumbel_full_, seat_gumbel_g3_;
+  std::vector<std::vector<uint32_t>> seat_gumbel_m_, seat_resign_consecutive_;
+  std::vector<std::vector<float>> seat_gumbel_c_visit_, seat_gumbel_c_scale_, seat_resign_threshold_;
   std::vector<std::vector<uint32_t>> seat_visits_, seat_cap_visits_;
   std::vector<std::vector<float>> seat_epsilon_, seat_root_temp_;
   std::vector<std::vector<float>> perm_scores_;

@@ -266,7 +266,16 @@ class OrcPlayParams(C.Structure):
                 ("has_seat_mcts_root_temp", C.c_int32), ("has_seat_root_fpu_zero", C.c_int32),
                 ("seat_visits", (C.c_uint32 * 4) * 8), ("seat_cap_visits", (C.c_uint32 * 4) * 8),
                 ("seat_epsilon", (C.c_float * 4) * 8), ("seat_mcts_root_temp", (C.c_float * 4) * 8),
-                ("seat_root_fpu_zero", (C.c_uint8 * 4) * 8), ("perm_base", C.c_uint32)]
+                ("seat_root_fpu_zero", (C.c_uint8 * 4) * 8), ("perm_base", C.c_uint32),
+                ("has_seat_gumbel_enabled", C.c_int32), ("has_seat_gumbel_m", C.c_int32), ("has_seat_gumbel_c_visit", C.c_int32),
+                ("has_seat_gumbel_c_scale", C.c_int32), ("has_seat_gumbel_full", C.c_int32),
+                ("has_seat_gumbel_use_improved_policy", C.c_int32), ("has_seat_resign_threshold", C.c_int32),
+                ("has_seat_resign_consecutive", C.c_int32),
+                ("seat_gumbel_enabled", (C.c_uint8 * 4) * 8), ("seat_gumbel_full", (C.c_uint8 * 4) * 8),
+                ("seat_gumbel_use_improved_policy", (C.c_uint8 * 4) * 8),
+                ("seat_gumbel_m", (C.c_uint32 * 4) * 8), ("seat_resign_consecutive", (C.c_uint32 * 4) * 8),
+                ("seat_gumbel_c_visit", (C.c_float * 4) * 8), ("seat_gumbel_c_scale", (C.c_float * 4) * 8),
+                ("seat_resign_threshold", (C.c_float * 4) * 8)]
 
 
 GROUP_EVAL_FN = C.CFUNCTYPE(None, C.c_uint32, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p)
@@ -285,7 +294,9 @@ def fill_seat_fields(c, pp):
         for sidx, g in enumerate(row):
             c.seat_perms[q][sidx] = int(g)
     for name, cast in (("seat_visits", int), ("seat_cap_visits", int), ("seat_epsilon", float), ("seat_mcts_root_temp", float),
-                       ("seat_root_fpu_zero", int)):
+                       ("seat_root_fpu_zero", int), ("seat_gumbel_enabled", int), ("seat_gumbel_m", int),
+                       ("seat_gumbel_c_visit", float), ("seat_gumbel_c_scale", float), ("seat_gumbel_full", int),
+                       ("seat_gumbel_use_improved_policy", int), ("seat_resign_threshold", float), ("seat_resign_consecutive", int)):
         mat = getattr(pp, name, []) or []
         setattr(c, "has_" + name, int(bool(mat)))
         for q, row in enumerate(mat):

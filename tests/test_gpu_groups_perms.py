@@ -131,3 +131,74 @@ def test_shape_errors_match_the_reference(az):
     pp.seat_visits = [[8, 8], [8]]
     with pytest.raises(RuntimeError, match="seat_visits inner dimension must match number of players"):
         az.PlayManager(az.Connect4GS(), pp)
+
+
+# ---- per-seat Gumbel and resign matrices (play_manager.h:126-153, play_manager.cc:116-176, 335-402, 602-617) ---------
+def test_per_seat_gumbel_connect4(az, oracle):
+    """one seat searches with Gumbel (its own m / c_visit / c_scale / full), the other with PUCT; the seats swap with the
+    permutation.  Global gumbel_enabled = False: history rows carry probs(1), not the improved policy."""
+    pp = _base(az, games_to_play=8, concurrent_games=8, mcts_visits=[32, 40], model_groups=[0, 1], seat_perms=[[0, 1], [1, 0]],
+               seat_gumbel_enabled=[[1, 0], [0, 1]], seat_gumbel_m=[[4, 16], [16, 8]], seat_gumbel_c_visit=[[50.0, 50.0], [50.0, 20.0]],
+               seat_gumbel_c_scale=[[1.0, 1.0], [1.0, 0.5]], seat_gumbel_full=[[1, 0], [0, 0]], epsilon=0.25)
+    _slotwise(az, oracle, az.Connect4GS, oracle.GAME_CONNECT4, pp, seed=71)
+    # global Gumbel with one seat opted out and the other acting by sampling the improved policy (G3), three temperature regimes
+    for temps in ((1.0, 1.0), (0.6, 0.6), (0.0, 0.0)):
+        pp = _base(az, games_to_play=6, concurrent_games=6, mcts_visits=[28, 28], model_groups=[0, 1], seat_perms=[[0, 1], [1, 0]],
+                   gumbel_enabled=True, gumbel_m=8, seat_gumbel_enabled=[[1, 0], [1, 1]],
+                   seat_gumbel_use_improved_policy=[[1, 0], [0, 1]], start_temp=temps[0], final_temp=temps[1])
+        _slotwise(az, oracle, az.Connect4GS, oracle.GAME_CONNECT4, pp, seed=72)
+
+
+def test_per_seat_gumbel_wide_games(az, oracle):
+    pp = _base(az, games_to_play=3, concurrent_games=3, mcts_visits=[20, 24], model_groups=[0, 1], seat_perms=[[0, 1], [1, 0]],
+               seat_gumbel_enabled=[[1, 0], [0, 1]], seat_gumbel_m=[[8, 16], [16, 4]], seat_gumbel_use_improved_policy=[[1, 0], [0, 0]],
+               start_temp=0.8, final_temp=0.8)
+    _slotwise(az, oracle, az.TawlbwrddGS, oracle.GAME_TAWLBWRDD, pp, seed=73)
+    pp = _base(az, games_to_play=4, concurrent_games=4, mcts_visits=[16, 16], gumbel_enabled=True, gumbel_m=6,
+               seat_gumbel_full=[[1, 0]], seat_gumbel_c_scale=[[0.5, 2.0]])
+    _slotwise(az, oracle, az.BrandubhGS, oracle.GAME_BRANDUBH, pp, seed=74)
+
+
+def test_per_seat_resign(az, oracle):
+    """seat_resign_threshold / seat_resign_consecutive (play_manager.cc:335-366): with the uniform evaluator W - L stays
+    near 0, so a threshold of 0.1 trips after `consecutive` own moves and the opponent is credited."""
+    pp = _base(az, games_to_play=8, concurrent_games=8, mcts_visits=[20, 20], model_groups=[0, 1], seat_perms=[[0, 1], [1, 0]],
+               seat_resign_threshold=[[0.1, -2.0], [-2.0, 0.1]], seat_resign_consecutive=[[3, 1], [1, 2]])
+    pm = _slotwise(az, oracle, az.Connect4GS, oracle.GAME_CONNECT4, pp, seed=75)
+    rows, _ = pm.move_log()
+    lens = [int((rows[:, 0] == s).sum()) for s in range(8)]
+    assert max(lens) <= 6                       # seat 0 resigns on its 3rd move (perm 0), seat 1 on its 2nd (perm 1)
+    assert pm.scores().sum() == 8 and pm.resign_scores().sum() == 8
+    pp = _base(az, games_to_play=3, concurrent_games=3, mcts_visits=[12, 12], seat_resign_threshold=[[-2.0, 0.2]],
+               seat_resign_consecutive=[[1, 4]])
+    _slotwise(az, oracle, az.BrandubhGS, oracle.GAME_BRANDUBH, pp, seed=76)
+
+
+def test_resign_streak_is_kept_across_games_of_a_slot(az, oracle):
+    """GameData::resign_streak is not cleared when the slot starts its next game (play_manager.cc:498-520): one slot,
+    three games, compared with the oracle's one-slot run."""
+    pp = _base(az, games_to_play=3, concurrent_games=1, mcts_visits=[16, 16], seat_resign_threshold=[[0.1, -2.0]],
+               seat_resign_consecutive=[[2, 1]])
+    seed = 77
+    pm = az.PlayManager(az.Connect4GS(), pp, seed=seed, log_moves=True)
+    pm.play()
+    o = oracle.PlayManager(oracle.GAME_CONNECT4, pp, oracle.slot_seed(seed, 0), per_slot_rng=False)
+    o.run()
+    rows, counts = pm.move_log()
+    orows, ocounts = o.moves()
+    assert np.array_equal(rows[:, 1:], orows[:, 1:]) and np.array_equal(counts, ocounts)
+    assert np.array_equal(pm.scores(), o.scores()) and np.array_equal(pm.resign_scores(), o.resign_scores())
+    games = [int((rows[:, 1] == g).sum()) for g in range(3)]
+    assert games[0] == 3 and games[1] == 1 and games[2] == 1      # later games resign at seat 0's first move: the streak carried over
+
+
+def test_per_seat_matrix_validation(az):
+    pp = _base(az, games_to_play=2, concurrent_games=2, mcts_visits=[8, 8], seat_gumbel_m=[[4, 4], [4, 4]])
+    with pytest.raises(RuntimeError, match="seat_gumbel_m outer dimension must match number of seat permutations"):
+        az.PlayManager(az.Connect4GS(), pp)
+    pp = _base(az, games_to_play=2, concurrent_games=2, mcts_visits=[8, 8], seat_resign_threshold=[[0.1]])
+    with pytest.raises(RuntimeError, match="seat_resign_threshold inner dimension must match number of players"):
+        az.PlayManager(az.Connect4GS(), pp)
+    pp = _base(az, games_to_play=2, concurrent_games=2, mcts_visits=[8, 8], seat_gumbel_enabled=[[1, 0]], seat_gumbel_m=[[100, 4]])
+    with pytest.raises(RuntimeError, match="gumbel_m"):
+        az.PlayManager(az.Connect4GS(), pp)
