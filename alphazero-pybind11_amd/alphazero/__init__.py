@@ -12,6 +12,7 @@ Put the directory that contains this package on sys.path:
 """
 import ctypes as C
 import enum
+import os
 
 import numpy as np
 
@@ -572,6 +573,47 @@ def dumb_eval(gs):
     ssum = np.float32(int(valids.sum()) & 0xFF)
     pi = np.zeros(valids.size, np.float32) if ssum == 0 else (valids.astype(np.float32) / ssum)
     return v, pi
+
+
+def playout_eval_batch(states, seeds=None):
+    """playout_eval_batch(list of GameState) -> (values, policies), py_wrapper.cc:748-770 / game_state.cc:62-95: uniform policy
+    over the legal moves and the scores of one uniformly random rollout per state, all states in one kernel launch.  The
+    reference seeds its rollout engines from std::random_device; `seeds` (one 64-bit seed per state) makes a run repeatable."""
+    states = list(states)
+    if not states:
+        return [], []
+    cls = type(states[0])
+    if any(type(g) is not cls for g in states):
+        raise RuntimeError("playout_eval_batch: all states must be of the same game")
+    P, M, _ = cls._info()
+    n = len(states)
+    if seeds is None:
+        seeds = np.frombuffer(os.urandom(8 * n), dtype=np.uint64)
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+    if seeds.shape != (n,):
+        raise RuntimeError("playout_eval_batch: one seed per state")
+    length = max(len(g._moves) for g in states) + 1
+    mv = np.full((n, length), -1, np.int32)
+    for i, g in enumerate(states):
+        mv[i, : len(g._moves)] = g._moves
+    init = None
+    if any(g._init is not None for g in states):
+        blank = cls().to_bytes() if hasattr(cls, "to_bytes") else None
+        rows = [g._init if g._init is not None else blank for g in states]
+        if any(r is None for r in rows):
+            raise RuntimeError("playout_eval_batch: this game has no serialized start position")
+        init = np.frombuffer(b"".join(rows), np.uint8)
+    v = np.zeros((n, P + 1), np.float32); pi = np.zeros((n, M), np.float32)
+    check(lib.azmi_playout_eval(cls.GAME_ID, states[0]._device, None if init is None else init.ctypes.data,
+                                0 if init is None else init.size // n, mv.ctypes.data, n, length, seeds.ctypes.data,
+                                v.ctypes.data, pi.ctypes.data))
+    return [v[i].copy() for i in range(n)], [pi[i].copy() for i in range(n)]
+
+
+def playout_eval(gs, seed=None):
+    """playout_eval(gs) -> (value, pi), py_wrapper.cc:726-746"""
+    v, pi = playout_eval_batch([gs], None if seed is None else [seed])
+    return v[0], pi[0]
 
 
 class _TaflBoardGS(GameState):

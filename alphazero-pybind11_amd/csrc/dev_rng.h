@@ -48,6 +48,7 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
   return x ^ (x >> 31);
 }
 constexpr uint64_t kCoinSalt = 0x5851F42D4C957F2DULL;
+constexpr uint64_t kRollSalt = 0x9E3779B97F4A7C15ULL;   // rollout stream of EvalType::PLAYOUT
 __host__ __device__ __forceinline__ uint64_t slot_seed(uint64_t seed, uint32_t slot) {
   return mix64(seed + 0x9E3779B97F4A7C15ULL * (static_cast<uint64_t>(slot) + 1));
 }

@@ -88,7 +88,8 @@ struct azmi_pm {
   uint32_t cache_shards = 0;
   std::vector<CacheView> group_caches;   // host copies of the per-model-group cache views
   std::vector<uint8_t> group_cache_counted;  // 0: stand-in for a `None` entry of an external cache list (not in the statistics)
-  bool all_random = false;               // every model group uses EvalType::RANDOM
+  bool all_random = false;               // no seat needs a net (EvalType::RANDOM / PLAYOUT everywhere)
+  bool any_playout = false;              // some seat uses EvalType::PLAYOUT
   std::vector<std::deque<uint32_t>> pending_g;   // host-buffer path: pending leaves per model group
   // hipGraph of kGraphRounds x (round kernels + net) for azmi_run_rounds: one graph launch instead of
   // ~5 kernel launches per round keeps the host ahead of the GPU
@@ -130,6 +131,8 @@ __global__ void k_seed(EngineArrays ar, uint32_t S, uint64_t seed) {
   ar.rng[s] = g.state;
   g.seed(sd ^ kCoinSalt);
   ar.coin[s] = g.state;
+  g.seed(sd ^ kRollSalt);
+  ar.roll[s] = g.state;
 }
 
 // start of a round: cache insert of last round's leaves + the restart/retire bookkeeping in one launch
@@ -153,7 +156,8 @@ int launch_round(azmi_pm* pm, hipStream_t st) {
       launch_pre_round<Connect4>(pm, st);
       const uint32_t slots_per_block = threads / Connect4::GROUP;
       const uint32_t blocks = (pm->ep.S + slots_per_block - 1) / slots_per_block;
-      k_round<Connect4><<<blocks, threads, 0, st>>>(pm->ep, pm->ar);
+      if (pm->any_playout) k_round<Connect4, true><<<blocks, threads, 0, st>>>(pm->ep, pm->ar);
+      else k_round<Connect4><<<blocks, threads, 0, st>>>(pm->ep, pm->ar);
       break;
     }
     case AZMI_GAME_TAWLBWRDD:
@@ -221,6 +225,40 @@ __global__ void k_replay(const uint8_t* init, const int32_t* moves, uint32_t n, 
   if (player) player[g] = s.player;
   if (turn) turn[g] = s.turn;
   if (key) key[g] = GM::key(s);
+}
+
+// playout_eval / playout_eval_batch (game_state.cc:10-95) for a batch of states given as start position + move list: one
+// thread per state, its rollout stream seeded with seeds[g]
+template <class GM>
+__global__ void k_playout(const uint8_t* init, const int32_t* moves, uint32_t n, uint32_t len, const uint64_t* seeds, float* v, float* pi,
+                          int32_t* status) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  typename GM::State s = GM::initial();
+  if (init) s = GM::from_bytes(init + static_cast<size_t>(g) * GM::SERIALIZED);
+  int32_t stt = 0;
+  for (uint32_t i = 0; i < len; ++i) {
+    const int32_t mv = moves[static_cast<size_t>(g) * len + i];
+    if (mv < 0) break;
+    if (mv >= GM::M || !((GM::valid_mask(s) >> mv) & 1u) || !GM::play(s, static_cast<uint32_t>(mv))) { stt = -1; break; }
+  }
+  status[g] = stt;
+  if (stt) return;
+  const uint32_t kl = GM::num_valid(s);
+  const float ksum = static_cast<float>(kl & 0xFFu);
+  for (int m = 0; m < GM::M; ++m)
+    pi[static_cast<size_t>(g) * GM::M + m] = (((GM::valid_mask(s) >> m) & 1u) && ksum > 0.0f) ? 1.0f / ksum : 0.0f;
+  Pcg32 roll;
+  roll.seed(seeds[g]);
+  uint32_t term = GM::terminal(s);
+  while (term == 0) {
+    const uint32_t k = GM::num_valid(s);
+    if (k == 0) break;
+    GM::play(s, GM::nth_valid(s, lemire_below(roll, k)));
+    term = GM::terminal(s);
+  }
+  for (int i = 0; i <= GM::P; ++i)
+    v[static_cast<size_t>(g) * (GM::P + 1) + i] = term ? ((static_cast<int>(term) - 1 == i) ? 1.0f : 0.0f) : static_cast<float>(1.0 / (GM::P + 1));
 }
 
 // Tafl-family replay: one thread per game, repetition list in a global scratch row per game
@@ -389,7 +427,7 @@ namespace {
 struct SeatTables {
   uint32_t num_groups = 1, num_perms = 1, max_visits = 0;
   bool all_random = true, any_random = false;
-  bool any_gumbel = false, any_seat_resign = false;
+  bool any_gumbel = false, any_seat_resign = false, any_playout = false;
   std::vector<uint32_t> words;   // [perm][seat][kSeatWords]
 };
 int build_seat_tables(const azmi_play_params* p, uint32_t P, SeatTables* out) {
@@ -430,10 +468,11 @@ int build_seat_tables(const azmi_play_params* p, uint32_t P, SeatTables* out) {
       const float eps = p->has_seat_epsilon ? p->seat_epsilon[q][s] : p->epsilon;
       const float rt = p->has_seat_mcts_root_temp ? p->seat_mcts_root_temp[q][s] : p->mcts_root_temp;
       const uint32_t fz = p->has_seat_root_fpu_zero ? (p->seat_root_fpu_zero[q][s] != 0) : (p->root_fpu_zero != 0);
-      const bool rnd = eval_g[g] == AZMI_EVAL_RANDOM;
-      if (eval_g[g] == AZMI_EVAL_PLAYOUT) return fail(AZMI_ERR_INVALID, "EvalType::PLAYOUT is not implemented on the device");
+      const bool playout = eval_g[g] == AZMI_EVAL_PLAYOUT;
+      const bool rnd = eval_g[g] == AZMI_EVAL_RANDOM;   // all_random below: "no seat needs a net" (RANDOM or PLAYOUT)
+      out->any_playout = out->any_playout || playout;
       if (capv > 0xFFFFFFu) return fail(AZMI_ERR_INVALID, "seat_cap_visits too large");
-      out->all_random = out->all_random && rnd; out->any_random = out->any_random || rnd;
+      out->all_random = out->all_random && (rnd || playout); out->any_random = out->any_random || rnd || playout;
       out->max_visits = std::max(out->max_visits, visits);
       if (p->playout_cap_randomization) out->max_visits = std::max(out->max_visits, capv);
       // per-seat Gumbel / resign overrides, play_manager.cc:116-176
@@ -451,7 +490,7 @@ int build_seat_tables(const azmi_play_params* p, uint32_t P, SeatTables* out) {
       out->any_gumbel = out->any_gumbel || gum;
       out->any_seat_resign = out->any_seat_resign || rth > -2.0f;
       uint32_t* w = &out->words[(static_cast<size_t>(q) * P + s) * kSeatWords];
-      w[0] = visits; w[1] = seat_w1_pack(capv, fz, rnd ? 1u : 0u, g);
+      w[0] = visits; w[1] = seat_w1_pack(capv, fz, rnd ? 1u : 0u, g, playout ? 1u : 0u);
       std::memcpy(&w[2], &eps, 4); std::memcpy(&w[3], &rt, 4);
       w[4] = seat_gum_pack(gum, gfull, g3, gm, rneed);
       std::memcpy(&w[5], &gcv, 4); std::memcpy(&w[6], &gcs, 4); std::memcpy(&w[7], &rth, 4);
@@ -489,6 +528,8 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
   SeatTables seats;
   { const int rc_seats = build_seat_tables(params, gi.P, &seats); if (rc_seats != AZMI_OK) return rc_seats; }
   if (params->resign_percent > 0 && gi.P != 2) return fail(AZMI_ERR_INVALID, "Resigning only works in 2 player games");
+  if (seats.any_playout && game != AZMI_GAME_CONNECT4)
+    return fail(AZMI_ERR_INVALID, "EvalType::PLAYOUT is implemented on the device for Connect4 only");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(AZMI_ERR_NO_DEVICE, "no HIP device: libazmi has no CPU path");
@@ -505,6 +546,7 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
   ep.cap_visits = params->playout_cap_depth;
   ep.num_perms = seats.num_perms; ep.num_groups = seats.num_groups;
   pm->all_random = seats.all_random;
+  pm->any_playout = seats.any_playout;
   ep.cpuct = params->cpuct; ep.start_temp = params->start_temp; ep.final_temp = params->final_temp;
   ep.half_life = params->temp_decay_half_life;
   ep.epsilon = params->epsilon; ep.root_temp = params->mcts_root_temp; ep.fpu_reduction = params->fpu_reduction;
@@ -644,6 +686,7 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
     A(gum_surv, static_cast<size_t>(S) * P * kGumMaxM, true);
   }
   A(resign_streak, static_cast<size_t>(S) * P, true);
+  A(roll, S, true);
 #undef A
   if (rc != AZMI_OK) { delete pm; return rc; }
   if (hipDeviceSynchronize() != hipSuccess) { delete pm; return fail(AZMI_ERR_NO_DEVICE, "device sync failed"); }
@@ -1106,6 +1149,46 @@ int azmi_game_replay_from(int game, int device, const uint8_t* init, uint32_t in
                           uint32_t n, uint32_t len, uint8_t* valid, float* scores, float* canonical,
                           uint32_t* player, uint32_t* turn, uint64_t* key, int32_t* status) {
   return azmi_game_replay_ex(game, device, init, init_stride, moves, n, len, valid, scores, canonical, player, turn, key, status, 0u);
+}
+
+int azmi_playout_eval(int game, int device, const uint8_t* init, uint32_t init_stride, const int32_t* moves, uint32_t n, uint32_t len,
+                      const uint64_t* seeds, float* v, float* pi) {
+  GameInfo gi;
+  if (!game_info(game, &gi)) return fail(AZMI_ERR_INVALID, "unknown game id %d", game);
+  if (game != AZMI_GAME_CONNECT4) return fail(AZMI_ERR_INVALID, "playout_eval is implemented on the device for Connect4 only");
+  if (!seeds || !v || !pi || (!moves && n * len)) return fail(AZMI_ERR_INVALID, "null argument");
+  if (init && init_stride != Connect4::SERIALIZED) return fail(AZMI_ERR_INVALID, "start positions: %u bytes per state", Connect4::SERIALIZED);
+  if (n == 0) return AZMI_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(AZMI_ERR_NO_DEVICE, "no HIP device: libazmi has no CPU path");
+  HIP_TRY(hipSetDevice(device));
+  std::vector<void*> tmp;
+  auto dalloc = [&](auto*& p, size_t count) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(count * sizeof(*p), 4));
+    if (e == hipSuccess) { tmp.push_back(q); p = static_cast<std::remove_reference_t<decltype(p)>>(q); }
+    return e;
+  };
+  auto cleanup = [&]() { for (void* q : tmp) (void)hipFree(q); };
+#define TRY3(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(AZMI_ERR_NO_DEVICE, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
+  int32_t* d_moves = nullptr; uint8_t* d_init = nullptr; uint64_t* d_seeds = nullptr; float *d_v = nullptr, *d_pi = nullptr; int32_t* d_status = nullptr;
+  const uint32_t V = gi.P + 1;
+  TRY3(dalloc(d_moves, static_cast<size_t>(n) * len));
+  if (len) TRY3(hipMemcpy(d_moves, moves, static_cast<size_t>(n) * len * 4, hipMemcpyHostToDevice));
+  if (init) { TRY3(dalloc(d_init, static_cast<size_t>(n) * init_stride)); TRY3(hipMemcpy(d_init, init, static_cast<size_t>(n) * init_stride, hipMemcpyHostToDevice)); }
+  TRY3(dalloc(d_seeds, n)); TRY3(hipMemcpy(d_seeds, seeds, static_cast<size_t>(n) * 8, hipMemcpyHostToDevice));
+  TRY3(dalloc(d_v, static_cast<size_t>(n) * V)); TRY3(dalloc(d_pi, static_cast<size_t>(n) * gi.M)); TRY3(dalloc(d_status, n));
+  k_playout<Connect4><<<(n + 63) / 64, 64>>>(d_init, d_moves, n, len, d_seeds, d_v, d_pi, d_status);
+  TRY3(hipGetLastError());
+  TRY3(hipDeviceSynchronize());
+  std::vector<int32_t> st(n);
+  TRY3(hipMemcpy(st.data(), d_status, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost));
+  TRY3(hipMemcpy(v, d_v, static_cast<size_t>(n) * V * 4, hipMemcpyDeviceToHost));
+  TRY3(hipMemcpy(pi, d_pi, static_cast<size_t>(n) * gi.M * 4, hipMemcpyDeviceToHost));
+#undef TRY3
+  cleanup();
+  for (uint32_t i = 0; i < n; ++i) if (st[i]) return fail(AZMI_ERR_INVALID, "illegal move in the game record of state %u", i);
+  return AZMI_OK;
 }
 
 int azmi_game_replay_ex(int game, int device, const uint8_t* init, uint32_t init_stride, const int32_t* moves,

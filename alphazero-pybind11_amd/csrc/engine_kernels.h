@@ -103,6 +103,7 @@ struct SlotCtx {
   __device__ __forceinline__ bool seat_fpu_zero(uint32_t seat) const { return (AZMI_SEL(sv_w1, seat) >> 24) & 1u; }
   __device__ __forceinline__ bool seat_eval_random(uint32_t seat) const { return (AZMI_SEL(sv_w1, seat) >> 25) & 1u; }
   __device__ __forceinline__ uint32_t seat_group(uint32_t seat) const { return (AZMI_SEL(sv_w1, seat) >> 26) & 3u; }
+  __device__ __forceinline__ bool seat_eval_playout(uint32_t seat) const { return (AZMI_SEL(sv_w1, seat) >> 28) & 1u; }
   __device__ __forceinline__ float seat_eps(uint32_t seat) const { return AZMI_SEL(sv_eps, seat); }
   __device__ __forceinline__ float seat_root_temp(uint32_t seat) const { return AZMI_SEL(sv_rt, seat); }
   // per-seat Gumbel / resign settings (words 4-7 of the seat record): read on demand, they are off the PUCT path
@@ -643,6 +644,32 @@ struct SlotCtx {
     sync_lanes();
   }
 
+  // ---- playout_eval, game_state.cc:10-54: uniform policy over the leaf's legal moves + the scores of a uniformly random
+  // rollout, written to the slot's (v, pi) rows like a net answer.  One draw of the slot's rollout stream per move picks
+  // the lemire_below(#legal)-th legal move in ascending order; every lane of the group plays the same rollout.
+  __device__ __forceinline__ void playout_eval(const typename GM::State& leaf) {
+    Pcg32 roll;
+    roll.state = ar.roll[slot];
+    typename GM::State sim = leaf;
+    uint32_t term = GM::terminal(sim);
+    while (term == 0) {
+      const uint32_t k = GM::num_valid(sim);
+      if (k == 0) break;
+      GM::play(sim, GM::nth_valid(sim, lemire_below(roll, k)));
+      term = GM::terminal(sim);
+    }
+    const uint32_t kl = GM::num_valid(leaf);
+    const float ksum = static_cast<float>(kl & 0xFFu);   // Vector<uint8_t>::sum() wraps mod 256
+    if (lane < static_cast<uint32_t>(M)) {
+      const bool legal = (GM::valid_mask(leaf) >> lane) & 1u;
+      ar.pi[static_cast<size_t>(slot) * M + lane] = (legal && ksum > 0.0f) ? 1.0f / ksum : 0.0f;
+    }
+    if (lane <= static_cast<uint32_t>(P))
+      ar.v[static_cast<size_t>(slot) * (P + 1) + lane] = term ? ((term - 1 == lane) ? 1.0f : 0.0f) : static_cast<float>(1.0 / (P + 1));
+    sync_lanes();
+    if (lane == 0) ar.roll[slot] = roll.state;
+  }
+
   // ---- lane-dense [M] vector helpers (lane m holds entry m) ------------------------------------
   template <class T>
   __device__ __forceinline__ T scatter_by_move(uint32_t k, uint32_t mv_l, T x_l) const {
@@ -1035,7 +1062,8 @@ struct SlotCtx {
 };
 
 // One round of PlayManager::play for every slot (play_manager.cc:272-599).
-template <class GM>
+// kPlayout: the instantiation for engines with an EvalType::PLAYOUT seat carries the rollout code; the common one does not
+template <class GM, bool kPlayout = false>
 __global__ __launch_bounds__(256, 1) void k_round(EngineParams ep, EngineArrays ar) {
   constexpr int G = GM::GROUP;
   constexpr int P = GM::P;
@@ -1073,9 +1101,12 @@ __global__ __launch_bounds__(256, 1) void k_round(EngineParams ep, EngineArrays 
     typename GM::State leaf;
     uint32_t term = 0;
     if (!c.find_leaf(cp, leaf, term)) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; c.store(kSlotDone); return; }
-    const bool needs_net = term == 0 && !c.seat_eval_random(cp);
+    const bool playout = kPlayout && term == 0 && c.seat_eval_playout(cp);   // (a terminal leaf's evaluation is never used)
+    const bool needs_net = term == 0 && !c.seat_eval_random(cp) && !playout;
     const uint32_t group = c.seat_group(cp);
-    c.flags = needs_net ? (c.flags | kFlagLeafNeedsNet) : (c.flags & ~kFlagLeafNeedsNet);
+    // kFlagLeafNeedsNet = "process_result reads the slot's (v, pi) rows": a net answer or the rollout's
+    c.flags = (needs_net || playout) ? (c.flags | kFlagLeafNeedsNet) : (c.flags & ~kFlagLeafNeedsNet);
+    if constexpr (kPlayout) { if (playout) c.playout_eval(leaf); }
     if (needs_net) {
       const uint64_t key = c.emit_leaf(leaf);
       const bool hit = ep.cache_on && c.cache_lookup(key, group);

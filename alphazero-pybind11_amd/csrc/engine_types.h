@@ -70,8 +70,9 @@ constexpr uint32_t kSeatWords = 8;
 __host__ __device__ inline uint32_t seat_gum_pack(uint32_t enabled, uint32_t full, uint32_t g3, uint32_t m, uint32_t resign_need) {
   return (enabled & 1u) | ((full & 1u) << 1) | ((g3 & 1u) << 2) | ((m & 0xFFFFu) << 8) | ((resign_need & 0xFFu) << 24);
 }
-__host__ __device__ inline uint32_t seat_w1_pack(uint32_t cap_visits, uint32_t fpu_zero, uint32_t eval_random, uint32_t group) {
-  return (cap_visits & 0xFFFFFFu) | (fpu_zero << 24) | (eval_random << 25) | (group << 26);
+__host__ __device__ inline uint32_t seat_w1_pack(uint32_t cap_visits, uint32_t fpu_zero, uint32_t eval_random, uint32_t group,
+                                                 uint32_t eval_playout = 0) {
+  return (cap_visits & 0xFFFFFFu) | (fpu_zero << 24) | (eval_random << 25) | (group << 26) | (eval_playout << 28);
 }
 
 struct Control {  // small device control block, copied back by azmi_pm_poll
@@ -159,6 +160,7 @@ struct EngineArrays {
   uint8_t* leaf_group;    // [S] model group of the pending leaf
   float* a_perm_scores;   // [S][perms][P+1] committed scores per permutation
   uint32_t* a_perm_games; // [S][perms]
+  uint64_t* roll;           // [S] rollout stream of EvalType::PLAYOUT seats (game_state.cc:56-59)
   uint32_t* resign_streak;  // [S][P] GameData::resign_streak (kept from one game of the slot to the next, like the reference)
   const CacheView* caches;  // [groups] one S3-FIFO per model group (play_manager.cc:195-203); `cache` = caches[0]
 };

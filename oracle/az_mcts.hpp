@@ -724,4 +724,30 @@ inline void dumb_eval(const Game& gs, float* value, float* pi) {
   for (uint32_t m = 0; m < M; ++m) pi[m] = static_cast<float>(valids[m]) / sum;
 }
 
+// playout_eval, game_state.cc:10-54: policy = uniform over the leaf's legal moves (the same u8-wrapping sum as dumb_eval),
+// value = the scores of a uniformly random rollout.  The reference draws from an UNSEEDABLE thread-local
+// std::default_random_engine; here the rollout stream is a pcg32 the caller owns and one draw per rollout move picks
+// the lemire_below(stream, #legal)-th legal move in ascending move order — build-defined, the same on the device.
+inline void playout_eval(const Game& gs, Pcg32& roll, float* value, float* pi) {
+  dumb_eval(gs, value, pi);          // the policy half; `value` is overwritten below
+  const uint32_t M = gs.num_moves();
+  const int P = gs.num_players();
+  auto sim = gs.copy();
+  std::vector<uint8_t> valids(M);
+  float sc[kMaxValue];
+  while (!sim->scores(sc)) {
+    sim->valid_moves(valids.data());
+    std::vector<uint32_t> idx;
+    for (uint32_t m = 0; m < M; ++m) if (valids[m]) idx.push_back(m);
+    if (idx.empty()) break;
+    sim->play_move(idx[lemire_below(roll, static_cast<uint32_t>(idx.size()))]);
+  }
+  if (sim->scores(sc)) {
+    // relative_values games rotate the scores to the leaf player's view (absolute_to_relative); no such game is restated
+    for (int i = 0; i <= P; ++i) value[i] = sc[i];
+    return;
+  }
+  for (int i = 0; i <= P; ++i) value[i] = static_cast<float>(1.0 / (P + 1));
+}
+
 }  // namespace orc

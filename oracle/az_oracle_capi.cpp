@@ -166,6 +166,11 @@ void orc_mcts_process_result(void* h, float* value, const float* pi, int noise) 
 }
 // dumb_eval(gs), game_state.h:160-173
 void orc_dumb_eval(void* game, float* v, float* pi) { dumb_eval(*static_cast<Game*>(game), v, pi); }
+// playout_eval(gs) with an explicit rollout stream seed (game_state.cc:10-59)
+void orc_playout_eval(void* game, uint64_t seed, float* v, float* pi) {
+  Pcg32 roll; roll.seed(seed);
+  playout_eval(*static_cast<Game*>(game), roll, v, pi);
+}
 // WU-UCT batched API (mcts.cc:752-851)
 void orc_mcts_find_leaf_batched(void* h, void* game) {
   auto* b = static_cast<MctsBox*>(h);

@@ -31,6 +31,7 @@ namespace orc {
 enum class EvalType : uint8_t { NN = 0, RANDOM = 1, PLAYOUT = 2 };  // play_manager.h:20
 
 constexpr uint64_t kCoinSalt = 0x5851F42D4C957F2DULL;
+constexpr uint64_t kRollSalt = 0x9E3779B97F4A7C15ULL;   // rollout stream of EvalType::PLAYOUT (game_state.cc:56-59 is unseedable)
 inline uint64_t slot_seed(uint64_t seed, uint32_t slot) {
   return mix64(seed + 0x9E3779B97F4A7C15ULL * (static_cast<uint64_t>(slot) + 1));
 }
@@ -107,10 +108,12 @@ class PlayManager {
     const uint32_t nstreams = per_slot_rng_ ? params_.concurrent_games : 1;
     tree_rng_.resize(nstreams);
     coin_rng_.resize(nstreams);
+    roll_rng_.resize(nstreams);
     for (uint32_t s = 0; s < nstreams; ++s) {
       const uint64_t sd = per_slot_rng_ ? slot_seed(seed, s) : seed;
       tree_rng_[s].seed(sd);
       coin_rng_[s].seed(sd ^ kCoinSalt);
+      roll_rng_[s].seed(sd ^ kRollSalt);
     }
     if (params_.max_cache_size > 0) {  // play_manager.cc:195-203: one cache per model group
       const uint32_t per_group = params_.max_cache_size / num_model_groups_;
@@ -505,8 +508,8 @@ class PlayManager {
     const uint32_t group = seat_perms_[game.perm_index][cp];   // play_manager.cc:577
     const EvalType et = eval_type_for_group(group);
     if (et != EvalType::NN) {
-      if (et == EvalType::PLAYOUT) throw std::runtime_error("PLAYOUT eval is not restated");
-      dumb_eval(*leaf, game.v.data(), game.pi.data());
+      if (et == EvalType::PLAYOUT) playout_eval(*leaf, roll_rng_[per_slot_rng_ ? i : 0], game.v.data(), game.pi.data());
+      else dumb_eval(*leaf, game.v.data(), game.pi.data());
       awaiting_mcts_.push_back(i);
       return;
     }
@@ -547,7 +550,7 @@ class PlayManager {
   std::unique_ptr<Game> base_;
   PlayParams params_;
   bool per_slot_rng_;
-  std::vector<Pcg32> tree_rng_, coin_rng_;
+  std::vector<Pcg32> tree_rng_, coin_rng_, roll_rng_;
   std::vector<Slot> slots_;
   std::deque<uint32_t> awaiting_mcts_;
   std::vector<std::deque<uint32_t>> awaiting_inference_;   // one queue per model group

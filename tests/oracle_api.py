@@ -244,6 +244,13 @@ def dumb_eval(game):
     return v, pi
 
 
+def playout_eval(game, seed):
+    """playout_eval(gs) with the rollout stream seeded by `seed` -> (value [P+1], pi [M]), game_state.cc:10-59"""
+    v = np.zeros(game.num_players() + 1, np.float32); pi = np.zeros(game.num_moves(), np.float32)
+    lib.orc_playout_eval(game.h, C.c_uint64(seed), _p(v), _p(pi))
+    return v, pi
+
+
 def node_uct(q, policy, n, sqrt_parent_n, cpuct, fpu):
     return lib.orc_node_uct(q, policy, n, sqrt_parent_n, cpuct, fpu)
 

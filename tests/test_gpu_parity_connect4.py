@@ -336,3 +336,68 @@ def test_hash_game_state_equality_semantics():
     c = az.Connect4GS(); c.play_move(3)
     assert az.hash_game_state(a) == az.hash_game_state(b) == az.hash_game_state(a.copy())
     assert az.hash_game_state(a) != az.hash_game_state(c)
+
+
+# ---- EvalType::PLAYOUT and playout_eval (game_state.cc:10-95, play_manager.cc:580-582) ------------------------------
+def test_playout_eval_matches_oracle_and_reference_statistics(oracle):
+    import alphazero as az
+    states, ogames = [], []
+    rng = np.random.default_rng(3)
+    for i in range(64):
+        g = az.Connect4GS(); og = oracle.Game(oracle.GAME_CONNECT4)
+        for _ in range(int(rng.integers(0, 12))):
+            legal = np.flatnonzero(g.valid_moves())
+            if g.scores() is not None or len(legal) == 0:
+                break
+            m = int(rng.choice(legal)); g.play_move(m); og.play(m)
+        if g.scores() is not None:
+            continue
+        states.append(g); ogames.append(og)
+    seeds = np.arange(1000, 1000 + len(states), dtype=np.uint64)
+    vs, pis = az.playout_eval_batch(states, seeds)
+    for g, og, sd, v, pi in zip(states, ogames, seeds, vs, pis):
+        ov, opi = oracle.playout_eval(og, int(sd))
+        assert np.array_equal(v, ov) and np.array_equal(pi, opi)
+        assert v.sum() == 1.0 and set(np.unique(v)) <= {0.0, 1.0}                 # a terminal score vector
+        valid = np.asarray(g.valid_moves(), dtype=np.float32)
+        assert np.array_equal(pi, valid / valid.sum())                             # uniform over the legal moves
+    v1, pi1 = az.playout_eval(states[0], seed=5)
+    assert np.array_equal(v1, az.playout_eval(states[0], seed=5)[0])
+    # random Connect4 playouts from the empty board: first player ~55.6 %, second ~44.2 %, draws ~0.25 %
+    n = 4000
+    vs, _ = az.playout_eval_batch([az.Connect4GS()] * n, np.arange(n, dtype=np.uint64))
+    mean = np.mean(vs, 0)
+    assert abs(mean[0] - 0.556) < 0.03 and abs(mean[1] - 0.442) < 0.03 and mean[2] < 0.01
+    with pytest.raises(RuntimeError, match="Connect4 only"):
+        az.playout_eval(az.TawlbwrddGS())
+
+
+def test_playout_seats_match_oracle(oracle):
+    """EvalType.PLAYOUT seats (alone and against a RANDOM seat): same moves / counts / scores as the oracle, whose rollout
+    stream is the slot's third pcg32 stream."""
+    import alphazero as az
+    for evals in ([az.EvalType.PLAYOUT, az.EvalType.PLAYOUT], [az.EvalType.PLAYOUT, az.EvalType.RANDOM]):
+        pp = az.PlayParams()
+        pp.games_to_play, pp.concurrent_games, pp.max_batch_size = 6, 6, 6
+        pp.mcts_visits = [40, 30]
+        pp.eval_type = evals
+        pp.cpuct, pp.fpu_reduction, pp.history_enabled = 1.25, 0.25, True
+        seed = 91
+        pm = az.PlayManager(az.Connect4GS(), pp, seed=seed, log_moves=True)
+        pm.play()
+        rows, counts = pm.move_log()
+        total = np.zeros(3, np.float32)
+        for s in range(6):
+            one = az.PlayParams(); one.__dict__.update(pp.__dict__)
+            one.games_to_play, one.concurrent_games = 1, 1
+            o = oracle.PlayManager(oracle.GAME_CONNECT4, one, oracle.slot_seed(seed, s), per_slot_rng=False)
+            o.run()
+            orows, ocounts = o.moves()
+            sel = rows[:, 0] == s
+            assert np.array_equal(rows[sel][:, 1:], orows[:, 1:]), s
+            assert np.array_equal(counts[sel], ocounts), s
+            total += o.scores()
+        assert np.array_equal(pm.scores(), total)
+    pp.eval_type = [az.EvalType.PLAYOUT, az.EvalType.PLAYOUT]
+    with pytest.raises(RuntimeError, match="Connect4 only"):
+        az.PlayManager(az.TawlbwrddGS(), pp)
