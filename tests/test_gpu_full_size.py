@@ -1,0 +1,162 @@
+"""-m gpu: BASELINE.json configs[1] at FULL size (Connect4, 4096 concurrent games, 800 MCTS simulations per move) through
+size-independent properties — the oracle cannot replay 80 M simulations, so it replays a sample of slots (a slot's game
+does not depend on how many other slots run beside it) and the rest is checked through invariants:
+every game finishes, scores add up, every search has its full budget, history rows are distributions, the run is a
+function of the seed alone (independent of how many simulations a round may finish inline), and with the HIP leaf net the
+position cache changes which leaves reach the net but not one move of one game."""
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+S, SIMS = 4096, 800
+
+
+def _params(az, evals=None, cache=0):
+    pp = az.PlayParams()
+    pp.games_to_play, pp.concurrent_games, pp.max_batch_size = S, S, S
+    pp.mcts_visits = [SIMS, SIMS]
+    pp.model_groups = [0, 0]
+    pp.cpuct, pp.fpu_reduction = 1.25, 0.25          # config.py:79-80
+    pp.history_enabled = True
+    pp.max_cache_size = cache
+    if evals is not None:
+        pp.eval_type = evals
+    return pp
+
+
+def _digest(rows, counts):
+    """order-free checksum of a move log: rows sorted by (slot, game, turn); columns slot, game, move, turn, player + counts"""
+    order = np.lexsort((rows[:, 3], rows[:, 1], rows[:, 0]))
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(rows[order][:, :5]).tobytes())
+    h.update(np.ascontiguousarray(counts[order]).tobytes())
+    return h.hexdigest()
+
+
+@pytest.fixture(scope="module")
+def random_run():
+    import alphazero as az
+    pm = az.PlayManager(az.Connect4GS(), _params(az, [az.EvalType.RANDOM, az.EvalType.RANDOM]), seed=20240601, log_moves=True)
+    pm.play()
+    return pm, pm.move_log()
+
+
+def test_full_size_every_game_finishes_with_full_searches(random_run):
+    pm, (rows, counts) = random_run
+    assert pm.games_completed() == S and pm.remaining_games() == 0
+    sc = pm.scores()
+    assert sc.sum() == S and (sc >= 0).all()
+    assert np.array_equal(np.unique(rows[:, 0]), np.arange(S))           # every slot played
+    # every move was chosen after a full search: the root has >= 800 visits, one of them its own evaluation
+    assert (counts.sum(1) >= SIMS - 1).all()
+    first = rows[:, 3] == 0
+    assert first.sum() == S and (counts[first].sum(1) == SIMS - 1).all()   # no reused subtree at the first move
+    # the log is a set of complete games: turns 0..len-1 per slot, players alternate, every move was legal when played
+    order = np.lexsort((rows[:, 3], rows[:, 0]))
+    r = rows[order]
+    start = np.r_[True, r[1:, 0] != r[:-1, 0]]
+    assert (r[start, 3] == 0).all() and (np.diff(r[:, 3])[~start[1:]] == 1).all()
+    assert (r[:, 4] == r[:, 3] % 2).all()
+    assert (counts[order][np.arange(len(r)), r[:, 2]] > 0).all()           # the played move had visits
+    lens = np.bincount(r[:, 0], minlength=S)
+    assert lens.min() >= 7 and lens.max() <= 42 and abs(pm.avg_game_length() - lens.mean()) < 1e-3
+    c = pm.counters()
+    assert c["sims"] >= int(lens.sum()) * (SIMS - 42) and c["evals"] == 0
+
+
+def test_full_size_history_rows_are_distributions(random_run):
+    pm, (rows, _) = random_run
+    n = pm.hist_count()
+    assert n == len(rows)                                  # one sample per move (no playout cap)
+    canon = np.zeros((n, 4, 6, 7), np.float32); v = np.zeros((n, 3), np.float32); pi = np.zeros((n, 7), np.float32)
+    assert pm.build_history_batch(canon, v, pi) == n
+    assert np.abs(pi.sum(1) - 1).max() < 1e-5 and (pi >= 0).all()
+    assert (v.sum(1) == 1).all() and np.isin(v, (0.0, 1.0)).all()          # game outcomes, one-hot (win/loss/draw)
+    stones = canon[:, :2].sum((1, 2, 3))
+    assert (canon[:, 2:].reshape(n, 2, -1).min(2).sum(1) == 1).all()       # exactly one player plane is all ones
+    to_move = canon[:, 3, 0, 0].astype(np.int64)
+    assert (stones.astype(np.int64) % 2 == to_move).all()                  # stones on the board = turn parity
+    assert (pi[np.arange(n)][canon[:, :2].sum(1)[:, 0, :] > 0] == 0).all()  # no target mass on a full column
+
+
+def test_full_size_sampled_slots_equal_the_oracle(random_run, oracle):
+    import alphazero as az
+    pm, (rows, counts) = random_run
+    for s in np.random.default_rng(5).choice(S, 6, replace=False):
+        one = _params(az, [az.EvalType.RANDOM, az.EvalType.RANDOM])
+        one.games_to_play, one.concurrent_games = 1, 1
+        o = oracle.PlayManager(oracle.GAME_CONNECT4, one, oracle.slot_seed(20240601, int(s)), per_slot_rng=False)
+        o.run()
+        orows, ocounts = o.moves()
+        sel = rows[:, 0] == s
+        assert np.array_equal(rows[sel][:, 1:], orows[:, 1:]), s           # moves, turns, players, pcg32 positions
+        assert np.array_equal(counts[sel], ocounts), s
+
+
+def test_full_size_run_is_a_function_of_the_seed(random_run):
+    """the same seed with another inline budget per round (a scheduling knob) gives the same 4096 games, move for move"""
+    import alphazero as az
+    pm, (rows, counts) = random_run
+    other = az.PlayManager(az.Connect4GS(), _params(az, [az.EvalType.RANDOM, az.EvalType.RANDOM]), seed=20240601, log_moves=True,
+                           max_inline=3)
+    other.play()
+    r2, c2 = other.move_log()
+    assert _digest(rows, counts) == _digest(r2, c2)
+    assert np.array_equal(pm.scores(), other.scores())
+
+
+def test_full_size_cache_is_transparent_with_the_hip_net():
+    """6b64c HIP net, 4096 games x 800 sims: the run with a 32 M-entry position cache plays exactly the games of the run
+    without one (so cached answers equal recomputed ones bit for bit: the net is batch-invariant at this size), while
+    sending far fewer leaves to the net."""
+    import torch
+    import alphazero as az
+    from alphazero import torch_net
+    net = torch_net.random_init(torch_net.connect4_spec(), seed=0)
+    hip = az.HipLeafNet(net, torch_net.connect4_spec())
+    st = torch.cuda.Stream()
+    out = []
+    for cache in (0, 32_000_000):
+        pm = az.PlayManager(az.Connect4GS(), _params(az, cache=cache), seed=77, log_moves=True)
+        while pm.poll(st.cuda_stream)[1] > 0:
+            az.run_rounds([pm], hip, 512, [st.cuda_stream])
+        assert pm.games_completed() == S
+        rows, counts = pm.move_log()
+        out.append((_digest(rows, counts), pm.counters(), pm.scores()))
+    (d0, c0, s0), (d1, c1, s1) = out
+    assert d0 == d1 and np.array_equal(s0, s1)
+    assert c0["sims"] == c1["sims"] and c0["cache_hits"] == 0
+    assert c1["cache_hits"] > 0.4 * c1["sims"] and c1["evals"] < 0.6 * c0["evals"]
+
+
+def test_full_size_tawlbwrdd_prefix_equals_the_oracle(oracle):
+    """BASELINE configs[2] at full size (Tawlbwrdd, 2048 concurrent games, 400 simulations): a bounded number of rounds, then
+    every sampled slot's moves so far equal the first moves of the oracle's game for that slot, and every logged search
+    had its full budget."""
+    import alphazero as az
+    pp = az.PlayParams()
+    pp.games_to_play, pp.concurrent_games, pp.max_batch_size = 2048, 2048, 2048
+    pp.mcts_visits = [400, 400]
+    pp.eval_type = [az.EvalType.RANDOM, az.EvalType.RANDOM]
+    pp.cpuct, pp.fpu_reduction = 1.25, 0.25
+    seed = 20240601
+    pm = az.PlayManager(az.TawlbwrddGS(), pp, seed=seed, log_moves=True, max_inline=8)
+    for _ in range(400):                     # 8 inline simulations per round: ~8 moves per slot
+        pm.round()
+    rows, counts = pm.move_log()
+    assert len(rows) >= 4 * 2048 and np.array_equal(np.unique(rows[:, 0]), np.arange(2048))
+    assert (counts.sum(1) >= 399).all()
+    for s in np.random.default_rng(9).choice(2048, 3, replace=False):
+        one = az.PlayParams(); one.__dict__.update(pp.__dict__)
+        one.games_to_play, one.concurrent_games = 1, 1
+        o = oracle.PlayManager(oracle.GAME_TAWLBWRDD, one, oracle.slot_seed(seed, int(s)), per_slot_rng=False)
+        o.run()
+        orows, ocounts = o.moves()
+        sel = rows[:, 0] == s
+        n = int(sel.sum())
+        assert n >= 4
+        assert np.array_equal(rows[sel][:, 1:], orows[:n, 1:]), s
+        assert np.array_equal(counts[sel], ocounts[:n]), s
