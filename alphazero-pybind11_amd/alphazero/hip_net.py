@@ -79,7 +79,7 @@ def _fold_trunk(net, sd, Cin):
     blob = bytearray()
     a, b = (t.cpu() for t in bn_affine(net.bn1))
     w = sd["conv1.weight"] * a[:, None, None, None]
-    wm = np.zeros((64, 64))
+    wm = np.zeros((64, 64 * ((9 * Cin + 63) // 64)))     # im2col rows in passes of 64 (spatial kernel: up to two)
     wm[:, : 9 * Cin] = w.permute(0, 2, 3, 1).reshape(64, 9 * Cin).numpy()
     blob += _frags(wm) + _f32(b)
     for i, blk in enumerate(net.conv_layers):
@@ -100,9 +100,10 @@ def fold_spatial(net):
     spec = net.spec
     Cin, H, W = spec.in_shape
     if not (spec.num_channels == 64 and spec.head_channels == 64 and spec.kernel_size == 3 and spec.head_pool
-            and spec.v_head_convs == 1 and spec.pi_head_convs == 1 and 9 * Cin <= 64 and (H, W) == (11, 11)):
-        raise RuntimeError("the bf16 MFMA spatial-head kernel covers the configs/tawlbwrdd.yaml net (11x11, 64 trunk / 64 head "
-                           "channels, one extra conv per head, 9*C_in <= 64); use precision='fp32' for other shapes")
+            and spec.v_head_convs == 1 and spec.pi_head_convs == 1 and 9 * Cin <= 128 and (H, W) == (11, 11)):
+        raise RuntimeError("the bf16 MFMA spatial-head kernel covers the configs/tawlbwrdd.yaml and configs/open_tafl.yaml nets "
+                           "(11x11, 64 trunk / 64 head channels, one extra conv per head, 9*C_in <= 128); use precision='fp32' "
+                           "for other shapes")
     pc = spec.policy_shape[0]
     Hd, L, P1 = spec.v_fc_hidden, spec.v_fc_layers, spec.num_players + 1
     sd = {k: v.detach().double().cpu() for k, v in net.state_dict().items()}

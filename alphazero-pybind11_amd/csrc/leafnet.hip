@@ -519,23 +519,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_leafnet_spatial(SpatialDesc nd,
     const uint32_t b = board0 + i / plane_sz;
     raw[i] = b < batch ? canon[static_cast<size_t>(b) * plane_sz + (i % plane_sz)] : 0.0f;
   }
-  for (int i = tid * 16; i < 2 * MT * WFRAG_BYTES; i += NTHREADS * 16)
+  // the im2col matrix has 9*C_in rows; the eight 8-row planes hold 64 of them, so a stem with more (8 input planes:
+  // OpenTafl) runs in passes of 64 rows that accumulate into the same tiles
+  const int npass = (9 * nd.C_in + 63) / 64;
+  for (int i = tid * 16; i < npass * 2 * MT * WFRAG_BYTES; i += NTHREADS * 16)
     *reinterpret_cast<u32x4*>(wbuf + i) = *reinterpret_cast<const u32x4*>(np.stem_w + i);
-  __syncthreads();
-  if (tid < G::NPIX) {
-    const int n = tid, b = n / G::PIX, p = n % G::PIX, h = p / W, w = p % W;
-    const float* rb = raw + b * plane_sz;
-    for (int tap = 0; tap < 9; ++tap) {
-      const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
-      const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
-      for (int ci = 0; ci < nd.C_in; ++ci) {
-        const int k = tap * nd.C_in + ci;
-        const float val = ok ? rb[ci * G::PIX + hh * W + ww] : 0.0f;
-        *reinterpret_cast<__bf16*>(act + (k >> 3) * G::PLANE + n * 16 + (k & 7) * 2) = static_cast<__bf16>(val);
-      }
-    }
-  }
-  __syncthreads();
 
   f32x4 s[G::NT_W][MT];
   {
@@ -546,16 +534,38 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_leafnet_spatial(SpatialDesc nd,
     for (int j = 0; j < G::NT_W; ++j)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) s[j][mt] = bias[mt];
+    for (int pass = 0; pass < npass; ++pass) {
+      __syncthreads();                     // pass 0: staging done; later passes: the previous pass has read its rows
+      if (pass > 0) {
+        for (int i = tid * 16; i < G::ACT_BYTES; i += NTHREADS * 16) *reinterpret_cast<u32x4*>(act + i) = u32x4{0, 0, 0, 0};
+        __syncthreads();
+      }
+      if (tid < G::NPIX) {
+        const int n = tid, b = n / G::PIX, p = n % G::PIX, h = p / W, w = p % W;
+        const float* rb = raw + b * plane_sz;
+        for (int tap = 0; tap < 9; ++tap) {
+          const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
+          const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+          for (int ci = 0; ci < nd.C_in; ++ci) {
+            const int k = tap * nd.C_in + ci - 64 * pass;
+            if (k < 0 || k >= 64) continue;
+            const float val = ok ? rb[ci * G::PIX + hh * W + ww] : 0.0f;
+            *reinterpret_cast<__bf16*>(act + (k >> 3) * G::PLANE + n * 16 + (k & 7) * 2) = static_cast<__bf16>(val);
+          }
+        }
+      }
+      __syncthreads();
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 a[MT];
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 a[MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a[mt] = lds_read_frag(wbuf + (ks * MT + mt) * WFRAG_BYTES + lane * 16);
+        for (int mt = 0; mt < MT; ++mt) a[mt] = lds_read_frag(wbuf + ((pass * 2 + ks) * MT + mt) * WFRAG_BYTES + lane * 16);
 #pragma unroll
-      for (int j = 0; j < G::NT_W; ++j) {
-        const bf16x8 b = lds_read_frag(act + (ks * 4 + quad) * G::PLANE + pix_off[j]);
+        for (int j = 0; j < G::NT_W; ++j) {
+          const bf16x8 b = lds_read_frag(act + (ks * 4 + quad) * G::PLANE + pix_off[j]);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) s[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, s[j][mt], 0, 0, 0);
+          for (int mt = 0; mt < MT; ++mt) s[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, s[j][mt], 0, 0, 0);
+        }
       }
     }
   }
@@ -914,10 +924,11 @@ struct azmi_net {
 
 namespace {
 bool is_spatial(const azmi_net_desc* d) { return d->policy_channels > 0; }
+size_t stem_passes(const azmi_net_desc* d) { return (9 * static_cast<size_t>(d->in_channels) + 63) / 64; }
 size_t spatial_blob_bytes(const azmi_net_desc* d) {
   const size_t wconv = 18 * MT * WFRAG_BYTES, wsmall = 2 * MT * WFRAG_BYTES;
   const size_t Hd = d->v_hidden, L = d->v_fc_layers;
-  size_t n = wsmall + CH * 4;                                         // stem
+  size_t n = stem_passes(d) * wsmall + CH * 4;                        // stem: one 64-row k-chunk pair per pass
   n += static_cast<size_t>(d->depth) * (3 * CH * 4 + 2 * wconv);      // trunk
   n += 2 * 8 * WFRAG_BYTES + 128 * 4;                                 // head 1x1 convs
   n += 2 * (wconv + 64 * 4);                                          // extra head convs
@@ -962,8 +973,8 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
     if (d->channels != CH || d->head_channels != HCS || d->kernel_size != 3 || d->v_head_convs != 1 || d->pi_head_convs != 1)
       return nfail(AZMI_ERR_INVALID, "spatial leaf net kernel covers 64 trunk / 64 head channels, 3x3 convs, one extra conv per head");
     if (!(d->height == 11 && d->width == 11)) return nfail(AZMI_ERR_INVALID, "spatial leaf net kernel: board %dx%d not instantiated", d->height, d->width);
-    if (9 * d->in_channels > 64 || d->policy_channels > 32 || d->policy_channels * d->height * d->width != d->num_moves)
-      return nfail(AZMI_ERR_INVALID, "spatial head: 9*C_in <= 64, policy channels <= 32, no global actions");
+    if (9 * d->in_channels > 128 || d->policy_channels > 32 || d->policy_channels * d->height * d->width != d->num_moves)
+      return nfail(AZMI_ERR_INVALID, "spatial head: 9*C_in <= 128, policy channels <= 32, no global actions");
     if (d->v_hidden > 512 || d->v_hidden % 256 || d->v_fc_layers < 1 || d->num_players + 1 > 16) return nfail(AZMI_ERR_INVALID, "value head sizes out of range");
     if (blob_bytes != spatial_blob_bytes(d)) return nfail(AZMI_ERR_INVALID, "weight blob is %zu bytes, expected %zu", blob_bytes, spatial_blob_bytes(d));
     int ndev = 0;
@@ -980,7 +991,7 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
     const size_t Hd = d->v_hidden, L = d->v_fc_layers;
     SpatialPtrs& sp = net->sp;
     auto f32p = [&](size_t count) { const float* q = reinterpret_cast<const float*>(p); p += count * 4; return q; };
-    sp.stem_w = p; p += wsmall; sp.stem_b = f32p(CH);
+    sp.stem_w = p; p += stem_passes(d) * wsmall; sp.stem_b = f32p(CH);
     sp.blocks = p; p += static_cast<size_t>(d->depth) * (3 * CH * 4 + 2 * wconv);
     sp.head_w = p; p += 2 * 8 * WFRAG_BYTES; sp.head_b = f32p(128);
     sp.vx_w = p; p += wconv; sp.vx_b = f32p(64);
@@ -994,7 +1005,8 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
     static_assert(GS::NPIX <= NTHREADS, "stem im2col maps one thread to one pixel");
     static_assert(GS::NPIX * 32 * 4 <= GS::ACT_BYTES, "pooling scratch must fit the activation planes");
     static_assert(8192 + GS::NPIX * 32 * 4 <= GS::WCONV_BYTES, "policy logits must fit the weight area");
-    static_assert(16384 + TBS * 64 * GS::PIX * 4 / 7 <= GS::WCONV_BYTES, "input staging must fit");
+    static_assert(16384 + TBS * 128 * GS::PIX * 4 / 9 <= GS::WCONV_BYTES, "input staging (<= 14 planes) must fit behind two stem passes");
+    static_assert(2 * 2 * MT * WFRAG_BYTES <= 16384, "two stem passes of weights sit in front of the input staging");
     net->vfc_lds = (2 * Hd * 16 + VFC_WAVES * 256) * sizeof(float);
     // scratch for 16384 positions up front: forward() may run under stream capture, where hipMalloc is not allowed
     net->vpool_rows = 16384;

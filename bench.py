@@ -83,25 +83,40 @@ def selfplay_params(az, games, sims, stream_games, cache=0, playout_cap=False, g
     return pp
 
 
-def cpu_baseline(az, sims, seconds):
-    """The oracle (CPU restatement of the reference PlayManager, one thread) on a bounded sample of the
-    same search: Connect4, 800 sims/move, same self-play flags, EvalType.RANDOM (no net) -> an upper
-    bound for the reference's tree side on one host core."""
+def cpu_baseline(az, sims, seconds, threads=None):
+    """The oracle (CPU restatement of the reference PlayManager) on a bounded sample of the same search: Connect4,
+    800 sims/move, same self-play flags, EvalType.RANDOM (no net), on `threads` host threads — the reference's default
+    worker count is cores - 1 (config.py:439-441).  Each thread runs independent one-slot PlayManagers back to back
+    (the C call releases the GIL), which is an upper bound for the reference's tree side: no queue, no mutex, no net."""
+    import threading
     import oracle_api as orc
+    if threads is None:
+        threads = max(1, len(os.sched_getaffinity(0)) - 1)
     pp = selfplay_params(az, 1, sims, 1)
     pp.eval_type = [1, 1]
     pp.history_enabled = True
-    games, t0, n_sims = 0, time.perf_counter(), 0
-    while time.perf_counter() - t0 < seconds:
-        o = orc.PlayManager(orc.GAME_CONNECT4, pp, 1000 + games, per_slot_rng=False, record_moves=False)
-        o.run()
-        games += o.games_completed()
-        n_sims += o.counters()["sims"]
+    totals = [[0, 0] for _ in range(threads)]
+    t0 = time.perf_counter()
+
+    def worker(t):
+        k = 0
+        while time.perf_counter() - t0 < seconds:
+            o = orc.PlayManager(orc.GAME_CONNECT4, pp, 1000 + 7919 * t + k, per_slot_rng=False, record_moves=False)
+            o.run()
+            totals[t][0] += o.games_completed()
+            totals[t][1] += o.counters()["sims"]
+            k += 1
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
+    for th in ths: th.start()
+    for th in ths: th.join()
     dt = time.perf_counter() - t0
-    return {"value": games / dt, "unit": "games/s", "cores": 1, "kind": "port",
+    games = sum(a for a, _ in totals); n_sims = sum(b for _, b in totals)
+    return {"value": games / dt, "unit": "games/s", "cores": threads, "kind": "port",
             "sample": f"{games} Connect4 self-play games x {sims} sims, oracle PlayManager, EvalType.RANDOM evaluator "
-                      f"(no net), 1 thread, {dt:.1f}s; {n_sims / dt / 1e6:.3f} Msims/s",
-            "sims_per_s": n_sims / dt}
+                      f"(no net), {threads} threads (host cores - 1), {dt:.1f}s; {n_sims / dt / 1e6:.3f} Msims/s total, "
+                      f"{n_sims / dt / threads / 1e6:.3f} Msims/s per thread",
+            "sims_per_s": n_sims / dt, "per_thread_games_per_s": games / dt / threads}
 
 
 def main():
@@ -308,6 +323,22 @@ def main():
             del pms2
         if world == 1 and not args.no_cpu_baseline and not tafl:
             out["cpu_baseline"] = cpu_baseline(az, sims, args.cpu_seconds)
+            # the same 6b64c net on the host cores (fp32, PyTorch's default intra-op threads, batch 256): the leaf
+            # evaluations a CPU-only run of this workload would also have to pay for
+            cpu_net = torch_net.random_init(spec, seed=0).eval()
+            xb = torch.zeros((256,) + tuple(int(d) for d in io[0][0].shape[1:]))
+            with torch.no_grad():
+                cpu_net.process(xb)
+                t3, reps = time.perf_counter(), 0
+                while time.perf_counter() - t3 < 3.0:
+                    cpu_net.process(xb); reps += 1
+            evals_cpu = reps * 256 / (time.perf_counter() - t3)
+            evals_per_game = n_evals / max(n_games, 1.0)
+            out["cpu_baseline"]["net_on_cpu"] = {
+                "evals_per_s": evals_cpu, "threads": torch.get_num_threads(), "evals_per_game": evals_per_game,
+                "games_per_s_bound": evals_cpu / evals_per_game,
+                "note": "derived: leaf-net throughput of the host cores / leaf evaluations per game of the GPU run; "
+                        "cpu_baseline.value itself uses the RANDOM evaluator (no net)"}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

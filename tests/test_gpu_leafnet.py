@@ -170,5 +170,41 @@ def test_fp32_path_other_tafl_nets(which):
     with torch.no_grad():
         vr, pr = net.to(dev).process(x)
     assert (v - vr).abs().max().item() <= TOL_F32 and (pi - pr).abs().max().item() <= TOL_F32
-    with pytest.raises(RuntimeError):
-        az.HipLeafNet(net)          # the bf16 MFMA kernels are instantiated for the BASELINE nets only: loud failure
+    if which == "brandubh":
+        with pytest.raises(RuntimeError):
+            az.HipLeafNet(net)      # no bf16 MFMA kernel for 7x7 / 32 channels: loud failure, never a silent fallback
+
+
+@pytest.mark.parametrize("batch", [1, 5, 64, 1000])
+def test_opentafl_net_on_the_mfma_path(batch):
+    """configs/open_tafl.yaml (4b64c, 64 head channels, spatial head, EIGHT input planes: 72 im2col rows, two stem passes)
+    on the bf16 MFMA kernels: same tolerance as the other bf16 nets against the fp32 PyTorch forward, row invariance,
+    and agreement with the library's own fp32 path."""
+    import alphazero as az
+    from alphazero import torch_net
+    dev = torch.device("cuda:0")
+    spec = torch_net.opentafl_spec()
+    net = torch_net.random_init(spec, seed=13)
+    hip = az.HipLeafNet(net)
+    x = (torch.rand((batch,) + tuple(spec.in_shape), generator=torch.Generator().manual_seed(batch)) < 0.15).float()
+    x[:, 7] = torch.rand(batch, 1, 1)            # plane 7 = turn / max_turns, a constant plane per board
+    x = x.to(dev)
+    v, pi = hip.process(x)
+    v1, pi1 = hip.process(x[:1].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(v[:1], v1) and torch.equal(pi[:1], pi1)
+    with torch.no_grad():
+        vr, pr = net.to(dev).process(x)
+    dv, dpi = (v - vr).abs().max().item(), (pi - pr).abs().max().item()
+    print("opentafl hip bf16 vs torch fp32: %.3e %.3e" % (dv, dpi))
+    assert dv <= TOL and dpi <= TOL
+    v16, pi16 = net.process(x, amp_dtype=torch.bfloat16)
+    e16 = max((v16 - vr).abs().max().item(), (pi16 - pr).abs().max().item())
+    assert max(dv, dpi) <= max(2 * e16, 5e-3)
+    # the second stem pass (im2col rows 64..71 = the bottom-right tap) is live: with that tap's weights zeroed in the
+    # PyTorch net the two disagree by far more than the bf16 noise
+    with torch.no_grad():
+        net.conv1.weight[:, :, 2, 2] = 0
+        vz, _ = net.process(x)
+    if batch >= 64:
+        assert (v - vz).abs().max().item() > 5 * dv

@@ -139,3 +139,36 @@ def test_symmetries_match_oracle(az, oracle):
         for i in range(3):
             ec, ev, ep = oracle.symmetries(oracle.SYM_TAFL_EIGHT, c[i], v[i], pi[i])
             assert np.array_equal(oc[i], ec) and np.array_equal(op[i], ep) and np.array_equal(ov[i], ev)
+
+
+def test_opentafl_selfplay_on_the_hip_net():
+    """OpenTafl self-play end to end on the device: engine rounds + the bf16 MFMA net (8 input planes) with Gumbel search as in
+    configs/open_tafl.yaml; every game finishes, every history row is a distribution over legal-looking moves."""
+    import torch
+    import alphazero as az
+    from alphazero import torch_net
+    pp = az.PlayParams()
+    pp.games_to_play, pp.concurrent_games, pp.max_batch_size = 48, 48, 48
+    pp.mcts_visits = [24, 24]
+    pp.model_groups = [0, 0]
+    pp.gumbel_enabled, pp.gumbel_m = True, 8
+    pp.history_enabled = True
+    pp.cpuct = 1.25
+    net = torch_net.random_init(torch_net.opentafl_spec(), seed=3)
+    hip = az.HipLeafNet(net)
+    pm = az.PlayManager(az.OpenTaflGS(), pp, seed=5, log_moves=True)
+    st = torch.cuda.Stream()
+    for _ in range(400):
+        az.run_rounds([pm], hip, 64, [st.cuda_stream])
+        if pm.poll(st.cuda_stream)[1] == 0:
+            break
+    assert pm.games_completed() == 48 and pm.scores().sum() == 48
+    n = pm.hist_count()
+    canon = np.zeros((n, 8, 11, 11), np.float32); v = np.zeros((n, 3), np.float32); pi = np.zeros((n, 2662), np.float32)
+    assert pm.build_history_batch(canon, v, pi) == n and n == len(pm.move_log()[0])
+    assert np.abs(pi.sum(1) - 1).max() < 1e-4 and (v.sum(1) == 1).all()
+    src = pi.reshape(n, 121, 22).sum(2).reshape(n, 11, 11)          # target mass per from-square
+    own = np.where(canon[:, 3, 0, 0][:, None, None] == 1, canon[:, 2], canon[:, 0] + canon[:, 1])   # attackers move for player 0
+    assert (src[own == 0] == 0).all()                               # only the mover's pieces carry policy mass
+    c = pm.counters()
+    assert c["evals"] > 0 and c["sims"] >= n * 23
