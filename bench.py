@@ -91,7 +91,14 @@ def cpu_baseline(az, sims, seconds, threads=None):
     import threading
     import oracle_api as orc
     if threads is None:
-        threads = max(1, len(os.sched_getaffinity(0)) - 1)
+        cores = len(os.sched_getaffinity(0))
+        try:                                   # a cgroup CPU quota is the real core count of a container
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+            if quota != "max":
+                cores = min(cores, max(1, int(quota) // int(period)))
+        except (OSError, ValueError):
+            pass
+        threads = max(1, cores - 1)
     pp = selfplay_params(az, 1, sims, 1)
     pp.eval_type = [1, 1]
     pp.history_enabled = True
