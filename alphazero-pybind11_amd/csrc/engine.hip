@@ -678,6 +678,7 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
   }
   ep.trace_slot = getenv("AZMI_TRACE_SLOT") ? static_cast<uint32_t>(atoi(getenv("AZMI_TRACE_SLOT"))) : 0xFFFFFFFFu;
   ep.trace_cap = ep.trace_slot != 0xFFFFFFFFu ? (1u << 16) : 1u;
+  ep.trace_after = getenv("AZMI_TRACE_AFTER") ? static_cast<uint32_t>(atoi(getenv("AZMI_TRACE_AFTER"))) : 0u;
   A(trace, 2 * static_cast<size_t>(ep.trace_cap), true);
   if (ep.half_nodes) A(compact_flag, T, true);
   if (ep.gumbel_on) {

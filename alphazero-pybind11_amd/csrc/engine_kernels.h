@@ -143,8 +143,11 @@ struct SlotCtx {
   __device__ __forceinline__ void sync_lanes() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
   __device__ __forceinline__ void trace(uint64_t tag) const {
     if (slot != ep.trace_slot || lane != 0) return;
+    if (ar.ctl->rounds < ep.trace_after) return;
     const uint64_t n = ar.trace[0];
-    if (n + 1 < ep.trace_cap) { ar.trace[2 * (n + 1)] = tag; ar.trace[2 * (n + 1) + 1] = rng.state; ar.trace[0] = n + 1; }
+    // tags >= 100 are phase marks of the round kernel: they carry the 100 MHz wall clock instead of the stream position
+    const uint64_t val = (tag & 0xFF) >= 100 ? wall_clock64() : rng.state;
+    if (n + 1 < ep.trace_cap) { ar.trace[2 * (n + 1)] = tag; ar.trace[2 * (n + 1) + 1] = val; ar.trace[0] = n + 1; }
   }
 
   // ---- state load / store ----------------------------------------------------------
@@ -572,24 +575,53 @@ struct SlotCtx {
 
   // ---- MCTS::process_result -------------------------------------------------------------------
   // from_net: read (v, pi) rows written by the net; otherwise synthesise dumb_eval.
-  __device__ __forceinline__ void process_result(uint32_t seat, bool from_net, bool root_noise) {
+  // have_regs: the answer is already in registers (a cache hit of this very round: lane m holds pi[m] in reg_pi, lane
+  // i <= P holds v[i] in reg_v), which saves reading back rows the probe stored a moment ago.
+  // The kernel is bound by dependent HBM round trips (~2 us each under load), so all loads of one dependency level are
+  // issued together: level 1 = leaf META, path entries, value row; level 2 = children moves, parents' META and the
+  // path nodes' N/Q/D; level 3 = the prior gather.  The priors half (writes Pr of the leaf's children) and the backup
+  // half (reads/writes N, Q, D, V of path nodes) touch disjoint data, so hoisting the backup loads is safe.
+  __device__ __forceinline__ void process_result(uint32_t seat, bool from_net, bool root_noise, bool have_regs = false,
+                                                 float reg_pi = 0.0f, float reg_v = 0.0f) {
     sync_lanes();
     const size_t tb = tree_base(seat);
     const uint32_t root = AZMI_SEL(t_root, seat);
+    const uint32_t* path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
+    // ---- level 1
     const uint64_t meta = ar.META[tb + cur];
+    const bool lvl = lane < plen;                       // this lane backs up level `lane` (first chunk of the path)
+    const uint32_t parent0 = lvl ? path[lane] : 0u;
+    const uint32_t node0 = lvl ? ((lane == plen - 1) ? cur : path[lane + 1]) : 0u;
+    float vrow = 0.0f;
+    if (from_net && !have_regs && lane <= static_cast<uint32_t>(P)) vrow = ar.v[static_cast<size_t>(slot) * (P + 1) + lane];
     const uint32_t term = meta_term(meta);
+    const uint32_t k = meta_nch(meta), c0 = meta_ch0(meta);
+    const size_t ci = tb + c0 + lane;
+    // ---- level 2
+    uint64_t cmeta = 0;
+    if (term == 0 && lane < k) cmeta = ar.META[ci];
+    uint64_t pmeta0 = 0, nmeta0 = 0; uint32_t nn0 = 0; float q0 = 0.0f, d0 = 0.0f;
+    if (lvl) {
+      const size_t ni = tb + node0;
+      pmeta0 = ar.META[tb + parent0]; nmeta0 = ar.META[ni];
+      nn0 = ar.N[ni]; q0 = ar.Q[ni]; d0 = ar.D[ni];
+    }
+    uint32_t rn = 0; uint64_t rmeta = 0;
+    if (lane == 0) { rn = ar.N[tb + root]; rmeta = ar.META[tb + root]; }
     float val[P + 1];
     if (term != 0) {
 #pragma unroll
       for (int i = 0; i <= P; ++i) val[i] = (static_cast<int>(term) - 1 == i) ? 1.0f : 0.0f;
     } else {
-      const uint32_t k = meta_nch(meta), c0 = meta_ch0(meta);
-      const size_t ci = tb + c0 + lane;
       float p = 0.0f;
       if (from_net) {
+        const float vsrc = have_regs ? reg_v : vrow;
 #pragma unroll
-        for (int i = 0; i <= P; ++i) val[i] = ar.v[static_cast<size_t>(slot) * (P + 1) + i];
-        if (lane < k) p = ar.pi[static_cast<size_t>(slot) * M + meta_mv(ar.META[ci])];
+        for (int i = 0; i <= P; ++i) val[i] = bcast(vsrc, i);
+        // ---- level 3: the prior of this lane's child
+        if (have_regs) p = bcast(reg_pi, static_cast<int>(meta_mv(cmeta)));
+        else if (lane < k) p = ar.pi[static_cast<size_t>(slot) * M + meta_mv(cmeta)];
+        if (lane >= k) p = 0.0f;
       } else {  // dumb_eval: uniform over legal moves, u8 sum wraps (game_state.h:160-173)
 #pragma unroll
         for (int i = 0; i <= P; ++i) val[i] = static_cast<float>(1.0 / (P + 1));
@@ -605,24 +637,26 @@ struct SlotCtx {
       if (lane < k) ar.Pr[ci] = p;
     }
     // backup: level i updates node_i (child of path[i]); levels are independent -> one lane each
-    const uint32_t* path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
     const float draw_share = val[P] / static_cast<int32_t>(P);
     for (uint32_t base = 0; base < plen; base += G) {
       const uint32_t i = base + lane;
       if (i < plen) {
-        const uint32_t node = (i == plen - 1) ? cur : path[i + 1];
-        const uint32_t parent = path[i];
-        const uint32_t pp = meta_player(ar.META[tb + parent]);
+        uint32_t node, nn; uint64_t pmeta, nmeta; float q, d;
+        if (base == 0) { node = node0; nn = nn0; pmeta = pmeta0; nmeta = nmeta0; q = q0; d = d0; }
+        else {
+          node = (i == plen - 1) ? cur : path[i + 1];
+          pmeta = ar.META[tb + path[i]]; nmeta = ar.META[tb + node];
+          nn = ar.N[tb + node]; q = ar.Q[tb + node]; d = ar.D[tb + node];
+        }
+        const uint32_t pp = meta_player(pmeta);
         const size_t ni = tb + node;
         float vv = (pp == 0) ? val[0] : val[1];
         if (P > 2) vv = val[pp];
         vv += draw_share;
-        const uint32_t nn = ar.N[ni];
-        const float q = ar.Q[ni], d = ar.D[ni];
         ar.Q[ni] = (q * static_cast<float>(nn) + vv) / static_cast<float>(nn + 1);
         ar.D[ni] = (d * static_cast<float>(nn) + val[P]) / static_cast<float>(nn + 1);
         if (nn == 0) {
-          const uint32_t np = meta_player(ar.META[ni]);
+          const uint32_t np = meta_player(nmeta);
           ar.V[ni] = ((np == 0) ? val[0] : val[1]) + draw_share;
         }
         ar.N[ni] = nn + 1;
@@ -630,9 +664,9 @@ struct SlotCtx {
     }
     if (lane == 0) {
       const size_t ri = tb + root;
-      const uint32_t rn = ar.N[ri];
+      // the root is never a path NODE (nodes are children), so its N was not changed by the loop above
       if (rn == 0) {
-        const uint32_t rp = meta_player(ar.META[ri]);
+        const uint32_t rp = meta_player(rmeta);
         ar.V[ri] = ((rp == 0) ? val[0] : val[1]) + draw_share;
         ar.D[ri] = val[P];
       }
@@ -1030,15 +1064,14 @@ struct SlotCtx {
   }
 
   // ---- leaf hand-off to the net: canonical planes + position key (play_manager.cc:589-598) ----------------
-  __device__ __forceinline__ uint64_t emit_leaf(const typename GM::State& leaf) const {
+  __device__ __forceinline__ void emit_leaf(const typename GM::State& leaf, uint64_t key) const {
     float* row = ar.canon + static_cast<size_t>(slot) * GM::CANON;
     for (uint32_t e = lane; e < static_cast<uint32_t>(GM::CANON); e += G) row[e] = GM::canonical_at(leaf, e);
-    const uint64_t key = GM::key(leaf);
     if (lane == 0) ar.leaf_key[slot] = key;
-    return key;
   }
-  // position-cache probe (play_manager.cc:592-597): on a hit the cached (pi, v) land in the slot's rows
-  __device__ __forceinline__ bool cache_lookup(uint64_t key, uint32_t group) const {
+  // position-cache probe (play_manager.cc:592-597): on a hit the cached (pi, v) land in the slot's rows AND in
+  // registers (lane m: pi[m] in hit_pi, lane i <= P: v[i] in hit_v) for a process_result later in this round
+  __device__ __forceinline__ bool cache_lookup(uint64_t key, uint32_t group, float& hit_pi, float& hit_v) const {
     uint32_t sh;
     const CacheView cache = ep.num_groups == 1 ? ar.cache : ar.caches[group];   // one cache per model group
     const int cslot = wave_shard_find<G>(cache, key, lane, &sh);
@@ -1048,15 +1081,21 @@ struct SlotCtx {
         atomicAdd(&st[1], 1ULL);
       } else {
         atomicAdd(&st[0], 1ULL);
+        // freq = min(freq + 1, 3) with two atomics that return nothing (no round trip); add-then-clamp ends at <= 3 for
+        // every interleaving of concurrent probes of the same entry
         uint32_t* f = cache.freq + static_cast<size_t>(sh) * kWaveCap + cslot;
-        if (atomicAdd(f, 1u) >= 3u) atomicSub(f, 1u);
+        atomicAdd(f, 1u);
+        atomicMin(f, 3u);
       }
     }
     if (cslot < 0) return false;
     const float* sp = cache.policy + (static_cast<size_t>(sh) * cache.cap + cslot) * M;
     const float* sv = cache.value + (static_cast<size_t>(sh) * cache.cap + cslot) * (P + 1);
-    for (uint32_t e = lane; e < static_cast<uint32_t>(M); e += G) ar.pi[static_cast<size_t>(slot) * M + e] = sp[e];
-    if (lane <= static_cast<uint32_t>(P)) ar.v[static_cast<size_t>(slot) * (P + 1) + lane] = sv[lane];
+    static_assert(M <= G, "one lane per policy entry");
+    hit_pi = lane < static_cast<uint32_t>(M) ? sp[lane] : 0.0f;
+    hit_v = lane <= static_cast<uint32_t>(P) ? sv[lane] : 0.0f;
+    if (lane < static_cast<uint32_t>(M)) ar.pi[static_cast<size_t>(slot) * M + lane] = hit_pi;
+    if (lane <= static_cast<uint32_t>(P)) ar.v[static_cast<size_t>(slot) * (P + 1) + lane] = hit_v;
     return true;
   }
 };
@@ -1076,7 +1115,9 @@ __global__ __launch_bounds__(256, 1) void k_round(EngineParams ep, EngineArrays 
   // k_cache_insert stores the net's answer under it (PlayManager::update_inferences -> insert_many)
   if (st == kSlotDone || st == kSlotEnded) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; return; }
   SlotCtx<GM> c(ep, ar, slot, lane);
+  c.trace(100);
   c.load();
+  c.trace(101);
   uint32_t inline_sims = 0, insert_key_set = 0;
   bool need_process = (st == kSlotWaitEval);
   if (!need_process) {  // kSlotFresh / kSlotRestart
@@ -1087,20 +1128,26 @@ __global__ __launch_bounds__(256, 1) void k_round(EngineParams ep, EngineArrays 
     // rebuilt AFTER set_gumbel_num_sims, so the first search of that game has no Gumbel target
     if (ep.gumbel_on && st == kSlotRestart && !ep.tree_reuse) c.set_gumbel_num_sims(c.gs.player, 0);
   }
+  bool have_regs = false;        // the pending answer is a cache hit of this round, still in registers
+  float reg_pi = 0.0f, reg_v = 0.0f;
   for (;;) {
     if (need_process) {
       const uint32_t cp = c.gs.player;
       const bool noise = c.seat_eps(cp) > 0 && !(c.flags & kFlagCapped);
-      c.process_result(cp, (c.flags & kFlagLeafNeedsNet) != 0, noise);
+      c.process_result(cp, (c.flags & kFlagLeafNeedsNet) != 0, noise, have_regs, reg_pi, reg_v);
+      have_regs = false;
+      c.trace(102);
       const uint32_t goal = (c.flags & kFlagCapped) ? c.seat_cap_visits(cp) : c.seat_visits(cp);
       if (AZMI_SEL(c.t_depth, cp) >= goal) {
-        if (c.make_move(cp)) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; c.store(kSlotEnded); return; }
+        if (c.make_move(cp)) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; c.store(kSlotEnded); c.trace(107); return; }
+        c.trace(103);
       }
     }
     const uint32_t cp = c.gs.player;
     typename GM::State leaf;
     uint32_t term = 0;
     if (!c.find_leaf(cp, leaf, term)) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; c.store(kSlotDone); return; }
+    c.trace(104 | (static_cast<uint64_t>(c.plen) << 8));
     const bool playout = kPlayout && term == 0 && c.seat_eval_playout(cp);   // (a terminal leaf's evaluation is never used)
     const bool needs_net = term == 0 && !c.seat_eval_random(cp) && !playout;
     const uint32_t group = c.seat_group(cp);
@@ -1108,9 +1155,12 @@ __global__ __launch_bounds__(256, 1) void k_round(EngineParams ep, EngineArrays 
     c.flags = (needs_net || playout) ? (c.flags | kFlagLeafNeedsNet) : (c.flags & ~kFlagLeafNeedsNet);
     if constexpr (kPlayout) { if (playout) c.playout_eval(leaf); }
     if (needs_net) {
-      const uint64_t key = c.emit_leaf(leaf);
-      const bool hit = ep.cache_on && c.cache_lookup(key, group);
+      const uint64_t key = GM::key(leaf);
+      const bool hit = ep.cache_on && c.cache_lookup(key, group, reg_pi, reg_v);
+      c.trace(105 | (static_cast<uint64_t>(hit ? 1 : 0) << 8));
+      have_regs = hit;
       if (!hit) {
+        c.emit_leaf(leaf, key);      // the planes are only needed when the net is (the cached answer replaces them)
         if (lane == 0) {
           ar.c_evals[slot] += 1;
           if (ep.cache_on) ar.cache_keys[slot] = cache_key(key);
@@ -1126,6 +1176,7 @@ __global__ __launch_bounds__(256, 1) void k_round(EngineParams ep, EngineArrays 
   }
   if (ep.cache_on && !insert_key_set && lane == 0) ar.cache_keys[slot] = 0;
   c.store(kSlotWaitEval);
+  c.trace(106);
 }
 
 // Deterministic restart / retire of the slots whose game ended in the previous round:

@@ -50,6 +50,7 @@ struct EngineParams {  // run constants (PlayParams, play_manager.h:60-154, afte
   uint32_t cache_on;       // device S3-FIFO position cache enabled (max_cache_size > 0)
   uint32_t trace_slot;     // debug: slot whose RNG events are traced (0xFFFFFFFF = off)
   uint32_t trace_cap;
+  uint32_t trace_after;    // debug: events are recorded from this round on (AZMI_TRACE_AFTER)
   // Gumbel AlphaZero (play_manager.h:103-116)
   uint32_t gumbel_on;     // some seat searches with Gumbel (the per-seat settings are in seat_tab)
   uint32_t gumbel_hist;   // PlayParams::gumbel_enabled: history rows carry the improved policy (play_manager.cc:411-417)

@@ -80,6 +80,10 @@ def selfplay_params(az, games, sims, stream_games, cache=0, playout_cap=False, g
     pp.max_cache_size = cache
     pp.gumbel_enabled = bool(gumbel)
     pp.model_groups = [0, 0]      # one network on both seats: set_model_groups(), game_runner.py:773-787, 2054
+    # experiment hook (never set for a reported number): AZMI_BENCH_OVERRIDES="history_enabled=0,epsilon=0.0"
+    for item in filter(None, os.environ.get("AZMI_BENCH_OVERRIDES", "").split(",")):
+        k, v = item.split("=")
+        setattr(pp, k, type(getattr(pp, k))(float(v)))
     return pp
 
 
