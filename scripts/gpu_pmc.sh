@@ -19,7 +19,8 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") != ctr:
                 continue
-            name = r["Kernel_Name"].split("(")[0][-60:]
+            kn = r["Kernel_Name"]
+            name = "k_leafnet<6 7 4 16>" if "k_leafnet<" in kn else kn.split("(")[0][-60:].replace(",", " ")
             acc[name][0] += float(r["Counter_Value"]); acc[name][1] += 1
     for k, (tot, n) in acc.items():
         out[k][ctr] = (tot / max(n, 1), n)
