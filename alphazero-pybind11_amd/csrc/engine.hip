@@ -614,7 +614,7 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
   A(a_len, S, true); A(a_dsum, 5 * static_cast<size_t>(S), true); A(a_cnt, 3 * static_cast<size_t>(S), true);
   A(c_sims, S, true); A(c_evals, S, true);
   A(ph_count, S, true);
-  A(ph_canon, ep.history ? static_cast<size_t>(S) * ep.max_hist_rows * CANON : 0, false);
+  A(ph_canon, ep.history ? static_cast<size_t>(S) * ep.max_hist_rows * (game == AZMI_GAME_CONNECT4 ? 2 * kPendingWords : CANON) : 0, false);
   A(ph_pi, ep.history ? static_cast<size_t>(S) * ep.max_hist_rows * M : 0, false);
   A(ph_meta, ep.history ? static_cast<size_t>(S) * ep.max_hist_rows * 2 : 0, false);
   A(root, T, true); A(bump, T, true); A(depth, T, true); A(tld, T, true);

@@ -964,8 +964,14 @@ struct SlotCtx {
                                : probs(1.0f, cnt_m, pol_m);
       const uint32_t r = ph_rows;
       if (r < ep.max_hist_rows) {
-        float* crow = ar.ph_canon + (static_cast<size_t>(slot) * ep.max_hist_rows + r) * GM::CANON;
-        for (uint32_t e = lane; e < static_cast<uint32_t>(GM::CANON); e += G) crow[e] = GM::canonical_at(gs, e);
+        // the pending row keeps the packed position (kPendingWords u64 = 24 B), not its 672 B of planes: the planes are
+        // generated from it when the game's rows are committed (end_game), so a row costs one small store here and no
+        // read-back there
+        if (lane == 0) {
+          uint64_t* st = reinterpret_cast<uint64_t*>(ar.ph_canon) + (static_cast<size_t>(slot) * ep.max_hist_rows + r) * kPendingWords;
+          st[0] = gs.bb[0]; st[1] = gs.bb[1];
+          st[2] = static_cast<uint64_t>(gs.turn) | (static_cast<uint64_t>(gs.player) << 32);
+        }
         if (lane < static_cast<uint32_t>(M)) ar.ph_pi[(static_cast<size_t>(slot) * ep.max_hist_rows + r) * M + lane] = target;
         if (lane == 0) {
           uint32_t* pm = ar.ph_meta + (static_cast<size_t>(slot) * ep.max_hist_rows + r) * 2;
@@ -1032,16 +1038,49 @@ struct SlotCtx {
       base = bcast(base, 0);
       if (base + rows <= ep.hist_cap) {
         const uint32_t game_idx = ar.slot_games[slot];
-        for (uint32_t r = 0; r < rows; ++r) {
-          const size_t src = static_cast<size_t>(slot) * ep.max_hist_rows + r;
-          const size_t dst = static_cast<size_t>(base) + r;
-          for (uint32_t e = lane; e < static_cast<uint32_t>(GM::CANON); e += G)
-            ar.h_canon[dst * GM::CANON + e] = ar.ph_canon[src * GM::CANON + e];
-          if (lane < static_cast<uint32_t>(M)) ar.h_pi[dst * M + lane] = ar.ph_pi[src * M + lane];
-          if (lane <= static_cast<uint32_t>(P)) ar.h_v[dst * (P + 1) + lane] = (lane == term - 1) ? 1.0f : 0.0f;
-          if (lane == 0) {
-            uint32_t* hm = ar.h_meta + dst * 4;
-            hm[0] = slot; hm[1] = game_idx; hm[2] = ar.ph_meta[src * 2 + 1]; hm[3] = ar.ph_meta[src * 2 + 0];
+        // The game's rows are contiguous on both sides (pending rows of the slot -> `rows` consecutive ring rows): a per-row
+        // copy loop is a chain of dependent round trips (measured 230 us per game end, which stretched every eighth round
+        // of a shard), so the planes are regenerated from packed positions and the policy rows move as one flat copy.
+        const size_t src0 = static_cast<size_t>(slot) * ep.max_hist_rows, dst0 = base;
+        {
+          // canonical planes from the packed pending positions: eight rows' positions per round trip, planes written straight
+          // into the ring (stores only)
+          const uint64_t* ps = reinterpret_cast<const uint64_t*>(ar.ph_canon) + src0 * kPendingWords;
+          for (uint32_t r0 = 0; r0 < rows; r0 += G) {
+            const uint32_t rr = r0 + lane;
+            uint64_t w0 = 0, w1 = 0, w2 = 0;
+            if (rr < rows) { w0 = ps[rr * kPendingWords]; w1 = ps[rr * kPendingWords + 1]; w2 = ps[rr * kPendingWords + 2]; }
+            const uint32_t nb = (rows - r0) < static_cast<uint32_t>(G) ? (rows - r0) : static_cast<uint32_t>(G);
+            for (uint32_t j = 0; j < nb; ++j) {
+              typename GM::State st;
+              st.bb[0] = bcast(w0, static_cast<int>(j)); st.bb[1] = bcast(w1, static_cast<int>(j));
+              const uint64_t t = bcast(w2, static_cast<int>(j));
+              st.turn = static_cast<uint32_t>(t); st.player = static_cast<uint32_t>(t >> 32);
+              float* drow = ar.h_canon + (dst0 + r0 + j) * GM::CANON;
+              for (uint32_t e = lane; e < static_cast<uint32_t>(GM::CANON); e += G) drow[e] = GM::canonical_at(st, e);
+            }
+          }
+          const float* sp = ar.ph_pi + src0 * M;
+          float* dp = ar.h_pi + dst0 * M;
+          const uint32_t np = rows * M;
+          for (uint32_t e0 = 0; e0 < np; e0 += 4 * G) {
+            float t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+            const uint32_t a = e0 + lane, b = a + G, c = b + G, d = c + G;
+            if (a < np) t0 = sp[a];
+            if (b < np) t1 = sp[b];
+            if (c < np) t2 = sp[c];
+            if (d < np) t3 = sp[d];
+            if (a < np) dp[a] = t0;
+            if (b < np) dp[b] = t1;
+            if (c < np) dp[c] = t2;
+            if (d < np) dp[d] = t3;
+          }
+          float* dv = ar.h_v + dst0 * (P + 1);
+          for (uint32_t e = lane; e < rows * (P + 1); e += G) dv[e] = (e % (P + 1) == term - 1) ? 1.0f : 0.0f;
+          for (uint32_t r = lane; r < rows; r += G) {
+            const uint32_t* pm = ar.ph_meta + (src0 + r) * 2;
+            uint32_t* hm = ar.h_meta + (dst0 + r) * 4;
+            hm[0] = slot; hm[1] = game_idx; hm[2] = pm[1]; hm[3] = pm[0];
           }
         }
       } else {
@@ -1050,14 +1089,23 @@ struct SlotCtx {
     }
     ph_rows = 0;
     if (lane == 0) {
-      ar.a_scores[static_cast<size_t>(slot) * (P + 1) + (term - 1)] += 1.0f;
-      if (resigned) ar.a_resign[static_cast<size_t>(slot) * (P + 1) + (term - 1)] += 1.0f;
-      ar.a_perm_scores[(static_cast<size_t>(slot) * ep.num_perms + perm) * (P + 1) + (term - 1)] += 1.0f;   // play_manager.cc:466-467
-      ar.a_perm_games[static_cast<size_t>(slot) * ep.num_perms + perm] += 1;
-      ar.a_len[slot] += gs.turn;
-      for (int j = 0; j < 5; ++j) { ar.a_dsum[j * S + slot] += ar.g_dsum[j * S + slot]; ar.g_dsum[j * S + slot] = 0.0; }
-      for (int j = 0; j < 3; ++j) { ar.a_cnt[j * S + slot] += ar.g_cnt[j * S + slot]; ar.g_cnt[j * S + slot] = 0; }
-      ar.slot_games[slot] += 1;
+      atomicAdd(&ar.a_scores[static_cast<size_t>(slot) * (P + 1) + (term - 1)], 1.0f);
+      if (resigned) atomicAdd(&ar.a_resign[static_cast<size_t>(slot) * (P + 1) + (term - 1)], 1.0f);
+      atomicAdd(&ar.a_perm_scores[(static_cast<size_t>(slot) * ep.num_perms + perm) * (P + 1) + (term - 1)], 1.0f);   // play_manager.cc:466-467
+      atomicAdd(&ar.a_perm_games[static_cast<size_t>(slot) * ep.num_perms + perm], 1u);
+      // one round trip for the game's running totals, then accumulations that return nothing (each cell has this
+      // one writer, so an atomic add is the same sum as load-add-store without the dependent load)
+      double gd[5]; uint32_t gc[3];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) gd[j] = ar.g_dsum[j * S + slot];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) gc[j] = ar.g_cnt[j * S + slot];
+      atomicAdd(reinterpret_cast<unsigned long long*>(&ar.a_len[slot]), static_cast<unsigned long long>(gs.turn));
+#pragma unroll
+      for (int j = 0; j < 5; ++j) { atomicAdd(&ar.a_dsum[j * S + slot], gd[j]); ar.g_dsum[j * S + slot] = 0.0; }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { atomicAdd(reinterpret_cast<unsigned long long*>(&ar.a_cnt[j * S + slot]), static_cast<unsigned long long>(gc[j])); ar.g_cnt[j * S + slot] = 0; }
+      atomicAdd(&ar.slot_games[slot], 1u);
       const uint32_t pos = atomicAdd(&ar.ctl->ended_count, 1u);
       ar.ended_list[pos] = slot;
     }

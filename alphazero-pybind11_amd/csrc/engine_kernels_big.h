@@ -1014,16 +1014,25 @@ struct BigSlot {
       base = __shfl(base, 0, 64);
       if (base + rows <= ep.hist_cap) {
         const uint32_t game_idx = ar.slot_games[slot];
-        for (uint32_t r = 0; r < rows; ++r) {
-          const size_t src = static_cast<size_t>(slot) * ep.max_hist_rows + r;
-          const size_t dst = static_cast<size_t>(base) + r;
-          for (uint32_t e = lane; e < static_cast<uint32_t>(GM::CANON); e += G) ar.h_canon[dst * GM::CANON + e] = ar.ph_canon[src * GM::CANON + e];
-          for (uint32_t m = lane; m < static_cast<uint32_t>(M); m += G) ar.h_pi[dst * M + m] = ar.ph_pi[src * M + m];
-          if (lane <= static_cast<uint32_t>(P)) ar.h_v[dst * (P + 1) + lane] = (lane == term - 1) ? 1.0f : 0.0f;
-          if (lane == 0) {
-            uint32_t* hm = ar.h_meta + dst * 4;
-            hm[0] = slot; hm[1] = game_idx; hm[2] = ar.ph_meta[src * 2 + 1]; hm[3] = ar.ph_meta[src * 2 + 0];
+        // the game's rows are contiguous on both sides: one flat copy per array, eight loads in flight per lane
+        const size_t src0 = static_cast<size_t>(slot) * ep.max_hist_rows, dst0 = base;
+        auto flat_copy = [&](const float* sp, float* dp, size_t n) {
+          for (size_t e0 = 0; e0 < n; e0 += 8 * G) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const size_t e = e0 + u * G + lane; if (e < n) t[u] = sp[e]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const size_t e = e0 + u * G + lane; if (e < n) dp[e] = t[u]; }
           }
+        };
+        flat_copy(ar.ph_canon + src0 * GM::CANON, ar.h_canon + dst0 * GM::CANON, static_cast<size_t>(rows) * GM::CANON);
+        flat_copy(ar.ph_pi + src0 * M, ar.h_pi + dst0 * M, static_cast<size_t>(rows) * M);
+        float* dv = ar.h_v + dst0 * (P + 1);
+        for (uint32_t e = lane; e < rows * (P + 1); e += G) dv[e] = (e % (P + 1) == term - 1) ? 1.0f : 0.0f;
+        for (uint32_t r = lane; r < rows; r += G) {
+          const uint32_t* pm = ar.ph_meta + (src0 + r) * 2;
+          uint32_t* hm = ar.h_meta + (dst0 + r) * 4;
+          hm[0] = slot; hm[1] = game_idx; hm[2] = pm[1]; hm[3] = pm[0];
         }
       } else {
         raise(2u);
@@ -1031,14 +1040,23 @@ struct BigSlot {
     }
     ph_rows = 0;
     if (lane == 0) {
-      ar.a_scores[static_cast<size_t>(slot) * (P + 1) + (term - 1)] += 1.0f;
-      if (resigned) ar.a_resign[static_cast<size_t>(slot) * (P + 1) + (term - 1)] += 1.0f;
-      ar.a_perm_scores[(static_cast<size_t>(slot) * ep.num_perms + perm) * (P + 1) + (term - 1)] += 1.0f;
-      ar.a_perm_games[static_cast<size_t>(slot) * ep.num_perms + perm] += 1;
-      ar.a_len[slot] += gs.turn;
-      for (int j = 0; j < 5; ++j) { ar.a_dsum[j * S + slot] += ar.g_dsum[j * S + slot]; ar.g_dsum[j * S + slot] = 0.0; }
-      for (int j = 0; j < 3; ++j) { ar.a_cnt[j * S + slot] += ar.g_cnt[j * S + slot]; ar.g_cnt[j * S + slot] = 0; }
-      ar.slot_games[slot] += 1;
+      atomicAdd(&ar.a_scores[static_cast<size_t>(slot) * (P + 1) + (term - 1)], 1.0f);
+      if (resigned) atomicAdd(&ar.a_resign[static_cast<size_t>(slot) * (P + 1) + (term - 1)], 1.0f);
+      atomicAdd(&ar.a_perm_scores[(static_cast<size_t>(slot) * ep.num_perms + perm) * (P + 1) + (term - 1)], 1.0f);
+      atomicAdd(&ar.a_perm_games[static_cast<size_t>(slot) * ep.num_perms + perm], 1u);
+      // one round trip for the game's running totals, then accumulations that return nothing (each cell has this
+      // one writer, so an atomic add is the same sum as load-add-store without the dependent load)
+      double gd[5]; uint32_t gc[3];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) gd[j] = ar.g_dsum[j * S + slot];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) gc[j] = ar.g_cnt[j * S + slot];
+      atomicAdd(reinterpret_cast<unsigned long long*>(&ar.a_len[slot]), static_cast<unsigned long long>(gs.turn));
+#pragma unroll
+      for (int j = 0; j < 5; ++j) { atomicAdd(&ar.a_dsum[j * S + slot], gd[j]); ar.g_dsum[j * S + slot] = 0.0; }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { atomicAdd(reinterpret_cast<unsigned long long*>(&ar.a_cnt[j * S + slot]), static_cast<unsigned long long>(gc[j])); ar.g_cnt[j * S + slot] = 0; }
+      atomicAdd(&ar.slot_games[slot], 1u);
       const uint32_t pos = atomicAdd(&ar.ctl->ended_count, 1u);
       ar.ended_list[pos] = slot;
     }

@@ -76,6 +76,8 @@ __host__ __device__ inline uint32_t seat_w1_pack(uint32_t cap_visits, uint32_t f
   return (cap_visits & 0xFFFFFFu) | (fpu_zero << 24) | (eval_random << 25) | (group << 26) | (eval_playout << 28);
 }
 
+constexpr uint32_t kPendingWords = 3;   // Connect4 pending history row: stones of player 0, of player 1, turn | player << 32
+
 struct Control {  // small device control block, copied back by azmi_pm_poll
   uint32_t games_started;
   uint32_t games_completed;
@@ -119,7 +121,7 @@ struct EngineArrays {
   uint64_t* c_evals;      // [S] leaves sent to the net
   // pending history rows of the running game (GameData::partial_history)
   uint32_t* ph_count;     // [S]
-  float* ph_canon;        // [S][max_hist_rows][CANON]
+  float* ph_canon;        // [S][max_hist_rows][CANON] pending planes (wide games) / [S][max_hist_rows][kPendingWords] u64 packed positions (Connect4)
   float* ph_pi;           // [S][max_hist_rows][M]
   uint32_t* ph_meta;      // [S][max_hist_rows][2]: player, turn
   // ---- per tree (slot * P + seat) -------------------------------------------------

@@ -36,7 +36,7 @@ def parse():
                     help="connect4 = BASELINE configs[1] (the headline); tawlbwrdd = configs[2] (2048 games, 400 sims, YAML net)")
     ap.add_argument("--games", type=int, default=None, help="concurrent games per GPU (4096 / 2048)")
     ap.add_argument("--sims", type=int, default=None, help="simulations per move (800 / 400)")
-    ap.add_argument("--engines", type=int, default=None, help="engine shards (HIP streams) per GPU (4 / 2)")
+    ap.add_argument("--engines", type=int, default=None, help="engine shards (HIP streams) per GPU (default 4)")
     ap.add_argument("--cache", type=int, default=None,
                     help="max_cache_size per GPU (reference default 200000, config.py:197; sized up for 288 GB of HBM)")
     ap.add_argument("--inline", type=int, default=0, help="max simulations finished per slot per round without the net (0 = engine default)")
@@ -150,7 +150,7 @@ def main():
     tafl = args.game == "tawlbwrdd"
     if args.games is None: args.games = 2048 if tafl else 4096
     if args.sims is None: args.sims = 400 if tafl else 800
-    if args.engines is None: args.engines = 2 if tafl else 4
+    if args.engines is None: args.engines = 4      # measured: Connect4 1/2/4/8 shards and Tawlbwrdd 2/4/8 shards both peak at 4
     if args.cache is None: args.cache = 0 if tafl else 32_000_000      # the device cache is wired for Connect4 only
     Game = az.TawlbwrddGS if tafl else az.Connect4GS
     flop_per_eval = 93.1e6 if tafl else FLOP_PER_EVAL
