@@ -314,8 +314,14 @@ __device__ __forceinline__ int wave_shard_find(const CacheView& c, uint64_t hash
     const int slot = i * G + static_cast<int>(glane);
     if (hs[slot] == k) found = slot;
   }
+  if constexpr (G == 8) {   // DPP moves instead of LDS-routed shuffles: xor 1, xor 2 inside quads, then the half-row mirror
+    found = max(found, __builtin_amdgcn_update_dpp(0, found, 0xB1, 0xF, 0xF, true));
+    found = max(found, __builtin_amdgcn_update_dpp(0, found, 0x4E, 0xF, 0xF, true));
+    found = max(found, __builtin_amdgcn_update_dpp(0, found, 0x141, 0xF, 0xF, true));
+  } else {
 #pragma unroll
-  for (int off = 1; off < G; off <<= 1) found = max(found, __shfl_xor(found, off, G));
+    for (int off = 1; off < G; off <<= 1) found = max(found, __shfl_xor(found, off, G));
+  }
   return found;
 }
 __device__ inline void wave_shard_find_account(const CacheView& c, uint64_t hash, uint32_t sh, int slot) {

@@ -125,6 +125,29 @@ struct SlotCtx {
   // ---- group primitives ---------------------------------------------------------
   template <class T>
   __device__ __forceinline__ T bcast(T v, int src) const { return __shfl(v, src, G); }
+  // ---- DPP forms of the two reductions of the PUCT select (the descent spends about as long in cross-lane traffic as
+  // in its one HBM round trip per level; a ds_bpermute costs an LDS round trip, a DPP move a few cycles) ----------
+  template <int CTRL>
+  __device__ __forceinline__ static float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+  }
+  template <int CTRL>
+  __device__ __forceinline__ static uint32_t dpp_u(uint32_t v) {
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xF, 0xF, true));
+  }
+  // x_0 + x_1 + ... + x_7 in lane order over the 8-lane group; lanes past the data must hold +0.0f.  Lane j takes lane
+  // j-1's running sum (row_shr:1) at step j, so the additions happen in exactly the sequential order.
+  __device__ __forceinline__ float seqsum8(float x) const {
+    static_assert(G == 8, "8-lane groups");
+    const uint32_t li = lane & 7u;
+    float run = x;
+#pragma unroll
+    for (uint32_t j = 1; j < 8; ++j) {
+      const float t = dpp_f<0x111>(run);          // row_shr:1
+      if (li == j) run = t + x;
+    }
+    return bcast(run, 7);
+  }
   __device__ __forceinline__ float seqsum(float x, uint32_t n) const {  // x_0 + x_1 + ... in lane order
     float s = 0.0f;
     for (uint32_t i = 0; i < n; ++i) s += bcast(x, i);
@@ -373,31 +396,37 @@ struct SlotCtx {
                               uint32_t& c0_out, uint32_t& k_out) {
     const size_t tb = tree_base(seat);
     const uint32_t k = GM::num_valid(st);
-    uint32_t mv = lane < k ? GM::nth_valid(st, lane) : 0u;
-    // std::shuffle (stl_algo.h:3729-3792): element `lane` of the array lives in lane `lane`
+    // The legal moves (ascending) as 4-bit fields of one word that every lane of the group holds: std::shuffle
+    // (stl_algo.h:3729-3792) then swaps fields of that word — the draws are group-uniform anyway — instead of moving
+    // values between lanes (a dependent ds_bpermute chain per swap); each lane finally picks field `lane`.
+    static_assert(GM::MAXK <= 8, "eight 4-bit move fields");
+    uint32_t packed = 0;
+    {
+      uint32_t vm = GM::valid_mask(st), pos = 0;
+      while (vm) { const uint32_t m = __builtin_ctz(vm); vm &= vm - 1; packed |= m << (4 * pos); ++pos; }
+    }
+    auto swap_fields = [&](uint32_t a, uint32_t b) {
+      const uint32_t fa = (packed >> (4 * a)) & 0xFu, fb = (packed >> (4 * b)) & 0xFu;
+      packed = (packed & ~((0xFu << (4 * a)) | (0xFu << (4 * b)))) | (fb << (4 * a)) | (fa << (4 * b));
+    };
     if (k > 1) {
       uint32_t i = 1;
       if ((k & 1u) == 0) {
         const uint32_t j = lemire_below(rng, 2);
-        const uint32_t vi = bcast(mv, i), vj = bcast(mv, j);
-        if (lane == i) mv = vj;
-        if (lane == j) mv = vi;
+        swap_fields(i, j);
         ++i;
       }
       while (i != k) {
         const uint32_t swap_range = i + 1, b1 = swap_range + 1;
         const uint32_t x = lemire_below(rng, swap_range * b1);
         const uint32_t p0 = x / b1, p1 = x % b1;
-        uint32_t vi = bcast(mv, i), vj = bcast(mv, p0);
-        if (lane == i) mv = vj;
-        if (lane == p0) mv = vi;
+        swap_fields(i, p0);
         ++i;
-        vi = bcast(mv, i); vj = bcast(mv, p1);
-        if (lane == i) mv = vj;
-        if (lane == p1) mv = vi;
+        swap_fields(i, p1);
         ++i;
       }
     }
+    const uint32_t mv = lane < k ? (packed >> (4 * lane)) & 0xFu : 0u;
     const uint32_t c0 = AZMI_SEL(t_bump, seat);
     if (c0 + k > ep.cap) { raise(1u); return false; }
     if (lane < k) {
@@ -419,23 +448,25 @@ struct SlotCtx {
   // (`if_l` = Node::n_in_flight of the child, `n_parent` includes the parent's: only the WU-UCT batched API has them non-zero)
   __device__ __forceinline__ uint32_t select_child(uint32_t k, uint32_t n_l, float q_l, float p_l, float v_parent,
                                    uint32_t n_parent, float fpu_reduction, uint32_t if_l = 0) const {
-    float seen = 0.0f;
-    for (uint32_t i = 0; i < k; ++i) {
-      const uint32_t ni = bcast(n_l, i);
-      const float pi = bcast(p_l, i);
-      if (ni > 0) seen += pi;
-    }
+    // seen_policy: the priors of the visited children added in child order; an unvisited child contributes +0.0f, which
+    // leaves the running sum unchanged, so the masked in-order sum is the reference's
+    const float seen = seqsum8((lane < k && n_l > 0) ? p_l : 0.0f);
     const float fpu_value = v_parent - fpu_reduction * sqrtf(seen);
     const float sqrt_n = sqrtf(static_cast<float>(n_parent));
     float u = (n_l == 0 ? fpu_value : q_l) + ep.cpuct * p_l * sqrt_n / static_cast<float>(n_l + if_l + 1);
     // a strict `>` scan never replaces the incumbent with a NaN and never leaves a NaN at
-    // index 0: map NaN to +inf at lane 0 and -inf elsewhere, then butterfly (score, index)
+    // index 0: map NaN to +inf at lane 0 and -inf elsewhere, then reduce (score, index) keys: largest score, smallest
+    // index among equals — an order-free reduction, done with DPP moves (xor 1, xor 2 inside quads, then the half-row
+    // mirror to meet the other quad)
     if (u != u) u = (lane == 0) ? __builtin_inff() : -__builtin_inff();
     if (lane >= k) u = -__builtin_inff();
     uint32_t idx = lane < k ? lane : 0xFFFFu;
-    for (int off = 1; off < G; off <<= 1) {
-      const float ou = __shfl_xor(u, off, G);
-      const uint32_t oi = __shfl_xor(idx, off, G);
+    {
+      float ou = dpp_f<0xB1>(u); uint32_t oi = dpp_u<0xB1>(idx);          // quad_perm [1,0,3,2]
+      if (ou > u || (ou == u && oi < idx)) { u = ou; idx = oi; }
+      ou = dpp_f<0x4E>(u); oi = dpp_u<0x4E>(idx);                           // quad_perm [2,3,0,1]
+      if (ou > u || (ou == u && oi < idx)) { u = ou; idx = oi; }
+      ou = dpp_f<0x141>(u); oi = dpp_u<0x141>(idx);                         // row_half_mirror: lane i <-> 7 - i
       if (ou > u || (ou == u && oi < idx)) { u = ou; idx = oi; }
     }
     return idx;
@@ -528,12 +559,14 @@ struct SlotCtx {
       n = bcast(n_l, best);
       meta = bcast(m_l, best);
       GM::play(leaf, meta_mv(meta));
+      trace(108);
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == seat) t_tld[p] += plen;
     term = meta_term(meta);
     if (n == 0) {
       term = GM::terminal(leaf);
+      trace(109);
       const uint64_t keep = meta_pack(0, 0, meta_mv(meta), leaf.player, term);
       uint32_t c0, k;
       if (!expand_node(seat, cur, leaf, keep, c0, k)) return false;
@@ -631,7 +664,7 @@ struct SlotCtx {
       const bool is_root = cur == root;
       const float root_temp = seat_root_temp(seat);
       if (is_root && root_temp != 1.0f && lane < k) p = az_powf(p, 1.0f / root_temp);
-      const float sum = seqsum(lane < k ? p : 0.0f, k);
+      const float sum = seqsum8(lane < k ? p : 0.0f);
       p = p / sum;
       if (is_root && root_noise && !seat_gumbel(seat)) { trace(1 | (static_cast<uint64_t>(k) << 8)); p = add_root_noise(k, p, seat_eps(seat)); trace(2); }
       if (lane < k) ar.Pr[ci] = p;
@@ -829,7 +862,7 @@ struct SlotCtx {
     const float root_temp = seat_root_temp(seat);
     if (root_temp != 1.0f) {
       if (lane < k) p = az_powf(p, 1.0f / root_temp);
-      const float sum = seqsum(lane < k ? p : 0.0f, k);
+      const float sum = seqsum8(lane < k ? p : 0.0f);
       if (sum > 0.0f) p = p / sum;
       dirty = true;
     }

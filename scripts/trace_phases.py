@@ -32,7 +32,7 @@ buf = np.zeros((1 << 16, 2), np.uint64); n = C.c_uint32()
 assert lib.azmi_debug_trace(pms[0]._h, buf.ctypes.data, 1 << 16, C.byref(n)) == 0
 ev = buf[: n.value]
 tags = (ev[:, 0] & 0xFF).astype(int); arg = (ev[:, 0] >> 8).astype(int); clk = ev[:, 1].astype(np.int64)
-names = {100: "start", 101: "load", 102: "process_result", 103: "make_move", 104: "find_leaf", 105: "emit+cache probe", 106: "store/end", 107: "game end"}
+names = {100: "start", 101: "load", 102: "process_result", 103: "make_move", 104: "find_leaf", 105: "emit+cache probe", 106: "store/end", 107: "game end", 108: "  descent level", 109: "  terminal check"}
 dur = {}
 rounds = []
 prev = None
