@@ -618,8 +618,12 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
   A(ph_pi, ep.history ? static_cast<size_t>(S) * ep.max_hist_rows * M : 0, false);
   A(ph_meta, ep.history ? static_cast<size_t>(S) * ep.max_hist_rows * 2 : 0, false);
   A(root, T, true); A(bump, T, true); A(depth, T, true); A(tld, T, true);
-  A(N, NODES, false); A(Q, NODES, false); A(Pr, NODES, false); A(D, NODES, false); A(V, NODES, false);
-  A(META, NODES, false);
+  if (game == AZMI_GAME_CONNECT4) {
+    A(nodes, NODES, false);
+  } else {
+    A(N, NODES, false); A(Q, NODES, false); A(Pr, NODES, false); A(D, NODES, false); A(V, NODES, false);
+    A(META, NODES, false);
+  }
   A(canon, static_cast<size_t>(S) * CANON, true);
   A(v, static_cast<size_t>(S) * (P + 1), true);
   A(pi, static_cast<size_t>(S) * M, true);

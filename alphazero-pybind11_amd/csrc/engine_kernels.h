@@ -218,7 +218,7 @@ struct SlotCtx {
     for (int p = 0; p < P; ++p)
       if (static_cast<uint32_t>(p) == seat) { t_root[p] = 0; t_bump[p] = 1; t_depth[p] = 0; t_tld[p] = 0; }
     const size_t tb = tree_base(seat);
-    if (lane == 0) { ar.N[tb] = 0; ar.Q[tb] = 0; ar.Pr[tb] = 0; ar.D[tb] = 0; ar.V[tb] = 0; ar.META[tb] = 0; }
+    if (lane == 0) { ar.nodes[tb].n = 0; ar.nodes[tb].q = 0; ar.nodes[tb].pr = 0; ar.nodes[tb].d = 0; ar.nodes[tb].v = 0; ar.nodes[tb].meta = 0; }
     if (ep.gumbel_on) set_gumbel_num_sims(seat, 0);   // a new MCTS object: target 0, nothing initialised
   }
 
@@ -431,13 +431,13 @@ struct SlotCtx {
     if (c0 + k > ep.cap) { raise(1u); return false; }
     if (lane < k) {
       const size_t ci = tb + c0 + lane;
-      ar.N[ci] = 0; ar.Q[ci] = 0.0f; ar.Pr[ci] = 0.0f; ar.D[ci] = 0.0f; ar.V[ci] = 0.0f;
-      ar.META[ci] = meta_pack(0, 0, mv, 0, 0);
+      ar.nodes[ci].n = 0; ar.nodes[ci].q = 0.0f; ar.nodes[ci].pr = 0.0f; ar.nodes[ci].d = 0.0f; ar.nodes[ci].v = 0.0f;
+      ar.nodes[ci].meta = meta_pack(0, 0, mv, 0, 0);
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == seat) t_bump[p] = c0 + k;
     if (lane == 0)
-      ar.META[tb + node] = meta_pack(c0, k, meta_mv(meta_keep), meta_player(meta_keep), meta_term(meta_keep));
+      ar.nodes[tb + node].meta = meta_pack(c0, k, meta_mv(meta_keep), meta_player(meta_keep), meta_term(meta_keep));
     c0_out = c0;
     k_out = k;
     return true;
@@ -482,8 +482,8 @@ struct SlotCtx {
     const uint32_t root = AZMI_SEL(t_root, seat);
     cur = root; plen = 0;
     leaf = gs;
-    uint64_t meta = ar.META[tb + cur];
-    uint32_t n = ar.N[tb + cur], nf = nif[cur];
+    uint64_t meta = ar.nodes[tb + cur].meta;
+    uint32_t n = ar.nodes[tb + cur].n, nf = nif[cur];
     uint32_t* path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
     while ((n > 0 || nf > 0) && meta_nch(meta) != 0 && meta_term(meta) == 0) {
       if (plen >= ep.max_depth) { raise(8u); return false; }
@@ -492,9 +492,9 @@ struct SlotCtx {
       const uint32_t k = meta_nch(meta), c0 = meta_ch0(meta);
       const size_t ci = tb + c0 + lane;
       uint32_t n_l = 0, if_l = 0; float q_l = 0.0f, p_l = 0.0f; uint64_t m_l = 0;
-      if (lane < k) { n_l = ar.N[ci]; q_l = ar.Q[ci]; p_l = ar.Pr[ci]; m_l = ar.META[ci]; if_l = nif[c0 + lane]; }
+      if (lane < k) { n_l = ar.nodes[ci].n; q_l = ar.nodes[ci].q; p_l = ar.nodes[ci].pr; m_l = ar.nodes[ci].meta; if_l = nif[c0 + lane]; }
       const float fpu = (cur == root && seat_fpu_zero(seat)) ? 0.0f : ep.fpu_reduction;
-      const uint32_t best = select_child(k, n_l, q_l, p_l, ar.V[tb + cur], n + nf, fpu, if_l);
+      const uint32_t best = select_child(k, n_l, q_l, p_l, ar.nodes[tb + cur].v, n + nf, fpu, if_l);
       if (lane == 0) nif[cur] = nf + 1;
       cur = c0 + best;
       n = bcast(n_l, best);
@@ -526,8 +526,8 @@ struct SlotCtx {
     const uint32_t root = AZMI_SEL(t_root, seat);
     cur = root; plen = 0;
     leaf = gs;
-    uint64_t meta = ar.META[tb + cur];
-    uint32_t n = ar.N[tb + cur];
+    uint64_t meta = ar.nodes[tb + cur].meta;
+    uint32_t n = ar.nodes[tb + cur].n;
     uint32_t* path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
     uint32_t gum_active = 0;   // (uint32_t: a bool carried across the descent loop is mis-tracked by hipcc in divergent groups)
     if (seat_gumbel(seat)) {  // lazy init, mcts.cc:465-472 (MCTS::gumbel_enabled_ of this seat's tree)
@@ -535,7 +535,7 @@ struct SlotCtx {
       gum_active = st[kGumInit];
       if (!gum_active && st[kGumTarget] > 0 && n > 0 && meta_nch(meta) != 0) {
         const uint32_t k0 = meta_nch(meta);
-        const float p0 = lane < k0 ? ar.Pr[tb + meta_ch0(meta) + lane] : 0.0f;
+        const float p0 = lane < k0 ? ar.nodes[tb + meta_ch0(meta) + lane].pr : 0.0f;
         init_gumbel_state(seat, k0, p0);
         gum_active = gum_state(seat)[kGumInit];
       }
@@ -548,9 +548,9 @@ struct SlotCtx {
       if (k == 0) { raise(8u); return false; }  // reference: children.at(0) throws
       const size_t ci = tb + c0 + lane;
       uint32_t n_l = 0; float q_l = 0.0f, p_l = 0.0f; uint64_t m_l = 0;
-      if (lane < k) { n_l = ar.N[ci]; q_l = ar.Q[ci]; p_l = ar.Pr[ci]; m_l = ar.META[ci]; }
+      if (lane < k) { n_l = ar.nodes[ci].n; q_l = ar.nodes[ci].q; p_l = ar.nodes[ci].pr; m_l = ar.nodes[ci].meta; }
       const float fpu = (cur == root && seat_fpu_zero(seat)) ? 0.0f : ep.fpu_reduction;
-      const float v_parent = ar.V[tb + cur];
+      const float v_parent = ar.nodes[tb + cur].v;
       uint32_t best;
       if (gum_active && cur == root) best = gumbel_next_root_child(seat, k, n_l, q_l, p_l);
       else if (gum_active && seat_gumbel_full(seat)) best = gumbel_interior_select(seat, k, n_l, q_l, p_l, v_parent);
@@ -621,7 +621,7 @@ struct SlotCtx {
     const uint32_t root = AZMI_SEL(t_root, seat);
     const uint32_t* path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
     // ---- level 1
-    const uint64_t meta = ar.META[tb + cur];
+    const uint64_t meta = ar.nodes[tb + cur].meta;
     const bool lvl = lane < plen;                       // this lane backs up level `lane` (first chunk of the path)
     const uint32_t parent0 = lvl ? path[lane] : 0u;
     const uint32_t node0 = lvl ? ((lane == plen - 1) ? cur : path[lane + 1]) : 0u;
@@ -632,15 +632,15 @@ struct SlotCtx {
     const size_t ci = tb + c0 + lane;
     // ---- level 2
     uint64_t cmeta = 0;
-    if (term == 0 && lane < k) cmeta = ar.META[ci];
+    if (term == 0 && lane < k) cmeta = ar.nodes[ci].meta;
     uint64_t pmeta0 = 0, nmeta0 = 0; uint32_t nn0 = 0; float q0 = 0.0f, d0 = 0.0f;
     if (lvl) {
       const size_t ni = tb + node0;
-      pmeta0 = ar.META[tb + parent0]; nmeta0 = ar.META[ni];
-      nn0 = ar.N[ni]; q0 = ar.Q[ni]; d0 = ar.D[ni];
+      pmeta0 = ar.nodes[tb + parent0].meta; nmeta0 = ar.nodes[ni].meta;
+      nn0 = ar.nodes[ni].n; q0 = ar.nodes[ni].q; d0 = ar.nodes[ni].d;
     }
     uint32_t rn = 0; uint64_t rmeta = 0;
-    if (lane == 0) { rn = ar.N[tb + root]; rmeta = ar.META[tb + root]; }
+    if (lane == 0) { rn = ar.nodes[tb + root].n; rmeta = ar.nodes[tb + root].meta; }
     float val[P + 1];
     if (term != 0) {
 #pragma unroll
@@ -667,7 +667,7 @@ struct SlotCtx {
       const float sum = seqsum8(lane < k ? p : 0.0f);
       p = p / sum;
       if (is_root && root_noise && !seat_gumbel(seat)) { trace(1 | (static_cast<uint64_t>(k) << 8)); p = add_root_noise(k, p, seat_eps(seat)); trace(2); }
-      if (lane < k) ar.Pr[ci] = p;
+      if (lane < k) ar.nodes[ci].pr = p;
     }
     // backup: level i updates node_i (child of path[i]); levels are independent -> one lane each
     const float draw_share = val[P] / static_cast<int32_t>(P);
@@ -678,21 +678,21 @@ struct SlotCtx {
         if (base == 0) { node = node0; nn = nn0; pmeta = pmeta0; nmeta = nmeta0; q = q0; d = d0; }
         else {
           node = (i == plen - 1) ? cur : path[i + 1];
-          pmeta = ar.META[tb + path[i]]; nmeta = ar.META[tb + node];
-          nn = ar.N[tb + node]; q = ar.Q[tb + node]; d = ar.D[tb + node];
+          pmeta = ar.nodes[tb + path[i]].meta; nmeta = ar.nodes[tb + node].meta;
+          nn = ar.nodes[tb + node].n; q = ar.nodes[tb + node].q; d = ar.nodes[tb + node].d;
         }
         const uint32_t pp = meta_player(pmeta);
         const size_t ni = tb + node;
         float vv = (pp == 0) ? val[0] : val[1];
         if (P > 2) vv = val[pp];
         vv += draw_share;
-        ar.Q[ni] = (q * static_cast<float>(nn) + vv) / static_cast<float>(nn + 1);
-        ar.D[ni] = (d * static_cast<float>(nn) + val[P]) / static_cast<float>(nn + 1);
+        ar.nodes[ni].q = (q * static_cast<float>(nn) + vv) / static_cast<float>(nn + 1);
+        ar.nodes[ni].d = (d * static_cast<float>(nn) + val[P]) / static_cast<float>(nn + 1);
         if (nn == 0) {
           const uint32_t np = meta_player(nmeta);
-          ar.V[ni] = ((np == 0) ? val[0] : val[1]) + draw_share;
+          ar.nodes[ni].v = ((np == 0) ? val[0] : val[1]) + draw_share;
         }
-        ar.N[ni] = nn + 1;
+        ar.nodes[ni].n = nn + 1;
       }
     }
     if (lane == 0) {
@@ -700,10 +700,10 @@ struct SlotCtx {
       // the root is never a path NODE (nodes are children), so its N was not changed by the loop above
       if (rn == 0) {
         const uint32_t rp = meta_player(rmeta);
-        ar.V[ri] = ((rp == 0) ? val[0] : val[1]) + draw_share;
-        ar.D[ri] = val[P];
+        ar.nodes[ri].v = ((rp == 0) ? val[0] : val[1]) + draw_share;
+        ar.nodes[ri].d = val[P];
       }
-      ar.N[ri] = rn + 1;
+      ar.nodes[ri].n = rn + 1;
       ar.c_sims[slot] += 1;
     }
 #pragma unroll
@@ -834,11 +834,11 @@ struct SlotCtx {
     sync_lanes();
     const size_t tb = tree_base(seat);
     const uint32_t root = AZMI_SEL(t_root, seat);
-    const uint64_t meta = ar.META[tb + root];
+    const uint64_t meta = ar.nodes[tb + root].meta;
     uint32_t k = meta_nch(meta), c0 = meta_ch0(meta);
     if (k == 0 && !expand_node(seat, root, gs, meta, c0, k)) return false;
     uint32_t hit = 0xFFFFu;
-    if (lane < k && meta_mv(ar.META[tb + c0 + lane]) == move) hit = lane;
+    if (lane < k && meta_mv(ar.nodes[tb + c0 + lane].meta) == move) hit = lane;
     for (int off = 1; off < G; off <<= 1) hit = min(hit, __shfl_xor(hit, off, G));
     if (hit == 0xFFFFu) { raise(32u); return false; }  // "ahh, what is this move"
 #pragma unroll
@@ -853,11 +853,11 @@ struct SlotCtx {
     sync_lanes();
     const size_t tb = tree_base(seat);
     const uint32_t root = AZMI_SEL(t_root, seat);
-    if (ar.N[tb + root] == 0) return;
-    const uint64_t meta = ar.META[tb + root];
+    if (ar.nodes[tb + root].n == 0) return;
+    const uint64_t meta = ar.nodes[tb + root].meta;
     const uint32_t k = meta_nch(meta), c0 = meta_ch0(meta);
     const size_t ci = tb + c0 + lane;
-    float p = lane < k ? ar.Pr[ci] : 0.0f;
+    float p = lane < k ? ar.nodes[ci].pr : 0.0f;
     bool dirty = false;
     const float root_temp = seat_root_temp(seat);
     if (root_temp != 1.0f) {
@@ -867,7 +867,7 @@ struct SlotCtx {
       dirty = true;
     }
     if (noise && k > 0) { trace(3 | (static_cast<uint64_t>(k) << 8)); p = add_root_noise(k, p, seat_eps(seat)); trace(4); dirty = true; }
-    if (dirty && lane < k) ar.Pr[ci] = p;
+    if (dirty && lane < k) ar.nodes[ci].pr = p;
   }
 
   // ---- new game: GameData reset + fresh trees (play_manager.cc:214-230, 515-520) ------------------------
@@ -887,12 +887,12 @@ struct SlotCtx {
     const size_t tb = tree_base(cp);
     const bool capped = flags & kFlagCapped;
     const uint32_t root = AZMI_SEL(t_root, cp);
-    const uint64_t rmeta = ar.META[tb + root];
+    const uint64_t rmeta = ar.nodes[tb + root].meta;
     const uint32_t k = meta_nch(rmeta), c0 = meta_ch0(rmeta);
-    const uint32_t root_n = ar.N[tb + root];
+    const uint32_t root_n = ar.nodes[tb + root].n;
     const size_t ci = tb + c0 + lane;
     uint32_t n_l = 0, mv_l = 0; float q_l = 0, p_l = 0, d_l = 0;
-    if (lane < k) { n_l = ar.N[ci]; q_l = ar.Q[ci]; p_l = ar.Pr[ci]; d_l = ar.D[ci]; mv_l = meta_mv(ar.META[ci]); }
+    if (lane < k) { n_l = ar.nodes[ci].n; q_l = ar.nodes[ci].q; p_l = ar.nodes[ci].pr; d_l = ar.nodes[ci].d; mv_l = meta_mv(ar.nodes[ci].meta); }
     const uint32_t cnt_m = scatter_by_move<uint32_t>(k, mv_l, n_l);
     const float pol_m = scatter_by_move<float>(k, mv_l, p_l);
 
@@ -911,7 +911,7 @@ struct SlotCtx {
         const uint32_t ni = bcast(n_l, i); const float qi = bcast(q_l, i), di = bcast(d_l, i);
         if (ni > 0 && qi > q) { q = qi; d = di; found = true; }
       }
-      if (!found && root_n > 0) { q = ar.V[tb + root]; d = ar.D[tb + root]; }
+      if (!found && root_n > 0) { q = ar.nodes[tb + root].v; d = ar.nodes[tb + root].d; }
       const float w = q - d / static_cast<int32_t>(P);
       const float l = static_cast<float>(1.0 - static_cast<double>(w) - static_cast<double>(d));
       const double resign_val = 1.0 - static_cast<double>(ep.resign_percent);
@@ -933,7 +933,7 @@ struct SlotCtx {
           const uint32_t ni = bcast(n_l, i); const float qi = bcast(q_l, i), di = bcast(d_l, i);
           if (ni > 0 && qi > q) { q = qi; d = di; found = true; }
         }
-        if (!found && root_n > 0) { q = ar.V[tb + root]; d = ar.D[tb + root]; }
+        if (!found && root_n > 0) { q = ar.nodes[tb + root].v; d = ar.nodes[tb + root].d; }
         const float w = q - d / static_cast<int32_t>(P);
         const float l = static_cast<float>(1.0 - static_cast<double>(w) - static_cast<double>(d));
         const float v_self = w - l;
@@ -952,7 +952,7 @@ struct SlotCtx {
         chosen = gumbel_final_action(cp, k, mv_l, n_l, q_l, p_l, cnt_m, pol_m);   // G1 acting
       } else {   // G3 opt-in: sample from improved policy ^ (1 / temp)
         const bool in = lane < static_cast<uint32_t>(M);
-        float pg = gumbel_improved_policy(cp, k, mv_l, n_l, q_l, p_l, ar.V[tb + root]);
+        float pg = gumbel_improved_policy(cp, k, mv_l, n_l, q_l, p_l, ar.nodes[tb + root].v);
         if (temp != 1.0f && temp > 0.0f) {
           pg = in ? az_powf(pg, 1.0f / temp) : 0.0f;
           const float sg = seqsum(pg, M);
@@ -991,7 +991,7 @@ struct SlotCtx {
     }
     // history sample, play_manager.cc:407-424
     if (ep.history && !capped) {
-      const float target = ep.gumbel_hist ? gumbel_improved_policy(cp, k, mv_l, n_l, q_l, p_l, ar.V[tb + root])  // play_manager.cc:411-417
+      const float target = ep.gumbel_hist ? gumbel_improved_policy(cp, k, mv_l, n_l, q_l, p_l, ar.nodes[tb + root].v)  // play_manager.cc:411-417
                            : (ep.pruning && seat_eps(cp) > 0)
                                ? probs_pruned(1.0f, root_n, k, mv_l, n_l, q_l, p_l, cnt_m, pol_m)
                                : probs(1.0f, cnt_m, pol_m);

@@ -78,6 +78,18 @@ __host__ __device__ inline uint32_t seat_w1_pack(uint32_t cap_visits, uint32_t f
 
 constexpr uint32_t kPendingWords = 3;   // Connect4 pending history row: stones of player 0, of player 1, turn | player << 32
 
+// One tree node of the lane-group engine (Connect4) — struct Node, mcts.h:14-48, as one 32-byte record: the descent reads a
+// node's children as consecutive records (two 16-byte loads per child lane, 7 x 32 B contiguous) instead of five separate
+// arrays, which is also one base pointer in scalar registers instead of six.  The wide-game engine keeps the SoA arrays
+// below (its wavefront scans ONE field of up to ~250 children at a time).
+struct alignas(32) NodeRec {
+  uint32_t n;     // Node::n
+  float q, pr, d; // Node::q, policy, d
+  float v;        // Node::v
+  uint32_t pad;
+  uint64_t meta;  // children range, move, player, terminal code (meta_pack)
+};
+
 struct Control {  // small device control block, copied back by azmi_pm_poll
   uint32_t games_started;
   uint32_t games_completed;
@@ -129,7 +141,9 @@ struct EngineArrays {
   uint32_t* bump;         // next free node of the arena
   uint32_t* depth;        // MCTS::depth_
   uint64_t* tld;          // MCTS::total_leaf_depth_
-  // ---- node arrays, [trees * cap] ---------------------------------------------------
+  // ---- node records of the lane-group engine, [trees * cap] (NULL for the wide games) ----------------
+  NodeRec* nodes;
+  // ---- node arrays of the wide-game engine, [trees * cap] (NULL for Connect4) -------------------------
   uint32_t* N;            // Node::n
   float* Q;               // Node::q
   float* Pr;              // Node::policy

@@ -50,7 +50,7 @@ __global__ void k_mcts_find_leaf(EngineParams ep, EngineArrays ar, uint32_t* nif
     const uint32_t* path = ar.path;
     for (uint32_t i = 0; i < c.plen; ++i) {
       const uint32_t node = (i + 1 < c.plen) ? path[i + 1] : c.cur;
-      out_moves[i] = static_cast<int32_t>(meta_mv(ar.META[tb + node]));
+      out_moves[i] = static_cast<int32_t>(meta_mv(ar.nodes[tb + node].meta));
     }
     *out_len = c.plen;
     *status = ok ? 0 : -2;
@@ -69,7 +69,7 @@ __global__ void k_mcts_process_result(EngineParams ep, EngineArrays ar, uint32_t
   SlotCtx<GM> c(ep, ar, 0, lane);
   c.load();
   if (ar.sstate[0] == kSlotFresh) c.start_game();   // first call: empty tree (root = node 0, arena bump = 1)
-  const uint32_t term = meta_term(ar.META[c.tree_base(0) + c.cur]);
+  const uint32_t term = meta_term(ar.nodes[c.tree_base(0) + c.cur].meta);
   c.process_result(0, true, root_noise != 0);
   if (lane == 0)
     for (int i = 0; i <= P; ++i) value_out[i] = term ? ((static_cast<int>(term) - 1 == i) ? 1.0f : 0.0f) : ar.v[i];
@@ -117,7 +117,7 @@ __global__ void k_mcts_find_leaf_batched(EngineParams ep, EngineArrays ar, WuArr
     for (uint32_t i = 0; i < c.plen; ++i) {
       rec[i] = ar.path[i];
       const uint32_t node = (i + 1 < c.plen) ? ar.path[i + 1] : c.cur;
-      out_moves[i] = static_cast<int32_t>(meta_mv(ar.META[tb + node]));
+      out_moves[i] = static_cast<int32_t>(meta_mv(ar.nodes[tb + node].meta));
     }
     wu.ifl_plen[index] = c.plen; wu.ifl_cur[index] = c.cur;
     *out_len = c.plen;
@@ -142,7 +142,7 @@ __global__ void k_mcts_process_result_batched(EngineParams ep, EngineArrays ar, 
     for (uint32_t i = 0; i < c.plen; ++i) { ar.path[i] = rec[i]; --nif[rec[i]]; }
   }
   c.sync_lanes();
-  const uint32_t term = meta_term(ar.META[c.tree_base(0) + c.cur]);
+  const uint32_t term = meta_term(ar.nodes[c.tree_base(0) + c.cur].meta);
   c.process_result(0, true, root_noise != 0);
   if (lane == 0)
     for (int i = 0; i <= P; ++i) value_out[i] = term ? ((static_cast<int>(term) - 1 == i) ? 1.0f : 0.0f) : ar.v[i];
@@ -168,11 +168,11 @@ __global__ void k_mcts_query(EngineParams ep, EngineArrays ar, uint32_t kind, fl
   c.sync_lanes();
   const size_t tb = c.tree_base(0);
   const uint32_t root = c.t_root[0];
-  const uint64_t rmeta = ar.META[tb + root];
-  const uint32_t k = meta_nch(rmeta), c0 = meta_ch0(rmeta), root_n = ar.N[tb + root];
+  const uint64_t rmeta = ar.nodes[tb + root].meta;
+  const uint32_t k = meta_nch(rmeta), c0 = meta_ch0(rmeta), root_n = ar.nodes[tb + root].n;
   const size_t ci = tb + c0 + lane;
   uint32_t n_l = 0, mv_l = 0; float q_l = 0, p_l = 0, d_l = 0;
-  if (lane < k) { n_l = ar.N[ci]; q_l = ar.Q[ci]; p_l = ar.Pr[ci]; d_l = ar.D[ci]; mv_l = meta_mv(ar.META[ci]); }
+  if (lane < k) { n_l = ar.nodes[ci].n; q_l = ar.nodes[ci].q; p_l = ar.nodes[ci].pr; d_l = ar.nodes[ci].d; mv_l = meta_mv(ar.nodes[ci].meta); }
   const uint32_t cnt_m = c.template scatter_by_move<uint32_t>(k, mv_l, n_l);
   const float pol_m = c.template scatter_by_move<float>(k, mv_l, p_l);
   const bool in = lane < static_cast<uint32_t>(M);
@@ -186,7 +186,7 @@ __global__ void k_mcts_query(EngineParams ep, EngineArrays ar, uint32_t kind, fl
         const uint32_t ni = c.bcast(n_l, i); const float qi = c.bcast(q_l, i), di = c.bcast(d_l, i);
         if (ni > 0 && qi > q) { q = qi; d = di; found = true; }
       }
-      if (!found && root_n > 0) { q = ar.V[tb + root]; d = ar.D[tb + root]; }
+      if (!found && root_n > 0) { q = ar.nodes[tb + root].v; d = ar.nodes[tb + root].d; }
       const float w = q - d / static_cast<int32_t>(P);
       const float l = static_cast<float>(1.0 - static_cast<double>(w) - static_cast<double>(d));
       if (lane == 0) { out_f[0] = w; out_f[1] = l; out_f[2] = d; }
@@ -212,10 +212,10 @@ __global__ void k_mcts_query(EngineParams ep, EngineArrays ar, uint32_t kind, fl
       }
       break;
     }
-    case kQGumbelPolicy: { const float p = c.gumbel_improved_policy(0, k, mv_l, n_l, q_l, p_l, ar.V[tb + root]); if (in) out_f[lane] = p; break; }
+    case kQGumbelPolicy: { const float p = c.gumbel_improved_policy(0, k, mv_l, n_l, q_l, p_l, ar.nodes[tb + root].v); if (in) out_f[lane] = p; break; }
     case kQGumbelFinal: { const uint32_t a = c.gumbel_final_action(0, k, mv_l, n_l, q_l, p_l, cnt_m, pol_m); if (lane == 0) out_u[0] = a; break; }
     case kQAddRootNoise: {   // MCTS::add_root_noise on the current root priors
-      if (k > 0) { const float p = c.add_root_noise(k, p_l, c.seat_eps(0)); if (lane < k) ar.Pr[ci] = p; }
+      if (k > 0) { const float p = c.add_root_noise(k, p_l, c.seat_eps(0)); if (lane < k) ar.nodes[ci].pr = p; }
       break;
     }
     case kQApplyRootTemp: {  // MCTS::apply_root_policy_temp, mcts.cc:448-460
@@ -224,7 +224,7 @@ __global__ void k_mcts_query(EngineParams ep, EngineArrays ar, uint32_t kind, fl
         float p = lane < k ? az_powf(p_l, 1.0f / rt) : 0.0f;
         const float sum = c.seqsum(p, k);
         if (sum > 0.0f) p = p / sum;
-        if (lane < k) ar.Pr[ci] = p;
+        if (lane < k) ar.nodes[ci].pr = p;
       }
       break;
     }
@@ -232,11 +232,11 @@ __global__ void k_mcts_query(EngineParams ep, EngineArrays ar, uint32_t kind, fl
     case kQPrincipalVariation: {   // mcts.cc:676-715: most-visited child per ply (root: the Gumbel final action when Gumbel is on)
       uint32_t node = root, len = 0;
       for (uint32_t ply = 0; ply < arg; ++ply) {
-        const uint64_t m = ar.META[tb + node];
+        const uint64_t m = ar.nodes[tb + node].meta;
         const uint32_t kk = meta_nch(m), cc0 = meta_ch0(m);
         if (kk == 0) break;
         uint32_t nn = 0, mm = 0;
-        if (lane < kk) { nn = ar.N[tb + cc0 + lane]; mm = meta_mv(ar.META[tb + cc0 + lane]); }
+        if (lane < kk) { nn = ar.nodes[tb + cc0 + lane].n; mm = meta_mv(ar.nodes[tb + cc0 + lane].meta); }
         uint32_t best = 0xFFFFu;
         if (ply == 0 && c.seat_gumbel(0)) {
           const uint32_t a = c.gumbel_final_action(0, k, mv_l, n_l, q_l, p_l, cnt_m, pol_m);

@@ -8,14 +8,14 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "alphazero-pybind11_amd")); sys.path.insert(0, ROOT)
-os.environ.setdefault("AZMI_TRACE_SLOT", "517")
+os.environ.setdefault("AZMI_TRACE_SLOT", "17")
 os.environ.setdefault("AZMI_TRACE_AFTER", "30000")
 import torch
 import alphazero as az
 from alphazero import torch_net, _capi
 import bench
 
-K, Se = 4, 1024
+K, Se = 4, int(os.environ.get("TRACE_SLOTS_PER_SHARD", "1024"))
 pms, streams = [], []
 for i in range(K):
     pp = bench.selfplay_params(az, Se, 800, Se * 16, cache=8_000_000)
