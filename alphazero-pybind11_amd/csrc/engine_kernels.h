@@ -166,10 +166,12 @@ struct SlotCtx {
   __device__ __forceinline__ void sync_lanes() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
   __device__ __forceinline__ void trace(uint64_t tag) const {
     if (slot != ep.trace_slot || lane != 0) return;
+    // tags >= 100 are phase marks of the round kernel: they carry the 100 MHz wall clock instead of the stream position.
+    // The clock is read BEFORE the hook's own two loads, so a phase does not include the hook's latency (the loads still
+    // delay the traced wave by about a microsecond per mark: totals over many marks overstate the untraced kernel).
+    const uint64_t val = (tag & 0xFF) >= 100 ? wall_clock64() : rng.state;
     if (ar.ctl->rounds < ep.trace_after) return;
     const uint64_t n = ar.trace[0];
-    // tags >= 100 are phase marks of the round kernel: they carry the 100 MHz wall clock instead of the stream position
-    const uint64_t val = (tag & 0xFF) >= 100 ? wall_clock64() : rng.state;
     if (n + 1 < ep.trace_cap) { ar.trace[2 * (n + 1)] = tag; ar.trace[2 * (n + 1) + 1] = val; ar.trace[0] = n + 1; }
   }
 

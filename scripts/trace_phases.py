@@ -1,5 +1,7 @@
 """Phase timing of the round kernel for one slot (debug hook AZMI_TRACE_SLOT / AZMI_TRACE_AFTER): prints, per phase of
-k_round, the mean / p50 / p90 time in microseconds over the traced rounds of a steady-state bench-like run."""
+k_round, the mean / p50 / p90 time in microseconds over the traced rounds of a steady-state bench-like run.
+The hook itself costs the traced wave about a microsecond per mark (two loads, three stores), which lands in the NEXT
+phase: use the numbers to compare phases and versions, and the rocprof kernel time for absolute durations."""
 import ctypes as C
 import os
 import sys
