@@ -160,3 +160,37 @@ def test_full_size_tawlbwrdd_prefix_equals_the_oracle(oracle):
         assert n >= 4
         assert np.array_equal(rows[sel][:, 1:], orows[:n, 1:]), s
         assert np.array_equal(counts[sel], ocounts[:n]), s
+
+
+@pytest.mark.parametrize("playout_cap", [False, True])
+def test_full_size_benchmark_flags_sampled_slots_equal_the_oracle(oracle, playout_cap):
+    """the benchmarked configuration itself — bench.py's self-play flags (shaped Dirichlet noise, root temperature, FPU rule,
+    temperature decay, target pruning, resign with play-through; with and without playout-cap randomisation) at 4096 x 800
+    with the RANDOM evaluator: sampled slots replayed by the oracle, coin stream included."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import alphazero as az
+    import bench
+    pp = bench.selfplay_params(az, S, SIMS, S, cache=0, playout_cap=playout_cap)
+    pp.eval_type = [az.EvalType.RANDOM, az.EvalType.RANDOM]
+    seed = 424242
+    pm = az.PlayManager(az.Connect4GS(), pp, seed=seed, log_moves=True)
+    pm.play()
+    assert pm.games_completed() == S and pm.scores().sum() == S
+    rows, counts = pm.move_log()
+    capped = rows[:, 5] == 1
+    assert capped.any() == playout_cap
+    assert (counts[~capped].sum(1) >= SIMS - 1).all()
+    if playout_cap:
+        frac = capped.mean()
+        assert 0.70 < frac < 0.80                       # playout_cap_percent 0.75 of the moves search 25 simulations
+        assert pm.hist_count() == int((~capped).sum())  # only full searches are recorded
+    for s in np.random.default_rng(3).choice(S, 4, replace=False):
+        one = az.PlayParams(); one.__dict__.update(pp.__dict__)
+        one.games_to_play, one.concurrent_games = 1, 1
+        o = oracle.PlayManager(oracle.GAME_CONNECT4, one, oracle.slot_seed(seed, int(s)), per_slot_rng=False)
+        o.run()
+        orows, ocounts = o.moves()
+        sel = rows[:, 0] == s
+        assert np.array_equal(rows[sel][:, 1:], orows[:, 1:]), s
+        assert np.array_equal(counts[sel], ocounts), s
