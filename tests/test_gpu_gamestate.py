@@ -81,3 +81,22 @@ def test_tawlbwrdd_object_walk_matches_oracle(az, oracle):
     assert gs.current_turn() == og.turn() and gs.current_player() == og.player()
     s = str(gs)
     assert s.startswith("Current Player:") and "@" in s
+
+
+@pytest.mark.parametrize("name", ["TawlbwrddGS", "BrandubhGS", "OpenTaflGS"])
+def test_tafl_objects_pickle_and_copy_round_trip(az, name):
+    """py::pickle on the game classes (py_wrapper.cc:77-83): a pickled object comes back equal, with its repetition history
+    (the object is its start position + move list, so the history travels with it); copies are independent."""
+    import copy
+    g = getattr(az, name)()
+    rng = np.random.default_rng(1)
+    for _ in range(9):
+        legal = np.flatnonzero(g.valid_moves())
+        g.play_move(int(rng.choice(legal)))
+    back = pickle.loads(pickle.dumps(g))
+    assert back == g and az.hash_game_state(back) == az.hash_game_state(g)
+    assert np.array_equal(back.canonicalized(), g.canonicalized()) and np.array_equal(back.valid_moves(), g.valid_moves())
+    assert back.current_turn() == g.current_turn() == 9
+    c = copy.deepcopy(g)
+    c.play_move(int(np.flatnonzero(c.valid_moves())[0]))
+    assert c != g and g.current_turn() == 9
