@@ -304,8 +304,20 @@ def main():
         # rocprofv3 --pmc summary of this same command (scripts/gpu_pmc.sh -> profiles/r1_pmc_traffic.csv), per launch,
         # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on gfx950
         pmc = os.path.join(ROOT, "profiles", "r1_pmc_traffic.csv")
+        if not tafl:
+            # the second kernel of the path, the tree step (HBM side): algorithmic bytes per simulation from SURVEY §8d
+            # (select + backup + expand + state + canonical + eval rows = 1.3 KB with the measured depth 3.5 / 6.8 children)
+            b_sim = 1300.0
+            out["roofline_tree"] = {
+                "kernel": "k_round<Connect4>", "bound": "hbm", "achieved": b_sim * n_sims / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
+                "frac": b_sim * n_sims / dt / 1e9 / 8000.0, "traffic": None, "per_launch_event_ms": tree_ms,
+                "note": "latency-bound, not bandwidth-bound: one simulation is a chain of ~8 dependent memory round trips; "
+                        "the figure to watch is the per-launch time (profiles/r1_kernel_stats.csv)"}
         if not tafl and hip_net is not None and os.path.exists(pmc):
             for line in open(pmc):
+                if "k_round<azmi::Connect4" in line:
+                    f = line.strip().split(",")
+                    out["roofline_tree"]["traffic"] = (2.0 * float(f[-2]) + float(f[-1])) * 1024.0
                 if line.startswith("k_leafnet"):
                     f = line.strip().split(",")
                     out["roofline"]["traffic"] = (2.0 * float(f[-2]) + float(f[-1])) * 1024.0
