@@ -3,13 +3,14 @@
 // One lane-group of GM::GROUP lanes owns one game slot; 64/GROUP slots share a
 // wavefront.  Per-child work (the N/Q/P walk of PUCT select, prior
 // normalisation, expansion, backup levels) is spread over the group's lanes so
-// that consecutive lanes touch consecutive children of the SoA node arrays
-// (coalesced HBM reads); per-slot scalars (bitboards, pcg32 state) are computed
-// redundantly by every lane of the group, which keeps them group-uniform
-// without any cross-lane traffic.  Order-sensitive float reductions (the
-// reference sums priors in child order) are done by an in-order lane sweep with
-// DPP/bpermute shuffles; arg-max uses a butterfly with a (score, index) key so
-// the first index wins ties exactly like the reference's strict `>` scan.
+// that consecutive lanes touch consecutive 32-byte node records (NodeRec,
+// engine_types.h: coalesced reads, one base pointer); per-slot scalars
+// (bitboards, pcg32 state) are computed redundantly by every lane of the group,
+// which keeps them group-uniform without any cross-lane traffic.  Order-sensitive
+// float reductions (the reference sums priors in child order) on the hot path are
+// DPP row_shr sweeps (seqsum8), elsewhere ds_bpermute sweeps; arg-max reduces a
+// (score, index) key with DPP quad / half-row permutes so the first index wins
+// ties exactly like the reference's strict `>` scan.
 //
 // Reference behaviour restated here (file:line under /root/reference/src):
 //   Node::add_children        mcts.cc:93-101      -> expand_node
