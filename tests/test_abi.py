@@ -3,6 +3,7 @@ compute entry points fail loudly (no CPU fallback)."""
 import ctypes as C
 import os
 import re
+import sys
 
 import pytest
 
@@ -49,3 +50,16 @@ def test_host_side_validation_matches_reference_messages():
     assert az.Connect4GS.NUM_PLAYERS() == 2 and az.Connect4GS.NUM_MOVES() == 7
     assert az.Connect4GS.CANONICAL_SHAPE() == (4, 6, 7)
     assert az.tracy_is_enabled() is False
+
+
+def test_bench_cpu_baseline_leg_runs_on_the_oracle():
+    """bench.py's cpu_baseline leg (the only place outside tests/ and smoke() that may touch oracle/): a short multi-threaded
+    sample returns a consistent record."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "alphazero-pybind11_amd"))
+    import alphazero as az
+    import bench
+    r = bench.cpu_baseline(az, 100, 1.0, threads=2)
+    assert r["kind"] == "port" and r["unit"] == "games/s" and r["cores"] == 2
+    assert r["value"] > 0 and r["sims_per_s"] > 0
+    assert abs(r["per_thread_games_per_s"] * 2 - r["value"]) < 1e-6 * max(1.0, r["value"])
