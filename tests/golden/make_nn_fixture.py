@@ -138,8 +138,64 @@ def main_tawlbwrdd():
     print("LeafNet vs reference NNArch (tawlbwrdd): max |dv| =", float((v2 - v).abs().max()), " max |dpi| =", float((pi2 - pi).abs().max()))
 
 
+
+def _tafl_fixture(name, game_id, statics, args_kw, spec_fn, n_pos, out_name):
+    """One more reference NNArch fixture: `statics` = the game class surface NNArch reads, `args_kw` = the YAML's net keys."""
+    cls = type(name, (), {k: staticmethod((lambda v: (lambda: v))(v)) for k, v in statics.items()})
+    args = ref_nn.NNArgs(dense_net=False, kernel_size=3, spatial_policy="on", **args_kw)
+    torch.manual_seed(0)
+    net = ref_nn.NNArch(cls, args)
+    g = torch.Generator().manual_seed(1)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.2)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) * 1.0 + 0.5)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) * 0.8 + 0.6)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    net.eval()
+    rng = np.random.default_rng(6)
+    xs = []
+    while len(xs) < n_pos:
+        game = orc.Game(game_id)
+        for _ in range(int(rng.integers(0, 50))):
+            if game.scores() is not None:
+                break
+            game.play(int(rng.choice(np.flatnonzero(game.valid()))))
+        xs.append(game.canonical())
+    x = torch.from_numpy(np.stack(xs))
+    with torch.no_grad():
+        v, pi = net(x)
+        v, pi = torch.exp(v), torch.exp(pi)
+    out = {"input": x.numpy(), "v": v.numpy(), "pi": pi.numpy()}
+    for k, t in net.state_dict().items():
+        out["sd." + k] = t.numpy()
+    path = os.path.join(HERE, out_name)
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes;", sum(p.numel() for p in net.parameters()), "params")
+    sys.modules.pop("alphazero", None)
+    sys.path.insert(0, os.path.join(ROOT, "alphazero-pybind11_amd"))
+    from alphazero import torch_net
+    mine = torch_net.LeafNet(getattr(torch_net, spec_fn)())
+    mine.load_state_dict(net.state_dict())
+    v2, pi2 = mine.process(x)
+    print(f"LeafNet vs reference NNArch ({name}): max |dv| =", float((v2 - v).abs().max()), " max |dpi| =", float((pi2 - pi).abs().max()))
+
+
+def main_opentafl():
+    """configs/open_tafl.yaml: 4 blocks x 64 ch, head 64, one extra conv per head, v_fc_layers 2, spatial head; 8 planes."""
+    _tafl_fixture("OpenTafl", orc.GAME_OPENTAFL,
+                  dict(CANONICAL_SHAPE=(8, 11, 11), NUM_PLAYERS=2, NUM_MOVES=2662, POLICY_SHAPE=(22, 11, 11)),
+                  dict(num_channels=64, depth=4, head_channels=64, v_head_convs=1, pi_head_convs=1, v_fc_layers=2),
+                  "opentafl_spec", 12, "nn_opentafl_4b64c.npz")
+
+
+def main_brandubh():
+    """configs/brandubh.yaml: 4 blocks x 32 ch, head 32, one extra conv per head, v_fc_layers 2, spatial head; 7x7."""
+    _tafl_fixture("Brandubh", orc.GAME_BRANDUBH,
+                  dict(CANONICAL_SHAPE=(7, 7, 7), NUM_PLAYERS=2, NUM_MOVES=686, POLICY_SHAPE=(14, 7, 7)),
+                  dict(num_channels=32, depth=4, head_channels=32, v_head_convs=1, pi_head_convs=1, v_fc_layers=2),
+                  "brandubh_spec", 16, "nn_brandubh_4b32c.npz")
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "tawlbwrdd":
-        main_tawlbwrdd()
-    else:
-        main()
+    mode = sys.argv[1] if len(sys.argv) > 1 else "connect4"
+    {"connect4": main, "tawlbwrdd": main_tawlbwrdd, "opentafl": main_opentafl, "brandubh": main_brandubh}[mode]()

@@ -208,3 +208,41 @@ def test_opentafl_net_on_the_mfma_path(batch):
         vz, _ = net.process(x)
     if batch >= 64:
         assert (v - vz).abs().max().item() > 5 * dv
+
+
+# ---- the other two Tafl configs against the REFERENCE's NNArch (fixtures made by tests/golden/make_nn_fixture.py) ----------
+def _ref_fixture(fname, spec_fn):
+    from alphazero import torch_net
+    fx = np.load(os.path.join(HERE, "golden", fname))
+    net = torch_net.LeafNet(getattr(torch_net, spec_fn)())
+    net.load_state_dict({k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("sd.")})
+    return fx, net.eval()
+
+
+def test_opentafl_net_matches_reference_nnarch_fixture():
+    """configs/open_tafl.yaml net, weights and expected outputs produced by the reference's NNArch: the bf16 MFMA path within
+    the bf16 tolerance, the library's fp32 path within the north star's 1e-5."""
+    import alphazero as az
+    fx, net = _ref_fixture("nn_opentafl_4b64c.npz", "opentafl_spec")
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(fx["input"]).to(dev)
+    v, pi = az.HipLeafNet(net).process(x)
+    dv, dpi = np.abs(v.cpu().numpy() - fx["v"]).max(), np.abs(pi.cpu().numpy() - fx["pi"]).max()
+    print("opentafl hip bf16 vs reference fp32: %.3e %.3e" % (dv, dpi))
+    assert dv <= TOL and dpi <= TOL
+    v16, pi16 = net.to(dev).process(x, amp_dtype=torch.bfloat16)
+    e16 = max(np.abs(v16.cpu().numpy() - fx["v"]).max(), np.abs(pi16.cpu().numpy() - fx["pi"]).max())
+    assert max(dv, dpi) <= max(2 * e16, 5e-3), (dv, dpi, e16)
+    v32, pi32 = az.HipLeafNet(net.cpu(), precision="fp32").process(x)
+    assert np.abs(v32.cpu().numpy() - fx["v"]).max() <= TOL_F32 and np.abs(pi32.cpu().numpy() - fx["pi"]).max() <= TOL_F32
+
+
+def test_brandubh_net_matches_reference_nnarch_fixture():
+    """configs/brandubh.yaml net (4b32c, 7x7): the library's fp32 path against the reference NNArch's outputs, 1e-5."""
+    import alphazero as az
+    fx, net = _ref_fixture("nn_brandubh_4b32c.npz", "brandubh_spec")
+    x = torch.from_numpy(fx["input"]).to(torch.device("cuda:0"))
+    v32, pi32 = az.HipLeafNet(net, precision="fp32").process(x)
+    dv, dpi = np.abs(v32.cpu().numpy() - fx["v"]).max(), np.abs(pi32.cpu().numpy() - fx["pi"]).max()
+    print("brandubh hip fp32 vs reference fp32: %.3e %.3e" % (dv, dpi))
+    assert dv <= TOL_F32 and dpi <= TOL_F32

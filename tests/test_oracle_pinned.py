@@ -446,3 +446,19 @@ def test_batched_search_reference_cases():
         m.process_result_batched(4, v, pi)
     m.reset_batch()
     assert m.in_flight_count() == 0 and len(set(keys)) >= 3   # WUUCTDiversity
+
+
+@pytest.mark.parametrize("fname,spec_fn", [("nn_connect4_6b64c.npz", "connect4_spec"), ("nn_tawlbwrdd_4b64c.npz", "tawlbwrdd_spec"),
+                                            ("nn_opentafl_4b64c.npz", "opentafl_spec"), ("nn_brandubh_4b32c.npz", "brandubh_spec")])
+def test_torch_leafnet_reproduces_the_reference_nnarch_fixtures(fname, spec_fn):
+    """the package's PyTorch restatement of NNArch (alphazero/torch_net.py: the fp32 reference of the HIP nets) loads the
+    reference's state_dict and reproduces the reference's outputs bit for bit on the CPU (fixtures: make_nn_fixture.py)."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "alphazero-pybind11_amd"))
+    from alphazero import torch_net
+    fx = np.load(os.path.join(HERE, "golden", fname))
+    net = torch_net.LeafNet(getattr(torch_net, spec_fn)())
+    net.load_state_dict({k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("sd.")})
+    v, pi = net.eval().process(torch.from_numpy(fx["input"]))
+    assert np.abs(v.numpy() - fx["v"]).max() <= 1e-6 and np.abs(pi.numpy() - fx["pi"]).max() <= 1e-6
