@@ -100,3 +100,45 @@ def test_tafl_objects_pickle_and_copy_round_trip(az, name):
     c = copy.deepcopy(g)
     c.play_move(int(np.flatnonzero(c.valid_moves())[0]))
     assert c != g and g.current_turn() == 9
+
+
+# ---- the reference's pickle contract (test_game_pickle.py:19-170) for the four device games ---------------------------------
+def _play_first_valid(gs, n):
+    for _ in range(n):
+        if gs.scores() is not None:
+            break
+        idx = np.flatnonzero(np.asarray(gs.valid_moves()))
+        if len(idx) == 0:
+            break
+        gs.play_move(int(idx[0]))
+
+
+def _assert_state_equal(a, b):
+    assert np.array_equal(np.asarray(a.canonicalized()), np.asarray(b.canonicalized()))
+    assert a.current_player() == b.current_player() and a.current_turn() == b.current_turn()
+    assert np.array_equal(np.asarray(a.valid_moves()), np.asarray(b.valid_moves()))
+    sa, sb = a.scores(), b.scores()
+    assert (sa is None) == (sb is None)
+    if sa is not None:
+        assert np.array_equal(np.asarray(sa), np.asarray(sb))
+
+
+@pytest.mark.parametrize("name", ["Connect4GS", "BrandubhGS", "OpenTaflGS", "TawlbwrddGS"])
+def test_reference_pickle_contract(az, name):
+    make = getattr(az, name)
+    for moves in (0, 4, 20):                                  # initial state, short play, long play
+        gs = make(); _play_first_valid(gs, moves)
+        _assert_state_equal(gs, pickle.loads(pickle.dumps(gs)))
+    gs = make()                                               # chain: pickle, play, pickle, play ...
+    for _ in range(3):
+        _play_first_valid(gs, 3)
+        gs = pickle.loads(pickle.dumps(gs))
+    _assert_state_equal(gs, pickle.loads(pickle.dumps(gs)))
+    orig = make(); _play_first_valid(orig, 5)                 # continued play is identical (repetition counters travel)
+    back = pickle.loads(pickle.dumps(orig))
+    for _ in range(5):
+        if orig.scores() is not None:
+            break
+        m = int(np.flatnonzero(np.asarray(orig.valid_moves()))[0])
+        orig.play_move(m); back.play_move(m)
+        _assert_state_equal(orig, back)
