@@ -688,6 +688,13 @@ class GameData:
         check(lib.azmi_pm_slot_canonical(self._pm._h, self._i, out.ctypes.data))
         return out
 
+    @property
+    def perm_index(self):
+        """GameData::perm_index (play_manager.h:41): the seat permutation this slot's game runs under."""
+        w = np.zeros(8, np.uint64); n = C.c_uint32()
+        check(lib.azmi_pm_slot_state(self._pm._h, self._i, w.ctypes.data, 8, C.byref(n)))
+        return int(w[n.value - 1])
+
     def gs(self):
         pm = self._pm
         w = np.zeros(8, np.uint64); n = C.c_uint32()

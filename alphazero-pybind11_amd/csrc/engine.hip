@@ -879,11 +879,14 @@ int azmi_pm_slot_state(azmi_pm* pm, uint32_t slot, uint64_t* words, uint32_t cap
   if (!pm || !words || !n) return fail(AZMI_ERR_INVALID, "null argument");
   if (slot >= pm->ep.S) return fail(AZMI_ERR_RANGE, "game index %u out of range", slot);
   const uint32_t W = pm->gi.state_words;
-  if (cap < W) return fail(AZMI_ERR_INVALID, "words too small");
+  if (cap < W + 1) return fail(AZMI_ERR_INVALID, "words too small");
   HIP_TRY(hipStreamSynchronize(pm->last));
   for (uint32_t w = 0; w < W; ++w)
     HIP_TRY(hipMemcpy(words + w, pm->ar.gs_words + static_cast<size_t>(w) * pm->ep.S + slot, 8, hipMemcpyDeviceToHost));
-  *n = W;
+  uint32_t perm = 0;
+  HIP_TRY(hipMemcpy(&perm, pm->ar.perm + slot, 4, hipMemcpyDeviceToHost));
+  words[W] = perm;      // GameData::perm_index, play_manager.h:41
+  *n = W + 1;
   return AZMI_OK;
 }
 

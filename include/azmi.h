@@ -176,7 +176,8 @@ int azmi_pm_stopped(azmi_pm* pm, int* out);
 int azmi_pm_queue_counts(azmi_pm* pm, uint32_t* awaiting_inference, uint32_t* awaiting_mcts);
 /* game_data(i).gs, play_manager.h:286: the packed state of the game in slot i.  Connect4: words = {stones of player 0, stones
  * of player 1 (bit h*7+w), turn | player << 32}; Tafl family: {defenders lo, hi, attackers lo, hi (bit = square),
- * king square | turn << 8 | player << 24 | repetition count << 32}.  AZMI_ERR_RANGE for a bad index. */
+ * king square | turn << 8 | player << 24 | repetition count << 32}; one more word follows: GameData::perm_index, the seat
+ * permutation the slot's game runs under (play_manager.h:41).  `cap` >= state words + 1.  AZMI_ERR_RANGE for a bad index. */
 int azmi_pm_slot_state(azmi_pm* pm, uint32_t slot, uint64_t* words, uint32_t cap, uint32_t* n);
 /* game_data(i).canonical(), py_wrapper.cc:279-288: the leaf planes slot i is waiting on, to a HOST array [C,H,W] */
 int azmi_pm_slot_canonical(azmi_pm* pm, uint32_t slot, float* out);

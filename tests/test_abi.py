@@ -63,3 +63,31 @@ def test_bench_cpu_baseline_leg_runs_on_the_oracle():
     assert r["kind"] == "port" and r["unit"] == "games/s" and r["cores"] == 2
     assert r["value"] > 0 and r["sims_per_s"] > 0
     assert abs(r["per_thread_games_per_s"] * 2 - r["value"]) < 1e-6 * max(1.0, r["value"])
+
+
+def _pm_params(az, **kw):
+    pp = az.PlayParams()
+    pp.games_to_play, pp.concurrent_games = 4, 2
+    pp.mcts_visits = [10, 10]
+    pp.eval_type = [az.EvalType.RANDOM, az.EvalType.RANDOM]
+    for k, v in kw.items():
+        setattr(pp, k, v)
+    return pp
+
+
+@pytest.mark.parametrize("field,value", [
+    ("seat_epsilon", [[0.25, 0.0], [0.0, 0.25]]),                 # play_manager_test.cc:74  SeatEpsilonWrongOuterDimThrows
+    ("seat_epsilon", [[0.25, 0.0, 0.1]]),                          # :87  SeatEpsilonWrongInnerDimThrows
+    ("seat_visits", [[10, 10], [10, 10], [10, 10]]),               # :100 SeatVisitsWrongDimThrows
+    ("seat_gumbel_use_improved_policy", [[1, 0], [0, 1]]),         # :190 SeatGumbelUseImprovedPolicyWrongDimThrows
+    ("seat_gumbel_use_improved_policy", [[1, 0, 1]]),              # :203 ...InnerDimThrows
+    ("seat_resign_threshold", [[-0.9, -0.9], [-0.9, -0.9]]),       # :216 SeatResignThresholdWrongDimThrows
+    ("seat_resign_consecutive", [[3, 3, 3]]),                      # :228 SeatResignConsecutiveWrongDimThrows
+])
+def test_reference_seat_matrix_dimension_errors(field, value):
+    """the reference's own PlayManager constructor tests for mis-shaped per-seat matrices (play_manager_test.cc:74-238): the
+    host side rejects them with the reference's message (play_manager.cc:57-68) before anything touches a device."""
+    sys.path.insert(0, os.path.join(ROOT, "alphazero-pybind11_amd"))
+    import alphazero as az
+    with pytest.raises(RuntimeError, match=f"{field} (outer dimension must match number of seat permutations|inner dimension must match number of players)"):
+        az.PlayManager(az.Connect4GS(), _pm_params(az, **{field: value}))
