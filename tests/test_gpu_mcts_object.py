@@ -243,3 +243,45 @@ def test_batched_parity_with_oracle(az, oracle, name, batch, cfg):
         gs.play_move(move); og.play(move)
         if gs.scores() is not None:
             break
+
+
+# ---- the reference's principal_variation tests (test_principal_variation.py:19-152), same calls, same assertions -----------
+def _ref_make_mcts(az, Game, gumbel_enabled=False):
+    # the 14-argument constructor overload, positionally (py_wrapper.cc:196-197)
+    return az.MCTS(1.25, Game.NUM_PLAYERS(), Game.NUM_MOVES(), 0.0, 1.0, 0.25, Game().relative_values(), False, False,
+                   bool(gumbel_enabled), 16, 50.0, 1.0, False)
+
+
+def _ref_uniform_sims(mcts, gs, n):
+    P = gs.num_players()
+    uniform_v = np.full(P + 1, 1.0 / (P + 1))                 # float64, like the reference test
+    for i in range(n):
+        leaf = mcts.find_leaf(gs)
+        if leaf.scores() is not None:
+            v = np.array(leaf.scores()); pi = np.zeros(gs.num_moves())
+        else:
+            v = uniform_v; pi = np.ones(gs.num_moves()) / gs.num_moves()
+        mcts.process_result(gs, v, pi, i == 0)
+
+
+def test_reference_principal_variation_cases(az):
+    Game = az.Connect4GS
+    assert list(_ref_make_mcts(az, Game).principal_variation(0)) == []            # depth zero
+    assert list(_ref_make_mcts(az, Game).principal_variation(5)) == []            # no simulations
+    gs = Game(); m = _ref_make_mcts(az, Game); _ref_uniform_sims(m, gs, 100)       # root = visit arg-max under PUCT
+    pv = list(m.principal_variation(5))
+    assert len(pv) >= 1 and pv[0] == int(np.argmax(np.array(m.counts())))
+    gs = Game(); m = _ref_make_mcts(az, Game); _ref_uniform_sims(m, gs, 200)       # depth cap
+    short, long_ = list(m.principal_variation(3)), list(m.principal_variation(10))
+    assert len(short) <= 3 and len(long_) >= len(short)
+    gs = Game(); m = _ref_make_mcts(az, Game); _ref_uniform_sims(m, gs, 3)         # stops at unvisited nodes
+    assert len(list(m.principal_variation(10))) <= 3
+    gs = Game(); m = _ref_make_mcts(az, Game, gumbel_enabled=True)                 # Gumbel: the root follows gumbel_final_action
+    m.set_gumbel_num_sims(64); _ref_uniform_sims(m, gs, 64)
+    pv = list(m.principal_variation(3))
+    assert len(pv) >= 1 and pv[0] == int(m.gumbel_final_action())
+    gs = Game(); m = _ref_make_mcts(az, Game); _ref_uniform_sims(m, gs, 30)        # valid move ids
+    assert all(0 <= int(x) < gs.num_moves() for x in m.principal_variation(4))
+    gs = Game(); m = _ref_make_mcts(az, Game); _ref_uniform_sims(m, gs, 50)        # first move legal at the start position
+    pv = list(m.principal_variation(1))
+    assert len(pv) == 1 and np.array(gs.valid_moves())[pv[0]] == 1
