@@ -760,6 +760,8 @@ class PlayManager:
             for i, c in enumerate(self._caches):
                 if c is not None and not isinstance(c, ShardedS3FIFOCache):
                     raise TypeError("caches must hold ShardedS3FIFOCache objects or None")
+                if c is not None:
+                    c._ensure_engine_layout()
                 arr[i] = None if c is None else c._h
             check(lib.azmi_pm_create_with_caches(game_id, C.byref(cparams), C.byref(opts), arr, len(self._caches), C.byref(h)))
         self._h = h
@@ -860,7 +862,10 @@ class PlayManager:
     def cache_evictions(self): return self._cache_stats()[2]
     def cache_reinserts(self): return self._cache_stats()[3]
     def cache_size(self): return self._cache_stats()[4]
-    def cache_max_size(self): return self._cache_stats()[5]
+    def cache_max_size(self):
+        if self._caches is not None:      # external caches report the size they were created with (see _ensure_engine_layout)
+            return sum(c.max_size() for c in self._caches if c is not None)
+        return self._cache_stats()[5]
 
     # per-variant tables (play_manager.h:218-275) exist only for multi-variant games; none of the device games has variants
     def num_tracked_variants(self): return 0
@@ -1032,11 +1037,35 @@ class ShardedS3FIFOCache:
         if rc != 0:
             raise RuntimeError(lib.azmi_cache_last_error().decode())
         self._h, self._np, self._nv = h, num_policy, num_value
+        self._args = (int(max_size), int(shards), int(ghost_size), int(device))
+        self._nominal_max = None      # set when the cache was re-laid out for an engine (see _ensure_engine_layout)
 
     def __del__(self):
         if getattr(self, "_h", None) and lib is not None:
             lib.azmi_cache_destroy(self._h)
             self._h = None
+
+    def _ensure_engine_layout(self):
+        """Called when the cache is handed to a PlayManager: the engine probes 64-entry shards, the reference's callers pass
+        any `shards` (cache_utils.create_sharded_cache defaults to 1).  A cache that has not been used yet is re-created in
+        the engine's layout behind the same object (capacity rounded down to a multiple of 64; max_size() keeps reporting
+        the requested size, like the reference's own shard rounding); one that already holds entries cannot be converted."""
+        max_size, shards, ghost, device = self._args
+        if max_size // max(1, shards) == 64:
+            return
+        st = self._stats()
+        if st[0] or st[1] or st[4]:
+            raise RuntimeError("this cache has been used with another shard layout; create it with ShardedS3FIFOCache.for_engine "
+                               "before the first use to share it with a PlayManager")
+        new_shards = max(1, max_size // 64)
+        h = C.c_void_p()
+        rc = lib.azmi_cache_create(new_shards * 64, new_shards, max(0, min(ghost, new_shards * 64)), self._np, self._nv, device, C.byref(h))
+        if rc != 0:
+            raise RuntimeError(lib.azmi_cache_last_error().decode())
+        lib.azmi_cache_destroy(self._h)
+        self._h = h
+        self._nominal_max = (max_size // max(1, shards)) * max(1, shards)
+        self._args = (new_shards * 64, new_shards, ghost, device)
 
     @classmethod
     def for_engine(cls, max_size, num_policy, num_value, device=0):
@@ -1078,7 +1107,7 @@ class ShardedS3FIFOCache:
     def evictions(self): return self._stats()[2]
     def reinserts(self): return self._stats()[3]
     def size(self): return self._stats()[4]
-    def max_size(self): return self._stats()[5]
+    def max_size(self): return self._nominal_max if self._nominal_max is not None else self._stats()[5]
 
 
 def hash_game_state(gs):

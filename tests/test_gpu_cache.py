@@ -222,9 +222,41 @@ def test_playmanager_external_cache_none_entries_and_errors():
     pm = az.PlayManager(az.Connect4GS(), pp, caches=[nn_cache, None], seed=3)
     pm.play()
     assert pm.games_completed() == 8 and pm.cache_max_size() == 1024
-    with pytest.raises(RuntimeError, match="64-entry shards"):
-        az.PlayManager(az.Connect4GS(), pp, caches=[az.ShardedS3FIFOCache(1000, 1, 900, 7, 3), None])
+    used = az.ShardedS3FIFOCache(1000, 1, 900, 7, 3)
+    used.insert(5, np.zeros(7, np.float32), np.zeros(3, np.float32))
+    with pytest.raises(RuntimeError, match="another shard layout"):          # a cache that already holds entries cannot be re-laid out
+        az.PlayManager(az.Connect4GS(), pp, caches=[used, None])
     with pytest.raises(RuntimeError, match="num_policy"):
         az.PlayManager(az.Connect4GS(), pp, caches=[az.ShardedS3FIFOCache.for_engine(1024, 9, 3), None])
     with pytest.raises(RuntimeError, match="model groups"):
         az.PlayManager(az.Connect4GS(), pp, caches=[nn_cache])
+
+
+def test_reference_cache_utils_style_caches_attach_to_a_playmanager():
+    """test_cache.py:259-300, 473-488: caches as the reference's helpers create them — any shard count, 1 by default
+    (cache_utils.create_sharded_cache) — work as PlayManager caches; cache_max_size() is the sum of the requested sizes."""
+    import alphazero as az
+    c = az.ShardedS3FIFOCache(1000, 2, 900, 7, 3)
+    assert (c.size(), c.max_size(), c.hits(), c.misses(), c.evictions(), c.reinserts()) == (0, 1000, 0, 0, 0, 0)
+    cache1 = az.ShardedS3FIFOCache(3000, 1, 2700, 7, 3)          # create_sharded_cache(Game, 3000)
+    cache2 = az.ShardedS3FIFOCache(5000, 1, 4500, 7, 3)
+    pp = _c4_params(az, games=4)
+    pp.model_groups = [0, 1]
+    pm = _play_two_groups(az, pp, [cache1, cache2])
+    assert pm.games_completed() == 4
+    assert pm.cache_max_size() == 3000 + 5000 and cache1.max_size() == 3000
+    assert cache1.size() > 0 and cache2.size() > 0 and cache1.misses() > 0
+    again = _play_two_groups(az, pp, [cache1, cache2])                         # the same objects again: warm
+    assert again.counters()["evals"] < pm.counters()["evals"]
+
+
+def _play_two_groups(az, pp, caches):
+    pm = az.PlayManager(az.Connect4GS(), pp, caches=caches, seed=21)
+    batch = np.zeros((int(pp.concurrent_games), 4, 6, 7), np.float32)
+    while pm.remaining_games() > 0:
+        for g in range(2):
+            idx = pm.build_batch(g, batch)
+            if idx:
+                v, pi = _evaluator(batch[: len(idx)])
+                pm.update_inferences(g, idx, v, pi)
+    return pm
