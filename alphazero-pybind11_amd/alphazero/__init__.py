@@ -782,8 +782,18 @@ class PlayManager:
         return self._params
 
     def play(self):
-        """PlayManager::play (play_manager.cc:258-600) for RANDOM-eval seats: runs to completion."""
-        check(lib.azmi_pm_play(self._h, _ENGINE_STREAM))
+        """PlayManager::play (play_manager.cc:258-600).  Engines whose seats need no net (RANDOM / PLAYOUT) run to completion
+        here; any number of threads may call it at once, like the reference's mcts_workers.  With NN seats the engine is
+        driven by whoever calls build_batch / update_inferences (the reference's batcher threads), so a worker thread that
+        calls play() just waits for the games to finish or for stop(), as the reference's workers do when they find
+        their queue empty."""
+        rc = lib.azmi_pm_play(self._h, _ENGINE_STREAM)
+        if rc == -5:                                       # AZMI_ERR_STATE: NN seats
+            import time
+            while self.remaining_games() > 0 and not self.stopped():
+                time.sleep(0.0005)
+            return
+        check(rc)
 
     def games_completed(self):
         done, live = C.c_uint32(), C.c_uint32()

@@ -15,6 +15,7 @@
 
 #include "../../include/azmi.h"
 #include <atomic>
+#include <mutex>
 
 #include "cache_host.h"
 #include "engine_kernels.h"
@@ -100,7 +101,11 @@ struct azmi_pm {
   std::deque<uint32_t> pending;        // slots whose leaf waits for the net
   std::vector<float> host_v, host_pi;  // mirrors of the slot-indexed rows
   uint32_t outstanding = 0;
-  std::atomic<bool> stopped{false};    // PlayManager::stop(), play_manager.h:177 (may be set from another thread)
+  std::atomic<bool> stopped{false};
+  // The reference's callers reach one PlayManager from several Python threads (mcts_workers x play(), batcher threads with
+  // build_batch / update_inferences, the main thread with counters): every entry point that touches the engine's host state
+  // takes this lock, so such callers are serialised instead of racing.  (Recursive: entry points call each other.)
+  std::recursive_mutex mu;    // PlayManager::stop(), play_manager.h:177 (may be set from another thread)
 
   template <class T>
   int alloc(T*& p, size_t n, bool zero) {
@@ -729,6 +734,7 @@ void azmi_pm_destroy(azmi_pm* pm) {
 
 int azmi_pm_round(azmi_pm* pm, void* stream) {
   if (!pm) return fail(AZMI_ERR_INVALID, "null pm");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   return launch_round(pm, pm->pick(stream));
 }
 
@@ -795,6 +801,7 @@ int azmi_run_rounds(azmi_pm* const* pms, azmi_net* net, uint32_t k, uint32_t rou
 
 int azmi_pm_net_forward(azmi_pm* pm, azmi_net* net, void* stream) {
   if (!pm || !net) return fail(AZMI_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   for (uint32_t g = 0; g < pm->ep.num_groups; ++g) {   // the same net for every model group
     const int rc = pm_net_forward(pm, g, net, pm->pick(stream));
     if (rc != AZMI_OK) return rc;
@@ -804,6 +811,7 @@ int azmi_pm_net_forward(azmi_pm* pm, azmi_net* net, void* stream) {
 
 int azmi_pm_net_forward_group(azmi_pm* pm, uint32_t group, azmi_net* net, void* stream) {
   if (!pm || !net) return fail(AZMI_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   if (group >= pm->ep.num_groups) return fail(AZMI_ERR_INVALID, "model group %u out of range", group);
   return pm_net_forward(pm, group, net, pm->pick(stream));
 }
@@ -817,6 +825,7 @@ int azmi_pm_groups(azmi_pm* pm, uint32_t* num_model_groups, uint32_t* num_seat_p
 
 int azmi_pm_perm_scores(azmi_pm* pm, uint32_t perm, float* out_scores, uint32_t* games_completed) {
   if (!pm) return fail(AZMI_ERR_INVALID, "null pm");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   if (perm >= pm->ep.num_perms) return fail(AZMI_ERR_INVALID, "seat permutation %u out of range", perm);
   const uint32_t S = pm->ep.S, V = pm->gi.P + 1, NP = pm->ep.num_perms;
   std::vector<float> a; std::vector<uint32_t> g;
@@ -840,6 +849,7 @@ int azmi_pm_io_buffers(azmi_pm* pm, float** dev_canonical, float** dev_v, float*
 
 int azmi_pm_poll(azmi_pm* pm, void* stream, uint32_t* games_completed, uint32_t* live_slots) {
   if (!pm) return fail(AZMI_ERR_INVALID, "null pm");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   Control c;
   const int rc = read_ctl(pm, pm->pick(stream), &c, true);
   if (rc != AZMI_OK) return rc;
@@ -863,6 +873,7 @@ int azmi_pm_stopped(azmi_pm* pm, int* out) {
 // slots that hold their answer (or need none) and wait for the next round
 int azmi_pm_queue_counts(azmi_pm* pm, uint32_t* awaiting_inference, uint32_t* awaiting_mcts) {
   if (!pm) return fail(AZMI_ERR_INVALID, "null pm");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   Control c;
   const int rc = read_ctl(pm, pm->last, &c, true);
   if (rc != AZMI_OK) return rc;
@@ -877,6 +888,7 @@ int azmi_pm_queue_counts(azmi_pm* pm, uint32_t* awaiting_inference, uint32_t* aw
 // turn | player << 32; Tafl family: defenders lo/hi, attackers lo/hi, king | turn << 8 | player << 24 | repetitions << 32)
 int azmi_pm_slot_state(azmi_pm* pm, uint32_t slot, uint64_t* words, uint32_t cap, uint32_t* n) {
   if (!pm || !words || !n) return fail(AZMI_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   if (slot >= pm->ep.S) return fail(AZMI_ERR_RANGE, "game index %u out of range", slot);
   const uint32_t W = pm->gi.state_words;
   if (cap < W + 1) return fail(AZMI_ERR_INVALID, "words too small");
@@ -893,6 +905,7 @@ int azmi_pm_slot_state(azmi_pm* pm, uint32_t slot, uint64_t* words, uint32_t cap
 // game_data(i).canonical(): the planes of the leaf slot `slot` is waiting on (host array [C,H,W])
 int azmi_pm_slot_canonical(azmi_pm* pm, uint32_t slot, float* out) {
   if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   if (slot >= pm->ep.S) return fail(AZMI_ERR_RANGE, "game index %u out of range", slot);
   const size_t CANON = static_cast<size_t>(pm->gi.C) * pm->gi.H * pm->gi.W;
   HIP_TRY(hipStreamSynchronize(pm->last));
@@ -906,6 +919,9 @@ int azmi_pm_play(azmi_pm* pm, void* stream) {
   hipStream_t st = pm->pick(stream);
   for (;;) {
     if (pm->stopped.load(std::memory_order_relaxed)) return AZMI_OK;   // play_manager.cc:272
+    // several threads may sit in play() at once (the reference starts mcts_workers of them): each takes the engine for a
+    // chunk of rounds, all of them return when the games are done
+    std::lock_guard<std::recursive_mutex> lock_(pm->mu);
     for (int r = 0; r < 32; ++r) {
       const int rc = launch_round(pm, st);
       if (rc != AZMI_OK) return rc;
@@ -919,6 +935,7 @@ int azmi_pm_play(azmi_pm* pm, void* stream) {
 
 int azmi_pm_scores(azmi_pm* pm, float* out) {
   if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   std::vector<float> a;
   const uint32_t V = pm->gi.P + 1;
   const int rc = d2h(a, pm->ar.a_scores, static_cast<size_t>(pm->ep.S) * V, pm->last);
@@ -929,6 +946,7 @@ int azmi_pm_scores(azmi_pm* pm, float* out) {
 }
 int azmi_pm_resign_scores(azmi_pm* pm, float* out) {
   if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   std::vector<float> a;
   const uint32_t V = pm->gi.P + 1;
   const int rc = d2h(a, pm->ar.a_resign, static_cast<size_t>(pm->ep.S) * V, pm->last);
@@ -940,6 +958,7 @@ int azmi_pm_resign_scores(azmi_pm* pm, float* out) {
 
 int azmi_pm_stats(azmi_pm* pm, float* out) {  // play_manager.h:288-315
   if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   const uint32_t S = pm->ep.S;
   std::vector<uint64_t> len, cnt; std::vector<double> ds; std::vector<uint32_t> games;
   int rc = d2h(len, pm->ar.a_len, S, pm->last); if (rc) return rc;
@@ -965,6 +984,7 @@ int azmi_pm_stats(azmi_pm* pm, float* out) {  // play_manager.h:288-315
 // cache_hits / misses / evictions / reinserts / size / max_size summed over the model groups' caches (play_manager.h:325-366)
 int azmi_pm_cache_stats(azmi_pm* pm, uint64_t out[6]) {
   if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   for (int i = 0; i < 6; ++i) out[i] = 0;
   if (!pm->ep.cache_on) return AZMI_OK;
   for (uint32_t g = 0; g < pm->ep.num_groups; ++g) {
@@ -984,6 +1004,7 @@ int azmi_pm_cache_stats(azmi_pm* pm, uint64_t out[6]) {
 
 int azmi_pm_counters(azmi_pm* pm, uint64_t* out) {
   if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   const uint32_t S = pm->ep.S;
   std::vector<uint64_t> sims, evals;
   int rc = d2h(sims, pm->ar.c_sims, S, pm->last); if (rc) return rc;
@@ -1002,6 +1023,7 @@ int azmi_pm_counters(azmi_pm* pm, uint64_t* out) {
 
 int azmi_pm_pop_history(azmi_pm* pm, float* canonical, float* v, float* pi, uint32_t cap, uint32_t* n) {
   if (!pm || !n) return fail(AZMI_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   Control c;
   int rc = read_ctl(pm, pm->last, &c, true); if (rc) return rc;
   const uint32_t avail = std::min(c.hist_rows, pm->ep.hist_cap) - pm->hist_read;
@@ -1021,6 +1043,7 @@ int azmi_pm_pop_history(azmi_pm* pm, float* canonical, float* v, float* pi, uint
 int azmi_pm_history_device(azmi_pm* pm, float** dev_canonical, float** dev_v, float** dev_pi, uint32_t** dev_meta,
                            uint32_t* rows) {
   if (!pm) return fail(AZMI_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   Control c;
   int rc = read_ctl(pm, pm->last, &c, true); if (rc) return rc;
   if (dev_canonical) *dev_canonical = pm->ar.h_canon;
@@ -1033,6 +1056,7 @@ int azmi_pm_history_device(azmi_pm* pm, float** dev_canonical, float** dev_v, fl
 
 int azmi_pm_move_log(azmi_pm* pm, uint32_t* rows, uint32_t* counts, uint32_t cap, uint32_t* n) {
   if (!pm || !n) return fail(AZMI_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   if (!pm->ep.log_moves) return fail(AZMI_ERR_STATE, "move log was not enabled (azmi_engine_opts.log_moves)");
   Control c;
   int rc = read_ctl(pm, pm->last, &c, true); if (rc) return rc;
@@ -1068,6 +1092,7 @@ int azmi_debug_trace(azmi_pm* pm, uint64_t* out, uint32_t cap, uint32_t* n) {
 
 int azmi_pm_slot_games(azmi_pm* pm, uint32_t* out) {
   if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   std::vector<uint32_t> g;
   const int rc = d2h(g, pm->ar.slot_games, pm->ep.S, pm->last);
   if (rc) return rc;
@@ -1083,6 +1108,7 @@ int azmi_pm_build_batch(azmi_pm* pm, float* batch, uint32_t cap, uint32_t* indic
 // group == 0xFFFFFFFF: leaves of any model group (single-evaluator callers)
 int azmi_pm_build_batch_group(azmi_pm* pm, uint32_t group, float* batch, uint32_t cap, uint32_t* indices, uint32_t* n) {
   if (!pm || !indices || !n) return fail(AZMI_ERR_INVALID, "null argument");   // batch == NULL: pop_games_upto (indices only)
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   *n = 0;
   if (cap == 0 || pm->stopped.load(std::memory_order_relaxed)) return AZMI_OK;
   if (group != 0xFFFFFFFFu && group >= pm->ep.num_groups) return fail(AZMI_ERR_INVALID, "model group %u out of range", group);
@@ -1133,6 +1159,7 @@ int azmi_pm_build_batch_group(azmi_pm* pm, uint32_t group, float* batch, uint32_
 
 int azmi_pm_update_inferences(azmi_pm* pm, const uint32_t* indices, uint32_t n, const float* v, const float* pi) {
   if (!pm || (n && (!indices || !v || !pi))) return fail(AZMI_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   const uint32_t S = pm->ep.S, V = pm->gi.P + 1, M = pm->gi.M;
   if (n > pm->outstanding) return fail(AZMI_ERR_STATE, "update_inferences: more rows than build_batch handed out");
   // rows go straight to the slot-indexed device buffers: rows of other slots (cache hits written by the round

@@ -81,3 +81,35 @@ def test_aggressive_resign_terminates_games(az):      # AggressiveResignTerminat
     rows, _ = pm.move_log()
     assert len(rows) == 8 and (rows[:, 3] == 0).all()  # ... at the very first move
     assert pm.scores()[1] == 8                        # the first mover resigns: the opponent is credited
+
+
+def test_seat_visits_overrides_visit_count_with_worker_threads(az):
+    """test_cache.py:543-592: PLAYOUT evaluators, one model group on both seats, seat_visits 200 vs 1 swapped by the
+    permutation, TWO worker threads in play() at once: the seat with 200 visits wins more in both permutations."""
+    pp = _params(az, 64, 8, max_batch_size=8, mcts_visits=[200, 1], eval_type=[az.EvalType.PLAYOUT] * 2, model_groups=[0, 0],
+                 seat_perms=[[0, 0], [0, 0]], seat_visits=[[200, 1], [1, 200]], cpuct=1.25, fpu_reduction=0.25)
+    pm = az.PlayManager(az.Connect4GS(), pp, seed=4)
+    workers = [threading.Thread(target=pm.play) for _ in range(2)]
+    for t in workers: t.start()
+    for t in workers: t.join()
+    assert pm.games_completed() == 64
+    p0, p1 = pm.perm_scores(0), pm.perm_scores(1)
+    assert pm.perm_games_completed(0) + pm.perm_games_completed(1) == 64
+    assert p0[0] > p0[1] and p1[1] > p1[0]
+
+
+def test_play_with_nn_seats_waits_for_the_batcher(az):
+    """the GameRunner shape (game_runner.py:651-726): worker threads sit in play() while a batcher thread drives
+    build_batch / update_inferences; everybody returns when the games are done."""
+    pp = _params(az, 12, 6, max_batch_size=6, mcts_visits=[16, 16], eval_type=[], model_groups=[0, 0])
+    pm = az.PlayManager(az.Connect4GS(), pp, seed=6)
+    workers = [threading.Thread(target=pm.play) for _ in range(3)]
+    for t in workers: t.start()
+    batch = np.zeros((6, 4, 6, 7), np.float32)
+    while pm.remaining_games() > 0:
+        idx = pm.build_batch(0, batch)
+        if idx:
+            n = len(idx)
+            pm.update_inferences(0, idx, np.full((n, 3), 1 / 3, np.float32), np.full((n, 7), 1 / 7, np.float32))
+    for t in workers: t.join(timeout=10)
+    assert not any(t.is_alive() for t in workers) and pm.games_completed() == 12
