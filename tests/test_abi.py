@@ -91,3 +91,19 @@ def test_reference_seat_matrix_dimension_errors(field, value):
     import alphazero as az
     with pytest.raises(RuntimeError, match=f"{field} (outer dimension must match number of seat permutations|inner dimension must match number of players)"):
         az.PlayManager(az.Connect4GS(), _pm_params(az, **{field: value}))
+
+
+def test_reference_playparams_binding_roundtrips():
+    """test_cache.py:491-541 and test_temp_decay.py:19-24: list-valued PlayParams fields read back what was set, the removed
+    `add_noise` field stays removed, epsilon defaults to 0."""
+    sys.path.insert(0, os.path.join(ROOT, "alphazero-pybind11_amd"))
+    import alphazero as az
+    p = az.PlayParams()
+    for name, value in (("seat_visits", [[1, 480], [480, 1]]), ("seat_epsilon", [[0.25, 0.0], [0.0, 0.25]]),
+                        ("seat_mcts_root_temp", [[1.25, 1.0], [1.0, 1.25]]), ("seat_root_fpu_zero", [[1, 0], [0, 1]]),
+                        ("temp_decay_half_life_by_variant", [8.0, 12.0, 0.0, 24.0])):
+        assert getattr(p, name) == []
+        setattr(p, name, value)
+        assert getattr(p, name) == value
+    assert not hasattr(p, "add_noise")
+    assert p.epsilon == 0.0
