@@ -260,3 +260,19 @@ def _play_two_groups(az, pp, caches):
                 v, pi = _evaluator(batch[: len(idx)])
                 pm.update_inferences(g, idx, v, pi)
     return pm
+
+
+def test_reference_s3fifo_cases_on_the_device_cache():
+    """s3fifo_cache_test.cc's single-thread cases (tests/s3fifo_cases.py) on the device S3FIFOCache / ShardedS3FIFOCache."""
+    import alphazero as az
+    import s3fifo_cases
+
+    class Dev:
+        def __init__(self, mx, gh, np_, nv, shards=1):
+            self.c = az.ShardedS3FIFOCache(mx, shards, gh, np_, nv)
+        def find(self, key): return self.c.find(key)
+        def insert(self, key, p, v): self.c.insert(key, p, v)
+        def stats(self):
+            return dict(hits=self.c.hits(), misses=self.c.misses(), evictions=self.c.evictions(), reinserts=self.c.reinserts(),
+                        size=self.c.size(), max_size=self.c.max_size())
+    assert len(s3fifo_cases.run_all(Dev)) == 21

@@ -462,3 +462,10 @@ def test_torch_leafnet_reproduces_the_reference_nnarch_fixtures(fname, spec_fn):
     net.load_state_dict({k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("sd.")})
     v, pi = net.eval().process(torch.from_numpy(fx["input"]))
     assert np.abs(v.numpy() - fx["v"]).max() <= 1e-6 and np.abs(pi.numpy() - fx["pi"]).max() <= 1e-6
+
+
+def test_reference_s3fifo_cases_on_the_oracle(oracle):
+    """s3fifo_cache_test.cc's 24 single-thread cases (tests/s3fifo_cases.py) on the oracle's restatement."""
+    import s3fifo_cases
+    ran = s3fifo_cases.run_all(lambda mx, gh, np_, nv, shards=1: oracle.Cache(mx, shards, gh, np_, nv))
+    assert len(ran) == 21
