@@ -383,6 +383,16 @@ class Connect4GS(GameState):  # py_wrapper.cc:562-586
     def NUM_SYMMETRIES():
         return 2
 
+    def play_move(self, move):
+        """connect4_gs.cc:48-58: a move into a full column throws at once (the object stays as it was)."""
+        super().play_move(move)
+        try:
+            self._state()
+        except RuntimeError:
+            self._moves.pop()
+            self._snap = None
+            raise RuntimeError("Invalid move: You have a bug in your code.") from None
+
     def to_bytes(self):          # connect4_gs.cc:172-178
         st = self._state()
         board = (st["canonical"][0, :2] != 0).astype(np.int8)

@@ -60,9 +60,9 @@ def test_connect4_from_board_ctor_and_pickle(az, oracle):
     for _ in range(6):
         full.play_move(0)
     assert full.valid_moves()[0] == 0
-    full.play_move(0)
-    with pytest.raises(RuntimeError):
-        full.valid_moves()
+    with pytest.raises(RuntimeError, match="Invalid move: You have a bug in your code."):   # connect4_gs.cc:48-58
+        full.play_move(0)
+    assert full.current_turn() == 6 and full.valid_moves()[0] == 0                          # the object is unchanged
 
 
 def test_tawlbwrdd_object_walk_matches_oracle(az, oracle):
@@ -142,3 +142,62 @@ def test_reference_pickle_contract(az, name):
         m = int(np.flatnonzero(np.asarray(orig.valid_moves()))[0])
         orig.play_move(m); back.play_move(m)
         _assert_state_equal(orig, back)
+
+
+# ---- the reference's connect4_gs_test.cc (:9-230) on the device Connect4GS object, case by case ---------------------------------
+def test_reference_connect4_gs_cases(az):
+    G = az.Connect4GS
+    # Equals (:9-29): transpositions are equal states
+    x, y = G(), G()
+    assert x == y
+    x.play_move(0); assert x != y
+    y.play_move(0); assert x == y
+    x, y = G(), G()
+    for m in (0, 1, 2): x.play_move(m)
+    for m in (2, 1, 0): y.play_move(m)
+    assert x == y
+    # Copy (:32-51)
+    x = G(); y = x.copy(); assert x == y
+    for m in (0, 1, 2): y.play_move(m)
+    assert x != y
+    z = y.copy(); assert y == z and x != z
+    for m in (2, 1, 0): x.play_move(m)
+    assert x == y and x == z
+    # ValidMoves (:54-71)
+    assert np.asarray(G().valid_moves()).tolist() == [1] * 7
+    board = np.zeros((2, 6, 7), np.int8); board[0, 0, 3] = 1; board[1, 0, 5] = 1
+    assert np.asarray(G(board, 0, 0).valid_moves()).tolist() == [1, 1, 1, 0, 1, 0, 1]
+    # PlayMove (:75-101): stones stack from the bottom row up; a full column throws the reference's message
+    board = np.zeros((2, 6, 7), np.int8)
+    x = G(); assert x == G(board, 0, 0)
+    i = 0
+    for h in range(5, 0, -2):
+        x.play_move(3); board[0, h, 3] = 1; i += 1; assert x == G(board, 1, i)
+        x.play_move(3); board[1, h - 1, 3] = 1; i += 1; assert x == G(board, 0, i)
+    with pytest.raises(RuntimeError, match="Invalid move: You have a bug in your code."):
+        x.play_move(3)
+    # WinState (:104-171): rows, columns, both diagonals, draw on a full top row
+    assert G().scores() is None
+    def score(b):
+        s = G(b, 0, 0).scores()
+        return None if s is None else np.asarray(s).tolist()
+    b = np.zeros((2, 6, 7), np.int8)
+    b[0, 3, 0:4] = 1; assert score(b) == [1, 0, 0]
+    b[0, 3, 2] = 0; assert score(b) is None
+    b[1, 1:5, 2] = 1; assert score(b) == [0, 1, 0]
+    b[1, 2, 2] = 0; assert score(b) is None
+    for k in (1, 2, 3, 4): b[0, k, k] = 1
+    assert score(b) == [1, 0, 0]
+    b[0, 2, 2] = 0; assert score(b) is None
+    b[1, 1, 3] = b[1, 2, 2] = b[1, 3, 1] = b[1, 4, 0] = 1; assert score(b) == [0, 1, 0]
+    b[1, 2, 2] = 0; assert score(b) is None
+    b = np.zeros((2, 6, 7), np.int8)
+    for w in range(7): b[w % 2, 0, w] = 1
+    assert score(b) == [0, 0, 1]
+    # Canonicalize (:174-227): stones are absolute planes 0/1, plane 2 + player is all ones
+    x = G(); e = np.zeros((4, 6, 7), np.float32); e[2] = 1
+    assert np.array_equal(np.asarray(x.canonicalized()), e)
+    x.play_move(0); e = np.zeros((4, 6, 7), np.float32); e[0, 5, 0] = 1; e[3] = 1
+    assert np.array_equal(np.asarray(x.canonicalized()), e)
+    x.play_move(0); e = np.zeros((4, 6, 7), np.float32); e[0, 5, 0] = 1; e[1, 4, 0] = 1; e[2] = 1
+    assert np.array_equal(np.asarray(x.canonicalized()), e)
