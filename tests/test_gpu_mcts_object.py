@@ -285,3 +285,75 @@ def test_reference_principal_variation_cases(az):
     gs = Game(); m = _ref_make_mcts(az, Game); _ref_uniform_sims(m, gs, 50)        # first move legal at the start position
     pv = list(m.principal_variation(1))
     assert len(pv) == 1 and np.array(gs.valid_moves())[pv[0]] == 1
+
+
+# ---- the reference's mcts_test.cc property and Gumbel cases (:127-278, :744-940) on the device MCTS object ---------------------
+def _dumb_search(az, m, gs, upto, noise=False):
+    while m.depth() < upto:
+        leaf = m.find_leaf(gs)
+        v, pi = az.dumb_eval(leaf)
+        m.process_result(gs, v, pi, noise)
+
+
+def test_reference_mcts_property_cases(az):
+    gs = az.Connect4GS()
+    m = az.MCTS(2, 2, 7, 0, 1.4, 0.25, seed=1)                 # RootValueSetOnFirstEval, :127-157
+    _dumb_search(az, m, gs, 31)
+    assert int((m.counts() > 0).sum()) >= 3
+    normal = az.MCTS(2, 2, 7, 0.0, 1.0, 0.25, False, False, seed=2)   # RootFpuZero, :198-230
+    fpu0 = az.MCTS(2, 2, 7, 0.0, 1.0, 0.25, False, True, seed=2)
+    _dumb_search(az, normal, gs, 50); _dumb_search(az, fpu0, gs, 50)
+    assert int((fpu0.counts() > 0).sum()) >= int((normal.counts() > 0).sum())
+    m = az.MCTS(2, 2, 7, 0.25, 1.4, 0.0, False, False, False, seed=3)  # PolicyTargetPruning, :233-276
+    _dumb_search(az, m, gs, 1, noise=True)
+    _dumb_search(az, m, gs, 200)
+    regular, pruned = m.probs(1.0), m.probs_pruned(1.0)
+    assert abs(regular.sum() - 1) < 1e-5 and abs(pruned.sum() - 1) < 1e-5
+    assert pruned.max() + 0.01 >= regular.max()
+    assert (pruned[regular == 0] == 0).all()                   # pruning creates no mass at unvisited moves (:563-568)
+    nn = az.MCTS(2, 2, 7, 0.0, 1.0, 0.0, False, False, False, seed=4)
+    _dumb_search(az, nn, gs, 100)
+    assert abs(nn.probs_pruned(1.0).sum() - 1) < 1e-5
+
+
+def _gumbel_mcts(az, m, full=False, seed=7):                   # make_gumbel_mcts, :713-728
+    return az.MCTS(2.0, 2, 7, 0.0, 1.0, 0.0, False, False, False, True, m, 50.0, 1.0, full, seed=seed)
+
+
+def _run_gumbel(az, mcts, gs, n):                              # run_gumbel_search, :730-738
+    mcts.set_gumbel_num_sims(n)
+    for _ in range(n):
+        leaf = mcts.find_leaf(gs)
+        v, pi = az.dumb_eval(leaf)
+        mcts.process_result(gs, v, pi)
+
+
+def test_reference_gumbel_mcts_cases(az):
+    for n in (4, 8, 16):                                       # RunsCleanlyAtLowVisits, :744-765
+        gs = az.Connect4GS(); m = _gumbel_mcts(az, 16); _run_gumbel(az, m, gs, n)
+        assert np.isfinite(m.root_q_values()).all() and abs(m.gumbel_improved_policy().sum() - 1) < 1e-4
+        fa = m.gumbel_final_action(); assert fa < 7 and gs.valid_moves()[fa] == 1
+    gs = az.Connect4GS(); m = _gumbel_mcts(az, 16); m.set_gumbel_num_sims(64)   # SkipsDirichletNoise, :768-798
+    leaf = m.find_leaf(gs); v, pi = az.dumb_eval(leaf); m.process_result(gs, v, pi, True)
+    assert np.allclose(m.gumbel_improved_policy(), 1.0 / 7, atol=1e-5)
+    gs = az.Connect4GS(); m = _gumbel_mcts(az, 4); _run_gumbel(az, m, gs, 13)    # SequentialHalvingVisitDistribution, :801-822
+    c = m.counts(); nz = sorted((int(x) for x in c if x > 0), reverse=True)
+    assert nz == [5, 5, 1, 1] and int(c.sum()) == 12
+    gs = az.Connect4GS(); m = _gumbel_mcts(az, 16); _run_gumbel(az, m, gs, 32)   # ImprovedPolicySumsToOne, :825-839
+    p = m.gumbel_improved_policy(); assert abs(p.sum() - 1) < 1e-4 and (p >= 0).all()
+    gs = az.Connect4GS(); m = _gumbel_mcts(az, 4); _run_gumbel(az, m, gs, 16)    # FinalActionIsValidMove, :842-852
+    fa1 = m.gumbel_final_action(); assert fa1 < 7 and gs.valid_moves()[fa1] == 1
+    m.set_gumbel_num_sims(0); m.set_gumbel_num_sims(16)                           # TreeReuseResamplesGumbel, :855-884
+    for _ in range(16):
+        leaf = m.find_leaf(gs); v, pi = az.dumb_eval(leaf); m.process_result(gs, v, pi)
+    assert gs.valid_moves()[m.gumbel_final_action()] == 1
+    gs = az.Connect4GS(); m = _gumbel_mcts(az, 16); m.set_gumbel_num_sims(0)      # FallbackToPuctWhenSimsTargetZero, :887-904
+    for _ in range(100):
+        leaf = m.find_leaf(gs); v, pi = az.dumb_eval(leaf); m.process_result(gs, v, pi)
+    fa = m.gumbel_final_action(); assert fa < 7 and gs.valid_moves()[fa] == 1
+    gs = az.Connect4GS()                                                            # FindsWinningMove, :907-924
+    for mv in (3, 0, 3, 0, 3, 1): gs.play_move(mv)
+    m = _gumbel_mcts(az, 16); _run_gumbel(az, m, gs, 128)
+    assert m.gumbel_final_action() == 3
+    gs = az.Connect4GS(); m = _gumbel_mcts(az, 16, full=True); _run_gumbel(az, m, gs, 64)   # FullGumbelInteriorRunsCleanly, :927-937
+    assert abs(m.gumbel_improved_policy().sum() - 1) < 1e-4 and gs.valid_moves()[m.gumbel_final_action()] == 1
