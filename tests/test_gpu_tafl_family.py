@@ -172,3 +172,79 @@ def test_opentafl_selfplay_on_the_hip_net():
     assert (src[own == 0] == 0).all()                               # only the mover's pieces carry policy mass
     c = pm.counters()
     assert c["evals"] > 0 and c["sims"] >= n * 23
+
+
+# ---- test_canon_symmetry.py:131-190: a symmetry-mirrored OpenTafl game stays a perfect image ------------------------------------
+_TW = _TH = 11
+_TWH = _TW + _TH
+
+
+def _t_decode(a):
+    sq, rem = a // _TWH, a % _TWH
+    fh, fw = sq // _TW, sq % _TW
+    return ("row", fh, fw, rem) if rem < _TW else ("col", fh, fw, rem - _TW)
+
+
+def _t_encode(kind, fh, fw, nl):
+    return (fh * _TW + fw) * _TWH + (nl if kind == "row" else _TW + nl)
+
+
+def _t_mirror_w(a):
+    kind, fh, fw, nl = _t_decode(a)
+    fw2 = _TW - 1 - fw
+    return _t_encode("row", fh, fw2, _TW - 1 - nl) if kind == "row" else _t_encode("col", fh, fw2, nl)
+
+
+def _t_rot90_cw(a):
+    kind, fh, fw, nl = _t_decode(a)
+    fh2, fw2 = fw, _TH - 1 - fh
+    return _t_encode("col", fh2, fw2, nl) if kind == "row" else _t_encode("row", fh2, fw2, _TH - 1 - nl)
+
+
+@pytest.mark.parametrize("name,move_map,board_map", [
+    ("mirror_w", _t_mirror_w, lambda bp: bp[:, :, ::-1]),
+    ("rot90_cw", _t_rot90_cw, lambda bp: np.rot90(bp, k=-1, axes=(1, 2))),
+])
+def test_reference_tafl_mirrored_game_stays_an_image(az, name, move_map, board_map):
+    """the reference's own test of the Tafl rules under the two generating symmetries, on the device OpenTaflGS objects
+    (12 games instead of 60: every call is a kernel launch)."""
+    rng = np.random.default_rng(11)
+    steps = 0
+    board = lambda g: np.array(g.canonicalized())[:3]
+    for _ in range(12):
+        ga, gb = az.OpenTaflGS(), az.OpenTaflGS()
+        assert np.array_equal(board_map(board(ga)), board(gb))
+        for _ in range(50):
+            va = np.flatnonzero(np.array(ga.valid_moves()))
+            if len(va) == 0:
+                break
+            a = int(rng.choice(va)); b = move_map(a)
+            assert np.array(gb.valid_moves())[b], f"{name}: mirrored move illegal"
+            ga.play_move(a); gb.play_move(b)
+            steps += 1
+            assert np.array_equal(board_map(board(ga)), board(gb)), f"{name}: desync"
+            if ga.scores() is not None:
+                break
+    assert steps > 100
+
+
+def test_symmetry_kernel_policy_permutation_equals_the_reference_move_maps(az):
+    """the device eightSym (tafl_helper.h:139-149) moves a one-hot policy exactly where test_canon_symmetry.py's independently
+    written move maps send the move: symmetry 1 is the mirror, symmetry 2 the clockwise quarter turn of symmetry 0."""
+    rng = np.random.default_rng(5)
+    moves = rng.choice(2662, 40, replace=False)
+    canon = np.zeros((len(moves), 8, 11, 11), np.float32); v = np.zeros((len(moves), 3), np.float32)
+    pi = np.zeros((len(moves), 2662), np.float32); pi[np.arange(len(moves)), moves] = 1
+    oc, ov, op = az.tafl_symmetries(11, canon, v, pi)
+    where = op.argmax(2)                                    # [n, 8]: where each symmetry sends the move
+    assert (op.sum(2) == 1).all() and (where[:, 0] == moves).all()
+    images = {int(m): set(int(x) for x in where[i]) for i, m in enumerate(moves)}
+    for m in moves:
+        orbit, frontier = {int(m)}, [int(m)]                # the orbit under the two generators
+        while frontier:
+            a = frontier.pop()
+            for f in (_t_mirror_w, _t_rot90_cw):
+                b = f(a)
+                if b not in orbit:
+                    orbit.add(b); frontier.append(b)
+        assert images[int(m)] == orbit
