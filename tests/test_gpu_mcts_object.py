@@ -357,3 +357,44 @@ def test_reference_gumbel_mcts_cases(az):
     assert m.gumbel_final_action() == 3
     gs = az.Connect4GS(); m = _gumbel_mcts(az, 16, full=True); _run_gumbel(az, m, gs, 64)   # FullGumbelInteriorRunsCleanly, :927-937
     assert abs(m.gumbel_improved_policy().sum() - 1) < 1e-4 and gs.valid_moves()[m.gumbel_final_action()] == 1
+
+
+def test_direct_mcts_consumer_shape(az):
+    """The call pattern of the reference's direct-MCTS consumers (play.py:274-343, cache_utils.cached_inference): leaves are
+    collected with find_leaf_batched, terminal / playout / cached leaves are backed up at once, the rest after one batched
+    evaluation that also fills an S3FIFOCache keyed by hash_game_state."""
+    gs = az.Connect4GS()
+    for mv in (3, 3, 2, 4):
+        gs.play_move(mv)
+    mcts = az.MCTS(1.25, 2, 7, 0.25, 1.25, 0.25, False, True, True, seed=9)
+    cache = az.S3FIFOCache(4096, 3686, 7, 3)
+    P1, M = gs.num_players() + 1, gs.num_moves()
+    sims, evals = 0, 0
+    while sims < 160:
+        pending = []
+        for attempt in range(16):
+            if len(pending) >= 8:
+                break
+            leaf = mcts.find_leaf_batched(gs)
+            idx = mcts.in_flight_count() - 1
+            noise = sims == 0 and attempt == 0
+            if leaf.scores() is not None:
+                mcts.process_result_batched(gs, idx, np.array(leaf.scores()), np.zeros(M), noise); sims += 1
+                continue
+            h = az.hash_game_state(leaf)
+            hit = cache.find(h, M, P1)
+            if hit is not None:
+                mcts.process_result_batched(gs, idx, np.array(hit[1]), np.array(hit[0]), noise); sims += 1
+                continue
+            pending.append((idx, h, noise, leaf))
+        for idx, h, noise, leaf in pending:                # the "GPU batch": a playout evaluation per leaf
+            v, pi = az.playout_eval(leaf, seed=h & 0xFFFF)
+            cache.insert(h, pi, v)
+            mcts.process_result_batched(gs, idx, v, pi, noise)
+            evals += 1
+        sims += len(pending)
+        mcts.reset_batch()
+    assert mcts.depth() == sims and int(mcts.counts().sum()) == sims - 1
+    assert cache.size() > 0 and cache.hits() + cache.misses() >= evals
+    pv = list(mcts.principal_variation(3))
+    assert len(pv) >= 1 and gs.valid_moves()[pv[0]] == 1
