@@ -855,6 +855,13 @@ class PlayManager:
         check(lib.azmi_pm_stats(self._h, out.ctypes.data))
         return out
 
+    def stat_sums(self):
+        """The accumulators behind the avg_* figures (play_manager.h:398-424), for exact aggregation over several engines."""
+        out = np.zeros(10, np.float64)
+        check(lib.azmi_pm_stat_sums(self._h, out.ctypes.data))
+        return dict(zip(("game_length", "games", "moves", "full_moves", "fast_moves", "leaf_depth", "entropy", "fast_leaf_depth",
+                         "fast_entropy", "valid_moves"), (float(x) for x in out)))
+
     def avg_game_length(self): return float(self._stats()[0])
     def avg_leaf_depth(self): return float(self._stats()[1])
     def avg_search_entropy(self): return float(self._stats()[2])

@@ -1,0 +1,107 @@
+"""Device counterpart of the reference's self-play harness (GameRunner.run + the read-out of self_play(),
+game_runner.py:392-747, 2057-2160): K engine shards on one GPU driven by the native round loop, the leaf net on the
+matrix cores, finished samples left in HBM.
+
+The reference spreads one PlayManager over `mcts_workers` threads and batcher threads; here the games are split over
+K engines (contiguous slot ranges, distinct seeds) because four independent streams keep the GPU busy.
+The results are the reference's: the multiset of (canonical, v, pi) rows and the counters self_play() reports."""
+import dataclasses
+
+import numpy as np
+
+from . import PlayManager, EvalType, ShardedS3FIFOCache, run_rounds
+
+
+@dataclasses.dataclass
+class SelfPlayResult:          # the fields of game_runner.SelfPlayResult that come from the PlayManager
+    win_rates: list
+    hit_rate: float
+    game_length: float
+    resign_win_rates: list
+    resign_rate: float
+    avg_leaf_depth: float
+    avg_search_entropy: float
+    fast_avg_leaf_depth: float
+    fast_avg_search_entropy: float
+    avg_moves_per_turn: float
+    avg_valid_moves: float
+    cache_saturation: float
+    cache_churn: float
+    games: int
+    simulations: int
+    leaf_evaluations: int
+    samples: int
+
+
+def _shard_params(params, k, K):
+    import copy
+    p = copy.copy(params)
+    S, N = int(params.concurrent_games), int(params.games_to_play)
+    lo, hi = S * k // K, S * (k + 1) // K
+    p.concurrent_games = hi - lo
+    p.games_to_play = N * (k + 1) // K - N * k // K        # contiguous game-index ranges
+    p.max_batch_size = max(1, min(int(params.max_batch_size), p.concurrent_games))
+    p.max_cache_size = int(params.max_cache_size) // K
+    return p
+
+
+def shard_seed(seed, k):
+    """seed of engine shard k (bench.py uses the same rule)"""
+    return int(seed) + 104729 * k
+
+
+def self_play(game, params, net=None, engines=4, seed=20240601, device=0, streams=None, rounds_per_poll=512):
+    """Runs `params.games_to_play` self-play games of `game` on `engines` shards; `net` is a HipLeafNet (or None when every
+    seat evaluates with RANDOM / PLAYOUT).  Returns (SelfPlayResult, (canonical, v, pi)) with the samples as device tensors
+    in shard order (numpy arrays without a net, since nothing else needs torch then)."""
+    K = max(1, min(int(engines), int(params.concurrent_games)))
+    pms = [PlayManager(game() if isinstance(game, type) else game, _shard_params(params, k, K), seed=shard_seed(seed, k), device=device)
+           for k in range(K)]
+    no_net = bool(params.eval_type) and all(int(e) != int(EvalType.NN) for e in params.eval_type)
+    if no_net:
+        for pm in pms:
+            pm.play()
+    else:
+        if net is None:
+            raise RuntimeError("self_play: seats with EvalType.NN need a net")
+        import torch
+        if streams is None:
+            streams = [torch.cuda.Stream(device=device) for _ in range(K)]
+        sps = [s.cuda_stream for s in streams]
+        live = list(range(K))
+        while live:
+            group = [pms[i] for i in live]
+            run_rounds(group, net, rounds_per_poll, [sps[i] for i in live])
+            live = [i for i in live if pms[i].poll(sps[i])[1] > 0]
+    # ---- the read-out of self_play(), game_runner.py:2073-2145, combined over the shards from the raw sums
+    P1 = pms[0]._P + 1
+    scores = np.sum([pm.scores() for pm in pms], 0)
+    resign = np.sum([pm.resign_scores() for pm in pms], 0)
+    sums = {}
+    for pm in pms:
+        for k, v in pm.stat_sums().items():
+            sums[k] = sums.get(k, 0.0) + v
+    cs = np.sum([pm._cache_stats() for pm in pms], 0)
+    cn = [pm.counters() for pm in pms]
+    sn, rn = float(scores.sum()), float(resign.sum())
+    hits, misses, evictions, reinserts, csize, cmax = (int(x) for x in cs)
+    div = lambda a, b: (a / b) if b else 0.0
+    if no_net:
+        hist = [pm.history() for pm in pms]
+        samples = tuple(np.concatenate([h[i] for h in hist], 0) for i in range(3))
+        n_samples = samples[0].shape[0]
+    else:
+        import torch
+        hist = [pm.history_device_tensors(torch.device("cuda", device)) for pm in pms]
+        samples = tuple(torch.cat([h[i] for h in hist], 0) for i in range(3))
+        n_samples = int(samples[0].shape[0])
+    res = SelfPlayResult(
+        win_rates=[div(float(x), sn) for x in scores], hit_rate=div(hits, hits + misses), game_length=div(sums["game_length"], sums["games"]),
+        resign_win_rates=[div(float(x), rn) for x in resign], resign_rate=div(rn, sn),
+        avg_leaf_depth=div(sums["leaf_depth"], sums["full_moves"]), avg_search_entropy=div(sums["entropy"], sums["full_moves"]),
+        fast_avg_leaf_depth=div(sums["fast_leaf_depth"], sums["fast_moves"]), fast_avg_search_entropy=div(sums["fast_entropy"], sums["fast_moves"]),
+        avg_moves_per_turn=div(sums["moves"], sums["game_length"]), avg_valid_moves=div(sums["valid_moves"], sums["moves"]),
+        cache_saturation=div(csize, cmax), cache_churn=div(evictions, hits), games=int(sums["games"]),
+        simulations=sum(c["sims"] for c in cn), leaf_evaluations=sum(c["evals"] for c in cn), samples=n_samples)
+    res._pms = pms                      # keeps the engines (and the device memory behind `samples`) alive
+    return res, samples

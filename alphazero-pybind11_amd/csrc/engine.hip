@@ -956,6 +956,27 @@ int azmi_pm_resign_scores(azmi_pm* pm, float* out) {
   return AZMI_OK;
 }
 
+// the sums behind azmi_pm_stats, for callers that combine several engines (shards / ranks) into one set of averages:
+// out[10] = game_length, games completed, total / full / fast move counts, leaf depth, entropy, fast leaf depth,
+//           fast entropy, valid moves (the accumulators of play_manager.h:398-424)
+int azmi_pm_stat_sums(azmi_pm* pm, double* out) {
+  if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
+  const uint32_t S = pm->ep.S;
+  std::vector<uint64_t> len, cnt; std::vector<double> ds; std::vector<uint32_t> games;
+  int rc = d2h(len, pm->ar.a_len, S, pm->last); if (rc) return rc;
+  rc = d2h(cnt, pm->ar.a_cnt, 3 * static_cast<size_t>(S), pm->last); if (rc) return rc;
+  rc = d2h(ds, pm->ar.a_dsum, 5 * static_cast<size_t>(S), pm->last); if (rc) return rc;
+  rc = d2h(games, pm->ar.slot_games, S, pm->last); if (rc) return rc;
+  for (int i = 0; i < 10; ++i) out[i] = 0.0;
+  for (uint32_t s = 0; s < S; ++s) {
+    out[0] += static_cast<double>(len[s]); out[1] += games[s];
+    for (int j = 0; j < 3; ++j) out[2 + j] += static_cast<double>(cnt[static_cast<size_t>(j) * S + s]);
+    for (int j = 0; j < 5; ++j) out[5 + j] += ds[static_cast<size_t>(j) * S + s];
+  }
+  return AZMI_OK;
+}
+
 int azmi_pm_stats(azmi_pm* pm, float* out) {  // play_manager.h:288-315
   if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");
   std::lock_guard<std::recursive_mutex> lock_(pm->mu);

@@ -188,6 +188,10 @@ int azmi_pm_resign_scores(azmi_pm* pm, float* out /* [P+1] */);   /* resign_scor
 /* out[7] = avg_game_length, avg_leaf_depth, avg_search_entropy, fast_avg_leaf_depth,
  *          fast_avg_search_entropy, avg_moves_per_turn, avg_valid_moves (play_manager.h:288-315) */
 int azmi_pm_stats(azmi_pm* pm, float* out);
+/* the sums behind those averages, to combine several engines (shards of one GPU, ranks) exactly: out[10] = sum of game
+ * lengths, games completed, total / full / fast move counts, sums of leaf depth, search entropy, fast leaf depth, fast
+ * entropy, valid moves (play_manager.h:398-424) */
+int azmi_pm_stat_sums(azmi_pm* pm, double* out);
 /* out[6] = simulations, leaf evaluations requested from the net, cache hits, cache misses,
  *          history rows available, rounds */
 int azmi_pm_counters(azmi_pm* pm, uint64_t* out);
