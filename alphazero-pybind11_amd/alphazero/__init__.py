@@ -1159,6 +1159,17 @@ def run_rounds(pms, net, rounds, streams):
     check(lib.azmi_run_rounds(arr_pm, net._h, k, int(rounds), arr_st))
 
 
+def run_rounds_groups(pms, nets, rounds, streams):
+    """azmi_run_rounds_groups: `nets[g]` (HipLeafNet or None) evaluates the leaves of model group g."""
+    k = len(pms)
+    arr_pm = (C.c_void_p * k)(*[pm._h for pm in pms])
+    arr_net = (C.c_void_p * len(nets))(*[None if n is None else n._h for n in nets])
+    arr_st = (C.c_void_p * k)(*[C.c_void_p(int(s)) for s in streams])
+    for pm, s in zip(pms, streams):
+        pm._last_stream = C.c_void_p(int(s))
+    check(lib.azmi_run_rounds_groups(arr_pm, arr_net, len(nets), k, int(rounds), arr_st))
+
+
 def game_replay(game_cls, moves, device=0):
     """Batched rules replay on the device (azmi_game_replay): moves [n, len] int32, -1 padded."""
     moves = np.ascontiguousarray(moves, dtype=np.int32)

@@ -9,7 +9,7 @@ import dataclasses
 
 import numpy as np
 
-from . import PlayManager, EvalType, ShardedS3FIFOCache, run_rounds
+from . import PlayManager, EvalType, ShardedS3FIFOCache, run_rounds, run_rounds_groups
 
 
 @dataclasses.dataclass
@@ -105,3 +105,69 @@ def self_play(game, params, net=None, engines=4, seed=20240601, device=0, stream
         simulations=sum(c["sims"] for c in cn), leaf_evaluations=sum(c["evals"] for c in cn), samples=n_samples)
     res._pms = pms                      # keeps the engines (and the device memory behind `samples`) alive
     return res, samples
+
+
+@dataclasses.dataclass
+class MatchResult:             # what play_past() returns from the PlayManager (game_runner.py:2250-2332)
+    nn_rate: float
+    draw_rate: float
+    hit_rate: float
+    game_length: float
+    n_games: int
+    nn_wins: int
+    past_wins: int
+    n_draws: int
+    perm_scores: list
+
+
+def gating_match(game, params, net_new, net_past, engines=2, seed=20240601, device=0, rounds_per_poll=256):
+    """play_past (game_runner.py:2184-2332) on the device: model group 0 = the new model, group 1 = the past one, every seating
+    of the two (2 players: both; N players: the new model alone in each seat, then the past model alone in each seat), games
+    split over `engines` shards.  `net_new` / `net_past` are HipLeafNets, or None for the reference's RandPlayer (RANDOM
+    evaluator).  `params` supplies the search settings (visits, temperatures, cache ...); its groups, permutations and
+    evaluator types are set here like play_past does."""
+    import copy
+    import torch
+    g = game() if isinstance(game, type) else game
+    P = type(g).NUM_PLAYERS()
+    p = copy.copy(params)
+    if P == 2:
+        p.model_groups, p.seat_perms = [0, 1], [[0, 1], [1, 0]]
+    else:
+        p.model_groups = [0] + [1] * (P - 1)
+        p.seat_perms = [[0 if j == i else 1 for j in range(P)] for i in range(P)] + [[1 if j == i else 0 for j in range(P)] for i in range(P)]
+    visits = list(p.mcts_visits)
+    nets = [net_new, net_past]
+    p.eval_type = [EvalType.NN if nets[grp] is not None else EvalType.RANDOM for grp in p.model_groups]
+    p.mcts_visits = visits
+    n_perms = len(p.seat_perms)
+    K = max(1, min(int(engines), int(p.concurrent_games)))
+    pms = [PlayManager(type(g)(), _shard_params(p, k, K), seed=shard_seed(seed, k), device=device) for k in range(K)]
+    streams = [torch.cuda.Stream(device=device) for _ in range(K)]
+    sps = [s.cuda_stream for s in streams]
+    live = list(range(K))
+    while live:
+        run_rounds_groups([pms[i] for i in live], nets, rounds_per_poll, [sps[i] for i in live])
+        live = [i for i in live if pms[i].poll(sps[i])[1] > 0]
+    perm_scores = [np.sum([pm.perm_scores(q) for pm in pms], 0) for q in range(n_perms)]
+    perm_games = [sum(pm.perm_games_completed(q) for pm in pms) for q in range(n_perms)]
+    nn_rate = draw_rate = 0.0
+    n_games = nn_wins = past_wins = n_draws = 0
+    for q in range(n_perms):                              # game_runner.py:2268-2288
+        if perm_games[q] == 0:
+            continue
+        n_games += perm_games[q]
+        for seat in range(P):
+            if p.seat_perms[q][seat] == 0:
+                nn_rate += float(perm_scores[q][seat]) / perm_games[q]; nn_wins += int(perm_scores[q][seat])
+            else:
+                past_wins += int(perm_scores[q][seat])
+        draw_rate += float(perm_scores[q][P]) / perm_games[q]; n_draws += int(perm_scores[q][P])
+    cs = np.sum([pm._cache_stats() for pm in pms], 0)
+    sums = {}
+    for pm in pms:
+        for k2, v in pm.stat_sums().items():
+            sums[k2] = sums.get(k2, 0.0) + v
+    return MatchResult(nn_rate=nn_rate / n_perms, draw_rate=draw_rate / n_perms, hit_rate=(float(cs[0]) / float(cs[0] + cs[1])) if cs[0] + cs[1] else 0.0,
+                       game_length=(sums["game_length"] / sums["games"]) if sums["games"] else 0.0, n_games=n_games, nn_wins=nn_wins,
+                       past_wins=past_wins, n_draws=n_draws, perm_scores=[x.tolist() for x in perm_scores])

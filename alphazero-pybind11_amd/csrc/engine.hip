@@ -781,7 +781,10 @@ int ensure_graph(azmi_pm* pm, azmi_net* net, hipStream_t st) {
 
 int azmi_run_rounds(azmi_pm* const* pms, azmi_net* net, uint32_t k, uint32_t rounds, void* const* streams) {
   if (!pms || !net || !streams || k == 0) return fail(AZMI_ERR_INVALID, "null argument");
-  const bool use_graph = getenv("AZMI_NO_GRAPH") == nullptr;
+  // hipGraph replay of 16 rounds per launch is available (AZMI_GRAPH=1) but off by default: measured equal to plain
+  // launches on this workload (2300 vs 2304 games/s — the host is ahead of the GPU either way), and capturing and
+  // instantiating a graph per engine costs about a second at start-up
+  const bool use_graph = getenv("AZMI_GRAPH") != nullptr && getenv("AZMI_NO_GRAPH") == nullptr;
   uint32_t done = 0;
   if (use_graph) {
     for (uint32_t i = 0; i < k; ++i) {
@@ -795,6 +798,28 @@ int azmi_run_rounds(azmi_pm* const* pms, azmi_net* net, uint32_t k, uint32_t rou
     for (uint32_t i = 0; i < k; ++i) {
       const int rc = one_round_with_net(pms[i], net, pms[i]->pick(streams[i]));
       if (rc != AZMI_OK) return rc;
+    }
+  return AZMI_OK;
+}
+
+// The round loop with one net PER MODEL GROUP (gating / benchmark matches, game_runner.py:2184-2332: two models, seats
+// swapped by the permutations): nets[g] evaluates the leaves of model group g; NULL = that group needs no net (RANDOM /
+// PLAYOUT evaluator).
+int azmi_run_rounds_groups(azmi_pm* const* pms, azmi_net* const* nets, uint32_t num_nets, uint32_t k, uint32_t rounds, void* const* streams) {
+  if (!pms || !nets || !streams || k == 0) return fail(AZMI_ERR_INVALID, "null argument");
+  for (uint32_t i = 0; i < k; ++i)
+    if (pms[i]->ep.num_groups > num_nets) return fail(AZMI_ERR_INVALID, "engine %u has %u model groups but %u nets were given", i, pms[i]->ep.num_groups, num_nets);
+  for (uint32_t r = 0; r < rounds; ++r)
+    for (uint32_t i = 0; i < k; ++i) {
+      azmi_pm* pm = pms[i];
+      hipStream_t st = pm->pick(streams[i]);
+      int rc = launch_round(pm, st);
+      if (rc != AZMI_OK) return rc;
+      for (uint32_t g = 0; g < pm->ep.num_groups; ++g) {
+        if (!nets[g]) continue;
+        rc = pm_net_forward(pm, g, nets[g], st);
+        if (rc != AZMI_OK) return rc;
+      }
     }
   return AZMI_OK;
 }

@@ -366,6 +366,9 @@ const char* azmi_cache_last_error(void);
  *      cores, another engine's tree kernel runs on the CUs the net leaves free.  Launch-only
  *      (asynchronous); poll with azmi_pm_poll. */
 int azmi_run_rounds(azmi_pm* const* pms, azmi_net* net, uint32_t k, uint32_t rounds, void* const* streams);
+/* the same loop with one net per MODEL GROUP (gating / benchmark matches between two models, game_runner.py:2184-2332):
+ * nets[g] evaluates the leaves of group g, NULL = the group needs no net (RANDOM / PLAYOUT evaluator) */
+int azmi_run_rounds_groups(azmi_pm* const* pms, azmi_net* const* nets, uint32_t num_nets, uint32_t k, uint32_t rounds, void* const* streams);
 
 /* The device RNG layer on its own (parity tier "RNG"): runs `thread_local pcg32 re` + the
  * libstdc++ algorithm the reference applies to it (mcts.cc:19,100,430-440,718) on the GPU.

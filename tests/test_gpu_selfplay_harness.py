@@ -74,3 +74,28 @@ def test_net_run_fills_the_history_and_the_shards_do_not_change_the_games():
     assert a.hit_rate > 0 and a.leaf_evaluations < a.simulations and 0 < a.cache_saturation <= 1
     one, (c1, _, _) = selfplay.self_play(az.Connect4GS, pp, net, engines=1, seed=7)
     assert one.games == 64 and abs(one.game_length - a.game_length) < 6             # same distribution, other seeds
+
+
+def test_gating_match_between_two_models():
+    """play_past's shape (game_runner.py:2184-2332): new model vs past model on both seatings, per-permutation score tables
+    folded into nn_rate / draw_rate / integer win counts; and new model vs RandPlayer (past_iter == 0)."""
+    import alphazero as az
+    from alphazero import selfplay, torch_net
+    spec = torch_net.connect4_spec()
+    new = az.HipLeafNet(torch_net.random_init(spec, seed=1), spec)
+    past = az.HipLeafNet(torch_net.random_init(spec, seed=2), spec)
+    pp = az.PlayParams()
+    pp.concurrent_games, pp.games_to_play, pp.max_batch_size = 32, 64, 32        # bs * cb * n_perms
+    pp.mcts_visits = [30, 30]
+    pp.cpuct, pp.fpu_reduction = 1.25, 0.25
+    pp.start_temp = pp.final_temp = 0.5                                           # eval_temp
+    pp.max_cache_size = 16384
+    r = selfplay.gating_match(az.Connect4GS, pp, new, past, engines=2, seed=3)
+    assert r.n_games == 64 and r.nn_wins + r.past_wins + r.n_draws == 64
+    assert len(r.perm_scores) == 2 and sum(sum(ps) for ps in r.perm_scores) == 64
+    assert 0 <= r.nn_rate <= 1 and 0 <= r.draw_rate <= 1 and r.hit_rate > 0
+    assert abs(r.nn_rate - (r.perm_scores[0][0] + r.perm_scores[1][1]) / 64) < 0.05      # both seatings weigh the same
+    again = selfplay.gating_match(az.Connect4GS, pp, new, past, engines=2, seed=3)
+    assert again == r                                                               # reproducible
+    rnd = selfplay.gating_match(az.Connect4GS, pp, new, None, engines=2, seed=3)    # vs RandPlayer: only group 0 reaches a net
+    assert rnd.n_games == 64 and rnd.nn_wins + rnd.past_wins + rnd.n_draws == 64
