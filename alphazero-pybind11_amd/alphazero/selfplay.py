@@ -50,10 +50,13 @@ def shard_seed(seed, k):
     return int(seed) + 104729 * k
 
 
-def self_play(game, params, net=None, engines=4, seed=20240601, device=0, streams=None, rounds_per_poll=512):
+def self_play(game, params, net=None, engines=4, seed=20240601, device=0, streams=None, rounds_per_poll=512, data_folder=None,
+              iteration=0, data_save_size=30_000):
     """Runs `params.games_to_play` self-play games of `game` on `engines` shards; `net` is a HipLeafNet (or None when every
     seat evaluates with RANDOM / PLAYOUT).  Returns (SelfPlayResult, (canonical, v, pi)) with the samples as device tensors
-    in shard order (numpy arrays without a net, since nothing else needs torch then)."""
+    in shard order (numpy arrays without a net, since nothing else needs torch then).  With `data_folder` the samples are
+    also written as the reference's `.ptz` triples, `data_save_size` rows per batch (GameRunner.hist_saver,
+    game_runner.py:736-747)."""
     K = max(1, min(int(engines), int(params.concurrent_games)))
     pms = [PlayManager(game() if isinstance(game, type) else game, _shard_params(params, k, K), seed=shard_seed(seed, k), device=device)
            for k in range(K)]
@@ -104,6 +107,13 @@ def self_play(game, params, net=None, engines=4, seed=20240601, device=0, stream
         cache_saturation=div(csize, cmax), cache_churn=div(evictions, hits), games=int(sums["games"]),
         simulations=sum(c["sims"] for c in cn), leaf_evaluations=sum(c["evals"] for c in cn), samples=n_samples)
     res._pms = pms                      # keeps the engines (and the device memory behind `samples`) alive
+    if data_folder is not None and n_samples:
+        from . import history_io
+        import torch
+        c, v, p = (torch.as_tensor(x) for x in samples)
+        for b, lo in enumerate(range(0, n_samples, int(data_save_size))):
+            hi = min(n_samples, lo + int(data_save_size))
+            history_io.write_history_batch(data_folder, iteration, b, c[lo:hi], v[lo:hi], p[lo:hi])
     return res, samples
 
 

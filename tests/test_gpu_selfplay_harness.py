@@ -1,5 +1,7 @@
 """-m gpu: alphazero.selfplay.self_play — the device counterpart of GameRunner.run + self_play()'s read-out:
 for a given PlayParams and evaluator, the multiset of (canonical, v, pi) rows and the counters equal the oracle's."""
+import os
+
 import numpy as np
 import pytest
 
@@ -44,6 +46,15 @@ def test_random_evaluator_rows_and_counters_equal_the_oracle(oracle):
             fdepth += float(st[3]) * nfast; fent += float(st[4]) * nfast
             valid += float(st[6]) * len(rows)
     assert sorted(want) == _rows_key(c, v, p)                          # the multiset of training rows, byte for byte
+    # the same run written to disk in the reference's layout and read back (float16 storage)
+    import tempfile
+    from alphazero import history_io
+    with tempfile.TemporaryDirectory() as d:
+        selfplay.self_play(az.Connect4GS, pp, engines=K, seed=seed, data_folder=d, iteration=5, data_save_size=100)
+        triples = history_io.glob_file_triples(d)
+        assert sum(t[3] for t in triples) == len(c) and all(os.path.basename(t[0]).startswith("0005-") for t in triples)
+        back = [np.concatenate([history_io.load_compressed(t[i]).float().numpy() for t in triples], 0) for i in range(3)]
+        assert np.array_equal(back[0], c) and np.array_equal(back[1], v) and np.abs(back[2] - p).max() < 1e-3
     assert np.allclose(res.win_rates, scores / scores.sum())
     assert res.game_length == pytest.approx(length / 12)
     assert res.avg_leaf_depth == pytest.approx(depth / full, rel=1e-5) and res.avg_search_entropy == pytest.approx(ent / full, rel=1e-5)
