@@ -335,6 +335,81 @@ __global__ void k_replay_tafl(const uint8_t* init, uint32_t init_stride, const i
   if (key) key[g] = GM::key(s);
 }
 
+// playout_eval / playout_eval_batch for the Tafl family: one thread per state; the repetition list of the game record and
+// of the rollout lives in the thread's scratch row (rep_stride >= record length + max_turns + 2 entries)
+template <class GM>
+__global__ void k_playout_tafl(const uint8_t* init, uint32_t init_stride, const int32_t* moves, uint32_t n, uint32_t len,
+                               uint64_t* rep_scratch, uint32_t rep_stride, const uint64_t* seeds, float* v, float* pi, int32_t* status) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  typename GM::State s = tafl_start<GM>(init, init_stride, g);
+  constexpr uint32_t SPAN = GM::W + GM::H;
+  uint64_t* reps = rep_scratch + static_cast<size_t>(g) * rep_stride;
+  uint32_t nrep = 0;
+  auto step = [&](uint32_t mv, bool unchecked) -> bool {     // one move with the reference's repetition bookkeeping
+    typename GM::State before = s;
+    bool cap = false, ok;
+    if constexpr (GM::kGameId == Tawlbwrdd::kGameId) ok = GM::apply_move(s, mv, &cap);
+    else ok = GM::apply_move(s, mv, &cap, unchecked);
+    if (!ok) return false;
+    if (before.turn == 0) { reps[0] = GM::rep_key(before); nrep = 1; }
+    if (cap) nrep = 0;
+    const uint64_t k = GM::rep_key(s);
+    uint32_t cnt = 1;
+    for (uint32_t j = 0; j < nrep; ++j) cnt += reps[j] == k;
+    if (nrep < rep_stride) reps[nrep++] = k;
+    s.rep = cnt;
+    return true;
+  };
+  int32_t stt = 0;
+  const bool unchecked = GM::kGameId != Tawlbwrdd::kGameId;       // the objects of these games replay like the reference's play_move
+  for (uint32_t i = 0; i < len; ++i) {
+    const int32_t mv = moves[static_cast<size_t>(g) * len + i];
+    if (mv < 0) break;
+    if (mv >= GM::M || !step(static_cast<uint32_t>(mv), unchecked)) { stt = -1; break; }
+  }
+  status[g] = stt;
+  if (stt) return;
+  auto count_moves = [&]() {
+    uint32_t k = 0;
+    for (uint32_t sq = 0; sq < static_cast<uint32_t>(GM::SQ); ++sq)
+      if (GM::own_piece(s, s.player, sq)) k += __builtin_popcount(GM::slide_mask(s, sq));
+    return k;
+  };
+  {   // policy: uniform over the leaf's legal moves, the u8 sum of the mask wraps mod 256 like dumb_eval
+    float* pr = pi + static_cast<size_t>(g) * GM::M;
+    for (int m = 0; m < GM::M; ++m) pr[m] = 0.0f;
+    const float ksum = static_cast<float>(count_moves() & 0xFFu);
+    if (ksum > 0.0f)
+      for (uint32_t sq = 0; sq < static_cast<uint32_t>(GM::SQ); ++sq) {
+        if (!GM::own_piece(s, s.player, sq)) continue;
+        const uint32_t mask = GM::slide_mask(s, sq);
+        for (uint32_t b = 0; b < SPAN; ++b) if ((mask >> b) & 1u) pr[sq * SPAN + b] = 1.0f / ksum;
+      }
+  }
+  Pcg32 roll;
+  roll.seed(seeds[g]);
+  uint32_t term = GM::terminal(s);
+  while (term == 0) {
+    const uint32_t k = count_moves();
+    if (k == 0) break;
+    uint32_t r = lemire_below(roll, k), mv = 0;
+    for (uint32_t sq = 0; sq < static_cast<uint32_t>(GM::SQ); ++sq) {    // the r-th legal move in ascending move order
+      if (!GM::own_piece(s, s.player, sq)) continue;
+      uint32_t mask = GM::slide_mask(s, sq);
+      const uint32_t c = __builtin_popcount(mask);
+      if (r >= c) { r -= c; continue; }
+      for (uint32_t j = 0; j < r; ++j) mask &= mask - 1;
+      mv = sq * SPAN + __builtin_ctz(mask);
+      break;
+    }
+    if (!step(mv, false)) break;
+    term = GM::terminal(s);
+  }
+  for (int i = 0; i <= GM::P; ++i)
+    v[static_cast<size_t>(g) * (GM::P + 1) + i] = term ? ((static_cast<int>(term) - 1 == i) ? 1.0f : 0.0f) : static_cast<float>(1.0 / (GM::P + 1));
+}
+
 // ---- RNG probe: the device RNG layer on its own (parity tier "RNG") -------------------------------
 __global__ void k_rng_probe(int kind, uint64_t seed, float param, uint32_t n, uint32_t reps, uint32_t* out_u, float* out_f) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -1236,9 +1311,12 @@ int azmi_playout_eval(int game, int device, const uint8_t* init, uint32_t init_s
                       const uint64_t* seeds, float* v, float* pi) {
   GameInfo gi;
   if (!game_info(game, &gi)) return fail(AZMI_ERR_INVALID, "unknown game id %d", game);
-  if (game != AZMI_GAME_CONNECT4) return fail(AZMI_ERR_INVALID, "playout_eval is implemented on the device for Connect4 only");
   if (!seeds || !v || !pi || (!moves && n * len)) return fail(AZMI_ERR_INVALID, "null argument");
-  if (init && init_stride != Connect4::SERIALIZED) return fail(AZMI_ERR_INVALID, "start positions: %u bytes per state", Connect4::SERIALIZED);
+  {
+    const uint32_t want = game == AZMI_GAME_CONNECT4 ? Connect4::SERIALIZED : game == AZMI_GAME_BRANDUBH ? 3u * Brandubh::SQ + 5u
+                        : game == AZMI_GAME_OPENTAFL ? 3u * OpenTafl::SQ + 5u : 0u;
+    if (init && (want == 0 || init_stride != want)) return fail(AZMI_ERR_INVALID, "start positions: %u bytes per state for this game", want);
+  }
   if (n == 0) return AZMI_OK;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(AZMI_ERR_NO_DEVICE, "no HIP device: libazmi has no CPU path");
@@ -1259,7 +1337,16 @@ int azmi_playout_eval(int game, int device, const uint8_t* init, uint32_t init_s
   if (init) { TRY3(dalloc(d_init, static_cast<size_t>(n) * init_stride)); TRY3(hipMemcpy(d_init, init, static_cast<size_t>(n) * init_stride, hipMemcpyHostToDevice)); }
   TRY3(dalloc(d_seeds, n)); TRY3(hipMemcpy(d_seeds, seeds, static_cast<size_t>(n) * 8, hipMemcpyHostToDevice));
   TRY3(dalloc(d_v, static_cast<size_t>(n) * V)); TRY3(dalloc(d_pi, static_cast<size_t>(n) * gi.M)); TRY3(dalloc(d_status, n));
-  k_playout<Connect4><<<(n + 63) / 64, 64>>>(d_init, d_moves, n, len, d_seeds, d_v, d_pi, d_status);
+  if (game == AZMI_GAME_CONNECT4) {
+    k_playout<Connect4><<<(n + 63) / 64, 64>>>(d_init, d_moves, n, len, d_seeds, d_v, d_pi, d_status);
+  } else {
+    uint64_t* d_rep = nullptr;
+    const uint32_t stride = len + gi.max_turns + 4;
+    TRY3(dalloc(d_rep, static_cast<size_t>(n) * stride));
+    if (game == AZMI_GAME_TAWLBWRDD) k_playout_tafl<Tawlbwrdd><<<(n + 63) / 64, 64>>>(d_init, init_stride, d_moves, n, len, d_rep, stride, d_seeds, d_v, d_pi, d_status);
+    else if (game == AZMI_GAME_BRANDUBH) k_playout_tafl<Brandubh><<<(n + 63) / 64, 64>>>(d_init, init_stride, d_moves, n, len, d_rep, stride, d_seeds, d_v, d_pi, d_status);
+    else k_playout_tafl<OpenTafl><<<(n + 63) / 64, 64>>>(d_init, init_stride, d_moves, n, len, d_rep, stride, d_seeds, d_v, d_pi, d_status);
+  }
   TRY3(hipGetLastError());
   TRY3(hipDeviceSynchronize());
   std::vector<int32_t> st(n);

@@ -248,3 +248,32 @@ def test_symmetry_kernel_policy_permutation_equals_the_reference_move_maps(az):
                 if b not in orbit:
                     orbit.add(b); frontier.append(b)
         assert images[int(m)] == orbit
+
+
+@pytest.mark.parametrize("name", ["TawlbwrddGS", "BrandubhGS", "OpenTaflGS"])
+def test_playout_eval_matches_oracle(az, oracle, name):
+    """playout_eval_batch (game_state.cc:10-95) for the Tafl family: uniform policy over the legal moves and the outcome of a
+    random rollout with the repetition rule in force, equal to the oracle's rollout on the same stream."""
+    Game = getattr(az, name)
+    gid = {"TawlbwrddGS": oracle.GAME_TAWLBWRDD, "BrandubhGS": oracle.GAME_BRANDUBH, "OpenTaflGS": oracle.GAME_OPENTAFL}[name]
+    rng = np.random.default_rng(12)
+    states, ogames = [], []
+    for i in range(10):
+        g = Game(); og = oracle.Game(gid)
+        for _ in range(int(rng.integers(0, 14))):
+            legal = np.flatnonzero(g.valid_moves())
+            if g.scores() is not None or len(legal) == 0:
+                break
+            m = int(rng.choice(legal)); g.play_move(m); og.play(m)
+        if g.scores() is None:
+            states.append(g); ogames.append(og)
+    seeds = np.arange(500, 500 + len(states), dtype=np.uint64)
+    vs, pis = az.playout_eval_batch(states, seeds)
+    outcomes = np.zeros(3)
+    for g, og, sd, v, pi in zip(states, ogames, seeds, vs, pis):
+        ov, opi = oracle.playout_eval(og, int(sd))
+        assert np.array_equal(v, ov) and np.array_equal(pi, opi)
+        valid = np.asarray(g.valid_moves(), dtype=np.float32)
+        assert np.array_equal(pi > 0, valid > 0) and abs(pi.sum() - 1) < 1e-5
+        outcomes += v
+    assert outcomes.sum() == len(states)
