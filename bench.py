@@ -270,6 +270,7 @@ def main():
         # cache and are not terminal) = the `evals` counter; other paths evaluate the whole slot-indexed batch
         rows_evaluated = n_evals if (hip_net is not None and not tafl) else float(Se) * launches
         achieved = flop_per_eval * rows_evaluated / dt / 1e12
+        per_launch = (flop_per_eval * rows_evaluated / launches) / (nn_ms * 1e-3) / 1e12 if nn_ms > 0 else achieved
         out = {
             "metric": "self-play games/sec (whole node), Connect4 @ 800 MCTS sims" if not tafl else f"self-play games/sec (whole node), Tawlbwrdd @ {sims} MCTS sims",
             "value": n_games / dt,
@@ -294,10 +295,15 @@ def main():
                 "games_in_window": n_games,
             },
             "roofline": {
-                "bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
+                "bound": "mfma", "achieved": per_launch, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": per_launch / MFMA_PEAK_TFLOPS, "traffic": None,
                 "kernel": "%s: %.0f positions (avg) x %.1f MFLOP per launch, %d overlapping launches per round" % ("k_leafnet_spatial" if tafl else "k_leafnet", rows_evaluated / launches, flop_per_eval / 1e6, K),
-                "per_launch_event_ms": nn_ms, "definition": "sum of algorithmic FLOPs of all k_leafnet launches in the timed region / wall time of the region",
+                "per_launch_event_ms": nn_ms,
+                "aggregate_achieved": achieved, "aggregate_frac": achieved / MFMA_PEAK_TFLOPS,
+                "definition": "achieved = algorithmic FLOPs of ONE launch (positions it evaluated x FLOP per position) / its average duration, "
+                              "HIP events on its stream over the timed region (the rocprof average in profiles/ agrees); K launches overlap "
+                              "and share the chip with each other and with the tree kernels, so the whole-GPU rate is aggregate_achieved = "
+                              "FLOPs of all launches of the region / wall time of the region",
             },
         }
         # HBM-side traffic of the dominant kernel: not measurable from inside the process; taken from the committed
@@ -308,9 +314,11 @@ def main():
             # the second kernel of the path, the tree step (HBM side): algorithmic bytes per simulation from SURVEY §8d
             # (select + backup + expand + state + canonical + eval rows = 1.3 KB with the measured depth 3.5 / 6.8 children)
             b_sim = 1300.0
+            tree_launch = (b_sim * n_sims / launches) / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
             out["roofline_tree"] = {
-                "kernel": "k_round<Connect4>", "bound": "hbm", "achieved": b_sim * n_sims / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
-                "frac": b_sim * n_sims / dt / 1e9 / 8000.0, "traffic": None, "per_launch_event_ms": tree_ms,
+                "kernel": "k_cache_insert + k_round<Connect4> (one shard-round)", "bound": "hbm", "achieved": tree_launch, "peak": 8000.0, "unit": "GB/s",
+                "frac": tree_launch / 8000.0, "traffic": None, "per_launch_event_ms": tree_ms,
+                "aggregate_achieved": b_sim * n_sims / dt / 1e9, "aggregate_frac": b_sim * n_sims / dt / 1e9 / 8000.0,
                 "note": "latency-bound, not bandwidth-bound: one simulation is a chain of ~8 dependent memory round trips; "
                         "the figure to watch is the per-launch time (profiles/r1_kernel_stats.csv)"}
         if not tafl and hip_net is not None and os.path.exists(pmc):
