@@ -167,17 +167,20 @@ int launch_round(azmi_pm* pm, hipStream_t st) {
     }
     case AZMI_GAME_TAWLBWRDD:
       launch_pre_round<Tawlbwrdd>(pm, st);
-      k_round_big<Tawlbwrdd><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
+      if (pm->any_playout) k_round_big<Tawlbwrdd, true><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
+      else k_round_big<Tawlbwrdd><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
       if (pm->ep.half_nodes) k_compact<Tawlbwrdd><<<pm->ep.S * pm->gi.P, 256, 0, st>>>(pm->ep, pm->ar);
       break;
     case AZMI_GAME_BRANDUBH:
       launch_pre_round<Brandubh>(pm, st);
-      k_round_big<Brandubh><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
+      if (pm->any_playout) k_round_big<Brandubh, true><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
+      else k_round_big<Brandubh><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
       if (pm->ep.half_nodes) k_compact<Brandubh><<<pm->ep.S * pm->gi.P, 256, 0, st>>>(pm->ep, pm->ar);
       break;
     case AZMI_GAME_OPENTAFL:
       launch_pre_round<OpenTafl>(pm, st);
-      k_round_big<OpenTafl><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
+      if (pm->any_playout) k_round_big<OpenTafl, true><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
+      else k_round_big<OpenTafl><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
       if (pm->ep.half_nodes) k_compact<OpenTafl><<<pm->ep.S * pm->gi.P, 256, 0, st>>>(pm->ep, pm->ar);
       break;
     default:
@@ -608,8 +611,6 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
   SeatTables seats;
   { const int rc_seats = build_seat_tables(params, gi.P, &seats); if (rc_seats != AZMI_OK) return rc_seats; }
   if (params->resign_percent > 0 && gi.P != 2) return fail(AZMI_ERR_INVALID, "Resigning only works in 2 player games");
-  if (seats.any_playout && game != AZMI_GAME_CONNECT4)
-    return fail(AZMI_ERR_INVALID, "EvalType::PLAYOUT is implemented on the device for Connect4 only");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(AZMI_ERR_NO_DEVICE, "no HIP device: libazmi has no CPU path");

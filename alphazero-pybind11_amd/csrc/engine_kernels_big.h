@@ -46,6 +46,8 @@ struct BigSlot {
   uint32_t t_root[P], t_bump[P], t_depth[P];
   uint64_t t_tld[P];
   uint32_t cur, plen, ph_rows, glen;
+  uint32_t leaf_rep_len = 0;      // find_leaf: entries of sm.plist at the leaf, and whether the game's list still counts
+  bool leaf_base_valid = true;    // (a capture on the path clears it); the rollout of a PLAYOUT seat continues from them
   // per-seat search settings of this game's seat permutation (see SlotCtx)
   uint32_t perm, sv_w0[P], sv_w1[P];
   float sv_eps[P], sv_rt[P];
@@ -54,6 +56,7 @@ struct BigSlot {
   __device__ __forceinline__ bool seat_fpu_zero(uint32_t seat) const { return (AZB_SEL(sv_w1, seat) >> 24) & 1u; }
   __device__ __forceinline__ bool seat_eval_random(uint32_t seat) const { return (AZB_SEL(sv_w1, seat) >> 25) & 1u; }
   __device__ __forceinline__ uint32_t seat_group(uint32_t seat) const { return (AZB_SEL(sv_w1, seat) >> 26) & 3u; }
+  __device__ __forceinline__ bool seat_eval_playout(uint32_t seat) const { return (AZB_SEL(sv_w1, seat) >> 28) & 1u; }
   __device__ __forceinline__ float seat_eps(uint32_t seat) const { return AZB_SEL(sv_eps, seat); }
   __device__ __forceinline__ float seat_root_temp(uint32_t seat) const { return AZB_SEL(sv_rt, seat); }
   // per-seat Gumbel / resign settings (words 4-7 of the seat record), read on demand
@@ -497,6 +500,7 @@ struct BigSlot {
       meta = ar.META[tb + cur];
       if (!step_state(leaf, meta_mv(meta), sm.plist, path_len, base_valid, glen)) { raise(64u); return false; }
     }
+    leaf_rep_len = path_len; leaf_base_valid = base_valid;
 #pragma unroll
     for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == seat) t_tld[p] += plen;
     term = meta_term(meta);
@@ -589,6 +593,56 @@ struct BigSlot {
     sync();
   }
 
+  // ---- playout_eval, game_state.cc:10-54, for the wide games: the scores of a uniformly random rollout from the leaf go
+  // to the slot's v row (process_result gives the leaf the uniform policy itself).  One draw of the slot's rollout stream
+  // per move picks the lemire_below(#legal)-th legal move in ascending move order; the repetition bookkeeping continues
+  // the descent's path-local list, so the rollout sees the same counts as the reference's copied game state.
+  __device__ __forceinline__ void playout_eval(const typename GM::State& leaf) {
+    Pcg32 roll;
+    roll.state = ar.roll[slot];
+    typename GM::State sim = leaf;
+    uint32_t rep_len = leaf_rep_len;
+    bool base_valid = leaf_base_valid;
+    uint32_t term = GM::terminal(sim);
+    while (term == 0) {
+      uint32_t mask[2], cnt[2], incl[2], total[2];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const uint32_t sq = half * 64 + lane;
+        mask[half] = (sq < static_cast<uint32_t>(GM::SQ) && GM::own_piece(sim, sim.player, sq)) ? GM::slide_mask(sim, sq) : 0u;
+        cnt[half] = __builtin_popcount(mask[half]);
+        uint32_t in = cnt[half];
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t o = __shfl_up(in, off, 64);
+          if (lane >= static_cast<uint32_t>(off)) in += o;
+        }
+        incl[half] = in;
+        total[half] = __shfl(in, 63, 64);
+      }
+      const uint32_t k = total[0] + total[1];
+      if (k == 0) break;
+      const uint32_t r = lemire_below(roll, k);
+      uint32_t mine = 0xFFFFFFFFu;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const uint32_t lo = (half ? total[0] : 0u) + incl[half] - cnt[half];
+        if (r >= lo && r < lo + cnt[half]) {
+          uint32_t m = mask[half];
+          for (uint32_t j = lo; j < r; ++j) m &= m - 1;
+          mine = (half * 64 + lane) * (GM::W + GM::H) + __builtin_ctz(m);
+        }
+      }
+      const uint64_t owner = __ballot(mine != 0xFFFFFFFFu);
+      const uint32_t mv = __shfl(mine, static_cast<int>(__builtin_ctzll(owner)), 64);
+      if (!step_state(sim, mv, sm.plist, rep_len, base_valid, glen)) break;
+      term = GM::terminal(sim);
+    }
+    if (lane <= static_cast<uint32_t>(P))
+      ar.v[static_cast<size_t>(slot) * (P + 1) + lane] = term ? ((term - 1 == lane) ? 1.0f : 0.0f) : static_cast<float>(1.0 / (P + 1));
+    if (lane == 0) ar.roll[slot] = roll.state;
+    sync();
+  }
+
   // ---- MCTS::process_result --------------------------------------------------------------------------------------------
   __device__ __forceinline__ void process_result(uint32_t seat, bool from_net, bool root_noise) {
     sync();
@@ -610,12 +664,13 @@ struct BigSlot {
         for (int i = 0; i <= P; ++i) val[i] = static_cast<float>(1.0 / (P + 1));
       }
       const float ksum = static_cast<float>(k & 0xFFu);  // dumb_eval: u8 sum wraps (game_state.h:167, shapes.h:14)
+      const bool pi_rows = from_net && !seat_eval_playout(seat);   // a PLAYOUT seat's rows hold the rollout's scores only
       const bool is_root = cur == root;
       const float root_temp = seat_root_temp(seat);
       const bool root_pow = is_root && root_temp != 1.0f;
       for (uint32_t i = lane; i < k; i += G) {
         float p;
-        if (from_net) p = ar.pi[static_cast<size_t>(slot) * M + meta_mv(ar.META[tb + c0 + i])];
+        if (pi_rows) p = ar.pi[static_cast<size_t>(slot) * M + meta_mv(ar.META[tb + c0 + i])];
         else p = (ksum == 0.0f) ? 0.0f : 1.0f / ksum;
         if (root_pow) p = az_powf(p, 1.0f / root_temp);
         sm.f0[i] = p;
@@ -1096,7 +1151,7 @@ struct BigSlot {
 };
 
 // One round for every slot of a wide-node game: one wavefront (= one workgroup) per slot.
-template <class GM>
+template <class GM, bool kPlayout = false>
 __global__ __launch_bounds__(64) void k_round_big(EngineParams ep, EngineArrays ar) {
   __shared__ BigScratch<GM> sm;
   const uint32_t slot = blockIdx.x, lane = threadIdx.x;
@@ -1126,8 +1181,11 @@ __global__ __launch_bounds__(64) void k_round_big(EngineParams ep, EngineArrays 
     typename GM::State leaf;
     uint32_t term = 0;
     if (!c.find_leaf(cp, leaf, term)) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; c.store(kSlotDone); return; }
-    const bool needs_net = term == 0 && !c.seat_eval_random(cp);
-    c.flags = needs_net ? (c.flags | kFlagLeafNeedsNet) : (c.flags & ~kFlagLeafNeedsNet);
+    const bool playout = kPlayout && term == 0 && c.seat_eval_playout(cp);   // (a terminal leaf's evaluation is never used)
+    const bool needs_net = term == 0 && !c.seat_eval_random(cp) && !playout;
+    // kFlagLeafNeedsNet = "process_result reads the slot's v row": a net answer or the rollout's
+    c.flags = (needs_net || playout) ? (c.flags | kFlagLeafNeedsNet) : (c.flags & ~kFlagLeafNeedsNet);
+    if constexpr (kPlayout) { if (playout) c.playout_eval(leaf); }
     if (needs_net) {
       const uint64_t key = c.emit_leaf(leaf);
       const uint32_t group = c.seat_group(cp);

@@ -240,7 +240,8 @@ int azmi_game_replay_from(int game, int device, const uint8_t* init, uint32_t in
 /* playout_eval(gs) / playout_eval_batch(states), game_state.cc:10-95 (Python: py_wrapper.cc:726-770): for each of n states
  * (start position + move list, as in azmi_game_replay_from) pi = uniform over the legal moves, v = the scores of a uniformly
  * random rollout.  The reference's rollout RNG is an unseedable thread-local engine; here state i uses a pcg32 stream
- * seeded with seeds[i].  v [n,P+1], pi [n,M] are HOST arrays.  All four games (EvalType::PLAYOUT seats of an engine: Connect4). */
+ * seeded with seeds[i].  v [n,P+1], pi [n,M] are HOST arrays.  All four games; EvalType::PLAYOUT seats of an engine run the same
+ * rollout on the device from the slot's third pcg32 stream. */
 int azmi_playout_eval(int game, int device, const uint8_t* init, uint32_t init_stride, const int32_t* moves, uint32_t n, uint32_t len,
                       const uint64_t* seeds, float* v, float* pi);
 /* flags bit 0 (Brandubh / OpenTafl): apply moves the way the reference's play_move does — no ownership or slide

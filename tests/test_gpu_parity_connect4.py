@@ -396,6 +396,3 @@ def test_playout_seats_match_oracle(oracle):
             assert np.array_equal(counts[sel], ocounts), s
             total += o.scores()
         assert np.array_equal(pm.scores(), total)
-    pp.eval_type = [az.EvalType.PLAYOUT, az.EvalType.PLAYOUT]
-    with pytest.raises(RuntimeError, match="Connect4 only"):
-        az.PlayManager(az.TawlbwrddGS(), pp)

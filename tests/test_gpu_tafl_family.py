@@ -277,3 +277,39 @@ def test_playout_eval_matches_oracle(az, oracle, name):
         assert np.array_equal(pi > 0, valid > 0) and abs(pi.sum() - 1) < 1e-5
         outcomes += v
     assert outcomes.sum() == len(states)
+
+
+@pytest.mark.parametrize("name,evals", [
+    ("BrandubhGS", ("PLAYOUT", "PLAYOUT")),
+    ("BrandubhGS", ("PLAYOUT", "RANDOM")),
+    ("OpenTaflGS", ("RANDOM", "PLAYOUT")),
+    ("TawlbwrddGS", ("PLAYOUT", "PLAYOUT")),
+])
+def test_playout_seats_match_oracle(az, oracle, name, evals):
+    """EvalType.PLAYOUT seats of the wide-game engine (play_manager.cc:580-582, game_state.cc:10-54): the rollout starts at
+    the leaf with the descent's repetition counts and draws from the slot's rollout stream; moves, visit counts and scores
+    equal the oracle's."""
+    Game = getattr(az, name)
+    gid = {"TawlbwrddGS": oracle.GAME_TAWLBWRDD, "BrandubhGS": oracle.GAME_BRANDUBH, "OpenTaflGS": oracle.GAME_OPENTAFL}[name]
+    n = 3 if name == "TawlbwrddGS" else 4
+    pp = az.PlayParams()
+    pp.eval_type = [getattr(az.EvalType, e) for e in evals]
+    pp.games_to_play, pp.concurrent_games, pp.max_batch_size = n, n, n
+    pp.mcts_visits = [12, 10]
+    pp.cpuct, pp.fpu_reduction = 1.25, 0.25
+    seed = 77
+    pm = az.PlayManager(Game(), pp, seed=seed, log_moves=True)
+    pm.play()
+    rows, counts = pm.move_log()
+    tot = np.zeros(3, np.float32)
+    for s in range(n):
+        one = az.PlayParams(); one.__dict__.update(pp.__dict__)
+        one.games_to_play, one.concurrent_games = 1, 1
+        o = oracle.PlayManager(gid, one, oracle.slot_seed(seed, s), per_slot_rng=False)
+        o.run()
+        orows, ocounts = o.moves()
+        sel = rows[:, 0] == s
+        assert np.array_equal(rows[sel][:, 1:], orows[:, 1:]), s
+        assert np.array_equal(counts[sel], ocounts), s
+        tot += o.scores()
+    assert np.array_equal(pm.scores(), tot)
