@@ -75,60 +75,67 @@ def _f32_frags(w):
     return out.tobytes()
 
 
+def _pad(t, *shape):
+    """t zero-padded (at the high end of every axis) to `shape`, float64."""
+    t = torch.as_tensor(t, dtype=torch.float64)
+    out = torch.zeros(shape, dtype=torch.float64)
+    out[tuple(slice(0, n) for n in t.shape)] = t
+    return out
+
+
 def _fold_trunk(net, sd, Cin):
+    """Stem + residual tower as 64-channel fragments.  A narrower trunk (configs/brandubh.yaml: 32 channels) is zero-padded:
+    the padded channels have zero weights, scales and biases, so they stay exactly 0 through every affine / ReLU / conv."""
     blob = bytearray()
     a, b = (t.cpu() for t in bn_affine(net.bn1))
     w = sd["conv1.weight"] * a[:, None, None, None]
     wm = np.zeros((64, 64 * ((9 * Cin + 63) // 64)))     # im2col rows in passes of 64 (spatial kernel: up to two)
-    wm[:, : 9 * Cin] = w.permute(0, 2, 3, 1).reshape(64, 9 * Cin).numpy()
-    blob += _frags(wm) + _f32(b)
+    wm[: w.shape[0], : 9 * Cin] = w.permute(0, 2, 3, 1).reshape(w.shape[0], 9 * Cin).numpy()
+    blob += _frags(wm) + _f32(_pad(b, 64))
     for i, blk in enumerate(net.conv_layers):
         a1, b1 = (t.cpu() for t in bn_affine(blk.bn1))
         a2, b2 = (t.cpu() for t in bn_affine(blk.bn2))
         w1 = sd[f"conv_layers.{i}.conv1.weight"] * a2[:, None, None, None]
         w2 = sd[f"conv_layers.{i}.conv2.weight"]
-        blob += _f32(a1) + _f32(b1) + _f32(b2)
-        blob += _frags(w1.permute(0, 2, 3, 1).reshape(64, 576).numpy())
-        blob += _frags(w2.permute(0, 2, 3, 1).reshape(64, 576).numpy())
+        blob += _f32(_pad(a1, 64)) + _f32(_pad(b1, 64)) + _f32(_pad(b2, 64))
+        blob += _frags(_pad(w1.permute(0, 2, 3, 1), 64, 3, 3, 64).reshape(64, 576).numpy())
+        blob += _frags(_pad(w2.permute(0, 2, 3, 1), 64, 3, 3, 64).reshape(64, 576).numpy())
     return blob
 
 
 def fold_spatial(net):
-    """Spatial-policy-head nets (Tafl family: head_channels 64, one extra conv per head, v_fc_layers >= 1).
+    """Spatial-policy-head nets (Tafl family: one extra conv per head, v_fc_layers >= 1; trunk and head widths up to 64
+    channels, narrower ones zero-padded to 64).
     Blob: stem | blocks | head frag[2][8] + b[128] | v_extra frag[18][4] + b[64] | pi_extra frag[18][4] + b[64] |
     policy 1x1 frag[2][2] + b[32] | fc1 f32-frag[Hd/16][4] b | extra FC (f32-frag[Hd/16][Hd/16])* then (b[Hd])* | fc2 f32-frag[1][Hd/16] b[16]."""
     spec = net.spec
     Cin, H, W = spec.in_shape
-    if not (spec.num_channels == 64 and spec.head_channels == 64 and spec.kernel_size == 3 and spec.head_pool
-            and spec.v_head_convs == 1 and spec.pi_head_convs == 1 and 9 * Cin <= 128 and (H, W) == (11, 11)):
-        raise RuntimeError("the bf16 MFMA spatial-head kernel covers the configs/tawlbwrdd.yaml and configs/open_tafl.yaml nets "
-                           "(11x11, 64 trunk / 64 head channels, one extra conv per head, 9*C_in <= 128); use precision='fp32' "
-                           "for other shapes")
+    if not (spec.num_channels <= 64 and spec.head_channels <= 64 and spec.kernel_size == 3 and spec.head_pool
+            and spec.v_head_convs == 1 and spec.pi_head_convs == 1 and 9 * Cin <= 128 and (H, W) in ((11, 11), (7, 7))):
+        raise RuntimeError("the bf16 MFMA spatial-head kernel covers the configs/tawlbwrdd.yaml, configs/open_tafl.yaml and "
+                           "configs/brandubh.yaml nets (11x11 or 7x7, <= 64 trunk / head channels, one extra conv per head, "
+                           "9*C_in <= 128); use precision='fp32' for other shapes")
     pc = spec.policy_shape[0]
     Hd, L, P1 = spec.v_fc_hidden, spec.v_fc_layers, spec.num_players + 1
     sd = {k: v.detach().double().cpu() for k, v in net.state_dict().items()}
     blob = _fold_trunk(net, sd, Cin)
     av, bv = (t.cpu() for t in bn_affine(net.v_bn))
     ap, bp = (t.cpu() for t in bn_affine(net.pi_bn))
-    wh = torch.cat([sd["v_conv.weight"][:, :, 0, 0] * av[:, None], sd["pi_conv.weight"][:, :, 0, 0] * ap[:, None]], 0)
-    blob += _frags(wh.numpy()) + _f32(torch.cat([bv, bp]))
+    wh = torch.cat([_pad(sd["v_conv.weight"][:, :, 0, 0] * av[:, None], 64, 64), _pad(sd["pi_conv.weight"][:, :, 0, 0] * ap[:, None], 64, 64)], 0)
+    blob += _frags(wh.numpy()) + _f32(torch.cat([_pad(bv, 64), _pad(bp, 64)]))
     for seq, name in ((net.v_extra_convs, "v_extra_convs"), (net.pi_extra_convs, "pi_extra_convs")):
         a, b = (t.cpu() for t in bn_affine(seq[1]))
         w = sd[f"{name}.0.weight"] * a[:, None, None, None]
-        blob += _frags(w.permute(0, 2, 3, 1).reshape(64, 576).numpy()) + _f32(b)
+        blob += _frags(_pad(w.permute(0, 2, 3, 1), 64, 3, 3, 64).reshape(64, 576).numpy()) + _f32(_pad(b, 64))
     a2, b2 = (t.cpu() for t in bn_affine(net.pi_bn2))
-    wpol = torch.zeros((32, 64), dtype=torch.float64)
-    wpol[:pc] = sd["pi_conv2.weight"][:, :, 0, 0] * a2[:, None]
-    bpol = torch.zeros(32, dtype=torch.float64); bpol[:pc] = b2
-    blob += _frags(wpol.numpy()) + _f32(bpol)
-    blob += _f32_frags(sd["v_fc1.weight"].numpy()) + _f32(sd["v_fc1.bias"])
+    wpol = _pad(sd["pi_conv2.weight"][:, :, 0, 0] * a2[:, None], 32, 64)
+    blob += _frags(wpol.numpy()) + _f32(_pad(b2, 32))
+    blob += _f32_frags(_pad(sd["v_fc1.weight"], Hd, 64).numpy()) + _f32(sd["v_fc1.bias"])
     for l in range(L - 1):
         blob += _f32_frags(sd[f"v_fc_extra.{2 * l}.weight"].numpy())
     for l in range(L - 1):
         blob += _f32(sd[f"v_fc_extra.{2 * l}.bias"])
-    w2 = np.zeros((16, Hd)); w2[:P1] = sd["v_fc2.weight"].numpy()
-    b2f = torch.zeros(16, dtype=torch.float64); b2f[:P1] = sd["v_fc2.bias"]
-    blob += _f32_frags(w2) + _f32(b2f)
+    blob += _f32_frags(_pad(sd["v_fc2.weight"], 16, Hd).numpy()) + _f32(_pad(sd["v_fc2.bias"], 16))
     desc = NetDescC(Cin, H, W, 64, spec.depth, 3, 64, Hd, spec.num_moves, spec.num_players, 1, 1, L, pc, 0)
     assert len(blob) == lib.azmi_net_blob_bytes(C.byref(desc)), (len(blob), lib.azmi_net_blob_bytes(C.byref(desc)))
     return desc, bytes(blob)

@@ -450,9 +450,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_leafnet(NetDesc nd, NetPtrs np,
 //            v2 = relu(conv3x3(hv) + b)           p2 = relu(conv3x3(hp) + b)           (extra head convs, BN folded)
 //            pooled = avgpool(v2)  -> k_value_fc  logits[h][w][c] = conv1x1(p2) + b    (pi_conv2 * pi_bn2 folded)
 //            pi = softmax over all H*W*C logits of a board (index (h*W + w)*C + c = the game's move index)
-// Same implicit-GEMM tower as k_leafnet with TBS = 3 boards per workgroup (3 * 121 = 363 pixels = 23 n-tiles,
-// 3 per wave); the value head's FC stack runs batched in k_value_fc on the exact-fp32 matrix pipe.
-constexpr int TBS = 3;
+// Same implicit-GEMM tower as k_leafnet with TBS boards per workgroup: 3 for 11x11 (3 * 121 = 363 pixels = 23 n-tiles,
+// 3 per wave), 7 for 7x7 (343 pixels = 22 n-tiles); the value head's FC stack runs batched in k_value_fc on the exact-fp32
+// matrix pipe.  Nets with fewer than 64 trunk / head channels (configs/brandubh.yaml: 32) are zero-padded to 64 by the
+// host-side fold: the padded channels stay exactly 0 through every affine, ReLU and convolution.
+constexpr int TBS11 = 3, TBS7 = 7;
 constexpr int HCS = 64;
 
 struct SpatialDesc {
@@ -474,7 +476,7 @@ struct SpatialPtrs {
   const float* fc2_b;      // [16]
 };
 
-template <int H, int W>
+template <int H, int W, int TBS>
 __global__ __launch_bounds__(NTHREADS, 2) void k_leafnet_spatial(SpatialDesc nd, SpatialPtrs np, const float* __restrict__ canon,
                                                                   float* __restrict__ vpool_out, float* __restrict__ pi_out,
                                                                   uint32_t batch) {
@@ -725,8 +727,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_leafnet_spatial(SpatialDesc nd,
         }
       }
       __syncthreads();
-      if (tid < TBS * 128) {
-        const int b = tid / 128, r = tid % 128, c = r % 32, part = r / 32;
+      for (int t = tid; t < TBS * 128; t += NTHREADS) {
+        const int b = t / 128, r = t % 128, c = r % 32, part = r / 32;
         constexpr int per = (G::PIX + 3) / 4;
         const int p0 = part * per, p1 = (p0 + per < G::PIX) ? p0 + per : G::PIX;
         float acc = 0.0f;
@@ -735,6 +737,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_leafnet_spatial(SpatialDesc nd,
       }
       __syncthreads();
     }
+    static_assert(TBS * 64 <= NTHREADS && TBS <= NWAVES, "one thread per (board, channel); one wave per board's softmax");
     if (tid < TBS * 64) {
       const int b = tid / 64, c = tid % 64;
       const float* q = psum + (b * 64 + c) * 4;
@@ -972,7 +975,8 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
   if (is_spatial(d)) {
     if (d->channels != CH || d->head_channels != HCS || d->kernel_size != 3 || d->v_head_convs != 1 || d->pi_head_convs != 1)
       return nfail(AZMI_ERR_INVALID, "spatial leaf net kernel covers 64 trunk / 64 head channels, 3x3 convs, one extra conv per head");
-    if (!(d->height == 11 && d->width == 11)) return nfail(AZMI_ERR_INVALID, "spatial leaf net kernel: board %dx%d not instantiated", d->height, d->width);
+    const bool b11 = d->height == 11 && d->width == 11, b7 = d->height == 7 && d->width == 7;
+    if (!b11 && !b7) return nfail(AZMI_ERR_INVALID, "spatial leaf net kernel: board %dx%d not instantiated", d->height, d->width);
     if (9 * d->in_channels > 128 || d->policy_channels > 32 || d->policy_channels * d->height * d->width != d->num_moves)
       return nfail(AZMI_ERR_INVALID, "spatial head: 9*C_in <= 128, policy channels <= 32, no global actions");
     if (d->v_hidden > 512 || d->v_hidden % 256 || d->v_fc_layers < 1 || d->num_players + 1 > 16) return nfail(AZMI_ERR_INVALID, "value head sizes out of range");
@@ -1000,12 +1004,15 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
     sp.fc1_w = f32p(64 * Hd); sp.fc1_b = f32p(Hd);
     sp.fcx_w = f32p((L - 1) * Hd * Hd); sp.fcx_b = f32p((L - 1) * Hd);
     sp.fc2_w = f32p(Hd * 16); sp.fc2_b = f32p(16);
-    using GS = Geo<11, 11, TBS>;
-    net->lds_bytes = GS::ACT_BYTES + GS::WCONV_BYTES;
-    static_assert(GS::NPIX <= NTHREADS, "stem im2col maps one thread to one pixel");
-    static_assert(GS::NPIX * 32 * 4 <= GS::ACT_BYTES, "pooling scratch must fit the activation planes");
-    static_assert(8192 + GS::NPIX * 32 * 4 <= GS::WCONV_BYTES, "policy logits must fit the weight area");
-    static_assert(16384 + TBS * 128 * GS::PIX * 4 / 9 <= GS::WCONV_BYTES, "input staging (<= 14 planes) must fit behind two stem passes");
+    auto reserve = [&](auto geo, const void* kernel) {
+      using GS = decltype(geo);
+      static_assert(GS::NPIX <= NTHREADS, "stem im2col maps one thread to one pixel");
+      static_assert(GS::NPIX * 32 * 4 <= GS::ACT_BYTES, "pooling scratch must fit the activation planes");
+      static_assert(8192 + GS::NPIX * 32 * 4 <= GS::WCONV_BYTES, "policy logits must fit the weight area");
+      static_assert(16384 + GS::NPIX * 128 * 4 / 9 <= GS::WCONV_BYTES, "input staging (<= 14 planes) must fit behind two stem passes");
+      net->lds_bytes = GS::ACT_BYTES + GS::WCONV_BYTES;
+      return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(net->lds_bytes)) == hipSuccess;
+    };
     static_assert(2 * 2 * MT * WFRAG_BYTES <= 16384, "two stem passes of weights sit in front of the input staging");
     net->vfc_lds = (2 * Hd * 16 + VFC_WAVES * 256) * sizeof(float);
     // scratch for 16384 positions up front: forward() may run under stream capture, where hipMalloc is not allowed
@@ -1014,10 +1021,10 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
       (void)hipFree(net->blob); delete net;
       return nfail(AZMI_ERR_OOM, "hipMalloc(value-head scratch) failed");
     }
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_leafnet_spatial<11, 11>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            static_cast<int>(net->lds_bytes)) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_value_fc), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            static_cast<int>(net->vfc_lds)) != hipSuccess) {
+    const bool reserved = b11 ? reserve(Geo<11, 11, TBS11>{}, reinterpret_cast<const void*>(&k_leafnet_spatial<11, 11, TBS11>))
+                              : reserve(Geo<7, 7, TBS7>{}, reinterpret_cast<const void*>(&k_leafnet_spatial<7, 7, TBS7>));
+    if (!reserved || hipFuncSetAttribute(reinterpret_cast<const void*>(&k_value_fc), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         static_cast<int>(net->vfc_lds)) != hipSuccess) {
       (void)hipFree(net->blob); delete net;
       return nfail(AZMI_ERR_NO_DEVICE, "cannot reserve LDS for the spatial leaf net");
     }
@@ -1092,7 +1099,10 @@ int azmi_net_forward(azmi_net* net, const float* dev_canonical, float* dev_v, fl
         return nfail(AZMI_ERR_OOM, "hipMalloc(value-head scratch) failed");
       net->vpool_rows = batch;
     }
-    k_leafnet_spatial<11, 11><<<(batch + TBS - 1) / TBS, NTHREADS, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, net->vpool, dev_pi, batch);
+    if (net->sd.H == 11)
+      k_leafnet_spatial<11, 11, TBS11><<<(batch + TBS11 - 1) / TBS11, NTHREADS, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, net->vpool, dev_pi, batch);
+    else
+      k_leafnet_spatial<7, 7, TBS7><<<(batch + TBS7 - 1) / TBS7, NTHREADS, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, net->vpool, dev_pi, batch);
     k_value_fc<<<(batch + 15) / 16, VFC_THREADS, net->vfc_lds, st>>>(net->sd, net->sp, net->vpool, dev_v, batch);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return nfail(AZMI_ERR_NO_DEVICE, "k_leafnet_spatial launch: %s", hipGetErrorString(e));

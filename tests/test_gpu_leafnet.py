@@ -171,8 +171,11 @@ def test_fp32_path_other_tafl_nets(which):
         vr, pr = net.to(dev).process(x)
     assert (v - vr).abs().max().item() <= TOL_F32 and (pi - pr).abs().max().item() <= TOL_F32
     if which == "brandubh":
+        wide = torch_net.random_init(torch_net.NetSpec(in_shape=(7, 9, 9), num_moves=18 * 81, num_players=2, num_channels=32, depth=1,
+                                                        kernel_size=3, head_channels=32, v_head_convs=1, pi_head_convs=1,
+                                                        v_fc_layers=2, policy_shape=(18, 9, 9)), seed=1)
         with pytest.raises(RuntimeError):
-            az.HipLeafNet(net)      # no bf16 MFMA kernel for 7x7 / 32 channels: loud failure, never a silent fallback
+            az.HipLeafNet(wide)     # no bf16 MFMA kernel instantiated for 9x9: loud failure, never a silent fallback
 
 
 @pytest.mark.parametrize("batch", [1, 5, 64, 1000])
@@ -246,3 +249,36 @@ def test_brandubh_net_matches_reference_nnarch_fixture():
     dv, dpi = np.abs(v32.cpu().numpy() - fx["v"]).max(), np.abs(pi32.cpu().numpy() - fx["pi"]).max()
     print("brandubh hip fp32 vs reference fp32: %.3e %.3e" % (dv, dpi))
     assert dv <= TOL_F32 and dpi <= TOL_F32
+    # the bf16 MFMA path (32 trunk / head channels zero-padded to the kernels' 64, 7 boards per workgroup): bf16 tolerance
+    v, pi = az.HipLeafNet(net).process(x)
+    dv, dpi = np.abs(v.cpu().numpy() - fx["v"]).max(), np.abs(pi.cpu().numpy() - fx["pi"]).max()
+    print("brandubh hip bf16 vs reference fp32: %.3e %.3e" % (dv, dpi))
+    assert dv <= TOL and dpi <= TOL
+    v16, pi16 = net.to(x.device).process(x, amp_dtype=torch.bfloat16)
+    e16 = max(np.abs(v16.cpu().numpy() - fx["v"]).max(), np.abs(pi16.cpu().numpy() - fx["pi"]).max())
+    assert max(dv, dpi) <= max(2 * e16, 5e-3), (dv, dpi, e16)
+
+
+@pytest.mark.parametrize("batch", [1, 6, 7, 8, 100, 1000])
+def test_brandubh_net_on_the_mfma_path(batch):
+    """configs/brandubh.yaml (4b32c, 7x7, 14 policy channels) on the bf16 MFMA kernels: tolerance against the fp32 PyTorch
+    forward, agreement with the library's own fp32 path, row invariance across tile boundaries (7 boards per workgroup)."""
+    import alphazero as az
+    from alphazero import torch_net
+    dev = torch.device("cuda:0")
+    spec = torch_net.brandubh_spec()
+    net = torch_net.random_init(spec, seed=21)
+    hip = az.HipLeafNet(net)
+    x = (torch.rand((batch,) + tuple(spec.in_shape), generator=torch.Generator().manual_seed(batch)) < 0.2).float().to(dev)
+    v, pi = hip.process(x)
+    v1, pi1 = hip.process(x[batch - 1:].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(v[batch - 1:], v1) and torch.equal(pi[batch - 1:], pi1)
+    assert pi.shape == (batch, 686) and np.allclose(pi.sum(1).cpu().numpy(), 1, atol=1e-4)
+    with torch.no_grad():
+        vr, pr = net.to(dev).process(x)
+    dv, dpi = (v - vr).abs().max().item(), (pi - pr).abs().max().item()
+    print("brandubh hip bf16 vs torch fp32: %.3e %.3e" % (dv, dpi))
+    assert dv <= TOL and dpi <= TOL
+    v32, pi32 = az.HipLeafNet(net.cpu(), precision="fp32").process(x)
+    assert (v32 - vr).abs().max().item() <= TOL_F32 and (pi32 - pr).abs().max().item() <= TOL_F32

@@ -174,6 +174,28 @@ def test_opentafl_selfplay_on_the_hip_net():
     assert c["evals"] > 0 and c["sims"] >= n * 23
 
 
+def test_brandubh_selfplay_on_the_hip_net():
+    """configs/brandubh.yaml end to end on the device: the wide-game engine + the bf16 MFMA net (4b32c zero-padded to the 64-channel
+    kernels, 7x7) through the self-play harness; every game finishes, every history row is a distribution whose mass sits on
+    legal moves of the stored position."""
+    import alphazero as az
+    from alphazero import selfplay, torch_net
+    pp = az.PlayParams()
+    pp.games_to_play, pp.concurrent_games, pp.max_batch_size = 64, 32, 32
+    pp.mcts_visits = [20, 20]
+    pp.model_groups = [0, 0]
+    pp.history_enabled = True
+    pp.cpuct, pp.epsilon = 1.25, 0.25
+    net = torch_net.random_init(torch_net.brandubh_spec(), seed=4)
+    res, (canon, v, pi) = selfplay.self_play(az.BrandubhGS(), pp, az.HipLeafNet(net), engines=2, seed=9)
+    canon, v, pi = (t.cpu().numpy() for t in (canon, v, pi))
+    n = len(canon)
+    assert res.games == 64 and res.samples == n and abs(sum(res.win_rates) - 1) < 1e-6
+    assert n > 64 and canon.shape[1:] == (7, 7, 7) and pi.shape == (n, 686)
+    assert np.abs(pi.sum(1) - 1).max() < 1e-4 and (np.abs(v.sum(1) - 1) < 1e-6).all()
+    assert res.leaf_evaluations > 0 and res.simulations >= 19 * n
+
+
 # ---- test_canon_symmetry.py:131-190: a symmetry-mirrored OpenTafl game stays a perfect image ------------------------------------
 _TW = _TH = 11
 _TWH = _TW + _TH
