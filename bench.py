@@ -139,8 +139,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # AZMI_BENCH_FORCE_DIST=1: run the N > 1 code path (RCCL init, barriers, sample gather, reductions) with whatever world size
+    # the launcher gave, 1 included: lets a one-GPU box exercise it under torchrun
+    use_dist = world > 1 or os.environ.get("AZMI_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -221,7 +225,7 @@ def main():
             done += chunk
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -243,7 +247,7 @@ def main():
         raise RuntimeError(f"game stream ran dry inside the timed region ({live} of {S} slots live): raise stream_games")
     hit_rate = (h1 - h0) / max(1, (h1 - h0) + (m1 - m0))
     gathered_rows = 0
-    if world > 1:
+    if use_dist:
         from alphazero import gather
         for pm in pms:
             gathered_rows += gather.gather_history_to_rank0(pm, dev, rank, world)
@@ -251,7 +255,7 @@ def main():
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev)
     games = torch.tensor([float(done1 - done0), float(sims1 - sims0), float(evals1 - evals0)], device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(games, op=dist.ReduceOp.SUM)
     dt = float(tmax.item())
@@ -379,7 +383,7 @@ def main():
                              f"{evals_per_game:.0f} net evaluations per game (the GPU run's count, cache included); "
                              f"value = 1 / (1/{tree_rate:.0f} + {evals_per_game:.0f}/{evals_cpu:.0f}) games/s")
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
