@@ -318,7 +318,9 @@ typedef struct azmi_net_desc {
   int32_t head_channels, v_hidden;      /* NNArgs.head_channels / v_fc_hidden */
   int32_t num_moves, num_players;
   /* head options (neural_net.py:56-75, 341-427). policy_channels > 0 selects the spatial policy head
-   * (POLICY_SHAPE[0]; Tafl family 22) and its kernel; 0 = flat FC policy head. */
+   * (POLICY_SHAPE[0]; Tafl family 22, Brandubh 14) and its kernel; 0 = flat FC policy head.
+   * bf16 kernels instantiated: 6x7 flat head (64 trunk / 32 head channels), 11x11 and 7x7 spatial head (64 / 64 channels;
+   * narrower nets are passed zero-padded to 64 by fold()).  Any other shape: AZMI_ERR_INVALID, or precision = 1. */
   int32_t v_head_convs, pi_head_convs, v_fc_layers, policy_channels;
   /* 0 = bf16 operands on the matrix cores, fp32 accumulation (what the reference runs under autocast,
    * neural_net.py:811-813) — the throughput path.  1 = plain fp32 arithmetic, layer by layer: the precision
