@@ -1032,6 +1032,31 @@ class PlayManager:
                 device_tensor(p.value, (n, self._M), torch.float32, dev),
                 device_tensor(m.value, (n, 4), torch.int32, dev))
 
+    def take_history_device(self, dev=None, consume=True):
+        """The UNREAD finished samples as device tensors (canonical, v, pi, meta) — copies out of the engine's ring
+        (azmi_pm_history_window: the window may wrap) — and, with `consume`, their release (azmi_pm_history_consume): the
+        device-side counterpart of build_history_batch for the RCCL sample gather and for long self-play streams."""
+        import torch
+        from ._torch_view import device_tensor
+        first, rows, cap = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(lib.azmi_pm_history_window(self._h, C.byref(first), C.byref(rows), C.byref(cap)))
+        n, f, cp = rows.value, first.value, cap.value
+        dev = dev or torch.device("cuda", torch.cuda.current_device())
+        if n == 0:
+            z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+            return z(0, *self._chw), z(0, self._P + 1), z(0, self._M), torch.zeros((0, 4), dtype=torch.int32, device=dev)
+        c, v, p, m = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(lib.azmi_pm_history_device(self._h, C.byref(c), C.byref(v), C.byref(p), C.byref(m), None))
+        full = (device_tensor(c.value, (cp,) + tuple(self._chw), torch.float32, dev),
+                device_tensor(v.value, (cp, self._P + 1), torch.float32, dev),
+                device_tensor(p.value, (cp, self._M), torch.float32, dev),
+                device_tensor(m.value, (cp, 4), torch.int32, dev))
+        n1 = min(n, cp - f)
+        out = tuple(torch.cat([t[f:f + n1], t[:n - n1]], 0) if n1 < n else t[f:f + n].clone() for t in full)
+        if consume:
+            check(lib.azmi_pm_history_consume(self._h, n))
+        return out
+
     def move_log(self):
         cap = (int(self._params.games_to_play) + self._S) * 512
         rows = np.zeros((cap, 8), np.uint32)

@@ -132,6 +132,8 @@ SYMBOLS = {
     "azmi_pm_counters": (C.c_int, [_VP, _VP]),
     "azmi_pm_pop_history": (C.c_int, [_VP, _VP, _VP, _VP, C.c_uint32, _PP(C.c_uint32)]),
     "azmi_pm_history_device": (C.c_int, [_VP, _PP(_VP), _PP(_VP), _PP(_VP), _PP(_VP), _PP(C.c_uint32)]),
+    "azmi_pm_history_window": (C.c_int, [_VP, _PP(C.c_uint32), _PP(C.c_uint32), _PP(C.c_uint32)]),
+    "azmi_pm_history_consume": (C.c_int, [_VP, C.c_uint32]),
     "azmi_pm_move_log": (C.c_int, [_VP, _VP, _VP, C.c_uint32, _PP(C.c_uint32)]),
     "azmi_pm_slot_games": (C.c_int, [_VP, _VP]),
     "azmi_pm_build_batch": (C.c_int, [_VP, _VP, C.c_uint32, _VP, _PP(C.c_uint32)]),

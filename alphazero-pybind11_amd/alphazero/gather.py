@@ -36,10 +36,8 @@ def gather_rows_to_rank0(parts, rank, world, group=None):
 
 def gather_history_to_rank0(pm, dev, rank, world):
     """Gathers the rows `pm` has finished since the previous call. Returns total rows on rank 0."""
-    c, v, p, meta = pm.history_device_tensors(dev)
-    start = getattr(pm, "_gather_cursor", 0)
-    parts = [c[start:], v[start:], p[start:]]
-    pm._gather_cursor = c.shape[0]
+    c, v, p, meta = pm.take_history_device(dev)      # the unread rows of the engine's ring, released once copied out
+    parts = [c, v, p]
     res = gather_rows_to_rank0(parts, rank, world)
     if rank == 0:
         pm._gathered = getattr(pm, "_gathered", [])

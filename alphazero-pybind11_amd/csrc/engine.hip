@@ -666,8 +666,19 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
   ep.log_moves = opts.log_moves != 0;
   ep.log_cap = ep.log_moves ? (opts.move_log_capacity ? opts.move_log_capacity
                                                        : (params->games_to_play + ep.S) * gi.max_turns) : 0;
-  ep.hist_cap = ep.history ? (opts.history_capacity ? opts.history_capacity
-                                                    : (params->games_to_play + ep.S) * gi.max_turns) : 0;
+  // finished-sample ring (rows): by default every row of the run, (games_to_play + S) * max_turns, computed in 64 bits and
+  // bounded to 8 GiB of rows (never less than two full games per slot) — a longer run has to drain it
+  // (build_history_batch / azmi_pm_history_consume), like the reference's hist_saver drains the unbounded queue
+  if (ep.history && opts.history_capacity) {
+    ep.hist_cap = opts.history_capacity;
+  } else if (ep.history) {
+    const uint64_t row_bytes = 4ull * (static_cast<uint64_t>(gi.C) * gi.H * gi.W + gi.P + 1 + gi.M + 4);
+    const uint64_t all_rows = (static_cast<uint64_t>(params->games_to_play) + ep.S) * gi.max_turns;
+    const uint64_t bound = std::max<uint64_t>(2ull * ep.S * gi.max_turns, (8ull << 30) / row_bytes);
+    ep.hist_cap = static_cast<uint32_t>(std::min<uint64_t>(std::min(all_rows, bound), 0x7FFFFFFFull));
+  } else {
+    ep.hist_cap = 0;
+  }
 
   const uint32_t S = ep.S, P = gi.P, M = gi.M, CANON = gi.C * gi.H * gi.W;
   const size_t T = static_cast<size_t>(S) * P, NODES = T * ep.cap;
@@ -1138,26 +1149,41 @@ int azmi_pm_counters(azmi_pm* pm, uint64_t* out) {
   uint64_t cs[6];
   rc = azmi_pm_cache_stats(pm, cs); if (rc) return rc;
   out[2] = cs[0]; out[3] = cs[1];
-  out[4] = std::min(c.hist_rows, pm->ep.hist_cap) - pm->hist_read;
+  out[4] = c.hist_rows - pm->hist_read;   // free-running u32 counters: the difference is the live row count
   out[5] = c.rounds;
   return AZMI_OK;
 }
+
+namespace {
+// tells the device how far the host has consumed the finished-sample ring (ordered behind the rounds already queued)
+int publish_hist_read(azmi_pm* pm) {
+  HIP_TRY(hipMemcpyAsync(&pm->ar.ctl->hist_read, &pm->hist_read, sizeof(uint32_t), hipMemcpyHostToDevice, pm->last));
+  HIP_TRY(hipStreamSynchronize(pm->last));
+  return AZMI_OK;
+}
+}  // namespace
 
 int azmi_pm_pop_history(azmi_pm* pm, float* canonical, float* v, float* pi, uint32_t cap, uint32_t* n) {
   if (!pm || !n) return fail(AZMI_ERR_INVALID, "null argument");
   std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   Control c;
   int rc = read_ctl(pm, pm->last, &c, true); if (rc) return rc;
-  const uint32_t avail = std::min(c.hist_rows, pm->ep.hist_cap) - pm->hist_read;
+  const uint32_t avail = c.hist_rows - pm->hist_read;
   const uint32_t take = std::min(avail, cap);
   const uint32_t CANON = pm->gi.C * pm->gi.H * pm->gi.W, V = pm->gi.P + 1, M = pm->gi.M;
-  const size_t r0 = pm->hist_read;
   if (take) {
-    HIP_TRY(hipMemcpy(canonical, pm->ar.h_canon + r0 * CANON, static_cast<size_t>(take) * CANON * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(v, pm->ar.h_v + r0 * V, static_cast<size_t>(take) * V * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(pi, pm->ar.h_pi + r0 * M, static_cast<size_t>(take) * M * 4, hipMemcpyDeviceToHost));
+    const uint32_t first = pm->hist_read % pm->ep.hist_cap;
+    const uint32_t n1 = std::min(take, pm->ep.hist_cap - first);
+    for (int seg = 0; seg < 2; ++seg) {     // the window may wrap around the end of the ring
+      const size_t r0 = seg == 0 ? first : 0, nr = seg == 0 ? n1 : take - n1, o = seg == 0 ? 0 : n1;
+      if (!nr) continue;
+      HIP_TRY(hipMemcpy(canonical + o * CANON, pm->ar.h_canon + r0 * CANON, nr * CANON * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(v + o * V, pm->ar.h_v + r0 * V, nr * V * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(pi + o * M, pm->ar.h_pi + r0 * M, nr * M * 4, hipMemcpyDeviceToHost));
+    }
+    pm->hist_read += take;
+    rc = publish_hist_read(pm); if (rc) return rc;
   }
-  pm->hist_read += take;
   *n = take;
   return AZMI_OK;
 }
@@ -1172,8 +1198,29 @@ int azmi_pm_history_device(azmi_pm* pm, float** dev_canonical, float** dev_v, fl
   if (dev_v) *dev_v = pm->ar.h_v;
   if (dev_pi) *dev_pi = pm->ar.h_pi;
   if (dev_meta) *dev_meta = pm->ar.h_meta;
-  if (rows) *rows = std::min(c.hist_rows, pm->ep.hist_cap);
+  if (rows) *rows = std::min(c.hist_rows, pm->ep.hist_cap);   // rows of the run while nothing has wrapped; use the window call for a ring
   return AZMI_OK;
+}
+
+int azmi_pm_history_window(azmi_pm* pm, uint32_t* first_row, uint32_t* rows, uint32_t* capacity) {
+  if (!pm) return fail(AZMI_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
+  Control c;
+  int rc = read_ctl(pm, pm->last, &c, true); if (rc) return rc;
+  if (first_row) *first_row = pm->ep.hist_cap ? pm->hist_read % pm->ep.hist_cap : 0;
+  if (rows) *rows = c.hist_rows - pm->hist_read;
+  if (capacity) *capacity = pm->ep.hist_cap;
+  return AZMI_OK;
+}
+
+int azmi_pm_history_consume(azmi_pm* pm, uint32_t rows) {
+  if (!pm) return fail(AZMI_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
+  Control c;
+  int rc = read_ctl(pm, pm->last, &c, true); if (rc) return rc;
+  if (rows > c.hist_rows - pm->hist_read) return fail(AZMI_ERR_INVALID, "history_consume: %u rows asked, %u unread", rows, c.hist_rows - pm->hist_read);
+  pm->hist_read += rows;
+  return publish_hist_read(pm);
 }
 
 int azmi_pm_move_log(azmi_pm* pm, uint32_t* rows, uint32_t* counts, uint32_t cap, uint32_t* n) {

@@ -1072,12 +1072,18 @@ struct SlotCtx {
       uint32_t base = 0;
       if (lane == 0) base = atomicAdd(&ar.ctl->hist_rows, rows);
       base = bcast(base, 0);
-      if (base + rows <= ep.hist_cap) {
+      // the finished-sample store is a ring of hist_cap rows (the reference's history queue is unbounded and drained by
+      // hist_saver, game_runner.py:729-747): row i of the run lives at i % hist_cap; it overflows only when the host has not
+      // consumed enough (hist_rows - hist_read > hist_cap).  hist_rows / hist_read are free-running u32 counters.
+      if (base + rows - ar.ctl->hist_read <= ep.hist_cap) {
         const uint32_t game_idx = ar.slot_games[slot];
-        // The game's rows are contiguous on both sides (pending rows of the slot -> `rows` consecutive ring rows): a per-row
+        // The game's rows are contiguous on the pending side and contiguous modulo the ring on the other: a per-row
         // copy loop is a chain of dependent round trips (measured 230 us per game end, which stretched every eighth round
-        // of a shard), so the planes are regenerated from packed positions and the policy rows move as one flat copy.
-        const size_t src0 = static_cast<size_t>(slot) * ep.max_hist_rows, dst0 = base;
+        // of a shard), so the planes are regenerated from packed positions and the policy rows move as flat copies
+        // (two segments when the game's rows wrap around the end of the ring).
+        const size_t src0 = static_cast<size_t>(slot) * ep.max_hist_rows;
+        const uint32_t first = base % ep.hist_cap;
+        const uint32_t n1 = rows < ep.hist_cap - first ? rows : ep.hist_cap - first;
         {
           // canonical planes from the packed pending positions: eight rows' positions per round trip, planes written straight
           // into the ring (stores only)
@@ -1092,31 +1098,36 @@ struct SlotCtx {
               st.bb[0] = bcast(w0, static_cast<int>(j)); st.bb[1] = bcast(w1, static_cast<int>(j));
               const uint64_t t = bcast(w2, static_cast<int>(j));
               st.turn = static_cast<uint32_t>(t); st.player = static_cast<uint32_t>(t >> 32);
-              float* drow = ar.h_canon + (dst0 + r0 + j) * GM::CANON;
+              const uint32_t r = r0 + j;
+              float* drow = ar.h_canon + static_cast<size_t>(r < n1 ? first + r : r - n1) * GM::CANON;
               for (uint32_t e = lane; e < static_cast<uint32_t>(GM::CANON); e += G) drow[e] = GM::canonical_at(st, e);
             }
           }
-          const float* sp = ar.ph_pi + src0 * M;
-          float* dp = ar.h_pi + dst0 * M;
-          const uint32_t np = rows * M;
-          for (uint32_t e0 = 0; e0 < np; e0 += 4 * G) {
-            float t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-            const uint32_t a = e0 + lane, b = a + G, c = b + G, d = c + G;
-            if (a < np) t0 = sp[a];
-            if (b < np) t1 = sp[b];
-            if (c < np) t2 = sp[c];
-            if (d < np) t3 = sp[d];
-            if (a < np) dp[a] = t0;
-            if (b < np) dp[b] = t1;
-            if (c < np) dp[c] = t2;
-            if (d < np) dp[d] = t3;
-          }
-          float* dv = ar.h_v + dst0 * (P + 1);
-          for (uint32_t e = lane; e < rows * (P + 1); e += G) dv[e] = (e % (P + 1) == term - 1) ? 1.0f : 0.0f;
-          for (uint32_t r = lane; r < rows; r += G) {
-            const uint32_t* pm = ar.ph_meta + (src0 + r) * 2;
-            uint32_t* hm = ar.h_meta + (dst0 + r) * 4;
-            hm[0] = slot; hm[1] = game_idx; hm[2] = pm[1]; hm[3] = pm[0];
+          for (uint32_t seg = 0; seg < 2; ++seg) {
+            const uint32_t sr = seg == 0 ? 0u : n1, nr = seg == 0 ? n1 : rows - n1;
+            const size_t dst0 = seg == 0 ? first : 0u;
+            const float* sp = ar.ph_pi + (src0 + sr) * M;
+            float* dp = ar.h_pi + dst0 * M;
+            const uint32_t np = nr * M;
+            for (uint32_t e0 = 0; e0 < np; e0 += 4 * G) {
+              float t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+              const uint32_t a = e0 + lane, b = a + G, c = b + G, d = c + G;
+              if (a < np) t0 = sp[a];
+              if (b < np) t1 = sp[b];
+              if (c < np) t2 = sp[c];
+              if (d < np) t3 = sp[d];
+              if (a < np) dp[a] = t0;
+              if (b < np) dp[b] = t1;
+              if (c < np) dp[c] = t2;
+              if (d < np) dp[d] = t3;
+            }
+            float* dv = ar.h_v + dst0 * (P + 1);
+            for (uint32_t e = lane; e < nr * (P + 1); e += G) dv[e] = (e % (P + 1) == term - 1) ? 1.0f : 0.0f;
+            for (uint32_t r = lane; r < nr; r += G) {
+              const uint32_t* pm = ar.ph_meta + (src0 + sr + r) * 2;
+              uint32_t* hm = ar.h_meta + (dst0 + r) * 4;
+              hm[0] = slot; hm[1] = game_idx; hm[2] = pm[1]; hm[3] = pm[0];
+            }
           }
         }
       } else {

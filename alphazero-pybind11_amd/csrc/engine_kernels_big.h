@@ -1067,10 +1067,14 @@ struct BigSlot {
       uint32_t base = 0;
       if (lane == 0) base = atomicAdd(&ar.ctl->hist_rows, rows);
       base = __shfl(base, 0, 64);
-      if (base + rows <= ep.hist_cap) {
+      // ring of hist_cap rows, row i of the run at i % hist_cap (see engine_kernels.h end_game)
+      if (base + rows - ar.ctl->hist_read <= ep.hist_cap) {
         const uint32_t game_idx = ar.slot_games[slot];
-        // the game's rows are contiguous on both sides: one flat copy per array, eight loads in flight per lane
-        const size_t src0 = static_cast<size_t>(slot) * ep.max_hist_rows, dst0 = base;
+        // the game's rows are contiguous on the pending side and contiguous modulo the ring on the other: flat copies,
+        // eight loads in flight per lane, in two segments when the rows wrap around the end of the ring
+        const size_t src0 = static_cast<size_t>(slot) * ep.max_hist_rows;
+        const uint32_t first = base % ep.hist_cap;
+        const uint32_t n1 = rows < ep.hist_cap - first ? rows : ep.hist_cap - first;
         auto flat_copy = [&](const float* sp, float* dp, size_t n) {
           for (size_t e0 = 0; e0 < n; e0 += 8 * G) {
             float t[8];
@@ -1080,14 +1084,19 @@ struct BigSlot {
             for (int u = 0; u < 8; ++u) { const size_t e = e0 + u * G + lane; if (e < n) dp[e] = t[u]; }
           }
         };
-        flat_copy(ar.ph_canon + src0 * GM::CANON, ar.h_canon + dst0 * GM::CANON, static_cast<size_t>(rows) * GM::CANON);
-        flat_copy(ar.ph_pi + src0 * M, ar.h_pi + dst0 * M, static_cast<size_t>(rows) * M);
-        float* dv = ar.h_v + dst0 * (P + 1);
-        for (uint32_t e = lane; e < rows * (P + 1); e += G) dv[e] = (e % (P + 1) == term - 1) ? 1.0f : 0.0f;
-        for (uint32_t r = lane; r < rows; r += G) {
-          const uint32_t* pm = ar.ph_meta + (src0 + r) * 2;
-          uint32_t* hm = ar.h_meta + (dst0 + r) * 4;
-          hm[0] = slot; hm[1] = game_idx; hm[2] = pm[1]; hm[3] = pm[0];
+        for (uint32_t seg = 0; seg < 2; ++seg) {
+          const uint32_t sr = seg == 0 ? 0u : n1, nr = seg == 0 ? n1 : rows - n1;
+          if (nr == 0) continue;
+          const size_t dst0 = seg == 0 ? first : 0u;
+          flat_copy(ar.ph_canon + (src0 + sr) * GM::CANON, ar.h_canon + dst0 * GM::CANON, static_cast<size_t>(nr) * GM::CANON);
+          flat_copy(ar.ph_pi + (src0 + sr) * M, ar.h_pi + dst0 * M, static_cast<size_t>(nr) * M);
+          float* dv = ar.h_v + dst0 * (P + 1);
+          for (uint32_t e = lane; e < nr * (P + 1); e += G) dv[e] = (e % (P + 1) == term - 1) ? 1.0f : 0.0f;
+          for (uint32_t r = lane; r < nr; r += G) {
+            const uint32_t* pm = ar.ph_meta + (src0 + sr + r) * 2;
+            uint32_t* hm = ar.h_meta + (dst0 + r) * 4;
+            hm[0] = slot; hm[1] = game_idx; hm[2] = pm[1]; hm[3] = pm[0];
+          }
         }
       } else {
         raise(2u);

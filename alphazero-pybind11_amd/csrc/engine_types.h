@@ -101,6 +101,8 @@ struct Control {  // small device control block, copied back by azmi_pm_poll
   uint32_t live_slots;
   uint64_t rounds;
   uint32_t eval_count[4]; // per model group: entries of eval_list[g] written by this round's k_round
+  uint32_t hist_read;     // finished-sample ring: rows the host has consumed (hist_rows - hist_read rows are live, <= hist_cap)
+  uint32_t pad_;
 };
 
 constexpr uint32_t kGumMaxM = 64;   // cap on PlayParams.gumbel_m (reference default 16)

@@ -1128,4 +1128,50 @@ int azmi_net_forward_rows(azmi_net* net, const float* dev_canonical, float* dev_
   return AZMI_OK;
 }
 
+namespace {
+struct HostEvalCtx {          // per calling thread: its own stream and staging buffers
+  int device = -1;
+  hipStream_t st = nullptr;
+  float *c = nullptr, *v = nullptr, *pi = nullptr;
+  uint32_t rows = 0, chw = 0, p1 = 0, m = 0;
+  ~HostEvalCtx() {
+    if (device < 0) return;
+    (void)hipSetDevice(device);
+    if (c) (void)hipFree(c); if (v) (void)hipFree(v); if (pi) (void)hipFree(pi);
+    if (st) (void)hipStreamDestroy(st);
+  }
+};
+}  // namespace
+
+void azmi_net_eval_host(const float* canonical, uint32_t n, float* v, float* pi, void* net_v) {
+  azmi_net* net = static_cast<azmi_net*>(net_v);
+  if (!net || !canonical || !v || !pi || n == 0) return;
+  uint32_t chw, p1, m;
+  if (net->f32) { azmi_f32::dims(net->f32, &chw, &p1, &m); }
+  else if (net->spatial) { chw = net->sd.C_in * net->sd.H * net->sd.W; p1 = net->sd.num_players + 1; m = net->sd.num_moves; }
+  else { chw = net->nd.C_in * net->nd.H * net->nd.W; p1 = net->nd.num_players + 1; m = net->nd.num_moves; }
+  auto poison = [&]() {
+    for (size_t i = 0; i < static_cast<size_t>(n) * p1; ++i) v[i] = __builtin_nanf("");
+    for (size_t i = 0; i < static_cast<size_t>(n) * m; ++i) pi[i] = __builtin_nanf("");
+  };
+  thread_local HostEvalCtx ctx;
+  if (hipSetDevice(net->device) != hipSuccess) { poison(); return; }
+  if (ctx.device != net->device || ctx.rows < n || ctx.chw != chw || ctx.p1 != p1 || ctx.m != m) {
+    if (ctx.c) (void)hipFree(ctx.c); if (ctx.v) (void)hipFree(ctx.v); if (ctx.pi) (void)hipFree(ctx.pi);
+    ctx.c = ctx.v = ctx.pi = nullptr;
+    if (!ctx.st && hipStreamCreateWithFlags(&ctx.st, hipStreamNonBlocking) != hipSuccess) { poison(); return; }
+    const uint32_t rows = n < 256 ? 256 : n;
+    if (hipMalloc(reinterpret_cast<void**>(&ctx.c), static_cast<size_t>(rows) * chw * 4) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&ctx.v), static_cast<size_t>(rows) * p1 * 4) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&ctx.pi), static_cast<size_t>(rows) * m * 4) != hipSuccess) { poison(); return; }
+    ctx.device = net->device; ctx.rows = rows; ctx.chw = chw; ctx.p1 = p1; ctx.m = m;
+  }
+  bool ok = hipMemcpyAsync(ctx.c, canonical, static_cast<size_t>(n) * chw * 4, hipMemcpyHostToDevice, ctx.st) == hipSuccess;
+  ok = ok && azmi_net_forward(net, ctx.c, ctx.v, ctx.pi, n, ctx.st) == AZMI_OK;
+  ok = ok && hipMemcpyAsync(v, ctx.v, static_cast<size_t>(n) * p1 * 4, hipMemcpyDeviceToHost, ctx.st) == hipSuccess;
+  ok = ok && hipMemcpyAsync(pi, ctx.pi, static_cast<size_t>(n) * m * 4, hipMemcpyDeviceToHost, ctx.st) == hipSuccess;
+  ok = ok && hipStreamSynchronize(ctx.st) == hipSuccess;
+  if (!ok) poison();
+}
+
 }  // extern "C"

@@ -13,4 +13,5 @@ int create(const azmi_net_desc* d, const void* blob, size_t bytes, int device, v
 int forward(void* impl, const float* canon, float* v, float* pi, uint32_t batch, void* stream, const char** err);
 int reserve(void* impl, uint32_t batch, const char** err);
 void destroy(void* impl);
+void dims(void* impl, uint32_t* chw, uint32_t* p1, uint32_t* m);   // floats per canonical row, P+1, M
 }  // namespace azmi_f32

@@ -130,6 +130,11 @@ namespace azmi_f32 {
 
 size_t blob_bytes(const azmi_net_desc* d) { return count_floats(d) * sizeof(float); }
 
+void dims(void* impl, uint32_t* chw, uint32_t* p1, uint32_t* m) {
+  const azmi_net_desc& d = static_cast<Net*>(impl)->d;
+  *chw = d.in_channels * d.height * d.width; *p1 = d.num_players + 1; *m = d.num_moves;
+}
+
 void destroy(void* impl) {
   auto* n = static_cast<Net*>(impl);
   if (!n) return;

@@ -2,19 +2,36 @@
 """Self-play throughput bench — BASELINE.json metric:
 "self-play games/sec (whole node), Connect4 @ 800 MCTS sims".
 
-A *step* is one engine round: every one of the `concurrent_games` slots on this GPU finishes one
-MCTS simulation (backup of the previous leaf, maybe a move, descent + expansion of the next leaf:
-k_round) and the 6-block/64-channel ResNet evaluates the resulting leaf batch.  Inputs live in HBM;
-no host round-trip happens inside the timed region.  Workload = BASELINE configs[1]
-(Connect4, 4096 concurrent games, 800 sims, 6b64c net, random-init weights, synthetic = self-generated
-positions), one engine + one weight replica per GPU (weak scaling), samples gathered to rank 0 with
-RCCL at the end of the timed region.
+Workload = BASELINE configs[1]: Connect4, 4096 concurrent games per GPU, 800 simulations on every move (playout cap
+off), 6-block/64-channel ResNet (k3, 32 head channels) with random-init weights, the reference's self-play flags
+(game_runner.py:2018-2041), positions self-generated (synthetic).  Everything lives in HBM; no host round-trip happens
+inside the timed region.
 
-Prints ONE JSON line on rank 0 (see README of the task contract).
+A *step* is a fixed block of `--rounds-per-step` engine rounds (default 2048): in one round every game slot of every
+engine shard advances by its next simulations (backup of the previous leaf, maybe a move, descent + expansion of the
+next leaf, position-cache probe) and the net evaluates the shard's leaf batch.  The run is a stream of games
+(play_manager_bench.cc:171-181: finished slots start the next game at once):
+
+  pre-roll   untimed rounds until 2 x concurrent_games games have finished, so that the slots are de-phased
+             (the games all start together, and opening / endgame rounds cost differently)
+  warm-up    W steps, untimed
+  window     K steps, timed between two barriers; games/s = games finished in the window / its wall time
+             (network_pareto.py:401-444 measures the same two counters over windows)
+
+The run FAILS (non-zero exit, no JSON line) if fewer than concurrent_games games finished inside the window or a slot's
+game stream ran dry: such a number would not be the metric.
+
+Multi-GPU: one process per GPU (RANK/LOCAL_RANK/WORLD_SIZE from the launcher; `--gpus N` without a launcher spawns the
+N processes itself, before anything touches a GPU), every rank runs the same workload on its own engines and weights
+(weak scaling), the window's samples are gathered to rank 0 over RCCL and the statistics are summed with one all-reduce.
+
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,13 +42,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 FLOP_PER_EVAL = 37.7e6     # Connect4 6b64c k3 (conv + linear MACs x 2)
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+B_SIM = 1300.0             # algorithmic bytes per simulation of the tree step
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30000, help="timed rounds; the default spans > 2 game lengths (13 k rounds each) so that the opening/endgame phase mix of the initially synchronised games averages out")
-    ap.add_argument("--warmup", type=int, default=30000)
+    ap.add_argument("--steps", type=int, default=20, help="timed steps; a step = --rounds-per-step engine rounds")
+    ap.add_argument("--warmup", type=int, default=5, help="untimed steps before the window (after the de-phasing pre-roll)")
+    ap.add_argument("--rounds-per-step", type=int, default=2048)
     ap.add_argument("--game", choices=["connect4", "tawlbwrdd"], default="connect4",
                     help="connect4 = BASELINE configs[1] (the headline); tawlbwrdd = configs[2] (2048 games, 400 sims, YAML net)")
     ap.add_argument("--games", type=int, default=None, help="concurrent games per GPU (4096 / 2048)")
@@ -45,11 +64,39 @@ def parse():
     ap.add_argument("--gumbel", action="store_true", help="Gumbel AlphaZero search (configs/tawlbwrdd.yaml:24-25: gumbel_enabled, capped searches PUCT)")
     ap.add_argument("--net", choices=["hip", "torch"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the short playout-cap-on measurement reported in config")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    return ap.parse_args()
+    ap.add_argument("--no-secondary", action="store_true", help="skip the two short secondary measurements reported in config")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall time of the CPU-baseline sample")
+    ap.add_argument("--preroll-factor", type=float, default=2.0, help="pre-roll until this many x concurrent_games games have finished")
+    ap.add_argument("--dry", action="store_true",
+                    help="CPU dry run of the launch / distributed plumbing (gloo, no device, a stand-in engine): used by the tests")
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# launcher: `bench.py --gpus N` without torchrun
+def spawn_ranks(args):
+    """Starts one fresh process per GPU (RANK/LOCAL_RANK/WORLD_SIZE set, rendezvous on 127.0.0.1) BEFORE this process has
+    made any GPU call, relays rank 0's JSON line, and fails if any rank fails."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(codes):
+        sys.stderr.write(f"bench.py: rank exit codes {codes}\n")
+        return 1
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def selfplay_params(az, games, sims, stream_games, cache=0, playout_cap=False, gumbel=False):
     """self_play() settings, game_runner.py:2018-2041 with TrainConfig defaults (config.py:79-139,235-236);
     playout-cap randomisation is OFF so that every move is a full 800-simulation search."""
@@ -87,51 +134,120 @@ def selfplay_params(az, games, sims, stream_games, cache=0, playout_cap=False, g
     return pp
 
 
-def cpu_baseline(az, sims, seconds, threads=None):
-    """The oracle (CPU restatement of the reference PlayManager) on a bounded sample of the same search: Connect4,
-    800 sims/move, same self-play flags, EvalType.RANDOM (no net), on `threads` host threads — the reference's default
-    worker count is cores - 1 (config.py:439-441).  Each thread runs independent one-slot PlayManagers back to back
-    (the C call releases the GIL), which is an upper bound for the reference's tree side: no queue, no mutex, no net."""
+def host_cores():
+    cores = len(os.sched_getaffinity(0))
+    try:                                   # a cgroup CPU quota is the real core count of a container
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def cpu_baseline(az, sims, seconds, S, hip_net, cache):
+    """the reference's architecture on this box's host cores, timed beside the GPU engine — the oracle
+    (CPU restatement of the reference PlayManager, `kind` "port") with `cores - 1` worker threads (the reference's default,
+    config.py:439-441), the 4096 concurrent games split over the workers, and the leaf net served by the MI355X through
+    HOST buffers (build_batch -> process -> update_inferences: canonical rows gathered on the host, copied to the GPU,
+    evaluated by the same HIP net, copied back; azmi_net_eval_host, no interpreter in the loop).  Each worker is one
+    single-threaded PlayManager over its share of the slots with a position cache of the reference's default size
+    (200 000 entries, config.py:197, split like the slots), so nothing is shared between workers: an upper bound for the
+    reference, whose workers contend on queue and cache mutexes (play_manager.h:66-72).  Bounded sample: `seconds` of
+    wall time of the game stream, the first `seconds / 4` discarded as warm-up of trees and caches."""
+    import ctypes as C
     import threading
     import oracle_api as orc
-    if threads is None:
-        cores = len(os.sched_getaffinity(0))
-        try:                                   # a cgroup CPU quota is the real core count of a container
-            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-            if quota != "max":
-                cores = min(cores, max(1, int(quota) // int(period)))
-        except (OSError, ValueError):
-            pass
-        threads = max(1, cores - 1)
-    pp = selfplay_params(az, 1, sims, 1)
-    pp.eval_type = [1, 1]
-    pp.history_enabled = True
-    totals = [[0, 0] for _ in range(threads)]
-    t0 = time.perf_counter()
+    from alphazero._capi import lib
+    threads = max(1, host_cores() - 1)
+    fn = C.cast(lib.azmi_net_eval_host, C.c_void_p).value
+    out = {"unit": "games/s", "cores": threads, "kind": "port"}
 
-    def worker(t):
-        k = 0
-        while time.perf_counter() - t0 < seconds:
-            o = orc.PlayManager(orc.GAME_CONNECT4, pp, 1000 + 7919 * t + k, per_slot_rng=False, record_moves=False)
-            o.run()
-            totals[t][0] += o.games_completed()
-            totals[t][1] += o.counters()["sims"]
-            k += 1
+    def leg(eval_kind, slots_total, nsims, secs, cache_total, nthreads):
+        """one timed run: `nthreads` oracle PlayManagers side by side; returns (games/s, sims/s, evals/s) after warm-up"""
+        per = max(1, slots_total // nthreads)
+        pms = []
+        for t in range(nthreads):
+            pp = selfplay_params(az, per, nsims, 1 << 30, cache=(cache_total // nthreads if eval_kind == "nn" else 0))
+            pp.max_batch_size = per
+            pp.history_enabled = True
+            if eval_kind == "random":
+                pp.eval_type = [1, 1]
+            pms.append(orc.PlayManager(orc.GAME_CONNECT4, pp, 1000 + 7919 * t, per_slot_rng=False, record_moves=False))
+        marks = []
 
-    ths = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
-    for th in ths: th.start()
-    for th in ths: th.join()
-    dt = time.perf_counter() - t0
-    games = sum(a for a, _ in totals); n_sims = sum(b for _, b in totals)
-    return {"value": games / dt, "unit": "games/s", "cores": threads, "kind": "port",
-            "sample": f"{games} Connect4 self-play games x {sims} sims, oracle PlayManager, EvalType.RANDOM evaluator "
-                      f"(no net), {threads} threads (host cores - 1), {dt:.1f}s; {n_sims / dt / 1e6:.3f} Msims/s total, "
-                      f"{n_sims / dt / threads / 1e6:.3f} Msims/s per thread",
-            "sims_per_s": n_sims / dt, "per_thread_games_per_s": games / dt / threads}
+        def snap():
+            return (time.perf_counter(), sum(o.games_completed() for o in pms), sum(o.counters()["sims"] for o in pms),
+                    sum(o.counters()["evals"] for o in pms))
+
+        def worker(o, limit):
+            o.set_time_limit(limit)
+            if eval_kind == "nn":
+                o.run_native(fn, hip_net._h.value)
+            else:
+                o.run()
+
+        for phase, limit in (("warm", secs / 4.0), ("timed", secs)):
+            ths = [threading.Thread(target=worker, args=(o, limit)) for o in pms]
+            a = snap()
+            for th in ths: th.start()
+            for th in ths: th.join()
+            b = snap()
+            marks.append((a, b))
+        (t0, g0, s0, e0), (t1, g1, s1, e1) = marks[1]
+        dt = t1 - t0
+        return (g1 - g0) / dt, (s1 - s0) / dt, (e1 - e0) / dt, g1 - g0, dt
+
+    if hip_net is not None:
+        g, s, e, n, dt = leg("nn", S, sims, seconds, 200_000, threads)
+        out["value"] = g
+        out["sample"] = (f"{n} Connect4 self-play games x {sims} sims finished in {dt:.1f}s (after {seconds / 4:.0f}s warm-up) by the oracle PlayManager: "
+                         f"{threads} worker threads (host cores - 1) x {max(1, S // threads)} concurrent games, 6b64c net served by the MI355X "
+                         f"through host buffers (azmi_net_eval_host), position cache 200000 entries; {s / 1e6:.3f} Msims/s, {e / 1e6:.3f} M net evaluations/s")
+        out["sims_per_s"] = s
+        out["evals_per_s"] = e
+    g, s, _, n, dt = leg("random", S, sims, max(4.0, seconds / 4), 0, threads)
+    out["tree_only"] = {"games_per_s": g, "sims_per_s": s, "note": f"EvalType.RANDOM (no net), {threads} threads, {n} games in {dt:.1f}s"}
+    if "value" not in out:
+        out["value"] = g
+        out["sample"] = out["tree_only"]["note"]
+    # BASELINE configs[0]: Connect4, 64 concurrent games, 100 sims, one worker thread — the reference's own CPU-runnable case
+    g, s, _, n, dt = leg("random", 64, 100, 3.0, 0, 1)
+    out["configs0"] = {"workload": "Connect4, 64 concurrent games, 100 sims, 1 worker thread", "random_eval_games_per_s": g, "random_eval_sims_per_s": s}
+    if hip_net is not None:
+        g, s, e, n, dt = leg("nn", 64, 100, 3.0, 200_000, 1)
+        out["configs0"].update({"gpu_served_net_games_per_s": g, "gpu_served_net_sims_per_s": s})
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class DryEngine:
+    """Stand-in for the engines in --dry mode (CPU, gloo): deterministic counters, a few fake sample rows per step."""
+
+    def __init__(self, rank, S):
+        import torch
+        self.torch, self.rank, self.S = torch, rank, S
+        self.games = self.sims = self.evals = 0
+        self.rows = []
+
+    def step(self, rounds):
+        self.games += self.S // 4
+        self.sims += self.S * rounds
+        self.evals += self.S * rounds // 3
+        n = 8 + self.rank
+        self.rows.append((self.torch.full((n, 4, 6, 7), float(self.rank)), self.torch.zeros(n, 3), self.torch.zeros(n, 7)))
+
+    def take_rows(self):
+        t = self.torch
+        out = tuple(t.cat([r[i] for r in self.rows], 0) for i in range(3)) if self.rows else (t.zeros(0, 4, 6, 7), t.zeros(0, 3), t.zeros(0, 7))
+        self.rows = []
+        return out
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
     if args.hwq:
         os.environ["GPU_MAX_HW_QUEUES"] = str(args.hwq)   # must be set before the HIP runtime starts
     import torch
@@ -139,142 +255,238 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and "RANK" in os.environ:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks\n")
+        sys.exit(2)
     # AZMI_BENCH_FORCE_DIST=1: run the N > 1 code path (RCCL init, barriers, sample gather, reductions) with whatever world size
     # the launcher gave, 1 included: lets a one-GPU box exercise it under torchrun
     use_dist = world > 1 or os.environ.get("AZMI_BENCH_FORCE_DIST") == "1"
+    dry = args.dry
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    import alphazero as az
-    from alphazero import torch_net
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     tafl = args.game == "tawlbwrdd"
     if args.games is None: args.games = 2048 if tafl else 4096
     if args.sims is None: args.sims = 400 if tafl else 800
     if args.engines is None: args.engines = 4      # measured: Connect4 1/2/4/8 shards and Tawlbwrdd 2/4/8 shards both peak at 4
     if args.cache is None: args.cache = 0 if tafl else 32_000_000      # Tawlbwrdd: measured 5 % hit rate with 2 M entries and 16 % fewer games/s, so off
-    Game = az.TawlbwrddGS if tafl else az.Connect4GS
     flop_per_eval = 93.1e6 if tafl else FLOP_PER_EVAL
-    S, sims, K = args.games, args.sims, args.engines
+    S, sims, K, R = args.games, args.sims, args.engines, args.rounds_per_step
     assert S % K == 0
     Se = S // K                       # slots per engine shard
-    # stream pool (play_manager_bench.cc:171-181: games_to_play = 8 x concurrent), widened when the run is
-    # long enough that a slot could finish more than 8 games: a dry stream would idle slots and void the number
-    rounds_per_game = 1000 if args.playout_cap else 4000        # conservative lower bounds (measured 2900 / 13000)
-    if tafl: rounds_per_game = 8000
-    stream_games = Se * max(8, -(-(args.warmup + args.steps) // rounds_per_game))
-    # K engine shards of S/K slots, one HIP stream each: while one shard's leaf batch is on the matrix
-    # cores another shard's tree kernel runs on the CUs the net leaves free.
-    pms, streams = [], []
-    for i in range(K):
-        pp = selfplay_params(az, Se, sims, stream_games, cache=args.cache // K, playout_cap=args.playout_cap, gumbel=args.gumbel)
-        pms.append(az.PlayManager(Game(), pp, seed=20240601 + 7919 * rank + 104729 * i, device=local_rank, max_inline=args.inline,
-                                  history_capacity=(400_000 // K if tafl else 0)))
-        streams.append(torch.cuda.Stream(device=dev))
-    sps = [st.cuda_stream for st in streams]
-    io = [pm.io_tensors() for pm in pms]
-
-    spec = torch_net.tawlbwrdd_spec() if tafl else torch_net.connect4_spec()
-    net = torch_net.random_init(spec, seed=0).to(dev)
-    net_kind = args.net or "hip"
-    hip_net = az.HipLeafNet(net, spec, device=local_rank) if net_kind == "hip" else None
-    if net_kind == "torch":
-        net = net.to(memory_format=torch.channels_last)
-
-    def evaluate(i):
-        canon, v_buf, pi_buf = io[i]
-        if hip_net is not None:
-            pms[i].net_forward(hip_net, sps[i])
-        else:
-            with torch.cuda.stream(streams[i]):
-                v, pi = net.process(canon, amp_dtype=torch.bfloat16)
-                v_buf.copy_(v)
-                pi_buf.copy_(pi)
-
-    def run_rounds(n, ev=None):
-        """n rounds of every shard. With the HIP net the loop is the native driver (azmi_run_rounds);
-        every 64th round is launched from here with HIP events around the two kernels of shard 0."""
-        done = 0
-        while done < n:
-            if ev is not None:
-                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-                for i in range(K):
-                    if i == 0:
-                        e0.record(streams[0])
-                    pms[i].round(sps[i])
-                    if i == 0:
-                        e1.record(streams[0])
-                    evaluate(i)
-                    if i == 0:
-                        e2.record(streams[0])
-                ev.append((e0, e1, e2))
-                done += 1
-            chunk = min(64 if ev is not None else 256, n - done)
-            if chunk <= 0:
-                continue
-            if hip_net is not None:
-                az.run_rounds(pms, hip_net, chunk, sps)
-            else:
-                for _ in range(chunk):
-                    for i in range(K):
-                        pms[i].round(sps[i])
-                        evaluate(i)
-            done += chunk
 
     def barrier():
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
-    def totals():
-        done = sum(pm.poll()[0] for pm in pms)
-        cs = [pm.counters() for pm in pms]
-        return done, sum(c["sims"] for c in cs), sum(c["evals"] for c in cs), sum(c["cache_hits"] for c in cs), sum(c["cache_misses"] for c in cs)
+    if dry:
+        eng = DryEngine(rank, S)
+        hip_net = None
+        net_kind = "dry"
 
-    run_rounds(args.warmup)
+        def run_rounds(n, ev=None):
+            eng.step(n)
+
+        def totals():
+            return eng.games, eng.sims, eng.evals, 0, 0
+
+        def live_slots():
+            return S
+
+        def take_rows():
+            return eng.take_rows()
+
+        def stat_vector():
+            return torch.arange(16, dtype=torch.float64) * (rank + 1)
+    else:
+        import alphazero as az
+        from alphazero import torch_net
+        Game = az.TawlbwrddGS if tafl else az.Connect4GS
+        # the game stream never runs dry: finished slots restart at once (play_manager_bench.cc:171-181 sizes its pool as
+        # 8 x concurrent for the same purpose); the finished samples leave the engines' ring every step (hist_saver's job)
+        STREAM = 1 << 30
+
+        def make_engines(cache, playout_cap, seed0):
+            out = []
+            for i in range(K):
+                pp = selfplay_params(az, Se, sims, STREAM, cache=cache // K, playout_cap=playout_cap, gumbel=args.gumbel)
+                out.append(az.PlayManager(Game(), pp, seed=seed0 + 7919 * rank + 104729 * i, device=local_rank, max_inline=args.inline,
+                                          history_capacity=Se * (400 if tafl else 42) * 4))
+            return out
+
+        # K engine shards of S/K slots, one HIP stream each: while one shard's leaf batch is on the matrix
+        # cores another shard's tree kernel runs on the CUs the net leaves free.
+        pms = make_engines(args.cache, args.playout_cap, 20240601)
+        streams = [torch.cuda.Stream(device=dev) for _ in range(K)]
+        sps = [st.cuda_stream for st in streams]
+        io = [pm.io_tensors() for pm in pms]
+        spec = torch_net.tawlbwrdd_spec() if tafl else torch_net.connect4_spec()
+        net = torch_net.random_init(spec, seed=0).to(dev)
+        net_kind = args.net or "hip"
+        hip_net = az.HipLeafNet(net, spec, device=local_rank) if net_kind == "hip" else None
+        if net_kind == "torch":
+            net = net.to(memory_format=torch.channels_last)
+
+        def evaluate(group, i):
+            canon, v_buf, pi_buf = io[i]
+            if hip_net is not None:
+                group[i].net_forward(hip_net, sps[i])
+            else:
+                with torch.cuda.stream(streams[i]):
+                    v, pi = net.process(canon, amp_dtype=torch.bfloat16)
+                    v_buf.copy_(v)
+                    pi_buf.copy_(pi)
+
+        def run_rounds_on(group, n, ev=None):
+            """n rounds of every shard. With the HIP net the loop is the native driver (azmi_run_rounds);
+            every 64th round is launched from here with HIP events around the two kernels of shard 0."""
+            done = 0
+            while done < n:
+                if ev is not None:
+                    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                    for i in range(K):
+                        if i == 0:
+                            e0.record(streams[0])
+                        group[i].round(sps[i])
+                        if i == 0:
+                            e1.record(streams[0])
+                        evaluate(group, i)
+                        if i == 0:
+                            e2.record(streams[0])
+                    ev.append((e0, e1, e2))
+                    done += 1
+                chunk = min(64 if ev is not None else 256, n - done)
+                if chunk <= 0:
+                    continue
+                if hip_net is not None:
+                    az.run_rounds(group, hip_net, chunk, sps)
+                else:
+                    for _ in range(chunk):
+                        for i in range(K):
+                            group[i].round(sps[i])
+                            evaluate(group, i)
+                done += chunk
+
+        def run_rounds(n, ev=None):
+            run_rounds_on(pms, n, ev)
+
+        def totals_of(group):
+            done = sum(pm.poll()[0] for pm in group)
+            cs = [pm.counters() for pm in group]
+            return (done, sum(c["sims"] for c in cs), sum(c["evals"] for c in cs), sum(c["cache_hits"] for c in cs),
+                    sum(c["cache_misses"] for c in cs))
+
+        def totals():
+            return totals_of(pms)
+
+        def live_slots():
+            return sum(pm.poll()[1] for pm in pms)
+
+        def take_rows_of(group):
+            parts = [pm.take_history_device(dev) for pm in group]
+            return tuple(torch.cat([p[i] for p in parts], 0) for i in range(3))
+
+        def take_rows():
+            return take_rows_of(pms)
+
+        def stat_vector():
+            """what self_play() reads from the PlayManager (game_runner.py:2073-2145) as raw sums: scores [P+1], resign scores
+            [P+1], then the ten accumulators of azmi_pm_stat_sums (game length, games, moves, full / fast moves, leaf depth,
+            entropy, fast leaf depth, fast entropy, valid moves) — one all-reduce sums them over the node"""
+            import numpy as np
+            sc = np.sum([pm.scores() for pm in pms], 0)
+            rs = np.sum([pm.resign_scores() for pm in pms], 0)
+            keys = ("game_length", "games", "moves", "full_moves", "fast_moves", "leaf_depth", "entropy", "fast_leaf_depth", "fast_entropy", "valid_moves")
+            sums = [sum(pm.stat_sums()[k] for pm in pms) for k in keys]
+            return torch.tensor(list(sc) + list(rs) + sums, dtype=torch.float64)
+
+    def preroll(run, tot, target_games, what):
+        """untimed rounds until `target_games` games have finished (slots de-phased); returns rounds used"""
+        used = 0
+        while tot()[0] < target_games:
+            run(R)
+            used += R
+            if used > 400 * R:
+                raise RuntimeError(f"{what}: pre-roll did not reach {target_games} finished games in {used} rounds")
+        return used
+
+    # ---- pre-roll (de-phasing), warm-up, timed window --------------------------------------------------------------
+    pre_rounds = preroll(run_rounds, totals, int(args.preroll_factor * S), "headline")
+    for _ in range(args.warmup):
+        run_rounds(R)
+        take_rows()
     barrier()
     done0, sims0, evals0, h0, m0 = totals()
-    events = []
+    events = [] if not dry else None
+    window_rows = []
     t0 = time.perf_counter()
-    run_rounds(args.steps, events)
-    # the one exchange step: finished samples of this window go to rank 0 over RCCL/xGMI
+    for _ in range(args.steps):
+        run_rounds(R, events)
+        window_rows.append(take_rows())          # the step's finished samples leave the engines (device to device)
     done1, sims1, evals1, h1, m1 = totals()
-    live = sum(pm.poll()[1] for pm in pms)
-    if live != S:
-        raise RuntimeError(f"game stream ran dry inside the timed region ({live} of {S} slots live): raise stream_games")
-    hit_rate = (h1 - h0) / max(1, (h1 - h0) + (m1 - m0))
+    live = live_slots()
+    # the one exchange step: the window's samples go to rank 0 over RCCL/xGMI
     gathered_rows = 0
     if use_dist:
         from alphazero import gather
-        for pm in pms:
-            gathered_rows += gather.gather_history_to_rank0(pm, dev, rank, world)
+        parts = [torch.cat([w[i] for w in window_rows], 0) for i in range(3)]
+        res = gather.gather_rows_to_rank0(parts, rank, world)
+        if rank == 0:
+            gathered_rows = int(res[0].shape[0])
     barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=dev)
-    games = torch.tensor([float(done1 - done0), float(sims1 - sims0), float(evals1 - evals0)], device=dev)
+    local_rows = sum(int(w[0].shape[0]) for w in window_rows)
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    cnt = torch.tensor([float(done1 - done0), float(sims1 - sims0), float(evals1 - evals0), float(h1 - h0), float(m1 - m0),
+                        float(local_rows), float(S - live)], device=dev, dtype=torch.float64)
+    stats = stat_vector().to(dev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(games, op=dist.ReduceOp.SUM)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)      # scores, game length, depth / entropy sums, ... of the whole node
+        mn = torch.tensor([float(done1 - done0)], device=dev, dtype=torch.float64)
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+        min_rank_games = float(mn.item())
+    else:
+        min_rank_games = float(done1 - done0)
     dt = float(tmax.item())
-    n_games, n_sims, n_evals = (float(x) for x in games.tolist())
+    n_games, n_sims, n_evals, n_hits, n_miss, n_rows, dead = (float(x) for x in cnt.tolist())
+    failure = None
+    if dead > 0:
+        failure = f"a game stream ran dry inside the timed region ({int(dead)} slots idle)"
+    elif min_rank_games < S:
+        failure = (f"only {int(min_rank_games)} games finished inside the window on some rank (< {S} concurrent games): "
+                   f"raise --steps or --rounds-per-step")
+    if failure:
+        if rank == 0:
+            sys.stderr.write("bench.py: INVALID RUN: " + failure + "\n")
+        if use_dist:
+            dist.destroy_process_group()
+        sys.exit(3)
 
     if rank == 0:
-        tree_ms = sum(a.elapsed_time(b) for a, b, _ in events) / max(1, len(events))
-        nn_ms = sum(b.elapsed_time(c) for _, b, c in events) / max(1, len(events))
-        # k_leafnet evaluates the Se rows of one shard per launch; K launches (one per shard) are in flight
-        # at once and share the chip with each other and with the tree kernels, so a per-launch event
-        # interval double-counts shared CUs.  `achieved` is therefore the algorithmic FLOPs of ALL net
-        # launches of the timed region / the region's wall time (a lower bound on the kernel's own rate);
-        # the per-launch HIP-event interval is reported next to it.
-        launches = args.steps * K
-        # Connect4 + HIP net: a launch evaluates only the rows of the engine's eval list (leaves that missed the
-        # cache and are not terminal) = the `evals` counter; other paths evaluate the whole slot-indexed batch
-        rows_evaluated = n_evals if (hip_net is not None and not tafl) else float(Se) * launches
-        achieved = flop_per_eval * rows_evaluated / dt / 1e12
-        per_launch = (flop_per_eval * rows_evaluated / launches) / (nn_ms * 1e-3) / 1e12 if nn_ms > 0 else achieved
+        hit_rate = n_hits / max(1.0, n_hits + n_miss)
+        st = stats.tolist()
+        nsc = 3
+        games_total = st[2 * nsc + 1]
+        node_stats = {"scores": st[:nsc], "resign_scores": st[nsc:2 * nsc],
+                      "avg_game_length": st[2 * nsc] / games_total if games_total else 0.0,
+                      "avg_leaf_depth": st[2 * nsc + 5] / st[2 * nsc + 3] if st[2 * nsc + 3] else 0.0,
+                      "avg_search_entropy": st[2 * nsc + 6] / st[2 * nsc + 3] if st[2 * nsc + 3] else 0.0,
+                      "avg_valid_moves": st[2 * nsc + 9] / st[2 * nsc + 2] if st[2 * nsc + 2] else 0.0,
+                      "games_since_start": games_total} if not dry else {"sum": st}
         out = {
             "metric": "self-play games/sec (whole node), Connect4 @ 800 MCTS sims" if not tafl else f"self-play games/sec (whole node), Tawlbwrdd @ {sims} MCTS sims",
             "value": n_games / dt,
@@ -293,12 +505,24 @@ def main():
                              if tafl else f"Connect4, {S} concurrent games/GPU, {sims} sims/move, 6-block/64-ch ResNet (k3, 32 head ch), ")
                             + f"self-play flags of game_runner.py:2018-2041 with playout-cap {'ON (25 sims on 75% of moves)' if args.playout_cap else 'off'}, random-init weights",
                 "concurrent_games_per_gpu": S, "engine_shards": K, "sims_per_move": sims, "net": net_kind,
+                "rounds_per_step": R, "preroll_rounds": pre_rounds, "ms_per_round": dt / (args.steps * R) * 1e3,
                 "max_cache_size": args.cache, "cache_hit_rate": hit_rate,
                 "sims_per_s": n_sims / dt, "leaf_evals_per_s": n_evals / dt,
-                "tree_kernel_ms": tree_ms, "net_ms": nn_ms, "samples_gathered": gathered_rows,
-                "games_in_window": n_games,
+                "games_in_window": n_games, "samples_in_window": n_rows, "samples_gathered": gathered_rows,
+                "node_stats": node_stats,
             },
-            "roofline": {
+        }
+        if not dry:
+            launches = args.steps * R * K
+            tree_ms = sum(a.elapsed_time(b) for a, b, _ in events) / max(1, len(events))
+            nn_ms = sum(b.elapsed_time(c) for _, b, c in events) / max(1, len(events))
+            # a k_leafnet launch evaluates the rows of its shard's eval list (leaves that missed the cache and are not
+            # terminal) = the `evals` counter; the torch path and the spatial kernel evaluate the whole slot-indexed batch
+            rows_evaluated = n_evals / world if (hip_net is not None and not tafl) else float(Se) * launches
+            achieved = flop_per_eval * rows_evaluated / dt / 1e12
+            per_launch = (flop_per_eval * rows_evaluated / launches) / (nn_ms * 1e-3) / 1e12 if nn_ms > 0 else 0.0
+            out["config"].update({"tree_kernel_ms": tree_ms, "net_ms": nn_ms})
+            out["roofline"] = {
                 "bound": "mfma", "achieved": per_launch, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": per_launch / MFMA_PEAK_TFLOPS, "traffic": None,
                 "kernel": "%s: %.0f positions (avg) x %.1f MFLOP per launch, %d overlapping launches per round" % ("k_leafnet_spatial" if tafl else "k_leafnet", rows_evaluated / launches, flop_per_eval / 1e6, K),
@@ -307,83 +531,64 @@ def main():
                 "definition": "achieved = algorithmic FLOPs of ONE launch (positions it evaluated x FLOP per position) / its average duration, "
                               "HIP events on its stream over the timed region (the rocprof average in profiles/ agrees); K launches overlap "
                               "and share the chip with each other and with the tree kernels, so the whole-GPU rate is aggregate_achieved = "
-                              "FLOPs of all launches of the region / wall time of the region",
-            },
-        }
-        # HBM-side traffic of the dominant kernel: not measurable from inside the process; taken from the committed
-        # rocprofv3 --pmc summary of this same command (scripts/gpu_pmc.sh -> profiles/r1_pmc_traffic.csv), per launch,
-        # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on gfx950
-        pmc = os.path.join(ROOT, "profiles", "r1_pmc_traffic.csv")
-        if not tafl:
-            # the second kernel of the path, the tree step (HBM side): algorithmic bytes per simulation from SURVEY §8d
-            # (select + backup + expand + state + canonical + eval rows = 1.3 KB with the measured depth 3.5 / 6.8 children)
-            b_sim = 1300.0
-            tree_launch = (b_sim * n_sims / launches) / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
-            out["roofline_tree"] = {
-                "kernel": "k_cache_insert + k_round<Connect4> (one shard-round)", "bound": "hbm", "achieved": tree_launch, "peak": 8000.0, "unit": "GB/s",
-                "frac": tree_launch / 8000.0, "traffic": None, "per_launch_event_ms": tree_ms,
-                "aggregate_achieved": b_sim * n_sims / dt / 1e9, "aggregate_frac": b_sim * n_sims / dt / 1e9 / 8000.0,
-                "note": "latency-bound, not bandwidth-bound: one simulation is a chain of ~8 dependent memory round trips; "
-                        "the figure to watch is the per-launch time (profiles/r1_kernel_stats.csv)"}
-        if not tafl and hip_net is not None and os.path.exists(pmc):
-            for line in open(pmc):
-                if "k_round<azmi::Connect4" in line:
+                              "FLOPs of all launches of the region / wall time of the region (rank 0's GPU)",
+            }
+            if not tafl:
+                # the second kernel of the path, the tree step (HBM side): algorithmic bytes per simulation from SURVEY §8d
+                # (select + backup + expand + state + canonical + eval rows = 1.3 KB with the measured depth 3.5 / 6.8 children)
+                sims_rank = n_sims / world
+                tree_launch = (B_SIM * sims_rank / launches) / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
+                out["roofline_tree"] = {
+                    "kernel": "k_cache_insert + k_round<Connect4> (one shard-round)", "bound": "hbm", "achieved": tree_launch, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": tree_launch / HBM_PEAK_GBS, "traffic": None, "per_launch_event_ms": tree_ms,
+                    "aggregate_achieved": B_SIM * sims_rank / dt / 1e9, "aggregate_frac": B_SIM * sims_rank / dt / 1e9 / HBM_PEAK_GBS,
+                    "note": "latency-bound, not bandwidth-bound: one simulation is a chain of dependent memory round trips; "
+                            "the figure to watch is the per-launch time (profiles/)"}
+            # HBM-side traffic of the dominant kernel: not measurable from inside the process; taken from the committed
+            # rocprofv3 --pmc summary of this same command (scripts/gpu_pmc.sh -> profiles/rN_pmc_traffic.csv), per launch,
+            # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on gfx950
+            pmc = next((p for p in (os.path.join(ROOT, "profiles", f"r{n}_pmc_traffic.csv") for n in (2, 1)) if os.path.exists(p)), None)
+            if not tafl and hip_net is not None and pmc:
+                for line in open(pmc):
                     f = line.strip().split(",")
-                    out["roofline_tree"]["traffic"] = (2.0 * float(f[-2]) + float(f[-1])) * 1024.0
-                if line.startswith("k_leafnet"):
-                    f = line.strip().split(",")
-                    out["roofline"]["traffic"] = (2.0 * float(f[-2]) + float(f[-1])) * 1024.0
-                    out["roofline"]["traffic_note"] = ("bytes per k_leafnet launch at the L2-to-fabric counters (2 x FETCH_SIZE + WRITE_SIZE, "
-                                                       "profiles/r1_pmc_traffic.csv); ~8 x the 0.94 MB weight image: each of the 8 XCD L2s "
-                                                       "fetches it once per launch, served from Infinity Cache")
-        if world == 1 and hip_net is not None and not args.playout_cap and not args.no_secondary and not tafl:
-            # the same workload with playout-cap randomisation at the reference's self-play defaults
-            # (fast_mcts_visits 25 on 75 % of moves, config.py:86,100): reported beside the headline, never as it
-            w2, k2 = 12000, 6000
-            pms2 = []
-            for i in range(K):
-                pp = selfplay_params(az, Se, sims, Se * 32, cache=args.cache // K, playout_cap=True)
-                pms2.append(az.PlayManager(az.Connect4GS(), pp, seed=977 + i, device=local_rank, max_inline=args.inline))
-            az.run_rounds(pms2, hip_net, w2, sps)
-            torch.cuda.synchronize()
-            d0 = sum(pm.poll()[0] for pm in pms2); s0 = sum(pm.counters()["sims"] for pm in pms2)
-            t2 = time.perf_counter()
-            az.run_rounds(pms2, hip_net, k2, sps)
-            d1 = sum(pm.poll()[0] for pm in pms2); s1 = sum(pm.counters()["sims"] for pm in pms2)
-            torch.cuda.synchronize()
-            dt2 = time.perf_counter() - t2
-            live2 = sum(pm.poll()[1] for pm in pms2)
-            out["config"]["playout_cap_on"] = {"games_per_s": (d1 - d0) / dt2, "sims_per_s": (s1 - s0) / dt2, "steps": k2, "warmup": w2,
-                                               "live_slots": live2, "note": "25 sims on 75% of moves, 800 on the rest; secondary figure"}
-            del pms2
-        if world == 1 and not args.no_cpu_baseline and not tafl:
-            out["cpu_baseline"] = cpu_baseline(az, sims, args.cpu_seconds)
-            # the same 6b64c net on the host cores (fp32, PyTorch's default intra-op threads, batch 256): the leaf
-            # evaluations a CPU-only run of this workload would also have to pay for
-            cpu_net = torch_net.random_init(spec, seed=0).eval()
-            xb = torch.zeros((256,) + tuple(int(d) for d in io[0][0].shape[1:]))
-            torch.set_num_threads(max(1, out["cpu_baseline"]["cores"]))     # the same cores the tree sample used
-            with torch.no_grad():
-                cpu_net.process(xb)
-                t3, reps = time.perf_counter(), 0
-                while time.perf_counter() - t3 < 3.0:
-                    cpu_net.process(xb); reps += 1
-            evals_cpu = reps * 256 / (time.perf_counter() - t3)
-            evals_per_game = n_evals / max(n_games, 1.0)
-            cb = out["cpu_baseline"]
-            tree_rate = cb["value"]
-            net_rate = evals_cpu / evals_per_game
-            # the SAME workload on the host cores = the tree search AND its leaf evaluations: both pieces are measured
-            # (bounded samples), the combination is serial time per game on the same cores
-            cb["tree_only_games_per_s"] = tree_rate
-            cb["net_on_cpu"] = {"evals_per_s": evals_cpu, "threads": torch.get_num_threads(), "evals_per_game": evals_per_game,
-                                "games_per_s_bound": net_rate}
-            cb["value"] = 1.0 / (1.0 / tree_rate + 1.0 / net_rate)
-            cb["sample"] += (f"; leaf net: 6b64c fp32 forward on the same host, batch 256, 3 s = {evals_cpu:.0f} evals/s, "
-                             f"{evals_per_game:.0f} net evaluations per game (the GPU run's count, cache included); "
-                             f"value = 1 / (1/{tree_rate:.0f} + {evals_per_game:.0f}/{evals_cpu:.0f}) games/s")
+                    if "k_round<azmi::Connect4" in line or line.startswith("k_sim"):
+                        out["roofline_tree"]["traffic"] = (2.0 * float(f[-2]) + float(f[-1])) * 1024.0
+                    if line.startswith("k_leafnet"):
+                        out["roofline"]["traffic"] = (2.0 * float(f[-2]) + float(f[-1])) * 1024.0
+                        out["roofline"]["traffic_note"] = ("bytes per k_leafnet launch at the L2-to-fabric counters (2 x FETCH_SIZE + WRITE_SIZE, "
+                                                           + os.path.relpath(pmc, ROOT) + ")")
+            if world == 1 and hip_net is not None and not args.no_secondary and not tafl and not args.playout_cap:
+                # two short secondary measurements of the same workload, reported beside the headline, never as it:
+                #  (a) playout-cap randomisation at the reference's self-play defaults (fast_mcts_visits 25 on 75 % of
+                #      moves, config.py:86,100): what self_play() runs by default
+                #  (b) the position cache at the reference's default size (200 000 entries, config.py:197), which separates
+                #      the share of the headline that comes from the cache being sized for 288 GB of HBM
+                pms.clear()            # frees the headline engines' HBM before the secondary engines are built
+                for name, cache2, cap2, note in (("playout_cap_on", args.cache, True, "25 sims on 75% of moves, 800 on the rest"),
+                                                 ("cache_200k", 200_000, False, "max_cache_size = 200000 (reference default), 800 sims on every move")):
+                    pms2 = make_engines(cache2, cap2, 977)
+                    tot2 = lambda: totals_of(pms2)
+                    run2 = lambda n: (run_rounds_on(pms2, n), take_rows_of(pms2))
+                    pre2 = preroll(run2, tot2, int(args.preroll_factor * S), name)
+                    run2(2 * R)
+                    torch.cuda.synchronize()
+                    d0, s0, e0, hh0, mm0 = tot2()
+                    t2 = time.perf_counter()
+                    k2 = 6
+                    for _ in range(k2):
+                        run2(R)
+                    d1, s1, e1, hh1, mm1 = tot2()
+                    torch.cuda.synchronize()
+                    dt2 = time.perf_counter() - t2
+                    out["config"][name] = {"games_per_s": (d1 - d0) / dt2, "sims_per_s": (s1 - s0) / dt2, "leaf_evals_per_s": (e1 - e0) / dt2,
+                                           "cache_hit_rate": (hh1 - hh0) / max(1, (hh1 - hh0) + (mm1 - mm0)), "steps": k2, "preroll_rounds": pre2,
+                                           "games_in_window": d1 - d0, "live_slots": sum(pm.poll()[1] for pm in pms2), "note": note + "; secondary figure"}
+                    del pms2, tot2, run2
+            if world == 1 and not args.no_cpu_baseline and not tafl:
+                out["cpu_baseline"] = cpu_baseline(az, sims, args.cpu_seconds, S, hip_net, args.cache)
         print(json.dumps(out))
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

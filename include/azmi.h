@@ -204,6 +204,13 @@ int azmi_pm_pop_history(azmi_pm* pm, float* canonical, float* v, float* pi, uint
 /* same rows, left in HBM: device pointers + row count (for the RCCL sample gather) */
 int azmi_pm_history_device(azmi_pm* pm, float** dev_canonical, float** dev_v, float** dev_pi,
                            uint32_t** dev_meta, uint32_t* rows);
+/* The finished-sample store is a RING of `capacity` rows (the reference's history queue is unbounded and drained by
+ * GameRunner.hist_saver, game_runner.py:729-747): the unread rows are `rows` rows starting at physical row `first_row`
+ * of the azmi_pm_history_device arrays, wrapping modulo `capacity`.  azmi_pm_history_consume releases the oldest `rows`
+ * unread rows (azmi_pm_pop_history does both for host arrays).  The engine stops with AZMI_ERR_OVERFLOW (mask 2) when a
+ * finished game finds less room than its rows. */
+int azmi_pm_history_window(azmi_pm* pm, uint32_t* first_row, uint32_t* rows, uint32_t* capacity);
+int azmi_pm_history_consume(azmi_pm* pm, uint32_t rows);
 /* per-move log (opts.log_moves): rows [n,8] = slot, game_in_slot, move, turn, player, capped,
  * pcg32 state (lo, hi) of the slot's tree stream right before pick_move's draw;
  * counts [n,M] = root counts() right before the move.  Parity-test hook. */
@@ -337,6 +344,12 @@ int azmi_net_forward(azmi_net* net, const float* dev_canonical, float* dev_v, fl
  * leaf really needs the net (cache hits, terminal leaves and retired slots do not). */
 int azmi_net_forward_rows(azmi_net* net, const float* dev_canonical, float* dev_v, float* dev_pi, const uint32_t* dev_rows,
                           const uint32_t* dev_row_count, uint32_t max_rows, void* stream);
+/* NNWrapper.process on HOST arrays (neural_net.py:800-823 behind game_runner.py:651-726's batcher -> gpu_loop -> result_worker):
+ * canonical [n,C,H,W] -> v [n,P+1], pi [n,M]; copies in, runs the net, copies out, synchronously, on a stream and staging
+ * buffers private to the calling thread (any number of host threads may call it at once).  The signature is that of a
+ * host PlayManager's evaluator callback (user = the azmi_net*), so a CPU-side PlayManager can be served by the GPU
+ * through host buffers without an interpreter in the loop.  Errors are reported by filling v / pi with NaN. */
+void azmi_net_eval_host(const float* canonical, uint32_t n, float* v, float* pi, void* net);
 /* azmi_net_forward_rows on an engine's own leaf batch and eval list (what azmi_run_rounds does after each round) */
 int azmi_pm_net_forward(azmi_pm* pm, azmi_net* net, void* stream);
 /* the same for one model group: only the leaves whose seat belongs to `group` (play_manager.cc:577, 597) */

@@ -344,6 +344,7 @@ uint32_t orc_pm_perm_scores(void* h, uint32_t perm, float* out) {
   for (size_t i = 0; i < sc.size(); ++i) out[i] = sc[i];
   return pm.perm_games_completed(perm);
 }
+void orc_pm_set_time_limit(void* h, double seconds) { static_cast<PmBox*>(h)->pm->time_limit_s = seconds; }
 int orc_pm_run(void* h, orc_eval_fn fn, void* user) {
   try {
     static_cast<PmBox*>(h)->pm->run([fn, user](const float* c, uint32_t n, float* v, float* pi) {

@@ -17,6 +17,7 @@
 //    evaluated in FIFO order in batches of max_batch_size (py_wrapper.cc:449-504
 //    + play_manager.cc:619-642), then pushed back in batch order.
 #pragma once
+#include <chrono>
 #include <deque>
 #include <functional>
 #include <memory>
@@ -144,14 +145,23 @@ class PlayManager {
   void run(const Evaluator& nn) {
     run_groups([&nn](uint32_t, const float* c, uint32_t n, float* v, float* pi) { nn(c, n, v, pi); });
   }
+  // bench hook (cpu_baseline leg): stop the run loop after this many seconds of wall time (0 = run to games_to_play)
+  double time_limit_s = 0.0;
   void run_groups(const GroupEvaluator& nn) {
+    const auto t_start = std::chrono::steady_clock::now();
+    auto expired = [&]() {
+      return time_limit_s > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() >= time_limit_s;
+    };
     while (games_completed_ < params_.games_to_play) {
+      uint32_t since_check = 0;
       while (!awaiting_mcts_.empty() && games_completed_ < params_.games_to_play) {
         const uint32_t i = awaiting_mcts_.front();
         awaiting_mcts_.pop_front();
         step(i);
+        if (time_limit_s > 0.0 && (++since_check & 1023u) == 0 && expired()) return;
       }
       if (games_completed_ >= params_.games_to_play) break;
+      if (expired()) return;
       bool any = false;
       for (auto& q : awaiting_inference_) any = any || !q.empty();
       if (!any) break;  // nothing left to do (all slots retired)

@@ -376,6 +376,16 @@ class PlayManager:
         if rc != 0:
             raise RuntimeError("oracle PlayManager.run failed")
 
+    def set_time_limit(self, seconds):
+        """bench hook: run() returns after `seconds` of wall time even if games_to_play is not reached."""
+        lib.orc_pm_set_time_limit(self.h, C.c_double(seconds))
+
+    def run_native(self, fn_ptr, user):
+        """run() with a NATIVE evaluator: fn_ptr(canonical, n, v, pi, user) is a C function pointer (e.g. libazmi's
+        azmi_net_eval_host), so no Python runs inside the loop and the call releases the GIL."""
+        if lib.orc_pm_run(self.h, C.c_void_p(fn_ptr), C.c_void_p(user)) != 0:
+            raise RuntimeError("oracle PlayManager.run failed")
+
     def run_groups(self, evaluator):
         """evaluator(group, canonical[n,C,H,W]) -> (v, pi): one evaluator per model group (play_manager.cc:577-597)."""
         chw, P, M = self.chw, self.P, self.M
