@@ -6,7 +6,7 @@ element j of lane l is  W[co = 16*mt + (l & 15)][k = 32*ks + 8*(l >> 4) + j]):
   stem    frag[2][4]   W[co][k = tap*C_in + ci] (k >= 9*C_in zero)      + bias[64] f32   (bn1 folded)
   block i a1[64] b1[64] c1[64] f32 | conv1 frag[18][4] (bn2 folded, k = tap*64 + ci) | conv2 frag[18][4]
   heads   frag[2][4]   rows 0-31 = v_conv * v_bn, rows 32-63 = pi_conv * pi_bn + bias[64] f32
-  v_fc1 W^T[32][hidden] b[hidden] | v_fc2 W[P+1][hidden] b[P+1] | pi_fc1 W^T[p*32 + c][16] b[M]   (all f32)
+  v_fc1 W^T[32][hidden] b[hidden] | v_fc2 W[P+1][hidden] b[P+1]  (f32) | pi_fc1: per pixel p frag hi(W[m][c*HW+p]) frag lo | b[M] f32
 """
 import ctypes as C
 
@@ -215,12 +215,16 @@ def fold(net, precision="bf16"):
     blob += _frags(wh.numpy()) + _f32(torch.cat([bv, bp]))
     blob += _f32(sd["v_fc1.weight"].t().contiguous()) + _f32(sd["v_fc1.bias"])       # [32][hidden]
     blob += _f32(sd["v_fc2.weight"]) + _f32(sd["v_fc2.bias"])
-    # flat policy head: reference feature order is (c, h, w) -> c*HW + p; the kernel sweeps p*32 + c
-    # and the weights are stored transposed [k'][16 rows] (rows >= num_moves zero) for the f32 MFMA A operand
-    wp = sd["pi_fc1.weight"].reshape(spec.num_moves, 32, H * W).permute(0, 2, 1).reshape(spec.num_moves, -1)
-    wt = torch.zeros((wp.shape[1], 16), dtype=torch.float64)
-    wt[:, : spec.num_moves] = wp.t()
-    blob += _f32(wt) + _f32(sd["pi_fc1.bias"])
+    # flat policy head: the reference's feature order is (c, h, w) -> c*HW + p.  The kernel contracts one pixel position p at
+    # a time on the bf16 matrix pipe, logits[m] += W_p[m][c] h[c][p], with W and h split into bf16 high + low parts:
+    # per p one A-fragment of the high parts of W_p (16 rows, rows >= num_moves zero), then one of the low parts
+    wp = torch.zeros((16, 32, H * W), dtype=torch.float64)
+    wp[: spec.num_moves] = sd["pi_fc1.weight"].reshape(spec.num_moves, 32, H * W)
+    hi = wp.float().to(torch.bfloat16).double()
+    lo = wp - hi
+    for p_ in range(H * W):
+        blob += _frags(hi[:, :, p_].numpy()) + _frags(lo[:, :, p_].numpy())
+    blob += _f32(sd["pi_fc1.bias"])
     desc = NetDescC(Cin, H, W, 64, spec.depth, 3, 32, spec.v_fc_hidden, spec.num_moves, spec.num_players, 0, 0, 1, 0, 0)
     assert len(blob) == lib.azmi_net_blob_bytes(C.byref(desc)), (len(blob), lib.azmi_net_blob_bytes(C.byref(desc)))
     return desc, bytes(blob)

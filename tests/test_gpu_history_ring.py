@@ -37,7 +37,7 @@ def test_a_drained_ring_yields_the_rows_of_an_unbounded_run(game):
     ref = az.PlayManager(G(), _params(az, games, S), seed=77)
     ref.play()
     want = _rows_sorted([_drain(ref, chw, M) for _ in range(8)])
-    cap = 2 * S * (42 if game == "connect4" else 150)            # far smaller than the run's rows; wraps several times
+    cap = 2 * S * 42 if game == "connect4" else 320            # far smaller than the run's rows; wraps several times
     pm = az.PlayManager(G(), _params(az, games, S), seed=77, history_capacity=cap)
     got = []
     while pm.remaining_games() > 0 or pm.games_completed() < games:
