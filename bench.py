@@ -145,7 +145,7 @@ def host_cores():
     return cores
 
 
-def cpu_baseline(az, sims, seconds, S, hip_net, cache):
+def cpu_baseline(az, sims, seconds, S, hip_net, cache, threads=None):
     """the reference's architecture on this box's host cores, timed beside the GPU engine — the oracle
     (CPU restatement of the reference PlayManager, `kind` "port") with `cores - 1` worker threads (the reference's default,
     config.py:439-441), the 4096 concurrent games split over the workers, and the leaf net served by the MI355X through
@@ -159,7 +159,7 @@ def cpu_baseline(az, sims, seconds, S, hip_net, cache):
     import threading
     import oracle_api as orc
     from alphazero._capi import lib
-    threads = max(1, host_cores() - 1)
+    threads = threads or max(1, host_cores() - 1)
     fn = C.cast(lib.azmi_net_eval_host, C.c_void_p).value
     out = {"unit": "games/s", "cores": threads, "kind": "port"}
 
@@ -210,6 +210,7 @@ def cpu_baseline(az, sims, seconds, S, hip_net, cache):
     out["tree_only"] = {"games_per_s": g, "sims_per_s": s, "note": f"EvalType.RANDOM (no net), {threads} threads, {n} games in {dt:.1f}s"}
     if "value" not in out:
         out["value"] = g
+        out["sims_per_s"] = s
         out["sample"] = out["tree_only"]["note"]
     # BASELINE configs[0]: Connect4, 64 concurrent games, 100 sims, one worker thread — the reference's own CPU-runnable case
     g, s, _, n, dt = leg("random", 64, 100, 3.0, 0, 1)

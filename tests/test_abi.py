@@ -59,10 +59,10 @@ def test_bench_cpu_baseline_leg_runs_on_the_oracle():
     sys.path.insert(0, os.path.join(ROOT, "alphazero-pybind11_amd"))
     import alphazero as az
     import bench
-    r = bench.cpu_baseline(az, 100, 1.0, threads=2)
+    r = bench.cpu_baseline(az, 100, 2.0, 64, None, 0, threads=2)      # no GPU here: the tree-only leg (EvalType.RANDOM) + configs[0]
     assert r["kind"] == "port" and r["unit"] == "games/s" and r["cores"] == 2
-    assert r["value"] > 0 and r["sims_per_s"] > 0
-    assert abs(r["per_thread_games_per_s"] * 2 - r["value"]) < 1e-6 * max(1.0, r["value"])
+    assert r["value"] > 0 and r["sims_per_s"] > 0 and r["value"] == r["tree_only"]["games_per_s"]
+    assert r["configs0"]["random_eval_games_per_s"] > 0 and "64 concurrent games, 100 sims" in r["configs0"]["workload"]
 
 
 def _pm_params(az, **kw):
