@@ -994,6 +994,11 @@ class PlayManager:
         else:
             check(lib.azmi_pm_net_forward(self._h, net._h, self._stream_arg(stream)))
 
+    def round_net(self, net, stream=None, part=0):
+        """One round with its leaf evaluation exactly as the native loop (run_rounds) issues it (azmi_pm_round_net):
+        part 0 = all of it, 1 = the tree half, 2 = the net half (with the move step of a split round fused in)."""
+        check(lib.azmi_pm_round_net(self._h, net._h, self._stream_arg(stream), int(part)))
+
     def poll(self, stream=None):
         done, live = C.c_uint32(), C.c_uint32()
         check(lib.azmi_pm_poll(self._h, self._stream_arg(stream), C.byref(done), C.byref(live)))

@@ -163,6 +163,7 @@ SYMBOLS = {
     "azmi_pm_build_batch_group": (C.c_int, [_VP, C.c_uint32, _VP, C.c_uint32, _VP, _PP(C.c_uint32)]),
     "azmi_net_forward_rows": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_uint32, _VP]),
     "azmi_net_eval_host": (None, [_VP, C.c_uint32, _VP, _VP, _VP]),
+    "azmi_pm_round_net": (C.c_int, [_VP, _VP, _VP, C.c_uint32]),
     "azmi_mcts_create": (C.c_int, [C.c_int, _VP, C.c_uint64, C.c_int, _PP(C.c_void_p)]),
     "azmi_mcts_destroy": (None, [_VP]),
     "azmi_mcts_find_leaf": (C.c_int, [_VP, _VP, C.c_uint32, _VP, C.c_uint32, _VP, C.c_uint32, _PP(C.c_uint32)]),

@@ -19,6 +19,7 @@
 
 #include "cache_host.h"
 #include "engine_kernels.h"
+#include "leafnet_c4.h"
 #include "engine_kernels_big.h"
 #include "mcts_object_kernels.h"
 
@@ -91,6 +92,7 @@ struct azmi_pm {
   std::vector<uint8_t> group_cache_counted;  // 0: stand-in for a `None` entry of an external cache list (not in the statistics)
   bool all_random = false;               // no seat needs a net (EvalType::RANDOM / PLAYOUT everywhere)
   bool any_playout = false;              // some seat uses EvalType::PLAYOUT
+  bool split_rounds = false;             // Connect4, plain PUCT seats: k_sim + move step instead of the one k_round (engine_kernels.h)
   std::vector<std::deque<uint32_t>> pending_g;   // host-buffer path: pending leaves per model group
   // hipGraph of kGraphRounds x (round kernels + net) for azmi_run_rounds: one graph launch instead of
   // ~5 kernel launches per round keeps the host ahead of the GPU
@@ -154,7 +156,8 @@ void launch_pre_round(azmi_pm* pm, hipStream_t st) {
     }
 }
 
-int launch_round(azmi_pm* pm, hipStream_t st) {
+// defer_moves: split rounds only - leave the move step to the fused net launch that follows (launch_net_move)
+int launch_round(azmi_pm* pm, hipStream_t st, bool defer_moves = false) {
   const uint32_t threads = 256;
   switch (pm->game) {
     case AZMI_GAME_CONNECT4: {
@@ -162,6 +165,11 @@ int launch_round(azmi_pm* pm, hipStream_t st) {
       const uint32_t slots_per_block = threads / Connect4::GROUP;
       const uint32_t blocks = (pm->ep.S + slots_per_block - 1) / slots_per_block;
       if (pm->any_playout) k_round<Connect4, true><<<blocks, threads, 0, st>>>(pm->ep, pm->ar);
+      else if (pm->split_rounds) {
+        // split round: the lean per-simulation kernel over every slot, then the move step over the slots it listed
+        k_sim<Connect4><<<blocks, threads, 0, st>>>(pm->ep, pm->ar);
+        if (!defer_moves) k_round<Connect4, false, true><<<blocks, threads, 0, st>>>(pm->ep, pm->ar);
+      }
       else k_round<Connect4><<<blocks, threads, 0, st>>>(pm->ep, pm->ar);
       break;
     }
@@ -188,6 +196,20 @@ int launch_round(azmi_pm* pm, hipStream_t st) {
   }
   HIP_TRY(hipGetLastError());
   return AZMI_OK;
+}
+
+// The net + move-step launch of a split round (Connect4 engine, one model group): workgroups [0, net_tiles) carry the tiles
+// of the round's eval list through the leaf net (leafnet_c4.h), the workgroups behind them run the round's move step
+// (round_body<kMover> over ar.mover_list).  The two are independent - a listed mover was not evaluated this round, its
+// new leaf is only queued for the next one - so the 20-60 us move chains hide behind the net instead of stretching the
+// tree kernel of every round.
+__global__ __launch_bounds__(256, 2) void k_net_move(azmi_net_dev::NetDesc nd, azmi_net_dev::NetPtrs np, EngineParams ep, EngineArrays ar,
+                                                     uint32_t net_tiles) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_fused[];
+  if (blockIdx.x < net_tiles)
+    azmi_net_dev::c4::tile<4, 4, 16>(nd, np, ar.canon, ar.v, ar.pi, ep.S, ar.eval_list, &ar.ctl->eval_count[0], blockIdx.x, lds_fused);
+  else
+    round_body<Connect4, false, true>(ep, ar, (blockIdx.x - net_tiles) * blockDim.x + threadIdx.x);
 }
 
 int read_ctl(azmi_pm* pm, hipStream_t st, Control* out, bool settle) {
@@ -628,6 +650,7 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
   ep.num_perms = seats.num_perms; ep.num_groups = seats.num_groups;
   pm->all_random = seats.all_random;
   pm->any_playout = seats.any_playout;
+  pm->split_rounds = game == AZMI_GAME_CONNECT4 && !seats.any_gumbel && !seats.any_playout && getenv("AZMI_NO_SPLIT") == nullptr;
   ep.cpuct = params->cpuct; ep.start_temp = params->start_temp; ep.final_temp = params->final_temp;
   ep.half_life = params->temp_decay_half_life;
   ep.epsilon = params->epsilon; ep.root_temp = params->mcts_root_temp; ep.fpu_reduction = params->fpu_reduction;
@@ -643,6 +666,7 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
   ep.seat_resign = seats.any_seat_resign ? 1u : 0u;
   ep.gum_stride = gi.maxk;
   ep.max_inline = opts.max_inline ? opts.max_inline : 4;
+  ep.sim_budget = getenv("AZMI_SIM_BUDGET_US") ? static_cast<uint32_t>(100.0 * atof(getenv("AZMI_SIM_BUDGET_US"))) : 0u;
   ep.max_hist_rows = gi.max_turns;
   ep.max_depth = gi.max_turns + 2;
   // every search expands at most one node (<= maxk children) per simulation and a tree is
@@ -687,6 +711,8 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
 #define A(field, count, zero) if (rc == AZMI_OK) rc = pm->alloc(ar.field, (count), (zero))
   A(ctl, 1, true);
   A(ended_list, S, true);
+  A(mover_list, S, true);
+  A(pend, game == AZMI_GAME_CONNECT4 ? static_cast<size_t>(S) * Connect4::GROUP : 0, true);
   A(eval_list, static_cast<size_t>(S) * ep.num_groups, true);
   A(seat_tab, seats.words.size(), false);
   A(perm, S, true);
@@ -838,7 +864,26 @@ int pm_net_forward(azmi_pm* pm, uint32_t group, azmi_net* net, hipStream_t st) {
   if (rc != AZMI_OK) return fail(rc, "%s", azmi_net_last_error());
   return AZMI_OK;
 }
+// split round + a Connect4-family bf16 net + one model group: the move step rides in the net launch (k_net_move)
+bool can_fuse(const azmi_pm* pm, const azmi_net* net, azmi_net_c4_view* view) {
+  return pm->split_rounds && pm->ep.num_groups == 1 && !pm->all_random && getenv("AZMI_NO_FUSE") == nullptr && azmi_net_c4_view_get(net, view) != 0;
+}
+int launch_net_move(azmi_pm* pm, const azmi_net_c4_view& view, hipStream_t st) {
+  static std::atomic<bool> reserved{false};
+  if (!reserved.exchange(true))
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_net_move), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(view.lds_bytes)));
+  const uint32_t net_tiles = (pm->ep.S + azmi_net_dev::c4::TBW - 1) / azmi_net_dev::c4::TBW;
+  const uint32_t move_blocks = (pm->ep.S * Connect4::GROUP + 255) / 256;
+  k_net_move<<<net_tiles + move_blocks, 256, view.lds_bytes, st>>>(view.nd, view.np, pm->ep, pm->ar, net_tiles);
+  HIP_TRY(hipGetLastError());
+  return AZMI_OK;
+}
 int one_round_with_net(azmi_pm* pm, azmi_net* net, hipStream_t st) {
+  azmi_net_c4_view view;
+  if (can_fuse(pm, net, &view)) {
+    const int rc = launch_round(pm, st, true);
+    return rc != AZMI_OK ? rc : launch_net_move(pm, view, st);
+  }
   int rc = launch_round(pm, st);
   if (rc != AZMI_OK) return rc;
   for (uint32_t g = 0; g < pm->ep.num_groups; ++g) {   // one net given: it serves every model group
@@ -916,6 +961,24 @@ int azmi_pm_net_forward(azmi_pm* pm, azmi_net* net, void* stream) {
   std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   for (uint32_t g = 0; g < pm->ep.num_groups; ++g) {   // the same net for every model group
     const int rc = pm_net_forward(pm, g, net, pm->pick(stream));
+    if (rc != AZMI_OK) return rc;
+  }
+  return AZMI_OK;
+}
+
+int azmi_pm_round_net(azmi_pm* pm, azmi_net* net, void* stream, uint32_t part) {
+  if (!pm || !net) return fail(AZMI_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
+  hipStream_t st = pm->pick(stream);
+  azmi_net_c4_view view;
+  const bool fused = can_fuse(pm, net, &view);
+  if (part == 0 || part == 1) {          // the tree half of the round
+    const int rc = launch_round(pm, st, fused);
+    if (rc != AZMI_OK || part == 1) return rc;
+  }
+  if (fused) return launch_net_move(pm, view, st);
+  for (uint32_t g = 0; g < pm->ep.num_groups; ++g) {
+    const int rc = pm_net_forward(pm, g, net, st);
     if (rc != AZMI_OK) return rc;
   }
   return AZMI_OK;

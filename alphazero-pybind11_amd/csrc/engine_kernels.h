@@ -74,6 +74,14 @@ __device__ __forceinline__ uint32_t gum_plan(uint32_t m, uint32_t n, uint32_t wa
   return count;
 }
 
+// lane image of a simulation's path (see PendRec, engine_types.h): level i in lane i, paths of <= 8 levels
+struct PathRegs {
+  uint32_t node = 0, n = 0, pp = 0, mv = 0;
+  float q = 0.0f, d = 0.0f, v = 0.0f;
+  uint64_t leaf_meta = 0;
+  uint32_t ok = 0;       // the path had at most 8 levels and is complete here
+};
+
 #define AZMI_SEL(arr, seat) ((seat) == 0 ? arr[0] : arr[P > 1 ? 1 : 0])
 template <class GM>
 struct SlotCtx {
@@ -396,7 +404,7 @@ struct SlotCtx {
   // ---- Node::add_children: legal moves ascending, std::shuffle, append to the arena ----
   // Returns false when the arena is full.  `meta_keep` supplies move/player/term of `node`.
   __device__ __forceinline__ bool expand_node(uint32_t seat, uint32_t node, const typename GM::State& st, uint64_t meta_keep,
-                              uint32_t& c0_out, uint32_t& k_out) {
+                              uint32_t& c0_out, uint32_t& k_out, uint32_t* mv_out = nullptr) {
     const size_t tb = tree_base(seat);
     const uint32_t k = GM::num_valid(st);
     // The legal moves (ascending) as 4-bit fields of one word that every lane of the group holds: std::shuffle
@@ -443,6 +451,7 @@ struct SlotCtx {
       ar.nodes[tb + node].meta = meta_pack(c0, k, meta_mv(meta_keep), meta_player(meta_keep), meta_term(meta_keep));
     c0_out = c0;
     k_out = k;
+    if (mv_out) *mv_out = mv;
     return true;
   }
 
@@ -523,7 +532,10 @@ struct SlotCtx {
   // ---- MCTS::find_leaf ---------------------------------------------------------------------
   // Descends from the root of `seat`'s tree, expands an unvisited node.  Outputs the leaf
   // state and its terminal code; stores MCTS::current_ / path_ for process_result.
-  __device__ __forceinline__ bool find_leaf(uint32_t seat, typename GM::State& leaf, uint32_t& term) {
+  // LEAN: the instantiation of the per-simulation kernel (k_sim): plain PUCT only, no Gumbel code
+  // rec != nullptr: also leaves the path's lane image there (the move step of a split round hands it to the next k_sim)
+  template <bool LEAN = false>
+  __device__ __forceinline__ bool find_leaf(uint32_t seat, typename GM::State& leaf, uint32_t& term, PathRegs* rec = nullptr) {
     sync_lanes();
     const size_t tb = tree_base(seat);
     const uint32_t root = AZMI_SEL(t_root, seat);
@@ -533,7 +545,7 @@ struct SlotCtx {
     uint32_t n = ar.nodes[tb + cur].n;
     uint32_t* path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
     uint32_t gum_active = 0;   // (uint32_t: a bool carried across the descent loop is mis-tracked by hipcc in divergent groups)
-    if (seat_gumbel(seat)) {  // lazy init, mcts.cc:465-472 (MCTS::gumbel_enabled_ of this seat's tree)
+    if (!LEAN && seat_gumbel(seat)) {  // lazy init, mcts.cc:465-472 (MCTS::gumbel_enabled_ of this seat's tree)
       const uint32_t* st = gum_state(seat);
       gum_active = st[kGumInit];
       if (!gum_active && st[kGumTarget] > 0 && n > 0 && meta_nch(meta) != 0) {
@@ -552,12 +564,19 @@ struct SlotCtx {
       const size_t ci = tb + c0 + lane;
       uint32_t n_l = 0; float q_l = 0.0f, p_l = 0.0f; uint64_t m_l = 0;
       if (lane < k) { n_l = ar.nodes[ci].n; q_l = ar.nodes[ci].q; p_l = ar.nodes[ci].pr; m_l = ar.nodes[ci].meta; }
+      float d_l = 0.0f, vv_l = 0.0f;
+      if (rec && lane < k) { d_l = ar.nodes[ci].d; vv_l = ar.nodes[ci].v; }
       const float fpu = (cur == root && seat_fpu_zero(seat)) ? 0.0f : ep.fpu_reduction;
       const float v_parent = ar.nodes[tb + cur].v;
       uint32_t best;
-      if (gum_active && cur == root) best = gumbel_next_root_child(seat, k, n_l, q_l, p_l);
-      else if (gum_active && seat_gumbel_full(seat)) best = gumbel_interior_select(seat, k, n_l, q_l, p_l, v_parent);
+      if (!LEAN && gum_active && cur == root) best = gumbel_next_root_child(seat, k, n_l, q_l, p_l);
+      else if (!LEAN && gum_active && seat_gumbel_full(seat)) best = gumbel_interior_select(seat, k, n_l, q_l, p_l, v_parent);
       else best = select_child(k, n_l, q_l, p_l, v_parent, n, fpu);
+      if (rec) {
+        const float s_q = bcast(q_l, best), s_d = bcast(d_l, best), s_v = bcast(vv_l, best);
+        const uint32_t s_n = bcast(n_l, best);
+        if (plen - 1 == lane) { rec->node = c0 + best; rec->n = s_n; rec->q = s_q; rec->d = s_d; rec->v = s_v; rec->pp = meta_player(meta); }
+      }
       cur = c0 + best;
       n = bcast(n_l, best);
       meta = bcast(m_l, best);
@@ -567,14 +586,23 @@ struct SlotCtx {
 #pragma unroll
     for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == seat) t_tld[p] += plen;
     term = meta_term(meta);
+    if (rec) { rec->leaf_meta = meta; rec->mv = 0; rec->ok = plen <= static_cast<uint32_t>(G) ? 1u : 0u; }
     if (n == 0) {
       term = GM::terminal(leaf);
       trace(109);
       const uint64_t keep = meta_pack(0, 0, meta_mv(meta), leaf.player, term);
-      uint32_t c0, k;
-      if (!expand_node(seat, cur, leaf, keep, c0, k)) return false;
+      uint32_t c0, k, mv = 0;
+      if (!expand_node(seat, cur, leaf, keep, c0, k, &mv)) return false;
+      if (rec) { rec->leaf_meta = meta_pack(c0, k, meta_mv(meta), leaf.player, term); rec->mv = mv; }
     }
     return true;
+  }
+  // the pending simulation's lane image to / from HBM (split rounds)
+  __device__ __forceinline__ void store_pend(const PathRegs& r) const {
+    PendRec* p = ar.pend + static_cast<size_t>(slot) * G + lane;
+    p->node = r.node; p->n = r.n; p->q = r.q; p->d = r.d; p->v = r.v;
+    p->pp_mv = (r.pp & 0xFFu) | (r.mv << 8);
+    p->leaf_meta = r.leaf_meta;
   }
 
   // ---- MCTS::add_root_noise: children in lanes [0,k), priors p_l -----------------------------
@@ -617,6 +645,8 @@ struct SlotCtx {
   // issued together: level 1 = leaf META, path entries, value row; level 2 = children moves, parents' META and the
   // path nodes' N/Q/D; level 3 = the prior gather.  The priors half (writes Pr of the leaf's children) and the backup
   // half (reads/writes N, Q, D, V of path nodes) touch disjoint data, so hoisting the backup loads is safe.
+  // LEAN (k_sim): the evaluated leaf is never the root, so the root temperature / Dirichlet code is not instantiated
+  template <bool LEAN = false>
   __device__ __forceinline__ void process_result(uint32_t seat, bool from_net, bool root_noise, bool have_regs = false,
                                                  float reg_pi = 0.0f, float reg_v = 0.0f) {
     sync_lanes();
@@ -664,12 +694,16 @@ struct SlotCtx {
         const float ksum = static_cast<float>(k & 0xFFu);
         if (lane < k) p = (ksum == 0.0f) ? 0.0f : 1.0f / ksum;
       }
-      const bool is_root = cur == root;
-      const float root_temp = seat_root_temp(seat);
-      if (is_root && root_temp != 1.0f && lane < k) p = az_powf(p, 1.0f / root_temp);
+      const bool is_root = !LEAN && cur == root;
+      if constexpr (!LEAN) {
+        const float root_temp = seat_root_temp(seat);
+        if (is_root && root_temp != 1.0f && lane < k) p = az_powf(p, 1.0f / root_temp);
+      }
       const float sum = seqsum8(lane < k ? p : 0.0f);
       p = p / sum;
-      if (is_root && root_noise && !seat_gumbel(seat)) { trace(1 | (static_cast<uint64_t>(k) << 8)); p = add_root_noise(k, p, seat_eps(seat)); trace(2); }
+      if constexpr (!LEAN) {
+        if (is_root && root_noise && !seat_gumbel(seat)) { trace(1 | (static_cast<uint64_t>(k) << 8)); p = add_root_noise(k, p, seat_eps(seat)); trace(2); }
+      }
       if (lane < k) ar.nodes[ci].pr = p;
     }
     // backup: level i updates node_i (child of path[i]); levels are independent -> one lane each
@@ -1197,12 +1231,19 @@ struct SlotCtx {
 
 // One round of PlayManager::play for every slot (play_manager.cc:272-599).
 // kPlayout: the instantiation for engines with an EvalType::PLAYOUT seat carries the rollout code; the common one does not
-template <class GM, bool kPlayout = false>
-__global__ __launch_bounds__(256, 1) void k_round(EngineParams ep, EngineArrays ar) {
+// kMover: the move step of a SPLIT round — the kernel runs over the slots k_sim listed in ar.mover_list (game starts, the
+// simulation that completes a search + the move, root leaves: everything rare and register-hungry), beside or behind the
+// net launch of the round; a leaf it sends to the net is only written (kSlotQueued), the next round's k_sim lists it.
+template <class GM, bool kPlayout = false, bool kMover = false>
+__device__ __forceinline__ void round_body(const EngineParams& ep, const EngineArrays& ar, const uint32_t gtid) {
   constexpr int G = GM::GROUP;
   constexpr int P = GM::P;
-  const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t slot = gtid / G, lane = gtid % G;
+  uint32_t slot = gtid / G;
+  const uint32_t lane = gtid % G;
+  if constexpr (kMover) {
+    if (slot >= ar.ctl->mover_count) return;
+    slot = ar.mover_list[slot];
+  }
   if (slot >= ep.S) return;
   if (ar.ctl->stop) return;
   const uint8_t st = ar.sstate[slot];
@@ -1214,6 +1255,7 @@ __global__ __launch_bounds__(256, 1) void k_round(EngineParams ep, EngineArrays 
   c.load();
   c.trace(101);
   uint32_t inline_sims = 0, insert_key_set = 0;
+  PathRegs prec;           // split rounds: the lane image of the simulation this step leaves pending
   bool need_process = (st == kSlotWaitEval);
   if (!need_process) {  // kSlotFresh / kSlotRestart
     c.start_game();
@@ -1241,7 +1283,7 @@ __global__ __launch_bounds__(256, 1) void k_round(EngineParams ep, EngineArrays 
     const uint32_t cp = c.gs.player;
     typename GM::State leaf;
     uint32_t term = 0;
-    if (!c.find_leaf(cp, leaf, term)) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; c.store(kSlotDone); return; }
+    if (!c.find_leaf(cp, leaf, term, kMover ? &prec : nullptr)) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; c.store(kSlotDone); return; }
     c.trace(104 | (static_cast<uint64_t>(c.plen) << 8));
     const bool playout = kPlayout && term == 0 && c.seat_eval_playout(cp);   // (a terminal leaf's evaluation is never used)
     const bool needs_net = term == 0 && !c.seat_eval_random(cp) && !playout;
@@ -1258,6 +1300,226 @@ __global__ __launch_bounds__(256, 1) void k_round(EngineParams ep, EngineArrays 
         c.emit_leaf(leaf, key);      // the planes are only needed when the net is (the cached answer replaces them)
         if (lane == 0) {
           ar.c_evals[slot] += 1;
+          ar.leaf_group[slot] = static_cast<uint8_t>(group);
+          if constexpr (!kMover) {
+            if (ep.cache_on) ar.cache_keys[slot] = cache_key(key);
+            ar.eval_list[static_cast<size_t>(group) * ep.S + atomicAdd(&ar.ctl->eval_count[group], 1u)] = slot;
+          }
+        }
+        insert_key_set = kMover ? 2 : 1;
+        break;
+      }
+    }
+    need_process = true;
+    if (++inline_sims >= ep.max_inline) break;
+    if constexpr (kMover) break;     // the move step stops at its first leaf: what follows is k_sim's work, and the step must stay shorter than the net launch it rides in
+  }
+  if (ep.cache_on && insert_key_set != 1 && lane == 0) ar.cache_keys[slot] = 0;
+  if constexpr (kMover) {
+    if (prec.ok) { c.store_pend(prec); c.flags |= kFlagPendRec; } else c.flags &= ~kFlagPendRec;
+  }
+  c.store(insert_key_set == 2 ? kSlotQueued : kSlotWaitEval);
+  c.trace(106);
+}
+template <class GM, bool kPlayout = false, bool kMover = false>
+__global__ __launch_bounds__(256, 1) void k_round(EngineParams ep, EngineArrays ar) {
+  round_body<GM, kPlayout, kMover>(ep, ar, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// The per-simulation kernel of a SPLIT round (lane-group engine, plain PUCT seats): backup of the pending evaluation, descent,
+// expansion, position-cache probe, leaf hand-off — up to max_inline times — for every slot whose next step is an ordinary
+// simulation.  Everything else (a game start, the simulation that completes a search and the move behind it, a leaf that
+// is the root: temperature / Dirichlet noise) is left untouched and listed for the move step (k_round<kMover>).  Without
+// that code the kernel needs half the registers of k_round, so two to four times as many waves share a SIMD, and no
+// wave waits for a neighbour slot's 20 us move.
+template <class GM>
+__global__ __launch_bounds__(256, 2) void k_sim(EngineParams ep, EngineArrays ar) {
+  constexpr int G = GM::GROUP;
+  constexpr int P = GM::P;
+  const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t slot = gtid / G, lane = gtid % G;
+  if (slot >= ep.S) return;
+  if (ar.ctl->stop) return;
+  const uint8_t st = ar.sstate[slot];
+  if (st == kSlotDone || st == kSlotEnded) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; return; }
+  if (st == kSlotQueued) {     // the move step's leaf: on this round's eval list, its answer is cached next round
+    if (lane == 0) {
+      const uint32_t group = ar.leaf_group[slot];
+      if (ep.cache_on) ar.cache_keys[slot] = cache_key(ar.leaf_key[slot]);
+      ar.eval_list[static_cast<size_t>(group) * ep.S + atomicAdd(&ar.ctl->eval_count[group], 1u)] = slot;
+      ar.sstate[slot] = kSlotWaitEval;
+    }
+    return;
+  }
+  auto defer = [&]() {
+    if (lane == 0) {
+      if (ep.cache_on) ar.cache_keys[slot] = 0;
+      ar.mover_list[atomicAdd(&ar.ctl->mover_count, 1u)] = slot;
+    }
+  };
+  if (st != kSlotWaitEval) { defer(); return; }          // kSlotFresh / kSlotRestart: a game start
+  SlotCtx<GM> c(ep, ar, slot, lane);
+  const uint64_t t_start = ep.sim_budget ? wall_clock64() : 0;
+  c.trace(100);
+  c.load();
+  static_assert(P == 2 && G == 8, "the register-resident path below is written for two players and 8-lane groups");
+  const uint32_t cp = c.gs.player;                 // no move happens in this kernel: one tree, one player to move
+  const size_t tb = c.tree_base(cp);
+  const uint32_t root = AZMI_SEL(c.t_root, cp);
+  const uint32_t goal = (c.flags & kFlagCapped) ? c.seat_cap_visits(cp) : c.seat_visits(cp);
+  // the next backup completes the search (a move follows), the evaluated leaf is the root (temperature, noise), or the
+  // pending simulation has no lane image (a path deeper than 8 levels): the move step's business
+  if (!(c.flags & kFlagPendRec) || AZMI_SEL(c.t_depth, cp) + 1 >= goal || c.cur == root) { defer(); return; }
+  const float fpu_root = c.seat_fpu_zero(cp) ? 0.0f : ep.fpu_reduction;
+  uint32_t* const path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
+  // ---- the pending simulation in registers: level i <-> lane i: the node chosen at level i as the descent saw it (n, q,
+  // d, v) and the player to move at its parent; lf_*: the evaluated leaf after its expansion (children in lanes).  The
+  // backup works on these, stores its results without waiting and FORWARDS them (fw_*, fl_*) to the next descent, which
+  // patches whatever it loads for those nodes.  (Only the immediately preceding simulation can have stores in flight:
+  // every descent waits for loads it issued behind them.)  One round trip at the start of the round brings in the
+  // slot's state, the image of the simulation left pending last round (ar.pend) and its (v, pi) rows.
+  const PendRec pr_in = ar.pend[static_cast<size_t>(slot) * G + lane];
+  float reg_pi = 0.0f, reg_v = 0.0f;   // lane m: pi[m]; lane i <= P: v[i] (the net's rows, or a cache hit of this round)
+  if (c.flags & kFlagLeafNeedsNet) {
+    if (lane < static_cast<uint32_t>(GM::M)) reg_pi = ar.pi[static_cast<size_t>(slot) * GM::M + lane];
+    if (lane <= static_cast<uint32_t>(P)) reg_v = ar.v[static_cast<size_t>(slot) * (P + 1) + lane];
+  }
+  uint32_t root_n; float root_v; uint64_t root_meta;
+  { const NodeRec* rr = ar.nodes + tb + root; root_n = rr->n; root_v = rr->v; root_meta = rr->meta; }
+  uint32_t lv_node = pr_in.node, lv_n = pr_in.n, lv_pp = pr_in.pp_mv & 0xFFu;
+  float lv_q = pr_in.q, lv_d = pr_in.d, lv_v = pr_in.v;
+  uint64_t lf_meta = pr_in.leaf_meta;
+  uint32_t lf_mv = pr_in.pp_mv >> 8;
+  uint32_t lf_c0 = meta_ch0(lf_meta), lf_k = meta_nch(lf_meta), lf_term = meta_term(lf_meta), lf_player = meta_player(lf_meta);
+  bool fw = false;               // fw_* / fl_* describe the simulation backed up last (in this round)
+  uint32_t fw_node = 0, fw_n = 0, fw_plen = 0;
+  float fw_q = 0.0f, fw_d = 0.0f, fw_v = 0.0f;
+  uint32_t fl_node = 0xFFFFFFFFu, fl_mv = 0;
+  uint64_t fl_meta = 0;
+  float fl_pr = 0.0f;
+  uint32_t inline_sims = 0, insert_key_set = 0, sims_done = 0;
+  bool rec_ok = true;
+  c.trace(101);
+  for (;;) {
+    if (AZMI_SEL(c.t_depth, cp) + 1 >= goal || c.cur == root || !rec_ok) {   // (never true in the first pass: checked above)
+      if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0;
+      if (lane == 0) ar.mover_list[atomicAdd(&ar.ctl->mover_count, 1u)] = slot;
+      break;
+    }
+    {
+      // ---- MCTS::process_result (mcts.cc:500-555) on the lane-resident path
+      const bool from_net = (c.flags & kFlagLeafNeedsNet) != 0;
+      float val[P + 1];
+      if (lf_term != 0) {
+#pragma unroll
+        for (int i = 0; i <= P; ++i) val[i] = (static_cast<int>(lf_term) - 1 == i) ? 1.0f : 0.0f;
+      } else {
+        float p = 0.0f;
+        if (from_net) {
+#pragma unroll
+          for (int i = 0; i <= P; ++i) val[i] = c.bcast(reg_v, i);
+          p = c.bcast(reg_pi, static_cast<int>(lf_mv));
+          if (lane >= lf_k) p = 0.0f;
+        } else {                  // dumb_eval: uniform over legal moves, u8 sum wraps (game_state.h:160-173)
+#pragma unroll
+          for (int i = 0; i <= P; ++i) val[i] = static_cast<float>(1.0 / (P + 1));
+          const float ksum = static_cast<float>(lf_k & 0xFFu);
+          if (lane < lf_k) p = (ksum == 0.0f) ? 0.0f : 1.0f / ksum;
+        }
+        const float sum = c.seqsum8(lane < lf_k ? p : 0.0f);
+        p = p / sum;
+        if (lane < lf_k) ar.nodes[tb + lf_c0 + lane].pr = p;
+        fl_pr = p;
+      }
+      fl_node = c.cur; fl_mv = lf_mv; fl_meta = lf_meta;
+      const float draw_share = val[P] / static_cast<int32_t>(P);
+      const uint32_t plen = c.plen;
+      float nq = 0.0f, nd = 0.0f, nv = lv_v;
+      if (lane < plen) {
+        const float vv = ((lv_pp == 0) ? val[0] : val[1]) + draw_share;
+        nq = (lv_q * static_cast<float>(lv_n) + vv) / static_cast<float>(lv_n + 1);
+        nd = (lv_d * static_cast<float>(lv_n) + val[P]) / static_cast<float>(lv_n + 1);
+        NodeRec* nr = ar.nodes + tb + lv_node;
+        nr->q = nq; nr->d = nd;
+        if (lv_n == 0) { nv = ((lf_player == 0) ? val[0] : val[1]) + draw_share; nr->v = nv; }   // only the leaf can be a first visit
+        nr->n = lv_n + 1;
+      }
+      fw_node = lv_node; fw_n = lv_n + 1; fw_q = nq; fw_d = nd; fw_v = nv; fw_plen = plen; fw = true;
+      root_n += 1;
+      if (lane == 0) ar.nodes[tb + root].n = root_n;
+#pragma unroll
+      for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == cp) c.t_depth[p] += 1;
+      sims_done += 1;
+    }
+    c.trace(102);
+    // ---- MCTS::find_leaf (mcts.cc:462-498), plain PUCT, with the forwarded values patched in
+    typename GM::State leaf = c.gs;
+    uint32_t cur = root, plen = 0, n = root_n;
+    uint64_t meta = root_meta;
+    float v_cur = root_v;
+    bool prefix = true;
+    while (n > 0 && meta_term(meta) == 0) {
+      if (plen >= ep.max_depth) { c.raise(8u); if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; c.store(kSlotDone); return; }
+      if (lane == 0) path[plen] = cur;
+      const uint32_t k = meta_nch(meta), c0 = meta_ch0(meta);
+      if (k == 0) { c.raise(8u); if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; c.store(kSlotDone); return; }
+      uint32_t n_l = 0; float q_l = 0.0f, p_l = 0.0f, d_l = 0.0f, v_l = 0.0f; uint64_t m_l = 0;
+      if (cur == fl_node) {                 // the children of the leaf evaluated a moment ago: all in registers
+        if (lane < k) { p_l = fl_pr; m_l = meta_pack(0, 0, fl_mv, 0, 0); }
+      } else {
+        if (lane < k) {
+          const NodeRec* cr = ar.nodes + tb + c0 + lane;
+          n_l = cr->n; q_l = cr->q; p_l = cr->pr; d_l = cr->d; v_l = cr->v; m_l = cr->meta;
+        }
+        if (prefix && plen < fw_plen && plen < 8u) {   // one child of this node was updated by the last backup
+          const uint32_t t_node = c.bcast(fw_node, static_cast<int>(plen));
+          const uint32_t t_n = c.bcast(fw_n, static_cast<int>(plen));
+          const float t_q = c.bcast(fw_q, static_cast<int>(plen)), t_d = c.bcast(fw_d, static_cast<int>(plen)), t_v = c.bcast(fw_v, static_cast<int>(plen));
+          if (c0 + lane == t_node) { n_l = t_n; q_l = t_q; d_l = t_d; v_l = t_v; if (t_node == fl_node) m_l = fl_meta; }
+        }
+      }
+      const float fpu = (cur == root) ? fpu_root : ep.fpu_reduction;
+      const uint32_t best = c.select_child(k, n_l, q_l, p_l, v_cur, n, fpu);
+      const uint32_t nxt = c0 + best;
+      const uint32_t s_n = c.bcast(n_l, static_cast<int>(best));
+      const float s_q = c.bcast(q_l, static_cast<int>(best)), s_d = c.bcast(d_l, static_cast<int>(best)), s_v = c.bcast(v_l, static_cast<int>(best));
+      const uint64_t s_m = c.bcast(m_l, static_cast<int>(best));
+      if (plen < 8u) {
+        if (lane == plen) { lv_node = nxt; lv_n = s_n; lv_q = s_q; lv_d = s_d; lv_v = s_v; lv_pp = meta_player(meta); }
+        prefix = prefix && plen < fw_plen && nxt == c.bcast(fw_node, static_cast<int>(plen));
+      } else {
+        prefix = false;
+      }
+      cur = nxt; n = s_n; meta = s_m; v_cur = s_v;
+      GM::play(leaf, meta_mv(meta));
+      ++plen;
+      c.trace(108);
+    }
+    c.cur = cur; c.plen = plen;
+    rec_ok = plen <= 8u;
+#pragma unroll
+    for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == cp) c.t_tld[p] += plen;
+    uint32_t term = meta_term(meta);
+    lf_k = meta_nch(meta); lf_c0 = meta_ch0(meta); lf_mv = 0; lf_meta = meta;
+    if (n == 0) {
+      term = GM::terminal(leaf);
+      const uint64_t keep = meta_pack(0, 0, meta_mv(meta), leaf.player, term);
+      if (!c.expand_node(cp, cur, leaf, keep, lf_c0, lf_k, &lf_mv)) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; c.store(kSlotDone); return; }
+      lf_meta = meta_pack(lf_c0, lf_k, meta_mv(meta), leaf.player, term);
+    }
+    lf_term = term; lf_player = leaf.player;
+    c.trace(109);
+    const bool needs_net = term == 0 && !c.seat_eval_random(cp);
+    const uint32_t group = c.seat_group(cp);
+    c.flags = needs_net ? (c.flags | kFlagLeafNeedsNet) : (c.flags & ~kFlagLeafNeedsNet);
+    if (needs_net) {
+      const uint64_t key = GM::key(leaf);
+      const bool hit = ep.cache_on && c.cache_lookup(key, group, reg_pi, reg_v);
+      c.trace(105 | (static_cast<uint64_t>(hit ? 1 : 0) << 8));
+      if (!hit) {
+        c.emit_leaf(leaf, key);
+        if (lane == 0) {
+          ar.c_evals[slot] += 1;
           if (ep.cache_on) ar.cache_keys[slot] = cache_key(key);
           ar.leaf_group[slot] = static_cast<uint8_t>(group);
           ar.eval_list[static_cast<size_t>(group) * ep.S + atomicAdd(&ar.ctl->eval_count[group], 1u)] = slot;
@@ -1266,10 +1528,25 @@ __global__ __launch_bounds__(256, 1) void k_round(EngineParams ep, EngineArrays 
         break;
       }
     }
-    need_process = true;
-    if (++inline_sims >= ep.max_inline) break;
+    // the answer of this leaf is at hand (terminal, RANDOM evaluator, cache hit): the slot goes on, unless the round's
+    // budget is used up - in simulations, or in time: the kernel lasts as long as its slowest wave, and the results do
+    // not depend on where a round ends
+    if (++inline_sims >= ep.max_inline || (ep.sim_budget && static_cast<uint32_t>(wall_clock64() - t_start) > ep.sim_budget)) {
+      if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0;
+      break;
+    }
   }
-  if (ep.cache_on && !insert_key_set && lane == 0) ar.cache_keys[slot] = 0;
+  (void)insert_key_set;
+  if (lane == 0 && sims_done) ar.c_sims[slot] += sims_done;
+  // the pending simulation's lane image for the next round (or for nobody, when the path was too deep: the move step reads memory)
+  if (rec_ok) {
+    PathRegs r;
+    r.node = lv_node; r.n = lv_n; r.q = lv_q; r.d = lv_d; r.v = lv_v; r.pp = lv_pp; r.mv = lf_mv; r.leaf_meta = lf_meta;
+    c.store_pend(r);
+    c.flags |= kFlagPendRec;
+  } else {
+    c.flags &= ~kFlagPendRec;
+  }
   c.store(kSlotWaitEval);
   c.trace(106);
 }
@@ -1285,6 +1562,7 @@ __device__ __forceinline__ void assign_body(const EngineParams& ep, const Engine
   if (threadIdx.x == 0 && count_round) {
     ctl->rounds += 1;
     ctl->eval_count[0] = 0; ctl->eval_count[1] = 0; ctl->eval_count[2] = 0; ctl->eval_count[3] = 0;
+    ctl->mover_count = 0;
   }
   if (n == 0) return;
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {

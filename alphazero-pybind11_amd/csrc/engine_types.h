@@ -14,10 +14,13 @@ enum SlotState : uint8_t {
   kSlotWaitEval = 1, // a leaf is pending: next round starts with process_result
   kSlotEnded = 2,    // game finished this round; k_assign decides restart / retire
   kSlotRestart = 3,  // start the next game at the beginning of the round
-  kSlotDone = 4      // retired (games_started >= games_to_play, play_manager.cc:507-509)
+  kSlotDone = 4,     // retired (games_started >= games_to_play, play_manager.cc:507-509)
+  kSlotQueued = 5    // split rounds: the move step left a leaf whose planes are written but which is not on an eval list yet;
+                     // the next round's k_sim lists it (and then waits for the answer like kSlotWaitEval)
 };
 
-enum SlotFlags : uint8_t { kFlagCapped = 1, kFlagPlaythrough = 2, kFlagLeafNeedsNet = 4 };
+enum SlotFlags : uint8_t { kFlagCapped = 1, kFlagPlaythrough = 2, kFlagLeafNeedsNet = 4,
+                           kFlagPendRec = 8 /* ar.pend[slot] describes the pending simulation (split rounds) */ };
 
 // node META word: [31:0] first child (tree-relative), [43:32] child count,
 // [55:44] move, [56] player to move at the node, [59:57] terminal code
@@ -44,6 +47,7 @@ struct EngineParams {  // run constants (PlayParams, play_manager.h:60-154, afte
   uint32_t history, tree_reuse, cap_rand, root_fpu_zero, shaped, pruning;
   uint32_t eval_random[4]; // seat uses EvalType::RANDOM (dumb_eval) instead of the net
   uint32_t max_inline;
+  uint32_t sim_budget;     // split rounds: k_sim starts no further simulation of a slot once this many 100 MHz ticks of the round have passed (0 = no budget)
   uint32_t hist_cap, log_cap, log_moves;
   uint32_t max_hist_rows;  // pending history rows per slot (= max moves of one game)
   uint32_t max_depth;      // path capacity per slot
@@ -90,6 +94,17 @@ struct alignas(32) NodeRec {
   uint64_t meta;  // children range, move, player, terminal code (meta_pack)
 };
 
+// Split rounds: the pending simulation's path as the descent saw it, one record per level (level i <-> lane i of the slot's
+// 8-lane group, paths of at most 8 levels): the node chosen at level i with its n, q, d, v, the player to move at its parent,
+// and - the same in every lane - the evaluated leaf's META after its expansion; lane j also carries the move of the leaf's
+// child j.  k_sim backs the simulation up from this record and the (v, pi) rows alone: one memory round trip.
+struct alignas(32) PendRec {
+  uint32_t node, n;
+  float q, d, v;
+  uint32_t pp_mv;       // bits 0-7 player to move at the parent, bits 8-19 move of the leaf's child `lane`
+  uint64_t leaf_meta;
+};
+
 struct Control {  // small device control block, copied back by azmi_pm_poll
   uint32_t games_started;
   uint32_t games_completed;
@@ -102,7 +117,7 @@ struct Control {  // small device control block, copied back by azmi_pm_poll
   uint64_t rounds;
   uint32_t eval_count[4]; // per model group: entries of eval_list[g] written by this round's k_round
   uint32_t hist_read;     // finished-sample ring: rows the host has consumed (hist_rows - hist_read rows are live, <= hist_cap)
-  uint32_t pad_;
+  uint32_t mover_count;   // split rounds: entries of mover_list written by this round's k_sim
 };
 
 constexpr uint32_t kGumMaxM = 64;   // cap on PlayParams.gumbel_m (reference default 16)
@@ -110,6 +125,8 @@ constexpr uint32_t kGumMaxM = 64;   // cap on PlayParams.gumbel_m (reference def
 struct EngineArrays {
   Control* ctl;
   uint32_t* ended_list;   // [S]
+  PendRec* pend;          // [S][8] split rounds: register image of the pending simulation's path (NULL for the wide games)
+  uint32_t* mover_list;   // [S] split rounds: slots k_sim left to the move step (k_round over this list), unordered
   // ---- per slot -----------------------------------------------------------------
   uint64_t* gs_words;     // [STATE_WORDS][S] game state, SoA
   uint64_t* rng;          // [S] tree stream   (mcts.cc:19)

@@ -360,10 +360,16 @@ def main():
                     for i in range(K):
                         if i == 0:
                             e0.record(streams[0])
-                        group[i].round(sps[i])
+                        if hip_net is not None:
+                            group[i].round_net(hip_net, sps[i], part=1)    # the launches of the native loop, in two halves
+                        else:
+                            group[i].round(sps[i])
                         if i == 0:
                             e1.record(streams[0])
-                        evaluate(group, i)
+                        if hip_net is not None:
+                            group[i].round_net(hip_net, sps[i], part=2)
+                        else:
+                            evaluate(group, i)
                         if i == 0:
                             e2.record(streams[0])
                     ev.append((e0, e1, e2))

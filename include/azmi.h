@@ -352,6 +352,10 @@ int azmi_net_forward_rows(azmi_net* net, const float* dev_canonical, float* dev_
 void azmi_net_eval_host(const float* canonical, uint32_t n, float* v, float* pi, void* net);
 /* azmi_net_forward_rows on an engine's own leaf batch and eval list (what azmi_run_rounds does after each round) */
 int azmi_pm_net_forward(azmi_pm* pm, azmi_net* net, void* stream);
+/* one engine round with its leaf evaluation, as azmi_run_rounds issues it: part 0 = the whole round, 1 = the tree half only
+ * (cache insert, simulations), 2 = the net half only (leaf net over the eval list; on the split-round Connect4 engine the
+ * round's move step rides in the same launch).  Parts 1 and 2 exist so that a caller can put timing events between them. */
+int azmi_pm_round_net(azmi_pm* pm, azmi_net* net, void* stream, uint32_t part);
 /* the same for one model group: only the leaves whose seat belongs to `group` (play_manager.cc:577, 597) */
 int azmi_pm_net_forward_group(azmi_pm* pm, uint32_t group, azmi_net* net, void* stream);
 /* num_model_groups() / num_seat_perms(), play_manager.h:210-211 */

@@ -25,7 +25,7 @@ for i in range(K):
     streams.append(torch.cuda.Stream())
 hip = az.HipLeafNet(torch_net.random_init(torch_net.connect4_spec(), seed=0), torch_net.connect4_spec())
 sps = [s.cuda_stream for s in streams]
-az.run_rounds(pms, hip, 33000, sps)
+az.run_rounds(pms, hip, int(os.environ.get('TRACE_ROUNDS', '33000')), sps)
 torch.cuda.synchronize()
 lib = _capi.lib
 lib.azmi_debug_trace.restype = C.c_int
@@ -34,7 +34,7 @@ buf = np.zeros((1 << 16, 2), np.uint64); n = C.c_uint32()
 assert lib.azmi_debug_trace(pms[0]._h, buf.ctypes.data, 1 << 16, C.byref(n)) == 0
 ev = buf[: n.value]
 tags = (ev[:, 0] & 0xFF).astype(int); arg = (ev[:, 0] >> 8).astype(int); clk = ev[:, 1].astype(np.int64)
-names = {100: "start", 101: "load", 102: "process_result", 103: "make_move", 104: "find_leaf", 105: "emit+cache probe", 106: "store/end", 107: "game end", 108: "  descent level", 109: "  terminal check"}
+names = {100: "start", 101: "load", 102: "process_result", 103: "make_move", 104: "find_leaf", 105: "key+cache probe", 106: "emit/store/end", 107: "game end", 108: "  descent level", 109: "  terminal+expand"}
 dur = {}
 rounds = []
 prev = None
@@ -56,5 +56,4 @@ for t in sorted(dur):
     print(f"{names[t]:>18}: n={len(d):6d} mean {d.mean():7.2f} us  p50 {np.percentile(d, 50):7.2f}  p90 {np.percentile(d, 90):7.2f}  max {d.max():7.2f}")
 r = np.array(rounds)
 print(f"{'slot total/round':>18}: mean {r.mean():7.2f} us  p50 {np.percentile(r, 50):7.2f}  p90 {np.percentile(r, 90):7.2f}  max {r.max():7.2f}")
-depth = arg[tags == 104]
-print("leaf depth mean", depth.mean(), "cache hit fraction of probes", arg[tags == 105].mean())
+print("cache hit fraction of probes", arg[tags == 105].mean() if (tags == 105).any() else None)
