@@ -550,9 +550,32 @@ struct azmi_net {
   size_t blob_bytes = 0;
   int device = 0;
   size_t lds_bytes = 0;
+  // row-list evaluation of the whole-batch kernels (spatial / fp32): the listed rows are gathered into a compact batch,
+  // evaluated, and scattered back (azmi_net_forward_rows)
+  float *g_canon = nullptr, *g_v = nullptr, *g_pi = nullptr;
+  uint32_t g_rows = 0;
 };
 
 namespace {
+// compact[i] = canon[rows[i]] for i < *count, zeros behind (those rows are evaluated and dropped)
+__global__ void k_gather_rows(const float* __restrict__ canon, const uint32_t* __restrict__ rows, const uint32_t* __restrict__ count,
+                              uint32_t max_rows, uint32_t chw, float* __restrict__ compact) {
+  const uint32_t i = blockIdx.x;
+  if (i >= max_rows) return;
+  const bool on = i < *count;
+  const float* src = canon + static_cast<size_t>(on ? rows[i] : 0u) * chw;
+  float* dst = compact + static_cast<size_t>(i) * chw;
+  for (uint32_t e = threadIdx.x; e < chw; e += blockDim.x) dst[e] = on ? src[e] : 0.0f;
+}
+// v[rows[i]] = v_c[i], pi[rows[i]] = pi_c[i] for i < *count: rows that are not listed are left untouched
+__global__ void k_scatter_rows(const float* __restrict__ v_c, const float* __restrict__ pi_c, const uint32_t* __restrict__ rows,
+                               const uint32_t* __restrict__ count, uint32_t p1, uint32_t m, float* __restrict__ v, float* __restrict__ pi) {
+  const uint32_t i = blockIdx.x;
+  if (i >= *count) return;
+  const uint32_t r = rows[i];
+  for (uint32_t e = threadIdx.x; e < p1; e += blockDim.x) v[static_cast<size_t>(r) * p1 + e] = v_c[static_cast<size_t>(i) * p1 + e];
+  for (uint32_t e = threadIdx.x; e < m; e += blockDim.x) pi[static_cast<size_t>(r) * m + e] = pi_c[static_cast<size_t>(i) * m + e];
+}
 bool is_spatial(const azmi_net_desc* d) { return d->policy_channels > 0; }
 size_t stem_passes(const azmi_net_desc* d) { return (9 * static_cast<size_t>(d->in_channels) + 63) / 64; }
 size_t spatial_blob_bytes(const azmi_net_desc* d) {
@@ -700,10 +723,19 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
 
 void azmi_net_destroy(azmi_net* net) {
   if (!net) return;
-  if (net->f32) { azmi_f32::destroy(net->f32); delete net; return; }
+  if (net->f32) {
+    (void)hipSetDevice(net->device);
+    if (net->g_canon) (void)hipFree(net->g_canon);
+    if (net->g_v) (void)hipFree(net->g_v);
+    if (net->g_pi) (void)hipFree(net->g_pi);
+    azmi_f32::destroy(net->f32); delete net; return;
+  }
   (void)hipSetDevice(net->device);
   (void)hipFree(net->blob);
   if (net->vpool) (void)hipFree(net->vpool);
+  if (net->g_canon) (void)hipFree(net->g_canon);
+  if (net->g_v) (void)hipFree(net->g_v);
+  if (net->g_pi) (void)hipFree(net->g_pi);
   delete net;
 }
 
@@ -744,8 +776,32 @@ int azmi_net_forward_rows(azmi_net* net, const float* dev_canonical, float* dev_
                           const uint32_t* dev_row_count, uint32_t max_rows, void* stream) {
   if (!net || !dev_canonical || !dev_v || !dev_pi || !dev_rows || !dev_row_count) return nfail(AZMI_ERR_INVALID, "null argument");
   if (max_rows == 0) return AZMI_OK;
-  if (net->f32 || net->spatial)   // those paths evaluate the whole slot-indexed batch (rows not listed keep valid rows too)
-    return azmi_net_forward(net, dev_canonical, dev_v, dev_pi, max_rows, stream);
+  if (net->f32 || net->spatial) {
+    // these kernels take a dense batch: gather the listed rows, evaluate, scatter the answers back.  Rows that are not
+    // listed are NOT touched (another model group's answers, cache hits already delivered: ADVICE r1, play_manager.cc:577-597)
+    uint32_t chw, p1, m;
+    if (net->f32) azmi_f32::dims(net->f32, &chw, &p1, &m);
+    else { chw = net->sd.C_in * net->sd.H * net->sd.W; p1 = net->sd.num_players + 1; m = net->sd.num_moves; }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (max_rows > net->g_rows) {      // grows on first use / larger engines only (synchronous, outside the steady state)
+      (void)hipSetDevice(net->device);
+      (void)hipDeviceSynchronize();
+      if (net->g_canon) (void)hipFree(net->g_canon); if (net->g_v) (void)hipFree(net->g_v); if (net->g_pi) (void)hipFree(net->g_pi);
+      net->g_canon = net->g_v = net->g_pi = nullptr; net->g_rows = 0;
+      if (hipMalloc(reinterpret_cast<void**>(&net->g_canon), static_cast<size_t>(max_rows) * chw * 4) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void**>(&net->g_v), static_cast<size_t>(max_rows) * p1 * 4) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void**>(&net->g_pi), static_cast<size_t>(max_rows) * m * 4) != hipSuccess)
+        return nfail(AZMI_ERR_OOM, "hipMalloc(row-list staging) failed");
+      net->g_rows = max_rows;
+    }
+    k_gather_rows<<<max_rows, 256, 0, st>>>(dev_canonical, dev_rows, dev_row_count, max_rows, chw, net->g_canon);
+    const int rc = azmi_net_forward(net, net->g_canon, net->g_v, net->g_pi, max_rows, stream);
+    if (rc != AZMI_OK) return rc;
+    k_scatter_rows<<<max_rows, 64, 0, st>>>(net->g_v, net->g_pi, dev_rows, dev_row_count, p1, m, dev_v, dev_pi);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return nfail(AZMI_ERR_NO_DEVICE, "row-list gather/scatter launch: %s", hipGetErrorString(e));
+    return AZMI_OK;
+  }
   const uint32_t tiles = (max_rows + c4::TBW - 1) / c4::TBW;
   c4::k_leafnet_c4<4, 4, 16><<<tiles, c4::NTH, net->lds_bytes, static_cast<hipStream_t>(stream)>>>(net->nd, net->np, dev_canonical, dev_v, dev_pi, max_rows, dev_rows, dev_row_count);
   const hipError_t e = hipGetLastError();

@@ -43,6 +43,20 @@ class C4:  # the static surface NNArch reads from a game class
     def NUM_MOVES(): return 7
 
 
+PEAKED = "--peaked" in sys.argv   # scale the last layer of both heads: a random-init net is nearly uniform (pi in [0.10, 0.19]),
+                                   # which no tolerance test can tell from a constant; the scaled nets spread over the simplex
+
+
+def _peak(net):
+    """x8 on the output layers' weights (the reference NNArch stays the producer of the expected outputs)"""
+    with torch.no_grad():
+        net.v_fc2.weight.mul_(8.0)
+        if hasattr(net, "pi_fc1"):
+            net.pi_fc1.weight.mul_(8.0)
+        else:
+            net.pi_bn2.weight.mul_(8.0)
+
+
 def main():
     args = ref_nn.NNArgs(num_channels=64, depth=6, kernel_size=3, dense_net=False, head_channels=32)
     torch.manual_seed(0)
@@ -54,6 +68,8 @@ def main():
             m.running_var.copy_(torch.rand(m.num_features, generator=g) * 1.0 + 0.5)
             m.weight.data.copy_(torch.rand(m.num_features, generator=g) * 0.8 + 0.6)
             m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    if PEAKED:
+        _peak(net)
     net.eval()
     rng = np.random.default_rng(3)
     xs = []
@@ -71,7 +87,7 @@ def main():
     out = {"input": x.numpy(), "v": v.numpy(), "pi": pi.numpy()}
     for k, t in net.state_dict().items():
         out["sd." + k] = t.numpy()
-    path = os.path.join(HERE, "nn_connect4_6b64c.npz")
+    path = os.path.join(HERE, "nn_connect4_6b64c_peaked.npz" if PEAKED else "nn_connect4_6b64c.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes;", sum(p.numel() for p in net.parameters()), "params")
     # the package's own LeafNet must accept this state_dict and reproduce the reference bit for bit
@@ -109,6 +125,8 @@ def main_tawlbwrdd():
             m.running_var.copy_(torch.rand(m.num_features, generator=g) * 1.0 + 0.5)
             m.weight.data.copy_(torch.rand(m.num_features, generator=g) * 0.8 + 0.6)
             m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    if PEAKED:
+        _peak(net)
     net.eval()
     rng = np.random.default_rng(4)
     xs = []
@@ -126,7 +144,7 @@ def main_tawlbwrdd():
     out = {"input": x.numpy(), "v": v.numpy(), "pi": pi.numpy()}
     for k, t in net.state_dict().items():
         out["sd." + k] = t.numpy()
-    path = os.path.join(HERE, "nn_tawlbwrdd_4b64c.npz")
+    path = os.path.join(HERE, "nn_tawlbwrdd_4b64c_peaked.npz" if PEAKED else "nn_tawlbwrdd_4b64c.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes;", sum(p.numel() for p in net.parameters()), "params")
     sys.modules.pop("alphazero", None)
@@ -197,5 +215,5 @@ def main_brandubh():
                   "brandubh_spec", 16, "nn_brandubh_4b32c.npz")
 
 if __name__ == "__main__":
-    mode = sys.argv[1] if len(sys.argv) > 1 else "connect4"
+    mode = next((a for a in sys.argv[1:] if not a.startswith("--")), "connect4")
     {"connect4": main, "tawlbwrdd": main_tawlbwrdd, "opentafl": main_opentafl, "brandubh": main_brandubh}[mode]()
