@@ -92,8 +92,10 @@ class PlayParams:
         self.seat_resign_threshold = []
         self.seat_resign_consecutive = []
 
-    # fields the device engine does not implement yet: anything but the default is an error
-    _UNSUPPORTED = ("temp_decay_half_life_by_variant",)    # indexed by get_variant_id(): no device game has variants
+    # fields the device engine does not implement yet: anything but the default is an error.
+    # (temp_decay_half_life_by_variant is NOT one of them: play_manager.cc:289-296 applies entry get_variant_id() only when
+    # that id is >= 0, and every device game answers -1 (game_state.h:79), so the reference itself ignores the list there.)
+    _UNSUPPORTED = ()
 
     def _to_c(self, num_players):
         c = _capi.PlayParamsC()
@@ -425,33 +427,6 @@ def _c4_from_bytes(data):
 _ENGINE_STREAM = C.c_void_p(-1)  # AZMI_STREAM_ENGINE
 
 
-class TawlbwrddGS(GameState):  # py_wrapper.cc:549-560
-    GAME_ID = 1
-
-    def __init__(self, max_turns=400):
-        super().__init__()
-        if max_turns != 400:
-            raise RuntimeError("the MI355X engine implements Tawlbwrdd with the default max_turns = 400")
-
-    @staticmethod
-    def NUM_SYMMETRIES():
-        return 8
-
-    @staticmethod
-    def POLICY_SHAPE():
-        return (22, 11, 11)
-
-    def __str__(self):           # tawlbwrdd_gs.cc:460-484
-        st = self._state()
-        c = st["canonical"][0]
-        rep = 3 if (c[5, 0, 0] and c[6, 0, 0] and st["turn"][0] > 0) else 2 if c[6, 0, 0] else 1 if c[5, 0, 0] else 0
-        out = "Current Player: %d\nCurrent Turn: %d out of 400\nCurrent Repetition Count: %d\n" % (st["player"][0], st["turn"][0], rep)
-        for h in range(11):
-            out += "".join("@" if c[0, h, w] == 1 else "O" if c[1, h, w] == 1 else "X" if c[2, h, w] == 1 else "."
-                           for w in range(11)) + "\n"
-        return out + "\n"
-
-
 class MCTS:
     """The stand-alone search tree (py_wrapper.cc:192-220, mcts.h:50-200) on the device: find_leaf / process_result /
     update_root and the read-outs, call by call; pass game=<GS class> for anything but Connect4.  `seed` seeds the object's pcg32 stream (the
@@ -612,7 +587,8 @@ def playout_eval_batch(states, seeds=None):
         rows = [g._init if g._init is not None else blank for g in states]
         if any(r is None for r in rows):
             raise RuntimeError("playout_eval_batch: this game has no serialized start position")
-        init = np.frombuffer(b"".join(rows), np.uint8)
+        stride = max(len(r) for r in rows)
+        init = np.frombuffer(b"".join(r + bytes(stride - len(r)) for r in rows), np.uint8)
     v = np.zeros((n, P + 1), np.float32); pi = np.zeros((n, M), np.float32)
     check(lib.azmi_playout_eval(cls.GAME_ID, states[0]._device, None if init is None else init.ctypes.data,
                                 0 if init is None else init.size // n, mv.ctypes.data, n, length, seeds.ctypes.data,
@@ -627,8 +603,11 @@ def playout_eval(gs, seed=None):
 
 
 class _TaflBoardGS(GameState):
-    """Brandubh / OpenTafl objects: optional start position as the reference's board tensor
-    (int8 [3, N, N] = king, defenders, attackers) with an empty repetition map."""
+    """Tafl-family objects.  A start position other than the game's own is the REFERENCE's pickle image
+    (tawlbwrdd_gs.cc:10-37, brandubh_gs.cc:11-41, opentafl_gs.cc:13-40):
+        board int8[3][N][N] (king, defenders, attackers) | u16 turn | u16 max_turns | i8 player | u8 current_repetition_count |
+        u32 n | n x (board | u8 player | u8 count)                       (little endian)
+    so a state pickled by the reference loads here and the other way round, repetition map included."""
     BOARD = 0
     MAX_TURNS = 0
     _REPLAY_FLAGS = 1          # play_move like the reference: no ownership / slide check (valid_moves is the validator)
@@ -639,13 +618,89 @@ class _TaflBoardGS(GameState):
             raise RuntimeError(f"the MI355X engine implements {type(self).__name__} with the default max_turns = {self.MAX_TURNS}")
 
     @classmethod
-    def from_board(cls, board, player, turn=0):
+    def _image(cls, board, player, turn, rep_count=1, entries=()):
         b = np.ascontiguousarray(board, dtype=np.int8)
         if b.shape != (3, cls.BOARD, cls.BOARD):
             raise RuntimeError("Improper tafl board shape")
+        out = [b.tobytes(), np.uint16(turn).tobytes(), np.uint16(cls.MAX_TURNS).tobytes(), np.int8(player).tobytes(),
+               np.uint8(rep_count).tobytes(), np.uint32(len(entries)).tobytes()]
+        for eb, ep, ec in entries:
+            out += [eb, np.uint8(ep).tobytes(), np.uint8(ec).tobytes()]
+        return b"".join(out)
+
+    @classmethod
+    def from_board(cls, board, player, turn=0):
+        """the C++ test helper MakeGS (opentafl_gs_test.cc:97-101): a board with an empty repetition map, count 1"""
         g = cls()
-        g._init = b.tobytes() + np.int8(player).tobytes() + np.int32(turn).tobytes()
+        g._init = cls._image(board, player, turn)
         return g
+
+    @classmethod
+    def from_bytes(cls, data):
+        data = bytes(data)
+        bb = 3 * cls.BOARD * cls.BOARD
+        if len(data) < bb + 10:
+            raise RuntimeError(f"{cls.__name__}::from_bytes: data too short")
+        n = int(np.frombuffer(data[bb + 6: bb + 10], np.uint32)[0])
+        if bb + 10 + n * (bb + 2) != len(data):
+            raise RuntimeError(f"{cls.__name__}::from_bytes: repetition entry count mismatch")
+        if int(np.frombuffer(data[bb + 2: bb + 4], np.uint16)[0]) != cls.MAX_TURNS:
+            raise RuntimeError(f"the MI355X engine implements {cls.__name__} with the default max_turns = {cls.MAX_TURNS}")
+        g = cls()
+        g._init = data
+        return g
+
+    def to_bytes(self):
+        """The reference's to_bytes image of the current position.  The repetition map holds boards, the device keeps
+        64-bit keys, so the boards are read back by replaying every prefix of the game record (one batched device call)
+        and applying the reference's bookkeeping: the start position is interned by the first move of a game, a capture
+        clears the map, every move counts the position it reaches (tawlbwrdd_gs.cc:253-259, 286-331)."""
+        if not self._moves and self._init is not None:
+            return self._init
+        P, M, chw = self._info()
+        L = len(self._moves)
+        mv = np.full((L + 1, L + 1), -1, np.int32)
+        for i in range(L + 1):
+            mv[i, :i] = self._moves[:i]
+        canon = np.zeros((L + 1,) + tuple(chw), np.float32)
+        player = np.zeros(L + 1, np.uint32); turn = np.zeros(L + 1, np.uint32); status = np.zeros(L + 1, np.int32)
+        init = None if self._init is None else np.frombuffer(self._init * (L + 1), np.uint8)
+        check(lib.azmi_game_replay_ex(self.GAME_ID, self._device, None if init is None else init.ctypes.data,
+                                      0 if init is None else len(self._init), mv.ctypes.data, L + 1, L + 1,
+                                      None, None, canon.ctypes.data, player.ctypes.data, turn.ctypes.data, None, status.ctypes.data,
+                                      self._REPLAY_FLAGS))
+        if status.any():
+            raise RuntimeError("illegal move in the game record")
+        boards = (canon[:, :3] != 0).astype(np.int8)
+        pieces = boards.reshape(L + 1, -1).sum(1)
+        bb = 3 * self.BOARD * self.BOARD
+        reps = []                                   # (board bytes, player) in insertion order, with multiplicity
+        rep_count = 1
+        if self._init is not None:
+            rep_count = self._init[bb + 5]
+            n = int(np.frombuffer(self._init[bb + 6: bb + 10], np.uint32)[0])
+            for e in range(n):
+                o = bb + 10 + e * (bb + 2)
+                reps += [(self._init[o: o + bb], self._init[o + bb])] * self._init[o + bb + 1]
+        for i in range(1, L + 1):
+            if turn[i - 1] == 0:
+                reps = [(boards[i - 1].tobytes(), int(player[i - 1]))]
+            if pieces[i] < pieces[i - 1]:
+                reps = []
+            key = (boards[i].tobytes(), int(player[i]))
+            reps.append(key)
+            rep_count = reps.count(key)
+        entries, seen = [], {}
+        for key in reps:
+            if key in seen:
+                entries[seen[key]][2] += 1
+            else:
+                seen[key] = len(entries)
+                entries.append([key[0], key[1], 1])
+        return self._image(boards[L], int(player[L]), int(turn[L]), rep_count, entries)
+
+    def __reduce__(self):        # ADD_GS_PICKLE, py_wrapper.cc:77-83
+        return (_tafl_from_bytes, (type(self).__name__, self.to_bytes()))
 
     @staticmethod
     def NUM_SYMMETRIES():
@@ -655,6 +710,11 @@ class _TaflBoardGS(GameState):
     def POLICY_SHAPE(cls):
         return (2 * cls.BOARD, cls.BOARD, cls.BOARD)
 
+    def _rep_count(self):
+        st = self._state()
+        c = st["canonical"][0]
+        return 3 if (c[5, 0, 0] and c[6, 0, 0] and st["turn"][0] > 0) else 2 if c[6, 0, 0] else 1 if c[5, 0, 0] else 0
+
     def __str__(self):           # brandubh_gs.cc:547-581 / opentafl_gs.cc:589-623 without the colour escapes
         st = self._state()
         c = st["canonical"][0]
@@ -662,6 +722,26 @@ class _TaflBoardGS(GameState):
         for h in range(self.BOARD):
             out += "".join("@" if c[0, h, w] == 1 else "O" if c[1, h, w] == 1 else "X" if c[2, h, w] == 1 else "."
                            for w in range(self.BOARD)) + "\n"
+        return out + "\n"
+
+
+def _tafl_from_bytes(name, data):
+    return {"TawlbwrddGS": TawlbwrddGS, "BrandubhGS": BrandubhGS, "OpenTaflGS": OpenTaflGS}[name].from_bytes(data)
+
+
+class TawlbwrddGS(_TaflBoardGS):  # py_wrapper.cc:549-560
+    GAME_ID = 1
+    BOARD = 11
+    MAX_TURNS = 400
+    _REPLAY_FLAGS = 0
+
+    def __str__(self):           # tawlbwrdd_gs.cc:460-484
+        st = self._state()
+        c = st["canonical"][0]
+        out = "Current Player: %d\nCurrent Turn: %d out of 400\nCurrent Repetition Count: %d\n" % (st["player"][0], st["turn"][0], self._rep_count())
+        for h in range(11):
+            out += "".join("@" if c[0, h, w] == 1 else "O" if c[1, h, w] == 1 else "X" if c[2, h, w] == 1 else "."
+                           for w in range(11)) + "\n"
         return out + "\n"
 
 

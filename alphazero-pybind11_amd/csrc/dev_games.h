@@ -487,4 +487,53 @@ struct TaflX {
 using Brandubh = TaflX<0>;
 using OpenTafl = TaflX<1>;
 
+
+// ---- the reference's pickle image of a Tafl-family position (tawlbwrdd_gs.cc:10-37, brandubh_gs.cc:11-41, opentafl_gs.cc:13-40):
+//   board int8[3][N][N] (king, defenders, attackers) | u16 turn | u16 max_turns | i8 player | u8 current_repetition_count |
+//   u32 n | n x (board int8[3][N][N] | u8 player | u8 count)          (little endian)
+// The repetition map travels with the position; on the device it becomes the list of 64-bit (board, player) keys the
+// rules already use, every entry repeated `count` times.
+template <class GM>
+struct TaflImage {
+  static constexpr uint32_t BB = 3u * GM::SQ, HEADER = BB + 6u, ENTRY = BB + 2u;
+  __host__ __device__ static uint32_t bytes(uint32_t entries) { return HEADER + 4u + entries * ENTRY; }
+};
+template <class GM>
+__host__ __device__ __forceinline__ typename GM::State tafl_board_state(const uint8_t* b, uint32_t player, uint32_t turn) {
+  typename GM::State s{};
+  s.king = GM::kNoKing;
+  for (uint32_t sq = 0; sq < static_cast<uint32_t>(GM::SQ); ++sq) {
+    if (b[sq]) s.king = sq;
+    if (b[GM::SQ + sq]) { if (sq < 64) s.def[0] |= 1ULL << sq; else s.def[1] |= 1ULL << (sq - 64); }
+    if (b[2 * GM::SQ + sq]) { if (sq < 64) s.atk[0] |= 1ULL << sq; else s.atk[1] |= 1ULL << (sq - 64); }
+  }
+  s.turn = turn; s.player = player & 1u; s.rep = 1;
+  return s;
+}
+// parses an image of at most `row_bytes` bytes: the position into `s`, the repetition keys into reps[0 .. nrep).
+// false: malformed (size mismatch, another max_turns than the device game's, more keys than `cap`)
+template <class GM>
+__host__ __device__ inline bool tafl_parse_image(const uint8_t* row, uint32_t row_bytes, typename GM::State& s, uint64_t* reps,
+                                                 uint32_t& nrep, uint32_t cap) {
+  using I = TaflImage<GM>;
+  nrep = 0;
+  if (row_bytes < I::bytes(0)) return false;
+  const uint8_t* h = row + I::BB;
+  const uint32_t turn = uint32_t(h[0]) | uint32_t(h[1]) << 8, max_turns = uint32_t(h[2]) | uint32_t(h[3]) << 8;
+  if (max_turns != static_cast<uint32_t>(GM::MAX_TURNS)) return false;
+  s = tafl_board_state<GM>(row, h[4], turn);
+  s.rep = h[5];
+  const uint32_t n = uint32_t(h[6]) | uint32_t(h[7]) << 8 | uint32_t(h[8]) << 16 | uint32_t(h[9]) << 24;
+  if (n > 4096u || I::bytes(n) > row_bytes) return false;
+  const uint8_t* e = row + I::bytes(0);
+  for (uint32_t i = 0; i < n; ++i, e += I::ENTRY) {
+    const uint64_t k = GM::rep_key(tafl_board_state<GM>(e, e[I::BB], 0));
+    for (uint32_t c = 0; c < e[I::BB + 1]; ++c) {
+      if (nrep >= cap) return false;
+      reps[nrep++] = k;
+    }
+  }
+  return true;
+}
+
 }  // namespace azmi

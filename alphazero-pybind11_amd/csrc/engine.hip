@@ -292,16 +292,13 @@ __global__ void k_playout(const uint8_t* init, const int32_t* moves, uint32_t n,
 }
 
 // Tafl-family replay: one thread per game, repetition list in a global scratch row per game
+// start position of game g: the game's initial position, or the reference pickle image in row g of `init` (dev_games.h
+// TaflImage) with its repetition keys; false = malformed image
 template <class GM>
-__device__ typename GM::State tafl_start(const uint8_t* init, uint32_t stride, uint32_t g) {
-  if constexpr (GM::kGameId == Tawlbwrdd::kGameId) {
-    return GM::initial();
-  } else {
-    if (!init) return GM::initial();
-    const uint8_t* b = init + static_cast<size_t>(g) * stride;
-    const uint8_t* t = b + 3 * GM::SQ + 1;
-    return GM::from_board(b, b[3 * GM::SQ], uint32_t(t[0]) | uint32_t(t[1]) << 8 | uint32_t(t[2]) << 16 | uint32_t(t[3]) << 24);
-  }
+__device__ bool tafl_start(const uint8_t* init, uint32_t stride, uint32_t g, typename GM::State& s, uint64_t* reps, uint32_t& nrep, uint32_t cap) {
+  nrep = 0;
+  if (!init) { s = GM::initial(); return true; }
+  return tafl_parse_image<GM>(init + static_cast<size_t>(g) * stride, stride, s, reps, nrep, cap);
 }
 template <class GM>
 __global__ void k_replay_tafl(const uint8_t* init, uint32_t init_stride, const int32_t* moves, uint32_t n, uint32_t len,
@@ -310,13 +307,14 @@ __global__ void k_replay_tafl(const uint8_t* init, uint32_t init_stride, const i
                               uint64_t* key, int32_t* status, uint32_t flags) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
-  typename GM::State s = tafl_start<GM>(init, init_stride, g);
   const bool unchecked = (flags & 1u) && GM::kGameId != Tawlbwrdd::kGameId;
   constexpr uint32_t SPAN = GM::W + GM::H;
   uint64_t* reps = rep_scratch + static_cast<size_t>(g) * rep_stride;
   uint32_t nrep = 0;
-  int32_t stt = 0;
-  for (uint32_t i = 0; i < len; ++i) {
+  typename GM::State s;
+  int32_t stt = tafl_start<GM>(init, init_stride, g, s, reps, nrep, rep_stride) ? 0 : -1;
+  if (stt != 0) s = GM::initial();
+  for (uint32_t i = 0; i < len && stt == 0; ++i) {
     const int32_t mv = moves[static_cast<size_t>(g) * len + i];
     if (mv < 0) break;
     bool legal = mv < GM::M;
@@ -367,10 +365,11 @@ __global__ void k_playout_tafl(const uint8_t* init, uint32_t init_stride, const 
                                uint64_t* rep_scratch, uint32_t rep_stride, const uint64_t* seeds, float* v, float* pi, int32_t* status) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
-  typename GM::State s = tafl_start<GM>(init, init_stride, g);
   constexpr uint32_t SPAN = GM::W + GM::H;
   uint64_t* reps = rep_scratch + static_cast<size_t>(g) * rep_stride;
   uint32_t nrep = 0;
+  typename GM::State s;
+  if (!tafl_start<GM>(init, init_stride, g, s, reps, nrep, rep_stride)) { if (status) status[g] = -1; return; }
   auto step = [&](uint32_t mv, bool unchecked) -> bool {     // one move with the reference's repetition bookkeeping
     typename GM::State before = s;
     bool cap = false, ok;
@@ -1418,16 +1417,39 @@ int azmi_game_replay_from(int game, int device, const uint8_t* init, uint32_t in
   return azmi_game_replay_ex(game, device, init, init_stride, moves, n, len, valid, scores, canonical, player, turn, key, status, 0u);
 }
 
+namespace {
+// start-position rows: Connect4 = the 89-byte to_bytes image; Tafl family = the reference pickle image (dev_games.h TaflImage),
+// rows zero-padded to a common stride.  *extra_reps = the most repetition keys any row brings along.
+int check_init_rows(int game, const uint8_t* init, uint32_t init_stride, uint32_t n, uint32_t* extra_reps) {
+  *extra_reps = 0;
+  if (!init) return AZMI_OK;
+  if (game == AZMI_GAME_CONNECT4) {
+    if (init_stride != Connect4::SERIALIZED) return fail(AZMI_ERR_INVALID, "start positions: Connect4 images are %u bytes", Connect4::SERIALIZED);
+    return AZMI_OK;
+  }
+  const uint32_t sq = game == AZMI_GAME_BRANDUBH ? Brandubh::SQ : 121u, bb = 3u * sq, header = bb + 6u, entry = bb + 2u;
+  if (init_stride < header + 4u) return fail(AZMI_ERR_INVALID, "start positions: a Tafl image is at least %u bytes, got %u", header + 4u, init_stride);
+  for (uint32_t g = 0; g < n; ++g) {
+    const uint8_t* row = init + static_cast<size_t>(g) * init_stride;
+    const uint8_t* h = row + header;
+    const uint32_t cnt = uint32_t(h[0]) | uint32_t(h[1]) << 8 | uint32_t(h[2]) << 16 | uint32_t(h[3]) << 24;
+    if (cnt > 4096u || header + 4u + static_cast<uint64_t>(cnt) * entry > init_stride)
+      return fail(AZMI_ERR_INVALID, "start position %u: repetition entry count mismatch", g);
+    uint32_t keys = 0;
+    for (uint32_t i = 0; i < cnt; ++i) keys += row[header + 4u + static_cast<size_t>(i) * entry + bb + 1u];
+    *extra_reps = std::max(*extra_reps, keys);
+  }
+  return AZMI_OK;
+}
+}  // namespace
+
 int azmi_playout_eval(int game, int device, const uint8_t* init, uint32_t init_stride, const int32_t* moves, uint32_t n, uint32_t len,
                       const uint64_t* seeds, float* v, float* pi) {
   GameInfo gi;
   if (!game_info(game, &gi)) return fail(AZMI_ERR_INVALID, "unknown game id %d", game);
   if (!seeds || !v || !pi || (!moves && n * len)) return fail(AZMI_ERR_INVALID, "null argument");
-  {
-    const uint32_t want = game == AZMI_GAME_CONNECT4 ? Connect4::SERIALIZED : game == AZMI_GAME_BRANDUBH ? 3u * Brandubh::SQ + 5u
-                        : game == AZMI_GAME_OPENTAFL ? 3u * OpenTafl::SQ + 5u : 0u;
-    if (init && (want == 0 || init_stride != want)) return fail(AZMI_ERR_INVALID, "start positions: %u bytes per state for this game", want);
-  }
+  uint32_t extra_reps = 0;
+  { const int rc_init = check_init_rows(game, init, init_stride, n, &extra_reps); if (rc_init != AZMI_OK) return rc_init; }
   if (n == 0) return AZMI_OK;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(AZMI_ERR_NO_DEVICE, "no HIP device: libazmi has no CPU path");
@@ -1452,7 +1474,7 @@ int azmi_playout_eval(int game, int device, const uint8_t* init, uint32_t init_s
     k_playout<Connect4><<<(n + 63) / 64, 64>>>(d_init, d_moves, n, len, d_seeds, d_v, d_pi, d_status);
   } else {
     uint64_t* d_rep = nullptr;
-    const uint32_t stride = len + gi.max_turns + 4;
+    const uint32_t stride = len + gi.max_turns + 4 + extra_reps;
     TRY3(dalloc(d_rep, static_cast<size_t>(n) * stride));
     if (game == AZMI_GAME_TAWLBWRDD) k_playout_tafl<Tawlbwrdd><<<(n + 63) / 64, 64>>>(d_init, init_stride, d_moves, n, len, d_rep, stride, d_seeds, d_v, d_pi, d_status);
     else if (game == AZMI_GAME_BRANDUBH) k_playout_tafl<Brandubh><<<(n + 63) / 64, 64>>>(d_init, init_stride, d_moves, n, len, d_rep, stride, d_seeds, d_v, d_pi, d_status);
@@ -1476,12 +1498,8 @@ int azmi_game_replay_ex(int game, int device, const uint8_t* init, uint32_t init
   GameInfo gi;
   if (!game_info(game, &gi)) return fail(AZMI_ERR_INVALID, "unknown game id %d", game);
   if (!moves && n * len) return fail(AZMI_ERR_INVALID, "null moves");
-  if (init) {
-    const uint32_t want = game == AZMI_GAME_CONNECT4 ? Connect4::SERIALIZED : game == AZMI_GAME_BRANDUBH ? 3u * Brandubh::SQ + 5u
-                        : game == AZMI_GAME_OPENTAFL ? 3u * OpenTafl::SQ + 5u : 0u;
-    if (want == 0 || init_stride != want)
-      return fail(AZMI_ERR_INVALID, "start positions: Connect4 (89 bytes), Brandubh (152) and OpenTafl (368) only; got stride %u for game %d", init_stride, game);
-  }
+  uint32_t extra_reps = 0;
+  { const int rc_init = check_init_rows(game, init, init_stride, n, &extra_reps); if (rc_init != AZMI_OK) return rc_init; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(AZMI_ERR_NO_DEVICE, "no HIP device: libazmi has no CPU path");
   HIP_TRY(hipSetDevice(device));
@@ -1515,7 +1533,7 @@ int azmi_game_replay_ex(int game, int device, const uint8_t* init, uint32_t init
       case AZMI_GAME_BRANDUBH:
       case AZMI_GAME_OPENTAFL: {
         uint64_t* d_rep = nullptr;
-        const uint32_t stride = len + 2;
+        const uint32_t stride = len + 2 + extra_reps;
         TRY2(dalloc(reinterpret_cast<void**>(&d_rep), static_cast<size_t>(n) * stride * 8));
         if (game == AZMI_GAME_TAWLBWRDD)
           k_replay_tafl<Tawlbwrdd><<<(n + 63) / 64, 64>>>(d_init, init_stride, d_moves, n, len, d_rep, stride, d_valid, d_scores, d_canon, d_player, d_turn, d_key, d_status, flags);
@@ -1548,9 +1566,17 @@ struct azmi_mcts {
   uint8_t* d_init = nullptr; int32_t* d_moves = nullptr; int32_t* d_out_moves = nullptr;
   uint32_t* d_len = nullptr; int32_t* d_status = nullptr; float* d_f = nullptr; uint32_t* d_u = nullptr;
   uint32_t moves_cap = 0, vec = 0;
+  uint32_t init_bytes = 0;               // size of the image in d_init (0 = the game's initial position)
   WuArrays wu{};                         // Node::n_in_flight + MCTS::in_flight_ (mcts.h:24,171)
   uint32_t ifl_count = 0, ifl_cap = 0;
 };
+
+namespace {
+// capacity of the start-position buffer: Connect4's 89 bytes; a Tafl pickle image with up to 512 repetition entries
+uint32_t mcts_init_bytes(int game) {
+  return game == AZMI_GAME_CONNECT4 ? Connect4::SERIALIZED : game == AZMI_GAME_BRANDUBH ? TaflImage<Brandubh>::bytes(512) : TaflImage<OpenTafl>::bytes(512);
+}
+}  // namespace
 
 int azmi_mcts_create(int game, const azmi_mcts_config* cfg, uint64_t seed, int device, azmi_mcts** out) {
   if (!cfg || !out) return fail(AZMI_ERR_INVALID, "null argument");
@@ -1588,7 +1614,7 @@ int azmi_mcts_create(int game, const azmi_mcts_config* cfg, uint64_t seed, int d
   m->moves_cap = gi.max_turns + 8;
   m->vec = std::max<uint32_t>(gi.M, 64u);
   auto A = [&](auto*& ptr, size_t n) { return m->pm->alloc(ptr, n, true); };
-  rc = A(m->d_init, 1024); if (rc == AZMI_OK) rc = A(m->d_moves, m->moves_cap); if (rc == AZMI_OK) rc = A(m->d_out_moves, m->moves_cap);
+  rc = A(m->d_init, mcts_init_bytes(game)); if (rc == AZMI_OK) rc = A(m->d_moves, m->moves_cap); if (rc == AZMI_OK) rc = A(m->d_out_moves, m->moves_cap);
   if (rc == AZMI_OK) rc = A(m->d_len, 1); if (rc == AZMI_OK) rc = A(m->d_status, 1);
   if (rc == AZMI_OK) rc = A(m->d_f, m->vec); if (rc == AZMI_OK) rc = A(m->d_u, m->vec + 64);
   m->ifl_cap = 1024;
@@ -1607,14 +1633,15 @@ void azmi_mcts_destroy(azmi_mcts* m) {
 }
 
 namespace {
-uint32_t mcts_init_bytes(int game) {
-  return game == AZMI_GAME_CONNECT4 ? Connect4::SERIALIZED : game == AZMI_GAME_BRANDUBH ? 3u * Brandubh::SQ + 5u
-       : game == AZMI_GAME_OPENTAFL ? 3u * OpenTafl::SQ + 5u : 0u;
-}
 int mcts_upload_state(azmi_mcts* m, const uint8_t* init, uint32_t init_bytes, const int32_t* moves, uint32_t len, hipStream_t st) {
   if (len > m->moves_cap) return fail(AZMI_ERR_INVALID, "game record too long");
-  if (init && (mcts_init_bytes(m->pm->game) == 0 || init_bytes != mcts_init_bytes(m->pm->game)))
-    return fail(AZMI_ERR_INVALID, "start position: %u bytes expected for this game", mcts_init_bytes(m->pm->game));
+  if (init) {
+    uint32_t extra = 0;
+    const int rc = check_init_rows(m->pm->game, init, init_bytes, 1, &extra);
+    if (rc != AZMI_OK) return rc;
+    if (init_bytes > mcts_init_bytes(m->pm->game)) return fail(AZMI_ERR_INVALID, "start position: image too large (%u bytes)", init_bytes);
+  }
+  m->init_bytes = init ? init_bytes : 0;
   if (init) HIP_TRY(hipMemcpyAsync(m->d_init, init, init_bytes, hipMemcpyHostToDevice, st));
   if (len) HIP_TRY(hipMemcpyAsync(m->d_moves, moves, static_cast<size_t>(len) * 4, hipMemcpyHostToDevice, st));
   return AZMI_OK;

@@ -278,17 +278,14 @@ namespace azmi {
 
 template <class GM>
 __device__ __forceinline__ bool mcts_big_replay(BigSlot<GM>& c, const uint8_t* init, uint32_t init_stride, const int32_t* moves, uint32_t len) {
-  if constexpr (GM::kGameId == Tawlbwrdd::kGameId) {
-    c.gs = GM::initial();
-  } else {
-    if (init) {
-      const uint8_t* t = init + 3 * GM::SQ + 1;
-      c.gs = GM::from_board(init, init[3 * GM::SQ], uint32_t(t[0]) | uint32_t(t[1]) << 8 | uint32_t(t[2]) << 16 | uint32_t(t[3]) << 24);
-    } else {
-      c.gs = GM::initial();
-    }
-  }
   c.glen = 0;
+  if (init) {       // the reference pickle image (dev_games.h TaflImage): position + repetition keys
+    uint32_t n = 0;
+    if (!tafl_parse_image<GM>(init, init_stride, c.gs, c.sm.glist, n, static_cast<uint32_t>(GM::MAX_TURNS))) return false;
+    c.glen = n;
+  } else {
+    c.gs = GM::initial();
+  }
   constexpr uint32_t SPAN = GM::W + GM::H;
   for (uint32_t i = 0; i < len; ++i) {
     const int32_t mv = moves[i];

@@ -201,3 +201,116 @@ def test_reference_connect4_gs_cases(az):
     assert np.array_equal(np.asarray(x.canonicalized()), e)
     x.play_move(0); e = np.zeros((4, 6, 7), np.float32); e[0, 5, 0] = 1; e[1, 4, 0] = 1; e[2] = 1
     assert np.array_equal(np.asarray(x.canonicalized()), e)
+
+
+# ---- the Tafl pickle BYTE LAYOUT (tawlbwrdd_gs.cc:10-37, brandubh_gs.cc:11-41, opentafl_gs.cc:13-40) -----------------
+import struct
+
+
+def _parse_tafl_image(data, N):
+    bb = 3 * N * N
+    board = np.frombuffer(data[:bb], np.int8).reshape(3, N, N)
+    turn, max_turns, player, rep, n = struct.unpack_from("<HHbBI", data, bb)
+    assert len(data) == bb + 10 + n * (bb + 2)
+    entries = []
+    for e in range(n):
+        o = bb + 10 + e * (bb + 2)
+        entries.append((data[o: o + bb], data[o + bb], data[o + bb + 1]))
+    return board, turn, max_turns, player, rep, entries
+
+
+@pytest.mark.parametrize("name,N,max_turns", [("TawlbwrddGS", 11, 400), ("BrandubhGS", 7, 150), ("OpenTaflGS", 11, 400)])
+def test_tafl_to_bytes_is_the_reference_image(az, name, N, max_turns):
+    G = getattr(az, name)
+    g = G()
+    img = g.to_bytes()                          # initial position: header only, repetition count 1, empty map
+    board, turn, mt, player, rep, entries = _parse_tafl_image(img, N)
+    assert (turn, mt, player, rep, entries) == (0, max_turns, 0, 1, [])
+    assert np.array_equal(board, (g.canonicalized()[:3] != 0).astype(np.int8)) and board[0].sum() == 1
+    # a quiet shuffle: attacker out and back, defender out and back -> the start position again, and again
+    def first_move_of(gs, to_back=None):
+        return int(np.flatnonzero(gs.valid_moves())[0])
+    seq = []
+    a1 = first_move_of(g); g.play_move(a1); seq.append(a1)
+    d1 = first_move_of(g); g.play_move(d1); seq.append(d1)
+    pieces = lambda gs: (gs.canonicalized()[:3] != 0).sum()
+    assert pieces(g) == pieces(G())                                        # no capture so far
+    board, turn, mt, player, rep, entries = _parse_tafl_image(g.to_bytes(), N)
+    assert (turn, player, rep) == (2, 0, 1)
+    # the map: the start position (interned by the first move) and the two positions reached, one each
+    assert len(entries) == 3 and [e[2] for e in entries] == [1, 1, 1] and [e[1] for e in entries] == [0, 1, 0]
+    assert entries[0][0] == (G().canonicalized()[:3] != 0).astype(np.int8).tobytes()
+    assert entries[2][0] == board.tobytes()
+    # round trip through the image keeps the bytes and the object
+    back = G.from_bytes(g.to_bytes())
+    assert back.to_bytes() == g.to_bytes() and back == g
+    assert pickle.loads(pickle.dumps(g)).to_bytes() == g.to_bytes()
+
+
+@pytest.mark.parametrize("name,N", [("BrandubhGS", 7), ("TawlbwrddGS", 11)])
+def test_a_reference_image_with_a_repetition_map_loads_and_counts_on(az, name, N):
+    """an image as the reference would have written it mid-game (hand-built per the layout): the repetition map travels, so
+    re-reaching a recorded position raises its count, and the third occurrence ends the game exactly as for the object
+    that played the whole record itself (tawlbwrdd_gs.cc:350-364)."""
+    G = getattr(az, name)
+    g = G()
+    # a move pair that can be undone: piece from a to b, later b to a (a rook slide along an open line is reversible)
+    def reverse(m):                        # move index = (h*N + w) * 2N + (column move ? N + new_h : new_w)
+        frm, tgt = divmod(m, 2 * N)
+        h, w = divmod(frm, N)
+        nh, nw = (tgt - N, w) if tgt >= N else (h, tgt)
+        return (nh * N + nw) * 2 * N + (N + h if nw == w else w)
+    pieces = lambda gs: int((gs.canonicalized()[:3] != 0).sum())
+    cycle = None
+    for m1 in np.flatnonzero(g.valid_moves())[:12]:
+        a = g.copy(); a.play_move(int(m1))
+        for m2 in np.flatnonzero(a.valid_moves())[:12]:
+            b = a.copy(); b.play_move(int(m2))
+            if pieces(b) != pieces(g) or not b.valid_moves()[reverse(int(m1))]:
+                continue
+            c = b.copy(); c.play_move(reverse(int(m1)))
+            if pieces(c) == pieces(g) and c.valid_moves()[reverse(int(m2))]:
+                d = c.copy(); d.play_move(reverse(int(m2)))
+                if pieces(d) == pieces(g) and np.array_equal(d.canonicalized()[:3], g.canonicalized()[:3]):
+                    cycle = [int(m1), int(m2), reverse(int(m1)), reverse(int(m2))]
+                    break
+        if cycle:
+            break
+    assert cycle is not None
+    for m in cycle:
+        assert g.valid_moves()[m] == 1
+        g.play_move(m)
+    board, turn, mt, player, rep, entries = _parse_tafl_image(g.to_bytes(), N)
+    assert turn == 4 and rep == 2 and g.scores() is None        # the start position for the second time
+    assert sorted(e[2] for e in entries) == [1, 1, 1, 2]
+    # hand-build the same image and load it
+    img = board.tobytes() + struct.pack("<HHbBI", 4, mt, 0, 2, len(entries)) + b"".join(e[0] + bytes([e[1], e[2]]) for e in entries)
+    assert img == g.to_bytes()
+    h = G.from_bytes(img)
+    assert h == g and np.array_equal(h.canonicalized(), g.canonicalized())
+    for m in cycle:                                             # once more round: third occurrence
+        g.play_move(m); h.play_move(m)
+        assert np.array_equal(h.canonicalized(), g.canonicalized()) and h.current_turn() == g.current_turn()
+    sg, sh = g.scores(), h.scores()
+    assert sg is not None and np.array_equal(sg, sh) and np.asarray(sg).tolist() == [1.0, 0.0, 0.0]   # side to move wins
+    assert h.to_bytes() == g.to_bytes()
+    # a capture clears the map (tawlbwrdd_gs.cc:286-318): entry lists never outlive it -> covered by the random-play round trips
+    with pytest.raises(RuntimeError, match="data too short"):
+        G.from_bytes(img[: 3 * N * N + 4])
+    with pytest.raises(RuntimeError, match="repetition entry count mismatch"):
+        G.from_bytes(img[:-1])
+
+
+def test_tafl_images_feed_the_search_and_the_rollouts(az):
+    """a position loaded from an image is a first-class start position: MCTS.find_leaf and playout_eval accept it"""
+    G = az.BrandubhGS
+    g = G()
+    for _ in range(6):
+        g.play_move(int(np.flatnonzero(g.valid_moves())[0]))
+    h = G.from_bytes(g.to_bytes())
+    v1, p1 = az.playout_eval(g, seed=7)
+    v2, p2 = az.playout_eval(h, seed=7)
+    assert np.array_equal(v1, v2) and np.array_equal(p1, p2)
+    t = az.MCTS(1.25, 2, G.NUM_MOVES(), game=G, seed=3)
+    leaf = t.find_leaf(h)
+    assert leaf.current_turn() >= h.current_turn()
