@@ -88,6 +88,9 @@ struct SlotCtx {
   static constexpr int G = GM::GROUP;
   static constexpr int P = GM::P;
   static constexpr int M = GM::M;
+  // process_result's first-visit value, make_move's resign entries and the per-seat AZMI_SEL selects are written for two
+  // players (every device game); an N-player game needs val[player] there
+  static_assert(GM::P == 2, "the lane-group engine is written for two-player games");
   static_assert(GM::MAXK <= G, "single-chunk child handling needs MAXK <= GROUP");
   static_assert(GM::M <= G, "lane-dense move vectors need M <= GROUP");
 

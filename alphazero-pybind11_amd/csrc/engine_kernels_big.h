@@ -35,6 +35,7 @@ struct BigScratch {  // per-wave LDS
 #define AZB_SEL(arr, seat) ((seat) == 0 ? arr[0] : arr[P > 1 ? 1 : 0])
 template <class GM>
 struct BigSlot {
+  static_assert(GM::P == 2, "the wide-game engine is written for two-player games (first-visit value, resign entries)");
   static constexpr int G = 64, P = GM::P, M = GM::M, MAXK = GM::MAXK;
   const EngineParams& ep;
   const EngineArrays& ar;

@@ -35,6 +35,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -540,20 +542,38 @@ struct azmi_net {
   NetDesc nd{};
   NetPtrs np{};
   void* f32 = nullptr;       // precision = 1: the fp32 path (leafnet_f32.hip) owns everything
+  void* f32_last_stream = nullptr;
+  bool f32_last_stream_set = false;
   bool spatial = false;      // spatial policy head (Tafl family): k_leafnet_spatial + k_value_fc
   SpatialDesc sd{};
   SpatialPtrs sp{};
-  float* vpool = nullptr;    // [vpool_rows][64] pooled value-head features between the two kernels
-  uint32_t vpool_rows = 0;
+  // Scratch between the kernels of one forward: PER STREAM - engines on different streams share one net object and run
+  // their forwards concurrently (round 1 kept one buffer per net: the value heads of concurrent shards read each other's
+  // pooled features)
+  struct StreamScratch {
+    float* vpool = nullptr;    // [vpool_rows][64] pooled value-head features between k_leafnet_spatial and k_value_fc
+    uint32_t vpool_rows = 0;
+    float *g_canon = nullptr, *g_v = nullptr, *g_pi = nullptr;   // row-list evaluation of the whole-batch kernels (azmi_net_forward_rows)
+    uint32_t g_rows = 0;
+  };
+  std::mutex scratch_mu;
+  std::map<void*, StreamScratch> scratch;
+  StreamScratch& scratch_of(void* stream) { std::lock_guard<std::mutex> l(scratch_mu); return scratch[stream]; }
+  void free_scratch() {
+    for (auto& kv : scratch) {
+      StreamScratch& sc = kv.second;
+      if (sc.vpool) (void)hipFree(sc.vpool);
+      if (sc.g_canon) (void)hipFree(sc.g_canon);
+      if (sc.g_v) (void)hipFree(sc.g_v);
+      if (sc.g_pi) (void)hipFree(sc.g_pi);
+    }
+    scratch.clear();
+  }
   size_t vfc_lds = 0;
   void* blob = nullptr;
   size_t blob_bytes = 0;
   int device = 0;
   size_t lds_bytes = 0;
-  // row-list evaluation of the whole-batch kernels (spatial / fp32): the listed rows are gathered into a compact batch,
-  // evaluated, and scattered back (azmi_net_forward_rows)
-  float *g_canon = nullptr, *g_v = nullptr, *g_pi = nullptr;
-  uint32_t g_rows = 0;
 };
 
 namespace {
@@ -665,12 +685,6 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
     };
     static_assert(2 * 2 * MT * WFRAG_BYTES <= 16384, "two stem passes of weights sit in front of the input staging");
     net->vfc_lds = (2 * Hd * 16 + VFC_WAVES * 256) * sizeof(float);
-    // scratch for 16384 positions up front: forward() may run under stream capture, where hipMalloc is not allowed
-    net->vpool_rows = 16384;
-    if (hipMalloc(reinterpret_cast<void**>(&net->vpool), static_cast<size_t>(net->vpool_rows) * 64 * sizeof(float)) != hipSuccess) {
-      (void)hipFree(net->blob); delete net;
-      return nfail(AZMI_ERR_OOM, "hipMalloc(value-head scratch) failed");
-    }
     const bool reserved = b11 ? reserve(Geo<11, 11, TBS11>{}, reinterpret_cast<const void*>(&k_leafnet_spatial<11, 11, TBS11>))
                               : reserve(Geo<7, 7, TBS7>{}, reinterpret_cast<const void*>(&k_leafnet_spatial<7, 7, TBS7>));
     if (!reserved || hipFuncSetAttribute(reinterpret_cast<const void*>(&k_value_fc), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -725,17 +739,12 @@ void azmi_net_destroy(azmi_net* net) {
   if (!net) return;
   if (net->f32) {
     (void)hipSetDevice(net->device);
-    if (net->g_canon) (void)hipFree(net->g_canon);
-    if (net->g_v) (void)hipFree(net->g_v);
-    if (net->g_pi) (void)hipFree(net->g_pi);
+    net->free_scratch();
     azmi_f32::destroy(net->f32); delete net; return;
   }
   (void)hipSetDevice(net->device);
   (void)hipFree(net->blob);
-  if (net->vpool) (void)hipFree(net->vpool);
-  if (net->g_canon) (void)hipFree(net->g_canon);
-  if (net->g_v) (void)hipFree(net->g_v);
-  if (net->g_pi) (void)hipFree(net->g_pi);
+  net->free_scratch();
   delete net;
 }
 
@@ -743,24 +752,30 @@ int azmi_net_forward(azmi_net* net, const float* dev_canonical, float* dev_v, fl
   if (!net || !dev_canonical || !dev_v || !dev_pi) return nfail(AZMI_ERR_INVALID, "null argument");
   if (batch == 0) return AZMI_OK;
   if (net->f32) {
+    // the fp32 path keeps ONE set of activation buffers per net: a forward on another stream first waits for the previous
+    // one (a correctness path, not a throughput path)
+    if (net->f32_last_stream_set && net->f32_last_stream != stream) (void)hipStreamSynchronize(static_cast<hipStream_t>(net->f32_last_stream));
+    net->f32_last_stream = stream; net->f32_last_stream_set = true;
     const char* msg = "";
     const int rc = azmi_f32::forward(net->f32, dev_canonical, dev_v, dev_pi, batch, stream, &msg);
     return rc == AZMI_OK ? rc : nfail(rc, "%s", msg);
   }
   if (net->spatial) {
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (batch > net->vpool_rows) {   // grows on first use / larger batches only (synchronous, outside steady state)
+    azmi_net::StreamScratch& sc = net->scratch_of(stream);
+    if (batch > sc.vpool_rows) {   // first use of this stream / a larger batch only (synchronous, outside the steady state and outside stream capture)
       (void)hipSetDevice(net->device);
-      if (net->vpool) { (void)hipDeviceSynchronize(); (void)hipFree(net->vpool); net->vpool = nullptr; net->vpool_rows = 0; }
-      if (hipMalloc(reinterpret_cast<void**>(&net->vpool), static_cast<size_t>(batch) * 64 * sizeof(float)) != hipSuccess)
+      if (sc.vpool) { (void)hipDeviceSynchronize(); (void)hipFree(sc.vpool); sc.vpool = nullptr; sc.vpool_rows = 0; }
+      const uint32_t want = batch < 4096u ? 4096u : batch;
+      if (hipMalloc(reinterpret_cast<void**>(&sc.vpool), static_cast<size_t>(want) * 64 * sizeof(float)) != hipSuccess)
         return nfail(AZMI_ERR_OOM, "hipMalloc(value-head scratch) failed");
-      net->vpool_rows = batch;
+      sc.vpool_rows = want;
     }
     if (net->sd.H == 11)
-      k_leafnet_spatial<11, 11, TBS11><<<(batch + TBS11 - 1) / TBS11, NTHREADS, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, net->vpool, dev_pi, batch);
+      k_leafnet_spatial<11, 11, TBS11><<<(batch + TBS11 - 1) / TBS11, NTHREADS, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, sc.vpool, dev_pi, batch);
     else
-      k_leafnet_spatial<7, 7, TBS7><<<(batch + TBS7 - 1) / TBS7, NTHREADS, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, net->vpool, dev_pi, batch);
-    k_value_fc<<<(batch + 15) / 16, VFC_THREADS, net->vfc_lds, st>>>(net->sd, net->sp, net->vpool, dev_v, batch);
+      k_leafnet_spatial<7, 7, TBS7><<<(batch + TBS7 - 1) / TBS7, NTHREADS, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, sc.vpool, dev_pi, batch);
+    k_value_fc<<<(batch + 15) / 16, VFC_THREADS, net->vfc_lds, st>>>(net->sd, net->sp, sc.vpool, dev_v, batch);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return nfail(AZMI_ERR_NO_DEVICE, "k_leafnet_spatial launch: %s", hipGetErrorString(e));
     return AZMI_OK;
@@ -783,21 +798,22 @@ int azmi_net_forward_rows(azmi_net* net, const float* dev_canonical, float* dev_
     if (net->f32) azmi_f32::dims(net->f32, &chw, &p1, &m);
     else { chw = net->sd.C_in * net->sd.H * net->sd.W; p1 = net->sd.num_players + 1; m = net->sd.num_moves; }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (max_rows > net->g_rows) {      // grows on first use / larger engines only (synchronous, outside the steady state)
+    azmi_net::StreamScratch& sc = net->scratch_of(stream);
+    if (max_rows > sc.g_rows) {      // first use of this stream / a larger engine only (synchronous, outside the steady state)
       (void)hipSetDevice(net->device);
       (void)hipDeviceSynchronize();
-      if (net->g_canon) (void)hipFree(net->g_canon); if (net->g_v) (void)hipFree(net->g_v); if (net->g_pi) (void)hipFree(net->g_pi);
-      net->g_canon = net->g_v = net->g_pi = nullptr; net->g_rows = 0;
-      if (hipMalloc(reinterpret_cast<void**>(&net->g_canon), static_cast<size_t>(max_rows) * chw * 4) != hipSuccess ||
-          hipMalloc(reinterpret_cast<void**>(&net->g_v), static_cast<size_t>(max_rows) * p1 * 4) != hipSuccess ||
-          hipMalloc(reinterpret_cast<void**>(&net->g_pi), static_cast<size_t>(max_rows) * m * 4) != hipSuccess)
+      if (sc.g_canon) (void)hipFree(sc.g_canon); if (sc.g_v) (void)hipFree(sc.g_v); if (sc.g_pi) (void)hipFree(sc.g_pi);
+      sc.g_canon = sc.g_v = sc.g_pi = nullptr; sc.g_rows = 0;
+      if (hipMalloc(reinterpret_cast<void**>(&sc.g_canon), static_cast<size_t>(max_rows) * chw * 4) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void**>(&sc.g_v), static_cast<size_t>(max_rows) * p1 * 4) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void**>(&sc.g_pi), static_cast<size_t>(max_rows) * m * 4) != hipSuccess)
         return nfail(AZMI_ERR_OOM, "hipMalloc(row-list staging) failed");
-      net->g_rows = max_rows;
+      sc.g_rows = max_rows;
     }
-    k_gather_rows<<<max_rows, 256, 0, st>>>(dev_canonical, dev_rows, dev_row_count, max_rows, chw, net->g_canon);
-    const int rc = azmi_net_forward(net, net->g_canon, net->g_v, net->g_pi, max_rows, stream);
+    k_gather_rows<<<max_rows, 256, 0, st>>>(dev_canonical, dev_rows, dev_row_count, max_rows, chw, sc.g_canon);
+    const int rc = azmi_net_forward(net, sc.g_canon, sc.g_v, sc.g_pi, max_rows, stream);
     if (rc != AZMI_OK) return rc;
-    k_scatter_rows<<<max_rows, 64, 0, st>>>(net->g_v, net->g_pi, dev_rows, dev_row_count, p1, m, dev_v, dev_pi);
+    k_scatter_rows<<<max_rows, 64, 0, st>>>(sc.g_v, sc.g_pi, dev_rows, dev_row_count, p1, m, dev_v, dev_pi);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return nfail(AZMI_ERR_NO_DEVICE, "row-list gather/scatter launch: %s", hipGetErrorString(e));
     return AZMI_OK;

@@ -540,27 +540,31 @@ def main():
                               "and share the chip with each other and with the tree kernels, so the whole-GPU rate is aggregate_achieved = "
                               "FLOPs of all launches of the region / wall time of the region (rank 0's GPU)",
             }
-            if not tafl:
+            if True:
                 # the second kernel of the path, the tree step (HBM side): algorithmic bytes per simulation from SURVEY §8d
-                # (select + backup + expand + state + canonical + eval rows = 1.3 KB with the measured depth 3.5 / 6.8 children)
+                # (select + backup + expand + state + canonical + eval rows: Connect4 1.3 KB with the measured depth 3.5 / 6.8
+                # children; Tawlbwrdd 18 KB with depth 1.7 / 113 children, dominated by the dense pi[2662] row)
                 sims_rank = n_sims / world
-                tree_launch = (B_SIM * sims_rank / launches) / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
+                b_sim = 18000.0 if tafl else B_SIM
+                tree_launch = (b_sim * sims_rank / launches) / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
                 out["roofline_tree"] = {
-                    "kernel": "k_cache_insert + k_round<Connect4> (one shard-round)", "bound": "hbm", "achieved": tree_launch, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "kernel": ("k_round_big<Tawlbwrdd> + k_compact (one shard-round)" if tafl else "k_cache_insert + k_sim<Connect4> (one shard-round; the move step rides in the net launch)"),
+                    "bound": "hbm", "achieved": tree_launch, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": tree_launch / HBM_PEAK_GBS, "traffic": None, "per_launch_event_ms": tree_ms,
-                    "aggregate_achieved": B_SIM * sims_rank / dt / 1e9, "aggregate_frac": B_SIM * sims_rank / dt / 1e9 / HBM_PEAK_GBS,
+                    "aggregate_achieved": b_sim * sims_rank / dt / 1e9, "aggregate_frac": b_sim * sims_rank / dt / 1e9 / HBM_PEAK_GBS,
+                    "bytes_per_simulation": b_sim,
                     "note": "latency-bound, not bandwidth-bound: one simulation is a chain of dependent memory round trips; "
                             "the figure to watch is the per-launch time (profiles/)"}
             # HBM-side traffic of the dominant kernel: not measurable from inside the process; taken from the committed
             # rocprofv3 --pmc summary of this same command (scripts/gpu_pmc.sh -> profiles/rN_pmc_traffic.csv), per launch,
             # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on gfx950
-            pmc = next((p for p in (os.path.join(ROOT, "profiles", f"r{n}_pmc_traffic.csv") for n in (2, 1)) if os.path.exists(p)), None)
-            if not tafl and hip_net is not None and pmc:
+            pmc = next((p for p in (os.path.join(ROOT, "profiles", f"r{n}_pmc_traffic{'_tawlbwrdd' if tafl else ''}.csv") for n in (2, 1)) if os.path.exists(p)), None)
+            if hip_net is not None and pmc:
                 for line in open(pmc):
                     f = line.strip().split(",")
-                    if "k_round<azmi::Connect4" in line or line.startswith("k_sim"):
+                    if ("k_round_big" in line) if tafl else ("k_sim<" in line or "k_round<azmi::Connect4" in line):
                         out["roofline_tree"]["traffic"] = (2.0 * float(f[-2]) + float(f[-1])) * 1024.0
-                    if line.startswith("k_leafnet"):
+                    if "k_leafnet" in line or "k_net_move" in line:
                         out["roofline"]["traffic"] = (2.0 * float(f[-2]) + float(f[-1])) * 1024.0
                         out["roofline"]["traffic_note"] = ("bytes per k_leafnet launch at the L2-to-fabric counters (2 x FETCH_SIZE + WRITE_SIZE, "
                                                            + os.path.relpath(pmc, ROOT) + ")")

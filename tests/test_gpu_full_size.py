@@ -194,3 +194,76 @@ def test_full_size_benchmark_flags_sampled_slots_equal_the_oracle(oracle, playou
         sel = rows[:, 0] == s
         assert np.array_equal(rows[sel][:, 1:], orows[:, 1:]), s
         assert np.array_equal(counts[sel], ocounts), s
+
+
+def test_full_size_tawlbwrdd_with_the_net_plays_every_game_to_the_end(oracle):
+    """BASELINE configs[2] at full size AND full length with the net in the loop: Tawlbwrdd, 2048 concurrent games, 400
+    simulations per move, the configs/tawlbwrdd.yaml net on the spatial MFMA kernels, four engine shards as the bench runs
+    them.  Size-independent properties over all games, and one sampled slot replayed by the oracle with the same net as
+    its evaluator (tier T3): move for move, count for count."""
+    import torch
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.tawlbwrdd_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=0), spec)
+    K, Se, sims, seed = 4, 512, 400, 20240601
+    pms, streams = [], []
+    for k in range(K):
+        pp = az.PlayParams()
+        pp.games_to_play, pp.concurrent_games, pp.max_batch_size = Se, Se, Se
+        pp.mcts_visits = [sims, sims]
+        pp.model_groups = [0, 0]
+        pp.cpuct, pp.fpu_reduction = 1.25, 0.25
+        pp.epsilon, pp.mcts_root_temp, pp.root_fpu_zero, pp.shaped_dirichlet = 0.25, 1.25, True, True
+        pp.start_temp, pp.final_temp, pp.temp_decay_half_life = 1.0, 0.2, 10.0
+        pp.history_enabled = True
+        pms.append(az.PlayManager(az.TawlbwrddGS(), pp, seed=seed + 104729 * k, log_moves=True))
+        streams.append(torch.cuda.Stream())
+    sps = [s.cuda_stream for s in streams]
+    live = list(range(K))
+    rounds = 0
+    while live:
+        az.run_rounds([pms[i] for i in live], hip, 512, [sps[i] for i in live])
+        rounds += 512
+        live = [i for i in live if pms[i].poll(sps[i])[1] > 0]
+        assert rounds < 400_000
+    torch.cuda.synchronize()
+    total_rows = 0
+    for k, pm in enumerate(pms):
+        assert pm.games_completed() == Se and pm.scores().sum() == Se
+        rows, counts = pm.move_log()
+        assert np.array_equal(np.unique(rows[:, 0]), np.arange(Se))
+        assert (counts.sum(1) >= sims - 1).all()                                  # every move after a full search
+        assert (counts[np.arange(len(rows)), rows[:, 2]] > 0).all()               # the played move had visits
+        lens = np.bincount(rows[:, 0], minlength=Se)
+        assert lens.min() >= 4 and lens.max() <= 400 and abs(pm.avg_game_length() - lens.mean()) < 1e-3
+        c = pm.counters()
+        assert c["evals"] > 0.9 * c["sims"] * 0.5 and c["evals"] <= c["sims"]    # Tafl leaves are rarely terminal
+        n = pm.hist_count()
+        assert n == len(rows)
+        total_rows += n
+    # history rows of one shard: distributions over legal moves, one-hot outcomes
+    pm = pms[1]
+    n = pm.hist_count()
+    canon = np.zeros((n, 7, 11, 11), np.float32); v = np.zeros((n, 3), np.float32); pi = np.zeros((n, 2662), np.float32)
+    assert pm.build_history_batch(canon, v, pi) == n
+    assert np.abs(pi.sum(1) - 1).max() < 1e-4 and (pi >= 0).all()
+    assert (v.sum(1) == 1).all() and np.isin(v, (0.0, 1.0)).all()
+    assert (canon[:, 0].reshape(n, -1).sum(1) <= 1).all()                          # at most one king
+    # one slot of shard 2 against the oracle driven by the same net
+    dev = torch.device("cuda", 0)
+
+    def evaluator(c):
+        vv, pp_ = hip.process(torch.from_numpy(np.ascontiguousarray(c)).to(dev))
+        torch.cuda.synchronize()
+        return vv.cpu().numpy(), pp_.cpu().numpy()
+    k, s = 2, 137
+    rows, counts = pms[k].move_log()
+    one = az.PlayParams(); one.__dict__.update(pms[k]._params.__dict__)
+    one.games_to_play, one.concurrent_games, one.max_batch_size = 1, 1, 1
+    o = oracle.PlayManager(oracle.GAME_TAWLBWRDD, one, oracle.slot_seed(seed + 104729 * k, s), per_slot_rng=False)
+    o.run(evaluator)
+    orows, ocounts = o.moves()
+    sel = rows[:, 0] == s
+    assert sel.sum() == len(orows)
+    assert np.array_equal(rows[sel][:, 1:], orows[:, 1:]) and np.array_equal(counts[sel], ocounts)
