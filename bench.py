@@ -67,6 +67,8 @@ def parse(argv=None):
     ap.add_argument("--no-secondary", action="store_true", help="skip the two short secondary measurements reported in config")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall time of the CPU-baseline sample")
     ap.add_argument("--preroll-factor", type=float, default=2.0, help="pre-roll until this many x concurrent_games games have finished")
+    ap.add_argument("--profile-window", action="store_true",
+                    help="for rocprofv3 runs: a short window is allowed (no validity gate); the line is marked profile_window and its value is not the metric")
     ap.add_argument("--dry", action="store_true",
                     help="CPU dry run of the launch / distributed plumbing (gloo, no device, a stand-in engine): used by the tests")
     return ap.parse_args(argv)
@@ -471,7 +473,9 @@ def main():
     dt = float(tmax.item())
     n_games, n_sims, n_evals, n_hits, n_miss, n_rows, dead = (float(x) for x in cnt.tolist())
     failure = None
-    if dead > 0:
+    if args.profile_window:
+        pass
+    elif dead > 0:
         failure = f"a game stream ran dry inside the timed region ({int(dead)} slots idle)"
     elif min_rank_games < S:
         failure = (f"only {int(min_rank_games)} games finished inside the window on some rank (< {S} concurrent games): "
@@ -503,6 +507,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
+            **({"profile_window": True} if args.profile_window else {}),
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "bf16",
@@ -532,7 +537,7 @@ def main():
             out["roofline"] = {
                 "bound": "mfma", "achieved": per_launch, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": per_launch / MFMA_PEAK_TFLOPS, "traffic": None,
-                "kernel": "%s: %.0f positions (avg) x %.1f MFLOP per launch, %d overlapping launches per round" % ("k_leafnet_spatial" if tafl else "k_leafnet", rows_evaluated / launches, flop_per_eval / 1e6, K),
+                "kernel": "%s: %.0f positions (avg) x %.1f MFLOP per launch, %d overlapping launches per round" % ("k_leafnet_spatial + k_value_fc" if tafl else "k_net_move (the leaf-net tiles of k_leafnet_c4 + the round's move step in one launch)", rows_evaluated / launches, flop_per_eval / 1e6, K),
                 "per_launch_event_ms": nn_ms,
                 "aggregate_achieved": achieved, "aggregate_frac": achieved / MFMA_PEAK_TFLOPS,
                 "definition": "achieved = algorithmic FLOPs of ONE launch (positions it evaluated x FLOP per position) / its average duration, "
