@@ -13,6 +13,8 @@
 
 namespace orc {
 
+struct Pcg32;   // az_rng.hpp
+
 constexpr int kMaxValue = 5;  // num_players + 1 <= 5
 
 // game_state.h:55-139 — the subset the search path touches.
@@ -31,6 +33,9 @@ struct Game {
   virtual void canonicalized(float* out) const = 0;
   virtual bool relative_values() const { return false; }
   virtual void randomize_start() {}
+  // randomize_start() for games whose start is random (StarGambitUnified's variant): the reference draws from an
+  // unseedable thread_local engine, here the draw comes from the slot's coin stream (build-defined)
+  virtual void randomize_start_from(Pcg32&) { randomize_start(); }
   virtual int num_variants() const { return 0; }
   virtual int get_variant_id() const { return -1; }
   // Build-defined deterministic 64-bit position key over exactly the fields

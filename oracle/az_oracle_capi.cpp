@@ -10,6 +10,7 @@
 #include "az_mcts.hpp"
 #include "az_playmanager.hpp"
 #include "az_rng.hpp"
+#include "az_stargambit.hpp"
 #include "az_symmetries.hpp"
 #include "az_tafl.hpp"
 #include "az_tafl_family.hpp"
@@ -23,6 +24,7 @@ std::unique_ptr<Game> make_game(int game_id) {
     case 1: return std::make_unique<Tawlbwrdd>();
     case 2: return std::make_unique<Brandubh>();
     case 3: return std::make_unique<OpenTafl>();
+    case 4: { const float p[4] = {0.25f, 0.25f, 0.25f, 0.25f}; return std::make_unique<StarGambitUnified>(-1, p, 0); }
     default: throw std::runtime_error("unknown game id");
   }
 }
@@ -90,6 +92,65 @@ void* orc_tafl_from_board(int game_id, const int8_t* board, int8_t player, uint3
     }
   } catch (...) { return nullptr; }
 }
+// StarGambitUnifiedGS(pinned_variant, probs) (py_wrapper.cc:662-667); `first_variant` is the variant the constructor's own
+// draw would have produced (the reference draws it from an unseedable engine; a pinned game ignores it)
+void* orc_sg_unified_new(int pinned, const float* probs, int first_variant) {
+  const int v = (pinned >= 0 && pinned <= 3) ? pinned : first_variant;
+  if (v < 0 || v > 3) return nullptr;
+  return new StarGambitUnified(pinned, probs, v);
+}
+// StarGambit{Skirmish,Showdown,Clash,Battle}GS in their own action space (star_gambit_gs.h:752-755)
+void* orc_sg_plain_new(int variant) { return (variant < 0 || variant > 3) ? nullptr : new StarGambit(variant); }
+static sg::Inner* sg_inner(void* g) {
+  if (auto* u = dynamic_cast<StarGambitUnified*>(static_cast<Game*>(g))) return &u->in;
+  if (auto* p = dynamic_cast<StarGambit*>(static_cast<Game*>(g))) return &p->in;
+  return nullptr;
+}
+// get_units (star_gambit_gs.cc, UnitInfo): rows of 9 int32 = type, player, slot, hp, facing, q, r, moves_left, cannons_fired
+// (dead units included, in creation order); returns the count
+uint32_t orc_sg_units(void* g, int32_t* out, uint32_t cap) {
+  sg::Inner* in = sg_inner(g);
+  if (!in) return 0;
+  uint32_t n = 0;
+  for (const auto& u : in->units) {
+    if (n >= cap) break;
+    int32_t* r = out + 9 * n++;
+    r[0] = u.type; r[1] = u.player; r[2] = u.slot; r[3] = u.hp; r[4] = u.facing; r[5] = u.q; r[6] = u.r; r[7] = u.moves_left; r[8] = u.cannons_fired;
+  }
+  return n;
+}
+// out[0..12] = reserves[2][4], acted, over, winner, history length, variant (-1 for the plain games)
+void orc_sg_info(void* g, int32_t* out) {
+  sg::Inner* in = sg_inner(g);
+  if (!in) return;
+  for (int p = 0; p < 2; ++p) for (int t = 0; t < 4; ++t) out[p * 4 + t] = in->reserves[p][t];
+  out[8] = in->acted; out[9] = in->over; out[10] = in->winner; out[11] = static_cast<int32_t>(in->history.size());
+  out[12] = static_cast<Game*>(g)->get_variant_id();
+}
+// to_bytes image (star_gambit_gs.cc:2253-2288 / 2451-2465); returns the size, writes at most cap bytes
+uint32_t orc_sg_to_bytes(void* g, uint8_t* out, uint32_t cap) {
+  std::string b;
+  if (auto* u = dynamic_cast<StarGambitUnified*>(static_cast<Game*>(g))) b = u->to_bytes();
+  else if (auto* p = dynamic_cast<StarGambit*>(static_cast<Game*>(g))) b = p->in.to_bytes();
+  std::memcpy(out, b.data(), std::min<size_t>(cap, b.size()));
+  return static_cast<uint32_t>(b.size());
+}
+// inner from_bytes (star_gambit_gs.cc:2290-2338) into an existing game object; 0 on success
+int orc_sg_from_bytes(void* g, const uint8_t* data, uint32_t n) {
+  sg::Inner* in = sg_inner(g);
+  if (!in) return -1;
+  try { in->from_bytes(std::string(reinterpret_cast<const char*>(data), n)); return 0; } catch (...) { return -1; }
+}
+int orc_game_equal(void* a, void* b) {
+  sg::Inner *x = sg_inner(a), *y = sg_inner(b);
+  if (!x || !y) return -1;
+  if (static_cast<Game*>(a)->get_variant_id() != static_cast<Game*>(b)->get_variant_id()) return 0;
+  return x->same(*y) ? 1 : 0;
+}
+int orc_game_relative_values(void* g) { return static_cast<Game*>(g)->relative_values() ? 1 : 0; }
+int orc_game_variant(void* g) { return static_cast<Game*>(g)->get_variant_id(); }
+int orc_game_num_variants(void* g) { return static_cast<Game*>(g)->num_variants(); }
+
 void* orc_game_copy(void* g) { return static_cast<Game*>(g)->copy().release(); }
 void orc_game_free(void* g) { delete static_cast<Game*>(g); }
 int orc_game_play(void* g, uint32_t m) {
@@ -274,9 +335,20 @@ struct OrcPlayParams {
 typedef void (*orc_group_eval_fn)(uint32_t group, const float* canonical, uint32_t n, float* v, float* pi, void* user);
 typedef void (*orc_eval_fn)(const float* canonical, uint32_t n, float* v, float* pi, void* user);
 
+static void* pm_new_from(std::unique_ptr<Game> base, const OrcPlayParams* c, uint64_t seed, int per_slot_rng, int record_moves,
+                         const float* half_life_by_variant, uint32_t n_half_life);
 void* orc_pm_new(int game_id, const OrcPlayParams* c, uint64_t seed, int per_slot_rng, int record_moves) {
+  try { return pm_new_from(make_game(game_id), c, seed, per_slot_rng, record_moves, nullptr, 0); } catch (...) { return nullptr; }
+}
+// PlayManager over a caller-made base game (copied, play_manager.cc / py_wrapper.cc:352-360) + temp_decay_half_life_by_variant
+void* orc_pm_new_game(void* base_game, const OrcPlayParams* c, uint64_t seed, int per_slot_rng, int record_moves,
+                      const float* half_life_by_variant, uint32_t n_half_life) {
+  try { return pm_new_from(static_cast<Game*>(base_game)->copy(), c, seed, per_slot_rng, record_moves, half_life_by_variant, n_half_life); }
+  catch (...) { return nullptr; }
+}
+static void* pm_new_from(std::unique_ptr<Game> base, const OrcPlayParams* c, uint64_t seed, int per_slot_rng, int record_moves,
+                         const float* half_life_by_variant, uint32_t n_half_life) {
   try {
-    auto base = make_game(game_id);
     const uint32_t P = base->num_players();
     PlayParams p;
     p.games_to_play = c->games_to_play; p.concurrent_games = c->concurrent_games;
@@ -285,6 +357,7 @@ void* orc_pm_new(int game_id, const OrcPlayParams* c, uint64_t seed, int per_slo
     p.mcts_visits.assign(c->mcts_visits, c->mcts_visits + P);
     p.cpuct = c->cpuct; p.start_temp = c->start_temp; p.final_temp = c->final_temp;
     p.temp_decay_half_life = c->temp_decay_half_life;
+    if (half_life_by_variant) p.temp_decay_half_life_by_variant.assign(half_life_by_variant, half_life_by_variant + n_half_life);
     p.history_enabled = c->history_enabled != 0; p.tree_reuse = c->tree_reuse != 0;
     p.epsilon = c->epsilon; p.mcts_root_temp = c->mcts_root_temp;
     p.playout_cap_randomization = c->playout_cap_randomization != 0;
@@ -343,6 +416,19 @@ uint32_t orc_pm_perm_scores(void* h, uint32_t perm, float* out) {
   const auto& sc = pm.perm_scores(perm);
   for (size_t i = 0; i < sc.size(); ++i) out[i] = sc[i];
   return pm.perm_games_completed(perm);
+}
+uint32_t orc_pm_num_variants(void* h) { return static_cast<PmBox*>(h)->pm->num_tracked_variants(); }
+// scores[P+1], perm_scores[perms][P+1], perm_games[perms], stats[7] (variant_avg_* getters); returns variant_games_completed
+uint32_t orc_pm_variant(void* h, uint32_t v, float* scores, float* perm_scores, uint32_t* perm_games, float* stats) {
+  auto& pm = *static_cast<PmBox*>(h)->pm;
+  const auto& vs = pm.variant(v);
+  for (size_t i = 0; i < vs.scores.size(); ++i) scores[i] = vs.scores[i];
+  for (size_t p = 0; p < vs.perm_scores.size(); ++p) {
+    for (size_t i = 0; i < vs.perm_scores[p].size(); ++i) perm_scores[p * vs.scores.size() + i] = vs.perm_scores[p][i];
+    perm_games[p] = vs.perm_games[p];
+  }
+  pm.variant_stats(v, stats);
+  return vs.games;
 }
 void orc_pm_set_time_limit(void* h, double seconds) { static_cast<PmBox*>(h)->pm->time_limit_s = seconds; }
 int orc_pm_run(void* h, orc_eval_fn fn, void* user) {

@@ -48,6 +48,7 @@ struct PlayParams {  // play_manager.h:60-154 (fields the path implements)
   float start_temp = 1.0f;
   float final_temp = 1.0f;
   float temp_decay_half_life = 0;
+  std::vector<float> temp_decay_half_life_by_variant;   // play_manager.h:87-90
   bool history_enabled = false;
   bool self_play = false;
   bool tree_reuse = true;
@@ -124,6 +125,13 @@ class PlayManager {
     }
     perm_scores_.assign(seat_perms_.size(), std::vector<float>(P + 1, 0.0f));
     perm_games_.assign(seat_perms_.size(), 0u);
+    for (int v = 0; v < base_->num_variants(); ++v) {   // play_manager.cc:237-255
+      VariantStats vs;
+      vs.scores.assign(P + 1, 0.0f);
+      vs.perm_scores.assign(seat_perms_.size(), std::vector<float>(P + 1, 0.0f));
+      vs.perm_games.assign(seat_perms_.size(), 0u);
+      variants_.push_back(std::move(vs));
+    }
     awaiting_inference_.resize(num_model_groups_);
     scores_.assign(P + 1, 0.0f);
     resign_scores_.assign(P + 1, 0.0f);
@@ -131,7 +139,7 @@ class PlayManager {
     for (uint32_t i = 0; i < params_.concurrent_games; ++i) {  // play_manager.cc:214-230
       Slot& g = slots_[i];
       g.gs = base_->copy();
-      g.gs->randomize_start();
+      g.gs->randomize_start_from(coin_rng(i));
       g.perm_index = static_cast<uint8_t>((perm_base + i) % seat_perms_.size());   // play_manager.cc:218
       for (uint32_t j = 0; j < P; ++j) g.mcts.push_back(make_mcts(i, g.perm_index, j));
       g.canonical.assign(base_->canonical_size(), 0.0f);
@@ -172,6 +180,30 @@ class PlayManager {
   uint32_t num_seat_perms() const { return static_cast<uint32_t>(seat_perms_.size()); }
   const std::vector<float>& perm_scores(uint32_t i) const { return perm_scores_[i]; }
   uint32_t perm_games_completed(uint32_t i) const { return perm_games_[i]; }
+  // per-variant tables (play_manager.h:218-275, 425-440); the getters' divisions are restated in variant_stats()
+  struct VariantStats {
+    std::vector<float> scores;
+    std::vector<std::vector<float>> perm_scores;
+    std::vector<uint32_t> perm_games;
+    uint32_t games = 0;
+    uint64_t game_length = 0, total_move_count = 0, full_move_count = 0, fast_move_count = 0;
+    double total_avg_leaf_depth = 0, total_search_entropy = 0, fast_total_avg_leaf_depth = 0, fast_total_search_entropy = 0,
+           total_valid_moves = 0;
+  };
+  uint32_t num_tracked_variants() const { return static_cast<uint32_t>(variants_.size()); }
+  const VariantStats& variant(uint32_t v) const { return variants_[v]; }
+  // out[0..6] = variant_avg_game_length, _avg_leaf_depth, _avg_search_entropy, _fast_avg_leaf_depth, _fast_avg_search_entropy,
+  //             _avg_moves_per_turn, _avg_valid_moves
+  void variant_stats(uint32_t v, float* out) const {
+    const VariantStats& m = variants_[v];
+    out[0] = m.games == 0 ? 0 : static_cast<float>(m.game_length) / static_cast<float>(m.games);
+    out[1] = m.full_move_count == 0 ? 0 : static_cast<float>(m.total_avg_leaf_depth / static_cast<double>(m.full_move_count));
+    out[2] = m.full_move_count == 0 ? 0 : static_cast<float>(m.total_search_entropy / static_cast<double>(m.full_move_count));
+    out[3] = m.fast_move_count == 0 ? 0 : static_cast<float>(m.fast_total_avg_leaf_depth / static_cast<double>(m.fast_move_count));
+    out[4] = m.fast_move_count == 0 ? 0 : static_cast<float>(m.fast_total_search_entropy / static_cast<double>(m.fast_move_count));
+    out[5] = m.game_length == 0 ? 0 : static_cast<float>(m.total_move_count) / static_cast<float>(m.game_length);
+    out[6] = m.total_move_count == 0 ? 0 : static_cast<float>(m.total_valid_moves / static_cast<double>(m.total_move_count));
+  }
 
   // ---- stats getters, play_manager.h:173-366 -------------------------------------
   const std::vector<float>& scores() const { return scores_; }
@@ -327,7 +359,12 @@ class PlayManager {
       const uint32_t goal_depth = game.capped ? seat_cap_visits_[game.perm_index][cp] : seat_visits_[game.perm_index][cp];
       if (mcts.depth() >= goal_depth) {
         float temp = params_.start_temp;
-        const float half_life = params_.temp_decay_half_life;
+        float half_life = params_.temp_decay_half_life;
+        if (!params_.temp_decay_half_life_by_variant.empty()) {   // play_manager.cc:290-296
+          const int vid = game.gs->get_variant_id();
+          if (vid >= 0 && vid < static_cast<int>(params_.temp_decay_half_life_by_variant.size()))
+            half_life = params_.temp_decay_half_life_by_variant[vid];
+        }
         if (half_life != 0) {  // play_manager.cc:297-304, ln2 hard-coded as 0.693
           const uint32_t t = game.gs->current_turn();
           constexpr float ln2 = 0.693;
@@ -466,6 +503,19 @@ class PlayManager {
           for (uint32_t k = 0; k <= P; ++k) scores_[k] += scores[k];
           for (uint32_t k = 0; k <= P; ++k) perm_scores_[game.perm_index][k] += scores[k];   // play_manager.cc:466-467
           ++perm_games_[game.perm_index];
+          {   // per-variant tables, play_manager.cc:468-484
+            const int vid = game.gs->get_variant_id();
+            if (vid >= 0 && vid < static_cast<int>(variants_.size())) {
+              VariantStats& vs = variants_[vid];
+              for (uint32_t k = 0; k <= P; ++k) { vs.scores[k] += scores[k]; vs.perm_scores[game.perm_index][k] += scores[k]; }
+              ++vs.games; ++vs.perm_games[game.perm_index];
+              vs.game_length += game.gs->current_turn();
+              vs.total_avg_leaf_depth += game.total_avg_leaf_depth; vs.total_search_entropy += game.total_search_entropy;
+              vs.fast_total_avg_leaf_depth += game.fast_total_avg_leaf_depth; vs.fast_total_search_entropy += game.fast_total_search_entropy;
+              vs.total_valid_moves += game.total_valid_moves;
+              vs.total_move_count += game.move_count; vs.full_move_count += game.full_move_count; vs.fast_move_count += game.fast_move_count;
+            }
+          }
           if (resign_score.has_value())
             for (uint32_t k = 0; k <= P; ++k) resign_scores_[k] += (*resign_score)[k];
           ++games_completed_;
@@ -487,7 +537,7 @@ class PlayManager {
           game.perm_index = static_cast<uint8_t>(games_started_ % seat_perms_.size());   // play_manager.cc:511
           ++games_started_;
           game.gs = base_->copy();
-          game.gs->randomize_start();
+          game.gs->randomize_start_from(coin_rng(i));
           for (uint32_t j = 0; j < P; ++j) game.mcts[j] = make_mcts(i, game.perm_index, j);
         }
         // play_manager.cc:522-555
@@ -561,6 +611,7 @@ class PlayManager {
   PlayParams params_;
   bool per_slot_rng_;
   std::vector<Pcg32> tree_rng_, coin_rng_, roll_rng_;
+  std::vector<VariantStats> variants_;
   std::vector<Slot> slots_;
   std::deque<uint32_t> awaiting_mcts_;
   std::vector<std::deque<uint32_t>> awaiting_inference_;   // one queue per model group

@@ -13,7 +13,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB = os.path.join(ORACLE_DIR, "liboracle.so")
 REF_RNG = os.path.join(ORACLE_DIR, "_ref", "librngref.so")
 
-GAME_CONNECT4, GAME_TAWLBWRDD, GAME_BRANDUBH, GAME_OPENTAFL = 0, 1, 2, 3
+GAME_CONNECT4, GAME_TAWLBWRDD, GAME_BRANDUBH, GAME_OPENTAFL, GAME_STARGAMBIT = 0, 1, 2, 3, 4
 
 
 def build():
@@ -26,7 +26,7 @@ def build():
 build()
 lib = C.CDLL(LIB)
 for name in ("orc_game_new", "orc_c4_from_board", "orc_tafl_from_board", "orc_game_copy", "orc_mcts_new", "orc_mcts_leaf", "orc_pm_new",
-             "orc_cache_new"):
+             "orc_cache_new", "orc_sg_unified_new", "orc_sg_plain_new", "orc_pm_new_game"):
     getattr(lib, name).restype = C.c_void_p
 lib.orc_game_key.restype = C.c_uint64
 lib.orc_pm_hist_count.restype = C.c_uint64
@@ -95,6 +95,50 @@ class Game:
         h = lib.orc_tafl_from_board(C.c_int(game_id), _p(b), C.c_int8(player), C.c_uint32(turn), C.c_uint32(max_turns))
         assert h
         return cls(handle=h)
+
+    @classmethod
+    def sg_unified(cls, pinned=-1, probs=(0.25, 0.25, 0.25, 0.25), first_variant=0):
+        """StarGambitUnifiedGS(pinned_variant, probs) (py_wrapper.cc:662-667); `first_variant` stands for the constructor's own
+        unseedable draw when the game is not pinned."""
+        pr = np.ascontiguousarray(probs, np.float32)
+        h = lib.orc_sg_unified_new(C.c_int(pinned), _p(pr), C.c_int(first_variant))
+        assert h
+        return cls(handle=h)
+
+    @classmethod
+    def sg_plain(cls, variant):
+        """StarGambit{Skirmish,Showdown,Clash,Battle}GS in their own action space."""
+        h = lib.orc_sg_plain_new(C.c_int(variant))
+        assert h
+        return cls(handle=h)
+
+    def sg_units(self):
+        """rows of (type, player, slot, hp, facing, q, r, moves_left, cannons_fired), dead units included"""
+        out = np.zeros((64, 9), np.int32)
+        n = lib.orc_sg_units(self.h, _p(out), C.c_uint32(64))
+        return out[:n].copy()
+
+    def sg_info(self):
+        out = np.zeros(13, np.int32)
+        lib.orc_sg_info(self.h, _p(out))
+        return dict(reserves=out[:8].reshape(2, 4).copy(), acted=int(out[8]), over=int(out[9]), winner=int(out[10]),
+                    history_len=int(out[11]), variant=int(out[12]))
+
+    def sg_to_bytes(self):
+        buf = np.zeros(1 << 16, np.uint8)
+        n = lib.orc_sg_to_bytes(self.h, _p(buf), C.c_uint32(buf.size))
+        return buf[:n].tobytes()
+
+    def sg_from_bytes(self, data):
+        """inner-game from_bytes (star_gambit_gs.cc:2290-2338) into this object"""
+        b = np.frombuffer(bytes(data), np.uint8).copy()
+        if lib.orc_sg_from_bytes(self.h, _p(b), C.c_uint32(b.size)) != 0:
+            raise RuntimeError("StarGambitGS::from_bytes failed")
+
+    def equals(self, other): return lib.orc_game_equal(self.h, other.h) == 1
+    def relative_values(self): return bool(lib.orc_game_relative_values(self.h))
+    def variant(self): return int(lib.orc_game_variant(self.h))
+    def num_variants(self): return int(lib.orc_game_num_variants(self.h))
 
     def __del__(self):
         if getattr(self, "owned", False) and self.h:
@@ -344,12 +388,19 @@ def params_from(pp, num_players):
 
 class PlayManager:
     def __init__(self, game_id, pp, seed, per_slot_rng=True, record_moves=True, num_players=2, perm_base=0):
+        """game_id: one of GAME_*, or an oracle `Game` object used as the base game (copied)."""
         self.c = params_from(pp, num_players)
         self.c.perm_base = int(perm_base)
-        self.h = C.c_void_p(lib.orc_pm_new(game_id, C.byref(self.c), C.c_uint64(seed), int(per_slot_rng), int(record_moves)))
+        if isinstance(game_id, Game):
+            g = game_id
+            hl = np.ascontiguousarray(getattr(pp, "temp_decay_half_life_by_variant", []) or [], np.float32)
+            self.h = C.c_void_p(lib.orc_pm_new_game(g.h, C.byref(self.c), C.c_uint64(seed), int(per_slot_rng), int(record_moves),
+                                                    _p(hl) if hl.size else None, C.c_uint32(hl.size)))
+        else:
+            self.h = C.c_void_p(lib.orc_pm_new(game_id, C.byref(self.c), C.c_uint64(seed), int(per_slot_rng), int(record_moves)))
+            g = Game(game_id)
         if not self.h.value:
             raise RuntimeError("oracle PlayManager construction failed")
-        g = Game(game_id)
         self.P, self.M = g.num_players(), g.num_moves()
         self.chw = g.canonical().shape
 
@@ -407,6 +458,16 @@ class PlayManager:
         out = np.zeros(self.P + 1, np.float32)
         n = lib.orc_pm_perm_scores(self.h, C.c_uint32(perm), _p(out))
         return out, int(n)
+
+    def num_tracked_variants(self): return int(lib.orc_pm_num_variants(self.h))
+
+    def variant(self, v):
+        """per-variant tables (play_manager.h:218-275): dict(scores, games, perm_scores, perm_games, stats[7])"""
+        np_ = self.num_seat_perms()
+        sc = np.zeros(self.P + 1, np.float32); ps = np.zeros((np_, self.P + 1), np.float32); pg = np.zeros(np_, np.uint32)
+        st = np.zeros(7, np.float32)
+        n = lib.orc_pm_variant(self.h, C.c_uint32(v), _p(sc), _p(ps), _p(pg), _p(st))
+        return dict(scores=sc, games=int(n), perm_scores=ps, perm_games=pg, stats=st)
 
     def scores(self):
         out = np.zeros(self.P + 1, np.float32); lib.orc_pm_scores(self.h, _p(out)); return out
