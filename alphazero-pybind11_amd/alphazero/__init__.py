@@ -13,6 +13,7 @@ Put the directory that contains this package on sys.path:
 import ctypes as C
 import enum
 import os
+import struct
 
 import numpy as np
 
@@ -151,6 +152,12 @@ class PlayParams:
         c.start_temp = self.start_temp
         c.final_temp = self.final_temp
         c.temp_decay_half_life = self.temp_decay_half_life
+        hl = [float(x) for x in self.temp_decay_half_life_by_variant]     # play_manager.h:87-90 (entry get_variant_id())
+        if len(hl) > 4:
+            raise RuntimeError("temp_decay_half_life_by_variant: at most 4 variants")
+        c.num_temp_decay_half_life_by_variant = len(hl)
+        for i, x in enumerate(hl):
+            c.temp_decay_half_life_by_variant[i] = x
         c.history_enabled = int(bool(self.history_enabled))
         c.self_play = int(bool(self.self_play))
         c.tree_reuse = int(bool(self.tree_reuse))
@@ -757,6 +764,281 @@ class OpenTaflGS(_TaflBoardGS):  # py_wrapper.cc:538-547
     MAX_TURNS = 400
 
 
+class UnitInfo:
+    """UnitInfo of get_units() (star_gambit_gs.h:424-433, py_wrapper.cc StarGambit bindings)."""
+    __slots__ = ("player", "type", "slot", "hp", "anchor_q", "anchor_r", "facing", "moves_left")
+
+    def __init__(self, player, type, slot, hp, anchor_q, anchor_r, facing, moves_left):
+        self.player, self.type, self.slot, self.hp = player, type, slot, hp
+        self.anchor_q, self.anchor_r, self.facing, self.moves_left = anchor_q, anchor_r, facing, moves_left
+
+    def __repr__(self):
+        return (f"UnitInfo(player={self.player}, type={self.type}, slot={self.slot}, hp={self.hp}, "
+                f"anchor=({self.anchor_q}, {self.anchor_r}), facing={self.facing}, moves_left={self.moves_left})")
+
+
+class StarGambitUnifiedGS(GameState):
+    """StarGambitUnifiedGS(pinned_variant=-1, probs=[.25]*4) (py_wrapper.cc:662-667; star_gambit_gs.h:788-887): the four
+    configurations on the 13 x 13 canvas.  The object is the reference's to_bytes image of a start position plus the moves
+    played from it; the device rules (csrc/dev_stargambit.h, one wavefront per object) answer every query.
+
+    Build-defined: the reference draws the variant of an unpinned game from an unseedable thread-local engine
+    (star_gambit_gs.cc:2357-2362); here the constructor / randomize_start() draw it from Python's `random` module, and a
+    PlayManager draws every game's variant from the slot's coin stream."""
+
+    GAME_ID = 4
+    _REPLAY_FLAGS = 1          # play_move does not validate, like the reference's (star_gambit_gs.cc:1093-1238)
+    _VARIANT_NAMES = ("Skirmish", "Showdown", "Clash", "Battle")
+
+    def __init__(self, pinned_variant=-1, probs=(0.25, 0.25, 0.25, 0.25)):
+        super().__init__()
+        self._pinned = int(pinned_variant)
+        self._probs = tuple(float(x) for x in probs)
+        if len(self._probs) != 4:
+            raise TypeError("probs must have four entries")
+        self._start_variant(self._pick_variant())
+
+    def _pick_variant(self):
+        if 0 <= self._pinned <= 3:
+            return self._pinned
+        import random
+        return random.choices(range(4), weights=self._probs)[0]
+
+    def _start_variant(self, v):
+        """the start position of variant v: two portals, full reserves, the position seen once (star_gambit_gs.cc:251-290)"""
+        side = 6 if v == 3 else 5
+        start = ((3, 1, 0), (4, 0, 1), (3, 2, 1), (4, 3, 2))[v]
+        units = bytes([3, 0, 0, 5, 2, 0, side, 0, 0]) + bytes([3, 1, 0, 5, 5, 0, (-side) & 0xFF, 0, 0])
+
+        def uh(t, pl, hp, f, q, r):
+            return ((t ^ (pl << 8) ^ (hp << 12) ^ (f << 20) ^ ((q + 10) << 28) ^ ((r + 10) << 36)) * 0x517cc1b727220a95) & (2**64 - 1)
+        h0 = uh(3, 0, 5, 2, 0, side) ^ uh(3, 1, 5, 5, 0, -side)     # compute_position_hash with player 0 to move, :1365-1382
+        inner = (struct.pack("<I", 2) + units + bytes(start) + b"\0" + bytes(start) + b"\0" + struct.pack("<BIBBbI", 0, 1, 0, 0, -1, 1)
+                 + struct.pack("<Q", h0))
+        self._init = self._header(v, len(inner)) + inner
+        self._moves = []
+        self._snap = None
+        self._img = None
+
+    def _header(self, variant, inner_size):
+        return struct.pack("<4fiBI", *self._probs, self._pinned, variant, inner_size)
+
+    @staticmethod
+    def NUM_SYMMETRIES():
+        return 2
+
+    @classmethod
+    def POLICY_SHAPE(cls):         # star_gambit_gs.h:818-819; neural_net.py:281 keys the spatial policy head on it
+        return (10, 13, 13)
+
+    def relative_values(self): return True           # star_gambit_gs.h:845
+    def num_variants(self): return 4                 # :863
+    def get_variant_id(self): return self._image()[20]
+
+    def randomize_start(self):                       # star_gambit_gs.cc:2421-2425
+        self._start_variant(self._pick_variant())
+
+    def _image(self):
+        """to_bytes image of the current position (device: azmi_sg_image); cached per move count (MCTS.find_leaf appends moves)"""
+        cached = getattr(self, "_img", None)
+        if cached is not None and cached[0] == len(self._moves):
+            return cached[1]
+        self._img = (len(self._moves), self._make_image())
+        return self._img[1]
+
+    def _make_image(self):
+        if True:
+            if not self._moves:
+                return bytes(self._init)
+            else:
+                mv = np.array([self._moves + [-1]], dtype=np.int32)
+                init = np.frombuffer(self._init, np.uint8)
+                cap = len(self._init) + 9 * 20 + 8 * (len(self._moves) + 4) + 64
+                out = np.zeros(cap, np.uint8); n = np.zeros(1, np.uint32); st = np.zeros(1, np.int32)
+                check(lib.azmi_sg_image(self._device, init.ctypes.data, init.size, mv.ctypes.data, 1, mv.shape[1], out.ctypes.data, cap,
+                                        n.ctypes.data, st.ctypes.data, self._REPLAY_FLAGS))
+                if st[0] != 0:
+                    raise RuntimeError("illegal move in the game record")
+                b = bytearray(out[: int(n[0])].tobytes())
+                b[:20] = struct.pack("<4fi", *self._probs, self._pinned)
+                return bytes(b)
+
+    def to_bytes(self):                              # star_gambit_gs.cc:2451-2465
+        return self._image()
+
+    @classmethod
+    def from_bytes(cls, data):                       # star_gambit_gs.cc:2467-2516
+        data = bytes(data)
+        if len(data) < 25:
+            raise RuntimeError("StarGambitUnifiedGS::from_bytes: short data")
+        probs = struct.unpack_from("<4f", data, 0)
+        pinned, variant, inner_size = struct.unpack_from("<iBI", data, 16)
+        if variant > 3:
+            raise RuntimeError("StarGambitUnifiedGS::from_bytes: bad variant_id")
+        if 25 + inner_size > len(data):
+            raise RuntimeError("StarGambitUnifiedGS::from_bytes: short inner")
+        if 25 + inner_size != len(data):
+            raise RuntimeError("StarGambitUnifiedGS::from_bytes: trailing bytes")
+        g = cls.__new__(cls)
+        GameState.__init__(g)
+        g._pinned, g._probs = int(pinned), tuple(float(x) for x in probs)
+        g._init, g._moves, g._snap, g._img = data, [], None, None
+        g._state()        # the device parses the inner image: malformed images raise here
+        return g
+
+    def __reduce__(self):                            # ADD_GS_PICKLE, py_wrapper.cc:77-83
+        return (_sg_from_bytes, (type(self).__name__, self.to_bytes()))
+
+    def _fields(self):
+        b = self._image()
+        n = struct.unpack_from("<I", b, 25)[0]
+        units = [struct.unpack_from("<5B2b2B", b, 29 + 9 * i) for i in range(n)]
+        off = 29 + 9 * n
+        reserves = list(b[off:off + 8])
+        player, turn, acted, over, winner, hist = struct.unpack_from("<BIBBbI", b, off + 8)
+        return units, reserves, player, turn, bool(acted), bool(over), winner, hist
+
+    def get_units(self):                             # alive units only, star_gambit_gs.cc:2102-2118
+        return [UnitInfo(u[1], u[0], u[2], u[3], u[5], u[6], u[4], u[7]) for u in self._fields()[0] if u[3] > 0]
+
+    def has_taken_action(self):                      # star_gambit_gs.h:654
+        return self._fields()[4]
+
+    def __eq__(self, other):                         # operator==, star_gambit_gs.cc:297-319, 2392-2397: turn and history take no part
+        if not isinstance(other, StarGambitUnifiedGS):
+            return False
+        a, b = self._fields(), other._fields()
+        return self.get_variant_id() == other.get_variant_id() and a[0] == b[0] and a[1] == b[1] and a[2] == b[2] and a[4] == b[4]
+
+    __hash__ = None
+
+    def dump(self):                                  # star_gambit_gs.cc:1807-1830 (header lines)
+        units, res, player, turn, acted, over, winner, _ = self._fields()
+        return (f"Turn: {turn}, Player: {player}{' (acted)' if acted else ''}\n"
+                f"P0 reserves: F={res[0]} C={res[1]} D={res[2]}\nP1 reserves: F={res[4]} C={res[5]} D={res[6]}\n"
+                + "".join(f"P{u[1]} {'FCDP'[u[0]]}{u[2] + 1} hp={u[3]} at ({u[5]}, {u[6]}) facing {u[4]}\n" for u in units if u[3] > 0))
+
+    __str__ = dump
+
+    def symmetries(self, base):
+        raise NotImplementedError("StarGambit training-sample symmetries are not on the device yet (sample-side augmentation, SURVEY 8f-1)")
+
+
+def _pinned_sg(name, variant):
+    def __init__(self):
+        StarGambitUnifiedGS.__init__(self, variant)
+    return type(name, (StarGambitUnifiedGS,), {"__init__": __init__, "__doc__": f"StarGambitUnifiedGS pinned to {name[17:-2]} (star_gambit_gs.h:893-911)"})
+
+
+StarGambitUnifiedSkirmishGS = _pinned_sg("StarGambitUnifiedSkirmishGS", 0)
+StarGambitUnifiedShowdownGS = _pinned_sg("StarGambitUnifiedShowdownGS", 1)
+StarGambitUnifiedClashGS = _pinned_sg("StarGambitUnifiedClashGS", 2)
+StarGambitUnifiedBattleGS = _pinned_sg("StarGambitUnifiedBattleGS", 3)
+
+
+class _StarGambitPlainGS:
+    """StarGambit{Skirmish,Showdown,Clash,Battle}GS (star_gambit_gs.h:752-755): one configuration in its OWN action space
+    (ActionSpace<Config>, :483-590) and its own 32-plane canonical form.  A view of the unified device game: actions map
+    through to_unified_action (star_gambit_gs.cc:2522-2554), the planes are the 32 x D x D window of the canvas."""
+
+    VARIANT = 0
+
+    def __init__(self):
+        self._u = StarGambitUnifiedGS(self.VARIANT)
+
+    @classmethod
+    def _dims(cls):
+        side = 6 if cls.VARIANT == 3 else 5
+        d = 2 * side + 1
+        return side, d, d * d * 10
+
+    @classmethod
+    def NUM_PLAYERS(cls): return 2
+    @classmethod
+    def NUM_MOVES(cls): return cls._dims()[2] + 19
+    @classmethod
+    def CANONICAL_SHAPE(cls): return (32, cls._dims()[1], cls._dims()[1])
+    @classmethod
+    def POLICY_SHAPE(cls): return (10, cls._dims()[1], cls._dims()[1])
+    @staticmethod
+    def NUM_SYMMETRIES(): return 2
+
+    def _to_unified(self, a):
+        side, d, sp = self._dims()
+        if self.VARIANT == 3:
+            return a
+        if a < sp:
+            return ((a // 10 // d + 1) * 13 + (a // 10 % d + 1)) * 10 + a % 10
+        return 1690 + (a - sp)
+
+    def copy(self):
+        g = self.__class__.__new__(self.__class__)
+        g._u = self._u.copy()
+        return g
+
+    def __eq__(self, other): return isinstance(other, _StarGambitPlainGS) and self._u == other._u
+    __hash__ = None
+    def current_player(self): return self._u.current_player()
+    def current_turn(self): return self._u.current_turn()
+    def num_players(self): return 2
+    def num_moves(self): return self.NUM_MOVES()
+    def num_symmetries(self): return 2
+    def relative_values(self): return True           # star_gambit_gs.h:628
+    def randomize_start(self): return None
+    def num_variants(self): return 0
+    def get_variant_id(self): return -1
+    def scores(self): return self._u.scores()
+    def get_units(self): return self._u.get_units()
+    def has_taken_action(self): return self._u.has_taken_action()
+    def dump(self): return self._u.dump()
+    __str__ = dump
+
+    def valid_moves(self):
+        side, d, sp = self._dims()
+        uv = self._u.valid_moves()
+        if self.VARIANT == 3:
+            return uv
+        out = np.zeros(sp + 19, np.uint8)
+        out[:sp] = uv[:1690].reshape(13, 13, 10)[1:1 + d, 1:1 + d].reshape(-1)
+        out[sp:] = uv[1690:]
+        return out
+
+    def play_move(self, move):
+        move = int(move)
+        if not 0 <= move < self.NUM_MOVES():
+            raise RuntimeError(f"move {move} out of range")
+        self._u.play_move(self._to_unified(move))
+
+    def canonicalized(self):
+        side, d, _ = self._dims()
+        off = 0 if self.VARIANT == 3 else 1
+        return self._u.canonicalized()[:32, off:off + d, off:off + d].copy()
+
+    def to_bytes(self):                              # the inner image, star_gambit_gs.cc:2253-2288
+        return self._u.to_bytes()[25:]
+
+    @classmethod
+    def from_bytes(cls, data):
+        data = bytes(data)
+        g = cls.__new__(cls)
+        g._u = StarGambitUnifiedGS.from_bytes(struct.pack("<4fiBI", 0.25, 0.25, 0.25, 0.25, cls.VARIANT, cls.VARIANT, len(data)) + data)
+        return g
+
+    def __reduce__(self):
+        return (_sg_from_bytes, (type(self).__name__, self.to_bytes()))
+
+
+class StarGambitSkirmishGS(_StarGambitPlainGS): VARIANT = 0
+class StarGambitShowdownGS(_StarGambitPlainGS): VARIANT = 1
+class StarGambitClashGS(_StarGambitPlainGS): VARIANT = 2
+class StarGambitBattleGS(_StarGambitPlainGS): VARIANT = 3
+StarGambitGS = StarGambitSkirmishGS                   # the legacy name, star_gambit_gs.h:758
+
+
+def _sg_from_bytes(name, data):
+    return globals()[name].from_bytes(data)
+
+
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
@@ -826,7 +1108,8 @@ class PlayManager:
         if gs is None:
             raise TypeError("PlayManager(): gs must not be None")  # py::arg().none(false)
         game_id = gs.GAME_ID
-        if not isinstance(gs, type) and (gs._moves or gs._init is not None):
+        is_sg = (gs if isinstance(gs, type) else type(gs)).GAME_ID == StarGambitUnifiedGS.GAME_ID
+        if not isinstance(gs, type) and not is_sg and (gs._moves or gs._init is not None):
             raise RuntimeError("the MI355X PlayManager starts every game from the game's initial position")
         nplayers = type(gs).NUM_PLAYERS() if not isinstance(gs, type) else gs.NUM_PLAYERS()
         self._game = gs if isinstance(gs, type) else type(gs)
@@ -840,6 +1123,13 @@ class PlayManager:
         opts.max_inline = int(max_inline)
         opts.log_moves = int(bool(log_moves))
         opts.history_capacity = int(history_capacity)
+        if is_sg:   # every game re-draws its variant (randomize_start): only the base game's constructor arguments matter
+            base = gs() if isinstance(gs, type) else gs
+            opts.sg_pinned_variant = base._pinned
+            for i in range(4):
+                opts.sg_variant_probs[i] = base._probs[i]
+            if not any(base._probs):
+                raise RuntimeError("StarGambitUnifiedGS: the variant weights are all zero")
         h = C.c_void_p()
         self._caches = None
         if caches is None:
@@ -974,13 +1264,38 @@ class PlayManager:
             return sum(c.max_size() for c in self._caches if c is not None)
         return self._cache_stats()[5]
 
-    # per-variant tables (play_manager.h:218-275) exist only for multi-variant games; none of the device games has variants
-    def num_tracked_variants(self): return 0
-    def _no_variant(self, *a):
-        raise IndexError("this game tracks no variants (num_tracked_variants() == 0)")
-    variant_scores = variant_games_completed = variant_perm_scores = variant_perm_games_completed = _no_variant
-    variant_avg_game_length = variant_avg_leaf_depth = variant_avg_search_entropy = _no_variant
-    variant_fast_avg_leaf_depth = variant_fast_avg_search_entropy = variant_avg_moves_per_turn = variant_avg_valid_moves = _no_variant
+    # per-variant tables (play_manager.h:218-275): only for games with variants (StarGambitUnifiedGS)
+    def num_tracked_variants(self): return int(lib.azmi_pm_num_variants(self._h))
+
+    def _variant(self, v):
+        v = int(v)
+        if not 0 <= v < self.num_tracked_variants():
+            raise IndexError("variant index out of range")
+        npm = self.num_seat_perms()
+        ps = np.zeros((npm, self._P + 1), np.float32); pg = np.zeros(npm, np.uint32); sums = np.zeros(10, np.float64)
+        check(lib.azmi_pm_variant_sums(self._h, v, ps.ctypes.data, pg.ctypes.data, sums.ctypes.data))
+        return ps, pg, sums
+
+    def variant_sums(self, v): return self._variant(v)[2]
+    def variant_scores(self, v): return self._variant(v)[0].sum(0)
+    def variant_games_completed(self, v): return int(self._variant(v)[1].sum())
+    def variant_perm_scores(self, v, p): return self._variant(v)[0][int(p)].copy()
+    def variant_perm_games_completed(self, v, p): return int(self._variant(v)[1][int(p)])
+
+    @staticmethod
+    def _ratio(a, b, single=False):
+        if b == 0:
+            return 0.0
+        return float(np.float32(a) / np.float32(b)) if single else float(np.float32(a / b))
+
+    # the variant_avg_* getters with the reference's own divisions (play_manager.h:233-275)
+    def variant_avg_game_length(self, v): s = self.variant_sums(v); return self._ratio(s[0], s[1], True)
+    def variant_avg_leaf_depth(self, v): s = self.variant_sums(v); return self._ratio(s[5], s[3])
+    def variant_avg_search_entropy(self, v): s = self.variant_sums(v); return self._ratio(s[6], s[3])
+    def variant_fast_avg_leaf_depth(self, v): s = self.variant_sums(v); return self._ratio(s[7], s[4])
+    def variant_fast_avg_search_entropy(self, v): s = self.variant_sums(v); return self._ratio(s[8], s[4])
+    def variant_avg_moves_per_turn(self, v): s = self.variant_sums(v); return self._ratio(s[2], s[0], True)
+    def variant_avg_valid_moves(self, v): s = self.variant_sums(v); return self._ratio(s[9], s[2])
 
     # ---- the raw queue interface (play_manager.h:186-192, 285-286): pop leaf indices, read the slot through
     # game_data(i), write its v() / pi() rows, push_inference(i)

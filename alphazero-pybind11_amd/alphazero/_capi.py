@@ -80,6 +80,8 @@ class PlayParamsC(C.Structure):
         ("seat_gumbel_c_visit", (C.c_float * AZMI_MAX_PLAYERS) * AZMI_MAX_PERMS),
         ("seat_gumbel_c_scale", (C.c_float * AZMI_MAX_PLAYERS) * AZMI_MAX_PERMS),
         ("seat_resign_threshold", (C.c_float * AZMI_MAX_PLAYERS) * AZMI_MAX_PERMS),
+        ("num_temp_decay_half_life_by_variant", C.c_uint32),
+        ("temp_decay_half_life_by_variant", C.c_float * 4),
     ]
 
 
@@ -99,6 +101,8 @@ class EngineOptsC(C.Structure):
         ("history_capacity", C.c_uint32),
         ("log_moves", C.c_int32),
         ("move_log_capacity", C.c_uint32),
+        ("sg_pinned_variant", C.c_int32),
+        ("sg_variant_probs", C.c_float * 4),
     ]
 
 
@@ -177,6 +181,9 @@ SYMBOLS = {
     "azmi_game_replay_ex": (C.c_int, [C.c_int, C.c_int, _VP, C.c_uint32, _VP, C.c_uint32, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_uint32]),
     "azmi_game_replay_from": (C.c_int, [C.c_int, C.c_int, _VP, C.c_uint32, _VP, C.c_uint32, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "azmi_playout_eval": (C.c_int, [C.c_int, C.c_int, _VP, C.c_uint32, _VP, C.c_uint32, C.c_uint32, _VP, _VP, _VP]),
+    "azmi_pm_num_variants": (C.c_uint32, [_VP]),
+    "azmi_pm_variant_sums": (C.c_int, [_VP, C.c_uint32, _VP, _VP, _VP]),
+    "azmi_sg_image": (C.c_int, [C.c_int, _VP, C.c_uint32, _VP, C.c_uint32, C.c_uint32, _VP, C.c_uint32, _VP, _VP, C.c_uint32]),
     "azmi_game_replay": (C.c_int, [C.c_int, C.c_int, _VP, C.c_uint32, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
 }
 

@@ -126,6 +126,7 @@ namespace azmi {
 
 struct Tawlbwrdd {
   static constexpr int kGameId = 1;
+  static constexpr bool kRelative = false;     // relative_values(), game_state.h:114
   static constexpr int P = 2;
   static constexpr int W = 11, H = 11, SQ = 121;
   static constexpr int M = SQ * (W + H);       // 2662
@@ -279,6 +280,7 @@ template <int VARIANT>   // 0 = Brandubh, 1 = OpenTafl
 struct TaflX {
   static constexpr bool kOpen = VARIANT == 1;
   static constexpr int kGameId = 2 + VARIANT;
+  static constexpr bool kRelative = false;
   static constexpr int P = 2;
   static constexpr int N = kOpen ? 11 : 7;
   static constexpr int W = N, H = N, SQ = N * N, T = N / 2;

@@ -67,6 +67,10 @@ bool game_info(int game, GameInfo* gi) {
       *gi = GameInfo{OpenTafl::P, OpenTafl::M, OpenTafl::C, OpenTafl::H, OpenTafl::W, OpenTafl::MAXK,
                      OpenTafl::MAX_TURNS, OpenTafl::STATE_WORDS, 160};
       return true;
+    case AZMI_GAME_STARGAMBIT:   // max_turns = the engine's bound on the ACTIONS of a game (dev_stargambit.h)
+      *gi = GameInfo{StarGambit::P, StarGambit::M, StarGambit::C, StarGambit::H, StarGambit::W, StarGambit::MAXK,
+                     StarGambit::MAX_TURNS, StarGambit::STATE_WORDS, 32};
+      return true;
     default:
       return false;
   }
@@ -191,6 +195,12 @@ int launch_round(azmi_pm* pm, hipStream_t st, bool defer_moves = false) {
       else k_round_big<OpenTafl><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
       if (pm->ep.half_nodes) k_compact<OpenTafl><<<pm->ep.S * pm->gi.P, 256, 0, st>>>(pm->ep, pm->ar);
       break;
+    case AZMI_GAME_STARGAMBIT:
+      launch_pre_round<StarGambit>(pm, st);
+      if (pm->any_playout) k_round_big<StarGambit, true><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
+      else k_round_big<StarGambit><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
+      if (pm->ep.half_nodes) k_compact<StarGambit><<<pm->ep.S * pm->gi.P, 256, 0, st>>>(pm->ep, pm->ar);
+      break;
     default:
       return fail(AZMI_ERR_INVALID, "game %d has no device kernels", pm->game);
   }
@@ -289,6 +299,195 @@ __global__ void k_playout(const uint8_t* init, const int32_t* moves, uint32_t n,
   }
   for (int i = 0; i <= GM::P; ++i)
     v[static_cast<size_t>(g) * (GM::P + 1) + i] = term ? ((static_cast<int>(term) - 1 == i) ? 1.0f : 0.0f) : static_cast<float>(1.0 / (GM::P + 1));
+}
+
+// StarGambit replay / rollout: ONE WAVEFRONT per game (its rules are wave-cooperative, dev_stargambit.h); the position
+// history of game g lives in row g of `hist` (hist_stride entries)
+struct SgListRep {
+  uint64_t* list; uint32_t& len; uint32_t cap; uint32_t lane; bool overflow = false;
+  __device__ __forceinline__ void clear() { len = 0; }
+  __device__ __forceinline__ uint32_t push(unsigned long long k) {
+    uint32_t cnt = 0;
+    for (uint32_t i = lane; i < len; i += 64) cnt += list[i] == k;
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if (len >= cap) { overflow = true; return cnt + 1; }
+    if (lane == 0) list[len] = k;
+    ++len;
+    StarGambit::lds_sync();
+    return cnt + 1;
+  }
+};
+__device__ __forceinline__ bool sg_start(const uint8_t* init, uint32_t stride, uint32_t g, uint32_t lane, StarGambit::State& s, uint64_t* hist,
+                                         uint32_t& nh, uint32_t cap) {
+  if (!init) {
+    s = StarGambit::initial(0, lane);
+    const unsigned long long h0 = StarGambit::position_hash(s);
+    if (lane == 0) hist[0] = h0;
+    nh = 1;
+    StarGambit::lds_sync();
+    return true;
+  }
+  const uint8_t* row = init + static_cast<size_t>(g) * stride;
+  const uint32_t inner = uint32_t(row[21]) | uint32_t(row[22]) << 8 | uint32_t(row[23]) << 16 | uint32_t(row[24]) << 24;
+  return sg_parse_image(row, 25u + inner, lane, s, hist, nh, cap);
+}
+// flags bit 0: play_move as the reference does (no validity check; a move that names no unit is ignored)
+__global__ __launch_bounds__(64) void k_replay_sg(const uint8_t* init, uint32_t init_stride, const int32_t* moves, uint32_t n, uint32_t len,
+                                                   uint64_t* hist, uint32_t hist_stride, uint8_t* valid, float* scores, float* canonical,
+                                                   uint32_t* player, uint32_t* turn, uint64_t* key, int32_t* status, uint32_t flags) {
+  using G = StarGambit;
+  __shared__ SgScratch sm;
+  const uint32_t g = blockIdx.x, lane = threadIdx.x;
+  if (g >= n) return;
+  G::State s;
+  uint64_t* hl = hist + static_cast<size_t>(g) * hist_stride;
+  uint32_t nh = 0;
+  int32_t stt = sg_start(init, init_stride, g, lane, s, hl, nh, hist_stride) ? 0 : -1;
+  SgListRep rep{hl, nh, hist_stride, lane};
+  for (uint32_t i = 0; i < len && stt == 0; ++i) {
+    const int32_t mv = moves[static_cast<size_t>(g) * len + i];
+    if (mv < 0) break;
+    if (mv >= G::M) { stt = -1; break; }
+    if (!(flags & 1u)) {
+      G::gen_valid(s, lane, sm);
+      const bool ok = G::is_valid_bit(sm, static_cast<uint32_t>(mv));
+      G::lds_sync();
+      if (!ok) { stt = -1; break; }
+    }
+    G::apply_move(s, static_cast<uint32_t>(mv), lane, sm, rep);
+    if (rep.overflow) { stt = -1; break; }
+  }
+  if (status && lane == 0) status[g] = stt;
+  if (valid) {
+    G::gen_valid(s, lane, sm);
+    for (uint32_t m = lane; m < static_cast<uint32_t>(G::M); m += 64) valid[static_cast<size_t>(g) * G::M + m] = G::is_valid_bit(sm, m) ? 1 : 0;
+    G::lds_sync();
+  }
+  if (scores && lane <= static_cast<uint32_t>(G::P)) {
+    const uint32_t t = G::terminal(s);
+    // over with no winner recorded (only reachable through a hand-made image): all zeros, like the reference's scores()
+    scores[static_cast<size_t>(g) * (G::P + 1) + lane] = t == 0 ? -1.0f : ((G::winner(s) < 3 && t - 1 == lane) ? 1.0f : 0.0f);
+  }
+  if (canonical) G::write_canonical(s, canonical + static_cast<size_t>(g) * G::CANON, lane, sm);
+  const uint64_t k = G::key(s, lane);
+  if (lane == 0) {
+    if (player) player[g] = s.player;
+    if (turn) turn[g] = s.turn;
+    if (key) key[g] = k;
+  }
+}
+// the state itself for the Python objects: to_bytes image of game g after its moves (row of out_stride bytes, size in out_len)
+__global__ __launch_bounds__(64) void k_sg_image(const uint8_t* init, uint32_t init_stride, const int32_t* moves, uint32_t n, uint32_t len,
+                                                  uint64_t* hist, uint32_t hist_stride, uint8_t* out, uint32_t out_stride, uint32_t* out_len,
+                                                  int32_t* status, uint32_t flags) {
+  using G = StarGambit;
+  __shared__ SgScratch sm;
+  const uint32_t g = blockIdx.x, lane = threadIdx.x;
+  if (g >= n) return;
+  G::State s;
+  uint64_t* hl = hist + static_cast<size_t>(g) * hist_stride;
+  uint32_t nh = 0;
+  int32_t stt = sg_start(init, init_stride, g, lane, s, hl, nh, hist_stride) ? 0 : -1;
+  SgListRep rep{hl, nh, hist_stride, lane};
+  for (uint32_t i = 0; i < len && stt == 0; ++i) {
+    const int32_t mv = moves[static_cast<size_t>(g) * len + i];
+    if (mv < 0) break;
+    if (mv >= G::M) { stt = -1; break; }
+    if (!(flags & 1u)) {
+      G::gen_valid(s, lane, sm);
+      const bool ok = G::is_valid_bit(sm, static_cast<uint32_t>(mv));
+      G::lds_sync();
+      if (!ok) { stt = -1; break; }
+    }
+    G::apply_move(s, static_cast<uint32_t>(mv), lane, sm, rep);
+    if (rep.overflow) { stt = -1; break; }
+  }
+  if (lane == 0) status[g] = stt;
+  // inner image (star_gambit_gs.cc:2253-2288) behind a 25-byte Unified header whose probs / pinned fields the caller fills in
+  uint8_t* row = out + static_cast<size_t>(g) * out_stride;
+  const uint32_t nu = G::nunits(s);
+  const uint32_t inner = 4u + 9u * nu + 8u + 12u + 8u * nh;
+  if (25u + inner > out_stride) { if (lane == 0) { status[g] = -2; out_len[g] = 0; } return; }
+  auto wr32 = [&](uint8_t* p, uint32_t x) { p[0] = uint8_t(x); p[1] = uint8_t(x >> 8); p[2] = uint8_t(x >> 16); p[3] = uint8_t(x >> 24); };
+  uint8_t* in = row + 25;
+  if (lane < nu) {
+    const uint32_t u = s.unit;
+    uint8_t* r = in + 4 + 9 * lane;
+    r[0] = uint8_t(G::u_type(u)); r[1] = uint8_t(G::u_player(u)); r[2] = uint8_t(G::u_slot(u)); r[3] = uint8_t(G::u_hp(u)); r[4] = uint8_t(G::u_facing(u));
+    r[5] = uint8_t(int8_t(G::u_q(u))); r[6] = uint8_t(int8_t(G::u_r(u))); r[7] = uint8_t(G::u_moves(u)); r[8] = uint8_t(G::u_cannons(u));
+  }
+  for (uint32_t i = lane; i < nh; i += 64) {
+    uint8_t* p = in + 4 + 9 * nu + 20 + 8 * i;
+    const uint64_t x = hl[i];
+    for (int k = 0; k < 8; ++k) p[k] = uint8_t(x >> (8 * k));
+  }
+  if (lane == 0) {
+    for (int i = 0; i < 20; ++i) row[i] = 0;
+    row[20] = uint8_t(G::variant(s));
+    wr32(row + 21, inner);
+    wr32(in, nu);
+    uint8_t* t = in + 4 + 9 * nu;
+    for (uint32_t pl = 0; pl < 2; ++pl) { for (uint32_t ty = 0; ty < 3; ++ty) t[pl * 4 + ty] = uint8_t(G::reserve(s, pl, ty)); t[pl * 4 + 3] = 0; }
+    t[8] = uint8_t(s.player);
+    wr32(t + 9, s.turn);
+    t[13] = G::acted(s) ? 1 : 0; t[14] = G::over(s) ? 1 : 0;
+    t[15] = uint8_t(int8_t(G::winner(s) < 3 ? int(G::winner(s)) : -1));
+    wr32(t + 16, nh);
+    out_len[g] = 25u + inner;
+  }
+}
+// playout_eval (game_state.cc:10-54) for StarGambit: pi uniform over the legal moves, v the scores of a uniformly random rollout
+__global__ __launch_bounds__(64) void k_playout_sg(const uint8_t* init, uint32_t init_stride, const int32_t* moves, uint32_t n, uint32_t len,
+                                                    uint64_t* hist, uint32_t hist_stride, const uint64_t* seeds, float* v, float* pi, int32_t* status) {
+  using G = StarGambit;
+  __shared__ SgScratch sm;
+  const uint32_t g = blockIdx.x, lane = threadIdx.x;
+  if (g >= n) return;
+  G::State s;
+  uint64_t* hl = hist + static_cast<size_t>(g) * hist_stride;
+  uint32_t nh = 0;
+  int32_t stt = sg_start(init, init_stride, g, lane, s, hl, nh, hist_stride) ? 0 : -1;
+  SgListRep rep{hl, nh, hist_stride, lane};
+  for (uint32_t i = 0; i < len && stt == 0; ++i) {
+    const int32_t mv = moves[static_cast<size_t>(g) * len + i];
+    if (mv < 0) break;
+    G::gen_valid(s, lane, sm);
+    const bool ok = mv < G::M && G::is_valid_bit(sm, static_cast<uint32_t>(mv));
+    G::lds_sync();
+    if (!ok) { stt = -1; break; }
+    G::apply_move(s, static_cast<uint32_t>(mv), lane, sm, rep);
+    if (rep.overflow) { stt = -1; break; }
+  }
+  if (lane == 0) status[g] = stt;
+  if (stt) return;
+  const uint32_t kl = G::gen_valid(s, lane, sm);
+  const float ksum = static_cast<float>(kl & 0xFFu);
+  for (uint32_t m = lane; m < static_cast<uint32_t>(G::M); m += 64)
+    pi[static_cast<size_t>(g) * G::M + m] = (G::is_valid_bit(sm, m) && ksum > 0.0f) ? 1.0f / ksum : 0.0f;
+  G::lds_sync();
+  Pcg32 roll;
+  roll.seed(seeds[g]);
+  uint32_t term = G::terminal(s);
+  while (term == 0) {
+    const uint32_t k = G::gen_valid(s, lane, sm);
+    if (k == 0) break;
+    const uint32_t r = lemire_below(roll, k);
+    const unsigned long long w = lane < 27 ? sm.vbits[lane] : 0ull;
+    const uint32_t cnt = static_cast<uint32_t>(__builtin_popcountll(w));
+    uint32_t in = cnt;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(in, off, 64); if (lane >= static_cast<uint32_t>(off)) in += o; }
+    const uint32_t lo = in - cnt;
+    uint32_t mine = 0xFFFFFFFFu;
+    if (r >= lo && r < lo + cnt) { unsigned long long m = w; for (uint32_t j = lo; j < r; ++j) m &= m - 1; mine = lane * 64 + static_cast<uint32_t>(__builtin_ctzll(m)); }
+    const uint64_t owner = __ballot(mine != 0xFFFFFFFFu);
+    const uint32_t mv = __shfl(mine, static_cast<int>(__builtin_ctzll(owner)), 64);
+    G::lds_sync();
+    G::apply_move(s, mv, lane, sm, rep);
+    if (rep.overflow) break;
+    term = G::terminal(s);
+  }
+  if (lane <= static_cast<uint32_t>(G::P))
+    v[static_cast<size_t>(g) * (G::P + 1) + lane] = term ? ((term - 1 == lane) ? 1.0f : 0.0f) : static_cast<float>(1.0 / (G::P + 1));
 }
 
 // Tafl-family replay: one thread per game, repetition list in a global scratch row per game
@@ -652,6 +851,15 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
   pm->split_rounds = game == AZMI_GAME_CONNECT4 && !seats.any_gumbel && !seats.any_playout && getenv("AZMI_NO_SPLIT") == nullptr;
   ep.cpuct = params->cpuct; ep.start_temp = params->start_temp; ep.final_temp = params->final_temp;
   ep.half_life = params->temp_decay_half_life;
+  ep.n_half_life_v = 0;
+  if (game == AZMI_GAME_STARGAMBIT) {
+    if (params->num_temp_decay_half_life_by_variant > 4) { delete pm; return fail(AZMI_ERR_INVALID, "temp_decay_half_life_by_variant: at most 4 entries"); }
+    ep.n_half_life_v = params->num_temp_decay_half_life_by_variant;
+    for (uint32_t i = 0; i < 4; ++i) ep.half_life_v[i] = i < ep.n_half_life_v ? params->temp_decay_half_life_by_variant[i] : 0.0f;
+    const bool given = opts.sg_variant_probs[0] != 0 || opts.sg_variant_probs[1] != 0 || opts.sg_variant_probs[2] != 0 || opts.sg_variant_probs[3] != 0;
+    ep.sg_pinned = given || opts.sg_pinned_variant != 0 ? opts.sg_pinned_variant : -1;   // zeroed opts = the constructor's defaults
+    for (uint32_t i = 0; i < 4; ++i) ep.sg_probs[i] = given ? opts.sg_variant_probs[i] : 0.25f;
+  }
   ep.epsilon = params->epsilon; ep.root_temp = params->mcts_root_temp; ep.fpu_reduction = params->fpu_reduction;
   ep.cap_percent = params->playout_cap_percent; ep.resign_percent = params->resign_percent;
   ep.resign_playthrough = params->resign_playthrough_percent;
@@ -731,7 +939,7 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
   A(a_len, S, true); A(a_dsum, 5 * static_cast<size_t>(S), true); A(a_cnt, 3 * static_cast<size_t>(S), true);
   A(c_sims, S, true); A(c_evals, S, true);
   A(ph_count, S, true);
-  A(ph_canon, ep.history ? static_cast<size_t>(S) * ep.max_hist_rows * (game == AZMI_GAME_CONNECT4 ? 2 * kPendingWords : CANON) : 0, false);
+  A(ph_canon, ep.history ? static_cast<size_t>(S) * ep.max_hist_rows * (game == AZMI_GAME_CONNECT4 ? 2 * kPendingWords : game == AZMI_GAME_STARGAMBIT ? 2 * kSgPendWords : CANON) : 0, false);
   A(ph_pi, ep.history ? static_cast<size_t>(S) * ep.max_hist_rows * M : 0, false);
   A(ph_meta, ep.history ? static_cast<size_t>(S) * ep.max_hist_rows * 2 : 0, false);
   A(root, T, true); A(bump, T, true); A(depth, T, true); A(tld, T, true);
@@ -809,6 +1017,14 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
   }
   A(resign_streak, static_cast<size_t>(S) * P, true);
   A(roll, S, true);
+  if (game == AZMI_GAME_STARGAMBIT) {
+    A(rep_path, static_cast<size_t>(S) * (gi.max_turns + 2), true);
+    A(a_var_scores, static_cast<size_t>(S) * 4 * ep.num_perms * (P + 1), true);
+    A(a_var_games, static_cast<size_t>(S) * 4 * ep.num_perms, true);
+    A(a_var_len, static_cast<size_t>(S) * 4, true);
+    A(a_var_dsum, static_cast<size_t>(S) * 4 * 5, true);
+    A(a_var_cnt, static_cast<size_t>(S) * 4 * 3, true);
+  }
 #undef A
   if (rc != AZMI_OK) { delete pm; return rc; }
   if (hipDeviceSynchronize() != hipSuccess) { delete pm; return fail(AZMI_ERR_NO_DEVICE, "device sync failed"); }
@@ -1151,6 +1367,35 @@ int azmi_pm_stat_sums(azmi_pm* pm, double* out) {
   return AZMI_OK;
 }
 
+uint32_t azmi_pm_num_variants(azmi_pm* pm) { return pm && pm->game == AZMI_GAME_STARGAMBIT ? 4u : 0u; }   // num_variants(), star_gambit_gs.h:863
+int azmi_pm_variant_sums(azmi_pm* pm, uint32_t variant, float* perm_scores, uint32_t* perm_games, double* sums) {
+  if (!pm || !perm_scores || !perm_games || !sums) return fail(AZMI_ERR_INVALID, "null argument");
+  if (variant >= azmi_pm_num_variants(pm)) return fail(AZMI_ERR_RANGE, "variant %u out of range", variant);
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
+  const uint32_t S = pm->ep.S, NP = pm->ep.num_perms, V = pm->gi.P + 1;
+  std::vector<float> sc; std::vector<uint32_t> gm; std::vector<uint64_t> len, cnt; std::vector<double> ds;
+  int rc = d2h(sc, pm->ar.a_var_scores, static_cast<size_t>(S) * 4 * NP * V, pm->last); if (rc) return rc;
+  rc = d2h(gm, pm->ar.a_var_games, static_cast<size_t>(S) * 4 * NP, pm->last); if (rc) return rc;
+  rc = d2h(len, pm->ar.a_var_len, static_cast<size_t>(S) * 4, pm->last); if (rc) return rc;
+  rc = d2h(ds, pm->ar.a_var_dsum, static_cast<size_t>(S) * 4 * 5, pm->last); if (rc) return rc;
+  rc = d2h(cnt, pm->ar.a_var_cnt, static_cast<size_t>(S) * 4 * 3, pm->last); if (rc) return rc;
+  for (uint32_t i = 0; i < NP * V; ++i) perm_scores[i] = 0.0f;
+  for (uint32_t i = 0; i < NP; ++i) perm_games[i] = 0;
+  for (int i = 0; i < 10; ++i) sums[i] = 0.0;
+  for (uint32_t s = 0; s < S; ++s) {      // slot order: a deterministic sum
+    const size_t sv = static_cast<size_t>(s) * 4 + variant;
+    for (uint32_t q = 0; q < NP; ++q) {
+      for (uint32_t i = 0; i < V; ++i) perm_scores[q * V + i] += sc[(sv * NP + q) * V + i];
+      perm_games[q] += gm[sv * NP + q];
+      sums[1] += gm[sv * NP + q];
+    }
+    sums[0] += static_cast<double>(len[sv]);
+    for (int j = 0; j < 3; ++j) sums[2 + j] += static_cast<double>(cnt[sv * 3 + j]);
+    for (int j = 0; j < 5; ++j) sums[5 + j] += ds[sv * 5 + j];
+  }
+  return AZMI_OK;
+}
+
 int azmi_pm_stats(azmi_pm* pm, float* out) {  // play_manager.h:288-315
   if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");
   std::lock_guard<std::recursive_mutex> lock_(pm->mu);
@@ -1427,6 +1672,19 @@ int check_init_rows(int game, const uint8_t* init, uint32_t init_stride, uint32_
     if (init_stride != Connect4::SERIALIZED) return fail(AZMI_ERR_INVALID, "start positions: Connect4 images are %u bytes", Connect4::SERIALIZED);
     return AZMI_OK;
   }
+  if (game == AZMI_GAME_STARGAMBIT) {   // rows hold one StarGambitUnifiedGS::to_bytes image each, zero-padded; the history rides along
+    if (init_stride < 25u + 24u) return fail(AZMI_ERR_INVALID, "start positions: a StarGambit image is at least 49 bytes, got %u", init_stride);
+    for (uint32_t g = 0; g < n; ++g) {
+      const uint8_t* row = init + static_cast<size_t>(g) * init_stride;
+      const uint32_t inner = uint32_t(row[21]) | uint32_t(row[22]) << 8 | uint32_t(row[23]) << 16 | uint32_t(row[24]) << 24;
+      if (25ull + inner > init_stride) return fail(AZMI_ERR_INVALID, "start position %u: image longer than the row", g);
+      const uint32_t nu = uint32_t(row[25]) | uint32_t(row[26]) << 8 | uint32_t(row[27]) << 16 | uint32_t(row[28]) << 24;
+      if (nu > 20u || 9ull * nu + 24ull > inner) return fail(AZMI_ERR_INVALID, "start position %u: malformed image", g);
+      const uint8_t* hl = row + 25 + 9 * nu + 20;
+      *extra_reps = std::max(*extra_reps, uint32_t(hl[0]) | uint32_t(hl[1]) << 8 | uint32_t(hl[2]) << 16 | uint32_t(hl[3]) << 24);
+    }
+    return AZMI_OK;
+  }
   const uint32_t sq = game == AZMI_GAME_BRANDUBH ? Brandubh::SQ : 121u, bb = 3u * sq, header = bb + 6u, entry = bb + 2u;
   if (init_stride < header + 4u) return fail(AZMI_ERR_INVALID, "start positions: a Tafl image is at least %u bytes, got %u", header + 4u, init_stride);
   for (uint32_t g = 0; g < n; ++g) {
@@ -1472,6 +1730,11 @@ int azmi_playout_eval(int game, int device, const uint8_t* init, uint32_t init_s
   TRY3(dalloc(d_v, static_cast<size_t>(n) * V)); TRY3(dalloc(d_pi, static_cast<size_t>(n) * gi.M)); TRY3(dalloc(d_status, n));
   if (game == AZMI_GAME_CONNECT4) {
     k_playout<Connect4><<<(n + 63) / 64, 64>>>(d_init, d_moves, n, len, d_seeds, d_v, d_pi, d_status);
+  } else if (game == AZMI_GAME_STARGAMBIT) {
+    uint64_t* d_rep = nullptr;
+    const uint32_t stride = len + gi.max_turns + 4 + extra_reps;
+    TRY3(dalloc(d_rep, static_cast<size_t>(n) * stride));
+    k_playout_sg<<<n, 64>>>(d_init, init_stride, d_moves, n, len, d_rep, stride, d_seeds, d_v, d_pi, d_status);
   } else {
     uint64_t* d_rep = nullptr;
     const uint32_t stride = len + gi.max_turns + 4 + extra_reps;
@@ -1543,6 +1806,13 @@ int azmi_game_replay_ex(int game, int device, const uint8_t* init, uint32_t init
           k_replay_tafl<OpenTafl><<<(n + 63) / 64, 64>>>(d_init, init_stride, d_moves, n, len, d_rep, stride, d_valid, d_scores, d_canon, d_player, d_turn, d_key, d_status, flags);
         break;
       }
+      case AZMI_GAME_STARGAMBIT: {
+        uint64_t* d_rep = nullptr;
+        const uint32_t stride = len + 4 + extra_reps;
+        TRY2(dalloc(reinterpret_cast<void**>(&d_rep), static_cast<size_t>(n) * stride * 8));
+        k_replay_sg<<<n, 64>>>(d_init, init_stride, d_moves, n, len, d_rep, stride, d_valid, d_scores, d_canon, d_player, d_turn, d_key, d_status, flags);
+        break;
+      }
       default: cleanup(); return fail(AZMI_ERR_INVALID, "game %d has no device kernels", game);
     }
     TRY2(hipGetLastError());
@@ -1556,6 +1826,41 @@ int azmi_game_replay_ex(int game, int device, const uint8_t* init, uint32_t init
   if (key) TRY2(hipMemcpy(key, d_key, static_cast<size_t>(n) * 8, hipMemcpyDeviceToHost));
   if (status) TRY2(hipMemcpy(status, d_status, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost));
 #undef TRY2
+  cleanup();
+  return AZMI_OK;
+}
+
+// StarGambitUnifiedGS::to_bytes (star_gambit_gs.cc:2451-2465) of n states given as start image + moves: rows of out_stride
+// bytes (probs / pinned_variant fields zero: they belong to the caller's object), sizes in out_len
+int azmi_sg_image(int device, const uint8_t* init, uint32_t init_stride, const int32_t* moves, uint32_t n, uint32_t len,
+                  uint8_t* out, uint32_t out_stride, uint32_t* out_len, int32_t* status, uint32_t flags) {
+  if (!out || !out_len || !status || (!moves && n * len)) return fail(AZMI_ERR_INVALID, "null argument");
+  uint32_t extra_reps = 0;
+  { const int rc_init = check_init_rows(AZMI_GAME_STARGAMBIT, init, init_stride, n, &extra_reps); if (rc_init != AZMI_OK) return rc_init; }
+  if (n == 0) return AZMI_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(AZMI_ERR_NO_DEVICE, "no HIP device: libazmi has no CPU path");
+  HIP_TRY(hipSetDevice(device));
+  std::vector<void*> tmp;
+  auto dalloc = [&](void** p, size_t bytes) { hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 4)); if (e == hipSuccess) tmp.push_back(*p); return e; };
+  auto cleanup = [&]() { for (void* q : tmp) (void)hipFree(q); };
+#define TRY4(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return fail(AZMI_ERR_NO_DEVICE, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
+  int32_t* d_moves = nullptr; uint8_t* d_init = nullptr; uint64_t* d_rep = nullptr; uint8_t* d_out = nullptr; uint32_t* d_len = nullptr; int32_t* d_status = nullptr;
+  TRY4(dalloc(reinterpret_cast<void**>(&d_moves), static_cast<size_t>(n) * len * 4));
+  if (len) TRY4(hipMemcpy(d_moves, moves, static_cast<size_t>(n) * len * 4, hipMemcpyHostToDevice));
+  if (init) { TRY4(dalloc(reinterpret_cast<void**>(&d_init), static_cast<size_t>(n) * init_stride)); TRY4(hipMemcpy(d_init, init, static_cast<size_t>(n) * init_stride, hipMemcpyHostToDevice)); }
+  const uint32_t stride = len + 4 + extra_reps;
+  TRY4(dalloc(reinterpret_cast<void**>(&d_rep), static_cast<size_t>(n) * stride * 8));
+  TRY4(dalloc(reinterpret_cast<void**>(&d_out), static_cast<size_t>(n) * out_stride));
+  TRY4(dalloc(reinterpret_cast<void**>(&d_len), static_cast<size_t>(n) * 4));
+  TRY4(dalloc(reinterpret_cast<void**>(&d_status), static_cast<size_t>(n) * 4));
+  k_sg_image<<<n, 64>>>(d_init, init_stride, d_moves, n, len, d_rep, stride, d_out, out_stride, d_len, d_status, flags);
+  TRY4(hipGetLastError());
+  TRY4(hipDeviceSynchronize());
+  TRY4(hipMemcpy(out, d_out, static_cast<size_t>(n) * out_stride, hipMemcpyDeviceToHost));
+  TRY4(hipMemcpy(out_len, d_len, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost));
+  TRY4(hipMemcpy(status, d_status, static_cast<size_t>(n) * 4, hipMemcpyDeviceToHost));
+#undef TRY4
   cleanup();
   return AZMI_OK;
 }
@@ -1574,6 +1879,7 @@ struct azmi_mcts {
 namespace {
 // capacity of the start-position buffer: Connect4's 89 bytes; a Tafl pickle image with up to 512 repetition entries
 uint32_t mcts_init_bytes(int game) {
+  if (game == AZMI_GAME_STARGAMBIT) return 25u + 4u + 9u * 20u + 20u + 8u * (StarGambit::MAX_TURNS + 2);
   return game == AZMI_GAME_CONNECT4 ? Connect4::SERIALIZED : game == AZMI_GAME_BRANDUBH ? TaflImage<Brandubh>::bytes(512) : TaflImage<OpenTafl>::bytes(512);
 }
 }  // namespace
@@ -1583,7 +1889,9 @@ int azmi_mcts_create(int game, const azmi_mcts_config* cfg, uint64_t seed, int d
   GameInfo gi;
   if (!game_info(game, &gi)) return fail(AZMI_ERR_INVALID, "unknown game id %d", game);
   if (cfg->num_players != gi.P || cfg->num_moves != gi.M) return fail(AZMI_ERR_INVALID, "MCTS(num_players, num_moves) do not match the game");
-  if (cfg->relative_values) return fail(AZMI_ERR_INVALID, "relative_values games are not implemented");
+  // MCTS(..., relative_values, ...) (mcts.h:54): on the device the rotation is part of the game's instantiation
+  if ((cfg->relative_values != 0) != (game == AZMI_GAME_STARGAMBIT))
+    return fail(AZMI_ERR_INVALID, "relative_values must be the game's relative_values() (true for StarGambit only)");
   azmi_play_params p;
   azmi_play_params_default(&p);
   p.games_to_play = 1; p.concurrent_games = 1; p.max_batch_size = 1;
@@ -1663,6 +1971,7 @@ int azmi_mcts_find_leaf(azmi_mcts* m, const uint8_t* init, uint32_t init_bytes, 
     case AZMI_GAME_CONNECT4: k_mcts_find_leaf<Connect4><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif, di, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
     case AZMI_GAME_TAWLBWRDD: k_mcts_big_find_leaf<Tawlbwrdd><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif, di, init_bytes, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
     case AZMI_GAME_BRANDUBH: k_mcts_big_find_leaf<Brandubh><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif, di, init_bytes, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
+    case AZMI_GAME_STARGAMBIT: k_mcts_big_find_leaf<StarGambit><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif, di, init_bytes, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
     default: k_mcts_big_find_leaf<OpenTafl><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif, di, init_bytes, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
   }
   int32_t status = 0; uint32_t n = 0;
@@ -1690,6 +1999,7 @@ int azmi_mcts_process_result(azmi_mcts* m, const float* value, const float* pi, 
     case AZMI_GAME_CONNECT4: k_mcts_process_result<Connect4><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, rn, m->d_f); break;
     case AZMI_GAME_TAWLBWRDD: k_mcts_big_process_result<Tawlbwrdd><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, rn, m->d_f); break;
     case AZMI_GAME_BRANDUBH: k_mcts_big_process_result<Brandubh><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, rn, m->d_f); break;
+    case AZMI_GAME_STARGAMBIT: k_mcts_big_process_result<StarGambit><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, rn, m->d_f); break;
     default: k_mcts_big_process_result<OpenTafl><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, rn, m->d_f); break;
   }
   float tmp[8];
@@ -1713,6 +2023,7 @@ int azmi_mcts_find_leaf_batched(azmi_mcts* m, const uint8_t* init, uint32_t init
     case AZMI_GAME_CONNECT4: k_mcts_find_leaf_batched<Connect4><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu, idx, di, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
     case AZMI_GAME_TAWLBWRDD: k_mcts_big_find_leaf_batched<Tawlbwrdd><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu, idx, di, init_bytes, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
     case AZMI_GAME_BRANDUBH: k_mcts_big_find_leaf_batched<Brandubh><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu, idx, di, init_bytes, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
+    case AZMI_GAME_STARGAMBIT: k_mcts_big_find_leaf_batched<StarGambit><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu, idx, di, init_bytes, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
     default: k_mcts_big_find_leaf_batched<OpenTafl><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu, idx, di, init_bytes, m->d_moves, len, m->d_out_moves, m->d_len, m->d_status); break;
   }
   int32_t status = 0; uint32_t n = 0;
@@ -1743,6 +2054,7 @@ int azmi_mcts_process_result_batched(azmi_mcts* m, uint32_t leaf_index, const fl
     case AZMI_GAME_CONNECT4: k_mcts_process_result_batched<Connect4><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu, leaf_index, rn, m->d_f); break;
     case AZMI_GAME_TAWLBWRDD: k_mcts_big_process_result_batched<Tawlbwrdd><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu, leaf_index, rn, m->d_f); break;
     case AZMI_GAME_BRANDUBH: k_mcts_big_process_result_batched<Brandubh><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu, leaf_index, rn, m->d_f); break;
+    case AZMI_GAME_STARGAMBIT: k_mcts_big_process_result_batched<StarGambit><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu, leaf_index, rn, m->d_f); break;
     default: k_mcts_big_process_result_batched<OpenTafl><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu, leaf_index, rn, m->d_f); break;
   }
   float tmp[8];
@@ -1781,6 +2093,10 @@ int azmi_mcts_update_root(azmi_mcts* m, const uint8_t* init, uint32_t init_bytes
       k_mcts_big_update_root<Brandubh><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif, di, init_bytes, m->d_moves, len, move, m->d_status);
       if (m->pm->ep.half_nodes) k_compact<Brandubh><<<trees, 256, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif);
       break;
+    case AZMI_GAME_STARGAMBIT:
+      k_mcts_big_update_root<StarGambit><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif, di, init_bytes, m->d_moves, len, move, m->d_status);
+      if (m->pm->ep.half_nodes) k_compact<StarGambit><<<trees, 256, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif);
+      break;
     default:
       k_mcts_big_update_root<OpenTafl><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif, di, init_bytes, m->d_moves, len, move, m->d_status);
       if (m->pm->ep.half_nodes) k_compact<OpenTafl><<<trees, 256, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif);
@@ -1812,6 +2128,7 @@ int azmi_mcts_query(azmi_mcts* m, uint32_t kind, float temp, uint32_t arg, const
     case AZMI_GAME_CONNECT4: k_mcts_query<Connect4><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, kind, temp, arg, m->d_f, m->d_u); break;
     case AZMI_GAME_TAWLBWRDD: k_mcts_big_query<Tawlbwrdd><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, kind, temp, arg, m->d_f, m->d_u); break;
     case AZMI_GAME_BRANDUBH: k_mcts_big_query<Brandubh><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, kind, temp, arg, m->d_f, m->d_u); break;
+    case AZMI_GAME_STARGAMBIT: k_mcts_big_query<StarGambit><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, kind, temp, arg, m->d_f, m->d_u); break;
     default: k_mcts_big_query<OpenTafl><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, kind, temp, arg, m->d_f, m->d_u); break;
   }
   if (out_f) HIP_TRY(hipMemcpyAsync(out_f, m->d_f, static_cast<size_t>(m->vec) * 4, hipMemcpyDeviceToHost, st));

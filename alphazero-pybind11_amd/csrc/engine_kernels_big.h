@@ -17,19 +17,32 @@
 
 #include "dev_games.h"
 #include "dev_rng.h"
+#include "dev_stargambit.h"
 #include "engine_kernels.h"
 #include "engine_types.h"
 
 namespace azmi {
 
+// StarGambit (dev_stargambit.h) rides in the same engine: its units are lane-resident, its rules are wave-cooperative
+// (they need their own LDS scratch), its position history lives in HBM (ar.rep_list / ar.rep_path: one entry per ACTION, up
+// to thousands) instead of LDS, and it adds relative values, variants and multi-action turns.  Every difference is an
+// `if constexpr (kSG)` branch below; the Tafl instantiations compile to what they were.
+template <class GM> struct is_stargambit { static constexpr bool value = false; };
+template <> struct is_stargambit<StarGambit> { static constexpr bool value = true; };
+struct NoRulesScratch {};
+template <class GM, bool SG = is_stargambit<GM>::value> struct RulesScratch { using type = NoRulesScratch; };
+template <class GM> struct RulesScratch<GM, true> { using type = SgScratch; };
+
 template <class GM>
 struct BigScratch {  // per-wave LDS
+  static constexpr int kRepLds = is_stargambit<GM>::value ? 1 : GM::MAX_TURNS + 2;
   uint16_t moves[GM::MAXK];
   float f0[GM::MAXK], f1[GM::MAXK], f2[GM::MAXK];
   uint32_t n[GM::MAXK];
   float dense[GM::M];
-  uint64_t glist[GM::MAX_TURNS + 2];  // game repetition list (since the last capture)
-  uint64_t plist[GM::MAX_TURNS + 2];  // path-local repetition list of the running descent
+  uint64_t glist[kRepLds];  // game repetition list (since the last capture)
+  uint64_t plist[kRepLds];  // path-local repetition list of the running descent
+  typename RulesScratch<GM>::type rules;
 };
 
 #define AZB_SEL(arr, seat) ((seat) == 0 ? arr[0] : arr[P > 1 ? 1 : 0])
@@ -37,6 +50,7 @@ template <class GM>
 struct BigSlot {
   static_assert(GM::P == 2, "the wide-game engine is written for two-player games (first-visit value, resign entries)");
   static constexpr int G = 64, P = GM::P, M = GM::M, MAXK = GM::MAXK;
+  static constexpr bool kSG = is_stargambit<GM>::value;
   const EngineParams& ep;
   const EngineArrays& ar;
   BigScratch<GM>& sm;
@@ -93,11 +107,15 @@ struct BigSlot {
   __device__ __forceinline__ void load() {
     rng.state = ar.rng[slot]; coin.state = ar.coin[slot]; flags = ar.flags[slot];
     const uint32_t S = ep.S;
-    const uint64_t w0 = ar.gs_words[0 * S + slot], w1 = ar.gs_words[1 * S + slot], w2 = ar.gs_words[2 * S + slot],
-                   w3 = ar.gs_words[3 * S + slot], w4 = ar.gs_words[4 * S + slot];
-    gs.def[0] = w0; gs.def[1] = w1; gs.atk[0] = w2; gs.atk[1] = w3;
-    gs.king = static_cast<uint32_t>(w4) & 0x7Fu; gs.turn = static_cast<uint32_t>(w4 >> 8) & 0xFFFFu;
-    gs.player = static_cast<uint32_t>(w4 >> 24) & 1u; gs.rep = static_cast<uint32_t>(w4 >> 32) & 0xFFu;
+    if constexpr (kSG) {
+      gs = GM::load_words(ar.gs_words, S, slot, lane);
+    } else {
+      const uint64_t w0 = ar.gs_words[0 * S + slot], w1 = ar.gs_words[1 * S + slot], w2 = ar.gs_words[2 * S + slot],
+                     w3 = ar.gs_words[3 * S + slot], w4 = ar.gs_words[4 * S + slot];
+      gs.def[0] = w0; gs.def[1] = w1; gs.atk[0] = w2; gs.atk[1] = w3;
+      gs.king = static_cast<uint32_t>(w4) & 0x7Fu; gs.turn = static_cast<uint32_t>(w4 >> 8) & 0xFFFFu;
+      gs.player = static_cast<uint32_t>(w4 >> 24) & 1u; gs.rep = static_cast<uint32_t>(w4 >> 32) & 0xFFu;
+    }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const uint32_t t = slot * P + p;
@@ -110,18 +128,23 @@ struct BigSlot {
       const uint32_t* rec = ar.seat_tab + (static_cast<size_t>(perm) * P + p) * kSeatWords;
       sv_w0[p] = rec[0]; sv_w1[p] = rec[1]; sv_eps[p] = __uint_as_float(rec[2]); sv_rt[p] = __uint_as_float(rec[3]);
     }
-    const uint64_t* gl = ar.rep_list + static_cast<size_t>(slot) * (GM::MAX_TURNS + 2);
-    for (uint32_t i = lane; i < glen; i += G) sm.glist[i] = gl[i];
+    if constexpr (!kSG) {
+      const uint64_t* gl = ar.rep_list + static_cast<size_t>(slot) * (GM::MAX_TURNS + 2);
+      for (uint32_t i = lane; i < glen; i += G) sm.glist[i] = gl[i];
+    }
     sync();
   }
   __device__ __forceinline__ void store(uint8_t sstate) const {
+    if constexpr (kSG) GM::store_words(ar.gs_words, ep.S, slot, lane, gs);
     if (lane != 0) return;
     ar.rng[slot] = rng.state; ar.coin[slot] = coin.state; ar.flags[slot] = flags; ar.sstate[slot] = sstate;
     const uint32_t S = ep.S;
-    ar.gs_words[0 * S + slot] = gs.def[0]; ar.gs_words[1 * S + slot] = gs.def[1];
-    ar.gs_words[2 * S + slot] = gs.atk[0]; ar.gs_words[3 * S + slot] = gs.atk[1];
-    ar.gs_words[4 * S + slot] = static_cast<uint64_t>(gs.king) | (static_cast<uint64_t>(gs.turn) << 8) |
-                                (static_cast<uint64_t>(gs.player) << 24) | (static_cast<uint64_t>(gs.rep) << 32);
+    if constexpr (!kSG) {
+      ar.gs_words[0 * S + slot] = gs.def[0]; ar.gs_words[1 * S + slot] = gs.def[1];
+      ar.gs_words[2 * S + slot] = gs.atk[0]; ar.gs_words[3 * S + slot] = gs.atk[1];
+      ar.gs_words[4 * S + slot] = static_cast<uint64_t>(gs.king) | (static_cast<uint64_t>(gs.turn) << 8) |
+                                  (static_cast<uint64_t>(gs.player) << 24) | (static_cast<uint64_t>(gs.rep) << 32);
+    }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const uint32_t t = slot * P + p;
@@ -140,8 +163,41 @@ struct BigSlot {
 
   // ---- repetition-aware move on a state; `list`/`len` is the list the new position is appended to --------
   // base list = glist[0, glen) unless a capture cleared it (tawlbwrdd_gs.cc:246-332)
+  __device__ __forceinline__ uint64_t* game_list() const {
+    if constexpr (kSG) return ar.rep_list + static_cast<size_t>(slot) * (GM::MAX_TURNS + 2); else return sm.glist;
+  }
+  __device__ __forceinline__ uint64_t* path_list() const {
+    if constexpr (kSG) return ar.rep_path + static_cast<size_t>(slot) * (GM::MAX_TURNS + 2); else return sm.plist;
+  }
+  // StarGambit: the position history as the rules see it (dev_stargambit.h apply_move): `list[0, len)` is the list being
+  // written - the game's own list (ar.rep_list) when a move is played, the path-local tail (ar.rep_path) during a descent,
+  // which also counts the game's list [0, base_len) until a deploy on the path clears it (star_gambit_gs.cc:1054)
+  struct SgRep {
+    BigSlot& c; uint64_t* list; uint32_t& len; bool& base_valid; uint32_t base_len; bool is_game; bool overflow = false;
+    __device__ __forceinline__ void clear() { len = 0; base_valid = false; }
+    __device__ __forceinline__ uint32_t push(unsigned long long k) {
+      uint32_t cnt = 0;
+      for (uint32_t i = c.lane; i < len; i += G) cnt += list[i] == k;
+      if (base_valid && !is_game) {
+        const uint64_t* gl = c.ar.rep_list + static_cast<size_t>(c.slot) * (GM::MAX_TURNS + 2);
+        for (uint32_t i = c.lane; i < base_len; i += G) cnt += gl[i] == k;
+      }
+      cnt = c.wave_sum(cnt) + 1;
+      if (len >= static_cast<uint32_t>(GM::MAX_TURNS + 1)) { overflow = true; return cnt; }
+      if (c.lane == 0) list[len] = k;
+      ++len;
+      c.sync();
+      return cnt;
+    }
+  };
   __device__ __forceinline__ bool step_state(typename GM::State& st, uint32_t mv, uint64_t* list, uint32_t& len, bool& base_valid,
                              uint32_t base_len) {
+    if constexpr (kSG) {
+      SgRep r{*this, list, len, base_valid, base_len, list == game_list()};
+      GM::apply_move(st, mv, lane, sm.rules, r);
+      if (r.overflow) { raise(8u); return false; }
+      return true;
+    } else {
     if (st.turn == 0) {  // the start position enters the map with count 1 at the first move
       if (lane == 0) list[len] = GM::rep_key(st);
       ++len;
@@ -162,14 +218,20 @@ struct BigSlot {
     st.rep = cnt;
     sync();
     return true;
+    }
   }
 
   // ---- Node::add_children: legal moves ascending (from the bitboards), std::shuffle, append -------------
   __device__ __forceinline__ bool expand_node(uint32_t seat, uint32_t node, const typename GM::State& st, uint64_t meta_keep,
                               uint32_t& c0_out, uint32_t& k_out) {
     const size_t tb = tree_base(seat);
-    // move generation: lane handles squares lane and lane + 64
     uint32_t base = 0;
+    if constexpr (kSG) {   // legal moves in ascending order from the dense bit map (dev_stargambit.h)
+      GM::gen_valid(st, lane, sm.rules);
+      base = GM::list_valid(lane, sm.rules, sm.moves, static_cast<uint32_t>(MAXK));
+      if (base > static_cast<uint32_t>(MAXK)) { raise(8u); return false; }
+    } else {
+    // move generation: lane handles squares lane and lane + 64
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const uint32_t sq = half * 64 + lane;
@@ -191,6 +253,7 @@ struct BigSlot {
         sm.moves[pos++] = static_cast<uint16_t>(sq * (GM::W + GM::H) + b);
       }
       base += total;
+    }
     }
     const uint32_t k = base;
     sync();
@@ -499,7 +562,7 @@ struct BigSlot {
       cur = c0 + best;
       n = ar.N[tb + cur];
       meta = ar.META[tb + cur];
-      if (!step_state(leaf, meta_mv(meta), sm.plist, path_len, base_valid, glen)) { raise(64u); return false; }
+      if (!step_state(leaf, meta_mv(meta), path_list(), path_len, base_valid, glen)) { raise(64u); return false; }
     }
     leaf_rep_len = path_len; leaf_base_valid = base_valid;
 #pragma unroll
@@ -538,7 +601,7 @@ struct BigSlot {
       n = ar.N[tb + cur];
       nf = nif[cur];
       meta = ar.META[tb + cur];
-      if (!step_state(leaf, meta_mv(meta), sm.plist, path_len, base_valid, glen)) { raise(64u); return false; }
+      if (!step_state(leaf, meta_mv(meta), path_list(), path_len, base_valid, glen)) { raise(64u); return false; }
     }
     if (lane == 0) nif[cur] = nf + 1;
 #pragma unroll
@@ -605,6 +668,33 @@ struct BigSlot {
     uint32_t rep_len = leaf_rep_len;
     bool base_valid = leaf_base_valid;
     uint32_t term = GM::terminal(sim);
+    if constexpr (kSG) {
+      while (term == 0) {
+        const uint32_t k = GM::gen_valid(sim, lane, sm.rules);
+        if (k == 0) break;
+        const uint32_t r = lemire_below(roll, k);
+        // the r-th set bit of the map, in ascending move order
+        const unsigned long long w = lane < 27 ? sm.rules.vbits[lane] : 0ull;
+        const uint32_t cnt = static_cast<uint32_t>(__builtin_popcountll(w));
+        uint32_t in = cnt;
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t o = __shfl_up(in, off, 64);
+          if (lane >= static_cast<uint32_t>(off)) in += o;
+        }
+        const uint32_t lo = in - cnt;
+        uint32_t mine = 0xFFFFFFFFu;
+        if (r >= lo && r < lo + cnt) {
+          unsigned long long m = w;
+          for (uint32_t j = lo; j < r; ++j) m &= m - 1;
+          mine = lane * 64 + static_cast<uint32_t>(__builtin_ctzll(m));
+        }
+        const uint64_t owner = __ballot(mine != 0xFFFFFFFFu);
+        const uint32_t mv = __shfl(mine, static_cast<int>(__builtin_ctzll(owner)), 64);
+        sync();
+        if (!step_state(sim, mv, path_list(), rep_len, base_valid, glen)) break;
+        term = GM::terminal(sim);
+      }
+    } else {
     while (term == 0) {
       uint32_t mask[2], cnt[2], incl[2], total[2];
 #pragma unroll
@@ -638,6 +728,7 @@ struct BigSlot {
       if (!step_state(sim, mv, sm.plist, rep_len, base_valid, glen)) break;
       term = GM::terminal(sim);
     }
+    }
     if (lane <= static_cast<uint32_t>(P))
       ar.v[static_cast<size_t>(slot) * (P + 1) + lane] = term ? ((term - 1 == lane) ? 1.0f : 0.0f) : static_cast<float>(1.0 / (P + 1));
     if (lane == 0) ar.roll[slot] = roll.state;
@@ -663,6 +754,9 @@ struct BigSlot {
       } else {
 #pragma unroll
         for (int i = 0; i <= P; ++i) val[i] = static_cast<float>(1.0 / (P + 1));
+      }
+      if constexpr (GM::kRelative) {   // relative_to_absolute(value, current_->player), mcts.cc:522-524, game_state.h:37-46 (P == 2: a swap)
+        if (meta_player(meta) == 1) { const float t = val[0]; val[0] = val[1]; val[1] = t; }
       }
       const float ksum = static_cast<float>(k & 0xFFu);  // dumb_eval: u8 sum wraps (game_state.h:167, shapes.h:14)
       const bool pi_rows = from_net && !seat_eval_playout(seat);   // a PLAYOUT seat's rows hold the rollout's scores only
@@ -866,10 +960,17 @@ struct BigSlot {
   }
 
   __device__ __forceinline__ void start_game() {
-    gs = GM::initial();
+    if constexpr (kSG) {   // randomize_start(): the variant of the new game, then its constructor's history entry (star_gambit_gs.cc:289)
+      gs = GM::initial(GM::pick_variant(ep.sg_pinned, ep.sg_probs, coin), lane);
+      const unsigned long long h0 = GM::position_hash(gs);
+      if (lane == 0) game_list()[0] = h0;
+      glen = 1;
+    } else {
+      gs = GM::initial();
+      glen = 0;
+    }
     for (uint32_t s = 0; s < static_cast<uint32_t>(P); ++s) reset_tree(s);
     ph_rows = 0;
-    glen = 0;
   }
   __device__ __forceinline__ void draw_capped() {
     const bool capped = ep.cap_rand && (canonical01(coin) < ep.cap_percent);
@@ -887,8 +988,13 @@ struct BigSlot {
     stage_root(tb, c0, k);
 
     float temp = ep.start_temp;
-    if (ep.half_life != 0) {
-      const float lambda = 0.693f / ep.half_life;
+    float half_life = ep.half_life;
+    if constexpr (kSG) {   // temp_decay_half_life_by_variant, play_manager.cc:290-296
+      const uint32_t vid = GM::variant(gs);
+      if (vid < ep.n_half_life_v) half_life = vid == 0 ? ep.half_life_v[0] : vid == 1 ? ep.half_life_v[1] : vid == 2 ? ep.half_life_v[2] : ep.half_life_v[3];
+    }
+    if (half_life != 0) {
+      const float lambda = 0.693f / half_life;
       temp -= ep.final_temp;
       temp *= az_expf(-lambda * gs.turn);
       temp += ep.final_temp;
@@ -988,8 +1094,12 @@ struct BigSlot {
       else if (ep.pruning && seat_eps(cp) > 0) probs_pruned(1.0f, root_n, k); else probs(1.0f, k);
       const uint32_t r = ph_rows;
       if (r < ep.max_hist_rows) {
-        float* crow = ar.ph_canon + (static_cast<size_t>(slot) * ep.max_hist_rows + r) * GM::CANON;
-        for (uint32_t e = lane; e < static_cast<uint32_t>(GM::CANON); e += G) crow[e] = GM::canonical_at(gs, e);
+        if constexpr (kSG) {   // pending rows hold the packed position (16 u64 words); the planes are written when the game's rows are committed
+          GM::store_words(reinterpret_cast<uint64_t*>(ar.ph_canon) + (static_cast<size_t>(slot) * ep.max_hist_rows + r) * kSgPendWords, 1, 0, lane, gs);
+        } else {
+          float* crow = ar.ph_canon + (static_cast<size_t>(slot) * ep.max_hist_rows + r) * GM::CANON;
+          for (uint32_t e = lane; e < static_cast<uint32_t>(GM::CANON); e += G) crow[e] = GM::canonical_at(gs, e);
+        }
         float* prow = ar.ph_pi + (static_cast<size_t>(slot) * ep.max_hist_rows + r) * M;
         for (uint32_t m = lane; m < static_cast<uint32_t>(M); m += G) prow[m] = sm.dense[m];
         if (lane == 0) {
@@ -1033,10 +1143,12 @@ struct BigSlot {
       if (!update_root(s, chosen)) return true;
     {
       bool base_valid = true;
-      if (!step_state(gs, chosen, sm.glist, glen, base_valid, 0)) { raise(64u); return true; }
-      // persist the game's repetition list (whole list: a capture may have cleared it)
-      uint64_t* gl = ar.rep_list + static_cast<size_t>(slot) * (GM::MAX_TURNS + 2);
-      for (uint32_t i = lane; i < glen; i += G) gl[i] = sm.glist[i];
+      if (!step_state(gs, chosen, game_list(), glen, base_valid, 0)) { raise(64u); return true; }
+      if constexpr (!kSG) {
+        // persist the game's repetition list (whole list: a capture may have cleared it)
+        uint64_t* gl = ar.rep_list + static_cast<size_t>(slot) * (GM::MAX_TURNS + 2);
+        for (uint32_t i = lane; i < glen; i += G) gl[i] = sm.glist[i];
+      }
     }
     uint32_t term = GM::terminal(gs);
     bool resigned = false;
@@ -1089,10 +1201,26 @@ struct BigSlot {
           const uint32_t sr = seg == 0 ? 0u : n1, nr = seg == 0 ? n1 : rows - n1;
           if (nr == 0) continue;
           const size_t dst0 = seg == 0 ? first : 0u;
-          flat_copy(ar.ph_canon + (src0 + sr) * GM::CANON, ar.h_canon + dst0 * GM::CANON, static_cast<size_t>(nr) * GM::CANON);
+          if constexpr (kSG) {
+            for (uint32_t r = 0; r < nr; ++r) {
+              const typename GM::State ps = GM::load_words(reinterpret_cast<const uint64_t*>(ar.ph_canon) + (src0 + sr + r) * kSgPendWords, 1, 0, lane);
+              GM::write_canonical(ps, ar.h_canon + (dst0 + r) * GM::CANON, lane, sm.rules);
+            }
+          } else {
+            flat_copy(ar.ph_canon + (src0 + sr) * GM::CANON, ar.h_canon + dst0 * GM::CANON, static_cast<size_t>(nr) * GM::CANON);
+          }
           flat_copy(ar.ph_pi + (src0 + sr) * M, ar.h_pi + dst0 * M, static_cast<size_t>(nr) * M);
           float* dv = ar.h_v + dst0 * (P + 1);
-          for (uint32_t e = lane; e < nr * (P + 1); e += G) dv[e] = (e % (P + 1) == term - 1) ? 1.0f : 0.0f;
+          if constexpr (GM::kRelative) {   // absolute_to_relative(scores, pending.player), play_manager.cc:451-454 (P == 2: a swap)
+            for (uint32_t e = lane; e < nr * (P + 1); e += G) {
+              const uint32_t rr = e / (P + 1), ent = e % (P + 1);
+              const uint32_t pl = ar.ph_meta[(src0 + sr + rr) * 2];
+              const uint32_t abs_ent = (ent < static_cast<uint32_t>(P) && pl == 1) ? 1u - ent : ent;
+              dv[e] = (abs_ent == term - 1) ? 1.0f : 0.0f;
+            }
+          } else {
+            for (uint32_t e = lane; e < nr * (P + 1); e += G) dv[e] = (e % (P + 1) == term - 1) ? 1.0f : 0.0f;
+          }
           for (uint32_t r = lane; r < nr; r += G) {
             const uint32_t* pm = ar.ph_meta + (src0 + sr + r) * 2;
             uint32_t* hm = ar.h_meta + (dst0 + r) * 4;
@@ -1117,6 +1245,16 @@ struct BigSlot {
 #pragma unroll
       for (int j = 0; j < 3; ++j) gc[j] = ar.g_cnt[j * S + slot];
       atomicAdd(reinterpret_cast<unsigned long long*>(&ar.a_len[slot]), static_cast<unsigned long long>(gs.turn));
+      if constexpr (kSG) {   // per-variant tables, play_manager.cc:468-484
+        const size_t sv = static_cast<size_t>(slot) * 4 + GM::variant(gs);
+        atomicAdd(&ar.a_var_scores[(sv * ep.num_perms + perm) * (P + 1) + (term - 1)], 1.0f);
+        atomicAdd(&ar.a_var_games[sv * ep.num_perms + perm], 1u);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&ar.a_var_len[sv]), static_cast<unsigned long long>(gs.turn));
+#pragma unroll
+        for (int j = 0; j < 5; ++j) atomicAdd(&ar.a_var_dsum[sv * 5 + j], gd[j]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) atomicAdd(reinterpret_cast<unsigned long long*>(&ar.a_var_cnt[sv * 3 + j]), static_cast<unsigned long long>(gc[j]));
+      }
 #pragma unroll
       for (int j = 0; j < 5; ++j) { atomicAdd(&ar.a_dsum[j * S + slot], gd[j]); ar.g_dsum[j * S + slot] = 0.0; }
 #pragma unroll
@@ -1129,8 +1267,14 @@ struct BigSlot {
 
   __device__ __forceinline__ uint64_t emit_leaf(const typename GM::State& leaf) const {
     float* row = ar.canon + static_cast<size_t>(slot) * GM::CANON;
-    for (uint32_t e = lane; e < static_cast<uint32_t>(GM::CANON); e += G) row[e] = GM::canonical_at(leaf, e);
-    const uint64_t key = GM::key(leaf);
+    uint64_t key;
+    if constexpr (kSG) {
+      GM::write_canonical(leaf, row, lane, sm.rules);
+      key = GM::key(leaf, lane);
+    } else {
+      for (uint32_t e = lane; e < static_cast<uint32_t>(GM::CANON); e += G) row[e] = GM::canonical_at(leaf, e);
+      key = GM::key(leaf);
+    }
     if (lane == 0) ar.leaf_key[slot] = key;
     return key;
   }

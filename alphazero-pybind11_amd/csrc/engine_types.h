@@ -65,6 +65,12 @@ struct EngineParams {  // run constants (PlayParams, play_manager.h:60-154, afte
   // (k_compact) once the active half holds more than `compact_above` nodes after a move. 0 = one flat arena.
   uint32_t half_nodes, compact_above;
   uint32_t num_perms, num_groups;   // seat permutations / model groups (play_manager.cc:24-113)
+  // games with variants (StarGambitUnifiedGS): the base game's pinned variant / variant weights (star_gambit_gs.h:828-830) and
+  // temp_decay_half_life_by_variant (play_manager.h:87-90; n_half_life_v entries)
+  int32_t sg_pinned;
+  float sg_probs[4];
+  uint32_t n_half_life_v;
+  float half_life_v[4];
 };
 
 // per (permutation, seat) record of ar.seat_tab, 8 words: visits | cap_visits + flags | epsilon | root temp |
@@ -80,6 +86,7 @@ __host__ __device__ inline uint32_t seat_w1_pack(uint32_t cap_visits, uint32_t f
   return (cap_visits & 0xFFFFFFu) | (fpu_zero << 24) | (eval_random << 25) | (group << 26) | (eval_playout << 28);
 }
 
+constexpr uint32_t kSgPendWords = 16;   // StarGambit pending history row: the packed position (11 state words), 128 B apart
 constexpr uint32_t kPendingWords = 3;   // Connect4 pending history row: stones of player 0, of player 1, turn | player << 32
 
 // One tree node of the lane-group engine (Connect4) — struct Node, mcts.h:14-48, as one 32-byte record: the descent reads a
@@ -199,6 +206,14 @@ struct EngineArrays {
   uint64_t* roll;           // [S] rollout stream of EvalType::PLAYOUT seats (game_state.cc:56-59)
   uint32_t* resign_streak;  // [S][P] GameData::resign_streak (kept from one game of the slot to the next, like the reference)
   const CacheView* caches;  // [groups] one S3-FIFO per model group (play_manager.cc:195-203); `cache` = caches[0]
+  // ---- StarGambit (games with variants and multi-action turns) ------------------------------------------------------
+  uint64_t* rep_path;       // [S][max_turns + 2] position history of the running descent (path-local tail of rep_list)
+  // committed per-variant totals of the slot's finished games (play_manager.cc:468-484), NULL for games without variants
+  float* a_var_scores;      // [S][4][perms][P+1]  (variant_perm_scores; variant_scores = sum over perms)
+  uint32_t* a_var_games;    // [S][4][perms]
+  uint64_t* a_var_len;      // [S][4]
+  double* a_var_dsum;       // [S][4][5]
+  uint64_t* a_var_cnt;      // [S][4][3]
 };
 
 }  // namespace azmi

@@ -278,6 +278,32 @@ namespace azmi {
 
 template <class GM>
 __device__ __forceinline__ bool mcts_big_replay(BigSlot<GM>& c, const uint8_t* init, uint32_t init_stride, const int32_t* moves, uint32_t len) {
+  if constexpr (is_stargambit<GM>::value) {
+    // the root is always given as the reference's pickle image (dev_stargambit.h sg_parse_image): units, flags and the
+    // position history; moves are checked against valid_moves() before they are played
+    uint64_t* gl = c.game_list();
+    if (init) {
+      uint32_t n = 0;
+      if (!sg_parse_image(init, init_stride, c.lane, c.gs, gl, n, static_cast<uint32_t>(GM::MAX_TURNS))) return false;
+      c.glen = n;
+    } else {
+      c.gs = GM::initial(0, c.lane);
+      const unsigned long long h0 = GM::position_hash(c.gs);
+      if (c.lane == 0) gl[0] = h0;
+      c.glen = 1;
+    }
+    c.sync();
+    for (uint32_t i = 0; i < len; ++i) {
+      const int32_t mv = moves[i];
+      if (mv < 0) break;
+      GM::gen_valid(c.gs, c.lane, c.sm.rules);
+      if (!GM::is_valid_bit(c.sm.rules, static_cast<uint32_t>(mv))) return false;
+      c.sync();
+      bool base_valid = true;
+      if (!c.step_state(c.gs, static_cast<uint32_t>(mv), gl, c.glen, base_valid, 0)) return false;
+    }
+    return true;
+  } else {
   c.glen = 0;
   if (init) {       // the reference pickle image (dev_games.h TaflImage): position + repetition keys
     uint32_t n = 0;
@@ -297,6 +323,7 @@ __device__ __forceinline__ bool mcts_big_replay(BigSlot<GM>& c, const uint8_t* i
     if (!c.step_state(c.gs, static_cast<uint32_t>(mv), c.sm.glist, c.glen, base_valid, 0)) return false;
   }
   return true;
+  }
 }
 
 template <class GM>

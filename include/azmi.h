@@ -36,7 +36,10 @@ typedef enum azmi_status {
 } azmi_status;
 
 /* game ids (reference GAME_REGISTRY, config.py:17-35) */
-typedef enum azmi_game { AZMI_GAME_CONNECT4 = 0, AZMI_GAME_TAWLBWRDD = 1, AZMI_GAME_BRANDUBH = 2, AZMI_GAME_OPENTAFL = 3 } azmi_game;
+typedef enum azmi_game { AZMI_GAME_CONNECT4 = 0, AZMI_GAME_TAWLBWRDD = 1, AZMI_GAME_BRANDUBH = 2, AZMI_GAME_OPENTAFL = 3,
+                         /* StarGambitUnifiedGS (star_gambit_gs.h:788-887): four variants on the 13 x 13 canvas, 36 planes, 1709 moves,
+                          * relative values, several actions per turn */
+                         AZMI_GAME_STARGAMBIT = 4 } azmi_game;
 
 /* EvalType, play_manager.h:20 */
 typedef enum azmi_eval_type { AZMI_EVAL_NN = 0, AZMI_EVAL_RANDOM = 1, AZMI_EVAL_PLAYOUT = 2 } azmi_eval_type;
@@ -113,6 +116,10 @@ typedef struct azmi_play_params {
   float seat_gumbel_c_visit[AZMI_MAX_PERMS][AZMI_MAX_PLAYERS];
   float seat_gumbel_c_scale[AZMI_MAX_PERMS][AZMI_MAX_PLAYERS];
   float seat_resign_threshold[AZMI_MAX_PERMS][AZMI_MAX_PLAYERS];
+  /* temp_decay_half_life_by_variant (play_manager.h:87-90, play_manager.cc:290-296): entry get_variant_id() replaces
+   * temp_decay_half_life when it exists; games without variants (id -1) ignore it */
+  uint32_t num_temp_decay_half_life_by_variant;
+  float temp_decay_half_life_by_variant[4];
 } azmi_play_params;
 
 /* engine-only knobs that have no reference counterpart */
@@ -124,6 +131,11 @@ typedef struct azmi_engine_opts {
   uint32_t history_capacity; /* rows of the device history buffer; 0 = sized from params */
   int32_t log_moves;      /* keep a per-move log (parity tests) */
   uint32_t move_log_capacity;
+  /* the base GameState of PlayManager(gs, params) where it has constructor arguments: StarGambitUnifiedGS(pinned_variant,
+   * probs) (py_wrapper.cc:662-667; defaults -1 and four times 0.25).  Every new game draws its variant from the slot's coin
+   * stream unless pinned (build-defined draw: the reference's engine is unseedable, star_gambit_gs.cc:2357-2362) */
+  int32_t sg_pinned_variant;
+  float sg_variant_probs[4];
 } azmi_engine_opts;
 
 typedef struct azmi_pm azmi_pm;
@@ -226,6 +238,13 @@ int azmi_pm_build_batch(azmi_pm* pm, float* batch, uint32_t cap, uint32_t* indic
 /* update_inferences(group, indices, v, pi) — play_manager.cc:619-642, HOST arrays */
 int azmi_pm_update_inferences(azmi_pm* pm, const uint32_t* indices, uint32_t n, const float* v, const float* pi);
 
+/* per-variant tables of a game with variants (play_manager.h:218-275; play_manager.cc:237-255, 468-484).
+ * azmi_pm_num_variants: num_tracked_variants().  azmi_pm_variant_sums(v): perm_scores [perms][P+1] (variant_perm_scores; their
+ * sum over perms = variant_scores), perm_games [perms], sums[10] = game_length, games, total / full / fast move counts, leaf
+ * depth, entropy, fast leaf depth, fast entropy, valid moves - the accumulators behind the variant_avg_* getters */
+uint32_t azmi_pm_num_variants(azmi_pm* pm);
+int azmi_pm_variant_sums(azmi_pm* pm, uint32_t variant, float* perm_scores, uint32_t* perm_games, double* sums);
+
 /* ---- GameState / MCTS single-object surface on the device (py_wrapper.cc:157-220) ----------
  * Batched over `n` independent states so one launch covers many objects. Used by the
  * parity tests of the rules kernels (SURVEY tier T0). `moves` is [n, len] row-major; a
@@ -240,7 +259,9 @@ int azmi_game_replay(int game, int device, const int32_t* moves, uint32_t n, uin
  * board[2][6][7], int8 player, int32 turn = 89 bytes; Connect4GS(board, player, turn) ctor,
  * py_wrapper.cc:563-581).  Brandubh / OpenTafl: int8 board[3][N][N] (king, defenders, attackers), int8 player,
  * int32 turn = 3*N*N + 5 bytes, with an empty repetition map (the reference tests' MakeGS helper,
- * opentafl_gs_test.cc:97-101).  NULL = the game's initial position. */
+ * opentafl_gs_test.cc:97-101).  StarGambit: StarGambitUnifiedGS::to_bytes (star_gambit_gs.cc:2446-2449 around the inner image
+ * :2246-2251), any length up to init_stride, rows padded with zeros; its replay/playout kernels take one wavefront per game.
+ * NULL = the game's initial position (StarGambit: the Skirmish variant). */
 int azmi_game_replay_from(int game, int device, const uint8_t* init, uint32_t init_stride, const int32_t* moves,
                           uint32_t n, uint32_t len, uint8_t* valid, float* scores, float* canonical,
                           uint32_t* player, uint32_t* turn, uint64_t* key, int32_t* status);
@@ -257,6 +278,13 @@ int azmi_playout_eval(int game, int device, const uint8_t* init, uint32_t init_s
 int azmi_game_replay_ex(int game, int device, const uint8_t* init, uint32_t init_stride, const int32_t* moves,
                         uint32_t n, uint32_t len, uint8_t* valid, float* scores, float* canonical,
                         uint32_t* player, uint32_t* turn, uint64_t* key, int32_t* status, uint32_t flags);
+
+/* StarGambitUnifiedGS::to_bytes (star_gambit_gs.cc:2451-2465; py::pickle of the game objects, py_wrapper.cc:77-83) of n
+ * states given as start image + moves (as azmi_game_replay_from; flags as azmi_game_replay_ex): out [n, out_stride] bytes,
+ * out_len [n] image sizes, status [n] (0 ok, -1 illegal move / malformed start, -2 image longer than out_stride).  The
+ * variant_probs / pinned_variant fields of the header (bytes 0-19) are left zero: they are constructor arguments the caller keeps. */
+int azmi_sg_image(int device, const uint8_t* init, uint32_t init_stride, const int32_t* moves, uint32_t n, uint32_t len,
+                  uint8_t* out, uint32_t out_stride, uint32_t* out_len, int32_t* status, uint32_t flags);
 
 /* ---- training-sample symmetries (GameState::symmetries(PlayHistory), py_wrapper.cc:178;
  *      connect4_gs.cc:151-170, tafl_helper.h:16-149, tawlbwrdd_gs.cc:455-458) ------------------
