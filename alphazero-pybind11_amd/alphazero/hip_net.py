@@ -21,7 +21,7 @@ from .torch_net import bn_affine
 class NetDescC(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("in_channels", "height", "width", "channels", "depth", "kernel_size",
                                          "head_channels", "v_hidden", "num_moves", "num_players", "v_head_convs",
-                                         "pi_head_convs", "v_fc_layers", "policy_channels", "precision")]
+                                         "pi_head_convs", "v_fc_layers", "policy_channels", "precision", "pi_hidden")]
 
 
 lib.azmi_net_blob_bytes.restype = C.c_size_t
@@ -89,7 +89,7 @@ def _fold_trunk(net, sd, Cin):
     blob = bytearray()
     a, b = (t.cpu() for t in bn_affine(net.bn1))
     w = sd["conv1.weight"] * a[:, None, None, None]
-    wm = np.zeros((64, 64 * ((9 * Cin + 63) // 64)))     # im2col rows in passes of 64 (spatial kernel: up to two)
+    wm = np.zeros((64, 64 * ((9 * Cin + 63) // 64)))     # im2col rows in passes of 64 (StarGambit's 36 planes: six)
     wm[: w.shape[0], : 9 * Cin] = w.permute(0, 2, 3, 1).reshape(w.shape[0], 9 * Cin).numpy()
     blob += _frags(wm) + _f32(_pad(b, 64))
     for i, blk in enumerate(net.conv_layers):
@@ -111,10 +111,10 @@ def fold_spatial(net):
     spec = net.spec
     Cin, H, W = spec.in_shape
     if not (spec.num_channels <= 64 and spec.head_channels <= 64 and spec.kernel_size == 3 and spec.head_pool
-            and spec.v_head_convs == 1 and spec.pi_head_convs == 1 and 9 * Cin <= 128 and (H, W) in ((11, 11), (7, 7))):
-        raise RuntimeError("the bf16 MFMA spatial-head kernel covers the configs/tawlbwrdd.yaml, configs/open_tafl.yaml and "
-                           "configs/brandubh.yaml nets (11x11 or 7x7, <= 64 trunk / head channels, one extra conv per head, "
-                           "9*C_in <= 128); use precision='fp32' for other shapes")
+            and spec.v_head_convs == 1 and spec.pi_head_convs == 1 and (H, W) in ((11, 11), (7, 7), (13, 13))):
+        raise RuntimeError("the bf16 MFMA spatial-head kernel covers the configs/tawlbwrdd.yaml, configs/open_tafl.yaml, "
+                           "configs/brandubh.yaml and configs/star_gambit_unified.yaml nets (11x11, 7x7 or 13x13, <= 64 trunk / head "
+                           "channels, one extra conv per head); use precision='fp32' for other shapes")
     pc = spec.policy_shape[0]
     Hd, L, P1 = spec.v_fc_hidden, spec.v_fc_layers, spec.num_players + 1
     sd = {k: v.detach().double().cpu() for k, v in net.state_dict().items()}
@@ -136,7 +136,13 @@ def fold_spatial(net):
     for l in range(L - 1):
         blob += _f32(sd[f"v_fc_extra.{2 * l}.bias"])
     blob += _f32_frags(_pad(sd["v_fc2.weight"], 16, Hd).numpy()) + _f32(_pad(sd["v_fc2.bias"], 16))
-    desc = NetDescC(Cin, H, W, 64, spec.depth, 3, 64, Hd, spec.num_moves, spec.num_players, 1, 1, L, pc, 0)
+    G = spec.num_moves - pc * H * W
+    Hp = spec.pi_fc_hidden if G > 0 else 0
+    if G > 0:   # pi_global (neural_net.py:421-426): W1^T [64][Hp] (head channels zero-padded to 64), b1, W2^T [Hp][32], b2, LayerNorm g / b
+        blob += _f32(_pad(sd["pi_global.0.weight"], Hp, 64).t().contiguous()) + _f32(sd["pi_global.0.bias"])
+        blob += _f32(_pad(sd["pi_global.2.weight"], 32, Hp).t().contiguous()) + _f32(_pad(sd["pi_global.2.bias"], 32))
+        blob += _f32(_pad(sd["pi_global.3.weight"], 32)) + _f32(_pad(sd["pi_global.3.bias"], 32))
+    desc = NetDescC(Cin, H, W, 64, spec.depth, 3, 64, Hd, spec.num_moves, spec.num_players, 1, 1, L, pc, 0, Hp)
     assert len(blob) == lib.azmi_net_blob_bytes(C.byref(desc)), (len(blob), lib.azmi_net_blob_bytes(C.byref(desc)))
     return desc, bytes(blob)
 
@@ -171,10 +177,14 @@ def fold_fp32(net):
     if spec.policy_shape is not None:
         pc = spec.policy_shape[0]
         blob += conv_bn("pi_conv2.weight", net.pi_bn2)
+        if spec.num_moves > pc * H * W:   # pi_global: torch layouts
+            for k in ("pi_global.0.weight", "pi_global.0.bias", "pi_global.2.weight", "pi_global.2.bias", "pi_global.3.weight", "pi_global.3.bias"):
+                blob += _f32(sd[k])
     else:
         blob += _f32(sd["pi_fc1.weight"]) + _f32(sd["pi_fc1.bias"])
     desc = NetDescC(Cin, H, W, spec.num_channels, spec.depth, 3, spec.head_channels, spec.v_fc_hidden, spec.num_moves, spec.num_players,
-                    spec.v_head_convs, spec.pi_head_convs, spec.v_fc_layers, pc, 1)
+                    spec.v_head_convs, spec.pi_head_convs, spec.v_fc_layers, pc, 1,
+                    spec.pi_fc_hidden if (pc and spec.num_moves > pc * H * W) else 0)
     assert len(blob) == lib.azmi_net_blob_bytes(C.byref(desc)), (len(blob), lib.azmi_net_blob_bytes(C.byref(desc)))
     return desc, bytes(blob)
 
@@ -225,7 +235,7 @@ def fold(net, precision="bf16"):
     for p_ in range(H * W):
         blob += _frags(hi[:, :, p_].numpy()) + _frags(lo[:, :, p_].numpy())
     blob += _f32(sd["pi_fc1.bias"])
-    desc = NetDescC(Cin, H, W, 64, spec.depth, 3, 32, spec.v_fc_hidden, spec.num_moves, spec.num_players, 0, 0, 1, 0, 0)
+    desc = NetDescC(Cin, H, W, 64, spec.depth, 3, 32, spec.v_fc_hidden, spec.num_moves, spec.num_players, 0, 0, 1, 0, 0, 0)
     assert len(blob) == lib.azmi_net_blob_bytes(C.byref(desc)), (len(blob), lib.azmi_net_blob_bytes(C.byref(desc)))
     return desc, bytes(blob)
 

@@ -33,10 +33,13 @@ class NetSpec:
     pi_head_convs: int = 0
     v_fc_layers: int = 1
     policy_shape: tuple = None  # POLICY_SHAPE (C, H, W) -> spatial head (neural_net.py:390-427)
+    pi_fc_hidden: int = -1   # -1 -> head_channels * 8; hidden width of pi_global (spatial head with global actions)
 
     def __post_init__(self):
         if self.v_fc_hidden == -1:
             self.v_fc_hidden = self.head_channels * 8
+        if self.pi_fc_hidden == -1:
+            self.pi_fc_hidden = self.head_channels * 8
 
 
 def _conv(cin, cout, k):
@@ -96,9 +99,15 @@ class LeafNet(nn.Module):
             self.pi_extra_convs = nn.Sequential(*layers)
         if spec.policy_shape is not None:
             pc, ph, pw = spec.policy_shape
-            assert (ph, pw) == (H, W) and pc * ph * pw == spec.num_moves, "global actions are not supported"
+            assert (ph, pw) == (H, W) and pc * ph * pw <= spec.num_moves
             self.pi_conv2 = _conv(HC, pc, 1)
             self.pi_bn2 = nn.BatchNorm2d(pc)
+            self.num_global_actions = spec.num_moves - pc * ph * pw
+            if self.num_global_actions > 0:   # neural_net.py:413-426: deploys + end turn of StarGambit
+                self.pi_flatten = nn.Flatten()
+                self.pi_pool = nn.AdaptiveAvgPool2d(1) if spec.head_pool else None
+                self.pi_global = nn.Sequential(nn.Linear(HC if spec.head_pool else HC * H * W, spec.pi_fc_hidden), nn.ReLU(inplace=True),
+                                               nn.Linear(spec.pi_fc_hidden, self.num_global_actions), nn.LayerNorm(self.num_global_actions))
         else:
             self.pi_flatten = nn.Flatten()
             self.pi_fc1 = nn.Linear(H * W * HC, spec.num_moves)
@@ -119,7 +128,11 @@ class LeafNet(nn.Module):
         if hasattr(self, "pi_extra_convs"):
             pi = self.pi_extra_convs(pi)
         if self.spec.policy_shape is not None:
-            pi = self.pi_bn2(self.pi_conv2(pi)).permute(0, 2, 3, 1).reshape(pi.shape[0], -1)
+            sp = self.pi_bn2(self.pi_conv2(pi)).permute(0, 2, 3, 1).reshape(pi.shape[0], -1)
+            if self.num_global_actions > 0:   # neural_net.py:486-493
+                flat = self.pi_flatten(self.pi_pool(pi) if self.pi_pool is not None else pi)
+                sp = torch.cat([sp, self.pi_global(flat)], dim=1)
+            pi = sp
         else:
             pi = self.pi_fc1(self.pi_flatten(pi))
         return v, torch.log_softmax(pi, dim=1)
@@ -159,6 +172,13 @@ def opentafl_spec(depth=4, channels=64, head_channels=64):
     """OpenTafl: 8 canonical planes (plane 7 = turn / max_turns), 11x11, spatial head (the Tawlbwrdd YAML shape)."""
     return NetSpec(in_shape=(8, 11, 11), num_moves=2662, num_players=2, num_channels=channels, depth=depth, kernel_size=3,
                    head_channels=head_channels, v_head_convs=1, pi_head_convs=1, v_fc_layers=2, policy_shape=(22, 11, 11))
+
+
+def stargambit_spec(depth=4, channels=64, head_channels=64):
+    """BASELINE config 5 / configs/star_gambit_unified.yaml:5-15: 4 blocks x 64 channels, k=3, head_channels 64, one extra conv
+    per head, two value FC layers, spatial policy head (POLICY_SHAPE 10 x 13 x 13) + 19 global actions (deploys, end turn)."""
+    return NetSpec(in_shape=(36, 13, 13), num_moves=1709, num_players=2, num_channels=channels, depth=depth, kernel_size=3,
+                   head_channels=head_channels, v_head_convs=1, pi_head_convs=1, v_fc_layers=2, policy_shape=(10, 13, 13))
 
 
 def random_init(spec, seed=0, randomize_bn=True):

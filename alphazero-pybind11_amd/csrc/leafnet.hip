@@ -83,11 +83,12 @@ struct Geo {
 // 3 per wave), 7 for 7x7 (343 pixels = 22 n-tiles); the value head's FC stack runs batched in k_value_fc on the exact-fp32
 // matrix pipe.  Nets with fewer than 64 trunk / head channels (configs/brandubh.yaml: 32) are zero-padded to 64 by the
 // host-side fold: the padded channels stay exactly 0 through every affine, ReLU and convolution.
-constexpr int TBS11 = 3, TBS7 = 7;
+constexpr int TBS11 = 3, TBS7 = 7, TBS13 = 2;   // 13x13 (StarGambit's canvas): 2 x 169 = 338 pixels = 22 n-tiles, 3 per wave
 constexpr int HCS = 64;
 
 struct SpatialDesc {
   int C_in, H, W, depth, num_moves, num_players, v_hidden, v_fc_layers, pol_ch;
+  int num_global, pi_hidden;   // global actions behind the spatial block (StarGambit: 19) and the width of pi_global's hidden layer
 };
 struct SpatialPtrs {
   const uint8_t* stem_w; const float* stem_b; const uint8_t* blocks;
@@ -103,6 +104,13 @@ struct SpatialPtrs {
   const float* fcx_b;      // (v_fc_layers-1) x [v_hidden]
   const float* fc2_w;      // fragments [1][v_hidden/16][64][4], rows >= P+1 zero
   const float* fc2_b;      // [16]
+  // pi_global (neural_net.py:421-426), fp32, transposed so that consecutive lanes read consecutive outputs:
+  const float* pg1_wT;     // [64][pi_hidden]
+  const float* pg1_b;      // [pi_hidden]
+  const float* pg2_wT;     // [pi_hidden][32] (columns >= num_global zero)
+  const float* pg2_b;      // [32]
+  const float* pg_ln_g;    // [32] LayerNorm weight
+  const float* pg_ln_b;    // [32] LayerNorm bias
 };
 
 template <int H, int W, int TBS>
@@ -152,9 +160,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_leafnet_spatial(SpatialDesc nd,
   }
   // the im2col matrix has 9*C_in rows; the eight 8-row planes hold 64 of them, so a stem with more (8 input planes:
   // OpenTafl) runs in passes of 64 rows that accumulate into the same tiles
+  // (StarGambit: 36 planes = 6 passes); a pass's 8 KB of weight fragments are staged at the start of the pass, so the
+  // input staging behind them (wbuf + 16 KB) has the rest of the weight area whatever the number of passes
   const int npass = (9 * nd.C_in + 63) / 64;
-  for (int i = tid * 16; i < npass * 2 * MT * WFRAG_BYTES; i += NTHREADS * 16)
-    *reinterpret_cast<u32x4*>(wbuf + i) = *reinterpret_cast<const u32x4*>(np.stem_w + i);
 
   f32x4 s[G::NT_W][MT];
   {
@@ -171,6 +179,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_leafnet_spatial(SpatialDesc nd,
         for (int i = tid * 16; i < G::ACT_BYTES; i += NTHREADS * 16) *reinterpret_cast<u32x4*>(act + i) = u32x4{0, 0, 0, 0};
         __syncthreads();
       }
+      for (int i = tid * 16; i < 2 * MT * WFRAG_BYTES; i += NTHREADS * 16)
+        *reinterpret_cast<u32x4*>(wbuf + i) = *reinterpret_cast<const u32x4*>(np.stem_w + pass * 2 * MT * WFRAG_BYTES + i);
       if (tid < G::NPIX) {
         const int n = tid, b = n / G::PIX, p = n % G::PIX, h = p / W, w = p % W;
         const float* rb = raw + b * plane_sz;
@@ -190,7 +200,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_leafnet_spatial(SpatialDesc nd,
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 a[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = lds_read_frag(wbuf + ((pass * 2 + ks) * MT + mt) * WFRAG_BYTES + lane * 16);
+        for (int mt = 0; mt < MT; ++mt) a[mt] = lds_read_frag(wbuf + (ks * MT + mt) * WFRAG_BYTES + lane * 16);
 #pragma unroll
         for (int j = 0; j < G::NT_W; ++j) {
           const bf16x8 b = lds_read_frag(act + (ks * 4 + quad) * G::PLANE + pix_off[j]);
@@ -419,11 +429,80 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_leafnet_spatial(SpatialDesc nd,
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int c = mt * 16 + quad * 4 + r;
-          if (c < nd.pol_ch) lg[n * nd.pol_ch + c] = pl[j][mt][r];
+          if (c < nd.pol_ch) lg[(n / G::PIX) * nd.num_moves + (n % G::PIX) * nd.pol_ch + c] = pl[j][mt][r];
         }
     }
   }
   __syncthreads();
+  if (nd.num_global > 0) {
+    // ---- global actions (StarGambit: 18 deploys + end turn), neural_net.py:413-426, 486-493: the average-pooled policy
+    // features -> Linear(64, pi_hidden) -> ReLU -> Linear(pi_hidden, G) -> LayerNorm(G), appended behind the spatial logits.
+    // fp32 on the vector units: 64 * pi_hidden + pi_hidden * G multiply-adds per board, one wave per board.
+    float* pool_buf = reinterpret_cast<float*>(act);                            // the policy 1x1 has read the planes
+    float* gscr = reinterpret_cast<float*>(wbuf + 8192 + 16384);                // behind the logits: psum | pooled | hidden
+    float* psum = gscr;                                                         // [TBS][64][4]
+    float* pooled = gscr + TBS * 256;                                           // [TBS][64]
+    float* hidden = pooled + TBS * 64;                                          // [TBS][pi_hidden]
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int j = 0; j < G::NT_W; ++j) {
+        if (!((real_m >> j) & 1u)) continue;
+        const int n = (wave + NWAVES * j) * 16 + col;
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2) {
+          f32x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = fmaxf(hp[j][half * 2 + m2][r], 0.0f);
+          *reinterpret_cast<f32x4*>(pool_buf + n * 32 + m2 * 16 + quad * 4) = o;
+        }
+      }
+      __syncthreads();
+      for (int t = tid; t < TBS * 128; t += NTHREADS) {
+        const int b = t / 128, r = t % 128, c = r % 32, part = r / 32;
+        constexpr int per = (G::PIX + 3) / 4;
+        const int p0 = part * per, p1 = (p0 + per < G::PIX) ? p0 + per : G::PIX;
+        float acc = 0.0f;
+        for (int p = p0; p < p1; ++p) acc += pool_buf[(b * G::PIX + p) * 32 + c];
+        psum[(b * 64 + half * 32 + c) * 4 + part] = acc;
+      }
+      __syncthreads();
+    }
+    if (tid < TBS * 64) {
+      const float* q = psum + tid * 4;
+      pooled[tid] = (((q[0] + q[1]) + q[2]) + q[3]) / static_cast<float>(G::PIX);
+    }
+    __syncthreads();
+    if (wave < TBS) {
+      const int Hp = nd.pi_hidden;
+      const float* x = pooled + wave * 64;
+      float* hrow = hidden + wave * Hp;
+      for (int o = lane; o < Hp; o += 64) {
+        float acc = np.pg1_b[o];
+        for (int k = 0; k < 64; ++k) acc += np.pg1_wT[k * Hp + o] * x[k];
+        hrow[o] = fmaxf(acc, 0.0f);
+      }
+    }
+    __syncthreads();
+    if (wave < TBS) {
+      const int Hp = nd.pi_hidden, Gn = nd.num_global;
+      const float* hrow = hidden + wave * Hp;
+      float acc = 0.0f;
+      if (lane < 32) {
+        acc = np.pg2_b[lane];
+        for (int k = 0; k < Hp; ++k) acc += np.pg2_wT[k * 32 + lane] * hrow[k];
+      }
+      const bool on = lane < Gn;
+      float sum = on ? acc : 0.0f;
+      for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+      const float mean = sum / static_cast<float>(Gn);
+      float dv = on ? (acc - mean) * (acc - mean) : 0.0f;
+      for (int off = 32; off > 0; off >>= 1) dv += __shfl_xor(dv, off, 64);
+      const float inv = 1.0f / sqrtf(dv / static_cast<float>(Gn) + 1e-5f);
+      if (on) lg[wave * nd.num_moves + G::PIX * nd.pol_ch + lane] = (acc - mean) * inv * np.pg_ln_g[lane] + np.pg_ln_b[lane];
+    }
+    __syncthreads();
+  }
   if (wave < TBS && board0 + wave < batch) {   // one wave per board: softmax = exp(log_softmax), neural_net.py:494,816
     const int M = nd.num_moves;
     const float* row = lg + wave * M;
@@ -607,6 +686,10 @@ size_t spatial_blob_bytes(const azmi_net_desc* d) {
   n += 2 * (wconv + 64 * 4);                                          // extra head convs
   n += 2 * 2 * WFRAG_BYTES + 32 * 4;                                  // policy 1x1
   n += (64 * Hd + Hd) * 4 + (L - 1) * (Hd * Hd + Hd) * 4 + (Hd * 16 + 16) * 4;
+  if (d->num_moves > d->policy_channels * d->height * d->width) {     // pi_global: W1^T[64][Hp] b[Hp] W2^T[Hp][32] b[32] ln_g[32] ln_b[32]
+    const size_t Hp = d->pi_hidden;
+    n += (64 * Hp + Hp + Hp * 32 + 3 * 32) * 4;
+  }
   return n;
 }
 }  // namespace
@@ -645,10 +728,21 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
   if (is_spatial(d)) {
     if (d->channels != CH || d->head_channels != HCS || d->kernel_size != 3 || d->v_head_convs != 1 || d->pi_head_convs != 1)
       return nfail(AZMI_ERR_INVALID, "spatial leaf net kernel covers 64 trunk / 64 head channels, 3x3 convs, one extra conv per head");
-    const bool b11 = d->height == 11 && d->width == 11, b7 = d->height == 7 && d->width == 7;
-    if (!b11 && !b7) return nfail(AZMI_ERR_INVALID, "spatial leaf net kernel: board %dx%d not instantiated", d->height, d->width);
-    if (9 * d->in_channels > 128 || d->policy_channels > 32 || d->policy_channels * d->height * d->width != d->num_moves)
-      return nfail(AZMI_ERR_INVALID, "spatial head: 9*C_in <= 128, policy channels <= 32, no global actions");
+    const bool b11 = d->height == 11 && d->width == 11, b7 = d->height == 7 && d->width == 7, b13 = d->height == 13 && d->width == 13;
+    if (!b11 && !b7 && !b13) return nfail(AZMI_ERR_INVALID, "spatial leaf net kernel: board %dx%d not instantiated", d->height, d->width);
+    const int tbs = b11 ? TBS11 : b7 ? TBS7 : TBS13;
+    const int num_global = d->num_moves - d->policy_channels * d->height * d->width;
+    if (d->policy_channels > 32 || num_global < 0 || num_global > 32)
+      return nfail(AZMI_ERR_INVALID, "spatial head: policy channels <= 32, 0..32 global actions");
+    if (num_global > 0 && (d->pi_hidden < 64 || d->pi_hidden > 1024 || d->pi_hidden % 64))
+      return nfail(AZMI_ERR_INVALID, "spatial head with global actions: pi_hidden must be a multiple of 64 in [64, 1024]");
+    // LDS budget of the head scratch (k_leafnet_spatial): input staging behind 16 KB of stem weights; logits behind 8 KB of
+    // policy weights; the global head's pooling / hidden scratch behind the logits
+    if (16384 + static_cast<size_t>(tbs) * d->in_channels * d->height * d->width * 4 > 18 * MT * WFRAG_BYTES)
+      return nfail(AZMI_ERR_INVALID, "spatial leaf net kernel: %d input planes do not fit the staging area", d->in_channels);
+    if (num_global > 0 && (static_cast<size_t>(tbs) * d->num_moves * 4 > 16384 ||
+                           8192 + 16384 + static_cast<size_t>(tbs) * (256 + 64 + d->pi_hidden) * 4 > 18 * MT * WFRAG_BYTES))
+      return nfail(AZMI_ERR_INVALID, "spatial head with global actions: logits / hidden scratch do not fit");
     if (d->v_hidden > 512 || d->v_hidden % 256 || d->v_fc_layers < 1 || d->num_players + 1 > 16) return nfail(AZMI_ERR_INVALID, "value head sizes out of range");
     if (blob_bytes != spatial_blob_bytes(d)) return nfail(AZMI_ERR_INVALID, "weight blob is %zu bytes, expected %zu", blob_bytes, spatial_blob_bytes(d));
     int ndev = 0;
@@ -656,7 +750,8 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
     if (hipSetDevice(device) != hipSuccess) return nfail(AZMI_ERR_NO_DEVICE, "hipSetDevice failed");
     auto net = new azmi_net();
     net->device = device; net->spatial = true;
-    net->sd = SpatialDesc{d->in_channels, d->height, d->width, d->depth, d->num_moves, d->num_players, d->v_hidden, d->v_fc_layers, d->policy_channels};
+    net->sd = SpatialDesc{d->in_channels, d->height, d->width, d->depth, d->num_moves, d->num_players, d->v_hidden, d->v_fc_layers, d->policy_channels,
+                          num_global, num_global > 0 ? d->pi_hidden : 0};
     if (hipMalloc(&net->blob, blob_bytes) != hipSuccess) { delete net; return nfail(AZMI_ERR_OOM, "hipMalloc(weights) failed"); }
     if (hipMemcpy(net->blob, blob, blob_bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(net->blob); delete net; return nfail(AZMI_ERR_NO_DEVICE, "weight upload failed"); }
     net->blob_bytes = blob_bytes;
@@ -674,19 +769,23 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
     sp.fc1_w = f32p(64 * Hd); sp.fc1_b = f32p(Hd);
     sp.fcx_w = f32p((L - 1) * Hd * Hd); sp.fcx_b = f32p((L - 1) * Hd);
     sp.fc2_w = f32p(Hd * 16); sp.fc2_b = f32p(16);
+    if (num_global > 0) {
+      const size_t Hp = d->pi_hidden;
+      sp.pg1_wT = f32p(64 * Hp); sp.pg1_b = f32p(Hp); sp.pg2_wT = f32p(Hp * 32); sp.pg2_b = f32p(32); sp.pg_ln_g = f32p(32); sp.pg_ln_b = f32p(32);
+    }
     auto reserve = [&](auto geo, const void* kernel) {
       using GS = decltype(geo);
       static_assert(GS::NPIX <= NTHREADS, "stem im2col maps one thread to one pixel");
       static_assert(GS::NPIX * 32 * 4 <= GS::ACT_BYTES, "pooling scratch must fit the activation planes");
       static_assert(8192 + GS::NPIX * 32 * 4 <= GS::WCONV_BYTES, "policy logits must fit the weight area");
-      static_assert(16384 + GS::NPIX * 128 * 4 / 9 <= GS::WCONV_BYTES, "input staging (<= 14 planes) must fit behind two stem passes");
       net->lds_bytes = GS::ACT_BYTES + GS::WCONV_BYTES;
       return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(net->lds_bytes)) == hipSuccess;
     };
-    static_assert(2 * 2 * MT * WFRAG_BYTES <= 16384, "two stem passes of weights sit in front of the input staging");
+    static_assert(2 * MT * WFRAG_BYTES <= 16384, "one stem pass of weights sits in front of the input staging");
     net->vfc_lds = (2 * Hd * 16 + VFC_WAVES * 256) * sizeof(float);
     const bool reserved = b11 ? reserve(Geo<11, 11, TBS11>{}, reinterpret_cast<const void*>(&k_leafnet_spatial<11, 11, TBS11>))
-                              : reserve(Geo<7, 7, TBS7>{}, reinterpret_cast<const void*>(&k_leafnet_spatial<7, 7, TBS7>));
+                        : b7 ? reserve(Geo<7, 7, TBS7>{}, reinterpret_cast<const void*>(&k_leafnet_spatial<7, 7, TBS7>))
+                             : reserve(Geo<13, 13, TBS13>{}, reinterpret_cast<const void*>(&k_leafnet_spatial<13, 13, TBS13>));
     if (!reserved || hipFuncSetAttribute(reinterpret_cast<const void*>(&k_value_fc), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          static_cast<int>(net->vfc_lds)) != hipSuccess) {
       (void)hipFree(net->blob); delete net;
@@ -773,6 +872,8 @@ int azmi_net_forward(azmi_net* net, const float* dev_canonical, float* dev_v, fl
     }
     if (net->sd.H == 11)
       k_leafnet_spatial<11, 11, TBS11><<<(batch + TBS11 - 1) / TBS11, NTHREADS, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, sc.vpool, dev_pi, batch);
+    else if (net->sd.H == 13)
+      k_leafnet_spatial<13, 13, TBS13><<<(batch + TBS13 - 1) / TBS13, NTHREADS, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, sc.vpool, dev_pi, batch);
     else
       k_leafnet_spatial<7, 7, TBS7><<<(batch + TBS7 - 1) / TBS7, NTHREADS, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, sc.vpool, dev_pi, batch);
     k_value_fc<<<(batch + 15) / 16, VFC_THREADS, net->vfc_lds, st>>>(net->sd, net->sp, sc.vpool, dev_v, batch);

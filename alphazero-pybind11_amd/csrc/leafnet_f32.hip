@@ -88,11 +88,15 @@ __global__ void k_fc(const float* __restrict__ in, const float* __restrict__ w, 
 
 // one wavefront per row: out = softmax(row).  `chw` != 0: the row is read as [C][HW] and written as [HW][C]
 // (spatial policy head: permute(0, 2, 3, 1) + flatten, neural_net.py:483-487)
-__global__ void k_softmax(const float* __restrict__ in, float* __restrict__ out, uint32_t B, int N, int C, int HW) {
+// `glob` != nullptr: the row's last G entries are the global-action logits glob[row][G] behind the C*HW spatial ones
+// (neural_net.py:486-493), the spatial block of row r then starts at in + r * C * HW
+__global__ void k_softmax(const float* __restrict__ in, float* __restrict__ out, uint32_t B, int N, int C, int HW,
+                          const float* __restrict__ glob = nullptr, int G = 0) {
   const uint32_t row = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64, lane = threadIdx.x % 64;
   if (row >= B) return;
-  const float* x = in + static_cast<size_t>(row) * N;
-  auto src = [&](int e) { return C ? x[(e % C) * HW + e / C] : x[e]; };
+  const float* x = in + static_cast<size_t>(row) * (N - G);
+  const float* gx = glob ? glob + static_cast<size_t>(row) * G : nullptr;
+  auto src = [&](int e) { return e >= N - G ? gx[e - (N - G)] : (C ? x[(e % C) * HW + e / C] : x[e]); };
   float mx = -__builtin_inff();
   for (int e = lane; e < N; e += 64) mx = fmaxf(mx, src(e));
   for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
@@ -100,6 +104,22 @@ __global__ void k_softmax(const float* __restrict__ in, float* __restrict__ out,
   for (int e = lane; e < N; e += 64) sum += expf(src(e) - mx);
   for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
   for (int e = lane; e < N; e += 64) out[static_cast<size_t>(row) * N + e] = expf(src(e) - mx) / sum;
+}
+
+// nn.LayerNorm(G) over the last dimension (biased variance, eps 1e-5), one thread per row
+__global__ void k_layernorm(const float* __restrict__ in, const float* __restrict__ gamma, const float* __restrict__ beta,
+                            float* __restrict__ out, uint32_t B, int G) {
+  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= B) return;
+  const float* x = in + static_cast<size_t>(row) * G;
+  float mean = 0.0f;
+  for (int i = 0; i < G; ++i) mean += x[i];
+  mean /= static_cast<float>(G);
+  float var = 0.0f;
+  for (int i = 0; i < G; ++i) var += (x[i] - mean) * (x[i] - mean);
+  var /= static_cast<float>(G);
+  const float inv = 1.0f / sqrtf(var + 1e-5f);
+  for (int i = 0; i < G; ++i) out[static_cast<size_t>(row) * G + i] = (x[i] - mean) * inv * gamma[i] + beta[i];
 }
 
 struct Net {
@@ -119,8 +139,11 @@ size_t count_floats(const azmi_net_desc* d) {
   n += HC * CH + HC + static_cast<size_t>(d->v_head_convs) * (HC * HC * 9 + HC);
   n += Hd * HC + Hd + static_cast<size_t>(d->v_fc_layers - 1) * (Hd * Hd + Hd) + P1 * Hd + P1;
   n += HC * CH + HC + static_cast<size_t>(d->pi_head_convs) * (HC * HC * 9 + HC);
-  if (d->policy_channels > 0) n += static_cast<size_t>(d->policy_channels) * HC + d->policy_channels;
-  else n += static_cast<size_t>(d->num_moves) * HC * HW + d->num_moves;
+  if (d->policy_channels > 0) {
+    n += static_cast<size_t>(d->policy_channels) * HC + d->policy_channels;
+    const size_t G = static_cast<size_t>(d->num_moves) - static_cast<size_t>(d->policy_channels) * HW, Hp = d->pi_hidden;
+    if (G > 0) n += Hp * HC + Hp + G * Hp + G + 2 * G;     // pi_global: Linear, Linear, LayerNorm (neural_net.py:421-426)
+  } else n += static_cast<size_t>(d->num_moves) * HC * HW + d->num_moves;
   return n;
 }
 
@@ -155,7 +178,7 @@ int reserve(void* impl, uint32_t batch, const char** err) {
   n->rows = 0;
   const size_t HW = static_cast<size_t>(n->d.height) * n->d.width;
   const size_t CH = std::max<size_t>(n->d.channels, n->d.head_channels);
-  const size_t wide = std::max<size_t>(std::max<size_t>(n->d.v_hidden, n->d.num_moves), n->d.head_channels);
+  const size_t wide = std::max<size_t>(std::max<size_t>(std::max<size_t>(n->d.v_hidden, n->d.pi_hidden), n->d.num_moves), n->d.head_channels);
   for (float*& p : n->buf)
     if (hipMalloc(reinterpret_cast<void**>(&p), static_cast<size_t>(batch) * CH * HW * sizeof(float)) != hipSuccess)
       return fail(err, AZMI_ERR_OOM, "hipMalloc(fp32 activations) failed");
@@ -170,8 +193,10 @@ int create(const azmi_net_desc* d, const void* blob, size_t bytes, int device, v
   if (d->channels < 1 || d->kernel_size != 3) return fail(err, AZMI_ERR_INVALID, "fp32 leaf net: 3x3 convolutions only");
   if (d->head_channels < 1 || d->v_fc_layers < 1 || d->v_head_convs < 0 || d->pi_head_convs < 0)
     return fail(err, AZMI_ERR_INVALID, "fp32 leaf net: head sizes out of range");
-  if (d->policy_channels > 0 && d->policy_channels * d->height * d->width != d->num_moves)
-    return fail(err, AZMI_ERR_INVALID, "fp32 leaf net: spatial head with global actions is not supported");
+  if (d->policy_channels > 0 && d->policy_channels * d->height * d->width > d->num_moves)
+    return fail(err, AZMI_ERR_INVALID, "fp32 leaf net: the spatial block exceeds num_moves");
+  if (d->policy_channels > 0 && d->policy_channels * d->height * d->width < d->num_moves && d->pi_hidden < 1)
+    return fail(err, AZMI_ERR_INVALID, "fp32 leaf net: global actions need pi_hidden");
   if (bytes != blob_bytes(d)) { char b[128]; snprintf(b, sizeof b, "fp32 weight blob is %zu bytes, expected %zu", bytes, blob_bytes(d)); return fail(err, AZMI_ERR_INVALID, b); }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(err, AZMI_ERR_NO_DEVICE, "no HIP device: libazmi has no CPU path");
@@ -257,6 +282,18 @@ int forward(void* impl, const float* canon, float* v_out, float* pi_out, uint32_
       const int PC = d.policy_channels;
       const float* w = take(static_cast<size_t>(PC) * HC); const float* b = take(PC);
       conv1(a, w, b, b2, HC, PC, 0);                                   // [B][PC][HW]
+      const int G = M - PC * HW;
+      if (G > 0) {   // pi_global over the average-pooled policy features (head_pool), neural_net.py:413-426, 486-493
+        const int Hp = d.pi_hidden;
+        k_avgpool<<<static_cast<uint32_t>((static_cast<size_t>(B) * HC + 255) / 256), 256, 0, st>>>(a, n->small[0], B, HC, HW);
+        const float* w1 = take(static_cast<size_t>(Hp) * HC); const float* c1 = take(Hp);
+        fc(n->small[0], w1, c1, n->small[1], HC, Hp, 1);
+        const float* w2 = take(static_cast<size_t>(G) * Hp); const float* c2 = take(G);
+        fc(n->small[1], w2, c2, n->small[0], Hp, G, 0);
+        const float* lg = take(G); const float* lb = take(G);
+        k_layernorm<<<(B + 63) / 64, 64, 0, st>>>(n->small[0], lg, lb, n->small[1], B, G);
+        k_softmax<<<(B + 3) / 4, 256, 0, st>>>(b2, pi_out, B, M, PC, HW, n->small[1], G);
+      } else
       k_softmax<<<(B + 3) / 4, 256, 0, st>>>(b2, pi_out, B, M, PC, HW);  // permuted to [HW][PC] on the fly
     } else {
       const float* w = take(static_cast<size_t>(M) * HC * HW); const float* b = take(M);

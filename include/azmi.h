@@ -361,6 +361,11 @@ typedef struct azmi_net_desc {
    * neural_net.py:811-813) — the throughput path.  1 = plain fp32 arithmetic, layer by layer: the precision
    * the 1e-5 parity tier refers to; blob layout in csrc/leafnet_f32.hip. */
   int32_t precision;
+  /* spatial head with GLOBAL actions (num_moves > policy_channels * H * W: StarGambit's 18 deploys + end turn,
+   * neural_net.py:413-426, 486-493): hidden width of pi_global (NNArgs.pi_fc_hidden); the global logits come from the
+   * average-pooled policy features through Linear - ReLU - Linear - LayerNorm and join the softmax behind the spatial block.
+   * 0 when the net has no global actions.  bf16 kernel: also instantiated for 13x13 (configs/star_gambit_unified.yaml). */
+  int32_t pi_hidden;
 } azmi_net_desc;
 typedef struct azmi_net azmi_net;
 size_t azmi_net_blob_bytes(const azmi_net_desc* desc);

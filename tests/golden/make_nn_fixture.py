@@ -157,7 +157,7 @@ def main_tawlbwrdd():
 
 
 
-def _tafl_fixture(name, game_id, statics, args_kw, spec_fn, n_pos, out_name):
+def _tafl_fixture(name, game_id, statics, args_kw, spec_fn, n_pos, out_name, make_game=None, peak=False):
     """One more reference NNArch fixture: `statics` = the game class surface NNArch reads, `args_kw` = the YAML's net keys."""
     cls = type(name, (), {k: staticmethod((lambda v: (lambda: v))(v)) for k, v in statics.items()})
     args = ref_nn.NNArgs(dense_net=False, kernel_size=3, spatial_policy="on", **args_kw)
@@ -170,11 +170,16 @@ def _tafl_fixture(name, game_id, statics, args_kw, spec_fn, n_pos, out_name):
             m.running_var.copy_(torch.rand(m.num_features, generator=g) * 1.0 + 0.5)
             m.weight.data.copy_(torch.rand(m.num_features, generator=g) * 0.8 + 0.6)
             m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    if peak:
+        _peak(net)
+        if hasattr(net, "pi_global"):
+            with torch.no_grad():
+                net.pi_global[3].weight.mul_(2.0)     # the global logits are LayerNorm outputs: spread them too
     net.eval()
     rng = np.random.default_rng(6)
     xs = []
     while len(xs) < n_pos:
-        game = orc.Game(game_id)
+        game = make_game(len(xs)) if make_game else orc.Game(game_id)
         for _ in range(int(rng.integers(0, 50))):
             if game.scores() is not None:
                 break
@@ -214,6 +219,18 @@ def main_brandubh():
                   dict(num_channels=32, depth=4, head_channels=32, v_head_convs=1, pi_head_convs=1, v_fc_layers=2),
                   "brandubh_spec", 16, "nn_brandubh_4b32c.npz")
 
+def main_stargambit():
+    """configs/star_gambit_unified.yaml:5-15: 4 blocks x 64 ch, head 64, one extra conv per head, v_fc_layers 2, spatial head over
+    the 13 x 13 canvas (10 channels) + the global head for the 19 deploy / end-turn actions; 36 planes.  Positions of all four
+    variants from oracle random playouts."""
+    _tafl_fixture("StarGambitUnified", orc.GAME_STARGAMBIT,
+                  dict(CANONICAL_SHAPE=(36, 13, 13), NUM_PLAYERS=2, NUM_MOVES=1709, POLICY_SHAPE=(10, 13, 13)),
+                  dict(num_channels=64, depth=4, head_channels=64, v_head_convs=1, pi_head_convs=1, v_fc_layers=2),
+                  "stargambit_spec", 12, "nn_stargambit_4b64c_peaked.npz" if PEAKED else "nn_stargambit_4b64c.npz",
+                  make_game=lambda i: orc.Game.sg_unified(pinned=i % 4), peak=PEAKED)
+
+
 if __name__ == "__main__":
     mode = next((a for a in sys.argv[1:] if not a.startswith("--")), "connect4")
-    {"connect4": main, "tawlbwrdd": main_tawlbwrdd, "opentafl": main_opentafl, "brandubh": main_brandubh}[mode]()
+    {"connect4": main, "tawlbwrdd": main_tawlbwrdd, "opentafl": main_opentafl, "brandubh": main_brandubh,
+     "stargambit": main_stargambit}[mode]()

@@ -295,6 +295,9 @@ PEAKED = {  # fixture, spec, max |dv|, max |dpi|, max relative error on entries 
     # Tawlbwrdd 3.1e-5 / 2.0e-5 / 9.3e-3 / 2.6e-6 (autocast: 6.7e-4 / 7.1e-5)
     "connect4": ("nn_connect4_6b64c_peaked.npz", "connect4_spec", 1e-3, 4e-3, 2e-2, 1e-3, 5e-5),
     "tawlbwrdd": ("nn_tawlbwrdd_4b64c_peaked.npz", "tawlbwrdd_spec", 1e-4, 5e-5, 2e-2, 1e-5, 1e-5),
+    # StarGambit (36 planes, 13 x 13, spatial block + the global head's 19 LayerNorm logits), measured on MI355X (round 2):
+    # see the printed line; bounds at ~3x the measured values
+    "stargambit": ("nn_stargambit_4b64c_peaked.npz", "stargambit_spec", 2e-4, 1e-4, 3e-2, 1e-4, 1e-5),   # measured 5.8e-5 / 2.8e-5 / 8.9e-3 / 2.0e-6 (autocast 6.0e-4 / 1.0e-4)
 }
 
 
@@ -330,3 +333,48 @@ def test_bf16_mfma_kernels_on_a_peaked_net(which):
     assert kl <= tol_kl, kl
     assert dv <= e16v and dpi <= e16pi, "the fused kernels must be at least as close to the fp32 reference as torch's bf16 autocast"
     assert np.array_equal(pi.argmax(1), rpi.argmax(1))
+
+
+def test_stargambit_net_matches_reference_nnarch_fixture():
+    """configs/star_gambit_unified.yaml net (36 x 13 x 13, spatial policy block + pi_global for the 19 deploy / end-turn actions,
+    neural_net.py:413-426, 486-493), weights and expected outputs produced by the REFERENCE's NNArch: the bf16 MFMA kernel
+    (k_leafnet_spatial<13, 13, 2>) within the bf16 tolerance and no further from fp32 than torch's bf16 autocast, the library's
+    fp32 path within the north star's 1e-5"""
+    import alphazero as az
+    fx, net = _ref_fixture("nn_stargambit_4b64c.npz", "stargambit_spec")
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(fx["input"]).to(dev)
+    v, pi = az.HipLeafNet(net).process(x)
+    dv, dpi = np.abs(v.cpu().numpy() - fx["v"]).max(), np.abs(pi.cpu().numpy() - fx["pi"]).max()
+    print("stargambit hip bf16 vs reference fp32: %.3e %.3e" % (dv, dpi))
+    assert dv <= TOL and dpi <= TOL
+    assert np.allclose(pi.sum(1).cpu().numpy(), 1, atol=1e-5)
+    v16, pi16 = net.to(dev).process(x, amp_dtype=torch.bfloat16)
+    e16 = max(np.abs(v16.cpu().numpy() - fx["v"]).max(), np.abs(pi16.cpu().numpy() - fx["pi"]).max())
+    assert max(dv, dpi) <= max(2 * e16, 5e-3), (dv, dpi, e16)
+    v32, pi32 = az.HipLeafNet(net.cpu(), precision="fp32").process(x)
+    d32v, d32p = np.abs(v32.cpu().numpy() - fx["v"]).max(), np.abs(pi32.cpu().numpy() - fx["pi"]).max()
+    print("stargambit hip fp32 vs reference fp32: %.3e %.3e" % (d32v, d32p))
+    assert d32v <= TOL_F32 and d32p <= TOL_F32
+    rel = np.abs(pi32.cpu().numpy() - fx["pi"]) / np.maximum(fx["pi"], 1e-12)
+    assert rel.max() <= 1e-3, rel.max()
+
+
+@pytest.mark.parametrize("batch", [1, 2, 3, 33, 1024])
+def test_stargambit_net_batch_shapes_and_invariance(batch):
+    """ragged batches (two boards per workgroup) and invariance of a row to its batch"""
+    import alphazero as az
+    from alphazero import torch_net
+    dev = torch.device("cuda:0")
+    net = torch_net.random_init(torch_net.stargambit_spec(), seed=5)
+    hip = az.HipLeafNet(net)
+    g = torch.Generator().manual_seed(batch)
+    x = (torch.rand((batch, 36, 13, 13), generator=g) < 0.2).float().to(dev)
+    v, pi = hip.process(x)
+    assert v.shape == (batch, 3) and pi.shape == (batch, 1709)
+    assert torch.allclose(pi.sum(1), torch.ones(batch, device=dev), atol=1e-5)
+    v1, pi1 = hip.process(x[:1].contiguous())
+    assert torch.equal(v1[0], v[0]) and torch.equal(pi1[0], pi[0])
+    if batch >= 3:
+        v3, pi3 = hip.process(x[2:3].contiguous())
+        assert torch.equal(v3[0], v[2]) and torch.equal(pi3[0], pi[2])
