@@ -51,8 +51,9 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=20, help="timed steps; a step = --rounds-per-step engine rounds")
     ap.add_argument("--warmup", type=int, default=5, help="untimed steps before the window (after the de-phasing pre-roll)")
     ap.add_argument("--rounds-per-step", type=int, default=2048)
-    ap.add_argument("--game", choices=["connect4", "tawlbwrdd"], default="connect4",
-                    help="connect4 = BASELINE configs[1] (the headline); tawlbwrdd = configs[2] (2048 games, 400 sims, YAML net)")
+    ap.add_argument("--game", choices=["connect4", "tawlbwrdd", "stargambit"], default="connect4",
+                    help="connect4 = BASELINE configs[1] (the headline); tawlbwrdd = configs[2] (2048 games, 400 sims, YAML net); "
+                         "stargambit = configs[4] per GPU (star_gambit_unified, 1024 games, 800 sims, 200000-entry device cache)")
     ap.add_argument("--games", type=int, default=None, help="concurrent games per GPU (4096 / 2048)")
     ap.add_argument("--sims", type=int, default=None, help="simulations per move (800 / 400)")
     ap.add_argument("--engines", type=int, default=None, help="engine shards (HIP streams) per GPU (default 4)")
@@ -278,12 +279,15 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    tafl = args.game == "tawlbwrdd"
-    if args.games is None: args.games = 2048 if tafl else 4096
-    if args.sims is None: args.sims = 400 if tafl else 800
+    sg = args.game == "stargambit"
+    tafl = args.game in ("tawlbwrdd", "stargambit")      # the wide-game engine (one wavefront per slot, spatial-head net)
+    if args.games is None: args.games = 1024 if sg else 2048 if tafl else 4096
+    if args.sims is None: args.sims = 800 if sg else 400 if tafl else 800
     if args.engines is None: args.engines = 4      # measured: Connect4 1/2/4/8 shards and Tawlbwrdd 2/4/8 shards both peak at 4
-    if args.cache is None: args.cache = 0 if tafl else 32_000_000      # Tawlbwrdd: measured 5 % hit rate with 2 M entries and 16 % fewer games/s, so off
-    flop_per_eval = 93.1e6 if tafl else FLOP_PER_EVAL
+    if args.cache is None: args.cache = 200_000 if sg else 0 if tafl else 32_000_000      # Tawlbwrdd: measured 5 % hit rate with 2 M entries and 16 % fewer games/s, so off; StarGambit: configs[4] / config.py:197
+    # SURVEY §8d; StarGambit net (configs/star_gambit_unified.yaml, 36 x 13 x 13): stem 7.0 + 8 trunk convs 99.7 + head 1x1s 2.8 + two
+    # head convs 24.9 + policy 1x1 0.2 + value / global FCs 0.7 = 135.3 MFLOP per position
+    flop_per_eval = 135.3e6 if sg else 93.1e6 if tafl else FLOP_PER_EVAL
     S, sims, K, R = args.games, args.sims, args.engines, args.rounds_per_step
     assert S % K == 0
     Se = S // K                       # slots per engine shard
@@ -316,7 +320,7 @@ def main():
     else:
         import alphazero as az
         from alphazero import torch_net
-        Game = az.TawlbwrddGS if tafl else az.Connect4GS
+        Game = az.StarGambitUnifiedGS if sg else az.TawlbwrddGS if tafl else az.Connect4GS
         # the game stream never runs dry: finished slots restart at once (play_manager_bench.cc:171-181 sizes its pool as
         # 8 x concurrent for the same purpose); the finished samples leave the engines' ring every step (hist_saver's job)
         STREAM = 1 << 30
@@ -325,8 +329,10 @@ def main():
             out = []
             for i in range(K):
                 pp = selfplay_params(az, Se, sims, STREAM, cache=cache // K, playout_cap=playout_cap, gumbel=args.gumbel)
+                if sg:   # configs/star_gambit_unified.yaml: self_play_temp 1.2, final_temp 0.2, per-variant half lives 3 / 4 / 5 / 8 turns
+                    pp.start_temp, pp.final_temp, pp.temp_decay_half_life_by_variant = 1.2, 0.2, [3.0, 4.0, 5.0, 8.0]
                 out.append(az.PlayManager(Game(), pp, seed=seed0 + 7919 * rank + 104729 * i, device=local_rank, max_inline=args.inline,
-                                          history_capacity=Se * (400 if tafl else 42) * 4))
+                                          history_capacity=Se * (300 if sg else 400 if tafl else 42) * 4))
             return out
 
         # K engine shards of S/K slots, one HIP stream each: while one shard's leaf batch is on the matrix
@@ -335,7 +341,7 @@ def main():
         streams = [torch.cuda.Stream(device=dev) for _ in range(K)]
         sps = [st.cuda_stream for st in streams]
         io = [pm.io_tensors() for pm in pms]
-        spec = torch_net.tawlbwrdd_spec() if tafl else torch_net.connect4_spec()
+        spec = torch_net.stargambit_spec() if sg else torch_net.tawlbwrdd_spec() if tafl else torch_net.connect4_spec()
         net = torch_net.random_init(spec, seed=0).to(dev)
         net_kind = args.net or "hip"
         hip_net = az.HipLeafNet(net, spec, device=local_rank) if net_kind == "hip" else None
@@ -499,7 +505,7 @@ def main():
                       "avg_valid_moves": st[2 * nsc + 9] / st[2 * nsc + 2] if st[2 * nsc + 2] else 0.0,
                       "games_since_start": games_total} if not dry else {"sum": st}
         out = {
-            "metric": "self-play games/sec (whole node), Connect4 @ 800 MCTS sims" if not tafl else f"self-play games/sec (whole node), Tawlbwrdd @ {sims} MCTS sims",
+            "metric": "self-play games/sec (whole node), Connect4 @ 800 MCTS sims" if not tafl else f"self-play games/sec (whole node), {'star_gambit_unified' if sg else 'Tawlbwrdd'} @ {sims} MCTS sims",
             "value": n_games / dt,
             "unit": "games/s",
             "n_gpus": world,
@@ -513,7 +519,8 @@ def main():
             "dtype": "bf16",
             "data": "synthetic",
             "config": {
-                "workload": (f"Tawlbwrdd 11x11, {S} concurrent games/GPU, {sims} sims/move, 4-block/64-ch ResNet (configs/tawlbwrdd.yaml net, spatial head), {'Gumbel' if args.gumbel else 'PUCT'}, "
+                "workload": (f"star_gambit_unified (four variants, 13x13 canvas, 1709 moves), {S} concurrent games/GPU, {sims} sims/move, 4-block/64-ch ResNet (configs/star_gambit_unified.yaml net, spatial + global policy head), {'Gumbel' if args.gumbel else 'PUCT'}, "
+                             if sg else f"Tawlbwrdd 11x11, {S} concurrent games/GPU, {sims} sims/move, 4-block/64-ch ResNet (configs/tawlbwrdd.yaml net, spatial head), {'Gumbel' if args.gumbel else 'PUCT'}, "
                              if tafl else f"Connect4, {S} concurrent games/GPU, {sims} sims/move, 6-block/64-ch ResNet (k3, 32 head ch), ")
                             + f"self-play flags of game_runner.py:2018-2041 with playout-cap {'ON (25 sims on 75% of moves)' if args.playout_cap else 'off'}, random-init weights",
                 "concurrent_games_per_gpu": S, "engine_shards": K, "sims_per_move": sims, "net": net_kind,
@@ -530,6 +537,7 @@ def main():
             nn_ms = sum(b.elapsed_time(c) for _, b, c in events) / max(1, len(events))
             # a k_leafnet launch evaluates the rows of its shard's eval list (leaves that missed the cache and are not
             # terminal) = the `evals` counter; the torch path and the spatial kernel evaluate the whole slot-indexed batch
+            # (the spatial kernels take the eval list too whenever the position cache is on: gather / scatter around a dense batch of Se rows)
             rows_evaluated = n_evals / world if (hip_net is not None and not tafl) else float(Se) * launches
             achieved = flop_per_eval * rows_evaluated / dt / 1e12
             per_launch = (flop_per_eval * rows_evaluated / launches) / (nn_ms * 1e-3) / 1e12 if nn_ms > 0 else 0.0
@@ -550,10 +558,11 @@ def main():
                 # (select + backup + expand + state + canonical + eval rows: Connect4 1.3 KB with the measured depth 3.5 / 6.8
                 # children; Tawlbwrdd 18 KB with depth 1.7 / 113 children, dominated by the dense pi[2662] row)
                 sims_rank = n_sims / world
-                b_sim = 18000.0 if tafl else B_SIM
+                # StarGambit: 24.3 KB canonical write + 6.8 KB pi row + ~1.7 KB tree (depth ~4, ~20 children) + 0.2 KB state
+                b_sim = 33000.0 if sg else 18000.0 if tafl else B_SIM
                 tree_launch = (b_sim * sims_rank / launches) / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
                 out["roofline_tree"] = {
-                    "kernel": ("k_round_big<Tawlbwrdd> + k_compact (one shard-round)" if tafl else "k_cache_insert + k_sim<Connect4> (one shard-round; the move step rides in the net launch)"),
+                    "kernel": ("k_cache_insert + k_round_big<StarGambit> + k_compact (one shard-round)" if sg else "k_round_big<Tawlbwrdd> + k_compact (one shard-round)" if tafl else "k_cache_insert + k_sim<Connect4> (one shard-round; the move step rides in the net launch)"),
                     "bound": "hbm", "achieved": tree_launch, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": tree_launch / HBM_PEAK_GBS, "traffic": None, "per_launch_event_ms": tree_ms,
                     "aggregate_achieved": b_sim * sims_rank / dt / 1e9, "aggregate_frac": b_sim * sims_rank / dt / 1e9 / HBM_PEAK_GBS,
@@ -563,7 +572,7 @@ def main():
             # HBM-side traffic of the dominant kernel: not measurable from inside the process; taken from the committed
             # rocprofv3 --pmc summary of this same command (scripts/gpu_pmc.sh -> profiles/rN_pmc_traffic.csv), per launch,
             # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on gfx950
-            pmc = next((p for p in (os.path.join(ROOT, "profiles", f"r{n}_pmc_traffic{'_tawlbwrdd' if tafl else ''}.csv") for n in (2, 1)) if os.path.exists(p)), None)
+            pmc = next((p for p in (os.path.join(ROOT, "profiles", f"r{n}_pmc_traffic{'_stargambit' if sg else '_tawlbwrdd' if tafl else ''}.csv") for n in (2, 1)) if os.path.exists(p)), None)
             if hip_net is not None and pmc:
                 for line in open(pmc):
                     f = line.strip().split(",")

@@ -285,3 +285,112 @@ def test_playout_seats_and_playout_eval(oracle):
         assert np.array_equal(v, ov) and np.array_equal(pi, opi), seed
     pp = _pp(az, eval_type=[az.EvalType.PLAYOUT, az.EvalType.RANDOM], games_to_play=4, concurrent_games=4, mcts_visits=[10, 10])
     _compare(az, oracle, (0, (0.25,) * 4), pp, seed=91)
+
+
+# ---- NN in the loop (tier T3) and BASELINE configs[4] at full size -------------------------------------------------------------
+def _net_eval(hip):
+    import torch
+    dev = torch.device("cuda", 0)
+
+    def f(canon):
+        v, pi = hip.process(torch.from_numpy(np.ascontiguousarray(canon)).to(dev))
+        torch.cuda.synchronize()
+        return v.cpu().numpy(), pi.cpu().numpy()
+    return f
+
+
+def _run_with_net(az, pm, hip):
+    import torch
+    st = torch.cuda.Stream()
+    while pm.remaining_games() > 0:
+        az.run_rounds([pm], hip, 64, [st.cuda_stream])
+        if pm.poll(st.cuda_stream)[1] == 0:
+            break
+    torch.cuda.synchronize()
+
+
+def test_nn_in_the_loop_equals_the_oracle_driven_by_the_same_net(oracle):
+    """T3 on StarGambit (configs/star_gambit_unified.yaml search: Gumbel, improved-policy targets, per-variant temperature decay):
+    the device fast path with the HIP net (k_leafnet_spatial<13,13,2>, relative values rotated to absolute in process_result)
+    plays exactly the games of the oracle PlayManager whose evaluator sends each leaf's planes through the same net"""
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.stargambit_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=17), spec)
+    S, seed = 6, 321
+    pp = _pp(az, eval_type=[], games_to_play=S, concurrent_games=S, max_batch_size=S, mcts_visits=[20, 20], model_groups=[0, 0],
+             gumbel_enabled=True, gumbel_m=8, start_temp=1.2, final_temp=0.2, temp_decay_half_life_by_variant=[3.0, 4.0, 5.0, 8.0])
+    pm = az.PlayManager(az.StarGambitUnifiedGS(), pp, seed=seed, log_moves=True)
+    _run_with_net(az, pm, hip)
+    assert pm.games_completed() == S
+    rows, counts = pm.move_log()
+    ev = _net_eval(hip)
+    for s in (0, 3, 5):
+        one = az.PlayParams(); one.__dict__.update(pp.__dict__)
+        one.games_to_play, one.concurrent_games, one.max_batch_size = 1, 1, 1
+        o = oracle.PlayManager(oracle.Game.sg_unified(), one, oracle.slot_seed(seed, s), per_slot_rng=False, perm_base=s)
+        o.run(ev)
+        orows, ocounts = o.moves()
+        sel = (rows[:, 0] == s) & (rows[:, 1] == 0)
+        assert sel.sum() == len(orows) > 0, (s, int(sel.sum()), len(orows))
+        assert np.array_equal(rows[sel][:, 2:], orows[:, 2:]), f"slot {s}: moves / stream positions differ from the oracle driven by the same net"
+        assert np.array_equal(counts[sel], ocounts), f"slot {s}: visit counts differ"
+
+
+def test_full_size_configs4_random_evaluator_equals_the_oracle(oracle):
+    """BASELINE configs[4] per GPU - star_gambit_unified, 1024 concurrent games, 800 simulations per move - with the RANDOM
+    evaluator, every game to its end: size-independent properties over all moves + sampled slots equal the oracle move for move"""
+    import alphazero as az
+    S, sims, seed = 1024, 800, 8088
+    pp = _pp(az, games_to_play=S, concurrent_games=S, mcts_visits=[sims, sims], epsilon=0.25, shaped_dirichlet=True, mcts_root_temp=1.25,
+             root_fpu_zero=True, policy_target_pruning=True, start_temp=1.2, final_temp=0.2, temp_decay_half_life_by_variant=[3.0, 4.0, 5.0, 8.0])
+    pm = az.PlayManager(az.StarGambitUnifiedGS(), pp, seed=seed, log_moves=True, history_capacity=S * 400)
+    pm.play()
+    assert pm.games_completed() == S
+    rows, counts = pm.move_log()
+    assert (counts.sum(1) >= sims - 1).all()          # every search had its full budget (a reused subtree brings its earlier visits along)
+    assert (pm.scores().sum() == S) and pm.scores()[2] < S
+    assert sum(pm.variant_games_completed(v) for v in range(4)) == S and all(pm.variant_games_completed(v) > 150 for v in range(4))
+    hc, hv, hp = pm.history()
+    assert len(hc) == len(rows) and np.allclose(hp.sum(1), 1.0, atol=1e-4) and (hv.sum(1) == 1.0).all()
+    assert (hc[:, 0].reshape(len(hc), -1).sum(1) >= 91).all()                            # channel 0 = the variant's board mask
+    assert ((hc[:, 32:36].reshape(len(hc), 4, -1).sum(2) > 0).sum(1) == 1).all()         # exactly one variant plane is lit
+    assert pm.avg_moves_per_turn() > 1.5                                                  # several actions per turn
+    for s in (0, 511, 1023):
+        one = az.PlayParams(); one.__dict__.update(pp.__dict__)
+        one.games_to_play, one.concurrent_games = 1, 1
+        o = oracle.PlayManager(oracle.Game.sg_unified(), one, oracle.slot_seed(seed, s), per_slot_rng=False, perm_base=s)
+        o.run()
+        orows, ocounts = o.moves()
+        sel = (rows[:, 0] == s) & (rows[:, 1] == 0)
+        assert sel.sum() == len(orows) > 0 and np.array_equal(rows[sel][:, 2:], orows[:, 2:]) and np.array_equal(counts[sel], ocounts), s
+
+
+def test_full_size_configs4_with_the_hip_net_and_the_device_cache():
+    """configs[4] with its evaluator and its cache (200 000 entries, config.py:197): 1024 games x 800 sims on four engine shards,
+    a bounded number of rounds; the cache takes part, the net sees only the misses, every sample row is well formed"""
+    import torch
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.stargambit_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=3), spec)
+    K, S, sims = 4, 1024, 800
+    pms = []
+    for i in range(K):
+        pp = _pp(az, eval_type=[], games_to_play=1 << 30, concurrent_games=S // K, max_batch_size=S // K, mcts_visits=[sims, sims],
+                 model_groups=[0, 0], epsilon=0.25, shaped_dirichlet=True, mcts_root_temp=1.25, root_fpu_zero=True, policy_target_pruning=True,
+                 start_temp=1.2, final_temp=0.2, temp_decay_half_life_by_variant=[3.0, 4.0, 5.0, 8.0], max_cache_size=200000 // K)
+        pms.append(az.PlayManager(az.StarGambitUnifiedGS(), pp, seed=77 + i, history_capacity=(S // K) * 400))
+    streams = [torch.cuda.Stream() for _ in range(K)]
+    sps = [s.cuda_stream for s in streams]
+    for _ in range(6):
+        az.run_rounds(pms, hip, 1024, sps)
+    torch.cuda.synchronize()
+    c = [pm.counters() for pm in pms]
+    sims_done, evals, hits = (sum(x[k] for x in c) for k in ("sims", "evals", "cache_hits"))
+    assert sims_done > 4e6 and hits > 0 and 0 < evals < sims_done
+    for pm in pms:
+        pm.poll()
+        hc, hv, hp = pm.history()
+        if len(hc):
+            assert np.allclose(hp.sum(1), 1.0, atol=1e-4) and (hv.sum(1) == 1.0).all() and np.isfinite(hc).all()
