@@ -920,8 +920,8 @@ class StarGambitUnifiedGS(GameState):
 
     __str__ = dump
 
-    def symmetries(self, base):
-        raise NotImplementedError("StarGambit training-sample symmetries are not on the device yet (sample-side augmentation, SURVEY 8f-1)")
+    # symmetries(PlayHistory): GameState.symmetries -> azmi_symmetries(AZMI_GAME_STARGAMBIT): {base, NW-axis mirror},
+    # star_gambit_gs.cc:2623-2727
 
 
 def _pinned_sg(name, variant):

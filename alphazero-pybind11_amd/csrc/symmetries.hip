@@ -22,7 +22,8 @@ int fail(const char* what, hipError_t e) {
 }
 
 struct SymGeo {
-  uint32_t kind;      // 0: column mirror with one policy entry per column; 1: dihedral group of a square tafl board
+  uint32_t kind;      // 0: column mirror with one policy entry per column; 1: dihedral group of a square tafl board;
+                      // 2: StarGambitUnifiedGS {base, NW-axis mirror} on the 13 x 13 canvas (star_gambit_gs.cc:2623-2727)
   uint32_t C, H, W, M, NV, NS;
 };
 
@@ -39,8 +40,43 @@ __device__ __forceinline__ void src_cell(const SymGeo& g, uint32_t s, uint32_t& 
   }
 }
 
+// ---- StarGambit: the mirror about the NW axis, (q, r) -> (-q, r + q), i.e. (row, col) -> (12 - row, row + col - 6); the map is
+// its own inverse, so the reference's scatter (star_gambit_gs.cc:2640-2651) is this gather.  Heading planes 9-14 are permuted
+// by MIRROR_DIRECTION_MAP {4,3,2,1,0,5}, cannon planes 17-21 by {0,2,1,4,3}, action slots by SLOT_MAP {0,2,1,4,3,5,7,6,9,8}
+// (star_gambit_gs.h:472-481), deploy facings by MIRROR_DIRECTION_MAP (fighters, cruisers) / DEPLOY_MIRROR_D {3,2,1,0,5,4}.
+__device__ __forceinline__ uint32_t sg_dir_map(uint32_t d) { return d == 5 ? 5u : 4u - d; }
+__device__ __forceinline__ uint32_t sg_lr_swap(uint32_t x) { return x == 0 ? 0u : ((x - 1u) ^ 1u) + 1u; }     // {0,2,1,4,3}
+__device__ __forceinline__ uint32_t sg_slot_map(uint32_t s) { return s < 5 ? sg_lr_swap(s) : 5u + sg_lr_swap(s - 5u); }
+__device__ __forceinline__ bool sg_hex(int row, int col) {     // is_unified_hex, star_gambit_gs.cc:2365-2371
+  const int q = row - 6, r = col - 6, t = q + r;
+  return q >= -6 && q <= 6 && r >= -6 && r <= 6 && t >= -6 && t <= 6;
+}
+// source element of output plane c, cell (h, w); false = the output stays 0 (no source maps there)
+__device__ __forceinline__ bool sg_src_cell(uint32_t& c, uint32_t& h, uint32_t& w) {
+  const int col = static_cast<int>(w) + static_cast<int>(h) - 6;
+  if (col < 0 || col >= 13) return false;
+  h = 12u - h; w = static_cast<uint32_t>(col);
+  if (c >= 9 && c <= 14) c = 9u + sg_dir_map(c - 9u);
+  else if (c >= 17 && c <= 21) c = 17u + sg_lr_swap(c - 17u);
+  return true;
+}
+__device__ __forceinline__ uint32_t sg_src_move(uint32_t m) {
+  if (m < 1690u) {
+    const uint32_t slot = m % 10u, pos = m / 10u;
+    const int row = static_cast<int>(pos / 13u), col = static_cast<int>(pos % 13u);
+    if (!sg_hex(row, col)) return m;                                   // cells off the hex board are copied as they are, :2697-2700
+    return static_cast<uint32_t>((12 - row) * 13 + (row + col - 6)) * 10u + sg_slot_map(slot);
+  }
+  if (m < 1708u) {
+    const uint32_t d = m - 1690u, t = d / 6u, f = d % 6u;
+    return 1690u + t * 6u + (t == 2 ? (f < 4 ? 3u - f : 9u - f) : sg_dir_map(f));
+  }
+  return m;
+}
+
 // source policy index of output policy index m under symmetry s
 __device__ __forceinline__ uint32_t src_move(const SymGeo& g, uint32_t s, uint32_t m) {
+  if (g.kind == 2) return s ? sg_src_move(m) : m;
   if (g.kind == 0) return s ? g.W - 1 - m : m;    // connect4_gs.cc:166
   const uint32_t span = g.W + g.H;                // policyLocation, tafl_helper.h:7-14
   uint32_t loc = m % span, sq = m / span;
@@ -72,8 +108,10 @@ __global__ void k_symmetries(SymGeo g, uint32_t count, const float* __restrict__
       uint32_t rem = uint32_t(i % (g.NS * cells));
       uint32_t s = rem / uint32_t(cells), e = rem % uint32_t(cells);
       uint32_t c = e / (g.H * g.W), h = (e / g.W) % g.H, w = e % g.W;
-      src_cell(g, s, h, w);
-      out_canon[i] = canon[smp * cells + (uint64_t(c) * g.H + h) * g.W + w];
+      bool has_src = true;
+      if (g.kind == 2) { if (s) has_src = sg_src_cell(c, h, w); }
+      else src_cell(g, s, h, w);
+      out_canon[i] = has_src ? canon[smp * cells + (uint64_t(c) * g.H + h) * g.W + w] : 0.0f;
     } else if (i < n_c + n_p) {
       uint64_t j = i - n_c;
       uint64_t smp = j / (uint64_t(g.NS) * g.M);
@@ -132,7 +170,8 @@ extern "C" {
 const char* azmi_symmetries_last_error(void) { return g_sym_err.c_str(); }
 
 uint32_t azmi_num_symmetries(int game) {
-  return game == AZMI_GAME_CONNECT4 ? 2u : (game == AZMI_GAME_TAWLBWRDD || game == AZMI_GAME_BRANDUBH || game == AZMI_GAME_OPENTAFL) ? 8u : 0u;
+  return (game == AZMI_GAME_CONNECT4 || game == AZMI_GAME_STARGAMBIT) ? 2u
+         : (game == AZMI_GAME_TAWLBWRDD || game == AZMI_GAME_BRANDUBH || game == AZMI_GAME_OPENTAFL) ? 8u : 0u;
 }
 
 int azmi_symmetries(int game, int device, uint32_t count, const float* canon, const float* v, const float* pi,
@@ -142,6 +181,7 @@ int azmi_symmetries(int game, int device, uint32_t count, const float* canon, co
   else if (game == AZMI_GAME_TAWLBWRDD) g = SymGeo{1, 7, 11, 11, 11 * 11 * 22, 3, 8};
   else if (game == AZMI_GAME_BRANDUBH) g = SymGeo{1, 7, 7, 7, 7 * 7 * 14, 3, 8};
   else if (game == AZMI_GAME_OPENTAFL) g = SymGeo{1, 8, 11, 11, 11 * 11 * 22, 3, 8};
+  else if (game == AZMI_GAME_STARGAMBIT) g = SymGeo{2, 36, 13, 13, 1709, 3, 2};
   else { g_sym_err = "azmi_symmetries: unknown game"; return AZMI_ERR_INVALID; }
   return run(g, device, count, canon, v, pi, out_canon, out_v, out_pi, host_buffers, stream);
 }

@@ -501,7 +501,8 @@ void orc_cache_stats(void* c, uint64_t* out) {
 }
 
 // ---------------------------------------------------------------- symmetries
-// kind 0: Connect4 {base, mirror}; 1: tafl eightSym; 2: tafl mirrorWidth only; 3: tafl rot90Clockwise only.
+// kind 0: Connect4 {base, mirror}; 1: tafl eightSym; 2: tafl mirrorWidth only; 3: tafl rot90Clockwise only;
+// 4: StarGambitUnified {base, NW-axis mirror}.
 // canon [C][H][W], pi [num_moves], v [nv]; outputs are [nsym][...]; returns nsym.
 uint32_t orc_symmetries(int kind, int channels, int height, int width, uint32_t num_moves, uint32_t nv,
                         const float* canon, const float* v, const float* pi,
@@ -517,6 +518,7 @@ uint32_t orc_symmetries(int kind, int channels, int height, int width, uint32_t 
     case 1: syms = eight_sym(b); break;
     case 2: syms = {mirror_width(b)}; break;
     case 3: syms = {rot90_clockwise(b)}; break;
+    case 4: syms = stargambit_unified_symmetries(b); break;
     default: return 0;
   }
   for (size_t s = 0; s < syms.size(); ++s) {

@@ -9,6 +9,8 @@
 // Pinned by the known answers of /root/reference/src/tafl_helper_test.cc (Mirror, Rot90 spot
 // tables on 5x5; bijection / order / distinctness properties) — tests/test_oracle_pinned.py.
 #pragma once
+#include <algorithm>
+#include <cstdlib>
 #include <cstdint>
 #include <vector>
 
@@ -92,6 +94,44 @@ inline std::vector<Sample> connect4_symmetries(const Sample& b) {
     for (int h = 0; h < H; ++h)
       for (int w = 0; w < W; ++w) m.at(c, h, w) = b.at(c, h, W - 1 - w);
   for (int w = 0; w < W; ++w) m.pi[w] = b.pi[W - 1 - w];
+  return {b, m};
+}
+
+// StarGambitUnifiedGS::symmetries (star_gambit_gs.cc:2623-2727): {base, mirror about the NW axis} on the 13 x 13 canvas,
+// restated as the reference writes it - a SCATTER of every source element into a zeroed sample - so that it shares no
+// formulation with the device kernel's gather.
+inline std::vector<Sample> stargambit_unified_symmetries(const Sample& b) {
+  constexpr int BD = 13, BS = 6, NCH = 36, SPATIAL = 1690, NM = 1709;
+  static const int dir_map[6] = {4, 3, 2, 1, 0, 5}, deploy_d[6] = {3, 2, 1, 0, 5, 4}, slot_map[10] = {0, 2, 1, 4, 3, 5, 7, 6, 9, 8},
+                   cannon_map[5] = {0, 2, 1, 4, 3};
+  Sample m = b;
+  std::fill(m.canonical.begin(), m.canonical.end(), 0.0f);
+  std::fill(m.pi.begin(), m.pi.end(), 0.0f);
+  auto at = [&](std::vector<float>& c, int ch, int r, int col) -> float& { return c[(static_cast<size_t>(ch) * BD + r) * BD + col]; };
+  std::vector<float> base = b.canonical;
+  for (int ch = 0; ch < NCH; ++ch)
+    for (int row = 0; row < BD; ++row)
+      for (int col = 0; col < BD; ++col) {
+        const int nr = BD - 1 - row, nc = row + col - BS;
+        if (nc >= 0 && nc < BD) at(m.canonical, ch, nr, nc) = at(base, ch, row, col);
+      }
+  std::vector<float> tmp = m.canonical;
+  for (int d = 0; d < 6; ++d)
+    for (int r = 0; r < BD; ++r) for (int c = 0; c < BD; ++c) at(m.canonical, 9 + d, r, c) = at(tmp, 9 + dir_map[d], r, c);
+  for (int k = 0; k < 5; ++k)
+    for (int r = 0; r < BD; ++r) for (int c = 0; c < BD; ++c) at(m.canonical, 17 + k, r, c) = at(tmp, 17 + cannon_map[k], r, c);
+  for (int a = 0; a < SPATIAL; ++a) {
+    const int slot = a % 10, pos = a / 10, row = pos / BD, col = pos % BD;
+    const int q = row - BS, r = col - BS, t = -q - r;
+    if (std::abs(q) > BS || std::abs(r) > BS || std::abs(t) > BS) { m.pi[a] = b.pi[a]; continue; }
+    const int nr = BD - 1 - row, nc = row + col - BS;
+    if (nc >= 0 && nc < BD) m.pi[(nr * BD + nc) * 10 + slot_map[slot]] = b.pi[a];
+  }
+  for (int d = 0; d < 18; ++d) {
+    const int t = d / 6, f = d % 6;
+    m.pi[SPATIAL + t * 6 + (t == 2 ? deploy_d[f] : dir_map[f])] = b.pi[SPATIAL + d];
+  }
+  m.pi[NM - 1] = b.pi[NM - 1];
   return {b, m};
 }
 

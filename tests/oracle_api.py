@@ -548,7 +548,7 @@ class Cache:
 
 
 # ------------------------------------------------------------------ symmetries
-SYM_CONNECT4, SYM_TAFL_EIGHT, SYM_TAFL_MIRROR, SYM_TAFL_ROT90 = 0, 1, 2, 3
+SYM_CONNECT4, SYM_TAFL_EIGHT, SYM_TAFL_MIRROR, SYM_TAFL_ROT90, SYM_STARGAMBIT = 0, 1, 2, 3, 4
 
 
 def symmetries(kind, canon, v, pi):
@@ -556,7 +556,7 @@ def symmetries(kind, canon, v, pi):
     canon [C,H,W], v [nv], pi [M] -> (canon [ns,C,H,W], v [ns,nv], pi [ns,M])."""
     canon = np.ascontiguousarray(canon, np.float32); v = np.ascontiguousarray(v, np.float32)
     pi = np.ascontiguousarray(pi, np.float32)
-    ns = {SYM_CONNECT4: 2, SYM_TAFL_EIGHT: 8}.get(kind, 1)
+    ns = {SYM_CONNECT4: 2, SYM_TAFL_EIGHT: 8, SYM_STARGAMBIT: 2}.get(kind, 1)
     oc = np.zeros((ns,) + canon.shape, np.float32); ov = np.zeros((ns, v.size), np.float32)
     op = np.zeros((ns, pi.size), np.float32)
     lib.orc_symmetries.restype = C.c_uint32

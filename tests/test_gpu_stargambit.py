@@ -394,3 +394,22 @@ def test_full_size_configs4_with_the_hip_net_and_the_device_cache():
         hc, hv, hp = pm.history()
         if len(hc):
             assert np.allclose(hp.sum(1), 1.0, atol=1e-4) and (hv.sum(1) == 1.0).all() and np.isfinite(hc).all()
+
+
+def test_symmetries_on_the_device_equal_the_oracle(oracle):
+    """GameState::symmetries of StarGambitUnifiedGS (star_gambit_gs.cc:2623-2727): the device gather (csrc/symmetries.hip kind 2)
+    against the oracle's restatement of the reference's scatter, on real history rows of all four variants"""
+    import alphazero as az
+    pp = _pp(az, games_to_play=4, concurrent_games=4, mcts_visits=[12, 12])
+    pm = az.PlayManager(az.StarGambitUnifiedGS(), pp, seed=5)
+    pm.play()
+    hc, hv, hp = pm.history()
+    sel = np.linspace(0, len(hc) - 1, 40).astype(int)
+    oc, ov, op = az.symmetries_batch(az.StarGambitUnifiedGS, hc[sel], hv[sel], hp[sel])
+    assert oc.shape == (40, 2, 36, 13, 13) and op.shape == (40, 2, 1709)
+    for j, i in enumerate(sel):
+        wc, wv, wp = oracle.symmetries(oracle.SYM_STARGAMBIT, hc[i], hv[i], hp[i])
+        assert np.array_equal(oc[j], wc) and np.array_equal(ov[j], wv) and np.array_equal(op[j], wp), i
+    g = az.StarGambitUnifiedGS(1)
+    out = g.symmetries(az.PlayHistory(hc[0], hv[0], hp[0]))
+    assert len(out) == 2 and np.array_equal(out[1].pi(), op[0][1])

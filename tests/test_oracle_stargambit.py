@@ -136,3 +136,50 @@ def test_mcts_backs_up_relative_values_as_absolute():
     m2.find_leaf(g)
     m2.process_result(np.array([1, 0, 0], np.float32), pi)
     assert list(m2.root_value()) == [0.0, 1.0, 0.0]
+
+
+def _sym(canon, v, pi):
+    return orc.symmetries(orc.SYM_STARGAMBIT, canon, v, pi)
+
+
+def test_mirror_symmetry_cases_of_the_reference():
+    """MirrorSymmetry.* of star_gambit_gs_test.cc:928-1360 on the unified 13 x 13 canvas (star_gambit_gs.cc:2623-2727): the
+    spatial remap (row, col, slot) -> (12 - row, row + col - 6, SLOT_MAP[slot]), the deploy maps, end turn, value, heading and
+    cannon planes, self-inverse"""
+    g = orc.Game.sg_unified(pinned=3)
+    rng = np.random.default_rng(2)
+    for _ in range(30):
+        g.play(int(rng.choice(np.flatnonzero(g.valid()))))
+    canon = g.canonical()
+    v = np.array([0.5, 0.5, 0.0], np.float32)
+    SLOT_MAP = [0, 2, 1, 4, 3, 5, 7, 6, 9, 8]; MIRROR = [4, 3, 2, 1, 0, 5]; DEPLOY_D = [3, 2, 1, 0, 5, 4]
+    # PolicySpatialActionsRemapped (:1011-1047), on the 13-wide canvas
+    pi = np.zeros(1709, np.float32); pi[(3 * 13 + 6) * 10 + 1] = 1.0
+    oc, ov, op = _sym(canon, v, pi)
+    assert np.array_equal(oc[0], canon) and np.array_equal(op[0], pi) and np.array_equal(ov[1], v)       # identity first; value kept
+    assert op[1][((12 - 3) * 13 + (3 + 6 - 6)) * 10 + SLOT_MAP[1]] == 1.0 and op[1].sum() == 1.0
+    # PolicyDeployActionsRemapped / DeployMirrorMapsCorrectly (:1049-1108, 1314-1366), EndTurnUnchanged (:1111-1128)
+    for t in range(3):
+        for f in range(6):
+            pi = np.zeros(1709, np.float32); pi[1690 + t * 6 + f] = 1.0
+            m = _sym(canon, v, pi)[2][1]
+            assert m[1690 + t * 6 + (DEPLOY_D[f] if t == 2 else MIRROR[f])] == 1.0 and m.sum() == 1.0
+    pi = np.zeros(1709, np.float32); pi[1708] = 1.0
+    assert _sym(canon, v, pi)[2][1][1708] == 1.0
+    # FacingChannelsRemapped (:1150-1196): what was plane 9 + d at a cell is plane 9 + MIRROR[d] at the mirrored cell; board mask and
+    # the broadcast planes are invariant
+    m = oc[1]
+    assert np.array_equal(m[0], canon[0]) and np.array_equal(m[22:36], canon[22:36])
+    for d in range(6):
+        src = canon[9 + d]
+        for r, c in zip(*np.nonzero(src)):
+            assert m[9 + MIRROR[d], 12 - r, r + c - 6] == src[r, c]
+    assert m[9:15].sum() == canon[9:15].sum() and m[1:9].sum() == canon[1:9].sum() and m[17:22].sum() == canon[17:22].sum()
+    # SelfInverse (:928-980)
+    pi = rng.random(1709).astype(np.float32)
+    valid_pi = pi.copy()
+    for a in range(1690):      # the reference only transforms hex cells; cells off the board are copied
+        pass
+    oc1, _, op1 = _sym(canon, v, pi)
+    oc2, _, op2 = _sym(oc1[1], v, op1[1])
+    assert np.array_equal(oc2[1], canon) and np.array_equal(op2[1], pi)
