@@ -31,6 +31,10 @@ class SelfPlayResult:          # the fields of game_runner.SelfPlayResult that c
     simulations: int
     leaf_evaluations: int
     samples: int
+    # games with variants (StarGambitUnifiedGS; game_runner.py:2136-2145, 153-176): {variant id: ...}, empty otherwise
+    variant_game_counts: dict = dataclasses.field(default_factory=dict)
+    variant_win_rates: dict = dataclasses.field(default_factory=dict)
+    variant_metrics: dict = dataclasses.field(default_factory=dict)
 
 
 def _shard_params(params, k, K):
@@ -106,6 +110,17 @@ def self_play(game, params, net=None, engines=4, seed=20240601, device=0, stream
         avg_moves_per_turn=div(sums["moves"], sums["game_length"]), avg_valid_moves=div(sums["valid_moves"], sums["moves"]),
         cache_saturation=div(csize, cmax), cache_churn=div(evictions, hits), games=int(sums["games"]),
         simulations=sum(c["sims"] for c in cn), leaf_evaluations=sum(c["evals"] for c in cn), samples=n_samples)
+    # per-variant read-out: the shards' raw sums (azmi_pm_variant_sums) added up, then the reference's own divisions
+    for vid in range(pms[0].num_tracked_variants()):
+        vs = np.sum([pm.variant_sums(vid) for pm in pms], 0)
+        vscores = np.sum([pm.variant_scores(vid) for pm in pms], 0)
+        res.variant_game_counts[vid] = int(vs[1])
+        if vs[1] > 0:
+            vn = float(vscores.sum())
+            res.variant_win_rates[vid] = [div(float(x), vn) for x in vscores]
+            res.variant_metrics[vid] = dict(game_length=div(vs[0], vs[1]), avg_depth=div(vs[5], vs[3]), avg_entropy=div(vs[6], vs[3]),
+                                            avg_mpt=div(vs[2], vs[0]), avg_vm=div(vs[9], vs[2]), fast_avg_depth=div(vs[7], vs[4]),
+                                            fast_avg_entropy=div(vs[8], vs[4]))
     res._pms = pms                      # keeps the engines (and the device memory behind `samples`) alive
     if data_folder is not None and n_samples:
         from . import history_io

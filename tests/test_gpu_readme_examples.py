@@ -35,3 +35,15 @@ def test_readme_host_path_and_device_path(tmp_path):
     vv, pp = my_model(np.zeros((1, 4, 6, 7)))
     m.process_result(gs, vv[0], pp[0])
     assert m.depth() == 1
+
+
+def test_readme_stargambit_snippet():
+    import alphazero
+    from alphazero import selfplay, torch_net
+    params = alphazero.PlayParams()
+    params.games_to_play, params.concurrent_games, params.max_batch_size = 4, 4, 4
+    params.mcts_visits = [12, 12]; params.model_groups = [0, 0]; params.history_enabled = True
+    params.temp_decay_half_life_by_variant = [3, 4, 5, 8]
+    sg_net = alphazero.HipLeafNet(torch_net.random_init(torch_net.stargambit_spec()), torch_net.stargambit_spec())
+    result, samples = selfplay.self_play(alphazero.StarGambitUnifiedGS(-1, [0.25] * 4), params, sg_net, engines=2)
+    assert result.games == 4 and sum(result.variant_game_counts.values()) == 4 and samples[0].shape[1:] == (36, 13, 13)

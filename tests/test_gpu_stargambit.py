@@ -413,3 +413,27 @@ def test_symmetries_on_the_device_equal_the_oracle(oracle):
     g = az.StarGambitUnifiedGS(1)
     out = g.symmetries(az.PlayHistory(hc[0], hv[0], hp[0]))
     assert len(out) == 2 and np.array_equal(out[1].pi(), op[0][1])
+
+
+def test_self_play_harness_on_stargambit(oracle):
+    """alphazero.selfplay.self_play (the device counterpart of GameRunner.run + self_play(), game_runner.py:2057-2160) on the
+    unified game: two engine shards, RANDOM evaluator; the sample rows equal the union of the oracle's per-slot runs byte for
+    byte and the per-variant read-out (game_runner.py:2136-2145) adds up"""
+    import alphazero as az
+    from alphazero import selfplay
+    pp = _pp(az, games_to_play=8, concurrent_games=8, mcts_visits=[16, 16], temp_decay_half_life_by_variant=[3.0, 4.0, 5.0, 8.0], final_temp=0.2)
+    res, (c, v, p) = selfplay.self_play(az.StarGambitUnifiedGS(), pp, net=None, engines=2, seed=99)
+    assert res.games == 8 and res.samples == len(c) and sum(res.variant_game_counts.values()) == 8
+    rows = []
+    for k in range(2):
+        for s in range(4):
+            one = az.PlayParams(); one.__dict__.update(pp.__dict__)
+            one.games_to_play, one.concurrent_games = 1, 1
+            o = oracle.PlayManager(oracle.Game.sg_unified(), one, oracle.slot_seed(selfplay.shard_seed(99, k), s), per_slot_rng=False, perm_base=s)
+            o.run()
+            rows.append(o.history())
+    oc = np.concatenate([h[0] for h in rows]); ov = np.concatenate([h[1] for h in rows]); op = np.concatenate([h[2] for h in rows])
+    assert _rows_multiset(c, v, p) == _rows_multiset(oc, ov, op)
+    for vid, n in res.variant_game_counts.items():
+        if n:
+            assert abs(sum(res.variant_win_rates[vid]) - 1.0) < 1e-6 and res.variant_metrics[vid]["avg_mpt"] >= 1.0
