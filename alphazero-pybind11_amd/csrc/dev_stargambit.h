@@ -127,7 +127,15 @@ struct StarGambit {
     const unsigned long long w = cell < 64 ? m.a : cell < 128 ? m.b : m.c;
     return (w >> (cell & 63u)) & 1ull;
   }
-  __device__ __forceinline__ static void lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __syncthreads(); }
+  // cross-lane hand-over inside the game's wavefront (every kernel that runs these rules uses 64-thread workgroups): a
+  // wavefront-scope fence, see BigSlot::sync (engine_kernels_big.h)
+  __device__ __forceinline__ static void lds_sync() {
+#ifdef AZMI_WG_SYNC
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __syncthreads();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+#endif
+  }
   template <class T>
   __device__ __forceinline__ static T wave_xor(T v) {
     for (int off = 32; off > 0; off >>= 1) v ^= __shfl_xor(v, off, 64);
@@ -619,7 +627,7 @@ __device__ inline bool sg_parse_image(const uint8_t* b, uint32_t bytes, uint32_t
     hist[i] = x;
   }
   nhist = hl;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __syncthreads();
+  G::lds_sync();
   const unsigned long long cur = G::position_hash(s);      // canonical plane 23 counts the current position in the history, :1591-1599
   uint32_t cnt = 0;
   for (uint32_t i = lane; i < hl; i += 64) cnt += hist[i] == cur;

@@ -92,7 +92,18 @@ struct BigSlot {
 
   __device__ __forceinline__ size_t tree_base(uint32_t seat) const { return (static_cast<size_t>(slot) * P + seat) * ep.cap; }
   __device__ __forceinline__ void raise(uint32_t bit) const { if (lane == 0) { atomicOr(&ar.ctl->overflow, bit); ar.ctl->stop = 1; } }
-  __device__ __forceinline__ void sync() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __syncthreads(); }
+  // Cross-LANE hand-over inside the slot's wavefront (LDS scratch, node records, history lists written by some lanes and read by
+  // others).  The workgroup IS one wavefront, whose LDS and vector-memory operations are performed in order as seen by that
+  // wavefront (one LDS, one vector L1 per CU: the AMDGPU memory model needs no instruction for wavefront scope), so this is a
+  // wavefront-scope fence + a scheduling barrier for the compiler - NOT a workgroup fence, whose s_waitcnt vmcnt(0) would stall
+  // the wave on every store still in flight (AZMI_WG_SYNC restores the round-1 form for comparison).
+  __device__ __forceinline__ void sync() const {
+#ifdef AZMI_WG_SYNC
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __syncthreads();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+#endif
+  }
   __device__ __forceinline__ void set_seat(uint32_t (&arr)[P], uint32_t seat, uint32_t v) {
 #pragma unroll
     for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == seat) arr[p] = v;

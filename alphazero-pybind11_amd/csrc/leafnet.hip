@@ -113,11 +113,14 @@ struct SpatialPtrs {
   const float* pg_ln_b;    // [32] LayerNorm bias
 };
 
+// `live` (may be NULL): device-side number of rows that are real; workgroups past it exit at once (a row-list evaluation
+// packs the listed rows at the front of a max_rows batch)
 template <int H, int W, int TBS>
 __global__ __launch_bounds__(NTHREADS, 2) void k_leafnet_spatial(SpatialDesc nd, SpatialPtrs np, const float* __restrict__ canon,
                                                                   float* __restrict__ vpool_out, float* __restrict__ pi_out,
-                                                                  uint32_t batch) {
+                                                                  uint32_t batch, const uint32_t* __restrict__ live) {
   using G = Geo<H, W, TBS>;
+  if (live) { const uint32_t n = *live; if (blockIdx.x * TBS >= n) return; batch = n < batch ? n : batch; }
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   uint8_t* act = lds;
   uint8_t* wbuf = lds + G::ACT_BYTES;
@@ -181,18 +184,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_leafnet_spatial(SpatialDesc nd,
       }
       for (int i = tid * 16; i < 2 * MT * WFRAG_BYTES; i += NTHREADS * 16)
         *reinterpret_cast<u32x4*>(wbuf + i) = *reinterpret_cast<const u32x4*>(np.stem_w + pass * 2 * MT * WFRAG_BYTES + i);
-      if (tid < G::NPIX) {
+      if (tid < G::NPIX) {     // the 64 im2col rows of this pass: row r = tap * C_in + ci
         const int n = tid, b = n / G::PIX, p = n % G::PIX, h = p / W, w = p % W;
         const float* rb = raw + b * plane_sz;
-        for (int tap = 0; tap < 9; ++tap) {
+        const int r_end = (9 * nd.C_in < 64 * pass + 64) ? 9 * nd.C_in : 64 * pass + 64;
+        int tap = (64 * pass) / nd.C_in, ci = (64 * pass) % nd.C_in;
+        for (int r = 64 * pass; r < r_end; ++r) {
           const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
           const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
-          for (int ci = 0; ci < nd.C_in; ++ci) {
-            const int k = tap * nd.C_in + ci - 64 * pass;
-            if (k < 0 || k >= 64) continue;
-            const float val = ok ? rb[ci * G::PIX + hh * W + ww] : 0.0f;
-            *reinterpret_cast<__bf16*>(act + (k >> 3) * G::PLANE + n * 16 + (k & 7) * 2) = static_cast<__bf16>(val);
-          }
+          const float val = ok ? rb[ci * G::PIX + hh * W + ww] : 0.0f;
+          const int k = r - 64 * pass;
+          *reinterpret_cast<__bf16*>(act + (k >> 3) * G::PLANE + n * 16 + (k & 7) * 2) = static_cast<__bf16>(val);
+          if (++ci == nd.C_in) { ci = 0; ++tap; }
         }
       }
       __syncthreads();
@@ -524,8 +527,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_leafnet_spatial(SpatialDesc nd,
 constexpr int VFC_THREADS = 1024;
 constexpr int VFC_WAVES = VFC_THREADS / 64;
 __global__ __launch_bounds__(VFC_THREADS) void k_value_fc(SpatialDesc nd, SpatialPtrs np, const float* __restrict__ vpool,
-                                                         float* __restrict__ v_out, uint32_t batch) {
+                                                         float* __restrict__ v_out, uint32_t batch, const uint32_t* __restrict__ live) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  if (live) { const uint32_t n = *live; if (blockIdx.x * 16 >= n) return; batch = n < batch ? n : batch; }
   float* xa = reinterpret_cast<float*>(lds);                  // [v_hidden][16]
   float* xb = xa + nd.v_hidden * 16;
   float* part = xb + nd.v_hidden * 16;                        // [VFC_WAVES][16 outputs][16 boards]
@@ -847,7 +851,14 @@ void azmi_net_destroy(azmi_net* net) {
   delete net;
 }
 
+static int net_forward_live(azmi_net* net, const float* dev_canonical, float* dev_v, float* dev_pi, uint32_t batch, void* stream,
+                            const uint32_t* live);
 int azmi_net_forward(azmi_net* net, const float* dev_canonical, float* dev_v, float* dev_pi, uint32_t batch, void* stream) {
+  return net_forward_live(net, dev_canonical, dev_v, dev_pi, batch, stream, nullptr);
+}
+// `live`: device-side count of real rows at the front of the batch (row-list evaluation), NULL = all of them
+static int net_forward_live(azmi_net* net, const float* dev_canonical, float* dev_v, float* dev_pi, uint32_t batch, void* stream,
+                            const uint32_t* live) {
   if (!net || !dev_canonical || !dev_v || !dev_pi) return nfail(AZMI_ERR_INVALID, "null argument");
   if (batch == 0) return AZMI_OK;
   if (net->f32) {
@@ -871,12 +882,12 @@ int azmi_net_forward(azmi_net* net, const float* dev_canonical, float* dev_v, fl
       sc.vpool_rows = want;
     }
     if (net->sd.H == 11)
-      k_leafnet_spatial<11, 11, TBS11><<<(batch + TBS11 - 1) / TBS11, NTHREADS, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, sc.vpool, dev_pi, batch);
+      k_leafnet_spatial<11, 11, TBS11><<<(batch + TBS11 - 1) / TBS11, NTHREADS, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, sc.vpool, dev_pi, batch, live);
     else if (net->sd.H == 13)
-      k_leafnet_spatial<13, 13, TBS13><<<(batch + TBS13 - 1) / TBS13, NTHREADS, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, sc.vpool, dev_pi, batch);
+      k_leafnet_spatial<13, 13, TBS13><<<(batch + TBS13 - 1) / TBS13, NTHREADS, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, sc.vpool, dev_pi, batch, live);
     else
-      k_leafnet_spatial<7, 7, TBS7><<<(batch + TBS7 - 1) / TBS7, NTHREADS, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, sc.vpool, dev_pi, batch);
-    k_value_fc<<<(batch + 15) / 16, VFC_THREADS, net->vfc_lds, st>>>(net->sd, net->sp, sc.vpool, dev_v, batch);
+      k_leafnet_spatial<7, 7, TBS7><<<(batch + TBS7 - 1) / TBS7, NTHREADS, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, sc.vpool, dev_pi, batch, live);
+    k_value_fc<<<(batch + 15) / 16, VFC_THREADS, net->vfc_lds, st>>>(net->sd, net->sp, sc.vpool, dev_v, batch, live);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return nfail(AZMI_ERR_NO_DEVICE, "k_leafnet_spatial launch: %s", hipGetErrorString(e));
     return AZMI_OK;
@@ -912,7 +923,7 @@ int azmi_net_forward_rows(azmi_net* net, const float* dev_canonical, float* dev_
       sc.g_rows = max_rows;
     }
     k_gather_rows<<<max_rows, 256, 0, st>>>(dev_canonical, dev_rows, dev_row_count, max_rows, chw, sc.g_canon);
-    const int rc = azmi_net_forward(net, sc.g_canon, sc.g_v, sc.g_pi, max_rows, stream);
+    const int rc = net_forward_live(net, sc.g_canon, sc.g_v, sc.g_pi, max_rows, stream, net->f32 ? nullptr : dev_row_count);
     if (rc != AZMI_OK) return rc;
     k_scatter_rows<<<max_rows, 64, 0, st>>>(sc.g_v, sc.g_pi, dev_rows, dev_row_count, p1, m, dev_v, dev_pi);
     const hipError_t e = hipGetLastError();
