@@ -89,9 +89,12 @@ def _fold_trunk(net, sd, Cin):
     blob = bytearray()
     a, b = (t.cpu() for t in bn_affine(net.bn1))
     w = sd["conv1.weight"] * a[:, None, None, None]
-    wm = np.zeros((64, 64 * ((9 * Cin + 63) // 64)))     # im2col rows in passes of 64 (StarGambit's 36 planes: six)
-    wm[: w.shape[0], : 9 * Cin] = w.permute(0, 2, 3, 1).reshape(w.shape[0], 9 * Cin).numpy()
-    blob += _frags(wm) + _f32(_pad(b, 64))
+    if 9 * Cin > 128:     # many input planes (StarGambit: 36): the stem runs as one more 64-channel convolution, k = tap*64 + ci
+        blob += _frags(_pad(w.permute(0, 2, 3, 1), 64, 3, 3, 64).reshape(64, 576).numpy()) + _f32(_pad(b, 64))
+    else:
+        wm = np.zeros((64, 64 * ((9 * Cin + 63) // 64)))     # im2col rows in passes of 64 (k = tap*C_in + ci; up to two passes)
+        wm[: w.shape[0], : 9 * Cin] = w.permute(0, 2, 3, 1).reshape(w.shape[0], 9 * Cin).numpy()
+        blob += _frags(wm) + _f32(_pad(b, 64))
     for i, blk in enumerate(net.conv_layers):
         a1, b1 = (t.cpu() for t in bn_affine(blk.bn1))
         a2, b2 = (t.cpu() for t in bn_affine(blk.bn2))

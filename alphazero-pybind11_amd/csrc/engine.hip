@@ -872,7 +872,12 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
   ep.fast_gumbel = params->fast_search_uses_gumbel != 0;
   ep.seat_resign = seats.any_seat_resign ? 1u : 0u;
   ep.gum_stride = gi.maxk;
-  ep.max_inline = opts.max_inline ? opts.max_inline : 4;
+  // simulations a slot may finish inside one round without the net.  A round lasts as long as its SLOWEST slot, so inline
+  // continuation pays only where a simulation is cheap next to the net launch (Connect4: 4).  In the wide-game engine a
+  // simulation costs ~100 us: with NN seats one chain of cache hits / terminal leaves would stretch the round for every slot
+  // (measured: Tawlbwrdd 4.49 -> 5.01 M sims/s, StarGambit 1.74 -> 2.14 M sims/s with 1 instead of 4); with RANDOM / PLAYOUT
+  // seats only there is no net to wait for and 4 stands.
+  ep.max_inline = opts.max_inline ? opts.max_inline : ((game != AZMI_GAME_CONNECT4 && !seats.all_random) ? 1u : 4u);
   ep.sim_budget = getenv("AZMI_SIM_BUDGET_US") ? static_cast<uint32_t>(100.0 * atof(getenv("AZMI_SIM_BUDGET_US"))) : 0u;
   ep.max_hist_rows = gi.max_turns;
   ep.max_depth = gi.max_turns + 2;

@@ -155,8 +155,36 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_leafnet_spatial(SpatialDesc nd,
   for (int i = tid * 16; i < G::ACT_BYTES; i += NTHREADS * 16) *reinterpret_cast<u32x4*>(act + i) = u32x4{0, 0, 0, 0};
 
   // ---- stem ---------------------------------------------------------------------------------------------
+  f32x4 s[G::NT_W][MT];
+  const bool stem_as_conv = 9 * nd.C_in > 128;
+  if (stem_as_conv) {
+    // many input planes (StarGambit: 36): the stem is run as ONE MORE 64-channel convolution - the planes go into the
+    // activation layout as bf16 (channels >= C_in stay zero), the weights are conv fragments with zero columns for the
+    // padding (alphazero/hip_net.py) - instead of 9*C_in/64 im2col passes of scattered 2-byte LDS stores
+    __syncthreads();                         // the zero fill of the planes is complete
+    if (tid < G::NPIX) {
+      const int n = tid, b = n / G::PIX, p = n % G::PIX;
+      const bool on = board0 + b < batch;
+      const float* src = canon + static_cast<size_t>(board0 + b) * nd.C_in * G::PIX + p;
+      for (int ci = 0; ci < nd.C_in; ++ci)
+        *reinterpret_cast<__bf16*>(act + (ci >> 3) * G::PLANE + n * 16 + (ci & 7) * 2) = static_cast<__bf16>(on ? src[ci * G::PIX] : 0.0f);
+    }
+    for (int i = tid * 16; i < G::WCONV_BYTES; i += NTHREADS * 16)
+      *reinterpret_cast<u32x4*>(wbuf + i) = *reinterpret_cast<const u32x4*>(np.stem_w + i);
+    {
+      f32x4 bias[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) bias[mt] = *reinterpret_cast<const f32x4*>(np.stem_b + mt * 16 + quad * 4);
+#pragma unroll
+      for (int j = 0; j < G::NT_W; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) s[j][mt] = bias[mt];
+    }
+    __syncthreads();
+  }
   float* raw = reinterpret_cast<float*>(wbuf + 16384);
   const int plane_sz = nd.C_in * G::PIX;
+  if (!stem_as_conv)
   for (int i = tid; i < TBS * plane_sz; i += NTHREADS) {
     const uint32_t b = board0 + i / plane_sz;
     raw[i] = b < batch ? canon[static_cast<size_t>(b) * plane_sz + (i % plane_sz)] : 0.0f;
@@ -167,8 +195,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_leafnet_spatial(SpatialDesc nd,
   // input staging behind them (wbuf + 16 KB) has the rest of the weight area whatever the number of passes
   const int npass = (9 * nd.C_in + 63) / 64;
 
-  f32x4 s[G::NT_W][MT];
-  {
+  if (!stem_as_conv) {
     f32x4 bias[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) bias[mt] = *reinterpret_cast<const f32x4*>(np.stem_b + mt * 16 + quad * 4);
@@ -276,6 +303,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_leafnet_spatial(SpatialDesc nd,
     }
   };
 
+  if (stem_as_conv) conv3x3(s);
   const size_t block_stride = 3 * CH * sizeof(float) + 2 * static_cast<size_t>(G::WCONV_BYTES);
   prefetch(np.blocks + 3 * CH * sizeof(float));
   __syncthreads();
@@ -681,10 +709,14 @@ __global__ void k_scatter_rows(const float* __restrict__ v_c, const float* __res
 }
 bool is_spatial(const azmi_net_desc* d) { return d->policy_channels > 0; }
 size_t stem_passes(const azmi_net_desc* d) { return (9 * static_cast<size_t>(d->in_channels) + 63) / 64; }
+// stem weights: im2col passes of 64 rows (few input planes) or one 64-channel convolution (9 * C_in > 128)
+size_t stem_bytes(const azmi_net_desc* d) {
+  return 9 * d->in_channels > 128 ? static_cast<size_t>(18) * MT * WFRAG_BYTES : stem_passes(d) * 2 * MT * WFRAG_BYTES;
+}
 size_t spatial_blob_bytes(const azmi_net_desc* d) {
   const size_t wconv = 18 * MT * WFRAG_BYTES, wsmall = 2 * MT * WFRAG_BYTES;
   const size_t Hd = d->v_hidden, L = d->v_fc_layers;
-  size_t n = stem_passes(d) * wsmall + CH * 4;                        // stem: one 64-row k-chunk pair per pass
+  size_t n = stem_bytes(d) + CH * 4;                                  // stem
   n += static_cast<size_t>(d->depth) * (3 * CH * 4 + 2 * wconv);      // trunk
   n += 2 * 8 * WFRAG_BYTES + 128 * 4;                                 // head 1x1 convs
   n += 2 * (wconv + 64 * 4);                                          // extra head convs
@@ -742,8 +774,8 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
       return nfail(AZMI_ERR_INVALID, "spatial head with global actions: pi_hidden must be a multiple of 64 in [64, 1024]");
     // LDS budget of the head scratch (k_leafnet_spatial): input staging behind 16 KB of stem weights; logits behind 8 KB of
     // policy weights; the global head's pooling / hidden scratch behind the logits
-    if (16384 + static_cast<size_t>(tbs) * d->in_channels * d->height * d->width * 4 > 18 * MT * WFRAG_BYTES)
-      return nfail(AZMI_ERR_INVALID, "spatial leaf net kernel: %d input planes do not fit the staging area", d->in_channels);
+    if (d->in_channels > 64 || (9 * d->in_channels <= 128 && 16384 + static_cast<size_t>(tbs) * d->in_channels * d->height * d->width * 4 > 18 * MT * WFRAG_BYTES))
+      return nfail(AZMI_ERR_INVALID, "spatial leaf net kernel: %d input planes not supported", d->in_channels);
     if (num_global > 0 && (static_cast<size_t>(tbs) * d->num_moves * 4 > 16384 ||
                            8192 + 16384 + static_cast<size_t>(tbs) * (256 + 64 + d->pi_hidden) * 4 > 18 * MT * WFRAG_BYTES))
       return nfail(AZMI_ERR_INVALID, "spatial head with global actions: logits / hidden scratch do not fit");
@@ -764,7 +796,7 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
     const size_t Hd = d->v_hidden, L = d->v_fc_layers;
     SpatialPtrs& sp = net->sp;
     auto f32p = [&](size_t count) { const float* q = reinterpret_cast<const float*>(p); p += count * 4; return q; };
-    sp.stem_w = p; p += stem_passes(d) * wsmall; sp.stem_b = f32p(CH);
+    sp.stem_w = p; p += stem_bytes(d); sp.stem_b = f32p(CH);
     sp.blocks = p; p += static_cast<size_t>(d->depth) * (3 * CH * 4 + 2 * wconv);
     sp.head_w = p; p += 2 * 8 * WFRAG_BYTES; sp.head_b = f32p(128);
     sp.vx_w = p; p += wconv; sp.vx_b = f32p(64);

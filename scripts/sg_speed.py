@@ -10,6 +10,7 @@ K = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 2048
 cache = int(sys.argv[5]) if len(sys.argv) > 5 else 200000
 rand = len(sys.argv) > 6 and sys.argv[6] == "random"
+inline = int(os.environ.get("SG_INLINE", "0"))
 dev = torch.device("cuda", 0)
 spec = torch_net.stargambit_spec()
 hip = az.HipLeafNet(torch_net.random_init(spec, seed=0), spec)
@@ -26,7 +27,7 @@ for i in range(K):
     pp.model_groups = [0, 0]
     if rand:
         pp.eval_type = [az.EvalType.RANDOM, az.EvalType.RANDOM]
-    pms.append(az.PlayManager(az.StarGambitUnifiedGS(), pp, seed=20240601 + i, history_capacity=(S // K) * 1200))
+    pms.append(az.PlayManager(az.StarGambitUnifiedGS(), pp, seed=20240601 + i, history_capacity=(S // K) * 1200, max_inline=inline))
 streams = [torch.cuda.Stream(device=dev) for _ in range(K)]
 sps = [st.cuda_stream for st in streams]
 def tot():
