@@ -537,8 +537,9 @@ def main():
             nn_ms = sum(b.elapsed_time(c) for _, b, c in events) / max(1, len(events))
             # a k_leafnet launch evaluates the rows of its shard's eval list (leaves that missed the cache and are not
             # terminal) = the `evals` counter; the torch path and the spatial kernel evaluate the whole slot-indexed batch
-            # (the spatial kernels take the eval list too whenever the position cache is on: gather / scatter around a dense batch of Se rows)
-            rows_evaluated = n_evals / world if (hip_net is not None and not tafl) else float(Se) * launches
+            # (the spatial kernels take the eval list too whenever the position cache is on: the listed rows are packed at the front of
+            # a dense batch and the workgroups past the live count exit at once)
+            rows_evaluated = n_evals / world if (hip_net is not None and (not tafl or args.cache > 0)) else float(Se) * launches
             achieved = flop_per_eval * rows_evaluated / dt / 1e12
             per_launch = (flop_per_eval * rows_evaluated / launches) / (nn_ms * 1e-3) / 1e12 if nn_ms > 0 else 0.0
             out["config"].update({"tree_kernel_ms": tree_ms, "net_ms": nn_ms})
