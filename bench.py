@@ -425,7 +425,11 @@ def main():
             rs = np.sum([pm.resign_scores() for pm in pms], 0)
             keys = ("game_length", "games", "moves", "full_moves", "fast_moves", "leaf_depth", "entropy", "fast_leaf_depth", "fast_entropy", "valid_moves")
             sums = [sum(pm.stat_sums()[k] for pm in pms) for k in keys]
-            return torch.tensor(list(sc) + list(rs) + sums, dtype=torch.float64)
+            # per-variant tables of a game with variants (play_manager.h:218-275): games and scores per variant ride in the same vector
+            var = []
+            for vid in range(pms[0].num_tracked_variants()):
+                var += [float(sum(pm.variant_games_completed(vid) for pm in pms))] + list(np.sum([pm.variant_scores(vid) for pm in pms], 0))
+            return torch.tensor(list(sc) + list(rs) + sums + var, dtype=torch.float64)
 
     def preroll(run, tot, target_games, what):
         """untimed rounds until `target_games` games have finished (slots de-phased); returns rounds used"""
@@ -504,6 +508,10 @@ def main():
                       "avg_search_entropy": st[2 * nsc + 6] / st[2 * nsc + 3] if st[2 * nsc + 3] else 0.0,
                       "avg_valid_moves": st[2 * nsc + 9] / st[2 * nsc + 2] if st[2 * nsc + 2] else 0.0,
                       "games_since_start": games_total} if not dry else {"sum": st}
+        if not dry and len(st) > 2 * nsc + 10:       # StarGambit: per-variant games and win / loss / draw counts over the node
+            vs = st[2 * nsc + 10:]
+            node_stats["variants"] = {("skirmish", "showdown", "clash", "battle")[i]: {"games": vs[4 * i], "scores": vs[4 * i + 1:4 * i + 4]}
+                                      for i in range(len(vs) // 4)}
         out = {
             "metric": "self-play games/sec (whole node), Connect4 @ 800 MCTS sims" if not tafl else f"self-play games/sec (whole node), {'star_gambit_unified' if sg else 'Tawlbwrdd'} @ {sims} MCTS sims",
             "value": n_games / dt,
