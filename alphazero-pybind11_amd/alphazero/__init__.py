@@ -1069,9 +1069,27 @@ class GameData:
 
     def gs(self):
         pm = self._pm
+        game = pm._game
+        if issubclass(game, StarGambitUnifiedGS):     # the to_bytes image from the packed units, the scalars and the position history
+            w = np.zeros(16, np.uint64); n = C.c_uint32()
+            check(lib.azmi_pm_slot_state(pm._h, self._i, w.ctypes.data, 16, C.byref(n)))
+            hist = np.zeros(4100, np.uint64); hn = C.c_uint32()
+            check(lib.azmi_pm_slot_history(pm._h, self._i, hist.ctypes.data, hist.size, C.byref(hn)))
+            sc = int(w[10]); misc = (sc >> 24) & 0xFFFF; res = (sc >> 40) & 0x3FFFF
+            units = b""
+            for i in range(misc & 31):
+                u = (int(w[i // 2]) >> (32 * (i % 2))) & 0xFFFFFFFF
+                units += struct.pack("<5B2b2B", u & 3, (u >> 2) & 1, (u >> 3) & 7, (u >> 6) & 7, (u >> 9) & 7, ((u >> 12) & 15) - 6,
+                                     ((u >> 16) & 15) - 6, (u >> 20) & 3, (u >> 22) & 15)
+            reserves = bytes([(res >> (3 * (p * 3 + t))) & 7 if t < 3 else 0 for p in range(2) for t in range(4)])
+            winner = (misc >> 7) & 3
+            inner = (struct.pack("<I", misc & 31) + units + reserves + struct.pack("<BIBBbI", sc & 1, (sc >> 8) & 0xFFFF, (misc >> 5) & 1,
+                                                                                    (misc >> 6) & 1, winner if winner < 3 else -1, hn.value)
+                     + hist[: hn.value].tobytes())
+            base = pm._sg_base
+            return game.from_bytes(struct.pack("<4fiBI", *base[1], base[0], (misc >> 9) & 3, len(inner)) + inner)
         w = np.zeros(8, np.uint64); n = C.c_uint32()
         check(lib.azmi_pm_slot_state(pm._h, self._i, w.ctypes.data, 8, C.byref(n)))
-        game = pm._game
         if game is Connect4GS:
             board = np.zeros((2, 6, 7), np.int8)
             for p in range(2):
@@ -1125,6 +1143,7 @@ class PlayManager:
         opts.history_capacity = int(history_capacity)
         if is_sg:   # every game re-draws its variant (randomize_start): only the base game's constructor arguments matter
             base = gs() if isinstance(gs, type) else gs
+            self._sg_base = (base._pinned, base._probs)
             opts.sg_pinned_variant = base._pinned
             for i in range(4):
                 opts.sg_variant_probs[i] = base._probs[i]

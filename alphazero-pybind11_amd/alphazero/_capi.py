@@ -122,6 +122,7 @@ SYMBOLS = {
     "azmi_pm_stopped": (C.c_int, [_VP, _PP(C.c_int)]),
     "azmi_pm_queue_counts": (C.c_int, [_VP, _PP(C.c_uint32), _PP(C.c_uint32)]),
     "azmi_pm_slot_state": (C.c_int, [_VP, C.c_uint32, _VP, C.c_uint32, _PP(C.c_uint32)]),
+    "azmi_pm_slot_history": (C.c_int, [_VP, C.c_uint32, _VP, C.c_uint32, _PP(C.c_uint32)]),
     "azmi_pm_cache_stats": (C.c_int, [_VP, _VP]),
     "azmi_pm_stat_sums": (C.c_int, [_VP, _VP]),
     "azmi_pm_slot_canonical": (C.c_int, [_VP, C.c_uint32, _VP]),

@@ -1297,6 +1297,22 @@ int azmi_pm_slot_state(azmi_pm* pm, uint32_t slot, uint64_t* words, uint32_t cap
   return AZMI_OK;
 }
 
+// game_data(i).gs of a game with a position history (StarGambit: position_history_, star_gambit_gs.h:745): the slot's
+// history entries (the reference's own position hashes since the last deploy)
+int azmi_pm_slot_history(azmi_pm* pm, uint32_t slot, uint64_t* out, uint32_t cap, uint32_t* n) {
+  if (!pm || !out || !n) return fail(AZMI_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
+  if (slot >= pm->ep.S) return fail(AZMI_ERR_RANGE, "game index %u out of range", slot);
+  if (pm->game == AZMI_GAME_CONNECT4) { *n = 0; return AZMI_OK; }
+  HIP_TRY(hipStreamSynchronize(pm->last));
+  uint32_t len = 0;
+  HIP_TRY(hipMemcpy(&len, pm->ar.rep_len + slot, 4, hipMemcpyDeviceToHost));
+  if (len > cap) return fail(AZMI_ERR_INVALID, "history of %u entries does not fit %u", len, cap);
+  if (len) HIP_TRY(hipMemcpy(out, pm->ar.rep_list + static_cast<size_t>(slot) * (pm->gi.max_turns + 2), static_cast<size_t>(len) * 8, hipMemcpyDeviceToHost));
+  *n = len;
+  return AZMI_OK;
+}
+
 // game_data(i).canonical(): the planes of the leaf slot `slot` is waiting on (host array [C,H,W])
 int azmi_pm_slot_canonical(azmi_pm* pm, uint32_t slot, float* out) {
   if (!pm || !out) return fail(AZMI_ERR_INVALID, "null argument");

@@ -191,6 +191,11 @@ int azmi_pm_queue_counts(azmi_pm* pm, uint32_t* awaiting_inference, uint32_t* aw
  * king square | turn << 8 | player << 24 | repetition count << 32}; one more word follows: GameData::perm_index, the seat
  * permutation the slot's game runs under (play_manager.h:41).  `cap` >= state words + 1.  AZMI_ERR_RANGE for a bad index. */
 int azmi_pm_slot_state(azmi_pm* pm, uint32_t slot, uint64_t* words, uint32_t cap, uint32_t* n);
+/* StarGambit: state words = 20 packed units (two per word: type 0:2 | player 2 | slot 3:3 | hp 6:3 | facing 9:3 | q+6 12:4 |
+ * r+6 16:4 | moves_left 20:2 | cannons_fired 22:4 | exists 26) + one word player | turn << 8 | misc << 24 (units 0:5, acted 5, over 6,
+ * winner 7:2, variant 9:2) | reserves << 40 (3 bits per [player][type]); its position history (star_gambit_gs.h:745) comes
+ * from azmi_pm_slot_history: the slot's entries since the last deploy (the reference's own position hashes); 0 entries for Connect4 */
+int azmi_pm_slot_history(azmi_pm* pm, uint32_t slot, uint64_t* out, uint32_t cap, uint32_t* n);
 /* game_data(i).canonical(), py_wrapper.cc:279-288: the leaf planes slot i is waiting on, to a HOST array [C,H,W] */
 int azmi_pm_slot_canonical(azmi_pm* pm, uint32_t slot, float* out);
 

@@ -437,3 +437,25 @@ def test_self_play_harness_on_stargambit(oracle):
     for vid, n in res.variant_game_counts.items():
         if n:
             assert abs(sum(res.variant_win_rates[vid]) - 1.0) < 1e-6 and res.variant_metrics[vid]["avg_mpt"] >= 1.0
+
+
+def test_game_data_gs_of_a_running_slot(oracle):
+    """game_data(i).gs() (py_wrapper.cc:265-288) on StarGambit: the slot's position as a game object, history included - it plays on
+    exactly like the oracle game that replays the slot's logged moves"""
+    import alphazero as az
+    pp = _pp(az, games_to_play=2, concurrent_games=2, mcts_visits=[16, 16])
+    pm = az.PlayManager(az.StarGambitUnifiedGS(2), pp, seed=12, log_moves=True)
+    for _ in range(40):
+        pm.round()
+    pm.poll()
+    rows, _ = pm.move_log()
+    games = pm.slot_games()
+    for slot in (0, 1):
+        g = pm.game_data(slot).gs()
+        mine = rows[(rows[:, 0] == slot) & (rows[:, 1] == games[slot])]     # the moves of the slot's running game
+        o = oracle.Game.sg_unified(2)
+        for m in mine[:, 2]:
+            o.play(int(m))
+        assert g.get_variant_id() == 2 and g.current_turn() == o.turn() and g.current_player() == o.player()
+        assert g.to_bytes()[25:] == o.sg_to_bytes()[25:]
+        assert np.array_equal(g.valid_moves(), o.valid()) and np.array_equal(g.canonicalized(), o.canonical())
