@@ -345,7 +345,7 @@ class GameState:
     def relative_values(self):   # game_state.h:114
         return False
 
-    def randomize_start(self):   # game_state.h:73 — no-op for both games
+    def randomize_start(self):   # game_state.h:73 — a no-op except for StarGambitUnifiedGS (which re-draws its variant)
         return None
 
     def num_variants(self):      # game_state.h:76

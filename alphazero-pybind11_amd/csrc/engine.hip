@@ -909,8 +909,11 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
     ep.hist_cap = opts.history_capacity;
   } else if (ep.history) {
     const uint64_t row_bytes = 4ull * (static_cast<uint64_t>(gi.C) * gi.H * gi.W + gi.P + 1 + gi.M + 4);
-    const uint64_t all_rows = (static_cast<uint64_t>(params->games_to_play) + ep.S) * gi.max_turns;
-    const uint64_t bound = std::max<uint64_t>(2ull * ep.S * gi.max_turns, (8ull << 30) / row_bytes);
+    // rows one game can produce: max_turns, except StarGambit whose 4096 is a hard bound on ACTIONS far above any real game
+    // (self-play games: ~220 sample rows; thousands of random games peak below 800) - the default ring counts 1024 per game
+    const uint64_t game_rows = game == AZMI_GAME_STARGAMBIT ? 1024u : gi.max_turns;
+    const uint64_t all_rows = (static_cast<uint64_t>(params->games_to_play) + ep.S) * game_rows;
+    const uint64_t bound = std::max<uint64_t>(2ull * ep.S * game_rows, (8ull << 30) / row_bytes);
     ep.hist_cap = static_cast<uint32_t>(std::min<uint64_t>(std::min(all_rows, bound), 0x7FFFFFFFull));
   } else {
     ep.hist_cap = 0;

@@ -273,7 +273,7 @@ int azmi_game_replay_from(int game, int device, const uint8_t* init, uint32_t in
 /* playout_eval(gs) / playout_eval_batch(states), game_state.cc:10-95 (Python: py_wrapper.cc:726-770): for each of n states
  * (start position + move list, as in azmi_game_replay_from) pi = uniform over the legal moves, v = the scores of a uniformly
  * random rollout.  The reference's rollout RNG is an unseedable thread-local engine; here state i uses a pcg32 stream
- * seeded with seeds[i].  v [n,P+1], pi [n,M] are HOST arrays.  All four games; EvalType::PLAYOUT seats of an engine run the same
+ * seeded with seeds[i].  v [n,P+1], pi [n,M] are HOST arrays.  All five games; EvalType::PLAYOUT seats of an engine run the same
  * rollout on the device from the slot's third pcg32 stream. */
 int azmi_playout_eval(int game, int device, const uint8_t* init, uint32_t init_stride, const int32_t* moves, uint32_t n, uint32_t len,
                       const uint64_t* seeds, float* v, float* pi);
@@ -308,7 +308,7 @@ int azmi_tafl_symmetries(uint32_t board, uint32_t channels, uint32_t num_values,
 const char* azmi_symmetries_last_error(void);
 
 /* ---- the stand-alone MCTS class (py_wrapper.cc:192-220, mcts.h:50-200): one search tree driven call by call.
- * All four games.  A GameState argument is passed as start position (`init`, NULL = initial position, else the
+ * All five games.  A GameState argument is passed as start position (`init`, NULL = initial position, else the
  * game's serialized image as in azmi_game_replay_from) + the moves played from it.  The object owns one pcg32
  * stream (the reference shares a thread_local one across all trees of a thread). */
 typedef struct azmi_mcts azmi_mcts;
