@@ -83,37 +83,23 @@ def _pad(t, *shape):
     return out
 
 
-def _fold_trunk(net, sd, Cin):
-    """Stem + residual tower as 64-channel fragments.  A narrower trunk (configs/brandubh.yaml: 32 channels) is zero-padded:
-    the padded channels have zero weights, scales and biases, so they stay exactly 0 through every affine / ReLU / conv."""
-    blob = bytearray()
-    a, b = (t.cpu() for t in bn_affine(net.bn1))
-    w = sd["conv1.weight"] * a[:, None, None, None]
-    if 9 * Cin > 128:     # many input planes (StarGambit: 36): the stem runs as one more 64-channel convolution, k = tap*64 + ci
-        blob += _frags(_pad(w.permute(0, 2, 3, 1), 64, 3, 3, 64).reshape(64, 576).numpy()) + _f32(_pad(b, 64))
-    else:
-        wm = np.zeros((64, 64 * ((9 * Cin + 63) // 64)))     # im2col rows in passes of 64 (k = tap*C_in + ci; up to two passes)
-        wm[: w.shape[0], : 9 * Cin] = w.permute(0, 2, 3, 1).reshape(w.shape[0], 9 * Cin).numpy()
-        blob += _frags(wm) + _f32(_pad(b, 64))
-    for i, blk in enumerate(net.conv_layers):
-        a1, b1 = (t.cpu() for t in bn_affine(blk.bn1))
-        a2, b2 = (t.cpu() for t in bn_affine(blk.bn2))
-        w1 = sd[f"conv_layers.{i}.conv1.weight"] * a2[:, None, None, None]
-        w2 = sd[f"conv_layers.{i}.conv2.weight"]
-        blob += _f32(_pad(a1, 64)) + _f32(_pad(b1, 64)) + _f32(_pad(b2, 64))
-        blob += _frags(_pad(w1.permute(0, 2, 3, 1), 64, 3, 3, 64).reshape(64, 576).numpy())
-        blob += _frags(_pad(w2.permute(0, 2, 3, 1), 64, 3, 3, 64).reshape(64, 576).numpy())
-    return blob
+def _conv_frags(w):
+    """conv weight [co][ci][3][3] (BatchNorm scale already folded) -> 9 chunks of 8 KB: k = tap*64 + ci, channels zero-padded to 64."""
+    return _frags(_pad(w.permute(0, 2, 3, 1), 64, 3, 3, 64).reshape(64, 576).numpy())
 
 
 def fold_spatial(net):
-    """Spatial-policy-head nets (Tafl family: one extra conv per head, v_fc_layers >= 1; trunk and head widths up to 64
-    channels, narrower ones zero-padded to 64).
-    Blob: stem | blocks | head frag[2][8] + b[128] | v_extra frag[18][4] + b[64] | pi_extra frag[18][4] + b[64] |
-    policy 1x1 frag[2][2] + b[32] | fc1 f32-frag[Hd/16][4] b | extra FC (f32-frag[Hd/16][Hd/16])* then (b[Hd])* | fc2 f32-frag[1][Hd/16] b[16]."""
+    """Spatial-policy-head nets (Tafl family, StarGambit: one extra conv per head, v_fc_layers >= 1; trunk and head widths up
+    to 64 channels - narrower ones (configs/brandubh.yaml: 32) are zero-padded: the padded channels have zero weights, scales
+    and biases, so they stay exactly 0 through every affine / ReLU / conv).  Image read by csrc/leafnet_sp.h:
+      stream of 8 KB chunks frag[2 k-steps][4 m-tiles]: stem conv (9) | per block conv1 (9) conv2 (9) | value-head 1x1 (1) |
+        policy-head 1x1 (1) | value extra conv (9) | policy extra conv (9) | policy 1x1 (1, rows >= policy channels zero)
+      fp32: stem_b[64] | per block a1 b1 c1 | head_b[128] | vx_b[64] | px_b[64] | pol_b[32]
+      value FC: fc1 f32-frag[Hd/16][4] b | extra FC (f32-frag[Hd/16][Hd/16])* then (b[Hd])* | fc2 f32-frag[1][Hd/16] b[16]
+      pi_global (StarGambit): W1 f32-frag[Hp/16][4] b1 | W2 f32-frag[2][Hp/16] b2[32] | LayerNorm g[32] b[32]."""
     spec = net.spec
     Cin, H, W = spec.in_shape
-    if not (spec.num_channels <= 64 and spec.head_channels <= 64 and spec.kernel_size == 3 and spec.head_pool
+    if not (spec.num_channels <= 64 and spec.head_channels <= 64 and spec.kernel_size == 3 and spec.head_pool and Cin <= 64
             and spec.v_head_convs == 1 and spec.pi_head_convs == 1 and (H, W) in ((11, 11), (7, 7), (13, 13))):
         raise RuntimeError("the bf16 MFMA spatial-head kernel covers the configs/tawlbwrdd.yaml, configs/open_tafl.yaml, "
                            "configs/brandubh.yaml and configs/star_gambit_unified.yaml nets (11x11, 7x7 or 13x13, <= 64 trunk / head "
@@ -121,18 +107,30 @@ def fold_spatial(net):
     pc = spec.policy_shape[0]
     Hd, L, P1 = spec.v_fc_hidden, spec.v_fc_layers, spec.num_players + 1
     sd = {k: v.detach().double().cpu() for k, v in net.state_dict().items()}
-    blob = _fold_trunk(net, sd, Cin)
+    stream, prm = bytearray(), bytearray()
+    a, b = (t.cpu() for t in bn_affine(net.bn1))
+    stream += _conv_frags(sd["conv1.weight"] * a[:, None, None, None])
+    prm += _f32(_pad(b, 64))
+    for i, blk in enumerate(net.conv_layers):
+        a1, b1 = (t.cpu() for t in bn_affine(blk.bn1))
+        a2, b2 = (t.cpu() for t in bn_affine(blk.bn2))
+        stream += _conv_frags(sd[f"conv_layers.{i}.conv1.weight"] * a2[:, None, None, None])
+        stream += _conv_frags(sd[f"conv_layers.{i}.conv2.weight"])
+        prm += _f32(_pad(a1, 64)) + _f32(_pad(b1, 64)) + _f32(_pad(b2, 64))
     av, bv = (t.cpu() for t in bn_affine(net.v_bn))
     ap, bp = (t.cpu() for t in bn_affine(net.pi_bn))
-    wh = torch.cat([_pad(sd["v_conv.weight"][:, :, 0, 0] * av[:, None], 64, 64), _pad(sd["pi_conv.weight"][:, :, 0, 0] * ap[:, None], 64, 64)], 0)
-    blob += _frags(wh.numpy()) + _f32(torch.cat([_pad(bv, 64), _pad(bp, 64)]))
+    stream += _frags(_pad(sd["v_conv.weight"][:, :, 0, 0] * av[:, None], 64, 64).numpy())
+    stream += _frags(_pad(sd["pi_conv.weight"][:, :, 0, 0] * ap[:, None], 64, 64).numpy())
+    prm += _f32(torch.cat([_pad(bv, 64), _pad(bp, 64)]))
     for seq, name in ((net.v_extra_convs, "v_extra_convs"), (net.pi_extra_convs, "pi_extra_convs")):
         a, b = (t.cpu() for t in bn_affine(seq[1]))
-        w = sd[f"{name}.0.weight"] * a[:, None, None, None]
-        blob += _frags(_pad(w.permute(0, 2, 3, 1), 64, 3, 3, 64).reshape(64, 576).numpy()) + _f32(_pad(b, 64))
+        stream += _conv_frags(sd[f"{name}.0.weight"] * a[:, None, None, None])
+        prm += _f32(_pad(b, 64))
     a2, b2 = (t.cpu() for t in bn_affine(net.pi_bn2))
-    wpol = _pad(sd["pi_conv2.weight"][:, :, 0, 0] * a2[:, None], 32, 64)
-    blob += _frags(wpol.numpy()) + _f32(_pad(b2, 32))
+    stream += _frags(_pad(sd["pi_conv2.weight"][:, :, 0, 0] * a2[:, None], 64, 64).numpy())
+    prm += _f32(_pad(b2, 32))
+    assert len(stream) == (9 + 18 * spec.depth + 2 + 18 + 1) * 8192
+    blob = stream + prm
     blob += _f32_frags(_pad(sd["v_fc1.weight"], Hd, 64).numpy()) + _f32(sd["v_fc1.bias"])
     for l in range(L - 1):
         blob += _f32_frags(sd[f"v_fc_extra.{2 * l}.weight"].numpy())
@@ -141,9 +139,9 @@ def fold_spatial(net):
     blob += _f32_frags(_pad(sd["v_fc2.weight"], 16, Hd).numpy()) + _f32(_pad(sd["v_fc2.bias"], 16))
     G = spec.num_moves - pc * H * W
     Hp = spec.pi_fc_hidden if G > 0 else 0
-    if G > 0:   # pi_global (neural_net.py:421-426): W1^T [64][Hp] (head channels zero-padded to 64), b1, W2^T [Hp][32], b2, LayerNorm g / b
-        blob += _f32(_pad(sd["pi_global.0.weight"], Hp, 64).t().contiguous()) + _f32(sd["pi_global.0.bias"])
-        blob += _f32(_pad(sd["pi_global.2.weight"], 32, Hp).t().contiguous()) + _f32(_pad(sd["pi_global.2.bias"], 32))
+    if G > 0:   # pi_global (neural_net.py:421-426): head channels zero-padded to 64, outputs to 32
+        blob += _f32_frags(_pad(sd["pi_global.0.weight"], Hp, 64).numpy()) + _f32(sd["pi_global.0.bias"])
+        blob += _f32_frags(_pad(sd["pi_global.2.weight"], 32, Hp).numpy()) + _f32(_pad(sd["pi_global.2.bias"], 32))
         blob += _f32(_pad(sd["pi_global.3.weight"], 32)) + _f32(_pad(sd["pi_global.3.bias"], 32))
     desc = NetDescC(Cin, H, W, 64, spec.depth, 3, 64, Hd, spec.num_moves, spec.num_players, 1, 1, L, pc, 0, Hp)
     assert len(blob) == lib.azmi_net_blob_bytes(C.byref(desc)), (len(blob), lib.azmi_net_blob_bytes(C.byref(desc)))

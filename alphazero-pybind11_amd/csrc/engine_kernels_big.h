@@ -1308,7 +1308,7 @@ struct BigSlot {
     if (cslot < 0) return false;
     const float* sp = cache.policy + (static_cast<size_t>(sh) * cache.cap + cslot) * M;
     const float* sv = cache.value + (static_cast<size_t>(sh) * cache.cap + cslot) * (P + 1);
-    for (uint32_t e = lane; e < static_cast<uint32_t>(M); e += G) ar.pi[static_cast<size_t>(slot) * M + e] = sp[e];
+    wave_copy_row(ar.pi + static_cast<size_t>(slot) * M, sp, static_cast<uint32_t>(M), lane);
     if (lane <= static_cast<uint32_t>(P)) ar.v[static_cast<size_t>(slot) * (P + 1) + lane] = sv[lane];
     sync();
     return true;
