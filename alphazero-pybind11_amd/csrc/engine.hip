@@ -1119,6 +1119,7 @@ int ensure_graph(azmi_pm* pm, azmi_net* net, hipStream_t st) {
   if (pm->graph_exec && pm->graph_stream == st && pm->graph_net == net) return AZMI_OK;
   if (pm->graph_exec) { (void)hipGraphExecDestroy(pm->graph_exec); pm->graph_exec = nullptr; }
   hipGraph_t graph = nullptr;
+  if (azmi_net_reserve_stream(net, st, pm->ep.S) != AZMI_OK) return fail(AZMI_ERR_OOM, "%s", azmi_net_last_error());
   HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
   int rc = AZMI_OK;
   for (uint32_t r = 0; r < kGraphRounds && rc == AZMI_OK; ++r) rc = one_round_with_net(pm, net, st);

@@ -265,20 +265,26 @@ void azmi_net_destroy(azmi_net* net) {
 
 static int net_forward_live(azmi_net* net, const float* dev_canonical, float* dev_v, float* dev_pi, uint32_t batch, void* stream,
                             const uint32_t* live);
+static int reserve_pool(azmi_net* net, void* stream, uint32_t batch) {
+  azmi_net::StreamScratch& sc = net->scratch_of(stream);
+  if (batch <= sc.pool_rows) return AZMI_OK;
+  // first use of this stream / a larger batch only (synchronous, outside the steady state and outside stream capture)
+  (void)hipSetDevice(net->device);
+  if (sc.pool) { (void)hipDeviceSynchronize(); (void)hipFree(sc.pool); sc.pool = nullptr; sc.pool_rows = 0; }
+  const uint32_t want = batch < 4096u ? 4096u : batch;
+  if (hipMalloc(reinterpret_cast<void**>(&sc.pool), static_cast<size_t>(want) * 2 * 64 * sizeof(float)) != hipSuccess)
+    return nfail(AZMI_ERR_OOM, "hipMalloc(head scratch) failed");
+  sc.pool_rows = want;
+  return AZMI_OK;
+}
 // two launches: the tiles (tower, both heads up to their pooled features / spatial logits), then the heads' FC parts batched;
 // `rows` / `row_count` (may be NULL) = the eval list (leafnet_sp.h)
 static int spatial_forward(azmi_net* net, const float* dev_canonical, float* dev_v, float* dev_pi, uint32_t batch, void* stream,
                            const uint32_t* rows, const uint32_t* row_count) {
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rrc = reserve_pool(net, stream, batch);
+  if (rrc != AZMI_OK) return rrc;
   azmi_net::StreamScratch& sc = net->scratch_of(stream);
-  if (batch > sc.pool_rows) {   // first use of this stream / a larger batch only (synchronous, outside the steady state and outside stream capture)
-    (void)hipSetDevice(net->device);
-    if (sc.pool) { (void)hipDeviceSynchronize(); (void)hipFree(sc.pool); sc.pool = nullptr; sc.pool_rows = 0; }
-    const uint32_t want = batch < 4096u ? 4096u : batch;
-    if (hipMalloc(reinterpret_cast<void**>(&sc.pool), static_cast<size_t>(want) * 2 * 64 * sizeof(float)) != hipSuccess)
-      return nfail(AZMI_ERR_OOM, "hipMalloc(head scratch) failed");
-    sc.pool_rows = want;
-  }
   float* vpool = sc.pool;
   float* ppool = sc.pool + static_cast<size_t>(sc.pool_rows) * 64;
   const uint32_t tiles = (batch + net->sp_tbw - 1) / net->sp_tbw;
@@ -292,6 +298,10 @@ static int spatial_forward(azmi_net* net, const float* dev_canonical, float* dev
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nfail(AZMI_ERR_NO_DEVICE, "k_leafnet_sp launch: %s", hipGetErrorString(e));
   return AZMI_OK;
+}
+int azmi_net_reserve_stream(azmi_net* net, void* stream, uint32_t max_rows) {
+  if (!net) return nfail(AZMI_ERR_INVALID, "null argument");
+  return net->spatial ? reserve_pool(net, stream, max_rows) : AZMI_OK;
 }
 int azmi_net_forward(azmi_net* net, const float* dev_canonical, float* dev_v, float* dev_pi, uint32_t batch, void* stream) {
   return net_forward_live(net, dev_canonical, dev_v, dev_pi, batch, stream, nullptr);

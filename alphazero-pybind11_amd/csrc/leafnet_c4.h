@@ -601,3 +601,6 @@ struct azmi_net_c4_view {
 };
 // fills `out` when `net` is a bf16 Connect4-family net (the kernel above); returns 0 otherwise
 extern "C" int azmi_net_c4_view_get(const struct azmi_net* net, azmi_net_c4_view* out);
+// allocates the per-stream scratch a forward of up to `max_rows` rows on `stream` needs (a forward allocates it on first use,
+// which a stream capture does not allow); 0 = ok
+extern "C" int azmi_net_reserve_stream(struct azmi_net* net, void* stream, uint32_t max_rows);

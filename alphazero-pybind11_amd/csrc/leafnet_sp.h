@@ -472,7 +472,7 @@ __global__ __launch_bounds__(NTH, 2) void k_leafnet_sp(SpDesc nd, SpPtrs np, con
 //   -> LayerNorm(G) = the logits of the global actions behind the tile's raw spatial logits; softmax over the whole pi row.
 // Activations live in LDS as [k][16]; weights stream from L2 in A-fragment order: frag[out tile][k group of 16][lane][4],
 // element j of lane l = W[16*tile + (l & 15)][16*group + 4*j + (l >> 4)], so one 16-byte load feeds four k-steps.  A wave owns
-// output tiles {wave, wave + HFC_WAVES} together with 8 k-groups of loads in flight (the loop is bound by L2 latency).
+// output tiles {wave, wave + HFC_WAVES} together with up to 16 k-groups of loads in flight (the loop is bound by L2 latency).
 constexpr int HFC_THREADS = 512, HFC_WAVES = HFC_THREADS / 64;
 __host__ __device__ inline size_t heads_fc_lds(int hidden) { return (2 * static_cast<size_t>(hidden) * 16 + HFC_WAVES * 256 + 16 * 32) * sizeof(float); }
 __global__ __launch_bounds__(HFC_THREADS) void k_heads_fc(SpDesc nd, SpPtrs np, const float* __restrict__ vpool, const float* __restrict__ ppool,
@@ -503,17 +503,20 @@ __global__ __launch_bounds__(HFC_THREADS) void k_heads_fc(SpDesc nd, SpPtrs np, 
       const f32x4* w0 = reinterpret_cast<const f32x4*>(wt) + static_cast<size_t>(t0) * kgroups * 64 + lane;
       const f32x4* w1 = reinterpret_cast<const f32x4*>(wt) + static_cast<size_t>(two ? t1 : t0) * kgroups * 64 + lane;
       f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
-      for (int kg0 = 0; kg0 < kgroups; kg0 += 4) {            // K is a multiple of 64
-        f32x4 a0[4], a1[4];
+      for (int kg0 = 0; kg0 < kgroups; kg0 += 16) {           // up to 32 weight loads in flight per lane
+        f32x4 a0[16], a1[16];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { a0[u] = w0[(kg0 + u) * 64]; a1[u] = w1[(kg0 + u) * 64]; }
+        for (int u = 0; u < 16; ++u)
+          if (kg0 + u < kgroups) { a0[u] = w0[(kg0 + u) * 64]; a1[u] = w1[(kg0 + u) * 64]; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 16; ++u)
+          if (kg0 + u < kgroups) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float bq = xin[((kg0 + u) * 16 + j * 4 + quad) * 16 + col];
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u][j], bq, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u][j], bq, acc1, 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+              const float bq = xin[((kg0 + u) * 16 + j * 4 + quad) * 16 + col];
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u][j], bq, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u][j], bq, acc1, 0, 0, 0);
+            }
           }
       }
 #pragma unroll

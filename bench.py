@@ -554,7 +554,7 @@ def main():
             out["roofline"] = {
                 "bound": "mfma", "achieved": per_launch, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": per_launch / MFMA_PEAK_TFLOPS, "traffic": None,
-                "kernel": "%s: %.0f positions (avg) x %.1f MFLOP per launch, %d overlapping launches per round" % ("k_leafnet_spatial + k_value_fc" if tafl else "k_net_move (the leaf-net tiles of k_leafnet_c4 + the round's move step in one launch)", rows_evaluated / launches, flop_per_eval / 1e6, K),
+                "kernel": "%s: %.0f positions (avg) x %.1f MFLOP per launch, %d overlapping launches per round" % ("k_leafnet_sp (+ k_heads_fc)" if tafl else "k_net_move (the leaf-net tiles of k_leafnet_c4 + the round's move step in one launch)", rows_evaluated / launches, flop_per_eval / 1e6, K),
                 "per_launch_event_ms": nn_ms,
                 "aggregate_achieved": achieved, "aggregate_frac": achieved / MFMA_PEAK_TFLOPS,
                 "definition": "achieved = algorithmic FLOPs of ONE launch (positions it evaluated x FLOP per position) / its average duration, "

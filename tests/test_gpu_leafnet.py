@@ -338,7 +338,7 @@ def test_bf16_mfma_kernels_on_a_peaked_net(which):
 def test_stargambit_net_matches_reference_nnarch_fixture():
     """configs/star_gambit_unified.yaml net (36 x 13 x 13, spatial policy block + pi_global for the 19 deploy / end-turn actions,
     neural_net.py:413-426, 486-493), weights and expected outputs produced by the REFERENCE's NNArch: the bf16 MFMA kernel
-    (k_leafnet_spatial<13, 13, 2>) within the bf16 tolerance and no further from fp32 than torch's bf16 autocast, the library's
+    (k_leafnet_sp on the 13x13 tile) within the bf16 tolerance and no further from fp32 than torch's bf16 autocast, the library's
     fp32 path within the north star's 1e-5"""
     import alphazero as az
     fx, net = _ref_fixture("nn_stargambit_4b64c.npz", "stargambit_spec")

@@ -311,7 +311,7 @@ def _run_with_net(az, pm, hip):
 
 def test_nn_in_the_loop_equals_the_oracle_driven_by_the_same_net(oracle):
     """T3 on StarGambit (configs/star_gambit_unified.yaml search: Gumbel, improved-policy targets, per-variant temperature decay):
-    the device fast path with the HIP net (k_leafnet_spatial<13,13,2>, relative values rotated to absolute in process_result)
+    the device fast path with the HIP net (k_leafnet_sp on the 13x13 tile, relative values rotated to absolute in process_result)
     plays exactly the games of the oracle PlayManager whose evaluator sends each leaf's planes through the same net"""
     import alphazero as az
     from alphazero import torch_net
