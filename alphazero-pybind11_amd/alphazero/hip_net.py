@@ -92,7 +92,8 @@ def fold_spatial(net):
     """Spatial-policy-head nets (Tafl family, StarGambit: one extra conv per head, v_fc_layers >= 1; trunk and head widths up
     to 64 channels - narrower ones (configs/brandubh.yaml: 32) are zero-padded: the padded channels have zero weights, scales
     and biases, so they stay exactly 0 through every affine / ReLU / conv).  Image read by csrc/leafnet_sp.h:
-      stream of 8 KB chunks frag[2 k-steps][4 m-tiles]: stem conv (9) | per block conv1 (9) conv2 (9) | value-head 1x1 (1) |
+      stream of 8 KB chunks frag[2 k-steps][4 m-tiles]: stem (2: k = tap*8 + ci for <= 8 input planes; else 9: one more 64-channel
+        conv) | per block conv1 (9) conv2 (9) | value-head 1x1 (1) |
         policy-head 1x1 (1) | value extra conv (9) | policy extra conv (9) | policy 1x1 (1, rows >= policy channels zero)
       fp32: stem_b[64] | per block a1 b1 c1 | head_b[128] | vx_b[64] | px_b[64] | pol_b[32]
       value FC: fc1 f32-frag[Hd/16][4] b | extra FC (f32-frag[Hd/16][Hd/16])* then (b[Hd])* | fc2 f32-frag[1][Hd/16] b[16]
@@ -109,7 +110,11 @@ def fold_spatial(net):
     sd = {k: v.detach().double().cpu() for k, v in net.state_dict().items()}
     stream, prm = bytearray(), bytearray()
     a, b = (t.cpu() for t in bn_affine(net.bn1))
-    stream += _conv_frags(sd["conv1.weight"] * a[:, None, None, None])
+    w = sd["conv1.weight"] * a[:, None, None, None]
+    if Cin <= 8:    # k = tap * 8 + ci, K = 72 padded to 128 (csrc/leafnet_sp.h stem_chunks)
+        stream += _frags(_pad(_pad(w.permute(0, 2, 3, 1), 64, 3, 3, 8).reshape(64, 72), 64, 128).numpy())
+    else:
+        stream += _conv_frags(w)
     prm += _f32(_pad(b, 64))
     for i, blk in enumerate(net.conv_layers):
         a1, b1 = (t.cpu() for t in bn_affine(blk.bn1))
@@ -129,7 +134,7 @@ def fold_spatial(net):
     a2, b2 = (t.cpu() for t in bn_affine(net.pi_bn2))
     stream += _frags(_pad(sd["pi_conv2.weight"][:, :, 0, 0] * a2[:, None], 64, 64).numpy())
     prm += _f32(_pad(b2, 32))
-    assert len(stream) == (9 + 18 * spec.depth + 2 + 18 + 1) * 8192
+    assert len(stream) == ((2 if Cin <= 8 else 9) + 18 * spec.depth + 2 + 18 + 1) * 8192
     blob = stream + prm
     blob += _f32_frags(_pad(sd["v_fc1.weight"], Hd, 64).numpy()) + _f32(sd["v_fc1.bias"])
     for l in range(L - 1):

@@ -115,7 +115,7 @@ bool is_spatial(const azmi_net_desc* d) { return d->policy_channels > 0; }
 // the heads | the value FC stack | pi_global
 size_t spatial_blob_bytes(const azmi_net_desc* d) {
   const size_t Hd = d->v_hidden, L = d->v_fc_layers;
-  size_t n = static_cast<size_t>(sp::stream_chunks(d->depth)) * sp::CHUNK_BYTES;
+  size_t n = static_cast<size_t>(sp::stream_chunks(d->depth, d->in_channels)) * sp::CHUNK_BYTES;
   n += (CH + static_cast<size_t>(d->depth) * 3 * CH + 2 * sp::HCS + sp::HCS + sp::HCS + 32) * 4;
   n += (64 * Hd + Hd) * 4 + (L - 1) * (Hd * Hd + Hd) * 4 + (Hd * 16 + 16) * 4;
   if (d->num_moves > d->policy_channels * d->height * d->width) {     // pi_global: W1^T[64][Hp] b[Hp] W2^T[Hp][32] b[32] ln_g[32] ln_b[32]
@@ -188,7 +188,7 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
     const size_t Hd = d->v_hidden, L = d->v_fc_layers;
     sp::SpPtrs& sp = net->sp;
     auto f32p = [&](size_t count) { const float* q = reinterpret_cast<const float*>(p); p += count * 4; return q; };
-    sp.stream = p; p += static_cast<size_t>(sp::stream_chunks(d->depth)) * sp::CHUNK_BYTES;
+    sp.stream = p; p += static_cast<size_t>(sp::stream_chunks(d->depth, d->in_channels)) * sp::CHUNK_BYTES;
     sp.prm = f32p(CH + static_cast<size_t>(d->depth) * 3 * CH + 2 * sp::HCS + sp::HCS + sp::HCS + 32);
     sp.fc1_w = f32p(64 * Hd); sp.fc1_b = f32p(Hd);
     sp.fcx_w = f32p((L - 1) * Hd * Hd); sp.fcx_b = f32p((L - 1) * Hd);

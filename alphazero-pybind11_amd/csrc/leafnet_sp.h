@@ -29,8 +29,18 @@ namespace azmi_net_dev {
 namespace sp {
 
 using c4::barrier_lds;
-using c4::dma16x2;
 using c4::wait_vm;
+// c4::dma16x2 with the destination as an LDS byte address: the pointer form casts flat -> LDS per call, and where the optimizer
+// moves that cast behind the readfirstlane of a wave-dependent address the backend emits an illegal compare against
+// src_shared_base ("Operand has incorrect register class"; seen when the tile grew a tail) - here the ring's LDS address is
+// taken once (tile) and the slots are integer arithmetic on it
+__device__ __forceinline__ void dma16x2_at(const uint8_t* src_lane, uint32_t dst_lds) {
+  const uint32_t dst = __builtin_amdgcn_readfirstlane(dst_lds);
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+               "global_load_lds_dwordx4 %1, off offset:1024\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src_lane), "s"(dst) : "memory");
+}
 
 constexpr int NTH = 256, NWV = 4;
 constexpr int CHUNK_KS = 2;
@@ -71,7 +81,7 @@ struct SpDesc {
   int num_global, pi_hidden;   // global actions behind the spatial block (StarGambit: 19) and the width of pi_global's hidden layer
 };
 struct SpPtrs {
-  // the weight stream, 8 KB chunks = frag[2 k-steps][4 m-tiles]: stem conv (9 chunks; input planes zero-padded to 64 channels) |
+  // the weight stream, 8 KB chunks = frag[2 k-steps][4 m-tiles]: stem (2 or 9 chunks, stem_chunks) |
   // per block conv1 (9) conv2 (9) | value-head 1x1 (1) | policy-head 1x1 (1) | value extra conv (9) | policy extra conv (9) |
   // policy 1x1 (1; rows >= pol_ch zero)
   const uint8_t* stream;
@@ -90,7 +100,11 @@ struct SpPtrs {
   const float* pg_ln_g;    // [32] LayerNorm weight
   const float* pg_ln_b;    // [32] LayerNorm bias
 };
-__host__ __device__ inline int stream_chunks(int depth) { return 9 + 2 * depth * 9 + 2 + 9 + 9 + 1; }
+// stem: up to 8 input planes sit in ONE activation plane, so the 3x3 stem is an implicit GEMM with k = tap * 8 + ci (K = 72,
+// padded to 128 = 2 chunks) whose B fragments are that plane read at the tap of each lane group; more planes (StarGambit: 36)
+// run as one more 64-channel convolution (9 chunks)
+__host__ __device__ inline int stem_chunks(int c_in) { return c_in <= 8 ? 2 : 9; }
+__host__ __device__ inline int stream_chunks(int depth, int c_in) { return stem_chunks(c_in) + 2 * depth * 9 + 2 + 9 + 9 + 1; }
 
 // rows != nullptr: evaluate only the rows listed in rows[0 .. *row_count) (the engine's eval list); the canonical planes are
 // read from, and (v, pi) written to, the LISTED row; workgroups past the end of the list leave at once.
@@ -111,7 +125,7 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
   const int col = lane & 15, quad = lane >> 4;
   const uint32_t board0 = tile_index * TBW;
   const int depth = nd.depth;
-  const int nchunks = stream_chunks(depth);
+  const int nchunks = stream_chunks(depth, nd.C_in);
 
   // ---- small fp32 parameters -> LDS (plain loads, before any DMA is in flight) ------------------------------------
   {
@@ -127,10 +141,11 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
   for (int i = tid * 16; i < G::ACT_BYTES; i += NTH * 16) *reinterpret_cast<u32x4*>(act + i) = u32x4{0, 0, 0, 0};
 
   // ---- weight stream: chunk g lives in ring slot g % NRING; every wave moves 2 of a chunk's 8 pieces ---------------
+  const uint32_t ring_lds = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((c4::lptr_t)ring));
   const uint8_t* wnext = np.stream + (wave * PIECES) * WFRAG_BYTES + lane * 16;
   int issued = 0;
   auto issue_next = [&](int slot) {
-    dma16x2(wnext, ring + slot * CHUNK_BYTES + (wave * PIECES) * WFRAG_BYTES);
+    dma16x2_at(wnext, ring_lds + slot * CHUNK_BYTES + (wave * PIECES) * WFRAG_BYTES);
     // after the run's last chunk the stream keeps re-sending that chunk into slots nobody reads any more: the tail of the
     // run then needs no special cases - one wait count, no branch around the issue (see conv)
     ++issued;
@@ -212,7 +227,8 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
   const uint8_t* const wlane = ring + lane * 16;
 
   // One convolution over `act`, accumulating into acc[][]: NCH weight chunks starting in ring slot `slot0` - 9 (a 3x3: chunk =
-  // tap) or 1 (a 1x1: the centre tap).  Software-pipelined over its 2 * NCH k-steps exactly like c4::tile's conv3x3: the A
+  // tap), 1 (a 1x1: the centre tap) or 2 (the stem over <= 8 input planes: k = tap * 8 + ci, lane group `quad` of k-step ks reads
+  // plane 0 at tap 4 * ks + quad; taps >= 9 read zeros against zero weights).  Software-pipelined over its 2 * NCH k-steps exactly like c4::tile's conv3x3: the A
   // (ring) and B (activation) fragments of k-step i + 1 are read while the MFMAs of k-step i issue; the barrier that opens
   // chunk c + 1 sits BEFORE the second k-step of chunk c: passing it means chunk c + 1 has landed for every wave and every wave
   // is done with the slot of chunk c - 1, which the DMA of chunk c + 4 refills.  The last such barrier of a convolution comes
@@ -228,14 +244,24 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
       for (int mt = 0; mt < MT; ++mt) fa[mt] = lds_read_frag(wsl + (ksl * MT + mt) * WFRAG_BYTES);
     };
     auto load_b = [&](int ks, bf16x8 (&fb)[NTW]) {
-      const int tap = NCH == 9 ? (ks >> 1) : 4, half = ks & 1;
-      const int tap_off = ((tap / 3 - 1) * BW + (tap % 3 - 1)) * 16;
+      if constexpr (NCH == 2) {
+        const int tap = 4 * ks + quad, th = tap / 3, tw = tap - 3 * th;
+        const int tap_off = ((th - 1) * BW + (tw - 1)) * 16;
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) {
-        int z = zd[j];
-        asm volatile("" : "+v"(z));     // keep the select here: hoisted out of the block loop, the offsets of a convolution cost VGPRs (spills)
-        const int d = ((tap_ok[j] >> tap) & 1u) ? tap_off : z;
-        fb[j] = lds_read_frag(po + d + (j * 256 + half * 4 * PLANE));
+        for (int j = 0; j < NTW; ++j) {
+          const int d = (tap < 9 && ((tap_ok[j] >> tap) & 1u)) ? tap_off : zd[j];
+          fb[j] = lds_read_frag(act + pix0 + d + j * 256);
+        }
+      } else {
+        const int tap = NCH == 9 ? (ks >> 1) : 4, half = ks & 1;
+        const int tap_off = ((tap / 3 - 1) * BW + (tap % 3 - 1)) * 16;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+          int z = zd[j];
+          asm volatile("" : "+v"(z));     // keep the select here: hoisted out of the block loop, the offsets of a convolution cost VGPRs (spills)
+          const int d = ((tap_ok[j] >> tap) & 1u) ? tap_off : z;
+          fb[j] = lds_read_frag(po + d + (j * 256 + half * 4 * PLANE));
+        }
       }
     };
     load_a(0, wlane + slot * CHUNK_BYTES, a[0]);
@@ -282,14 +308,15 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
   };
   const std::integral_constant<int, 9> k3x3{};
   const std::integral_constant<int, 1> k1x1{};
+  const std::integral_constant<int, 2> kstem8{};
 
-  // ---- stem: one more 64-channel convolution over the input planes (channels >= C_in are zero on both sides) --------
+  // ---- stem (see stem_chunks) --------------------------------------------------------------------------------------------
   f32x4 s[NTW][MT];
   set_bias(s, prm + PRM_STEM);
   wait_vm<4>();                      // chunk 0 (chunks 1 and 2 may still be in flight)
   barrier_lds();                     // input planes visible, chunk 0 landed for every wave, parameters in place
   issue_next(3);
-  int slot = conv(k3x3, s, 0);
+  int slot = nd.C_in <= 8 ? conv(kstem8, s, 0) : conv(k3x3, s, 0);
 
   for (int blk = 0; blk < depth; ++blk) {
     const float* affine = prm + PRM_BLOCKS + blk * 3 * CH;        // a1[64] b1[64] c1[64]
@@ -472,7 +499,7 @@ __global__ __launch_bounds__(NTH, 2) void k_leafnet_sp(SpDesc nd, SpPtrs np, con
 //   -> LayerNorm(G) = the logits of the global actions behind the tile's raw spatial logits; softmax over the whole pi row.
 // Activations live in LDS as [k][16]; weights stream from L2 in A-fragment order: frag[out tile][k group of 16][lane][4],
 // element j of lane l = W[16*tile + (l & 15)][16*group + 4*j + (l >> 4)], so one 16-byte load feeds four k-steps.  A wave owns
-// output tiles {wave, wave + HFC_WAVES} together with up to 16 k-groups of loads in flight (the loop is bound by L2 latency).
+// output tiles {wave, wave + HFC_WAVES} together with up to 8 k-groups of loads in flight (the loop is bound by L2 latency).
 constexpr int HFC_THREADS = 512, HFC_WAVES = HFC_THREADS / 64;
 __host__ __device__ inline size_t heads_fc_lds(int hidden) { return (2 * static_cast<size_t>(hidden) * 16 + HFC_WAVES * 256 + 16 * 32) * sizeof(float); }
 __global__ __launch_bounds__(HFC_THREADS) void k_heads_fc(SpDesc nd, SpPtrs np, const float* __restrict__ vpool, const float* __restrict__ ppool,
@@ -503,13 +530,13 @@ __global__ __launch_bounds__(HFC_THREADS) void k_heads_fc(SpDesc nd, SpPtrs np, 
       const f32x4* w0 = reinterpret_cast<const f32x4*>(wt) + static_cast<size_t>(t0) * kgroups * 64 + lane;
       const f32x4* w1 = reinterpret_cast<const f32x4*>(wt) + static_cast<size_t>(two ? t1 : t0) * kgroups * 64 + lane;
       f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
-      for (int kg0 = 0; kg0 < kgroups; kg0 += 16) {           // up to 32 weight loads in flight per lane
-        f32x4 a0[16], a1[16];
+      for (int kg0 = 0; kg0 < kgroups; kg0 += 8) {            // 16 weight loads in flight per lane (and <= 128 VGPRs: two of these
+        f32x4 a0[8], a1[8];                                   // waves fit a SIMD beside one tile workgroup's)
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
+        for (int u = 0; u < 8; ++u)
           if (kg0 + u < kgroups) { a0[u] = w0[(kg0 + u) * 64]; a1[u] = w1[(kg0 + u) * 64]; }
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
+        for (int u = 0; u < 8; ++u)
           if (kg0 + u < kgroups) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
