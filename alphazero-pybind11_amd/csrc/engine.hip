@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void k_net_move(azmi_net_dev::NetDesc nd, a
                                                      uint32_t net_tiles) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_fused[];
   if (blockIdx.x < net_tiles)
-    azmi_net_dev::c4::tile<4, 4, 16>(nd, np, ar.canon, ar.v, ar.pi, ep.S, ar.eval_list, &ar.ctl->eval_count[0], blockIdx.x, lds_fused);
+    azmi_net_dev::c4::tile<azmi_net_dev::c4::TileSmall, 4, 4, 16>(nd, np, ar.canon, ar.v, ar.pi, ep.S, ar.eval_list, &ar.ctl->eval_count[0], blockIdx.x, lds_fused);
   else
     round_body<Connect4, false, true>(ep, ar, (blockIdx.x - net_tiles) * blockDim.x + threadIdx.x);
 }
@@ -873,11 +873,12 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
   ep.seat_resign = seats.any_seat_resign ? 1u : 0u;
   ep.gum_stride = gi.maxk;
   // simulations a slot may finish inside one round without the net.  A round lasts as long as its SLOWEST slot, so inline
-  // continuation pays only where a simulation is cheap next to the net launch (Connect4: 4).  In the wide-game engine a
+  // continuation pays only where a simulation is cheap next to the net launch (Connect4 with NN seats: 3 - measured 2588 / 2637 /
+  // 2559 / 2502 games/s at 2 / 3 / 4 / 5 with the 3-board net tiles; 4 was the optimum behind the slower 6-board tiles).  In the wide-game engine a
   // simulation costs ~100 us: with NN seats one chain of cache hits / terminal leaves would stretch the round for every slot
   // (measured: Tawlbwrdd 4.49 -> 5.01 M sims/s, StarGambit 1.74 -> 2.14 M sims/s with 1 instead of 4); with RANDOM / PLAYOUT
   // seats only there is no net to wait for and 4 stands.
-  ep.max_inline = opts.max_inline ? opts.max_inline : ((game != AZMI_GAME_CONNECT4 && !seats.all_random) ? 1u : 4u);
+  ep.max_inline = opts.max_inline ? opts.max_inline : (seats.all_random ? 4u : game == AZMI_GAME_CONNECT4 ? 3u : 1u);
   ep.sim_budget = getenv("AZMI_SIM_BUDGET_US") ? static_cast<uint32_t>(100.0 * atof(getenv("AZMI_SIM_BUDGET_US"))) : 0u;
   ep.max_hist_rows = gi.max_turns;
   ep.max_depth = gi.max_turns + 2;
@@ -1095,7 +1096,7 @@ int launch_net_move(azmi_pm* pm, const azmi_net_c4_view& view, hipStream_t st) {
   static std::atomic<bool> reserved{false};
   if (!reserved.exchange(true))
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_net_move), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(view.lds_bytes)));
-  const uint32_t net_tiles = (pm->ep.S + azmi_net_dev::c4::TBW - 1) / azmi_net_dev::c4::TBW;
+  const uint32_t net_tiles = (pm->ep.S + azmi_net_dev::c4::TileSmall::TBW - 1) / azmi_net_dev::c4::TileSmall::TBW;
   const uint32_t move_blocks = (pm->ep.S * Connect4::GROUP + 255) / 256;
   k_net_move<<<net_tiles + move_blocks, 256, view.lds_bytes, st>>>(view.nd, view.np, pm->ep, pm->ar, net_tiles);
   HIP_TRY(hipGetLastError());
@@ -1135,8 +1136,18 @@ int ensure_graph(azmi_pm* pm, azmi_net* net, hipStream_t st) {
 }
 }  // namespace
 
+// holds a stream for about `us` microseconds (wall_clock64 ticks at 100 MHz)
+__global__ void k_delay(uint32_t us) {
+  const uint64_t t0 = wall_clock64();
+  while (wall_clock64() - t0 < static_cast<uint64_t>(us) * 100u) __builtin_amdgcn_s_sleep(32);
+}
+
 int azmi_run_rounds(azmi_pm* const* pms, azmi_net* net, uint32_t k, uint32_t rounds, void* const* streams) {
   if (!pms || !net || !streams || k == 0) return fail(AZMI_ERR_INVALID, "null argument");
+  if (const char* sg = getenv("AZMI_STAGGER_US")) {     // experiment: odd shards start half a cycle late
+    const uint32_t us = static_cast<uint32_t>(atoi(sg));
+    for (uint32_t i = 1; i < k && us; i += 2) k_delay<<<1, 64, 0, pms[i]->pick(streams[i])>>>(us);
+  }
   // hipGraph replay of 16 rounds per launch is available (AZMI_GRAPH=1) but off by default: measured equal to plain
   // launches on this workload (2300 vs 2304 games/s — the host is ahead of the GPU either way), and capturing and
   // instantiating a graph per engine costs about a second at start-up

@@ -240,9 +240,11 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
   np.v_fc2_b = reinterpret_cast<const float*>(p); p += static_cast<size_t>(d->num_players + 1) * 4;
   np.pi_fc_w = p; p += static_cast<size_t>(d->height) * d->width * 2 * WFRAG_BYTES;
   np.pi_fc_b = reinterpret_cast<const float*>(p); p += static_cast<size_t>(d->num_moves) * 4;
-  net->lds_bytes = c4::LDS_BYTES;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&c4::k_leafnet_c4<4, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          static_cast<int>(net->lds_bytes)) != hipSuccess) {
+  net->lds_bytes = c4::TileBig::LDS_BYTES;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&c4::k_leafnet_c4<c4::TileBig, 4, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          static_cast<int>(c4::TileBig::LDS_BYTES)) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&c4::k_leafnet_c4<c4::TileSmall, 4, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          static_cast<int>(c4::TileSmall::LDS_BYTES)) != hipSuccess) {
     (void)hipFree(net->blob); delete net;
     return nfail(AZMI_ERR_NO_DEVICE, "cannot reserve %zu bytes of LDS", net->lds_bytes);
   }
@@ -265,6 +267,18 @@ void azmi_net_destroy(azmi_net* net) {
 
 static int net_forward_live(azmi_net* net, const float* dev_canonical, float* dev_v, float* dev_pi, uint32_t batch, void* stream,
                             const uint32_t* live);
+// Connect4-family net: 6-board tiles when the batch fills the chip's 512 workgroup slots with them, 3-board tiles below that
+// (a launch of a few hundred rows is a LATENCY: leafnet_c4.h, Tile)
+static void c4_launch(azmi_net* net, const float* canon, float* v, float* pi, uint32_t rows_max, const uint32_t* rows, const uint32_t* row_count,
+                      hipStream_t st) {
+  if (rows_max >= 512u * c4::TileBig::TBW) {
+    const uint32_t tiles = (rows_max + c4::TileBig::TBW - 1) / c4::TileBig::TBW;
+    c4::k_leafnet_c4<c4::TileBig, 4, 4, 16><<<tiles, c4::NTH, c4::TileBig::LDS_BYTES, st>>>(net->nd, net->np, canon, v, pi, rows_max, rows, row_count);
+  } else {
+    const uint32_t tiles = (rows_max + c4::TileSmall::TBW - 1) / c4::TileSmall::TBW;
+    c4::k_leafnet_c4<c4::TileSmall, 4, 4, 16><<<tiles, c4::NTH, c4::TileSmall::LDS_BYTES, st>>>(net->nd, net->np, canon, v, pi, rows_max, rows, row_count);
+  }
+}
 static int reserve_pool(azmi_net* net, void* stream, uint32_t batch) {
   azmi_net::StreamScratch& sc = net->scratch_of(stream);
   if (batch <= sc.pool_rows) return AZMI_OK;
@@ -321,8 +335,7 @@ static int net_forward_live(azmi_net* net, const float* dev_canonical, float* de
     return rc == AZMI_OK ? rc : nfail(rc, "%s", msg);
   }
   if (net->spatial) return spatial_forward(net, dev_canonical, dev_v, dev_pi, batch, stream, nullptr, nullptr);
-  const uint32_t tiles = (batch + c4::TBW - 1) / c4::TBW;
-  c4::k_leafnet_c4<4, 4, 16><<<tiles, c4::NTH, net->lds_bytes, static_cast<hipStream_t>(stream)>>>(net->nd, net->np, dev_canonical, dev_v, dev_pi, batch, nullptr, nullptr);
+  c4_launch(net, dev_canonical, dev_v, dev_pi, batch, nullptr, nullptr, static_cast<hipStream_t>(stream));
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nfail(AZMI_ERR_NO_DEVICE, "k_leafnet launch: %s", hipGetErrorString(e));
   return AZMI_OK;
@@ -360,8 +373,7 @@ int azmi_net_forward_rows(azmi_net* net, const float* dev_canonical, float* dev_
     if (e != hipSuccess) return nfail(AZMI_ERR_NO_DEVICE, "row-list gather/scatter launch: %s", hipGetErrorString(e));
     return AZMI_OK;
   }
-  const uint32_t tiles = (max_rows + c4::TBW - 1) / c4::TBW;
-  c4::k_leafnet_c4<4, 4, 16><<<tiles, c4::NTH, net->lds_bytes, static_cast<hipStream_t>(stream)>>>(net->nd, net->np, dev_canonical, dev_v, dev_pi, max_rows, dev_rows, dev_row_count);
+  c4_launch(net, dev_canonical, dev_v, dev_pi, max_rows, dev_rows, dev_row_count, static_cast<hipStream_t>(stream));
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nfail(AZMI_ERR_NO_DEVICE, "k_leafnet launch: %s", hipGetErrorString(e));
   return AZMI_OK;
@@ -415,7 +427,7 @@ void azmi_net_eval_host(const float* canonical, uint32_t n, float* v, float* pi,
 
 int azmi_net_c4_view_get(const azmi_net* net, azmi_net_c4_view* out) {
   if (!net || !out || net->f32 || net->spatial) return 0;
-  out->nd = net->nd; out->np = net->np; out->lds_bytes = net->lds_bytes;
+  out->nd = net->nd; out->np = net->np; out->lds_bytes = c4::TileSmall::LDS_BYTES;   // the engine's fused launch runs the small tile
   return 1;
 }
 

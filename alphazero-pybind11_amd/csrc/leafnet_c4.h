@@ -61,16 +61,8 @@ __device__ __forceinline__ bf16x8 lds_read_frag(const uint8_t* p) {
 //   * every reduction runs in an order that does not depend on where a board sits in its tile or batch, so a position's
 //     (v, pi) is bit-identical wherever the engine's unordered eval list places it.
 namespace c4 {
-constexpr int TBW = 6;                 // boards per workgroup
 constexpr int NTH = 256, NWV = 4;      // threads, waves (one per SIMD)
-constexpr int NTW = 4;                 // n-tiles per wave
-constexpr int BH = 6, BW = 7, PIX = BH * BW, NPIX = TBW * PIX;   // 252 GEMM columns
-constexpr int NT = 16;                 // n-tiles (256 columns, the last 4 unused)
-constexpr int ZSLOT = NT * 16;         // first all-zero cell
-constexpr int SLOTS = ZSLOT + 16;      // 272
-constexpr int PLANE = SLOTS * 16;      // 4352 B, a multiple of 256
-constexpr int ZERO_OFF = ZSLOT * 16;
-constexpr int ACT_BYTES = 8 * PLANE;   // 34,816
+constexpr int BH = 6, BW = 7, PIX = BH * BW;
 constexpr int CHUNK_KS = 2;            // k-steps per weight chunk (= one 3x3 tap)
 constexpr int CHUNK_BYTES = CHUNK_KS * MT * WFRAG_BYTES;   // 8,192
 constexpr int PIECES = CHUNK_BYTES / (NWV * WFRAG_BYTES);  // 1 KB DMA pieces per wave and chunk: 2
@@ -79,9 +71,30 @@ constexpr int RING_BYTES = NRING * CHUNK_BYTES;            // 40,960
 constexpr int CHUNKS_PER_CONV = 18 / CHUNK_KS;             // 9
 constexpr int MAXDEPTH = 6;
 constexpr int PRM_FLOATS = CH + MAXDEPTH * 3 * CH + CH;    // stem bias | per block a1 b1 c1 | head bias
-constexpr int LDS_BYTES = ACT_BYTES + RING_BYTES + PRM_FLOATS * 4;   // 80,896: two workgroups per CU
-static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
-static_assert(NPIX * HC * 4 + NWV * 256 * 4 <= RING_BYTES, "value-head scratch + policy partials reuse the ring");
+// Tile geometry.  Big: 6 boards (252 pixels = 16 n-tiles, 4 per wave, exactly) - the most boards per weight byte, for batches
+// that fill the chip.  Small: 3 boards (126 pixels = 8 n-tiles, 2 per wave) - half the matrix work per k-step behind the same
+// A-fragment reads, i.e. a shorter dependent chain per tile (the LDS, not the matrix pipe, then sets the k-step) for twice
+// the workgroups: what the engine's rounds want, where a launch is a few hundred rows and its LATENCY is what the round
+// waits for (at one workgroup per CU a 6-board tile takes 68 us, 55 of them matrix-pipe bound).
+template <int TBW_, int NTW_>
+struct Tile {
+  static constexpr int TBW = TBW_;                 // boards per workgroup
+  static constexpr int NTW = NTW_;                 // n-tiles per wave
+  static constexpr int NPIX = TBW * PIX;           // GEMM columns in use
+  static constexpr int NT = NWV * NTW;             // n-tiles
+  static constexpr int ZSLOT = NT * 16;            // first all-zero cell
+  static constexpr int SLOTS = ZSLOT + 16;
+  static constexpr int PLANE = SLOTS * 16;         // a multiple of 256 B
+  static constexpr int ZERO_OFF = ZSLOT * 16;
+  static constexpr int ACT_BYTES = 8 * PLANE;
+  static constexpr int LDS_BYTES = ACT_BYTES + RING_BYTES + PRM_FLOATS * 4;   // big: 80,896 - two workgroups per CU
+  static_assert(NPIX <= NT * 16 && NPIX <= NTH, "the tile's pixels fit its n-tiles; one thread per pixel");
+  static_assert(PLANE % 256 == 0, "conflict-free fragment reads need a plane stride that is a multiple of 256 B");
+  static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+  static_assert(NPIX * HC * 4 + NWV * 256 * 4 <= RING_BYTES, "value-head scratch + policy partials reuse the ring");
+};
+using TileBig = Tile<6, 4>;
+using TileSmall = Tile<3, 2>;
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 // 64 lanes x 16 B from per-lane global addresses into LDS at the wave-uniform `dst` + lane * 16, no VGPR destination.
@@ -124,12 +137,13 @@ __device__ __forceinline__ void barrier_lds() {
 // 6 = stem only, 7 = stem + trunk
 // `tile_index` = which tile of TBW rows this workgroup takes (the block index of the plain launch; the fused net + move-step
 // launch of the engine passes its own); `lds` = the workgroup's LDS_BYTES of dynamic LDS.
-template <int CIN, int MAXP1, int MAXM, int DBG = 0>
+template <class TG, int CIN, int MAXP1, int MAXM, int DBG = 0>
 __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const float* __restrict__ canon,
                                      float* __restrict__ v_out, float* __restrict__ pi_out, uint32_t batch,
                                      const uint32_t* __restrict__ rows, const uint32_t* __restrict__ row_count,
                                      const uint32_t tile_index, uint8_t* const lds) {
   static_assert(9 * CIN <= 64, "stem im2col fits one 64-row k-chunk");
+  constexpr int TBW = TG::TBW, NTW = TG::NTW, NPIX = TG::NPIX, PLANE = TG::PLANE, ZERO_OFF = TG::ZERO_OFF, ACT_BYTES = TG::ACT_BYTES;
   // rows != nullptr: evaluate only the rows listed in rows[0 .. *row_count) (the engine's eval list: slots whose
   // pending leaf really needs the net); workgroups past the end of the list leave at once
   // (the list length and this thread's list entry are loaded together: one memory round trip, not two)
@@ -336,14 +350,15 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
         if (ks + 1 < 18) {
           // issue order inside the k-step: 2 MFMAs and one A fragment of the next k-step (x4: its first MFMAs need all
           // four), then 2 MFMAs, the address arithmetic and the read of one B fragment (x4)
+          constexpr int MF_A = NTW >= 4 ? 2 : 1, MF_B = (NTW * MT - 4 * MF_A) / NTW;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MF_A, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           }
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          for (int i = 0; i < NTW; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, MF_B, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           }
@@ -582,12 +597,12 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
   }
 }
 
-template <int CIN, int MAXP1, int MAXM>
+template <class TG, int CIN, int MAXP1, int MAXM>
 __global__ __launch_bounds__(NTH, 2) void k_leafnet_c4(NetDesc nd, NetPtrs np, const float* __restrict__ canon,
                                                         float* __restrict__ v_out, float* __restrict__ pi_out, uint32_t batch,
                                                         const uint32_t* __restrict__ rows, const uint32_t* __restrict__ row_count) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_c4[];
-  tile<CIN, MAXP1, MAXM>(nd, np, canon, v_out, pi_out, batch, rows, row_count, blockIdx.x, lds_c4);
+  tile<TG, CIN, MAXP1, MAXM>(nd, np, canon, v_out, pi_out, batch, rows, row_count, blockIdx.x, lds_c4);
 }
 }  // namespace c4
 
