@@ -181,25 +181,25 @@ int launch_round(azmi_pm* pm, hipStream_t st, bool defer_moves = false) {
       launch_pre_round<Tawlbwrdd>(pm, st);
       if (pm->any_playout) k_round_big<Tawlbwrdd, true><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
       else k_round_big<Tawlbwrdd><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
-      if (pm->ep.half_nodes) k_compact<Tawlbwrdd><<<pm->ep.S * pm->gi.P, 256, 0, st>>>(pm->ep, pm->ar);
+      if (pm->ep.half_nodes) k_compact<Tawlbwrdd><<<std::min(pm->ep.S * pm->gi.P, kCompactBlocks), 256, 0, st>>>(pm->ep, pm->ar, pm->ep.S * pm->gi.P);
       break;
     case AZMI_GAME_BRANDUBH:
       launch_pre_round<Brandubh>(pm, st);
       if (pm->any_playout) k_round_big<Brandubh, true><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
       else k_round_big<Brandubh><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
-      if (pm->ep.half_nodes) k_compact<Brandubh><<<pm->ep.S * pm->gi.P, 256, 0, st>>>(pm->ep, pm->ar);
+      if (pm->ep.half_nodes) k_compact<Brandubh><<<std::min(pm->ep.S * pm->gi.P, kCompactBlocks), 256, 0, st>>>(pm->ep, pm->ar, pm->ep.S * pm->gi.P);
       break;
     case AZMI_GAME_OPENTAFL:
       launch_pre_round<OpenTafl>(pm, st);
       if (pm->any_playout) k_round_big<OpenTafl, true><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
       else k_round_big<OpenTafl><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
-      if (pm->ep.half_nodes) k_compact<OpenTafl><<<pm->ep.S * pm->gi.P, 256, 0, st>>>(pm->ep, pm->ar);
+      if (pm->ep.half_nodes) k_compact<OpenTafl><<<std::min(pm->ep.S * pm->gi.P, kCompactBlocks), 256, 0, st>>>(pm->ep, pm->ar, pm->ep.S * pm->gi.P);
       break;
     case AZMI_GAME_STARGAMBIT:
       launch_pre_round<StarGambit>(pm, st);
       if (pm->any_playout) k_round_big<StarGambit, true><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
       else k_round_big<StarGambit><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
-      if (pm->ep.half_nodes) k_compact<StarGambit><<<pm->ep.S * pm->gi.P, 256, 0, st>>>(pm->ep, pm->ar);
+      if (pm->ep.half_nodes) k_compact<StarGambit><<<std::min(pm->ep.S * pm->gi.P, kCompactBlocks), 256, 0, st>>>(pm->ep, pm->ar, pm->ep.S * pm->gi.P);
       break;
     default:
       return fail(AZMI_ERR_INVALID, "game %d has no device kernels", pm->game);
@@ -2123,19 +2123,19 @@ int azmi_mcts_update_root(azmi_mcts* m, const uint8_t* init, uint32_t init_bytes
     case AZMI_GAME_CONNECT4: k_mcts_update_root<Connect4><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif, di, m->d_moves, len, move, m->d_status); break;
     case AZMI_GAME_TAWLBWRDD:
       k_mcts_big_update_root<Tawlbwrdd><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif, di, init_bytes, m->d_moves, len, move, m->d_status);
-      if (m->pm->ep.half_nodes) k_compact<Tawlbwrdd><<<trees, 256, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif);
+      if (m->pm->ep.half_nodes) k_compact<Tawlbwrdd><<<std::min<uint32_t>(trees, kCompactBlocks), 256, 0, st>>>(m->pm->ep, m->pm->ar, trees, m->wu.nif);
       break;
     case AZMI_GAME_BRANDUBH:
       k_mcts_big_update_root<Brandubh><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif, di, init_bytes, m->d_moves, len, move, m->d_status);
-      if (m->pm->ep.half_nodes) k_compact<Brandubh><<<trees, 256, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif);
+      if (m->pm->ep.half_nodes) k_compact<Brandubh><<<std::min<uint32_t>(trees, kCompactBlocks), 256, 0, st>>>(m->pm->ep, m->pm->ar, trees, m->wu.nif);
       break;
     case AZMI_GAME_STARGAMBIT:
       k_mcts_big_update_root<StarGambit><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif, di, init_bytes, m->d_moves, len, move, m->d_status);
-      if (m->pm->ep.half_nodes) k_compact<StarGambit><<<trees, 256, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif);
+      if (m->pm->ep.half_nodes) k_compact<StarGambit><<<std::min<uint32_t>(trees, kCompactBlocks), 256, 0, st>>>(m->pm->ep, m->pm->ar, trees, m->wu.nif);
       break;
     default:
       k_mcts_big_update_root<OpenTafl><<<1, 64, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif, di, init_bytes, m->d_moves, len, move, m->d_status);
-      if (m->pm->ep.half_nodes) k_compact<OpenTafl><<<trees, 256, 0, st>>>(m->pm->ep, m->pm->ar, m->wu.nif);
+      if (m->pm->ep.half_nodes) k_compact<OpenTafl><<<std::min<uint32_t>(trees, kCompactBlocks), 256, 0, st>>>(m->pm->ep, m->pm->ar, trees, m->wu.nif);
       break;
   }
   int32_t status = 0;

@@ -1379,10 +1379,10 @@ __global__ __launch_bounds__(64) void k_round_big(EngineParams ep, EngineArrays 
 // simulation (MCTS::current_ / path_).  One workgroup per flagged tree; HBM-bound: 28 B read + 28 B
 // written per live node.
 template <class GM>
-__global__ __launch_bounds__(256) void k_compact(EngineParams ep, EngineArrays ar, uint32_t* nif = nullptr) {
+__device__ __forceinline__ void compact_tree(const EngineParams& ep, const EngineArrays& ar, uint32_t* nif, const uint32_t t,
+                                             uint32_t* s_off, uint32_t* s_oldc0, uint32_t* s_scan) {
   constexpr int P = GM::P;
-  const uint32_t t = blockIdx.x, tid = threadIdx.x;
-  if (ar.ctl->stop || !ar.compact_flag[t]) return;
+  const uint32_t tid = threadIdx.x;
   const uint32_t slot = t / P, seat = t % P;
   const uint32_t H = ep.half_nodes;
   const size_t tb = static_cast<size_t>(t) * ep.cap;
@@ -1390,7 +1390,6 @@ __global__ __launch_bounds__(256) void k_compact(EngineParams ep, EngineArrays a
   uint64_t* META = ar.META + tb;
   const uint32_t old_root = ar.root[t], old_bump = ar.bump[t];
   const uint32_t dst0 = (((old_bump - 1) / H) ^ 1u) * H;
-  __shared__ uint32_t s_off[256], s_oldc0[256], s_scan[256];
   if (tid == 0) {
     N[dst0] = N[old_root]; Q[dst0] = Q[old_root]; Pr[dst0] = Pr[old_root]; D[dst0] = D[old_root]; V[dst0] = V[old_root];
     META[dst0] = META[old_root];
@@ -1443,6 +1442,35 @@ __global__ __launch_bounds__(256) void k_compact(EngineParams ep, EngineArrays a
       ar.cur[slot] = static_cast<uint32_t>(META[ar.cur[slot]]);
     }
     ar.root[t] = dst0; ar.bump[t] = bump; ar.compact_flag[t] = 0;
+  }
+  __syncthreads();      // the next tree of this workgroup reuses the scratch
+}
+// A tree is flagged every few moves, i.e. a handful of the S x P trees per round: a grid of one workgroup per tree spent its
+// time being dispatched (16 us in the mix for a kernel whose work is ~1 us).  A few workgroups each look through a stripe of
+// the flags at once and compact the trees they find, one after the other.
+constexpr uint32_t kCompactBlocks = 32;
+template <class GM>
+__global__ __launch_bounds__(256) void k_compact(EngineParams ep, EngineArrays ar, uint32_t trees, uint32_t* nif = nullptr) {
+  __shared__ uint32_t s_off[256], s_oldc0[256], s_scan[256];
+  __shared__ uint32_t s_list[256], s_n;
+  if (ar.ctl->stop) return;
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t base = blockIdx.x; base < trees; base += gridDim.x * 256) {
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const uint32_t t = base + tid * gridDim.x;
+    if (t < trees && ar.compact_flag[t]) s_list[atomicAdd(&s_n, 1u)] = t;
+    __syncthreads();
+    const uint32_t n = s_n;
+    for (uint32_t i = 0; i < n; ++i) {
+      uint32_t tt = s_list[0];              // the smallest tree index not done yet: a fixed order whatever the atomics did
+      for (uint32_t j = 0; j < n; ++j) { const uint32_t c = s_list[j]; tt = c < tt ? c : tt; }
+      __syncthreads();
+      if (tid == 0) for (uint32_t j = 0; j < n; ++j) if (s_list[j] == tt) s_list[j] = 0xFFFFFFFFu;
+      __syncthreads();
+      compact_tree<GM>(ep, ar, nif, tt, s_off, s_oldc0, s_scan);
+    }
+    __syncthreads();
   }
 }
 
