@@ -50,7 +50,7 @@ def test_matches_reference_nnarch_fixture():
 
 @pytest.mark.parametrize("batch", [1, 7, 8, 9, 100, 4096])
 def test_batch_shapes_and_batch_invariance(batch):
-    """Ragged batches (not a multiple of the 8-board tile) and invariance of a row to its batch."""
+    """Ragged batches (not a multiple of the 3- / 6-board tiles) and invariance of a row to its batch."""
     import alphazero as az
     from alphazero import torch_net
     dev = torch.device("cuda:0")
@@ -65,6 +65,22 @@ def test_batch_shapes_and_batch_invariance(batch):
     with torch.no_grad():
         vr, pr = net.to(dev).process(x)
     assert (v - vr).abs().max().item() <= TOL and (pi - pr).abs().max().item() <= TOL
+
+
+def test_big_and_small_tiles_give_the_same_bits():
+    """azmi_net_forward runs 6-board tiles from 3072 rows on and 3-board tiles below (csrc/leafnet_c4.h, Tile): every row of a
+    big batch equals, bit for bit, the same row evaluated in small batches - the engine evaluates leaves through the small
+    tiles, a training-time caller may use the big ones, and the T3 replays rely on a position's answer being one value."""
+    import alphazero as az
+    from alphazero import torch_net
+    dev = torch.device("cuda:0")
+    hip = az.HipLeafNet(torch_net.random_init(torch_net.connect4_spec(), seed=5))
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand((3100, 4, 6, 7), generator=g) < 0.3).float().to(dev)
+    v, pi = hip.process(x)
+    for lo in range(0, 3100, 1000):
+        vs, ps = hip.process(x[lo:lo + 1000])
+        assert torch.equal(v[lo:lo + 1000], vs) and torch.equal(pi[lo:lo + 1000], ps), lo
 
 
 # ---------------------------------------------------------------- spatial policy head (Tafl family)
