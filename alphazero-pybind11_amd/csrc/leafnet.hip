@@ -61,13 +61,15 @@ struct azmi_net {
   sp::SpDesc sd{};
   sp::SpPtrs sp{};
   uint32_t sp_tbw = 0;       // boards per workgroup of the instantiated tile
-  size_t fc_lds = 0;         // dynamic LDS of k_heads_fc
+  size_t fc_lds = 0;         // dynamic LDS of k_heads_fc / k_heads_fc_a / _b
+  bool fc_split = false;     // the heads' FC step as k_heads_fc_a + _b (big FC stacks) instead of the one k_heads_fc
   // Scratch between the kernels of one forward: PER STREAM - engines on different streams share one net object and run
   // their forwards concurrently (round 1 kept one buffer per net: the value heads of concurrent shards read each other's
   // pooled features)
   struct StreamScratch {
-    float* pool = nullptr;     // [2][pool_rows][64] pooled value-head / policy-head features between k_leafnet_sp and k_heads_fc
-    uint32_t pool_rows = 0;
+    float* pool = nullptr;     // [2][pool_rows][64] pooled value-head / policy-head features between k_leafnet_sp and k_heads_fc_a,
+    uint32_t pool_rows = 0;    // [pool_rows][32] global-action logits and [pool_rows][hidden] last hidden layer between _a and _b
+    uint32_t pool_hidden = 0;
     float *g_canon = nullptr, *g_v = nullptr, *g_pi = nullptr;   // row-list evaluation of the whole-batch kernels (azmi_net_forward_rows)
     uint32_t g_rows = 0;
   };
@@ -172,7 +174,7 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
     if (d->in_channels < 1 || d->in_channels > 64) return nfail(AZMI_ERR_INVALID, "spatial leaf net kernel: %d input planes not supported", d->in_channels);
     if (d->depth < 1 || d->depth > sp::MAXDEPTH) return nfail(AZMI_ERR_INVALID, "spatial leaf net kernel: 1..%d residual blocks", sp::MAXDEPTH);
     if (static_cast<size_t>(tbw) * d->num_moves * 4 > sp::RING_BYTES) return nfail(AZMI_ERR_INVALID, "spatial head: logits do not fit the tile's LDS");
-    if (d->v_hidden > 512 || d->v_hidden % 64 || d->v_fc_layers < 1 || d->num_players + 1 > 16) return nfail(AZMI_ERR_INVALID, "value head sizes out of range");
+    if (d->v_hidden > 512 || d->v_hidden % 128 || d->v_fc_layers < 1 || d->num_players + 1 > 16) return nfail(AZMI_ERR_INVALID, "value head sizes out of range");
     if (blob_bytes != spatial_blob_bytes(d)) return nfail(AZMI_ERR_INVALID, "weight blob is %zu bytes, expected %zu", blob_bytes, spatial_blob_bytes(d));
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return nfail(AZMI_ERR_NO_DEVICE, "no HIP device: libazmi has no CPU path");
@@ -201,9 +203,12 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
     net->lds_bytes = tile_lds;
     const void* kernel = b11 ? reinterpret_cast<const void*>(&sp::k_leafnet_sp<sp::Geo11>)
                        : b7 ? reinterpret_cast<const void*>(&sp::k_leafnet_sp<sp::Geo7>) : reinterpret_cast<const void*>(&sp::k_leafnet_sp<sp::Geo13>);
+    net->fc_split = d->v_hidden > 256 || num_global > 0;   // more than ~0.4 MB of FC weights per group
     net->fc_lds = sp::heads_fc_lds(d->v_hidden > d->pi_hidden || num_global == 0 ? d->v_hidden : d->pi_hidden);
     if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(net->lds_bytes)) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&sp::k_heads_fc), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(net->fc_lds)) != hipSuccess) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&sp::k_heads_fc), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(net->fc_lds)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&sp::k_heads_fc_a), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(net->fc_lds)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&sp::k_heads_fc_b), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(net->fc_lds)) != hipSuccess) {
       (void)hipFree(net->blob); delete net;
       return nfail(AZMI_ERR_NO_DEVICE, "cannot reserve LDS for the spatial leaf net");
     }
@@ -281,17 +286,18 @@ static void c4_launch(azmi_net* net, const float* canon, float* v, float* pi, ui
 }
 static int reserve_pool(azmi_net* net, void* stream, uint32_t batch) {
   azmi_net::StreamScratch& sc = net->scratch_of(stream);
-  if (batch <= sc.pool_rows) return AZMI_OK;
+  const uint32_t Hd = static_cast<uint32_t>(net->sd.v_hidden);
+  if (batch <= sc.pool_rows && sc.pool_hidden == Hd) return AZMI_OK;
   // first use of this stream / a larger batch only (synchronous, outside the steady state and outside stream capture)
   (void)hipSetDevice(net->device);
   if (sc.pool) { (void)hipDeviceSynchronize(); (void)hipFree(sc.pool); sc.pool = nullptr; sc.pool_rows = 0; }
-  const uint32_t want = batch < 4096u ? 4096u : batch;
-  if (hipMalloc(reinterpret_cast<void**>(&sc.pool), static_cast<size_t>(want) * 2 * 64 * sizeof(float)) != hipSuccess)
+  const uint32_t want = ((batch < 4096u ? 4096u : batch) + 15u) / 16u * 16u;
+  if (hipMalloc(reinterpret_cast<void**>(&sc.pool), static_cast<size_t>(want) * (2 * 64 + 32 + Hd) * sizeof(float)) != hipSuccess)
     return nfail(AZMI_ERR_OOM, "hipMalloc(head scratch) failed");
-  sc.pool_rows = want;
+  sc.pool_rows = want; sc.pool_hidden = Hd;
   return AZMI_OK;
 }
-// two launches: the tiles (tower, both heads up to their pooled features / spatial logits), then the heads' FC parts batched;
+// the tiles (tower, both heads up to their pooled features / spatial logits), then the heads' FC parts batched (two small launches);
 // `rows` / `row_count` (may be NULL) = the eval list (leafnet_sp.h)
 static int spatial_forward(azmi_net* net, const float* dev_canonical, float* dev_v, float* dev_pi, uint32_t batch, void* stream,
                            const uint32_t* rows, const uint32_t* row_count) {
@@ -301,6 +307,8 @@ static int spatial_forward(azmi_net* net, const float* dev_canonical, float* dev
   azmi_net::StreamScratch& sc = net->scratch_of(stream);
   float* vpool = sc.pool;
   float* ppool = sc.pool + static_cast<size_t>(sc.pool_rows) * 64;
+  float* glob = sc.pool + static_cast<size_t>(sc.pool_rows) * 128;
+  float* hidden = sc.pool + static_cast<size_t>(sc.pool_rows) * 160;
   const uint32_t tiles = (batch + net->sp_tbw - 1) / net->sp_tbw;
   if (net->sd.H == 11)
     sp::k_leafnet_sp<sp::Geo11><<<tiles, sp::NTH, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, vpool, ppool, dev_pi, batch, rows, row_count);
@@ -308,7 +316,14 @@ static int spatial_forward(azmi_net* net, const float* dev_canonical, float* dev
     sp::k_leafnet_sp<sp::Geo13><<<tiles, sp::NTH, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, vpool, ppool, dev_pi, batch, rows, row_count);
   else
     sp::k_leafnet_sp<sp::Geo7><<<tiles, sp::NTH, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, vpool, ppool, dev_pi, batch, rows, row_count);
-  sp::k_heads_fc<<<(batch + 15) / 16, sp::HFC_THREADS, net->fc_lds, st>>>(net->sd, net->sp, vpool, ppool, dev_v, dev_pi, batch, rows, row_count);
+  const uint32_t groups = (batch + 15) / 16;
+  const uint32_t parts = static_cast<uint32_t>(net->sd.v_hidden / sp::HFC_SLICE) + (net->sd.num_global > 0 ? 1u : 0u);
+  if (net->fc_split) {
+    sp::k_heads_fc_a<<<groups * parts, sp::HFC_THREADS, net->fc_lds, st>>>(net->sd, net->sp, vpool, ppool, hidden, glob, batch, row_count);
+    sp::k_heads_fc_b<<<groups, sp::HFC_THREADS, net->fc_lds, st>>>(net->sd, net->sp, hidden, glob, dev_v, dev_pi, batch, rows, row_count);
+  } else {
+    sp::k_heads_fc<<<groups, sp::HFC_THREADS, net->fc_lds, st>>>(net->sd, net->sp, vpool, ppool, dev_v, dev_pi, batch, rows, row_count);
+  }
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return nfail(AZMI_ERR_NO_DEVICE, "k_leafnet_sp launch: %s", hipGetErrorString(e));
   return AZMI_OK;

@@ -437,7 +437,7 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
         if (c < nd.pol_ch) lg[(n / PIX) * M + (n % PIX) * nd.pol_ch + c] = pl[j][mt][r];
       }
   }
-  // pooled value-head features of the tile's boards -> vpool[list position][64] (the FC stack runs batched in k_heads_fc)
+  // pooled value-head features of the tile's boards -> vpool[list position][64] (the FC stack runs batched in k_heads_fc_a / _b)
   auto put_pooled = [&](float* __restrict__ dst, const float (&x)[2][G::PITER]) {
 #pragma unroll
     for (int it = 0; it < G::PITER; ++it) {
@@ -452,7 +452,7 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
   put_pooled(vpool, vp);
   if (nd.num_global > 0) {
     // global actions (StarGambit: 18 deploys + end turn), neural_net.py:413-426, 486-493: the average-pooled policy features
-    // go to ppool, the raw spatial logits to the pi row; k_heads_fc runs pi_global and the softmax over the whole row
+    // go to ppool, the raw spatial logits to the pi row; k_heads_fc_a / _b run pi_global and the softmax over the whole row
     float pp[2][G::PITER];
     barrier_lds();                     // the logits are written (the policy 1x1 is done with the planes: its last barrier)
     pool(hp, pp);
@@ -491,17 +491,198 @@ __global__ __launch_bounds__(NTH, 2) void k_leafnet_sp(SpDesc nd, SpPtrs np, con
   tile<G>(nd, np, canon, vpool, ppool, pi_out, batch, rows, row_count, blockIdx.x, lds_sp);
 }
 
-// The heads' fully connected parts over 16 list entries per workgroup, on the exact-fp32 matrix pipe (v_mfma_f32_16x16x4_f32)
-// with the boards as the 16 MFMA columns - batched, because their weights (0.3 - 1.3 MB fp32) would otherwise be re-read from
-// L2 by every tile of 1 - 5 boards:
-//   value head (neural_net.py:448-470): x0 = vpool [64]; x = relu(W x + b) for fc1 and the extra layers; v = softmax(W2 x + b2);
-//   pi_global (StarGambit, neural_net.py:413-426, 486-494): ppool [64] -> Linear(64, pi_hidden) -> ReLU -> Linear(pi_hidden, G)
-//   -> LayerNorm(G) = the logits of the global actions behind the tile's raw spatial logits; softmax over the whole pi row.
-// Activations live in LDS as [k][16]; weights stream from L2 in A-fragment order: frag[out tile][k group of 16][lane][4],
-// element j of lane l = W[16*tile + (l & 15)][16*group + 4*j + (l >> 4)], so one 16-byte load feeds four k-steps.  A wave owns
-// output tiles {wave, wave + HFC_WAVES} together with up to 8 k-groups of loads in flight (the loop is bound by L2 latency).
+// The heads' fully connected parts, batched over groups of 16 list entries (the boards are the 16 columns of the exact-fp32
+// v_mfma_f32_16x16x4_f32), because their weights (0.3 - 1.5 MB fp32) would otherwise be re-read from L2 by every tile of 1 - 5
+// boards.  A workgroup streams its weights through the fabric at ~60 GB/s (`profiles/r2_pmc_traffic_*`: no L2 sharing between
+// the workgroups of a launch), so the LATENCY of this step is bytes per workgroup - and the step is split over workgroups:
+//   k_heads_fc_a, workgroup (group, part):
+//     part < NS = v_hidden / 128: value head (neural_net.py:448-470) x0 = vpool [64]; x = relu(W x + b) for fc1 and the extra
+//       layers - all of them but the LAST hidden layer in full (small), of the last one only output units [128 part, 128 part
+//       + 128) -> hidden[group][unit][16] in HBM;
+//     part == NS (StarGambit): pi_global (neural_net.py:413-426, 486-494) ppool [64] -> Linear(64, pi_hidden) -> ReLU ->
+//       Linear(pi_hidden, G) -> LayerNorm(G) = the logits of the global actions -> glob[group][board][32];
+//   k_heads_fc_b, workgroup = group: v = softmax(W2 hidden + b2); with global actions the softmax over the whole pi row
+//     ([0, S) = the tile's raw spatial logits, then the global logits).
+// Activations live in LDS as [k][16]; weights stream in A-fragment order: frag[out tile][k group of 16][lane][4], element j of
+// lane l = W[16*tile + (l & 15)][16*group + 4*j + (l >> 4)], so one 16-byte load feeds four k-steps; up to 16 loads in flight
+// per lane and <= 128 VGPRs (two of these waves fit a SIMD beside one tile workgroup).
 constexpr int HFC_THREADS = 512, HFC_WAVES = HFC_THREADS / 64;
+constexpr int HFC_SLICE = 128;     // units of the last hidden layer per workgroup of k_heads_fc_a (8 tiles: one per wave)
 __host__ __device__ inline size_t heads_fc_lds(int hidden) { return (2 * static_cast<size_t>(hidden) * 16 + HFC_WAVES * 256 + 16 * 32) * sizeof(float); }
+
+// x_out[unit][16] = act(W x_in + b) for output tiles [t_begin, t_begin + t_count) of a layer with K inputs; x_out is indexed
+// by the layer's unit number (LDS, or the group's hidden block in HBM).  A wave owns tiles {t, t + HFC_WAVES} together.
+__device__ __forceinline__ void fc_tiles(const float* __restrict__ wt, const float* __restrict__ bias, int K, int t_begin, int t_count,
+                                         const float* xin, float* xout, bool relu) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 15, quad = lane >> 4;
+  const int kgroups = K / 16;
+  for (int i = wave; i < t_count; i += 2 * HFC_WAVES) {
+    const int t0 = t_begin + i, t1 = t0 + HFC_WAVES;
+    const bool two = i + HFC_WAVES < t_count;
+    const f32x4* w0 = reinterpret_cast<const f32x4*>(wt) + static_cast<size_t>(t0) * kgroups * 64 + lane;
+    const f32x4* w1 = reinterpret_cast<const f32x4*>(wt) + static_cast<size_t>(two ? t1 : t0) * kgroups * 64 + lane;
+    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int kg0 = 0; kg0 < kgroups; kg0 += 8) {
+      f32x4 a0[8], a1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (kg0 + u < kgroups) { a0[u] = w0[(kg0 + u) * 64]; a1[u] = w1[(kg0 + u) * 64]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (kg0 + u < kgroups) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float bq = xin[((kg0 + u) * 16 + j * 4 + quad) * 16 + col];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u][j], bq, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u][j], bq, acc1, 0, 0, 0);
+          }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o0 = t0 * 16 + quad * 4 + r;
+      const float y0 = acc0[r] + bias[o0];
+      xout[o0 * 16 + col] = relu ? fmaxf(y0, 0.0f) : y0;
+      if (two) { const int o1 = t1 * 16 + quad * 4 + r; const float y1 = acc1[r] + bias[o1]; xout[o1 * 16 + col] = relu ? fmaxf(y1, 0.0f) : y1; }
+    }
+  }
+}
+// 16 outputs x 16 boards of a layer with ONE output tile per `tile` index, K split over the waves that share the tile:
+// wave w takes tile (w % ntile), K part (w / ntile) of HFC_WAVES / ntile; partial tiles go to part[w][16][16]
+__device__ __forceinline__ void fc_ksplit(const float* __restrict__ wt, int K, int ntile, const float* xin, float* part) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 15, quad = lane >> 4;
+  const int kgroups = K / 16, kparts = HFC_WAVES / ntile, t = wave % ntile, kp = wave / ntile;
+  const int gper = kgroups / kparts;
+  const f32x4* w = reinterpret_cast<const f32x4*>(wt) + static_cast<size_t>(t) * kgroups * 64 + lane;
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (int kg0 = kp * gper; kg0 < (kp + 1) * gper; kg0 += 8) {
+    f32x4 a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (kg0 + u < (kp + 1) * gper) a[u] = w[(kg0 + u) * 64];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (kg0 + u < (kp + 1) * gper) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][j], xin[((kg0 + u) * 16 + j * 4 + quad) * 16 + col], acc, 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) part[(wave * 16 + quad * 4 + r) * 16 + col] = acc[r];
+}
+
+__global__ __launch_bounds__(HFC_THREADS) void k_heads_fc_a(SpDesc nd, SpPtrs np, const float* __restrict__ vpool, const float* __restrict__ ppool,
+                                                            float* __restrict__ hidden, float* __restrict__ glob, uint32_t batch,
+                                                            const uint32_t* __restrict__ row_count) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_fc[];
+  if (row_count) { const uint32_t n = *row_count; batch = n < batch ? n : batch; }
+  const int Hd = nd.v_hidden, NS = Hd / HFC_SLICE, parts = NS + (nd.num_global > 0 ? 1 : 0);
+  const uint32_t group = blockIdx.x / parts;
+  const int part_id = blockIdx.x % parts;
+  const uint32_t b0 = group * 16;
+  if (b0 >= batch) return;
+  const int tid = threadIdx.x;
+  const int Hmax = nd.v_hidden > nd.pi_hidden ? nd.v_hidden : nd.pi_hidden;
+  float* xa = reinterpret_cast<float*>(lds_fc);               // [hidden][16]
+  float* xb = xa + Hmax * 16;
+  float* part = xb + Hmax * 16;                               // [HFC_WAVES][16 outputs][16 boards]
+  const float* pooled = part_id < NS ? vpool : ppool;
+  for (int i = tid; i < 64 * 16; i += HFC_THREADS) {
+    const int k = i / 16, b = i % 16;
+    xa[i] = (b0 + b < batch) ? pooled[static_cast<size_t>(b0 + b) * 64 + k] : 0.0f;
+  }
+  __syncthreads();
+  if (part_id < NS) {
+    float* hid = hidden + static_cast<size_t>(group) * Hd * 16;   // the group's last hidden layer, [unit][16]
+    const int L = nd.v_fc_layers;
+    if (L == 1) { fc_tiles(np.fc1_w, np.fc1_b, 64, part_id * (HFC_SLICE / 16), HFC_SLICE / 16, xa, hid, true); return; }
+    fc_tiles(np.fc1_w, np.fc1_b, 64, 0, Hd / 16, xa, xb, true);
+    __syncthreads();
+    float *cur = xb, *nxt = xa;
+    for (int l = 0; l + 2 < L; ++l) {
+      fc_tiles(np.fcx_w + static_cast<size_t>(l) * Hd * Hd, np.fcx_b + l * Hd, Hd, 0, Hd / 16, cur, nxt, true);
+      __syncthreads();
+      float* t = cur; cur = nxt; nxt = t;
+    }
+    fc_tiles(np.fcx_w + static_cast<size_t>(L - 2) * Hd * Hd, np.fcx_b + (L - 2) * Hd, Hd, part_id * (HFC_SLICE / 16), HFC_SLICE / 16, cur, hid, true);
+    return;
+  }
+  // ---- pi_global -------------------------------------------------------------------------------------------------------
+  const int Hp = nd.pi_hidden, Gn = nd.num_global;
+  fc_tiles(np.pg1_w, np.pg1_b, 64, 0, Hp / 16, xa, xb, true);
+  __syncthreads();
+  fc_ksplit(np.pg2_w, Hp, 2, xb, part);                         // 32 outputs = 2 tiles, K over 4 waves each
+  __syncthreads();
+  if (tid < 256) {                   // LayerNorm over the G outputs of a board: 16 lanes per board, two outputs per lane
+    const int b = tid >> 4, i = tid & 15;
+    float y0 = np.pg2_b[i], y1 = np.pg2_b[i + 16];
+    for (int kp = 0; kp < HFC_WAVES / 2; ++kp) { y0 += part[((kp * 2 + 0) * 16 + i) * 16 + b]; y1 += part[((kp * 2 + 1) * 16 + i) * 16 + b]; }
+    if (i >= Gn) y0 = 0.0f;
+    if (i + 16 >= Gn) y1 = 0.0f;
+    float sum = y0 + y1;
+    for (int off = 8; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    const float mean = sum / static_cast<float>(Gn);
+    float dv = (i < Gn ? (y0 - mean) * (y0 - mean) : 0.0f) + (i + 16 < Gn ? (y1 - mean) * (y1 - mean) : 0.0f);
+    for (int off = 8; off > 0; off >>= 1) dv += __shfl_xor(dv, off, 64);
+    const float inv = 1.0f / sqrtf(dv / static_cast<float>(Gn) + 1e-5f);
+    float* g = glob + (static_cast<size_t>(group) * 16 + b) * 32;
+    if (i < Gn) g[i] = (y0 - mean) * inv * np.pg_ln_g[i] + np.pg_ln_b[i];
+    if (i + 16 < Gn) g[i + 16] = (y1 - mean) * inv * np.pg_ln_g[i + 16] + np.pg_ln_b[i + 16];
+  }
+}
+
+__global__ __launch_bounds__(HFC_THREADS) void k_heads_fc_b(SpDesc nd, SpPtrs np, const float* __restrict__ hidden, const float* __restrict__ glob,
+                                                            float* __restrict__ v_out, float* __restrict__ pi_out, uint32_t batch,
+                                                            const uint32_t* __restrict__ rows, const uint32_t* __restrict__ row_count) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_fc[];
+  if (rows) { const uint32_t n = *row_count; batch = n < batch ? n : batch; }
+  const uint32_t group = blockIdx.x, b0 = group * 16;
+  if (b0 >= batch) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int Hd = nd.v_hidden;
+  float* xa = reinterpret_cast<float*>(lds_fc);               // [v_hidden][16]
+  float* part = xa + Hd * 16;                                 // [HFC_WAVES][16 outputs][16 boards]
+  const float* hid = hidden + static_cast<size_t>(group) * Hd * 16;
+  for (int i = tid; i < Hd * 16; i += HFC_THREADS) xa[i] = hid[i];
+  __syncthreads();
+  fc_ksplit(np.fc2_w, Hd, 1, xa, part);                       // one tile of 16 padded outputs, K over the 8 waves
+  __syncthreads();
+  if (tid < 256) {                   // lane group of 16 = one board; lane i of the group = output i
+    const int P1 = nd.num_players + 1, b = tid >> 4, i = tid & 15;
+    const bool on = i < P1;
+    float a = on ? np.fc2_b[i] : 0.0f;
+    for (int w = 0; w < HFC_WAVES; ++w) a += part[(w * 16 + i) * 16 + b];
+    float mx = on ? a : -__builtin_inff();
+    for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    const float e = on ? expf(a - mx) : 0.0f;
+    float sum = e;
+    for (int off = 8; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (on && b0 + b < batch) {
+      const uint32_t out_row = rows ? rows[b0 + b] : b0 + b;
+      v_out[static_cast<size_t>(out_row) * P1 + i] = e / sum;
+    }
+  }
+  if (nd.num_global == 0) return;
+  const int Gn = nd.num_global, M = nd.num_moves, S = M - Gn;
+  for (int b = wave; b < 16; b += HFC_WAVES) {     // one wave per board: softmax = exp(log_softmax), neural_net.py:494,816
+    if (b0 + b >= batch) continue;
+    const uint32_t out_row = rows ? rows[b0 + b] : b0 + b;
+    float* row = pi_out + static_cast<size_t>(out_row) * M;   // [0, S): the tile's raw spatial logits
+    const float g = lane < Gn ? glob[(static_cast<size_t>(group) * 16 + b) * 32 + lane] : -__builtin_inff();
+    float mx = g;
+    for (int e = lane; e < S; e += 64) mx = fmaxf(mx, row[e]);
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    float sum = lane < Gn ? expf(g - mx) : 0.0f;
+    for (int e = lane; e < S; e += 64) sum += expf(row[e] - mx);
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    for (int e = lane; e < S; e += 64) row[e] = expf(row[e] - mx) / sum;
+    if (lane < Gn) row[S + lane] = expf(g - mx) / sum;
+  }
+}
+
+// The same step as ONE launch, a workgroup per group running every layer (round 2's first form): what a small FC stack wants
+// (Tafl nets: 0.3 MB of weights, no global actions - the split costs a launch and gains nothing: Tawlbwrdd 266 vs 262 games/s);
+// the split above is for the big ones (StarGambit: 1.5 MB per group, 18.4 -> 19.7 games/s).
 __global__ __launch_bounds__(HFC_THREADS) void k_heads_fc(SpDesc nd, SpPtrs np, const float* __restrict__ vpool, const float* __restrict__ ppool,
                                                           float* __restrict__ v_out, float* __restrict__ pi_out, uint32_t batch,
                                                           const uint32_t* __restrict__ rows, const uint32_t* __restrict__ row_count) {
@@ -514,7 +695,7 @@ __global__ __launch_bounds__(HFC_THREADS) void k_heads_fc(SpDesc nd, SpPtrs np, 
   float* xa = reinterpret_cast<float*>(lds_fc);               // [hidden][16]
   float* xb = xa + Hmax * 16;
   float* part = xb + Hmax * 16;                               // [HFC_WAVES][16 outputs][16 boards]
-  float* glob = part + HFC_WAVES * 256;                       // [16 boards][32] logits of the global actions
+  (void)ppool; (void)pi_out;
   auto load_x0 = [&](const float* pooled) {
     for (int i = tid; i < 64 * 16; i += HFC_THREADS) {
       const int k = i / 16, b = i % 16;
@@ -595,43 +776,7 @@ __global__ __launch_bounds__(HFC_THREADS) void k_heads_fc(SpDesc nd, SpPtrs np, 
       }
     }
   }
-  if (nd.num_global == 0) return;
-  // ---- pi_global + the softmax of the whole row ----------------------------------------------------------------------------
-  {
-    const int Hp = nd.pi_hidden, Gn = nd.num_global, M = nd.num_moves, S = M - Gn;
-    __syncthreads();
-    load_x0(ppool);
-    layer(np.pg1_w, np.pg1_b, 64, Hp, xa, xb, true);
-    layer(np.pg2_w, np.pg2_b, Hp, 32, xb, xa, false);          // xa[o][board], o < 32
-    if (tid < 256) {                   // LayerNorm over the G outputs of a board: 16 lanes per board, two outputs per lane
-      const int b = tid >> 4, i = tid & 15;
-      const float y0 = i < Gn ? xa[i * 16 + b] : 0.0f, y1 = i + 16 < Gn ? xa[(i + 16) * 16 + b] : 0.0f;
-      float sum = y0 + y1;
-      for (int off = 8; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-      const float mean = sum / static_cast<float>(Gn);
-      float dv = (i < Gn ? (y0 - mean) * (y0 - mean) : 0.0f) + (i + 16 < Gn ? (y1 - mean) * (y1 - mean) : 0.0f);
-      for (int off = 8; off > 0; off >>= 1) dv += __shfl_xor(dv, off, 64);
-      const float inv = 1.0f / sqrtf(dv / static_cast<float>(Gn) + 1e-5f);
-      if (i < Gn) glob[b * 32 + i] = (y0 - mean) * inv * np.pg_ln_g[i] + np.pg_ln_b[i];
-      if (i + 16 < Gn) glob[b * 32 + i + 16] = (y1 - mean) * inv * np.pg_ln_g[i + 16] + np.pg_ln_b[i + 16];
-    }
-    __syncthreads();
-    for (int b = wave; b < 16; b += HFC_WAVES) {     // one wave per board: softmax = exp(log_softmax), neural_net.py:494,816
-      if (b0 + b >= batch) continue;
-      const uint32_t out_row = rows ? rows[b0 + b] : b0 + b;
-      float* row = pi_out + static_cast<size_t>(out_row) * M;   // [0, S): the tile's raw spatial logits
-      const float g = lane < Gn ? glob[b * 32 + lane] : -__builtin_inff();
-      float mx = g;
-      for (int e = lane; e < S; e += 64) mx = fmaxf(mx, row[e]);
-      for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-      float sum = lane < Gn ? expf(g - mx) : 0.0f;
-      for (int e = lane; e < S; e += 64) sum += expf(row[e] - mx);
-      for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-      for (int e = lane; e < S; e += 64) row[e] = expf(row[e] - mx) / sum;
-      if (lane < Gn) row[S + lane] = expf(g - mx) / sum;
-    }
-  }
-}
+}   // (nets with global actions take the split form: leafnet.hip, fc_split)
 
 }  // namespace sp
 }  // namespace azmi_net_dev
