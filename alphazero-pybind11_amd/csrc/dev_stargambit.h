@@ -550,34 +550,59 @@ struct StarGambit {
     lds_sync();
     const uint32_t v = variant(s);
     const float repv = rep(s) == 0 ? 0.0f : rep(s) == 1 ? 0.5f : 1.0f;
-    for (uint32_t e = lane; e < static_cast<uint32_t>(CANON); e += 64) {
-      const uint32_t ch = e / 169u, cell = e % 169u;
-      const uint32_t src = p1 ? 168u - cell : cell;          // (q, r) -> (-q, -r) for player 1
-      const bool board = inb(static_cast<int>(src / 13u) - 6, static_cast<int>(src % 13u) - 6, sd);
-      float x = 0.0f;
-      if (ch == 0) x = board ? 1.0f : 0.0f;
-      else if (ch <= 14 || (ch >= 17 && ch <= 21)) {
-        const uint32_t mi = ch <= 14 ? ch - 1u : 14u + (ch - 17u);
-        x = ((sm.masks[mi * 3 + (src >> 6)] >> (src & 63u)) & 1ull) ? 1.0f : 0.0f;
-      } else if (ch == 15 || ch == 16) {
-        const uint32_t cu = sm.cellunit[src];
-        if (cu != 0xFF) {
-          const uint32_t w = sm.uword[cu], t = u_type(w);
-          if (ch == 15) x = static_cast<float>(u_hp(w)) / static_cast<float>(max_hp(t));
-          else if (t != PORTAL) x = static_cast<float>(u_moves(w)) / static_cast<float>(max_moves(t));
-        }
-      } else if (!board) x = 0.0f;
-      else if (ch == 22) x = acted(s) ? 1.0f : 0.0f;
-      else if (ch == 23) x = repv;
-      else if (ch <= 29) {
-        const uint32_t k = ch - 24u, pl = k < 3 ? s.player : 1u - s.player, t = k % 3u;
-        const uint32_t st = start_count(v, t);
-        x = st > 0 ? static_cast<float>(reserve(s, pl, t)) / static_cast<float>(st) : 0.0f;
-      } else if (ch == 30) x = portal_hp[0];
-      else if (ch == 31) x = portal_hp[1];
-      else x = (ch - 32u == v) ? 1.0f : 0.0f;
-      row[e] = x;
+    // plane-outer: which source a plane reads is wave-uniform, the lane's three cells (lane, lane + 64, lane + 128 < 169), their
+    // source cells and the on-board test are computed once (the element-outer form spent ~60 vector instructions per element
+    // on the index arithmetic and the plane switch: 95 iterations per leaf)
+    uint32_t src[3];
+    bool on[3], brd[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const uint32_t cell = lane + 64u * j;
+      on[j] = cell < 169u;
+      src[j] = on[j] ? (p1 ? 168u - cell : cell) : 0u;          // (q, r) -> (-q, -r) for player 1
+      brd[j] = on[j] && inb(static_cast<int>(src[j] / 13u) - 6, static_cast<int>(src[j] % 13u) - 6, sd);
     }
+    auto put = [&](uint32_t ch, const float (&x)[3]) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (on[j]) row[ch * 169u + lane + 64u * j] = x[j];
+    };
+    auto put_board_const = [&](uint32_t ch, float val) {       // a scalar broadcast over the board's cells
+      float x[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) x[j] = brd[j] ? val : 0.0f;
+      put(ch, x);
+    };
+    put_board_const(0, 1.0f);
+    for (uint32_t ch = 1; ch <= 21; ++ch) {
+      float x[3] = {0.0f, 0.0f, 0.0f};
+      if (ch == 15 || ch == 16) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const uint32_t cu = on[j] ? sm.cellunit[src[j]] : 0xFFu;
+          if (cu != 0xFF) {
+            const uint32_t w = sm.uword[cu], t = u_type(w);
+            if (ch == 15) x[j] = static_cast<float>(u_hp(w)) / static_cast<float>(max_hp(t));
+            else if (t != PORTAL) x[j] = static_cast<float>(u_moves(w)) / static_cast<float>(max_moves(t));
+          }
+        }
+      } else {
+        const uint32_t mi = ch <= 14 ? ch - 1u : 14u + (ch - 17u);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) x[j] = (on[j] && ((sm.masks[mi * 3 + (src[j] >> 6)] >> (src[j] & 63u)) & 1ull)) ? 1.0f : 0.0f;
+      }
+      put(ch, x);
+    }
+    put_board_const(22, acted(s) ? 1.0f : 0.0f);
+    put_board_const(23, repv);
+    for (uint32_t ch = 24; ch <= 29; ++ch) {
+      const uint32_t k = ch - 24u, pl = k < 3 ? s.player : 1u - s.player, t = k % 3u;
+      const uint32_t st = start_count(v, t);
+      put_board_const(ch, st > 0 ? static_cast<float>(reserve(s, pl, t)) / static_cast<float>(st) : 0.0f);
+    }
+    put_board_const(30, portal_hp[0]);
+    put_board_const(31, portal_hp[1]);
+    for (uint32_t ch = 32; ch < 36; ++ch) put_board_const(ch, (ch - 32u == v) ? 1.0f : 0.0f);
     lds_sync();
   }
 };
