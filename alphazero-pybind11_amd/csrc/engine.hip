@@ -180,19 +180,19 @@ int launch_round(azmi_pm* pm, hipStream_t st, bool defer_moves = false) {
     case AZMI_GAME_TAWLBWRDD:
       launch_pre_round<Tawlbwrdd>(pm, st);
       if (pm->any_playout) k_round_big<Tawlbwrdd, true><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
-      else k_round_big<Tawlbwrdd><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
+      else k_round_big_o2<Tawlbwrdd><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
       if (pm->ep.half_nodes) k_compact<Tawlbwrdd><<<std::min(pm->ep.S * pm->gi.P, kCompactBlocks), 256, 0, st>>>(pm->ep, pm->ar, pm->ep.S * pm->gi.P);
       break;
     case AZMI_GAME_BRANDUBH:
       launch_pre_round<Brandubh>(pm, st);
       if (pm->any_playout) k_round_big<Brandubh, true><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
-      else k_round_big<Brandubh><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
+      else k_round_big_o2<Brandubh><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
       if (pm->ep.half_nodes) k_compact<Brandubh><<<std::min(pm->ep.S * pm->gi.P, kCompactBlocks), 256, 0, st>>>(pm->ep, pm->ar, pm->ep.S * pm->gi.P);
       break;
     case AZMI_GAME_OPENTAFL:
       launch_pre_round<OpenTafl>(pm, st);
       if (pm->any_playout) k_round_big<OpenTafl, true><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
-      else k_round_big<OpenTafl><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
+      else k_round_big_o2<OpenTafl><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
       if (pm->ep.half_nodes) k_compact<OpenTafl><<<std::min(pm->ep.S * pm->gi.P, kCompactBlocks), 256, 0, st>>>(pm->ep, pm->ar, pm->ep.S * pm->gi.P);
       break;
     case AZMI_GAME_STARGAMBIT:

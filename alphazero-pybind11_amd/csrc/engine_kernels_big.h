@@ -1316,9 +1316,8 @@ struct BigSlot {
 };
 
 // One round for every slot of a wide-node game: one wavefront (= one workgroup) per slot.
-template <class GM, bool kPlayout = false>
-__global__ __launch_bounds__(64) void k_round_big(EngineParams ep, EngineArrays ar) {
-  __shared__ BigScratch<GM> sm;
+template <class GM, bool kPlayout>
+__device__ __forceinline__ void round_big_body(const EngineParams& ep, const EngineArrays& ar, BigScratch<GM>& sm) {
   const uint32_t slot = blockIdx.x, lane = threadIdx.x;
   if (slot >= ep.S) return;
   if (ar.ctl->stop) return;
@@ -1371,6 +1370,21 @@ __global__ __launch_bounds__(64) void k_round_big(EngineParams ep, EngineArrays 
   }
   if (ep.cache_on && !insert_key_set && lane == 0) ar.cache_keys[slot] = 0;
   c.store(kSlotWaitEval);
+}
+
+template <class GM, bool kPlayout = false>
+__global__ __launch_bounds__(64) void k_round_big(EngineParams ep, EngineArrays ar) {
+  __shared__ BigScratch<GM> sm;
+  round_big_body<GM, kPlayout>(ep, ar, sm);
+}
+// The same round held to 256 registers, i.e. two waves per SIMD (the default build takes 256 VGPRs + 82 AGPRs = one wave per
+// SIMD): the Tafl family's tree phase is wave-slot bound when the four shards' tree kernels meet (2048 waves on 1024 slots),
+// and its 360 bytes of scratch spill cost less than the second pass (Tawlbwrdd tree side 165 -> 144 us, 266 -> 274 games/s);
+// StarGambit spills 500 bytes and loses 5 %: it keeps the default.
+template <class GM, bool kPlayout = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_round_big_o2(EngineParams ep, EngineArrays ar) {
+  __shared__ BigScratch<GM> sm;
+  round_big_body<GM, kPlayout>(ep, ar, sm);
 }
 
 // Arena compaction for wide games: copies the subtree under the current root into the idle half of the
