@@ -680,9 +680,10 @@ __global__ __launch_bounds__(HFC_THREADS) void k_heads_fc_b(SpDesc nd, SpPtrs np
   }
 }
 
-// The same step as ONE launch, a workgroup per group running every layer (round 2's first form): what a small FC stack wants
-// (Tafl nets: 0.3 MB of weights, no global actions - the split costs a launch and gains nothing: Tawlbwrdd 266 vs 262 games/s);
-// the split above is for the big ones (StarGambit: 1.5 MB per group, 18.4 -> 19.7 games/s).
+// The same step as ONE launch, a workgroup per group running every layer (round 2's first form): for a small FC stack
+// (v_hidden <= 256, no global actions - Brandubh: 0.3 MB of weights), where the split's second launch costs more than its
+// shorter weight streams gain.  The 512-wide stacks (Tawlbwrdd, OpenTafl: 1.2 MB; StarGambit: 1.5 MB with pi_global) take the
+// split form above (StarGambit 18.4 -> 19.7 games/s; Tawlbwrdd's FC step 58 -> 38 + 13 us in the mix).
 __global__ __launch_bounds__(HFC_THREADS) void k_heads_fc(SpDesc nd, SpPtrs np, const float* __restrict__ vpool, const float* __restrict__ ppool,
                                                           float* __restrict__ v_out, float* __restrict__ pi_out, uint32_t batch,
                                                           const uint32_t* __restrict__ rows, const uint32_t* __restrict__ row_count) {
