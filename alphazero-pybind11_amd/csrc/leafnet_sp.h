@@ -669,6 +669,25 @@ __global__ __launch_bounds__(HFC_THREADS) void k_heads_fc_b(SpDesc nd, SpPtrs np
     const uint32_t out_row = rows ? rows[b0 + b] : b0 + b;
     float* row = pi_out + static_cast<size_t>(out_row) * M;   // [0, S): the tile's raw spatial logits
     const float g = lane < Gn ? glob[(static_cast<size_t>(group) * 16 + b) * 32 + lane] : -__builtin_inff();
+    constexpr int RU = 28;           // the row in registers when it fits (StarGambit: 1690 spatial logits = 27 per lane): one
+    if (S <= 64 * RU) {              // round trip for the whole row instead of three passes over it
+      float r[RU];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) { const int e = lane + 64 * u; r[u] = e < S ? row[e] : -__builtin_inff(); }
+      float mx = g;
+#pragma unroll
+      for (int u = 0; u < RU; ++u) mx = fmaxf(mx, r[u]);
+      for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      const float eg = lane < Gn ? expf(g - mx) : 0.0f;
+      float sum = eg;                // (same order of additions as the three-pass form: the global term, then the row)
+#pragma unroll
+      for (int u = 0; u < RU; ++u) { const int e = lane + 64 * u; r[u] = e < S ? expf(r[u] - mx) : 0.0f; if (e < S) sum += r[u]; }
+      for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+#pragma unroll
+      for (int u = 0; u < RU; ++u) { const int e = lane + 64 * u; if (e < S) row[e] = r[u] / sum; }
+      if (lane < Gn) row[S + lane] = eg / sum;
+      continue;
+    }
     float mx = g;
     for (int e = lane; e < S; e += 64) mx = fmaxf(mx, row[e]);
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
