@@ -366,12 +366,19 @@ __device__ __forceinline__ void cache_apply_batch(const CacheView& c, const uint
                                                    const float* value, uint32_t n, uint32_t* s_sid,
                                                    const uint8_t* groups = nullptr, uint32_t group = 0) {
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const uint32_t i = blockIdx.x * (blockDim.x >> 6) + wave;
+  // this wave's own element - key and, when a row is at most one load per lane, the payload - is requested together with the
+  // batch's keys: the insert below is a chain of dependent round trips (keys, shard state, key again, payload), and in the
+  // common case of one element per shard the last two are these registers
+  const bool own_rows = c.np <= 64 && c.nv <= 64;
+  const uint64_t own_key = i < n ? keys[i] : 0ull;
+  const float own_p = (i < n && own_rows && lane < c.np) ? policy[static_cast<size_t>(i) * c.np + lane] : 0.0f;
+  const float own_v = (i < n && own_rows && lane < c.nv) ? value[static_cast<size_t>(i) * c.nv + lane] : 0.0f;
   for (uint32_t j = tid; j < n; j += blockDim.x) {
     const uint64_t k = (groups && groups[j] != group) ? 0 : keys[j];   // elements of another model group are not ours
     s_sid[j] = k ? static_cast<uint32_t>(k % c.shards) : 0xFFFFFFFFu;
   }
   __syncthreads();
-  const uint32_t i = blockIdx.x * (blockDim.x >> 6) + wave;
   if (i >= n) return;
   const uint32_t my = s_sid[i];
   if (my == 0xFFFFFFFFu) return;
@@ -386,12 +393,17 @@ __device__ __forceinline__ void cache_apply_batch(const CacheView& c, const uint
       const uint32_t b = __builtin_ctzll(m);
       m &= m - 1;
       const uint32_t jj = base + b;
-      const int slot = ws.insert(keys[jj]);
+      const int slot = ws.insert(jj == i ? own_key : keys[jj]);
       if (slot >= 0) {
         float* dp = c.policy + (static_cast<size_t>(my) * kWaveCap + slot) * c.np;
         float* dv = c.value + (static_cast<size_t>(my) * kWaveCap + slot) * c.nv;
-        wave_copy_row(dp, policy + static_cast<size_t>(jj) * c.np, c.np, lane);
-        for (uint32_t e = lane; e < c.nv; e += 64) dv[e] = value[static_cast<size_t>(jj) * c.nv + e];
+        if (jj == i && own_rows) {
+          if (lane < c.np) dp[lane] = own_p;
+          if (lane < c.nv) dv[lane] = own_v;
+        } else {
+          wave_copy_row(dp, policy + static_cast<size_t>(jj) * c.np, c.np, lane);
+          for (uint32_t e = lane; e < c.nv; e += 64) dv[e] = value[static_cast<size_t>(jj) * c.nv + e];
+        }
       }
     }
   }
