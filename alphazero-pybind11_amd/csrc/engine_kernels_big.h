@@ -61,6 +61,7 @@ struct BigSlot {
   uint32_t t_root[P], t_bump[P], t_depth[P];
   uint64_t t_tld[P];
   uint32_t cur, plen, ph_rows, glen;
+  uint32_t staged_k = 0;          // children staged by stage_root (0: none): the support of sm.dense, see dense_pow
   uint32_t leaf_rep_len = 0;      // find_leaf: entries of sm.plist at the leaf, and whether the game's list still counts
   bool leaf_base_valid = true;    // (a capture on the path clears it); the rollout of a PLAYOUT seat continues from them
   // per-seat search settings of this game's seat permutation (see SlotCtx)
@@ -822,20 +823,45 @@ struct BigSlot {
   }
 
   // ---- dense [M] helpers on sm.dense ------------------------------------------------------------------------------------
+  // f(m, x) for every NONZERO entry of sm.dense in ascending index order (m and x wave-uniform); f returns false to stop.
+  // The reference's dense vectors are sums / scans over all M entries in index order (mcts.cc:575-735); an entry that is +-0
+  // changes neither a running fp32 sum nor a `sum > choice` test, so walking the ~100 nonzero ones gives the same bits as
+  // walking all 2662 - and the move step, whose wave every round's launch waits for, spent most of its time in those walks.
+  template <class F>
+  __device__ __forceinline__ void dense_for_nonzero(F&& f) const {
+    for (uint32_t base = 0; base < static_cast<uint32_t>(M); base += G) {
+      const uint32_t m = base + lane;
+      const float x = m < static_cast<uint32_t>(M) ? sm.dense[m] : 0.0f;
+      unsigned long long mask = __ballot(x != 0.0f);
+      while (mask) {
+        const int b = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        if (!f(base + static_cast<uint32_t>(b), __shfl(x, b, 64))) return;
+      }
+    }
+  }
   __device__ __forceinline__ float dense_seq_sum() const {
     float s = 0.0f;
-    for (uint32_t m = 0; m < static_cast<uint32_t>(M); ++m) s += sm.dense[m];
+    dense_for_nonzero([&](uint32_t, float x) { s += x; return true; });
     return s;
   }
   __device__ __forceinline__ void dense_zero() { for (uint32_t m = lane; m < static_cast<uint32_t>(M); m += G) sm.dense[m] = 0.0f; sync(); }
   __device__ __forceinline__ void dense_div(float s) { for (uint32_t m = lane; m < static_cast<uint32_t>(M); m += G) sm.dense[m] = sm.dense[m] / s; sync(); }
   __device__ __forceinline__ void dense_pow(float e) {
     if (e == 1.0f) return;
+    if (e > 0.0f && staged_k != 0) {
+      // every nonzero entry of sm.dense sits at the move of a staged root child (all its builders scatter through sm.moves),
+      // and pow(0, e > 0) = 0: the double-precision pow runs over the k children, not over the M entries
+      for (uint32_t i = lane; i < staged_k; i += G) { const uint32_t m = sm.moves[i]; sm.dense[m] = az_powf(sm.dense[m], e); }
+      sync();
+      return;
+    }
     for (uint32_t m = lane; m < static_cast<uint32_t>(M); m += G) sm.dense[m] = az_powf(sm.dense[m], e);
     sync();
   }
   // root children staged in LDS: moves, n (sm.n), q (f1), p (f2)
   __device__ __forceinline__ void stage_root(size_t tb, uint32_t c0, uint32_t k) {
+    staged_k = k;
     for (uint32_t i = lane; i < k; i += G) {
       const size_t ci = tb + c0 + i;
       sm.moves[i] = static_cast<uint16_t>(meta_mv(ar.META[ci]));
@@ -898,8 +924,9 @@ struct BigSlot {
     const float total = dense_seq_sum();
     if (total == 0) { sync(); probs(temp, k); return; }
     if (temp == 0) {
-      float best = sm.dense[0];
-      for (uint32_t m = 1; m < static_cast<uint32_t>(M); ++m) best = (best < sm.dense[m]) ? sm.dense[m] : best;
+      float best = -__builtin_inff();       // the maximum over all entries (order does not matter for a maximum)
+      for (uint32_t m = lane; m < static_cast<uint32_t>(M); m += G) best = (best < sm.dense[m]) ? sm.dense[m] : best;
+      for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(best, off, 64); best = (best < o) ? o : best; }
       uint32_t cnt = 0;
       for (uint32_t m = lane; m < static_cast<uint32_t>(M); m += G) cnt += sm.dense[m] == best;
       cnt = wave_sum(cnt);
@@ -914,12 +941,15 @@ struct BigSlot {
   __device__ __forceinline__ uint32_t pick_move() {  // mcts.cc:717-735 on sm.dense
     const float choice = canonical01(rng) * 1.0f + 0.0f;
     float sum = 0.0f;
-    for (uint32_t m = 0; m < static_cast<uint32_t>(M); ++m) {
-      sum += sm.dense[m];
-      if (sum > choice) return m;
-    }
-    for (int m = M - 1; m >= 0; --m)
-      if (sm.dense[m] > 0) return static_cast<uint32_t>(m);
+    uint32_t picked = 0xFFFFFFFFu, last_pos = 0xFFFFFFFFu;
+    dense_for_nonzero([&](uint32_t m, float x) {
+      sum += x;
+      if (x > 0) last_pos = m;
+      if (sum > choice) { picked = m; return false; }
+      return true;
+    });
+    if (picked != 0xFFFFFFFFu) return picked;
+    if (last_pos != 0xFFFFFFFFu) return last_pos;     // rounding left the total below `choice`: the last positive entry
     raise(16u);
     return 0;
   }
