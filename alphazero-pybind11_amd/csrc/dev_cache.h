@@ -350,16 +350,17 @@ __device__ inline void wave_shard_find_account(const CacheView& c, uint64_t hash
 // `keys[j] == 0` marks an element that is not to be inserted.  Rows j of `policy` / `value`
 // (row strides np / nv floats) are the payload.  Launch: <<<ceil(n / 4), 256>>>, n <= kApplyMax.
 constexpr uint32_t kApplyMax = 8192;
-// dst[0..n) = src[0..n) by one wavefront with 8 loads in flight per lane: a plain `dst[e] = src[e]` loop waits for every
+// dst[0..n) = src[0..n) by one wavefront with U loads in flight per lane: a plain `dst[e] = src[e]` loop waits for every
 // load before its store (the two rows may alias as far as the compiler knows), i.e. one memory round trip per 64 floats -
 // 27 dependent trips for a StarGambit policy row
+template <uint32_t U = 8>
 __device__ __forceinline__ void wave_copy_row(float* __restrict__ dst, const float* __restrict__ src, uint32_t n, uint32_t lane) {
-  for (uint32_t e0 = 0; e0 < n; e0 += 64 * 8) {
-    float t[8];
+  for (uint32_t e0 = 0; e0 < n; e0 += 64 * U) {
+    float t[U];
 #pragma unroll
-    for (uint32_t u = 0; u < 8; ++u) { const uint32_t e = e0 + u * 64 + lane; t[u] = e < n ? src[e] : 0.0f; }
+    for (uint32_t u = 0; u < U; ++u) { const uint32_t e = e0 + u * 64 + lane; t[u] = e < n ? src[e] : 0.0f; }
 #pragma unroll
-    for (uint32_t u = 0; u < 8; ++u) { const uint32_t e = e0 + u * 64 + lane; if (e < n) dst[e] = t[u]; }
+    for (uint32_t u = 0; u < U; ++u) { const uint32_t e = e0 + u * 64 + lane; if (e < n) dst[e] = t[u]; }
   }
 }
 __device__ __forceinline__ void cache_apply_batch(const CacheView& c, const uint64_t* keys, const float* policy,
@@ -401,7 +402,7 @@ __device__ __forceinline__ void cache_apply_batch(const CacheView& c, const uint
           if (lane < c.np) dp[lane] = own_p;
           if (lane < c.nv) dv[lane] = own_v;
         } else {
-          wave_copy_row(dp, policy + static_cast<size_t>(jj) * c.np, c.np, lane);
+          wave_copy_row<32>(dp, policy + static_cast<size_t>(jj) * c.np, c.np, lane);   // a StarGambit row in one round trip
           for (uint32_t e = lane; e < c.nv; e += 64) dv[e] = value[static_cast<size_t>(jj) * c.nv + e];
         }
       }
