@@ -1603,6 +1603,25 @@ def run_rounds(pms, net, rounds, streams):
     check(lib.azmi_run_rounds(arr_pm, net._h, k, int(rounds), arr_st))
 
 
+def pipeline_supported(pm, net):
+    """azmi_pipeline_supported: True when azmi_run_pipeline can drive this engine with this net (the Connect4 engine with plain
+    PUCT seats, one model group, NN seats, a bf16 Connect4-family HipLeafNet, at most 4096 concurrent games)."""
+    return net is not None and bool(lib.azmi_pipeline_supported(pm._h, net._h))
+
+
+def run_pipeline(pm, net, epochs, sims_per_epoch, stream=None):
+    """azmi_run_pipeline: `epochs` epochs of the asynchronous tree / net pipeline on one engine (persistent tree wavefronts and
+    net workgroups side by side; moves, game ends and cache inserts between epochs).  Synchronous.  Returns a dict of
+    pipeline counters: net tiles run and boards in them since the pipeline was created, simulations / insert-log entries of
+    the last epoch, workgroups launched and started."""
+    st = pm._stream_arg(stream)
+    out = (C.c_uint64 * 16)()
+    check(lib.azmi_run_pipeline(pm._h, net._h, int(epochs), int(sims_per_epoch), st, out))
+    keys = ("tiles", "tile_boards", "last_epoch_sims", "tree_wgs_started", "net_wgs_started", "last_epoch_inserts", "net_wgs", "tree_wgs",
+            "tree_latest_start_us", "net_latest_start_us")
+    return dict(zip(keys, (int(x) for x in out)))
+
+
 def run_rounds_groups(pms, nets, rounds, streams):
     """azmi_run_rounds_groups: `nets[g]` (HipLeafNet or None) evaluates the leaves of model group g."""
     k = len(pms)

@@ -194,7 +194,27 @@ constexpr uint32_t kWaveCap = 64;
 __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
-struct WaveShard {
+// COH = true: every access is an agent-scope relaxed atomic (sc1: served by L2, written through) - the form the shard's data
+// needs when wavefronts on different CUs take turns on it under the shard's insert lock (wave_shard_insert_locked)
+template <bool COH>
+__device__ __forceinline__ uint32_t c_ld(const uint32_t* p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else return *p;
+}
+template <bool COH>
+__device__ __forceinline__ uint64_t c_ld(const uint64_t* p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void c_st(uint32_t* p, uint32_t v) {
+  if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+template <bool COH>
+__device__ __forceinline__ void c_st(uint64_t* p, uint64_t v) {
+  if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+
+template <bool COH = false>
+struct WaveShardT {
   const CacheView& c;
   uint32_t sh, lane;
   // v_writelane as a select (this clang has no writelane builtin): element `at` of a lane-resident array
@@ -207,33 +227,35 @@ struct WaveShard {
   uint32_t s_head, s_size, m_head, m_size, next_free, g_head, g_count, size;
   unsigned long long evictions;
 
-  __device__ WaveShard(const CacheView& cv, uint32_t s, uint32_t l) : c(cv), sh(s), lane(l), evictions(0) {
+  __device__ WaveShardT(const CacheView& cv, uint32_t s, uint32_t l) : c(cv), sh(s), lane(l), evictions(0) {
     const size_t b = static_cast<size_t>(s) * kWaveCap + l;
-    const uint64_t h = cv.hashes[b];
+    const uint64_t h = c_ld<COH>(cv.hashes + b);
     hlo = static_cast<uint32_t>(h); hhi = static_cast<uint32_t>(h >> 32);
-    fq = cv.freq[b]; sr = cv.s_ring[b]; mr = cv.m_ring[b];
+    fq = c_ld<COH>(cv.freq + b); sr = c_ld<COH>(cv.s_ring + b); mr = c_ld<COH>(cv.m_ring + b);
     uint64_t g = 0;
     gin = 0;
-    if (l < cv.ghost_cap) { g = cv.ghost_ring[static_cast<size_t>(s) * cv.ghost_cap + l]; gin = cv.map_val[b]; }
+    if (l < cv.ghost_cap) { g = c_ld<COH>(cv.ghost_ring + static_cast<size_t>(s) * cv.ghost_cap + l); gin = c_ld<COH>(cv.map_val + b); }
     glo = static_cast<uint32_t>(g); ghi = static_cast<uint32_t>(g >> 32);
     const uint32_t* st = cv.state + static_cast<size_t>(s) * 8;
-    s_head = uni(st[kSHead]); s_size = uni(st[kSSize]); m_head = uni(st[kMHead]); m_size = uni(st[kMSize]);
-    next_free = uni(st[kNextFree]); g_head = uni(st[kGHead]); g_count = uni(st[kGCount]); size = uni(st[kSize]);
+    const uint32_t stl = l < 8 ? c_ld<COH>(st + l) : 0u;       // the eight state words in one access
+    s_head = rl(stl, kSHead); s_size = rl(stl, kSSize); m_head = rl(stl, kMHead); m_size = rl(stl, kMSize);
+    next_free = rl(stl, kNextFree); g_head = rl(stl, kGHead); g_count = rl(stl, kGCount); size = rl(stl, kSize);
   }
   __device__ void store() const {
     const size_t b = static_cast<size_t>(sh) * kWaveCap + lane;
-    c.hashes[b] = static_cast<uint64_t>(hlo) | (static_cast<uint64_t>(hhi) << 32);
-    c.freq[b] = fq; c.s_ring[b] = sr; c.m_ring[b] = mr;
+    c_st<COH>(c.hashes + b, static_cast<uint64_t>(hlo) | (static_cast<uint64_t>(hhi) << 32));
+    c_st<COH>(c.freq + b, fq); c_st<COH>(c.s_ring + b, sr); c_st<COH>(c.m_ring + b, mr);
     if (lane < c.ghost_cap) {
-      c.ghost_ring[static_cast<size_t>(sh) * c.ghost_cap + lane] = static_cast<uint64_t>(glo) | (static_cast<uint64_t>(ghi) << 32);
-      c.map_val[b] = gin;  // map_val is unused by wave shards: it keeps the ghost-set membership bits
+      c_st<COH>(c.ghost_ring + static_cast<size_t>(sh) * c.ghost_cap + lane, static_cast<uint64_t>(glo) | (static_cast<uint64_t>(ghi) << 32));
+      c_st<COH>(c.map_val + b, gin);  // map_val is unused by wave shards: it keeps the ghost-set membership bits
     }
-    if (lane == 0) {
+    if (lane < 8) {
       uint32_t* st = c.state + static_cast<size_t>(sh) * 8;
-      st[kSHead] = s_head; st[kSSize] = s_size; st[kMHead] = m_head; st[kMSize] = m_size;
-      st[kNextFree] = next_free; st[kGHead] = g_head; st[kGCount] = g_count; st[kSize] = size;
-      if (evictions) atomicAdd(&c.stats[static_cast<size_t>(sh) * 4 + 2], evictions);
+      const uint32_t v = lane == kSHead ? s_head : lane == kSSize ? s_size : lane == kMHead ? m_head : lane == kMSize ? m_size
+                       : lane == kNextFree ? next_free : lane == kGHead ? g_head : lane == kGCount ? g_count : size;
+      c_st<COH>(st + lane, v);
     }
+    if (lane == 0 && evictions) atomicAdd(&c.stats[static_cast<size_t>(sh) * 4 + 2], evictions);
   }
   __device__ __forceinline__ unsigned long long match_slots(uint32_t klo, uint32_t khi) const {
     return __ballot(hlo == klo && hhi == khi);
@@ -299,6 +321,48 @@ struct WaveShard {
     return static_cast<int>(slot);
   }
 };
+
+using WaveShard = WaveShardT<false>;
+
+// S3FIFOCache::insert (s3fifo_cache.h:61-80: lock, insert_locked, copy the rows) by ONE wavefront while other wavefronts
+// insert into the same cache: the shard's lock word (0 = free) is taken with an agent-scope compare-and-swap, the shard is
+// read and written with agent-scope accesses (no fence: nothing of it sits in an L1), and the lock is released after the
+// stores have drained.  The slot's key is cleared before its payload is rewritten and set after it, so a concurrent probe
+// that re-reads the key after the payload (wave_shard_find's validated form) never returns a torn row.
+// p_lane / v_lane: entry `lane` of the policy / value row (np, nv <= 64).  Returns false when the lock could not be had
+// within `spin_cap` tries (the caller raises an error; nothing was changed).
+__device__ inline bool wave_shard_insert_locked(const CacheView& c, uint32_t* locks, uint64_t hash, float p_lane, float v_lane,
+                                                uint32_t lane, uint32_t spin_cap = 1u << 20) {
+  const uint32_t sh = static_cast<uint32_t>(hash % c.shards);
+  uint32_t got = 0;
+  if (lane == 0) {
+    for (uint32_t spins = 0; spins < spin_cap; ++spins) {
+      if (__hip_atomic_load(locks + sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        uint32_t expect = 0u;
+        if (__hip_atomic_compare_exchange_strong(locks + sh, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { got = 1; break; }
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  got = uni(got);
+  if (!got) return false;
+  {
+    WaveShardT<true> ws(c, sh, lane);
+    const int slot = ws.insert(hash);
+    if (slot >= 0) {
+      const size_t e = static_cast<size_t>(sh) * kWaveCap + slot;
+      if (lane == 0) c_st<true>(c.hashes + e, 0ull);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane < c.np) c_st<true>(reinterpret_cast<uint32_t*>(c.policy) + e * c.np + lane, __float_as_uint(p_lane));
+      if (lane < c.nv) c_st<true>(reinterpret_cast<uint32_t*>(c.value) + e * c.nv + lane, __float_as_uint(v_lane));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ws.store();
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_store(locks + sh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
 
 // find on a wave shard by a group of `G` cooperating lanes (G divides 64): each lane checks 64/G slots.
 // Returns the slot or -1 (uniform over the group).  Accounting as in cache_find_account.

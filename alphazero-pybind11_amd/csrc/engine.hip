@@ -18,6 +18,7 @@
 #include <mutex>
 
 #include "cache_host.h"
+#include "engine_host.h"
 #include "engine_kernels.h"
 #include "leafnet_c4.h"
 #include "engine_kernels_big.h"
@@ -37,6 +38,17 @@ int fail(int code, const char* fmt, ...) {
   g_err = buf;
   return code;
 }
+}  // namespace
+int azmi_host_fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+namespace {
 #define HIP_TRY(expr)                                                                     \
   do {                                                                                    \
     hipError_t e_ = (expr);                                                               \
@@ -45,10 +57,6 @@ int fail(int code, const char* fmt, ...) {
                   hipGetErrorString(e_));                                                 \
   } while (0)
 
-struct GameInfo {
-  uint32_t P, M, C, H, W, maxk, max_turns, state_words;
-  uint32_t cap_branch;  // children per expansion the tree arena is sized for (== maxk when that is affordable)
-};
 bool game_info(int game, GameInfo* gi) {
   switch (game) {
     case AZMI_GAME_CONNECT4:
@@ -77,59 +85,6 @@ bool game_info(int game, GameInfo* gi) {
 }
 
 }  // namespace
-
-struct azmi_pm {
-  int game = 0;
-  int device = 0;
-  GameInfo gi{};
-  azmi_play_params params{};
-  EngineParams ep{};
-  EngineArrays ar{};
-  std::vector<void*> allocs;
-  size_t bytes = 0;
-  hipStream_t stream = nullptr;  // engine-owned stream (AZMI_STREAM_ENGINE)
-  hipStream_t last = nullptr;    // stream of the most recent round: result queries order themselves behind it
-  hipStream_t pick(void* s) { last = (s == AZMI_STREAM_ENGINE) ? stream : static_cast<hipStream_t>(s); return last; }
-  uint32_t hist_read = 0;
-  uint32_t cache_shards = 0;
-  std::vector<CacheView> group_caches;   // host copies of the per-model-group cache views
-  std::vector<uint8_t> group_cache_counted;  // 0: stand-in for a `None` entry of an external cache list (not in the statistics)
-  bool all_random = false;               // no seat needs a net (EvalType::RANDOM / PLAYOUT everywhere)
-  bool any_playout = false;              // some seat uses EvalType::PLAYOUT
-  bool split_rounds = false;             // Connect4, plain PUCT seats: k_sim + move step instead of the one k_round (engine_kernels.h)
-  std::vector<std::deque<uint32_t>> pending_g;   // host-buffer path: pending leaves per model group
-  // hipGraph of kGraphRounds x (round kernels + net) for azmi_run_rounds: one graph launch instead of
-  // ~5 kernel launches per round keeps the host ahead of the GPU
-  hipGraphExec_t graph_exec = nullptr;
-  hipStream_t graph_stream = nullptr;
-  azmi_net* graph_net = nullptr;
-  // host-buffer compatibility path
-  std::deque<uint32_t> pending;        // slots whose leaf waits for the net
-  std::vector<float> host_v, host_pi;  // mirrors of the slot-indexed rows
-  uint32_t outstanding = 0;
-  std::atomic<bool> stopped{false};
-  // The reference's callers reach one PlayManager from several Python threads (mcts_workers x play(), batcher threads with
-  // build_batch / update_inferences, the main thread with counters): every entry point that touches the engine's host state
-  // takes this lock, so such callers are serialised instead of racing.  (Recursive: entry points call each other.)
-  std::recursive_mutex mu;    // PlayManager::stop(), play_manager.h:177 (may be set from another thread)
-
-  template <class T>
-  int alloc(T*& p, size_t n, bool zero) {
-    void* q = nullptr;
-    const size_t sz = std::max<size_t>(n, 1) * sizeof(T);
-    HIP_TRY(hipMalloc(&q, sz));
-    allocs.push_back(q);
-    bytes += sz;
-    if (zero) HIP_TRY(hipMemset(q, 0, sz));
-    p = static_cast<T*>(q);
-    return AZMI_OK;
-  }
-  ~azmi_pm() {
-    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
-    for (void* q : allocs) (void)hipFree(q);
-    if (stream) (void)hipStreamDestroy(stream);
-  }
-};
 
 namespace {
 
@@ -221,6 +176,22 @@ __global__ __launch_bounds__(256, 2) void k_net_move(azmi_net_dev::NetDesc nd, a
   else
     round_body<Connect4, false, true>(ep, ar, (blockIdx.x - net_tiles) * blockDim.x + threadIdx.x);
 }
+
+}  // namespace
+// the two between-epoch steps of the asynchronous pipeline (pipeline.hip): the move step of a split round over the slots the
+// tree side listed, as a launch of its own, and the restart / retire bookkeeping
+int azmi_host_launch_move_step(azmi_pm* pm, hipStream_t st) {
+  const uint32_t blocks = (pm->ep.S * Connect4::GROUP + 255u) / 256u;
+  k_round<Connect4, false, true><<<blocks, 256, 0, st>>>(pm->ep, pm->ar);
+  HIP_TRY(hipGetLastError());
+  return AZMI_OK;
+}
+int azmi_host_launch_assign(azmi_pm* pm, hipStream_t st, uint32_t count_round) {
+  k_assign<<<1, 256, 0, st>>>(pm->ep, pm->ar, count_round);
+  HIP_TRY(hipGetLastError());
+  return AZMI_OK;
+}
+namespace {
 
 int read_ctl(azmi_pm* pm, hipStream_t st, Control* out, bool settle) {
   if (settle) k_assign<<<1, 256, 0, st>>>(pm->ep, pm->ar, 0u);
@@ -962,6 +933,7 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
   A(v, static_cast<size_t>(S) * (P + 1), true);
   A(pi, static_cast<size_t>(S) * M, true);
   A(leaf_key, S, true);
+  if (game == AZMI_GAME_CONNECT4) { A(leaf_pos, 3 * static_cast<size_t>(S), true); A(req_seq, S, true); }
   A(h_canon, static_cast<size_t>(ep.hist_cap) * CANON, false);
   A(h_v, static_cast<size_t>(ep.hist_cap) * (P + 1), false);
   A(h_pi, static_cast<size_t>(ep.hist_cap) * M, false);

@@ -1199,7 +1199,14 @@ struct SlotCtx {
   __device__ __forceinline__ void emit_leaf(const typename GM::State& leaf, uint64_t key) const {
     float* row = ar.canon + static_cast<size_t>(slot) * GM::CANON;
     for (uint32_t e = lane; e < static_cast<uint32_t>(GM::CANON); e += G) row[e] = GM::canonical_at(leaf, e);
-    if (lane == 0) ar.leaf_key[slot] = key;
+    if (lane == 0) {
+      ar.leaf_key[slot] = key;
+      if (ar.leaf_pos) {     // the packed position: what the asynchronous pipeline's request carries instead of the planes
+        ar.leaf_pos[0 * static_cast<size_t>(ep.S) + slot] = leaf.bb[0];
+        ar.leaf_pos[1 * static_cast<size_t>(ep.S) + slot] = leaf.bb[1];
+        ar.leaf_pos[2 * static_cast<size_t>(ep.S) + slot] = leaf.player;
+      }
+    }
   }
   // position-cache probe (play_manager.cc:592-597): on a hit the cached (pi, v) land in the slot's rows AND in
   // registers (lane m: pi[m] in hit_pi, lane i <= P: v[i] in hit_v) for a process_result later in this round
@@ -1587,7 +1594,9 @@ __device__ __forceinline__ void assign_body(const EngineParams& ep, const Engine
   }
 }
 
+#ifndef AZMI_KERNELS_NO_ASSIGN   // (a plain, non-template kernel: one translation unit of the library defines it)
 __global__ void k_assign(EngineParams ep, EngineArrays ar, uint32_t count_round) { assign_body(ep, ar, count_round); }
+#endif
 
 // Start of a round with the position cache on: the leaves the net evaluated in the previous round go into
 // the cache (PlayManager::update_inferences -> insert_many, play_manager.cc:631-640; one wave per leaf, batch

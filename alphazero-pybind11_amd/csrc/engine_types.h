@@ -20,7 +20,9 @@ enum SlotState : uint8_t {
 };
 
 enum SlotFlags : uint8_t { kFlagCapped = 1, kFlagPlaythrough = 2, kFlagLeafNeedsNet = 4,
-                           kFlagPendRec = 8 /* ar.pend[slot] describes the pending simulation (split rounds) */ };
+                           kFlagPendRec = 8 /* ar.pend[slot] describes the pending simulation (split rounds) */,
+                           kFlagReqOut = 16 /* pipeline: the pending leaf is a request in the net ring / an answer in the result
+                                               granules tagged ar.req_seq[slot]; cleared when the answer is consumed or settled */ };
 
 // node META word: [31:0] first child (tree-relative), [43:32] child count,
 // [55:44] move, [56] player to move at the node, [59:57] terminal code
@@ -181,6 +183,8 @@ struct EngineArrays {
   float* v;               // [S][P+1]     net value  (probabilities)
   float* pi;              // [S][M]       net policy (probabilities)
   uint64_t* leaf_key;     // [S]          position key of the pending leaf
+  uint64_t* leaf_pos;     // [3][S]       pipeline (Connect4): the pending leaf's packed position (stones p0, stones p1, player); NULL = not kept
+  uint32_t* req_seq;      // [S]          pipeline: sequence number of the slot's latest net request (tags its result granules)
   // ---- finished samples (PlayHistory rows) ---------------------------------------------
   float* h_canon;         // [hist_cap][CANON]
   float* h_v;             // [hist_cap][P+1]

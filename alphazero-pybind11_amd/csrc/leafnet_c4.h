@@ -137,11 +137,22 @@ __device__ __forceinline__ void barrier_lds() {
 // 6 = stem only, 7 = stem + trunk
 // `tile_index` = which tile of TBW rows this workgroup takes (the block index of the plain launch; the fused net + move-step
 // launch of the engine passes its own); `lds` = the workgroup's LDS_BYTES of dynamic LDS.
-template <class TG, int CIN, int MAXP1, int MAXM, int DBG = 0>
+// PIPE (the asynchronous pipeline's persistent net workgroups, pipeline.hip): the caller has already written the tile's raw
+// input planes into their LDS staging area (ring slot 4: [board][CIN][PIX] floats) - there is no DMA from `canon` -, and the
+// outputs leave as tagged result granules instead of rows: entry k of board b (pi entries first, then the value entries) goes to
+// pio->res[pio->slot[b] * pio->stride + k] as ONE 8-byte agent-scope store {pio->seq[b] << 32 | float bits}; boards whose
+// slot is 0xFFFFFFFF are padding.  pio->slot / pio->seq live in LDS behind the tile's own LDS_BYTES.
+struct PipeIO {
+  unsigned long long* res;
+  const uint32_t* slot;
+  const uint32_t* seq;
+  uint32_t stride, v_first;
+};
+template <class TG, int CIN, int MAXP1, int MAXM, int DBG = 0, bool PIPE = false>
 __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const float* __restrict__ canon,
                                      float* __restrict__ v_out, float* __restrict__ pi_out, uint32_t batch,
                                      const uint32_t* __restrict__ rows, const uint32_t* __restrict__ row_count,
-                                     const uint32_t tile_index, uint8_t* const lds) {
+                                     const uint32_t tile_index, uint8_t* const lds, const PipeIO* pio = nullptr) {
   static_assert(9 * CIN <= 64, "stem im2col fits one 64-row k-chunk");
   constexpr int TBW = TG::TBW, NTW = TG::NTW, NPIX = TG::NPIX, PLANE = TG::PLANE, ZERO_OFF = TG::ZERO_OFF, ACT_BYTES = TG::ACT_BYTES;
   // rows != nullptr: evaluate only the rows listed in rows[0 .. *row_count) (the engine's eval list: slots whose
@@ -156,7 +167,11 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
   uint8_t* const ring = lds + ACT_BYTES;
   float* const prm = reinterpret_cast<float*>(lds + ACT_BYTES + RING_BYTES);
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  int tid_ = threadIdx.x;
+  // a persistent caller runs this body in a loop: everything below that depends on the thread index alone would be hoisted out
+  // of that loop and spilled (64 scratch stores in its preheader); an opaque copy keeps it where it is
+  if constexpr (PIPE) asm volatile("" : "+v"(tid_));
+  const int tid = tid_, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, quad = lane >> 4;
   const uint32_t board0 = tile_index * TBW;
@@ -200,9 +215,11 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
   uint8_t* const stem_w_lds = ring + 3 * CHUNK_BYTES;
   float* const raw = reinterpret_cast<float*>(ring + 4 * CHUNK_BYTES);
   static_assert(2 * MT * WFRAG_BYTES <= CHUNK_BYTES && TBW * CIN * PIX * 4 <= CHUNK_BYTES, "stem operands fit two ring slots");
-  if (tid < TBW * (CIN * PIX / 4))
-    dma16(reinterpret_cast<const uint8_t*>(canon + static_cast<size_t>(in_row) * (CIN * PIX)) + in_piece * 16,
-          reinterpret_cast<uint8_t*>(raw) + wave * 1024);
+  if constexpr (!PIPE) {
+    if (tid < TBW * (CIN * PIX / 4))
+      dma16(reinterpret_cast<const uint8_t*>(canon + static_cast<size_t>(in_row) * (CIN * PIX)) + in_piece * 16,
+            reinterpret_cast<uint8_t*>(raw) + wave * 1024);
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) dma16(np.stem_w + (wave * 2 + i) * WFRAG_BYTES + lane * 16, stem_w_lds + (wave * 2 + i) * WFRAG_BYTES);
   issue_next(0);
@@ -591,8 +608,15 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
       float sum = 0.0f;
       for (int i = 0; i < cnt; ++i) sum += expf(lg[i] - mx);
       const float pr = expf(lg[idx] - mx) / sum;
-      if (is_v) v_out[static_cast<size_t>(out_row) * P1 + idx] = pr;
-      else pi_out[static_cast<size_t>(out_row) * M + idx] = pr;
+      if constexpr (PIPE) {
+        const uint32_t sl = pio->slot[b];
+        if (sl != 0xFFFFFFFFu)
+          __hip_atomic_store(pio->res + static_cast<size_t>(sl) * pio->stride + (is_v ? pio->v_first + idx : idx),
+                             (static_cast<unsigned long long>(pio->seq[b]) << 32) | __float_as_uint(pr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        if (is_v) v_out[static_cast<size_t>(out_row) * P1 + idx] = pr;
+        else pi_out[static_cast<size_t>(out_row) * M + idx] = pr;
+      }
     }
   }
 }

@@ -1,0 +1,82 @@
+// Asynchronous tree / net pipeline of the Connect4 engine (pipeline.hip): the structures its kernels share.
+//
+// The reference's worker loop has no global barrier: every game advances on its own through the queues between the MCTS
+// workers and the batcher threads (play_manager.cc:258-600, concurrent_queue.h:130-217).  The lock-step round of
+// engine.hip (cache insert -> k_sim -> k_net_move, one after the other, a round as long as its slowest slot) gave that up.
+// Here it is back, on the device: for one EPOCH
+//   * tree wavefronts (persistent, 8 game slots each, k_pipe_tree) run simulation after simulation for their slots and hand
+//     every leaf that needs the net to
+//   * net workgroups (persistent, k_pipe_net) that pull 3- or 6-board tiles off a request ring as soon as leaves exist
+//     (continuous batching) and hand the (v, pi) rows back to the slot that asked.
+// The two sides talk through HBM only:
+//   * request ring: a tree group takes a ticket (tail) and writes its leaf as kReqGranules 8-byte granules
+//     {tag16 | payload48}: stones of player 0 | stones of player 1 | slot, player | sequence number; a net workgroup claims
+//     [head, head + n) and re-reads the granules until every tag is the tag of the ring lap;
+//   * result granules: per slot kResStride 8-byte granules {seq32 | float bits}, pi[0..M) then v[0..P]; the slot's tree group
+//     polls them until every tag is the sequence number of its request.
+// Every granule is ONE naturally aligned 8-byte agent-scope atomic store / load (write-through, L1-bypassing): the data is
+// its own flag, no fence, no ordering between granules is assumed (cdna_hip_programming.md Guideline 16, form R2).
+// Everything else a slot owns (its trees, its state) is only ever touched by the one wavefront that owns the slot, and
+// what happens rarely - a move, a game's end, a new game (the register-hungry code) - is done between epochs by the
+// kernels of the lock-step engine, at a kernel boundary.  Every spin is bounded by a wall-clock cap.
+#pragma once
+#include <stdint.h>
+
+namespace azmi {
+
+constexpr uint32_t kReqGranules = 4;     // ring entry = 32 bytes
+constexpr uint32_t kResStride = 16;      // result granules per slot: M + P + 1 = 10 used, padded to one 128-byte line
+constexpr uint32_t kResV = 7;            // first value granule (Connect4: pi in [0, 7), v in [7, 10))
+constexpr uint32_t kPipeRing = 8192;     // ring entries (a power of two above the slots of an engine: one request per slot at most)
+enum PipeErr : uint32_t { kPipeErrTimeout = 1, kPipeErrRing = 2, kPipeErrTag = 4, kPipeErrLog = 8, kPipeErrLock = 16, kPipeErrSlots = 32, kPipeErrNetTimeout = 64 };
+
+__host__ __device__ inline uint64_t pipe_lap_tag(uint32_t pos) { return static_cast<uint64_t>(((pos / kPipeRing) & 0x7FFFu) + 1u); }
+
+struct PipeCtl {          // zeroed when the pipeline is created; lives across epochs.  Every hot word on a 128-byte line of its own
+  uint32_t head; uint32_t pad0[31];             // ring entries claimed by net workgroups (free-running: position = value % kPipeRing)
+  uint32_t tail; uint32_t pad1[31];             // ring tickets handed out to tree wavefronts (free-running)
+  uint32_t err;           // PipeErr bits, sticky: every pipeline kernel leaves at once when it is set
+  uint32_t pad2;
+  unsigned long long tiles;         // net tiles run
+  unsigned long long tile_boards;   // boards in them
+  unsigned long long epochs;
+  uint32_t dbg[24];       // diagnostics of the first time-out: slot, sequence number, group state, the tags seen
+  // tree-side time accounting (100 MHz ticks / counts, summed over wavefronts): [0] in simulation passes, [1] polling with no
+  // group ready, [2] passes, [3] groups active in them, [4] polls, [5] in the request step, [6] wavefront lifetimes, [7] net: ticks
+  // waiting for requests, [8] net: ticks in tiles
+  unsigned long long prof[16];
+};
+static_assert(sizeof(PipeCtl) == 512, "four lines");
+
+struct PipeEpoch {        // an allocation of its own, zeroed before every epoch (one memset)
+  unsigned long long sims; uint32_t pad0[30];   // simulations finished in this epoch
+  unsigned long long t0;  // wall clock of the epoch's first workgroup
+  uint32_t stop;          // the epoch is over: quota reached, enough slots wait for the move step, time cap passed, or an error
+  uint32_t tree_done;     // tree workgroups that have stored their slots and left
+  uint32_t tree_arrived, net_arrived;   // census: workgroups that started
+  uint32_t ins_count;     // entries of the insert log
+  uint32_t waiting;       // slots whose next step is the move step's (listed for it): they idle until the epoch ends
+  uint32_t dead;          // slots without a game (retired, or ended and not yet restarted)
+  uint32_t tree_late, net_late;   // census: the latest start of a tree / net workgroup, in 100 MHz ticks after the first workgroup of the epoch
+  uint32_t pad1[21];
+};
+static_assert(sizeof(PipeEpoch) == 256, "memset block: a multiple of 16 bytes");
+
+struct PipeArrays {
+  PipeCtl* ctl;
+  PipeEpoch* ep;
+  unsigned long long* ring;   // [kPipeRing][kReqGranules]
+  unsigned long long* res;    // [S][kResStride]
+  // insert log: (key, pi, v) of every answer consumed in the epoch; applied to the position cache between epochs
+  uint64_t* ins_key;          // [ins_cap]
+  float* ins_pi;              // [ins_cap][M]
+  float* ins_v;               // [ins_cap][P + 1]
+  uint32_t ins_cap;
+  uint32_t* locks;            // [cache shards] insert locks of the position cache (0 = free)
+  uint32_t n_tree_wgs;
+  unsigned long long quota;       // simulations per epoch
+  uint32_t idle_num;              // the epoch also ends when `waiting` reaches idle_num / 1024 of the slots that have a game
+  unsigned long long cap_ticks;   // hard time cap of an epoch in 100 MHz ticks
+};
+
+}  // namespace azmi

@@ -1,0 +1,867 @@
+// The asynchronous tree / net pipeline of the Connect4 engine (see pipe_types.h for the structure and the hand-off
+// protocol): persistent tree wavefronts + persistent net workgroups for one EPOCH, then - at a kernel boundary - the rare,
+// register-hungry steps (moves, game ends, new games: the move step and k_assign of the lock-step engine) and the position
+// cache inserts of everything the net answered in the epoch.
+//
+// Reference behaviour restated: the worker loop of PlayManager::play (play_manager.cc:258-600) with its queues
+// (concurrent_queue.h:130-217) and GameRunner's batcher / gpu_loop / result_worker threads (game_runner.py:483-552, 651-726);
+// the search itself is k_sim's (engine_kernels.h): MCTS::process_result (mcts.cc:500-555), MCTS::find_leaf (mcts.cc:462-498),
+// Node::add_children (mcts.cc:93-101), S3FIFOCache::find / insert (s3fifo_cache.h:41-80).
+// A slot's game is a function of its seed alone (the answer to a position does not depend on where or when the net evaluates
+// it), so the games are the lock-step engine's games: tests/test_gpu_pipeline.py.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../include/azmi.h"
+#include "engine_host.h"
+#define AZMI_KERNELS_NO_ASSIGN
+#include "engine_kernels.h"
+#include "leafnet_c4.h"
+#include "pipe_types.h"
+
+using namespace azmi;
+
+namespace azmi {
+
+__device__ __forceinline__ unsigned long long g_ld(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t g_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void g_st(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void g_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+enum : uint32_t { kGrpIdle = 0, kGrpReady = 1, kGrpWait = 2, kGrpPush = 3 };
+constexpr uint64_t kMask48 = (1ull << 48) - 1;
+
+// ---- tree side ---------------------------------------------------------------------------------------------------------------------
+// One 8-lane group per slot, 8 slots per wavefront, for the whole epoch.  A group is
+//   READY  its pending simulation has its answer (in the slot's (v, pi) rows and in registers): back it up, descend again
+//   PUSH   the new leaf needs the net: it gets a ring ticket at the top of the wavefront's next pass
+//   WAIT   the request is out: the group polls its result granules
+//   IDLE   nothing to do here any more this epoch (the slot's next step is a move / a game start: listed for the move step)
+// The body of a pass is k_sim's (engine_kernels.h): the pending simulation's path in registers, level i in lane i.
+template <class GM>
+__global__ __launch_bounds__(256, 2) void k_pipe_tree(EngineParams ep, EngineArrays ar, PipeArrays pa) {
+  constexpr int G = GM::GROUP;
+  constexpr int P = GM::P;
+  static_assert(P == 2 && G == 8 && GM::M == 7, "written for Connect4's 8-lane groups");
+  const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t slot_raw = gtid / G, lane = gtid % G;
+  const uint32_t wlane = threadIdx.x & 63u, grp = wlane >> 3;
+  const bool in_range = slot_raw < ep.S;
+  const uint32_t slot = in_range ? slot_raw : 0u;
+  const uint64_t t_start = wall_clock64();
+  PipeCtl* const pc = pa.ctl;
+  PipeEpoch* const pe = pa.ep;
+  // census first, then the epoch's stop word: a workgroup that only gets a place on the chip after the epoch has ended (the net
+  // side, which leaves when every ARRIVED tree workgroup is done, may be gone by then) must not send requests any more
+  if (threadIdx.x == 0) {
+    unsigned long long t0 = atomicCAS(&pe->t0, 0ull, static_cast<unsigned long long>(t_start));
+    if (t0 == 0ull) t0 = t_start;
+    atomicMax(&pe->tree_late, static_cast<uint32_t>(t_start > t0 ? t_start - t0 : 0ull));
+    const uint32_t before = atomicAdd(&pe->tree_arrived, 1u);
+    asm volatile("s_waitcnt vmcnt(0)" :: "v"(before) : "memory");
+  }
+  __syncthreads();
+
+  uint32_t st = kGrpIdle;
+  bool dirty = false;                      // the slot's state changed here: stored on the way out
+  uint8_t final_state = kSlotWaitEval;
+  bool live = in_range && ar.ctl->stop == 0 && g_ld(&pc->err) == 0 && g_ld(&pe->stop) == 0;
+  uint8_t sst = kSlotDone;
+  if (live) { sst = ar.sstate[slot]; live = sst != kSlotDone && sst != kSlotEnded; }
+  auto defer = [&]() { if (lane == 0) ar.mover_list[atomicAdd(&ar.ctl->mover_count, 1u)] = slot; };
+  if (live && sst != kSlotWaitEval && sst != kSlotQueued) { defer(); live = false; }     // kSlotFresh / kSlotRestart: a game start
+  SlotCtx<GM> c(ep, ar, slot, lane);
+  uint32_t cp = 0, root = 0, goal = 0, seq = 0;
+  size_t tb = 0;
+  float fpu_root = 0.0f;
+  uint32_t* const path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
+  float reg_pi = 0.0f, reg_v = 0.0f;
+  uint32_t root_n = 0; float root_v = 0.0f; uint64_t root_meta = 0;
+  uint32_t lv_node = 0, lv_n = 0, lv_pp = 0;
+  float lv_q = 0.0f, lv_d = 0.0f, lv_v = 0.0f;
+  uint64_t lf_meta = 0;
+  uint32_t lf_mv = 0, lf_c0 = 0, lf_k = 0, lf_term = 0, lf_player = 0;
+  bool fw = false;
+  uint32_t fw_node = 0, fw_n = 0, fw_plen = 0;
+  float fw_q = 0.0f, fw_d = 0.0f, fw_v = 0.0f;
+  uint32_t fl_node = 0xFFFFFFFFu, fl_mv = 0;
+  uint64_t fl_meta = 0;
+  float fl_pr = 0.0f;
+  uint32_t sims_done = 0;
+  bool rec_ok = true;
+  uint64_t cur_key = 0, push_b0 = 0, push_b1 = 0;
+  uint32_t push_pl = 0;
+  bool queued_leaf = false;
+  if (live) {
+    c.load();
+    cp = c.gs.player;
+    tb = c.tree_base(cp);
+    root = AZMI_SEL(c.t_root, cp);
+    goal = (c.flags & kFlagCapped) ? c.seat_cap_visits(cp) : c.seat_visits(cp);
+    fpu_root = c.seat_fpu_zero(cp) ? 0.0f : ep.fpu_reduction;
+    seq = ar.req_seq[slot];
+    rec_ok = (c.flags & kFlagPendRec) != 0;
+    if (c.flags & kFlagReqOut) {            // every request of the previous epoch was settled at its end
+      if (lane == 0) atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTag));
+      live = false;
+    }
+  }
+  if (live) {
+    if (sst == kSlotQueued) {
+      // the move step's leaf (planes and key written, not evaluated yet): its request goes out first thing
+      push_b0 = ar.leaf_pos[0 * static_cast<size_t>(ep.S) + slot];
+      push_b1 = ar.leaf_pos[1 * static_cast<size_t>(ep.S) + slot];
+      push_pl = static_cast<uint32_t>(ar.leaf_pos[2 * static_cast<size_t>(ep.S) + slot]);
+      cur_key = ar.leaf_key[slot];
+      st = kGrpPush;
+      queued_leaf = true;
+    } else if (!rec_ok || AZMI_SEL(c.t_depth, cp) + 1 >= goal || c.cur == root) {
+      // the next backup completes the search, the evaluated leaf is the root, or the path has no lane image: the move step's
+      defer();
+      live = false;
+    } else {
+      st = kGrpReady;
+      if (c.flags & kFlagLeafNeedsNet) {
+        if (lane < static_cast<uint32_t>(GM::M)) reg_pi = ar.pi[static_cast<size_t>(slot) * GM::M + lane];
+        if (lane <= static_cast<uint32_t>(P)) reg_v = ar.v[static_cast<size_t>(slot) * (P + 1) + lane];
+      }
+    }
+  }
+  if (live) {
+    const PendRec pr_in = ar.pend[static_cast<size_t>(slot) * G + lane];
+    { const NodeRec* rr = ar.nodes + tb + root; root_n = rr->n; root_v = rr->v; root_meta = rr->meta; }
+    lv_node = pr_in.node; lv_n = pr_in.n; lv_pp = pr_in.pp_mv & 0xFFu;
+    lv_q = pr_in.q; lv_d = pr_in.d; lv_v = pr_in.v;
+    lf_meta = pr_in.leaf_meta;
+    lf_mv = pr_in.pp_mv >> 8;
+    lf_c0 = meta_ch0(lf_meta); lf_k = meta_nch(lf_meta); lf_term = meta_term(lf_meta); lf_player = meta_player(lf_meta);
+  }
+  unsigned long long* const res = pa.res + static_cast<size_t>(slot) * kResStride;
+  {   // slots that have nothing to do here from the start: without a game, or waiting for the move step
+    const bool no_game = in_range && (sst == kSlotDone || sst == kSlotEnded);
+    const unsigned long long dm = __ballot(no_game && lane == 0);
+    const unsigned long long im = __ballot(in_range && !no_game && st == kGrpIdle && lane == 0);
+    if (dm && wlane == 0) atomicAdd(&pe->dead, static_cast<uint32_t>(__popcll(dm)));
+    if (im && wlane == 0) atomicAdd(&pe->waiting, static_cast<uint32_t>(__popcll(im)));
+  }
+
+  uint64_t pf_pass = 0, pf_idle = 0, pf_push = 0, pf_n = 0, pf_act = 0, pf_polls = 0;
+  for (;;) {
+    const uint64_t pf_t0 = wall_clock64();
+    // ---- A: the requests of the groups whose new leaf needs the net: one ticket draw per wavefront
+    {
+      const unsigned long long pm = __ballot(st == kGrpPush && lane == 0);
+      if (pm) {
+        uint32_t base = 0;
+        if (wlane == 0) base = atomicAdd(&pc->tail, static_cast<uint32_t>(__popcll(pm)));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (st == kGrpPush) {
+          const uint32_t pos = base + static_cast<uint32_t>(__popcll(pm & ((1ull << (grp * 8)) - 1ull)));
+          seq = seq + 1u == 0u ? 1u : seq + 1u;
+          const uint64_t payload = lane == 0 ? push_b0 : lane == 1 ? push_b1 : lane == 2 ? (static_cast<uint64_t>(slot) | (static_cast<uint64_t>(push_pl) << 16))
+                                                                                          : static_cast<uint64_t>(seq);
+          if (lane < kReqGranules)
+            g_st(pa.ring + static_cast<size_t>(pos & (kPipeRing - 1u)) * kReqGranules + lane, (pipe_lap_tag(pos) << 48) | (payload & kMask48));
+          if (lane == 0) { if (!queued_leaf) ar.c_evals[slot] += 1; ar.leaf_key[slot] = cur_key; }   // (the move step counted its own leaf)
+          queued_leaf = false;
+          c.flags |= kFlagReqOut;
+          st = kGrpWait;
+          dirty = true;
+        }
+      }
+    }
+    const uint64_t pf_t1 = wall_clock64();
+    pf_push += pf_t1 - pf_t0; pf_polls += 1;
+    // ---- B: poll - the result granules of the waiting groups, and the epoch's end
+    unsigned long long g0 = 0, g1 = 0;
+    if (st == kGrpWait) {
+      if (lane < static_cast<uint32_t>(GM::M)) g0 = g_ld(res + lane);
+      if (lane <= static_cast<uint32_t>(P)) g1 = g_ld(res + kResV + lane);
+    }
+    uint32_t ctl_word = 0;
+    if (wlane == 7) ctl_word = g_ld(&pe->stop) | g_ld(&pc->err);
+    else if (wlane == 15) ctl_word = g_ld(&pe->sims) >= pa.quota ? 1u : 0u;
+    else if (wlane == 23) ctl_word = g_ld(&pe->waiting);
+    else if (wlane == 31) ctl_word = g_ld(&pe->dead);
+    uint32_t stop_seen = __builtin_amdgcn_readlane(ctl_word, 7) | __builtin_amdgcn_readlane(ctl_word, 15);
+    {
+      // enough slots wait for the move step (or nothing is left to simulate at all): the epoch ends early
+      const uint32_t w = __builtin_amdgcn_readlane(ctl_word, 23), d = __builtin_amdgcn_readlane(ctl_word, 31);
+      const uint32_t with_game = ep.S > d ? ep.S - d : 0u;
+      const uint32_t thr = max(1u, static_cast<uint32_t>((static_cast<unsigned long long>(with_game) * pa.idle_num) >> 10));
+      if (w >= thr || w + d >= ep.S) stop_seen = 1u;
+    }
+    if (stop_seen && wlane == 0) g_st(&pe->stop, 1u);
+    if (wall_clock64() - t_start > pa.cap_ticks) {
+      if (wlane == 0) { atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTimeout)); g_st(&pe->stop, 1u); }
+      if (st == kGrpWait) {        // which request never came back
+        if (lane == 0 && atomicAdd(&pc->dbg[0], 1u) == 0u) { pc->dbg[1] = slot; pc->dbg[2] = seq; pc->dbg[3] = c.flags; pc->dbg[4] = static_cast<uint32_t>(g1 >> 32); }
+        if (pc->dbg[1] == slot && lane < 7) pc->dbg[8 + lane] = static_cast<uint32_t>(g0 >> 32);
+      }
+      if (wlane == 0) { pc->dbg[16] = __builtin_amdgcn_readlane(ctl_word, 23); pc->dbg[17] = __builtin_amdgcn_readlane(ctl_word, 31); pc->dbg[18] = static_cast<uint32_t>(g_ld(&pe->sims)); }
+      atomicAdd(&pc->dbg[19 + (st & 3u)], lane == 0 ? 1u : 0u);
+      break;
+    }
+    if (stop_seen) break;
+    const bool ok = st == kGrpWait && (lane >= static_cast<uint32_t>(GM::M) || static_cast<uint32_t>(g0 >> 32) == seq) &&
+                    (lane > static_cast<uint32_t>(P) || static_cast<uint32_t>(g1 >> 32) == seq);
+    const unsigned long long okm = __ballot(ok);
+    const bool arrived = st == kGrpWait && ((okm >> (grp * 8)) & 0xFFull) == 0xFFull;
+    if (arrived) {
+      reg_pi = lane < static_cast<uint32_t>(GM::M) ? __uint_as_float(static_cast<uint32_t>(g0)) : 0.0f;
+      reg_v = lane <= static_cast<uint32_t>(P) ? __uint_as_float(static_cast<uint32_t>(g1)) : 0.0f;
+      // the rows keep the pending answer, as they do for the lock-step kernels (the move step reads them)
+      if (lane < static_cast<uint32_t>(GM::M)) ar.pi[static_cast<size_t>(slot) * GM::M + lane] = reg_pi;
+      if (lane <= static_cast<uint32_t>(P)) ar.v[static_cast<size_t>(slot) * (P + 1) + lane] = reg_v;
+      c.flags &= ~kFlagReqOut;
+      st = kGrpReady;
+    }
+    if (ep.cache_on) {        // PlayManager::update_inferences -> insert_many (play_manager.cc:631-640): logged, applied after the epoch
+      const unsigned long long am = __ballot(arrived && lane == 0);
+      if (am) {
+        uint32_t base = 0;
+        if (wlane == 0) base = atomicAdd(&pe->ins_count, static_cast<uint32_t>(__popcll(am)));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (arrived) {
+          const uint32_t idx = base + static_cast<uint32_t>(__popcll(am & ((1ull << (grp * 8)) - 1ull)));
+          if (idx < pa.ins_cap) {
+            if (lane == 0) pa.ins_key[idx] = cur_key;
+            if (lane < static_cast<uint32_t>(GM::M)) pa.ins_pi[static_cast<size_t>(idx) * GM::M + lane] = reg_pi;
+            if (lane <= static_cast<uint32_t>(P)) pa.ins_v[static_cast<size_t>(idx) * (P + 1) + lane] = reg_v;
+          } else if (lane == 0) {
+            atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrLog));
+          }
+        }
+      }
+    }
+    if (__ballot(st == kGrpReady) == 0ull) { __builtin_amdgcn_s_sleep(24); pf_idle += wall_clock64() - pf_t1; continue; }
+    const uint64_t pf_t2 = wall_clock64();
+    pf_idle += pf_t2 - pf_t1; pf_n += 1; pf_act += static_cast<uint64_t>(__popcll(__ballot(st == kGrpReady && lane == 0)));
+
+    // ---- C: simulations of the READY groups (k_sim's body)
+    uint32_t iter_sims = 0;
+    const bool was_ready = st == kGrpReady;
+    if (st == kGrpReady) {
+      uint32_t inline_sims = 0;
+      for (;;) {
+        if (AZMI_SEL(c.t_depth, cp) + 1 >= goal || c.cur == root || !rec_ok) { defer(); st = kGrpIdle; dirty = true; break; }
+        {
+          // ---- MCTS::process_result (mcts.cc:500-555) on the lane-resident path
+          const bool from_net = (c.flags & kFlagLeafNeedsNet) != 0;
+          float val[P + 1];
+          if (lf_term != 0) {
+#pragma unroll
+            for (int i = 0; i <= P; ++i) val[i] = (static_cast<int>(lf_term) - 1 == i) ? 1.0f : 0.0f;
+          } else {
+            float p = 0.0f;
+            if (from_net) {
+#pragma unroll
+              for (int i = 0; i <= P; ++i) val[i] = c.bcast(reg_v, i);
+              p = c.bcast(reg_pi, static_cast<int>(lf_mv));
+              if (lane >= lf_k) p = 0.0f;
+            } else {                  // dumb_eval: uniform over legal moves, u8 sum wraps (game_state.h:160-173)
+#pragma unroll
+              for (int i = 0; i <= P; ++i) val[i] = static_cast<float>(1.0 / (P + 1));
+              const float ksum = static_cast<float>(lf_k & 0xFFu);
+              if (lane < lf_k) p = (ksum == 0.0f) ? 0.0f : 1.0f / ksum;
+            }
+            const float sum = c.seqsum8(lane < lf_k ? p : 0.0f);
+            p = p / sum;
+            if (lane < lf_k) ar.nodes[tb + lf_c0 + lane].pr = p;
+            fl_pr = p;
+          }
+          fl_node = c.cur; fl_mv = lf_mv; fl_meta = lf_meta;
+          const float draw_share = val[P] / static_cast<int32_t>(P);
+          const uint32_t plen = c.plen;
+          float nq = 0.0f, nd = 0.0f, nv = lv_v;
+          if (lane < plen) {
+            const float vv = ((lv_pp == 0) ? val[0] : val[1]) + draw_share;
+            nq = (lv_q * static_cast<float>(lv_n) + vv) / static_cast<float>(lv_n + 1);
+            nd = (lv_d * static_cast<float>(lv_n) + val[P]) / static_cast<float>(lv_n + 1);
+            NodeRec* nr = ar.nodes + tb + lv_node;
+            nr->q = nq; nr->d = nd;
+            if (lv_n == 0) { nv = ((lf_player == 0) ? val[0] : val[1]) + draw_share; nr->v = nv; }   // only the leaf can be a first visit
+            nr->n = lv_n + 1;
+          }
+          fw_node = lv_node; fw_n = lv_n + 1; fw_q = nq; fw_d = nd; fw_v = nv; fw_plen = plen; fw = true;
+          root_n += 1;
+          if (lane == 0) ar.nodes[tb + root].n = root_n;
+#pragma unroll
+          for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == cp) c.t_depth[p] += 1;
+          sims_done += 1; iter_sims += 1;
+          dirty = true;
+        }
+        // ---- MCTS::find_leaf (mcts.cc:462-498), plain PUCT, with the forwarded values patched in
+        typename GM::State leaf = c.gs;
+        uint32_t cur = root, plen = 0, n = root_n;
+        uint64_t meta = root_meta;
+        float v_cur = root_v;
+        bool prefix = true, failed = false;
+        while (n > 0 && meta_term(meta) == 0) {
+          if (plen >= ep.max_depth) { failed = true; break; }
+          if (lane == 0) path[plen] = cur;
+          const uint32_t k = meta_nch(meta), c0 = meta_ch0(meta);
+          if (k == 0) { failed = true; break; }
+          uint32_t n_l = 0; float q_l = 0.0f, p_l = 0.0f, d_l = 0.0f, v_l = 0.0f; uint64_t m_l = 0;
+          if (cur == fl_node) {                 // the children of the leaf evaluated a moment ago: all in registers
+            if (lane < k) { p_l = fl_pr; m_l = meta_pack(0, 0, fl_mv, 0, 0); }
+          } else {
+            if (lane < k) {
+              const NodeRec* cr = ar.nodes + tb + c0 + lane;
+              n_l = cr->n; q_l = cr->q; p_l = cr->pr; d_l = cr->d; v_l = cr->v; m_l = cr->meta;
+            }
+            if (fw && prefix && plen < fw_plen && plen < 8u) {   // one child of this node was updated by the last backup
+              const uint32_t t_node = c.bcast(fw_node, static_cast<int>(plen));
+              const uint32_t t_n = c.bcast(fw_n, static_cast<int>(plen));
+              const float t_q = c.bcast(fw_q, static_cast<int>(plen)), t_d = c.bcast(fw_d, static_cast<int>(plen)), t_v = c.bcast(fw_v, static_cast<int>(plen));
+              if (c0 + lane == t_node) { n_l = t_n; q_l = t_q; d_l = t_d; v_l = t_v; if (t_node == fl_node) m_l = fl_meta; }
+            }
+          }
+          const float fpu = (cur == root) ? fpu_root : ep.fpu_reduction;
+          const uint32_t best = c.select_child(k, n_l, q_l, p_l, v_cur, n, fpu);
+          const uint32_t nxt = c0 + best;
+          const uint32_t s_n = c.bcast(n_l, static_cast<int>(best));
+          const float s_q = c.bcast(q_l, static_cast<int>(best)), s_d = c.bcast(d_l, static_cast<int>(best)), s_v = c.bcast(v_l, static_cast<int>(best));
+          const uint64_t s_m = c.bcast(m_l, static_cast<int>(best));
+          if (plen < 8u) {
+            if (lane == plen) { lv_node = nxt; lv_n = s_n; lv_q = s_q; lv_d = s_d; lv_v = s_v; lv_pp = meta_player(meta); }
+            prefix = prefix && plen < fw_plen && nxt == c.bcast(fw_node, static_cast<int>(plen));
+          } else {
+            prefix = false;
+          }
+          cur = nxt; n = s_n; meta = s_m; v_cur = s_v;
+          GM::play(leaf, meta_mv(meta));
+          ++plen;
+        }
+        if (failed) { c.raise(8u); final_state = kSlotDone; st = kGrpIdle; dirty = true; break; }
+        c.cur = cur; c.plen = plen;
+        rec_ok = plen <= 8u;
+#pragma unroll
+        for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == cp) c.t_tld[p] += plen;
+        uint32_t term = meta_term(meta);
+        lf_k = meta_nch(meta); lf_c0 = meta_ch0(meta); lf_mv = 0; lf_meta = meta;
+        if (n == 0) {
+          term = GM::terminal(leaf);
+          const uint64_t keep = meta_pack(0, 0, meta_mv(meta), leaf.player, term);
+          if (!c.expand_node(cp, cur, leaf, keep, lf_c0, lf_k, &lf_mv)) { final_state = kSlotDone; st = kGrpIdle; dirty = true; break; }
+          lf_meta = meta_pack(lf_c0, lf_k, meta_mv(meta), leaf.player, term);
+        }
+        lf_term = term; lf_player = leaf.player;
+        const bool needs_net = term == 0 && !c.seat_eval_random(cp);
+        c.flags = needs_net ? (c.flags | kFlagLeafNeedsNet) : (c.flags & ~kFlagLeafNeedsNet);
+        if (needs_net) {
+          const uint64_t key = GM::key(leaf);
+          const bool hit = ep.cache_on && c.cache_lookup(key, 0u, reg_pi, reg_v);
+          if (!hit) {
+            cur_key = key; push_b0 = leaf.bb[0]; push_b1 = leaf.bb[1]; push_pl = leaf.player;
+            st = kGrpPush;
+            break;
+          }
+        }
+        // the answer of this leaf is at hand (terminal, RANDOM evaluator, cache hit): the group goes on, a few times - the
+        // wavefront's other groups wait for this pass to end before their answers are looked at
+        if (++inline_sims >= ep.max_inline) break;
+      }
+    }
+    // ---- D: the epoch's simulation count (its quota is what ends it)
+    {
+      uint32_t x = lane == 0 ? iter_sims : 0u;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+      if (wlane == 0 && x) atomicAdd(&pe->sims, static_cast<unsigned long long>(x));
+      const unsigned long long im = __ballot(was_ready && st == kGrpIdle && lane == 0);
+      if (im && wlane == 0) atomicAdd(&pe->waiting, static_cast<uint32_t>(__popcll(im)));
+    }
+    pf_pass += wall_clock64() - pf_t2;
+  }
+
+  if (wlane == 0) {
+    atomicAdd(&pc->prof[0], pf_pass); atomicAdd(&pc->prof[1], pf_idle); atomicAdd(&pc->prof[2], pf_n); atomicAdd(&pc->prof[3], pf_act);
+    atomicAdd(&pc->prof[4], pf_polls); atomicAdd(&pc->prof[5], pf_push); atomicAdd(&pc->prof[6], static_cast<unsigned long long>(wall_clock64() - t_start));
+  }
+  // ---- the slots go back to HBM in the form the lock-step kernels expect (k_sim's exit)
+  if (dirty) {
+    if (lane == 0) {
+      if (sims_done) ar.c_sims[slot] += sims_done;
+      ar.req_seq[slot] = seq;
+    }
+    if (rec_ok) {
+      PathRegs r;
+      r.node = lv_node; r.n = lv_n; r.q = lv_q; r.d = lv_d; r.v = lv_v; r.pp = lv_pp; r.mv = lf_mv; r.leaf_meta = lf_meta;
+      c.store_pend(r);
+      c.flags |= kFlagPendRec;
+    } else {
+      c.flags &= ~kFlagPendRec;
+    }
+    c.store(final_state);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&pe->tree_done, 1u);
+}
+
+// ---- net side -----------------------------------------------------------------------------------------------------------------------
+// A persistent workgroup of the leaf net (leafnet_c4.h: 4 waves, one tile of boards through the whole tower): claim up to six
+// requests, read their granules, build the input planes from the packed positions (connect4_gs.cc:131-149: planes 0 / 1 the
+// stones, plane 2 + player all ones), run the 3- or the 6-board tile, write the (v, pi) granules of every board, again.
+// Leaves when the epoch is over: stop is up, every tree workgroup has left and the ring is empty.
+constexpr uint32_t kPipeXs = 512;      // bytes of claim scratch behind the tile's LDS
+template <class TG>
+__device__ __forceinline__ void pipe_stage_planes(uint8_t* lds, const uint32_t* xs, uint32_t tid) {
+  constexpr int PIX = azmi_net_dev::c4::PIX;
+  float* const raw = reinterpret_cast<float*>(lds + TG::ACT_BYTES + 4 * azmi_net_dev::c4::CHUNK_BYTES);
+  if (tid < static_cast<uint32_t>(TG::TBW * PIX)) {
+    const uint32_t b = tid / PIX, p = tid % PIX;
+    const unsigned long long* xb = reinterpret_cast<const unsigned long long*>(xs + 32);
+    const unsigned long long b0 = xb[b], b1 = xb[8 + b];
+    const uint32_t pl = xs[24 + b];
+    float* rb = raw + b * (4 * PIX);
+    rb[0 * PIX + p] = static_cast<float>((b0 >> p) & 1ull);
+    rb[1 * PIX + p] = static_cast<float>((b1 >> p) & 1ull);
+    rb[2 * PIX + p] = pl == 0u ? 1.0f : 0.0f;
+    rb[3 * PIX + p] = pl == 1u ? 1.0f : 0.0f;
+  }
+}
+
+template <int MODE>     // 0: the 3- and the 6-board tile (by what the claim brought), 1: the 6-board tile only, 2: the 3-board tile only
+__global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, azmi_net_dev::NetPtrs np, PipeArrays pa) {
+  constexpr uint32_t kMaxTake = MODE == 2 ? 3u : 6u;
+  constexpr uint64_t kPatienceTicks = 150;       // 1.5 us: how long a request that is there waits for the rest of its window
+  using namespace azmi_net_dev;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_pipe[];
+  // claim scratch: [0] boards claimed (0 = leave), [1] first ring position; [8..14) slot, [16..22) sequence number,
+  // [24..30) player, then as u64: [0..6) stones of player 0, [8..14) stones of player 1
+  uint32_t* const xs = reinterpret_cast<uint32_t*>(lds_pipe + c4::TileBig::LDS_BYTES);
+  static_assert(c4::TileBig::LDS_BYTES >= c4::TileSmall::LDS_BYTES && 2 * (c4::TileBig::LDS_BYTES + kPipeXs) <= 160 * 1024, "two workgroups per CU");
+  const uint32_t tid = threadIdx.x;
+  const uint64_t t_start = wall_clock64();
+  PipeCtl* const pc = pa.ctl;
+  PipeEpoch* const pe = pa.ep;
+  if (tid == 0) {
+    unsigned long long t0 = atomicCAS(&pe->t0, 0ull, static_cast<unsigned long long>(t_start));
+    if (t0 == 0ull) t0 = t_start;
+    atomicMax(&pe->net_late, static_cast<uint32_t>(t_start > t0 ? t_start - t0 : 0ull));
+    atomicAdd(&pe->net_arrived, 1u);
+  }
+  // The workgroup's WINDOW: kMaxTake consecutive ring positions drawn with ONE fetch-add on `head` (a compare-and-swap claim
+  // of "what is there" serialises every workgroup of the chip on one word: a claim then costs a memory round trip per
+  // contender).  The window's positions are this workgroup's to serve, whenever their requests arrive: it waits until the
+  // rest of the window is there - or, when a request is waiting, for a short patience only -, runs a tile over what
+  // arrived, and draws a new window once this one is used up.  head therefore runs ahead of tail.
+  uint32_t w0 = 0, wn = 0, wdone = 0;        // window start, size, positions served (wave 0 keeps them; uniform)
+  uint64_t pf_wait = 0, pf_tile = 0, pf_mark = wall_clock64();
+  for (;;) {
+    __syncthreads();
+    { const uint64_t nowp = wall_clock64(); pf_tile += nowp - pf_mark; pf_mark = nowp; }
+    if (tid < 64) {        // wave 0 runs the claim; lanes 0..7 look at one ring entry each
+      uint32_t n = 0;
+      uint32_t sl = 0xFFFFFFFFu, sq = 0, pl = 0;
+      unsigned long long b0 = 0, b1 = 0;
+      uint64_t t_first = 0;                  // when the first request of this pass was seen
+      for (;;) {
+        if (wdone == wn) {
+          uint32_t h = 0;
+          if (tid == 0) h = atomicAdd(&pc->head, kMaxTake);
+          w0 = __builtin_amdgcn_readfirstlane(h); wn = kMaxTake; wdone = 0;
+        }
+        const uint32_t left = wn - wdone;
+        bool here = false;
+        if (tid < left) {
+          const uint32_t pos = w0 + wdone + tid;
+          const unsigned long long want = pipe_lap_tag(pos);
+          const unsigned long long* e = pa.ring + static_cast<size_t>(pos & (kPipeRing - 1u)) * kReqGranules;
+          const unsigned long long a0 = g_ld(e), a1 = g_ld(e + 1), a2 = g_ld(e + 2), a3 = g_ld(e + 3);
+          here = (a0 >> 48) == want && (a1 >> 48) == want && (a2 >> 48) == want && (a3 >> 48) == want;
+          if (here) {
+            b0 = a0 & kMask48; b1 = a1 & kMask48;
+            sl = static_cast<uint32_t>(a2 & 0xFFFFull); pl = static_cast<uint32_t>((a2 >> 16) & 1ull);
+            sq = static_cast<uint32_t>(a3);
+          }
+        }
+        const uint32_t hm = static_cast<uint32_t>(__ballot(here)) & 0xFFu;
+        const uint32_t k = static_cast<uint32_t>(__builtin_ctz(~hm));          // arrived prefix of the window's rest
+        const uint64_t now = wall_clock64();
+        if (k == left) { n = k; break; }
+        if (k != 0u) {
+          if (t_first == 0) t_first = now;
+          if (now - t_first > kPatienceTicks) { n = k; break; }
+          continue;
+        }
+        // nothing there: is the epoch over?  stop is up (no tree workgroup that arrives from now on sends anything) and every
+        // tree workgroup that did arrive has left: tail is final, and what lies at or beyond it never comes
+        uint32_t over = 0;
+        if (tid == 0) {
+          if (g_ld(&pc->err)) over = 1;
+          else if (g_ld(&pe->stop) != 0u && g_ld(&pe->tree_done) >= g_ld(&pe->tree_arrived)) {
+            const uint32_t t2 = g_ld(&pc->tail);
+            if (static_cast<int32_t>(t2 - (w0 + wdone)) <= 0) over = 1;
+          }
+          if (!over && now - t_start > pa.cap_ticks + pa.cap_ticks / 4) { atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrNetTimeout)); g_st(&pe->stop, 1u); over = 1; }
+        }
+        if (__builtin_amdgcn_readfirstlane(over)) { n = 0; break; }
+        __builtin_amdgcn_s_sleep(16);
+      }
+      if (tid < 8) {
+        const bool mine = tid < n;
+        xs[8 + tid] = mine ? sl : 0xFFFFFFFFu; xs[16 + tid] = sq; xs[24 + tid] = pl;
+        unsigned long long* xb = reinterpret_cast<unsigned long long*>(xs + 32);
+        xb[tid] = mine ? b0 : 0ull; xb[8 + tid] = mine ? b1 : 0ull;
+      }
+      if (tid == 0) xs[0] = n;
+      wdone += n;
+    }
+    __syncthreads();
+    { const uint64_t nowp = wall_clock64(); pf_wait += nowp - pf_mark; pf_mark = nowp; }
+    const uint32_t n = xs[0];
+    if (n == 0) break;
+    if (tid == 0) { atomicAdd(&pc->tiles, 1ull); atomicAdd(&pc->tile_boards, static_cast<unsigned long long>(n)); }
+    __syncthreads();
+    c4::PipeIO pio{pa.res, xs + 8, xs + 16, kResStride, kResV};
+    // the weight pointers are made opaque per pass: otherwise the tile's loads of its (pass-invariant) head weights are
+    // hoisted out of this loop and sit in ~120 registers for the whole tile (spills)
+    NetPtrs npi = np;
+    asm volatile("" : "+s"(npi.stem_w), "+s"(npi.stem_b), "+s"(npi.blocks), "+s"(npi.head_w), "+s"(npi.head_b), "+s"(npi.v_fc1_w));
+    asm volatile("" : "+s"(npi.v_fc1_b), "+s"(npi.v_fc2_w), "+s"(npi.v_fc2_b), "+s"(npi.pi_fc_w), "+s"(npi.pi_fc_b));
+    if (MODE == 2 || (MODE == 0 && n <= static_cast<uint32_t>(c4::TileSmall::TBW))) {
+      if constexpr (MODE != 1) {
+        pipe_stage_planes<c4::TileSmall>(lds_pipe, xs, tid);
+        c4::tile<c4::TileSmall, 4, 4, 16, 0, true>(nd, npi, nullptr, nullptr, nullptr, c4::TileSmall::TBW, nullptr, nullptr, 0u, lds_pipe, &pio);
+      }
+    } else {
+      if constexpr (MODE != 2) {
+        pipe_stage_planes<c4::TileBig>(lds_pipe, xs, tid);
+        c4::tile<c4::TileBig, 4, 4, 16, 0, true>(nd, npi, nullptr, nullptr, nullptr, c4::TileBig::TBW, nullptr, nullptr, 0u, lds_pipe, &pio);
+      }
+    }
+  }
+  if (tid == 0) { atomicAdd(&pc->prof[7], pf_wait); atomicAdd(&pc->prof[8], pf_tile); }
+}
+
+// (the net kernel's time accounting is added by its thread 0 when it leaves)
+// ---- between epochs -----------------------------------------------------------------------------------------------------------------
+// Requests that were still out when the epoch ended have been answered by now (the net workgroups drain the ring before they
+// leave): their answers move from the granules into the slots' (v, pi) rows - the lock-step form of a pending answer - and
+// into the insert log.
+__global__ void k_pipe_settle(EngineParams ep, EngineArrays ar, PipeArrays pa) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  // the net workgroups left with unused window positions (head ran ahead of tail): the next epoch's windows start at tail
+  if (slot == 0) pa.ctl->head = pa.ctl->tail;
+  if (slot >= ep.S) return;
+  const uint8_t f = ar.flags[slot];
+  if (!(f & kFlagReqOut)) return;
+  const uint32_t seq = ar.req_seq[slot];
+  constexpr int M = Connect4::M, P1 = Connect4::P + 1;
+  float val[M + P1];
+  bool bad = false;
+#pragma unroll
+  for (int i = 0; i < M + P1; ++i) {
+    const unsigned long long g = pa.res[static_cast<size_t>(slot) * kResStride + i];
+    bad = bad || static_cast<uint32_t>(g >> 32) != seq;
+    val[i] = __uint_as_float(static_cast<uint32_t>(g));
+  }
+  if (bad) { atomicOr(&pa.ctl->err, static_cast<uint32_t>(kPipeErrTag)); return; }
+#pragma unroll
+  for (int i = 0; i < M; ++i) ar.pi[static_cast<size_t>(slot) * M + i] = val[i];
+#pragma unroll
+  for (int i = 0; i < P1; ++i) ar.v[static_cast<size_t>(slot) * P1 + i] = val[kResV + i];
+  ar.flags[slot] = f & static_cast<uint8_t>(~kFlagReqOut);
+  if (ep.cache_on) {
+    const uint32_t idx = atomicAdd(&pa.ep->ins_count, 1u);
+    if (idx < pa.ins_cap) {
+      pa.ins_key[idx] = ar.leaf_key[slot];
+#pragma unroll
+      for (int i = 0; i < M; ++i) pa.ins_pi[static_cast<size_t>(idx) * M + i] = val[i];
+#pragma unroll
+      for (int i = 0; i < P1; ++i) pa.ins_v[static_cast<size_t>(idx) * P1 + i] = val[kResV + i];
+    } else {
+      atomicOr(&pa.ctl->err, static_cast<uint32_t>(kPipeErrLog));
+    }
+  }
+}
+
+// The epoch's answers go into the position cache (PlayManager::update_inferences -> insert_many, play_manager.cc:631-640): one
+// wavefront per log entry, under the shard's insert lock (dev_cache.h).  The order of the inserts is the order the
+// wavefronts get there - the reference's is the order its threads get the mutex.
+__global__ __launch_bounds__(256) void k_pipe_cache_insert(EngineArrays ar, PipeArrays pa) {
+  const uint32_t n = min(pa.ep->ins_count, pa.ins_cap);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+  constexpr uint32_t M = Connect4::M, P1 = Connect4::P + 1;
+  for (uint32_t i = wave; i < n; i += waves) {
+    const uint64_t key = pa.ins_key[i];
+    const float p = lane < M ? pa.ins_pi[static_cast<size_t>(i) * M + lane] : 0.0f;
+    const float v = lane < P1 ? pa.ins_v[static_cast<size_t>(i) * P1 + lane] : 0.0f;
+    if (!wave_shard_insert_locked(ar.cache, pa.locks, key, p, v, lane) && lane == 0) atomicOr(&pa.ctl->err, static_cast<uint32_t>(kPipeErrLock));
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------------------
+struct PipeState {
+  PipeArrays pa{};
+  std::vector<void*> allocs;
+  hipStream_t net_stream = nullptr;
+  hipEvent_t ev_go = nullptr, ev_net = nullptr;
+  uint32_t net_wgs = 0, tree_wgs = 0;
+  size_t lds_bytes = 0;
+  bool lds_set = false;
+};
+void pipe_state_free(PipeState* p) {
+  if (!p) return;
+  for (void* q : p->allocs) (void)hipFree(q);
+  if (p->net_stream) (void)hipStreamDestroy(p->net_stream);
+  if (p->ev_go) (void)hipEventDestroy(p->ev_go);
+  if (p->ev_net) (void)hipEventDestroy(p->ev_net);
+  delete p;
+}
+
+}  // namespace azmi
+
+// defined in engine.hip: the move step of a split round as its own launch, and the restart / retire bookkeeping
+int azmi_host_launch_move_step(azmi_pm* pm, hipStream_t st);
+int azmi_host_launch_assign(azmi_pm* pm, hipStream_t st, uint32_t count_round);
+
+namespace {
+
+template <class T>
+int pipe_alloc(PipeState* ps, T*& p, size_t n) {
+  void* q = nullptr;
+  const size_t sz = std::max<size_t>(n, 1) * sizeof(T);
+  AZMI_HIP_TRY(hipMalloc(&q, sz));
+  ps->allocs.push_back(q);
+  AZMI_HIP_TRY(hipMemset(q, 0, sz));
+  p = static_cast<T*>(q);
+  return AZMI_OK;
+}
+
+int pipe_create(azmi_pm* pm, size_t tile_lds) {
+  auto ps = new PipeState();
+  pm->pipe = ps;       // owned by the engine from here on (freed with it, also after a failed set-up)
+  PipeArrays& pa = ps->pa;
+  const uint32_t S = pm->ep.S;
+  int rc = pipe_alloc(ps, pa.ctl, 1);
+  if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.ep, 1);
+  if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.ring, static_cast<size_t>(kPipeRing) * kReqGranules);
+  if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.res, static_cast<size_t>(S) * kResStride);
+  if (rc != AZMI_OK) return rc;
+  ps->tree_wgs = (S * Connect4::GROUP + 255u) / 256u;
+  pa.n_tree_wgs = ps->tree_wgs;
+  ps->lds_bytes = tile_lds + kPipeXs;
+  // The chip holds two 256-thread workgroups of 256 registers per lane on a CU: the tree side takes tree_wgs of those 512
+  // places, the net side what is left (AZMI_PIPE_NET_WGS overrides; a net workgroup that finds no place starts late and
+  // leaves at once, nothing waits for it)
+  hipDeviceProp_t prop;
+  AZMI_HIP_TRY(hipGetDeviceProperties(&prop, pm->device));
+  // workgroups are dealt round-robin to the shader engines (8 CUs = 16 places each) and stay there: a tree workgroup dealt to
+  // an engine that the net side has filled never starts (measured: 4 tree workgroups beside 480 net workgroups all run, beside
+  // 488 they do not; 128 beside 384 do, beside 400 the last net workgroups start when the epoch is over).  So the places
+  // are counted per shader engine.
+  const uint32_t engines = std::max<uint32_t>(1u, static_cast<uint32_t>(prop.multiProcessorCount) / 8u), places = 16u;
+  const uint32_t tree_per_engine = (ps->tree_wgs + engines - 1u) / engines;
+  uint32_t net = engines * (places > tree_per_engine ? places - tree_per_engine : 1u);
+  if (const char* e = getenv("AZMI_PIPE_NET_WGS")) net = static_cast<uint32_t>(atoi(e));
+  ps->net_wgs = std::max<uint32_t>(1u, net);
+  AZMI_HIP_TRY(hipStreamCreateWithFlags(&ps->net_stream, hipStreamNonBlocking));
+  AZMI_HIP_TRY(hipEventCreateWithFlags(&ps->ev_go, hipEventDisableTiming));
+  AZMI_HIP_TRY(hipEventCreateWithFlags(&ps->ev_net, hipEventDisableTiming));
+  return AZMI_OK;
+}
+
+}  // namespace
+
+extern "C" int azmi_net_c4_view_get(const struct azmi_net* net, azmi_net_c4_view* out);
+
+namespace {
+bool pipe_supported(const azmi_pm* pm, const azmi_net* net, azmi_net_c4_view* view) {
+  return pm->game == AZMI_GAME_CONNECT4 && pm->split_rounds && pm->ep.num_groups == 1 && !pm->all_random && pm->ep.S <= kPipeRing / 2u &&
+         azmi_net_c4_view_get(net, view) != 0;
+}
+}  // namespace
+extern "C" int azmi_pipeline_supported(azmi_pm* pm, azmi_net* net) {
+  azmi_net_c4_view view;
+  return pm && net && pipe_supported(pm, net, &view) ? 1 : 0;
+}
+
+extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, uint64_t sims_per_epoch, void* stream, uint64_t* out_stats) {
+  if (!pm || !net) return azmi_host_fail(AZMI_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
+  azmi_net_c4_view view;
+  if (!pipe_supported(pm, net, &view))
+    return azmi_host_fail(AZMI_ERR_STATE, "azmi_run_pipeline: the pipeline drives the Connect4 engine with plain PUCT seats, one model group and a bf16 "
+                          "Connect4-family net, at most %u concurrent games (azmi_pipeline_supported); use azmi_run_rounds for everything else", kPipeRing / 2u);
+  if (sims_per_epoch == 0) return azmi_host_fail(AZMI_ERR_INVALID, "azmi_run_pipeline: sims_per_epoch must be > 0");
+  AZMI_HIP_TRY(hipSetDevice(pm->device));
+  hipStream_t st = pm->pick(stream);
+  if (!pm->pipe) {
+    const int rc = pipe_create(pm, view.lds_bytes > azmi_net_dev::c4::TileBig::LDS_BYTES ? view.lds_bytes : azmi_net_dev::c4::TileBig::LDS_BYTES);
+    if (rc != AZMI_OK) return rc;
+  }
+  PipeState* ps = pm->pipe;
+  PipeArrays& pa = ps->pa;
+  if (!ps->lds_set) {
+    AZMI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_net<0>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ps->lds_bytes)));
+    AZMI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_net<1>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ps->lds_bytes)));
+    AZMI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_net<2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ps->lds_bytes)));
+    ps->lds_set = true;
+  }
+  // the insert log holds an epoch's answers: at most one per simulation, in practice a third of them
+  const uint64_t want_log = pm->ep.cache_on ? std::min<uint64_t>(sims_per_epoch + pm->ep.S, 1ull << 24) : 0ull;
+  if (want_log > pa.ins_cap) {
+    PipeState* p = ps;
+    int rc = pipe_alloc(p, pa.ins_key, want_log);
+    if (rc == AZMI_OK) rc = pipe_alloc(p, pa.ins_pi, want_log * Connect4::M);
+    if (rc == AZMI_OK) rc = pipe_alloc(p, pa.ins_v, want_log * (Connect4::P + 1));
+    if (rc != AZMI_OK) return rc;
+    pa.ins_cap = static_cast<uint32_t>(want_log);
+  }
+  if (pm->ep.cache_on && !pa.locks) {
+    const int rc = pipe_alloc(ps, pa.locks, pm->ar.cache.shards);
+    if (rc != AZMI_OK) return rc;
+  }
+  pa.quota = sims_per_epoch;
+  // an epoch also ends when this share of the slots waits for the move step (all of them: the start of a run)
+  double idle_frac = 0.125;
+  if (const char* e = getenv("AZMI_PIPE_IDLE_FRAC")) idle_frac = atof(e);
+  pa.idle_num = std::max<uint32_t>(1u, std::min<uint32_t>(1024u, static_cast<uint32_t>(idle_frac * 1024.0)));
+  double cap_ms = 250.0;
+  if (const char* e = getenv("AZMI_PIPE_CAP_MS")) cap_ms = atof(e);
+  pa.cap_ticks = static_cast<unsigned long long>(cap_ms * 1e5);
+  // the lock-step kernels leave the key of a round's leaf in cache_keys for the next round's insert: none of that here
+  if (pm->ep.cache_on) AZMI_HIP_TRY(hipMemsetAsync(pm->ar.cache_keys, 0, sizeof(uint64_t) * pm->ep.S, st));
+  int rc = azmi_host_launch_assign(pm, st, 1u);
+  if (rc != AZMI_OK) return rc;
+  const uint32_t settle_blocks = (pm->ep.S + 255u) / 256u;
+  const int net_mode = getenv("AZMI_PIPE_TILE") ? atoi(getenv("AZMI_PIPE_TILE")) : 1;
+  for (uint32_t e = 0; e < epochs; ++e) {
+    AZMI_HIP_TRY(hipMemsetAsync(pa.ep, 0, sizeof(PipeEpoch), st));
+    AZMI_HIP_TRY(hipEventRecord(ps->ev_go, st));
+    AZMI_HIP_TRY(hipStreamWaitEvent(ps->net_stream, ps->ev_go, 0));
+    if (net_mode == 1) k_pipe_net<1><<<ps->net_wgs, 256, ps->lds_bytes, ps->net_stream>>>(view.nd, view.np, pa);
+    else if (net_mode == 2) k_pipe_net<2><<<ps->net_wgs, 256, ps->lds_bytes, ps->net_stream>>>(view.nd, view.np, pa);
+    else k_pipe_net<0><<<ps->net_wgs, 256, ps->lds_bytes, ps->net_stream>>>(view.nd, view.np, pa);
+    AZMI_HIP_TRY(hipGetLastError());
+    k_pipe_tree<Connect4><<<ps->tree_wgs, 256, 0, st>>>(pm->ep, pm->ar, pa);
+    AZMI_HIP_TRY(hipGetLastError());
+    AZMI_HIP_TRY(hipEventRecord(ps->ev_net, ps->net_stream));
+    AZMI_HIP_TRY(hipStreamWaitEvent(st, ps->ev_net, 0));
+    k_pipe_settle<<<settle_blocks, 256, 0, st>>>(pm->ep, pm->ar, pa);
+    AZMI_HIP_TRY(hipGetLastError());
+    rc = azmi_host_launch_move_step(pm, st);
+    if (rc != AZMI_OK) return rc;
+    rc = azmi_host_launch_assign(pm, st, 1u);
+    if (rc != AZMI_OK) return rc;
+    if (pm->ep.cache_on) {
+      k_pipe_cache_insert<<<1024, 256, 0, st>>>(pm->ar, pa);
+      AZMI_HIP_TRY(hipGetLastError());
+    }
+  }
+  // the run is synchronous: a pipeline error (a spin that hit its time cap, a tag that did not match) must not go unseen
+  PipeCtl hc;
+  PipeEpoch he;
+  AZMI_HIP_TRY(hipMemcpyAsync(&hc, pa.ctl, sizeof(hc), hipMemcpyDeviceToHost, st));
+  AZMI_HIP_TRY(hipMemcpyAsync(&he, pa.ep, sizeof(he), hipMemcpyDeviceToHost, st));
+  AZMI_HIP_TRY(hipStreamSynchronize(st));
+  if (out_stats) {
+    out_stats[0] = hc.tiles; out_stats[1] = hc.tile_boards; out_stats[2] = he.sims; out_stats[3] = he.tree_arrived;
+    out_stats[4] = he.net_arrived; out_stats[5] = he.ins_count; out_stats[6] = ps->net_wgs; out_stats[7] = ps->tree_wgs;
+    out_stats[8] = he.tree_late / 100u; out_stats[9] = he.net_late / 100u;
+    if (getenv("AZMI_PIPE_PROF")) {
+      fprintf(stderr, "pipe prof:");
+      for (int i = 0; i < 9; ++i) fprintf(stderr, " %llu", hc.prof[i]);
+      fprintf(stderr, "\n");
+    }
+  }
+  if (hc.err) {
+    fprintf(stderr, "pipeline dbg:");
+    for (int i = 0; i < 24; ++i) fprintf(stderr, " %u", hc.dbg[i]);
+    fprintf(stderr, "\n");
+  }
+  if (hc.err)
+    return azmi_host_fail(AZMI_ERR_STATE, "pipeline error mask 0x%x (1 a spin hit the epoch's time cap, 2 a ring entry never arrived, 4 a result tag "
+                          "did not match, 8 insert log full, 16 cache lock, 32 slots); census: %u of %u tree and %u of %u net workgroups started; "
+                          "last epoch: head %u tail %u sims %llu waiting %u dead %u stop %u tree_done %u tiles %llu boards %llu; latest tree / net workgroup start %u / %u us",
+                          hc.err, he.tree_arrived, ps->tree_wgs, he.net_arrived, ps->net_wgs, hc.head, hc.tail, he.sims, he.waiting, he.dead, he.stop,
+                          he.tree_done, hc.tiles, hc.tile_boards, he.tree_late / 100u, he.net_late / 100u);
+  if (hc.err && getenv("AZMI_PIPE_DEBUG")) {
+    fprintf(stderr, "pipeline dbg:");
+    for (int i = 0; i < 24; ++i) fprintf(stderr, " %u", hc.dbg[i]);
+    fprintf(stderr, "\n");
+  }
+  return AZMI_OK;
+}
+
+// ---- diagnostics: the net side alone -----------------------------------------------------------------------------------------
+namespace azmi {
+__global__ void k_pipe_fill(PipeArrays pa, uint32_t n, uint32_t S, uint64_t seed) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) { pa.ep->stop = 1u; }
+  if (i >= n) return;
+  const uint32_t pos = pa.ctl->tail + i;
+  // a random legal-looking position: stones dropped column by column
+  uint64_t x = mix64(seed + i);
+  uint64_t b0 = 0, b1 = 0;
+  uint32_t player = 0;
+  for (uint32_t w = 0; w < 7; ++w) {
+    const uint32_t hgt = static_cast<uint32_t>(x % 5u); x = mix64(x);
+    for (uint32_t j = 0; j < hgt; ++j) {
+      const uint64_t bit = 1ull << ((5u - j) * 7u + w);
+      if (x & 1ull) b0 |= bit; else b1 |= bit;
+      x >>= 1; player ^= 1u;
+    }
+  }
+  unsigned long long* e = pa.ring + static_cast<size_t>(pos & (kPipeRing - 1u)) * kReqGranules;
+  const unsigned long long tag = pipe_lap_tag(pos) << 48;
+  e[0] = tag | b0; e[1] = tag | b1; e[2] = tag | (i % S) | (static_cast<unsigned long long>(player & 1u) << 16); e[3] = tag | (i + 1u);
+}
+__global__ void k_pipe_fill_done(PipeArrays pa, uint32_t n) { pa.ctl->tail += n; }
+}  // namespace azmi
+
+// Fills the request ring with `n` synthetic positions (n <= the ring) and lets the persistent net kernel alone drain it, `reps`
+// times; ms_out = average milliseconds per drain (HIP events).  mode: the tile selection of k_pipe_net (0 both, 1 six-board, 2
+// three-board).  Timing only: the slots' result granules are overwritten.
+extern "C" int azmi_debug_pipe_net_bench(azmi_pm* pm, azmi_net* net, uint32_t n, uint32_t reps, uint32_t net_wgs, int mode, float* ms_out) {
+  if (!pm || !net || !ms_out) return azmi_host_fail(AZMI_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
+  azmi_net_c4_view view;
+  if (!pipe_supported(pm, net, &view)) return azmi_host_fail(AZMI_ERR_STATE, "not a pipeline engine");
+  if (n > kPipeRing) return azmi_host_fail(AZMI_ERR_INVALID, "at most %u requests", kPipeRing);
+  AZMI_HIP_TRY(hipSetDevice(pm->device));
+  if (!pm->pipe) { const int rc = pipe_create(pm, azmi_net_dev::c4::TileBig::LDS_BYTES); if (rc != AZMI_OK) return rc; }
+  PipeState* ps = pm->pipe;
+  PipeArrays& pa = ps->pa;
+  if (!ps->lds_set) {
+    AZMI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_net<0>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ps->lds_bytes)));
+    AZMI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_net<1>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ps->lds_bytes)));
+    AZMI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_net<2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ps->lds_bytes)));
+    ps->lds_set = true;
+  }
+  pa.cap_ticks = 25000000ull;
+  hipStream_t st = pm->stream;
+  hipEvent_t e0, e1;
+  AZMI_HIP_TRY(hipEventCreate(&e0)); AZMI_HIP_TRY(hipEventCreate(&e1));
+  float total = 0.0f;
+  const uint32_t wgs = net_wgs ? net_wgs : ps->net_wgs;
+  for (uint32_t r = 0; r < reps + 1; ++r) {
+    AZMI_HIP_TRY(hipMemsetAsync(pa.ep, 0, sizeof(PipeEpoch), st));
+    k_pipe_fill<<<(n + 255) / 256, 256, 0, st>>>(pa, n, pm->ep.S, 1234 + r);
+    k_pipe_fill_done<<<1, 1, 0, st>>>(pa, n);
+    AZMI_HIP_TRY(hipEventRecord(e0, st));
+    if (mode == 1) k_pipe_net<1><<<wgs, 256, ps->lds_bytes, st>>>(view.nd, view.np, pa);
+    else if (mode == 2) k_pipe_net<2><<<wgs, 256, ps->lds_bytes, st>>>(view.nd, view.np, pa);
+    else k_pipe_net<0><<<wgs, 256, ps->lds_bytes, st>>>(view.nd, view.np, pa);
+    AZMI_HIP_TRY(hipEventRecord(e1, st));
+    k_pipe_settle<<<1, 64, 0, st>>>(pm->ep, pm->ar, pa);      // (head = tail for the next drain; no slot has a request out)
+    AZMI_HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0.0f;
+    AZMI_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (r > 0) total += ms;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *ms_out = total / static_cast<float>(reps);
+  PipeCtl hc;
+  AZMI_HIP_TRY(hipMemcpy(&hc, pa.ctl, sizeof(hc), hipMemcpyDeviceToHost));
+  if (hc.err) return azmi_host_fail(AZMI_ERR_STATE, "pipeline error mask 0x%x in the net drain", hc.err);
+  return AZMI_OK;
+}

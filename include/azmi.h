@@ -424,6 +424,26 @@ const char* azmi_cache_last_error(void);
  *      cores, another engine's tree kernel runs on the CUs the net leaves free.  Launch-only
  *      (asynchronous); poll with azmi_pm_poll. */
 int azmi_run_rounds(azmi_pm* const* pms, azmi_net* net, uint32_t k, uint32_t rounds, void* const* streams);
+/* ---- asynchronous tree / net pipeline (Connect4 engine, plain PUCT seats, one model group, bf16 Connect4-family net): what
+ *      azmi_run_rounds does, without its lock step.  The reference's worker loop has no global barrier - every game advances
+ *      on its own through the queues between PlayManager::play's workers and GameRunner's batcher threads
+ *      (play_manager.cc:258-600, concurrent_queue.h:130-217, game_runner.py:483-552) - and neither has this: for one EPOCH
+ *      persistent tree wavefronts simulate their slots and hand the leaves that need the net to persistent net workgroups
+ *      (request ring / tagged result granules in HBM, csrc/pipe_types.h); an epoch ends after `sims_per_epoch` simulations
+ *      (or when an eighth of the slots waits for a move), then the moves, game ends and restarts of the epoch and the
+ *      position-cache inserts of its answers run at a kernel boundary.  `epochs` epochs, synchronous (returns when they are
+ *      done; a pipeline error is reported here).  The games are those of azmi_run_rounds for the same seeds.
+ *      out_stats (may be NULL): [0] net tiles run since the pipeline was created, [1] boards in them, [2] simulations of the
+ *      last epoch, [3] / [4] tree / net workgroups that started in it, [5] its insert-log entries, [6] / [7] net / tree
+ *      workgroups launched, [8] / [9] the latest start of a tree / net workgroup after the epoch's first, in microseconds (all
+ *      of them must be on the chip together: a late one found its place only when another left); 16 entries. */
+int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, uint64_t sims_per_epoch, void* stream, uint64_t* out_stats);
+/* diagnostics: the pipeline's persistent net kernel alone, draining `n` synthetic requests (n <= 8192) `reps` times with
+ * `net_wgs` workgroups (0 = the pipeline's own count) and tile selection `mode` (0 = 3- and 6-board tiles, 1 = 6-board, 2 =
+ * 3-board); *ms_out = milliseconds per drain.  Timing only (scripts/pipe_net_timing.py -> profiles/). */
+int azmi_debug_pipe_net_bench(azmi_pm* pm, azmi_net* net, uint32_t n, uint32_t reps, uint32_t net_wgs, int mode, float* ms_out);
+/* 1 when azmi_run_pipeline can drive this engine with this net, 0 otherwise (then azmi_run_rounds is the driver) */
+int azmi_pipeline_supported(azmi_pm* pm, azmi_net* net);
 /* the same loop with one net per MODEL GROUP (gating / benchmark matches between two models, game_runner.py:2184-2332):
  * nets[g] evaluates the leaves of group g, NULL = the group needs no net (RANDOM / PLAYOUT evaluator) */
 int azmi_run_rounds_groups(azmi_pm* const* pms, azmi_net* const* nets, uint32_t num_nets, uint32_t k, uint32_t rounds, void* const* streams);

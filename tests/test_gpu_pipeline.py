@@ -1,0 +1,151 @@
+"""-m gpu: the asynchronous tree / net pipeline (azmi_run_pipeline, csrc/pipeline.hip) plays the games of the lock-step engine and
+of the oracle.  A slot's game is a function of its seed alone: the answer to a position does not depend on when, where or in
+which tile the net evaluates it, so persistent tree wavefronts + persistent net workgroups (request ring, tagged result granules,
+moves and cache inserts between epochs) must reproduce, move for move / visit count for visit count / pcg32 position for pcg32
+position, what azmi_run_rounds plays and what the ORACLE PlayManager plays when its evaluator sends each leaf through the same
+HIP net (tier T3).  Reference: PlayManager::play (play_manager.cc:258-600), which has no global barrier either."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_t3_nn_in_the_loop import _check_slots, _net_eval, _selfplay_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _pipeline_games(az, pp, seed, hip, sims_per_epoch, max_epochs=4000, env=None):
+    pm = az.PlayManager(az.Connect4GS(), pp, seed=seed, log_moves=True)
+    assert az.pipeline_supported(pm, hip)
+    st = torch.cuda.Stream()
+    stats, epochs = None, 0
+    while pm.remaining_games() > 0 and epochs < max_epochs:
+        stats = az.run_pipeline(pm, hip, 4, sims_per_epoch, st.cuda_stream)
+        epochs += 4
+        if pm.poll(st.cuda_stream)[1] == 0:
+            break
+    torch.cuda.synchronize()
+    return pm, pm.move_log(), stats
+
+
+def _lockstep_games(az, pp, seed, hip):
+    pm = az.PlayManager(az.Connect4GS(), pp, seed=seed, log_moves=True)
+    st = torch.cuda.Stream()
+    while pm.remaining_games() > 0:
+        az.run_rounds([pm], hip, 64, [st.cuda_stream])
+        if pm.poll(st.cuda_stream)[1] == 0:
+            break
+    torch.cuda.synchronize()
+    return pm, pm.move_log()
+
+
+def _sorted_log(rows, counts):
+    order = np.lexsort((rows[:, 2], rows[:, 1], rows[:, 0]))          # by slot, game in slot, turn
+    return rows[order], counts[order]
+
+
+def _history_multiset(pm):
+    c, v, p = pm.history()
+    rows = np.concatenate([c.reshape(len(c), -1), v, p], 1)
+    return rows[np.lexsort(rows.T[::-1])]
+
+
+@pytest.mark.parametrize("cache", [0, 1 << 16])
+def test_pipeline_plays_the_lockstep_engines_games(cache):
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=21), spec)
+    S, seed = 128, 9001
+    pp = _selfplay_params(az, S, 100, cache=cache)
+    pa, (ra, ca), stats = _pipeline_games(az, pp, seed, hip, sims_per_epoch=S * 40)
+    pb, (rb, cb) = _lockstep_games(az, pp, seed, hip)
+    assert pa.games_completed() == pb.games_completed() == S
+    ra, ca = _sorted_log(ra, ca)
+    rb, cb = _sorted_log(rb, cb)
+    assert ra.shape == rb.shape and len(ra) > 8 * S
+    assert np.array_equal(ra, rb), "moves / pcg32 positions differ between the pipeline and the lock-step engine"
+    assert np.array_equal(ca, cb), "visit counts differ"
+    assert np.array_equal(pa.scores(), pb.scores())
+    assert np.array_equal(_history_multiset(pa), _history_multiset(pb)), "sample rows differ"
+    xa, xb = pa.counters(), pb.counters()
+    assert xa["sims"] == xb["sims"]
+    assert stats["tiles"] > 0 and stats["tile_boards"] >= stats["tiles"]
+    assert stats["tree_wgs_started"] == stats["tree_wgs"]
+    if cache:
+        assert xa["cache_hits"] > 0 and xa["evals"] < xa["sims"]
+    else:
+        assert xa["evals"] == xb["evals"]         # without a cache every non-terminal leaf goes to the net on both paths
+
+
+def test_pipeline_equals_the_oracle_driven_by_the_same_net(oracle):
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=11), spec)
+    S, seed = 96, 4242
+    pp = _selfplay_params(az, S, 120, cache=1 << 16)
+    pm, (rows, counts), _ = _pipeline_games(az, pp, seed, hip, sims_per_epoch=S * 64)
+    assert pm.games_completed() == S
+    n = _check_slots(az, oracle, oracle.GAME_CONNECT4, pp, seed, rows, counts, (0, 1, 17, 40, 95), evaluator=_net_eval(hip))
+    assert n > 40
+
+
+def test_pipeline_with_playout_cap_resign_and_restarts(oracle):
+    """playout-cap randomisation, resignation with play-through and a game stream longer than the slots (restarts between
+    epochs): the first game of sampled slots equals the oracle's, the stream completes."""
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=12), spec)
+    S, seed = 48, 77
+    pp = _selfplay_params(az, S, 80, cache=1 << 14)
+    pp.games_to_play = 3 * S
+    pp.playout_cap_randomization, pp.playout_cap_depth, pp.playout_cap_percent = True, 12, 0.5
+    pp.resign_percent, pp.resign_playthrough_percent = 0.05, 0.2
+    pm, (rows, counts), _ = _pipeline_games(az, pp, seed, hip, sims_per_epoch=S * 32)
+    assert pm.games_completed() == 3 * S
+    _check_slots(az, oracle, oracle.GAME_CONNECT4, pp, seed, rows, counts, (0, 7, 47), evaluator=_net_eval(hip))
+
+
+def test_pipeline_and_lockstep_rounds_interleave_on_one_engine():
+    """epochs of the pipeline and rounds of the lock-step driver alternate on ONE engine: between epochs a slot is in the
+    lock-step kernels' own form (pending answers in the (v, pi) rows), so the games are still the games of either driver."""
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=5), spec)
+    S, seed = 64, 31337
+    pp = _selfplay_params(az, S, 64, cache=1 << 14)
+    pm = az.PlayManager(az.Connect4GS(), pp, seed=seed, log_moves=True)
+    st = torch.cuda.Stream()
+    turn = 0
+    while pm.remaining_games() > 0 and turn < 5000:
+        if turn % 2 == 0:
+            az.run_pipeline(pm, hip, 2, S * 16, st.cuda_stream)
+        else:
+            az.run_rounds([pm], hip, 5, [st.cuda_stream])
+        turn += 1
+        if pm.poll(st.cuda_stream)[1] == 0:
+            break
+    torch.cuda.synchronize()
+    assert pm.games_completed() == S
+    ra, ca = _sorted_log(*pm.move_log())
+    pb, (rb, cb) = _lockstep_games(az, pp, seed, hip)
+    rb, cb = _sorted_log(rb, cb)
+    assert np.array_equal(ra, rb) and np.array_equal(ca, cb)
+
+
+def test_pipeline_rejects_what_it_does_not_drive():
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=1), spec)
+    pp = _selfplay_params(az, 8, 16, cache=0)
+    pp.gumbel_enabled = True
+    pm = az.PlayManager(az.Connect4GS(), pp, seed=1)
+    assert not az.pipeline_supported(pm, hip)
+    with pytest.raises(RuntimeError, match="pipeline"):
+        az.run_pipeline(pm, hip, 1, 100)
+    pp2 = _selfplay_params(az, 4, 8, cache=0)
+    tw = az.PlayManager(az.TawlbwrddGS(), pp2, seed=1)
+    assert not az.pipeline_supported(tw, hip)
