@@ -331,9 +331,17 @@ using WaveShard = WaveShardT<false>;
 // that re-reads the key after the payload (wave_shard_find's validated form) never returns a torn row.
 // p_lane / v_lane: entry `lane` of the policy / value row (np, nv <= 64).  Returns false when the lock could not be had
 // within `spin_cap` tries (the caller raises an error; nothing was changed).
+// PROBE_SAFE = false: no probe runs while the inserts do (a kernel of inserts between two epochs): the slot's key and payload
+// go out together, one wait.  Either way an entry that is already there is recognised before the lock is taken (most repeated
+// positions - a whole batch of identical openings - never touch it).
+template <bool PROBE_SAFE = true>
 __device__ inline bool wave_shard_insert_locked(const CacheView& c, uint32_t* locks, uint64_t hash, float p_lane, float v_lane,
                                                 uint32_t lane, uint32_t spin_cap = 1u << 20) {
   const uint32_t sh = static_cast<uint32_t>(hash % c.shards);
+  {
+    const uint64_t have = c_ld<true>(c.hashes + static_cast<size_t>(sh) * kWaveCap + lane);
+    if (__ballot(have == cache_key(hash)) != 0ull) return true;
+  }
   uint32_t got = 0;
   if (lane == 0) {
     for (uint32_t spins = 0; spins < spin_cap; ++spins) {
@@ -351,11 +359,13 @@ __device__ inline bool wave_shard_insert_locked(const CacheView& c, uint32_t* lo
     const int slot = ws.insert(hash);
     if (slot >= 0) {
       const size_t e = static_cast<size_t>(sh) * kWaveCap + slot;
-      if (lane == 0) c_st<true>(c.hashes + e, 0ull);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (PROBE_SAFE) {
+        if (lane == 0) c_st<true>(c.hashes + e, 0ull);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       if (lane < c.np) c_st<true>(reinterpret_cast<uint32_t*>(c.policy) + e * c.np + lane, __float_as_uint(p_lane));
       if (lane < c.nv) c_st<true>(reinterpret_cast<uint32_t*>(c.value) + e * c.nv + lane, __float_as_uint(v_lane));
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (PROBE_SAFE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       ws.store();
     }
   }

@@ -35,6 +35,8 @@ __host__ __device__ inline uint64_t pipe_lap_tag(uint32_t pos) { return static_c
 struct PipeCtl {          // zeroed when the pipeline is created; lives across epochs.  Every hot word on a 128-byte line of its own
   uint32_t head; uint32_t pad0[31];             // ring entries claimed by net workgroups (free-running: position = value % kPipeRing)
   uint32_t tail; uint32_t pad1[31];             // ring tickets handed out to tree wavefronts (free-running)
+  uint32_t rhead; uint32_t pad4[31];            // READY-ring positions drawn by tree wavefronts (free-running, runs ahead of rtail)
+  uint32_t rtail; uint32_t pad5[31];            // READY-ring tickets handed out (seed kernel, net workgroups, tree wavefronts)
   uint32_t err;           // PipeErr bits, sticky: every pipeline kernel leaves at once when it is set
   uint32_t pad2;
   unsigned long long tiles;         // net tiles run
@@ -46,7 +48,7 @@ struct PipeCtl {          // zeroed when the pipeline is created; lives across e
   // waiting for requests, [8] net: ticks in tiles
   unsigned long long prof[16];
 };
-static_assert(sizeof(PipeCtl) == 512, "four lines");
+static_assert(sizeof(PipeCtl) == 768, "six lines");
 
 struct PipeEpoch {        // an allocation of its own, zeroed before every epoch (one memset)
   unsigned long long sims; uint32_t pad0[30];   // simulations finished in this epoch
@@ -66,6 +68,7 @@ struct PipeArrays {
   PipeCtl* ctl;
   PipeEpoch* ep;
   unsigned long long* ring;   // [kPipeRing][kReqGranules]
+  unsigned long long* rring;  // [kPipeRing] READY ring: {tag16 | slot}
   unsigned long long* res;    // [S][kResStride]
   // insert log: (key, pi, v) of every answer consumed in the epoch; applied to the position cache between epochs
   uint64_t* ins_key;          // [ins_cap]

@@ -34,22 +34,62 @@ enum : uint32_t { kGrpIdle = 0, kGrpReady = 1, kGrpWait = 2, kGrpPush = 3 };
 constexpr uint64_t kMask48 = (1ull << 48) - 1;
 
 // ---- tree side ---------------------------------------------------------------------------------------------------------------------
-// One 8-lane group per slot, 8 slots per wavefront, for the whole epoch.  A group is
-//   READY  its pending simulation has its answer (in the slot's (v, pi) rows and in registers): back it up, descend again
-//   PUSH   the new leaf needs the net: it gets a ring ticket at the top of the wavefront's next pass
-//   WAIT   the request is out: the group polls its result granules
-//   IDLE   nothing to do here any more this epoch (the slot's next step is a move / a game start: listed for the move step)
-// The body of a pass is k_sim's (engine_kernels.h): the pending simulation's path in registers, level i in lane i.
-template <class GM>
-__global__ __launch_bounds__(256, 2) void k_pipe_tree(EngineParams ep, EngineArrays ar, PipeArrays pa) {
+// A slot is not tied to a wavefront: every slot that can take its next step sits, as a token, in the READY ring (seeded by
+// k_pipe_seed when the epoch starts, refilled by the net workgroups with the slots they have answered and by the tree
+// wavefronts with slots whose next answer is already at hand).  A tree wavefront works in PASSES: draw eight tokens (a window of
+// ring positions, one fetch-add), load the eight slots - one 8-lane group each -, back the pending simulations up and descend
+// again until each group's new leaf needs the net (k_sim's body, engine_kernels.h: the path in registers, level i in lane i),
+// store the slots, hand the leaves to the request ring.  Every group of a pass has work, which is what keeps the 64 lanes busy:
+// with slots bound to wavefronts 3.3 of 8 groups had an answer when a pass started.
+// A slot's state and its trees move between CUs from pass to pass: a pass starts with an agent-scope acquire (this CU's L1 holds
+// nothing stale) and ends, before its tokens go out, with an agent-scope release.
+constexpr uint32_t kTreeWindow = 8;
+constexpr uint64_t kTreePatience = 100;       // ticks (1 us) a wavefront that holds some tokens waits for the rest of its window
+
+// The epoch's first tokens: one thread per slot.  A slot whose leaf was left by the move step (kSlotQueued) sends its request, a
+// slot with its answer in the (v, pi) rows goes to the READY ring, a slot whose game has to start goes to the move step's list.
+__global__ void k_pipe_seed(EngineParams ep, EngineArrays ar, PipeArrays pa) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= ep.S) return;
+  PipeCtl* const pc = pa.ctl;
+  PipeEpoch* const pe = pa.ep;
+  if (ar.ctl->stop != 0 || pc->err != 0) { atomicAdd(&pe->dead, 1u); return; }
+  const uint8_t sst = ar.sstate[slot];
+  if (sst == kSlotDone || sst == kSlotEnded) { atomicAdd(&pe->dead, 1u); return; }
+  if (sst != kSlotWaitEval && sst != kSlotQueued) {       // kSlotFresh / kSlotRestart: a game start
+    ar.mover_list[atomicAdd(&ar.ctl->mover_count, 1u)] = slot;
+    atomicAdd(&pe->waiting, 1u);
+    return;
+  }
+  const uint8_t f = ar.flags[slot];
+  if (f & kFlagReqOut) { atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTag)); return; }      // (every request was settled)
+  if (sst == kSlotQueued) {
+    const uint32_t pos = atomicAdd(&pc->tail, 1u);
+    uint32_t seq = ar.req_seq[slot] + 1u;
+    if (seq == 0u) seq = 1u;
+    ar.req_seq[slot] = seq;
+    const unsigned long long tag = pipe_lap_tag(pos) << 48;
+    unsigned long long* e = pa.ring + static_cast<size_t>(pos & (kPipeRing - 1u)) * kReqGranules;
+    g_st(e + 0, tag | (ar.leaf_pos[0 * static_cast<size_t>(ep.S) + slot] & kMask48));
+    g_st(e + 1, tag | (ar.leaf_pos[1 * static_cast<size_t>(ep.S) + slot] & kMask48));
+    g_st(e + 2, tag | static_cast<unsigned long long>(slot) | ((ar.leaf_pos[2 * static_cast<size_t>(ep.S) + slot] & 1ull) << 16));
+    g_st(e + 3, tag | static_cast<unsigned long long>(seq));
+    ar.flags[slot] = f | kFlagReqOut;
+    ar.sstate[slot] = kSlotWaitEval;
+    return;
+  }
+  const uint32_t pos = atomicAdd(&pc->rtail, 1u);
+  g_st(pa.rring + (pos & (kPipeRing - 1u)), (pipe_lap_tag(pos) << 48) | static_cast<unsigned long long>(slot));
+}
+
+// NT: threads per workgroup.  512 = eight wavefronts of 256 registers: the workgroup has a CU to itself, so no tree wavefront
+// shares its SIMD's issue port with a net wavefront's matrix stream (256-thread tree workgroups sit beside a net workgroup)
+template <class GM, int NT>
+__global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArrays ar, PipeArrays pa) {
   constexpr int G = GM::GROUP;
   constexpr int P = GM::P;
   static_assert(P == 2 && G == 8 && GM::M == 7, "written for Connect4's 8-lane groups");
-  const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t slot_raw = gtid / G, lane = gtid % G;
-  const uint32_t wlane = threadIdx.x & 63u, grp = wlane >> 3;
-  const bool in_range = slot_raw < ep.S;
-  const uint32_t slot = in_range ? slot_raw : 0u;
+  const uint32_t wlane = threadIdx.x & 63u, grp = wlane >> 3, lane = wlane & 7u;
   const uint64_t t_start = wall_clock64();
   PipeCtl* const pc = pa.ctl;
   PipeEpoch* const pe = pa.ep;
@@ -63,168 +103,161 @@ __global__ __launch_bounds__(256, 2) void k_pipe_tree(EngineParams ep, EngineArr
     asm volatile("s_waitcnt vmcnt(0)" :: "v"(before) : "memory");
   }
   __syncthreads();
+  bool go = ar.ctl->stop == 0 && g_ld(&pc->err) == 0 && g_ld(&pe->stop) == 0;
+  uint32_t w0 = 0, wn = 0, wdone = 0;        // the wavefront's window of READY-ring positions: start, size, positions used
+  uint64_t pf_pass = 0, pf_idle = 0, pf_n = 0, pf_act = 0, pf_polls = 0, pf_io = 0, pf_lvls = 0;
+  uint64_t pf_ph[5] = {0, 0, 0, 0, 0};     // per group (lane 0 counts): ticks in backup / descent / expansion / probe, simulations
+  SlotCtx<GM> c(ep, ar, 0u, lane);
 
-  uint32_t st = kGrpIdle;
-  bool dirty = false;                      // the slot's state changed here: stored on the way out
-  uint8_t final_state = kSlotWaitEval;
-  bool live = in_range && ar.ctl->stop == 0 && g_ld(&pc->err) == 0 && g_ld(&pe->stop) == 0;
-  uint8_t sst = kSlotDone;
-  if (live) { sst = ar.sstate[slot]; live = sst != kSlotDone && sst != kSlotEnded; }
-  auto defer = [&]() { if (lane == 0) ar.mover_list[atomicAdd(&ar.ctl->mover_count, 1u)] = slot; };
-  if (live && sst != kSlotWaitEval && sst != kSlotQueued) { defer(); live = false; }     // kSlotFresh / kSlotRestart: a game start
-  SlotCtx<GM> c(ep, ar, slot, lane);
-  uint32_t cp = 0, root = 0, goal = 0, seq = 0;
-  size_t tb = 0;
-  float fpu_root = 0.0f;
-  uint32_t* const path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
-  float reg_pi = 0.0f, reg_v = 0.0f;
-  uint32_t root_n = 0; float root_v = 0.0f; uint64_t root_meta = 0;
-  uint32_t lv_node = 0, lv_n = 0, lv_pp = 0;
-  float lv_q = 0.0f, lv_d = 0.0f, lv_v = 0.0f;
-  uint64_t lf_meta = 0;
-  uint32_t lf_mv = 0, lf_c0 = 0, lf_k = 0, lf_term = 0, lf_player = 0;
-  bool fw = false;
-  uint32_t fw_node = 0, fw_n = 0, fw_plen = 0;
-  float fw_q = 0.0f, fw_d = 0.0f, fw_v = 0.0f;
-  uint32_t fl_node = 0xFFFFFFFFu, fl_mv = 0;
-  uint64_t fl_meta = 0;
-  float fl_pr = 0.0f;
-  uint32_t sims_done = 0;
-  bool rec_ok = true;
-  uint64_t cur_key = 0, push_b0 = 0, push_b1 = 0;
-  uint32_t push_pl = 0;
-  bool queued_leaf = false;
-  if (live) {
-    c.load();
-    cp = c.gs.player;
-    tb = c.tree_base(cp);
-    root = AZMI_SEL(c.t_root, cp);
-    goal = (c.flags & kFlagCapped) ? c.seat_cap_visits(cp) : c.seat_visits(cp);
-    fpu_root = c.seat_fpu_zero(cp) ? 0.0f : ep.fpu_reduction;
-    seq = ar.req_seq[slot];
-    rec_ok = (c.flags & kFlagPendRec) != 0;
-    if (c.flags & kFlagReqOut) {            // every request of the previous epoch was settled at its end
-      if (lane == 0) atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTag));
-      live = false;
+  while (go) {
+    const uint64_t pf_t0 = wall_clock64();
+    // ---- tokens for this pass: the arrived prefix of the window's rest
+    uint32_t my_slot = 0xFFFFFFFFu, n_tok = 0;
+    uint64_t t_first = 0;
+    for (;;) {
+      if (wdone == wn) {
+        uint32_t h = 0;
+        if (wlane == 0) h = atomicAdd(&pc->rhead, kTreeWindow);
+        w0 = __builtin_amdgcn_readfirstlane(h); wn = kTreeWindow; wdone = 0;
+      }
+      const uint32_t left = wn - wdone;
+      unsigned long long tok = 0;
+      bool here = false;
+      if (lane == 0 && grp < left) {
+        const uint32_t pos = w0 + wdone + grp;
+        tok = g_ld(pa.rring + (pos & (kPipeRing - 1u)));
+        here = (tok >> 48) == pipe_lap_tag(pos);
+      }
+      // the epoch's end: stop word / error, the quota, the slots that wait for the move step
+      uint32_t ctl_word = 0;
+      if (wlane == 7) ctl_word = g_ld(&pe->stop) | g_ld(&pc->err);
+      else if (wlane == 15) ctl_word = g_ld(&pe->sims) >= pa.quota ? 1u : 0u;
+      else if (wlane == 23) ctl_word = g_ld(&pe->waiting);
+      else if (wlane == 31) ctl_word = g_ld(&pe->dead);
+      uint32_t stop_seen = __builtin_amdgcn_readlane(ctl_word, 7) | __builtin_amdgcn_readlane(ctl_word, 15);
+      {
+        const uint32_t w = __builtin_amdgcn_readlane(ctl_word, 23), d = __builtin_amdgcn_readlane(ctl_word, 31);
+        const uint32_t with_game = ep.S > d ? ep.S - d : 0u;
+        const uint32_t thr = max(1u, static_cast<uint32_t>((static_cast<unsigned long long>(with_game) * pa.idle_num) >> 10));
+        if (w >= thr || w + d >= ep.S) stop_seen = 1u;
+      }
+      const uint64_t now = wall_clock64();
+      if (now - t_start > pa.cap_ticks) {
+        if (wlane == 0) { atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTimeout)); pc->dbg[16] = __builtin_amdgcn_readlane(ctl_word, 23); pc->dbg[17] = __builtin_amdgcn_readlane(ctl_word, 31); }
+        stop_seen = 1u;
+      }
+      if (stop_seen) {          // (tokens this wavefront holds are dropped: their slots are whole in HBM, the next epoch seeds them again)
+        if (wlane == 0) g_st(&pe->stop, 1u);
+        go = false;
+        break;
+      }
+      const unsigned long long hm = __ballot(here);
+      // group g's token is bit 8 g: the arrived prefix in group order
+      uint32_t k = 0;
+      while (k < left && ((hm >> (8 * k)) & 1ull)) ++k;
+      pf_polls += 1;
+      if (k == left || (k != 0u && t_first != 0 && now - t_first > kTreePatience)) {
+        n_tok = k;
+        const uint32_t sl = static_cast<uint32_t>(__shfl(static_cast<uint32_t>(tok & 0xFFFFull), static_cast<int>(grp * 8), 64));
+        if (grp < k) my_slot = sl;
+        break;
+      }
+      if (k != 0u && t_first == 0) t_first = now;
+      if (k == 0u) __builtin_amdgcn_s_sleep(8);
     }
-  }
-  if (live) {
-    if (sst == kSlotQueued) {
-      // the move step's leaf (planes and key written, not evaluated yet): its request goes out first thing
-      push_b0 = ar.leaf_pos[0 * static_cast<size_t>(ep.S) + slot];
-      push_b1 = ar.leaf_pos[1 * static_cast<size_t>(ep.S) + slot];
-      push_pl = static_cast<uint32_t>(ar.leaf_pos[2 * static_cast<size_t>(ep.S) + slot]);
-      cur_key = ar.leaf_key[slot];
-      st = kGrpPush;
-      queued_leaf = true;
-    } else if (!rec_ok || AZMI_SEL(c.t_depth, cp) + 1 >= goal || c.cur == root) {
-      // the next backup completes the search, the evaluated leaf is the root, or the path has no lane image: the move step's
-      defer();
-      live = false;
-    } else {
+    if (!go) break;
+    wdone += n_tok;
+    const uint64_t pf_t1 = wall_clock64();
+    pf_idle += pf_t1 - pf_t0; pf_n += 1; pf_act += n_tok;
+
+    // ---- the pass: this CU's L1 may hold lines of these slots from an earlier pass here
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const bool on = my_slot != 0xFFFFFFFFu;
+    const uint32_t slot = on ? my_slot : 0u;
+    c.slot = slot;
+    uint32_t st = kGrpIdle;
+    uint8_t final_state = kSlotWaitEval;
+    uint32_t cp = 0, root = 0, goal = 0, seq = 0;
+    size_t tb = 0;
+    float fpu_root = 0.0f;
+    uint32_t* const path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
+    unsigned long long* const res = pa.res + static_cast<size_t>(slot) * kResStride;
+    float reg_pi = 0.0f, reg_v = 0.0f;
+    uint32_t root_n = 0; float root_v = 0.0f; uint64_t root_meta = 0;
+    uint32_t lv_node = 0, lv_n = 0, lv_pp = 0;
+    float lv_q = 0.0f, lv_d = 0.0f, lv_v = 0.0f;
+    uint64_t lf_meta = 0;
+    uint32_t lf_mv = 0, lf_c0 = 0, lf_k = 0, lf_term = 0, lf_player = 0;
+    bool fw = false;
+    uint32_t fw_node = 0, fw_n = 0, fw_plen = 0;
+    float fw_q = 0.0f, fw_d = 0.0f, fw_v = 0.0f;
+    uint32_t fl_node = 0xFFFFFFFFu, fl_mv = 0;
+    uint64_t fl_meta = 0;
+    float fl_pr = 0.0f;
+    uint32_t sims_done = 0, sims_mem = 0;
+    bool rec_ok = true, answered = false;
+    uint64_t cur_key = 0, push_b0 = 0, push_b1 = 0;
+    uint32_t push_pl = 0;
+    if (on) {
+      c.load();
+      cp = c.gs.player;
+      tb = c.tree_base(cp);
+      root = AZMI_SEL(c.t_root, cp);
+      goal = (c.flags & kFlagCapped) ? c.seat_cap_visits(cp) : c.seat_visits(cp);
+      fpu_root = c.seat_fpu_zero(cp) ? 0.0f : ep.fpu_reduction;
+      seq = ar.req_seq[slot];
+      rec_ok = (c.flags & kFlagPendRec) != 0;
       st = kGrpReady;
-      if (c.flags & kFlagLeafNeedsNet) {
+      const PendRec pr_in = ar.pend[static_cast<size_t>(slot) * G + lane];
+      { const NodeRec* rr = ar.nodes + tb + root; root_n = rr->n; root_v = rr->v; root_meta = rr->meta; }
+      lv_node = pr_in.node; lv_n = pr_in.n; lv_pp = pr_in.pp_mv & 0xFFu;
+      lv_q = pr_in.q; lv_d = pr_in.d; lv_v = pr_in.v;
+      lf_meta = pr_in.leaf_meta;
+      lf_mv = pr_in.pp_mv >> 8;
+      lf_c0 = meta_ch0(lf_meta); lf_k = meta_nch(lf_meta); lf_term = meta_term(lf_meta); lf_player = meta_player(lf_meta);
+      if (c.flags & kFlagReqOut) {
+        // the answer of the slot's request: its granules (on their way at the latest: the net workgroup sent the token after them)
+        cur_key = ar.leaf_key[slot];
+        unsigned long long g0 = 0, g1 = 0;
+        for (uint32_t spins = 0;; ++spins) {
+          if (lane < static_cast<uint32_t>(GM::M)) g0 = g_ld(res + lane);
+          if (lane <= static_cast<uint32_t>(P)) g1 = g_ld(res + kResV + lane);
+          const bool ok = (lane >= static_cast<uint32_t>(GM::M) || static_cast<uint32_t>(g0 >> 32) == seq) &&
+                          (lane > static_cast<uint32_t>(P) || static_cast<uint32_t>(g1 >> 32) == seq);
+          // (all eight lanes of the group agree through a group-wide AND of ok)
+          uint32_t okg = ok ? 1u : 0u;
+          okg &= c.bcast(okg, 0) & c.bcast(okg, 1) & c.bcast(okg, 2) & c.bcast(okg, 3) & c.bcast(okg, 4) & c.bcast(okg, 5) & c.bcast(okg, 6);
+          okg = c.bcast(okg, 0);
+          if (okg) break;
+          if (wall_clock64() - t_start > pa.cap_ticks) {
+            if (lane == 0 && atomicAdd(&pc->dbg[0], 1u) == 0u) { pc->dbg[1] = slot; pc->dbg[2] = seq; pc->dbg[3] = c.flags; pc->dbg[4] = static_cast<uint32_t>(g1 >> 32); pc->dbg[5] = static_cast<uint32_t>(g0 >> 32); }
+            if (lane == 0) atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTag));
+            st = kGrpIdle;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        if (st == kGrpReady) {
+          reg_pi = lane < static_cast<uint32_t>(GM::M) ? __uint_as_float(static_cast<uint32_t>(g0)) : 0.0f;
+          reg_v = lane <= static_cast<uint32_t>(P) ? __uint_as_float(static_cast<uint32_t>(g1)) : 0.0f;
+          // the rows keep the pending answer, as they do for the lock-step kernels (the move step reads them)
+          if (lane < static_cast<uint32_t>(GM::M)) ar.pi[static_cast<size_t>(slot) * GM::M + lane] = reg_pi;
+          if (lane <= static_cast<uint32_t>(P)) ar.v[static_cast<size_t>(slot) * (P + 1) + lane] = reg_v;
+          c.flags &= ~kFlagReqOut;
+          answered = true;
+        }
+      } else if (c.flags & kFlagLeafNeedsNet) {
         if (lane < static_cast<uint32_t>(GM::M)) reg_pi = ar.pi[static_cast<size_t>(slot) * GM::M + lane];
         if (lane <= static_cast<uint32_t>(P)) reg_v = ar.v[static_cast<size_t>(slot) * (P + 1) + lane];
       }
     }
-  }
-  if (live) {
-    const PendRec pr_in = ar.pend[static_cast<size_t>(slot) * G + lane];
-    { const NodeRec* rr = ar.nodes + tb + root; root_n = rr->n; root_v = rr->v; root_meta = rr->meta; }
-    lv_node = pr_in.node; lv_n = pr_in.n; lv_pp = pr_in.pp_mv & 0xFFu;
-    lv_q = pr_in.q; lv_d = pr_in.d; lv_v = pr_in.v;
-    lf_meta = pr_in.leaf_meta;
-    lf_mv = pr_in.pp_mv >> 8;
-    lf_c0 = meta_ch0(lf_meta); lf_k = meta_nch(lf_meta); lf_term = meta_term(lf_meta); lf_player = meta_player(lf_meta);
-  }
-  unsigned long long* const res = pa.res + static_cast<size_t>(slot) * kResStride;
-  {   // slots that have nothing to do here from the start: without a game, or waiting for the move step
-    const bool no_game = in_range && (sst == kSlotDone || sst == kSlotEnded);
-    const unsigned long long dm = __ballot(no_game && lane == 0);
-    const unsigned long long im = __ballot(in_range && !no_game && st == kGrpIdle && lane == 0);
-    if (dm && wlane == 0) atomicAdd(&pe->dead, static_cast<uint32_t>(__popcll(dm)));
-    if (im && wlane == 0) atomicAdd(&pe->waiting, static_cast<uint32_t>(__popcll(im)));
-  }
-
-  uint64_t pf_pass = 0, pf_idle = 0, pf_push = 0, pf_n = 0, pf_act = 0, pf_polls = 0;
-  for (;;) {
-    const uint64_t pf_t0 = wall_clock64();
-    // ---- A: the requests of the groups whose new leaf needs the net: one ticket draw per wavefront
-    {
-      const unsigned long long pm = __ballot(st == kGrpPush && lane == 0);
-      if (pm) {
-        uint32_t base = 0;
-        if (wlane == 0) base = atomicAdd(&pc->tail, static_cast<uint32_t>(__popcll(pm)));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (st == kGrpPush) {
-          const uint32_t pos = base + static_cast<uint32_t>(__popcll(pm & ((1ull << (grp * 8)) - 1ull)));
-          seq = seq + 1u == 0u ? 1u : seq + 1u;
-          const uint64_t payload = lane == 0 ? push_b0 : lane == 1 ? push_b1 : lane == 2 ? (static_cast<uint64_t>(slot) | (static_cast<uint64_t>(push_pl) << 16))
-                                                                                          : static_cast<uint64_t>(seq);
-          if (lane < kReqGranules)
-            g_st(pa.ring + static_cast<size_t>(pos & (kPipeRing - 1u)) * kReqGranules + lane, (pipe_lap_tag(pos) << 48) | (payload & kMask48));
-          if (lane == 0) { if (!queued_leaf) ar.c_evals[slot] += 1; ar.leaf_key[slot] = cur_key; }   // (the move step counted its own leaf)
-          queued_leaf = false;
-          c.flags |= kFlagReqOut;
-          st = kGrpWait;
-          dirty = true;
-        }
-      }
-    }
-    const uint64_t pf_t1 = wall_clock64();
-    pf_push += pf_t1 - pf_t0; pf_polls += 1;
-    // ---- B: poll - the result granules of the waiting groups, and the epoch's end
-    unsigned long long g0 = 0, g1 = 0;
-    if (st == kGrpWait) {
-      if (lane < static_cast<uint32_t>(GM::M)) g0 = g_ld(res + lane);
-      if (lane <= static_cast<uint32_t>(P)) g1 = g_ld(res + kResV + lane);
-    }
-    uint32_t ctl_word = 0;
-    if (wlane == 7) ctl_word = g_ld(&pe->stop) | g_ld(&pc->err);
-    else if (wlane == 15) ctl_word = g_ld(&pe->sims) >= pa.quota ? 1u : 0u;
-    else if (wlane == 23) ctl_word = g_ld(&pe->waiting);
-    else if (wlane == 31) ctl_word = g_ld(&pe->dead);
-    uint32_t stop_seen = __builtin_amdgcn_readlane(ctl_word, 7) | __builtin_amdgcn_readlane(ctl_word, 15);
-    {
-      // enough slots wait for the move step (or nothing is left to simulate at all): the epoch ends early
-      const uint32_t w = __builtin_amdgcn_readlane(ctl_word, 23), d = __builtin_amdgcn_readlane(ctl_word, 31);
-      const uint32_t with_game = ep.S > d ? ep.S - d : 0u;
-      const uint32_t thr = max(1u, static_cast<uint32_t>((static_cast<unsigned long long>(with_game) * pa.idle_num) >> 10));
-      if (w >= thr || w + d >= ep.S) stop_seen = 1u;
-    }
-    if (stop_seen && wlane == 0) g_st(&pe->stop, 1u);
-    if (wall_clock64() - t_start > pa.cap_ticks) {
-      if (wlane == 0) { atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTimeout)); g_st(&pe->stop, 1u); }
-      if (st == kGrpWait) {        // which request never came back
-        if (lane == 0 && atomicAdd(&pc->dbg[0], 1u) == 0u) { pc->dbg[1] = slot; pc->dbg[2] = seq; pc->dbg[3] = c.flags; pc->dbg[4] = static_cast<uint32_t>(g1 >> 32); }
-        if (pc->dbg[1] == slot && lane < 7) pc->dbg[8 + lane] = static_cast<uint32_t>(g0 >> 32);
-      }
-      if (wlane == 0) { pc->dbg[16] = __builtin_amdgcn_readlane(ctl_word, 23); pc->dbg[17] = __builtin_amdgcn_readlane(ctl_word, 31); pc->dbg[18] = static_cast<uint32_t>(g_ld(&pe->sims)); }
-      atomicAdd(&pc->dbg[19 + (st & 3u)], lane == 0 ? 1u : 0u);
-      break;
-    }
-    if (stop_seen) break;
-    const bool ok = st == kGrpWait && (lane >= static_cast<uint32_t>(GM::M) || static_cast<uint32_t>(g0 >> 32) == seq) &&
-                    (lane > static_cast<uint32_t>(P) || static_cast<uint32_t>(g1 >> 32) == seq);
-    const unsigned long long okm = __ballot(ok);
-    const bool arrived = st == kGrpWait && ((okm >> (grp * 8)) & 0xFFull) == 0xFFull;
-    if (arrived) {
-      reg_pi = lane < static_cast<uint32_t>(GM::M) ? __uint_as_float(static_cast<uint32_t>(g0)) : 0.0f;
-      reg_v = lane <= static_cast<uint32_t>(P) ? __uint_as_float(static_cast<uint32_t>(g1)) : 0.0f;
-      // the rows keep the pending answer, as they do for the lock-step kernels (the move step reads them)
-      if (lane < static_cast<uint32_t>(GM::M)) ar.pi[static_cast<size_t>(slot) * GM::M + lane] = reg_pi;
-      if (lane <= static_cast<uint32_t>(P)) ar.v[static_cast<size_t>(slot) * (P + 1) + lane] = reg_v;
-      c.flags &= ~kFlagReqOut;
-      st = kGrpReady;
-    }
     if (ep.cache_on) {        // PlayManager::update_inferences -> insert_many (play_manager.cc:631-640): logged, applied after the epoch
-      const unsigned long long am = __ballot(arrived && lane == 0);
+      const unsigned long long am = __ballot(answered && lane == 0);
       if (am) {
         uint32_t base = 0;
         if (wlane == 0) base = atomicAdd(&pe->ins_count, static_cast<uint32_t>(__popcll(am)));
         base = __builtin_amdgcn_readfirstlane(base);
-        if (arrived) {
+        if (answered) {
           const uint32_t idx = base + static_cast<uint32_t>(__popcll(am & ((1ull << (grp * 8)) - 1ull)));
           if (idx < pa.ins_cap) {
             if (lane == 0) pa.ins_key[idx] = cur_key;
@@ -236,18 +269,31 @@ __global__ __launch_bounds__(256, 2) void k_pipe_tree(EngineParams ep, EngineArr
         }
       }
     }
-    if (__ballot(st == kGrpReady) == 0ull) { __builtin_amdgcn_s_sleep(24); pf_idle += wall_clock64() - pf_t1; continue; }
     const uint64_t pf_t2 = wall_clock64();
-    pf_idle += pf_t2 - pf_t1; pf_n += 1; pf_act += static_cast<uint64_t>(__popcll(__ballot(st == kGrpReady && lane == 0)));
+    pf_io += pf_t2 - pf_t1;
 
-    // ---- C: simulations of the READY groups (k_sim's body)
-    uint32_t iter_sims = 0;
-    const bool was_ready = st == kGrpReady;
+    // ---- simulations (k_sim's body)
+    bool listed = false;
     if (st == kGrpReady) {
       uint32_t inline_sims = 0;
       for (;;) {
-        if (AZMI_SEL(c.t_depth, cp) + 1 >= goal || c.cur == root || !rec_ok) { defer(); st = kGrpIdle; dirty = true; break; }
-        {
+        if (AZMI_SEL(c.t_depth, cp) + 1 >= goal || c.cur == root) {
+          // the next backup completes the search (a move follows) or the evaluated leaf is the root (temperature, noise): the move step's
+          if (lane == 0) ar.mover_list[atomicAdd(&ar.ctl->mover_count, 1u)] = slot;
+          listed = true;
+          st = kGrpIdle;
+          break;
+        }
+        const uint64_t ph0 = wall_clock64();
+        if (!rec_ok) {
+          // a path deeper than the 8 levels of the lane image: the backup walks MCTS::path_ in memory (the lock-step engine hands
+          // these to the move step; here that would park the slot until the epoch ends)
+          const bool from_net = (c.flags & kFlagLeafNeedsNet) != 0;
+          c.template process_result<true>(cp, from_net, false, from_net, reg_pi, reg_v);     // (counts the simulation in c_sims itself)
+          root_n += 1;
+          sims_mem += 1;
+          fw = false; fl_node = 0xFFFFFFFFu;
+        } else {
           // ---- MCTS::process_result (mcts.cc:500-555) on the lane-resident path
           const bool from_net = (c.flags & kFlagLeafNeedsNet) != 0;
           float val[P + 1];
@@ -290,10 +336,10 @@ __global__ __launch_bounds__(256, 2) void k_pipe_tree(EngineParams ep, EngineArr
           if (lane == 0) ar.nodes[tb + root].n = root_n;
 #pragma unroll
           for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == cp) c.t_depth[p] += 1;
-          sims_done += 1; iter_sims += 1;
-          dirty = true;
+          sims_done += 1;
         }
         // ---- MCTS::find_leaf (mcts.cc:462-498), plain PUCT, with the forwarded values patched in
+        const uint64_t ph1 = wall_clock64();
         typename GM::State leaf = c.gs;
         uint32_t cur = root, plen = 0, n = root_n;
         uint64_t meta = root_meta;
@@ -335,7 +381,9 @@ __global__ __launch_bounds__(256, 2) void k_pipe_tree(EngineParams ep, EngineArr
           GM::play(leaf, meta_mv(meta));
           ++plen;
         }
-        if (failed) { c.raise(8u); final_state = kSlotDone; st = kGrpIdle; dirty = true; break; }
+        if (failed) { c.raise(8u); final_state = kSlotDone; st = kGrpIdle; break; }
+        const uint64_t ph2 = wall_clock64();
+        pf_lvls += plen;
         c.cur = cur; c.plen = plen;
         rec_ok = plen <= 8u;
 #pragma unroll
@@ -345,10 +393,11 @@ __global__ __launch_bounds__(256, 2) void k_pipe_tree(EngineParams ep, EngineArr
         if (n == 0) {
           term = GM::terminal(leaf);
           const uint64_t keep = meta_pack(0, 0, meta_mv(meta), leaf.player, term);
-          if (!c.expand_node(cp, cur, leaf, keep, lf_c0, lf_k, &lf_mv)) { final_state = kSlotDone; st = kGrpIdle; dirty = true; break; }
+          if (!c.expand_node(cp, cur, leaf, keep, lf_c0, lf_k, &lf_mv)) { final_state = kSlotDone; st = kGrpIdle; break; }
           lf_meta = meta_pack(lf_c0, lf_k, meta_mv(meta), leaf.player, term);
         }
         lf_term = term; lf_player = leaf.player;
+        const uint64_t ph3 = wall_clock64();
         const bool needs_net = term == 0 && !c.seat_eval_random(cp);
         c.flags = needs_net ? (c.flags | kFlagLeafNeedsNet) : (c.flags & ~kFlagLeafNeedsNet);
         if (needs_net) {
@@ -357,45 +406,86 @@ __global__ __launch_bounds__(256, 2) void k_pipe_tree(EngineParams ep, EngineArr
           if (!hit) {
             cur_key = key; push_b0 = leaf.bb[0]; push_b1 = leaf.bb[1]; push_pl = leaf.player;
             st = kGrpPush;
-            break;
           }
         }
+        {
+          const uint64_t ph4 = wall_clock64();
+          pf_ph[0] += ph1 - ph0; pf_ph[1] += ph2 - ph1; pf_ph[2] += ph3 - ph2; pf_ph[3] += ph4 - ph3; pf_ph[4] += 1;
+        }
+        if (st == kGrpPush) break;
         // the answer of this leaf is at hand (terminal, RANDOM evaluator, cache hit): the group goes on, a few times - the
-        // wavefront's other groups wait for this pass to end before their answers are looked at
+        // pass ends with its slowest group
         if (++inline_sims >= ep.max_inline) break;
       }
     }
-    // ---- D: the epoch's simulation count (its quota is what ends it)
+    const uint64_t pf_t3 = wall_clock64();
+    pf_pass += pf_t3 - pf_t2;
+
+    // ---- the slots go back to HBM (k_sim's exit); the request's sequence number is drawn here, its flag is part of the state
+    if (on) {
+      if (st == kGrpPush) { seq = seq + 1u == 0u ? 1u : seq + 1u; c.flags |= kFlagReqOut; }
+      if (lane == 0) {
+        if (sims_done) ar.c_sims[slot] += sims_done;
+        ar.req_seq[slot] = seq;
+        if (st == kGrpPush) { ar.c_evals[slot] += 1; ar.leaf_key[slot] = cur_key; }
+      }
+      if (rec_ok) {
+        PathRegs r;
+        r.node = lv_node; r.n = lv_n; r.q = lv_q; r.d = lv_d; r.v = lv_v; r.pp = lv_pp; r.mv = lf_mv; r.leaf_meta = lf_meta;
+        c.store_pend(r);
+        c.flags |= kFlagPendRec;
+      } else {
+        c.flags &= ~kFlagPendRec;
+      }
+      c.store(final_state);
+    }
+    // everything this pass wrote is visible before any of its tokens is
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- tokens out: requests for the new leaves that need the net, READY tokens for the slots whose next answer is at hand
     {
-      uint32_t x = lane == 0 ? iter_sims : 0u;
+      const unsigned long long pm = __ballot(st == kGrpPush && lane == 0);
+      if (pm) {
+        uint32_t base = 0;
+        if (wlane == 0) base = atomicAdd(&pc->tail, static_cast<uint32_t>(__popcll(pm)));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (st == kGrpPush) {
+          const uint32_t pos = base + static_cast<uint32_t>(__popcll(pm & ((1ull << (grp * 8)) - 1ull)));
+          const uint64_t payload = lane == 0 ? push_b0 : lane == 1 ? push_b1 : lane == 2 ? (static_cast<uint64_t>(slot) | (static_cast<uint64_t>(push_pl) << 16))
+                                                                                          : static_cast<uint64_t>(seq);
+          if (lane < kReqGranules)
+            g_st(pa.ring + static_cast<size_t>(pos & (kPipeRing - 1u)) * kReqGranules + lane, (pipe_lap_tag(pos) << 48) | (payload & kMask48));
+        }
+      }
+      const unsigned long long rm = __ballot(st == kGrpReady && lane == 0);
+      if (rm) {
+        uint32_t base = 0;
+        if (wlane == 0) base = atomicAdd(&pc->rtail, static_cast<uint32_t>(__popcll(rm)));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (st == kGrpReady && lane == 0) {
+          const uint32_t pos = base + static_cast<uint32_t>(__popcll(rm & ((1ull << (grp * 8)) - 1ull)));
+          g_st(pa.rring + (pos & (kPipeRing - 1u)), (pipe_lap_tag(pos) << 48) | static_cast<unsigned long long>(slot));
+        }
+      }
+    }
+    // ---- the epoch's counts: simulations (the quota ends it), slots handed to the move step
+    {
+      uint32_t x = lane == 0 ? sims_done + sims_mem : 0u;
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
       if (wlane == 0 && x) atomicAdd(&pe->sims, static_cast<unsigned long long>(x));
-      const unsigned long long im = __ballot(was_ready && st == kGrpIdle && lane == 0);
+      const unsigned long long im = __ballot(listed && lane == 0);
       if (im && wlane == 0) atomicAdd(&pe->waiting, static_cast<uint32_t>(__popcll(im)));
     }
-    pf_pass += wall_clock64() - pf_t2;
+    pf_io += wall_clock64() - pf_t3;
   }
 
   if (wlane == 0) {
+    g_st(&pe->stop, 1u);       // a tree wavefront leaves: the epoch is over (also when it never began: engine stopped, error)
     atomicAdd(&pc->prof[0], pf_pass); atomicAdd(&pc->prof[1], pf_idle); atomicAdd(&pc->prof[2], pf_n); atomicAdd(&pc->prof[3], pf_act);
-    atomicAdd(&pc->prof[4], pf_polls); atomicAdd(&pc->prof[5], pf_push); atomicAdd(&pc->prof[6], static_cast<unsigned long long>(wall_clock64() - t_start));
-  }
-  // ---- the slots go back to HBM in the form the lock-step kernels expect (k_sim's exit)
-  if (dirty) {
-    if (lane == 0) {
-      if (sims_done) ar.c_sims[slot] += sims_done;
-      ar.req_seq[slot] = seq;
-    }
-    if (rec_ok) {
-      PathRegs r;
-      r.node = lv_node; r.n = lv_n; r.q = lv_q; r.d = lv_d; r.v = lv_v; r.pp = lv_pp; r.mv = lf_mv; r.leaf_meta = lf_meta;
-      c.store_pend(r);
-      c.flags |= kFlagPendRec;
-    } else {
-      c.flags &= ~kFlagPendRec;
-    }
-    c.store(final_state);
+    atomicAdd(&pc->prof[4], pf_polls); atomicAdd(&pc->prof[5], pf_io);
+    atomicAdd(&pc->prof[9], pf_ph[0]); atomicAdd(&pc->prof[10], pf_ph[1]); atomicAdd(&pc->prof[11], pf_ph[2]); atomicAdd(&pc->prof[12], pf_ph[3]);
+    atomicAdd(&pc->prof[13], pf_ph[4]); atomicAdd(&pc->prof[14], pf_lvls); atomicAdd(&pc->prof[6], static_cast<unsigned long long>(wall_clock64() - t_start));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -535,6 +625,17 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
         c4::tile<c4::TileBig, 4, 4, 16, 0, true>(nd, npi, nullptr, nullptr, nullptr, c4::TileBig::TBW, nullptr, nullptr, 0u, lds_pipe, &pio);
       }
     }
+    // READY tokens of the answered slots (the tree wavefront that draws one checks the granules' tags itself, so the tokens
+    // need no ordering behind the tile's stores)
+    if (tid < 64) {
+      uint32_t base = 0;
+      if (tid == 0) base = atomicAdd(&pc->rtail, n);
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (tid < n) {
+        const uint32_t pos = base + tid;
+        g_st(pa.rring + (pos & (kPipeRing - 1u)), (pipe_lap_tag(pos) << 48) | static_cast<unsigned long long>(xs[8 + tid]));
+      }
+    }
   }
   if (tid == 0) { atomicAdd(&pc->prof[7], pf_wait); atomicAdd(&pc->prof[8], pf_tile); }
 }
@@ -547,7 +648,7 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
 __global__ void k_pipe_settle(EngineParams ep, EngineArrays ar, PipeArrays pa) {
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   // the net workgroups left with unused window positions (head ran ahead of tail): the next epoch's windows start at tail
-  if (slot == 0) pa.ctl->head = pa.ctl->tail;
+  if (slot == 0) { pa.ctl->head = pa.ctl->tail; pa.ctl->rhead = pa.ctl->rtail; }
   if (slot >= ep.S) return;
   const uint8_t f = ar.flags[slot];
   if (!(f & kFlagReqOut)) return;
@@ -594,7 +695,7 @@ __global__ __launch_bounds__(256) void k_pipe_cache_insert(EngineArrays ar, Pipe
     const uint64_t key = pa.ins_key[i];
     const float p = lane < M ? pa.ins_pi[static_cast<size_t>(i) * M + lane] : 0.0f;
     const float v = lane < P1 ? pa.ins_v[static_cast<size_t>(i) * P1 + lane] : 0.0f;
-    if (!wave_shard_insert_locked(ar.cache, pa.locks, key, p, v, lane) && lane == 0) atomicOr(&pa.ctl->err, static_cast<uint32_t>(kPipeErrLock));
+    if (!wave_shard_insert_locked<false>(ar.cache, pa.locks, key, p, v, lane) && lane == 0) atomicOr(&pa.ctl->err, static_cast<uint32_t>(kPipeErrLock));
   }
 }
 
@@ -604,7 +705,8 @@ struct PipeState {
   std::vector<void*> allocs;
   hipStream_t net_stream = nullptr;
   hipEvent_t ev_go = nullptr, ev_net = nullptr;
-  uint32_t net_wgs = 0, tree_wgs = 0;
+  uint32_t net_wgs = 0, tree_wgs = 0, tree_block = 256;
+  std::vector<hipEvent_t> tev;      // timing events: four per epoch of a run (net kernel start / end, tree kernel start / end)
   size_t lds_bytes = 0;
   bool lds_set = false;
 };
@@ -614,6 +716,7 @@ void pipe_state_free(PipeState* p) {
   if (p->net_stream) (void)hipStreamDestroy(p->net_stream);
   if (p->ev_go) (void)hipEventDestroy(p->ev_go);
   if (p->ev_net) (void)hipEventDestroy(p->ev_net);
+  for (hipEvent_t e : p->tev) (void)hipEventDestroy(e);
   delete p;
 }
 
@@ -644,9 +747,14 @@ int pipe_create(azmi_pm* pm, size_t tile_lds) {
   int rc = pipe_alloc(ps, pa.ctl, 1);
   if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.ep, 1);
   if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.ring, static_cast<size_t>(kPipeRing) * kReqGranules);
+  if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.rring, static_cast<size_t>(kPipeRing));
   if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.res, static_cast<size_t>(S) * kResStride);
   if (rc != AZMI_OK) return rc;
-  ps->tree_wgs = (S * Connect4::GROUP + 255u) / 256u;
+  // tree workgroups: lane-groups for half of the slots (the other half is with the net at any time; slots are not bound to
+  // wavefronts).  Measured at 4096 slots, 3-board tiles: 48 / 64 / 80 / 128 workgroups -> 56 / 68 / 62 / 60 M simulations/s: more
+  // of them take places from the net side and run each pass slower.  AZMI_PIPE_TREE_WGS sets another count.
+  ps->tree_wgs = std::max<uint32_t>(1u, (S * Connect4::GROUP + 511u) / 512u);
+  if (const char* e = getenv("AZMI_PIPE_TREE_WGS")) ps->tree_wgs = std::max(1, atoi(e));
   pa.n_tree_wgs = ps->tree_wgs;
   ps->lds_bytes = tile_lds + kPipeXs;
   // The chip holds two 256-thread workgroups of 256 registers per lane on a CU: the tree side takes tree_wgs of those 512
@@ -659,7 +767,8 @@ int pipe_create(azmi_pm* pm, size_t tile_lds) {
   // 488 they do not; 128 beside 384 do, beside 400 the last net workgroups start when the epoch is over).  So the places
   // are counted per shader engine.
   const uint32_t engines = std::max<uint32_t>(1u, static_cast<uint32_t>(prop.multiProcessorCount) / 8u), places = 16u;
-  const uint32_t tree_per_engine = (ps->tree_wgs + engines - 1u) / engines;
+  if (const char* e = getenv("AZMI_PIPE_TREE_BLOCK")) ps->tree_block = atoi(e) == 512 ? 512u : 256u;
+  const uint32_t tree_per_engine = ((ps->tree_wgs + engines - 1u) / engines) * (ps->tree_block / 256u);
   uint32_t net = engines * (places > tree_per_engine ? places - tree_per_engine : 1u);
   if (const char* e = getenv("AZMI_PIPE_NET_WGS")) net = static_cast<uint32_t>(atoi(e));
   ps->net_wgs = std::max<uint32_t>(1u, net);
@@ -707,7 +816,8 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
     ps->lds_set = true;
   }
   // the insert log holds an epoch's answers: at most one per simulation, in practice a third of them
-  const uint64_t want_log = pm->ep.cache_on ? std::min<uint64_t>(sims_per_epoch + pm->ep.S, 1ull << 24) : 0ull;
+  // (the quota is checked between passes: an epoch overshoots it by what the passes under way still finish)
+  const uint64_t want_log = pm->ep.cache_on ? std::min<uint64_t>(sims_per_epoch + 2ull * pm->ep.S + static_cast<uint64_t>(ps->tree_wgs) * 32u * (pm->ep.max_inline + 1u), 1ull << 24) : 0ull;
   if (want_log > pa.ins_cap) {
     PipeState* p = ps;
     int rc = pipe_alloc(p, pa.ins_key, want_log);
@@ -733,17 +843,32 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
   int rc = azmi_host_launch_assign(pm, st, 1u);
   if (rc != AZMI_OK) return rc;
   const uint32_t settle_blocks = (pm->ep.S + 255u) / 256u;
-  const int net_mode = getenv("AZMI_PIPE_TILE") ? atoi(getenv("AZMI_PIPE_TILE")) : 1;
+  // 3-board tiles: the net side has places to spare, so the shorter tile (its latency is what a slot waits for) beats the
+  // 6-board tile's better use of the weight stream (measured 68 vs 65 M simulations/s); AZMI_PIPE_TILE = 0 / 1 selects by fill / 6-board
+  const int net_mode = getenv("AZMI_PIPE_TILE") ? atoi(getenv("AZMI_PIPE_TILE")) : 2;
+  while (ps->tev.size() < 4ull * epochs) {
+    hipEvent_t ev;
+    AZMI_HIP_TRY(hipEventCreate(&ev));
+    ps->tev.push_back(ev);
+  }
   for (uint32_t e = 0; e < epochs; ++e) {
     AZMI_HIP_TRY(hipMemsetAsync(pa.ep, 0, sizeof(PipeEpoch), st));
+    k_pipe_seed<<<settle_blocks, 256, 0, st>>>(pm->ep, pm->ar, pa);
+    AZMI_HIP_TRY(hipGetLastError());
     AZMI_HIP_TRY(hipEventRecord(ps->ev_go, st));
     AZMI_HIP_TRY(hipStreamWaitEvent(ps->net_stream, ps->ev_go, 0));
+    // the tree kernel goes first: its 512-thread workgroups want CUs of their own, and find them only while the chip is empty
+    AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 2], st));
+    if (ps->tree_block == 512) k_pipe_tree<Connect4, 512><<<ps->tree_wgs, 512, 0, st>>>(pm->ep, pm->ar, pa);
+    else k_pipe_tree<Connect4, 256><<<ps->tree_wgs, 256, 0, st>>>(pm->ep, pm->ar, pa);
+    AZMI_HIP_TRY(hipGetLastError());
+    AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 3], st));
+    AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 0], ps->net_stream));
     if (net_mode == 1) k_pipe_net<1><<<ps->net_wgs, 256, ps->lds_bytes, ps->net_stream>>>(view.nd, view.np, pa);
     else if (net_mode == 2) k_pipe_net<2><<<ps->net_wgs, 256, ps->lds_bytes, ps->net_stream>>>(view.nd, view.np, pa);
     else k_pipe_net<0><<<ps->net_wgs, 256, ps->lds_bytes, ps->net_stream>>>(view.nd, view.np, pa);
     AZMI_HIP_TRY(hipGetLastError());
-    k_pipe_tree<Connect4><<<ps->tree_wgs, 256, 0, st>>>(pm->ep, pm->ar, pa);
-    AZMI_HIP_TRY(hipGetLastError());
+    AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 1], ps->net_stream));
     AZMI_HIP_TRY(hipEventRecord(ps->ev_net, ps->net_stream));
     AZMI_HIP_TRY(hipStreamWaitEvent(st, ps->ev_net, 0));
     k_pipe_settle<<<settle_blocks, 256, 0, st>>>(pm->ep, pm->ar, pa);
@@ -753,7 +878,7 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
     rc = azmi_host_launch_assign(pm, st, 1u);
     if (rc != AZMI_OK) return rc;
     if (pm->ep.cache_on) {
-      k_pipe_cache_insert<<<1024, 256, 0, st>>>(pm->ar, pa);
+      k_pipe_cache_insert<<<2048, 256, 0, st>>>(pm->ar, pa);
       AZMI_HIP_TRY(hipGetLastError());
     }
   }
@@ -767,9 +892,16 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
     out_stats[0] = hc.tiles; out_stats[1] = hc.tile_boards; out_stats[2] = he.sims; out_stats[3] = he.tree_arrived;
     out_stats[4] = he.net_arrived; out_stats[5] = he.ins_count; out_stats[6] = ps->net_wgs; out_stats[7] = ps->tree_wgs;
     out_stats[8] = he.tree_late / 100u; out_stats[9] = he.net_late / 100u;
+    double net_us = 0.0, tree_us = 0.0;
+    for (uint32_t e = 0; e < epochs; ++e) {
+      float ms = 0.0f;
+      if (hipEventElapsedTime(&ms, ps->tev[4 * e + 0], ps->tev[4 * e + 1]) == hipSuccess) net_us += 1e3 * ms;
+      if (hipEventElapsedTime(&ms, ps->tev[4 * e + 2], ps->tev[4 * e + 3]) == hipSuccess) tree_us += 1e3 * ms;
+    }
+    out_stats[10] = static_cast<uint64_t>(net_us); out_stats[11] = static_cast<uint64_t>(tree_us); out_stats[12] = epochs;
     if (getenv("AZMI_PIPE_PROF")) {
       fprintf(stderr, "pipe prof:");
-      for (int i = 0; i < 9; ++i) fprintf(stderr, " %llu", hc.prof[i]);
+      for (int i = 0; i < 15; ++i) fprintf(stderr, " %llu", hc.prof[i]);
       fprintf(stderr, "\n");
     }
   }

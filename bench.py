@@ -50,7 +50,12 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20, help="timed steps; a step = --rounds-per-step engine rounds")
     ap.add_argument("--warmup", type=int, default=5, help="untimed steps before the window (after the de-phasing pre-roll)")
-    ap.add_argument("--rounds-per-step", type=int, default=2048)
+    ap.add_argument("--rounds-per-step", type=int, default=None,
+                    help="lock-step driver: engine rounds per step (default 2048); pipeline driver: epochs per step (default 192)")
+    ap.add_argument("--driver", choices=["auto", "pipeline", "rounds"], default="auto",
+                    help="pipeline = asynchronous tree / net pipeline (azmi_run_pipeline: Connect4, PUCT); rounds = lock-step rounds "
+                         "(azmi_run_rounds); auto = the pipeline where it applies")
+    ap.add_argument("--sims-per-epoch", type=int, default=None, help="pipeline driver: simulations per epoch (default 64 x concurrent games)")
     ap.add_argument("--game", choices=["connect4", "tawlbwrdd", "stargambit"], default="connect4",
                     help="connect4 = BASELINE configs[1] (the headline); tawlbwrdd = configs[2] (2048 games, 400 sims, YAML net); "
                          "stargambit = configs[4] per GPU (star_gambit_unified, 1024 games, 800 sims, 200000-entry device cache)")
@@ -283,7 +288,10 @@ def main():
     tafl = args.game in ("tawlbwrdd", "stargambit")      # the wide-game engine (one wavefront per slot, spatial-head net)
     if args.games is None: args.games = 1024 if sg else 2048 if tafl else 4096
     if args.sims is None: args.sims = 800 if sg else 400 if tafl else 800
-    if args.engines is None: args.engines = 4      # measured: Connect4 1/2/4/8 shards and Tawlbwrdd 2/4/8 shards both peak at 4
+    # the pipeline drives ONE engine with every slot (one GPU-wide position cache); the lock-step driver wants 4 shards
+    use_pipe = args.driver == "pipeline" or (args.driver == "auto" and not tafl and not args.gumbel and (args.net or "hip") == "hip" and not args.dry)
+    if args.engines is None: args.engines = 1 if use_pipe else 4      # lock-step, measured: Connect4 1/2/4/8 shards and Tawlbwrdd 2/4/8 shards both peak at 4
+    if args.rounds_per_step is None: args.rounds_per_step = 192 if use_pipe else 2048
     if args.cache is None: args.cache = 200_000 if sg else 0 if tafl else 32_000_000      # Tawlbwrdd: measured 5 % hit rate with 2 M entries and 16 % fewer games/s, so off; StarGambit: configs[4] / config.py:197
     # SURVEY §8d; StarGambit net (configs/star_gambit_unified.yaml, 36 x 13 x 13): stem 7.0 + 8 trunk convs 99.7 + head 1x1s 2.8 + two
     # head convs 24.9 + policy 1x1 0.2 + value / global FCs 0.7 = 135.3 MFLOP per position
@@ -358,9 +366,25 @@ def main():
                     v_buf.copy_(v)
                     pi_buf.copy_(pi)
 
+        spe = args.sims_per_epoch or 64 * S
+        pipe_acc = {"net_us": 0.0, "tree_us": 0.0, "epochs": 0, "tiles": 0, "boards": 0, "late": 0}
+
         def run_rounds_on(group, n, ev=None):
             """n rounds of every shard. With the HIP net the loop is the native driver (azmi_run_rounds);
-            every 64th round is launched from here with HIP events around the two kernels of shard 0."""
+            every 64th round is launched from here with HIP events around the two kernels of shard 0.
+            Pipeline driver: n EPOCHS of the asynchronous pipeline (azmi_run_pipeline) on the one engine; the durations of
+            its net / tree kernels (HIP events on their own streams, inside the library) are summed when `ev` is given."""
+            if use_pipe:
+                for pm_ in group:
+                    st_ = az.run_pipeline(pm_, hip_net, n, spe, sps[0])
+                    if ev is not None:
+                        pipe_acc["net_us"] += st_["net_kernel_us"]; pipe_acc["tree_us"] += st_["tree_kernel_us"]; pipe_acc["epochs"] += st_["epochs"]
+                        pipe_acc.setdefault("tiles0", pipe_acc.get("tiles_now", 0)); pipe_acc.setdefault("boards0", pipe_acc.get("boards_now", 0))
+                        pipe_acc["late"] = max(pipe_acc["late"], st_["tree_latest_start_us"], st_["net_latest_start_us"])
+                        pipe_acc["net_wgs"], pipe_acc["tree_wgs"] = st_["net_wgs"], st_["tree_wgs"]
+                    pipe_acc["tiles_now"], pipe_acc["boards_now"] = st_["tiles"], st_["tile_boards"]
+                    pipe_acc["tiles"] = pipe_acc["tiles_now"] - pipe_acc.get("tiles0", 0); pipe_acc["boards"] = pipe_acc["boards_now"] - pipe_acc.get("boards0", 0)
+                return
             done = 0
             while done < n:
                 if ev is not None:
@@ -532,6 +556,8 @@ def main():
                              if tafl else f"Connect4, {S} concurrent games/GPU, {sims} sims/move, 6-block/64-ch ResNet (k3, 32 head ch), ")
                             + f"self-play flags of game_runner.py:2018-2041 with playout-cap {'ON (25 sims on 75% of moves)' if args.playout_cap else 'off'}, random-init weights",
                 "concurrent_games_per_gpu": S, "engine_shards": K, "sims_per_move": sims, "net": net_kind,
+                "driver": ("pipeline (azmi_run_pipeline): a step = %d epochs of <= %d simulations; persistent tree wavefronts + persistent net workgroups, "
+                           "moves / game ends / cache inserts between epochs" % (R, spe)) if use_pipe else "rounds (azmi_run_rounds): a step = %d lock-step rounds of every shard" % R,
                 "rounds_per_step": R, "preroll_rounds": pre_rounds, "ms_per_round": dt / (args.steps * R) * 1e3,
                 "max_cache_size": args.cache, "cache_hit_rate": hit_rate,
                 "sims_per_s": n_sims / dt, "leaf_evals_per_s": n_evals / dt,
@@ -541,8 +567,13 @@ def main():
         }
         if not dry:
             launches = args.steps * R * K
-            tree_ms = sum(a.elapsed_time(b) for a, b, _ in events) / max(1, len(events))
-            nn_ms = sum(b.elapsed_time(c) for _, b, c in events) / max(1, len(events))
+            if use_pipe:        # one launch of each persistent kernel per epoch: the library's own HIP events
+                launches = max(1, pipe_acc["epochs"])
+                tree_ms = pipe_acc["tree_us"] / launches / 1e3
+                nn_ms = pipe_acc["net_us"] / launches / 1e3
+            else:
+                tree_ms = sum(a.elapsed_time(b) for a, b, _ in events) / max(1, len(events))
+                nn_ms = sum(b.elapsed_time(c) for _, b, c in events) / max(1, len(events))
             # a k_leafnet launch evaluates the rows of its shard's eval list (leaves that missed the cache and are not
             # terminal) = the `evals` counter; the torch path and the spatial kernel evaluate the whole slot-indexed batch
             # (the spatial kernels take the eval list too whenever the position cache is on: the listed rows are packed at the front of
@@ -554,7 +585,10 @@ def main():
             out["roofline"] = {
                 "bound": "mfma", "achieved": per_launch, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": per_launch / MFMA_PEAK_TFLOPS, "traffic": None,
-                "kernel": "%s: %.0f positions (avg) x %.1f MFLOP per launch, %d overlapping launches per round" % ("k_leafnet_sp (+ k_heads_fc)" if tafl else "k_net_move (the leaf-net tiles of k_leafnet_c4 + the round's move step in one launch)", rows_evaluated / launches, flop_per_eval / 1e6, K),
+                "kernel": ("k_pipe_net (persistent leaf-net workgroups of the asynchronous pipeline: 3- / 6-board tiles of k_leafnet_c4 pulled off the request ring): "
+                           "%.0f positions (avg) x %.1f MFLOP per launch = one epoch, %d net workgroups beside %d tree workgroups, %.2f boards per tile"
+                           % (rows_evaluated / launches, flop_per_eval / 1e6, pipe_acc.get("net_wgs", 0), pipe_acc.get("tree_wgs", 0), pipe_acc["boards"] / max(1, pipe_acc["tiles"]))) if use_pipe else
+                          "%s: %.0f positions (avg) x %.1f MFLOP per launch, %d overlapping launches per round" % ("k_leafnet_sp (+ k_heads_fc)" if tafl else "k_net_move (the leaf-net tiles of k_leafnet_c4 + the round's move step in one launch)", rows_evaluated / launches, flop_per_eval / 1e6, K),
                 "per_launch_event_ms": nn_ms,
                 "aggregate_achieved": achieved, "aggregate_frac": achieved / MFMA_PEAK_TFLOPS,
                 "definition": "achieved = algorithmic FLOPs of ONE launch (positions it evaluated x FLOP per position) / its average duration, "
@@ -571,7 +605,7 @@ def main():
                 b_sim = 33000.0 if sg else 18000.0 if tafl else B_SIM
                 tree_launch = (b_sim * sims_rank / launches) / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
                 out["roofline_tree"] = {
-                    "kernel": ("k_cache_insert + k_round_big<StarGambit> + k_compact (one shard-round)" if sg else "k_round_big<Tawlbwrdd> + k_compact (one shard-round)" if tafl else "k_cache_insert + k_sim<Connect4> (one shard-round; the move step rides in the net launch)"),
+                    "kernel": ("k_pipe_tree<Connect4> (persistent tree wavefronts of the asynchronous pipeline, one launch per epoch)" if use_pipe else "k_cache_insert + k_round_big<StarGambit> + k_compact (one shard-round)" if sg else "k_round_big<Tawlbwrdd> + k_compact (one shard-round)" if tafl else "k_cache_insert + k_sim<Connect4> (one shard-round; the move step rides in the net launch)"),
                     "bound": "hbm", "achieved": tree_launch, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": tree_launch / HBM_PEAK_GBS, "traffic": None, "per_launch_event_ms": tree_ms,
                     "aggregate_achieved": b_sim * sims_rank / dt / 1e9, "aggregate_frac": b_sim * sims_rank / dt / 1e9 / HBM_PEAK_GBS,

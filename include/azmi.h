@@ -436,7 +436,9 @@ int azmi_run_rounds(azmi_pm* const* pms, azmi_net* net, uint32_t k, uint32_t rou
  *      out_stats (may be NULL): [0] net tiles run since the pipeline was created, [1] boards in them, [2] simulations of the
  *      last epoch, [3] / [4] tree / net workgroups that started in it, [5] its insert-log entries, [6] / [7] net / tree
  *      workgroups launched, [8] / [9] the latest start of a tree / net workgroup after the epoch's first, in microseconds (all
- *      of them must be on the chip together: a late one found its place only when another left); 16 entries. */
+ *      of them must be on the chip together: a late one found its place only when another left), [10] / [11] the summed
+ *      durations of this call's net / tree kernels in microseconds (HIP events on their streams), [12] the epochs of this
+ *      call; 16 entries. */
 int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, uint64_t sims_per_epoch, void* stream, uint64_t* out_stats);
 /* diagnostics: the pipeline's persistent net kernel alone, draining `n` synthetic requests (n <= 8192) `reps` times with
  * `net_wgs` workgroups (0 = the pipeline's own count) and tile selection `mode` (0 = 3- and 6-board tiles, 1 = 6-board, 2 =

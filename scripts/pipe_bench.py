@@ -7,7 +7,7 @@ import alphazero as az
 from alphazero import torch_net
 import bench
 S = int(os.environ.get("S", 4096)); sims = int(os.environ.get("SIMS", 800)); cache = int(os.environ.get("CACHE", 32_000_000))
-Q = int(os.environ.get("Q", 64)); E = int(os.environ.get("E", 50)); BLOCKS = int(os.environ.get("BLOCKS", 12)); PRE = float(os.environ.get("PRE", 1.0))
+Q = int(os.environ.get("Q", 64)); E = int(os.environ.get("E", 300)); BLOCKS = int(os.environ.get("BLOCKS", 12)); PRE = float(os.environ.get("PRE", 1.0))
 pp = bench.selfplay_params(az, S, sims, 1 << 30, cache=cache)
 spec = torch_net.connect4_spec()
 hip = az.HipLeafNet(torch_net.random_init(spec, seed=0), spec)

@@ -1,4 +1,10 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-BLOCKS=1 PRE=0.5 E=20 timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_pipe -o pipe -- python scripts/pipe_bench.py > gpurun_out/prof_pipe.log 2>&1
-find gpurun_out/prof_pipe -name "*stats*" | head -5
-f=$(find gpurun_out/prof_pipe -name "*kernel_stats.csv" | head -1); head -14 "$f" | cut -c1-260
+timeout -k 10 400 python -m pytest tests/test_gpu_pipeline.py -x -q 2>&1 | tail -3
+for t in 2 0; do
+AZMI_PIPE_TILE=$t timeout -k 10 500 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > gpurun_out/bench_pipe_$t.json 2> gpurun_out/bench_pipe.err; tail -2 gpurun_out/bench_pipe.err
+python - <<PY
+import json
+d=json.loads(open('gpurun_out/bench_pipe_$t.json').read().strip().splitlines()[-1])
+c=d['config']; r=d['roofline']
+print("TILE $t", d['value'], d['ms_per_step'], c['sims_per_s'], c['leaf_evals_per_s'], c['cache_hit_rate'], c['tree_kernel_ms'], c['net_ms'], r['achieved'], r['frac'])
+PY
+done
