@@ -27,7 +27,7 @@ namespace azmi {
 constexpr uint32_t kReqGranules = 4;     // ring entry = 32 bytes
 constexpr uint32_t kResStride = 16;      // result granules per slot: M + P + 1 = 10 used, padded to one 128-byte line
 constexpr uint32_t kResV = 7;            // first value granule (Connect4: pi in [0, 7), v in [7, 10))
-constexpr uint32_t kPipeRing = 8192;     // ring entries (a power of two above the slots of an engine: one request per slot at most)
+constexpr uint32_t kPipeRing = 32768;    // ring entries (a power of two, twice the most slots of an engine: one request / one READY token per slot at most)
 enum PipeErr : uint32_t { kPipeErrTimeout = 1, kPipeErrRing = 2, kPipeErrTag = 4, kPipeErrLog = 8, kPipeErrLock = 16, kPipeErrSlots = 32, kPipeErrNetTimeout = 64 };
 
 __host__ __device__ inline uint64_t pipe_lap_tag(uint32_t pos) { return static_cast<uint64_t>(((pos / kPipeRing) & 0x7FFFu) + 1u); }

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
   while (go) {
     const uint64_t pf_t0 = wall_clock64();
     // ---- tokens for this pass: the arrived prefix of the window's rest
-    uint32_t my_slot = 0xFFFFFFFFu, n_tok = 0;
+    uint32_t my_slot = 0xFFFFFFFFu, n_tok = 0, empty_polls = 0, ctl_word = 0;
     uint64_t t_first = 0;
     for (;;) {
       if (wdone == wn) {
@@ -128,12 +128,15 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
         tok = g_ld(pa.rring + (pos & (kPipeRing - 1u)));
         here = (tok >> 48) == pipe_lap_tag(pos);
       }
-      // the epoch's end: stop word / error, the quota, the slots that wait for the move step
-      uint32_t ctl_word = 0;
-      if (wlane == 7) ctl_word = g_ld(&pe->stop) | g_ld(&pc->err);
-      else if (wlane == 15) ctl_word = g_ld(&pe->sims) >= pa.quota ? 1u : 0u;
-      else if (wlane == 23) ctl_word = g_ld(&pe->waiting);
-      else if (wlane == 31) ctl_word = g_ld(&pe->dead);
+      // the epoch's end: stop word / error, the quota, the slots that wait for the move step.  (Looked at on the first poll of a
+      // pass and on every fourth poll of a wavefront that finds nothing: idle wavefronts must not hammer four hot lines)
+      if ((empty_polls & 3u) == 0u) {
+        ctl_word = 0;
+        if (wlane == 7) ctl_word = g_ld(&pe->stop) | g_ld(&pc->err);
+        else if (wlane == 15) ctl_word = g_ld(&pe->sims) >= pa.quota ? 1u : 0u;
+        else if (wlane == 23) ctl_word = g_ld(&pe->waiting);
+        else if (wlane == 31) ctl_word = g_ld(&pe->dead);
+      }
       uint32_t stop_seen = __builtin_amdgcn_readlane(ctl_word, 7) | __builtin_amdgcn_readlane(ctl_word, 15);
       {
         const uint32_t w = __builtin_amdgcn_readlane(ctl_word, 23), d = __builtin_amdgcn_readlane(ctl_word, 31);
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
         break;
       }
       if (k != 0u && t_first == 0) t_first = now;
-      if (k == 0u) __builtin_amdgcn_s_sleep(8);
+      if (k == 0u) { ++empty_polls; __builtin_amdgcn_s_sleep(24); }
     }
     if (!go) break;
     wdone += n_tok;

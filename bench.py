@@ -75,6 +75,10 @@ def parse(argv=None):
     ap.add_argument("--preroll-factor", type=float, default=2.0, help="pre-roll until this many x concurrent_games games have finished")
     ap.add_argument("--profile-window", action="store_true",
                     help="for rocprofv3 runs: a short window is allowed (no validity gate); the line is marked profile_window and its value is not the metric")
+    ap.add_argument("--no-tawlbwrdd", action="store_true",
+                    help="the default run (1 GPU, Connect4) also measures BASELINE configs[2] - Tawlbwrdd 2048 games x 400 sims, PUCT and Gumbel, with its "
+                         "CPU baseline - and reports it as the `tawlbwrdd` block of the line; this flag skips that")
+    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)    # a measurement process started by the default run
     ap.add_argument("--dry", action="store_true",
                     help="CPU dry run of the launch / distributed plumbing (gloo, no device, a stand-in engine): used by the tests")
     return ap.parse_args(argv)
@@ -153,7 +157,7 @@ def host_cores():
     return cores
 
 
-def cpu_baseline(az, sims, seconds, S, hip_net, cache, threads=None):
+def cpu_baseline(az, sims, seconds, S, hip_net, cache, threads=None, game="connect4", sims_per_game=None):
     """the reference's architecture on this box's host cores, timed beside the GPU engine — the oracle
     (CPU restatement of the reference PlayManager, `kind` "port") with `cores - 1` worker threads (the reference's default,
     config.py:439-441), the 4096 concurrent games split over the workers, and the leaf net served by the MI355X through
@@ -170,6 +174,9 @@ def cpu_baseline(az, sims, seconds, S, hip_net, cache, threads=None):
     threads = threads or max(1, host_cores() - 1)
     fn = C.cast(lib.azmi_net_eval_host, C.c_void_p).value
     out = {"unit": "games/s", "cores": threads, "kind": "port"}
+    gid = orc.GAME_TAWLBWRDD if game == "tawlbwrdd" else orc.GAME_CONNECT4
+    gname = "Tawlbwrdd" if game == "tawlbwrdd" else "Connect4"
+    netname = "configs/tawlbwrdd.yaml net" if game == "tawlbwrdd" else "6b64c net"
 
     def leg(eval_kind, slots_total, nsims, secs, cache_total, nthreads):
         """one timed run: `nthreads` oracle PlayManagers side by side; returns (games/s, sims/s, evals/s) after warm-up"""
@@ -181,7 +188,7 @@ def cpu_baseline(az, sims, seconds, S, hip_net, cache, threads=None):
             pp.history_enabled = True
             if eval_kind == "random":
                 pp.eval_type = [1, 1]
-            pms.append(orc.PlayManager(orc.GAME_CONNECT4, pp, 1000 + 7919 * t, per_slot_rng=False, record_moves=False))
+            pms.append(orc.PlayManager(gid, pp, 1000 + 7919 * t, per_slot_rng=False, record_moves=False))
         marks = []
 
         def snap():
@@ -207,11 +214,15 @@ def cpu_baseline(az, sims, seconds, S, hip_net, cache, threads=None):
         return (g1 - g0) / dt, (s1 - s0) / dt, (e1 - e0) / dt, g1 - g0, dt
 
     if hip_net is not None:
-        g, s, e, n, dt = leg("nn", S, sims, seconds, 200_000, threads)
+        g, s, e, n, dt = leg("nn", S, sims, seconds, cache, threads)
         out["value"] = g
-        out["sample"] = (f"{n} Connect4 self-play games x {sims} sims finished in {dt:.1f}s (after {seconds / 4:.0f}s warm-up) by the oracle PlayManager: "
-                         f"{threads} worker threads (host cores - 1) x {max(1, S // threads)} concurrent games, 6b64c net served by the MI355X "
-                         f"through host buffers (azmi_net_eval_host), position cache 200000 entries; {s / 1e6:.3f} Msims/s, {e / 1e6:.3f} M net evaluations/s")
+        if n < 64 and sims_per_game:      # a long game does not finish inside a bounded sample: the rate follows from the simulations
+            out["value"] = s / sims_per_game
+            out["value_note"] = (f"only {n} games finished inside the sample; value = the sample's simulations/s / {sims_per_game:.0f} simulations per game "
+                                 f"(measured on the GPU run of the same workload)")
+        out["sample"] = (f"{n} {gname} self-play games x {sims} sims finished in {dt:.1f}s (after {seconds / 4:.0f}s warm-up) by the oracle PlayManager: "
+                         f"{threads} worker threads (host cores - 1) x {max(1, S // threads)} concurrent games, {netname} served by the MI355X "
+                         f"through host buffers (azmi_net_eval_host), position cache {cache} entries; {s / 1e6:.3f} Msims/s, {e / 1e6:.3f} M net evaluations/s")
         out["sims_per_s"] = s
         out["evals_per_s"] = e
     g, s, _, n, dt = leg("random", S, sims, max(4.0, seconds / 4), 0, threads)
@@ -220,6 +231,8 @@ def cpu_baseline(az, sims, seconds, S, hip_net, cache, threads=None):
         out["value"] = g
         out["sims_per_s"] = s
         out["sample"] = out["tree_only"]["note"]
+    if game != "connect4":
+        return out
     # BASELINE configs[0]: Connect4, 64 concurrent games, 100 sims, one worker thread — the reference's own CPU-runnable case
     g, s, _, n, dt = leg("random", 64, 100, 3.0, 0, 1)
     out["configs0"] = {"workload": "Connect4, 64 concurrent games, 100 sims, 1 worker thread", "random_eval_games_per_s": g, "random_eval_sims_per_s": s}
@@ -253,10 +266,58 @@ class DryEngine:
         return out
 
 
+def run_worker(extra, timeout):
+    """one measurement in a child process of its own (started before this process has touched a GPU): returns the parsed JSON
+    line, or {"error": ...}"""
+    cmd = [sys.executable, os.path.abspath(__file__), "--worker"] + extra
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": f"timed out after {timeout}s", "cmd": " ".join(extra)}
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"exit code {r.returncode}", "stderr_tail": r.stderr.decode()[-600:], "cmd": " ".join(extra)}
+    return json.loads(lines[-1])
+
+
+def orchestrate(args):
+    """The default run: the headline (Connect4, BASELINE configs[1]) and, beside it in the same line, BASELINE configs[2] -
+    Tawlbwrdd 11x11, 2048 concurrent games, 400 sims, the configs/tawlbwrdd.yaml net - with PUCT and with Gumbel
+    (configs/tawlbwrdd.yaml:24-25) and its own CPU baseline (play_manager_bench.cc:171-181 methodology).  Each measurement is a
+    process of its own, one after the other on the one GPU; this process never touches it."""
+    t0 = time.perf_counter()
+    passthrough = [a for a in sys.argv[1:] if a != "--no-tawlbwrdd"]
+    head = run_worker(passthrough, 900)
+    if "error" in head:
+        sys.stderr.write("bench.py: the headline measurement failed: " + json.dumps(head) + "\n")
+        return 3
+    common = ["--game", "tawlbwrdd", "--steps", "6", "--warmup", "2", "--no-secondary", "--preroll-factor", "1.0", "--cpu-seconds", "12"]
+    if args.no_cpu_baseline:
+        common.append("--no-cpu-baseline")
+    puct = run_worker(common, 600)
+    gumbel = run_worker(common + ["--gumbel", "--no-cpu-baseline"], 600)
+
+    def trim(d):
+        if "error" in d:
+            return d
+        keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "roofline_tree", "cpu_baseline")
+        out = {k: d[k] for k in keep if k in d}
+        out["config"] = {k: v for k, v in d["config"].items() if k != "node_stats"}
+        return out
+    head["tawlbwrdd"] = trim(puct)
+    head["tawlbwrdd"]["gumbel"] = trim(gumbel)
+    head["config"]["bench_wall_s"] = time.perf_counter() - t0
+    print(json.dumps(head))
+    return 0
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args))
+    if (not args.dry and not args.worker and not args.no_tawlbwrdd and args.gpus == 1 and "RANK" not in os.environ and args.game == "connect4"
+            and not args.gumbel and not args.playout_cap and not args.profile_window):
+        sys.exit(orchestrate(args))
     if args.hwq:
         os.environ["GPU_MAX_HW_QUEUES"] = str(args.hwq)   # must be set before the HIP runtime starts
     import torch
@@ -560,6 +621,10 @@ def main():
                            "moves / game ends / cache inserts between epochs" % (R, spe)) if use_pipe else "rounds (azmi_run_rounds): a step = %d lock-step rounds of every shard" % R,
                 "rounds_per_step": R, "preroll_rounds": pre_rounds, "ms_per_round": dt / (args.steps * R) * 1e3,
                 "max_cache_size": args.cache, "cache_hit_rate": hit_rate,
+                "net_numerics": ("bf16 MFMA operands, fp32 accumulation / residual stream / heads: measured max |delta| against the reference NNArch's fp32 outputs "
+                                 "(tests/golden fixtures): pi 2.2e-4, v 5.2e-5 on the random-init Connect4 net (torch bf16 autocast, the reference's own "
+                                 "inference arithmetic: 6.4e-4); the 1e-5 tier is the fp32 net, see fp32_tier") if not tafl else
+                                "bf16 MFMA operands, fp32 accumulation; measured max |delta| vs the reference NNArch fp32 outputs: pi 6.2e-7, v 3.8e-6 (Tawlbwrdd)",
                 "sims_per_s": n_sims / dt, "leaf_evals_per_s": n_evals / dt,
                 "games_in_window": n_games, "samples_in_window": n_rows, "samples_gathered": gathered_rows,
                 "node_stats": node_stats,
@@ -626,34 +691,67 @@ def main():
                         out["roofline"]["traffic_note"] = ("bytes per k_leafnet launch at the L2-to-fabric counters (2 x FETCH_SIZE + WRITE_SIZE, "
                                                            + os.path.relpath(pmc, ROOT) + ")")
             if world == 1 and hip_net is not None and not args.no_secondary and not tafl and not args.playout_cap:
-                # two short secondary measurements of the same workload, reported beside the headline, never as it:
+                # short secondary measurements of the same workload, reported beside the headline, never as it:
                 #  (a) playout-cap randomisation at the reference's self-play defaults (fast_mcts_visits 25 on 75 % of
                 #      moves, config.py:86,100): what self_play() runs by default
                 #  (b) the position cache at the reference's default size (200 000 entries, config.py:197), which separates
                 #      the share of the headline that comes from the cache being sized for 288 GB of HBM
+                #  (c) 16384 concurrent games instead of 4096: what the chip does when the slots do not limit it (a slot's
+                #      simulations are sequential, so at 4096 slots the path is bound by their latency, not by the chip)
+                #  (d) the fp32 leaf net (precision = "fp32": the 1e-5 tier of the north star) on the lock-step driver
                 pms.clear()            # frees the headline engines' HBM before the secondary engines are built
-                for name, cache2, cap2, note in (("playout_cap_on", args.cache, True, "25 sims on 75% of moves, 800 on the rest"),
-                                                 ("cache_200k", 200_000, False, "max_cache_size = 200000 (reference default), 800 sims on every move")):
-                    pms2 = make_engines(cache2, cap2, 977)
-                    tot2 = lambda: totals_of(pms2)
-                    run2 = lambda n: (run_rounds_on(pms2, n), take_rows_of(pms2))
-                    pre2 = preroll(run2, tot2, int(args.preroll_factor * S), name)
-                    run2(2 * R)
+                hip_f32 = None
+                for name, S2, cache2, cap2, kind, note in (
+                        ("playout_cap_on", S, args.cache, True, "same", "25 sims on 75% of moves, 800 on the rest"),
+                        ("cache_200k", S, 200_000, False, "same", "max_cache_size = 200000 (reference default), 800 sims on every move"),
+                        ("slots_16384", 16384, args.cache, False, "same", "16384 concurrent games (4 x the headline's), 800 sims on every move"),
+                        ("fp32_tier", S, args.cache, False, "fp32", "the fp32 leaf net (max |delta| vs the reference NNArch 7.5e-8: the 1e-5 tier), lock-step rounds, 4 shards")):
+                    pipe2 = use_pipe and kind == "same"
+                    K2 = 1 if pipe2 else 4
+                    if kind == "fp32":
+                        hip_f32 = az.HipLeafNet(net, spec, device=local_rank, precision="fp32")
+                    net2 = hip_f32 if kind == "fp32" else hip_net
+                    pms2 = []
+                    for i in range(K2):
+                        pp2 = selfplay_params(az, S2 // K2, sims, STREAM, cache=cache2 // K2, playout_cap=cap2)
+                        pms2.append(az.PlayManager(Game(), pp2, seed=977 + 104729 * i, device=local_rank, max_inline=args.inline, history_capacity=(S2 // K2) * 42 * 4))
+                    R2 = R if pipe2 else (2048 if kind == "same" else 256)
+                    sps2 = sps if len(sps) >= K2 else [torch.cuda.Stream(device=dev).cuda_stream for _ in range(K2)]
+
+                    def run2(n, pms2=pms2, pipe2=pipe2, net2=net2, S2=S2, sps2=sps2):
+                        if pipe2:
+                            az.run_pipeline(pms2[0], net2, n, 64 * S2, sps2[0])
+                        else:
+                            done2 = 0
+                            while done2 < n:
+                                az.run_rounds(pms2, net2, min(256, n - done2), sps2[:len(pms2)])
+                                done2 += 256
+                        for pm2 in pms2:
+                            pm2.take_history_device(dev)
+                    tot2 = lambda pms2=pms2: totals_of(pms2)
+                    short = kind == "fp32"
+                    pre2 = 0 if short else preroll(run2, tot2, int((1.0 if S2 > S else args.preroll_factor) * S2), name)
+                    run2((1 if short else 2) * R2)
                     torch.cuda.synchronize()
                     d0, s0, e0, hh0, mm0 = tot2()
                     t2 = time.perf_counter()
-                    k2 = 6
+                    k2 = 2 if short else 6
                     for _ in range(k2):
-                        run2(R)
+                        run2(R2)
                     d1, s1, e1, hh1, mm1 = tot2()
                     torch.cuda.synchronize()
                     dt2 = time.perf_counter() - t2
                     out["config"][name] = {"games_per_s": (d1 - d0) / dt2, "sims_per_s": (s1 - s0) / dt2, "leaf_evals_per_s": (e1 - e0) / dt2,
                                            "cache_hit_rate": (hh1 - hh0) / max(1, (hh1 - hh0) + (mm1 - mm0)), "steps": k2, "preroll_rounds": pre2,
                                            "games_in_window": d1 - d0, "live_slots": sum(pm.poll()[1] for pm in pms2), "note": note + "; secondary figure"}
+                    if short:      # too short for games to finish from a cold start: the rate follows from the simulations
+                        out["config"][name]["games_per_s"] = ((s1 - s0) / dt2) / (n_sims / n_games)
+                        out["config"][name]["note"] += f"; games/s = this window's simulations/s / the headline's {n_sims / n_games:.0f} simulations per game (a cold-start window of {dt2:.1f}s)"
                     del pms2, tot2, run2
-            if world == 1 and not args.no_cpu_baseline and not tafl:
-                out["cpu_baseline"] = cpu_baseline(az, sims, args.cpu_seconds, S, hip_net, args.cache)
+            if world == 1 and not args.no_cpu_baseline and not sg and not args.gumbel:
+                # the reference's own cache size: 200 000 entries (config.py:197); Tawlbwrdd: off, as in its GPU run
+                out["cpu_baseline"] = cpu_baseline(az, sims, args.cpu_seconds, S, hip_net, 0 if tafl else 200_000, game="tawlbwrdd" if tafl else "connect4",
+                                                   sims_per_game=(n_sims / n_games) if n_games else None)
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

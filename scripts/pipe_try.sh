@@ -1,10 +1,5 @@
-timeout -k 10 400 python -m pytest tests/test_gpu_pipeline.py -x -q 2>&1 | tail -3
-for t in 2 0; do
-AZMI_PIPE_TILE=$t timeout -k 10 500 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > gpurun_out/bench_pipe_$t.json 2> gpurun_out/bench_pipe.err; tail -2 gpurun_out/bench_pipe.err
-python - <<PY
-import json
-d=json.loads(open('gpurun_out/bench_pipe_$t.json').read().strip().splitlines()[-1])
-c=d['config']; r=d['roofline']
-print("TILE $t", d['value'], d['ms_per_step'], c['sims_per_s'], c['leaf_evals_per_s'], c['cache_hit_rate'], c['tree_kernel_ms'], c['net_ms'], r['achieved'], r['frac'])
-PY
-done
+run() { echo "== $*"; env "$@" AZMI_PIPE_PROF=1 BLOCKS=2 PRE=2 E=300 timeout -k 10 280 python scripts/pipe_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-200 | grep block; }
+run AZMI_PIPE_TREE_WGS=64 AZMI_PIPE_TILE=0
+run AZMI_PIPE_TREE_WGS=96 AZMI_PIPE_TILE=0
+run AZMI_PIPE_TREE_WGS=128 AZMI_PIPE_TILE=0
+run AZMI_PIPE_TREE_WGS=96 AZMI_PIPE_TILE=2
