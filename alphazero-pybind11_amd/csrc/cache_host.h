@@ -35,7 +35,7 @@ inline hipError_t cache_alloc(CacheView& c, std::vector<void*>& allocs, uint32_t
   CGET(s_ring, S * C); CGET(m_ring, S * C); CGET(ghost_ring, S * G); CGET(state, S * 8);
   CGET(map_key, S * c.tcap); CGET(map_val, S * c.tcap); CGET(gset_key, S * c.gcap); CGET(stats, S * 4);
 #undef CGET
-  return hipSuccess;
+  return hipStreamSynchronize(nullptr);      // the memsets above are asynchronous to the host
 }
 
 }  // namespace azmi

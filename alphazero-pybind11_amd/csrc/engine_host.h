@@ -77,7 +77,10 @@ struct azmi_pm {
     AZMI_HIP_TRY(hipMalloc(&q, sz));
     allocs.push_back(q);
     bytes += sz;
-    if (zero) AZMI_HIP_TRY(hipMemset(q, 0, sz));
+    if (zero) {     // (hipMemset is asynchronous to the host, on the null stream: nothing on another stream may run ahead of it)
+      AZMI_HIP_TRY(hipMemset(q, 0, sz));
+      AZMI_HIP_TRY(hipStreamSynchronize(nullptr));
+    }
     p = static_cast<T*>(q);
     return AZMI_OK;
   }

@@ -299,12 +299,15 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
     *reinterpret_cast<bf16x4*>(act + (plane0 + (quad >> 1)) * PLANE + pix0 + j * 256 + (quad & 1) * 8) = o;
   };
 
-  // B-fragment addressing: the lane's pixel in plane `quad` (po), and the distance from there to the all-zero cell with
-  // the pixel's own 16-byte-slot residue (zd): a tap reads po + (on the board ? tap offset : zd), two VALU per fragment
+  // B-fragment addressing: the lane's pixel in plane `quad` (po), and the distance from there to the first all-zero cell
+  // (zd): a tap reads po + (on the board ? tap offset : zd + the 16-byte-slot residue of the cell the tap WOULD have read).
+  // Round 2 sent an out-of-board tap to the zero cell with the residue of the lane's OWN pixel: beside lanes that read their
+  // shifted on-board neighbour (residue + tap shift) that was a 2-way bank conflict wherever a lane group mixed the two -
+  // every border pixel - and SQ_LDS_BANK_CONFLICT read 28 % of the convolutions' LDS cycles (profiles/r3_c4_tile_pmc.csv).
   const uint8_t* const po = act + quad * PLANE + pix0;     // tile j: + j * 256, an immediate of the read
   int zd[NTW];
 #pragma unroll
-  for (int j = 0; j < NTW; ++j) zd[j] = ZERO_OFF + (pix0 & 0xF0) - pix0 - j * 256;
+  for (int j = 0; j < NTW; ++j) zd[j] = ZERO_OFF - pix0 - j * 256;
   const uint8_t* const wlane = ring + lane * 16;
 
   // One 3x3 convolution over `act`, accumulating into acc[][]; g0 = index of its first weight chunk in the run, slot0 = that
@@ -326,11 +329,13 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
     auto load_b = [&](int ks, bf16x8 (&fb)[NTW]) {
       const int tap = ks >> 1, half = ks & 1;
       const int tap_off = ((tap / 3 - 1) * BW + (tap % 3 - 1)) * 16;
+      int zs = (pix0 + tap_off) & 0xF0;       // slot residue of the cell this tap reads on the board (the same for every tile j)
+      asm volatile("" : "+v"(zs));
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
         int z = zd[j];
         asm volatile("" : "+v"(z));     // keep the select here: hoisted out of the block loop, the 36 offsets of a convolution cost 36 VGPRs (spills)
-        const int d = ((tap_ok[j] >> tap) & 1u) ? tap_off : z;
+        const int d = ((tap_ok[j] >> tap) & 1u) ? tap_off : z + zs;
         fb[j] = lds_read_frag(po + d + (j * 256 + half * 4 * PLANE));
       }
     };
@@ -376,7 +381,7 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
 #pragma unroll
           for (int i = 0; i < NTW; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, MF_B, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           }
         }

@@ -223,7 +223,7 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
   const uint8_t* const po = act + quad * PLANE + pix0;     // tile j: + j * 256, an immediate of the read
   int zd[NTW];
 #pragma unroll
-  for (int j = 0; j < NTW; ++j) zd[j] = G::ZERO_OFF + (pix0 & 0xF0) - pix0 - j * 256;
+  for (int j = 0; j < NTW; ++j) zd[j] = G::ZERO_OFF - pix0 - j * 256;   // + the slot residue of the cell the tap would have read (load_b; c4::tile)
   const uint8_t* const wlane = ring + lane * 16;
 
   // One convolution over `act`, accumulating into acc[][]: NCH weight chunks starting in ring slot `slot0` - 9 (a 3x3: chunk =
@@ -249,17 +249,19 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
         const int tap_off = ((th - 1) * BW + (tw - 1)) * 16;
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
-          const int d = (tap < 9 && ((tap_ok[j] >> tap) & 1u)) ? tap_off : zd[j];
+          const int d = (tap < 9 && ((tap_ok[j] >> tap) & 1u)) ? tap_off : zd[j] + ((pix0 + tap_off) & 0xF0);
           fb[j] = lds_read_frag(act + pix0 + d + j * 256);
         }
       } else {
         const int tap = NCH == 9 ? (ks >> 1) : 4, half = ks & 1;
         const int tap_off = ((tap / 3 - 1) * BW + (tap % 3 - 1)) * 16;
+        int zs = (pix0 + tap_off) & 0xF0;   // an out-of-board tap reads the zero cell in the bank slot its on-board cell would have had (no conflict with the lanes beside it)
+        asm volatile("" : "+v"(zs));
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
           int z = zd[j];
           asm volatile("" : "+v"(z));     // keep the select here: hoisted out of the block loop, the offsets of a convolution cost VGPRs (spills)
-          const int d = ((tap_ok[j] >> tap) & 1u) ? tap_off : z;
+          const int d = ((tap_ok[j] >> tap) & 1u) ? tap_off : z + zs;
           fb[j] = lds_read_frag(po + d + (j * 256 + half * 4 * PLANE));
         }
       }

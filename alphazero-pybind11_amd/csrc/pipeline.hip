@@ -737,7 +737,11 @@ int pipe_alloc(PipeState* ps, T*& p, size_t n) {
   const size_t sz = std::max<size_t>(n, 1) * sizeof(T);
   AZMI_HIP_TRY(hipMalloc(&q, sz));
   ps->allocs.push_back(q);
+  // hipMemset is asynchronous with respect to the host and runs on the null stream, which the (non-blocking) streams of the
+  // pipeline do not wait for: without the synchronisation the zeroes can land while the first epoch is already running
+  // (seen: the epoch block wiped under a running epoch of the second engine of a process)
   AZMI_HIP_TRY(hipMemset(q, 0, sz));
+  AZMI_HIP_TRY(hipStreamSynchronize(nullptr));
   p = static_cast<T*>(q);
   return AZMI_OK;
 }
@@ -756,7 +760,9 @@ int pipe_create(azmi_pm* pm, size_t tile_lds) {
   // tree workgroups: lane-groups for half of the slots (the other half is with the net at any time; slots are not bound to
   // wavefronts).  Measured at 4096 slots, 3-board tiles: 48 / 64 / 80 / 128 workgroups -> 56 / 68 / 62 / 60 M simulations/s: more
   // of them take places from the net side and run each pass slower.  AZMI_PIPE_TREE_WGS sets another count.
-  ps->tree_wgs = std::max<uint32_t>(1u, (S * Connect4::GROUP + 511u) / 512u);
+  // Beyond that the tree side is paid for in net places without being short of lane-groups: at 16384 slots 256 tree workgroups
+  // (256 net workgroups left) ran 37 M simulations/s, fewer than the 4096-slot engine.
+  ps->tree_wgs = std::min<uint32_t>(96u, std::max<uint32_t>(1u, (S * Connect4::GROUP + 511u) / 512u));
   if (const char* e = getenv("AZMI_PIPE_TREE_WGS")) ps->tree_wgs = std::max(1, atoi(e));
   pa.n_tree_wgs = ps->tree_wgs;
   ps->lds_bytes = tile_lds + kPipeXs;
@@ -846,9 +852,10 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
   int rc = azmi_host_launch_assign(pm, st, 1u);
   if (rc != AZMI_OK) return rc;
   const uint32_t settle_blocks = (pm->ep.S + 255u) / 256u;
-  // 3-board tiles: the net side has places to spare, so the shorter tile (its latency is what a slot waits for) beats the
-  // 6-board tile's better use of the weight stream (measured 68 vs 65 M simulations/s); AZMI_PIPE_TILE = 0 / 1 selects by fill / 6-board
-  const int net_mode = getenv("AZMI_PIPE_TILE") ? atoi(getenv("AZMI_PIPE_TILE")) : 2;
+  // tile selection: 0 = by what a window brings within its patience (<= 3 requests: the 3-board tile), 1 = 6-board tiles only,
+  // 2 = 3-board tiles only.  At 4096 slots 0 and 2 measure the same (the net side has places to spare); at 16384 slots the
+  // 3-board tile's capacity (19.5 M evaluations/s on 416 workgroups) is the limit, so 0 it is.
+  const int net_mode = getenv("AZMI_PIPE_TILE") ? atoi(getenv("AZMI_PIPE_TILE")) : 0;
   while (ps->tev.size() < 4ull * epochs) {
     hipEvent_t ev;
     AZMI_HIP_TRY(hipEventCreate(&ev));
@@ -883,6 +890,19 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
     if (pm->ep.cache_on) {
       k_pipe_cache_insert<<<2048, 256, 0, st>>>(pm->ar, pa);
       AZMI_HIP_TRY(hipGetLastError());
+    }
+    if (getenv("AZMI_PIPE_DEBUG")) {      // stop at the first epoch that raised an error, with that epoch's own counters
+      PipeCtl dc; PipeEpoch de;
+      AZMI_HIP_TRY(hipMemcpyAsync(&dc, pa.ctl, sizeof(dc), hipMemcpyDeviceToHost, st));
+      AZMI_HIP_TRY(hipMemcpyAsync(&de, pa.ep, sizeof(de), hipMemcpyDeviceToHost, st));
+      AZMI_HIP_TRY(hipStreamSynchronize(st));
+      if (dc.err) {
+        fprintf(stderr, "pipeline debug: epoch %u of this call: err 0x%x head %u tail %u rhead %u rtail %u sims %llu waiting %u dead %u stop %u tree_done %u/%u arrived, net arrived %u, ins %u, late %u/%u\n",
+                e, dc.err, dc.head, dc.tail, dc.rhead, dc.rtail, de.sims, de.waiting, de.dead, de.stop, de.tree_done, de.tree_arrived, de.net_arrived, de.ins_count,
+                de.tree_late / 100u, de.net_late / 100u);
+        epochs = e + 1;
+        break;
+      }
     }
   }
   // the run is synchronous: a pipeline error (a spin that hit its time cap, a tag that did not match) must not go unseen

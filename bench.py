@@ -526,6 +526,8 @@ def main():
                 raise RuntimeError(f"{what}: pre-roll did not reach {target_games} finished games in {used} rounds")
         return used
 
+    if rank == 0 and not dry:
+        sys.stderr.write(f"bench.py: {args.game} S={S} sims={sims} driver={'pipeline' if use_pipe else 'rounds'}: pre-roll ...\n"); sys.stderr.flush()
     # ---- pre-roll (de-phasing), warm-up, timed window --------------------------------------------------------------
     pre_rounds = preroll(run_rounds, totals, int(args.preroll_factor * S), "headline")
     for _ in range(args.warmup):
@@ -706,6 +708,9 @@ def main():
                         ("cache_200k", S, 200_000, False, "same", "max_cache_size = 200000 (reference default), 800 sims on every move"),
                         ("slots_16384", 16384, args.cache, False, "same", "16384 concurrent games (4 x the headline's), 800 sims on every move"),
                         ("fp32_tier", S, args.cache, False, "fp32", "the fp32 leaf net (max |delta| vs the reference NNArch 7.5e-8: the 1e-5 tier), lock-step rounds, 4 shards")):
+                    if os.environ.get("AZMI_BENCH_SECONDARY") and name not in os.environ["AZMI_BENCH_SECONDARY"].split(","):
+                        continue
+                    sys.stderr.write(f"bench.py: secondary {name} ...\n"); sys.stderr.flush()
                     pipe2 = use_pipe and kind == "same"
                     K2 = 1 if pipe2 else 4
                     if kind == "fp32":
@@ -716,7 +721,9 @@ def main():
                         pp2 = selfplay_params(az, S2 // K2, sims, STREAM, cache=cache2 // K2, playout_cap=cap2)
                         pms2.append(az.PlayManager(Game(), pp2, seed=977 + 104729 * i, device=local_rank, max_inline=args.inline, history_capacity=(S2 // K2) * 42 * 4))
                     R2 = R if pipe2 else (2048 if kind == "same" else 256)
-                    sps2 = sps if len(sps) >= K2 else [torch.cuda.Stream(device=dev).cuda_stream for _ in range(K2)]
+                    if len(streams) < K2:
+                        streams.extend(torch.cuda.Stream(device=dev) for _ in range(K2 - len(streams)))
+                    sps2 = [st_.cuda_stream for st_ in streams[:K2]]
 
                     def run2(n, pms2=pms2, pipe2=pipe2, net2=net2, S2=S2, sps2=sps2):
                         if pipe2:
@@ -749,6 +756,7 @@ def main():
                         out["config"][name]["note"] += f"; games/s = this window's simulations/s / the headline's {n_sims / n_games:.0f} simulations per game (a cold-start window of {dt2:.1f}s)"
                     del pms2, tot2, run2
             if world == 1 and not args.no_cpu_baseline and not sg and not args.gumbel:
+                sys.stderr.write("bench.py: cpu baseline ...\n"); sys.stderr.flush()
                 # the reference's own cache size: 200 000 entries (config.py:197); Tawlbwrdd: off, as in its GPU run
                 out["cpu_baseline"] = cpu_baseline(az, sims, args.cpu_seconds, S, hip_net, 0 if tafl else 200_000, game="tawlbwrdd" if tafl else "connect4",
                                                    sims_per_game=(n_sims / n_games) if n_games else None)
