@@ -71,7 +71,7 @@ def parse(argv=None):
     ap.add_argument("--net", choices=["hip", "torch"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the two short secondary measurements reported in config")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall time of the CPU-baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0, help="wall time of the CPU-baseline sample")
     ap.add_argument("--preroll-factor", type=float, default=2.0, help="pre-roll until this many x concurrent_games games have finished")
     ap.add_argument("--profile-window", action="store_true",
                     help="for rocprofv3 runs: a short window is allowed (no validity gate); the line is marked profile_window and its value is not the metric")
@@ -291,11 +291,12 @@ def orchestrate(args):
     if "error" in head:
         sys.stderr.write("bench.py: the headline measurement failed: " + json.dumps(head) + "\n")
         return 3
-    common = ["--game", "tawlbwrdd", "--steps", "6", "--warmup", "2", "--no-secondary", "--preroll-factor", "1.0", "--cpu-seconds", "12"]
+    # windows long enough for more than 2048 games to finish (the validity gate of a run): ~200 / ~145 games per 2048-round step
+    common = ["--game", "tawlbwrdd", "--warmup", "1", "--no-secondary", "--preroll-factor", "1.0", "--cpu-seconds", "12"]
     if args.no_cpu_baseline:
         common.append("--no-cpu-baseline")
-    puct = run_worker(common, 600)
-    gumbel = run_worker(common + ["--gumbel", "--no-cpu-baseline"], 600)
+    puct = run_worker(common + ["--steps", "13"], 600)
+    gumbel = run_worker(common + ["--steps", "17", "--gumbel", "--no-cpu-baseline"], 600)
 
     def trim(d):
         if "error" in d:
@@ -720,7 +721,7 @@ def main():
                     for i in range(K2):
                         pp2 = selfplay_params(az, S2 // K2, sims, STREAM, cache=cache2 // K2, playout_cap=cap2)
                         pms2.append(az.PlayManager(Game(), pp2, seed=977 + 104729 * i, device=local_rank, max_inline=args.inline, history_capacity=(S2 // K2) * 42 * 4))
-                    R2 = R if pipe2 else (2048 if kind == "same" else 256)
+                    R2 = R if pipe2 else (2048 if kind == "same" else 128)
                     if len(streams) < K2:
                         streams.extend(torch.cuda.Stream(device=dev) for _ in range(K2 - len(streams)))
                     sps2 = [st_.cuda_stream for st_ in streams[:K2]]
