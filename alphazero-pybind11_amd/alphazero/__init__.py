@@ -1442,6 +1442,12 @@ class PlayManager:
         rows = C.c_uint32()
         check(lib.azmi_pm_history_device(self._h, C.byref(c), C.byref(v), C.byref(p), C.byref(m), C.byref(rows)))
         n = rows.value
+        # these are views of the ring's first rows: only the whole story while nothing has been consumed and nothing has wrapped
+        first, live, cap = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(lib.azmi_pm_history_window(self._h, C.byref(first), C.byref(live), C.byref(cap)))
+        if first.value != 0 or live.value != n:
+            raise RuntimeError("history_device_tensors: rows of this engine's sample ring have been consumed or overwritten; "
+                               "read it with take_history_device()")
         dev = dev or torch.device("cuda", torch.cuda.current_device())
         if n == 0:
             z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
@@ -1473,6 +1479,9 @@ class PlayManager:
         n1 = min(n, cp - f)
         out = tuple(torch.cat([t[f:f + n1], t[:n - n1]], 0) if n1 < n else t[f:f + n].clone() for t in full)
         if consume:
+            # the copies above run on torch's current stream, asynchronously: the rows may only be released to the engine
+            # (whose later rounds overwrite them) once they have been read
+            torch.cuda.current_stream(dev).synchronize()
             check(lib.azmi_pm_history_consume(self._h, n))
         return out
 

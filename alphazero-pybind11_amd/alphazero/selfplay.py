@@ -9,7 +9,7 @@ import dataclasses
 
 import numpy as np
 
-from . import PlayManager, EvalType, ShardedS3FIFOCache, run_rounds, run_rounds_groups
+from . import PlayManager, EvalType, ShardedS3FIFOCache, run_rounds, run_rounds_groups, run_pipeline, pipeline_supported
 
 
 @dataclasses.dataclass
@@ -54,17 +54,32 @@ def shard_seed(seed, k):
     return int(seed) + 104729 * k
 
 
-def self_play(game, params, net=None, engines=4, seed=20240601, device=0, streams=None, rounds_per_poll=512, data_folder=None,
-              iteration=0, data_save_size=30_000):
-    """Runs `params.games_to_play` self-play games of `game` on `engines` shards; `net` is a HipLeafNet (or None when every
-    seat evaluates with RANDOM / PLAYOUT).  Returns (SelfPlayResult, (canonical, v, pi)) with the samples as device tensors
-    in shard order (numpy arrays without a net, since nothing else needs torch then).  With `data_folder` the samples are
-    also written as the reference's `.ptz` triples, `data_save_size` rows per batch (GameRunner.hist_saver,
-    game_runner.py:736-747)."""
-    K = max(1, min(int(engines), int(params.concurrent_games)))
-    pms = [PlayManager(game() if isinstance(game, type) else game, _shard_params(params, k, K), seed=shard_seed(seed, k), device=device)
-           for k in range(K)]
+def self_play(game, params, net=None, engines=None, seed=20240601, device=0, streams=None, rounds_per_poll=512, data_folder=None,
+              iteration=0, data_save_size=30_000, driver="auto", epochs_per_poll=64):
+    """Runs `params.games_to_play` self-play games of `game`; `net` is a HipLeafNet (or None when every seat evaluates with
+    RANDOM / PLAYOUT).  Returns (SelfPlayResult, (canonical, v, pi)) with the samples as device tensors in shard order (numpy
+    arrays without a net, since nothing else needs torch then).  With `data_folder` the samples are also written as the
+    reference's `.ptz` triples, `data_save_size` rows per batch (GameRunner.hist_saver, game_runner.py:736-747).
+    driver: "pipeline" = ONE engine with every game on the asynchronous tree / net pipeline (azmi_run_pipeline: Connect4, plain
+    PUCT seats, one model group, at most 16384 concurrent games), "rounds" = `engines` shards (default 4) on the lock-step round
+    driver, "auto" = the pipeline where it applies.  The finished samples are taken out of the engines' rings at every poll
+    (the ring is bounded: a long stream would overflow it), like the reference's hist_saver drains its queue."""
+    want_pipe = driver in ("auto", "pipeline") and net is not None and (engines in (None, 1) or driver == "pipeline")
+    if want_pipe:
+        probe = PlayManager(game() if isinstance(game, type) else game, _shard_params(params, 0, 1), seed=shard_seed(seed, 0), device=device)
+        if pipeline_supported(probe, net):
+            pms, K = [probe], 1
+        else:
+            if driver == "pipeline":
+                raise RuntimeError("self_play: the pipeline does not drive this engine / net (alphazero.pipeline_supported)")
+            del probe
+            want_pipe = False
+    if not want_pipe:
+        K = max(1, min(int(engines or 4), int(params.concurrent_games)))
+        pms = [PlayManager(game() if isinstance(game, type) else game, _shard_params(params, k, K), seed=shard_seed(seed, k), device=device)
+               for k in range(K)]
     no_net = bool(params.eval_type) and all(int(e) != int(EvalType.NN) for e in params.eval_type)
+    drained = [[] for _ in range(K)]          # per shard: the sample rows taken out of its ring so far
     if no_net:
         for pm in pms:
             pm.play()
@@ -76,9 +91,17 @@ def self_play(game, params, net=None, engines=4, seed=20240601, device=0, stream
             streams = [torch.cuda.Stream(device=device) for _ in range(K)]
         sps = [s.cuda_stream for s in streams]
         live = list(range(K))
+        tdev = torch.device("cuda", device)
+        spe = 64 * int(params.concurrent_games)
         while live:
             group = [pms[i] for i in live]
-            run_rounds(group, net, rounds_per_poll, [sps[i] for i in live])
+            if want_pipe:
+                run_pipeline(pms[0], net, epochs_per_poll, spe, sps[0])
+            else:
+                run_rounds(group, net, rounds_per_poll, [sps[i] for i in live])
+            for i in live:
+                if params.history_enabled:
+                    drained[i].append(pms[i].take_history_device(tdev)[:3])
             live = [i for i in live if pms[i].poll(sps[i])[1] > 0]
     # ---- the read-out of self_play(), game_runner.py:2073-2145, combined over the shards from the raw sums
     P1 = pms[0]._P + 1
@@ -99,7 +122,12 @@ def self_play(game, params, net=None, engines=4, seed=20240601, device=0, stream
         n_samples = samples[0].shape[0]
     else:
         import torch
-        hist = [pm.history_device_tensors(torch.device("cuda", device)) for pm in pms]
+        tdev = torch.device("cuda", device)
+        for k in range(K):
+            if params.history_enabled:
+                drained[k].append(pms[k].take_history_device(tdev)[:3])          # what finished after the last poll
+        hist = [tuple(torch.cat([part[i] for part in drained[k]], 0) for i in range(3)) if drained[k] else pms[k].history_device_tensors(tdev)[:3]
+                for k in range(K)]
         samples = tuple(torch.cat([h[i] for h in hist], 0) for i in range(3))
         n_samples = int(samples[0].shape[0])
     res = SelfPlayResult(

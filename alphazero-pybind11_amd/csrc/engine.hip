@@ -1065,9 +1065,16 @@ bool can_fuse(const azmi_pm* pm, const azmi_net* net, azmi_net_c4_view* view) {
   return pm->split_rounds && pm->ep.num_groups == 1 && !pm->all_random && getenv("AZMI_NO_FUSE") == nullptr && azmi_net_c4_view_get(net, view) != 0;
 }
 int launch_net_move(azmi_pm* pm, const azmi_net_c4_view& view, hipStream_t st) {
-  static std::atomic<bool> reserved{false};
-  if (!reserved.exchange(true))
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_net_move), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(view.lds_bytes)));
+  // (per device: the attribute belongs to the device's copy of the kernel; the tile's LDS need is a constant of the geometry)
+  static std::mutex reserved_mu;
+  static std::vector<int> reserved_devices;
+  {
+    std::lock_guard<std::mutex> l(reserved_mu);
+    if (std::find(reserved_devices.begin(), reserved_devices.end(), pm->device) == reserved_devices.end()) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_net_move), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(view.lds_bytes)));
+      reserved_devices.push_back(pm->device);
+    }
+  }
   const uint32_t net_tiles = (pm->ep.S + azmi_net_dev::c4::TileSmall::TBW - 1) / azmi_net_dev::c4::TileSmall::TBW;
   const uint32_t move_blocks = (pm->ep.S * Connect4::GROUP + 255) / 256;
   k_net_move<<<net_tiles + move_blocks, 256, view.lds_bytes, st>>>(view.nd, view.np, pm->ep, pm->ar, net_tiles);
@@ -1464,7 +1471,7 @@ int azmi_pm_counters(azmi_pm* pm, uint64_t* out) {
   uint64_t cs[6];
   rc = azmi_pm_cache_stats(pm, cs); if (rc) return rc;
   out[2] = cs[0]; out[3] = cs[1];
-  out[4] = c.hist_rows - pm->hist_read;   // free-running u32 counters: the difference is the live row count
+  out[4] = c.hist_rows - pm->hist_read;   // free-running 64-bit counters: the difference is the live row count
   out[5] = c.rounds;
   return AZMI_OK;
 }
@@ -1472,7 +1479,7 @@ int azmi_pm_counters(azmi_pm* pm, uint64_t* out) {
 namespace {
 // tells the device how far the host has consumed the finished-sample ring (ordered behind the rounds already queued)
 int publish_hist_read(azmi_pm* pm) {
-  HIP_TRY(hipMemcpyAsync(&pm->ar.ctl->hist_read, &pm->hist_read, sizeof(uint32_t), hipMemcpyHostToDevice, pm->last));
+  HIP_TRY(hipMemcpyAsync(&pm->ar.ctl->hist_read, &pm->hist_read, sizeof(pm->hist_read), hipMemcpyHostToDevice, pm->last));
   HIP_TRY(hipStreamSynchronize(pm->last));
   return AZMI_OK;
 }
@@ -1483,11 +1490,11 @@ int azmi_pm_pop_history(azmi_pm* pm, float* canonical, float* v, float* pi, uint
   std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   Control c;
   int rc = read_ctl(pm, pm->last, &c, true); if (rc) return rc;
-  const uint32_t avail = c.hist_rows - pm->hist_read;
+  const uint32_t avail = static_cast<uint32_t>(c.hist_rows - pm->hist_read);
   const uint32_t take = std::min(avail, cap);
   const uint32_t CANON = pm->gi.C * pm->gi.H * pm->gi.W, V = pm->gi.P + 1, M = pm->gi.M;
   if (take) {
-    const uint32_t first = pm->hist_read % pm->ep.hist_cap;
+    const uint32_t first = static_cast<uint32_t>(pm->hist_read % pm->ep.hist_cap);
     const uint32_t n1 = std::min(take, pm->ep.hist_cap - first);
     for (int seg = 0; seg < 2; ++seg) {     // the window may wrap around the end of the ring
       const size_t r0 = seg == 0 ? first : 0, nr = seg == 0 ? n1 : take - n1, o = seg == 0 ? 0 : n1;
@@ -1513,7 +1520,7 @@ int azmi_pm_history_device(azmi_pm* pm, float** dev_canonical, float** dev_v, fl
   if (dev_v) *dev_v = pm->ar.h_v;
   if (dev_pi) *dev_pi = pm->ar.h_pi;
   if (dev_meta) *dev_meta = pm->ar.h_meta;
-  if (rows) *rows = std::min(c.hist_rows, pm->ep.hist_cap);   // rows of the run while nothing has wrapped; use the window call for a ring
+  if (rows) *rows = static_cast<uint32_t>(std::min<unsigned long long>(c.hist_rows, pm->ep.hist_cap));   // rows of the run while nothing has wrapped; use the window call for a ring
   return AZMI_OK;
 }
 
@@ -1522,8 +1529,8 @@ int azmi_pm_history_window(azmi_pm* pm, uint32_t* first_row, uint32_t* rows, uin
   std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   Control c;
   int rc = read_ctl(pm, pm->last, &c, true); if (rc) return rc;
-  if (first_row) *first_row = pm->ep.hist_cap ? pm->hist_read % pm->ep.hist_cap : 0;
-  if (rows) *rows = c.hist_rows - pm->hist_read;
+  if (first_row) *first_row = pm->ep.hist_cap ? static_cast<uint32_t>(pm->hist_read % pm->ep.hist_cap) : 0;
+  if (rows) *rows = static_cast<uint32_t>(c.hist_rows - pm->hist_read);
   if (capacity) *capacity = pm->ep.hist_cap;
   return AZMI_OK;
 }
@@ -1533,7 +1540,7 @@ int azmi_pm_history_consume(azmi_pm* pm, uint32_t rows) {
   std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   Control c;
   int rc = read_ctl(pm, pm->last, &c, true); if (rc) return rc;
-  if (rows > c.hist_rows - pm->hist_read) return fail(AZMI_ERR_INVALID, "history_consume: %u rows asked, %u unread", rows, c.hist_rows - pm->hist_read);
+  if (rows > c.hist_rows - pm->hist_read) return fail(AZMI_ERR_INVALID, "history_consume: %u rows asked, %u unread", rows, static_cast<uint32_t>(c.hist_rows - pm->hist_read));
   pm->hist_read += rows;
   return publish_hist_read(pm);
 }

@@ -46,7 +46,7 @@ struct azmi_pm {
   hipStream_t stream = nullptr;  // engine-owned stream (AZMI_STREAM_ENGINE)
   hipStream_t last = nullptr;    // stream of the most recent round: result queries order themselves behind it
   hipStream_t pick(void* s) { last = (s == AZMI_STREAM_ENGINE) ? stream : static_cast<hipStream_t>(s); return last; }
-  uint32_t hist_read = 0;
+  unsigned long long hist_read = 0;
   uint32_t cache_shards = 0;
   std::vector<azmi::CacheView> group_caches;   // host copies of the per-model-group cache views
   std::vector<uint8_t> group_cache_counted;  // 0: stand-in for a `None` entry of an external cache list (not in the statistics)

@@ -1106,12 +1106,12 @@ struct SlotCtx {
     sync_lanes();
     const uint32_t rows = ep.history ? ph_rows : 0u;
     if (rows > 0) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&ar.ctl->hist_rows, rows);
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(&ar.ctl->hist_rows, static_cast<unsigned long long>(rows));
       base = bcast(base, 0);
       // the finished-sample store is a ring of hist_cap rows (the reference's history queue is unbounded and drained by
       // hist_saver, game_runner.py:729-747): row i of the run lives at i % hist_cap; it overflows only when the host has not
-      // consumed enough (hist_rows - hist_read > hist_cap).  hist_rows / hist_read are free-running u32 counters.
+      // consumed enough (hist_rows - hist_read > hist_cap).  hist_rows / hist_read are free-running 64-bit counters.
       if (base + rows - ar.ctl->hist_read <= ep.hist_cap) {
         const uint32_t game_idx = ar.slot_games[slot];
         // The game's rows are contiguous on the pending side and contiguous modulo the ring on the other: a per-row
@@ -1119,7 +1119,7 @@ struct SlotCtx {
         // of a shard), so the planes are regenerated from packed positions and the policy rows move as flat copies
         // (two segments when the game's rows wrap around the end of the ring).
         const size_t src0 = static_cast<size_t>(slot) * ep.max_hist_rows;
-        const uint32_t first = base % ep.hist_cap;
+        const uint32_t first = static_cast<uint32_t>(base % ep.hist_cap);
         const uint32_t n1 = rows < ep.hist_cap - first ? rows : ep.hist_cap - first;
         {
           // canonical planes from the packed pending positions: eight rows' positions per round trip, planes written straight

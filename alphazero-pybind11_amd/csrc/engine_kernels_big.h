@@ -1218,8 +1218,8 @@ struct BigSlot {
     const uint32_t S = ep.S;
     const uint32_t rows = ep.history ? ph_rows : 0u;
     if (rows > 0) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&ar.ctl->hist_rows, rows);
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(&ar.ctl->hist_rows, static_cast<unsigned long long>(rows));
       base = __shfl(base, 0, 64);
       // ring of hist_cap rows, row i of the run at i % hist_cap (see engine_kernels.h end_game)
       if (base + rows - ar.ctl->hist_read <= ep.hist_cap) {
@@ -1227,7 +1227,7 @@ struct BigSlot {
         // the game's rows are contiguous on the pending side and contiguous modulo the ring on the other: flat copies,
         // eight loads in flight per lane, in two segments when the rows wrap around the end of the ring
         const size_t src0 = static_cast<size_t>(slot) * ep.max_hist_rows;
-        const uint32_t first = base % ep.hist_cap;
+        const uint32_t first = static_cast<uint32_t>(base % ep.hist_cap);
         const uint32_t n1 = rows < ep.hist_cap - first ? rows : ep.hist_cap - first;
         auto flat_copy = [&](const float* sp, float* dp, size_t n) {
           for (size_t e0 = 0; e0 < n; e0 += 8 * G) {

@@ -119,14 +119,18 @@ struct Control {  // small device control block, copied back by azmi_pm_poll
   uint32_t games_completed;
   uint32_t stop;
   uint32_t ended_count;
-  uint32_t hist_rows;
+  uint32_t pad_hist;      // (was the 32-bit row counter)
   uint32_t log_rows;
   uint32_t overflow;      // bit0 tree arena, bit1 history, bit2 move log, bit3 path
   uint32_t live_slots;
   uint64_t rounds;
   uint32_t eval_count[4]; // per model group: entries of eval_list[g] written by this round's k_round
-  uint32_t hist_read;     // finished-sample ring: rows the host has consumed (hist_rows - hist_read rows are live, <= hist_cap)
+  uint32_t pad_read;
   uint32_t mover_count;   // split rounds: entries of mover_list written by this round's k_sim
+  // finished-sample ring: rows finished / rows the host has consumed, free-running 64-bit counters (row i of the run lives at
+  // i % hist_cap; 32-bit counters would break that sequence when they wrap, after ~14 h at the headline's sample rate)
+  unsigned long long hist_rows;
+  unsigned long long hist_read;
 };
 
 constexpr uint32_t kGumMaxM = 64;   // cap on PlayParams.gumbel_m (reference default 16)

@@ -205,10 +205,15 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
                        : b7 ? reinterpret_cast<const void*>(&sp::k_leafnet_sp<sp::Geo7>) : reinterpret_cast<const void*>(&sp::k_leafnet_sp<sp::Geo13>);
     net->fc_split = d->v_hidden > 256 || num_global > 0;   // more than ~0.4 MB of FC weights per group
     net->fc_lds = sp::heads_fc_lds(d->v_hidden > d->pi_hidden || num_global == 0 ? d->v_hidden : d->pi_hidden);
+    // The FC kernels are shared by every spatial net of the process: the attribute is set to the most any descriptor this
+    // library accepts can ask for (v_hidden / pi_hidden <= 1024), never to this net's own need - a later, smaller net must
+    // not lower it under an earlier, larger one
+    const int fc_max = static_cast<int>(sp::heads_fc_lds(1024));
+    if (net->fc_lds > static_cast<size_t>(fc_max)) { (void)hipFree(net->blob); delete net; return nfail(AZMI_ERR_INVALID, "v_hidden / pi_hidden above 1024"); }
     if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(net->lds_bytes)) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&sp::k_heads_fc), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(net->fc_lds)) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&sp::k_heads_fc_a), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(net->fc_lds)) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&sp::k_heads_fc_b), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(net->fc_lds)) != hipSuccess) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&sp::k_heads_fc), hipFuncAttributeMaxDynamicSharedMemorySize, fc_max) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&sp::k_heads_fc_a), hipFuncAttributeMaxDynamicSharedMemorySize, fc_max) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&sp::k_heads_fc_b), hipFuncAttributeMaxDynamicSharedMemorySize, fc_max) != hipSuccess) {
       (void)hipFree(net->blob); delete net;
       return nfail(AZMI_ERR_NO_DEVICE, "cannot reserve LDS for the spatial leaf net");
     }

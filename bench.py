@@ -28,6 +28,7 @@ N processes itself, before anything touches a GPU), every rank runs the same wor
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import datetime
 import json
 import os
 import socket
@@ -98,12 +99,34 @@ def spawn_ranks(args):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0)
+    # rank 0's line is read by a thread; the ranks are polled together: when one of them dies (before or at the rendezvous, in a
+    # collective) the others would wait for it for ever, so they are terminated and the run fails instead of hanging
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad:
+            failed = bad
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    codes = []
+    for p in procs:
+        try:
+            codes.append(p.wait(timeout=30))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            codes.append(p.wait())
+    reader.join(10)
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
-    if any(codes):
-        sys.stderr.write(f"bench.py: rank exit codes {codes}\n")
+    if failed or any(codes):
+        sys.stderr.write(f"bench.py: rank exit codes {codes}" + (f" (first failure: rank, code = {failed})" if failed else "") + "\n")
         return 1
     return 0
 
@@ -342,9 +365,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if dry:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=600))
 
     sg = args.game == "stargambit"
     tafl = args.game in ("tawlbwrdd", "stargambit")      # the wide-game engine (one wavefront per slot, spatial-head net)

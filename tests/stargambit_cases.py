@@ -392,4 +392,32 @@ def case_unified_shapes_and_remap(make, make_unified):   # star_gambit_unified_g
             assert (su is None) == (sp is None) and (su is None or list(su) == list(sp))
 
 
+def case_unit_and_action_space_constants(make, make_unified):
+    """UnitProperties.MaxHP / NumCannons / UnitSize (:1369-1397), ActionSpace.*ActionCounts / BoardSizes (:1401-1462),
+    CharacterizationFighter / Cruiser / Dreadnought unit shapes (:2206-2240, 2410-2460) - the reference checks free functions
+    and class constants that have no binding; here the same numbers are read off what the game shows: the action-space
+    size, the hex mask of the observation, and a freshly deployed unit's hit points, cannon planes and cells."""
+    max_hp, cannons, size = {0: 3, 1: 4, 2: 6}, {0: 1, 1: 3, 2: 4}, {0: 1, 1: 2, 2: 3}
+    for v, (moves, hexes) in {0: (1229, 91), 1: (1229, 91), 2: (1229, 91), 3: (1709, 127)}.items():
+        g = make(v)
+        assert g.num_moves() == moves == dim(v) * dim(v) * 10 + 18 + 1
+        assert int(np.asarray(g.canonicalized())[0].sum()) == hexes == 3 * SIDE[v] ** 2 + 3 * SIDE[v] + 1
+    for t in range(3):
+        v = 3                                            # Battle starts with every unit type in reserve
+        g = make(v)
+        before = np.asarray(g.canonicalized())
+        a = first_valid(g.valid_moves(), deploy_offset(v) + 6 * t, deploy_offset(v) + 6 * t + 6)
+        g.play_move(a)
+        u = [x for x in g.get_units() if x.type == t][0]
+        assert u.hp == max_hp[t] and u.player == 0
+        obs = np.asarray(g.canonicalized())               # player 1's view now: player 0's new unit is an OPPONENT unit
+        opp_type_plane = 5 + t                            # channels 1-4 mine (F, C, D, portal), 5-8 the opponent's
+        assert int(obs[opp_type_plane].sum() - before[1 + t].sum()) == size[t]
+        # unfired cannon slots (channels 17-21) are shown for the viewer's OWN units, at the anchor hex only: once player 1 has
+        # deployed too, player 0 sees all the cannons of its fresh unit
+        g.play_move(first_valid(g.valid_moves(), deploy_offset(v), end_offset(v)))
+        assert g.current_player() == 0
+        assert int(np.asarray(g.canonicalized())[17:22].sum()) == cannons[t]
+
+
 ALL_CASES = [v for k, v in sorted(globals().items()) if k.startswith("case_")]

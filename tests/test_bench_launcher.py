@@ -50,3 +50,15 @@ def test_gpus_must_match_the_launcher():
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry", "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 2 and "launcher started 1 ranks" in r.stderr
+
+
+def test_gpus_8_dry_run_of_the_whole_node():
+    """the driver's N = 8 case, dry: eight rank processes rendezvous on 127.0.0.1 over gloo, every rank's samples reach rank 0,
+    the statistics are summed over the node, one JSON line comes out"""
+    r = _run("--gpus", "8", "--steps", "5", "--warmup", "1")
+    assert r.returncode == 0, r.stderr
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 8 and j["scaling"] == "weak"
+    assert j["config"]["games_in_window"] == 8 * 5 * 4096 // 4
+    assert j["config"]["samples_gathered"] == 5 * sum(8 + k for k in range(8)) == j["config"]["samples_in_window"]
+    assert j["config"]["node_stats"]["sum"] == [36.0 * i for i in range(16)]

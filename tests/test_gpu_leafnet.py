@@ -4,9 +4,11 @@
 
 Tolerance: the kernel computes the convolutions with bf16 operands and fp32 accumulation (what the
 reference's `process()` does under bf16 autocast, neural_net.py:811-813) and keeps the residual
-stream and the heads in fp32, so it is compared with the fp32 reference at |dp| <= 2e-2 on
-probabilities (bf16 has 8 significand bits; 13 stacked convolutions), and must be at least as close
-to fp32 as torch's own bf16-autocast forward.  The 1e-5 tier needs fp32 operands.
+stream and the heads in fp32.  Measured against the reference NNArch's fp32 outputs on the random-init
+fixtures: Connect4 max |dpi| 2.2e-4, |dv| 5.2e-5, the spatial nets below 1e-5; the bound asserted for
+every random-init fixture is TOL = 1e-3 (about 4 x the worst measured), and the kernel must be at least as
+close to fp32 as torch's own bf16-autocast forward (6.4e-4 on Connect4).  The peaked-net test further down
+asserts 2-3 x its own measured errors.  The 1e-5 tier needs fp32 operands (precision="fp32").
 """
 import os
 
@@ -16,7 +18,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-TOL = 2e-2
+TOL = 1e-3
 
 
 def _fixture_net():

@@ -362,6 +362,33 @@ def test_gumbel_mcts_known_answers(oracle):
     assert sorted((int(c) for c in f.counts() if c > 0), reverse=True) == [5, 5, 1, 1]
 
 
+def test_gumbel_effective_m_and_prior_tables(oracle):
+    """the remaining tables of the reference's test_gumbel.py, read off the oracle's MCTS on Connect4 (7 legal moves):
+    effective m = max(1, min(gumbel_m, legal moves, simulations)) (test_gumbel.py:298-318, mcts.cc:190-227) as the number of
+    Gumbel-top-k survivors after the lazy initialisation, and pi' = the prior while nothing has been visited
+    (test_improved_policy_no_visits_equals_prior, test_gumbel.py:207-218)."""
+    gs = oracle.Game(oracle.GAME_CONNECT4)
+    for gumbel_m, sims, want in ((16, 32, 7),      # capped by the legal moves
+                                 (16, 240, 7),
+                                 (16, 5, 4),       # capped by the simulations LEFT when the root has been evaluated (mcts.cc:190-199: target - depth)
+                                 (4, 240, 4),      # no cap: gumbel_m
+                                 (1, 10, 1), (0, 10, 1)):   # never below one
+        m = oracle.Mcts(2.0, 2, 7, gumbel_enabled=True, gumbel_m=gumbel_m, seed=3)
+        m.set_gumbel_num_sims(sims)
+        m.find_leaf(gs)
+        m.process_result(np.full(3, 1 / 3, np.float32), np.full(7, 1 / 7, np.float32))
+        m.find_leaf(gs)                 # the first descent below an evaluated root initialises the Gumbel state
+        sv, _ = m.gumbel_state()
+        assert len(sv) == want, (gumbel_m, sims, len(sv))
+        assert len(set(int(x) for x in sv)) == len(sv) and all(0 <= int(x) < 7 for x in sv)     # top-k WITHOUT replacement (test_gumbel.py:338-345)
+    prior = np.array([0.05, 0.3, 0.1, 0.25, 0.1, 0.15, 0.05], np.float32)
+    m = oracle.Mcts(2.0, 2, 7, gumbel_enabled=True, gumbel_m=16, seed=4)
+    m.set_gumbel_num_sims(64)
+    m.find_leaf(gs)
+    m.process_result(np.array([0.2, 0.5, 0.3], np.float32), prior)
+    assert np.allclose(m.gumbel_improved_policy(), prior, atol=1e-6)
+
+
 # ---------------------------------------------------------------- Brandubh / OpenTafl (opentafl_gs_test.cc, brandubh_gs_test.cc)
 def test_opentafl_rule_known_answers(oracle):
     import tafl_cases as tc
