@@ -79,7 +79,7 @@ __global__ void k_pipe_seed(EngineParams ep, EngineArrays ar, PipeArrays pa) {
     return;
   }
   const uint32_t pos = atomicAdd(&pc->rtail, 1u);
-  g_st(pa.rring + (pos & (kPipeRing - 1u)), (pipe_lap_tag(pos) << 48) | static_cast<unsigned long long>(slot));
+  g_st(pa.rring + (pos & (kPipeRing - 1u)), (pipe_lap_tag(pos) << 48) | static_cast<unsigned long long>(slot));     // (answers no request: sequence field 0)
 }
 
 // NT: threads per workgroup.  512 = eight wavefronts of 256 registers: the workgroup has a CU to itself, so no tree wavefront
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
   while (go) {
     const uint64_t pf_t0 = wall_clock64();
     // ---- tokens for this pass: the arrived prefix of the window's rest
-    uint32_t my_slot = 0xFFFFFFFFu, n_tok = 0, empty_polls = 0, ctl_word = 0;
+    uint32_t my_slot = 0xFFFFFFFFu, tok_seq = 0, n_tok = 0, empty_polls = 0, ctl_word = 0;
     uint64_t t_first = 0;
     for (;;) {
       if (wdone == wn) {
@@ -162,7 +162,8 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
       if (k == left || (k != 0u && t_first != 0 && now - t_first > kTreePatience)) {
         n_tok = k;
         const uint32_t sl = static_cast<uint32_t>(__shfl(static_cast<uint32_t>(tok & 0xFFFFull), static_cast<int>(grp * 8), 64));
-        if (grp < k) my_slot = sl;
+        const uint32_t sq = static_cast<uint32_t>(__shfl(static_cast<uint32_t>((tok >> 16) & 0xFFFFFFFFull), static_cast<int>(grp * 8), 64));
+        if (grp < k) { my_slot = sl; tok_seq = sq; }
         break;
       }
       if (k != 0u && t_first == 0) t_first = now;
@@ -173,10 +174,23 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
     const uint64_t pf_t1 = wall_clock64();
     pf_idle += pf_t1 - pf_t0; pf_n += 1; pf_act += n_tok;
 
-    // ---- the pass: this CU's L1 may hold lines of these slots from an earlier pass here
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // ---- the pass.  A token that answers a request (its sequence field is not 0) may be here before the wavefront that sent
+    // the request - early, in the middle of its own pass - has put the slot back: req_seq[slot] is written last, behind that
+    // pass's release, so the slot is whole once it shows the token's sequence number.  Then the acquire: this CU's L1 may hold
+    // lines of these slots from an earlier pass here.
     const bool on = my_slot != 0xFFFFFFFFu;
     const uint32_t slot = on ? my_slot : 0u;
+    if (on && tok_seq != 0u) {
+      while (g_ld(ar.req_seq + slot) != tok_seq) {
+        if (wall_clock64() - t_start > pa.cap_ticks) {
+          if (lane == 0 && atomicAdd(&pc->dbg[0], 1u) == 0u) { pc->dbg[1] = slot; pc->dbg[2] = tok_seq; pc->dbg[3] = g_ld(ar.req_seq + slot); pc->dbg[4] = 0xEEEEu; }
+          if (lane == 0) atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTag));
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     c.slot = slot;
     uint32_t st = kGrpIdle;
     uint8_t final_state = kSlotWaitEval;
@@ -199,8 +213,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
     float fl_pr = 0.0f;
     uint32_t sims_done = 0, sims_mem = 0;
     bool rec_ok = true, answered = false;
-    uint64_t cur_key = 0, push_b0 = 0, push_b1 = 0;
-    uint32_t push_pl = 0;
+    uint64_t cur_key = 0;
     if (on) {
       c.load();
       cp = c.gs.player;
@@ -407,7 +420,17 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
           const uint64_t key = GM::key(leaf);
           const bool hit = ep.cache_on && c.cache_lookup(key, 0u, reg_pi, reg_v);
           if (!hit) {
-            cur_key = key; push_b0 = leaf.bb[0]; push_b1 = leaf.bb[1]; push_pl = leaf.player;
+            // the request goes out NOW, not when the pass ends (its slowest group may run two more simulations): the net's
+            // answer and this pass's tail overlap.  Nobody can take the slot before it is back: see the pass start.
+            cur_key = key;
+            seq = seq + 1u == 0u ? 1u : seq + 1u;
+            uint32_t pos = 0;
+            if (lane == 0) pos = atomicAdd(&pc->tail, 1u);
+            pos = c.bcast(pos, 0);
+            const uint64_t payload = lane == 0 ? leaf.bb[0] : lane == 1 ? leaf.bb[1] : lane == 2 ? (static_cast<uint64_t>(slot) | (static_cast<uint64_t>(leaf.player) << 16))
+                                                                                                  : static_cast<uint64_t>(seq);
+            if (lane < kReqGranules)
+              g_st(pa.ring + static_cast<size_t>(pos & (kPipeRing - 1u)) * kReqGranules + lane, (pipe_lap_tag(pos) << 48) | (payload & kMask48));
             st = kGrpPush;
           }
         }
@@ -426,10 +449,9 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
 
     // ---- the slots go back to HBM (k_sim's exit); the request's sequence number is drawn here, its flag is part of the state
     if (on) {
-      if (st == kGrpPush) { seq = seq + 1u == 0u ? 1u : seq + 1u; c.flags |= kFlagReqOut; }
+      if (st == kGrpPush) c.flags |= kFlagReqOut;
       if (lane == 0) {
         if (sims_done) ar.c_sims[slot] += sims_done;
-        ar.req_seq[slot] = seq;
         if (st == kGrpPush) { ar.c_evals[slot] += 1; ar.leaf_key[slot] = cur_key; }
       }
       if (rec_ok) {
@@ -445,21 +467,10 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
     // everything this pass wrote is visible before any of its tokens is
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // ---- tokens out: requests for the new leaves that need the net, READY tokens for the slots whose next answer is at hand
+    // the slot is whole: publish it (the word a token's taker waits for)
+    if (on && lane == 0) g_st(ar.req_seq + slot, seq);
+    // ---- tokens out: READY tokens for the slots whose next answer is at hand (the requests went out when their leaves were found)
     {
-      const unsigned long long pm = __ballot(st == kGrpPush && lane == 0);
-      if (pm) {
-        uint32_t base = 0;
-        if (wlane == 0) base = atomicAdd(&pc->tail, static_cast<uint32_t>(__popcll(pm)));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (st == kGrpPush) {
-          const uint32_t pos = base + static_cast<uint32_t>(__popcll(pm & ((1ull << (grp * 8)) - 1ull)));
-          const uint64_t payload = lane == 0 ? push_b0 : lane == 1 ? push_b1 : lane == 2 ? (static_cast<uint64_t>(slot) | (static_cast<uint64_t>(push_pl) << 16))
-                                                                                          : static_cast<uint64_t>(seq);
-          if (lane < kReqGranules)
-            g_st(pa.ring + static_cast<size_t>(pos & (kPipeRing - 1u)) * kReqGranules + lane, (pipe_lap_tag(pos) << 48) | (payload & kMask48));
-        }
-      }
       const unsigned long long rm = __ballot(st == kGrpReady && lane == 0);
       if (rm) {
         uint32_t base = 0;
@@ -636,7 +647,7 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
       base = __builtin_amdgcn_readfirstlane(base);
       if (tid < n) {
         const uint32_t pos = base + tid;
-        g_st(pa.rring + (pos & (kPipeRing - 1u)), (pipe_lap_tag(pos) << 48) | static_cast<unsigned long long>(xs[8 + tid]));
+        g_st(pa.rring + (pos & (kPipeRing - 1u)), (pipe_lap_tag(pos) << 48) | static_cast<unsigned long long>(xs[8 + tid]) | (static_cast<unsigned long long>(xs[16 + tid]) << 16));
       }
     }
   }
@@ -758,11 +769,12 @@ int pipe_create(azmi_pm* pm, size_t tile_lds) {
   if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.res, static_cast<size_t>(S) * kResStride);
   if (rc != AZMI_OK) return rc;
   // tree workgroups: lane-groups for half of the slots (the other half is with the net at any time; slots are not bound to
-  // wavefronts).  Measured at 4096 slots, 3-board tiles: 48 / 64 / 80 / 128 workgroups -> 56 / 68 / 62 / 60 M simulations/s: more
-  // of them take places from the net side and run each pass slower.  AZMI_PIPE_TREE_WGS sets another count.
+  // wavefronts).  Measured at 4096 slots: 64 / 96 / 128 workgroups -> 64 / 71 / 68 M simulations/s: more of them take places
+  // from the net side and run each pass slower (44 / 50 / 53 us).  AZMI_PIPE_TREE_WGS sets another count.
   // Beyond that the tree side is paid for in net places without being short of lane-groups: at 16384 slots 256 tree workgroups
   // (256 net workgroups left) ran 37 M simulations/s, fewer than the 4096-slot engine.
-  ps->tree_wgs = std::min<uint32_t>(96u, std::max<uint32_t>(1u, (S * Connect4::GROUP + 511u) / 512u));
+  // (With the requests sent early - pass start, below - the answers come back sooner and 96 workgroups beat 64: 71 vs 64 M.)
+  ps->tree_wgs = std::min<uint32_t>(96u, std::max<uint32_t>(1u, (S * 3u + 127u) / 128u));
   if (const char* e = getenv("AZMI_PIPE_TREE_WGS")) ps->tree_wgs = std::max(1, atoi(e));
   pa.n_tree_wgs = ps->tree_wgs;
   ps->lds_bytes = tile_lds + kPipeXs;

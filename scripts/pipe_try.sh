@@ -1,2 +1,4 @@
-timeout -k 10 300 python -m pytest tests/test_gpu_pipeline.py -x -q 2>&1 | tail -3
-BLOCKS=1 PRE=0.5 E=100 timeout -k 10 280 python scripts/pipe_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-600 | tail -4
+run() { echo "== $*"; env "$@" AZMI_PIPE_PROF=1 BLOCKS=2 PRE=2 E=300 timeout -k 10 280 python scripts/pipe_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-400 | tail -3; }
+run AZMI_PIPE_TREE_WGS=96
+run AZMI_PIPE_TREE_WGS=128
+run AZMI_PIPE_TREE_WGS=128 MAXI=2
