@@ -92,7 +92,7 @@ def self_play(game, params, net=None, engines=None, seed=20240601, device=0, str
         sps = [s.cuda_stream for s in streams]
         live = list(range(K))
         tdev = torch.device("cuda", device)
-        spe = 64 * int(params.concurrent_games)
+        spe = 96 * int(params.concurrent_games)
         while live:
             group = [pms[i] for i in live]
             if want_pipe:

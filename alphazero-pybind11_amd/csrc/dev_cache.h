@@ -338,21 +338,25 @@ template <bool PROBE_SAFE = true>
 __device__ inline bool wave_shard_insert_locked(const CacheView& c, uint32_t* locks, uint64_t hash, float p_lane, float v_lane,
                                                 uint32_t lane, uint32_t spin_cap = 1u << 20) {
   const uint32_t sh = static_cast<uint32_t>(hash % c.shards);
-  {
-    const uint64_t have = c_ld<true>(c.hashes + static_cast<size_t>(sh) * kWaveCap + lane);
-    if (__ballot(have == cache_key(hash)) != 0ull) return true;
-  }
+  // the key check and the first try at the lock travel together (one round trip): an entry that is already there gives the lock
+  // straight back; a wavefront that waits for the lock keeps looking at the keys, so a batch of identical positions - every
+  // slot's opening move - is done with the shard as soon as the first of them is in
   uint32_t got = 0;
-  if (lane == 0) {
-    for (uint32_t spins = 0; spins < spin_cap; ++spins) {
-      if (__hip_atomic_load(locks + sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-        uint32_t expect = 0u;
-        if (__hip_atomic_compare_exchange_strong(locks + sh, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { got = 1; break; }
-      }
-      __builtin_amdgcn_s_sleep(8);
+  for (uint32_t spins = 0; spins < spin_cap; ++spins) {
+    const uint64_t have = c_ld<true>(c.hashes + static_cast<size_t>(sh) * kWaveCap + lane);
+    uint32_t g = 0;
+    if (lane == 0) {
+      uint32_t expect = 0u;
+      g = __hip_atomic_compare_exchange_strong(locks + sh, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
     }
+    g = uni(g);
+    if (__ballot(have == cache_key(hash)) != 0ull) {
+      if (g && lane == 0) __hip_atomic_store(locks + sh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return true;
+    }
+    if (g) { got = 1; break; }
+    __builtin_amdgcn_s_sleep(8);
   }
-  got = uni(got);
   if (!got) return false;
   {
     WaveShardT<true> ws(c, sh, lane);

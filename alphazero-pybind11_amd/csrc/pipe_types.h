@@ -60,7 +60,8 @@ struct PipeEpoch {        // an allocation of its own, zeroed before every epoch
   uint32_t waiting;       // slots whose next step is the move step's (listed for it): they idle until the epoch ends
   uint32_t dead;          // slots without a game (retired, or ended and not yet restarted)
   uint32_t tree_late, net_late;   // census: the latest start of a tree / net workgroup, in 100 MHz ticks after the first workgroup of the epoch
-  uint32_t pad1[21];
+  uint32_t ins_done;      // insert-log entries already applied (the first insert launch runs while the net side drains)
+  uint32_t pad1[20];
 };
 static_assert(sizeof(PipeEpoch) == 256, "memset block: a multiple of 16 bytes");
 

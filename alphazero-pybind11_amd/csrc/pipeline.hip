@@ -699,20 +699,24 @@ __global__ void k_pipe_settle(EngineParams ep, EngineArrays ar, PipeArrays pa) {
 // The epoch's answers go into the position cache (PlayManager::update_inferences -> insert_many, play_manager.cc:631-640): one
 // wavefront per log entry, under the shard's insert lock (dev_cache.h).  The order of the inserts is the order the
 // wavefronts get there - the reference's is the order its threads get the mutex.
-__global__ __launch_bounds__(256) void k_pipe_cache_insert(EngineArrays ar, PipeArrays pa) {
+// Two launches per epoch: `late` = 0 right behind the tree kernel - the log holds every answer a tree wavefront consumed - while
+// the net side is still finishing its last tiles (it does not touch the cache); `late` = 1 after k_pipe_settle for the few answers
+// that arrived when the tree side had left.
+__global__ __launch_bounds__(256) void k_pipe_cache_insert(EngineArrays ar, PipeArrays pa, uint32_t late) {
   const uint32_t n = min(pa.ep->ins_count, pa.ins_cap);
+  const uint32_t from = late ? min(pa.ep->ins_done, n) : 0u;
+  if (!late && blockIdx.x == 0 && threadIdx.x == 0) pa.ep->ins_done = n;     // (read by the second launch only; the log does not grow before k_pipe_settle)
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
   const uint32_t waves = gridDim.x * (blockDim.x >> 6);
   constexpr uint32_t M = Connect4::M, P1 = Connect4::P + 1;
-  for (uint32_t i = wave; i < n; i += waves) {
+  for (uint32_t i = from + wave; i < n; i += waves) {
     const uint64_t key = pa.ins_key[i];
     const float p = lane < M ? pa.ins_pi[static_cast<size_t>(i) * M + lane] : 0.0f;
     const float v = lane < P1 ? pa.ins_v[static_cast<size_t>(i) * P1 + lane] : 0.0f;
     if (!wave_shard_insert_locked<false>(ar.cache, pa.locks, key, p, v, lane) && lane == 0) atomicOr(&pa.ctl->err, static_cast<uint32_t>(kPipeErrLock));
   }
 }
-
 // ---- host side ------------------------------------------------------------------------------------------------------------------------
 struct PipeState {
   PipeArrays pa{};
@@ -885,6 +889,10 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
     else k_pipe_tree<Connect4, 256><<<ps->tree_wgs, 256, 0, st>>>(pm->ep, pm->ar, pa);
     AZMI_HIP_TRY(hipGetLastError());
     AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 3], st));
+    if (pm->ep.cache_on) {      // behind the tree kernel, beside the net side's last tiles
+      k_pipe_cache_insert<<<2048, 256, 0, st>>>(pm->ar, pa, 0u);
+      AZMI_HIP_TRY(hipGetLastError());
+    }
     AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 0], ps->net_stream));
     if (net_mode == 1) k_pipe_net<1><<<ps->net_wgs, 256, ps->lds_bytes, ps->net_stream>>>(view.nd, view.np, pa);
     else if (net_mode == 2) k_pipe_net<2><<<ps->net_wgs, 256, ps->lds_bytes, ps->net_stream>>>(view.nd, view.np, pa);
@@ -900,7 +908,7 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
     rc = azmi_host_launch_assign(pm, st, 1u);
     if (rc != AZMI_OK) return rc;
     if (pm->ep.cache_on) {
-      k_pipe_cache_insert<<<2048, 256, 0, st>>>(pm->ar, pa);
+      k_pipe_cache_insert<<<256, 256, 0, st>>>(pm->ar, pa, 1u);
       AZMI_HIP_TRY(hipGetLastError());
     }
     if (getenv("AZMI_PIPE_DEBUG")) {      // stop at the first epoch that raised an error, with that epoch's own counters

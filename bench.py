@@ -56,7 +56,7 @@ def parse(argv=None):
     ap.add_argument("--driver", choices=["auto", "pipeline", "rounds"], default="auto",
                     help="pipeline = asynchronous tree / net pipeline (azmi_run_pipeline: Connect4, PUCT); rounds = lock-step rounds "
                          "(azmi_run_rounds); auto = the pipeline where it applies")
-    ap.add_argument("--sims-per-epoch", type=int, default=None, help="pipeline driver: simulations per epoch (default 64 x concurrent games)")
+    ap.add_argument("--sims-per-epoch", type=int, default=None, help="pipeline driver: simulations per epoch (default 96 x concurrent games)")
     ap.add_argument("--game", choices=["connect4", "tawlbwrdd", "stargambit"], default="connect4",
                     help="connect4 = BASELINE configs[1] (the headline); tawlbwrdd = configs[2] (2048 games, 400 sims, YAML net); "
                          "stargambit = configs[4] per GPU (star_gambit_unified, 1024 games, 800 sims, 200000-entry device cache)")
@@ -451,7 +451,7 @@ def main():
                     v_buf.copy_(v)
                     pi_buf.copy_(pi)
 
-        spe = args.sims_per_epoch or 64 * S
+        spe = args.sims_per_epoch or 96 * S
         pipe_acc = {"net_us": 0.0, "tree_us": 0.0, "epochs": 0, "tiles": 0, "boards": 0, "late": 0}
 
         def run_rounds_on(group, n, ev=None):
@@ -707,7 +707,21 @@ def main():
             # rocprofv3 --pmc summary of this same command (scripts/gpu_pmc.sh -> profiles/rN_pmc_traffic.csv), per launch,
             # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on gfx950
             pmc = next((p for p in (os.path.join(ROOT, "profiles", f"r{n}_pmc_traffic{'_stargambit' if sg else '_tawlbwrdd' if tafl else ''}.csv") for n in (2, 1)) if os.path.exists(p)), None)
-            if hip_net is not None and pmc:
+            pmc3 = os.path.join(ROOT, "profiles", "r3_pmc_traffic.csv")
+            if use_pipe and os.path.exists(pmc3):
+                # the pipeline's two kernels of an epoch must be co-resident and counter collection serialises dispatches
+                # (profiles/r3_pmc_pipeline_probe.txt), so the counters are taken on k_pipe_net ALONE draining a pre-filled ring
+                # (scripts/pipe_net_pmc.py): bytes per position there x the positions of an average launch here
+                for line in open(pmc3):
+                    f = line.strip().split(",")
+                    if f[0].startswith("k_pipe_net") and float(f[2]) > 0:
+                        b_pos = (2.0 * float(f[3]) + float(f[4])) * 1024.0 / float(f[2])
+                        out["roofline"]["traffic"] = b_pos * rows_evaluated / launches
+                        out["roofline"]["traffic_note"] = ("L2-to-fabric bytes per k_pipe_net launch = %.0f B per position (2 x FETCH_SIZE + WRITE_SIZE of the net kernel alone "
+                                                           "on a pre-filled request ring, profiles/r3_pmc_traffic.csv taken at commit %s) x the positions of an average launch; "
+                                                           "the co-resident tree kernel cannot be counted (rocprofv3 --pmc serialises dispatches)" % (b_pos, f[5]))
+                out["roofline_tree"]["traffic_note"] = "not collected: see roofline.traffic_note"
+            elif hip_net is not None and pmc:
                 for line in open(pmc):
                     f = line.strip().split(",")
                     if ("k_round_big" in line) if tafl else ("k_sim<" in line or "k_round<azmi::Connect4" in line):
@@ -751,7 +765,7 @@ def main():
 
                     def run2(n, pms2=pms2, pipe2=pipe2, net2=net2, S2=S2, sps2=sps2):
                         if pipe2:
-                            az.run_pipeline(pms2[0], net2, n, 64 * S2, sps2[0])
+                            az.run_pipeline(pms2[0], net2, n, 96 * S2, sps2[0])
                         else:
                             done2 = 0
                             while done2 < n:
