@@ -195,12 +195,35 @@ def fold_fp32(net):
     return desc, bytes(blob)
 
 
+def _split_frags(wmat, passes=("hi", "hi", "lo")):
+    """wmat [64][K] (K = 64 * taps) -> the bf16x3 weight stream of one convolution: per tap (two k-steps = one 8 KB chunk) the
+    high parts' fragments, the high parts' again, the low parts' (w = hi + lo; csrc/leafnet_c4.h SPLIT: the three chunks meet
+    the activations' high, low and high planes)."""
+    w = torch.as_tensor(np.ascontiguousarray(wmat), dtype=torch.float64)
+    hi = w.float().to(torch.bfloat16).double()
+    lo = w - hi
+    fh = np.frombuffer(_frags(hi.numpy()), np.int16).reshape(-1, 2, 4, 64, 8)     # [tap][2 k-steps][4 m-tiles][64 lanes][8]
+    fl = np.frombuffer(_frags(lo.numpy()), np.int16).reshape(-1, 2, 4, 64, 8)
+    out = bytearray()
+    for t in range(fh.shape[0]):
+        for which in passes:
+            out += (fh if which == "hi" else fl)[t].tobytes()
+    return bytes(out)
+
+
 def fold(net, precision="bf16"):
-    """LeafNet (reference NNArch parameter names) -> (NetDescC, blob bytes)."""
+    """LeafNet (reference NNArch parameter names) -> (NetDescC, blob bytes).  precision: "bf16" (bf16 MFMA operands), "bf16x3"
+    (Connect4 family: weights and activations as bf16 high + low parts, three MFMAs per product - the 1e-5 tier on the matrix
+    cores) or "fp32" (plain fp32 kernels, any shape)."""
     if precision == "fp32":
         return fold_fp32(net)
     spec = net.spec
+    x3 = precision == "bf16x3"
+    if precision not in ("bf16", "bf16x3"):
+        raise ValueError("precision must be 'bf16', 'bf16x3' or 'fp32'")
     if spec.policy_shape is not None:
+        if x3:
+            raise RuntimeError("precision='bf16x3' covers the Connect4 net family; spatial-head nets: 'bf16' or 'fp32'")
         return fold_spatial(net)
     Cin, H, W = spec.in_shape
     if not (spec.num_channels == 64 and spec.head_channels == 32 and spec.kernel_size == 3 and spec.policy_shape is None
@@ -216,19 +239,20 @@ def fold(net, precision="bf16"):
     w = sd["conv1.weight"] * a[:, None, None, None]                  # [64][Cin][3][3]
     wm = np.zeros((64, 64))
     wm[:, : 9 * Cin] = w.permute(0, 2, 3, 1).reshape(64, 9 * Cin).numpy()  # k = tap*Cin + ci
-    blob += _frags(wm) + _f32(b)
+    blob += (_split_frags(wm, ("hi", "lo")) if x3 else _frags(wm)) + _f32(b)       # (inputs are 0 / 1: only the weights split)
+    conv = (lambda m: _split_frags(m)) if x3 else _frags
     for i, blk in enumerate(net.conv_layers):
         a1, b1 = (t.cpu() for t in bn_affine(blk.bn1))
         a2, b2 = (t.cpu() for t in bn_affine(blk.bn2))
         w1 = sd[f"conv_layers.{i}.conv1.weight"] * a2[:, None, None, None]
         w2 = sd[f"conv_layers.{i}.conv2.weight"]
         blob += _f32(a1) + _f32(b1) + _f32(b2)
-        blob += _frags(w1.permute(0, 2, 3, 1).reshape(64, 576).numpy())   # k = tap*64 + ci
-        blob += _frags(w2.permute(0, 2, 3, 1).reshape(64, 576).numpy())
+        blob += conv(w1.permute(0, 2, 3, 1).reshape(64, 576).numpy())   # k = tap*64 + ci
+        blob += conv(w2.permute(0, 2, 3, 1).reshape(64, 576).numpy())
     av, bv = (t.cpu() for t in bn_affine(net.v_bn))
     ap, bp = (t.cpu() for t in bn_affine(net.pi_bn))
     wh = torch.cat([sd["v_conv.weight"][:, :, 0, 0] * av[:, None], sd["pi_conv.weight"][:, :, 0, 0] * ap[:, None]], 0)
-    blob += _frags(wh.numpy()) + _f32(torch.cat([bv, bp]))
+    blob += conv(wh.numpy()) + _f32(torch.cat([bv, bp]))
     blob += _f32(sd["v_fc1.weight"].t().contiguous()) + _f32(sd["v_fc1.bias"])       # [32][hidden]
     blob += _f32(sd["v_fc2.weight"]) + _f32(sd["v_fc2.bias"])
     # flat policy head: the reference's feature order is (c, h, w) -> c*HW + p.  The kernel contracts one pixel position p at
@@ -241,7 +265,7 @@ def fold(net, precision="bf16"):
     for p_ in range(H * W):
         blob += _frags(hi[:, :, p_].numpy()) + _frags(lo[:, :, p_].numpy())
     blob += _f32(sd["pi_fc1.bias"])
-    desc = NetDescC(Cin, H, W, 64, spec.depth, 3, 32, spec.v_fc_hidden, spec.num_moves, spec.num_players, 0, 0, 1, 0, 0, 0)
+    desc = NetDescC(Cin, H, W, 64, spec.depth, 3, 32, spec.v_fc_hidden, spec.num_moves, spec.num_players, 0, 0, 1, 0, 2 if x3 else 0, 0)
     assert len(blob) == lib.azmi_net_blob_bytes(C.byref(desc)), (len(blob), lib.azmi_net_blob_bytes(C.byref(desc)))
     return desc, bytes(blob)
 
@@ -250,8 +274,9 @@ class HipLeafNet:
     """The fused MFMA kernel as an evaluator: forward(canonical, v_out, pi_out) on device tensors."""
 
     def __init__(self, net, spec=None, max_batch=None, device=0, precision="bf16"):
-        """precision: "bf16" = MFMA fast path (bf16 operands, fp32 accumulate); "fp32" = plain fp32 path for the
-        1e-5 parity tier."""
+        """precision: "bf16" = MFMA fast path (bf16 operands, fp32 accumulate); "bf16x3" = the same tile with split operands
+        (hi + lo bf16 parts, three MFMAs per product; Connect4 family): the 1e-5 tier on the matrix cores; "fp32" = plain fp32
+        kernels for any shape."""
         self.desc, blob = fold(net, precision)
         self._blob = blob
         h = C.c_void_p()

@@ -54,6 +54,7 @@ int nfail(int code, const char* fmt, ...) {
 struct azmi_net {
   NetDesc nd{};
   NetPtrs np{};
+  bool x3 = false;           // precision = 2: the Connect4-family tile with split bf16 operands (leafnet_c4.h, SPLIT)
   void* f32 = nullptr;       // precision = 1: the fp32 path (leafnet_f32.hip) owns everything
   void* f32_last_stream = nullptr;
   bool f32_last_stream_set = false;
@@ -136,10 +137,12 @@ size_t azmi_net_blob_bytes(const azmi_net_desc* d) {
   if (!d) return 0;
   if (d->precision == 1) return azmi_f32::blob_bytes(d);
   if (is_spatial(d)) return spatial_blob_bytes(d);
-  const size_t wconv = 18 * MT * WFRAG_BYTES, wsmall = 2 * MT * WFRAG_BYTES;
-  size_t n = wsmall + CH * 4;
+  // precision 2 (bf16x3): the stem's fragments twice (high, low parts), three chunks per tap and for the head 1x1 (leafnet_c4.h, SPLIT)
+  const size_t x3 = d->precision == 2 ? 3 : 1;
+  const size_t wconv = x3 * 18 * MT * WFRAG_BYTES, wsmall = 2 * MT * WFRAG_BYTES;
+  size_t n = (d->precision == 2 ? 2 : 1) * wsmall + CH * 4;
   n += static_cast<size_t>(d->depth) * (3 * CH * 4 + 2 * wconv);
-  n += wsmall + CH * 4;
+  n += x3 * wsmall + CH * 4;
   n += (static_cast<size_t>(d->v_hidden) * HC + d->v_hidden) * 4;
   n += (static_cast<size_t>(d->num_players + 1) * d->v_hidden + d->num_players + 1) * 4;
   n += static_cast<size_t>(d->height) * d->width * 2 * WFRAG_BYTES + static_cast<size_t>(d->num_moves) * 4;   // policy FC: bf16 hi / lo fragments per pixel position
@@ -158,7 +161,8 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
     *out = net;
     return AZMI_OK;
   }
-  if (d->precision != 0) return nfail(AZMI_ERR_INVALID, "precision must be 0 (bf16 MFMA) or 1 (fp32)");
+  if (d->precision != 0 && d->precision != 2) return nfail(AZMI_ERR_INVALID, "precision must be 0 (bf16 MFMA), 1 (fp32) or 2 (bf16x3: split bf16 MFMA, Connect4 family)");
+  if (d->precision == 2 && is_spatial(d)) return nfail(AZMI_ERR_INVALID, "precision 2 (bf16x3) covers the Connect4-family net; spatial nets: 0 or 1");
   if (is_spatial(d)) {
     if (d->channels != CH || d->head_channels != sp::HCS || d->kernel_size != 3 || d->v_head_convs != 1 || d->pi_head_convs != 1)
       return nfail(AZMI_ERR_INVALID, "spatial leaf net kernel covers 64 trunk / 64 head channels, 3x3 convs, one extra conv per head");
@@ -237,12 +241,14 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
   if (hipMemcpy(net->blob, blob, blob_bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(net->blob); delete net; return nfail(AZMI_ERR_NO_DEVICE, "weight upload failed"); }
   net->blob_bytes = blob_bytes;
   const uint8_t* p = static_cast<const uint8_t*>(net->blob);
-  const size_t wconv = 18 * MT * WFRAG_BYTES, wsmall = 2 * MT * WFRAG_BYTES;
+  const bool x3 = d->precision == 2;
+  net->x3 = x3;
+  const size_t wconv = (x3 ? 3 : 1) * 18 * MT * WFRAG_BYTES, wsmall = 2 * MT * WFRAG_BYTES;
   NetPtrs& np = net->np;
-  np.stem_w = p; p += wsmall;
+  np.stem_w = p; p += (x3 ? 2 : 1) * wsmall;
   np.stem_b = reinterpret_cast<const float*>(p); p += CH * 4;
   np.blocks = p; p += static_cast<size_t>(d->depth) * (3 * CH * 4 + 2 * wconv);
-  np.head_w = p; p += wsmall;
+  np.head_w = p; p += (x3 ? 3 : 1) * wsmall;
   np.head_b = reinterpret_cast<const float*>(p); p += CH * 4;
   np.v_fc1_w = reinterpret_cast<const float*>(p); p += static_cast<size_t>(d->v_hidden) * HC * 4;
   np.v_fc1_b = reinterpret_cast<const float*>(p); p += static_cast<size_t>(d->v_hidden) * 4;
@@ -250,11 +256,15 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
   np.v_fc2_b = reinterpret_cast<const float*>(p); p += static_cast<size_t>(d->num_players + 1) * 4;
   np.pi_fc_w = p; p += static_cast<size_t>(d->height) * d->width * 2 * WFRAG_BYTES;
   np.pi_fc_b = reinterpret_cast<const float*>(p); p += static_cast<size_t>(d->num_moves) * 4;
-  net->lds_bytes = c4::TileBig::LDS_BYTES;
+  net->lds_bytes = x3 ? c4::TileBigX3::LDS_BYTES : c4::TileBig::LDS_BYTES;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&c4::k_leafnet_c4<c4::TileBig, 4, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           static_cast<int>(c4::TileBig::LDS_BYTES)) != hipSuccess ||
       hipFuncSetAttribute(reinterpret_cast<const void*>(&c4::k_leafnet_c4<c4::TileSmall, 4, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          static_cast<int>(c4::TileSmall::LDS_BYTES)) != hipSuccess) {
+                          static_cast<int>(c4::TileSmall::LDS_BYTES)) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&c4::k_leafnet_c4<c4::TileBigX3, 4, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          static_cast<int>(c4::TileBigX3::LDS_BYTES)) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&c4::k_leafnet_c4<c4::TileSmallX3, 4, 4, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          static_cast<int>(c4::TileSmallX3::LDS_BYTES)) != hipSuccess) {
     (void)hipFree(net->blob); delete net;
     return nfail(AZMI_ERR_NO_DEVICE, "cannot reserve %zu bytes of LDS", net->lds_bytes);
   }
@@ -281,7 +291,15 @@ static int net_forward_live(azmi_net* net, const float* dev_canonical, float* de
 // (a launch of a few hundred rows is a LATENCY: leafnet_c4.h, Tile)
 static void c4_launch(azmi_net* net, const float* canon, float* v, float* pi, uint32_t rows_max, const uint32_t* rows, const uint32_t* row_count,
                       hipStream_t st) {
-  if (rows_max >= 512u * c4::TileBig::TBW) {
+  if (net->x3) {      // one workgroup per CU (16 activation planes): 6-board tiles once the 3-board ones would need a second pass over the chip
+    if (rows_max > 256u * c4::TileSmallX3::TBW) {
+      const uint32_t tiles = (rows_max + c4::TileBigX3::TBW - 1) / c4::TileBigX3::TBW;
+      c4::k_leafnet_c4<c4::TileBigX3, 4, 4, 16><<<tiles, c4::NTH, c4::TileBigX3::LDS_BYTES, st>>>(net->nd, net->np, canon, v, pi, rows_max, rows, row_count);
+    } else {
+      const uint32_t tiles = (rows_max + c4::TileSmallX3::TBW - 1) / c4::TileSmallX3::TBW;
+      c4::k_leafnet_c4<c4::TileSmallX3, 4, 4, 16><<<tiles, c4::NTH, c4::TileSmallX3::LDS_BYTES, st>>>(net->nd, net->np, canon, v, pi, rows_max, rows, row_count);
+    }
+  } else if (rows_max >= 512u * c4::TileBig::TBW) {
     const uint32_t tiles = (rows_max + c4::TileBig::TBW - 1) / c4::TileBig::TBW;
     c4::k_leafnet_c4<c4::TileBig, 4, 4, 16><<<tiles, c4::NTH, c4::TileBig::LDS_BYTES, st>>>(net->nd, net->np, canon, v, pi, rows_max, rows, row_count);
   } else {
@@ -446,7 +464,7 @@ void azmi_net_eval_host(const float* canonical, uint32_t n, float* v, float* pi,
 }
 
 int azmi_net_c4_view_get(const azmi_net* net, azmi_net_c4_view* out) {
-  if (!net || !out || net->f32 || net->spatial) return 0;
+  if (!net || !out || net->f32 || net->spatial || net->x3) return 0;
   out->nd = net->nd; out->np = net->np; out->lds_bytes = c4::TileSmall::LDS_BYTES;   // the engine's fused launch runs the small tile
   return 1;
 }

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace azmi_net_dev {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -76,25 +78,33 @@ constexpr int PRM_FLOATS = CH + MAXDEPTH * 3 * CH + CH;    // stem bias | per bl
 // A-fragment reads, i.e. a shorter dependent chain per tile (the LDS, not the matrix pipe, then sets the k-step) for twice
 // the workgroups: what the engine's rounds want, where a launch is a few hundred rows and its LATENCY is what the round
 // waits for (at one workgroup per CU a 6-board tile takes 68 us, 55 of them matrix-pipe bound).
-template <int TBW_, int NTW_>
+// SPLIT (the "bf16x3" precision tier): weights and activations are carried as bf16 HIGH + LOW parts (x = hi + lo to ~16 bits of
+// mantissa) and every product runs as three MFMAs, hi*hi + hi*lo + lo*hi - the K dimension of each convolution tripled: per tap
+// three 8 KB chunks [W_hi][W_hi][W_lo] against the activation planes [X_hi][X_lo][X_hi].  Twice the activation planes (16), so one
+// workgroup per CU; everything else (ring, barriers, software pipeline) is the bf16 tile's.
+template <int TBW_, int NTW_, int SPLIT_ = 0>
 struct Tile {
   static constexpr int TBW = TBW_;                 // boards per workgroup
   static constexpr int NTW = NTW_;                 // n-tiles per wave
+  static constexpr int SPLIT = SPLIT_;
+  static constexpr int NPLANES = SPLIT_ ? 16 : 8;  // 8-channel activation planes (SPLIT: planes 8-15 hold the low parts)
   static constexpr int NPIX = TBW * PIX;           // GEMM columns in use
   static constexpr int NT = NWV * NTW;             // n-tiles
   static constexpr int ZSLOT = NT * 16;            // first all-zero cell
   static constexpr int SLOTS = ZSLOT + 16;
   static constexpr int PLANE = SLOTS * 16;         // a multiple of 256 B
   static constexpr int ZERO_OFF = ZSLOT * 16;
-  static constexpr int ACT_BYTES = 8 * PLANE;
+  static constexpr int ACT_BYTES = NPLANES * PLANE;
   static constexpr int LDS_BYTES = ACT_BYTES + RING_BYTES + PRM_FLOATS * 4;   // big: 80,896 - two workgroups per CU
   static_assert(NPIX <= NT * 16 && NPIX <= NTH, "the tile's pixels fit its n-tiles; one thread per pixel");
   static_assert(PLANE % 256 == 0, "conflict-free fragment reads need a plane stride that is a multiple of 256 B");
-  static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+  static_assert((SPLIT_ ? 1 : 2) * LDS_BYTES <= 160 * 1024, "two workgroups per CU (SPLIT: one)");
   static_assert(NPIX * HC * 4 + NWV * 256 * 4 <= RING_BYTES, "value-head scratch + policy partials reuse the ring");
 };
 using TileBig = Tile<6, 4>;
 using TileSmall = Tile<3, 2>;
+using TileBigX3 = Tile<6, 4, 1>;
+using TileSmallX3 = Tile<3, 2, 1>;
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 // 64 lanes x 16 B from per-lane global addresses into LDS at the wave-uniform `dst` + lane * 16, no VGPR destination.
@@ -176,8 +186,12 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
   const int col = lane & 15, quad = lane >> 4;
   const uint32_t board0 = tile_index * TBW;
   const int depth = nd.depth;
-  const int nchunks = 2 * depth * CHUNKS_PER_CONV + 1;        // + the head 1x1 weights, streamed as one more chunk
-  const size_t block_stride = 3 * CH * sizeof(float) + 2 * static_cast<size_t>(18 * MT * WFRAG_BYTES);
+  constexpr bool SPLIT = TG::SPLIT != 0;
+  constexpr int CPC = SPLIT ? 3 * CHUNKS_PER_CONV : CHUNKS_PER_CONV;     // weight chunks per 3x3 convolution
+  constexpr int HEADCH = SPLIT ? 3 : 1;                                  // ... of the head 1x1 convolution
+  static_assert(!(SPLIT && PIPE), "the pipeline runs the bf16 tiles");
+  const int nchunks = 2 * depth * CPC + HEADCH;               // + the head 1x1 weights, streamed as the run's last chunk(s)
+  const size_t block_stride = 3 * CH * sizeof(float) + 2 * static_cast<size_t>(CPC) * CHUNK_BYTES;
 
   // ---- small fp32 parameters -> LDS (plain loads, before any DMA is in flight) ------------------------------------
   if (tid < CH) { prm[tid] = np.stem_b[tid]; prm[CH + MAXDEPTH * 3 * CH + tid] = np.head_b[tid]; }
@@ -204,11 +218,13 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
     // after the run's last chunk (the head's) the stream keeps re-sending that chunk into slots nobody reads any more: the
     // tail of the run then needs no special cases - one wait count, no branch around the issue (see conv3x3)
     ++issued; ++in_block;
-    if (issued < nchunks - 1) {
+    if (issued < nchunks - HEADCH) {
       wnext += CHUNK_BYTES;
-      if (in_block == 2 * CHUNKS_PER_CONV) { in_block = 0; wnext += 3 * CH * sizeof(float); }
-    } else {
+      if (in_block == 2 * CPC) { in_block = 0; wnext += 3 * CH * sizeof(float); }
+    } else if (issued == nchunks - HEADCH || !SPLIT) {
       wnext = np.head_w + (wave * PIECES) * WFRAG_BYTES;
+    } else if (issued < nchunks) {
+      wnext += CHUNK_BYTES;                 // (SPLIT: the head's second and third chunk)
     }
   };
   // ring slots 3 and 4 first hold the stem's operands: 8 KB of stem fragments, and the tile's raw input planes
@@ -290,6 +306,27 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) s[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[j], s[j][mt], 0, 0, 0);
   }
+  if constexpr (SPLIT) {
+    // the input planes are 0 / 1 (exact in bf16): only the stem's weights have a low part.  Its fragments follow the high ones in
+    // the blob and take their place in the ring slot once every wave has read those; one exposed DMA round trip per tile
+    barrier_lds();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma16(np.stem_w + 2 * MT * WFRAG_BYTES + (wave * 2 + i) * WFRAG_BYTES + lane * 16, stem_w_lds + (wave * 2 + i) * WFRAG_BYTES);
+    wait_vm<0>();
+    barrier_lds();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[MT], b[NTW];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = lds_read_frag(stem_w_lds + (ks * MT + mt) * WFRAG_BYTES + lane * 16);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) b[j] = lds_read_frag(act + (ks * 4 + quad) * PLANE + pix0 + j * 256);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) s[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[j], s[j][mt], 0, 0, 0);
+    }
+  }
 
   // epilogue helper: 4 consecutive channels (mt*16 + quad*4 ..) of the lane's pixel as bf16, into plane `plane0 + quad/2`
   auto store4 = [&](int j, int plane0, f32x4 val) {
@@ -297,6 +334,12 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
     o[0] = static_cast<__bf16>(val[0]); o[1] = static_cast<__bf16>(val[1]);
     o[2] = static_cast<__bf16>(val[2]); o[3] = static_cast<__bf16>(val[3]);
     *reinterpret_cast<bf16x4*>(act + (plane0 + (quad >> 1)) * PLANE + pix0 + j * 256 + (quad & 1) * 8) = o;
+    if constexpr (SPLIT) {        // the low parts: what the bf16 rounding left, in the same cell of plane + 8
+      bf16x4 l;
+      l[0] = static_cast<__bf16>(val[0] - static_cast<float>(o[0])); l[1] = static_cast<__bf16>(val[1] - static_cast<float>(o[1]));
+      l[2] = static_cast<__bf16>(val[2] - static_cast<float>(o[2])); l[3] = static_cast<__bf16>(val[3] - static_cast<float>(o[3]));
+      *reinterpret_cast<bf16x4*>(act + (8 + plane0 + (quad >> 1)) * PLANE + pix0 + j * 256 + (quad & 1) * 8) = l;
+    }
   };
 
   // B-fragment addressing: the lane's pixel in plane `quad` (po), and the distance from there to the first all-zero cell
@@ -319,7 +362,12 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
   // The last such barrier of a convolution comes after every activation read of the convolution has RETURNED
   // (lgkmcnt(0)), so the epilogue may overwrite the planes without another barrier.
   // Precondition: the activations are visible and chunk g0 has landed for all waves.
-  auto conv3x3 = [&](f32x4 (&acc)[NTW][MT], int slot0) {
+  // SPLIT: the same loop over three chunks per tap - chunk c = tap c / 3, pass c % 3 = (W_hi, X_hi), (W_hi, X_lo), (W_lo, X_hi).
+  // ONE_BY_ONE: the head's 1x1 convolution as the centre tap alone (SPLIT only: its three chunks ride the same stream).
+  auto conv_run = [&](f32x4 (&acc)[NTW][MT], int slot0, auto nch_tag, auto one_tag) {
+    constexpr int NCH = decltype(nch_tag)::value;          // weight chunks of this convolution
+    constexpr bool ONE_BY_ONE = decltype(one_tag)::value;
+    constexpr int NKS = NCH * CHUNK_KS;
     bf16x8 a[2][MT], b[2][NTW];
     int slot = slot0;
     auto load_a = [&](int ksl, const uint8_t* wsl, bf16x8 (&fa)[MT]) {
@@ -327,7 +375,9 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
       for (int mt = 0; mt < MT; ++mt) fa[mt] = lds_read_frag(wsl + (ksl * MT + mt) * WFRAG_BYTES);
     };
     auto load_b = [&](int ks, bf16x8 (&fb)[NTW]) {
-      const int tap = ks >> 1, half = ks & 1;
+      const int chunk = ks >> 1, half = ks & 1;
+      const int tap = ONE_BY_ONE ? 4 : (SPLIT ? chunk / 3 : chunk);
+      const int lo_planes = (SPLIT && chunk % 3 == 1) ? 8 * PLANE : 0;     // pass 1 reads the activations' low parts
       const int tap_off = ((tap / 3 - 1) * BW + (tap % 3 - 1)) * 16;
       int zs = (pix0 + tap_off) & 0xF0;       // slot residue of the cell this tap reads on the board (the same for every tile j)
       asm volatile("" : "+v"(zs));
@@ -336,17 +386,17 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
         int z = zd[j];
         asm volatile("" : "+v"(z));     // keep the select here: hoisted out of the block loop, the 36 offsets of a convolution cost 36 VGPRs (spills)
         const int d = ((tap_ok[j] >> tap) & 1u) ? tap_off : z + zs;
-        fb[j] = lds_read_frag(po + d + (j * 256 + half * 4 * PLANE));
+        fb[j] = lds_read_frag(po + d + (j * 256 + half * 4 * PLANE + lo_planes));
       }
     };
     load_a(0, wlane + slot * CHUNK_BYTES, a[0]);
     load_b(0, b[0]);
 #pragma unroll
-    for (int ks = 0; ks < 18; ++ks) {
+    for (int ks = 0; ks < NKS; ++ks) {
       const int cur = ks & 1, c = ks / CHUNK_KS, ksl = ks % CHUNK_KS;
-      if (ksl == CHUNK_KS - 1) {            // open chunk c + 1 (the next convolution's first chunk when c == 8)
+      if (ksl == CHUNK_KS - 1) {            // open chunk c + 1 (the next convolution's first chunk when c is the last)
         if constexpr (DBG == 0) wait_vm<4>();      // chunk g + 1 has landed; g + 2 and g + 3 (2 pieces each) may still be in flight
-        if (c == CHUNKS_PER_CONV - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (c == NCH - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (DBG != 2) { __builtin_amdgcn_s_barrier(); }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (DBG != 3) issue_next(slot == 0 ? NRING - 1 : slot - 1);     // chunk g + 4 (past the end: a harmless repeat)
@@ -354,7 +404,7 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (DBG != 4) {
-        if (ks + 1 < 18) {
+        if (ks + 1 < NKS) {
           load_a((ks + 1) % CHUNK_KS, wlane + slot * CHUNK_BYTES, a[cur ^ 1]);
           load_b(ks + 1, b[cur ^ 1]);
         }
@@ -369,7 +419,7 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
         for (int j = 0; j < NTW; ++j)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[cur][mt], b[cur][j], acc[j][mt], 0, 0, 0);
-        if (ks + 1 < 18) {
+        if (ks + 1 < NKS) {
           // issue order inside the k-step: 2 MFMAs and one A fragment of the next k-step (x4: its first MFMAs need all
           // four), then 2 MFMAs, the address arithmetic and the read of one B fragment (x4)
           constexpr int MF_A = NTW >= 4 ? 2 : 1, MF_B = (NTW * MT - 4 * MF_A) / NTW;
@@ -389,6 +439,9 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
       __builtin_amdgcn_sched_barrier(0);
     }
     return slot;
+  };
+  auto conv3x3 = [&](f32x4 (&acc)[NTW][MT], int slot0) {
+    return conv_run(acc, slot0, std::integral_constant<int, CPC>{}, std::false_type{});
   };
 
   if constexpr (DBG == 6) { if (s[0][0][0] == 12345.678f) v_out[0] = s[1][1][1] + s[2][2][2] + s[3][3][3]; return; }   // timing: stem only
@@ -451,6 +504,10 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
 #pragma unroll
     for (int j = 0; j < NTW; ++j) hacc[j][mt] = bh;
   }
+  if constexpr (SPLIT) {              // the head's three chunks ride the weight stream like a convolution's
+    barrier_lds();                    // the stream's planes are visible
+    slot = conv_run(hacc, slot, std::integral_constant<int, HEADCH>{}, std::true_type{});
+  }
   wait_vm<0>();                       // the head fragments (the run's last chunk, ring slot `slot`): nothing is in flight any more
   // Every global operand of the heads is requested HERE, together, and lands while the head convolution runs: the
   // heads are a chain of small dependent steps, and one memory round trip per step used to cost more than the arithmetic.
@@ -471,19 +528,21 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
   const bool out_on = tid < TBW * (MAXP1 + MAXM) && out_row < batch;
   if (out_on && rows) out_row = rows[out_row];
   barrier_lds();
+  if constexpr (!SPLIT) {
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    bf16x8 a[MT], b[NTW];
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[MT], b[NTW];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = lds_read_frag(ring + slot * CHUNK_BYTES + (ks * MT + mt) * WFRAG_BYTES + lane * 16);
+      for (int mt = 0; mt < MT; ++mt) a[mt] = lds_read_frag(ring + slot * CHUNK_BYTES + (ks * MT + mt) * WFRAG_BYTES + lane * 16);
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) b[j] = lds_read_frag(act + (ks * 4 + quad) * PLANE + pix0 + j * 256);
+      for (int j = 0; j < NTW; ++j) b[j] = lds_read_frag(act + (ks * 4 + quad) * PLANE + pix0 + j * 256);
 #pragma unroll
-    for (int j = 0; j < NTW; ++j)
+      for (int j = 0; j < NTW; ++j)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) hacc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[j], hacc[j][mt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) hacc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[j], hacc[j][mt], 0, 0, 0);
+    }
+    barrier_lds();
   }
-  barrier_lds();
   // (the value head's FC operands are requested now - the head accumulators are about to die - and land during the policy FC)
   float w1[HC], w1b = 0.0f;           // value fc1 column of this thread (weights transposed on the host: [32][v_hidden])
   const int o1 = tid < Hd ? tid : 0;

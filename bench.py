@@ -649,7 +649,7 @@ def main():
                 "max_cache_size": args.cache, "cache_hit_rate": hit_rate,
                 "net_numerics": ("bf16 MFMA operands, fp32 accumulation / residual stream / heads: measured max |delta| against the reference NNArch's fp32 outputs "
                                  "(tests/golden fixtures): pi 2.2e-4, v 5.2e-5 on the random-init Connect4 net (torch bf16 autocast, the reference's own "
-                                 "inference arithmetic: 6.4e-4); the 1e-5 tier is the fp32 net, see fp32_tier") if not tafl else
+                                 "inference arithmetic: 6.4e-4); the 1e-5 tier is the bf16x3 net (split bf16 operands, 4.3e-7), see tier_1e5") if not tafl else
                                 "bf16 MFMA operands, fp32 accumulation; measured max |delta| vs the reference NNArch fp32 outputs: pi 6.2e-7, v 3.8e-6 (Tawlbwrdd)",
                 "sims_per_s": n_sims / dt, "leaf_evals_per_s": n_evals / dt,
                 "games_in_window": n_games, "samples_in_window": n_rows, "samples_gathered": gathered_rows,
@@ -712,14 +712,20 @@ def main():
                 # the pipeline's two kernels of an epoch must be co-resident and counter collection serialises dispatches
                 # (profiles/r3_pmc_pipeline_probe.txt), so the counters are taken on k_pipe_net ALONE draining a pre-filled ring
                 # (scripts/pipe_net_pmc.py): bytes per position there x the positions of an average launch here
+                pts = []
                 for line in open(pmc3):
                     f = line.strip().split(",")
-                    if f[0].startswith("k_pipe_net") and float(f[2]) > 0:
-                        b_pos = (2.0 * float(f[3]) + float(f[4])) * 1024.0 / float(f[2])
-                        out["roofline"]["traffic"] = b_pos * rows_evaluated / launches
-                        out["roofline"]["traffic_note"] = ("L2-to-fabric bytes per k_pipe_net launch = %.0f B per position (2 x FETCH_SIZE + WRITE_SIZE of the net kernel alone "
-                                                           "on a pre-filled request ring, profiles/r3_pmc_traffic.csv taken at commit %s) x the positions of an average launch; "
-                                                           "the co-resident tree kernel cannot be counted (rocprofv3 --pmc serialises dispatches)" % (b_pos, f[5]))
+                    if "k_pipe_net" in f[0] and float(f[2]) > 0:
+                        pts.append((float(f[2]), (2.0 * float(f[3]) + float(f[4])) * 1024.0, f[5]))
+                if len(pts) >= 2:
+                    (n1, b1, commit), (n2, b2, _) = pts[0], pts[-1]
+                    per_pos = (b2 - b1) / (n2 - n1)
+                    fixed = b1 - per_pos * n1
+                    out["roofline"]["traffic"] = fixed + per_pos * rows_evaluated / launches
+                    out["roofline"]["traffic_note"] = ("L2-to-fabric bytes per k_pipe_net launch = %.2f MB once (the weight image into each XCD's L2) + %.0f B per position x the positions of "
+                                                       "an average launch; both from 2 x FETCH_SIZE + WRITE_SIZE of the net kernel ALONE draining %d and %d pre-filled requests "
+                                                       "(profiles/r3_pmc_traffic.csv, commit %s): the co-resident tree kernel cannot be counted, rocprofv3 --pmc serialises dispatches "
+                                                       "(profiles/r3_pmc_pipeline_probe.txt)" % (fixed / 1e6, per_pos, int(n1), int(n2), commit))
                 out["roofline_tree"]["traffic_note"] = "not collected: see roofline.traffic_note"
             elif hip_net is not None and pmc:
                 for line in open(pmc):
@@ -738,27 +744,29 @@ def main():
                 #      the share of the headline that comes from the cache being sized for 288 GB of HBM
                 #  (c) 16384 concurrent games instead of 4096: what the chip does when the slots do not limit it (a slot's
                 #      simulations are sequential, so at 4096 slots the path is bound by their latency, not by the chip)
-                #  (d) the fp32 leaf net (precision = "fp32": the 1e-5 tier of the north star) on the lock-step driver
+                #  (d) the bf16x3 leaf net (split bf16 operands: the 1e-5 tier of the north star) on the lock-step driver
                 pms.clear()            # frees the headline engines' HBM before the secondary engines are built
                 hip_f32 = None
                 for name, S2, cache2, cap2, kind, note in (
                         ("playout_cap_on", S, args.cache, True, "same", "25 sims on 75% of moves, 800 on the rest"),
                         ("cache_200k", S, 200_000, False, "same", "max_cache_size = 200000 (reference default), 800 sims on every move"),
                         ("slots_16384", 16384, args.cache, False, "same", "16384 concurrent games (4 x the headline's), 800 sims on every move"),
-                        ("fp32_tier", S, args.cache, False, "fp32", "the fp32 leaf net (max |delta| vs the reference NNArch 7.5e-8: the 1e-5 tier), lock-step rounds, 4 shards")):
+                        ("tier_1e5", S, args.cache, False, "x3", "the bf16x3 leaf net (precision='bf16x3': bf16 high + low parts of weights and activations, three MFMAs per product; "
+                                                                    "max |delta| vs the reference NNArch's fp32 outputs 4.3e-7 on the random-init fixture, 5.4e-6 on the peaked one: the north star's 1e-5 tier), "
+                                                                    "lock-step rounds, 4 shards; the plain-fp32 kernels (precision='fp32', any net shape, 7.5e-8) run this workload at 15 games/s")):
                     if os.environ.get("AZMI_BENCH_SECONDARY") and name not in os.environ["AZMI_BENCH_SECONDARY"].split(","):
                         continue
                     sys.stderr.write(f"bench.py: secondary {name} ...\n"); sys.stderr.flush()
                     pipe2 = use_pipe and kind == "same"
                     K2 = 1 if pipe2 else 4
-                    if kind == "fp32":
-                        hip_f32 = az.HipLeafNet(net, spec, device=local_rank, precision="fp32")
-                    net2 = hip_f32 if kind == "fp32" else hip_net
+                    if kind == "x3":
+                        hip_f32 = az.HipLeafNet(net, spec, device=local_rank, precision="bf16x3")
+                    net2 = hip_f32 if kind == "x3" else hip_net
                     pms2 = []
                     for i in range(K2):
                         pp2 = selfplay_params(az, S2 // K2, sims, STREAM, cache=cache2 // K2, playout_cap=cap2)
                         pms2.append(az.PlayManager(Game(), pp2, seed=977 + 104729 * i, device=local_rank, max_inline=args.inline, history_capacity=(S2 // K2) * 42 * 4))
-                    R2 = R if pipe2 else (2048 if kind == "same" else 128)
+                    R2 = R if pipe2 else 2048
                     if len(streams) < K2:
                         streams.extend(torch.cuda.Stream(device=dev) for _ in range(K2 - len(streams)))
                     sps2 = [st_.cuda_stream for st_ in streams[:K2]]
@@ -774,7 +782,7 @@ def main():
                         for pm2 in pms2:
                             pm2.take_history_device(dev)
                     tot2 = lambda pms2=pms2: totals_of(pms2)
-                    short = kind == "fp32"
+                    short = False
                     pre2 = 0 if short else preroll(run2, tot2, int((1.0 if S2 > S else args.preroll_factor) * S2), name)
                     run2((1 if short else 2) * R2)
                     torch.cuda.synchronize()

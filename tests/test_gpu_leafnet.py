@@ -396,3 +396,62 @@ def test_stargambit_net_batch_shapes_and_invariance(batch):
     if batch >= 3:
         v3, pi3 = hip.process(x[2:3].contiguous())
         assert torch.equal(v3[0], v[2]) and torch.equal(pi3[0], pi[2])
+
+
+# ---------------------------------------------------------------- bf16x3: the 1e-5 tier on the matrix cores (Connect4 family)
+@pytest.mark.parametrize("fixture", ["nn_connect4_6b64c.npz", "nn_connect4_6b64c_peaked.npz"])
+def test_bf16x3_tile_matches_reference_nnarch_within_1e5(fixture):
+    """precision="bf16x3" (csrc/leafnet_c4.h, SPLIT): weights and activations as bf16 high + low parts, three MFMAs per product,
+    against the reference NNArch's own fp32 outputs - the random-init fixture and the peaked one (pi 0.003 .. 0.59), at the north
+    star's tolerance, with a relative bound on every policy entry."""
+    import alphazero as az
+    from alphazero import torch_net
+    fx = np.load(os.path.join(HERE, "golden", fixture))
+    net = torch_net.LeafNet(torch_net.connect4_spec())
+    net.load_state_dict({k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("sd.")})
+    net.eval()
+    dev = torch.device("cuda:0")
+    hip = az.HipLeafNet(net, precision="bf16x3")
+    x = torch.from_numpy(fx["input"]).to(dev)
+    v, pi = hip.process(x)
+    torch.cuda.synchronize()
+    dv = np.abs(v.cpu().numpy() - fx["v"]).max()
+    dpi = np.abs(pi.cpu().numpy() - fx["pi"]).max()
+    rel = (np.abs(pi.cpu().numpy() - fx["pi"]) / np.maximum(fx["pi"], 1e-12)).max()
+    v16, pi16 = az.HipLeafNet(net).process(x)
+    e16 = max(np.abs(v16.cpu().numpy() - fx["v"]).max(), np.abs(pi16.cpu().numpy() - fx["pi"]).max())
+    print("%s bf16x3 vs reference fp32: max|dv| %.3e max|dpi| %.3e max rel %.3e (bf16 tile: %.3e)" % (fixture, dv, dpi, rel, e16))
+    assert dv <= TOL_F32 and dpi <= TOL_F32, (dv, dpi)
+    assert rel <= 1e-3, rel
+    assert max(dv, dpi) * 20 <= e16, "the split tile should be far closer to fp32 than the bf16 tile"
+
+
+@pytest.mark.parametrize("batch", [1, 5, 100, 769, 1600])
+def test_bf16x3_batch_shapes_and_invariance(batch):
+    """ragged batches on both split tiles (3 boards up to 768 rows, 6 boards above) and a row's answer independent of its batch"""
+    import alphazero as az
+    from alphazero import torch_net
+    dev = torch.device("cuda:0")
+    net = torch_net.random_init(torch_net.connect4_spec(), seed=3)
+    hip = az.HipLeafNet(net, precision="bf16x3")
+    g = torch.Generator().manual_seed(batch)
+    x = (torch.rand((batch, 4, 6, 7), generator=g) < 0.3).float().to(dev)
+    v, pi = hip.process(x)
+    v1, pi1 = hip.process(x[:1])
+    torch.cuda.synchronize()
+    assert torch.equal(v[:1], v1) and torch.equal(pi[:1], pi1)
+    with torch.no_grad():
+        vr, pr = net.to(dev).process(x)
+    assert (v - vr).abs().max().item() <= TOL_F32 and (pi - pr).abs().max().item() <= TOL_F32
+    if batch == 1600:          # the 6-board split tile against the 3-board one, bit for bit
+        for lo in range(0, 1600, 700):
+            vs, ps = hip.process(x[lo:lo + 700])
+            assert torch.equal(v[lo:lo + 700], vs) and torch.equal(pi[lo:lo + 700], ps), lo
+
+
+def test_bf16x3_rejects_spatial_nets():
+    import alphazero as az
+    from alphazero import torch_net
+    net = torch_net.random_init(torch_net.tawlbwrdd_spec(), seed=1)
+    with pytest.raises(RuntimeError, match="bf16x3"):
+        az.HipLeafNet(net, precision="bf16x3")
