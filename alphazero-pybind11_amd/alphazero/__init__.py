@@ -1622,12 +1622,12 @@ def run_pipeline(pm, net, epochs, sims_per_epoch, stream=None):
     """azmi_run_pipeline: `epochs` epochs of the asynchronous tree / net pipeline on one engine (persistent tree wavefronts and
     net workgroups side by side; moves, game ends and cache inserts between epochs).  Synchronous.  Returns a dict of
     pipeline counters: net tiles run and boards in them since the pipeline was created, simulations / insert-log entries of
-    the last epoch, workgroups launched and started."""
+    the last epoch, workgroups launched and started, kernel and host-enqueue times of this call."""
     st = pm._stream_arg(stream)
     out = (C.c_uint64 * 16)()
     check(lib.azmi_run_pipeline(pm._h, net._h, int(epochs), int(sims_per_epoch), st, out))
     keys = ("tiles", "tile_boards", "last_epoch_sims", "tree_wgs_started", "net_wgs_started", "last_epoch_inserts", "net_wgs", "tree_wgs",
-            "tree_latest_start_us", "net_latest_start_us", "net_kernel_us", "tree_kernel_us", "epochs")
+            "tree_latest_start_us", "net_latest_start_us", "net_kernel_us", "tree_kernel_us", "epochs", "host_enqueue_us")
     return dict(zip(keys, (int(x) for x in out)))
 
 

@@ -95,7 +95,9 @@ struct Tile {
   static constexpr int PLANE = SLOTS * 16;         // a multiple of 256 B
   static constexpr int ZERO_OFF = ZSLOT * 16;
   static constexpr int ACT_BYTES = NPLANES * PLANE;
-  static constexpr int LDS_BYTES = ACT_BYTES + RING_BYTES + PRM_FLOATS * 4;   // big: 80,896 - two workgroups per CU
+  static constexpr int ACT_OFF = 256;              // the planes start 256 B into the workgroup's LDS: a B-fragment read's base is the lane's pixel - 128 (conv_run)
+  static constexpr int RING_OFF = ACT_OFF + ACT_BYTES;
+  static constexpr int LDS_BYTES = RING_OFF + RING_BYTES + PRM_FLOATS * 4;   // big: 81,152 - two workgroups per CU
   static_assert(NPIX <= NT * 16 && NPIX <= NTH, "the tile's pixels fit its n-tiles; one thread per pixel");
   static_assert(PLANE % 256 == 0, "conflict-free fragment reads need a plane stride that is a multiple of 256 B");
   static_assert((SPLIT_ ? 1 : 2) * LDS_BYTES <= 160 * 1024, "two workgroups per CU (SPLIT: one)");
@@ -173,9 +175,9 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
   if (in_row >= max_rows) in_row = max_rows - 1;
   if (rows) { batch = *row_count; in_row = rows[in_row]; }
   if (tile_index * TBW >= batch) return;
-  uint8_t* const act = lds;
-  uint8_t* const ring = lds + ACT_BYTES;
-  float* const prm = reinterpret_cast<float*>(lds + ACT_BYTES + RING_BYTES);
+  uint8_t* const act = lds + TG::ACT_OFF;
+  uint8_t* const ring = lds + TG::RING_OFF;
+  float* const prm = reinterpret_cast<float*>(lds + TG::RING_OFF + RING_BYTES);
 
   int tid_ = threadIdx.x;
   // a persistent caller runs this body in a loop: everything below that depends on the thread index alone would be hoisted out
@@ -190,8 +192,7 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
   constexpr int CPC = SPLIT ? 3 * CHUNKS_PER_CONV : CHUNKS_PER_CONV;     // weight chunks per 3x3 convolution
   constexpr int HEADCH = SPLIT ? 3 : 1;                                  // ... of the head 1x1 convolution
   static_assert(!(SPLIT && PIPE), "the pipeline runs the bf16 tiles");
-  const int nchunks = 2 * depth * CPC + HEADCH;               // + the head 1x1 weights, streamed as the run's last chunk(s)
-  const size_t block_stride = 3 * CH * sizeof(float) + 2 * static_cast<size_t>(CPC) * CHUNK_BYTES;
+    const size_t block_stride = 3 * CH * sizeof(float) + 2 * static_cast<size_t>(CPC) * CHUNK_BYTES;
 
   // ---- small fp32 parameters -> LDS (plain loads, before any DMA is in flight) ------------------------------------
   if (tid < CH) { prm[tid] = np.stem_b[tid]; prm[CH + MAXDEPTH * 3 * CH + tid] = np.head_b[tid]; }
@@ -204,29 +205,17 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
   // ---- zero the activation planes once (covers the zero cells and the k rows the stem does not use) ----------------
   for (int i = tid * 16; i < ACT_BYTES; i += NTH * 16) *reinterpret_cast<u32x4*>(act + i) = u32x4{0, 0, 0, 0};
 
-  // ---- weight stream: chunk g of the run = 8 KB of fragments (one tap of one convolution); every wave moves 2 of its
-  // 8 pieces.  Chunk g lives in ring slot g % NRING.
-  // The stream's chunks are consecutive in the weight blob except for the 768 bytes of fp32 block parameters in front of
-  // every block's fragments; the head's fragments come last.  `wnext` walks the blob: source of the next chunk to issue.
-  const uint8_t* wnext = np.blocks + 3 * CH * sizeof(float) + (wave * PIECES) * WFRAG_BYTES;
-  int issued = 0, in_block = 0;            // chunks issued so far; how many of them belong to the current block
-  auto issue_next = [&](int slot) {
-    const uint8_t* src = wnext + lane * 16;
-    uint8_t* dst = ring + slot * CHUNK_BYTES + (wave * PIECES) * WFRAG_BYTES;
+  // ---- weight stream: a chunk = 8 KB of fragments (one tap of one convolution; SPLIT: one of a tap's three passes); every wave
+  // moves 2 of its 8 pieces.  The chunks of a convolution are consecutive in the blob, so are the two convolutions of a block;
+  // 768 bytes of fp32 block parameters sit in front of every block's fragments and the head's fragments come last.  A convolution
+  // therefore issues from two bases with compile-time offsets (conv_run: its own chunks, then the next convolution's) - the
+  // bookkeeping of a running pointer cost ~25 scalar instructions per chunk in the middle of the matrix stream.
+  const size_t wave_off = static_cast<size_t>(wave * PIECES) * WFRAG_BYTES;
+  auto issue_chunk = [&](const uint8_t* chunk_src, int slot) {
     static_assert(PIECES == 2, "dma16x2 moves the wave's two pieces");
-    dma16x2(src, dst);
-    // after the run's last chunk (the head's) the stream keeps re-sending that chunk into slots nobody reads any more: the
-    // tail of the run then needs no special cases - one wait count, no branch around the issue (see conv3x3)
-    ++issued; ++in_block;
-    if (issued < nchunks - HEADCH) {
-      wnext += CHUNK_BYTES;
-      if (in_block == 2 * CPC) { in_block = 0; wnext += 3 * CH * sizeof(float); }
-    } else if (issued == nchunks - HEADCH || !SPLIT) {
-      wnext = np.head_w + (wave * PIECES) * WFRAG_BYTES;
-    } else if (issued < nchunks) {
-      wnext += CHUNK_BYTES;                 // (SPLIT: the head's second and third chunk)
-    }
+    dma16x2(chunk_src + wave_off + lane * 16, ring + slot * CHUNK_BYTES + wave_off);
   };
+  const uint8_t* const conv0_w = np.blocks + 3 * CH * sizeof(float);      // block 0, conv1
   // ring slots 3 and 4 first hold the stem's operands: 8 KB of stem fragments, and the tile's raw input planes
   uint8_t* const stem_w_lds = ring + 3 * CHUNK_BYTES;
   float* const raw = reinterpret_cast<float*>(ring + 4 * CHUNK_BYTES);
@@ -238,9 +227,9 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) dma16(np.stem_w + (wave * 2 + i) * WFRAG_BYTES + lane * 16, stem_w_lds + (wave * 2 + i) * WFRAG_BYTES);
-  issue_next(0);
-  issue_next(1);
-  issue_next(2);
+  issue_chunk(conv0_w, 0);
+  issue_chunk(conv0_w + CHUNK_BYTES, 1);
+  issue_chunk(conv0_w + 2 * CHUNK_BYTES, 2);
 
   // ---- per-lane pixel geometry of the wave's n-tiles: tile t = wave * 4 + j ---------------------------------------
   // the lane's pixel of tile j sits at byte pix0 + j * 256 of a plane (tiles are 16 consecutive pixel slots)
@@ -342,15 +331,15 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
     }
   };
 
-  // B-fragment addressing: the lane's pixel in plane `quad` (po), and the distance from there to the first all-zero cell
-  // (zd): a tap reads po + (on the board ? tap offset : zd + the 16-byte-slot residue of the cell the tap WOULD have read).
-  // Round 2 sent an out-of-board tap to the zero cell with the residue of the lane's OWN pixel: beside lanes that read their
-  // shifted on-board neighbour (residue + tap shift) that was a 2-way bank conflict wherever a lane group mixed the two -
-  // every border pixel - and SQ_LDS_BANK_CONFLICT read 28 % of the convolutions' LDS cycles (profiles/r3_c4_tile_pmc.csv).
-  const uint8_t* const po = act + quad * PLANE + pix0;     // tile j: + j * 256, an immediate of the read
-  int zd[NTW];
-#pragma unroll
-  for (int j = 0; j < NTW; ++j) zd[j] = ZERO_OFF - pix0 - j * 256;
+  // B-fragment addressing: a tap reads the lane's pixel + the tap offset when that neighbour is on the board, else an all-zero
+  // cell with the 16-byte-slot residue of the cell the tap WOULD have read.  (Round 2 used the residue of the lane's OWN pixel:
+  // beside lanes that read their shifted on-board neighbour that was a 2-way bank conflict wherever a lane group mixed the two -
+  // every border pixel -, 28 % of the convolutions' LDS cycles in SQ_LDS_BANK_CONFLICT: profiles/r3_c4_tile_pmc.csv.)
+  // The choice is made once per tap and tile - one literal add, one select - and serves both k-steps of the tap; the tap offset
+  // rides in the read's immediate, biased by 128 so that it is never negative: 5.5 VALU per k-step instead of 19.
+  const uint8_t* const po = act + quad * PLANE + pix0;     // the lane's pixel in plane `quad` (tile j: + j * 256, an immediate of the read)
+  const uint8_t* const pom = po - 128;                     // on-board base of a tap read (act starts ACT_OFF = 256 B into LDS: never below 0)
+  const uint8_t* const zcell = act + quad * PLANE + ZERO_OFF;   // first all-zero cell of the lane's plane
   const uint8_t* const wlane = ring + lane * 16;
 
   // One 3x3 convolution over `act`, accumulating into acc[][]; g0 = index of its first weight chunk in the run, slot0 = that
@@ -364,7 +353,9 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
   // Precondition: the activations are visible and chunk g0 has landed for all waves.
   // SPLIT: the same loop over three chunks per tap - chunk c = tap c / 3, pass c % 3 = (W_hi, X_hi), (W_hi, X_lo), (W_lo, X_hi).
   // ONE_BY_ONE: the head's 1x1 convolution as the centre tap alone (SPLIT only: its three chunks ride the same stream).
-  auto conv_run = [&](f32x4 (&acc)[NTW][MT], int slot0, auto nch_tag, auto one_tag) {
+  // wbase: this convolution's first chunk; wnext: the first chunk of the convolution after it (chunk c + 4 is issued at chunk
+  // c's barrier; past the end of the run the stream re-reads bytes behind the head's fragments into slots nobody reads).
+  auto conv_run = [&](f32x4 (&acc)[NTW][MT], int slot0, const uint8_t* wbase, const uint8_t* wnext, auto nch_tag, auto one_tag) {
     constexpr int NCH = decltype(nch_tag)::value;          // weight chunks of this convolution
     constexpr bool ONE_BY_ONE = decltype(one_tag)::value;
     constexpr int NKS = NCH * CHUNK_KS;
@@ -374,20 +365,22 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) fa[mt] = lds_read_frag(wsl + (ksl * MT + mt) * WFRAG_BYTES);
     };
+    const uint8_t* sel[NTW];       // per tile j: the base the tap's reads go through (on the board: pom; else a zero cell minus the immediate)
     auto load_b = [&](int ks, bf16x8 (&fb)[NTW]) {
       const int chunk = ks >> 1, half = ks & 1;
       const int tap = ONE_BY_ONE ? 4 : (SPLIT ? chunk / 3 : chunk);
       const int lo_planes = (SPLIT && chunk % 3 == 1) ? 8 * PLANE : 0;     // pass 1 reads the activations' low parts
       const int tap_off = ((tap / 3 - 1) * BW + (tap % 3 - 1)) * 16;
-      int zs = (pix0 + tap_off) & 0xF0;       // slot residue of the cell this tap reads on the board (the same for every tile j)
-      asm volatile("" : "+v"(zs));
+      if (half == 0 && (!SPLIT || chunk % 3 == 0)) {       // a new tap
+        int zs = (pix0 + tap_off) & 0xF0;       // slot residue of the cell this tap reads on the board (the same for every tile j)
+        asm volatile("" : "+v"(zs));            // keeps the selects here: hoisted out of the block loop, a convolution's 36 bases cost 36 VGPRs (spills)
+        const uint8_t* const zc = zcell + zs;
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) {
-        int z = zd[j];
-        asm volatile("" : "+v"(z));     // keep the select here: hoisted out of the block loop, the 36 offsets of a convolution cost 36 VGPRs (spills)
-        const int d = ((tap_ok[j] >> tap) & 1u) ? tap_off : z + zs;
-        fb[j] = lds_read_frag(po + d + (j * 256 + half * 4 * PLANE + lo_planes));
+        for (int j = 0; j < NTW; ++j)
+          sel[j] = ((tap_ok[j] >> tap) & 1u) ? pom : zc - (tap_off + 128 + j * 256);
       }
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) fb[j] = lds_read_frag(sel[j] + (tap_off + 128 + j * 256 + half * 4 * PLANE + lo_planes));
     };
     load_a(0, wlane + slot * CHUNK_BYTES, a[0]);
     load_b(0, b[0]);
@@ -399,10 +392,12 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
         if (c == NCH - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (DBG != 2) { __builtin_amdgcn_s_barrier(); }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (DBG != 3) issue_next(slot == 0 ? NRING - 1 : slot - 1);     // chunk g + 4 (past the end: a harmless repeat)
+        if constexpr (DBG != 3)      // chunk c + 4 into the slot chunk c - 1 has left
+          issue_chunk(c + 4 < NCH ? wbase + (c + 4) * CHUNK_BYTES : wnext + (c + 4 - NCH) * CHUNK_BYTES, slot == 0 ? NRING - 1 : slot - 1);
         slot = slot == NRING - 1 ? 0 : slot + 1;                 // ring slot of chunk c + 1
+      } else {
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
       if constexpr (DBG != 4) {
         if (ks + 1 < NKS) {
           load_a((ks + 1) % CHUNK_KS, wlane + slot * CHUNK_BYTES, a[cur ^ 1]);
@@ -431,7 +426,7 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
 #pragma unroll
           for (int i = 0; i < NTW; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, MF_B, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           }
         }
@@ -440,8 +435,8 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
     }
     return slot;
   };
-  auto conv3x3 = [&](f32x4 (&acc)[NTW][MT], int slot0) {
-    return conv_run(acc, slot0, std::integral_constant<int, CPC>{}, std::false_type{});
+  auto conv3x3 = [&](f32x4 (&acc)[NTW][MT], int slot0, const uint8_t* wbase, const uint8_t* wnext) {
+    return conv_run(acc, slot0, wbase, wnext, std::integral_constant<int, CPC>{}, std::false_type{});
   };
 
   if constexpr (DBG == 6) { if (s[0][0][0] == 12345.678f) v_out[0] = s[1][1][1] + s[2][2][2] + s[3][3][3]; return; }   // timing: stem only
@@ -473,8 +468,11 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
     }
     if (blk == 0) { if constexpr (DBG == 0) wait_vm<4>(); }      // chunk 0 (chunks 1 and 2 stay in flight)
     barrier_lds();                                        // barrier C: planes visible (and, block 0, chunk 0 landed for every wave)
-    if (blk == 0) { if constexpr (DBG != 3) issue_next(3); }  // the stem is done with slot 3 (slot 4: chunk 4, at the first chunk barrier)
-    slot = conv3x3(u, slot);
+    if (blk == 0) { if constexpr (DBG != 3) issue_chunk(conv0_w + 3 * CHUNK_BYTES, 3); }  // the stem is done with slot 3 (slot 4: chunk 4, at the first chunk barrier)
+    const uint8_t* const w1 = np.blocks + blk * block_stride + 3 * CH * sizeof(float);
+    const uint8_t* const w2 = w1 + CPC * CHUNK_BYTES;
+    const uint8_t* const wn = blk + 1 < depth ? w2 + CPC * CHUNK_BYTES + 3 * CH * sizeof(float) : np.head_w;
+    slot = conv3x3(u, slot, w1, w2);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -487,7 +485,7 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
       }
     barrier_lds();
     // s = s + conv2(u)
-    slot = conv3x3(s, slot);
+    slot = conv3x3(s, slot, w2, wn);
   }
 
   if constexpr (DBG == 7) { if (s[0][0][0] == 12345.678f) v_out[0] = s[1][1][1] + s[2][2][2] + s[3][3][3]; return; }   // timing: stem + trunk
@@ -506,7 +504,7 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
   }
   if constexpr (SPLIT) {              // the head's three chunks ride the weight stream like a convolution's
     barrier_lds();                    // the stream's planes are visible
-    slot = conv_run(hacc, slot, std::integral_constant<int, HEADCH>{}, std::true_type{});
+    slot = conv_run(hacc, slot, np.head_w, np.head_w, std::integral_constant<int, HEADCH>{}, std::true_type{});
   }
   wait_vm<0>();                       // the head fragments (the run's last chunk, ring slot `slot`): nothing is in flight any more
   // Every global operand of the heads is requested HERE, together, and lands while the head convolution runs: the

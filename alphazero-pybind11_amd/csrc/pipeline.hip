@@ -11,6 +11,7 @@
 // it), so the games are the lock-step engine's games: tests/test_gpu_pipeline.py.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 
@@ -515,7 +516,7 @@ constexpr uint32_t kPipeXs = 512;      // bytes of claim scratch behind the tile
 template <class TG>
 __device__ __forceinline__ void pipe_stage_planes(uint8_t* lds, const uint32_t* xs, uint32_t tid) {
   constexpr int PIX = azmi_net_dev::c4::PIX;
-  float* const raw = reinterpret_cast<float*>(lds + TG::ACT_BYTES + 4 * azmi_net_dev::c4::CHUNK_BYTES);
+  float* const raw = reinterpret_cast<float*>(lds + TG::RING_OFF + 4 * azmi_net_dev::c4::CHUNK_BYTES);
   if (tid < static_cast<uint32_t>(TG::TBW * PIX)) {
     const uint32_t b = tid / PIX, p = tid % PIX;
     const unsigned long long* xb = reinterpret_cast<const unsigned long long*>(xs + 32);
@@ -877,6 +878,7 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
     AZMI_HIP_TRY(hipEventCreate(&ev));
     ps->tev.push_back(ev);
   }
+  const auto host_t0 = std::chrono::steady_clock::now();       // what the host spends enqueueing the epochs (it runs ahead of the GPU)
   for (uint32_t e = 0; e < epochs; ++e) {
     AZMI_HIP_TRY(hipMemsetAsync(pa.ep, 0, sizeof(PipeEpoch), st));
     k_pipe_seed<<<settle_blocks, 256, 0, st>>>(pm->ep, pm->ar, pa);
@@ -925,6 +927,7 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
       }
     }
   }
+  const uint64_t host_enqueue_us = static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - host_t0).count());
   // the run is synchronous: a pipeline error (a spin that hit its time cap, a tag that did not match) must not go unseen
   PipeCtl hc;
   PipeEpoch he;
@@ -941,7 +944,7 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
       if (hipEventElapsedTime(&ms, ps->tev[4 * e + 0], ps->tev[4 * e + 1]) == hipSuccess) net_us += 1e3 * ms;
       if (hipEventElapsedTime(&ms, ps->tev[4 * e + 2], ps->tev[4 * e + 3]) == hipSuccess) tree_us += 1e3 * ms;
     }
-    out_stats[10] = static_cast<uint64_t>(net_us); out_stats[11] = static_cast<uint64_t>(tree_us); out_stats[12] = epochs;
+    out_stats[10] = static_cast<uint64_t>(net_us); out_stats[11] = static_cast<uint64_t>(tree_us); out_stats[12] = epochs; out_stats[13] = host_enqueue_us;
     if (getenv("AZMI_PIPE_PROF")) {
       fprintf(stderr, "pipe prof:");
       for (int i = 0; i < 15; ++i) fprintf(stderr, " %llu", hc.prof[i]);

@@ -452,7 +452,7 @@ def main():
                     pi_buf.copy_(pi)
 
         spe = args.sims_per_epoch or 96 * S
-        pipe_acc = {"net_us": 0.0, "tree_us": 0.0, "epochs": 0, "tiles": 0, "boards": 0, "late": 0}
+        pipe_acc = {"net_us": 0.0, "tree_us": 0.0, "epochs": 0, "tiles": 0, "boards": 0, "late": 0, "host_us": 0.0}
 
         def run_rounds_on(group, n, ev=None):
             """n rounds of every shard. With the HIP net the loop is the native driver (azmi_run_rounds);
@@ -463,7 +463,7 @@ def main():
                 for pm_ in group:
                     st_ = az.run_pipeline(pm_, hip_net, n, spe, sps[0])
                     if ev is not None:
-                        pipe_acc["net_us"] += st_["net_kernel_us"]; pipe_acc["tree_us"] += st_["tree_kernel_us"]; pipe_acc["epochs"] += st_["epochs"]
+                        pipe_acc["net_us"] += st_["net_kernel_us"]; pipe_acc["tree_us"] += st_["tree_kernel_us"]; pipe_acc["epochs"] += st_["epochs"]; pipe_acc["host_us"] += st_["host_enqueue_us"]
                         pipe_acc.setdefault("tiles0", pipe_acc.get("tiles_now", 0)); pipe_acc.setdefault("boards0", pipe_acc.get("boards_now", 0))
                         pipe_acc["late"] = max(pipe_acc["late"], st_["tree_latest_start_us"], st_["net_latest_start_us"])
                         pipe_acc["net_wgs"], pipe_acc["tree_wgs"] = st_["net_wgs"], st_["tree_wgs"]
@@ -673,6 +673,8 @@ def main():
             achieved = flop_per_eval * rows_evaluated / dt / 1e12
             per_launch = (flop_per_eval * rows_evaluated / launches) / (nn_ms * 1e-3) / 1e12 if nn_ms > 0 else 0.0
             out["config"].update({"tree_kernel_ms": tree_ms, "net_ms": nn_ms})
+            if use_pipe:      # the host's share: enqueueing an epoch's launches (it runs ahead of the GPU; one synchronisation per step)
+                out["config"]["host_enqueue_us_per_epoch"] = pipe_acc["host_us"] / launches
             out["roofline"] = {
                 "bound": "mfma", "achieved": per_launch, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": per_launch / MFMA_PEAK_TFLOPS, "traffic": None,

@@ -148,3 +148,19 @@ def test_fp32_net_with_cache_and_one_inline_simulation(oracle):
     pm, (rows, counts) = _device_games(az, az.Connect4GS(), pp, seed, hip, max_inline=1)
     assert pm.games_completed() == S and pm.counters()["cache_hits"] > 0
     _check_slots(az, oracle, oracle.GAME_CONNECT4, pp, seed, rows, counts, (0, 11, 23), evaluator=_net_eval(hip))
+
+
+def test_bf16x3_net_in_the_loop_equals_the_oracle_driven_by_the_same_net(oracle):
+    """the 1e-5 tier on the matrix cores (precision="bf16x3", csrc/leafnet_c4.h SPLIT) as the engine's evaluator: lock-step rounds
+    with the eval list (the split tiles are not fused with the move step), device cache on; the games are the oracle's when its
+    evaluator sends each leaf through the same net."""
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=15), spec, precision="bf16x3")
+    S, seed = 64, 2024
+    pp = _selfplay_params(az, S, 80, cache=1 << 14)
+    pm, (rows, counts) = _device_games(az, az.Connect4GS(), pp, seed, hip)
+    assert pm.games_completed() == S and pm.counters()["cache_hits"] > 0
+    assert not az.pipeline_supported(az.PlayManager(az.Connect4GS(), pp, seed=1), hip)      # the pipeline runs the bf16 tiles
+    _check_slots(az, oracle, oracle.GAME_CONNECT4, pp, seed, rows, counts, (0, 31, 63), evaluator=_net_eval(hip))
