@@ -121,8 +121,9 @@ __device__ __forceinline__ void dma16(const uint8_t* src_lane, uint8_t* dst_wave
                : "=&s"(keep) : "v"(src_lane), "s"(dst) : "memory");
 }
 // two consecutive 1 KB pieces (source and destination both advance by 1024: the instruction offset applies to both sides)
-__device__ __forceinline__ void dma16x2(const uint8_t* src_lane, uint8_t* dst_wave) {
-  const uint32_t dst = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lptr_t)dst_wave)));
+// (dst = the LDS byte address as a number: a generic-to-LDS pointer cast per call carries a null check, four scalar instructions
+// in the middle of the matrix stream)
+__device__ __forceinline__ void dma16x2(const uint8_t* src_lane, uint32_t dst) {
   uint32_t keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
                "global_load_lds_dwordx4 %1, off offset:1024\n\ts_mov_b32 m0, %0"
@@ -211,9 +212,10 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
   // therefore issues from two bases with compile-time offsets (conv_run: its own chunks, then the next convolution's) - the
   // bookkeeping of a running pointer cost ~25 scalar instructions per chunk in the middle of the matrix stream.
   const size_t wave_off = static_cast<size_t>(wave * PIECES) * WFRAG_BYTES;
+  const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lptr_t)ring))) + static_cast<uint32_t>(wave_off);
   auto issue_chunk = [&](const uint8_t* chunk_src, int slot) {
     static_assert(PIECES == 2, "dma16x2 moves the wave's two pieces");
-    dma16x2(chunk_src + wave_off + lane * 16, ring + slot * CHUNK_BYTES + wave_off);
+    dma16x2(chunk_src + wave_off + lane * 16, ring_lds + static_cast<uint32_t>(slot) * CHUNK_BYTES);
   };
   const uint8_t* const conv0_w = np.blocks + 3 * CH * sizeof(float);      // block 0, conv1
   // ring slots 3 and 4 first hold the stem's operands: 8 KB of stem fragments, and the tile's raw input planes

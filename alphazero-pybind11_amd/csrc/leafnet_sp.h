@@ -218,12 +218,10 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
     }
   };
 
-  // B-fragment addressing: the lane's pixel in plane `quad` (po), and the distance from there to the all-zero cell with
-  // the pixel's own 16-byte-slot residue (zd): a tap reads po + (on the board ? tap offset : zd), two VALU per fragment
+  // B-fragment addressing (c4::tile): a tap reads the lane's pixel + the tap offset when that neighbour is on the board, else an
+  // all-zero cell with the 16-byte-slot residue of the cell the tap would have read (no bank conflict with the lanes beside it).
+  // The choice is made once per tap and tile and serves both k-steps of the tap: 6 VALU per k-step instead of 16.
   const uint8_t* const po = act + quad * PLANE + pix0;     // tile j: + j * 256, an immediate of the read
-  int zd[NTW];
-#pragma unroll
-  for (int j = 0; j < NTW; ++j) zd[j] = G::ZERO_OFF - pix0 - j * 256;   // + the slot residue of the cell the tap would have read (load_b; c4::tile)
   const uint8_t* const wlane = ring + lane * 16;
 
   // One convolution over `act`, accumulating into acc[][]: NCH weight chunks starting in ring slot `slot0` - 9 (a 3x3: chunk =
@@ -243,27 +241,29 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) fa[mt] = lds_read_frag(wsl + (ksl * MT + mt) * WFRAG_BYTES);
     };
+    int sel[NTW];                  // per tile j: the plane offset the current tap's reads go through
     auto load_b = [&](int ks, bf16x8 (&fb)[NTW]) {
       if constexpr (NCH == 2) {
         const int tap = 4 * ks + quad, th = tap / 3, tw = tap - 3 * th;
         const int tap_off = ((th - 1) * BW + (tw - 1)) * 16;
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
-          const int d = (tap < 9 && ((tap_ok[j] >> tap) & 1u)) ? tap_off : zd[j] + ((pix0 + tap_off) & 0xF0);
+          const int d = (tap < 9 && ((tap_ok[j] >> tap) & 1u)) ? tap_off : (G::ZERO_OFF - pix0 - j * 256) + ((pix0 + tap_off) & 0xF0);
           fb[j] = lds_read_frag(act + pix0 + d + j * 256);
         }
       } else {
         const int tap = NCH == 9 ? (ks >> 1) : 4, half = ks & 1;
         const int tap_off = ((tap / 3 - 1) * BW + (tap % 3 - 1)) * 16;
-        int zs = (pix0 + tap_off) & 0xF0;   // an out-of-board tap reads the zero cell in the bank slot its on-board cell would have had (no conflict with the lanes beside it)
-        asm volatile("" : "+v"(zs));
+        if (half == 0) {                    // a new tap
+          int zs = (pix0 + tap_off) & 0xF0;   // slot residue of the cell this tap reads on the board (the same for every tile j)
+          asm volatile("" : "+v"(zs));        // keeps the selects here: hoisted out of the block loop, a convolution's bases cost VGPRs (spills)
+          const int zc = quad * PLANE + G::ZERO_OFF + zs;          // byte offsets into the planes (32-bit: a pointer here costs two registers)
+          const int pot = quad * PLANE + pix0 + tap_off;
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-          int z = zd[j];
-          asm volatile("" : "+v"(z));     // keep the select here: hoisted out of the block loop, the offsets of a convolution cost VGPRs (spills)
-          const int d = ((tap_ok[j] >> tap) & 1u) ? tap_off : z + zs;
-          fb[j] = lds_read_frag(po + d + (j * 256 + half * 4 * PLANE));
+          for (int j = 0; j < NTW; ++j) sel[j] = ((tap_ok[j] >> tap) & 1u) ? pot : zc - j * 256;
         }
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) fb[j] = lds_read_frag(act + sel[j] + (j * 256 + half * 4 * PLANE));
       }
     };
     load_a(0, wlane + slot * CHUNK_BYTES, a[0]);
@@ -300,7 +300,7 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, MF_B, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
       }

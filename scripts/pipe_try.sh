@@ -1,5 +1,3 @@
-run() { echo "== $*"; env "$@" BLOCKS=3 PRE=2 E=300 Q=96 timeout -k 10 280 python scripts/pipe_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-400 | tail -3; }
-run AZMI_PIPE_SMALL_THR=0 &&
-run AZMI_PIPE_SMALL_THR=60 &&
-run AZMI_PIPE_SMALL_THR=180 &&
-run AZMI_PIPE_SMALL_THR=480
+run() { echo "== $*"; env "$@" BLOCKS=4 PRE=2 E=300 Q=96 AZMI_PIPE_PROF=1 timeout -k 10 280 python scripts/pipe_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-400 | tail -4; }
+timeout -k 10 280 python -m pytest tests/test_gpu_pipeline.py -x -q 2>&1 | tail -2 &&
+run X=1
