@@ -55,7 +55,7 @@ def shard_seed(seed, k):
 
 
 def self_play(game, params, net=None, engines=None, seed=20240601, device=0, streams=None, rounds_per_poll=512, data_folder=None,
-              iteration=0, data_save_size=30_000, driver="auto", epochs_per_poll=64):
+              iteration=0, data_save_size=30_000, driver="auto", epochs_per_poll=16):
     """Runs `params.games_to_play` self-play games of `game`; `net` is a HipLeafNet (or None when every seat evaluates with
     RANDOM / PLAYOUT).  Returns (SelfPlayResult, (canonical, v, pi)) with the samples as device tensors in shard order (numpy
     arrays without a net, since nothing else needs torch then).  With `data_folder` the samples are also written as the
@@ -92,7 +92,7 @@ def self_play(game, params, net=None, engines=None, seed=20240601, device=0, str
         sps = [s.cuda_stream for s in streams]
         live = list(range(K))
         tdev = torch.device("cuda", device)
-        spe = 96 * int(params.concurrent_games)
+        spe = 256 * int(params.concurrent_games)
         while live:
             group = [pms[i] for i in live]
             if want_pipe:

@@ -1244,25 +1244,23 @@ struct SlotCtx {
 // kMover: the move step of a SPLIT round — the kernel runs over the slots k_sim listed in ar.mover_list (game starts, the
 // simulation that completes a search + the move, root leaves: everything rare and register-hungry), beside or behind the
 // net launch of the round; a leaf it sends to the net is only written (kSlotQueued), the next round's k_sim lists it.
+// round_slot: the round of ONE slot by its lane group (lane = 0 .. GROUP-1); returns the slot state it stored (kSlotWaitEval,
+// kSlotQueued, kSlotEnded, kSlotDone) or 0xFF when it had nothing to do.  round_body maps a thread to its slot (kMover: through
+// ar.mover_list); the asynchronous pipeline's mover wavefronts (pipeline.hip) call round_slot on the slots their tokens name.
 template <class GM, bool kPlayout = false, bool kMover = false>
-__device__ __forceinline__ void round_body(const EngineParams& ep, const EngineArrays& ar, const uint32_t gtid) {
+__device__ __forceinline__ uint32_t round_slot(const EngineParams& ep, const EngineArrays& ar, const uint32_t slot, const uint32_t lane) {
   constexpr int G = GM::GROUP;
   constexpr int P = GM::P;
-  uint32_t slot = gtid / G;
-  const uint32_t lane = gtid % G;
-  if constexpr (kMover) {
-    if (slot >= ar.ctl->mover_count) return;
-    slot = ar.mover_list[slot];
-  }
-  if (slot >= ep.S) return;
-  if (ar.ctl->stop) return;
+  if (slot >= ep.S) return 0xFFu;
+  if (ar.ctl->stop) return 0xFFu;
   const uint8_t st = ar.sstate[slot];
   // cache_keys[slot] = key of the leaf this slot sends to the net this round (0 = none): the next round's
   // k_cache_insert stores the net's answer under it (PlayManager::update_inferences -> insert_many)
-  if (st == kSlotDone || st == kSlotEnded) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; return; }
+  if (st == kSlotDone || st == kSlotEnded) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; return 0xFFu; }
   SlotCtx<GM> c(ep, ar, slot, lane);
   c.trace(100);
   c.load();
+  if constexpr (kMover) c.flags &= ~kFlagListed;      // (set by the pipeline's tree wavefronts when they hand a slot to the move step)
   c.trace(101);
   uint32_t inline_sims = 0, insert_key_set = 0;
   PathRegs prec;           // split rounds: the lane image of the simulation this step leaves pending
@@ -1286,14 +1284,14 @@ __device__ __forceinline__ void round_body(const EngineParams& ep, const EngineA
       c.trace(102);
       const uint32_t goal = (c.flags & kFlagCapped) ? c.seat_cap_visits(cp) : c.seat_visits(cp);
       if (AZMI_SEL(c.t_depth, cp) >= goal) {
-        if (c.make_move(cp)) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; c.store(kSlotEnded); c.trace(107); return; }
+        if (c.make_move(cp)) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; c.store(kSlotEnded); c.trace(107); return kSlotEnded; }
         c.trace(103);
       }
     }
     const uint32_t cp = c.gs.player;
     typename GM::State leaf;
     uint32_t term = 0;
-    if (!c.find_leaf(cp, leaf, term, kMover ? &prec : nullptr)) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; c.store(kSlotDone); return; }
+    if (!c.find_leaf(cp, leaf, term, kMover ? &prec : nullptr)) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; c.store(kSlotDone); return kSlotDone; }
     c.trace(104 | (static_cast<uint64_t>(c.plen) << 8));
     const bool playout = kPlayout && term == 0 && c.seat_eval_playout(cp);   // (a terminal leaf's evaluation is never used)
     const bool needs_net = term == 0 && !c.seat_eval_random(cp) && !playout;
@@ -1330,6 +1328,18 @@ __device__ __forceinline__ void round_body(const EngineParams& ep, const EngineA
   }
   c.store(insert_key_set == 2 ? kSlotQueued : kSlotWaitEval);
   c.trace(106);
+  return insert_key_set == 2 ? kSlotQueued : kSlotWaitEval;
+}
+template <class GM, bool kPlayout = false, bool kMover = false>
+__device__ __forceinline__ void round_body(const EngineParams& ep, const EngineArrays& ar, const uint32_t gtid) {
+  constexpr int G = GM::GROUP;
+  uint32_t slot = gtid / G;
+  const uint32_t lane = gtid % G;
+  if constexpr (kMover) {
+    if (slot >= ar.ctl->mover_count) return;
+    slot = ar.mover_list[slot];
+  }
+  (void)round_slot<GM, kPlayout, kMover>(ep, ar, slot, lane);
 }
 template <class GM, bool kPlayout = false, bool kMover = false>
 __global__ __launch_bounds__(256, 1) void k_round(EngineParams ep, EngineArrays ar) {

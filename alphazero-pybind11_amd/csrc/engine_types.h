@@ -22,7 +22,9 @@ enum SlotState : uint8_t {
 enum SlotFlags : uint8_t { kFlagCapped = 1, kFlagPlaythrough = 2, kFlagLeafNeedsNet = 4,
                            kFlagPendRec = 8 /* ar.pend[slot] describes the pending simulation (split rounds) */,
                            kFlagReqOut = 16 /* pipeline: the pending leaf is a request in the net ring / an answer in the result
-                                               granules tagged ar.req_seq[slot]; cleared when the answer is consumed or settled */ };
+                                               granules tagged ar.req_seq[slot]; cleared when the answer is consumed or settled */,
+                           kFlagListed = 32 /* pipeline: a tree wavefront handed the slot to the move step (MOVE ring); cleared by the
+                                               move step - what is still set when an epoch ends goes to the boundary's move step */ };
 
 // node META word: [31:0] first child (tree-relative), [43:32] child count,
 // [55:44] move, [56] player to move at the node, [59:57] terminal code

@@ -37,6 +37,8 @@ struct PipeCtl {          // zeroed when the pipeline is created; lives across e
   uint32_t tail; uint32_t pad1[31];             // ring tickets handed out to tree wavefronts (free-running)
   uint32_t rhead; uint32_t pad4[31];            // READY-ring positions drawn by tree wavefronts (free-running, runs ahead of rtail)
   uint32_t rtail; uint32_t pad5[31];            // READY-ring tickets handed out (seed kernel, net workgroups, tree wavefronts)
+  uint32_t mhead; uint32_t pad6[31];            // MOVE-ring positions drawn by mover wavefronts
+  uint32_t mtail; uint32_t pad7[31];            // MOVE-ring tickets handed out (seed kernel: game starts; tree wavefronts: completed searches)
   uint32_t err;           // PipeErr bits, sticky: every pipeline kernel leaves at once when it is set
   uint32_t pad2;
   unsigned long long tiles;         // net tiles run
@@ -48,7 +50,7 @@ struct PipeCtl {          // zeroed when the pipeline is created; lives across e
   // waiting for requests, [8] net: ticks in tiles
   unsigned long long prof[16];
 };
-static_assert(sizeof(PipeCtl) == 768, "six lines");
+static_assert(sizeof(PipeCtl) == 1024, "eight lines");
 
 struct PipeEpoch {        // an allocation of its own, zeroed before every epoch (one memset)
   unsigned long long sims; uint32_t pad0[30];   // simulations finished in this epoch
@@ -61,7 +63,8 @@ struct PipeEpoch {        // an allocation of its own, zeroed before every epoch
   uint32_t dead;          // slots without a game (retired, or ended and not yet restarted)
   uint32_t tree_late, net_late;   // census: the latest start of a tree / net workgroup, in 100 MHz ticks after the first workgroup of the epoch
   uint32_t ins_done;      // insert-log entries already applied (the first insert launch runs while the net side drains)
-  uint32_t pad1[20];
+  uint32_t moved;         // move steps run by the mover wavefronts in this epoch
+  uint32_t pad1[19];
 };
 static_assert(sizeof(PipeEpoch) == 256, "memset block: a multiple of 16 bytes");
 
@@ -70,6 +73,9 @@ struct PipeArrays {
   PipeEpoch* ep;
   unsigned long long* ring;   // [kPipeRing][kReqGranules]
   unsigned long long* rring;  // [kPipeRing] READY ring: {tag16 | slot}
+  unsigned long long* mring;  // [kPipeRing] MOVE ring: {tag16 | slot} - slots whose next step is the move step's (a game start; the
+                              // simulation that completes a search and the move behind it; a leaf that is the root)
+  uint32_t n_mover_wgs;       // the first n tree workgroups give their last wavefront to the move step
   unsigned long long* res;    // [S][kResStride]
   // insert log: (key, pi, v) of every answer consumed in the epoch; applied to the position cache between epochs
   uint64_t* ins_key;          // [ins_cap]

@@ -57,8 +57,9 @@ __global__ void k_pipe_seed(EngineParams ep, EngineArrays ar, PipeArrays pa) {
   if (ar.ctl->stop != 0 || pc->err != 0) { atomicAdd(&pe->dead, 1u); return; }
   const uint8_t sst = ar.sstate[slot];
   if (sst == kSlotDone || sst == kSlotEnded) { atomicAdd(&pe->dead, 1u); return; }
-  if (sst != kSlotWaitEval && sst != kSlotQueued) {       // kSlotFresh / kSlotRestart: a game start
-    ar.mover_list[atomicAdd(&ar.ctl->mover_count, 1u)] = slot;
+  if (sst != kSlotWaitEval && sst != kSlotQueued) {       // kSlotFresh / kSlotRestart: a game start is the move step's
+    const uint32_t pos = atomicAdd(&pc->mtail, 1u);
+    g_st(pa.mring + (pos & (kPipeRing - 1u)), (pipe_lap_tag(pos) << 48) | static_cast<unsigned long long>(slot));
     atomicAdd(&pe->waiting, 1u);
     return;
   }
@@ -81,6 +82,105 @@ __global__ void k_pipe_seed(EngineParams ep, EngineArrays ar, PipeArrays pa) {
   }
   const uint32_t pos = atomicAdd(&pc->rtail, 1u);
   g_st(pa.rring + (pos & (kPipeRing - 1u)), (pipe_lap_tag(pos) << 48) | static_cast<unsigned long long>(slot));     // (answers no request: sequence field 0)
+}
+
+// ---- the move step inside the epoch: the last wavefront of the first n_mover_wgs workgroups serves the MOVE ring -----------------
+// A slot a tree wavefront lists (its next backup completes a search, or its leaf is the root) and a slot whose game has to start
+// run the lock-step engine's own move step (round_slot<kMover>: backup, move, history row, re-rooting, game step / game end,
+// first descent of the next search) here, eight slots per pass, and go straight back into the pipeline: a leaf for the net
+// becomes a request, an answer at hand a READY token.  A finished game waits for the epoch boundary (k_assign restarts it).
+// Moves are rare (one per ~800 simulations of a slot): a few wavefronts keep up, and no slot idles until the epoch ends.
+// A function of its own, NOT inlined: inside k_pipe_tree its 244 registers pushed the tree loop into scratch (pass 50 -> 73 us).
+template <class GM>
+__device__ __attribute__((noinline)) void pipe_mover_loop(const EngineParams& ep, const EngineArrays& ar, const PipeArrays& pa, const uint64_t t_start) {
+  const uint32_t wlane = threadIdx.x & 63u, grp = wlane >> 3, lane = wlane & 7u;
+  PipeCtl* const pc = pa.ctl;
+  PipeEpoch* const pe = pa.ep;
+  uint32_t mw0 = 0, mwn = 0, mwdone = 0;
+  for (;;) {
+    uint32_t my_slot = 0xFFFFFFFFu, n_tok = 0;
+    uint64_t t_first = 0;
+    bool leave = false;
+    for (;;) {
+      if (mwdone == mwn) {
+        uint32_t h = 0;
+        if (wlane == 0) h = atomicAdd(&pc->mhead, kTreeWindow);
+        mw0 = __builtin_amdgcn_readfirstlane(h); mwn = kTreeWindow; mwdone = 0;
+      }
+      const uint32_t left = mwn - mwdone;
+      unsigned long long tok = 0;
+      bool here = false;
+      if (lane == 0 && grp < left) {
+        const uint32_t pos = mw0 + mwdone + grp;
+        tok = g_ld(pa.mring + (pos & (kPipeRing - 1u)));
+        here = (tok >> 48) == pipe_lap_tag(pos);
+      }
+      uint32_t ctl_word = 0;
+      if (wlane == 7) ctl_word = g_ld(&pe->stop) | g_ld(&pc->err);
+      const uint64_t now = wall_clock64();
+      if (__builtin_amdgcn_readlane(ctl_word, 7) != 0u || ar.ctl->stop != 0) { leave = true; break; }
+      if (now - t_start > pa.cap_ticks) { if (wlane == 0) atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTimeout)); leave = true; break; }
+      const unsigned long long hm = __ballot(here);
+      uint32_t k = 0;
+      while (k < left && ((hm >> (8 * k)) & 1ull)) ++k;
+      if (k == left || (k != 0u && t_first != 0 && now - t_first > kTreePatience)) {
+        n_tok = k;
+        const uint32_t sl = static_cast<uint32_t>(__shfl(static_cast<uint32_t>(tok & 0xFFFFull), static_cast<int>(grp * 8), 64));
+        if (grp < k) my_slot = sl;
+        break;
+      }
+      if (k != 0u && t_first == 0) t_first = now;
+      if (k == 0u) __builtin_amdgcn_s_sleep(32);
+    }
+    if (leave) break;
+    mwdone += n_tok;
+    const bool on = my_slot != 0xFFFFFFFFu;
+    const uint32_t slot = on ? my_slot : 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    uint32_t res_state = 0xFFu, seq = 0;
+    if (on) res_state = round_slot<GM, false, true>(ep, ar, slot, lane);
+    if (on && res_state == kSlotQueued && lane == 0) {
+      // the leaf goes to the net: the slot takes the form of a slot with a request out (k_pipe_seed does the same between epochs)
+      seq = ar.req_seq[slot] + 1u;
+      if (seq == 0u) seq = 1u;
+      ar.flags[slot] = ar.flags[slot] | kFlagReqOut;
+      ar.sstate[slot] = kSlotWaitEval;
+    }
+    seq = __shfl(seq, static_cast<int>(grp * 8), 64);
+    // everything the move steps wrote is visible before a request or a token of theirs is
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (on && res_state == kSlotQueued) {
+      if (lane == 0) g_st(ar.req_seq + slot, seq);
+      uint32_t pos = 0;
+      if (lane == 0) pos = atomicAdd(&pc->tail, 1u);
+      pos = __shfl(pos, static_cast<int>(grp * 8), 64);
+      const size_t S_ = static_cast<size_t>(ep.S);
+      const uint64_t payload = lane == 0 ? ar.leaf_pos[0 * S_ + slot] : lane == 1 ? ar.leaf_pos[1 * S_ + slot]
+                             : lane == 2 ? (static_cast<uint64_t>(slot) | ((ar.leaf_pos[2 * S_ + slot] & 1ull) << 16)) : static_cast<uint64_t>(seq);
+      if (lane < kReqGranules)
+        g_st(pa.ring + static_cast<size_t>(pos & (kPipeRing - 1u)) * kReqGranules + lane, (pipe_lap_tag(pos) << 48) | (payload & kMask48));
+    }
+    {
+      const unsigned long long rm = __ballot(on && res_state == kSlotWaitEval && lane == 0);
+      if (rm) {
+        uint32_t base = 0;
+        if (wlane == 0) base = atomicAdd(&pc->rtail, static_cast<uint32_t>(__popcll(rm)));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (on && res_state == kSlotWaitEval && lane == 0) {
+          const uint32_t pos = base + static_cast<uint32_t>(__popcll(rm & ((1ull << (grp * 8)) - 1ull)));
+          g_st(pa.rring + (pos & (kPipeRing - 1u)), (pipe_lap_tag(pos) << 48) | static_cast<unsigned long long>(slot));
+        }
+      }
+      const unsigned long long dm = __ballot(on && lane == 0 && (res_state == kSlotEnded || res_state == kSlotDone));
+      const unsigned long long om = __ballot(on && lane == 0);
+      if (wlane == 0) {
+        if (dm) atomicAdd(&pe->dead, static_cast<uint32_t>(__popcll(dm)));
+        atomicSub(&pe->waiting, static_cast<uint32_t>(__popcll(om)));
+        atomicAdd(&pe->moved, static_cast<uint32_t>(__popcll(om)));
+      }
+    }
+  }
 }
 
 // NT: threads per workgroup.  512 = eight wavefronts of 256 registers: the workgroup has a CU to itself, so no tree wavefront
@@ -109,6 +209,17 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
   uint64_t pf_pass = 0, pf_idle = 0, pf_n = 0, pf_act = 0, pf_polls = 0, pf_io = 0, pf_lvls = 0;
   uint64_t pf_ph[5] = {0, 0, 0, 0, 0};     // per group (lane 0 counts): ticks in backup / descent / expansion / probe, simulations
   SlotCtx<GM> c(ep, ar, 0u, lane);
+
+  // ---- the move step inside the epoch: the last wavefront of the first n_mover_wgs workgroups serves the MOVE ring (pipe_mover_loop)
+  if (go && blockIdx.x < pa.n_mover_wgs && (threadIdx.x >> 6) == static_cast<uint32_t>(NT / 64 - 1)) {
+    // (copies: the callee takes references; references to the kernel's own arguments would move THOSE to the stack - the tree
+    // loop below then reads every array pointer from scratch)
+    const EngineParams ep_m = ep;
+    const EngineArrays ar_m = ar;
+    const PipeArrays pa_m = pa;
+    pipe_mover_loop<GM>(ep_m, ar_m, pa_m, t_start);
+    go = false;
+  }
 
   while (go) {
     const uint64_t pf_t0 = wall_clock64();
@@ -296,7 +407,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
       for (;;) {
         if (AZMI_SEL(c.t_depth, cp) + 1 >= goal || c.cur == root) {
           // the next backup completes the search (a move follows) or the evaluated leaf is the root (temperature, noise): the move step's
-          if (lane == 0) ar.mover_list[atomicAdd(&ar.ctl->mover_count, 1u)] = slot;
+          c.flags |= kFlagListed;
           listed = true;
           st = kGrpIdle;
           break;
@@ -483,14 +594,23 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
         }
       }
     }
-    // ---- the epoch's counts: simulations (the quota ends it), slots handed to the move step
+    // ---- the epoch's counts: simulations (the quota ends it), slots handed to the move step (MOVE-ring tokens: a mover
+    // wavefront takes them inside the epoch; what it does not get to is the boundary's)
     {
       uint32_t x = lane == 0 ? sims_done + sims_mem : 0u;
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
       if (wlane == 0 && x) atomicAdd(&pe->sims, static_cast<unsigned long long>(x));
       const unsigned long long im = __ballot(listed && lane == 0);
-      if (im && wlane == 0) atomicAdd(&pe->waiting, static_cast<uint32_t>(__popcll(im)));
+      if (im) {
+        uint32_t base = 0;
+        if (wlane == 0) { atomicAdd(&pe->waiting, static_cast<uint32_t>(__popcll(im))); base = atomicAdd(&pc->mtail, static_cast<uint32_t>(__popcll(im))); }
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (listed && lane == 0) {
+          const uint32_t pos = base + static_cast<uint32_t>(__popcll(im & ((1ull << (grp * 8)) - 1ull)));
+          g_st(pa.mring + (pos & (kPipeRing - 1u)), (pipe_lap_tag(pos) << 48) | static_cast<unsigned long long>(slot));
+        }
+      }
     }
     pf_io += wall_clock64() - pf_t3;
   }
@@ -663,8 +783,11 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
 __global__ void k_pipe_settle(EngineParams ep, EngineArrays ar, PipeArrays pa) {
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   // the net workgroups left with unused window positions (head ran ahead of tail): the next epoch's windows start at tail
-  if (slot == 0) { pa.ctl->head = pa.ctl->tail; pa.ctl->rhead = pa.ctl->rtail; }
+  if (slot == 0) { pa.ctl->head = pa.ctl->tail; pa.ctl->rhead = pa.ctl->rtail; pa.ctl->mhead = pa.ctl->mtail; }
   if (slot >= ep.S) return;
+  // slots the mover wavefronts did not get to (listed late in the epoch, or no mover wavefronts at all): the boundary's move step
+  if (ar.flags[slot] & kFlagListed) ar.mover_list[atomicAdd(&ar.ctl->mover_count, 1u)] = slot;
+  else { const uint8_t s0 = ar.sstate[slot]; if (s0 == kSlotFresh || s0 == kSlotRestart) ar.mover_list[atomicAdd(&ar.ctl->mover_count, 1u)] = slot; }
   const uint8_t f = ar.flags[slot];
   if (!(f & kFlagReqOut)) return;
   const uint32_t seq = ar.req_seq[slot];
@@ -771,6 +894,7 @@ int pipe_create(azmi_pm* pm, size_t tile_lds) {
   if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.ep, 1);
   if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.ring, static_cast<size_t>(kPipeRing) * kReqGranules);
   if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.rring, static_cast<size_t>(kPipeRing));
+  if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.mring, static_cast<size_t>(kPipeRing));
   if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.res, static_cast<size_t>(S) * kResStride);
   if (rc != AZMI_OK) return rc;
   // tree workgroups: lane-groups for half of the slots (the other half is with the net at any time; slots are not bound to
@@ -782,6 +906,8 @@ int pipe_create(azmi_pm* pm, size_t tile_lds) {
   ps->tree_wgs = std::min<uint32_t>(96u, std::max<uint32_t>(1u, (S * 3u + 127u) / 128u));
   if (const char* e = getenv("AZMI_PIPE_TREE_WGS")) ps->tree_wgs = std::max(1, atoi(e));
   pa.n_tree_wgs = ps->tree_wgs;
+  // mover wavefronts: 8 of them take 64 move steps per ~70 us, ten times the rate 4096 slots x 800 simulations ask for
+  pa.n_mover_wgs = std::min<uint32_t>(ps->tree_wgs, getenv("AZMI_PIPE_MOVERS") ? static_cast<uint32_t>(std::max(0, atoi(getenv("AZMI_PIPE_MOVERS")))) : 8u);
   ps->lds_bytes = tile_lds + kPipeXs;
   // The chip holds two 256-thread workgroups of 256 registers per lane on a CU: the tree side takes tree_wgs of those 512
   // places, the net side what is left (AZMI_PIPE_NET_WGS overrides; a net workgroup that finds no place starts late and

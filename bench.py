@@ -52,11 +52,11 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=20, help="timed steps; a step = --rounds-per-step engine rounds")
     ap.add_argument("--warmup", type=int, default=5, help="untimed steps before the window (after the de-phasing pre-roll)")
     ap.add_argument("--rounds-per-step", type=int, default=None,
-                    help="lock-step driver: engine rounds per step (default 2048); pipeline driver: epochs per step (default 192)")
+                    help="lock-step driver: engine rounds per step (default 2048); pipeline driver: epochs per step (default 80)")
     ap.add_argument("--driver", choices=["auto", "pipeline", "rounds"], default="auto",
                     help="pipeline = asynchronous tree / net pipeline (azmi_run_pipeline: Connect4, PUCT); rounds = lock-step rounds "
                          "(azmi_run_rounds); auto = the pipeline where it applies")
-    ap.add_argument("--sims-per-epoch", type=int, default=None, help="pipeline driver: simulations per epoch (default 96 x concurrent games)")
+    ap.add_argument("--sims-per-epoch", type=int, default=None, help="pipeline driver: simulations per epoch (default 256 x concurrent games)")
     ap.add_argument("--game", choices=["connect4", "tawlbwrdd", "stargambit"], default="connect4",
                     help="connect4 = BASELINE configs[1] (the headline); tawlbwrdd = configs[2] (2048 games, 400 sims, YAML net); "
                          "stargambit = configs[4] per GPU (star_gambit_unified, 1024 games, 800 sims, 200000-entry device cache)")
@@ -376,7 +376,7 @@ def main():
     # the pipeline drives ONE engine with every slot (one GPU-wide position cache); the lock-step driver wants 4 shards
     use_pipe = args.driver == "pipeline" or (args.driver == "auto" and not tafl and not args.gumbel and (args.net or "hip") == "hip" and not args.dry)
     if args.engines is None: args.engines = 1 if use_pipe else 4      # lock-step, measured: Connect4 1/2/4/8 shards and Tawlbwrdd 2/4/8 shards both peak at 4
-    if args.rounds_per_step is None: args.rounds_per_step = 192 if use_pipe else 2048
+    if args.rounds_per_step is None: args.rounds_per_step = 80 if use_pipe else 2048
     if args.cache is None: args.cache = 200_000 if sg else 0 if tafl else 32_000_000      # Tawlbwrdd: measured 5 % hit rate with 2 M entries and 16 % fewer games/s, so off; StarGambit: configs[4] / config.py:197
     # SURVEY §8d; StarGambit net (configs/star_gambit_unified.yaml, 36 x 13 x 13): stem 7.0 + 8 trunk convs 99.7 + head 1x1s 2.8 + two
     # head convs 24.9 + policy 1x1 0.2 + value / global FCs 0.7 = 135.3 MFLOP per position
@@ -451,7 +451,7 @@ def main():
                     v_buf.copy_(v)
                     pi_buf.copy_(pi)
 
-        spe = args.sims_per_epoch or 96 * S
+        spe = args.sims_per_epoch or 256 * S
         pipe_acc = {"net_us": 0.0, "tree_us": 0.0, "epochs": 0, "tiles": 0, "boards": 0, "late": 0, "host_us": 0.0}
 
         def run_rounds_on(group, n, ev=None):
@@ -775,7 +775,7 @@ def main():
 
                     def run2(n, pms2=pms2, pipe2=pipe2, net2=net2, S2=S2, sps2=sps2):
                         if pipe2:
-                            az.run_pipeline(pms2[0], net2, n, 96 * S2, sps2[0])
+                            az.run_pipeline(pms2[0], net2, n, 256 * S2, sps2[0])
                         else:
                             done2 = 0
                             while done2 < n:
