@@ -364,7 +364,10 @@ typedef struct azmi_net_desc {
   int32_t v_head_convs, pi_head_convs, v_fc_layers, policy_channels;
   /* 0 = bf16 operands on the matrix cores, fp32 accumulation (what the reference runs under autocast,
    * neural_net.py:811-813) — the throughput path.  1 = plain fp32 arithmetic, layer by layer: the precision
-   * the 1e-5 parity tier refers to; blob layout in csrc/leafnet_f32.hip. */
+   * the 1e-5 parity tier refers to, for any net shape; blob layout in csrc/leafnet_f32.hip.  2 = "bf16x3" (6x7 flat-head
+   * family only): the bf16 tile with weights and activations split into bf16 high + low parts, three MFMAs per product -
+   * within 1e-5 of the fp32 outputs (measured 4e-7 / 5e-6) at a third of the bf16 rate; blob: the bf16 layout with the
+   * stem's fragments twice (high, low) and three chunks [W_hi][W_hi][W_lo] per tap and for the head 1x1 (hip_net.fold). */
   int32_t precision;
   /* spatial head with GLOBAL actions (num_moves > policy_channels * H * W: StarGambit's 18 deploys + end turn,
    * neural_net.py:413-426, 486-493): hidden width of pi_global (NNArgs.pi_fc_hidden); the global logits come from the
