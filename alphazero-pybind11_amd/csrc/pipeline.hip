@@ -891,6 +891,13 @@ int pipe_create(azmi_pm* pm, size_t tile_lds) {
   PipeArrays& pa = ps->pa;
   const uint32_t S = pm->ep.S;
   int rc = pipe_alloc(ps, pa.ctl, 1);
+  if (rc == AZMI_OK && getenv("AZMI_PIPE_POS0")) {
+    // test hook: the rings' free-running 32-bit positions start here instead of at 0 (a long run wraps them after ~2 minutes:
+    // tests/test_gpu_pipeline.py starts just below 2^32)
+    PipeCtl h{};
+    h.head = h.tail = h.rhead = h.rtail = h.mhead = h.mtail = static_cast<uint32_t>(strtoul(getenv("AZMI_PIPE_POS0"), nullptr, 0));
+    if (hipMemcpy(pa.ctl, &h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) return azmi_host_fail(AZMI_ERR_NO_DEVICE, "pipeline: control block upload failed");
+  }
   if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.ep, 1);
   if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.ring, static_cast<size_t>(kPipeRing) * kReqGranules);
   if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.rring, static_cast<size_t>(kPipeRing));

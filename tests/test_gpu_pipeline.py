@@ -149,3 +149,24 @@ def test_pipeline_rejects_what_it_does_not_drive():
     pp2 = _selfplay_params(az, 4, 8, cache=0)
     tw = az.PlayManager(az.TawlbwrddGS(), pp2, seed=1)
     assert not az.pipeline_supported(tw, hip)
+
+
+def test_ring_positions_wrap_past_2_to_the_32(monkeypatch):
+    """the rings' positions are free-running 32-bit counters (a long run wraps them after about two minutes): started 40,000
+    positions below 2^32 (AZMI_PIPE_POS0, read when an engine's pipeline is created), the request, READY and MOVE rings all wrap
+    inside this run and the games are still the lock-step engine's."""
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=33), spec)
+    S, seed = 192, 555
+    pp = _selfplay_params(az, S, 150, cache=1 << 15)
+    monkeypatch.setenv("AZMI_PIPE_POS0", str((1 << 32) - 40000))
+    pa, (ra, ca), stats = _pipeline_games(az, pp, seed, hip, sims_per_epoch=S * 48)
+    monkeypatch.delenv("AZMI_PIPE_POS0")
+    assert pa.counters()["evals"] > 60000             # more requests than the distance to the wrap
+    pb, (rb, cb) = _lockstep_games(az, pp, seed, hip)
+    assert pa.games_completed() == pb.games_completed() == S
+    ra, ca = _sorted_log(ra, ca)
+    rb, cb = _sorted_log(rb, cb)
+    assert np.array_equal(ra, rb) and np.array_equal(ca, cb)
