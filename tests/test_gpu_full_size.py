@@ -267,3 +267,53 @@ def test_full_size_tawlbwrdd_with_the_net_plays_every_game_to_the_end(oracle):
     sel = rows[:, 0] == s
     assert sel.sum() == len(orows)
     assert np.array_equal(rows[sel][:, 1:], orows[:, 1:]) and np.array_equal(counts[sel], ocounts)
+
+
+def test_full_size_pipeline_plays_the_lockstep_engines_games(oracle):
+    """the benched configuration through the benched driver: bench.py's self-play flags, 4096 x 800, the 6b64c HIP net, one
+    engine with a 32 M-entry cache driven by the asynchronous pipeline (persistent tree / mover / net wavefronts, 12 ms epochs)
+    - all 4096 games equal, move for move and visit count for visit count, the games of the lock-step engine with the same
+    seed; one sampled slot is replayed by the oracle with the same net as its evaluator."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import alphazero as az
+    import bench
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=0), spec)
+    st = torch.cuda.Stream()
+    seed = 31415
+    pp = bench.selfplay_params(az, S, SIMS, S, cache=32_000_000)
+    runs = []
+    for driver in ("pipeline", "rounds"):
+        pm = az.PlayManager(az.Connect4GS(), pp, seed=seed, log_moves=True, history_capacity=S * 42 * 2)
+        assert az.pipeline_supported(pm, hip)
+        guard = 0
+        while pm.poll(st.cuda_stream)[1] > 0 and guard < 4000:
+            if driver == "pipeline":
+                az.run_pipeline(pm, hip, 4, 256 * S, st.cuda_stream)
+            else:
+                az.run_rounds([pm], hip, 512, [st.cuda_stream])
+            guard += 1
+        assert pm.games_completed() == S and pm.scores().sum() == S
+        rows, counts = pm.move_log()
+        runs.append((pm, rows, counts))
+    (pa, ra, ca), (pb, rb, cb) = runs
+    assert _digest(ra, ca) == _digest(rb, cb)
+    assert np.array_equal(pa.scores(), pb.scores()) and pa.counters()["sims"] == pb.counters()["sims"]
+    assert pa.counters()["cache_hits"] > 0.4 * pa.counters()["sims"]
+    dev = torch.device("cuda", 0)
+
+    def net_eval(canon):
+        v, pi = hip.process(torch.from_numpy(np.ascontiguousarray(canon)).to(dev))
+        torch.cuda.synchronize()
+        return v.cpu().numpy(), pi.cpu().numpy()
+    s = 2718
+    one = az.PlayParams(); one.__dict__.update(pp.__dict__)
+    one.games_to_play, one.concurrent_games, one.max_batch_size = 1, 1, 1
+    o = oracle.PlayManager(oracle.GAME_CONNECT4, one, oracle.slot_seed(seed, s), per_slot_rng=False, perm_base=s)
+    o.run(net_eval)
+    orows, ocounts = o.moves()
+    sel = ra[:, 0] == s
+    assert np.array_equal(ra[sel][:, 1:], orows[:, 1:]) and np.array_equal(ca[sel], ocounts)
