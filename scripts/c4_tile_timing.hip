@@ -87,6 +87,9 @@ void sweep(const NetDesc& nd, const NetPtrs& np, uint32_t batch) {
     printf("  5 no MFMAs                  %7.1f us\n", run<TG, 5>(nd, np, canon, v, pi, batch, reps));
     printf("  6 stem only                 %7.1f us\n", run<TG, 6>(nd, np, canon, v, pi, batch, reps));
     printf("  7 stem + trunk              %7.1f us\n", run<TG, 7>(nd, np, canon, v, pi, batch, reps));
+    printf("  8 ... + head 1x1 conv       %7.1f us\n", run<TG, 8>(nd, np, canon, v, pi, batch, reps));
+    printf("  9 ... + policy FC, v pool   %7.1f us\n", run<TG, 9>(nd, np, canon, v, pi, batch, reps));
+    printf(" 10 ... + value FCs           %7.1f us\n", run<TG, 10>(nd, np, canon, v, pi, batch, reps));
     if (getenv("C4T_NO_CLOCK")) { CK(hipFree(canon)); CK(hipFree(v)); CK(hipFree(pi)); return; }
     clock_of<TG, 0>(nd, np, canon, v, pi, batch, "full tile");
     clock_of<TG, 4>(nd, np, canon, v, pi, batch, "matrix stream alone (no fragment reads)");
