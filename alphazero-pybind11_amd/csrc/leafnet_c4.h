@@ -394,16 +394,11 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
         if (c == NCH - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (DBG != 2) { __builtin_amdgcn_s_barrier(); }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (DBG != 3) {    // chunk c + 4 into the slot chunk c - 1 has left (the convolution's last chunk: issued here; else
-          if (c == NCH - 1)          // one k-step later, inside the next chunk's matrix stream instead of in front of this k-step's)
-            issue_chunk(c + 4 < NCH ? wbase + (c + 4) * CHUNK_BYTES : wnext + (c + 4 - NCH) * CHUNK_BYTES, slot == 0 ? NRING - 1 : slot - 1);
-        }
+        if constexpr (DBG != 3)      // chunk c + 4 into the slot chunk c - 1 has left
+          issue_chunk(c + 4 < NCH ? wbase + (c + 4) * CHUNK_BYTES : wnext + (c + 4 - NCH) * CHUNK_BYTES, slot == 0 ? NRING - 1 : slot - 1);
         slot = slot == NRING - 1 ? 0 : slot + 1;                 // ring slot of chunk c + 1
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (DBG != 3) {
-        if (ksl == 0 && c > 0)       // (slot = chunk c's slot: chunk c - 2's is two behind it)
-          issue_chunk(c + 3 < NCH ? wbase + (c + 3) * CHUNK_BYTES : wnext + (c + 3 - NCH) * CHUNK_BYTES, slot >= 2 ? slot - 2 : slot + NRING - 2);
+      } else {
+        __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (DBG != 4) {
         if (ks + 1 < NKS) {
