@@ -1091,7 +1091,7 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
   }
   if (hc.err)
     return azmi_host_fail(AZMI_ERR_STATE, "pipeline error mask 0x%x (1 a spin hit the epoch's time cap, 2 a ring entry never arrived, 4 a result tag "
-                          "did not match, 8 insert log full, 16 cache lock, 32 slots); census: %u of %u tree and %u of %u net workgroups started; "
+                          "did not match, 8 insert log full, 16 cache lock, 32 slots, 64 the net side hit the time cap); census: %u of %u tree and %u of %u net workgroups started; "
                           "last epoch: head %u tail %u sims %llu waiting %u dead %u stop %u tree_done %u tiles %llu boards %llu; latest tree / net workgroup start %u / %u us",
                           hc.err, he.tree_arrived, ps->tree_wgs, he.net_arrived, ps->net_wgs, hc.head, hc.tail, he.sims, he.waiting, he.dead, he.stop,
                           he.tree_done, hc.tiles, hc.tile_boards, he.tree_late / 100u, he.net_late / 100u);

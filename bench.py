@@ -335,6 +335,26 @@ def orchestrate(args):
     return 0
 
 
+def _pipeline_probe(device_index, slots):
+    """three short calls of the asynchronous pipeline on a throw-away engine of `slots` games (50 simulations per move, small cache);
+    False when the engine does not qualify or the library reports a pipeline error"""
+    try:
+        import alphazero as az
+        from alphazero import torch_net
+        spec = torch_net.connect4_spec()
+        hip = az.HipLeafNet(torch_net.random_init(spec, seed=0), spec, device=device_index)
+        pp = selfplay_params(az, slots, 50, 1 << 30, cache=1 << 20)
+        pm = az.PlayManager(az.Connect4GS(), pp, seed=1, device=device_index)
+        if not az.pipeline_supported(pm, hip):
+            return False
+        for _ in range(3):
+            az.run_pipeline(pm, hip, 2, 64 * slots)
+        return True
+    except RuntimeError as e:
+        sys.stderr.write("bench.py: pipeline probe: %s\n" % (str(e)[:300],))
+        return False
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -375,6 +395,19 @@ def main():
     if args.sims is None: args.sims = 800 if sg else 400 if tafl else 800
     # the pipeline drives ONE engine with every slot (one GPU-wide position cache); the lock-step driver wants 4 shards
     use_pipe = args.driver == "pipeline" or (args.driver == "auto" and not tafl and not args.gumbel and (args.net or "hip") == "hip" and not args.dry)
+    if use_pipe and args.driver == "auto":
+        # a safety net, not a tuning knob: the pipeline's persistent kernels rely on how this part places workgroups.
+        # A short probe at the bench's slot count runs before anything is sized; if it raises on this box (census, time cap), every
+        # rank falls back to the lock-step driver - a slower line beats none - and the line's config says which driver ran.
+        ok = _pipeline_probe(local_rank, args.games)
+        if use_dist:
+            flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(flag.item() > 0.5)
+        if not ok:
+            if rank == 0:
+                sys.stderr.write("bench.py: the pipeline probe failed on this box: falling back to --driver rounds\n")
+            use_pipe = False
     if args.engines is None: args.engines = 1 if use_pipe else 4      # lock-step, measured: Connect4 1/2/4/8 shards and Tawlbwrdd 2/4/8 shards both peak at 4
     if args.rounds_per_step is None: args.rounds_per_step = 80 if use_pipe else 2048
     if args.cache is None: args.cache = 200_000 if sg else 0 if tafl else 32_000_000      # Tawlbwrdd: measured 5 % hit rate with 2 M entries and 16 % fewer games/s, so off; StarGambit: configs[4] / config.py:197
