@@ -4,21 +4,26 @@
 // workers and the batcher threads (play_manager.cc:258-600, concurrent_queue.h:130-217).  The lock-step round of
 // engine.hip (cache insert -> k_sim -> k_net_move, one after the other, a round as long as its slowest slot) gave that up.
 // Here it is back, on the device: for one EPOCH
-//   * tree wavefronts (persistent, 8 game slots each, k_pipe_tree) run simulation after simulation for their slots and hand
-//     every leaf that needs the net to
+//   * tree wavefronts (persistent, k_pipe_tree) draw eight slot tokens at a time from the READY ring - a slot is not bound to a
+//     wavefront -, run simulation after simulation for them and hand every leaf that needs the net to
 //   * net workgroups (persistent, k_pipe_net) that pull 3- or 6-board tiles off a request ring as soon as leaves exist
-//     (continuous batching) and hand the (v, pi) rows back to the slot that asked.
-// The two sides talk through HBM only:
+//     (continuous batching), write the (v, pi) answers as result granules and put the answered slots back into the READY ring;
+//   * mover wavefronts (the last wavefront of a few tree workgroups) serve the MOVE ring: slots whose next step is the rare,
+//     register-hungry one - the simulation that completes a search and the move behind it, a game start - run the lock-step
+//     engine's own move step (round_slot<kMover>) there and go straight back into the pipeline.
+// The sides talk through HBM only:
 //   * request ring: a tree group takes a ticket (tail) and writes its leaf as kReqGranules 8-byte granules
-//     {tag16 | payload48}: stones of player 0 | stones of player 1 | slot, player | sequence number; a net workgroup claims
-//     [head, head + n) and re-reads the granules until every tag is the tag of the ring lap;
-//   * result granules: per slot kResStride 8-byte granules {seq32 | float bits}, pi[0..M) then v[0..P]; the slot's tree group
-//     polls them until every tag is the sequence number of its request.
-// Every granule is ONE naturally aligned 8-byte agent-scope atomic store / load (write-through, L1-bypassing): the data is
-// its own flag, no fence, no ordering between granules is assumed (cdna_hip_programming.md Guideline 16, form R2).
-// Everything else a slot owns (its trees, its state) is only ever touched by the one wavefront that owns the slot, and
-// what happens rarely - a move, a game's end, a new game (the register-hungry code) - is done between epochs by the
-// kernels of the lock-step engine, at a kernel boundary.  Every spin is bounded by a wall-clock cap.
+//     {tag16 | payload48}: stones of player 0 | stones of player 1 | slot, player | sequence number; a net workgroup draws a
+//     window [head, head + n) with one fetch-add and re-reads its granules until every tag is the tag of the ring lap;
+//   * result granules: per slot kResStride 8-byte granules {seq32 | float bits}, pi[0..M) then v[0..P]; the slot's next tree
+//     group polls them until every tag is the sequence number of its request;
+//   * READY / MOVE rings: one 8-byte token {tag16 | seq32 | slot16} per slot that can take its next step.
+// Every granule and token is ONE naturally aligned 8-byte agent-scope atomic store / load (write-through, L1-bypassing): the
+// data is its own flag, no ordering between granules is assumed (cdna_hip_programming.md Guideline 16, form R2).  A slot's
+// state and trees are plain memory that moves between CUs from pass to pass: every pass starts with an agent-scope acquire and
+// ends, before its tokens go out, with an agent-scope release; req_seq[slot] is the word a slot is published with.
+// What still needs a kernel boundary: the position-cache inserts of the epoch's answers (an insert log), game restarts
+// (k_assign), the leftovers of the MOVE ring.  Every spin is bounded by a wall-clock cap; errors are a sticky word (PipeErr).
 #pragma once
 #include <stdint.h>
 

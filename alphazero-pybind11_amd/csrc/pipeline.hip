@@ -1,7 +1,7 @@
 // The asynchronous tree / net pipeline of the Connect4 engine (see pipe_types.h for the structure and the hand-off
-// protocol): persistent tree wavefronts + persistent net workgroups for one EPOCH, then - at a kernel boundary - the rare,
-// register-hungry steps (moves, game ends, new games: the move step and k_assign of the lock-step engine) and the position
-// cache inserts of everything the net answered in the epoch.
+// protocol): persistent tree wavefronts, mover wavefronts and net workgroups for one EPOCH, then - at a kernel boundary - the
+// position-cache inserts of everything the net answered in the epoch, game restarts (k_assign of the lock-step engine) and the
+// move steps the mover wavefronts did not get to.
 //
 // Reference behaviour restated: the worker loop of PlayManager::play (play_manager.cc:258-600) with its queues
 // (concurrent_queue.h:130-217) and GameRunner's batcher / gpu_loop / result_worker threads (game_runner.py:483-552, 651-726);
