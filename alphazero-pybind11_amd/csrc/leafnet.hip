@@ -342,8 +342,9 @@ static int spatial_forward(azmi_net* net, const float* dev_canonical, float* dev
   const uint32_t groups = (batch + 15) / 16;
   const uint32_t parts = static_cast<uint32_t>(net->sd.v_hidden / sp::HFC_SLICE) + (net->sd.num_global > 0 ? 1u : 0u);
   if (net->fc_split) {
-    sp::k_heads_fc_a<<<groups * parts, sp::HFC_THREADS, net->fc_lds, st>>>(net->sd, net->sp, vpool, ppool, hidden, glob, batch, row_count);
-    sp::k_heads_fc_b<<<groups, sp::HFC_THREADS, net->fc_lds, st>>>(net->sd, net->sp, hidden, glob, dev_v, dev_pi, batch, rows, row_count);
+    const int hmax = net->sd.v_hidden > net->sd.pi_hidden || net->sd.num_global == 0 ? net->sd.v_hidden : net->sd.pi_hidden;
+    sp::k_heads_fc_a<<<groups * parts, sp::HFC_THREADS, sp::heads_fc_a_lds(hmax, net->sd.v_fc_layers), st>>>(net->sd, net->sp, vpool, ppool, hidden, glob, batch, row_count);
+    sp::k_heads_fc_b<<<groups, sp::HFC_THREADS, sp::heads_fc_b_lds(net->sd.v_hidden), st>>>(net->sd, net->sp, hidden, glob, dev_v, dev_pi, batch, rows, row_count);
   } else {
     sp::k_heads_fc<<<groups, sp::HFC_THREADS, net->fc_lds, st>>>(net->sd, net->sp, vpool, ppool, dev_v, dev_pi, batch, rows, row_count);
   }

@@ -511,6 +511,14 @@ __global__ __launch_bounds__(NTH, 2) void k_leafnet_sp(SpDesc nd, SpPtrs np, con
 constexpr int HFC_THREADS = 512, HFC_WAVES = HFC_THREADS / 64;
 constexpr int HFC_SLICE = 128;     // units of the last hidden layer per workgroup of k_heads_fc_a (8 tiles: one per wave)
 __host__ __device__ inline size_t heads_fc_lds(int hidden) { return (2 * static_cast<size_t>(hidden) * 16 + HFC_WAVES * 256 + 16 * 32) * sizeof(float); }
+// what the two halves of the split form really use (LDS is what the kernels of a wide-game round compete for: two tile workgroups
+// fill a CU's 160 KB, and so do six tree wavefronts): k_heads_fc_a with two value layers keeps the 64 pooled inputs in its
+// first buffer and one hidden layer in its second; k_heads_fc_b holds one hidden layer.
+__host__ __device__ inline int heads_fc_a_first(int hidden, int layers) { return layers > 2 ? hidden : 64; }
+__host__ __device__ inline size_t heads_fc_a_lds(int hidden, int layers) {
+  return ((static_cast<size_t>(heads_fc_a_first(hidden, layers)) + hidden) * 16 + HFC_WAVES * 256 + 16 * 32) * sizeof(float);
+}
+__host__ __device__ inline size_t heads_fc_b_lds(int hidden) { return (static_cast<size_t>(hidden) * 16 + HFC_WAVES * 256 + 16 * 32) * sizeof(float); }
 
 // x_out[unit][16] = act(W x_in + b) for output tiles [t_begin, t_begin + t_count) of a layer with K inputs; x_out is indexed
 // by the layer's unit number (LDS, or the group's hidden block in HBM).  A wave owns tiles {t, t + HFC_WAVES} together.
@@ -585,8 +593,8 @@ __global__ __launch_bounds__(HFC_THREADS) void k_heads_fc_a(SpDesc nd, SpPtrs np
   if (b0 >= batch) return;
   const int tid = threadIdx.x;
   const int Hmax = nd.v_hidden > nd.pi_hidden ? nd.v_hidden : nd.pi_hidden;
-  float* xa = reinterpret_cast<float*>(lds_fc);               // [hidden][16]
-  float* xb = xa + Hmax * 16;
+  float* xa = reinterpret_cast<float*>(lds_fc);               // [64 inputs, or a hidden layer when there are more than two][16]
+  float* xb = xa + heads_fc_a_first(Hmax, nd.v_fc_layers) * 16;   // [hidden][16]
   float* part = xb + Hmax * 16;                               // [HFC_WAVES][16 outputs][16 boards]
   const float* pooled = part_id < NS ? vpool : ppool;
   for (int i = tid; i < 64 * 16; i += HFC_THREADS) {
