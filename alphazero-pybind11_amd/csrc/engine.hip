@@ -850,6 +850,7 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
   // (measured: Tawlbwrdd 4.49 -> 5.01 M sims/s, StarGambit 1.74 -> 2.14 M sims/s with 1 instead of 4); with RANDOM / PLAYOUT
   // seats only there is no net to wait for and 4 stands.
   ep.max_inline = opts.max_inline ? opts.max_inline : (seats.all_random ? 4u : game == AZMI_GAME_CONNECT4 ? 3u : 1u);
+  pm->max_inline_explicit = opts.max_inline != 0;
   ep.sim_budget = getenv("AZMI_SIM_BUDGET_US") ? static_cast<uint32_t>(100.0 * atof(getenv("AZMI_SIM_BUDGET_US"))) : 0u;
   ep.max_hist_rows = gi.max_turns;
   ep.max_depth = gi.max_turns + 2;

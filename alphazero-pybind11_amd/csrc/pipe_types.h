@@ -81,6 +81,7 @@ struct PipeArrays {
   unsigned long long* mring;  // [kPipeRing] MOVE ring: {tag16 | slot} - slots whose next step is the move step's (a game start; the
                               // simulation that completes a search and the move behind it; a leaf that is the root)
   uint32_t n_mover_wgs;       // the first n tree workgroups give their last wavefront to the move step
+  uint32_t max_inline;        // simulations a group may finish in one pass without the net (cache hits, terminal leaves) before its slot re-queues
   unsigned long long* res;    // [S][kResStride]
   // insert log: (key, pi, v) of every answer consumed in the epoch; applied to the position cache between epochs
   uint64_t* ins_key;          // [ins_cap]

@@ -410,7 +410,7 @@ def main():
             use_pipe = False
     if args.engines is None: args.engines = 1 if use_pipe else 4      # lock-step, measured: Connect4 1/2/4/8 shards and Tawlbwrdd 2/4/8 shards both peak at 4
     if args.rounds_per_step is None: args.rounds_per_step = 80 if use_pipe else 2048
-    if args.cache is None: args.cache = 200_000 if sg else 0 if tafl else 32_000_000      # Tawlbwrdd: measured 5 % hit rate with 2 M entries and 16 % fewer games/s, so off; StarGambit: configs[4] / config.py:197
+    if args.cache is None: args.cache = 200_000 if sg else 0 if tafl else 128_000_000      # Tawlbwrdd: measured 5 % hit rate with 2 M entries and 16 % fewer games/s, so off; StarGambit: configs[4] / config.py:197
     # SURVEY §8d; StarGambit net (configs/star_gambit_unified.yaml, 36 x 13 x 13): stem 7.0 + 8 trunk convs 99.7 + head 1x1s 2.8 + two
     # head convs 24.9 + policy 1x1 0.2 + value / global FCs 0.7 = 135.3 MFLOP per position
     flop_per_eval = 135.3e6 if sg else 93.1e6 if tafl else FLOP_PER_EVAL
@@ -785,6 +785,7 @@ def main():
                 for name, S2, cache2, cap2, kind, note in (
                         ("playout_cap_on", S, args.cache, True, "same", "25 sims on 75% of moves, 800 on the rest"),
                         ("cache_200k", S, 200_000, False, "same", "max_cache_size = 200000 (reference default), 800 sims on every move"),
+                        ("cache_32m", S, 32_000_000, False, "same", "max_cache_size = 32 M entries (the headline's setting in rounds 1-2 and in the first half of round 3), 800 sims on every move"),
                         ("slots_16384", 16384, args.cache, False, "same", "16384 concurrent games (4 x the headline's), 800 sims on every move"),
                         ("tier_1e5", S, args.cache, False, "x3", "the bf16x3 leaf net (precision='bf16x3': bf16 high + low parts of weights and activations, three MFMAs per product; "
                                                                     "max |delta| vs the reference NNArch's fp32 outputs 4.3e-7 on the random-init fixture, 5.4e-6 on the peaked one: the north star's 1e-5 tier), "
