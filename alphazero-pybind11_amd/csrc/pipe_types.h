@@ -82,6 +82,7 @@ struct PipeArrays {
                               // simulation that completes a search and the move behind it; a leaf that is the root)
   uint32_t n_mover_wgs;       // the first n tree workgroups give their last wavefront to the move step
   uint32_t max_inline;        // simulations a group may finish in one pass without the net (cache hits, terminal leaves) before its slot re-queues
+  uint32_t min_active;        // ... and a pass ends early once fewer than this many of its eight groups are still running (the others idle meanwhile)
   unsigned long long* res;    // [S][kResStride]
   // insert log: (key, pi, v) of every answer consumed in the epoch; applied to the position cache between epochs
   uint64_t* ins_key;          // [ins_cap]
