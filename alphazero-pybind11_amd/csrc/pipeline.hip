@@ -183,8 +183,8 @@ __device__ __attribute__((noinline)) void pipe_mover_loop(const EngineParams& ep
   }
 }
 
-// NT: threads per workgroup.  512 = eight wavefronts of 256 registers: the workgroup has a CU to itself, so no tree wavefront
-// shares its SIMD's issue port with a net wavefront's matrix stream (256-thread tree workgroups sit beside a net workgroup)
+// NT: threads per workgroup (256: four wavefronts beside one net workgroup on a CU; eight-wavefront workgroups on CUs of their own
+// were measured equal and are no longer instantiated)
 template <class GM, int NT>
 __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArrays ar, PipeArrays pa) {
   constexpr int G = GM::GROUP;
@@ -936,7 +936,6 @@ int pipe_create(azmi_pm* pm, size_t tile_lds) {
   // 488 they do not; 128 beside 384 do, beside 400 the last net workgroups start when the epoch is over).  So the places
   // are counted per shader engine.
   const uint32_t engines = std::max<uint32_t>(1u, static_cast<uint32_t>(prop.multiProcessorCount) / 8u), places = 16u;
-  if (const char* e = getenv("AZMI_PIPE_TREE_BLOCK")) ps->tree_block = atoi(e) == 512 ? 512u : 256u;
   const uint32_t tree_per_engine = ((ps->tree_wgs + engines - 1u) / engines) * (ps->tree_block / 256u);
   uint32_t net = engines * (places > tree_per_engine ? places - tree_per_engine : 1u);
   if (const char* e = getenv("AZMI_PIPE_NET_WGS")) net = static_cast<uint32_t>(atoi(e));
@@ -1028,10 +1027,9 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
     AZMI_HIP_TRY(hipGetLastError());
     AZMI_HIP_TRY(hipEventRecord(ps->ev_go, st));
     AZMI_HIP_TRY(hipStreamWaitEvent(ps->net_stream, ps->ev_go, 0));
-    // the tree kernel goes first: its 512-thread workgroups want CUs of their own, and find them only while the chip is empty
+    // the tree kernel goes first: its workgroups take their places per shader engine, the net kernel is sized for what is left
     AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 2], st));
-    if (ps->tree_block == 512) k_pipe_tree<Connect4, 512><<<ps->tree_wgs, 512, 0, st>>>(pm->ep, pm->ar, pa);
-    else k_pipe_tree<Connect4, 256><<<ps->tree_wgs, 256, 0, st>>>(pm->ep, pm->ar, pa);
+    k_pipe_tree<Connect4, 256><<<ps->tree_wgs, 256, 0, st>>>(pm->ep, pm->ar, pa);
     AZMI_HIP_TRY(hipGetLastError());
     AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 3], st));
     if (pm->ep.cache_on) {      // behind the tree kernel, beside the net side's last tiles
