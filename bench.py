@@ -80,6 +80,7 @@ def parse(argv=None):
                     help="the default run (1 GPU, Connect4) also measures BASELINE configs[2] - Tawlbwrdd 2048 games x 400 sims, PUCT and Gumbel, with its "
                          "CPU baseline - and reports it as the `tawlbwrdd` block of the line; this flag skips that")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)    # a measurement process started by the default run
+    ap.add_argument("--probe", action="store_true", help=argparse.SUPPRESS)     # child process of the default driver choice: exit 0 when the pipeline runs here
     ap.add_argument("--dry", action="store_true",
                     help="CPU dry run of the launch / distributed plumbing (gloo, no device, a stand-in engine): used by the tests")
     return ap.parse_args(argv)
@@ -357,6 +358,8 @@ def _pipeline_probe(device_index, slots):
 
 def main():
     args = parse()
+    if args.probe:
+        sys.exit(0 if _pipeline_probe(int(os.environ.get("LOCAL_RANK", "0")), args.games or 4096) else 7)
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args))
     if (not args.dry and not args.worker and not args.no_tawlbwrdd and args.gpus == 1 and "RANK" not in os.environ and args.game == "connect4"
@@ -364,6 +367,16 @@ def main():
         sys.exit(orchestrate(args))
     if args.hwq:
         os.environ["GPU_MAX_HW_QUEUES"] = str(args.hwq)   # must be set before the HIP runtime starts
+    # The probe of the pipeline (see use_pipe below) runs in a process of its own, BEFORE this one starts the HIP runtime: run here, its
+    # streams stayed mapped to hardware queues and the lock-step secondaries of the same process (4 shards = 4 streams on the
+    # runtime's 4 queues) ran at half speed.
+    probe_ok = None
+    if (args.driver == "auto" and not args.dry and args.game == "connect4" and not args.gumbel and (args.net or "hip") == "hip"):
+        try:
+            probe_ok = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe", "--games", str(args.games or 4096)],
+                                      env=dict(os.environ), timeout=600).returncode == 0
+        except subprocess.TimeoutExpired:
+            probe_ok = False
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -399,7 +412,7 @@ def main():
         # a safety net, not a tuning knob: the pipeline's persistent kernels rely on how this part places workgroups.
         # A short probe at the bench's slot count runs before anything is sized; if it raises on this box (census, time cap), every
         # rank falls back to the lock-step driver - a slower line beats none - and the line's config says which driver ran.
-        ok = _pipeline_probe(local_rank, args.games)
+        ok = bool(probe_ok)
         if use_dist:
             flag = torch.tensor([1.0 if ok else 0.0], device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
