@@ -170,3 +170,52 @@ def test_ring_positions_wrap_past_2_to_the_32(monkeypatch):
     ra, ca = _sorted_log(ra, ca)
     rb, cb = _sorted_log(rb, cb)
     assert np.array_equal(ra, rb) and np.array_equal(ca, cb)
+
+
+@pytest.mark.parametrize("S,sims,cache,spe,epochs", [
+    (100, 60, 1 << 12, 37, 3),            # fewer simulations per epoch than slots: epochs of a fraction of a pass
+    (257, 33, 0, 257 * 5, 1),             # odd slot count, no cache, one epoch per call
+    (1000, 25, 1 << 16, 1000 * 300, 2),   # the quota never ends an epoch: the waiting-slot rule and the movers do
+    (24, 200, 1 << 10, 24 * 8, 7),        # fewer slots than one workgroup serves, a cache that evicts constantly
+])
+def test_pipeline_equals_lockstep_over_odd_shapes(S, sims, cache, spe, epochs):
+    """slot counts that are not multiples of anything, epochs far shorter and far longer than a search, a cache smaller than one
+    game's positions: the games are the lock-step engine's every time (moves, visit counts, pcg32 positions, sample rows)"""
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=S), spec)
+    pp = _selfplay_params(az, S, sims, cache=cache)
+    pp.games_to_play = S + S // 2                      # restarts and retirements inside the run
+    seed = 1000 + S
+    pm = az.PlayManager(az.Connect4GS(), pp, seed=seed, log_moves=True)
+    st = torch.cuda.Stream()
+    calls = 0
+    while pm.remaining_games() > 0 and calls < 200000:
+        az.run_pipeline(pm, hip, epochs, spe, st.cuda_stream)
+        calls += 1
+        if pm.poll(st.cuda_stream)[1] == 0:
+            break
+    torch.cuda.synchronize()
+    pb, (rb, cb) = _lockstep_games(az, pp, seed, hip)
+    assert pm.games_completed() == pb.games_completed() == pp.games_to_play
+    ra, ca = _sorted_log(*pm.move_log())
+    rb, cb = _sorted_log(rb, cb)
+    # WHICH slots receive the last restarts depends on the order in which games end (the reference's workers race for
+    # games_started_ the same way, play_manager.cc:506-513) - the lock-step engine hands them out round by round, the pipeline epoch
+    # by epoch -, but the k-th game of a slot is a function of the seed alone: every (slot, game) both drivers played is identical
+    def by_game(rows, counts):
+        out = {}
+        for key in np.unique(rows[:, :2], axis=0):
+            sel = (rows[:, 0] == key[0]) & (rows[:, 1] == key[1])
+            out[(int(key[0]), int(key[1]))] = (rows[sel], counts[sel])
+        return out
+    ga, gb = by_game(ra, ca), by_game(rb, cb)
+    common = sorted(set(ga) & set(gb))
+    assert all((s_, 0) in ga and (s_, 0) in gb for s_ in range(S))            # every slot's first game ran on both
+    assert len(common) >= S + S // 4
+    for key in common:
+        assert np.array_equal(ga[key][0], gb[key][0]) and np.array_equal(ga[key][1], gb[key][1]), key
+    if set(ga) == set(gb):
+        assert np.array_equal(pm.scores(), pb.scores())
+        assert np.array_equal(_history_multiset(pm), _history_multiset(pb))
