@@ -1124,6 +1124,8 @@ __global__ void k_delay(uint32_t us) {
 
 int azmi_run_rounds(azmi_pm* const* pms, azmi_net* net, uint32_t k, uint32_t rounds, void* const* streams) {
   if (!pms || !net || !streams || k == 0) return fail(AZMI_ERR_INVALID, "null argument");
+  for (uint32_t i = 0; i < k; ++i)      // PlayManager::stop(): the workers leave their loop (play_manager.cc:272)
+    if (pms[i] && pms[i]->stopped.load(std::memory_order_relaxed)) return AZMI_OK;
   if (const char* sg = getenv("AZMI_STAGGER_US")) {     // experiment: odd shards start half a cycle late
     const uint32_t us = static_cast<uint32_t>(atoi(sg));
     for (uint32_t i = 1; i < k && us; i += 2) k_delay<<<1, 64, 0, pms[i]->pick(streams[i])>>>(us);

@@ -969,6 +969,10 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
     return azmi_host_fail(AZMI_ERR_STATE, "azmi_run_pipeline: the pipeline drives the Connect4 engine with plain PUCT seats, one model group and a bf16 "
                           "Connect4-family net, at most %u concurrent games (azmi_pipeline_supported); use azmi_run_rounds for everything else", kPipeRing / 2u);
   if (sims_per_epoch == 0) return azmi_host_fail(AZMI_ERR_INVALID, "azmi_run_pipeline: sims_per_epoch must be > 0");
+  if (pm->stopped.load(std::memory_order_relaxed)) {     // PlayManager::stop(): the workers leave their loop (play_manager.cc:272)
+    if (out_stats) for (int i = 0; i < 16; ++i) out_stats[i] = 0;
+    return AZMI_OK;
+  }
   AZMI_HIP_TRY(hipSetDevice(pm->device));
   hipStream_t st = pm->pick(stream);
   if (!pm->pipe) {

@@ -441,7 +441,8 @@ int azmi_run_rounds(azmi_pm* const* pms, azmi_net* net, uint32_t k, uint32_t rou
  *      workgroups launched, [8] / [9] the latest start of a tree / net workgroup after the epoch's first, in microseconds (all
  *      of them must be on the chip together: a late one found its place only when another left), [10] / [11] the summed
  *      durations of this call's net / tree kernels in microseconds (HIP events on their streams), [12] the epochs of this
- *      call, [13] the host time spent enqueueing them in microseconds (the host runs ahead of the GPU); 16 entries. */
+ *      call, [13] the host time spent enqueueing them in microseconds (the host runs ahead of the GPU); 16 entries.
+ *      After azmi_pm_stop both this call and azmi_run_rounds return AZMI_OK at once and run nothing (play_manager.cc:272). */
 int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, uint64_t sims_per_epoch, void* stream, uint64_t* out_stats);
 /* diagnostics: the pipeline's persistent net kernel alone, draining `n` synthetic requests (n <= 8192) `reps` times with
  * `net_wgs` workgroups (0 = the pipeline's own count) and tile selection `mode` (0 = 3- and 6-board tiles, 1 = 6-board, 2 =

@@ -219,3 +219,26 @@ def test_pipeline_equals_lockstep_over_odd_shapes(S, sims, cache, spe, epochs):
     if set(ga) == set(gb):
         assert np.array_equal(pm.scores(), pb.scores())
         assert np.array_equal(_history_multiset(pm), _history_multiset(pb))
+
+
+def test_pipeline_after_stop_returns_at_once_and_changes_nothing():
+    """PlayManager.stop() (py_wrapper.cc:369-372): epochs asked for afterwards find the stop word, every persistent workgroup leaves
+    at once, no pipeline error is raised and no simulation runs"""
+    import time
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=2), spec)
+    S = 512
+    pp = _selfplay_params(az, S, 200, cache=1 << 14)
+    pp.games_to_play = 1 << 20
+    pm = az.PlayManager(az.Connect4GS(), pp, seed=5)
+    az.run_pipeline(pm, hip, 4, S * 32)
+    before = pm.counters()["sims"]
+    assert before > 0
+    pm.stop()
+    assert pm.stopped()
+    t0 = time.perf_counter()
+    stats = az.run_pipeline(pm, hip, 8, S * 32)
+    assert time.perf_counter() - t0 < 1.0
+    assert stats["last_epoch_sims"] == 0 and pm.counters()["sims"] == before
