@@ -844,11 +844,28 @@ __global__ __launch_bounds__(256) void k_pipe_cache_insert(EngineArrays ar, Pipe
     if (!wave_shard_insert_locked<false>(ar.cache, pa.locks, key, p, v, lane) && lane == 0) atomicOr(&pa.ctl->err, static_cast<uint32_t>(kPipeErrLock));
   }
 }
+// ---- do two streams run side by side? -------------------------------------------------------------------------------------------
+// The runtime multiplexes streams onto a few hardware queues (4 by default): two streams that share a queue run their kernels
+// one after the other, and an epoch's tree and net kernels, each waiting for the other, would then sit there until the time cap.
+// k_pair_wait (launched first, on the tree side's stream) waits up to 2 ms for the word k_pair_set (net side's stream) writes.
+__global__ void k_pair_wait(uint32_t* flag) {
+  const uint64_t t0 = wall_clock64();
+  while (g_ld(flag) == 0u) {
+    if (wall_clock64() - t0 > 200000ull) { g_st(flag + 1, 1u); return; }     // 2 ms: the partner never started
+    __builtin_amdgcn_s_sleep(32);
+  }
+}
+__global__ void k_pair_set(uint32_t* flag) { g_st(flag, 1u); }
+
 // ---- host side ------------------------------------------------------------------------------------------------------------------------
 struct PipeState {
   PipeArrays pa{};
   std::vector<void*> allocs;
   hipStream_t net_stream = nullptr;
+  hipStream_t paired_with = nullptr;     // the tree-side stream net_stream was last seen running beside
+  bool paired = false;
+  std::vector<hipStream_t> parked;       // streams that shared a hardware queue with a tree-side stream (kept: destroying one frees its queue slot for the next try)
+  uint32_t* pair_flag = nullptr;
   hipEvent_t ev_go = nullptr, ev_net = nullptr;
   uint32_t net_wgs = 0, tree_wgs = 0, tree_block = 256;
   std::vector<hipEvent_t> tev;      // timing events: four per epoch of a run (net kernel start / end, tree kernel start / end)
@@ -859,6 +876,7 @@ void pipe_state_free(PipeState* p) {
   if (!p) return;
   for (void* q : p->allocs) (void)hipFree(q);
   if (p->net_stream) (void)hipStreamDestroy(p->net_stream);
+  for (hipStream_t q : p->parked) (void)hipStreamDestroy(q);
   if (p->ev_go) (void)hipEventDestroy(p->ev_go);
   if (p->ev_net) (void)hipEventDestroy(p->ev_net);
   for (hipEvent_t e : p->tev) (void)hipEventDestroy(e);
@@ -946,6 +964,33 @@ int pipe_create(azmi_pm* pm, size_t tile_lds) {
   return AZMI_OK;
 }
 
+// net_stream must run beside `st` (see k_pair_wait): checked once per tree-side stream; a stream that shares st's hardware queue is
+// parked and another one is tried.  Fails when no stream can be found (GPU_MAX_HW_QUEUES = 1): the caller drives the engine with
+// azmi_run_rounds then.
+int pipe_pair_streams(PipeState* ps, hipStream_t st) {
+  if (ps->paired && ps->paired_with == st) return AZMI_OK;
+  if (!ps->pair_flag) { const int rc = pipe_alloc(ps, ps->pair_flag, 4); if (rc != AZMI_OK) return rc; }
+  for (int attempt = 0; attempt < 12; ++attempt) {
+    AZMI_HIP_TRY(hipMemsetAsync(ps->pair_flag, 0, 4 * sizeof(uint32_t), st));
+    AZMI_HIP_TRY(hipEventRecord(ps->ev_go, st));
+    AZMI_HIP_TRY(hipStreamWaitEvent(ps->net_stream, ps->ev_go, 0));
+    k_pair_wait<<<1, 1, 0, st>>>(ps->pair_flag);
+    AZMI_HIP_TRY(hipGetLastError());
+    k_pair_set<<<1, 1, 0, ps->net_stream>>>(ps->pair_flag);
+    AZMI_HIP_TRY(hipGetLastError());
+    uint32_t h[2] = {0, 0};
+    AZMI_HIP_TRY(hipStreamSynchronize(ps->net_stream));
+    AZMI_HIP_TRY(hipMemcpyAsync(h, ps->pair_flag, sizeof(h), hipMemcpyDeviceToHost, st));
+    AZMI_HIP_TRY(hipStreamSynchronize(st));
+    if (h[1] == 0u) { ps->paired = true; ps->paired_with = st; return AZMI_OK; }
+    ps->parked.push_back(ps->net_stream);          // shares st's hardware queue
+    ps->net_stream = nullptr;
+    AZMI_HIP_TRY(hipStreamCreateWithFlags(&ps->net_stream, hipStreamNonBlocking));
+  }
+  return azmi_host_fail(AZMI_ERR_STATE, "azmi_run_pipeline: no second stream runs beside the caller's (one hardware queue? GPU_MAX_HW_QUEUES); "
+                        "the pipeline needs its tree and net kernels on the chip together - use azmi_run_rounds");
+}
+
 }  // namespace
 
 extern "C" int azmi_net_c4_view_get(const struct azmi_net* net, azmi_net_c4_view* out);
@@ -981,6 +1026,7 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
   }
   PipeState* ps = pm->pipe;
   PipeArrays& pa = ps->pa;
+  { const int rc = pipe_pair_streams(ps, st); if (rc != AZMI_OK) return rc; }
   if (!ps->lds_set) {
     AZMI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_net<0>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ps->lds_bytes)));
     AZMI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_net<1>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ps->lds_bytes)));

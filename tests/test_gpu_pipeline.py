@@ -242,3 +242,32 @@ def test_pipeline_after_stop_returns_at_once_and_changes_nothing():
     stats = az.run_pipeline(pm, hip, 8, S * 32)
     assert time.perf_counter() - t0 < 1.0
     assert stats["last_epoch_sims"] == 0 and pm.counters()["sims"] == before
+
+
+def test_two_pipelines_and_two_nets_alternate_in_one_process():
+    """two engines, each with its own pipeline state, take turns on one stream, each with its own net: nothing of a pipeline is
+    process-wide, so both play the games their lock-step twins play"""
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    nets = [az.HipLeafNet(torch_net.random_init(spec, seed=s), spec) for s in (41, 42)]
+    cfgs = [(128, 70, 1 << 14, 901), (96, 90, 0, 902)]
+    pms = []
+    for (S, sims, cache, seed) in cfgs:
+        pms.append(az.PlayManager(az.Connect4GS(), _selfplay_params(az, S, sims, cache=cache), seed=seed, log_moves=True))
+    st = torch.cuda.Stream()
+    for _ in range(100000):
+        live = 0
+        for pm, net, (S, _, _, _) in zip(pms, nets, cfgs):
+            if pm.remaining_games() > 0 and pm.poll(st.cuda_stream)[1] > 0:
+                az.run_pipeline(pm, net, 2, S * 24, st.cuda_stream)
+                live += 1
+        if live == 0:
+            break
+    torch.cuda.synchronize()
+    for pm, net, (S, sims, cache, seed) in zip(pms, nets, cfgs):
+        pb, (rb, cb) = _lockstep_games(az, _selfplay_params(az, S, sims, cache=cache), seed, net)
+        assert pm.games_completed() == pb.games_completed() == S
+        ra, ca = _sorted_log(*pm.move_log())
+        rb, cb = _sorted_log(rb, cb)
+        assert np.array_equal(ra, rb) and np.array_equal(ca, cb)
