@@ -271,3 +271,19 @@ def test_two_pipelines_and_two_nets_alternate_in_one_process():
         ra, ca = _sorted_log(*pm.move_log())
         rb, cb = _sorted_log(rb, cb)
         assert np.array_equal(ra, rb) and np.array_equal(ca, cb)
+
+
+def test_pipeline_reports_a_full_sample_ring_by_name():
+    """a sample ring that is too small and never drained: the move step raises the engine's overflow bit inside an epoch, every
+    persistent workgroup leaves, and the call fails with the engine's own message - no hang, no pipeline time-out"""
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=7), spec)
+    pp = _selfplay_params(az, 64, 30, cache=0)
+    pp.games_to_play = 640
+    pm = az.PlayManager(az.Connect4GS(), pp, seed=5, history_capacity=128)
+    with pytest.raises(RuntimeError, match="history"):
+        for _ in range(400):
+            az.run_pipeline(pm, hip, 2, 64 * 16)
+            pm.poll()
