@@ -1035,7 +1035,7 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
   }
   // the insert log holds an epoch's answers: at most one per simulation, in practice a third of them
   // (the quota is checked between passes: an epoch overshoots it by what the passes under way still finish)
-  const uint64_t want_log = pm->ep.cache_on ? std::min<uint64_t>(sims_per_epoch + 2ull * pm->ep.S + static_cast<uint64_t>(ps->tree_wgs) * 32u * (pa.max_inline + 1u), 1ull << 24) : 0ull;
+  const uint64_t want_log = pm->ep.cache_on ? std::min<uint64_t>(std::min<uint64_t>(sims_per_epoch, 1024ull * pm->ep.S) + 2ull * pm->ep.S + static_cast<uint64_t>(ps->tree_wgs) * 32u * (pa.max_inline + 1u), 1ull << 24) : 0ull;
   if (want_log > pa.ins_cap) {
     PipeState* p = ps;
     int rc = pipe_alloc(p, pa.ins_key, want_log);
@@ -1048,7 +1048,9 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
     const int rc = pipe_alloc(ps, pa.locks, pm->ar.cache.shards);
     if (rc != AZMI_OK) return rc;
   }
-  pa.quota = sims_per_epoch;
+  // an epoch must end long before the wall-clock cap (a stall detector, 250 ms): with the move step inside the epoch nothing else ends it,
+  // so the quota is held to 1024 simulations per slot (~50 ms at the slowest per-slot rate measured)
+  pa.quota = std::min<uint64_t>(sims_per_epoch, 1024ull * pm->ep.S);
   // an epoch also ends when this share of the slots waits for the move step (all of them: the start of a run)
   double idle_frac = 0.125;
   if (const char* e = getenv("AZMI_PIPE_IDLE_FRAC")) idle_frac = atof(e);

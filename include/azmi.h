@@ -433,7 +433,8 @@ int azmi_run_rounds(azmi_pm* const* pms, azmi_net* net, uint32_t k, uint32_t rou
  *      (play_manager.cc:258-600, concurrent_queue.h:130-217, game_runner.py:483-552) - and neither has this: for one EPOCH
  *      persistent tree wavefronts simulate their slots and hand the leaves that need the net to persistent net workgroups
  *      (request ring / tagged result granules in HBM, csrc/pipe_types.h); an epoch ends after `sims_per_epoch` simulations
- *      (or when an eighth of the slots waits for a move), then the moves, game ends and restarts of the epoch and the
+ *      (held to 1024 per slot: an epoch must stay far below the 250 ms stall cap; or when an eighth of the slots waits for a
+ *      move), then the moves the mover wavefronts did not get to, game restarts and the
  *      position-cache inserts of its answers run at a kernel boundary.  `epochs` epochs, synchronous (returns when they are
  *      done; a pipeline error is reported here).  The games are those of azmi_run_rounds for the same seeds.
  *      out_stats (may be NULL): [0] net tiles run since the pipeline was created, [1] boards in them, [2] simulations of the

@@ -287,3 +287,21 @@ def test_pipeline_reports_a_full_sample_ring_by_name():
         for _ in range(400):
             az.run_pipeline(pm, hip, 2, 64 * 16)
             pm.poll()
+
+
+def test_pipeline_holds_a_huge_epoch_quota_below_the_stall_cap():
+    """sims_per_epoch far beyond what an epoch may last: the library holds the quota to 1024 simulations per slot, the epochs
+    end by it and the run completes without touching the wall-clock cap"""
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=8), spec)
+    S = 256
+    pp = _selfplay_params(az, S, 300, cache=1 << 14)
+    pm = az.PlayManager(az.Connect4GS(), pp, seed=12)
+    for _ in range(4000):
+        st = az.run_pipeline(pm, hip, 1, 1 << 40)
+        assert st["last_epoch_sims"] <= 1024 * S + 64 * S
+        if pm.poll()[1] == 0:
+            break
+    assert pm.games_completed() == S
