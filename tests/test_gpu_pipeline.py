@@ -305,3 +305,30 @@ def test_pipeline_holds_a_huge_epoch_quota_below_the_stall_cap():
         if pm.poll()[1] == 0:
             break
     assert pm.games_completed() == S
+
+
+def test_pipeline_follows_the_callers_stream_from_call_to_call():
+    """the caller's stream changes between calls (two torch streams and the engine's own): the net-side stream is re-checked against
+    each new partner (a shared hardware queue would serialise the two persistent kernels) and the games stay the lock-step engine's"""
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=9), spec)
+    S, seed = 128, 77
+    pp = _selfplay_params(az, S, 80, cache=1 << 14)
+    pm = az.PlayManager(az.Connect4GS(), pp, seed=seed, log_moves=True)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream(), None, torch.cuda.Stream(), torch.cuda.Stream()]
+    i = 0
+    while pm.remaining_games() > 0 and i < 20000:
+        s = streams[i % len(streams)]
+        torch.cuda.synchronize()                     # (the engine's state is handed from stream to stream by the caller)
+        az.run_pipeline(pm, hip, 2, S * 32, None if s is None else s.cuda_stream)
+        i += 1
+        if pm.poll(None if s is None else s.cuda_stream)[1] == 0:
+            break
+    torch.cuda.synchronize()
+    pb, (rb, cb) = _lockstep_games(az, pp, seed, hip)
+    assert pm.games_completed() == pb.games_completed() == S
+    ra, ca = _sorted_log(*pm.move_log())
+    rb, cb = _sorted_log(rb, cb)
+    assert np.array_equal(ra, rb) and np.array_equal(ca, cb)
