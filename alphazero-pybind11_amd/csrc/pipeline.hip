@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 
@@ -1006,9 +1007,13 @@ extern "C" int azmi_pipeline_supported(azmi_pm* pm, azmi_net* net) {
   return pm && net && pipe_supported(pm, net, &view) ? 1 : 0;
 }
 
+// An epoch's workgroup counts assume the chip to itself (placement): two engines' epochs at once would each find half of
+// their workgroups without a place.  Calls from different threads therefore take turns (they are synchronous anyway).
+static std::mutex g_pipeline_turn;
 extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, uint64_t sims_per_epoch, void* stream, uint64_t* out_stats) {
   if (!pm || !net) return azmi_host_fail(AZMI_ERR_INVALID, "null argument");
   std::lock_guard<std::recursive_mutex> lock_(pm->mu);
+  std::lock_guard<std::mutex> turn_(g_pipeline_turn);
   azmi_net_c4_view view;
   if (!pipe_supported(pm, net, &view))
     return azmi_host_fail(AZMI_ERR_STATE, "azmi_run_pipeline: the pipeline drives the Connect4 engine with plain PUCT seats, one model group and a bf16 "

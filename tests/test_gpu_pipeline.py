@@ -332,3 +332,41 @@ def test_pipeline_follows_the_callers_stream_from_call_to_call():
     ra, ca = _sorted_log(*pm.move_log())
     rb, cb = _sorted_log(rb, cb)
     assert np.array_equal(ra, rb) and np.array_equal(ca, cb)
+
+
+def test_two_threads_drive_two_pipelines():
+    """two host threads, each driving its own engine through azmi_run_pipeline (ctypes releases the GIL): the calls take turns inside
+    the library - an epoch's workgroup counts assume the chip to itself - and both engines finish with their lock-step twins' games"""
+    import threading
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=10), spec)
+    cfgs = [(160, 60, 1 << 13, 301), (96, 70, 0, 302)]
+    pms = [az.PlayManager(az.Connect4GS(), _selfplay_params(az, S, sims, cache=cache), seed=seed, log_moves=True) for (S, sims, cache, seed) in cfgs]
+    errors = []
+
+    def drive(pm, S):
+        try:
+            st = torch.cuda.Stream()
+            n = 0
+            while pm.remaining_games() > 0 and n < 20000:
+                az.run_pipeline(pm, hip, 2, S * 24, st.cuda_stream)
+                n += 1
+                if pm.poll(st.cuda_stream)[1] == 0:
+                    break
+        except Exception as e:          # noqa: BLE001 - reported by the main thread
+            errors.append(e)
+    threads = [threading.Thread(target=drive, args=(pm, cfg[0])) for pm, cfg in zip(pms, cfgs)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for pm, (S, sims, cache, seed) in zip(pms, cfgs):
+        pb, (rb, cb) = _lockstep_games(az, _selfplay_params(az, S, sims, cache=cache), seed, hip)
+        assert pm.games_completed() == pb.games_completed() == S
+        ra, ca = _sorted_log(*pm.move_log())
+        rb, cb = _sorted_log(rb, cb)
+        assert np.array_equal(ra, rb) and np.array_equal(ca, cb)
