@@ -735,6 +735,24 @@ def main():
                               "and share the chip with each other and with the tree kernels, so the whole-GPU rate is aggregate_achieved = "
                               "FLOPs of all launches of the region / wall time of the region (rank 0's GPU)",
             }
+            if use_pipe and hip_net is not None and world == 1:
+                # the same tiles ALONE on the chip (no tree wavefronts beside them, every workgroup with work from the first cycle): 3072
+                # rows = 512 six-board tiles, two per CU, 200 launches timed with events - what the kernel itself does, beside what it does
+                # in the mix (profiles/r3_leafnet_pmc_3072.csv has the counters of this launch)
+                xr = (torch.rand((3072,) + tuple(spec.in_shape), device=dev) < 0.3).float()
+                vr = torch.empty((3072, spec.num_players + 1), device=dev); pr = torch.empty((3072, spec.num_moves), device=dev)
+                for _ in range(20):
+                    hip_net.forward(xr, vr, pr)
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record()
+                for _ in range(200):
+                    hip_net.forward(xr, vr, pr)
+                eb.record(); torch.cuda.synchronize()
+                us = ea.elapsed_time(eb) * 1e3 / 200
+                tf = 3072 * flop_per_eval / us / 1e6
+                out["roofline"]["tiles_alone"] = {"rows": 3072, "us_per_launch": us, "achieved": tf, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS,
+                                                  "note": "k_leafnet_c4 (the tile the persistent net workgroups run) as a plain launch of 512 six-board tiles, alone on the chip"}
+                del xr, vr, pr
             if True:
                 # the second kernel of the path, the tree step (HBM side): algorithmic bytes per simulation from SURVEY §8d
                 # (select + backup + expand + state + canonical + eval rows: Connect4 1.3 KB with the measured depth 3.5 / 6.8
