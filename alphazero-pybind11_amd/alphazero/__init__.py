@@ -1614,8 +1614,9 @@ def run_rounds(pms, net, rounds, streams):
 
 def pipeline_supported(pm, net):
     """azmi_pipeline_supported: True when azmi_run_pipeline can drive this engine with this net (the Connect4 engine with plain
-    PUCT seats, one model group, NN seats, a bf16 Connect4-family HipLeafNet, at most 4096 concurrent games)."""
-    return net is not None and bool(lib.azmi_pipeline_supported(pm._h, net._h))
+    PUCT seats, one model group, NN seats and a bf16 Connect4-family HipLeafNet - or `net=None` for an engine whose seats all use
+    EvalType.RANDOM: the tree side alone -, at most 16384 concurrent games)."""
+    return bool(lib.azmi_pipeline_supported(pm._h, None if net is None else net._h))
 
 
 def run_pipeline(pm, net, epochs, sims_per_epoch, stream=None):
@@ -1625,7 +1626,7 @@ def run_pipeline(pm, net, epochs, sims_per_epoch, stream=None):
     the last epoch, workgroups launched and started, kernel and host-enqueue times of this call."""
     st = pm._stream_arg(stream)
     out = (C.c_uint64 * 16)()
-    check(lib.azmi_run_pipeline(pm._h, net._h, int(epochs), int(sims_per_epoch), st, out))
+    check(lib.azmi_run_pipeline(pm._h, None if net is None else net._h, int(epochs), int(sims_per_epoch), st, out))
     keys = ("tiles", "tile_boards", "last_epoch_sims", "tree_wgs_started", "net_wgs_started", "last_epoch_inserts", "net_wgs", "tree_wgs",
             "tree_latest_start_us", "net_latest_start_us", "net_kernel_us", "tree_kernel_us", "epochs", "host_enqueue_us")
     return dict(zip(keys, (int(x) for x in out)))

@@ -17,13 +17,17 @@
 //     window [head, head + n) with one fetch-add and re-reads its granules until every tag is the tag of the ring lap;
 //   * result granules: per slot kResStride 8-byte granules {seq32 | float bits}, pi[0..M) then v[0..P]; the slot's next tree
 //     group polls them until every tag is the sequence number of its request;
-//   * READY / MOVE rings: one 8-byte token {tag16 | seq32 | slot16} per slot that can take its next step.
+//   * READY rings, ONE PER TREE WORKGROUP: one 8-byte token {tag16 | seq32 | move1 | slot15} per slot that can take its next step.
 // Every granule and token is ONE naturally aligned 8-byte agent-scope atomic store / load (write-through, L1-bypassing): the
-// data is its own flag, no ordering between granules is assumed (cdna_hip_programming.md Guideline 16, form R2).  A slot's
-// state and trees are plain memory that moves between CUs from pass to pass: every pass starts with an agent-scope acquire and
-// ends, before its tokens go out, with an agent-scope release; req_seq[slot] is the word a slot is published with.
+// data is its own flag, no ordering between granules is assumed (cdna_hip_programming.md Guideline 16, form R2).
+// Round 4: a slot has a HOME workgroup (slot % tree workgroups) for the whole epoch.  Its state, its path image and its trees are
+// plain memory that only the four wavefronts of that workgroup - one CU, one vector L1 - ever touch inside an epoch, so a pass
+// needs no agent-scope acquire / release any more (round 3 paid ~10 us of buffer_wbl2 / buffer_inv per 75 us pass for slots that
+// wandered between CUs, and more with every tree workgroup added): a wavefront's stores are drained (s_waitcnt vmcnt(0)) before
+// its tokens go out, which is all workgroup scope asks for.  The move step (round_slot<kMover>) is run by the home workgroup too
+// (a token with the `move` bit): no mover wavefronts, no MOVE ring, no hand-over at all.
 // What still needs a kernel boundary: the position-cache inserts of the epoch's answers (an insert log), game restarts
-// (k_assign), the leftovers of the MOVE ring.  Every spin is bounded by a wall-clock cap; errors are a sticky word (PipeErr).
+// (k_assign).  Every spin is bounded by a wall-clock cap; errors are a word (PipeErr) the host reads after every call.
 #pragma once
 #include <stdint.h>
 
@@ -36,14 +40,22 @@ constexpr uint32_t kPipeRing = 32768;    // ring entries (a power of two, twice 
 enum PipeErr : uint32_t { kPipeErrTimeout = 1, kPipeErrRing = 2, kPipeErrTag = 4, kPipeErrLog = 8, kPipeErrLock = 16, kPipeErrSlots = 32, kPipeErrNetTimeout = 64 };
 
 __host__ __device__ inline uint64_t pipe_lap_tag(uint32_t pos) { return static_cast<uint64_t>(((pos / kPipeRing) & 0x7FFFu) + 1u); }
+// the per-workgroup READY rings have 1 << shift entries
+__host__ __device__ inline uint64_t pipe_lap_tag_r(uint32_t pos, uint32_t shift) { return static_cast<uint64_t>(((pos >> shift) & 0x7FFFu) + 1u); }
+constexpr unsigned long long kTokMove = 0x8000ull;     // token: the slot's next step is the move step's (a game start, the simulation that completes a search)
+constexpr unsigned long long kTokSlotMask = 0x7FFFull;
+
+struct PipeWg {           // one 128-byte line per tree workgroup: its READY ring's positions (free-running)
+  uint32_t rhead;         // positions drawn by the workgroup's wavefronts
+  uint32_t rtail;         // tickets handed out (seed kernel, net workgroups, the workgroup's own wavefronts)
+  uint32_t pad[30];
+};
+static_assert(sizeof(PipeWg) == 128, "one line");
 
 struct PipeCtl {          // zeroed when the pipeline is created; lives across epochs.  Every hot word on a 128-byte line of its own
   uint32_t head; uint32_t pad0[31];             // ring entries claimed by net workgroups (free-running: position = value % kPipeRing)
   uint32_t tail; uint32_t pad1[31];             // ring tickets handed out to tree wavefronts (free-running)
-  uint32_t rhead; uint32_t pad4[31];            // READY-ring positions drawn by tree wavefronts (free-running, runs ahead of rtail)
-  uint32_t rtail; uint32_t pad5[31];            // READY-ring tickets handed out (seed kernel, net workgroups, tree wavefronts)
-  uint32_t mhead; uint32_t pad6[31];            // MOVE-ring positions drawn by mover wavefronts
-  uint32_t mtail; uint32_t pad7[31];            // MOVE-ring tickets handed out (seed kernel: game starts; tree wavefronts: completed searches)
+  uint32_t pad4[32], pad5[32], pad6[32], pad7[32];   // (round 3: the chip-wide READY / MOVE ring positions; now per workgroup, PipeWg)
   uint32_t err;           // PipeErr bits, sticky: every pipeline kernel leaves at once when it is set
   uint32_t pad2;
   unsigned long long tiles;         // net tiles run
@@ -64,8 +76,8 @@ struct PipeEpoch {        // an allocation of its own, zeroed before every epoch
   uint32_t tree_done;     // tree workgroups that have stored their slots and left
   uint32_t tree_arrived, net_arrived;   // census: workgroups that started
   uint32_t ins_count;     // entries of the insert log
-  uint32_t waiting;       // slots whose next step is the move step's (listed for it): they idle until the epoch ends
-  uint32_t dead;          // slots without a game (retired, or ended and not yet restarted)
+  uint32_t ended;         // games that ended in this epoch: their slots idle until the boundary's k_assign restarts or retires them
+  uint32_t dead;          // slots without a game when the epoch began (retired) or lost to an engine error
   uint32_t tree_late, net_late;   // census: the latest start of a tree / net workgroup, in 100 MHz ticks after the first workgroup of the epoch
   uint32_t ins_done;      // insert-log entries already applied (the first insert launch runs while the net side drains)
   uint32_t moved;         // move steps run by the mover wavefronts in this epoch
@@ -77,10 +89,11 @@ struct PipeArrays {
   PipeCtl* ctl;
   PipeEpoch* ep;
   unsigned long long* ring;   // [kPipeRing][kReqGranules]
-  unsigned long long* rring;  // [kPipeRing] READY ring: {tag16 | slot}
-  unsigned long long* mring;  // [kPipeRing] MOVE ring: {tag16 | slot} - slots whose next step is the move step's (a game start; the
-                              // simulation that completes a search and the move behind it; a leaf that is the root)
-  uint32_t n_mover_wgs;       // the first n tree workgroups give their last wavefront to the move step
+  unsigned long long* rring;  // [n_tree_wgs][1 << rshift] READY rings: {tag16 | seq32 | move | slot}
+  PipeWg* wg;                 // [n_tree_wgs]
+  uint32_t rshift;            // log2 of a READY ring's entries (>= twice the slots of a workgroup)
+  uint32_t big_at;            // net side, tile selection 0: a workgroup draws a 6-request window when at least this many requests wait in the ring (else 3); 0 = always 6
+  uint32_t take_wait;         // ticks a wavefront that found fewer than kTreeWindow tokens waits for more before it starts its pass
   uint32_t max_inline;        // simulations a group may finish in one pass without the net (cache hits, terminal leaves) before its slot re-queues
   uint32_t min_active;        // ... and a pass ends early once fewer than this many of its eight groups are still running (the others idle meanwhile)
   unsigned long long* res;    // [S][kResStride]
@@ -92,7 +105,7 @@ struct PipeArrays {
   uint32_t* locks;            // [cache shards] insert locks of the position cache (0 = free)
   uint32_t n_tree_wgs;
   unsigned long long quota;       // simulations per epoch
-  uint32_t idle_num;              // the epoch also ends when `waiting` reaches idle_num / 1024 of the slots that have a game
+  uint32_t idle_num;              // the epoch also ends when `ended` reaches idle_num / 1024 of the slots that have a game
   unsigned long long cap_ticks;   // hard time cap of an epoch in 100 MHz ticks
 };
 

@@ -32,24 +32,34 @@ __device__ __forceinline__ uint32_t g_ld(const uint32_t* p) { return __hip_atomi
 __device__ __forceinline__ void g_st(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void g_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+
 enum : uint32_t { kGrpIdle = 0, kGrpReady = 1, kGrpWait = 2, kGrpPush = 3 };
 constexpr uint64_t kMask48 = (1ull << 48) - 1;
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+
+// one struct = the whole kernarg segment of k_pipe_tree: the move step (a function of its own, below) reads its arguments from
+// there instead of from copies on the stack
+struct PipeKernArgs { EngineParams ep; EngineArrays ar; PipeArrays pa; };
 
 // ---- tree side ---------------------------------------------------------------------------------------------------------------------
-// A slot is not tied to a wavefront: every slot that can take its next step sits, as a token, in the READY ring (seeded by
-// k_pipe_seed when the epoch starts, refilled by the net workgroups with the slots they have answered and by the tree
-// wavefronts with slots whose next answer is already at hand).  A tree wavefront works in PASSES: draw eight tokens (a window of
-// ring positions, one fetch-add), load the eight slots - one 8-lane group each -, back the pending simulations up and descend
-// again until each group's new leaf needs the net (k_sim's body, engine_kernels.h: the path in registers, level i in lane i),
-// store the slots, hand the leaves to the request ring.  Every group of a pass has work, which is what keeps the 64 lanes busy:
-// with slots bound to wavefronts 3.3 of 8 groups had an answer when a pass started.
-// A slot's state and its trees move between CUs from pass to pass: a pass starts with an agent-scope acquire (this CU's L1 holds
-// nothing stale) and ends, before its tokens go out, with an agent-scope release.
+// Every slot has a HOME workgroup (slot % tree workgroups).  A slot that can take its next step sits, as a token, in its home
+// workgroup's READY ring (seeded by k_pipe_seed when the epoch starts, refilled by the net workgroups with the slots they have
+// answered and by the workgroup's own wavefronts with slots whose next answer is already at hand or whose next step is the move
+// step's).  A tree wavefront works in PASSES: look at the ring's head | tail word, draw what is there (at most eight tokens: one
+// fetch-add), load the slots - one 8-lane group each -, back the pending simulations up and descend again until each group's new
+// leaf needs the net (k_sim's body, engine_kernels.h: the path in registers, level i in lane i), store the slots, hand the leaves
+// to the request ring.  A slot's state and trees are plain memory that only ever moves between the wavefronts of ONE workgroup =
+// one CU = one vector L1: a pass drains its stores (s_waitcnt vmcnt(0)) before its tokens go out and that is all (round 3 let
+// slots wander between CUs and paid an agent-scope acquire + release, ~10 us, per pass).
 constexpr uint32_t kTreeWindow = 8;
-constexpr uint64_t kTreePatience = 100;       // ticks (1 us) a wavefront that holds some tokens waits for the rest of its window
+constexpr uint64_t kTreePatience = 100;       // ticks (1 us) a wavefront that holds some tokens of a window waits for the window's rest
+
+__device__ __forceinline__ void pipe_push_token(const PipeArrays& pa, uint32_t home, uint32_t pos, unsigned long long payload) {
+  g_st(pa.rring + ((static_cast<size_t>(home) << pa.rshift) + (pos & ((1u << pa.rshift) - 1u))), (pipe_lap_tag_r(pos, pa.rshift) << 48) | payload);
+}
 
 // The epoch's first tokens: one thread per slot.  A slot whose leaf was left by the move step (kSlotQueued) sends its request, a
-// slot with its answer in the (v, pi) rows goes to the READY ring, a slot whose game has to start goes to the move step's list.
+// slot with its answer in the (v, pi) rows gets a READY token, a slot whose game has to start a READY token with the move bit.
 __global__ void k_pipe_seed(EngineParams ep, EngineArrays ar, PipeArrays pa) {
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= ep.S) return;
@@ -58,13 +68,13 @@ __global__ void k_pipe_seed(EngineParams ep, EngineArrays ar, PipeArrays pa) {
   if (ar.ctl->stop != 0 || pc->err != 0) { atomicAdd(&pe->dead, 1u); return; }
   const uint8_t sst = ar.sstate[slot];
   if (sst == kSlotDone || sst == kSlotEnded) { atomicAdd(&pe->dead, 1u); return; }
-  if (sst != kSlotWaitEval && sst != kSlotQueued) {       // kSlotFresh / kSlotRestart: a game start is the move step's
-    const uint32_t pos = atomicAdd(&pc->mtail, 1u);
-    g_st(pa.mring + (pos & (kPipeRing - 1u)), (pipe_lap_tag(pos) << 48) | static_cast<unsigned long long>(slot));
-    atomicAdd(&pe->waiting, 1u);
+  const uint32_t home = slot % pa.n_tree_wgs;
+  const uint8_t f = ar.flags[slot];
+  if ((sst != kSlotWaitEval && sst != kSlotQueued) || (f & kFlagListed)) {       // kSlotFresh / kSlotRestart: a game start is the move step's
+    const uint32_t pos = atomicAdd(&pa.wg[home].rtail, 1u);
+    pipe_push_token(pa, home, pos, static_cast<unsigned long long>(slot) | kTokMove);
     return;
   }
-  const uint8_t f = ar.flags[slot];
   if (f & kFlagReqOut) { atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTag)); return; }      // (every request was settled)
   if (sst == kSlotQueued) {
     const uint32_t pos = atomicAdd(&pc->tail, 1u);
@@ -81,120 +91,85 @@ __global__ void k_pipe_seed(EngineParams ep, EngineArrays ar, PipeArrays pa) {
     ar.sstate[slot] = kSlotWaitEval;
     return;
   }
-  const uint32_t pos = atomicAdd(&pc->rtail, 1u);
-  g_st(pa.rring + (pos & (kPipeRing - 1u)), (pipe_lap_tag(pos) << 48) | static_cast<unsigned long long>(slot));     // (answers no request: sequence field 0)
+  const uint32_t pos = atomicAdd(&pa.wg[home].rtail, 1u);
+  pipe_push_token(pa, home, pos, static_cast<unsigned long long>(slot));     // (answers no request: sequence field 0)
 }
 
-// ---- the move step inside the epoch: the last wavefront of the first n_mover_wgs workgroups serves the MOVE ring -----------------
+// ---- the move step inside the epoch ---------------------------------------------------------------------------------------------
 // A slot a tree wavefront lists (its next backup completes a search, or its leaf is the root) and a slot whose game has to start
-// run the lock-step engine's own move step (round_slot<kMover>: backup, move, history row, re-rooting, game step / game end,
-// first descent of the next search) here, eight slots per pass, and go straight back into the pipeline: a leaf for the net
-// becomes a request, an answer at hand a READY token.  A finished game waits for the epoch boundary (k_assign restarts it).
-// Moves are rare (one per ~800 simulations of a slot): a few wavefronts keep up, and no slot idles until the epoch ends.
+// come back to their home workgroup as tokens with the move bit; the wavefront that draws them runs the lock-step engine's own
+// move step (round_slot<kMover>: backup, move, history row, re-rooting, game step / game end, first descent of the next search)
+// for those groups before the pass proper.  What a group gets back: kSlotWaitEval - the next answer is at hand, the group goes on
+// into the pass like any READY slot; kSlotQueued - the new leaf is a request now (sent here), the group sits this pass out;
+// kSlotEnded / kSlotDone - the game is over, the slot waits for the boundary's k_assign.
 // A function of its own, NOT inlined: inside k_pipe_tree its 244 registers pushed the tree loop into scratch (pass 50 -> 73 us).
+// Its arguments are references into the kernel's kernarg segment (PipeKernArgs), not into copies.
 template <class GM>
-__device__ __attribute__((noinline)) void pipe_mover_loop(const EngineParams& ep, const EngineArrays& ar, const PipeArrays& pa, const uint64_t t_start) {
+__device__ __attribute__((noinline)) uint32_t pipe_move_groups(const EngineParams& ep, const EngineArrays& ar, const PipeArrays& pa, const uint32_t my_slot) {
   const uint32_t wlane = threadIdx.x & 63u, grp = wlane >> 3, lane = wlane & 7u;
   PipeCtl* const pc = pa.ctl;
   PipeEpoch* const pe = pa.ep;
-  uint32_t mw0 = 0, mwn = 0, mwdone = 0;
-  for (;;) {
-    uint32_t my_slot = 0xFFFFFFFFu, n_tok = 0;
-    uint64_t t_first = 0;
-    bool leave = false;
-    for (;;) {
-      if (mwdone == mwn) {
-        uint32_t h = 0;
-        if (wlane == 0) h = atomicAdd(&pc->mhead, kTreeWindow);
-        mw0 = __builtin_amdgcn_readfirstlane(h); mwn = kTreeWindow; mwdone = 0;
-      }
-      const uint32_t left = mwn - mwdone;
-      unsigned long long tok = 0;
-      bool here = false;
-      if (lane == 0 && grp < left) {
-        const uint32_t pos = mw0 + mwdone + grp;
-        tok = g_ld(pa.mring + (pos & (kPipeRing - 1u)));
-        here = (tok >> 48) == pipe_lap_tag(pos);
-      }
-      uint32_t ctl_word = 0;
-      if (wlane == 7) ctl_word = g_ld(&pe->stop) | g_ld(&pc->err);
-      const uint64_t now = wall_clock64();
-      if (__builtin_amdgcn_readlane(ctl_word, 7) != 0u || ar.ctl->stop != 0) { leave = true; break; }
-      if (now - t_start > pa.cap_ticks) { if (wlane == 0) atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTimeout)); leave = true; break; }
-      const unsigned long long hm = __ballot(here);
-      uint32_t k = 0;
-      while (k < left && ((hm >> (8 * k)) & 1ull)) ++k;
-      if (k == left || (k != 0u && t_first != 0 && now - t_first > kTreePatience)) {
-        n_tok = k;
-        const uint32_t sl = static_cast<uint32_t>(__shfl(static_cast<uint32_t>(tok & 0xFFFFull), static_cast<int>(grp * 8), 64));
-        if (grp < k) my_slot = sl;
-        break;
-      }
-      if (k != 0u && t_first == 0) t_first = now;
-      if (k == 0u) __builtin_amdgcn_s_sleep(32);
-    }
-    if (leave) break;
-    mwdone += n_tok;
-    const bool on = my_slot != 0xFFFFFFFFu;
-    const uint32_t slot = on ? my_slot : 0u;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    uint32_t res_state = 0xFFu, seq = 0;
-    if (on) res_state = round_slot<GM, false, true>(ep, ar, slot, lane);
-    if (on && res_state == kSlotQueued && lane == 0) {
-      // the leaf goes to the net: the slot takes the form of a slot with a request out (k_pipe_seed does the same between epochs)
-      seq = ar.req_seq[slot] + 1u;
-      if (seq == 0u) seq = 1u;
-      ar.flags[slot] = ar.flags[slot] | kFlagReqOut;
-      ar.sstate[slot] = kSlotWaitEval;
-    }
-    seq = __shfl(seq, static_cast<int>(grp * 8), 64);
-    // everything the move steps wrote is visible before a request or a token of theirs is
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (on && res_state == kSlotQueued) {
-      if (lane == 0) g_st(ar.req_seq + slot, seq);
-      uint32_t pos = 0;
-      if (lane == 0) pos = atomicAdd(&pc->tail, 1u);
-      pos = __shfl(pos, static_cast<int>(grp * 8), 64);
-      const size_t S_ = static_cast<size_t>(ep.S);
-      const uint64_t payload = lane == 0 ? ar.leaf_pos[0 * S_ + slot] : lane == 1 ? ar.leaf_pos[1 * S_ + slot]
-                             : lane == 2 ? (static_cast<uint64_t>(slot) | ((ar.leaf_pos[2 * S_ + slot] & 1ull) << 16)) : static_cast<uint64_t>(seq);
-      if (lane < kReqGranules)
-        g_st(pa.ring + static_cast<size_t>(pos & (kPipeRing - 1u)) * kReqGranules + lane, (pipe_lap_tag(pos) << 48) | (payload & kMask48));
-    }
-    {
-      const unsigned long long rm = __ballot(on && res_state == kSlotWaitEval && lane == 0);
-      if (rm) {
-        uint32_t base = 0;
-        if (wlane == 0) base = atomicAdd(&pc->rtail, static_cast<uint32_t>(__popcll(rm)));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (on && res_state == kSlotWaitEval && lane == 0) {
-          const uint32_t pos = base + static_cast<uint32_t>(__popcll(rm & ((1ull << (grp * 8)) - 1ull)));
-          g_st(pa.rring + (pos & (kPipeRing - 1u)), (pipe_lap_tag(pos) << 48) | static_cast<unsigned long long>(slot));
-        }
-      }
-      const unsigned long long dm = __ballot(on && lane == 0 && (res_state == kSlotEnded || res_state == kSlotDone));
-      const unsigned long long om = __ballot(on && lane == 0);
-      if (wlane == 0) {
-        if (dm) atomicAdd(&pe->dead, static_cast<uint32_t>(__popcll(dm)));
-        atomicSub(&pe->waiting, static_cast<uint32_t>(__popcll(om)));
-        atomicAdd(&pe->moved, static_cast<uint32_t>(__popcll(om)));
-      }
+  const bool on = my_slot != kNoSlot;
+  const uint32_t slot = on ? my_slot : 0u;
+  uint32_t res_state = 0xFFu, seq = 0, was_sim = 0;
+  if (on) {
+    was_sim = ar.sstate[slot] == kSlotWaitEval ? 1u : 0u;        // (a listed slot's step finishes a simulation; a game start does not)
+    res_state = round_slot<GM, false, true>(ep, ar, slot, lane);
+  }
+  if (on && res_state == kSlotQueued && lane == 0) {
+    // the leaf goes to the net: the slot takes the form of a slot with a request out (k_pipe_seed does the same between epochs)
+    seq = g_ld(ar.req_seq + slot) + 1u;
+    if (seq == 0u) seq = 1u;
+    ar.flags[slot] = ar.flags[slot] | kFlagReqOut;
+    ar.sstate[slot] = kSlotWaitEval;
+  }
+  seq = __shfl(seq, static_cast<int>(grp * 8), 64);
+  // everything the move steps wrote is in L2 before a request of theirs is out (its answer's token may be drawn by another
+  // wavefront of this workgroup)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (on && res_state == kSlotQueued) {
+    if (lane == 0) g_st(ar.req_seq + slot, seq);
+    uint32_t pos = 0;
+    if (lane == 0) pos = atomicAdd(&pc->tail, 1u);
+    pos = __shfl(pos, static_cast<int>(grp * 8), 64);
+    const size_t S_ = static_cast<size_t>(ep.S);
+    const uint64_t payload = lane == 0 ? ar.leaf_pos[0 * S_ + slot] : lane == 1 ? ar.leaf_pos[1 * S_ + slot]
+                           : lane == 2 ? (static_cast<uint64_t>(slot) | ((ar.leaf_pos[2 * S_ + slot] & 1ull) << 16)) : static_cast<uint64_t>(seq);
+    if (lane < kReqGranules)
+      g_st(pa.ring + static_cast<size_t>(pos & (kPipeRing - 1u)) * kReqGranules + lane, (pipe_lap_tag(pos) << 48) | (payload & kMask48));
+  }
+  {
+    const unsigned long long em = __ballot(on && lane == 0 && res_state == kSlotEnded);
+    const unsigned long long dm = __ballot(on && lane == 0 && (res_state == kSlotDone || res_state == 0xFFu));
+    const unsigned long long om = __ballot(on && lane == 0);
+    const unsigned long long sm = __ballot(on && lane == 0 && was_sim != 0u);
+    if (wlane == 0) {
+      if (em) atomicAdd(&pe->ended, static_cast<uint32_t>(__popcll(em)));
+      if (dm) atomicAdd(&pe->dead, static_cast<uint32_t>(__popcll(dm)));
+      if (sm) atomicAdd(&pe->sims, static_cast<unsigned long long>(__popcll(sm)));
+      atomicAdd(&pe->moved, static_cast<uint32_t>(__popcll(om)));
     }
   }
+  return res_state;
 }
 
-// NT: threads per workgroup (256: four wavefronts beside one net workgroup on a CU; eight-wavefront workgroups on CUs of their own
-// were measured equal and are no longer instantiated)
-template <class GM, int NT>
-__global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArrays ar, PipeArrays pa) {
+// NT: threads per workgroup (256: four wavefronts beside one net workgroup on a CU)
+// PROF: the time accounting of AZMI_PIPE_PROF (a build of its own: the counters cost a dozen registers of a kernel that has none to spare)
+template <class GM, int NT, bool PROF>
+__global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
   constexpr int G = GM::GROUP;
   constexpr int P = GM::P;
   static_assert(P == 2 && G == 8 && GM::M == 7, "written for Connect4's 8-lane groups");
+  const EngineParams& ep = ka.ep;
+  const EngineArrays& ar = ka.ar;
+  const PipeArrays& pa = ka.pa;
   const uint32_t wlane = threadIdx.x & 63u, grp = wlane >> 3, lane = wlane & 7u;
   const uint64_t t_start = wall_clock64();
   PipeCtl* const pc = pa.ctl;
   PipeEpoch* const pe = pa.ep;
+  PipeWg* const wc = pa.wg + blockIdx.x;
+  const uint32_t rmask = (1u << pa.rshift) - 1u;
+  unsigned long long* const myring = pa.rring + (static_cast<size_t>(blockIdx.x) << pa.rshift);
   // census first, then the epoch's stop word: a workgroup that only gets a place on the chip after the epoch has ended (the net
   // side, which leaves when every ARRIVED tree workgroup is done, may be gone by then) must not send requests any more
   if (threadIdx.x == 0) {
@@ -205,49 +180,38 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
     asm volatile("s_waitcnt vmcnt(0)" :: "v"(before) : "memory");
   }
   __syncthreads();
-  bool go = ar.ctl->stop == 0 && g_ld(&pc->err) == 0 && g_ld(&pe->stop) == 0;
+  bool go = g_ld(&ar.ctl->stop) == 0 && g_ld(&pc->err) == 0 && g_ld(&pe->stop) == 0;
   uint32_t w0 = 0, wn = 0, wdone = 0;        // the wavefront's window of READY-ring positions: start, size, positions used
-  uint64_t pf_pass = 0, pf_idle = 0, pf_n = 0, pf_act = 0, pf_polls = 0, pf_io = 0, pf_lvls = 0;
+  uint64_t pf_pass = 0, pf_idle = 0, pf_n = 0, pf_act = 0, pf_polls = 0, pf_io = 0, pf_lvls = 0, pf_mv = 0;
   uint64_t pf_ph[5] = {0, 0, 0, 0, 0};     // per group (lane 0 counts): ticks in backup / descent / expansion / probe, simulations
   SlotCtx<GM> c(ep, ar, 0u, lane);
 
-  // ---- the move step inside the epoch: the last wavefront of the first n_mover_wgs workgroups serves the MOVE ring (pipe_mover_loop)
-  if (go && blockIdx.x < pa.n_mover_wgs && (threadIdx.x >> 6) == static_cast<uint32_t>(NT / 64 - 1)) {
-    // (copies: the callee takes references; references to the kernel's own arguments would move THOSE to the stack - the tree
-    // loop below then reads every array pointer from scratch)
-    const EngineParams ep_m = ep;
-    const EngineArrays ar_m = ar;
-    const PipeArrays pa_m = pa;
-    pipe_mover_loop<GM>(ep_m, ar_m, pa_m, t_start);
-    go = false;
-  }
-
   while (go) {
-    const uint64_t pf_t0 = wall_clock64();
-    // ---- tokens for this pass: the arrived prefix of the window's rest
-    uint32_t my_slot = 0xFFFFFFFFu, tok_seq = 0, n_tok = 0, empty_polls = 0, ctl_word = 0;
-    uint64_t t_first = 0;
+    const uint64_t pf_t0 = PROF ? wall_clock64() : 0;
+    // ---- tokens for this pass: what the ring holds now (at most a window of eight); a window is only drawn when tokens are there,
+    // so no wavefront sits on ring positions while it works (with four wavefronts per ring a token behind a busy wavefront's
+    // window would wait for that wavefront's whole pass)
+    uint32_t my_slot = kNoSlot, tok_seq = 0, tok_move = 0, n_tok = 0, empty_polls = 0, ctl_word = 0;
+    uint64_t t_first = 0, t_seen = 0;
     for (;;) {
-      if (wdone == wn) {
-        uint32_t h = 0;
-        if (wlane == 0) h = atomicAdd(&pc->rhead, kTreeWindow);
-        w0 = __builtin_amdgcn_readfirstlane(h); wn = kTreeWindow; wdone = 0;
-      }
-      const uint32_t left = wn - wdone;
+      const bool need_window = wdone == wn;
+      unsigned long long ht = 0;
+      if (need_window && wlane == 0) ht = g_ld(reinterpret_cast<const unsigned long long*>(wc));
+      const uint32_t left = need_window ? 0u : wn - wdone;
       unsigned long long tok = 0;
       bool here = false;
       if (lane == 0 && grp < left) {
         const uint32_t pos = w0 + wdone + grp;
-        tok = g_ld(pa.rring + (pos & (kPipeRing - 1u)));
-        here = (tok >> 48) == pipe_lap_tag(pos);
+        tok = g_ld(myring + (pos & rmask));
+        here = (tok >> 48) == pipe_lap_tag_r(pos, pa.rshift);
       }
-      // the epoch's end: stop word / error, the quota, the slots that wait for the move step.  (Looked at on the first poll of a
-      // pass and on every fourth poll of a wavefront that finds nothing: idle wavefronts must not hammer four hot lines)
+      // the epoch's end: stop word / error, the quota, games that ended, the engine's own stop word.  (Looked at on the first poll
+      // of a pass and on every fourth poll of a wavefront that finds nothing: idle wavefronts must not hammer hot lines)
       if ((empty_polls & 3u) == 0u) {
         ctl_word = 0;
-        if (wlane == 7) ctl_word = g_ld(&pe->stop) | g_ld(&pc->err);
+        if (wlane == 7) ctl_word = g_ld(&pe->stop) | g_ld(&pc->err) | g_ld(&ar.ctl->stop);
         else if (wlane == 15) ctl_word = g_ld(&pe->sims) >= pa.quota ? 1u : 0u;
-        else if (wlane == 23) ctl_word = g_ld(&pe->waiting);
+        else if (wlane == 23) ctl_word = g_ld(&pe->ended);
         else if (wlane == 31) ctl_word = g_ld(&pe->dead);
       }
       uint32_t stop_seen = __builtin_amdgcn_readlane(ctl_word, 7) | __builtin_amdgcn_readlane(ctl_word, 15);
@@ -267,31 +231,61 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
         go = false;
         break;
       }
+      if constexpr (PROF) pf_polls += 1;
+      if (need_window) {
+        const uint32_t hlo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(ht))));
+        const uint32_t hhi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(ht >> 32))));
+        const int32_t avail = static_cast<int32_t>(hhi - hlo);      // tail - head
+        if (avail > 0) {
+          // fewer than a window: a short wait gathers what is on its way (AZMI_PIPE_TAKE_WAIT; 0 = take what is there)
+          if (static_cast<uint32_t>(avail) < kTreeWindow && pa.take_wait != 0u) {
+            if (t_seen == 0) t_seen = now;
+            if (now - t_seen <= pa.take_wait) { __builtin_amdgcn_s_sleep(2); continue; }
+          }
+          const uint32_t n = min(static_cast<uint32_t>(avail), kTreeWindow);
+          uint32_t h = 0;
+          if (wlane == 0) h = atomicAdd(&wc->rhead, n);
+          w0 = __builtin_amdgcn_readfirstlane(h); wn = n; wdone = 0;
+          continue;            // (the tokens of the window are at most a store's latency behind their tickets)
+        }
+        ++empty_polls; __builtin_amdgcn_s_sleep(24);
+        continue;
+      }
       const unsigned long long hm = __ballot(here);
       // group g's token is bit 8 g: the arrived prefix in group order
       uint32_t k = 0;
       while (k < left && ((hm >> (8 * k)) & 1ull)) ++k;
-      pf_polls += 1;
+      // (a window can reach past tail when another wavefront's draw came between this one's look at the ring and its fetch-add:
+      // then its last tokens arrive when their slots do, and the arrived prefix starts the pass after a short patience)
       if (k == left || (k != 0u && t_first != 0 && now - t_first > kTreePatience)) {
         n_tok = k;
         const uint32_t sl = static_cast<uint32_t>(__shfl(static_cast<uint32_t>(tok & 0xFFFFull), static_cast<int>(grp * 8), 64));
         const uint32_t sq = static_cast<uint32_t>(__shfl(static_cast<uint32_t>((tok >> 16) & 0xFFFFFFFFull), static_cast<int>(grp * 8), 64));
-        if (grp < k) { my_slot = sl; tok_seq = sq; }
+        if (grp < k) { my_slot = sl & static_cast<uint32_t>(kTokSlotMask); tok_move = (sl >> 15) & 1u; tok_seq = sq; }
         break;
       }
       if (k != 0u && t_first == 0) t_first = now;
-      if (k == 0u) { ++empty_polls; __builtin_amdgcn_s_sleep(24); }
+      if (k == 0u) { ++empty_polls; __builtin_amdgcn_s_sleep(8); }
     }
     if (!go) break;
     wdone += n_tok;
-    const uint64_t pf_t1 = wall_clock64();
-    pf_idle += pf_t1 - pf_t0; pf_n += 1; pf_act += n_tok;
+    const uint64_t pf_t1 = PROF ? wall_clock64() : 0;
+    if constexpr (PROF) { pf_idle += pf_t1 - pf_t0; pf_n += 1; pf_act += n_tok; }
+
+    // ---- the move step for the groups whose token carries the move bit (pipe_move_groups); a group whose next answer is at
+    // hand afterwards goes on into the pass like any READY slot
+    if (__ballot(tok_move != 0u) != 0ull) {
+      const PipeKernArgs* const kargs = reinterpret_cast<const PipeKernArgs*>(reinterpret_cast<uintptr_t>(__builtin_amdgcn_kernarg_segment_ptr()));
+      const uint32_t rs = pipe_move_groups<GM>(kargs->ep, kargs->ar, kargs->pa, tok_move != 0u ? my_slot : kNoSlot);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (tok_move != 0u) { if (rs == kSlotWaitEval) tok_seq = 0u; else my_slot = kNoSlot; }
+      if constexpr (PROF) pf_mv += wall_clock64() - pf_t1;
+    }
 
     // ---- the pass.  A token that answers a request (its sequence field is not 0) may be here before the wavefront that sent
     // the request - early, in the middle of its own pass - has put the slot back: req_seq[slot] is written last, behind that
-    // pass's release, so the slot is whole once it shows the token's sequence number.  Then the acquire: this CU's L1 may hold
-    // lines of these slots from an earlier pass here.
-    const bool on = my_slot != 0xFFFFFFFFu;
+    // pass's drained stores, so the slot is whole once it shows the token's sequence number.  (Same CU, same L1: no acquire.)
+    const bool on = my_slot != kNoSlot;
     const uint32_t slot = on ? my_slot : 0u;
     if (on && tok_seq != 0u) {
       while (g_ld(ar.req_seq + slot) != tok_seq) {
@@ -303,7 +297,6 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
         __builtin_amdgcn_s_sleep(2);
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     c.slot = slot;
     uint32_t st = kGrpIdle;
     uint8_t final_state = kSlotWaitEval;
@@ -334,7 +327,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
       root = AZMI_SEL(c.t_root, cp);
       goal = (c.flags & kFlagCapped) ? c.seat_cap_visits(cp) : c.seat_visits(cp);
       fpu_root = c.seat_fpu_zero(cp) ? 0.0f : ep.fpu_reduction;
-      seq = ar.req_seq[slot];
+      seq = g_ld(ar.req_seq + slot);
       rec_ok = (c.flags & kFlagPendRec) != 0;
       st = kGrpReady;
       const PendRec pr_in = ar.pend[static_cast<size_t>(slot) * G + lane];
@@ -393,13 +386,13 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
             if (lane < static_cast<uint32_t>(GM::M)) pa.ins_pi[static_cast<size_t>(idx) * GM::M + lane] = reg_pi;
             if (lane <= static_cast<uint32_t>(P)) pa.ins_v[static_cast<size_t>(idx) * (P + 1) + lane] = reg_v;
           } else if (lane == 0) {
-            atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrLog));
+            g_st(&pe->stop, 1u);      // the log is full: this answer is not cached (nothing else is lost) and the epoch ends here
           }
         }
       }
     }
-    const uint64_t pf_t2 = wall_clock64();
-    pf_io += pf_t2 - pf_t1;
+    const uint64_t pf_t2 = PROF ? wall_clock64() : 0;
+    if constexpr (PROF) pf_io += pf_t2 - pf_t1;
 
     // ---- simulations (k_sim's body)
     bool listed = false;
@@ -413,7 +406,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
           st = kGrpIdle;
           break;
         }
-        const uint64_t ph0 = wall_clock64();
+        const uint64_t ph0 = PROF ? wall_clock64() : 0;
         if (!rec_ok) {
           // a path deeper than the 8 levels of the lane image: the backup walks MCTS::path_ in memory (the lock-step engine hands
           // these to the move step; here that would park the slot until the epoch ends)
@@ -468,7 +461,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
           sims_done += 1;
         }
         // ---- MCTS::find_leaf (mcts.cc:462-498), plain PUCT, with the forwarded values patched in
-        const uint64_t ph1 = wall_clock64();
+        const uint64_t ph1 = PROF ? wall_clock64() : 0;
         typename GM::State leaf = c.gs;
         uint32_t cur = root, plen = 0, n = root_n;
         uint64_t meta = root_meta;
@@ -511,8 +504,8 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
           ++plen;
         }
         if (failed) { c.raise(8u); final_state = kSlotDone; st = kGrpIdle; break; }
-        const uint64_t ph2 = wall_clock64();
-        pf_lvls += plen;
+        const uint64_t ph2 = PROF ? wall_clock64() : 0;
+        if constexpr (PROF) pf_lvls += plen;
         c.cur = cur; c.plen = plen;
         rec_ok = plen <= 8u;
 #pragma unroll
@@ -526,7 +519,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
           lf_meta = meta_pack(lf_c0, lf_k, meta_mv(meta), leaf.player, term);
         }
         lf_term = term; lf_player = leaf.player;
-        const uint64_t ph3 = wall_clock64();
+        const uint64_t ph3 = PROF ? wall_clock64() : 0;
         const bool needs_net = term == 0 && !c.seat_eval_random(cp);
         c.flags = needs_net ? (c.flags | kFlagLeafNeedsNet) : (c.flags & ~kFlagLeafNeedsNet);
         if (needs_net) {
@@ -544,10 +537,12 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
                                                                                                   : static_cast<uint64_t>(seq);
             if (lane < kReqGranules)
               g_st(pa.ring + static_cast<size_t>(pos & (kPipeRing - 1u)) * kReqGranules + lane, (pipe_lap_tag(pos) << 48) | (payload & kMask48));
+            // (the packed position stays with the slot: a request dropped by a pipeline error is sent again from there)
+            if (lane < 3u) ar.leaf_pos[static_cast<size_t>(lane) * ep.S + slot] = lane == 2u ? static_cast<uint64_t>(leaf.player) : payload;
             st = kGrpPush;
           }
         }
-        {
+        if constexpr (PROF) {
           const uint64_t ph4 = wall_clock64();
           pf_ph[0] += ph1 - ph0; pf_ph[1] += ph2 - ph1; pf_ph[2] += ph3 - ph2; pf_ph[3] += ph4 - ph3; pf_ph[4] += 1;
         }
@@ -560,8 +555,9 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
         if (static_cast<uint32_t>(__popcll(__ballot(lane == 0))) < pa.min_active) break;
       }
     }
-    const uint64_t pf_t3 = wall_clock64();
-    pf_pass += pf_t3 - pf_t2;
+    const uint64_t pf_t3 = PROF ? wall_clock64() : 0;
+    if constexpr (PROF) pf_pass += pf_t3 - pf_t2;
+
 
     // ---- the slots go back to HBM (k_sim's exit); the request's sequence number is drawn here, its flag is part of the state
     if (on) {
@@ -580,51 +576,43 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(EngineParams ep, EngineArra
       }
       c.store(final_state);
     }
-    // everything this pass wrote is visible before any of its tokens is
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // everything this pass wrote is in L2 before any of its tokens is out (workgroup scope: the slots stay on this CU)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // the slot is whole: publish it (the word a token's taker waits for)
     if (on && lane == 0) g_st(ar.req_seq + slot, seq);
-    // ---- tokens out: READY tokens for the slots whose next answer is at hand (the requests went out when their leaves were found)
+    // ---- tokens out, into this workgroup's own ring: READY tokens for the slots whose next answer is at hand (the requests went
+    // out when their leaves were found), READY tokens with the move bit for the slots whose next step is the move step's
     {
-      const unsigned long long rm = __ballot(st == kGrpReady && lane == 0);
+      const bool tok_out = on && lane == 0 && (st == kGrpReady || listed);
+      const unsigned long long rm = __ballot(tok_out);
       if (rm) {
         uint32_t base = 0;
-        if (wlane == 0) base = atomicAdd(&pc->rtail, static_cast<uint32_t>(__popcll(rm)));
+        if (wlane == 0) base = atomicAdd(&wc->rtail, static_cast<uint32_t>(__popcll(rm)));
         base = __builtin_amdgcn_readfirstlane(base);
-        if (st == kGrpReady && lane == 0) {
+        if (tok_out) {
           const uint32_t pos = base + static_cast<uint32_t>(__popcll(rm & ((1ull << (grp * 8)) - 1ull)));
-          g_st(pa.rring + (pos & (kPipeRing - 1u)), (pipe_lap_tag(pos) << 48) | static_cast<unsigned long long>(slot));
+          g_st(myring + (pos & rmask), (pipe_lap_tag_r(pos, pa.rshift) << 48) | static_cast<unsigned long long>(slot) | (listed ? kTokMove : 0ull));
         }
       }
     }
-    // ---- the epoch's counts: simulations (the quota ends it), slots handed to the move step (MOVE-ring tokens: a mover
-    // wavefront takes them inside the epoch; what it does not get to is the boundary's)
+    // ---- the epoch's counts: simulations (the quota ends it), slots lost to an engine error
     {
       uint32_t x = lane == 0 ? sims_done + sims_mem : 0u;
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
       if (wlane == 0 && x) atomicAdd(&pe->sims, static_cast<unsigned long long>(x));
-      const unsigned long long im = __ballot(listed && lane == 0);
-      if (im) {
-        uint32_t base = 0;
-        if (wlane == 0) { atomicAdd(&pe->waiting, static_cast<uint32_t>(__popcll(im))); base = atomicAdd(&pc->mtail, static_cast<uint32_t>(__popcll(im))); }
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (listed && lane == 0) {
-          const uint32_t pos = base + static_cast<uint32_t>(__popcll(im & ((1ull << (grp * 8)) - 1ull)));
-          g_st(pa.mring + (pos & (kPipeRing - 1u)), (pipe_lap_tag(pos) << 48) | static_cast<unsigned long long>(slot));
-        }
-      }
+      const unsigned long long fm = __ballot(on && lane == 0 && final_state == kSlotDone);
+      if (wlane == 0 && fm) atomicAdd(&pe->dead, static_cast<uint32_t>(__popcll(fm)));
     }
-    pf_io += wall_clock64() - pf_t3;
+    if constexpr (PROF) pf_io += wall_clock64() - pf_t3;
   }
 
-  if (wlane == 0) {
-    g_st(&pe->stop, 1u);       // a tree wavefront leaves: the epoch is over (also when it never began: engine stopped, error)
+  if (wlane == 0) g_st(&pe->stop, 1u);       // a tree wavefront leaves: the epoch is over (also when it never began: engine stopped, error)
+  if (PROF && wlane == 0) {
     atomicAdd(&pc->prof[0], pf_pass); atomicAdd(&pc->prof[1], pf_idle); atomicAdd(&pc->prof[2], pf_n); atomicAdd(&pc->prof[3], pf_act);
     atomicAdd(&pc->prof[4], pf_polls); atomicAdd(&pc->prof[5], pf_io);
     atomicAdd(&pc->prof[9], pf_ph[0]); atomicAdd(&pc->prof[10], pf_ph[1]); atomicAdd(&pc->prof[11], pf_ph[2]); atomicAdd(&pc->prof[12], pf_ph[3]);
-    atomicAdd(&pc->prof[13], pf_ph[4]); atomicAdd(&pc->prof[14], pf_lvls); atomicAdd(&pc->prof[6], static_cast<unsigned long long>(wall_clock64() - t_start));
+    atomicAdd(&pc->prof[13], pf_ph[4]); atomicAdd(&pc->prof[14], pf_lvls); atomicAdd(&pc->prof[15], pf_mv); atomicAdd(&pc->prof[6], static_cast<unsigned long long>(wall_clock64() - t_start));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -691,9 +679,18 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
       uint64_t t_first = 0;                  // when the first request of this pass was seen
       for (;;) {
         if (wdone == wn) {
-          uint32_t h = 0;
-          if (tid == 0) h = atomicAdd(&pc->head, kMaxTake);
-          w0 = __builtin_amdgcn_readfirstlane(h); wn = kMaxTake; wdone = 0;
+          // the window's size follows the load (MODE 0): with a backlog of requests the 6-board tile (capacity: 28 M evaluations/s on
+          // the chip's net places), with none - this workgroup is idle, and so are others - the 3-board tile (latency: 39 us alone
+          // against 60; the slots, not the matrix cores, are what is short then)
+          uint32_t h = 0, take = kMaxTake;
+          if (MODE == 0 && pa.big_at != 0u) {
+            uint32_t hd = 0, tl = 0;
+            if (tid == 0) { hd = g_ld(&pc->head); tl = g_ld(&pc->tail); }
+            const int32_t backlog = static_cast<int32_t>(__builtin_amdgcn_readfirstlane(tl) - __builtin_amdgcn_readfirstlane(hd));
+            if (backlog < static_cast<int32_t>(pa.big_at)) take = 3u;
+          }
+          if (tid == 0) h = atomicAdd(&pc->head, take);
+          w0 = __builtin_amdgcn_readfirstlane(h); wn = take; wdone = 0;
         }
         const uint32_t left = wn - wdone;
         bool here = false;
@@ -766,14 +763,12 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
     }
     // READY tokens of the answered slots (the tree wavefront that draws one checks the granules' tags itself, so the tokens
     // need no ordering behind the tile's stores)
-    if (tid < 64) {
-      uint32_t base = 0;
-      if (tid == 0) base = atomicAdd(&pc->rtail, n);
-      base = __builtin_amdgcn_readfirstlane(base);
-      if (tid < n) {
-        const uint32_t pos = base + tid;
-        g_st(pa.rring + (pos & (kPipeRing - 1u)), (pipe_lap_tag(pos) << 48) | static_cast<unsigned long long>(xs[8 + tid]) | (static_cast<unsigned long long>(xs[16 + tid]) << 16));
-      }
+    // (each into the ring of its slot's home workgroup: one ticket per board, drawn side by side)
+    if (tid < n) {
+      const uint32_t sl = xs[8 + tid];
+      const uint32_t home = sl % pa.n_tree_wgs;
+      const uint32_t pos = atomicAdd(&pa.wg[home].rtail, 1u);
+      pipe_push_token(pa, home, pos, static_cast<unsigned long long>(sl) | (static_cast<unsigned long long>(xs[16 + tid]) << 16));
     }
   }
   if (tid == 0) { atomicAdd(&pc->prof[7], pf_wait); atomicAdd(&pc->prof[8], pf_tile); }
@@ -786,10 +781,12 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
 // into the insert log.
 __global__ void k_pipe_settle(EngineParams ep, EngineArrays ar, PipeArrays pa) {
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-  // the net workgroups left with unused window positions (head ran ahead of tail): the next epoch's windows start at tail
-  if (slot == 0) { pa.ctl->head = pa.ctl->tail; pa.ctl->rhead = pa.ctl->rtail; pa.ctl->mhead = pa.ctl->mtail; }
+  // the net workgroups left with unused window positions (head ran ahead of tail): the next epoch's windows start at tail; tokens
+  // that were still in a READY ring when the epoch ended are dropped (their slots are whole in HBM: k_pipe_seed sends new ones)
+  if (slot == 0) pa.ctl->head = pa.ctl->tail;
+  if (slot < pa.n_tree_wgs) pa.wg[slot].rhead = pa.wg[slot].rtail;
   if (slot >= ep.S) return;
-  // slots the mover wavefronts did not get to (listed late in the epoch, or no mover wavefronts at all): the boundary's move step
+  // slots the epoch listed for the move step and did not get to (listed as it ended): the boundary's move step
   if (ar.flags[slot] & kFlagListed) ar.mover_list[atomicAdd(&ar.ctl->mover_count, 1u)] = slot;
   else { const uint8_t s0 = ar.sstate[slot]; if (s0 == kSlotFresh || s0 == kSlotRestart) ar.mover_list[atomicAdd(&ar.ctl->mover_count, 1u)] = slot; }
   const uint8_t f = ar.flags[slot];
@@ -804,7 +801,22 @@ __global__ void k_pipe_settle(EngineParams ep, EngineArrays ar, PipeArrays pa) {
     bad = bad || static_cast<uint32_t>(g >> 32) != seq;
     val[i] = __uint_as_float(static_cast<uint32_t>(g));
   }
-  if (bad) { atomicOr(&pa.ctl->err, static_cast<uint32_t>(kPipeErrTag)); return; }
+  if (bad) {
+    // the request was never answered - only when the net side left early (a pipeline error: time cap, engine stop).  The slot goes back
+    // to the form the move step leaves a leaf in (kSlotQueued: planes + packed position written, no request out), so the next epoch
+    // sends the request again and a lock-step round lists it: the engine stays usable after the error has been reported.
+    if (g_ld(&pa.ctl->err) == 0u && ar.ctl->stop == 0u) { atomicOr(&pa.ctl->err, static_cast<uint32_t>(kPipeErrTag)); return; }
+    Connect4::State leaf;
+    leaf.bb[0] = ar.leaf_pos[0 * static_cast<size_t>(ep.S) + slot];
+    leaf.bb[1] = ar.leaf_pos[1 * static_cast<size_t>(ep.S) + slot];
+    leaf.player = static_cast<uint32_t>(ar.leaf_pos[2 * static_cast<size_t>(ep.S) + slot]) & 1u;
+    leaf.turn = static_cast<uint32_t>(__popcll(leaf.bb[0] | leaf.bb[1]));
+    float* row = ar.canon + static_cast<size_t>(slot) * Connect4::CANON;
+    for (uint32_t e = 0; e < static_cast<uint32_t>(Connect4::CANON); ++e) row[e] = Connect4::canonical_at(leaf, e);
+    ar.flags[slot] = f & static_cast<uint8_t>(~kFlagReqOut);
+    ar.sstate[slot] = kSlotQueued;
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < M; ++i) ar.pi[static_cast<size_t>(slot) * M + i] = val[i];
 #pragma unroll
@@ -818,9 +830,8 @@ __global__ void k_pipe_settle(EngineParams ep, EngineArrays ar, PipeArrays pa) {
       for (int i = 0; i < M; ++i) pa.ins_pi[static_cast<size_t>(idx) * M + i] = val[i];
 #pragma unroll
       for (int i = 0; i < P1; ++i) pa.ins_v[static_cast<size_t>(idx) * P1 + i] = val[kResV + i];
-    } else {
-      atomicOr(&pa.ctl->err, static_cast<uint32_t>(kPipeErrLog));
     }
+    // (a full log only loses cache entries, never answers: the epoch's quota bounds it, k_pipe_tree stops filling it at its end)
   }
 }
 
@@ -907,43 +918,53 @@ int pipe_alloc(PipeState* ps, T*& p, size_t n) {
   return AZMI_OK;
 }
 
+uint32_t pipe_tree_wgs_for(uint32_t S) {
+  // tree workgroups: a slot lives in ONE workgroup for an epoch (its home), so a workgroup's 32 lane-groups serve S / workgroups
+  // slots.  Roughly a third of the slots is with the net or in a ring at any time: ~26 slots per workgroup keep its lane-groups
+  // fed without queueing for them.  AZMI_PIPE_TREE_WGS sets another count.
+  uint32_t t = std::min<uint32_t>(160u, std::max<uint32_t>(1u, (S + 25u) / 26u));
+  if (const char* e = getenv("AZMI_PIPE_TREE_WGS")) t = static_cast<uint32_t>(std::max(1, atoi(e)));
+  return std::min<uint32_t>(t, std::max<uint32_t>(1u, S));
+}
+
 int pipe_create(azmi_pm* pm, size_t tile_lds) {
   auto ps = new PipeState();
-  pm->pipe = ps;       // owned by the engine from here on (freed with it, also after a failed set-up)
+  struct Guard { PipeState* p; ~Guard() { if (p) pipe_state_free(p); } } guard{ps};     // (a failed set-up leaves nothing half-built behind)
   PipeArrays& pa = ps->pa;
   const uint32_t S = pm->ep.S;
+  ps->tree_wgs = pipe_tree_wgs_for(S);
+  pa.n_tree_wgs = ps->tree_wgs;
+  {   // a workgroup's READY ring: at least twice its slots (every slot has at most one token out), a power of two
+    const uint32_t per_wg = (S + ps->tree_wgs - 1u) / ps->tree_wgs;
+    uint32_t sh = 6;
+    while ((1u << sh) < 2u * per_wg + 2u * kTreeWindow) ++sh;
+    pa.rshift = sh;
+  }
   int rc = pipe_alloc(ps, pa.ctl, 1);
+  if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.wg, ps->tree_wgs);
   if (rc == AZMI_OK && getenv("AZMI_PIPE_POS0")) {
     // test hook: the rings' free-running 32-bit positions start here instead of at 0 (a long run wraps them after ~2 minutes:
     // tests/test_gpu_pipeline.py starts just below 2^32)
+    const uint32_t p0 = static_cast<uint32_t>(strtoul(getenv("AZMI_PIPE_POS0"), nullptr, 0));
     PipeCtl h{};
-    h.head = h.tail = h.rhead = h.rtail = h.mhead = h.mtail = static_cast<uint32_t>(strtoul(getenv("AZMI_PIPE_POS0"), nullptr, 0));
+    h.head = h.tail = p0;
     if (hipMemcpy(pa.ctl, &h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) return azmi_host_fail(AZMI_ERR_NO_DEVICE, "pipeline: control block upload failed");
+    std::vector<PipeWg> hw(ps->tree_wgs);
+    for (auto& w : hw) { w = PipeWg{}; w.rhead = w.rtail = p0; }
+    if (hipMemcpy(pa.wg, hw.data(), hw.size() * sizeof(PipeWg), hipMemcpyHostToDevice) != hipSuccess) return azmi_host_fail(AZMI_ERR_NO_DEVICE, "pipeline: control block upload failed");
   }
   if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.ep, 1);
   if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.ring, static_cast<size_t>(kPipeRing) * kReqGranules);
-  if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.rring, static_cast<size_t>(kPipeRing));
-  if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.mring, static_cast<size_t>(kPipeRing));
+  if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.rring, static_cast<size_t>(ps->tree_wgs) << pa.rshift);
   if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.res, static_cast<size_t>(S) * kResStride);
   if (rc != AZMI_OK) return rc;
-  // tree workgroups: lane-groups for half of the slots (the other half is with the net at any time; slots are not bound to
-  // wavefronts).  Measured at 4096 slots: 64 / 96 / 128 workgroups -> 64 / 71 / 68 M simulations/s: more of them take places
-  // from the net side and run each pass slower (44 / 50 / 53 us).  AZMI_PIPE_TREE_WGS sets another count.
-  // Beyond that the tree side is paid for in net places without being short of lane-groups: at 16384 slots 256 tree workgroups
-  // (256 net workgroups left) ran 37 M simulations/s, fewer than the 4096-slot engine.
-  // (With the requests sent early - pass start, below - the answers come back sooner and 96 workgroups beat 64: 71 vs 64 M.)
-  ps->tree_wgs = std::min<uint32_t>(96u, std::max<uint32_t>(1u, (S * 3u + 127u) / 128u));
-  if (const char* e = getenv("AZMI_PIPE_TREE_WGS")) ps->tree_wgs = std::max(1, atoi(e));
-  pa.n_tree_wgs = ps->tree_wgs;
-  // mover wavefronts: 8 of them take 64 move steps per ~70 us, ten times the rate 4096 slots x 800 simulations ask for
   // inline budget of a pass: a group runs up to 5 simulations whose answers are at hand (cache hits, terminal leaves) before its slot
-  // re-queues, and the pass ends as soon as fewer than 3 of its 8 groups are still running - the stragglers re-queue as READY instead
-  // of keeping the other lanes idle.  Measured at a 0.76 hit rate, M simulations/s: budget 2 / 3 / 4 / 5 / 8 alone 87 / 97.4 / 100.3 /
-  // 98 / 97.7; budget 5 with the early end at 3 groups 102.8 (at 4: 101.7; budget 6: 99.3; budget 8 with 2 / 3 / 4: 97 - 98.6).
-  // An engine created with an explicit max_inline keeps it as its budget.
+  // re-queues, and the pass ends as soon as fewer than min_active of its groups are still running - the stragglers re-queue as READY
+  // instead of keeping the other lanes idle.  An engine created with an explicit max_inline keeps it as its budget.
   pa.max_inline = getenv("AZMI_PIPE_INLINE") ? static_cast<uint32_t>(std::max(1, atoi(getenv("AZMI_PIPE_INLINE")))) : (pm->max_inline_explicit ? pm->ep.max_inline : 5u);
-  pa.min_active = getenv("AZMI_PIPE_MIN_ACTIVE") ? static_cast<uint32_t>(std::max(0, atoi(getenv("AZMI_PIPE_MIN_ACTIVE")))) : 3u;
-  pa.n_mover_wgs = std::min<uint32_t>(ps->tree_wgs, getenv("AZMI_PIPE_MOVERS") ? static_cast<uint32_t>(std::max(0, atoi(getenv("AZMI_PIPE_MOVERS")))) : 8u);
+  pa.min_active = getenv("AZMI_PIPE_MIN_ACTIVE") ? static_cast<uint32_t>(std::max(0, atoi(getenv("AZMI_PIPE_MIN_ACTIVE")))) : 0u;
+  pa.big_at = getenv("AZMI_PIPE_BIG_AT") ? static_cast<uint32_t>(std::max(0, atoi(getenv("AZMI_PIPE_BIG_AT")))) : 0u;
+  pa.take_wait = getenv("AZMI_PIPE_TAKE_WAIT") ? static_cast<uint32_t>(std::max(0, atoi(getenv("AZMI_PIPE_TAKE_WAIT")))) : 0u;
   ps->lds_bytes = tile_lds + kPipeXs;
   // The chip holds two 256-thread workgroups of 256 registers per lane on a CU: the tree side takes tree_wgs of those 512
   // places, the net side what is left (AZMI_PIPE_NET_WGS overrides; a net workgroup that finds no place starts late and
@@ -962,6 +983,8 @@ int pipe_create(azmi_pm* pm, size_t tile_lds) {
   AZMI_HIP_TRY(hipStreamCreateWithFlags(&ps->net_stream, hipStreamNonBlocking));
   AZMI_HIP_TRY(hipEventCreateWithFlags(&ps->ev_go, hipEventDisableTiming));
   AZMI_HIP_TRY(hipEventCreateWithFlags(&ps->ev_net, hipEventDisableTiming));
+  guard.p = nullptr;
+  pm->pipe = ps;       // owned by the engine from here on (freed with it)
   return AZMI_OK;
 }
 
@@ -997,27 +1020,32 @@ int pipe_pair_streams(PipeState* ps, hipStream_t st) {
 extern "C" int azmi_net_c4_view_get(const struct azmi_net* net, azmi_net_c4_view* out);
 
 namespace {
+// net == nullptr: the tree side alone - an engine whose seats all use EvalType::RANDOM (dumb_eval) never sends a request, so no net
+// kernel is launched (what rocprofv3 --pmc can look at: one persistent kernel, no partner it has to run beside)
 bool pipe_supported(const azmi_pm* pm, const azmi_net* net, azmi_net_c4_view* view) {
-  return pm->game == AZMI_GAME_CONNECT4 && pm->split_rounds && pm->ep.num_groups == 1 && !pm->all_random && pm->ep.S <= kPipeRing / 2u &&
-         azmi_net_c4_view_get(net, view) != 0;
+  if (!(pm->game == AZMI_GAME_CONNECT4 && pm->split_rounds && pm->ep.num_groups == 1 && pm->ep.S <= kPipeRing / 2u)) return false;
+  if (!net) return pm->all_random;
+  return !pm->all_random && azmi_net_c4_view_get(net, view) != 0;
 }
 }  // namespace
 extern "C" int azmi_pipeline_supported(azmi_pm* pm, azmi_net* net) {
   azmi_net_c4_view view;
-  return pm && net && pipe_supported(pm, net, &view) ? 1 : 0;
+  return pm && pipe_supported(pm, net, &view) ? 1 : 0;
 }
 
 // An epoch's workgroup counts assume the chip to itself (placement): two engines' epochs at once would each find half of
 // their workgroups without a place.  Calls from different threads therefore take turns (they are synchronous anyway).
 static std::mutex g_pipeline_turn;
 extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, uint64_t sims_per_epoch, void* stream, uint64_t* out_stats) {
-  if (!pm || !net) return azmi_host_fail(AZMI_ERR_INVALID, "null argument");
+  if (!pm) return azmi_host_fail(AZMI_ERR_INVALID, "null argument");
   std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   std::lock_guard<std::mutex> turn_(g_pipeline_turn);
-  azmi_net_c4_view view;
+  azmi_net_c4_view view{};
   if (!pipe_supported(pm, net, &view))
     return azmi_host_fail(AZMI_ERR_STATE, "azmi_run_pipeline: the pipeline drives the Connect4 engine with plain PUCT seats, one model group and a bf16 "
-                          "Connect4-family net, at most %u concurrent games (azmi_pipeline_supported); use azmi_run_rounds for everything else", kPipeRing / 2u);
+                          "Connect4-family net (or no net at all when every seat uses EvalType::RANDOM), at most %u concurrent games (azmi_pipeline_supported); "
+                          "use azmi_run_rounds for everything else", kPipeRing / 2u);
+  const bool tree_only = net == nullptr;
   if (sims_per_epoch == 0) return azmi_host_fail(AZMI_ERR_INVALID, "azmi_run_pipeline: sims_per_epoch must be > 0");
   if (pm->stopped.load(std::memory_order_relaxed)) {     // PlayManager::stop(): the workers leave their loop (play_manager.cc:272)
     if (out_stats) for (int i = 0; i < 16; ++i) out_stats[i] = 0;
@@ -1031,8 +1059,8 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
   }
   PipeState* ps = pm->pipe;
   PipeArrays& pa = ps->pa;
-  { const int rc = pipe_pair_streams(ps, st); if (rc != AZMI_OK) return rc; }
-  if (!ps->lds_set) {
+  if (!tree_only) { const int rc = pipe_pair_streams(ps, st); if (rc != AZMI_OK) return rc; }
+  if (!tree_only && !ps->lds_set) {
     AZMI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_net<0>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ps->lds_bytes)));
     AZMI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_net<1>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ps->lds_bytes)));
     AZMI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_net<2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ps->lds_bytes)));
@@ -1077,30 +1105,36 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
     AZMI_HIP_TRY(hipEventCreate(&ev));
     ps->tev.push_back(ev);
   }
+  const bool prof = getenv("AZMI_PIPE_PROF") != nullptr;
   const auto host_t0 = std::chrono::steady_clock::now();       // what the host spends enqueueing the epochs (it runs ahead of the GPU)
   for (uint32_t e = 0; e < epochs; ++e) {
     AZMI_HIP_TRY(hipMemsetAsync(pa.ep, 0, sizeof(PipeEpoch), st));
     k_pipe_seed<<<settle_blocks, 256, 0, st>>>(pm->ep, pm->ar, pa);
     AZMI_HIP_TRY(hipGetLastError());
-    AZMI_HIP_TRY(hipEventRecord(ps->ev_go, st));
-    AZMI_HIP_TRY(hipStreamWaitEvent(ps->net_stream, ps->ev_go, 0));
+    if (!tree_only) {
+      AZMI_HIP_TRY(hipEventRecord(ps->ev_go, st));
+      AZMI_HIP_TRY(hipStreamWaitEvent(ps->net_stream, ps->ev_go, 0));
+    }
     // the tree kernel goes first: its workgroups take their places per shader engine, the net kernel is sized for what is left
     AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 2], st));
-    k_pipe_tree<Connect4, 256><<<ps->tree_wgs, 256, 0, st>>>(pm->ep, pm->ar, pa);
+    if (prof) k_pipe_tree<Connect4, 256, true><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
+    else k_pipe_tree<Connect4, 256, false><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
     AZMI_HIP_TRY(hipGetLastError());
     AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 3], st));
     if (pm->ep.cache_on) {      // behind the tree kernel, beside the net side's last tiles
       k_pipe_cache_insert<<<2048, 256, 0, st>>>(pm->ar, pa, 0u);
       AZMI_HIP_TRY(hipGetLastError());
     }
-    AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 0], ps->net_stream));
-    if (net_mode == 1) k_pipe_net<1><<<ps->net_wgs, 256, ps->lds_bytes, ps->net_stream>>>(view.nd, view.np, pa);
-    else if (net_mode == 2) k_pipe_net<2><<<ps->net_wgs, 256, ps->lds_bytes, ps->net_stream>>>(view.nd, view.np, pa);
-    else k_pipe_net<0><<<ps->net_wgs, 256, ps->lds_bytes, ps->net_stream>>>(view.nd, view.np, pa);
-    AZMI_HIP_TRY(hipGetLastError());
-    AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 1], ps->net_stream));
-    AZMI_HIP_TRY(hipEventRecord(ps->ev_net, ps->net_stream));
-    AZMI_HIP_TRY(hipStreamWaitEvent(st, ps->ev_net, 0));
+    if (!tree_only) {
+      AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 0], ps->net_stream));
+      if (net_mode == 1) k_pipe_net<1><<<ps->net_wgs, 256, ps->lds_bytes, ps->net_stream>>>(view.nd, view.np, pa);
+      else if (net_mode == 2) k_pipe_net<2><<<ps->net_wgs, 256, ps->lds_bytes, ps->net_stream>>>(view.nd, view.np, pa);
+      else k_pipe_net<0><<<ps->net_wgs, 256, ps->lds_bytes, ps->net_stream>>>(view.nd, view.np, pa);
+      AZMI_HIP_TRY(hipGetLastError());
+      AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 1], ps->net_stream));
+      AZMI_HIP_TRY(hipEventRecord(ps->ev_net, ps->net_stream));
+      AZMI_HIP_TRY(hipStreamWaitEvent(st, ps->ev_net, 0));
+    }
     k_pipe_settle<<<settle_blocks, 256, 0, st>>>(pm->ep, pm->ar, pa);
     AZMI_HIP_TRY(hipGetLastError());
     rc = azmi_host_launch_move_step(pm, st);
@@ -1117,8 +1151,8 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
       AZMI_HIP_TRY(hipMemcpyAsync(&de, pa.ep, sizeof(de), hipMemcpyDeviceToHost, st));
       AZMI_HIP_TRY(hipStreamSynchronize(st));
       if (dc.err) {
-        fprintf(stderr, "pipeline debug: epoch %u of this call: err 0x%x head %u tail %u rhead %u rtail %u sims %llu waiting %u dead %u stop %u tree_done %u/%u arrived, net arrived %u, ins %u, late %u/%u\n",
-                e, dc.err, dc.head, dc.tail, dc.rhead, dc.rtail, de.sims, de.waiting, de.dead, de.stop, de.tree_done, de.tree_arrived, de.net_arrived, de.ins_count,
+        fprintf(stderr, "pipeline debug: epoch %u of this call: err 0x%x head %u tail %u sims %llu ended %u dead %u stop %u tree_done %u/%u arrived, net arrived %u, ins %u, late %u/%u\n",
+                e, dc.err, dc.head, dc.tail, de.sims, de.ended, de.dead, de.stop, de.tree_done, de.tree_arrived, de.net_arrived, de.ins_count,
                 de.tree_late / 100u, de.net_late / 100u);
         epochs = e + 1;
         break;
@@ -1139,13 +1173,13 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
     double net_us = 0.0, tree_us = 0.0;
     for (uint32_t e = 0; e < epochs; ++e) {
       float ms = 0.0f;
-      if (hipEventElapsedTime(&ms, ps->tev[4 * e + 0], ps->tev[4 * e + 1]) == hipSuccess) net_us += 1e3 * ms;
+      if (!tree_only && hipEventElapsedTime(&ms, ps->tev[4 * e + 0], ps->tev[4 * e + 1]) == hipSuccess) net_us += 1e3 * ms;
       if (hipEventElapsedTime(&ms, ps->tev[4 * e + 2], ps->tev[4 * e + 3]) == hipSuccess) tree_us += 1e3 * ms;
     }
     out_stats[10] = static_cast<uint64_t>(net_us); out_stats[11] = static_cast<uint64_t>(tree_us); out_stats[12] = epochs; out_stats[13] = host_enqueue_us;
     if (getenv("AZMI_PIPE_PROF")) {
       fprintf(stderr, "pipe prof:");
-      for (int i = 0; i < 15; ++i) fprintf(stderr, " %llu", hc.prof[i]);
+      for (int i = 0; i < 16; ++i) fprintf(stderr, " %llu", hc.prof[i]);
       fprintf(stderr, "\n");
     }
   }
@@ -1154,11 +1188,18 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
     for (int i = 0; i < 24; ++i) fprintf(stderr, " %u", hc.dbg[i]);
     fprintf(stderr, "\n");
   }
+  if (hc.err) {
+    // reported once: k_pipe_settle has put every slot whose request went unanswered back into the move step's kSlotQueued form, so
+    // the engine is whole - the next call (either driver) carries on from here
+    AZMI_HIP_TRY(hipMemsetAsync(&pa.ctl->err, 0, sizeof(uint32_t), st));
+    AZMI_HIP_TRY(hipMemsetAsync(pa.ctl->dbg, 0, sizeof(pa.ctl->dbg), st));
+    AZMI_HIP_TRY(hipStreamSynchronize(st));
+  }
   if (hc.err)
     return azmi_host_fail(AZMI_ERR_STATE, "pipeline error mask 0x%x (1 a spin hit the epoch's time cap, 2 a ring entry never arrived, 4 a result tag "
                           "did not match, 8 insert log full, 16 cache lock, 32 slots, 64 the net side hit the time cap); census: %u of %u tree and %u of %u net workgroups started; "
-                          "last epoch: head %u tail %u sims %llu waiting %u dead %u stop %u tree_done %u tiles %llu boards %llu; latest tree / net workgroup start %u / %u us",
-                          hc.err, he.tree_arrived, ps->tree_wgs, he.net_arrived, ps->net_wgs, hc.head, hc.tail, he.sims, he.waiting, he.dead, he.stop,
+                          "last epoch: head %u tail %u sims %llu ended %u dead %u stop %u tree_done %u tiles %llu boards %llu; latest tree / net workgroup start %u / %u us",
+                          hc.err, he.tree_arrived, ps->tree_wgs, he.net_arrived, ps->net_wgs, hc.head, hc.tail, he.sims, he.ended, he.dead, he.stop,
                           he.tree_done, hc.tiles, hc.tile_boards, he.tree_late / 100u, he.net_late / 100u);
   if (hc.err && getenv("AZMI_PIPE_DEBUG")) {
     fprintf(stderr, "pipeline dbg:");
