@@ -1628,8 +1628,16 @@ def run_pipeline(pm, net, epochs, sims_per_epoch, stream=None):
     out = (C.c_uint64 * 16)()
     check(lib.azmi_run_pipeline(pm._h, None if net is None else net._h, int(epochs), int(sims_per_epoch), st, out))
     keys = ("tiles", "tile_boards", "last_epoch_sims", "tree_wgs_started", "net_wgs_started", "last_epoch_inserts", "net_wgs", "tree_wgs",
-            "tree_latest_start_us", "net_latest_start_us", "net_kernel_us", "tree_kernel_us", "epochs", "host_enqueue_us")
+            "tree_latest_start_us", "net_latest_start_us", "net_kernel_us", "tree_kernel_us", "epochs", "host_enqueue_us", "calibration_rounds")
     return dict(zip(keys, (int(x) for x in out)))
+
+
+def pipeline_log_duplicates(pm):
+    """azmi_debug_pipe_log_dupes: (answers consumed in the last epoch, of those asked for more than once, of those within 4096 log
+    entries of their twin) - what inserting at answer time / coalescing requests in flight would save."""
+    out = (C.c_uint64 * 3)()
+    check(lib.azmi_debug_pipe_log_dupes(pm._h, out))
+    return int(out[0]), int(out[1]), int(out[2])
 
 
 def run_rounds_groups(pms, nets, rounds, streams):

@@ -96,7 +96,24 @@ def self_play(game, params, net=None, engines=None, seed=20240601, device=0, str
         while live:
             group = [pms[i] for i in live]
             if want_pipe:
-                run_pipeline(pms[0], net, epochs_per_poll, spe, sps[0])
+                try:
+                    run_pipeline(pms[0], net, epochs_per_poll, spe, sps[0])
+                except RuntimeError:
+                    # the pipeline's run-time preconditions (a second hardware queue beside the caller's stream, room for its tree and
+                    # net workgroups side by side) are only known once it runs: "auto" falls back to the lock-step driver - with fresh
+                    # shards while no game has finished, on the same engine otherwise (a pipeline error leaves the engine whole)
+                    if driver != "auto":
+                        raise
+                    want_pipe = False
+                    if pms[0].games_completed() == 0 and not drained[0]:
+                        K = max(1, min(int(engines or 4), int(params.concurrent_games)))
+                        pms = [PlayManager(game() if isinstance(game, type) else game, _shard_params(params, k, K), seed=shard_seed(seed, k), device=device)
+                               for k in range(K)]
+                        drained = [[] for _ in range(K)]
+                        streams = [torch.cuda.Stream(device=device) for _ in range(K)]
+                        sps = [s_.cuda_stream for s_ in streams]
+                        live = list(range(K))
+                    continue
             else:
                 run_rounds(group, net, rounds_per_poll, [sps[i] for i in live])
             for i in live:

@@ -61,7 +61,8 @@ struct PipeCtl {          // zeroed when the pipeline is created; lives across e
   unsigned long long tiles;         // net tiles run
   unsigned long long tile_boards;   // boards in them
   unsigned long long epochs;
-  uint32_t dbg[24];       // diagnostics of the first time-out: slot, sequence number, group state, the tags seen
+  unsigned long long sims_total;    // simulations of all epochs so far (k_pipe_settle adds an epoch's count)
+  uint32_t dbg[22];       // diagnostics of the first time-out: slot, sequence number, group state, the tags seen
   // tree-side time accounting (100 MHz ticks / counts, summed over wavefronts): [0] in simulation passes, [1] polling with no
   // group ready, [2] passes, [3] groups active in them, [4] polls, [5] in the request step, [6] wavefront lifetimes, [7] net: ticks
   // waiting for requests, [8] net: ticks in tiles
@@ -81,7 +82,8 @@ struct PipeEpoch {        // an allocation of its own, zeroed before every epoch
   uint32_t tree_late, net_late;   // census: the latest start of a tree / net workgroup, in 100 MHz ticks after the first workgroup of the epoch
   uint32_t ins_done;      // insert-log entries already applied (the first insert launch runs while the net side drains)
   uint32_t moved;         // move steps run by the mover wavefronts in this epoch
-  uint32_t pad1[19];
+  uint32_t tree_late_n, net_late_n;   // calibration launches: workgroups that only started when the others had left
+  uint32_t pad1[17];
 };
 static_assert(sizeof(PipeEpoch) == 256, "memset block: a multiple of 16 bytes");
 
@@ -93,6 +95,7 @@ struct PipeArrays {
   PipeWg* wg;                 // [n_tree_wgs]
   uint32_t rshift;            // log2 of a READY ring's entries (>= twice the slots of a workgroup)
   uint32_t big_at;            // net side, tile selection 0: a workgroup draws a 6-request window when at least this many requests wait in the ring (else 3); 0 = always 6
+  uint32_t census_hold;       // != 0: a calibration launch - every workgroup holds its place this many ticks and leaves (pipe_calibrate)
   uint32_t take_wait;         // ticks a wavefront that found fewer than kTreeWindow tokens waits for more before it starts its pass
   uint32_t max_inline;        // simulations a group may finish in one pass without the net (cache hits, terminal leaves) before its slot re-queues
   uint32_t min_active;        // ... and a pass ends early once fewer than this many of its eight groups are still running (the others idle meanwhile)

@@ -180,6 +180,16 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
     asm volatile("s_waitcnt vmcnt(0)" :: "v"(before) : "memory");
   }
   __syncthreads();
+  if (pa.census_hold != 0u) {
+    // calibration launch (pipe_calibrate): hold the place until census_hold ticks after the epoch's first workgroup started, do
+    // nothing else.  A workgroup the chip had no place for starts when the others have left: it finds itself late and is counted.
+    if (threadIdx.x == 0) {
+      const unsigned long long t0 = g_ld(&pe->t0);
+      if (t_start > t0 && t_start - t0 >= pa.census_hold) atomicAdd(&pe->tree_late_n, 1u);
+      while (wall_clock64() < t0 + pa.census_hold) __builtin_amdgcn_s_sleep(32);
+    }
+    return;
+  }
   bool go = g_ld(&ar.ctl->stop) == 0 && g_ld(&pc->err) == 0 && g_ld(&pe->stop) == 0;
   uint32_t w0 = 0, wn = 0, wdone = 0;        // the wavefront's window of READY-ring positions: start, size, positions used
   uint64_t pf_pass = 0, pf_idle = 0, pf_n = 0, pf_act = 0, pf_polls = 0, pf_io = 0, pf_lvls = 0, pf_mv = 0;
@@ -222,6 +232,9 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
         if (w >= thr || w + d >= ep.S) stop_seen = 1u;
       }
       const uint64_t now = wall_clock64();
+      // an epoch that runs long (a cold cache sends every leaf to the net: 16384 slots x 256 simulations take > 200 ms then) simply
+      // ends at a quarter of the cap; the cap itself is the stall detector
+      if (now - t_start > pa.cap_ticks / 4u) stop_seen = 1u;
       if (now - t_start > pa.cap_ticks) {
         if (wlane == 0) { atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTimeout)); pc->dbg[16] = __builtin_amdgcn_readlane(ctl_word, 23); pc->dbg[17] = __builtin_amdgcn_readlane(ctl_word, 31); }
         stop_seen = 1u;
@@ -285,18 +298,19 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
     // ---- the pass.  A token that answers a request (its sequence field is not 0) may be here before the wavefront that sent
     // the request - early, in the middle of its own pass - has put the slot back: req_seq[slot] is written last, behind that
     // pass's drained stores, so the slot is whole once it shows the token's sequence number.  (Same CU, same L1: no acquire.)
-    const bool on = my_slot != kNoSlot;
-    const uint32_t slot = on ? my_slot : 0u;
-    if (on && tok_seq != 0u) {
-      while (g_ld(ar.req_seq + slot) != tok_seq) {
+    if (my_slot != kNoSlot && tok_seq != 0u) {
+      while (g_ld(ar.req_seq + my_slot) != tok_seq) {
         if (wall_clock64() - t_start > pa.cap_ticks) {
-          if (lane == 0 && atomicAdd(&pc->dbg[0], 1u) == 0u) { pc->dbg[1] = slot; pc->dbg[2] = tok_seq; pc->dbg[3] = g_ld(ar.req_seq + slot); pc->dbg[4] = 0xEEEEu; }
-          if (lane == 0) atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTag));
+          if (lane == 0 && atomicAdd(&pc->dbg[0], 1u) == 0u) { pc->dbg[1] = my_slot; pc->dbg[2] = tok_seq; pc->dbg[3] = g_ld(ar.req_seq + my_slot); pc->dbg[4] = 0xEEEEu; }
+          if (lane == 0) atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTimeout));
+          my_slot = kNoSlot;      // (its other holder is still at work: the slot is not touched; k_pipe_settle takes its answer over)
           break;
         }
         __builtin_amdgcn_s_sleep(2);
       }
     }
+    const bool on = my_slot != kNoSlot;
+    const uint32_t slot = on ? my_slot : 0u;
     c.slot = slot;
     uint32_t st = kGrpIdle;
     uint8_t final_state = kSlotWaitEval;
@@ -353,7 +367,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
           if (okg) break;
           if (wall_clock64() - t_start > pa.cap_ticks) {
             if (lane == 0 && atomicAdd(&pc->dbg[0], 1u) == 0u) { pc->dbg[1] = slot; pc->dbg[2] = seq; pc->dbg[3] = c.flags; pc->dbg[4] = static_cast<uint32_t>(g1 >> 32); pc->dbg[5] = static_cast<uint32_t>(g0 >> 32); }
-            if (lane == 0) atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTag));
+            if (lane == 0) atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTimeout));
             st = kGrpIdle;
             break;
           }
@@ -661,7 +675,12 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
     if (t0 == 0ull) t0 = t_start;
     atomicMax(&pe->net_late, static_cast<uint32_t>(t_start > t0 ? t_start - t0 : 0ull));
     atomicAdd(&pe->net_arrived, 1u);
+    if (pa.census_hold != 0u) {      // calibration launch: see k_pipe_tree
+      if (t_start > t0 && t_start - t0 >= pa.census_hold) atomicAdd(&pe->net_late_n, 1u);
+      while (wall_clock64() < t0 + pa.census_hold) __builtin_amdgcn_s_sleep(32);
+    }
   }
+  if (pa.census_hold != 0u) return;
   // The workgroup's WINDOW: kMaxTake consecutive ring positions drawn with ONE fetch-add on `head` (a compare-and-swap claim
   // of "what is there" serialises every workgroup of the chip on one word: a claim then costs a memory round trip per
   // contender).  The window's positions are this workgroup's to serve, whenever their requests arrive: it waits until the
@@ -783,7 +802,7 @@ __global__ void k_pipe_settle(EngineParams ep, EngineArrays ar, PipeArrays pa) {
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   // the net workgroups left with unused window positions (head ran ahead of tail): the next epoch's windows start at tail; tokens
   // that were still in a READY ring when the epoch ended are dropped (their slots are whole in HBM: k_pipe_seed sends new ones)
-  if (slot == 0) pa.ctl->head = pa.ctl->tail;
+  if (slot == 0) { pa.ctl->head = pa.ctl->tail; pa.ctl->sims_total += pa.ep->sims; }
   if (slot < pa.n_tree_wgs) pa.wg[slot].rhead = pa.wg[slot].rtail;
   if (slot >= ep.S) return;
   // slots the epoch listed for the move step and did not get to (listed as it ended): the boundary's move step
@@ -883,6 +902,13 @@ struct PipeState {
   std::vector<hipEvent_t> tev;      // timing events: four per epoch of a run (net kernel start / end, tree kernel start / end)
   size_t lds_bytes = 0;
   bool lds_set = false;
+  bool calibrated = false;          // net_wgs has been measured beside the tree workgroups (pipe_calibrate)
+  uint32_t calib_rounds = 0;
+  // balance between the two sides (pipe_balance): rings are allocated for tree_wgs_alloc workgroups, `places` = tree + net workgroups
+  // the chip was measured to hold, the cumulative counters are those of the previous call
+  uint32_t tree_wgs_alloc = 0, tree_wgs_min = 1, places = 0;
+  bool balance = false;
+  unsigned long long bal_sims = 0, bal_boards = 0;
 };
 void pipe_state_free(PipeState* p) {
   if (!p) return;
@@ -920,9 +946,10 @@ int pipe_alloc(PipeState* ps, T*& p, size_t n) {
 
 uint32_t pipe_tree_wgs_for(uint32_t S) {
   // tree workgroups: a slot lives in ONE workgroup for an epoch (its home), so a workgroup's 32 lane-groups serve S / workgroups
-  // slots.  Roughly a third of the slots is with the net or in a ring at any time: ~26 slots per workgroup keep its lane-groups
-  // fed without queueing for them.  AZMI_PIPE_TREE_WGS sets another count.
-  uint32_t t = std::min<uint32_t>(160u, std::max<uint32_t>(1u, (S + 25u) / 26u));
+  // slots; about a third of the slots is with the net or in a ring at any time.  Every tree workgroup takes a place from the net
+  // side, and at 4096 slots both sides are full (tree wavefronts 94 % busy, net workgroups 87-91 %): measured, M simulations/s at 96 /
+  // 112 / 128 / 144 / 160 workgroups: 89 / 101 / 102-105 / 100 / 88.  AZMI_PIPE_TREE_WGS sets another count.
+  uint32_t t = std::min<uint32_t>(128u, std::max<uint32_t>(1u, (S + 31u) / 32u));
   if (const char* e = getenv("AZMI_PIPE_TREE_WGS")) t = static_cast<uint32_t>(std::max(1, atoi(e)));
   return std::min<uint32_t>(t, std::max<uint32_t>(1u, S));
 }
@@ -934,14 +961,19 @@ int pipe_create(azmi_pm* pm, size_t tile_lds) {
   const uint32_t S = pm->ep.S;
   ps->tree_wgs = pipe_tree_wgs_for(S);
   pa.n_tree_wgs = ps->tree_wgs;
+  // the tree side may grow or shrink between calls with the share of leaves that reach the net (pipe_balance): unless the count was
+  // fixed by hand, rings exist for 1.5 x the default and are sized for a third of it
+  ps->balance = getenv("AZMI_PIPE_TREE_WGS") == nullptr && getenv("AZMI_PIPE_NET_WGS") == nullptr && getenv("AZMI_PIPE_NO_BALANCE") == nullptr && ps->tree_wgs >= 48u;
+  ps->tree_wgs_alloc = ps->balance ? ps->tree_wgs + ps->tree_wgs / 2u : ps->tree_wgs;
+  ps->tree_wgs_min = ps->balance ? ps->tree_wgs / 3u : ps->tree_wgs;
   {   // a workgroup's READY ring: at least twice its slots (every slot has at most one token out), a power of two
-    const uint32_t per_wg = (S + ps->tree_wgs - 1u) / ps->tree_wgs;
+    const uint32_t per_wg = (S + ps->tree_wgs_min - 1u) / ps->tree_wgs_min;
     uint32_t sh = 6;
     while ((1u << sh) < 2u * per_wg + 2u * kTreeWindow) ++sh;
     pa.rshift = sh;
   }
   int rc = pipe_alloc(ps, pa.ctl, 1);
-  if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.wg, ps->tree_wgs);
+  if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.wg, ps->tree_wgs_alloc);
   if (rc == AZMI_OK && getenv("AZMI_PIPE_POS0")) {
     // test hook: the rings' free-running 32-bit positions start here instead of at 0 (a long run wraps them after ~2 minutes:
     // tests/test_gpu_pipeline.py starts just below 2^32)
@@ -949,35 +981,37 @@ int pipe_create(azmi_pm* pm, size_t tile_lds) {
     PipeCtl h{};
     h.head = h.tail = p0;
     if (hipMemcpy(pa.ctl, &h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) return azmi_host_fail(AZMI_ERR_NO_DEVICE, "pipeline: control block upload failed");
-    std::vector<PipeWg> hw(ps->tree_wgs);
+    std::vector<PipeWg> hw(ps->tree_wgs_alloc);
     for (auto& w : hw) { w = PipeWg{}; w.rhead = w.rtail = p0; }
     if (hipMemcpy(pa.wg, hw.data(), hw.size() * sizeof(PipeWg), hipMemcpyHostToDevice) != hipSuccess) return azmi_host_fail(AZMI_ERR_NO_DEVICE, "pipeline: control block upload failed");
   }
   if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.ep, 1);
   if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.ring, static_cast<size_t>(kPipeRing) * kReqGranules);
-  if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.rring, static_cast<size_t>(ps->tree_wgs) << pa.rshift);
+  if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.rring, static_cast<size_t>(ps->tree_wgs_alloc) << pa.rshift);
   if (rc == AZMI_OK) rc = pipe_alloc(ps, pa.res, static_cast<size_t>(S) * kResStride);
   if (rc != AZMI_OK) return rc;
-  // inline budget of a pass: a group runs up to 5 simulations whose answers are at hand (cache hits, terminal leaves) before its slot
-  // re-queues, and the pass ends as soon as fewer than min_active of its groups are still running - the stragglers re-queue as READY
-  // instead of keeping the other lanes idle.  An engine created with an explicit max_inline keeps it as its budget.
-  pa.max_inline = getenv("AZMI_PIPE_INLINE") ? static_cast<uint32_t>(std::max(1, atoi(getenv("AZMI_PIPE_INLINE")))) : (pm->max_inline_explicit ? pm->ep.max_inline : 5u);
+  // inline budget of a pass: a group runs up to 8 simulations whose answers are at hand (cache hits, terminal leaves) before its slot
+  // re-queues (M simulations/s at 3 / 5 / 6 / 8 / 16: 82 / 89-96 / 102 / 102-110 / 97-100); a pass may also end early once fewer than
+  // min_active of its groups are still running (round 3: 3; with home workgroups 0 - the stragglers' slots would only queue for the
+  // same four wavefronts).  An engine created with an explicit max_inline keeps it as its budget.
+  pa.max_inline = getenv("AZMI_PIPE_INLINE") ? static_cast<uint32_t>(std::max(1, atoi(getenv("AZMI_PIPE_INLINE")))) : (pm->max_inline_explicit ? pm->ep.max_inline : 8u);
   pa.min_active = getenv("AZMI_PIPE_MIN_ACTIVE") ? static_cast<uint32_t>(std::max(0, atoi(getenv("AZMI_PIPE_MIN_ACTIVE")))) : 0u;
-  pa.big_at = getenv("AZMI_PIPE_BIG_AT") ? static_cast<uint32_t>(std::max(0, atoi(getenv("AZMI_PIPE_BIG_AT")))) : 0u;
+  // net side: a workgroup draws a 6-request window (the 6-board tile: capacity) when at least big_at requests wait in the ring, else a
+  // 3-request window (the 3-board tile: 39 us instead of 60 alone - with 4096 slots a slot's wait for its answer is what is short)
+  pa.big_at = getenv("AZMI_PIPE_BIG_AT") ? static_cast<uint32_t>(std::max(0, atoi(getenv("AZMI_PIPE_BIG_AT")))) : 48u;
   pa.take_wait = getenv("AZMI_PIPE_TAKE_WAIT") ? static_cast<uint32_t>(std::max(0, atoi(getenv("AZMI_PIPE_TAKE_WAIT")))) : 0u;
   ps->lds_bytes = tile_lds + kPipeXs;
-  // The chip holds two 256-thread workgroups of 256 registers per lane on a CU: the tree side takes tree_wgs of those 512
-  // places, the net side what is left (AZMI_PIPE_NET_WGS overrides; a net workgroup that finds no place starts late and
-  // leaves at once, nothing waits for it)
+  // Net workgroups: what the chip holds beside the tree workgroups.  First guess = the runtime's own occupancy answer for the net
+  // kernel (workgroups per CU at its registers and LDS) x CUs - tree workgroups (a tree workgroup takes a net workgroup's place);
+  // pipe_calibrate then MEASURES it with the two kernels themselves before the first epoch (a persistent kernel only works when
+  // every workgroup is resident, and how the dispatcher deals workgroups to shader engines is nothing this code may assume).
   hipDeviceProp_t prop;
   AZMI_HIP_TRY(hipGetDeviceProperties(&prop, pm->device));
-  // workgroups are dealt round-robin to the shader engines (8 CUs = 16 places each) and stay there: a tree workgroup dealt to
-  // an engine that the net side has filled never starts (measured: 4 tree workgroups beside 480 net workgroups all run, beside
-  // 488 they do not; 128 beside 384 do, beside 400 the last net workgroups start when the epoch is over).  So the places
-  // are counted per shader engine.
-  const uint32_t engines = std::max<uint32_t>(1u, static_cast<uint32_t>(prop.multiProcessorCount) / 8u), places = 16u;
-  const uint32_t tree_per_engine = ((ps->tree_wgs + engines - 1u) / engines) * (ps->tree_block / 256u);
-  uint32_t net = engines * (places > tree_per_engine ? places - tree_per_engine : 1u);
+  int per_cu = 0;
+  AZMI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_net<0>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ps->lds_bytes)));
+  AZMI_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_pipe_net<0>), 256, ps->lds_bytes));
+  const uint32_t places_total = static_cast<uint32_t>(std::max(1, per_cu)) * static_cast<uint32_t>(prop.multiProcessorCount);
+  uint32_t net = places_total > ps->tree_wgs ? places_total - ps->tree_wgs : 1u;
   if (const char* e = getenv("AZMI_PIPE_NET_WGS")) net = static_cast<uint32_t>(atoi(e));
   ps->net_wgs = std::max<uint32_t>(1u, net);
   AZMI_HIP_TRY(hipStreamCreateWithFlags(&ps->net_stream, hipStreamNonBlocking));
@@ -1015,6 +1049,38 @@ int pipe_pair_streams(PipeState* ps, hipStream_t st) {
                         "the pipeline needs its tree and net kernels on the chip together - use azmi_run_rounds");
 }
 
+// Measures how many net workgroups run BESIDE the tree workgroups: both persistent kernels are launched as they are in an epoch, with
+// PipeArrays::census_hold set - every workgroup that gets a place holds it until 1 ms after the first one started (far longer than the
+// two launches are apart) and leaves; one that the chip has no place for starts only then, finds itself late and is counted.  The net side gives up as many workgroups as came late (tree workgroups that came
+// late count too: the net kernel had taken their places) until nobody is late.  No constant of the part's dealing order is involved;
+// a second tenant on the chip, a CU mask or a new runtime change the answer, not the code.  (AZMI_PIPE_NO_CALIBRATE=1 skips it.)
+int pipe_calibrate(azmi_pm* pm, PipeState* ps, hipStream_t st, const azmi_net_c4_view& view) {
+  if (ps->calibrated || getenv("AZMI_PIPE_NO_CALIBRATE")) { ps->calibrated = true; return AZMI_OK; }
+  PipeArrays pa = ps->pa;
+  pa.census_hold = 100000u;
+  for (int attempt = 0; attempt < 24; ++attempt) {
+    AZMI_HIP_TRY(hipMemsetAsync(pa.ep, 0, sizeof(PipeEpoch), st));
+    AZMI_HIP_TRY(hipEventRecord(ps->ev_go, st));
+    AZMI_HIP_TRY(hipStreamWaitEvent(ps->net_stream, ps->ev_go, 0));
+    k_pipe_tree<Connect4, 256, false><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
+    AZMI_HIP_TRY(hipGetLastError());
+    k_pipe_net<0><<<ps->net_wgs, 256, ps->lds_bytes, ps->net_stream>>>(view.nd, view.np, pa);
+    AZMI_HIP_TRY(hipGetLastError());
+    AZMI_HIP_TRY(hipEventRecord(ps->ev_net, ps->net_stream));
+    AZMI_HIP_TRY(hipStreamWaitEvent(st, ps->ev_net, 0));
+    PipeEpoch he;
+    AZMI_HIP_TRY(hipMemcpyAsync(&he, pa.ep, sizeof(he), hipMemcpyDeviceToHost, st));
+    AZMI_HIP_TRY(hipStreamSynchronize(st));
+    ps->calib_rounds = static_cast<uint32_t>(attempt) + 1u;
+    const uint32_t late = he.tree_late_n + he.net_late_n;
+    if (late == 0u && he.tree_arrived == ps->tree_wgs && he.net_arrived == ps->net_wgs) { ps->calibrated = true; ps->places = ps->tree_wgs + ps->net_wgs; return AZMI_OK; }
+    if (ps->net_wgs <= 1u) break;
+    ps->net_wgs = ps->net_wgs > late + 1u ? ps->net_wgs - std::max<uint32_t>(late, 1u) : 1u;
+  }
+  return azmi_host_fail(AZMI_ERR_STATE, "azmi_run_pipeline: the chip does not hold %u tree workgroups beside one net workgroup (another tenant on the GPU? "
+                        "AZMI_PIPE_TREE_WGS too large?); use azmi_run_rounds", ps->tree_wgs);
+}
+
 }  // namespace
 
 extern "C" int azmi_net_c4_view_get(const struct azmi_net* net, azmi_net_c4_view* out);
@@ -1031,6 +1097,35 @@ bool pipe_supported(const azmi_pm* pm, const azmi_net* net, azmi_net_c4_view* vi
 extern "C" int azmi_pipeline_supported(azmi_pm* pm, azmi_net* net) {
   azmi_net_c4_view view;
   return pm && pipe_supported(pm, net, &view) ? 1 : 0;
+}
+
+// The two sides share the chip's workgroup places, and how many each needs follows the share of leaves that reach the net.  Measured
+// at 4096 slots on 512 places (M simulations/s by tree workgroups; m = evaluations per simulation):
+//   m = 0.19 (128 M-entry cache):  96 / 112 / 128 / 144 / 160 -> 88 / 96-101 / 96-105 / 100 / 88
+//   m = 0.29 (32 M entries):       80 /  96 / 112 / 128       -> 70 / 78 / 80 / 77
+//   m = 0.55 (200 k entries):      48 /  64 /  80 / 128       -> 43 / 51 / 52 / 39
+// i.e. the best count falls about linearly with m: tree workgroups = places x (0.297 - 0.293 m), between a quarter and 1.5 x the
+// default (AZMI_PIPE_BALANCE_A / _B set other coefficients).  m is taken over the PREVIOUS call; the count moves 8 workgroups per call,
+// between epochs only (a slot's home is slot % tree workgroups for one epoch at a time; between epochs a slot is whole in HBM).  The
+// games do not depend on it (a slot's game is a function of its seed alone).
+void pipe_balance(PipeState* ps, const PipeCtl& hc) {
+  if (!ps->balance || !ps->calibrated || ps->places == 0u) return;
+  const unsigned long long ds = hc.sims_total - ps->bal_sims, db = hc.tile_boards - ps->bal_boards;
+  ps->bal_sims = hc.sims_total; ps->bal_boards = hc.tile_boards;
+  if (ds < 4096ull || db == 0ull) return;
+  double ca = 0.297, cb = 0.293;
+  if (const char* e = getenv("AZMI_PIPE_BALANCE_A")) ca = atof(e);
+  if (const char* e = getenv("AZMI_PIPE_BALANCE_B")) cb = atof(e);
+  const double m = static_cast<double>(db) / static_cast<double>(ds);
+  const double share = std::max(0.02, ca - cb * m);
+  uint32_t want = static_cast<uint32_t>(static_cast<double>(ps->places) * share + 0.5);
+  want = std::min(ps->tree_wgs_alloc, std::max(ps->tree_wgs_min, (want + 4u) / 8u * 8u));
+  if (want + 8u <= ps->tree_wgs) ps->tree_wgs -= 8u;
+  else if (want >= ps->tree_wgs + 8u) ps->tree_wgs += 8u;
+  else return;
+  ps->tree_wgs = std::min(ps->tree_wgs_alloc, std::max(ps->tree_wgs_min, ps->tree_wgs));
+  ps->pa.n_tree_wgs = ps->tree_wgs;
+  ps->net_wgs = ps->places > ps->tree_wgs ? ps->places - ps->tree_wgs : 1u;
 }
 
 // An epoch's workgroup counts assume the chip to itself (placement): two engines' epochs at once would each find half of
@@ -1066,6 +1161,7 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
     AZMI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_net<2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ps->lds_bytes)));
     ps->lds_set = true;
   }
+  if (!tree_only) { const int rc = pipe_calibrate(pm, ps, st, view); if (rc != AZMI_OK) return rc; }
   // the insert log holds an epoch's answers: at most one per simulation, in practice a third of them
   // (the quota is checked between passes: an epoch overshoots it by what the passes under way still finish)
   const uint64_t want_log = pm->ep.cache_on ? std::min<uint64_t>(std::min<uint64_t>(sims_per_epoch, 1024ull * pm->ep.S) + 2ull * pm->ep.S + static_cast<uint64_t>(ps->tree_wgs) * 32u * (pa.max_inline + 1u), 1ull << 24) : 0ull;
@@ -1166,6 +1262,7 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
   AZMI_HIP_TRY(hipMemcpyAsync(&hc, pa.ctl, sizeof(hc), hipMemcpyDeviceToHost, st));
   AZMI_HIP_TRY(hipMemcpyAsync(&he, pa.ep, sizeof(he), hipMemcpyDeviceToHost, st));
   AZMI_HIP_TRY(hipStreamSynchronize(st));
+  if (!tree_only && !hc.err) pipe_balance(ps, hc);       // (takes effect with the next call's first epoch)
   if (out_stats) {
     out_stats[0] = hc.tiles; out_stats[1] = hc.tile_boards; out_stats[2] = he.sims; out_stats[3] = he.tree_arrived;
     out_stats[4] = he.net_arrived; out_stats[5] = he.ins_count; out_stats[6] = ps->net_wgs; out_stats[7] = ps->tree_wgs;
@@ -1176,7 +1273,7 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
       if (!tree_only && hipEventElapsedTime(&ms, ps->tev[4 * e + 0], ps->tev[4 * e + 1]) == hipSuccess) net_us += 1e3 * ms;
       if (hipEventElapsedTime(&ms, ps->tev[4 * e + 2], ps->tev[4 * e + 3]) == hipSuccess) tree_us += 1e3 * ms;
     }
-    out_stats[10] = static_cast<uint64_t>(net_us); out_stats[11] = static_cast<uint64_t>(tree_us); out_stats[12] = epochs; out_stats[13] = host_enqueue_us;
+    out_stats[10] = static_cast<uint64_t>(net_us); out_stats[11] = static_cast<uint64_t>(tree_us); out_stats[12] = epochs; out_stats[13] = host_enqueue_us; out_stats[14] = ps->calib_rounds;
     if (getenv("AZMI_PIPE_PROF")) {
       fprintf(stderr, "pipe prof:");
       for (int i = 0; i < 16; ++i) fprintf(stderr, " %llu", hc.prof[i]);
@@ -1185,7 +1282,7 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
   }
   if (hc.err) {
     fprintf(stderr, "pipeline dbg:");
-    for (int i = 0; i < 24; ++i) fprintf(stderr, " %u", hc.dbg[i]);
+    for (int i = 0; i < 22; ++i) fprintf(stderr, " %u", hc.dbg[i]);
     fprintf(stderr, "\n");
   }
   if (hc.err) {
@@ -1203,9 +1300,35 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
                           he.tree_done, hc.tiles, hc.tile_boards, he.tree_late / 100u, he.net_late / 100u);
   if (hc.err && getenv("AZMI_PIPE_DEBUG")) {
     fprintf(stderr, "pipeline dbg:");
-    for (int i = 0; i < 24; ++i) fprintf(stderr, " %u", hc.dbg[i]);
+    for (int i = 0; i < 22; ++i) fprintf(stderr, " %u", hc.dbg[i]);
     fprintf(stderr, "\n");
   }
+  return AZMI_OK;
+}
+
+// ---- diagnostics: how many of the last epoch's answers were asked for more than once --------------------------------------------
+// The insert log holds the key of every answer the tree side consumed in the last epoch of the last azmi_run_pipeline call.  A key that
+// is there k times went to the net k times inside one epoch - k - 1 evaluations an insert at answer time (the reference's,
+// play_manager.cc:631-640) or a table of requests in flight would have saved.  out[0] = entries, out[1] = entries beyond the first
+// of their key, out[2] = of those, the ones whose twin sits within 4096 log entries (~ in flight together).
+extern "C" int azmi_debug_pipe_log_dupes(azmi_pm* pm, uint64_t* out) {
+  if (!pm || !out || !pm->pipe) return azmi_host_fail(AZMI_ERR_INVALID, "no pipeline on this engine");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
+  PipeState* ps = pm->pipe;
+  AZMI_HIP_TRY(hipSetDevice(pm->device));
+  AZMI_HIP_TRY(hipDeviceSynchronize());
+  PipeEpoch he;
+  AZMI_HIP_TRY(hipMemcpy(&he, ps->pa.ep, sizeof(he), hipMemcpyDeviceToHost));
+  const uint32_t n = std::min(he.ins_count, ps->pa.ins_cap);
+  std::vector<uint64_t> keys(n);
+  if (n) AZMI_HIP_TRY(hipMemcpy(keys.data(), ps->pa.ins_key, sizeof(uint64_t) * n, hipMemcpyDeviceToHost));
+  std::vector<std::pair<uint64_t, uint32_t>> kv(n);
+  for (uint32_t i = 0; i < n; ++i) kv[i] = {keys[i], i};
+  std::sort(kv.begin(), kv.end());
+  uint64_t dup = 0, near = 0;
+  for (uint32_t i = 1; i < n; ++i)
+    if (kv[i].first == kv[i - 1].first) { ++dup; if (kv[i].second - kv[i - 1].second < 4096u) ++near; }
+  out[0] = n; out[1] = dup; out[2] = near;
   return AZMI_OK;
 }
 

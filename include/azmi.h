@@ -449,7 +449,12 @@ int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, uint64_t sims
  * `net_wgs` workgroups (0 = the pipeline's own count) and tile selection `mode` (0 = 3- and 6-board tiles, 1 = 6-board, 2 =
  * 3-board); *ms_out = milliseconds per drain.  Timing only (scripts/pipe_net_timing.py -> profiles/). */
 int azmi_debug_pipe_net_bench(azmi_pm* pm, azmi_net* net, uint32_t n, uint32_t reps, uint32_t net_wgs, int mode, float* ms_out);
-/* 1 when azmi_run_pipeline can drive this engine with this net, 0 otherwise (then azmi_run_rounds is the driver) */
+/* diagnostics: out[0] = answers the tree side consumed in the last epoch of the last azmi_run_pipeline call (its insert log), out[1] =
+ * those whose key is in the log more than once (evaluations an insert at answer time - PlayManager::update_inferences,
+ * play_manager.cc:631-640 - or a table of requests in flight would have saved), out[2] = of those, twins within 4096 log entries */
+int azmi_debug_pipe_log_dupes(azmi_pm* pm, uint64_t* out);
+/* 1 when azmi_run_pipeline can drive this engine with this net (net may be NULL for an engine whose seats all use
+ * EvalType::RANDOM: the tree kernel alone), 0 otherwise (then azmi_run_rounds is the driver) */
 int azmi_pipeline_supported(azmi_pm* pm, azmi_net* net);
 /* the same loop with one net per MODEL GROUP (gating / benchmark matches between two models, game_runner.py:2184-2332):
  * nets[g] evaluates the leaves of group g, NULL = the group needs no net (RANDOM / PLAYOUT evaluator) */

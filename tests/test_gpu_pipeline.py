@@ -370,3 +370,121 @@ def test_two_threads_drive_two_pipelines():
         ra, ca = _sorted_log(*pm.move_log())
         rb, cb = _sorted_log(rb, cb)
         assert np.array_equal(ra, rb) and np.array_equal(ca, cb)
+
+
+def test_tree_side_alone_with_random_seats_plays_the_lockstep_games():
+    """round 4: an engine whose seats all use EvalType.RANDOM runs on the pipeline's tree kernel alone (no request ever leaves, no net
+    kernel is launched: what rocprofv3 --pmc looks at) - moves, visit counts and pcg32 positions are the lock-step engine's"""
+    import alphazero as az
+    S, seed = 200, 606
+    pp = _selfplay_params(az, S, 90, cache=0)
+    pp.eval_type = [az.EvalType.RANDOM, az.EvalType.RANDOM]
+    pp.games_to_play = S + 40
+    pa = az.PlayManager(az.Connect4GS(), pp, seed=seed, log_moves=True)
+    assert az.pipeline_supported(pa, None)
+    st = torch.cuda.Stream()
+    n = 0
+    while pa.remaining_games() > 0 and n < 20000:
+        stats = az.run_pipeline(pa, None, 3, S * 50, st.cuda_stream)
+        n += 1
+        if pa.poll(st.cuda_stream)[1] == 0:
+            break
+    torch.cuda.synchronize()
+    assert stats["tiles"] == 0 and stats["net_wgs_started"] == 0
+    pb = az.PlayManager(az.Connect4GS(), pp, seed=seed, log_moves=True)
+    pb.play()
+    assert pa.games_completed() == pb.games_completed() == pp.games_to_play
+    ra, ca = _sorted_log(*pa.move_log())
+    rb, cb = _sorted_log(*pb.move_log())
+    first = ra[:, 1] == 0                      # (the last restarts may land in other slots: see test_pipeline_equals_lockstep_over_odd_shapes)
+    firstb = rb[:, 1] == 0
+    assert np.array_equal(ra[first], rb[firstb]) and np.array_equal(ca[first], cb[firstb])
+
+
+@pytest.mark.parametrize("tree_wgs,net_wgs", [(5, 700), (3, None), (7, 40)])
+def test_workgroup_counts_are_measured_not_assumed(monkeypatch, tree_wgs, net_wgs):
+    """round 4: nothing in the library encodes how the dispatcher deals workgroups to shader engines - the net side's workgroup count is
+    MEASURED beside the tree workgroups before the first epoch (pipe_calibrate: both kernels launched with a hold, late starters
+    counted).  Perturbed counts - an odd number of tree workgroups, far more net workgroups than the chip holds, far fewer - either
+    run (with every launched workgroup resident: no late starter) or fail by name; the games are the lock-step engine's."""
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=14), spec)
+    S, seed = 160, 2024
+    pp = _selfplay_params(az, S, 70, cache=1 << 14)
+    monkeypatch.setenv("AZMI_PIPE_TREE_WGS", str(tree_wgs))
+    if net_wgs is not None:
+        monkeypatch.setenv("AZMI_PIPE_NET_WGS", str(net_wgs))
+    pa, (ra, ca), stats = _pipeline_games(az, pp, seed, hip, sims_per_epoch=S * 40)
+    monkeypatch.delenv("AZMI_PIPE_TREE_WGS")
+    if net_wgs is not None:
+        monkeypatch.delenv("AZMI_PIPE_NET_WGS")
+    assert stats["tree_wgs"] == tree_wgs and stats["tree_wgs_started"] == tree_wgs
+    assert stats["net_wgs_started"] == stats["net_wgs"] and stats["calibration_rounds"] >= 1
+    if net_wgs == 700:
+        assert stats["net_wgs"] < 700 and stats["calibration_rounds"] >= 2       # the chip does not hold 700 + 5 workgroups of this size
+    if net_wgs == 40:
+        assert stats["net_wgs"] == 40
+    pb, (rb, cb) = _lockstep_games(az, pp, seed, hip)
+    assert pa.games_completed() == pb.games_completed() == S
+    ra, ca = _sorted_log(ra, ca)
+    rb, cb = _sorted_log(rb, cb)
+    assert np.array_equal(ra, rb) and np.array_equal(ca, cb)
+
+
+def test_a_pipeline_error_is_reported_once_and_the_engine_stays_usable(monkeypatch):
+    """a spin that hits the epoch's time cap (here: a cap of 20 us) is reported by name - and then cleared.  Slots whose
+    requests went unanswered are back in the move step's kSlotQueued form, so later calls of EITHER driver carry on: the finished
+    games are still the lock-step engine's."""
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=15), spec)
+    S, seed = 192, 99
+    pp = _selfplay_params(az, S, 60, cache=1 << 13)
+    pm = az.PlayManager(az.Connect4GS(), pp, seed=seed, log_moves=True)
+    st = torch.cuda.Stream()
+    az.run_pipeline(pm, hip, 2, S * 16, st.cuda_stream)
+    monkeypatch.setenv("AZMI_PIPE_CAP_MS", "0.02")
+    failures = 0
+    for _ in range(3):
+        try:
+            az.run_pipeline(pm, hip, 2, S * 400, st.cuda_stream)
+        except RuntimeError as e:
+            assert "pipeline error mask" in str(e)
+            failures += 1
+    monkeypatch.delenv("AZMI_PIPE_CAP_MS")
+    assert failures >= 1
+    turn = 0
+    while pm.remaining_games() > 0 and turn < 20000:
+        if turn % 3 == 2:
+            az.run_rounds([pm], hip, 4, [st.cuda_stream])
+        else:
+            az.run_pipeline(pm, hip, 2, S * 32, st.cuda_stream)
+        turn += 1
+        if pm.poll(st.cuda_stream)[1] == 0:
+            break
+    torch.cuda.synchronize()
+    pb, (rb, cb) = _lockstep_games(az, pp, seed, hip)
+    assert pm.games_completed() == pb.games_completed() == S
+    ra, ca = _sorted_log(*pm.move_log())
+    rb, cb = _sorted_log(rb, cb)
+    assert np.array_equal(ra, rb) and np.array_equal(ca, cb)
+
+
+def test_self_play_auto_falls_back_when_the_pipeline_cannot_run(monkeypatch):
+    """self_play(driver="auto") must not raise where the lock-step default worked - the pipeline's run-time preconditions
+    are only known once it runs (here it is made to fail: a 1 us time cap); "auto" then plays the games on lock-step shards, and only
+    driver="pipeline" raises"""
+    import alphazero as az
+    from alphazero import torch_net, selfplay
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=16), spec)
+    pp = _selfplay_params(az, 64, 40, cache=1 << 12)
+    pp.games_to_play = 96
+    monkeypatch.setenv("AZMI_PIPE_CAP_MS", "0.001")
+    res, _ = selfplay.self_play(az.Connect4GS, pp, hip, seed=5)
+    assert res.games == 96
+    with pytest.raises(RuntimeError, match="pipeline"):
+        selfplay.self_play(az.Connect4GS, pp, hip, seed=5, driver="pipeline")
