@@ -1356,6 +1356,7 @@ __global__ void k_pipe_fill(PipeArrays pa, uint32_t n, uint32_t S, uint64_t seed
   e[0] = tag | b0; e[1] = tag | b1; e[2] = tag | (i % S) | (static_cast<unsigned long long>(player & 1u) << 16); e[3] = tag | (i + 1u);
 }
 __global__ void k_pipe_fill_done(PipeArrays pa, uint32_t n) { pa.ctl->tail += n; }
+__global__ void k_pipe_head_reset(PipeArrays pa) { pa.ctl->head = pa.ctl->tail; for (uint32_t w = 0; w < pa.n_tree_wgs; ++w) pa.wg[w].rhead = pa.wg[w].rtail; }
 }  // namespace azmi
 
 // Fills the request ring with `n` synthetic positions (n <= the ring) and lets the persistent net kernel alone drain it, `reps`
@@ -1392,13 +1393,16 @@ extern "C" int azmi_debug_pipe_net_bench(azmi_pm* pm, azmi_net* net, uint32_t n,
     else if (mode == 2) k_pipe_net<2><<<wgs, 256, ps->lds_bytes, st>>>(view.nd, view.np, pa);
     else k_pipe_net<0><<<wgs, 256, ps->lds_bytes, st>>>(view.nd, view.np, pa);
     AZMI_HIP_TRY(hipEventRecord(e1, st));
-    k_pipe_settle<<<1, 64, 0, st>>>(pm->ep, pm->ar, pa);      // (head = tail for the next drain; no slot has a request out)
+    k_pipe_head_reset<<<1, 1, 0, st>>>(pa);                   // (head = tail for the next drain; the READY tokens of the synthetic answers are dropped)
     AZMI_HIP_TRY(hipStreamSynchronize(st));
     float ms = 0.0f;
     AZMI_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     if (r > 0) total += ms;
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  // the synthetic answers carry sequence numbers a real request of the same slot could draw later: wipe the granules
+  AZMI_HIP_TRY(hipMemsetAsync(pa.res, 0, sizeof(unsigned long long) * static_cast<size_t>(pm->ep.S) * kResStride, st));
+  AZMI_HIP_TRY(hipStreamSynchronize(st));
   *ms_out = total / static_cast<float>(reps);
   PipeCtl hc;
   AZMI_HIP_TRY(hipMemcpy(&hc, pa.ctl, sizeof(hc), hipMemcpyDeviceToHost));

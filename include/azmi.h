@@ -433,19 +433,24 @@ int azmi_run_rounds(azmi_pm* const* pms, azmi_net* net, uint32_t k, uint32_t rou
  *      (play_manager.cc:258-600, concurrent_queue.h:130-217, game_runner.py:483-552) - and neither has this: for one EPOCH
  *      persistent tree wavefronts simulate their slots and hand the leaves that need the net to persistent net workgroups
  *      (request ring / tagged result granules in HBM, csrc/pipe_types.h); an epoch ends after `sims_per_epoch` simulations
- *      (held to 1024 per slot: an epoch must stay far below the 250 ms stall cap; or when an eighth of the slots waits for a
- *      move), then the moves the mover wavefronts did not get to, game restarts and the
- *      position-cache inserts of its answers run at a kernel boundary.  `epochs` epochs, synchronous (returns when they are
- *      done; a pipeline error is reported here).  The games are those of azmi_run_rounds for the same seeds.
+ *      (held to 1024 per slot; an epoch also ends a quarter of the way to the 250 ms stall cap, or when an eighth of the slots'
+ *      games have ended in it), then game restarts, the moves the epoch's end cut off and the position-cache inserts of its answers
+ *      run at a kernel boundary.  A slot lives in ONE tree workgroup (slot % tree workgroups) for an epoch - searches AND moves -, so
+ *      nothing but requests, answers and READY tokens crosses between CUs inside an epoch.  `epochs` epochs, synchronous (returns
+ *      when they are done).  net == NULL: an engine whose seats all use EvalType::RANDOM runs on the tree kernel alone.
+ *      A pipeline error (a spin that hit the time cap: another tenant holds the chip, the host stalled between the two launches)
+ *      is reported here ONCE and cleared: slots whose requests went unanswered are back in the move step's kSlotQueued form, so
+ *      the next call of either driver carries on.  The games are those of azmi_run_rounds for the same seeds.
  *      out_stats (may be NULL): [0] net tiles run since the pipeline was created, [1] boards in them, [2] simulations of the
  *      last epoch, [3] / [4] tree / net workgroups that started in it, [5] its insert-log entries, [6] / [7] net / tree
  *      workgroups launched, [8] / [9] the latest start of a tree / net workgroup after the epoch's first, in microseconds (all
  *      of them must be on the chip together: a late one found its place only when another left), [10] / [11] the summed
  *      durations of this call's net / tree kernels in microseconds (HIP events on their streams), [12] the epochs of this
- *      call, [13] the host time spent enqueueing them in microseconds (the host runs ahead of the GPU); 16 entries.
+ *      call, [13] the host time spent enqueueing them in microseconds (the host runs ahead of the GPU), [14] the calibration
+ *      launches that measured [6] (0 = not measured: tree side alone); 16 entries.
  *      After azmi_pm_stop both this call and azmi_run_rounds return AZMI_OK at once and run nothing (play_manager.cc:272). */
 int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, uint64_t sims_per_epoch, void* stream, uint64_t* out_stats);
-/* diagnostics: the pipeline's persistent net kernel alone, draining `n` synthetic requests (n <= 8192) `reps` times with
+/* diagnostics: the pipeline's persistent net kernel alone, draining `n` synthetic requests (n <= 32768, the request ring) `reps` times with
  * `net_wgs` workgroups (0 = the pipeline's own count) and tile selection `mode` (0 = 3- and 6-board tiles, 1 = 6-board, 2 =
  * 3-board); *ms_out = milliseconds per drain.  Timing only (scripts/pipe_net_timing.py -> profiles/). */
 int azmi_debug_pipe_net_bench(azmi_pm* pm, azmi_net* net, uint32_t n, uint32_t reps, uint32_t net_wgs, int mode, float* ms_out);

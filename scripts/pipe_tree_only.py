@@ -21,3 +21,8 @@ for b in range(BLOCKS):
     c = pm.counters()["sims"]; t1 = time.perf_counter()
     print("block %d: %.1f Msims/s  games %d  tree kernel %.2f ms/epoch (wall %.2f)" % (b, (c - a) / (t1 - t0) / 1e6, pm.poll(st.cuda_stream)[0], s["tree_kernel_us"] / E / 1e3, (t1 - t0) / E * 1e3), flush=True)
     a, t0 = c, t1
+if os.environ.get("STATS_OUT"):
+    import json
+    n0 = pm.counters()["sims"]
+    az.run_pipeline(pm, None, E, S * Q, st.cuda_stream)
+    json.dump({"sims_per_epoch": (pm.counters()["sims"] - n0) / E, "S": S, "sims": sims, "quota": S * Q}, open(os.environ["STATS_OUT"], "w"))
