@@ -715,7 +715,9 @@ def main():
             # terminal) = the `evals` counter; the torch path and the spatial kernel evaluate the whole slot-indexed batch
             # (the spatial kernels take the eval list too whenever the position cache is on: the listed rows are packed at the front of
             # a dense batch and the workgroups past the live count exit at once)
-            rows_evaluated = n_evals / world if (hip_net is not None and (not tafl or args.cache > 0)) else float(Se) * launches
+            # (round 4: the `evals` counter for every HIP net - without a cache the spatial kernel runs every slot's row, terminal leaves
+            # included, but only the leaves the search asked for are algorithmic work: counting all slots read 1.7 % high)
+            rows_evaluated = n_evals / world if hip_net is not None else float(Se) * launches
             achieved = flop_per_eval * rows_evaluated / dt / 1e12
             per_launch = (flop_per_eval * rows_evaluated / launches) / (nn_ms * 1e-3) / 1e12 if nn_ms > 0 else 0.0
             out["config"].update({"tree_kernel_ms": tree_ms, "net_ms": nn_ms})
@@ -769,17 +771,20 @@ def main():
                     "bytes_per_simulation": b_sim,
                     "note": "latency-bound, not bandwidth-bound: one simulation is a chain of dependent memory round trips; "
                             "the figure to watch is the per-launch time (profiles/)"}
-            # HBM-side traffic of the dominant kernel: not measurable from inside the process; taken from the committed
-            # rocprofv3 --pmc summary of this same command (scripts/gpu_pmc.sh -> profiles/rN_pmc_traffic.csv), per launch,
-            # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on gfx950
-            pmc = next((p for p in (os.path.join(ROOT, "profiles", f"r{n}_pmc_traffic{'_stargambit' if sg else '_tawlbwrdd' if tafl else ''}.csv") for n in (2, 1)) if os.path.exists(p)), None)
-            pmc3 = os.path.join(ROOT, "profiles", "r3_pmc_traffic.csv")
-            if use_pipe and os.path.exists(pmc3):
+            # HBM-side traffic: not measurable from inside the process; taken from the committed rocprofv3 --pmc summaries of THIS
+            # round (profiles/r4_*: every row carries the commit it was collected at; a file of another round is not read), per
+            # launch, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on gfx950 (the tree
+            # kernel's 32-byte record reads are calibrated instead: FETCH_SIZE = TCC_EA0_RDREQ x 64 B there, profiles/r4_pmc_tree.csv)
+            RND = "r4"
+            suffix = "_stargambit" if sg else "_tawlbwrdd" if tafl else ""
+            pmc_net = os.path.join(ROOT, "profiles", f"{RND}_pmc_traffic{suffix}.csv")
+            pmc_tree = os.path.join(ROOT, "profiles", f"{RND}_pmc_tree.csv")
+            if use_pipe and os.path.exists(pmc_net):
                 # the pipeline's two kernels of an epoch must be co-resident and counter collection serialises dispatches
                 # (profiles/r3_pmc_pipeline_probe.txt), so the counters are taken on k_pipe_net ALONE draining a pre-filled ring
                 # (scripts/pipe_net_pmc.py): bytes per position there x the positions of an average launch here
                 pts = []
-                for line in open(pmc3):
+                for line in open(pmc_net):
                     f = line.strip().split(",")
                     if "k_pipe_net" in f[0] and float(f[2]) > 0:
                         pts.append((float(f[2]), (2.0 * float(f[3]) + float(f[4])) * 1024.0, f[5]))
@@ -788,20 +793,45 @@ def main():
                     per_pos = (b2 - b1) / (n2 - n1)
                     fixed = b1 - per_pos * n1
                     out["roofline"]["traffic"] = fixed + per_pos * rows_evaluated / launches
+                    out["roofline"]["traffic_commit"] = commit
                     out["roofline"]["traffic_note"] = ("L2-to-fabric bytes per k_pipe_net launch = %.2f MB once (the weight image into each XCD's L2) + %.0f B per position x the positions of "
                                                        "an average launch; both from 2 x FETCH_SIZE + WRITE_SIZE of the net kernel ALONE draining %d and %d pre-filled requests "
-                                                       "(profiles/r3_pmc_traffic.csv, commit %s): the co-resident tree kernel cannot be counted, rocprofv3 --pmc serialises dispatches "
-                                                       "(profiles/r3_pmc_pipeline_probe.txt)" % (fixed / 1e6, per_pos, int(n1), int(n2), commit))
-                out["roofline_tree"]["traffic_note"] = "not collected: see roofline.traffic_note"
-            elif hip_net is not None and pmc:
-                for line in open(pmc):
+                                                       "(profiles/%s_pmc_traffic.csv, commit %s): rocprofv3 --pmc serialises dispatches, the co-resident pair cannot be counted"
+                                                       % (fixed / 1e6, per_pos, int(n1), int(n2), RND, commit))
+            if use_pipe and os.path.exists(pmc_tree):
+                # the tree kernel ALONE (every seat EvalType.RANDOM, scripts/pipe_tree_only.py under rocprofv3 --pmc, separate passes):
+                # bytes per simulation at the L2-to-fabric counters x the simulations of an average launch here.  That run has no
+                # cache probes and no requests (the mix adds ~0.6 KB of shard keys + payload per probe), so it is a floor.
+                vals, commit = {}, "?"
+                for line in open(pmc_tree):
+                    f = line.strip().split(",")
+                    if len(f) >= 7 and f[1] in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum", "TCP_TCC_READ_REQ_sum", "TCP_TCC_READ_REQ_LATENCY_sum", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"):
+                        vals[f[1]] = float(f[4]); commit = f[6]
+                if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+                    per_sim = (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+                    rt = out["roofline_tree"]
+                    rt["traffic"] = per_sim * sims_rank / launches
+                    rt["traffic_commit"] = commit
+                    rt["traffic_bytes_per_simulation"] = per_sim
+                    rt["traffic_over_algorithmic"] = per_sim / 620.0
+                    rt["traffic_note"] = ("k_pipe_tree ALONE with EvalType.RANDOM seats (no net kernel beside it, so rocprofv3 --pmc can count it): FETCH_SIZE + WRITE_SIZE = %.0f B per "
+                                          "simulation x the simulations of an average launch here; the algorithmic bytes of THAT mode are ~620 B (no canonical planes, no eval rows, no cache probe), "
+                                          "ratio %.2f.  Same passes: L2 hit rate %.2f, L1 -> L2 read latency %.0f cycles average, wavefront cycles %.0f %% parked on waits / %.0f %% issuing "
+                                          "(profiles/%s_pmc_tree.csv, commit %s)" % (per_sim, per_sim / 620.0,
+                                          vals.get("TCC_HIT_sum", 0) / max(1e-9, vals.get("TCC_HIT_sum", 0) + vals.get("TCC_MISS_sum", 0)),
+                                          vals.get("TCP_TCC_READ_REQ_LATENCY_sum", 0) / max(1e-9, vals.get("TCP_TCC_READ_REQ_sum", 0)),
+                                          100.0 * vals.get("SQ_WAIT_ANY", 0) / max(1e-9, vals.get("SQ_WAVE_CYCLES", 0)), 100.0 * vals.get("SQ_ACTIVE_INST_ANY", 0) / max(1e-9, vals.get("SQ_WAVE_CYCLES", 0)), RND, commit))
+            elif hip_net is not None and not use_pipe and os.path.exists(pmc_net):
+                for line in open(pmc_net):
                     f = line.strip().split(",")
                     if ("k_round_big" in line) if tafl else ("k_sim<" in line or "k_round<azmi::Connect4" in line):
-                        out["roofline_tree"]["traffic"] = (2.0 * float(f[-2]) + float(f[-1])) * 1024.0
+                        out["roofline_tree"]["traffic"] = (2.0 * float(f[2]) + float(f[3])) * 1024.0
+                        out["roofline_tree"]["traffic_commit"] = f[4] if len(f) > 4 else None
                     if "k_leafnet" in line or "k_net_move" in line:
-                        out["roofline"]["traffic"] = (2.0 * float(f[-2]) + float(f[-1])) * 1024.0
+                        out["roofline"]["traffic"] = (2.0 * float(f[2]) + float(f[3])) * 1024.0
+                        out["roofline"]["traffic_commit"] = f[4] if len(f) > 4 else None
                         out["roofline"]["traffic_note"] = ("bytes per k_leafnet launch at the L2-to-fabric counters (2 x FETCH_SIZE + WRITE_SIZE, "
-                                                           + os.path.relpath(pmc, ROOT) + ")")
+                                                           + os.path.relpath(pmc_net, ROOT) + ")")
             if world == 1 and hip_net is not None and not args.no_secondary and not tafl and not args.playout_cap:
                 # short secondary measurements of the same workload, reported beside the headline, never as it:
                 #  (a) playout-cap randomisation at the reference's self-play defaults (fast_mcts_visits 25 on 75 % of
