@@ -1063,7 +1063,7 @@ int pm_net_forward(azmi_pm* pm, uint32_t group, azmi_net* net, hipStream_t st) {
 }
 // split round + a Connect4-family bf16 net + one model group: the move step rides in the net launch (k_net_move)
 bool can_fuse(const azmi_pm* pm, const azmi_net* net, azmi_net_c4_view* view) {
-  return pm->split_rounds && pm->ep.num_groups == 1 && !pm->all_random && getenv("AZMI_NO_FUSE") == nullptr && azmi_net_c4_view_get(net, view) != 0;
+  return pm->split_rounds && pm->ep.num_groups == 1 && !pm->all_random && getenv("AZMI_NO_FUSE") == nullptr && azmi_net_c4_view_get(net, view) != 0 && view->x3 == 0;
 }
 int launch_net_move(azmi_pm* pm, const azmi_net_c4_view& view, hipStream_t st) {
   // (per device: the attribute belongs to the device's copy of the kernel; the tile's LDS need is a constant of the geometry)

@@ -465,8 +465,9 @@ void azmi_net_eval_host(const float* canonical, uint32_t n, float* v, float* pi,
 }
 
 int azmi_net_c4_view_get(const azmi_net* net, azmi_net_c4_view* out) {
-  if (!net || !out || net->f32 || net->spatial || net->x3) return 0;
-  out->nd = net->nd; out->np = net->np; out->lds_bytes = c4::TileSmall::LDS_BYTES;   // the engine's fused launch runs the small tile
+  if (!net || !out || net->f32 || net->spatial) return 0;
+  out->nd = net->nd; out->np = net->np; out->x3 = net->x3 ? 1 : 0;
+  out->lds_bytes = net->x3 ? c4::TileBigX3::LDS_BYTES : c4::TileSmall::LDS_BYTES;   // (bf16: the engine's fused launch runs the small tile)
   return 1;
 }
 

@@ -192,7 +192,6 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
   constexpr bool SPLIT = TG::SPLIT != 0;
   constexpr int CPC = SPLIT ? 3 * CHUNKS_PER_CONV : CHUNKS_PER_CONV;     // weight chunks per 3x3 convolution
   constexpr int HEADCH = SPLIT ? 3 : 1;                                  // ... of the head 1x1 convolution
-  static_assert(!(SPLIT && PIPE), "the pipeline runs the bf16 tiles");
     const size_t block_stride = 3 * CH * sizeof(float) + 2 * static_cast<size_t>(CPC) * CHUNK_BYTES;
 
   // ---- small fp32 parameters -> LDS (plain loads, before any DMA is in flight) ------------------------------------
@@ -707,8 +706,10 @@ struct azmi_net_c4_view {
   azmi_net_dev::NetDesc nd;
   azmi_net_dev::NetPtrs np;
   size_t lds_bytes;
+  int x3;                 // the bf16x3 tier (split bf16 operands, Tile<.., SPLIT>): one workgroup per CU; only the pipeline runs it through a view
 };
-// fills `out` when `net` is a bf16 Connect4-family net (the kernel above); returns 0 otherwise
+// fills `out` when `net` is a Connect4-family net on the matrix cores (bf16, or bf16x3: out->x3 - the lock-step engine's fused
+// launch takes the bf16 tile only and checks the flag); returns 0 otherwise
 extern "C" int azmi_net_c4_view_get(const struct azmi_net* net, azmi_net_c4_view* out);
 // allocates the per-stream scratch a forward of up to `max_rows` rows on `stream` needs (a forward allocates it on first use,
 // which a stream capture does not allow); 0 = ok

@@ -656,16 +656,21 @@ __device__ __forceinline__ void pipe_stage_planes(uint8_t* lds, const uint32_t* 
   }
 }
 
-template <int MODE>     // 0: the 3- and the 6-board tile (by what the claim brought), 1: the 6-board tile only, 2: the 3-board tile only
+// MODE 0: the 3- and the 6-board tile (by what the claim brought), 1: the 6-board tile only, 2: the 3-board tile only
+// X3: the bf16x3 tier's tiles (Tile<.., SPLIT>: weights and activations as bf16 high + low parts, three MFMAs per product - the north
+// star's 1e-5 on the matrix cores); 16 activation planes, so ONE workgroup per CU, beside which a tree workgroup still fits
+template <int MODE, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, azmi_net_dev::NetPtrs np, PipeArrays pa) {
   constexpr uint32_t kMaxTake = MODE == 2 ? 3u : 6u;
   constexpr uint64_t kPatienceTicks = 150;       // 1.5 us: how long a request that is there waits for the rest of its window
   using namespace azmi_net_dev;
+  using TBig = std::conditional_t<X3, c4::TileBigX3, c4::TileBig>;
+  using TSmall = std::conditional_t<X3, c4::TileSmallX3, c4::TileSmall>;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_pipe[];
   // claim scratch: [0] boards claimed (0 = leave), [1] first ring position; [8..14) slot, [16..22) sequence number,
   // [24..30) player, then as u64: [0..6) stones of player 0, [8..14) stones of player 1
-  uint32_t* const xs = reinterpret_cast<uint32_t*>(lds_pipe + c4::TileBig::LDS_BYTES);
-  static_assert(c4::TileBig::LDS_BYTES >= c4::TileSmall::LDS_BYTES && 2 * (c4::TileBig::LDS_BYTES + kPipeXs) <= 160 * 1024, "two workgroups per CU");
+  uint32_t* const xs = reinterpret_cast<uint32_t*>(lds_pipe + TBig::LDS_BYTES);
+  static_assert(TBig::LDS_BYTES >= TSmall::LDS_BYTES && (X3 ? 1 : 2) * (TBig::LDS_BYTES + kPipeXs) <= 160 * 1024, "two workgroups per CU (X3: one)");
   const uint32_t tid = threadIdx.x;
   const uint64_t t_start = wall_clock64();
   PipeCtl* const pc = pa.ctl;
@@ -769,15 +774,15 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
     NetPtrs npi = np;
     asm volatile("" : "+s"(npi.stem_w), "+s"(npi.stem_b), "+s"(npi.blocks), "+s"(npi.head_w), "+s"(npi.head_b), "+s"(npi.v_fc1_w));
     asm volatile("" : "+s"(npi.v_fc1_b), "+s"(npi.v_fc2_w), "+s"(npi.v_fc2_b), "+s"(npi.pi_fc_w), "+s"(npi.pi_fc_b));
-    if (MODE == 2 || (MODE == 0 && n <= static_cast<uint32_t>(c4::TileSmall::TBW))) {
+    if (MODE == 2 || (MODE == 0 && n <= static_cast<uint32_t>(TSmall::TBW))) {
       if constexpr (MODE != 1) {
-        pipe_stage_planes<c4::TileSmall>(lds_pipe, xs, tid);
-        c4::tile<c4::TileSmall, 4, 4, 16, 0, true>(nd, npi, nullptr, nullptr, nullptr, c4::TileSmall::TBW, nullptr, nullptr, 0u, lds_pipe, &pio);
+        pipe_stage_planes<TSmall>(lds_pipe, xs, tid);
+        c4::tile<TSmall, 4, 4, 16, 0, true>(nd, npi, nullptr, nullptr, nullptr, TSmall::TBW, nullptr, nullptr, 0u, lds_pipe, &pio);
       }
     } else {
       if constexpr (MODE != 2) {
-        pipe_stage_planes<c4::TileBig>(lds_pipe, xs, tid);
-        c4::tile<c4::TileBig, 4, 4, 16, 0, true>(nd, npi, nullptr, nullptr, nullptr, c4::TileBig::TBW, nullptr, nullptr, 0u, lds_pipe, &pio);
+        pipe_stage_planes<TBig>(lds_pipe, xs, tid);
+        c4::tile<TBig, 4, 4, 16, 0, true>(nd, npi, nullptr, nullptr, nullptr, TBig::TBW, nullptr, nullptr, 0u, lds_pipe, &pio);
       }
     }
     // READY tokens of the answered slots (the tree wavefront that draws one checks the granules' tags itself, so the tokens
@@ -901,12 +906,12 @@ struct PipeState {
   uint32_t net_wgs = 0, tree_wgs = 0, tree_block = 256;
   std::vector<hipEvent_t> tev;      // timing events: four per epoch of a run (net kernel start / end, tree kernel start / end)
   size_t lds_bytes = 0;
-  bool lds_set = false;
+  bool sized = false, x3 = false;   // pipe_size_net has run for a net of this precision tier
   bool calibrated = false;          // net_wgs has been measured beside the tree workgroups (pipe_calibrate)
   uint32_t calib_rounds = 0;
   // balance between the two sides (pipe_balance): rings are allocated for tree_wgs_alloc workgroups, `places` = tree + net workgroups
   // the chip was measured to hold, the cumulative counters are those of the previous call
-  uint32_t tree_wgs_alloc = 0, tree_wgs_min = 1, places = 0;
+  uint32_t tree_wgs_alloc = 0, tree_wgs_min = 1, tree_wgs_default = 1, places = 0;
   bool balance = false;
   unsigned long long bal_sims = 0, bal_boards = 0;
 };
@@ -944,6 +949,15 @@ int pipe_alloc(PipeState* ps, T*& p, size_t n) {
   return AZMI_OK;
 }
 
+// the persistent net kernel's instantiations: tile selection x precision tier
+using PipeNetFn = void (*)(azmi_net_dev::NetDesc, azmi_net_dev::NetPtrs, PipeArrays);
+PipeNetFn pipe_net_fn(int mode, bool x3) {
+  if (x3) return mode == 1 ? &k_pipe_net<1, true> : mode == 2 ? &k_pipe_net<2, true> : &k_pipe_net<0, true>;
+  return mode == 1 ? &k_pipe_net<1, false> : mode == 2 ? &k_pipe_net<2, false> : &k_pipe_net<0, false>;
+}
+int pipe_launch_net(PipeState* ps, const azmi_net_c4_view& view, int mode, uint32_t wgs, hipStream_t st, const PipeArrays& pa);
+int pipe_size_net(azmi_pm* pm, PipeState* ps, const azmi_net_c4_view& view);
+
 uint32_t pipe_tree_wgs_for(uint32_t S) {
   // tree workgroups: a slot lives in ONE workgroup for an epoch (its home), so a workgroup's 32 lane-groups serve S / workgroups
   // slots; about a third of the slots is with the net or in a ring at any time.  Every tree workgroup takes a place from the net
@@ -959,7 +973,7 @@ int pipe_create(azmi_pm* pm, size_t tile_lds) {
   struct Guard { PipeState* p; ~Guard() { if (p) pipe_state_free(p); } } guard{ps};     // (a failed set-up leaves nothing half-built behind)
   PipeArrays& pa = ps->pa;
   const uint32_t S = pm->ep.S;
-  ps->tree_wgs = pipe_tree_wgs_for(S);
+  ps->tree_wgs = ps->tree_wgs_default = pipe_tree_wgs_for(S);
   pa.n_tree_wgs = ps->tree_wgs;
   // the tree side may grow or shrink between calls with the share of leaves that reach the net (pipe_balance): unless the count was
   // fixed by hand, rings exist for 1.5 x the default and are sized for a third of it
@@ -1000,25 +1014,47 @@ int pipe_create(azmi_pm* pm, size_t tile_lds) {
   // 3-request window (the 3-board tile: 39 us instead of 60 alone - with 4096 slots a slot's wait for its answer is what is short)
   pa.big_at = getenv("AZMI_PIPE_BIG_AT") ? static_cast<uint32_t>(std::max(0, atoi(getenv("AZMI_PIPE_BIG_AT")))) : 48u;
   pa.take_wait = getenv("AZMI_PIPE_TAKE_WAIT") ? static_cast<uint32_t>(std::max(0, atoi(getenv("AZMI_PIPE_TAKE_WAIT")))) : 0u;
-  ps->lds_bytes = tile_lds + kPipeXs;
-  // Net workgroups: what the chip holds beside the tree workgroups.  First guess = the runtime's own occupancy answer for the net
-  // kernel (workgroups per CU at its registers and LDS) x CUs - tree workgroups (a tree workgroup takes a net workgroup's place);
-  // pipe_calibrate then MEASURES it with the two kernels themselves before the first epoch (a persistent kernel only works when
-  // every workgroup is resident, and how the dispatcher deals workgroups to shader engines is nothing this code may assume).
-  hipDeviceProp_t prop;
-  AZMI_HIP_TRY(hipGetDeviceProperties(&prop, pm->device));
-  int per_cu = 0;
-  AZMI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_net<0>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ps->lds_bytes)));
-  AZMI_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_pipe_net<0>), 256, ps->lds_bytes));
-  const uint32_t places_total = static_cast<uint32_t>(std::max(1, per_cu)) * static_cast<uint32_t>(prop.multiProcessorCount);
-  uint32_t net = places_total > ps->tree_wgs ? places_total - ps->tree_wgs : 1u;
-  if (const char* e = getenv("AZMI_PIPE_NET_WGS")) net = static_cast<uint32_t>(atoi(e));
-  ps->net_wgs = std::max<uint32_t>(1u, net);
+  (void)tile_lds;
   AZMI_HIP_TRY(hipStreamCreateWithFlags(&ps->net_stream, hipStreamNonBlocking));
   AZMI_HIP_TRY(hipEventCreateWithFlags(&ps->ev_go, hipEventDisableTiming));
   AZMI_HIP_TRY(hipEventCreateWithFlags(&ps->ev_net, hipEventDisableTiming));
   guard.p = nullptr;
   pm->pipe = ps;       // owned by the engine from here on (freed with it)
+  return AZMI_OK;
+}
+
+// The net side for THIS net: LDS per workgroup (bf16: the 6-board tile, two workgroups per CU; bf16x3: its 16-plane tile, one per CU)
+// and the first guess of the workgroup count = the runtime's own occupancy answer x CUs - an UPPER bound; pipe_calibrate then measures
+// what really runs beside the tree workgroups (a persistent kernel only works when every workgroup is resident, and how the dispatcher
+// deals workgroups to shader engines is nothing this code may assume).  Called again when a call brings a net of the other tier.
+int pipe_size_net(azmi_pm* pm, PipeState* ps, const azmi_net_c4_view& view) {
+  const bool x3 = view.x3 != 0;
+  if (ps->sized && ps->x3 == x3) return AZMI_OK;
+  ps->x3 = x3;
+  ps->lds_bytes = (x3 ? azmi_net_dev::c4::TileBigX3::LDS_BYTES : azmi_net_dev::c4::TileBig::LDS_BYTES) + kPipeXs;
+  for (int mode = 0; mode < 3; ++mode)
+    AZMI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pipe_net_fn(mode, x3)), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ps->lds_bytes)));
+  hipDeviceProp_t prop;
+  AZMI_HIP_TRY(hipGetDeviceProperties(&prop, pm->device));
+  int per_cu = 0;
+  AZMI_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(pipe_net_fn(0, x3)), 256, ps->lds_bytes));
+  uint32_t net = static_cast<uint32_t>(std::max(1, per_cu)) * static_cast<uint32_t>(prop.multiProcessorCount);
+  if (const char* e = getenv("AZMI_PIPE_NET_WGS")) net = static_cast<uint32_t>(atoi(e));
+  ps->net_wgs = std::max<uint32_t>(1u, net);
+  ps->calibrated = false;
+  ps->places = 0;
+  ps->sized = true;
+  // the bf16x3 tiles cost three times the matrix work and get one workgroup per CU: the net side is what is short, and every tree
+  // wavefront beside a tile slows it - half the tree workgroups (M simulations/s at 128 / 96 / 64: 27.7 / 33.4 / 36.2)
+  if (ps->balance) {
+    ps->tree_wgs = x3 ? std::max(ps->tree_wgs_min, ps->tree_wgs_default / 2u) : ps->tree_wgs_default;
+    ps->pa.n_tree_wgs = ps->tree_wgs;
+  }
+  return AZMI_OK;
+}
+int pipe_launch_net(PipeState* ps, const azmi_net_c4_view& view, int mode, uint32_t wgs, hipStream_t st, const PipeArrays& pa) {
+  pipe_net_fn(mode, ps->x3)<<<wgs, 256, ps->lds_bytes, st>>>(view.nd, view.np, pa);
+  AZMI_HIP_TRY(hipGetLastError());
   return AZMI_OK;
 }
 
@@ -1064,8 +1100,7 @@ int pipe_calibrate(azmi_pm* pm, PipeState* ps, hipStream_t st, const azmi_net_c4
     AZMI_HIP_TRY(hipStreamWaitEvent(ps->net_stream, ps->ev_go, 0));
     k_pipe_tree<Connect4, 256, false><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
     AZMI_HIP_TRY(hipGetLastError());
-    k_pipe_net<0><<<ps->net_wgs, 256, ps->lds_bytes, ps->net_stream>>>(view.nd, view.np, pa);
-    AZMI_HIP_TRY(hipGetLastError());
+    { const int rc = pipe_launch_net(ps, view, 0, ps->net_wgs, ps->net_stream, pa); if (rc != AZMI_OK) return rc; }
     AZMI_HIP_TRY(hipEventRecord(ps->ev_net, ps->net_stream));
     AZMI_HIP_TRY(hipStreamWaitEvent(st, ps->ev_net, 0));
     PipeEpoch he;
@@ -1073,7 +1108,7 @@ int pipe_calibrate(azmi_pm* pm, PipeState* ps, hipStream_t st, const azmi_net_c4
     AZMI_HIP_TRY(hipStreamSynchronize(st));
     ps->calib_rounds = static_cast<uint32_t>(attempt) + 1u;
     const uint32_t late = he.tree_late_n + he.net_late_n;
-    if (late == 0u && he.tree_arrived == ps->tree_wgs && he.net_arrived == ps->net_wgs) { ps->calibrated = true; ps->places = ps->tree_wgs + ps->net_wgs; return AZMI_OK; }
+    if (late == 0u && he.tree_arrived == ps->tree_wgs && he.net_arrived == ps->net_wgs) { ps->calibrated = true; ps->places = ps->x3 ? 0u : ps->tree_wgs + ps->net_wgs; return AZMI_OK; }
     if (ps->net_wgs <= 1u) break;
     ps->net_wgs = ps->net_wgs > late + 1u ? ps->net_wgs - std::max<uint32_t>(late, 1u) : 1u;
   }
@@ -1155,12 +1190,7 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
   PipeState* ps = pm->pipe;
   PipeArrays& pa = ps->pa;
   if (!tree_only) { const int rc = pipe_pair_streams(ps, st); if (rc != AZMI_OK) return rc; }
-  if (!tree_only && !ps->lds_set) {
-    AZMI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_net<0>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ps->lds_bytes)));
-    AZMI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_net<1>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ps->lds_bytes)));
-    AZMI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_net<2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ps->lds_bytes)));
-    ps->lds_set = true;
-  }
+  if (!tree_only) { const int rc = pipe_size_net(pm, ps, view); if (rc != AZMI_OK) return rc; }
   if (!tree_only) { const int rc = pipe_calibrate(pm, ps, st, view); if (rc != AZMI_OK) return rc; }
   // the insert log holds an epoch's answers: at most one per simulation, in practice a third of them
   // (the quota is checked between passes: an epoch overshoots it by what the passes under way still finish)
@@ -1223,10 +1253,8 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
     }
     if (!tree_only) {
       AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 0], ps->net_stream));
-      if (net_mode == 1) k_pipe_net<1><<<ps->net_wgs, 256, ps->lds_bytes, ps->net_stream>>>(view.nd, view.np, pa);
-      else if (net_mode == 2) k_pipe_net<2><<<ps->net_wgs, 256, ps->lds_bytes, ps->net_stream>>>(view.nd, view.np, pa);
-      else k_pipe_net<0><<<ps->net_wgs, 256, ps->lds_bytes, ps->net_stream>>>(view.nd, view.np, pa);
-      AZMI_HIP_TRY(hipGetLastError());
+      rc = pipe_launch_net(ps, view, net_mode, ps->net_wgs, ps->net_stream, pa);
+      if (rc != AZMI_OK) return rc;
       AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 1], ps->net_stream));
       AZMI_HIP_TRY(hipEventRecord(ps->ev_net, ps->net_stream));
       AZMI_HIP_TRY(hipStreamWaitEvent(st, ps->ev_net, 0));
@@ -1372,12 +1400,7 @@ extern "C" int azmi_debug_pipe_net_bench(azmi_pm* pm, azmi_net* net, uint32_t n,
   if (!pm->pipe) { const int rc = pipe_create(pm, azmi_net_dev::c4::TileBig::LDS_BYTES); if (rc != AZMI_OK) return rc; }
   PipeState* ps = pm->pipe;
   PipeArrays& pa = ps->pa;
-  if (!ps->lds_set) {
-    AZMI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_net<0>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ps->lds_bytes)));
-    AZMI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_net<1>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ps->lds_bytes)));
-    AZMI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pipe_net<2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(ps->lds_bytes)));
-    ps->lds_set = true;
-  }
+  { const int rc = pipe_size_net(pm, ps, view); if (rc != AZMI_OK) return rc; }
   pa.cap_ticks = 25000000ull;
   hipStream_t st = pm->stream;
   hipEvent_t e0, e1;
@@ -1389,9 +1412,7 @@ extern "C" int azmi_debug_pipe_net_bench(azmi_pm* pm, azmi_net* net, uint32_t n,
     k_pipe_fill<<<(n + 255) / 256, 256, 0, st>>>(pa, n, pm->ep.S, 1234 + r);
     k_pipe_fill_done<<<1, 1, 0, st>>>(pa, n);
     AZMI_HIP_TRY(hipEventRecord(e0, st));
-    if (mode == 1) k_pipe_net<1><<<wgs, 256, ps->lds_bytes, st>>>(view.nd, view.np, pa);
-    else if (mode == 2) k_pipe_net<2><<<wgs, 256, ps->lds_bytes, st>>>(view.nd, view.np, pa);
-    else k_pipe_net<0><<<wgs, 256, ps->lds_bytes, st>>>(view.nd, view.np, pa);
+    { const int rc = pipe_launch_net(ps, view, mode, wgs, st, pa); if (rc != AZMI_OK) return rc; }
     AZMI_HIP_TRY(hipEventRecord(e1, st));
     k_pipe_head_reset<<<1, 1, 0, st>>>(pa);                   // (head = tail for the next drain; the READY tokens of the synthetic answers are dropped)
     AZMI_HIP_TRY(hipStreamSynchronize(st));

@@ -848,13 +848,14 @@ def main():
                         ("cache_200k", S, 200_000, False, "same", "max_cache_size = 200000 (reference default), 800 sims on every move"),
                         ("cache_32m", S, 32_000_000, False, "same", "max_cache_size = 32 M entries (the headline's setting in rounds 1-2 and in the first half of round 3), 800 sims on every move"),
                         ("slots_16384", 16384, args.cache, False, "same", "16384 concurrent games (4 x the headline's), 800 sims on every move"),
-                        ("tier_1e5", S, 32_000_000, False, "x3", "the bf16x3 leaf net (precision='bf16x3': bf16 high + low parts of weights and activations, three MFMAs per product; "
+                        ("tier_1e5", S, args.cache, False, "x3", "the bf16x3 leaf net (precision='bf16x3': bf16 high + low parts of weights and activations, three MFMAs per product; "
                                                                     "max |delta| vs the reference NNArch's fp32 outputs 4.3e-7 on the random-init fixture, 5.4e-6 on the peaked one: the north star's 1e-5 tier), "
-                                                                    "lock-step rounds, 4 shards of 8 M cache entries (the lock-step driver does not gain from a larger cache); the plain-fp32 kernels (precision='fp32', any net shape, 7.5e-8) run this workload at 15 games/s")):
+                                                                    "on the asynchronous pipeline (round 4: k_pipe_net<.., X3>, one net workgroup per CU beside the tree workgroups; round 3: lock-step, 1384 games/s), the headline's cache size; "
+                                                                    "the plain-fp32 kernels (precision='fp32', any net shape, 7.5e-8) run this workload at 15 games/s")):
                     if os.environ.get("AZMI_BENCH_SECONDARY") and name not in os.environ["AZMI_BENCH_SECONDARY"].split(","):
                         continue
                     sys.stderr.write(f"bench.py: secondary {name} ...\n"); sys.stderr.flush()
-                    pipe2 = use_pipe and kind == "same"
+                    pipe2 = use_pipe            # (round 4: the bf16x3 tier runs on the pipeline too: k_pipe_net<.., X3>, one net workgroup per CU)
                     K2 = 1 if pipe2 else 4
                     if kind == "x3":
                         hip_f32 = az.HipLeafNet(net, spec, device=local_rank, precision="bf16x3")

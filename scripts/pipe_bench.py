@@ -10,7 +10,7 @@ S = int(os.environ.get("S", 4096)); sims = int(os.environ.get("SIMS", 800)); cac
 Q = int(os.environ.get("Q", 64)); E = int(os.environ.get("E", 300)); BLOCKS = int(os.environ.get("BLOCKS", 12)); PRE = float(os.environ.get("PRE", 1.0))
 pp = bench.selfplay_params(az, S, sims, 1 << 30, cache=cache)
 spec = torch_net.connect4_spec()
-hip = az.HipLeafNet(torch_net.random_init(spec, seed=0), spec)
+hip = az.HipLeafNet(torch_net.random_init(spec, seed=0), spec, **({"precision": os.environ["PRECISION"]} if os.environ.get("PRECISION") else {}))
 pm = az.PlayManager(az.Connect4GS(), pp, seed=20240601, history_capacity=S * 42 * 4, max_inline=int(os.environ.get('MAXI', 0)))
 st = torch.cuda.Stream()
 def tot():

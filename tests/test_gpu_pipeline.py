@@ -488,3 +488,34 @@ def test_self_play_auto_falls_back_when_the_pipeline_cannot_run(monkeypatch):
     assert res.games == 96
     with pytest.raises(RuntimeError, match="pipeline"):
         selfplay.self_play(az.Connect4GS, pp, hip, seed=5, driver="pipeline")
+
+
+def test_pipeline_runs_the_bf16x3_tier(oracle):
+    """round 4: the north star's 1e-5 tier (precision="bf16x3": bf16 high + low parts, three MFMAs per product) on the fast driver -
+    k_pipe_net<.., X3>, one net workgroup per CU (16 activation planes) beside the tree workgroups, its workgroup count measured like
+    the bf16 kernel's.  The games are the lock-step engine's with the same net, and the oracle's driven by that net."""
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=23), spec, precision="bf16x3")
+    S, seed = 144, 808
+    pp = _selfplay_params(az, S, 90, cache=1 << 14)
+    pm0 = az.PlayManager(az.Connect4GS(), pp, seed=seed)
+    assert az.pipeline_supported(pm0, hip)
+    del pm0
+    pa, (ra, ca), stats = _pipeline_games(az, pp, seed, hip, sims_per_epoch=S * 40)
+    assert stats["tiles"] > 0 and stats["net_wgs_started"] == stats["net_wgs"] and stats["calibration_rounds"] >= 1
+    pb, (rb, cb) = _lockstep_games(az, pp, seed, hip)
+    assert pa.games_completed() == pb.games_completed() == S
+    sa, sb = _sorted_log(ra, ca), _sorted_log(rb, cb)
+    assert np.array_equal(sa[0], sb[0]) and np.array_equal(sa[1], sb[1])
+    n = _check_slots(az, oracle, oracle.GAME_CONNECT4, pp, seed, ra, ca, (0, 5, 143), evaluator=_net_eval(hip))
+    assert n > 20
+    # one engine, two tiers: a bf16 net on the same engine re-sizes and re-measures the net side
+    hip16 = az.HipLeafNet(torch_net.random_init(spec, seed=23), spec)
+    pp2 = _selfplay_params(az, 64, 40, cache=0)
+    pm2 = az.PlayManager(az.Connect4GS(), pp2, seed=3)
+    st = torch.cuda.Stream()
+    a = az.run_pipeline(pm2, hip, 1, 64 * 16, st.cuda_stream)
+    b = az.run_pipeline(pm2, hip16, 1, 64 * 16, st.cuda_stream)
+    assert a["net_wgs_started"] == a["net_wgs"] and b["net_wgs_started"] == b["net_wgs"] and b["net_wgs"] >= a["net_wgs"]
