@@ -1628,7 +1628,7 @@ def run_pipeline(pm, net, epochs, sims_per_epoch, stream=None):
     out = (C.c_uint64 * 16)()
     check(lib.azmi_run_pipeline(pm._h, None if net is None else net._h, int(epochs), int(sims_per_epoch), st, out))
     keys = ("tiles", "tile_boards", "last_epoch_sims", "tree_wgs_started", "net_wgs_started", "last_epoch_inserts", "net_wgs", "tree_wgs",
-            "tree_latest_start_us", "net_latest_start_us", "net_kernel_us", "tree_kernel_us", "epochs", "host_enqueue_us", "calibration_rounds")
+            "tree_latest_start_us", "net_latest_start_us", "net_kernel_us", "tree_kernel_us", "epochs", "host_enqueue_us", "calibration_rounds", "answer_table_hits")
     return dict(zip(keys, (int(x) for x in out)))
 
 

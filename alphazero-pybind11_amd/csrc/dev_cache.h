@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "dev_rng.h"
 
 namespace azmi {
@@ -380,18 +382,24 @@ __device__ inline bool wave_shard_insert_locked(const CacheView& c, uint32_t* lo
 
 // find on a wave shard by a group of `G` cooperating lanes (G divides 64): each lane checks 64/G slots.
 // Returns the slot or -1 (uniform over the group).  Accounting as in cache_find_account.
-template <int G>
-__device__ __forceinline__ int wave_shard_find(const CacheView& c, uint64_t hash, uint32_t glane, uint32_t* shard_out) {
+struct NoPreload { __device__ __forceinline__ void operator()() const {} };
+// `before_loads` runs once the shard is known, right in front of the key loads: loads it issues travel with them (one round trip)
+template <int G, class F = NoPreload>
+__device__ __forceinline__ int wave_shard_find(const CacheView& c, uint64_t hash, uint32_t glane, uint32_t* shard_out, F&& before_loads = F()) {
   const uint64_t k = cache_key(hash);
   const uint32_t sh = static_cast<uint32_t>(hash % c.shards);
   *shard_out = sh;
   const uint64_t* hs = c.hashes + static_cast<size_t>(sh) * kWaveCap;
+  // all of the lane's key loads are issued, then the caller's preloads (they return behind the keys: one round trip for both), then
+  // the compares
+  uint64_t hv[kWaveCap / G];
+#pragma unroll
+  for (int i = 0; i < static_cast<int>(kWaveCap) / G; ++i) hv[i] = hs[i * G + static_cast<int>(glane)];
+  before_loads();
   int found = -1;
 #pragma unroll
-  for (int i = 0; i < static_cast<int>(kWaveCap) / G; ++i) {
-    const int slot = i * G + static_cast<int>(glane);
-    if (hs[slot] == k) found = slot;
-  }
+  for (int i = 0; i < static_cast<int>(kWaveCap) / G; ++i)
+    if (hv[i] == k) found = i * G + static_cast<int>(glane);
   if constexpr (G == 8) {   // DPP moves instead of LDS-routed shuffles: xor 1, xor 2 inside quads, then the half-row mirror
     found = max(found, __builtin_amdgcn_update_dpp(0, found, 0xB1, 0xF, 0xF, true));
     found = max(found, __builtin_amdgcn_update_dpp(0, found, 0x4E, 0xF, 0xF, true));

@@ -180,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void k_net_move(azmi_net_dev::NetDesc nd, a
 }  // namespace
 // the two between-epoch steps of the asynchronous pipeline (pipeline.hip): the move step of a split round over the slots the
 // tree side listed, as a launch of its own, and the restart / retire bookkeeping
+unsigned long long azmi_host_pipe_l0_hits(azmi_pm* pm, hipStream_t st);    // pipeline.hip
 int azmi_host_launch_move_step(azmi_pm* pm, hipStream_t st) {
   const uint32_t blocks = (pm->ep.S * Connect4::GROUP + 255u) / 256u;
   k_round<Connect4, false, true><<<blocks, 256, 0, st>>>(pm->ep, pm->ar);
@@ -1457,6 +1458,9 @@ int azmi_pm_cache_stats(azmi_pm* pm, uint64_t out[6]) {
     }
     out[5] += static_cast<uint64_t>(c.cap) * c.shards;
   }
+  // the pipeline's in-epoch answer table answers probes the S3-FIFO shard counted as misses (pipe_types.h)
+  const unsigned long long l0 = azmi_host_pipe_l0_hits(pm, pm->last);
+  out[0] += l0; out[1] -= std::min<uint64_t>(out[1], l0);
   return AZMI_OK;
 }
 

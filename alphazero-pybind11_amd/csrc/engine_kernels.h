@@ -1210,10 +1210,12 @@ struct SlotCtx {
   }
   // position-cache probe (play_manager.cc:592-597): on a hit the cached (pi, v) land in the slot's rows AND in
   // registers (lane m: pi[m] in hit_pi, lane i <= P: v[i] in hit_v) for a process_result later in this round
-  __device__ __forceinline__ bool cache_lookup(uint64_t key, uint32_t group, float& hit_pi, float& hit_v) const {
+  // (before_loads: see wave_shard_find - the pipeline asks for its in-epoch answer table's granules there)
+  template <class F = NoPreload>
+  __device__ __forceinline__ bool cache_lookup(uint64_t key, uint32_t group, float& hit_pi, float& hit_v, F&& before_loads = F()) const {
     uint32_t sh;
     const CacheView cache = ep.num_groups == 1 ? ar.cache : ar.caches[group];   // one cache per model group
-    const int cslot = wave_shard_find<G>(cache, key, lane, &sh);
+    const int cslot = wave_shard_find<G>(cache, key, lane, &sh, before_loads);
     if (lane == 0) {  // hits / misses / freq; the ghost "reinserts" statistic is not kept for in-round probes
       unsigned long long* st = cache.stats + static_cast<size_t>(sh) * 4;
       if (cslot < 0) {

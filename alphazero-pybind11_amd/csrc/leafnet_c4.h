@@ -160,7 +160,17 @@ struct PipeIO {
   const uint32_t* slot;
   const uint32_t* seq;
   uint32_t stride, v_first;
+  // in-epoch answer table (pipe_types.h): every output entry also goes to l0[l0_entry[b] * stride + k] as {l0_tag(key[b], k) | float bits};
+  // l0 == nullptr: off.  l0_entry / key live in LDS beside slot / seq.
+  unsigned long long* l0;
+  const uint32_t* l0_entry;
+  const unsigned long long* key;
 };
+__device__ __forceinline__ uint32_t pipe_io_tag(unsigned long long key, uint32_t k) {     // = pipe_l0_tag (pipe_types.h)
+  unsigned long long x = key + 0x9E3779B97F4A7C15ULL * (k + 1u);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 27; x *= 0x94D049BB133111EBULL; x ^= x >> 31;
+  return static_cast<uint32_t>(x >> 32) | 1u;
+}
 template <class TG, int CIN, int MAXP1, int MAXM, int DBG = 0, bool PIPE = false>
 __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const float* __restrict__ canon,
                                      float* __restrict__ v_out, float* __restrict__ pi_out, uint32_t batch,
@@ -679,9 +689,14 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
       const float pr = expf(lg[idx] - mx) / sum;
       if constexpr (PIPE) {
         const uint32_t sl = pio->slot[b];
-        if (sl != 0xFFFFFFFFu)
-          __hip_atomic_store(pio->res + static_cast<size_t>(sl) * pio->stride + (is_v ? pio->v_first + idx : idx),
+        if (sl != 0xFFFFFFFFu) {
+          const uint32_t gk = is_v ? pio->v_first + idx : idx;
+          __hip_atomic_store(pio->res + static_cast<size_t>(sl) * pio->stride + gk,
                              (static_cast<unsigned long long>(pio->seq[b]) << 32) | __float_as_uint(pr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (pio->l0)
+            __hip_atomic_store(pio->l0 + static_cast<size_t>(pio->l0_entry[b]) * pio->stride + gk,
+                               (static_cast<unsigned long long>(pipe_io_tag(pio->key[b], gk)) << 32) | __float_as_uint(pr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       } else {
         if (is_v) v_out[static_cast<size_t>(out_row) * P1 + idx] = pr;
         else pi_out[static_cast<size_t>(out_row) * M + idx] = pr;

@@ -41,6 +41,10 @@ enum PipeErr : uint32_t { kPipeErrTimeout = 1, kPipeErrRing = 2, kPipeErrTag = 4
 
 __host__ __device__ inline uint64_t pipe_lap_tag(uint32_t pos) { return static_cast<uint64_t>(((pos / kPipeRing) & 0x7FFFu) + 1u); }
 // the per-workgroup READY rings have 1 << shift entries
+// in-epoch answer table: entry of a key, tag of granule k of that key's entry (splitmix finaliser; k + 1 keeps granule 0's tag apart from the index)
+__host__ __device__ inline uint64_t pipe_mix64(uint64_t x) { x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 27; x *= 0x94D049BB133111EBULL; x ^= x >> 31; return x; }
+__host__ __device__ inline uint32_t pipe_l0_entry(uint64_t key, uint32_t mask) { return static_cast<uint32_t>(pipe_mix64(key ^ 0x5851F42D4C957F2DULL)) & mask; }
+__host__ __device__ inline uint32_t pipe_l0_tag(uint64_t key, uint32_t k) { return static_cast<uint32_t>(pipe_mix64(key + 0x9E3779B97F4A7C15ULL * (k + 1u)) >> 32) | 1u; }
 __host__ __device__ inline uint64_t pipe_lap_tag_r(uint32_t pos, uint32_t shift) { return static_cast<uint64_t>(((pos >> shift) & 0x7FFFu) + 1u); }
 constexpr unsigned long long kTokMove = 0x8000ull;     // token: the slot's next step is the move step's (a game start, the simulation that completes a search)
 constexpr unsigned long long kTokSlotMask = 0x7FFFull;
@@ -62,7 +66,8 @@ struct PipeCtl {          // zeroed when the pipeline is created; lives across e
   unsigned long long tile_boards;   // boards in them
   unsigned long long epochs;
   unsigned long long sims_total;    // simulations of all epochs so far (k_pipe_settle adds an epoch's count)
-  uint32_t dbg[22];       // diagnostics of the first time-out: slot, sequence number, group state, the tags seen
+  unsigned long long l0_hits;       // probes the S3-FIFO missed and the in-epoch answer table answered
+  uint32_t dbg[20];       // diagnostics of the first time-out: slot, sequence number, group state, the tags seen
   // tree-side time accounting (100 MHz ticks / counts, summed over wavefronts): [0] in simulation passes, [1] polling with no
   // group ready, [2] passes, [3] groups active in them, [4] polls, [5] in the request step, [6] wavefront lifetimes, [7] net: ticks
   // waiting for requests, [8] net: ticks in tiles
@@ -100,6 +105,12 @@ struct PipeArrays {
   uint32_t max_inline;        // simulations a group may finish in one pass without the net (cache hits, terminal leaves) before its slot re-queues
   uint32_t min_active;        // ... and a pass ends early once fewer than this many of its eight groups are still running (the others idle meanwhile)
   unsigned long long* res;    // [S][kResStride]
+  // in-epoch answer table (round 4): a direct-mapped table of self-validating granules {tag32(key, k) | float bits}, entry =
+  // mix64(key) & l0_mask, written by the NET workgroup the moment it has an answer (the reference inserts at update_inferences time,
+  // play_manager.cc:631-640; the S3-FIFO insert proper waits for the epoch boundary) and probed by the tree side beside the S3-FIFO
+  // shard.  No lock, no ordering: a reader accepts an entry only when all ten granules carry the tag of ITS key.  NULL = off.
+  unsigned long long* l0;     // [l0_mask + 1][kResStride]
+  uint32_t l0_mask;
   // insert log: (key, pi, v) of every answer consumed in the epoch; applied to the position cache between epochs
   uint64_t* ins_key;          // [ins_cap]
   float* ins_pi;              // [ins_cap][M]
@@ -109,7 +120,8 @@ struct PipeArrays {
   uint32_t n_tree_wgs;
   unsigned long long quota;       // simulations per epoch
   uint32_t idle_num;              // the epoch also ends when `ended` reaches idle_num / 1024 of the slots that have a game
-  unsigned long long cap_ticks;   // hard time cap of an epoch in 100 MHz ticks
+  unsigned long long cap_ticks;   // hard time cap of an epoch in 100 MHz ticks (a stall detector: an error)
+  unsigned long long soft_ticks;  // an epoch that has run this long ends like one that reached its quota
 };
 
 }  // namespace azmi

@@ -183,11 +183,11 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
   if (pa.census_hold != 0u) {
     // calibration launch (pipe_calibrate): hold the place until census_hold ticks after the epoch's first workgroup started, do
     // nothing else.  A workgroup the chip had no place for starts when the others have left: it finds itself late and is counted.
-    if (threadIdx.x == 0) {
-      const unsigned long long t0 = g_ld(&pe->t0);
-      if (t_start > t0 && t_start - t0 >= pa.census_hold) atomicAdd(&pe->tree_late_n, 1u);
-      while (wall_clock64() < t0 + pa.census_hold) __builtin_amdgcn_s_sleep(32);
-    }
+    // (EVERY wavefront holds: a wavefront that ends gives its registers back, and a workgroup of one live wavefront would let a
+    // third workgroup onto the CU - the measurement would admit more than an epoch can hold)
+    const unsigned long long t0 = g_ld(&pe->t0);
+    if (threadIdx.x == 0 && t_start > t0 && t_start - t0 >= pa.census_hold) atomicAdd(&pe->tree_late_n, 1u);
+    while (wall_clock64() < t0 + pa.census_hold) __builtin_amdgcn_s_sleep(32);
     return;
   }
   bool go = g_ld(&ar.ctl->stop) == 0 && g_ld(&pc->err) == 0 && g_ld(&pe->stop) == 0;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
       const uint64_t now = wall_clock64();
       // an epoch that runs long (a cold cache sends every leaf to the net: 16384 slots x 256 simulations take > 200 ms then) simply
       // ends at a quarter of the cap; the cap itself is the stall detector
-      if (now - t_start > pa.cap_ticks / 4u) stop_seen = 1u;
+      if (now - t_start > pa.soft_ticks) stop_seen = 1u;
       if (now - t_start > pa.cap_ticks) {
         if (wlane == 0) { atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTimeout)); pc->dbg[16] = __builtin_amdgcn_readlane(ctl_word, 23); pc->dbg[17] = __builtin_amdgcn_readlane(ctl_word, 31); }
         stop_seen = 1u;
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
     uint32_t fl_node = 0xFFFFFFFFu, fl_mv = 0;
     uint64_t fl_meta = 0;
     float fl_pr = 0.0f;
-    uint32_t sims_done = 0, sims_mem = 0;
+    uint32_t sims_done = 0, sims_mem = 0, l0_hits = 0;
     bool rec_ok = true, answered = false;
     uint64_t cur_key = 0;
     if (on) {
@@ -538,7 +538,31 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
         c.flags = needs_net ? (c.flags | kFlagLeafNeedsNet) : (c.flags & ~kFlagLeafNeedsNet);
         if (needs_net) {
           const uint64_t key = GM::key(leaf);
-          const bool hit = ep.cache_on && c.cache_lookup(key, 0u, reg_pi, reg_v);
+          // the in-epoch answer table's granules are asked for first and land with the S3-FIFO shard's keys: no extra round trip
+          // (issued inside the lookup, once the shard is known and right in front of its key loads: the two travel together)
+          unsigned long long l0a = 0, l0b = 0;
+          const unsigned long long* const le = pa.l0 + static_cast<size_t>(pipe_l0_entry(key, pa.l0_mask)) * kResStride;
+          bool hit = ep.cache_on && c.cache_lookup(key, 0u, reg_pi, reg_v, [&]() {
+            if (pa.l0) {
+              if (lane < static_cast<uint32_t>(GM::M)) l0a = g_ld(le + lane);
+              if (lane <= static_cast<uint32_t>(P)) l0b = g_ld(le + kResV + lane);
+            }
+          });
+          if (ep.cache_on && pa.l0 && !hit) {
+            // an answer of THIS epoch (the S3-FIFO gets it at the boundary): valid only when all ten granules carry this key's tags
+            uint32_t okg = ((lane >= static_cast<uint32_t>(GM::M) || static_cast<uint32_t>(l0a >> 32) == pipe_l0_tag(key, lane)) &&
+                            (lane > static_cast<uint32_t>(P) || static_cast<uint32_t>(l0b >> 32) == pipe_l0_tag(key, kResV + lane))) ? 1u : 0u;
+            okg &= c.bcast(okg, 0) & c.bcast(okg, 1) & c.bcast(okg, 2) & c.bcast(okg, 3) & c.bcast(okg, 4) & c.bcast(okg, 5) & c.bcast(okg, 6);
+            okg = c.bcast(okg, 0);
+            if (okg) {
+              reg_pi = lane < static_cast<uint32_t>(GM::M) ? __uint_as_float(static_cast<uint32_t>(l0a)) : 0.0f;
+              reg_v = lane <= static_cast<uint32_t>(P) ? __uint_as_float(static_cast<uint32_t>(l0b)) : 0.0f;
+              if (lane < static_cast<uint32_t>(GM::M)) ar.pi[static_cast<size_t>(slot) * GM::M + lane] = reg_pi;
+              if (lane <= static_cast<uint32_t>(P)) ar.v[static_cast<size_t>(slot) * (P + 1) + lane] = reg_v;
+              l0_hits += 1;
+              hit = true;
+            }
+          }
           if (!hit) {
             // the request goes out NOW, not when the pass ends (its slowest group may run two more simulations): the net's
             // answer and this pass's tail overlap.  Nobody can take the slot before it is back: see the pass start.
@@ -615,6 +639,12 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
       if (wlane == 0 && x) atomicAdd(&pe->sims, static_cast<unsigned long long>(x));
+      if (pa.l0) {
+        uint32_t y = lane == 0 ? l0_hits : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) y += __shfl_xor(y, off, 64);
+        if (wlane == 0 && y) atomicAdd(&pc->l0_hits, static_cast<unsigned long long>(y));
+      }
       const unsigned long long fm = __ballot(on && lane == 0 && final_state == kSlotDone);
       if (wlane == 0 && fm) atomicAdd(&pe->dead, static_cast<uint32_t>(__popcll(fm)));
     }
@@ -680,12 +710,14 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
     if (t0 == 0ull) t0 = t_start;
     atomicMax(&pe->net_late, static_cast<uint32_t>(t_start > t0 ? t_start - t0 : 0ull));
     atomicAdd(&pe->net_arrived, 1u);
-    if (pa.census_hold != 0u) {      // calibration launch: see k_pipe_tree
-      if (t_start > t0 && t_start - t0 >= pa.census_hold) atomicAdd(&pe->net_late_n, 1u);
-      while (wall_clock64() < t0 + pa.census_hold) __builtin_amdgcn_s_sleep(32);
-    }
+    if (pa.census_hold != 0u && t_start > t0 && t_start - t0 >= pa.census_hold) atomicAdd(&pe->net_late_n, 1u);      // calibration launch: see k_pipe_tree
   }
-  if (pa.census_hold != 0u) return;
+  if (pa.census_hold != 0u) {
+    __syncthreads();
+    const unsigned long long t0 = g_ld(&pe->t0);
+    while (wall_clock64() < t0 + pa.census_hold) __builtin_amdgcn_s_sleep(32);
+    return;
+  }
   // The workgroup's WINDOW: kMaxTake consecutive ring positions drawn with ONE fetch-add on `head` (a compare-and-swap claim
   // of "what is there" serialises every workgroup of the chip on one word: a claim then costs a memory round trip per
   // contender).  The window's positions are this workgroup's to serve, whenever their requests arrive: it waits until the
@@ -758,6 +790,12 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
         xs[8 + tid] = mine ? sl : 0xFFFFFFFFu; xs[16 + tid] = sq; xs[24 + tid] = pl;
         unsigned long long* xb = reinterpret_cast<unsigned long long*>(xs + 32);
         xb[tid] = mine ? b0 : 0ull; xb[8 + tid] = mine ? b1 : 0ull;
+        if (pa.l0) {       // the position's cache key (Connect4::key: stones and the player to move) for the in-epoch answer table
+          Connect4::State ps_; ps_.bb[0] = b0; ps_.bb[1] = b1; ps_.player = pl; ps_.turn = 0;
+          const unsigned long long k64 = Connect4::key(ps_);
+          xb[16 + tid] = k64;
+          xs[96 + tid] = pipe_l0_entry(k64, pa.l0_mask);
+        }
       }
       if (tid == 0) xs[0] = n;
       wdone += n;
@@ -768,7 +806,7 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
     if (n == 0) break;
     if (tid == 0) { atomicAdd(&pc->tiles, 1ull); atomicAdd(&pc->tile_boards, static_cast<unsigned long long>(n)); }
     __syncthreads();
-    c4::PipeIO pio{pa.res, xs + 8, xs + 16, kResStride, kResV};
+    c4::PipeIO pio{pa.res, xs + 8, xs + 16, kResStride, kResV, pa.l0, xs + 96, reinterpret_cast<const unsigned long long*>(xs + 32) + 16};
     // the weight pointers are made opaque per pass: otherwise the tile's loads of its (pass-invariant) head weights are
     // hoisted out of this loop and sit in ~120 registers for the whole tile (spills)
     NetPtrs npi = np;
@@ -1207,6 +1245,17 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
     const int rc = pipe_alloc(ps, pa.locks, pm->ar.cache.shards);
     if (rc != AZMI_OK) return rc;
   }
+  if (pm->ep.cache_on && !pa.l0 && !tree_only && getenv("AZMI_PIPE_NO_L0") == nullptr) {
+    // the in-epoch answer table: a power of two of 128-byte entries, an eighth of the S3-FIFO's entries, between 4 Ki and 4 Mi
+    // (512 MB: an epoch of the headline brings ~200 k answers)
+    uint64_t want = static_cast<uint64_t>(pm->ar.cache.shards) * kWaveCap / 8u;
+    uint32_t sh = 12;
+    while (sh < 22u && (1ull << sh) < want) ++sh;
+    if (const char* e = getenv("AZMI_PIPE_L0_LOG2")) sh = static_cast<uint32_t>(std::min(26, std::max(4, atoi(e))));
+    const int rc = pipe_alloc(ps, pa.l0, (static_cast<size_t>(1) << sh) * kResStride);
+    if (rc != AZMI_OK) return rc;
+    pa.l0_mask = (1u << sh) - 1u;
+  }
   // an epoch must end long before the wall-clock cap (a stall detector, 250 ms): with the move step inside the epoch nothing else ends it,
   // so the quota is held to 1024 simulations per slot (~50 ms at the slowest per-slot rate measured)
   pa.quota = std::min<uint64_t>(sims_per_epoch, 1024ull * pm->ep.S);
@@ -1217,6 +1266,9 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
   double cap_ms = 250.0;
   if (const char* e = getenv("AZMI_PIPE_CAP_MS")) cap_ms = atof(e);
   pa.cap_ticks = static_cast<unsigned long long>(cap_ms * 1e5);
+  // (an epoch that runs long simply ends at a quarter of the cap; AZMI_PIPE_SOFT_MS sets another limit - the error-path test asks for
+  // one beyond the cap)
+  pa.soft_ticks = getenv("AZMI_PIPE_SOFT_MS") ? static_cast<unsigned long long>(atof(getenv("AZMI_PIPE_SOFT_MS")) * 1e5) : pa.cap_ticks / 4u;
   // the lock-step kernels leave the key of a round's leaf in cache_keys for the next round's insert: none of that here
   if (pm->ep.cache_on) AZMI_HIP_TRY(hipMemsetAsync(pm->ar.cache_keys, 0, sizeof(uint64_t) * pm->ep.S, st));
   int rc = azmi_host_launch_assign(pm, st, 1u);
@@ -1301,7 +1353,7 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
       if (!tree_only && hipEventElapsedTime(&ms, ps->tev[4 * e + 0], ps->tev[4 * e + 1]) == hipSuccess) net_us += 1e3 * ms;
       if (hipEventElapsedTime(&ms, ps->tev[4 * e + 2], ps->tev[4 * e + 3]) == hipSuccess) tree_us += 1e3 * ms;
     }
-    out_stats[10] = static_cast<uint64_t>(net_us); out_stats[11] = static_cast<uint64_t>(tree_us); out_stats[12] = epochs; out_stats[13] = host_enqueue_us; out_stats[14] = ps->calib_rounds;
+    out_stats[10] = static_cast<uint64_t>(net_us); out_stats[11] = static_cast<uint64_t>(tree_us); out_stats[12] = epochs; out_stats[13] = host_enqueue_us; out_stats[14] = ps->calib_rounds; out_stats[15] = hc.l0_hits;
     if (getenv("AZMI_PIPE_PROF")) {
       fprintf(stderr, "pipe prof:");
       for (int i = 0; i < 16; ++i) fprintf(stderr, " %llu", hc.prof[i]);
@@ -1310,7 +1362,7 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
   }
   if (hc.err) {
     fprintf(stderr, "pipeline dbg:");
-    for (int i = 0; i < 22; ++i) fprintf(stderr, " %u", hc.dbg[i]);
+    for (int i = 0; i < 20; ++i) fprintf(stderr, " %u", hc.dbg[i]);
     fprintf(stderr, "\n");
   }
   if (hc.err) {
@@ -1328,10 +1380,18 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
                           he.tree_done, hc.tiles, hc.tile_boards, he.tree_late / 100u, he.net_late / 100u);
   if (hc.err && getenv("AZMI_PIPE_DEBUG")) {
     fprintf(stderr, "pipeline dbg:");
-    for (int i = 0; i < 22; ++i) fprintf(stderr, " %u", hc.dbg[i]);
+    for (int i = 0; i < 20; ++i) fprintf(stderr, " %u", hc.dbg[i]);
     fprintf(stderr, "\n");
   }
   return AZMI_OK;
+}
+
+// probes the S3-FIFO missed and the in-epoch answer table answered (azmi_pm_cache_stats moves them from misses to hits)
+unsigned long long azmi_host_pipe_l0_hits(azmi_pm* pm, hipStream_t st) {
+  if (!pm->pipe || !pm->pipe->pa.l0) return 0ull;
+  unsigned long long v = 0;
+  if (hipMemcpyAsync(&v, &pm->pipe->pa.ctl->l0_hits, sizeof(v), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return 0ull;
+  return v;
 }
 
 // ---- diagnostics: how many of the last epoch's answers were asked for more than once --------------------------------------------

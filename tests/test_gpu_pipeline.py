@@ -447,6 +447,7 @@ def test_a_pipeline_error_is_reported_once_and_the_engine_stays_usable(monkeypat
     st = torch.cuda.Stream()
     az.run_pipeline(pm, hip, 2, S * 16, st.cuda_stream)
     monkeypatch.setenv("AZMI_PIPE_CAP_MS", "0.02")
+    monkeypatch.setenv("AZMI_PIPE_SOFT_MS", "1000")        # (an epoch normally ends at a quarter of the cap, before it can trip)
     failures = 0
     for _ in range(3):
         try:
@@ -455,6 +456,7 @@ def test_a_pipeline_error_is_reported_once_and_the_engine_stays_usable(monkeypat
             assert "pipeline error mask" in str(e)
             failures += 1
     monkeypatch.delenv("AZMI_PIPE_CAP_MS")
+    monkeypatch.delenv("AZMI_PIPE_SOFT_MS")
     assert failures >= 1
     turn = 0
     while pm.remaining_games() > 0 and turn < 20000:
@@ -484,6 +486,7 @@ def test_self_play_auto_falls_back_when_the_pipeline_cannot_run(monkeypatch):
     pp = _selfplay_params(az, 64, 40, cache=1 << 12)
     pp.games_to_play = 96
     monkeypatch.setenv("AZMI_PIPE_CAP_MS", "0.001")
+    monkeypatch.setenv("AZMI_PIPE_SOFT_MS", "1000")
     res, _ = selfplay.self_play(az.Connect4GS, pp, hip, seed=5)
     assert res.games == 96
     with pytest.raises(RuntimeError, match="pipeline"):
@@ -519,3 +522,30 @@ def test_pipeline_runs_the_bf16x3_tier(oracle):
     a = az.run_pipeline(pm2, hip, 1, 64 * 16, st.cuda_stream)
     b = az.run_pipeline(pm2, hip16, 1, 64 * 16, st.cuda_stream)
     assert a["net_wgs_started"] == a["net_wgs"] and b["net_wgs_started"] == b["net_wgs"] and b["net_wgs"] >= a["net_wgs"]
+
+
+def test_in_epoch_answer_table_is_transparent_and_saves_evaluations(monkeypatch):
+    """round 4: the reference inserts an answer into the position cache the moment it arrives (PlayManager::update_inferences,
+    play_manager.cc:631-640); the pipeline's S3-FIFO inserts wait for the epoch boundary, so the net workgroups also drop every answer
+    into a direct-mapped table of self-validating granules {tag32(key, k) | float} that the tree side probes beside the S3-FIFO shard.
+    With long epochs it answers probes (fewer evaluations than without it), and the games do not change (the lock-step engine's)."""
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=31), spec)
+    S, seed = 256, 4711
+    pp = _selfplay_params(az, S, 120, cache=1 << 16)
+    pa, (ra, ca), stats = _pipeline_games(az, pp, seed, hip, sims_per_epoch=S * 600)
+    assert stats["answer_table_hits"] > 0
+    monkeypatch.setenv("AZMI_PIPE_NO_L0", "1")
+    pn, (rn, cn), stats_n = _pipeline_games(az, pp, seed, hip, sims_per_epoch=S * 600)
+    monkeypatch.delenv("AZMI_PIPE_NO_L0")
+    assert stats_n["answer_table_hits"] == 0
+    pb, (rb, cb) = _lockstep_games(az, pp, seed, hip)
+    assert pa.games_completed() == pn.games_completed() == pb.games_completed() == S
+    sa, sn, sb = _sorted_log(ra, ca), _sorted_log(rn, cn), _sorted_log(rb, cb)
+    assert np.array_equal(sa[0], sb[0]) and np.array_equal(sa[1], sb[1])
+    assert np.array_equal(sn[0], sb[0]) and np.array_equal(sn[1], sb[1])
+    xa, xn = pa.counters(), pn.counters()
+    assert xa["sims"] == xn["sims"] and xa["evals"] < xn["evals"]
+    assert xa["cache_hits"] + xa["cache_misses"] == xn["cache_hits"] + xn["cache_misses"]      # same probes, more of them answered

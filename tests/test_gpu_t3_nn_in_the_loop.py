@@ -162,5 +162,5 @@ def test_bf16x3_net_in_the_loop_equals_the_oracle_driven_by_the_same_net(oracle)
     pp = _selfplay_params(az, S, 80, cache=1 << 14)
     pm, (rows, counts) = _device_games(az, az.Connect4GS(), pp, seed, hip)
     assert pm.games_completed() == S and pm.counters()["cache_hits"] > 0
-    assert not az.pipeline_supported(az.PlayManager(az.Connect4GS(), pp, seed=1), hip)      # the pipeline runs the bf16 tiles
+    assert az.pipeline_supported(az.PlayManager(az.Connect4GS(), pp, seed=1), hip)      # round 4: the pipeline runs this tier too (test_gpu_pipeline.py)
     _check_slots(az, oracle, oracle.GAME_CONNECT4, pp, seed, rows, counts, (0, 31, 63), evaluator=_net_eval(hip))
