@@ -780,7 +780,12 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
             const uint32_t t2 = g_ld(&pc->tail);
             if (static_cast<int32_t>(t2 - (w0 + wdone)) <= 0) over = 1;
           }
-          if (!over && now - t_start > pa.cap_ticks + pa.cap_ticks / 4) { atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrNetTimeout)); g_st(&pe->stop, 1u); over = 1; }
+          // the stall detector: cap x 1.25 once the tree side is there; while no tree workgroup has started yet (the host was held up
+          // between the two launches, the tree kernel waits for a place) four caps - long enough for any scheduling hiccup, short
+          // enough that a launch that never comes is an error and not a hang
+          if (!over && now - t_start > pa.cap_ticks + pa.cap_ticks / 4 && (g_ld(&pe->tree_arrived) != 0u || now - t_start > 4u * pa.cap_ticks)) {
+            atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrNetTimeout)); g_st(&pe->stop, 1u); over = 1;
+          }
         }
         if (__builtin_amdgcn_readfirstlane(over)) { n = 0; break; }
         __builtin_amdgcn_s_sleep(16);

@@ -170,6 +170,24 @@ def selfplay_params(az, games, sims, stream_games, cache=0, playout_cap=False, g
     return pp
 
 
+PIPE_ERRORS = []      # pipeline errors met (and recovered from) during this run: reported in config.pipeline_errors, never hidden
+
+
+def pipe_call(az, pm, net, n, spe, stream):
+    """azmi_run_pipeline through the recoverable-error contract of round 4: a pipeline error (a spin that hit the stall cap: the host
+    was held up between the two launches, another tenant took CUs) is reported once, leaves the engine whole, and the call is made
+    again - at most three such errors per run, each one recorded in the bench line."""
+    for _ in range(3):
+        try:
+            return az.run_pipeline(pm, net, n, spe, stream)
+        except RuntimeError as e:
+            if "pipeline error mask" not in str(e) or len(PIPE_ERRORS) >= 3:
+                raise
+            PIPE_ERRORS.append(str(e)[:160])
+            sys.stderr.write("bench.py: pipeline error (recovered, call repeated): %s\n" % str(e)[:160]); sys.stderr.flush()
+    raise RuntimeError("pipeline failed three times in a row")
+
+
 def host_cores():
     cores = len(os.sched_getaffinity(0))
     try:                                   # a cgroup CPU quota is the real core count of a container
@@ -507,7 +525,7 @@ def main():
             its net / tree kernels (HIP events on their own streams, inside the library) are summed when `ev` is given."""
             if use_pipe:
                 for pm_ in group:
-                    st_ = az.run_pipeline(pm_, hip_net, n, spe, sps[0])
+                    st_ = pipe_call(az, pm_, hip_net, n, spe, sps[0])
                     if ev is not None:
                         pipe_acc["net_us"] += st_["net_kernel_us"]; pipe_acc["tree_us"] += st_["tree_kernel_us"]; pipe_acc["epochs"] += st_["epochs"]; pipe_acc["host_us"] += st_["host_enqueue_us"]
                         pipe_acc.setdefault("tiles0", pipe_acc.get("tiles_now", 0)); pipe_acc.setdefault("boards0", pipe_acc.get("boards_now", 0))
@@ -721,6 +739,8 @@ def main():
             achieved = flop_per_eval * rows_evaluated / dt / 1e12
             per_launch = (flop_per_eval * rows_evaluated / launches) / (nn_ms * 1e-3) / 1e12 if nn_ms > 0 else 0.0
             out["config"].update({"tree_kernel_ms": tree_ms, "net_ms": nn_ms})
+            if use_pipe:
+                out["config"]["pipeline_errors"] = list(PIPE_ERRORS)      # recovered pipeline errors of this process (normally none)
             if use_pipe:      # the host's share: enqueueing an epoch's launches (it runs ahead of the GPU; one synchronisation per step)
                 out["config"]["host_enqueue_us_per_epoch"] = pipe_acc["host_us"] / launches
             out["roofline"] = {
@@ -871,7 +891,7 @@ def main():
 
                     def run2(n, pms2=pms2, pipe2=pipe2, net2=net2, S2=S2, sps2=sps2):
                         if pipe2:
-                            az.run_pipeline(pms2[0], net2, n, 256 * S2, sps2[0])
+                            pipe_call(az, pms2[0], net2, n, 256 * S2, sps2[0])
                         else:
                             done2 = 0
                             while done2 < n:
