@@ -88,7 +88,7 @@ def _conv_frags(w):
     return _frags(_pad(w.permute(0, 2, 3, 1), 64, 3, 3, 64).reshape(64, 576).numpy())
 
 
-def fold_spatial(net):
+def fold_spatial(net, x3=False):
     """Spatial-policy-head nets (Tafl family, StarGambit: one extra conv per head, v_fc_layers >= 1; trunk and head widths up
     to 64 channels - narrower ones (configs/brandubh.yaml: 32) are zero-padded: the padded channels have zero weights, scales
     and biases, so they stay exactly 0 through every affine / ReLU / conv).  Image read by csrc/leafnet_sp.h:
@@ -109,6 +109,9 @@ def fold_spatial(net):
     Hd, L, P1 = spec.v_fc_hidden, spec.v_fc_layers, spec.num_players + 1
     sd = {k: v.detach().double().cpu() for k, v in net.state_dict().items()}
     stream, prm = bytearray(), bytearray()
+    # x3 (precision "bf16x3", csrc/leafnet_sp.h Geo<.., SPLIT>): every 8 KB chunk three times - high parts, high parts, low parts
+    _frags = _split_frags if x3 else globals()["_frags"]
+    _conv_frags = (lambda w_: _split_frags(_pad(w_.permute(0, 2, 3, 1), 64, 3, 3, 64).reshape(64, 576).numpy())) if x3 else globals()["_conv_frags"]
     a, b = (t.cpu() for t in bn_affine(net.bn1))
     w = sd["conv1.weight"] * a[:, None, None, None]
     if Cin <= 8:    # k = tap * 8 + ci, K = 72 padded to 128 (csrc/leafnet_sp.h stem_chunks)
@@ -134,7 +137,7 @@ def fold_spatial(net):
     a2, b2 = (t.cpu() for t in bn_affine(net.pi_bn2))
     stream += _frags(_pad(sd["pi_conv2.weight"][:, :, 0, 0] * a2[:, None], 64, 64).numpy())
     prm += _f32(_pad(b2, 32))
-    assert len(stream) == ((2 if Cin <= 8 else 9) + 18 * spec.depth + 2 + 18 + 1) * 8192
+    assert len(stream) == (3 if x3 else 1) * ((2 if Cin <= 8 else 9) + 18 * spec.depth + 2 + 18 + 1) * 8192
     blob = stream + prm
     blob += _f32_frags(_pad(sd["v_fc1.weight"], Hd, 64).numpy()) + _f32(sd["v_fc1.bias"])
     for l in range(L - 1):
@@ -148,7 +151,7 @@ def fold_spatial(net):
         blob += _f32_frags(_pad(sd["pi_global.0.weight"], Hp, 64).numpy()) + _f32(sd["pi_global.0.bias"])
         blob += _f32_frags(_pad(sd["pi_global.2.weight"], 32, Hp).numpy()) + _f32(_pad(sd["pi_global.2.bias"], 32))
         blob += _f32(_pad(sd["pi_global.3.weight"], 32)) + _f32(_pad(sd["pi_global.3.bias"], 32))
-    desc = NetDescC(Cin, H, W, 64, spec.depth, 3, 64, Hd, spec.num_moves, spec.num_players, 1, 1, L, pc, 0, Hp)
+    desc = NetDescC(Cin, H, W, 64, spec.depth, 3, 64, Hd, spec.num_moves, spec.num_players, 1, 1, L, pc, 2 if x3 else 0, Hp)
     assert len(blob) == lib.azmi_net_blob_bytes(C.byref(desc)), (len(blob), lib.azmi_net_blob_bytes(C.byref(desc)))
     return desc, bytes(blob)
 
@@ -213,8 +216,8 @@ def _split_frags(wmat, passes=("hi", "hi", "lo")):
 
 def fold(net, precision="bf16"):
     """LeafNet (reference NNArch parameter names) -> (NetDescC, blob bytes).  precision: "bf16" (bf16 MFMA operands), "bf16x3"
-    (Connect4 family: weights and activations as bf16 high + low parts, three MFMAs per product - the 1e-5 tier on the matrix
-    cores) or "fp32" (plain fp32 kernels, any shape)."""
+    (weights and activations as bf16 high + low parts, three MFMAs per product - the 1e-5 tier on the matrix cores; the Connect4
+    family and, since round 4, the spatial-head nets) or "fp32" (plain fp32 kernels, any shape)."""
     if precision == "fp32":
         return fold_fp32(net)
     spec = net.spec
@@ -222,9 +225,7 @@ def fold(net, precision="bf16"):
     if precision not in ("bf16", "bf16x3"):
         raise ValueError("precision must be 'bf16', 'bf16x3' or 'fp32'")
     if spec.policy_shape is not None:
-        if x3:
-            raise RuntimeError("precision='bf16x3' covers the Connect4 net family; spatial-head nets: 'bf16' or 'fp32'")
-        return fold_spatial(net)
+        return fold_spatial(net, x3)
     Cin, H, W = spec.in_shape
     if not (spec.num_channels == 64 and spec.head_channels == 32 and spec.kernel_size == 3 and spec.policy_shape is None
             and spec.head_pool and spec.v_head_convs == 0 and spec.pi_head_convs == 0 and spec.v_fc_layers == 1

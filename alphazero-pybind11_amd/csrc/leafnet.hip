@@ -118,7 +118,7 @@ bool is_spatial(const azmi_net_desc* d) { return d->policy_channels > 0; }
 // the heads | the value FC stack | pi_global
 size_t spatial_blob_bytes(const azmi_net_desc* d) {
   const size_t Hd = d->v_hidden, L = d->v_fc_layers;
-  size_t n = static_cast<size_t>(sp::stream_chunks(d->depth, d->in_channels)) * sp::CHUNK_BYTES;
+  size_t n = static_cast<size_t>(sp::stream_chunks(d->depth, d->in_channels, d->precision == 2)) * sp::CHUNK_BYTES;   // (bf16x3: every chunk three times)
   n += (CH + static_cast<size_t>(d->depth) * 3 * CH + 2 * sp::HCS + sp::HCS + sp::HCS + 32) * 4;
   n += (64 * Hd + Hd) * 4 + (L - 1) * (Hd * Hd + Hd) * 4 + (Hd * 16 + 16) * 4;
   if (d->num_moves > d->policy_channels * d->height * d->width) {     // pi_global: W1^T[64][Hp] b[Hp] W2^T[Hp][32] b[32] ln_g[32] ln_b[32]
@@ -161,15 +161,16 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
     *out = net;
     return AZMI_OK;
   }
-  if (d->precision != 0 && d->precision != 2) return nfail(AZMI_ERR_INVALID, "precision must be 0 (bf16 MFMA), 1 (fp32) or 2 (bf16x3: split bf16 MFMA, Connect4 family)");
-  if (d->precision == 2 && is_spatial(d)) return nfail(AZMI_ERR_INVALID, "precision 2 (bf16x3) covers the Connect4-family net; spatial nets: 0 or 1");
+  if (d->precision != 0 && d->precision != 2) return nfail(AZMI_ERR_INVALID, "precision must be 0 (bf16 MFMA), 1 (fp32) or 2 (bf16x3: split bf16 MFMA)");
   if (is_spatial(d)) {
     if (d->channels != CH || d->head_channels != sp::HCS || d->kernel_size != 3 || d->v_head_convs != 1 || d->pi_head_convs != 1)
       return nfail(AZMI_ERR_INVALID, "spatial leaf net kernel covers 64 trunk / 64 head channels, 3x3 convs, one extra conv per head");
     const bool b11 = d->height == 11 && d->width == 11, b7 = d->height == 7 && d->width == 7, b13 = d->height == 13 && d->width == 13;
     if (!b11 && !b7 && !b13) return nfail(AZMI_ERR_INVALID, "spatial leaf net kernel: board %dx%d not instantiated", d->height, d->width);
     const int tbw = b11 ? sp::Geo11::TBW : b7 ? sp::Geo7::TBW : sp::Geo13::TBW;
-    const size_t tile_lds = b11 ? sp::Geo11::LDS_BYTES : b7 ? sp::Geo7::LDS_BYTES : sp::Geo13::LDS_BYTES;
+    const bool x3 = d->precision == 2;       // the bf16x3 tier: Geo<.., SPLIT>, 16 activation planes, one workgroup per CU
+    const size_t tile_lds = x3 ? (b11 ? sp::Geo11X3::LDS_BYTES : b7 ? sp::Geo7X3::LDS_BYTES : sp::Geo13X3::LDS_BYTES)
+                               : (b11 ? sp::Geo11::LDS_BYTES : b7 ? sp::Geo7::LDS_BYTES : sp::Geo13::LDS_BYTES);
     const int num_global = d->num_moves - d->policy_channels * d->height * d->width;
     if (d->policy_channels > 32 || num_global < 0 || num_global > 32)
       return nfail(AZMI_ERR_INVALID, "spatial head: policy channels <= 32, 0..32 global actions");
@@ -184,7 +185,7 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return nfail(AZMI_ERR_NO_DEVICE, "no HIP device: libazmi has no CPU path");
     if (hipSetDevice(device) != hipSuccess) return nfail(AZMI_ERR_NO_DEVICE, "hipSetDevice failed");
     auto net = new azmi_net();
-    net->device = device; net->spatial = true;
+    net->device = device; net->spatial = true; net->x3 = x3;
     net->sd = sp::SpDesc{d->in_channels, d->height, d->width, d->depth, d->num_moves, d->num_players, d->v_hidden, d->v_fc_layers, d->policy_channels,
                          num_global, num_global > 0 ? d->pi_hidden : 0};
     if (hipMalloc(&net->blob, blob_bytes) != hipSuccess) { delete net; return nfail(AZMI_ERR_OOM, "hipMalloc(weights) failed"); }
@@ -194,7 +195,7 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
     const size_t Hd = d->v_hidden, L = d->v_fc_layers;
     sp::SpPtrs& sp = net->sp;
     auto f32p = [&](size_t count) { const float* q = reinterpret_cast<const float*>(p); p += count * 4; return q; };
-    sp.stream = p; p += static_cast<size_t>(sp::stream_chunks(d->depth, d->in_channels)) * sp::CHUNK_BYTES;
+    sp.stream = p; p += static_cast<size_t>(sp::stream_chunks(d->depth, d->in_channels, x3)) * sp::CHUNK_BYTES;
     sp.prm = f32p(CH + static_cast<size_t>(d->depth) * 3 * CH + 2 * sp::HCS + sp::HCS + sp::HCS + 32);
     sp.fc1_w = f32p(64 * Hd); sp.fc1_b = f32p(Hd);
     sp.fcx_w = f32p((L - 1) * Hd * Hd); sp.fcx_b = f32p((L - 1) * Hd);
@@ -205,8 +206,10 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
     }
     net->sp_tbw = tbw;
     net->lds_bytes = tile_lds;
-    const void* kernel = b11 ? reinterpret_cast<const void*>(&sp::k_leafnet_sp<sp::Geo11>)
-                       : b7 ? reinterpret_cast<const void*>(&sp::k_leafnet_sp<sp::Geo7>) : reinterpret_cast<const void*>(&sp::k_leafnet_sp<sp::Geo13>);
+    const void* kernel = x3 ? (b11 ? reinterpret_cast<const void*>(&sp::k_leafnet_sp<sp::Geo11X3>)
+                                   : b7 ? reinterpret_cast<const void*>(&sp::k_leafnet_sp<sp::Geo7X3>) : reinterpret_cast<const void*>(&sp::k_leafnet_sp<sp::Geo13X3>))
+                            : (b11 ? reinterpret_cast<const void*>(&sp::k_leafnet_sp<sp::Geo11>)
+                                   : b7 ? reinterpret_cast<const void*>(&sp::k_leafnet_sp<sp::Geo7>) : reinterpret_cast<const void*>(&sp::k_leafnet_sp<sp::Geo13>));
     net->fc_split = d->v_hidden > 256 || num_global > 0;   // more than ~0.4 MB of FC weights per group
     net->fc_lds = sp::heads_fc_lds(d->v_hidden > d->pi_hidden || num_global == 0 ? d->v_hidden : d->pi_hidden);
     // The FC kernels are shared by every spatial net of the process: the attribute is set to the most any descriptor this
@@ -333,7 +336,14 @@ static int spatial_forward(azmi_net* net, const float* dev_canonical, float* dev
   float* glob = sc.pool + static_cast<size_t>(sc.pool_rows) * 128;
   float* hidden = sc.pool + static_cast<size_t>(sc.pool_rows) * 160;
   const uint32_t tiles = (batch + net->sp_tbw - 1) / net->sp_tbw;
-  if (net->sd.H == 11)
+  if (net->x3) {
+    if (net->sd.H == 11)
+      sp::k_leafnet_sp<sp::Geo11X3><<<tiles, sp::NTH, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, vpool, ppool, dev_pi, batch, rows, row_count);
+    else if (net->sd.H == 13)
+      sp::k_leafnet_sp<sp::Geo13X3><<<tiles, sp::NTH, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, vpool, ppool, dev_pi, batch, rows, row_count);
+    else
+      sp::k_leafnet_sp<sp::Geo7X3><<<tiles, sp::NTH, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, vpool, ppool, dev_pi, batch, rows, row_count);
+  } else if (net->sd.H == 11)
     sp::k_leafnet_sp<sp::Geo11><<<tiles, sp::NTH, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, vpool, ppool, dev_pi, batch, rows, row_count);
   else if (net->sd.H == 13)
     sp::k_leafnet_sp<sp::Geo13><<<tiles, sp::NTH, net->lds_bytes, st>>>(net->sd, net->sp, dev_canonical, vpool, ppool, dev_pi, batch, rows, row_count);

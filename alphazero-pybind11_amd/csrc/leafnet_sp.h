@@ -54,27 +54,34 @@ constexpr int HCS = 64;                                    // head channels (val
 constexpr int PRM_STEM = 0, PRM_BLOCKS = CH, PRM_HEAD = PRM_BLOCKS + MAXDEPTH * 3 * CH, PRM_VX = PRM_HEAD + 2 * HCS,
               PRM_PX = PRM_VX + HCS, PRM_POL = PRM_PX + HCS, PRM_FLOATS = PRM_POL + 32;   // 1,504
 
-template <int H_, int W_, int TBW_, int NTW_>
+// SPLIT (the "bf16x3" precision tier, as c4::Tile's): weights and activations as bf16 HIGH + LOW parts (x = hi + lo to ~16 bits of
+// mantissa), every product as three MFMAs hi*hi + hi*lo + lo*hi - each chunk of the weight stream three times ([W_hi][W_hi][W_lo])
+// against the activation planes [X_hi][X_lo][X_hi] (planes 8-15 hold the low parts): 16 planes, so one workgroup per CU.
+template <int H_, int W_, int TBW_, int NTW_, int SPLIT_ = 0>
 struct Geo {
-  static constexpr int H = H_, W = W_, TBW = TBW_, NTW = NTW_;
+  static constexpr int H = H_, W = W_, TBW = TBW_, NTW = NTW_, SPLIT = SPLIT_;
+  static constexpr int NPLANES = SPLIT_ ? 16 : 8;
   static constexpr int PIX = H * W, NPIX = TBW * PIX;
   static constexpr int NT = NWV * NTW;                // n-tiles of the workgroup
   static constexpr int ZSLOT = NT * 16;               // first all-zero cell
   static constexpr int SLOTS = ZSLOT + 16;
   static constexpr int PLANE = SLOTS * 16;            // a multiple of 256 B
   static constexpr int ZERO_OFF = ZSLOT * 16;
-  static constexpr int ACT_BYTES = 8 * PLANE;
+  static constexpr int ACT_BYTES = NPLANES * PLANE;
   static constexpr int LDS_BYTES = ACT_BYTES + RING_BYTES + PRM_FLOATS * 4;
   static constexpr int PITER = (TBW * 128 + NTH - 1) / NTH;   // pooling passes: one thread per (board, channel of a half, quarter)
   static_assert(NPIX <= NT * 16 && NPIX <= NTH, "one thread per pixel; the tile's pixels fit its n-tiles");
   static_assert(PLANE % 256 == 0, "conflict-free fragment reads need a plane stride that is a multiple of 256 B");
-  static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+  static_assert((SPLIT_ ? 1 : 2) * LDS_BYTES <= 160 * 1024, "two workgroups per CU (SPLIT: one)");
   static_assert(NT * 16 * 32 * 4 <= ACT_BYTES, "pooling scratch fits the activation planes");
   static_assert(NPIX * 32 * 4 <= RING_BYTES, "policy logits fit the ring");
 };
 using Geo11 = Geo<11, 11, 2, 4>;
 using Geo7 = Geo<7, 7, 5, 4>;
 using Geo13 = Geo<13, 13, 1, 3>;
+using Geo11X3 = Geo<11, 11, 2, 4, 1>;
+using Geo7X3 = Geo<7, 7, 5, 4, 1>;
+using Geo13X3 = Geo<13, 13, 1, 3, 1>;
 
 struct SpDesc {
   int C_in, H, W, depth, num_moves, num_players, v_hidden, v_fc_layers, pol_ch;
@@ -104,7 +111,7 @@ struct SpPtrs {
 // padded to 128 = 2 chunks) whose B fragments are that plane read at the tap of each lane group; more planes (StarGambit: 36)
 // run as one more 64-channel convolution (9 chunks)
 __host__ __device__ inline int stem_chunks(int c_in) { return c_in <= 8 ? 2 : 9; }
-__host__ __device__ inline int stream_chunks(int depth, int c_in) { return stem_chunks(c_in) + 2 * depth * 9 + 2 + 9 + 9 + 1; }
+__host__ __device__ inline int stream_chunks(int depth, int c_in, int split = 0) { return (split ? 3 : 1) * (stem_chunks(c_in) + 2 * depth * 9 + 2 + 9 + 9 + 1); }
 
 // rows != nullptr: evaluate only the rows listed in rows[0 .. *row_count) (the engine's eval list); the canonical planes are
 // read from, and (v, pi) written to, the LISTED row; workgroups past the end of the list leave at once.
@@ -125,7 +132,8 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
   const int col = lane & 15, quad = lane >> 4;
   const uint32_t board0 = tile_index * TBW;
   const int depth = nd.depth;
-  const int nchunks = stream_chunks(depth, nd.C_in);
+  constexpr bool SPLIT = G::SPLIT != 0;
+  const int nchunks = stream_chunks(depth, nd.C_in, G::SPLIT);
 
   // ---- small fp32 parameters -> LDS (plain loads, before any DMA is in flight) ------------------------------------
   {
@@ -187,6 +195,12 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = static_cast<__bf16>(x[e]);
       if (tid < NPIX) *reinterpret_cast<bf16x8*>(act + c8 * PLANE + tid * 16) = o;
+      if constexpr (SPLIT) {          // (an input plane need not be 0 / 1: OpenTafl's turn / max_turns plane) the low parts
+        bf16x8 l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) l[e] = static_cast<__bf16>(x[e] - static_cast<float>(o[e]));
+        if (tid < NPIX) *reinterpret_cast<bf16x8*>(act + (8 + c8) * PLANE + tid * 16) = l;
+      }
     }
   }
 
@@ -196,6 +210,12 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
     o[0] = static_cast<__bf16>(val[0]); o[1] = static_cast<__bf16>(val[1]);
     o[2] = static_cast<__bf16>(val[2]); o[3] = static_cast<__bf16>(val[3]);
     *reinterpret_cast<bf16x4*>(act + (plane0 + (quad >> 1)) * PLANE + pix0 + j * 256 + (quad & 1) * 8) = o;
+    if constexpr (SPLIT) {        // the low parts: what the bf16 rounding left, in the same cell of plane + 8
+      bf16x4 l;
+      l[0] = static_cast<__bf16>(val[0] - static_cast<float>(o[0])); l[1] = static_cast<__bf16>(val[1] - static_cast<float>(o[1]));
+      l[2] = static_cast<__bf16>(val[2] - static_cast<float>(o[2])); l[3] = static_cast<__bf16>(val[3] - static_cast<float>(o[3]));
+      *reinterpret_cast<bf16x4*>(act + (8 + plane0 + (quad >> 1)) * PLANE + pix0 + j * 256 + (quad & 1) * 8) = l;
+    }
   };
   auto store_relu = [&](f32x4 (&x)[NTW][MT]) {
 #pragma unroll
@@ -234,7 +254,9 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
   // another barrier.  Precondition: the activations are visible and the first chunk has landed for all waves.
   // Returns the ring slot of the next convolution's first chunk.
   auto conv = [&](auto nch_tag, f32x4 (&acc)[NTW][MT], int slot0) -> int {
-    constexpr int NCH = decltype(nch_tag)::value, NKS = NCH * CHUNK_KS;
+    // SPLIT: every chunk of the convolution three times - stream chunk c = the convolution's chunk c / 3, pass c % 3 =
+    // (W_hi, X_hi), (W_hi, X_lo), (W_lo, X_hi)
+    constexpr int NCH0 = decltype(nch_tag)::value, NCH = (SPLIT ? 3 : 1) * NCH0, NKS = NCH * CHUNK_KS;
     bf16x8 a[2][MT], b[2][NTW];
     int slot = slot0;
     auto load_a = [&](int ksl, const uint8_t* wsl, bf16x8 (&fa)[MT]) {
@@ -242,19 +264,22 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
       for (int mt = 0; mt < MT; ++mt) fa[mt] = lds_read_frag(wsl + (ksl * MT + mt) * WFRAG_BYTES);
     };
     int sel[NTW];                  // per tile j: the plane offset the current tap's reads go through
-    auto load_b = [&](int ks, bf16x8 (&fb)[NTW]) {
-      if constexpr (NCH == 2) {
+    auto load_b = [&](int ks_stream, bf16x8 (&fb)[NTW]) {
+      const int chunk_s = ks_stream >> 1, pass = SPLIT ? chunk_s % 3 : 0;
+      const int ks = SPLIT ? ((chunk_s / 3) << 1) | (ks_stream & 1) : ks_stream;      // the k-step of the convolution itself
+      const int lo_planes = (SPLIT && pass == 1) ? 8 * PLANE : 0;                      // pass 1 reads the activations' low parts
+      if constexpr (NCH0 == 2) {
         const int tap = 4 * ks + quad, th = tap / 3, tw = tap - 3 * th;
         const int tap_off = ((th - 1) * BW + (tw - 1)) * 16;
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
           const int d = (tap < 9 && ((tap_ok[j] >> tap) & 1u)) ? tap_off : (G::ZERO_OFF - pix0 - j * 256) + ((pix0 + tap_off) & 0xF0);
-          fb[j] = lds_read_frag(act + pix0 + d + j * 256);
+          fb[j] = lds_read_frag(act + pix0 + d + j * 256 + lo_planes);
         }
       } else {
-        const int tap = NCH == 9 ? (ks >> 1) : 4, half = ks & 1;
+        const int tap = NCH0 == 9 ? (ks >> 1) : 4, half = ks & 1;
         const int tap_off = ((tap / 3 - 1) * BW + (tap % 3 - 1)) * 16;
-        if (half == 0) {                    // a new tap
+        if (half == 0 && pass == 0) {       // a new tap
           int zs = (pix0 + tap_off) & 0xF0;   // slot residue of the cell this tap reads on the board (the same for every tile j)
           asm volatile("" : "+v"(zs));        // keeps the selects here: hoisted out of the block loop, a convolution's bases cost VGPRs (spills)
           const int zc = quad * PLANE + G::ZERO_OFF + zs;          // byte offsets into the planes (32-bit: a pointer here costs two registers)
@@ -263,7 +288,7 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
           for (int j = 0; j < NTW; ++j) sel[j] = ((tap_ok[j] >> tap) & 1u) ? pot : zc - j * 256;
         }
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) fb[j] = lds_read_frag(act + sel[j] + (j * 256 + half * 4 * PLANE));
+        for (int j = 0; j < NTW; ++j) fb[j] = lds_read_frag(act + sel[j] + (j * 256 + half * 4 * PLANE + lo_planes));
       }
     };
     load_a(0, wlane + slot * CHUNK_BYTES, a[0]);
@@ -396,7 +421,7 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
     }
   };
   auto rezero_cells = [&]() {          // the pooling scratch ran over the zero cells of the activation planes
-    if (tid < 8 * 16) *reinterpret_cast<u32x4*>(act + (tid >> 4) * PLANE + G::ZERO_OFF + (tid & 15) * 16) = u32x4{0, 0, 0, 0};
+    if (tid < G::NPLANES * 16) *reinterpret_cast<u32x4*>(act + (tid >> 4) * PLANE + G::ZERO_OFF + (tid & 15) * 16) = u32x4{0, 0, 0, 0};
   };
 
   // ---- value head: extra conv, average pool (the FC stack runs last) -----------------------------------------------------
@@ -486,7 +511,7 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
 }
 
 template <class G>
-__global__ __launch_bounds__(NTH, 2) void k_leafnet_sp(SpDesc nd, SpPtrs np, const float* __restrict__ canon,
+__global__ __launch_bounds__(NTH, G::SPLIT ? 1 : 2) void k_leafnet_sp(SpDesc nd, SpPtrs np, const float* __restrict__ canon,
                                                         float* __restrict__ vpool, float* __restrict__ ppool, float* __restrict__ pi_out,
                                                         uint32_t batch, const uint32_t* __restrict__ rows, const uint32_t* __restrict__ row_count) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_sp[];

@@ -449,9 +449,48 @@ def test_bf16x3_batch_shapes_and_invariance(batch):
             assert torch.equal(v[lo:lo + 700], vs) and torch.equal(pi[lo:lo + 700], ps), lo
 
 
-def test_bf16x3_rejects_spatial_nets():
+SPATIAL_X3 = [("nn_tawlbwrdd_4b64c.npz", "tawlbwrdd_spec"), ("nn_tawlbwrdd_4b64c_peaked.npz", "tawlbwrdd_spec"),
+              ("nn_opentafl_4b64c.npz", "opentafl_spec"), ("nn_brandubh_4b32c.npz", "brandubh_spec"),
+              ("nn_stargambit_4b64c.npz", "stargambit_spec"), ("nn_stargambit_4b64c_peaked.npz", "stargambit_spec")]
+
+
+@pytest.mark.parametrize("fixture,spec_fn", SPATIAL_X3)
+def test_bf16x3_spatial_tile_matches_reference_nnarch_within_1e5(fixture, spec_fn):
+    """round 4: precision="bf16x3" on the spatial-head nets (csrc/leafnet_sp.h, Geo<.., SPLIT>: every chunk of the weight stream three
+    times against the activations' high / low planes, 16 planes, one workgroup per CU) against the reference NNArch's own fp32
+    outputs - Tawlbwrdd (random-init and PEAKED: the bf16 tile's 3.1e-5 / 2.0e-5 there is outside the north star's 1e-5), OpenTafl
+    (a fractional input plane: the inputs are split too), Brandubh (zero-padded to 64 channels), StarGambit (36 input planes, the
+    global head behind the spatial logits)."""
+    import alphazero as az
+    fx, net = _ref_fixture(fixture, spec_fn)
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(fx["input"]).to(dev)
+    v, pi = az.HipLeafNet(net, precision="bf16x3").process(x)
+    torch.cuda.synchronize()
+    dv = np.abs(v.cpu().numpy() - fx["v"]).max()
+    dpi = np.abs(pi.cpu().numpy() - fx["pi"]).max()
+    v16, pi16 = az.HipLeafNet(net).process(x)
+    e16 = max(np.abs(v16.cpu().numpy() - fx["v"]).max(), np.abs(pi16.cpu().numpy() - fx["pi"]).max())
+    print("%s bf16x3 vs reference fp32: max|dv| %.3e max|dpi| %.3e (bf16 tile: %.3e)" % (fixture, dv, dpi, e16))
+    assert dv <= TOL_F32 and dpi <= TOL_F32, (dv, dpi)
+    assert np.allclose(v.sum(1).cpu().numpy(), 1, atol=1e-5) and np.allclose(pi.sum(1).cpu().numpy(), 1, atol=1e-5)
+    assert max(dv, dpi) <= e16, "the split tile must not be further from fp32 than the bf16 tile"
+
+
+@pytest.mark.parametrize("batch", [1, 3, 33, 700])
+def test_bf16x3_spatial_batch_shapes_and_invariance(batch):
+    """ragged batches (not a multiple of the 2-board tile / the 16-board FC group) and a row's answer independent of its batch"""
     import alphazero as az
     from alphazero import torch_net
-    net = torch_net.random_init(torch_net.tawlbwrdd_spec(), seed=1)
-    with pytest.raises(RuntimeError, match="bf16x3"):
-        az.HipLeafNet(net, precision="bf16x3")
+    dev = torch.device("cuda:0")
+    net = torch_net.random_init(torch_net.tawlbwrdd_spec(), seed=5)
+    hip = az.HipLeafNet(net, precision="bf16x3")
+    g = torch.Generator().manual_seed(batch)
+    x = (torch.rand((batch, 7, 11, 11), generator=g) < 0.2).float().to(dev)
+    v, pi = hip.process(x)
+    v1, pi1 = hip.process(x[:1].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(v[:1], v1) and torch.equal(pi[:1], pi1)
+    with torch.no_grad():
+        vr, pr = net.to(dev).process(x)
+    assert (v - vr).abs().max().item() <= TOL_F32 and (pi - pr).abs().max().item() <= TOL_F32

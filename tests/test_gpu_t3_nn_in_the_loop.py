@@ -112,6 +112,19 @@ def test_tawlbwrdd_fast_path_equals_the_oracle_driven_by_the_same_net(oracle):
     _check_slots(az, oracle, oracle.GAME_TAWLBWRDD, pp, seed, rows, counts, (0, 5), evaluator=_net_eval(hip))
 
 
+def test_tawlbwrdd_with_the_bf16x3_net_equals_the_oracle_driven_by_the_same_net(oracle):
+    """round 4: the spatial tile's bf16x3 tier (csrc/leafnet_sp.h, Geo<.., SPLIT>) as the engine's evaluator"""
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.tawlbwrdd_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=13), spec, precision="bf16x3")
+    S, seed = 6, 99
+    pp = _selfplay_params(az, S, 24, cache=1 << 12)
+    pm, (rows, counts) = _device_games(az, az.TawlbwrddGS(), pp, seed, hip)
+    assert pm.games_completed() == S
+    _check_slots(az, oracle, oracle.GAME_TAWLBWRDD, pp, seed, rows, counts, (0, 5), evaluator=_net_eval(hip))
+
+
 def test_two_nets_routed_by_model_group_on_a_tafl_game(oracle):
     """gating shape (play_past, game_runner.py:2184-2332) on Brandubh: two DIFFERENT spatial nets, both seatings.  Each net
     must only write the rows of its own model group's leaves (the spatial kernels used to evaluate the whole
