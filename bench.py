@@ -70,6 +70,8 @@ def parse(argv=None):
     ap.add_argument("--playout-cap", action="store_true", help="playout-cap randomisation at the TrainConfig defaults (config.py:86,100)")
     ap.add_argument("--gumbel", action="store_true", help="Gumbel AlphaZero search (configs/tawlbwrdd.yaml:24-25: gumbel_enabled, capped searches PUCT)")
     ap.add_argument("--net", choices=["hip", "torch"], default=None)
+    ap.add_argument("--precision", choices=["bf16", "bf16x3", "fp32"], default="bf16",
+                    help="HIP leaf net tier: bf16 (the reference's autocast arithmetic, the headline), bf16x3 (split bf16 operands: the north star's 1e-5 on the matrix cores), fp32 (plain kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the two short secondary measurements reported in config")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="wall time of the CPU-baseline sample")
@@ -501,7 +503,7 @@ def main():
         spec = torch_net.stargambit_spec() if sg else torch_net.tawlbwrdd_spec() if tafl else torch_net.connect4_spec()
         net = torch_net.random_init(spec, seed=0).to(dev)
         net_kind = args.net or "hip"
-        hip_net = az.HipLeafNet(net, spec, device=local_rank) if net_kind == "hip" else None
+        hip_net = az.HipLeafNet(net, spec, device=local_rank, precision=args.precision) if net_kind == "hip" else None
         if net_kind == "torch":
             net = net.to(memory_format=torch.channels_last)
 
@@ -699,7 +701,7 @@ def main():
             **({"profile_window": True} if args.profile_window else {}),
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16",
+            "dtype": {"bf16": "bf16", "bf16x3": "bf16x3 (split bf16 operands, fp32 accumulate: within 1e-5 of the reference's fp32 outputs)", "fp32": "f32"}[args.precision],
             "data": "synthetic",
             "config": {
                 "workload": (f"star_gambit_unified (four variants, 13x13 canvas, 1709 moves), {S} concurrent games/GPU, {sims} sims/move, 4-block/64-ch ResNet (configs/star_gambit_unified.yaml net, spatial + global policy head), {'Gumbel' if args.gumbel else 'PUCT'}, "
