@@ -52,7 +52,6 @@ struct PipeKernArgs { EngineParams ep; EngineArrays ar; PipeArrays pa; };
 // one CU = one vector L1: a pass drains its stores (s_waitcnt vmcnt(0)) before its tokens go out and that is all (round 3 let
 // slots wander between CUs and paid an agent-scope acquire + release, ~10 us, per pass).
 constexpr uint32_t kTreeWindow = 8;
-constexpr uint64_t kTreePatience = 100;       // ticks (1 us) a wavefront that holds some tokens of a window waits for the window's rest
 
 __device__ __forceinline__ void pipe_push_token(const PipeArrays& pa, uint32_t home, uint32_t pos, unsigned long long payload) {
   g_st(pa.rring + ((static_cast<size_t>(home) << pa.rshift) + (pos & ((1u << pa.rshift) - 1u))), (pipe_lap_tag_r(pos, pa.rshift) << 48) | payload);
@@ -191,27 +190,27 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
     return;
   }
   bool go = g_ld(&ar.ctl->stop) == 0 && g_ld(&pc->err) == 0 && g_ld(&pe->stop) == 0;
-  uint32_t w0 = 0, wn = 0, wdone = 0;        // the wavefront's window of READY-ring positions: start, size, positions used
+  // The ring's HEAD lives in LDS for the epoch: this workgroup's four wavefronts are its only consumers, so a draw is one look at the
+  // ring (eight token loads side by side) and a compare-and-swap in LDS - no head | tail word, no fetch-add in HBM, no window that
+  // can reach past the tail (round 4, second half: three dependent round trips per pass became one).
+  __shared__ uint32_t s_head;
+  if (threadIdx.x == 0) s_head = wc->rhead;
+  __syncthreads();
   uint64_t pf_pass = 0, pf_idle = 0, pf_n = 0, pf_act = 0, pf_polls = 0, pf_io = 0, pf_lvls = 0, pf_mv = 0;
   uint64_t pf_ph[5] = {0, 0, 0, 0, 0};     // per group (lane 0 counts): ticks in backup / descent / expansion / probe, simulations
   SlotCtx<GM> c(ep, ar, 0u, lane);
 
   while (go) {
     const uint64_t pf_t0 = PROF ? wall_clock64() : 0;
-    // ---- tokens for this pass: what the ring holds now (at most a window of eight); a window is only drawn when tokens are there,
-    // so no wavefront sits on ring positions while it works (with four wavefronts per ring a token behind a busy wavefront's
-    // window would wait for that wavefront's whole pass)
+    // ---- tokens for this pass: the arrived prefix of the eight ring positions at the head
     uint32_t my_slot = kNoSlot, tok_seq = 0, tok_move = 0, n_tok = 0, empty_polls = 0, ctl_word = 0;
-    uint64_t t_first = 0, t_seen = 0;
+    uint64_t t_seen = 0;
     for (;;) {
-      const bool need_window = wdone == wn;
-      unsigned long long ht = 0;
-      if (need_window && wlane == 0) ht = g_ld(reinterpret_cast<const unsigned long long*>(wc));
-      const uint32_t left = need_window ? 0u : wn - wdone;
+      const uint32_t h = __builtin_amdgcn_readfirstlane(*const_cast<volatile uint32_t*>(&s_head));
       unsigned long long tok = 0;
       bool here = false;
-      if (lane == 0 && grp < left) {
-        const uint32_t pos = w0 + wdone + grp;
+      if (lane == 0) {
+        const uint32_t pos = h + grp;
         tok = g_ld(myring + (pos & rmask));
         here = (tok >> 48) == pipe_lap_tag_r(pos, pa.rshift);
       }
@@ -239,49 +238,35 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
         if (wlane == 0) { atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTimeout)); pc->dbg[16] = __builtin_amdgcn_readlane(ctl_word, 23); pc->dbg[17] = __builtin_amdgcn_readlane(ctl_word, 31); }
         stop_seen = 1u;
       }
-      if (stop_seen) {          // (tokens this wavefront holds are dropped: their slots are whole in HBM, the next epoch seeds them again)
+      if (stop_seen) {          // (tokens still in the ring are dropped: their slots are whole in HBM, the next epoch seeds them again)
         if (wlane == 0) g_st(&pe->stop, 1u);
         go = false;
         break;
       }
       if constexpr (PROF) pf_polls += 1;
-      if (need_window) {
-        const uint32_t hlo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(ht))));
-        const uint32_t hhi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(ht >> 32))));
-        const int32_t avail = static_cast<int32_t>(hhi - hlo);      // tail - head
-        if (avail > 0) {
-          // fewer than a window: a short wait gathers what is on its way (AZMI_PIPE_TAKE_WAIT; 0 = take what is there)
-          if (static_cast<uint32_t>(avail) < kTreeWindow && pa.take_wait != 0u) {
-            if (t_seen == 0) t_seen = now;
-            if (now - t_seen <= pa.take_wait) { __builtin_amdgcn_s_sleep(2); continue; }
-          }
-          const uint32_t n = min(static_cast<uint32_t>(avail), kTreeWindow);
-          uint32_t h = 0;
-          if (wlane == 0) h = atomicAdd(&wc->rhead, n);
-          w0 = __builtin_amdgcn_readfirstlane(h); wn = n; wdone = 0;
-          continue;            // (the tokens of the window are at most a store's latency behind their tickets)
-        }
-        ++empty_polls; __builtin_amdgcn_s_sleep(24);
-        continue;
-      }
       const unsigned long long hm = __ballot(here);
       // group g's token is bit 8 g: the arrived prefix in group order
       uint32_t k = 0;
-      while (k < left && ((hm >> (8 * k)) & 1ull)) ++k;
-      // (a window can reach past tail when another wavefront's draw came between this one's look at the ring and its fetch-add:
-      // then its last tokens arrive when their slots do, and the arrived prefix starts the pass after a short patience)
-      if (k == left || (k != 0u && t_first != 0 && now - t_first > kTreePatience)) {
-        n_tok = k;
+      while (k < kTreeWindow && ((hm >> (8 * k)) & 1ull)) ++k;
+      if (k == 0u) { ++empty_polls; __builtin_amdgcn_s_sleep(16); continue; }
+      // fewer than a window: a short wait gathers what is on its way (AZMI_PIPE_TAKE_WAIT; 0 = take what is there)
+      if (k < kTreeWindow && pa.take_wait != 0u) {
+        if (t_seen == 0) t_seen = now;
+        if (now - t_seen <= pa.take_wait) { __builtin_amdgcn_s_sleep(2); continue; }
+      }
+      // claim [h, h + k): another wavefront of this workgroup may have been faster - then look again from the new head
+      uint32_t won = 0;
+      if (wlane == 0) won = atomicCAS(&s_head, h, h + k) == h ? 1u : 0u;
+      if (__builtin_amdgcn_readfirstlane(won) == 0u) continue;
+      n_tok = k;
+      {
         const uint32_t sl = static_cast<uint32_t>(__shfl(static_cast<uint32_t>(tok & 0xFFFFull), static_cast<int>(grp * 8), 64));
         const uint32_t sq = static_cast<uint32_t>(__shfl(static_cast<uint32_t>((tok >> 16) & 0xFFFFFFFFull), static_cast<int>(grp * 8), 64));
         if (grp < k) { my_slot = sl & static_cast<uint32_t>(kTokSlotMask); tok_move = (sl >> 15) & 1u; tok_seq = sq; }
-        break;
       }
-      if (k != 0u && t_first == 0) t_first = now;
-      if (k == 0u) { ++empty_polls; __builtin_amdgcn_s_sleep(8); }
+      break;
     }
     if (!go) break;
-    wdone += n_tok;
     const uint64_t pf_t1 = PROF ? wall_clock64() : 0;
     if constexpr (PROF) { pf_idle += pf_t1 - pf_t0; pf_n += 1; pf_act += n_tok; }
 
@@ -298,19 +283,10 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
     // ---- the pass.  A token that answers a request (its sequence field is not 0) may be here before the wavefront that sent
     // the request - early, in the middle of its own pass - has put the slot back: req_seq[slot] is written last, behind that
     // pass's drained stores, so the slot is whole once it shows the token's sequence number.  (Same CU, same L1: no acquire.)
-    if (my_slot != kNoSlot && tok_seq != 0u) {
-      while (g_ld(ar.req_seq + my_slot) != tok_seq) {
-        if (wall_clock64() - t_start > pa.cap_ticks) {
-          if (lane == 0 && atomicAdd(&pc->dbg[0], 1u) == 0u) { pc->dbg[1] = my_slot; pc->dbg[2] = tok_seq; pc->dbg[3] = g_ld(ar.req_seq + my_slot); pc->dbg[4] = 0xEEEEu; }
-          if (lane == 0) atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTimeout));
-          my_slot = kNoSlot;      // (its other holder is still at work: the slot is not touched; k_pipe_settle takes its answer over)
-          break;
-        }
-        __builtin_amdgcn_s_sleep(2);
-      }
-    }
-    const bool on = my_slot != kNoSlot;
-    const uint32_t slot = on ? my_slot : 0u;
+    // Everything the pass needs of its slots is asked for in ONE batch - the publication word, the answer's granules (speculatively:
+    // they are where the token says), the slot's state, its path image, the leaf's key - and checked afterwards; only a slot that
+    // turns out not to be back yet (rare) costs a second round (round 4, second half: four dependent round trips became two).
+    const uint32_t slot = my_slot != kNoSlot ? my_slot : 0u;
     c.slot = slot;
     uint32_t st = kGrpIdle;
     uint8_t final_state = kSlotWaitEval;
@@ -334,17 +310,44 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
     uint32_t sims_done = 0, sims_mem = 0, l0_hits = 0;
     bool rec_ok = true, answered = false;
     uint64_t cur_key = 0;
+    unsigned long long g0 = 0, g1 = 0;
+    PendRec pr_in{};
+    uint32_t seq_now = 0;
+    for (;;) {
+      if (my_slot != kNoSlot) {
+        seq_now = g_ld(ar.req_seq + slot);
+        if (tok_seq != 0u) {
+          if (lane < static_cast<uint32_t>(GM::M)) g0 = g_ld(res + lane);
+          if (lane <= static_cast<uint32_t>(P)) g1 = g_ld(res + kResV + lane);
+        }
+        pr_in = ar.pend[static_cast<size_t>(slot) * G + lane];
+        cur_key = ar.leaf_key[slot];
+        c.load();
+      }
+      const bool stale = my_slot != kNoSlot && tok_seq != 0u && seq_now != tok_seq;
+      if (__ballot(stale) == 0ull) break;
+      if (stale) {      // the slot's last holder is still storing it: wait for the publication, then ask again (for every group: rare)
+        while (g_ld(ar.req_seq + slot) != tok_seq) {
+          if (wall_clock64() - t_start > pa.cap_ticks) {
+            if (lane == 0 && atomicAdd(&pc->dbg[0], 1u) == 0u) { pc->dbg[1] = slot; pc->dbg[2] = tok_seq; pc->dbg[3] = g_ld(ar.req_seq + slot); pc->dbg[4] = 0xEEEEu; }
+            if (lane == 0) atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTimeout));
+            my_slot = kNoSlot;      // (its other holder is still at work: the slot is not touched; k_pipe_settle takes its answer over)
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+    }
+    const bool on = my_slot != kNoSlot;
     if (on) {
-      c.load();
       cp = c.gs.player;
       tb = c.tree_base(cp);
       root = AZMI_SEL(c.t_root, cp);
       goal = (c.flags & kFlagCapped) ? c.seat_cap_visits(cp) : c.seat_visits(cp);
       fpu_root = c.seat_fpu_zero(cp) ? 0.0f : ep.fpu_reduction;
-      seq = g_ld(ar.req_seq + slot);
+      seq = seq_now;
       rec_ok = (c.flags & kFlagPendRec) != 0;
       st = kGrpReady;
-      const PendRec pr_in = ar.pend[static_cast<size_t>(slot) * G + lane];
       { const NodeRec* rr = ar.nodes + tb + root; root_n = rr->n; root_v = rr->v; root_meta = rr->meta; }
       lv_node = pr_in.node; lv_n = pr_in.n; lv_pp = pr_in.pp_mv & 0xFFu;
       lv_q = pr_in.q; lv_d = pr_in.d; lv_v = pr_in.v;
@@ -352,12 +355,13 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
       lf_mv = pr_in.pp_mv >> 8;
       lf_c0 = meta_ch0(lf_meta); lf_k = meta_nch(lf_meta); lf_term = meta_term(lf_meta); lf_player = meta_player(lf_meta);
       if (c.flags & kFlagReqOut) {
-        // the answer of the slot's request: its granules (on their way at the latest: the net workgroup sent the token after them)
-        cur_key = ar.leaf_key[slot];
-        unsigned long long g0 = 0, g1 = 0;
+        // the answer of the slot's request: its granules (asked for with the batch above; on their way at the latest - the net
+        // workgroup sent the token after them -, so a granule that is not there yet is simply asked for again)
         for (uint32_t spins = 0;; ++spins) {
-          if (lane < static_cast<uint32_t>(GM::M)) g0 = g_ld(res + lane);
-          if (lane <= static_cast<uint32_t>(P)) g1 = g_ld(res + kResV + lane);
+          if (spins != 0u || tok_seq == 0u) {
+            if (lane < static_cast<uint32_t>(GM::M)) g0 = g_ld(res + lane);
+            if (lane <= static_cast<uint32_t>(P)) g1 = g_ld(res + kResV + lane);
+          }
           const bool ok = (lane >= static_cast<uint32_t>(GM::M) || static_cast<uint32_t>(g0 >> 32) == seq) &&
                           (lane > static_cast<uint32_t>(P) || static_cast<uint32_t>(g1 >> 32) == seq);
           // (all eight lanes of the group agree through a group-wide AND of ok)
@@ -614,18 +618,20 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
       }
       c.store(final_state);
     }
-    // everything this pass wrote is in L2 before any of its tokens is out (workgroup scope: the slots stay on this CU)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // the slot is whole: publish it (the word a token's taker waits for)
-    if (on && lane == 0) g_st(ar.req_seq + slot, seq);
     // ---- tokens out, into this workgroup's own ring: READY tokens for the slots whose next answer is at hand (the requests went
-    // out when their leaves were found), READY tokens with the move bit for the slots whose next step is the move step's
+    // out when their leaves were found), READY tokens with the move bit for the slots whose next step is the move step's.  The
+    // ring TICKET is drawn before the stores have drained (it only reserves positions: its round trip and the drain overlap); the
+    // tokens themselves go out behind the drain.
     {
       const bool tok_out = on && lane == 0 && (st == kGrpReady || listed);
       const unsigned long long rm = __ballot(tok_out);
+      uint32_t base = 0;
+      if (rm && wlane == 0) base = atomicAdd(&wc->rtail, static_cast<uint32_t>(__popcll(rm)));
+      // everything this pass wrote is in L2 before any of its tokens is out (workgroup scope: the slots stay on this CU)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // the slot is whole: publish it (the word a token's taker waits for)
+      if (on && lane == 0) g_st(ar.req_seq + slot, seq);
       if (rm) {
-        uint32_t base = 0;
-        if (wlane == 0) base = atomicAdd(&wc->rtail, static_cast<uint32_t>(__popcll(rm)));
         base = __builtin_amdgcn_readfirstlane(base);
         if (tok_out) {
           const uint32_t pos = base + static_cast<uint32_t>(__popcll(rm & ((1ull << (grp * 8)) - 1ull)));
@@ -660,7 +666,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(&pe->tree_done, 1u);
+  if (threadIdx.x == 0) { wc->rhead = s_head; atomicAdd(&pe->tree_done, 1u); }
 }
 
 // ---- net side -----------------------------------------------------------------------------------------------------------------------
