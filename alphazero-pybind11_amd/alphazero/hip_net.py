@@ -254,7 +254,10 @@ def fold(net, precision="bf16"):
     ap, bp = (t.cpu() for t in bn_affine(net.pi_bn))
     wh = torch.cat([sd["v_conv.weight"][:, :, 0, 0] * av[:, None], sd["pi_conv.weight"][:, :, 0, 0] * ap[:, None]], 0)
     blob += conv(wh.numpy()) + _f32(torch.cat([bv, bp]))
-    blob += _f32(sd["v_fc1.weight"].t().contiguous()) + _f32(sd["v_fc1.bias"])       # [32][hidden]
+    # value fc1 for v_mfma_f32_16x16x4_f32 (csrc/leafnet_c4.h): A-fragments [hidden / 16][2][64 lanes][4]
+    if spec.v_fc_hidden % 16:
+        raise RuntimeError("the Connect4-family tile wants v_fc_hidden to be a multiple of 16")
+    blob += _f32_frags(sd["v_fc1.weight"].numpy()) + _f32(sd["v_fc1.bias"])
     blob += _f32(sd["v_fc2.weight"]) + _f32(sd["v_fc2.bias"])
     # flat policy head: the reference's feature order is (c, h, w) -> c*HW + p.  The kernel contracts one pixel position p at
     # a time on the bf16 matrix pipe, logits[m] += W_p[m][c] h[c][p], with W and h split into bf16 high + low parts:

@@ -232,7 +232,7 @@ int azmi_net_create(const azmi_net_desc* d, const void* blob, size_t blob_bytes,
   if (!(d->height == 6 && d->width == 7)) return nfail(AZMI_ERR_INVALID, "leaf net kernel: board %dx%d not instantiated", d->height, d->width);
   if (d->in_channels != 4) return nfail(AZMI_ERR_INVALID, "leaf net kernel: %d input planes not instantiated (Connect4 has 4)", d->in_channels);
   if (d->depth < 1 || d->depth > c4::MAXDEPTH) return nfail(AZMI_ERR_INVALID, "leaf net kernel: 1..%d residual blocks", c4::MAXDEPTH);
-  if (d->v_hidden > 256 || d->num_players + 1 > 4 || d->num_moves > 16) return nfail(AZMI_ERR_INVALID, "head sizes out of range");
+  if (d->v_hidden > 256 || d->v_hidden % 16 || d->num_players + 1 > 4 || d->num_moves > 16) return nfail(AZMI_ERR_INVALID, "head sizes out of range (v_hidden: a multiple of 16, at most 256)");
   if (blob_bytes != azmi_net_blob_bytes(d)) return nfail(AZMI_ERR_INVALID, "weight blob is %zu bytes, expected %zu", blob_bytes, azmi_net_blob_bytes(d));
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return nfail(AZMI_ERR_NO_DEVICE, "no HIP device: libazmi has no CPU path");

@@ -31,7 +31,7 @@ struct NetPtrs {           // device pointers into the folded weight blob
   const uint8_t* blocks;   // per block: a1[64] b1[64] c1[64] (fp32) | conv1 frags | conv2 frags
   const uint8_t* head_w;   // [2 ks][4 mt] fragments (rows 0-31 value conv, 32-63 policy conv)
   const float* head_b;     // [64]
-  const float* v_fc1_w;    // [32][v_hidden]  (transposed on the host)
+  const float* v_fc1_w;    // f32 A-fragments [v_hidden / 16][2][64 lanes][4] (hip_net._f32_frags)
   const float* v_fc1_b;    // [v_hidden]
   const float* v_fc2_w;    // [P+1][v_hidden]
   const float* v_fc2_b;    // [P+1]
@@ -165,6 +165,11 @@ struct PipeIO {
   unsigned long long* l0;
   const uint32_t* l0_entry;
   const unsigned long long* key;
+  // the tile's input, as the request carried it: stones of player 0 at bb[b], of player 1 at bb[8 + b] (bit = h * 7 + w), the player to
+  // move at player[b] (connect4_gs.cc:131-149: planes 0 / 1 the stones, plane 2 + player all ones) - the stem builds its im2col
+  // operand straight from these bits (round 4: no float planes staged in LDS, no reads of them: ~3 us of a 60 us tile)
+  const unsigned long long* bb;
+  const uint32_t* player;
 };
 __device__ __forceinline__ uint32_t pipe_io_tag(unsigned long long key, uint32_t k) {     // = pipe_l0_tag (pipe_types.h)
   unsigned long long x = key + 0x9E3779B97F4A7C15ULL * (k + 1u);
@@ -265,7 +270,32 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
   // ---- stem: im2col of the CIN input planes, B[k = tap*CIN + ci][pixel] (k < 64), one thread per pixel --------------
   wait_vm<6>();                      // input planes + stem fragments have landed (chunks 0-2 stay in flight)
   barrier_lds();
-  if (tid < NPIX) {
+  if constexpr (PIPE) {
+    static_assert(CIN == 4, "the packed-position stem is Connect4's: two stone planes + two player planes");
+    if (tid < NPIX) {
+      const int b = tid / PIX, p = tid % PIX, h = p / BW, w = p % BW;
+      const unsigned long long s0 = pio->bb[b], s1 = pio->bb[8 + b];
+      const uint32_t one2 = pio->player[b] == 0u ? 0x3F80u : 0u, one3 = pio->player[b] == 1u ? 0x3F80u : 0u;     // bf16 1.0 = 0x3F80
+      // per tap: is the neighbour on the board, and the two stone bits there (k = tap * 4 + ci: two taps per 8-element plane entry)
+      uint32_t e01[9], on[9];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
+        const bool ok = hh >= 0 && hh < BH && ww >= 0 && ww < BW;
+        const int q = ok ? hh * BW + ww : 0;
+        const uint32_t v0 = ok ? static_cast<uint32_t>(s0 >> q) & 1u : 0u, v1 = ok ? static_cast<uint32_t>(s1 >> q) & 1u : 0u;
+        e01[tap] = v0 * 0x3F80u | v1 * 0x3F800000u;      // (ci 0, ci 1) as two bf16
+        on[tap] = ok ? (one2 | one3 << 16) : 0u;          // (ci 2, ci 3)
+      }
+#pragma unroll
+      for (int pl = 0; pl < (9 * CIN + 7) / 8; ++pl) {
+        u32x4 o;
+        o[0] = e01[2 * pl]; o[1] = on[2 * pl];
+        o[2] = 2 * pl + 1 < 9 ? e01[2 * pl + 1 < 9 ? 2 * pl + 1 : 0] : 0u; o[3] = 2 * pl + 1 < 9 ? on[2 * pl + 1 < 9 ? 2 * pl + 1 : 0] : 0u;
+        *reinterpret_cast<u32x4*>(act + pl * PLANE + tid * 16) = o;
+      }
+    }
+  } else if (tid < NPIX) {
     const int b = tid / PIX, p = tid % PIX, h = p / BW, w = p % BW;
     const float* rb = raw + b * (CIN * PIX);
 #pragma unroll
@@ -554,11 +584,19 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
   }
   if constexpr (DBG == 8) { if (hacc[0][0][0] == 12345.678f) v_out[0] = hacc[1][1][1] + hacc[2][2][2]; return; }   // timing: ... + head 1x1 conv
   // (the value head's FC operands are requested now - the head accumulators are about to die - and land during the policy FC)
-  float w1[HC], w1b = 0.0f;           // value fc1 column of this thread (weights transposed on the host: [32][v_hidden])
-  const int o1 = tid < Hd ? tid : 0;
+  // value fc1 on the exact-fp32 matrix pipe (v_mfma_f32_16x16x4_f32, the boards as the 16 columns; round 4 - the VALU form, one
+  // hidden unit per thread, was 4.3 us of a lone wavefront per SIMD): this wave's output tiles wave, wave + 4, ... of 16 units, the
+  // weights in A-fragment order [tile][k group of 16][lane][4] (element j of lane l = W[16 tile + (l & 15)][16 group + 4 j + (l >> 4)])
+  constexpr int FT = 4;               // output tiles per wave: v_hidden <= 256
+  const int ntile = Hd >> 4;
+  f32x4 fa[FT][2], fb1[FT];
 #pragma unroll
-  for (int i = 0; i < HC; ++i) w1[i] = np.v_fc1_w[i * Hd + o1];
-  w1b = np.v_fc1_b[o1];
+  for (int i = 0; i < FT; ++i) {
+    const int t = wave + NWV * i, tt = t < ntile ? t : 0;
+    fa[i][0] = reinterpret_cast<const f32x4*>(np.v_fc1_w)[(tt * 2 + 0) * 64 + lane];
+    fa[i][1] = reinterpret_cast<const f32x4*>(np.v_fc1_w)[(tt * 2 + 1) * 64 + lane];
+    fb1[i] = *reinterpret_cast<const f32x4*>(np.v_fc1_b + tt * 16 + quad * 4);
+  }
   float w2[MAXP1][4], w2b[MAXP1];     // value fc2: this lane's hidden units lane + 64 k
 #pragma unroll
   for (int o = 0; o < MAXP1; ++o) {
@@ -637,20 +675,25 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
     for (int w = 0; w < NWV; ++w) a += part[(w * 16 + m) * 16 + b];
     logits[b * (MAXP1 + MAXM) + MAXP1 + m] = a;
   }
-  if (tid < Hd) {            // value fc1
-    float acc[TBW];
+  {                          // value fc1: hidden[unit][board] = relu(W1 pooled + b1), 8 exact-fp32 MFMAs per tile of 16 units
 #pragma unroll
-    for (int b = 0; b < TBW; ++b) acc[b] = w1b;
+    for (int i = 0; i < FT; ++i) {
+      const int t = wave + NWV * i;
+      if (t < ntile) {
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int i = 0; i < HC; i += 4) {          // (the pooled features four at a time: 48 LDS reads instead of 192; same sum order)
+        for (int g = 0; g < 2; ++g)
 #pragma unroll
-      for (int b = 0; b < TBW; ++b) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(vpool + b * HC + i);
-        acc[b] += w1[i] * x[0]; acc[b] += w1[i + 1] * x[1]; acc[b] += w1[i + 2] * x[2]; acc[b] += w1[i + 3] * x[3];
+          for (int j = 0; j < 4; ++j) {
+            const float bq = col < TBW ? vpool[col * HC + g * 16 + j * 4 + quad] : 0.0f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][g][j], bq, acc, 0, 0, 0);
+          }
+        if (col < TBW) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vh[col * 256 + t * 16 + quad * 4 + r] = fmaxf(acc[r] + fb1[i][r], 0.0f);
+        }
       }
     }
-#pragma unroll
-    for (int b = 0; b < TBW; ++b) vh[b * 256 + tid] = fmaxf(acc[b], 0.0f);
   }
   barrier_lds();
   for (int b = wave; b < TBW; b += NWV) {      // value fc2: a wave per board, lane l sums hidden units l, l + 64, ...

@@ -675,23 +675,6 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
 // stones, plane 2 + player all ones), run the 3- or the 6-board tile, write the (v, pi) granules of every board, again.
 // Leaves when the epoch is over: stop is up, every tree workgroup has left and the ring is empty.
 constexpr uint32_t kPipeXs = 512;      // bytes of claim scratch behind the tile's LDS
-template <class TG>
-__device__ __forceinline__ void pipe_stage_planes(uint8_t* lds, const uint32_t* xs, uint32_t tid) {
-  constexpr int PIX = azmi_net_dev::c4::PIX;
-  float* const raw = reinterpret_cast<float*>(lds + TG::RING_OFF + 4 * azmi_net_dev::c4::CHUNK_BYTES);
-  if (tid < static_cast<uint32_t>(TG::TBW * PIX)) {
-    const uint32_t b = tid / PIX, p = tid % PIX;
-    const unsigned long long* xb = reinterpret_cast<const unsigned long long*>(xs + 32);
-    const unsigned long long b0 = xb[b], b1 = xb[8 + b];
-    const uint32_t pl = xs[24 + b];
-    float* rb = raw + b * (4 * PIX);
-    rb[0 * PIX + p] = static_cast<float>((b0 >> p) & 1ull);
-    rb[1 * PIX + p] = static_cast<float>((b1 >> p) & 1ull);
-    rb[2 * PIX + p] = pl == 0u ? 1.0f : 0.0f;
-    rb[3 * PIX + p] = pl == 1u ? 1.0f : 0.0f;
-  }
-}
-
 // MODE 0: the 3- and the 6-board tile (by what the claim brought), 1: the 6-board tile only, 2: the 3-board tile only
 // X3: the bf16x3 tier's tiles (Tile<.., SPLIT>: weights and activations as bf16 high + low parts, three MFMAs per product - the north
 // star's 1e-5 on the matrix cores); 16 activation planes, so ONE workgroup per CU, beside which a tree workgroup still fits
@@ -823,7 +806,8 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
     if (n == 0) break;
     if (tid == 0) { atomicAdd(&pc->tiles, 1ull); atomicAdd(&pc->tile_boards, static_cast<unsigned long long>(n)); }
     __syncthreads();
-    c4::PipeIO pio{pa.res, xs + 8, xs + 16, kResStride, kResV, pa.l0, xs + 96, reinterpret_cast<const unsigned long long*>(xs + 32) + 16};
+    c4::PipeIO pio{pa.res, xs + 8, xs + 16, kResStride, kResV, pa.l0, xs + 96, reinterpret_cast<const unsigned long long*>(xs + 32) + 16,
+                   reinterpret_cast<const unsigned long long*>(xs + 32), xs + 24};
     // the weight pointers are made opaque per pass: otherwise the tile's loads of its (pass-invariant) head weights are
     // hoisted out of this loop and sit in ~120 registers for the whole tile (spills)
     NetPtrs npi = np;
@@ -831,12 +815,10 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
     asm volatile("" : "+s"(npi.v_fc1_b), "+s"(npi.v_fc2_w), "+s"(npi.v_fc2_b), "+s"(npi.pi_fc_w), "+s"(npi.pi_fc_b));
     if (MODE == 2 || (MODE == 0 && n <= static_cast<uint32_t>(TSmall::TBW))) {
       if constexpr (MODE != 1) {
-        pipe_stage_planes<TSmall>(lds_pipe, xs, tid);
         c4::tile<TSmall, 4, 4, 16, 0, true>(nd, npi, nullptr, nullptr, nullptr, TSmall::TBW, nullptr, nullptr, 0u, lds_pipe, &pio);
       }
     } else {
       if constexpr (MODE != 2) {
-        pipe_stage_planes<TBig>(lds_pipe, xs, tid);
         c4::tile<TBig, 4, 4, 16, 0, true>(nd, npi, nullptr, nullptr, nullptr, TBig::TBW, nullptr, nullptr, 0u, lds_pipe, &pio);
       }
     }
