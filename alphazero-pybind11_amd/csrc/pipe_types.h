@@ -4,13 +4,13 @@
 // workers and the batcher threads (play_manager.cc:258-600, concurrent_queue.h:130-217).  The lock-step round of
 // engine.hip (cache insert -> k_sim -> k_net_move, one after the other, a round as long as its slowest slot) gave that up.
 // Here it is back, on the device: for one EPOCH
-//   * tree wavefronts (persistent, k_pipe_tree) draw eight slot tokens at a time from the READY ring - a slot is not bound to a
-//     wavefront -, run simulation after simulation for them and hand every leaf that needs the net to
+//   * tree wavefronts (persistent, k_pipe_tree) take the slot tokens that have arrived in their WORKGROUP's READY ring (a slot has a
+//     home workgroup for the epoch, not a home wavefront), run simulation after simulation for them - and the rare, register-hungry
+//     move step (round_slot<kMover>: the simulation that completes a search and the move behind it, a game start) as a non-inlined
+//     function when a token carries the move bit - and hand every leaf that needs the net to
 //   * net workgroups (persistent, k_pipe_net) that pull 3- or 6-board tiles off a request ring as soon as leaves exist
-//     (continuous batching), write the (v, pi) answers as result granules and put the answered slots back into the READY ring;
-//   * mover wavefronts (the last wavefront of a few tree workgroups) serve the MOVE ring: slots whose next step is the rare,
-//     register-hungry one - the simulation that completes a search and the move behind it, a game start - run the lock-step
-//     engine's own move step (round_slot<kMover>) there and go straight back into the pipeline.
+//     (continuous batching), write the (v, pi) answers as result granules, drop them into the in-epoch answer table and put the
+//     answered slots back into their home workgroups' READY rings.
 // The sides talk through HBM only:
 //   * request ring: a tree group takes a ticket (tail) and writes its leaf as kReqGranules 8-byte granules
 //     {tag16 | payload48}: stones of player 0 | stones of player 1 | slot, player | sequence number; a net workgroup draws a
