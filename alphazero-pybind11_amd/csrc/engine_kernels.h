@@ -1210,9 +1210,14 @@ struct SlotCtx {
   }
   // position-cache probe (play_manager.cc:592-597): on a hit the cached (pi, v) land in the slot's rows AND in
   // registers (lane m: pi[m] in hit_pi, lane i <= P: v[i] in hit_v) for a process_result later in this round
-  // (before_loads: see wave_shard_find - the pipeline asks for its in-epoch answer table's granules there)
-  template <class F = NoPreload>
-  __device__ __forceinline__ bool cache_lookup(uint64_t key, uint32_t group, float& hit_pi, float& hit_v, F&& before_loads = F()) const {
+  // (before_loads: see wave_shard_find - the pipeline asks for its answer table's granules there; early(cslot, pi, v): called when
+  // the shard's keys are back - true = the caller has the answer already (its answer table's granules were valid), the payload
+  // round trip is skipped; after_hit(pi, v): called with a shard hit's payload (the pipeline copies it into its answer table))
+  struct NoEarly { __device__ __forceinline__ bool operator()(int, float&, float&) const { return false; } };
+  struct NoAfter { __device__ __forceinline__ void operator()(float, float) const {} };
+  template <class F = NoPreload, class E = NoEarly, class A = NoAfter>
+  __device__ __forceinline__ bool cache_lookup(uint64_t key, uint32_t group, float& hit_pi, float& hit_v, F&& before_loads = F(), E&& early = E(),
+                                               A&& after_hit = A()) const {
     uint32_t sh;
     const CacheView cache = ep.num_groups == 1 ? ar.cache : ar.caches[group];   // one cache per model group
     const int cslot = wave_shard_find<G>(cache, key, lane, &sh, before_loads);
@@ -1229,12 +1234,16 @@ struct SlotCtx {
         atomicMin(f, 3u);
       }
     }
-    if (cslot < 0) return false;
-    const float* sp = cache.policy + (static_cast<size_t>(sh) * cache.cap + cslot) * M;
-    const float* sv = cache.value + (static_cast<size_t>(sh) * cache.cap + cslot) * (P + 1);
     static_assert(M <= G, "one lane per policy entry");
-    hit_pi = lane < static_cast<uint32_t>(M) ? sp[lane] : 0.0f;
-    hit_v = lane <= static_cast<uint32_t>(P) ? sv[lane] : 0.0f;
+    bool have = early(cslot, hit_pi, hit_v);
+    if (!have) {
+      if (cslot < 0) return false;
+      const float* sp = cache.policy + (static_cast<size_t>(sh) * cache.cap + cslot) * M;
+      const float* sv = cache.value + (static_cast<size_t>(sh) * cache.cap + cslot) * (P + 1);
+      hit_pi = lane < static_cast<uint32_t>(M) ? sp[lane] : 0.0f;
+      hit_v = lane <= static_cast<uint32_t>(P) ? sv[lane] : 0.0f;
+      after_hit(hit_pi, hit_v);
+    }
     if (lane < static_cast<uint32_t>(M)) ar.pi[static_cast<size_t>(slot) * M + lane] = hit_pi;
     if (lane <= static_cast<uint32_t>(P)) ar.v[static_cast<size_t>(slot) * (P + 1) + lane] = hit_v;
     return true;

@@ -67,7 +67,8 @@ struct PipeCtl {          // zeroed when the pipeline is created; lives across e
   unsigned long long epochs;
   unsigned long long sims_total;    // simulations of all epochs so far (k_pipe_settle adds an epoch's count)
   unsigned long long l0_hits;       // probes the S3-FIFO missed and the in-epoch answer table answered
-  uint32_t dbg[20];       // diagnostics of the first time-out: slot, sequence number, group state, the tags seen
+  uint32_t lost_total, pad3;        // requests given up on and sent again (see PipeEpoch::lost), all epochs
+  uint32_t dbg[18];       // diagnostics of the first time-out: slot, sequence number, group state, the tags seen
   // tree-side time accounting (100 MHz ticks / counts, summed over wavefronts): [0] in simulation passes, [1] polling with no
   // group ready, [2] passes, [3] groups active in them, [4] polls, [5] in the request step, [6] wavefront lifetimes, [7] net: ticks
   // waiting for requests, [8] net: ticks in tiles
@@ -88,7 +89,9 @@ struct PipeEpoch {        // an allocation of its own, zeroed before every epoch
   uint32_t ins_done;      // insert-log entries already applied (the first insert launch runs while the net side drains)
   uint32_t moved;         // move steps run by the mover wavefronts in this epoch
   uint32_t tree_late_n, net_late_n;   // calibration launches: workgroups that only started when the others had left
-  uint32_t pad1[17];
+  uint32_t lost;          // ring positions a net workgroup gave up on in this epoch (their requests were overwritten a lap later before
+                          // it could look: the workgroup had been switched out): k_pipe_settle re-queues those slots, no error
+  uint32_t pad1[16];
 };
 static_assert(sizeof(PipeEpoch) == 256, "memset block: a multiple of 16 bytes");
 
@@ -111,6 +114,7 @@ struct PipeArrays {
   // shard.  No lock, no ordering: a reader accepts an entry only when all ten granules carry the tag of ITS key.  NULL = off.
   unsigned long long* l0;     // [l0_mask + 1][kResStride]
   uint32_t l0_mask;
+  uint32_t l0_wb;             // 1: a shard hit the table did not have is copied into it
   // insert log: (key, pi, v) of every answer consumed in the epoch; applied to the position cache between epochs
   uint64_t* ins_key;          // [ins_cap]
   float* ins_pi;              // [ins_cap][M]

@@ -542,31 +542,37 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
         c.flags = needs_net ? (c.flags | kFlagLeafNeedsNet) : (c.flags & ~kFlagLeafNeedsNet);
         if (needs_net) {
           const uint64_t key = GM::key(leaf);
-          // the in-epoch answer table's granules are asked for first and land with the S3-FIFO shard's keys: no extra round trip
-          // (issued inside the lookup, once the shard is known and right in front of its key loads: the two travel together)
+          // the answer table's granules are asked for inside the lookup, right behind the S3-FIFO shard's key loads (one round trip for
+          // both); when they are valid - all ten carry this key's tags - the answer is there and the shard's payload round trip is
+          // skipped; a shard hit the table did not have is copied into it (ten granule stores, nothing waits for them)
           unsigned long long l0a = 0, l0b = 0;
           const unsigned long long* const le = pa.l0 + static_cast<size_t>(pipe_l0_entry(key, pa.l0_mask)) * kResStride;
-          bool hit = ep.cache_on && c.cache_lookup(key, 0u, reg_pi, reg_v, [&]() {
-            if (pa.l0) {
-              if (lane < static_cast<uint32_t>(GM::M)) l0a = g_ld(le + lane);
-              if (lane <= static_cast<uint32_t>(P)) l0b = g_ld(le + kResV + lane);
-            }
-          });
-          if (ep.cache_on && pa.l0 && !hit) {
-            // an answer of THIS epoch (the S3-FIFO gets it at the boundary): valid only when all ten granules carry this key's tags
-            uint32_t okg = ((lane >= static_cast<uint32_t>(GM::M) || static_cast<uint32_t>(l0a >> 32) == pipe_l0_tag(key, lane)) &&
-                            (lane > static_cast<uint32_t>(P) || static_cast<uint32_t>(l0b >> 32) == pipe_l0_tag(key, kResV + lane))) ? 1u : 0u;
-            okg &= c.bcast(okg, 0) & c.bcast(okg, 1) & c.bcast(okg, 2) & c.bcast(okg, 3) & c.bcast(okg, 4) & c.bcast(okg, 5) & c.bcast(okg, 6);
-            okg = c.bcast(okg, 0);
-            if (okg) {
-              reg_pi = lane < static_cast<uint32_t>(GM::M) ? __uint_as_float(static_cast<uint32_t>(l0a)) : 0.0f;
-              reg_v = lane <= static_cast<uint32_t>(P) ? __uint_as_float(static_cast<uint32_t>(l0b)) : 0.0f;
-              if (lane < static_cast<uint32_t>(GM::M)) ar.pi[static_cast<size_t>(slot) * GM::M + lane] = reg_pi;
-              if (lane <= static_cast<uint32_t>(P)) ar.v[static_cast<size_t>(slot) * (P + 1) + lane] = reg_v;
-              l0_hits += 1;
-              hit = true;
-            }
-          }
+          const bool hit = ep.cache_on && c.cache_lookup(key, 0u, reg_pi, reg_v,
+            [&]() {
+              if (pa.l0) {
+                if (lane < static_cast<uint32_t>(GM::M)) l0a = g_ld(le + lane);
+                if (lane <= static_cast<uint32_t>(P)) l0b = g_ld(le + kResV + lane);
+              }
+            },
+            [&](int cslot, float& o_pi, float& o_v) -> bool {
+              if (!pa.l0) return false;
+              uint32_t okg = ((lane >= static_cast<uint32_t>(GM::M) || static_cast<uint32_t>(l0a >> 32) == pipe_l0_tag(key, lane)) &&
+                              (lane > static_cast<uint32_t>(P) || static_cast<uint32_t>(l0b >> 32) == pipe_l0_tag(key, kResV + lane))) ? 1u : 0u;
+              okg &= c.bcast(okg, 0) & c.bcast(okg, 1) & c.bcast(okg, 2) & c.bcast(okg, 3) & c.bcast(okg, 4) & c.bcast(okg, 5) & c.bcast(okg, 6);
+              okg = c.bcast(okg, 0);
+              if (!okg) return false;
+              o_pi = lane < static_cast<uint32_t>(GM::M) ? __uint_as_float(static_cast<uint32_t>(l0a)) : 0.0f;
+              o_v = lane <= static_cast<uint32_t>(P) ? __uint_as_float(static_cast<uint32_t>(l0b)) : 0.0f;
+              if (cslot < 0) l0_hits += 1;          // (the shard counted a miss: the host moves these to the hits)
+              return true;
+            },
+            [&](float h_pi, float h_v) {
+              if (pa.l0 && pa.l0_wb) {
+                unsigned long long* const we = pa.l0 + static_cast<size_t>(pipe_l0_entry(key, pa.l0_mask)) * kResStride;
+                if (lane < static_cast<uint32_t>(GM::M)) g_st(we + lane, (static_cast<unsigned long long>(pipe_l0_tag(key, lane)) << 32) | __float_as_uint(h_pi));
+                if (lane <= static_cast<uint32_t>(P)) g_st(we + kResV + lane, (static_cast<unsigned long long>(pipe_l0_tag(key, kResV + lane)) << 32) | __float_as_uint(h_v));
+              }
+            });
           if (!hit) {
             // the request goes out NOW, not when the pass ends (its slowest group may run two more simulations): the net's
             // answer and this pass's tail overlap.  Nobody can take the slot before it is back: see the pass start.
@@ -762,8 +768,12 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
         }
         // nothing there: is the epoch over?  stop is up (no tree workgroup that arrives from now on sends anything) and every
         // tree workgroup that did arrive has left: tail is final, and what lies at or beyond it never comes
-        uint32_t over = 0;
+        uint32_t over = 0, stale = 0;
         if (tid == 0) {
+          // A position more than half a ring BEHIND the tail will never show this lap's tag again: its request was overwritten a lap
+          // later before this workgroup could look (seen once in ~1e10 requests: the workgroup sat 2 laps behind - it had been
+          // switched out).  Give the window up; the slot stays unanswered and k_pipe_settle sends its request again.
+          if (static_cast<int32_t>(g_ld(&pc->tail) - (w0 + wdone)) > static_cast<int32_t>(kPipeRing / 2u)) stale = 1;
           if (g_ld(&pc->err)) over = 1;
           else if (g_ld(&pe->stop) != 0u && g_ld(&pe->tree_done) >= g_ld(&pe->tree_arrived)) {
             const uint32_t t2 = g_ld(&pc->tail);
@@ -783,6 +793,11 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
           }
         }
         if (__builtin_amdgcn_readfirstlane(over)) { n = 0; break; }
+        if (__builtin_amdgcn_readfirstlane(stale)) {
+          if (tid == 0) { atomicAdd(&pe->lost, left); atomicAdd(&pc->lost_total, left); }
+          wdone = wn;          // (the next turn of the loop draws a new window)
+          continue;
+        }
         __builtin_amdgcn_s_sleep(16);
       }
       if (tid < 8) {
@@ -863,10 +878,11 @@ __global__ void k_pipe_settle(EngineParams ep, EngineArrays ar, PipeArrays pa) {
     val[i] = __uint_as_float(static_cast<uint32_t>(g));
   }
   if (bad) {
-    // the request was never answered - only when the net side left early (a pipeline error: time cap, engine stop).  The slot goes back
+    // the request was never answered - the net side left early (a pipeline error: time cap, engine stop) or gave a ring position up
+    // (PipeEpoch::lost).  The slot goes back
     // to the form the move step leaves a leaf in (kSlotQueued: planes + packed position written, no request out), so the next epoch
     // sends the request again and a lock-step round lists it: the engine stays usable after the error has been reported.
-    if (g_ld(&pa.ctl->err) == 0u && ar.ctl->stop == 0u) { atomicOr(&pa.ctl->err, static_cast<uint32_t>(kPipeErrTag)); return; }
+    if (g_ld(&pa.ctl->err) == 0u && ar.ctl->stop == 0u && pa.ep->lost == 0u) { atomicOr(&pa.ctl->err, static_cast<uint32_t>(kPipeErrTag)); return; }
     Connect4::State leaf;
     leaf.bb[0] = ar.leaf_pos[0 * static_cast<size_t>(ep.S) + slot];
     leaf.bb[1] = ar.leaf_pos[1 * static_cast<size_t>(ep.S) + slot];
@@ -951,6 +967,7 @@ struct PipeState {
   uint32_t tree_wgs_alloc = 0, tree_wgs_min = 1, tree_wgs_default = 1, places = 0;
   bool balance = false;
   unsigned long long bal_sims = 0, bal_boards = 0;
+  uint32_t lost_seen = 0;           // PipeCtl::lost_total already reported
 };
 void pipe_state_free(PipeState* p) {
   if (!p) return;
@@ -1245,15 +1262,17 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
     if (rc != AZMI_OK) return rc;
   }
   if (pm->ep.cache_on && !pa.l0 && !tree_only && getenv("AZMI_PIPE_NO_L0") == nullptr) {
-    // the in-epoch answer table: a power of two of 128-byte entries, an eighth of the S3-FIFO's entries, between 4 Ki and 4 Mi
-    // (512 MB: an epoch of the headline brings ~200 k answers)
-    uint64_t want = static_cast<uint64_t>(pm->ar.cache.shards) * kWaveCap / 8u;
+    // the answer table: a power of two of 128-byte entries, about half the S3-FIFO's entries, between 4 Ki and 64 Mi (8 GB of the
+    // 288: an epoch of the headline brings ~200 k answers, and shard hits are copied in too - a table hit costs the probe one round
+    // trip, a shard hit two)
+    uint64_t want = static_cast<uint64_t>(pm->ar.cache.shards) * kWaveCap / 2u;
     uint32_t sh = 12;
-    while (sh < 22u && (1ull << sh) < want) ++sh;
+    while (sh < 26u && (1ull << sh) < want) ++sh;
     if (const char* e = getenv("AZMI_PIPE_L0_LOG2")) sh = static_cast<uint32_t>(std::min(26, std::max(4, atoi(e))));
     const int rc = pipe_alloc(ps, pa.l0, (static_cast<size_t>(1) << sh) * kResStride);
     if (rc != AZMI_OK) return rc;
     pa.l0_mask = (1u << sh) - 1u;
+    pa.l0_wb = getenv("AZMI_PIPE_L0_WB") ? static_cast<uint32_t>(atoi(getenv("AZMI_PIPE_L0_WB"))) : 1u;
   }
   // an epoch must end long before the wall-clock cap (a stall detector, 250 ms): with the move step inside the epoch nothing else ends it,
   // so the quota is held to 1024 simulations per slot (~50 ms at the slowest per-slot rate measured)
@@ -1341,6 +1360,10 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
   AZMI_HIP_TRY(hipMemcpyAsync(&hc, pa.ctl, sizeof(hc), hipMemcpyDeviceToHost, st));
   AZMI_HIP_TRY(hipMemcpyAsync(&he, pa.ep, sizeof(he), hipMemcpyDeviceToHost, st));
   AZMI_HIP_TRY(hipStreamSynchronize(st));
+  if (hc.lost_total != ps->lost_seen) {
+    fprintf(stderr, "azmi_run_pipeline: %u request(s) were given up by the net side and sent again (a net workgroup fell more than half a ring behind)\n", hc.lost_total - ps->lost_seen);
+    ps->lost_seen = hc.lost_total;
+  }
   if (!tree_only && !hc.err) pipe_balance(ps, hc);       // (takes effect with the next call's first epoch)
   if (out_stats) {
     out_stats[0] = hc.tiles; out_stats[1] = hc.tile_boards; out_stats[2] = he.sims; out_stats[3] = he.tree_arrived;
@@ -1361,7 +1384,7 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
   }
   if (hc.err) {
     fprintf(stderr, "pipeline dbg:");
-    for (int i = 0; i < 20; ++i) fprintf(stderr, " %u", hc.dbg[i]);
+    for (int i = 0; i < 18; ++i) fprintf(stderr, " %u", hc.dbg[i]);
     fprintf(stderr, "\n");
   }
   if (hc.err) {
@@ -1381,7 +1404,7 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
                           hc.dbg[1], hc.dbg[2], hc.dbg[3], hc.dbg[8], hc.dbg[9], hc.dbg[10], hc.dbg[11], hc.dbg[12], hc.dbg[13]);
   if (hc.err && getenv("AZMI_PIPE_DEBUG")) {
     fprintf(stderr, "pipeline dbg:");
-    for (int i = 0; i < 20; ++i) fprintf(stderr, " %u", hc.dbg[i]);
+    for (int i = 0; i < 18; ++i) fprintf(stderr, " %u", hc.dbg[i]);
     fprintf(stderr, "\n");
   }
   return AZMI_OK;
