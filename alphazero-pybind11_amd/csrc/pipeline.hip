@@ -1262,17 +1262,18 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
     if (rc != AZMI_OK) return rc;
   }
   if (pm->ep.cache_on && !pa.l0 && !tree_only && getenv("AZMI_PIPE_NO_L0") == nullptr) {
-    // the answer table: a power of two of 128-byte entries, about half the S3-FIFO's entries, between 4 Ki and 64 Mi (8 GB of the
-    // 288: an epoch of the headline brings ~200 k answers, and shard hits are copied in too - a table hit costs the probe one round
-    // trip, a shard hit two)
-    uint64_t want = static_cast<uint64_t>(pm->ar.cache.shards) * kWaveCap / 2u;
+    // the answer table: a power of two of 128-byte entries, an eighth of the S3-FIFO's entries, between 4 Ki and 4 Mi (512 MB: an
+    // epoch of the headline brings ~200 k answers).  Measured and dropped: a table of half the S3-FIFO's entries (64 Mi = 8 GB at the
+    // headline's cache) with shard hits copied into it - a table hit costs the probe one round trip instead of two, but 8 GB more of
+    // randomly probed memory made every probe slower: 4968 games/s against 5667 (AZMI_PIPE_L0_LOG2 / AZMI_PIPE_L0_WB bring it back)
+    uint64_t want = static_cast<uint64_t>(pm->ar.cache.shards) * kWaveCap / 8u;
     uint32_t sh = 12;
-    while (sh < 26u && (1ull << sh) < want) ++sh;
+    while (sh < 22u && (1ull << sh) < want) ++sh;
     if (const char* e = getenv("AZMI_PIPE_L0_LOG2")) sh = static_cast<uint32_t>(std::min(26, std::max(4, atoi(e))));
     const int rc = pipe_alloc(ps, pa.l0, (static_cast<size_t>(1) << sh) * kResStride);
     if (rc != AZMI_OK) return rc;
     pa.l0_mask = (1u << sh) - 1u;
-    pa.l0_wb = getenv("AZMI_PIPE_L0_WB") ? static_cast<uint32_t>(atoi(getenv("AZMI_PIPE_L0_WB"))) : 1u;
+    pa.l0_wb = getenv("AZMI_PIPE_L0_WB") ? static_cast<uint32_t>(atoi(getenv("AZMI_PIPE_L0_WB"))) : 0u;
   }
   // an epoch must end long before the wall-clock cap (a stall detector, 250 ms): with the move step inside the epoch nothing else ends it,
   // so the quota is held to 1024 simulations per slot (~50 ms at the slowest per-slot rate measured)
