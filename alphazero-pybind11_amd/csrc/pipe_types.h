@@ -114,6 +114,7 @@ struct PipeArrays {
   // shard.  No lock, no ordering: a reader accepts an entry only when all ten granules carry the tag of ITS key.  NULL = off.
   unsigned long long* l0;     // [l0_mask + 1][kResStride]
   uint32_t l0_mask;
+  uint32_t test_drop;         // test hook: the request at this ring position goes out with a foreign lap tag (0 = off)
   uint32_t l0_wb;             // 1: a shard hit the table did not have is copied into it
   // insert log: (key, pi, v) of every answer consumed in the epoch; applied to the position cache between epochs
   uint64_t* ins_key;          // [ins_cap]

@@ -583,8 +583,11 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
             pos = c.bcast(pos, 0);
             const uint64_t payload = lane == 0 ? leaf.bb[0] : lane == 1 ? leaf.bb[1] : lane == 2 ? (static_cast<uint64_t>(slot) | (static_cast<uint64_t>(leaf.player) << 16))
                                                                                                   : static_cast<uint64_t>(seq);
+            // (test hook, AZMI_PIPE_TEST_DROP = n: the request at ring position n goes out with a foreign lap tag - what an entry looks
+            // like that was overwritten before its net workgroup could read it; tests/test_gpu_pipeline.py)
+            const unsigned long long rtag = (pa.test_drop != 0u && pos == pa.test_drop) ? pipe_lap_tag(pos + kPipeRing) : pipe_lap_tag(pos);
             if (lane < kReqGranules)
-              g_st(pa.ring + static_cast<size_t>(pos & (kPipeRing - 1u)) * kReqGranules + lane, (pipe_lap_tag(pos) << 48) | (payload & kMask48));
+              g_st(pa.ring + static_cast<size_t>(pos & (kPipeRing - 1u)) * kReqGranules + lane, (rtag << 48) | (payload & kMask48));
             // (the packed position stays with the slot: a request dropped by a pipeline error is sent again from there)
             if (lane < 3u) ar.leaf_pos[static_cast<size_t>(lane) * ep.S + slot] = lane == 2u ? static_cast<uint64_t>(leaf.player) : payload;
             st = kGrpPush;
@@ -728,6 +731,8 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
       uint32_t sl = 0xFFFFFFFFu, sq = 0, pl = 0;
       unsigned long long b0 = 0, b1 = 0;
       uint64_t t_first = 0;                  // when the first request of this pass was seen
+      uint32_t final_looks = 0;              // empty looks at the window after the tree side had left
+      uint64_t t_empty = 0;                  // when this claim first found nothing at its position
       for (;;) {
         if (wdone == wn) {
           // the window's size follows the load (MODE 0): with a backlog of requests the 6-board tile (capacity: 28 M evaluations/s on
@@ -773,11 +778,17 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
           // A position more than half a ring BEHIND the tail will never show this lap's tag again: its request was overwritten a lap
           // later before this workgroup could look (seen once in ~1e10 requests: the workgroup sat 2 laps behind - it had been
           // switched out).  Give the window up; the slot stays unanswered and k_pipe_settle sends its request again.
-          if (static_cast<int32_t>(g_ld(&pc->tail) - (w0 + wdone)) > static_cast<int32_t>(kPipeRing / 2u)) stale = 1;
+          // (looked at only once this position has been empty for 0.5 ms: `tail` is the hottest word of the pipeline - every request
+          // is a returning add on it - and 384 idle workgroups reading it on every poll slowed every request: the headline lost 12 %)
+          if (t_empty == 0) t_empty = now;
+          if (now - t_empty > 50000ull && static_cast<int32_t>(g_ld(&pc->tail) - (w0 + wdone)) > static_cast<int32_t>(kPipeRing / 2u)) stale = 1;
           if (g_ld(&pc->err)) over = 1;
           else if (g_ld(&pe->stop) != 0u && g_ld(&pe->tree_done) >= g_ld(&pe->tree_arrived)) {
             const uint32_t t2 = g_ld(&pc->tail);
             if (static_cast<int32_t>(t2 - (w0 + wdone)) <= 0) over = 1;
+            // every writer has left (and drained its stores before it was counted done): a position below the final tail that is
+            // still not there on the second look after that will never be - given up like a stale one
+            else if (++final_looks >= 2u) stale = 1;
           }
           // the stall detector: cap x 1.25 once the tree side is there; while no tree workgroup has started yet (the host was held up
           // between the two launches, the tree kernel waits for a place) four caps - long enough for any scheduling hiccup, short
@@ -1287,6 +1298,7 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
   pa.cap_ticks = static_cast<unsigned long long>(cap_ms * 1e5);
   // (an epoch that runs long simply ends at a quarter of the cap; AZMI_PIPE_SOFT_MS sets another limit - the error-path test asks for
   // one beyond the cap)
+  pa.test_drop = getenv("AZMI_PIPE_TEST_DROP") ? static_cast<uint32_t>(strtoul(getenv("AZMI_PIPE_TEST_DROP"), nullptr, 0)) : 0u;
   pa.soft_ticks = getenv("AZMI_PIPE_SOFT_MS") ? static_cast<unsigned long long>(atof(getenv("AZMI_PIPE_SOFT_MS")) * 1e5) : pa.cap_ticks / 4u;
   // the lock-step kernels leave the key of a round's leaf in cache_keys for the next round's insert: none of that here
   if (pm->ep.cache_on) AZMI_HIP_TRY(hipMemsetAsync(pm->ar.cache_keys, 0, sizeof(uint64_t) * pm->ep.S, st));

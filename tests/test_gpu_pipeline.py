@@ -549,3 +549,25 @@ def test_in_epoch_answer_table_is_transparent_and_saves_evaluations(monkeypatch)
     xa, xn = pa.counters(), pn.counters()
     assert xa["sims"] == xn["sims"] and xa["evals"] < xn["evals"]
     assert xa["cache_hits"] + xa["cache_misses"] == xn["cache_hits"] + xn["cache_misses"]      # same probes, more of them answered
+
+
+def test_a_request_the_net_side_cannot_read_is_given_up_and_sent_again(monkeypatch, capfd):
+    """round 4: once in ~1e10 requests a net workgroup was found waiting at a ring position two laps behind the tail (it had been
+    switched out; its request was overwritten a lap later) - and it waited until the stall cap.  Now a position more than half a ring
+    behind the tail is given up, the slot stays unanswered, k_pipe_settle puts it back into the move step's kSlotQueued form and the
+    next epoch sends the request again: no stall, no error, same games.  The hook writes ONE request (ring position 3000) with a
+    foreign lap tag - what an overwritten entry looks like."""
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=17), spec)
+    S, seed = 512, 321
+    pp = _selfplay_params(az, S, 150, cache=0)            # no cache: every leaf is a request, the tail moves fast
+    monkeypatch.setenv("AZMI_PIPE_TEST_DROP", "3000")
+    pa, (ra, ca), stats = _pipeline_games(az, pp, seed, hip, sims_per_epoch=S * 256)
+    monkeypatch.delenv("AZMI_PIPE_TEST_DROP")
+    assert "given up by the net side and sent again" in capfd.readouterr().err
+    pb, (rb, cb) = _lockstep_games(az, pp, seed, hip)
+    assert pa.games_completed() == pb.games_completed() == S
+    sa, sb = _sorted_log(ra, ca), _sorted_log(rb, cb)
+    assert np.array_equal(sa[0], sb[0]) and np.array_equal(sa[1], sb[1])
