@@ -1201,10 +1201,11 @@ extern "C" int azmi_pipeline_supported(azmi_pm* pm, azmi_net* net) {
 
 // The two sides share the chip's workgroup places, and how many each needs follows the share of leaves that reach the net.  Measured
 // at 4096 slots on 512 places (M simulations/s by tree workgroups; m = evaluations per simulation):
-//   m = 0.19 (128 M-entry cache):  96 / 112 / 128 / 144 / 160 -> 88 / 96-101 / 96-105 / 100 / 88
-//   m = 0.29 (32 M entries):       80 /  96 / 112 / 128       -> 70 / 78 / 80 / 77
-//   m = 0.55 (200 k entries):      48 /  64 /  80 / 128       -> 43 / 51 / 52 / 39
-// i.e. the best count falls about linearly with m: tree workgroups = places x (0.297 - 0.293 m), between a quarter and 1.5 x the
+//   m = 0.17 (128 M-entry cache, answer table on, the final tree pass):  128 / 144 / 160      -> 114 / 118 / 116
+//   m = 0.19 (128 M entries, first half of the round):                    96 / 112 / 128 / 144 / 160 -> 88 / 96-101 / 96-105 / 100 / 88
+//   m = 0.29 (32 M entries, first half):                                  80 /  96 / 112 / 128 -> 70 / 78 / 80 / 77
+//   m = 0.55 (200 k entries, first half):                                 48 /  64 /  80 / 128 -> 43 / 51 / 52 / 39
+// i.e. the best count falls about linearly with m: tree workgroups = places x (0.342 - 0.367 m), between a third and 1.5 x the
 // default (AZMI_PIPE_BALANCE_A / _B set other coefficients).  m is taken over the PREVIOUS call; the count moves 8 workgroups per call,
 // between epochs only (a slot's home is slot % tree workgroups for one epoch at a time; between epochs a slot is whole in HBM).  The
 // games do not depend on it (a slot's game is a function of its seed alone).
@@ -1213,7 +1214,7 @@ void pipe_balance(PipeState* ps, const PipeCtl& hc) {
   const unsigned long long ds = hc.sims_total - ps->bal_sims, db = hc.tile_boards - ps->bal_boards;
   ps->bal_sims = hc.sims_total; ps->bal_boards = hc.tile_boards;
   if (ds < 4096ull || db == 0ull) return;
-  double ca = 0.297, cb = 0.293;
+  double ca = 0.342, cb = 0.367;
   if (const char* e = getenv("AZMI_PIPE_BALANCE_A")) ca = atof(e);
   if (const char* e = getenv("AZMI_PIPE_BALANCE_B")) cb = atof(e);
   const double m = static_cast<double>(db) / static_cast<double>(ds);
