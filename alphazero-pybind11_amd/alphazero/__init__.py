@@ -1627,9 +1627,29 @@ def run_pipeline(pm, net, epochs, sims_per_epoch, stream=None):
     st = pm._stream_arg(stream)
     out = (C.c_uint64 * 16)()
     check(lib.azmi_run_pipeline(pm._h, None if net is None else net._h, int(epochs), int(sims_per_epoch), st, out))
-    keys = ("tiles", "tile_boards", "last_epoch_sims", "tree_wgs_started", "net_wgs_started", "last_epoch_inserts", "net_wgs", "tree_wgs",
-            "tree_latest_start_us", "net_latest_start_us", "net_kernel_us", "tree_kernel_us", "epochs", "host_enqueue_us", "calibration_rounds", "answer_table_hits")
-    return dict(zip(keys, (int(x) for x in out)))
+    return dict(zip(_PIPE_KEYS, (int(x) for x in out)))
+
+
+_PIPE_KEYS = ("tiles", "tile_boards", "last_epoch_sims", "tree_wgs_started", "net_wgs_started", "last_epoch_inserts", "net_wgs", "tree_wgs",
+              "tree_latest_start_us", "net_latest_start_us", "net_kernel_us", "tree_kernel_us", "epochs", "host_enqueue_us", "calibration_rounds",
+              "answer_table_hits")
+
+
+def pipeline_supported_groups(pm, nets):
+    """azmi_pipeline_supported_groups: True when azmi_run_pipeline_groups can drive this engine with nets[g] behind model group g
+    (None = a group of RANDOM seats)."""
+    arr = (C.c_void_p * len(nets))(*[None if n is None else n._h for n in nets])
+    return bool(lib.azmi_pipeline_supported_groups(pm._h, arr, len(nets)))
+
+
+def run_pipeline_groups(pm, nets, epochs, sims_per_epoch, stream=None):
+    """azmi_run_pipeline_groups: run_pipeline with one net per model group (play_past: the new model behind group 0, the past one
+    behind group 1; None = the reference's RandPlayer)."""
+    st = pm._stream_arg(stream)
+    out = (C.c_uint64 * 16)()
+    arr = (C.c_void_p * len(nets))(*[None if n is None else n._h for n in nets])
+    check(lib.azmi_run_pipeline_groups(pm._h, arr, len(nets), int(epochs), int(sims_per_epoch), st, out))
+    return dict(zip(_PIPE_KEYS, (int(x) for x in out)))
 
 
 def pipeline_log_duplicates(pm):

@@ -703,6 +703,7 @@ struct SeatTables {
   uint32_t num_groups = 1, num_perms = 1, max_visits = 0;
   bool all_random = true, any_random = false;
   bool any_gumbel = false, any_seat_resign = false, any_playout = false;
+  uint32_t nn_groups = 0;        // bit g: a seat of model group g evaluates with the net
   std::vector<uint32_t> words;   // [perm][seat][kSeatWords]
 };
 int build_seat_tables(const azmi_play_params* p, uint32_t P, SeatTables* out) {
@@ -748,6 +749,7 @@ int build_seat_tables(const azmi_play_params* p, uint32_t P, SeatTables* out) {
       out->any_playout = out->any_playout || playout;
       if (capv > 0xFFFFFFu) return fail(AZMI_ERR_INVALID, "seat_cap_visits too large");
       out->all_random = out->all_random && (rnd || playout); out->any_random = out->any_random || rnd || playout;
+      if (!(rnd || playout)) out->nn_groups |= 1u << g;
       out->max_visits = std::max(out->max_visits, visits);
       if (p->playout_cap_randomization) out->max_visits = std::max(out->max_visits, capv);
       // per-seat Gumbel / resign overrides, play_manager.cc:116-176
@@ -819,6 +821,7 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
   ep.cap_visits = params->playout_cap_depth;
   ep.num_perms = seats.num_perms; ep.num_groups = seats.num_groups;
   pm->all_random = seats.all_random;
+  pm->nn_groups = seats.nn_groups;
   pm->any_playout = seats.any_playout;
   pm->split_rounds = game == AZMI_GAME_CONNECT4 && !seats.any_gumbel && !seats.any_playout && getenv("AZMI_NO_SPLIT") == nullptr;
   ep.cpuct = params->cpuct; ep.start_temp = params->start_temp; ep.final_temp = params->final_temp;

@@ -1268,6 +1268,17 @@ __device__ __forceinline__ uint32_t round_slot(const EngineParams& ep, const Eng
   // cache_keys[slot] = key of the leaf this slot sends to the net this round (0 = none): the next round's
   // k_cache_insert stores the net's answer under it (PlayManager::update_inferences -> insert_many)
   if (st == kSlotDone || st == kSlotEnded) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; return 0xFFu; }
+  if constexpr (!kMover) {
+    if (st == kSlotQueued) {   // a leaf the asynchronous pipeline left unsent (k_pipe_settle after an error): on this round's eval list, as in k_sim
+      if (lane == 0) {
+        const uint32_t group = ar.leaf_group[slot];
+        if (ep.cache_on) ar.cache_keys[slot] = cache_key(ar.leaf_key[slot]);
+        ar.eval_list[static_cast<size_t>(group) * ep.S + atomicAdd(&ar.ctl->eval_count[group], 1u)] = slot;
+        ar.sstate[slot] = kSlotWaitEval;
+      }
+      return kSlotWaitEval;
+    }
+  }
   SlotCtx<GM> c(ep, ar, slot, lane);
   c.trace(100);
   c.load();

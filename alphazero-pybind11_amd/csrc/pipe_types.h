@@ -43,6 +43,7 @@ __host__ __device__ inline uint64_t pipe_lap_tag(uint32_t pos) { return static_c
 // the per-workgroup READY rings have 1 << shift entries
 // in-epoch answer table: entry of a key, tag of granule k of that key's entry (splitmix finaliser; k + 1 keeps granule 0's tag apart from the index)
 __host__ __device__ inline uint64_t pipe_mix64(uint64_t x) { x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 27; x *= 0x94D049BB133111EBULL; x ^= x >> 31; return x; }
+constexpr unsigned long long kPipeGroupSalt = 0xA5A5A5A55A5A5A5AULL;      // model group 1's lines of the one answer table: its keys under this salt
 __host__ __device__ inline uint32_t pipe_l0_entry(uint64_t key, uint32_t mask) { return static_cast<uint32_t>(pipe_mix64(key ^ 0x5851F42D4C957F2DULL)) & mask; }
 __host__ __device__ inline uint32_t pipe_l0_tag(uint64_t key, uint32_t k) { return static_cast<uint32_t>(pipe_mix64(key + 0x9E3779B97F4A7C15ULL * (k + 1u)) >> 32) | 1u; }
 __host__ __device__ inline uint64_t pipe_lap_tag_r(uint32_t pos, uint32_t shift) { return static_cast<uint64_t>(((pos >> shift) & 0x7FFFu) + 1u); }
@@ -59,7 +60,9 @@ static_assert(sizeof(PipeWg) == 128, "one line");
 struct PipeCtl {          // zeroed when the pipeline is created; lives across epochs.  Every hot word on a 128-byte line of its own
   uint32_t head; uint32_t pad0[31];             // ring entries claimed by net workgroups (free-running: position = value % kPipeRing)
   uint32_t tail; uint32_t pad1[31];             // ring tickets handed out to tree wavefronts (free-running)
-  uint32_t pad4[32], pad5[32], pad6[32], pad7[32];   // (round 3: the chip-wide READY / MOVE ring positions; now per workgroup, PipeWg)
+  uint32_t head1; uint32_t pad4[31];            // the same two words for the request ring of model group 1 (the generic tree kernel
+  uint32_t tail1; uint32_t pad5[31];            // routes a leaf to the ring of its seat's group: one net per group, play_past)
+  uint32_t pad6[32], pad7[32];                  // (round 3: the chip-wide READY / MOVE ring positions; now per workgroup, PipeWg)
   uint32_t err;           // PipeErr bits, sticky: every pipeline kernel leaves at once when it is set
   uint32_t pad2;
   unsigned long long tiles;         // net tiles run
@@ -99,6 +102,11 @@ struct PipeArrays {
   PipeCtl* ctl;
   PipeEpoch* ep;
   unsigned long long* ring;   // [kPipeRing][kReqGranules]
+  unsigned long long* ring1;  // the request ring of model group 1 (NULL: one group)
+  uint32_t n_groups;          // model groups that send requests (1 or 2)
+  uint32_t net_groups;        // bit g: group g has a net behind its ring in this call
+  uint32_t lock_base1;        // first insert lock of group 1's cache in `locks`
+  uint8_t* ins_grp;           // [ins_cap] model group of an insert-log entry (NULL: all group 0)
   unsigned long long* rring;  // [n_tree_wgs][1 << rshift] READY rings: {tag16 | seq32 | move | slot}
   PipeWg* wg;                 // [n_tree_wgs]
   uint32_t rshift;            // log2 of a READY ring's entries (>= twice the slots of a workgroup)

@@ -57,6 +57,11 @@ __device__ __forceinline__ void pipe_push_token(const PipeArrays& pa, uint32_t h
   g_st(pa.rring + ((static_cast<size_t>(home) << pa.rshift) + (pos & ((1u << pa.rshift) - 1u))), (pipe_lap_tag_r(pos, pa.rshift) << 48) | payload);
 }
 
+// request ring of model group g (0 or 1): its tail / head words and its entries
+__device__ __forceinline__ uint32_t* pipe_tail_of(PipeCtl* pc, uint32_t g) { return g ? &pc->tail1 : &pc->tail; }
+__device__ __forceinline__ uint32_t* pipe_head_of(PipeCtl* pc, uint32_t g) { return g ? &pc->head1 : &pc->head; }
+__device__ __forceinline__ unsigned long long* pipe_ring_of(const PipeArrays& pa, uint32_t g) { return g ? pa.ring1 : pa.ring; }
+
 // The epoch's first tokens: one thread per slot.  A slot whose leaf was left by the move step (kSlotQueued) sends its request, a
 // slot with its answer in the (v, pi) rows gets a READY token, a slot whose game has to start a READY token with the move bit.
 __global__ void k_pipe_seed(EngineParams ep, EngineArrays ar, PipeArrays pa) {
@@ -76,12 +81,13 @@ __global__ void k_pipe_seed(EngineParams ep, EngineArrays ar, PipeArrays pa) {
   }
   if (f & kFlagReqOut) { atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTag)); return; }      // (every request was settled)
   if (sst == kSlotQueued) {
-    const uint32_t pos = atomicAdd(&pc->tail, 1u);
+    const uint32_t grp_ = pa.n_groups > 1u ? (ar.leaf_group[slot] & 1u) : 0u;
+    const uint32_t pos = atomicAdd(pipe_tail_of(pc, grp_), 1u);
     uint32_t seq = ar.req_seq[slot] + 1u;
     if (seq == 0u) seq = 1u;
     ar.req_seq[slot] = seq;
     const unsigned long long tag = pipe_lap_tag(pos) << 48;
-    unsigned long long* e = pa.ring + static_cast<size_t>(pos & (kPipeRing - 1u)) * kReqGranules;
+    unsigned long long* e = pipe_ring_of(pa, grp_) + static_cast<size_t>(pos & (kPipeRing - 1u)) * kReqGranules;
     g_st(e + 0, tag | (ar.leaf_pos[0 * static_cast<size_t>(ep.S) + slot] & kMask48));
     g_st(e + 1, tag | (ar.leaf_pos[1 * static_cast<size_t>(ep.S) + slot] & kMask48));
     g_st(e + 2, tag | static_cast<unsigned long long>(slot) | ((ar.leaf_pos[2 * static_cast<size_t>(ep.S) + slot] & 1ull) << 16));
@@ -128,14 +134,15 @@ __device__ __attribute__((noinline)) uint32_t pipe_move_groups(const EngineParam
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (on && res_state == kSlotQueued) {
     if (lane == 0) g_st(ar.req_seq + slot, seq);
+    const uint32_t mg = pa.n_groups > 1u ? (ar.leaf_group[slot] & 1u) : 0u;       // the leaf's model group: its net's ring
     uint32_t pos = 0;
-    if (lane == 0) pos = atomicAdd(&pc->tail, 1u);
+    if (lane == 0) pos = atomicAdd(pipe_tail_of(pc, mg), 1u);
     pos = __shfl(pos, static_cast<int>(grp * 8), 64);
     const size_t S_ = static_cast<size_t>(ep.S);
     const uint64_t payload = lane == 0 ? ar.leaf_pos[0 * S_ + slot] : lane == 1 ? ar.leaf_pos[1 * S_ + slot]
                            : lane == 2 ? (static_cast<uint64_t>(slot) | ((ar.leaf_pos[2 * S_ + slot] & 1ull) << 16)) : static_cast<uint64_t>(seq);
     if (lane < kReqGranules)
-      g_st(pa.ring + static_cast<size_t>(pos & (kPipeRing - 1u)) * kReqGranules + lane, (pipe_lap_tag(pos) << 48) | (payload & kMask48));
+      g_st(pipe_ring_of(pa, mg) + static_cast<size_t>(pos & (kPipeRing - 1u)) * kReqGranules + lane, (pipe_lap_tag(pos) << 48) | (payload & kMask48));
   }
   {
     const unsigned long long em = __ballot(on && lane == 0 && res_state == kSlotEnded);
@@ -154,7 +161,9 @@ __device__ __attribute__((noinline)) uint32_t pipe_move_groups(const EngineParam
 
 // NT: threads per workgroup (256: four wavefronts beside one net workgroup on a CU)
 // PROF: the time accounting of AZMI_PIPE_PROF (a build of its own: the counters cost a dozen registers of a kernel that has none to spare)
-template <class GM, int NT, bool PROF>
+// TWO: two model groups (play_past: a leaf goes to the S3-FIFO, the answer table lines and the request ring of the group its seat belongs
+// to) - a build of its own for the same reason
+template <class GM, int NT, bool PROF, bool TWO = false>
 __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
   constexpr int G = GM::GROUP;
   constexpr int P = GM::P;
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
     c.slot = slot;
     uint32_t st = kGrpIdle;
     uint8_t final_state = kSlotWaitEval;
-    uint32_t cp = 0, root = 0, goal = 0, seq = 0;
+    uint32_t cp = 0, root = 0, goal = 0, seq = 0, mg = 0;
     size_t tb = 0;
     float fpu_root = 0.0f;
     uint32_t* const path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
@@ -341,6 +350,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
     const bool on = my_slot != kNoSlot;
     if (on) {
       cp = c.gs.player;
+      if constexpr (TWO) mg = c.seat_group(cp) & 1u;        // (no move inside a pass: one player to move, one model group, also for the answer the pass starts with)
       tb = c.tree_base(cp);
       root = AZMI_SEL(c.t_root, cp);
       goal = (c.flags & kFlagCapped) ? c.seat_cap_visits(cp) : c.seat_visits(cp);
@@ -401,6 +411,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
           const uint32_t idx = base + static_cast<uint32_t>(__popcll(am & ((1ull << (grp * 8)) - 1ull)));
           if (idx < pa.ins_cap) {
             if (lane == 0) pa.ins_key[idx] = cur_key;
+            if constexpr (TWO) { if (lane == 1) pa.ins_grp[idx] = static_cast<uint8_t>(mg); }
             if (lane < static_cast<uint32_t>(GM::M)) pa.ins_pi[static_cast<size_t>(idx) * GM::M + lane] = reg_pi;
             if (lane <= static_cast<uint32_t>(P)) pa.ins_v[static_cast<size_t>(idx) * (P + 1) + lane] = reg_v;
           } else if (lane == 0) {
@@ -546,8 +557,9 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
           // both); when they are valid - all ten carry this key's tags - the answer is there and the shard's payload round trip is
           // skipped; a shard hit the table did not have is copied into it (ten granule stores, nothing waits for them)
           unsigned long long l0a = 0, l0b = 0;
-          const unsigned long long* const le = pa.l0 + static_cast<size_t>(pipe_l0_entry(key, pa.l0_mask)) * kResStride;
-          const bool hit = ep.cache_on && c.cache_lookup(key, 0u, reg_pi, reg_v,
+          const uint64_t lkey = TWO ? key ^ (mg ? kPipeGroupSalt : 0ull) : key;        // the answer table is one: group 1's lines under a salted key
+          const unsigned long long* const le = pa.l0 + static_cast<size_t>(pipe_l0_entry(lkey, pa.l0_mask)) * kResStride;
+          const bool hit = ep.cache_on && c.cache_lookup(key, mg, reg_pi, reg_v,
             [&]() {
               if (pa.l0) {
                 if (lane < static_cast<uint32_t>(GM::M)) l0a = g_ld(le + lane);
@@ -556,8 +568,8 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
             },
             [&](int cslot, float& o_pi, float& o_v) -> bool {
               if (!pa.l0) return false;
-              uint32_t okg = ((lane >= static_cast<uint32_t>(GM::M) || static_cast<uint32_t>(l0a >> 32) == pipe_l0_tag(key, lane)) &&
-                              (lane > static_cast<uint32_t>(P) || static_cast<uint32_t>(l0b >> 32) == pipe_l0_tag(key, kResV + lane))) ? 1u : 0u;
+              uint32_t okg = ((lane >= static_cast<uint32_t>(GM::M) || static_cast<uint32_t>(l0a >> 32) == pipe_l0_tag(lkey, lane)) &&
+                              (lane > static_cast<uint32_t>(P) || static_cast<uint32_t>(l0b >> 32) == pipe_l0_tag(lkey, kResV + lane))) ? 1u : 0u;
               okg &= c.bcast(okg, 0) & c.bcast(okg, 1) & c.bcast(okg, 2) & c.bcast(okg, 3) & c.bcast(okg, 4) & c.bcast(okg, 5) & c.bcast(okg, 6);
               okg = c.bcast(okg, 0);
               if (!okg) return false;
@@ -568,9 +580,9 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
             },
             [&](float h_pi, float h_v) {
               if (pa.l0 && pa.l0_wb) {
-                unsigned long long* const we = pa.l0 + static_cast<size_t>(pipe_l0_entry(key, pa.l0_mask)) * kResStride;
-                if (lane < static_cast<uint32_t>(GM::M)) g_st(we + lane, (static_cast<unsigned long long>(pipe_l0_tag(key, lane)) << 32) | __float_as_uint(h_pi));
-                if (lane <= static_cast<uint32_t>(P)) g_st(we + kResV + lane, (static_cast<unsigned long long>(pipe_l0_tag(key, kResV + lane)) << 32) | __float_as_uint(h_v));
+                unsigned long long* const we = pa.l0 + static_cast<size_t>(pipe_l0_entry(lkey, pa.l0_mask)) * kResStride;
+                if (lane < static_cast<uint32_t>(GM::M)) g_st(we + lane, (static_cast<unsigned long long>(pipe_l0_tag(lkey, lane)) << 32) | __float_as_uint(h_pi));
+                if (lane <= static_cast<uint32_t>(P)) g_st(we + kResV + lane, (static_cast<unsigned long long>(pipe_l0_tag(lkey, kResV + lane)) << 32) | __float_as_uint(h_v));
               }
             });
           if (!hit) {
@@ -579,7 +591,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
             cur_key = key;
             seq = seq + 1u == 0u ? 1u : seq + 1u;
             uint32_t pos = 0;
-            if (lane == 0) pos = atomicAdd(&pc->tail, 1u);
+            if (lane == 0) pos = atomicAdd(TWO ? pipe_tail_of(pc, mg) : &pc->tail, 1u);
             pos = c.bcast(pos, 0);
             const uint64_t payload = lane == 0 ? leaf.bb[0] : lane == 1 ? leaf.bb[1] : lane == 2 ? (static_cast<uint64_t>(slot) | (static_cast<uint64_t>(leaf.player) << 16))
                                                                                                   : static_cast<uint64_t>(seq);
@@ -587,9 +599,10 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
             // like that was overwritten before its net workgroup could read it; tests/test_gpu_pipeline.py)
             const unsigned long long rtag = (pa.test_drop != 0u && pos == pa.test_drop) ? pipe_lap_tag(pos + kPipeRing) : pipe_lap_tag(pos);
             if (lane < kReqGranules)
-              g_st(pa.ring + static_cast<size_t>(pos & (kPipeRing - 1u)) * kReqGranules + lane, (rtag << 48) | (payload & kMask48));
+              g_st((TWO ? pipe_ring_of(pa, mg) : pa.ring) + static_cast<size_t>(pos & (kPipeRing - 1u)) * kReqGranules + lane, (rtag << 48) | (payload & kMask48));
             // (the packed position stays with the slot: a request dropped by a pipeline error is sent again from there)
             if (lane < 3u) ar.leaf_pos[static_cast<size_t>(lane) * ep.S + slot] = lane == 2u ? static_cast<uint64_t>(leaf.player) : payload;
+            if constexpr (TWO) { if (lane == 3u) ar.leaf_group[slot] = static_cast<uint8_t>(mg); }
             st = kGrpPush;
           }
         }
@@ -678,6 +691,163 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
   if (threadIdx.x == 0) { wc->rhead = s_head; atomicAdd(&pe->tree_done, 1u); }
 }
 
+// ---- the generic tree kernel: every search variant, two model groups -----------------------------------------------------------
+// Engines the fast kernel above does not drive - Gumbel seats (k_sim is plain PUCT), two model groups (play_past: a leaf goes to the
+// net of its seat's group) - run EVERY step through the lock-step engine's own round_slot<kMover> (pipe_move_groups): a pass = the
+// tokens that have arrived, for an answer token first the answer (granules -> the slot's (v, pi) rows, the insert log), then one
+// step per slot (backup, a move if the search is complete, descent to the next leaf, cache probe), then a request (sent by
+// pipe_move_groups, into the ring of the leaf's group) or - when the answer is at hand - the slot's token back into the ring.  One
+// simulation per slot and pass instead of the fast kernel's several, but no round barrier: a slot waits for its own answer only.
+// Same rings, granules, home workgroups, epoch boundaries and exit conditions as k_pipe_tree.
+template <class GM, int NT>
+__global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
+  constexpr int P = GM::P;
+  const EngineParams& ep = ka.ep;
+  const EngineArrays& ar = ka.ar;
+  const PipeArrays& pa = ka.pa;
+  const uint32_t wlane = threadIdx.x & 63u, grp = wlane >> 3, lane = wlane & 7u;
+  const uint64_t t_start = wall_clock64();
+  PipeCtl* const pc = pa.ctl;
+  PipeEpoch* const pe = pa.ep;
+  PipeWg* const wc = pa.wg + blockIdx.x;
+  const uint32_t rmask = (1u << pa.rshift) - 1u;
+  unsigned long long* const myring = pa.rring + (static_cast<size_t>(blockIdx.x) << pa.rshift);
+  if (threadIdx.x == 0) {
+    unsigned long long t0 = atomicCAS(&pe->t0, 0ull, static_cast<unsigned long long>(t_start));
+    if (t0 == 0ull) t0 = t_start;
+    atomicMax(&pe->tree_late, static_cast<uint32_t>(t_start > t0 ? t_start - t0 : 0ull));
+    const uint32_t before = atomicAdd(&pe->tree_arrived, 1u);
+    asm volatile("s_waitcnt vmcnt(0)" :: "v"(before) : "memory");
+  }
+  __syncthreads();
+  if (pa.census_hold != 0u) {        // calibration launch: see k_pipe_tree
+    const unsigned long long t0 = g_ld(&pe->t0);
+    if (threadIdx.x == 0 && t_start > t0 && t_start - t0 >= pa.census_hold) atomicAdd(&pe->tree_late_n, 1u);
+    while (wall_clock64() < t0 + pa.census_hold) __builtin_amdgcn_s_sleep(32);
+    return;
+  }
+  bool go = g_ld(&ar.ctl->stop) == 0 && g_ld(&pc->err) == 0 && g_ld(&pe->stop) == 0;
+  __shared__ uint32_t s_head;
+  if (threadIdx.x == 0) s_head = wc->rhead;
+  __syncthreads();
+  const PipeKernArgs* const kargs = reinterpret_cast<const PipeKernArgs*>(reinterpret_cast<uintptr_t>(__builtin_amdgcn_kernarg_segment_ptr()));
+  while (go) {
+    // ---- tokens (as k_pipe_tree: the arrived prefix of the eight ring positions at the LDS head)
+    uint32_t my_slot = kNoSlot, tok_seq = 0, empty_polls = 0, ctl_word = 0;
+    for (;;) {
+      const uint32_t h = __builtin_amdgcn_readfirstlane(*const_cast<volatile uint32_t*>(&s_head));
+      unsigned long long tok = 0;
+      bool here = false;
+      if (lane == 0) {
+        const uint32_t pos = h + grp;
+        tok = g_ld(myring + (pos & rmask));
+        here = (tok >> 48) == pipe_lap_tag_r(pos, pa.rshift);
+      }
+      if ((empty_polls & 3u) == 0u) {
+        ctl_word = 0;
+        if (wlane == 7) ctl_word = g_ld(&pe->stop) | g_ld(&pc->err) | g_ld(&ar.ctl->stop);
+        else if (wlane == 15) ctl_word = g_ld(&pe->sims) >= pa.quota ? 1u : 0u;
+        else if (wlane == 23) ctl_word = g_ld(&pe->ended);
+        else if (wlane == 31) ctl_word = g_ld(&pe->dead);
+      }
+      uint32_t stop_seen = __builtin_amdgcn_readlane(ctl_word, 7) | __builtin_amdgcn_readlane(ctl_word, 15);
+      {
+        const uint32_t w = __builtin_amdgcn_readlane(ctl_word, 23), d = __builtin_amdgcn_readlane(ctl_word, 31);
+        const uint32_t with_game = ep.S > d ? ep.S - d : 0u;
+        const uint32_t thr = max(1u, static_cast<uint32_t>((static_cast<unsigned long long>(with_game) * pa.idle_num) >> 10));
+        if (w >= thr || w + d >= ep.S) stop_seen = 1u;
+      }
+      const uint64_t now = wall_clock64();
+      if (now - t_start > pa.soft_ticks) stop_seen = 1u;
+      if (now - t_start > pa.cap_ticks) { if (wlane == 0) atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTimeout)); stop_seen = 1u; }
+      if (stop_seen) { if (wlane == 0) g_st(&pe->stop, 1u); go = false; break; }
+      const unsigned long long hm = __ballot(here);
+      uint32_t k = 0;
+      while (k < kTreeWindow && ((hm >> (8 * k)) & 1ull)) ++k;
+      if (k == 0u) { ++empty_polls; __builtin_amdgcn_s_sleep(16); continue; }
+      uint32_t won = 0;
+      if (wlane == 0) won = atomicCAS(&s_head, h, h + k) == h ? 1u : 0u;
+      if (__builtin_amdgcn_readfirstlane(won) == 0u) continue;
+      const uint32_t sl = static_cast<uint32_t>(__shfl(static_cast<uint32_t>(tok & 0xFFFFull), static_cast<int>(grp * 8), 64));
+      const uint32_t sq = static_cast<uint32_t>(__shfl(static_cast<uint32_t>((tok >> 16) & 0xFFFFFFFFull), static_cast<int>(grp * 8), 64));
+      if (grp < k) { my_slot = sl & static_cast<uint32_t>(kTokSlotMask); tok_seq = sq; }
+      break;
+    }
+    if (!go) break;
+    // ---- an answer token: the slot is back once req_seq shows the token's number; its granules become the slot's (v, pi) rows
+    if (my_slot != kNoSlot && tok_seq != 0u) {
+      while (g_ld(ar.req_seq + my_slot) != tok_seq) {
+        if (wall_clock64() - t_start > pa.cap_ticks) { if (lane == 0) atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTimeout)); my_slot = kNoSlot; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    bool answered = false;
+    float reg_pi = 0.0f, reg_v = 0.0f;
+    if (my_slot != kNoSlot && tok_seq != 0u) {
+      const unsigned long long* const res = pa.res + static_cast<size_t>(my_slot) * kResStride;
+      unsigned long long g0 = 0, g1 = 0;
+      for (;;) {
+        if (lane < static_cast<uint32_t>(GM::M)) g0 = g_ld(res + lane);
+        if (lane <= static_cast<uint32_t>(P)) g1 = g_ld(res + kResV + lane);
+        uint32_t okg = ((lane >= static_cast<uint32_t>(GM::M) || static_cast<uint32_t>(g0 >> 32) == tok_seq) &&
+                        (lane > static_cast<uint32_t>(P) || static_cast<uint32_t>(g1 >> 32) == tok_seq)) ? 1u : 0u;
+#pragma unroll
+        for (int i = 1; i < 8; i <<= 1) okg &= static_cast<uint32_t>(__shfl_xor(static_cast<int>(okg), i, 8));
+        if (okg) { answered = true; break; }
+        if (wall_clock64() - t_start > pa.cap_ticks) { if (lane == 0) atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTimeout)); my_slot = kNoSlot; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (answered) {
+        reg_pi = lane < static_cast<uint32_t>(GM::M) ? __uint_as_float(static_cast<uint32_t>(g0)) : 0.0f;
+        reg_v = lane <= static_cast<uint32_t>(P) ? __uint_as_float(static_cast<uint32_t>(g1)) : 0.0f;
+        if (lane < static_cast<uint32_t>(GM::M)) ar.pi[static_cast<size_t>(my_slot) * GM::M + lane] = reg_pi;
+        if (lane <= static_cast<uint32_t>(P)) ar.v[static_cast<size_t>(my_slot) * (P + 1) + lane] = reg_v;
+        if (lane == 0) ar.flags[my_slot] = ar.flags[my_slot] & static_cast<uint8_t>(~kFlagReqOut);
+      }
+    }
+    if (ep.cache_on) {        // PlayManager::update_inferences -> insert_many: logged with the leaf's group, applied after the epoch
+      const unsigned long long am = __ballot(answered && lane == 0);
+      if (am) {
+        uint32_t base = 0;
+        if (wlane == 0) base = atomicAdd(&pe->ins_count, static_cast<uint32_t>(__popcll(am)));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (answered) {
+          const uint32_t idx = base + static_cast<uint32_t>(__popcll(am & ((1ull << (grp * 8)) - 1ull)));
+          if (idx < pa.ins_cap) {
+            if (lane == 0) { pa.ins_key[idx] = ar.leaf_key[my_slot]; if (pa.ins_grp) pa.ins_grp[idx] = ar.leaf_group[my_slot]; }
+            if (lane < static_cast<uint32_t>(GM::M)) pa.ins_pi[static_cast<size_t>(idx) * GM::M + lane] = reg_pi;
+            if (lane <= static_cast<uint32_t>(P)) pa.ins_v[static_cast<size_t>(idx) * (P + 1) + lane] = reg_v;
+          } else if (lane == 0) {
+            g_st(&pe->stop, 1u);
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the rows are in place before the step reads them
+    // ---- one step of every slot of the pass (requests leave inside)
+    const uint32_t rs = pipe_move_groups<GM>(kargs->ep, kargs->ar, kargs->pa, my_slot);
+    // ---- a slot whose next answer is at hand (cache hit, terminal leaf, RANDOM seat) goes straight back into the ring
+    {
+      const bool tok_out = my_slot != kNoSlot && lane == 0 && rs == kSlotWaitEval;
+      const unsigned long long rm = __ballot(tok_out);
+      uint32_t base = 0;
+      if (rm && wlane == 0) base = atomicAdd(&wc->rtail, static_cast<uint32_t>(__popcll(rm)));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (rm) {
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (tok_out) {
+          const uint32_t pos = base + static_cast<uint32_t>(__popcll(rm & ((1ull << (grp * 8)) - 1ull)));
+          g_st(myring + (pos & rmask), (pipe_lap_tag_r(pos, pa.rshift) << 48) | static_cast<unsigned long long>(my_slot));
+        }
+      }
+    }
+  }
+  if (wlane == 0) g_st(&pe->stop, 1u);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) { wc->rhead = s_head; atomicAdd(&pe->tree_done, 1u); }
+}
+
 // ---- net side -----------------------------------------------------------------------------------------------------------------------
 // A persistent workgroup of the leaf net (leafnet_c4.h: 4 waves, one tile of boards through the whole tower): claim up to six
 // requests, read their granules, build the input planes from the packed positions (connect4_gs.cc:131-149: planes 0 / 1 the
@@ -687,8 +857,10 @@ constexpr uint32_t kPipeXs = 512;      // bytes of claim scratch behind the tile
 // MODE 0: the 3- and the 6-board tile (by what the claim brought), 1: the 6-board tile only, 2: the 3-board tile only
 // X3: the bf16x3 tier's tiles (Tile<.., SPLIT>: weights and activations as bf16 high + low parts, three MFMAs per product - the north
 // star's 1e-5 on the matrix cores); 16 activation planes, so ONE workgroup per CU, beside which a tree workgroup still fits
+// Two model groups (play_past: one net per group): np1 = the weights of group 1's net; a workgroup serves ONE group's ring for the
+// whole epoch (its index's parity when both groups have a net behind them, pa.net_groups).
 template <int MODE, bool X3 = false>
-__global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, azmi_net_dev::NetPtrs np, PipeArrays pa) {
+__global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, azmi_net_dev::NetPtrs np, azmi_net_dev::NetPtrs np1, PipeArrays pa) {
   constexpr uint32_t kMaxTake = MODE == 2 ? 3u : 6u;
   constexpr uint64_t kPatienceTicks = 150;       // 1.5 us: how long a request that is there waits for the rest of its window
   using namespace azmi_net_dev;
@@ -703,6 +875,10 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
   const uint64_t t_start = wall_clock64();
   PipeCtl* const pc = pa.ctl;
   PipeEpoch* const pe = pa.ep;
+  const uint32_t mg = pa.net_groups == 3u ? (blockIdx.x & 1u) : (pa.net_groups == 2u ? 1u : 0u);      // this workgroup's model group
+  uint32_t* const q_head = pipe_head_of(pc, mg);
+  uint32_t* const q_tail = pipe_tail_of(pc, mg);
+  const unsigned long long* const q_ring = pipe_ring_of(pa, mg);
   if (tid == 0) {
     unsigned long long t0 = atomicCAS(&pe->t0, 0ull, static_cast<unsigned long long>(t_start));
     if (t0 == 0ull) t0 = t_start;
@@ -741,11 +917,11 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
           uint32_t h = 0, take = kMaxTake;
           if (MODE == 0 && pa.big_at != 0u) {
             uint32_t hd = 0, tl = 0;
-            if (tid == 0) { hd = g_ld(&pc->head); tl = g_ld(&pc->tail); }
+            if (tid == 0) { hd = g_ld(q_head); tl = g_ld(q_tail); }
             const int32_t backlog = static_cast<int32_t>(__builtin_amdgcn_readfirstlane(tl) - __builtin_amdgcn_readfirstlane(hd));
             if (backlog < static_cast<int32_t>(pa.big_at)) take = 3u;
           }
-          if (tid == 0) h = atomicAdd(&pc->head, take);
+          if (tid == 0) h = atomicAdd(q_head, take);
           w0 = __builtin_amdgcn_readfirstlane(h); wn = take; wdone = 0;
         }
         const uint32_t left = wn - wdone;
@@ -753,7 +929,7 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
         if (tid < left) {
           const uint32_t pos = w0 + wdone + tid;
           const unsigned long long want = pipe_lap_tag(pos);
-          const unsigned long long* e = pa.ring + static_cast<size_t>(pos & (kPipeRing - 1u)) * kReqGranules;
+          const unsigned long long* e = q_ring + static_cast<size_t>(pos & (kPipeRing - 1u)) * kReqGranules;
           const unsigned long long a0 = g_ld(e), a1 = g_ld(e + 1), a2 = g_ld(e + 2), a3 = g_ld(e + 3);
           here = (a0 >> 48) == want && (a1 >> 48) == want && (a2 >> 48) == want && (a3 >> 48) == want;
           if (here) {
@@ -781,10 +957,10 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
           // (looked at only once this position has been empty for 0.5 ms: `tail` is the hottest word of the pipeline - every request
           // is a returning add on it - and 384 idle workgroups reading it on every poll slowed every request: the headline lost 12 %)
           if (t_empty == 0) t_empty = now;
-          if (now - t_empty > 50000ull && static_cast<int32_t>(g_ld(&pc->tail) - (w0 + wdone)) > static_cast<int32_t>(kPipeRing / 2u)) stale = 1;
+          if (now - t_empty > 50000ull && static_cast<int32_t>(g_ld(q_tail) - (w0 + wdone)) > static_cast<int32_t>(kPipeRing / 2u)) stale = 1;
           if (g_ld(&pc->err)) over = 1;
           else if (g_ld(&pe->stop) != 0u && g_ld(&pe->tree_done) >= g_ld(&pe->tree_arrived)) {
-            const uint32_t t2 = g_ld(&pc->tail);
+            const uint32_t t2 = g_ld(q_tail);
             if (static_cast<int32_t>(t2 - (w0 + wdone)) <= 0) over = 1;
             // every writer has left (and drained its stores before it was counted done): a position below the final tail that is
             // still not there on the second look after that will never be - given up like a stale one
@@ -798,7 +974,7 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
             // the window position it waits at, 10 us units since its start)
             if (atomicAdd(&pc->dbg[7], 1u) == 0u) {
               pc->dbg[8] = g_ld(&pe->stop); pc->dbg[9] = g_ld(&pe->tree_done); pc->dbg[10] = g_ld(&pe->tree_arrived);
-              pc->dbg[11] = g_ld(&pc->tail); pc->dbg[12] = w0 + wdone; pc->dbg[13] = static_cast<uint32_t>((now - t_start) / 1000u);
+              pc->dbg[11] = g_ld(q_tail); pc->dbg[12] = w0 + wdone; pc->dbg[13] = static_cast<uint32_t>((now - t_start) / 1000u);
             }
             atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrNetTimeout)); g_st(&pe->stop, 1u); over = 1;
           }
@@ -818,7 +994,7 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
         xb[tid] = mine ? b0 : 0ull; xb[8 + tid] = mine ? b1 : 0ull;
         if (pa.l0) {       // the position's cache key (Connect4::key: stones and the player to move) for the in-epoch answer table
           Connect4::State ps_; ps_.bb[0] = b0; ps_.bb[1] = b1; ps_.player = pl; ps_.turn = 0;
-          const unsigned long long k64 = Connect4::key(ps_);
+          const unsigned long long k64 = Connect4::key(ps_) ^ (mg ? kPipeGroupSalt : 0ull);
           xb[16 + tid] = k64;
           xs[96 + tid] = pipe_l0_entry(k64, pa.l0_mask);
         }
@@ -836,7 +1012,7 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
                    reinterpret_cast<const unsigned long long*>(xs + 32), xs + 24};
     // the weight pointers are made opaque per pass: otherwise the tile's loads of its (pass-invariant) head weights are
     // hoisted out of this loop and sit in ~120 registers for the whole tile (spills)
-    NetPtrs npi = np;
+    NetPtrs npi = mg ? np1 : np;
     asm volatile("" : "+s"(npi.stem_w), "+s"(npi.stem_b), "+s"(npi.blocks), "+s"(npi.head_w), "+s"(npi.head_b), "+s"(npi.v_fc1_w));
     asm volatile("" : "+s"(npi.v_fc1_b), "+s"(npi.v_fc2_w), "+s"(npi.v_fc2_b), "+s"(npi.pi_fc_w), "+s"(npi.pi_fc_b));
     if (MODE == 2 || (MODE == 0 && n <= static_cast<uint32_t>(TSmall::TBW))) {
@@ -870,7 +1046,7 @@ __global__ void k_pipe_settle(EngineParams ep, EngineArrays ar, PipeArrays pa) {
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   // the net workgroups left with unused window positions (head ran ahead of tail): the next epoch's windows start at tail; tokens
   // that were still in a READY ring when the epoch ended are dropped (their slots are whole in HBM: k_pipe_seed sends new ones)
-  if (slot == 0) { pa.ctl->head = pa.ctl->tail; pa.ctl->sims_total += pa.ep->sims; }
+  if (slot == 0) { pa.ctl->head = pa.ctl->tail; pa.ctl->head1 = pa.ctl->tail1; pa.ctl->sims_total += pa.ep->sims; }
   if (slot < pa.n_tree_wgs) pa.wg[slot].rhead = pa.wg[slot].rtail;
   if (slot >= ep.S) return;
   // slots the epoch listed for the move step and did not get to (listed as it ended): the boundary's move step
@@ -914,6 +1090,7 @@ __global__ void k_pipe_settle(EngineParams ep, EngineArrays ar, PipeArrays pa) {
     const uint32_t idx = atomicAdd(&pa.ep->ins_count, 1u);
     if (idx < pa.ins_cap) {
       pa.ins_key[idx] = ar.leaf_key[slot];
+      if (pa.ins_grp) pa.ins_grp[idx] = ar.leaf_group[slot];
 #pragma unroll
       for (int i = 0; i < M; ++i) pa.ins_pi[static_cast<size_t>(idx) * M + i] = val[i];
 #pragma unroll
@@ -941,7 +1118,10 @@ __global__ __launch_bounds__(256) void k_pipe_cache_insert(EngineArrays ar, Pipe
     const uint64_t key = pa.ins_key[i];
     const float p = lane < M ? pa.ins_pi[static_cast<size_t>(i) * M + lane] : 0.0f;
     const float v = lane < P1 ? pa.ins_v[static_cast<size_t>(i) * P1 + lane] : 0.0f;
-    if (!wave_shard_insert_locked<false>(ar.cache, pa.locks, key, p, v, lane) && lane == 0) atomicOr(&pa.ctl->err, static_cast<uint32_t>(kPipeErrLock));
+    const uint32_t g = pa.ins_grp ? (pa.ins_grp[i] & 1u) : 0u;           // (one S3-FIFO per model group, play_manager.cc:195-203)
+    const bool ok = g ? wave_shard_insert_locked<false>(ar.caches[1], pa.locks + pa.lock_base1, key, p, v, lane)
+                      : wave_shard_insert_locked<false>(ar.cache, pa.locks, key, p, v, lane);
+    if (!ok && lane == 0) atomicOr(&pa.ctl->err, static_cast<uint32_t>(kPipeErrLock));
   }
 }
 // ---- do two streams run side by side? -------------------------------------------------------------------------------------------
@@ -971,6 +1151,9 @@ struct PipeState {
   std::vector<hipEvent_t> tev;      // timing events: four per epoch of a run (net kernel start / end, tree kernel start / end)
   size_t lds_bytes = 0;
   bool sized = false, x3 = false;   // pipe_size_net has run for a net of this precision tier
+  bool np1_valid = false;           // this call has a second net (model group 1): its weights
+  azmi_net_dev::NetPtrs np1{};
+  int kind = 0;                     // PipePlan::kind of the current call (which tree kernel)
   bool calibrated = false;          // net_wgs has been measured beside the tree workgroups (pipe_calibrate)
   uint32_t calib_rounds = 0;
   // balance between the two sides (pipe_balance): rings are allocated for tree_wgs_alloc workgroups, `places` = tree + net workgroups
@@ -1015,12 +1198,19 @@ int pipe_alloc(PipeState* ps, T*& p, size_t n) {
 }
 
 // the persistent net kernel's instantiations: tile selection x precision tier
-using PipeNetFn = void (*)(azmi_net_dev::NetDesc, azmi_net_dev::NetPtrs, PipeArrays);
+using PipeNetFn = void (*)(azmi_net_dev::NetDesc, azmi_net_dev::NetPtrs, azmi_net_dev::NetPtrs, PipeArrays);
 PipeNetFn pipe_net_fn(int mode, bool x3) {
   if (x3) return mode == 1 ? &k_pipe_net<1, true> : mode == 2 ? &k_pipe_net<2, true> : &k_pipe_net<0, true>;
   return mode == 1 ? &k_pipe_net<1, false> : mode == 2 ? &k_pipe_net<2, false> : &k_pipe_net<0, false>;
 }
 int pipe_launch_net(PipeState* ps, const azmi_net_c4_view& view, int mode, uint32_t wgs, hipStream_t st, const PipeArrays& pa);
+// how a call is driven: which tree kernel, which model groups have a net behind their request ring
+struct PipePlan {
+  int kind = 0;                       // 0 = not supported, 1 = fast kernel (plain PUCT, one group), 2 = generic kernel (any search, <= 2 groups)
+  bool tree_only = false;             // no net kernel at all (every seat RANDOM)
+  uint32_t net_groups = 0;            // bit g: nets[g] serves group g's ring
+  azmi_net_c4_view view[2]{};         // view[g] of group g's net (view[1] = view[0] when group 1 has none)
+};
 int pipe_size_net(azmi_pm* pm, PipeState* ps, const azmi_net_c4_view& view);
 
 uint32_t pipe_tree_wgs_for(uint32_t S) {
@@ -1118,7 +1308,7 @@ int pipe_size_net(azmi_pm* pm, PipeState* ps, const azmi_net_c4_view& view) {
   return AZMI_OK;
 }
 int pipe_launch_net(PipeState* ps, const azmi_net_c4_view& view, int mode, uint32_t wgs, hipStream_t st, const PipeArrays& pa) {
-  pipe_net_fn(mode, ps->x3)<<<wgs, 256, ps->lds_bytes, st>>>(view.nd, view.np, pa);
+  pipe_net_fn(mode, ps->x3)<<<wgs, 256, ps->lds_bytes, st>>>(view.nd, view.np, ps->np1_valid ? ps->np1 : view.np, pa);
   AZMI_HIP_TRY(hipGetLastError());
   return AZMI_OK;
 }
@@ -1163,7 +1353,9 @@ int pipe_calibrate(azmi_pm* pm, PipeState* ps, hipStream_t st, const azmi_net_c4
     AZMI_HIP_TRY(hipMemsetAsync(pa.ep, 0, sizeof(PipeEpoch), st));
     AZMI_HIP_TRY(hipEventRecord(ps->ev_go, st));
     AZMI_HIP_TRY(hipStreamWaitEvent(ps->net_stream, ps->ev_go, 0));
-    k_pipe_tree<Connect4, 256, false><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
+    if (ps->kind == 2) k_pipe_tree_generic<Connect4, 256><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
+    else if (pa.n_groups > 1u) k_pipe_tree<Connect4, 256, false, true><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
+    else k_pipe_tree<Connect4, 256, false><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
     AZMI_HIP_TRY(hipGetLastError());
     { const int rc = pipe_launch_net(ps, view, 0, ps->net_wgs, ps->net_stream, pa); if (rc != AZMI_OK) return rc; }
     AZMI_HIP_TRY(hipEventRecord(ps->ev_net, ps->net_stream));
@@ -1186,19 +1378,41 @@ int pipe_calibrate(azmi_pm* pm, PipeState* ps, hipStream_t st, const azmi_net_c4
 extern "C" int azmi_net_c4_view_get(const struct azmi_net* net, azmi_net_c4_view* out);
 
 namespace {
-// net == nullptr: the tree side alone - an engine whose seats all use EvalType::RANDOM (dumb_eval) never sends a request, so no net
-// kernel is launched (what rocprofv3 --pmc can look at: one persistent kernel, no partner it has to run beside)
-bool pipe_supported(const azmi_pm* pm, const azmi_net* net, azmi_net_c4_view* view) {
-  if (!(pm->game == AZMI_GAME_CONNECT4 && pm->split_rounds && pm->ep.num_groups == 1 && pm->ep.S <= kPipeRing / 2u)) return false;
-  if (!net) return pm->all_random;
-  return !pm->all_random && azmi_net_c4_view_get(net, view) != 0;
+// What azmi_run_pipeline(_groups) can drive: the Connect4 engine without PLAYOUT seats, at most two model groups, every group
+// that evaluates with a net has a Connect4-family matrix-core net of ONE precision tier behind it.  nets[g] == NULL: group g needs
+// no net (RANDOM seats: the reference's RandPlayer); no net at all: the tree side alone.
+PipePlan pipe_plan(const azmi_pm* pm, azmi_net* const* nets, uint32_t num_nets) {
+  PipePlan pl;
+  const uint32_t G = pm->ep.num_groups;
+  if (!(pm->game == AZMI_GAME_CONNECT4 && !pm->any_playout && G >= 1u && G <= 2u && pm->ep.S <= kPipeRing / 2u)) return pl;
+  int x3 = -1;
+  for (uint32_t g = 0; g < G; ++g) {
+    if (!(pm->nn_groups >> g & 1u)) continue;                   // RANDOM seats: whatever stands in nets[g] is not asked
+    azmi_net* n = (nets && g < num_nets) ? nets[g] : nullptr;
+    if (!n) return pl;                                          // NN seats without a net
+    if (azmi_net_c4_view_get(n, &pl.view[g]) == 0) return pl;
+    if (x3 >= 0 && x3 != pl.view[g].x3) return pl;           // one precision tier per call (one net kernel)
+    x3 = pl.view[g].x3;
+    pl.net_groups |= 1u << g;
+  }
+  if (pl.net_groups == 0u) pl.tree_only = true;
+  if (pl.net_groups == 2u) pl.view[0] = pl.view[1];             // (descriptor and LDS size of the one net there is)
+  if (!(pl.net_groups & 2u)) pl.view[1] = pl.view[0];
+  // the fast tree kernel drives plain PUCT seats (the lock-step engine's SPLIT rounds), the generic one everything else
+  pl.kind = (pm->split_rounds && getenv("AZMI_PIPE_GENERIC") == nullptr) ? 1 : 2;
+  return pl;
 }
 }  // namespace
 extern "C" int azmi_pipeline_supported(azmi_pm* pm, azmi_net* net) {
-  azmi_net_c4_view view;
-  return pm && pipe_supported(pm, net, &view) ? 1 : 0;
+  if (!pm) return 0;
+  azmi_net* nets[2] = {net, net};
+  return pipe_plan(pm, nets, 2).kind != 0 ? 1 : 0;
+}
+extern "C" int azmi_pipeline_supported_groups(azmi_pm* pm, azmi_net* const* nets, uint32_t num_nets) {
+  return pm && pipe_plan(pm, nets, num_nets).kind != 0 ? 1 : 0;
 }
 
+namespace {
 // The two sides share the chip's workgroup places, and how many each needs follows the share of leaves that reach the net.  Measured
 // at 4096 slots on 512 places (M simulations/s by tree workgroups; m = evaluations per simulation):
 //   m = 0.17 (128 M-entry cache, answer table on, the final tree pass):  128 / 144 / 160      -> 114 / 118 / 116
@@ -1228,20 +1442,31 @@ void pipe_balance(PipeState* ps, const PipeCtl& hc) {
   ps->pa.n_tree_wgs = ps->tree_wgs;
   ps->net_wgs = ps->places > ps->tree_wgs ? ps->places - ps->tree_wgs : 1u;
 }
+}  // namespace
 
 // An epoch's workgroup counts assume the chip to itself (placement): two engines' epochs at once would each find half of
 // their workgroups without a place.  Calls from different threads therefore take turns (they are synchronous anyway).
 static std::mutex g_pipeline_turn;
+static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_nets, uint32_t epochs, uint64_t sims_per_epoch, void* stream, uint64_t* out_stats);
 extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, uint64_t sims_per_epoch, void* stream, uint64_t* out_stats) {
+  azmi_net* nets[2] = {net, net};            // the same net for every model group (azmi_pm_net_forward's rule)
+  return run_pipeline_impl(pm, nets, 2, epochs, sims_per_epoch, stream, out_stats);
+}
+extern "C" int azmi_run_pipeline_groups(azmi_pm* pm, azmi_net* const* nets, uint32_t num_nets, uint32_t epochs, uint64_t sims_per_epoch, void* stream,
+                                        uint64_t* out_stats) {
+  return run_pipeline_impl(pm, nets, num_nets, epochs, sims_per_epoch, stream, out_stats);
+}
+static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_nets, uint32_t epochs, uint64_t sims_per_epoch, void* stream, uint64_t* out_stats) {
   if (!pm) return azmi_host_fail(AZMI_ERR_INVALID, "null argument");
   std::lock_guard<std::recursive_mutex> lock_(pm->mu);
   std::lock_guard<std::mutex> turn_(g_pipeline_turn);
-  azmi_net_c4_view view{};
-  if (!pipe_supported(pm, net, &view))
-    return azmi_host_fail(AZMI_ERR_STATE, "azmi_run_pipeline: the pipeline drives the Connect4 engine with plain PUCT seats, one model group and a bf16 "
-                          "Connect4-family net (or no net at all when every seat uses EvalType::RANDOM), at most %u concurrent games (azmi_pipeline_supported); "
-                          "use azmi_run_rounds for everything else", kPipeRing / 2u);
-  const bool tree_only = net == nullptr;
+  const PipePlan plan = pipe_plan(pm, nets, num_nets);
+  if (plan.kind == 0)
+    return azmi_host_fail(AZMI_ERR_STATE, "azmi_run_pipeline: the pipeline drives the Connect4 engine (no PLAYOUT seats, at most two model groups, at most %u "
+                          "concurrent games) with a Connect4-family matrix-core net of one precision tier behind every model group that evaluates with a net "
+                          "(or no net at all when every seat uses EvalType::RANDOM) - azmi_pipeline_supported; use azmi_run_rounds for everything else", kPipeRing / 2u);
+  const azmi_net_c4_view& view = plan.view[0];
+  const bool tree_only = plan.tree_only;
   if (sims_per_epoch == 0) return azmi_host_fail(AZMI_ERR_INVALID, "azmi_run_pipeline: sims_per_epoch must be > 0");
   if (pm->stopped.load(std::memory_order_relaxed)) {     // PlayManager::stop(): the workers leave their loop (play_manager.cc:272)
     if (out_stats) for (int i = 0; i < 16; ++i) out_stats[i] = 0;
@@ -1255,6 +1480,15 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
   }
   PipeState* ps = pm->pipe;
   PipeArrays& pa = ps->pa;
+  ps->kind = plan.kind;
+  ps->np1_valid = (plan.net_groups & 2u) != 0u;
+  ps->np1 = plan.view[1].np;
+  pa.n_groups = pm->ep.num_groups;
+  pa.net_groups = plan.net_groups;
+  if (pa.n_groups > 1u && !pa.ring1) {
+    const int rc = pipe_alloc(ps, pa.ring1, static_cast<size_t>(kPipeRing) * kReqGranules);
+    if (rc != AZMI_OK) return rc;
+  }
   if (!tree_only) { const int rc = pipe_pair_streams(ps, st); if (rc != AZMI_OK) return rc; }
   if (!tree_only) { const int rc = pipe_size_net(pm, ps, view); if (rc != AZMI_OK) return rc; }
   if (!tree_only) { const int rc = pipe_calibrate(pm, ps, st, view); if (rc != AZMI_OK) return rc; }
@@ -1266,14 +1500,19 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
     int rc = pipe_alloc(p, pa.ins_key, want_log);
     if (rc == AZMI_OK) rc = pipe_alloc(p, pa.ins_pi, want_log * Connect4::M);
     if (rc == AZMI_OK) rc = pipe_alloc(p, pa.ins_v, want_log * (Connect4::P + 1));
+    if (rc == AZMI_OK && pa.n_groups > 1u) rc = pipe_alloc(p, pa.ins_grp, want_log);
     if (rc != AZMI_OK) return rc;
     pa.ins_cap = static_cast<uint32_t>(want_log);
   }
-  if (pm->ep.cache_on && !pa.locks) {
-    const int rc = pipe_alloc(ps, pa.locks, pm->ar.cache.shards);
+  if (pm->ep.cache_on && !pa.locks) {      // one insert lock per shard, group 0's cache first
+    size_t total = 0;
+    for (uint32_t g = 0; g < pm->ep.num_groups && g < pm->group_caches.size(); ++g) total += pm->group_caches[g].shards;
+    total = std::max<size_t>(total, pm->ar.cache.shards);
+    pa.lock_base1 = pm->group_caches.empty() ? 0u : pm->group_caches[0].shards;
+    const int rc = pipe_alloc(ps, pa.locks, total);
     if (rc != AZMI_OK) return rc;
   }
-  if (pm->ep.cache_on && !pa.l0 && !tree_only && getenv("AZMI_PIPE_NO_L0") == nullptr) {
+  if (pm->ep.cache_on && !pa.l0 && !tree_only && plan.kind == 1 && getenv("AZMI_PIPE_NO_L0") == nullptr) {
     // the answer table: a power of two of 128-byte entries, an eighth of the S3-FIFO's entries, between 4 Ki and 4 Mi (512 MB: an
     // epoch of the headline brings ~200 k answers).  Measured and dropped: a table of half the S3-FIFO's entries (64 Mi = 8 GB at the
     // headline's cache) with shard hits copied into it - a table hit costs the probe one round trip instead of two, but 8 GB more of
@@ -1327,7 +1566,9 @@ extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, ui
     }
     // the tree kernel goes first: its workgroups take their places per shader engine, the net kernel is sized for what is left
     AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 2], st));
-    if (prof) k_pipe_tree<Connect4, 256, true><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
+    if (plan.kind == 2) k_pipe_tree_generic<Connect4, 256><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
+    else if (pa.n_groups > 1u) k_pipe_tree<Connect4, 256, false, true><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
+    else if (prof) k_pipe_tree<Connect4, 256, true><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
     else k_pipe_tree<Connect4, 256, false><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
     AZMI_HIP_TRY(hipGetLastError());
     AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 3], st));
@@ -1491,8 +1732,10 @@ __global__ void k_pipe_head_reset(PipeArrays pa) { pa.ctl->head = pa.ctl->tail; 
 extern "C" int azmi_debug_pipe_net_bench(azmi_pm* pm, azmi_net* net, uint32_t n, uint32_t reps, uint32_t net_wgs, int mode, float* ms_out) {
   if (!pm || !net || !ms_out) return azmi_host_fail(AZMI_ERR_INVALID, "null argument");
   std::lock_guard<std::recursive_mutex> lock_(pm->mu);
-  azmi_net_c4_view view;
-  if (!pipe_supported(pm, net, &view)) return azmi_host_fail(AZMI_ERR_STATE, "not a pipeline engine");
+  azmi_net* nets_[2] = {net, net};
+  const PipePlan plan_ = pipe_plan(pm, nets_, 2);
+  if (plan_.kind == 0 || plan_.tree_only) return azmi_host_fail(AZMI_ERR_STATE, "not a pipeline engine");
+  const azmi_net_c4_view view = plan_.view[0];
   if (n > kPipeRing) return azmi_host_fail(AZMI_ERR_INVALID, "at most %u requests", kPipeRing);
   AZMI_HIP_TRY(hipSetDevice(pm->device));
   if (!pm->pipe) { const int rc = pipe_create(pm, azmi_net_dev::c4::TileBig::LDS_BYTES); if (rc != AZMI_OK) return rc; }

@@ -427,7 +427,8 @@ const char* azmi_cache_last_error(void);
  *      cores, another engine's tree kernel runs on the CUs the net leaves free.  Launch-only
  *      (asynchronous); poll with azmi_pm_poll. */
 int azmi_run_rounds(azmi_pm* const* pms, azmi_net* net, uint32_t k, uint32_t rounds, void* const* streams);
-/* ---- asynchronous tree / net pipeline (Connect4 engine, plain PUCT seats, one model group, bf16 Connect4-family net): what
+/* ---- asynchronous tree / net pipeline (Connect4 engine; plain PUCT seats + one model group on the fast tree kernel, Gumbel seats and
+ *      two model groups on the generic one; bf16 or bf16x3 Connect4-family net): what
  *      azmi_run_rounds does, without its lock step.  The reference's worker loop has no global barrier - every game advances
  *      on its own through the queues between PlayManager::play's workers and GameRunner's batcher threads
  *      (play_manager.cc:258-600, concurrent_queue.h:130-217, game_runner.py:483-552) - and neither has this: for one EPOCH
@@ -450,6 +451,14 @@ int azmi_run_rounds(azmi_pm* const* pms, azmi_net* net, uint32_t k, uint32_t rou
  *      launches that measured [6] (0 = not measured: tree side alone); 16 entries.
  *      After azmi_pm_stop both this call and azmi_run_rounds return AZMI_OK at once and run nothing (play_manager.cc:272). */
 int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, uint64_t sims_per_epoch, void* stream, uint64_t* out_stats);
+/* the same with one net PER MODEL GROUP (azmi_run_rounds_groups' counterpart: play_past, game_runner.py:2184-2332 - two models, seats
+ * swapped by the permutations): nets[g] evaluates the leaves of group g (its own request ring, its own S3-FIFO), NULL = that group
+ * needs no net (RANDOM seats: the reference's RandPlayer).  At most two groups; every net a Connect4-family matrix-core net of ONE
+ * precision tier.  Engines the fast tree kernel does not cover - Gumbel seats, two model groups - run on the generic tree kernel
+ * (every step through the lock-step engine's own move-step function, one simulation per slot and pass, no round barrier). */
+int azmi_run_pipeline_groups(azmi_pm* pm, azmi_net* const* nets, uint32_t num_nets, uint32_t epochs, uint64_t sims_per_epoch, void* stream,
+                             uint64_t* out_stats);
+int azmi_pipeline_supported_groups(azmi_pm* pm, azmi_net* const* nets, uint32_t num_nets);
 /* diagnostics: the pipeline's persistent net kernel alone, draining `n` synthetic requests (n <= 32768, the request ring) `reps` times with
  * `net_wgs` workgroups (0 = the pipeline's own count) and tile selection `mode` (0 = 3- and 6-board tiles, 1 = 6-board, 2 =
  * 3-board); *ms_out = milliseconds per drain.  Timing only (scripts/pipe_net_timing.py -> profiles/). */

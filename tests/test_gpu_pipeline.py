@@ -141,14 +141,148 @@ def test_pipeline_rejects_what_it_does_not_drive():
     spec = torch_net.connect4_spec()
     hip = az.HipLeafNet(torch_net.random_init(spec, seed=1), spec)
     pp = _selfplay_params(az, 8, 16, cache=0)
-    pp.gumbel_enabled = True
+    pp.eval_type = [az.EvalType.NN, az.EvalType.PLAYOUT]
+    pp.model_groups = [0, 1]
     pm = az.PlayManager(az.Connect4GS(), pp, seed=1)
-    assert not az.pipeline_supported(pm, hip)
+    assert not az.pipeline_supported(pm, hip)                     # a PLAYOUT seat: the rollout code is the lock-step engine's
     with pytest.raises(RuntimeError, match="pipeline"):
         az.run_pipeline(pm, hip, 1, 100)
     pp2 = _selfplay_params(az, 4, 8, cache=0)
     tw = az.PlayManager(az.TawlbwrddGS(), pp2, seed=1)
-    assert not az.pipeline_supported(tw, hip)
+    assert not az.pipeline_supported(tw, hip)                     # the wide-game engine
+    pp3 = _selfplay_params(az, 8, 16, cache=0)
+    pp3.model_groups = [0, 1]
+    two = az.PlayManager(az.Connect4GS(), pp3, seed=1)
+    x3 = az.HipLeafNet(torch_net.random_init(spec, seed=2), spec, precision="bf16x3")
+    assert az.pipeline_supported_groups(two, [hip, hip])
+    assert not az.pipeline_supported_groups(two, [hip, None])     # NN seats without a net
+    assert not az.pipeline_supported_groups(two, [hip, x3])       # two precision tiers in one call
+    with pytest.raises(RuntimeError, match="pipeline"):
+        az.run_pipeline_groups(two, [hip, None], 1, 100)
+
+
+# ---- the generic tree kernel (round 4): Gumbel seats, two model groups ---------------------------------------------------------
+def _groups_pipeline_games(az, pp, seed, nets, sims_per_epoch, max_calls=4000):
+    pm = az.PlayManager(az.Connect4GS(), pp, seed=seed, log_moves=True)
+    assert az.pipeline_supported_groups(pm, nets)
+    st = torch.cuda.Stream()
+    stats, n = None, 0
+    while pm.remaining_games() > 0 and n < max_calls:
+        stats = az.run_pipeline_groups(pm, nets, 4, sims_per_epoch, st.cuda_stream)
+        n += 1
+        if pm.poll(st.cuda_stream)[1] == 0:
+            break
+    torch.cuda.synchronize()
+    return pm, pm.move_log(), stats
+
+
+def _groups_lockstep_games(az, pp, seed, nets):
+    pm = az.PlayManager(az.Connect4GS(), pp, seed=seed, log_moves=True)
+    st = torch.cuda.Stream()
+    while pm.remaining_games() > 0:
+        az.run_rounds_groups([pm], list(nets), 64, [st.cuda_stream])
+        if pm.poll(st.cuda_stream)[1] == 0:
+            break
+    torch.cuda.synchronize()
+    return pm, pm.move_log()
+
+
+def _same_games(pa, la, pb, lb, S):
+    assert pa.games_completed() == pb.games_completed() == S
+    ra, ca = _sorted_log(*la)
+    rb, cb = _sorted_log(*lb)
+    assert ra.shape == rb.shape and len(ra) > 6 * S
+    assert np.array_equal(ra, rb), "moves / pcg32 positions differ between the pipeline and the lock-step engine"
+    assert np.array_equal(ca, cb), "visit counts differ"
+    assert np.array_equal(pa.scores(), pb.scores())
+    assert np.array_equal(_history_multiset(pa), _history_multiset(pb)), "sample rows differ"
+    assert pa.counters()["sims"] == pb.counters()["sims"]
+
+
+_GUMBEL = {
+    "global": dict(gumbel_enabled=True, gumbel_m=8),
+    "full_improved": dict(gumbel_enabled=True, gumbel_m=16, gumbel_full=True, seat_gumbel_use_improved_policy=[[1, 1]], gumbel_c_scale=0.5),
+    "one_seat": dict(seat_gumbel_enabled=[[1, 0]], seat_gumbel_m=[[4, 16]], seat_gumbel_c_visit=[[50.0, 20.0]]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(_GUMBEL))
+@pytest.mark.parametrize("cache", [0, 1 << 15])
+def test_pipeline_drives_gumbel_seats(name, cache):
+    """Sequential-halving Gumbel roots (mcts.cc:233-342) on the pipeline: every step through the lock-step engine's move-step function
+    on the generic tree kernel - moves, visit counts, pcg32 positions and sample rows (the improved policy) are the lock-step engine's"""
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=31), spec)
+    S, seed = 96, 515
+    pp = _selfplay_params(az, S, 64, cache=cache)
+    for k, v in _GUMBEL[name].items():
+        setattr(pp, k, v)
+    pa, la, stats = _groups_pipeline_games(az, pp, seed, [hip], S * 24)
+    pb, lb = _groups_lockstep_games(az, pp, seed, [hip])
+    _same_games(pa, la, pb, lb, S)
+    assert stats["tiles"] > 0 and stats["tree_wgs_started"] == stats["tree_wgs"]
+    if cache:
+        assert pa.counters()["cache_hits"] > 0
+
+
+def test_pipeline_gumbel_equals_the_oracle_driven_by_the_same_net(oracle):
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=32), spec)
+    S, seed = 40, 616
+    pp = _selfplay_params(az, S, 48, cache=1 << 14)
+    pp.gumbel_enabled, pp.gumbel_m = True, 8
+    pm, (rows, counts), _ = _groups_pipeline_games(az, pp, seed, [hip], S * 16)
+    assert pm.games_completed() == S
+    _check_slots(az, oracle, oracle.GAME_CONNECT4, pp, seed, rows, counts, (0, 13, 39), evaluator=_net_eval(hip))
+
+
+@pytest.mark.parametrize("cache", [0, 1 << 15])
+def test_pipeline_routes_two_model_groups_to_two_nets(oracle, cache):
+    """play_past (game_runner.py:2184-2332): two DIFFERENT nets, seats swapped by the permutations, one request ring and one S3-FIFO per
+    group - the games of the lock-step engine with the same two nets and of the oracle whose group evaluator sends a leaf to its
+    group's net; swapping the nets changes the games"""
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    nets = [az.HipLeafNet(torch_net.random_init(spec, seed=41), spec), az.HipLeafNet(torch_net.random_init(spec, seed=42), spec)]
+    evs = [_net_eval(n) for n in nets]
+    S, seed = 64, 727
+    pp = _selfplay_params(az, S, 60, cache=cache)
+    pp.mcts_visits = [60, 44]
+    pp.model_groups, pp.seat_perms = [0, 1], [[0, 1], [1, 0]]
+    pa, la, stats = _groups_pipeline_games(az, pp, seed, nets, S * 24)
+    pb, lb = _groups_lockstep_games(az, pp, seed, nets)
+    _same_games(pa, la, pb, lb, S)
+    for q in range(2):
+        assert np.array_equal(pa.perm_scores(q), pb.perm_scores(q)) and pa.perm_games_completed(q) == pb.perm_games_completed(q)
+    rows, counts = la
+    _check_slots(az, oracle, oracle.GAME_CONNECT4, pp, seed, rows, counts, (0, 1, 62, 63), group_evaluator=lambda g, c: evs[g](c))
+    pc, lc, _ = _groups_pipeline_games(az, pp, seed, nets[::-1], S * 24)
+    assert not np.array_equal(_sorted_log(*lc)[0][:, 2:4], _sorted_log(*la)[0][:, 2:4]) or len(lc[0]) != len(la[0])
+    if cache:
+        assert pa.counters()["cache_hits"] > 0
+
+
+def test_pipeline_with_a_net_behind_one_group_and_random_seats_in_the_other():
+    """the reference's baseline match (game_runner.py:2143-2182: the model against RandPlayer): group 1's seats use EvalType.RANDOM, so
+    only group 0 has a ring and a net behind it; a per-seat Gumbel seat on top"""
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=43), spec)
+    S, seed = 48, 838
+    pp = _selfplay_params(az, S, 40, cache=1 << 14)
+    pp.model_groups, pp.seat_perms = [0, 1], [[0, 1], [1, 0]]
+    pp.eval_type = [az.EvalType.NN, az.EvalType.RANDOM]
+    pp.seat_gumbel_enabled = [[1, 0], [0, 0]]
+    pa, la, stats = _groups_pipeline_games(az, pp, seed, [hip, None], S * 16)
+    pb, lb = _groups_lockstep_games(az, pp, seed, [hip, None])
+    _same_games(pa, la, pb, lb, S)
+    assert 0 < pa.counters()["evals"] < pa.counters()["sims"]
 
 
 def test_ring_positions_wrap_past_2_to_the_32(monkeypatch):
