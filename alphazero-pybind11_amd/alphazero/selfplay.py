@@ -9,7 +9,8 @@ import dataclasses
 
 import numpy as np
 
-from . import PlayManager, EvalType, ShardedS3FIFOCache, run_rounds, run_rounds_groups, run_pipeline, pipeline_supported
+from . import (PlayManager, EvalType, ShardedS3FIFOCache, run_rounds, run_rounds_groups, run_pipeline, pipeline_supported, run_pipeline_groups,
+               pipeline_supported_groups)
 
 
 @dataclasses.dataclass
@@ -60,8 +61,8 @@ def self_play(game, params, net=None, engines=None, seed=20240601, device=0, str
     RANDOM / PLAYOUT).  Returns (SelfPlayResult, (canonical, v, pi)) with the samples as device tensors in shard order (numpy
     arrays without a net, since nothing else needs torch then).  With `data_folder` the samples are also written as the
     reference's `.ptz` triples, `data_save_size` rows per batch (GameRunner.hist_saver, game_runner.py:736-747).
-    driver: "pipeline" = ONE engine with every game on the asynchronous tree / net pipeline (azmi_run_pipeline: Connect4, plain
-    PUCT seats, one model group, at most 16384 concurrent games), "rounds" = `engines` shards (default 4) on the lock-step round
+    driver: "pipeline" = ONE engine with every game on the asynchronous tree / net pipeline (azmi_run_pipeline: Connect4, PUCT or
+    Gumbel seats, at most 16384 concurrent games), "rounds" = `engines` shards (default 4) on the lock-step round
     driver, "auto" = the pipeline where it applies.  The finished samples are taken out of the engines' rings at every poll
     (the ring is bounded: a long stream would overflow it), like the reference's hist_saver drains its queue."""
     want_pipe = driver in ("auto", "pipeline") and net is not None and (engines in (None, 1) or driver == "pipeline")
@@ -190,12 +191,15 @@ class MatchResult:             # what play_past() returns from the PlayManager (
     perm_scores: list
 
 
-def gating_match(game, params, net_new, net_past, engines=2, seed=20240601, device=0, rounds_per_poll=256):
+def gating_match(game, params, net_new, net_past, engines=2, seed=20240601, device=0, rounds_per_poll=256, driver="auto", epochs_per_poll=16):
     """play_past (game_runner.py:2184-2332) on the device: model group 0 = the new model, group 1 = the past one, every seating
     of the two (2 players: both; N players: the new model alone in each seat, then the past model alone in each seat), games
     split over `engines` shards.  `net_new` / `net_past` are HipLeafNets, or None for the reference's RandPlayer (RANDOM
     evaluator).  `params` supplies the search settings (visits, temperatures, cache ...); its groups, permutations and
-    evaluator types are set here like play_past does."""
+    evaluator types are set here like play_past does.
+    driver: "auto" = ONE engine on the asynchronous pipeline with one net per model group (azmi_run_pipeline_groups) where it applies
+    (Connect4 with Connect4-family nets), falling back to the lock-step driver on the same engine when the pipeline cannot run;
+    "rounds" = `engines` shards on the lock-step driver; "pipeline" = the pipeline or an error."""
     import copy
     import torch
     g = game() if isinstance(game, type) else game
@@ -211,13 +215,32 @@ def gating_match(game, params, net_new, net_past, engines=2, seed=20240601, devi
     p.eval_type = [EvalType.NN if nets[grp] is not None else EvalType.RANDOM for grp in p.model_groups]
     p.mcts_visits = visits
     n_perms = len(p.seat_perms)
-    K = max(1, min(int(engines), int(p.concurrent_games)))
-    pms = [PlayManager(type(g)(), _shard_params(p, k, K), seed=shard_seed(seed, k), device=device) for k in range(K)]
+    use_pipe = False
+    if driver in ("auto", "pipeline") and any(n is not None for n in nets):
+        probe = PlayManager(type(g)(), _shard_params(p, 0, 1), seed=shard_seed(seed, 0), device=device)
+        if pipeline_supported_groups(probe, nets):
+            pms, K, use_pipe = [probe], 1, True
+        elif driver == "pipeline":
+            raise RuntimeError("gating_match: the pipeline does not drive this engine / these nets (alphazero.pipeline_supported_groups)")
+        else:
+            del probe
+    if not use_pipe:
+        K = max(1, min(int(engines), int(p.concurrent_games)))
+        pms = [PlayManager(type(g)(), _shard_params(p, k, K), seed=shard_seed(seed, k), device=device) for k in range(K)]
     streams = [torch.cuda.Stream(device=device) for _ in range(K)]
     sps = [s.cuda_stream for s in streams]
     live = list(range(K))
     while live:
-        run_rounds_groups([pms[i] for i in live], nets, rounds_per_poll, [sps[i] for i in live])
+        if use_pipe:
+            try:
+                run_pipeline_groups(pms[0], nets, epochs_per_poll, 256 * int(p.concurrent_games), sps[0])
+            except RuntimeError:
+                if driver != "auto":
+                    raise
+                use_pipe = False          # (a pipeline error leaves the engine whole: the lock-step driver carries on with it)
+                continue
+        else:
+            run_rounds_groups([pms[i] for i in live], nets, rounds_per_poll, [sps[i] for i in live])
         live = [i for i in live if pms[i].poll(sps[i])[1] > 0]
     perm_scores = [np.sum([pm.perm_scores(q) for pm in pms], 0) for q in range(n_perms)]
     perm_games = [sum(pm.perm_games_completed(q) for pm in pms) for q in range(n_perms)]

@@ -163,7 +163,11 @@ __device__ __attribute__((noinline)) uint32_t pipe_move_groups(const EngineParam
 // PROF: the time accounting of AZMI_PIPE_PROF (a build of its own: the counters cost a dozen registers of a kernel that has none to spare)
 // TWO: two model groups (play_past: a leaf goes to the S3-FIFO, the answer table lines and the request ring of the group its seat belongs
 // to) - a build of its own for the same reason
-template <class GM, int NT, bool PROF, bool TWO = false>
+// GUM: Gumbel seats (mcts.cc:233-342).  A search differs from plain PUCT in the choice at the root (the sequential-halving schedule,
+// gumbel_next_root_child) and - gumbel_full - at interior nodes (gumbel_interior_select): both are SlotCtx's own functions, called
+// from the descent below; the Gumbel state of a search (g, survivors, phase) is initialised by the move step's first descent
+// (find_leaf's lazy init), so a search whose state is not there yet is handed to the move step.  Built with TWO.
+template <class GM, int NT, bool PROF, bool TWO = false, bool GUM = false>
 __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
   constexpr int G = GM::GROUP;
   constexpr int P = GM::P;
@@ -299,7 +303,8 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
     c.slot = slot;
     uint32_t st = kGrpIdle;
     uint8_t final_state = kSlotWaitEval;
-    uint32_t cp = 0, root = 0, goal = 0, seq = 0, mg = 0;
+    uint32_t cp = 0, root = 0, goal = 0, seq = 0, mg = 0, gum_active = 0, gum_full = 0;
+    bool gum_defer = false;
     size_t tb = 0;
     float fpu_root = 0.0f;
     uint32_t* const path = ar.path + static_cast<size_t>(slot) * ep.max_depth;
@@ -358,6 +363,14 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
       seq = seq_now;
       rec_ok = (c.flags & kFlagPendRec) != 0;
       st = kGrpReady;
+      if constexpr (GUM) {
+        if (c.seat_gumbel(cp)) {
+          const uint32_t* const gst = c.gum_state(cp);
+          gum_active = gst[SlotCtx<GM>::kGumInit];
+          gum_defer = gum_active == 0u && gst[SlotCtx<GM>::kGumTarget] > 0u;      // (not initialised yet: find_leaf's lazy init is the move step's)
+          gum_full = c.seat_gumbel_full(cp) ? 1u : 0u;
+        }
+      }
       { const NodeRec* rr = ar.nodes + tb + root; root_n = rr->n; root_v = rr->v; root_meta = rr->meta; }
       lv_node = pr_in.node; lv_n = pr_in.n; lv_pp = pr_in.pp_mv & 0xFFu;
       lv_q = pr_in.q; lv_d = pr_in.d; lv_v = pr_in.v;
@@ -411,7 +424,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
           const uint32_t idx = base + static_cast<uint32_t>(__popcll(am & ((1ull << (grp * 8)) - 1ull)));
           if (idx < pa.ins_cap) {
             if (lane == 0) pa.ins_key[idx] = cur_key;
-            if constexpr (TWO) { if (lane == 1) pa.ins_grp[idx] = static_cast<uint8_t>(mg); }
+            if constexpr (TWO) { if (lane == 1 && pa.ins_grp) pa.ins_grp[idx] = static_cast<uint8_t>(mg); }
             if (lane < static_cast<uint32_t>(GM::M)) pa.ins_pi[static_cast<size_t>(idx) * GM::M + lane] = reg_pi;
             if (lane <= static_cast<uint32_t>(P)) pa.ins_v[static_cast<size_t>(idx) * (P + 1) + lane] = reg_v;
           } else if (lane == 0) {
@@ -428,7 +441,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
     if (st == kGrpReady) {
       uint32_t inline_sims = 0;
       for (;;) {
-        if (AZMI_SEL(c.t_depth, cp) + 1 >= goal || c.cur == root) {
+        if (AZMI_SEL(c.t_depth, cp) + 1 >= goal || c.cur == root || (GUM && gum_defer)) {
           // the next backup completes the search (a move follows) or the evaluated leaf is the root (temperature, noise): the move step's
           c.flags |= kFlagListed;
           listed = true;
@@ -517,7 +530,14 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
             }
           }
           const float fpu = (cur == root) ? fpu_root : ep.fpu_reduction;
-          const uint32_t best = c.select_child(k, n_l, q_l, p_l, v_cur, n, fpu);
+          uint32_t best;
+          if constexpr (GUM) {
+            if (gum_active != 0u && cur == root) best = c.gumbel_next_root_child(cp, k, n_l, q_l, p_l);
+            else if (gum_active != 0u && gum_full != 0u) best = c.gumbel_interior_select(cp, k, n_l, q_l, p_l, v_cur);
+            else best = c.select_child(k, n_l, q_l, p_l, v_cur, n, fpu);
+          } else {
+            best = c.select_child(k, n_l, q_l, p_l, v_cur, n, fpu);
+          }
           const uint32_t nxt = c0 + best;
           const uint32_t s_n = c.bcast(n_l, static_cast<int>(best));
           const float s_q = c.bcast(q_l, static_cast<int>(best)), s_d = c.bcast(d_l, static_cast<int>(best)), s_v = c.bcast(v_l, static_cast<int>(best));
@@ -1354,6 +1374,7 @@ int pipe_calibrate(azmi_pm* pm, PipeState* ps, hipStream_t st, const azmi_net_c4
     AZMI_HIP_TRY(hipEventRecord(ps->ev_go, st));
     AZMI_HIP_TRY(hipStreamWaitEvent(ps->net_stream, ps->ev_go, 0));
     if (ps->kind == 2) k_pipe_tree_generic<Connect4, 256><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
+    else if (pm->ep.gumbel_on) k_pipe_tree<Connect4, 256, false, true, true><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
     else if (pa.n_groups > 1u) k_pipe_tree<Connect4, 256, false, true><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
     else k_pipe_tree<Connect4, 256, false><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
     AZMI_HIP_TRY(hipGetLastError());
@@ -1398,8 +1419,9 @@ PipePlan pipe_plan(const azmi_pm* pm, azmi_net* const* nets, uint32_t num_nets) 
   if (pl.net_groups == 0u) pl.tree_only = true;
   if (pl.net_groups == 2u) pl.view[0] = pl.view[1];             // (descriptor and LDS size of the one net there is)
   if (!(pl.net_groups & 2u)) pl.view[1] = pl.view[0];
-  // the fast tree kernel drives plain PUCT seats (the lock-step engine's SPLIT rounds), the generic one everything else
-  pl.kind = (pm->split_rounds && getenv("AZMI_PIPE_GENERIC") == nullptr) ? 1 : 2;
+  // the fast tree kernel (its plain, two-group and Gumbel builds) drives all of them; AZMI_PIPE_GENERIC=1 asks for the generic one (every
+  // step through the lock-step engine's move-step function: an independent implementation kept as a cross-check, tests/test_gpu_pipeline.py)
+  pl.kind = getenv("AZMI_PIPE_GENERIC") == nullptr ? 1 : 2;
   return pl;
 }
 }  // namespace
@@ -1567,6 +1589,7 @@ static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_ne
     // the tree kernel goes first: its workgroups take their places per shader engine, the net kernel is sized for what is left
     AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 2], st));
     if (plan.kind == 2) k_pipe_tree_generic<Connect4, 256><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
+    else if (pm->ep.gumbel_on) k_pipe_tree<Connect4, 256, false, true, true><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
     else if (pa.n_groups > 1u) k_pipe_tree<Connect4, 256, false, true><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
     else if (prof) k_pipe_tree<Connect4, 256, true><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
     else k_pipe_tree<Connect4, 256, false><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});

@@ -181,6 +181,8 @@ def pipe_call(az, pm, net, n, spe, stream):
     again - at most three such errors per run, each one recorded in the bench line."""
     for _ in range(3):
         try:
+            if isinstance(net, (list, tuple)):
+                return az.run_pipeline_groups(pm, list(net), n, spe, stream)
             return az.run_pipeline(pm, net, n, spe, stream)
         except RuntimeError as e:
             if "pipeline error mask" not in str(e) or len(PIPE_ERRORS) >= 3:
@@ -391,7 +393,7 @@ def main():
     # streams stayed mapped to hardware queues and the lock-step secondaries of the same process (4 shards = 4 streams on the
     # runtime's 4 queues) ran at half speed.
     probe_ok = None
-    if (args.driver == "auto" and not args.dry and args.game == "connect4" and not args.gumbel and (args.net or "hip") == "hip"):
+    if (args.driver == "auto" and not args.dry and args.game == "connect4" and (args.net or "hip") == "hip"):
         try:
             probe_ok = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe", "--games", str(args.games or 4096)],
                                       env=dict(os.environ), timeout=600).returncode == 0
@@ -427,7 +429,7 @@ def main():
     if args.games is None: args.games = 1024 if sg else 2048 if tafl else 4096
     if args.sims is None: args.sims = 800 if sg else 400 if tafl else 800
     # the pipeline drives ONE engine with every slot (one GPU-wide position cache); the lock-step driver wants 4 shards
-    use_pipe = args.driver == "pipeline" or (args.driver == "auto" and not tafl and not args.gumbel and (args.net or "hip") == "hip" and not args.dry)
+    use_pipe = args.driver == "pipeline" or (args.driver == "auto" and not tafl and (args.net or "hip") == "hip" and not args.dry)
     if use_pipe and args.driver == "auto":
         # a safety net, not a tuning knob: the pipeline's persistent kernels rely on how this part places workgroups.
         # A short probe at the bench's slot count runs before anything is sized; if it raises on this box (census, time cap), every
@@ -873,7 +875,11 @@ def main():
                         ("tier_1e5", S, args.cache, False, "x3", "the bf16x3 leaf net (precision='bf16x3': bf16 high + low parts of weights and activations, three MFMAs per product; "
                                                                     "max |delta| vs the reference NNArch's fp32 outputs 4.3e-7 on the random-init fixture, 5.4e-6 on the peaked one: the north star's 1e-5 tier), "
                                                                     "on the asynchronous pipeline (round 4: k_pipe_net<.., X3>, one net workgroup per CU beside the tree workgroups; round 3: lock-step, 1384 games/s), the headline's cache size; "
-                                                                    "the plain-fp32 kernels (precision='fp32', any net shape, 7.5e-8) run this workload at 15 games/s")):
+                                                                    "the plain-fp32 kernels (precision='fp32', any net shape, 7.5e-8) run this workload at 15 games/s"),
+                        ("gumbel", S, args.cache, False, "gumbel", "Gumbel AlphaZero roots (gumbel_enabled, m = 16: mcts.cc:233-342), 800 sims on every move; round 4: the pipeline's Gumbel build of the tree kernel "
+                                                                   "(lock-step rounds, 4 shards, same box: see DESIGN 8)"),
+                        ("two_nets", S, args.cache, False, "two", "the gating shape (play_past, game_runner.py:2184-2332): two different nets behind two model groups, seats swapped by the permutations, one request ring and "
+                                                                  "one S3-FIFO (half the entries each) per group; round 4: azmi_run_pipeline_groups")):
                     if os.environ.get("AZMI_BENCH_SECONDARY") and name not in os.environ["AZMI_BENCH_SECONDARY"].split(","):
                         continue
                     sys.stderr.write(f"bench.py: secondary {name} ...\n"); sys.stderr.flush()
@@ -882,9 +888,13 @@ def main():
                     if kind == "x3":
                         hip_f32 = az.HipLeafNet(net, spec, device=local_rank, precision="bf16x3")
                     net2 = hip_f32 if kind == "x3" else hip_net
+                    if kind == "two":
+                        net2 = [hip_net, az.HipLeafNet(torch_net.random_init(spec, seed=1), spec, device=local_rank)]
                     pms2 = []
                     for i in range(K2):
-                        pp2 = selfplay_params(az, S2 // K2, sims, STREAM, cache=cache2 // K2, playout_cap=cap2)
+                        pp2 = selfplay_params(az, S2 // K2, sims, STREAM, cache=cache2 // K2, playout_cap=cap2, gumbel=(kind == "gumbel"))
+                        if kind == "two":
+                            pp2.model_groups, pp2.seat_perms = [0, 1], [[0, 1], [1, 0]]
                         pms2.append(az.PlayManager(Game(), pp2, seed=977 + 104729 * i, device=local_rank, max_inline=args.inline, history_capacity=(S2 // K2) * 42 * 4))
                     R2 = R if pipe2 else 2048
                     if len(streams) < K2:
@@ -897,7 +907,10 @@ def main():
                         else:
                             done2 = 0
                             while done2 < n:
-                                az.run_rounds(pms2, net2, min(256, n - done2), sps2[:len(pms2)])
+                                if isinstance(net2, list):
+                                    az.run_rounds_groups(pms2, net2, min(256, n - done2), sps2[:len(pms2)])
+                                else:
+                                    az.run_rounds(pms2, net2, min(256, n - done2), sps2[:len(pms2)])
                                 done2 += 256
                         for pm2 in pms2:
                             pm2.take_history_device(dev)

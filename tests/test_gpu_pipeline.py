@@ -44,9 +44,11 @@ def _sorted_log(rows, counts):
 
 
 def _history_multiset(pm):
-    c, v, p = pm.history()
-    rows = np.concatenate([c.reshape(len(c), -1), v, p], 1)
-    return rows[np.lexsort(rows.T[::-1])]
+    if getattr(pm, "_hist_rows", None) is None:       # (history() hands the rows out once)
+        c, v, p = pm.history()
+        rows = np.concatenate([c.reshape(len(c), -1), v, p], 1)
+        pm._hist_rows = rows[np.lexsort(rows.T[::-1])]
+    return pm._hist_rows
 
 
 @pytest.mark.parametrize("cache", [0, 1 << 16])
@@ -209,8 +211,9 @@ _GUMBEL = {
 @pytest.mark.parametrize("name", sorted(_GUMBEL))
 @pytest.mark.parametrize("cache", [0, 1 << 15])
 def test_pipeline_drives_gumbel_seats(name, cache):
-    """Sequential-halving Gumbel roots (mcts.cc:233-342) on the pipeline: every step through the lock-step engine's move-step function
-    on the generic tree kernel - moves, visit counts, pcg32 positions and sample rows (the improved policy) are the lock-step engine's"""
+    """Sequential-halving Gumbel roots (mcts.cc:233-342) on the pipeline (the fast tree kernel's Gumbel build: the root's choice by the
+    halving schedule, interior nodes by the improved policy when gumbel_full) - moves, visit counts, pcg32 positions and sample rows
+    (the improved policy) are the lock-step engine's"""
     import alphazero as az
     from alphazero import torch_net
     spec = torch_net.connect4_spec()
@@ -225,6 +228,31 @@ def test_pipeline_drives_gumbel_seats(name, cache):
     assert stats["tiles"] > 0 and stats["tree_wgs_started"] == stats["tree_wgs"]
     if cache:
         assert pa.counters()["cache_hits"] > 0
+
+
+@pytest.mark.parametrize("shape", ["gumbel", "two_nets"])
+def test_generic_tree_kernel_plays_the_same_games(monkeypatch, shape):
+    """AZMI_PIPE_GENERIC=1: the generic tree kernel (every step of a slot through the lock-step engine's own move-step function, one
+    simulation per pass) as an independent cross-check of the fast kernel's Gumbel and two-group builds"""
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    nets = [az.HipLeafNet(torch_net.random_init(spec, seed=51), spec), az.HipLeafNet(torch_net.random_init(spec, seed=52), spec)]
+    S, seed = 64, 949
+    pp = _selfplay_params(az, S, 48, cache=1 << 14)
+    if shape == "gumbel":
+        pp.gumbel_enabled, pp.gumbel_m, pp.gumbel_full = True, 8, True
+        nets = nets[:1]
+    else:
+        pp.model_groups, pp.seat_perms = [0, 1], [[0, 1], [1, 0]]
+        pp.seat_gumbel_enabled = [[1, 0], [0, 0]]
+    pa, la, _ = _groups_pipeline_games(az, pp, seed, nets, S * 16)
+    monkeypatch.setenv("AZMI_PIPE_GENERIC", "1")
+    pb, lb, stats = _groups_pipeline_games(az, pp, seed, nets, S * 16)
+    monkeypatch.delenv("AZMI_PIPE_GENERIC")
+    _same_games(pa, la, pb, lb, S)
+    pc, lc = _groups_lockstep_games(az, pp, seed, nets)
+    _same_games(pa, la, pc, lc, S)
 
 
 def test_pipeline_gumbel_equals_the_oracle_driven_by_the_same_net(oracle):

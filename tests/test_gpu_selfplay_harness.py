@@ -101,12 +101,19 @@ def test_gating_match_between_two_models():
     pp.cpuct, pp.fpu_reduction = 1.25, 0.25
     pp.start_temp = pp.final_temp = 0.5                                           # eval_temp
     pp.max_cache_size = 16384
-    r = selfplay.gating_match(az.Connect4GS, pp, new, past, engines=2, seed=3)
+    r = selfplay.gating_match(az.Connect4GS, pp, new, past, engines=2, seed=3, driver="rounds")
     assert r.n_games == 64 and r.nn_wins + r.past_wins + r.n_draws == 64
     assert len(r.perm_scores) == 2 and sum(sum(ps) for ps in r.perm_scores) == 64
     assert 0 <= r.nn_rate <= 1 and 0 <= r.draw_rate <= 1 and r.hit_rate > 0
     assert abs(r.nn_rate - (r.perm_scores[0][0] + r.perm_scores[1][1]) / 64) < 0.05      # both seatings weigh the same
-    again = selfplay.gating_match(az.Connect4GS, pp, new, past, engines=2, seed=3)
+    again = selfplay.gating_match(az.Connect4GS, pp, new, past, engines=2, seed=3, driver="rounds")
     assert again == r                                                               # reproducible
+    # driver="auto" (the default): one engine on the asynchronous pipeline, one net per model group (azmi_run_pipeline_groups); which
+    # slot a restarted game lands in depends on the order the games end in, so the totals are checked, not the very games
+    pipe = selfplay.gating_match(az.Connect4GS, pp, new, past, seed=3)
+    assert pipe.n_games == 64 and pipe.nn_wins + pipe.past_wins + pipe.n_draws == 64 and pipe.hit_rate > 0
+    assert sum(sum(ps) for ps in pipe.perm_scores) == 64 and abs(pipe.nn_rate - r.nn_rate) < 0.35
+    with pytest.raises(RuntimeError, match="pipeline"):
+        selfplay.gating_match(az.TawlbwrddGS, pp, new, past, driver="pipeline")
     rnd = selfplay.gating_match(az.Connect4GS, pp, new, None, engines=2, seed=3)    # vs RandPlayer: only group 0 reaches a net
     assert rnd.n_games == 64 and rnd.nn_wins + rnd.past_wins + rnd.n_draws == 64
