@@ -23,9 +23,9 @@ a = tot(); t0 = time.perf_counter(); tiles0, boards0 = s["tiles"], s["tile_board
 for b in range(BLOCKS):
     s = az.run_pipeline(pm, hip, E, S * Q, st.cuda_stream); pm.take_history_device(torch.device("cuda", 0))
     c = tot(); t1 = time.perf_counter(); dt = t1 - t0
-    print("T %d N %d " % (s["tree_wgs"], s["net_wgs"]) + "block %d: %.0f games/s %.1f Msims/s %.1f Mevals/s hit %.3f  ms/epoch %.2f  boards/tile %.2f late %d/%d us" % (
+    print("T %d N %d " % (s["tree_wgs"], s["net_wgs"]) + "block %d: %.0f games/s %.1f Msims/s %.1f Mevals/s hit %.3f  ms/epoch %.2f  boards/tile %.2f late %d/%d us tiles_total %d" % (
         b, (c[0] - a[0]) / dt, (c[1] - a[1]) / dt / 1e6, (c[2] - a[2]) / dt / 1e6, (c[3] - a[3]) / max(1, c[3] - a[3] + c[4] - a[4]),
-        dt / E * 1e3, (s["tile_boards"] - boards0) / max(1, s["tiles"] - tiles0), s["tree_latest_start_us"], s["net_latest_start_us"]), flush=True)
+        dt / E * 1e3, (s["tile_boards"] - boards0) / max(1, s["tiles"] - tiles0), s["tree_latest_start_us"], s["net_latest_start_us"], s["tiles"]), flush=True)
     a = c; t0 = t1; tiles0, boards0 = s["tiles"], s["tile_boards"]
 if os.environ.get("DUPES"):
     for q in (64, 256, 1024):

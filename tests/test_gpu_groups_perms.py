@@ -44,6 +44,24 @@ def _slotwise(az, oracle, game_cls, gid, pp, seed):
         want[s % nperm] += o.scores(); games[s % nperm] += 1
     for q in range(nperm):
         assert np.array_equal(pm.perm_scores(q), want[q]) and pm.perm_games_completed(q) == games[q]
+    # the same case on the asynchronous pipeline (round 4: azmi_run_pipeline_groups drives Gumbel seats and two model groups; with
+    # RANDOM seats it is the tree kernel alone): the very same games, permutation tables included
+    nets = [None] * pm.num_model_groups()
+    pq = az.PlayManager(game_cls(), pp, seed=seed, log_moves=True)
+    if az.pipeline_supported_groups(pq, nets):
+        n = 0
+        while pq.remaining_games() > 0 and n < 20000:
+            az.run_pipeline_groups(pq, nets, 2, S * 64)
+            n += 1
+            if pq.poll()[1] == 0:
+                break
+        rows2, counts2 = pq.move_log()
+        o1, o2 = np.lexsort((rows[:, 2], rows[:, 1], rows[:, 0])), np.lexsort((rows2[:, 2], rows2[:, 1], rows2[:, 0]))
+        assert np.array_equal(rows[o1], rows2[o2]) and np.array_equal(counts[o1], counts2[o2]), "the pipeline plays other games than the lock-step engine"
+        for q in range(nperm):
+            assert np.array_equal(pq.perm_scores(q), want[q]) and pq.perm_games_completed(q) == games[q]
+    else:
+        assert game_cls is not az.Connect4GS, "every Connect4 case of this file runs on the pipeline too"
     return pm
 
 

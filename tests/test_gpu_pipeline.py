@@ -295,6 +295,44 @@ def test_pipeline_routes_two_model_groups_to_two_nets(oracle, cache):
         assert pa.counters()["cache_hits"] > 0
 
 
+def test_pipeline_groups_with_external_caches_of_two_sizes():
+    """PlayManager(gs, params, caches=[...]) (play_manager.cc:644-649): the caller's ShardedS3FIFOCache per model group, of DIFFERENT sizes
+    (the insert locks of group 1's shards start behind group 0's); a second engine on the same caches starts warm"""
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    nets = [az.HipLeafNet(torch_net.random_init(spec, seed=61), spec), az.HipLeafNet(torch_net.random_init(spec, seed=62), spec)]
+    S, seed = 48, 1051
+    pp = _selfplay_params(az, S, 50, cache=0)
+    pp.model_groups, pp.seat_perms = [0, 1], [[0, 1], [1, 0]]
+
+    def games(caches, pipeline):
+        pm = az.PlayManager(az.Connect4GS(), pp, caches=caches, seed=seed, log_moves=True)
+        st = torch.cuda.Stream()
+        n = 0
+        while pm.remaining_games() > 0 and n < 4000:
+            if pipeline:
+                az.run_pipeline_groups(pm, nets, 4, S * 20, st.cuda_stream)
+            else:
+                az.run_rounds_groups([pm], nets, 64, [st.cuda_stream])
+            n += 1
+            if pm.poll(st.cuda_stream)[1] == 0:
+                break
+        torch.cuda.synchronize()
+        return pm
+    ca = [az.ShardedS3FIFOCache.for_engine(8192, 7, 3), az.ShardedS3FIFOCache.for_engine(2048, 7, 3)]
+    cb = [az.ShardedS3FIFOCache.for_engine(8192, 7, 3), az.ShardedS3FIFOCache.for_engine(2048, 7, 3)]
+    pa, pb = games(ca, True), games(cb, False)
+    _same_games(pa, pa.move_log(), pb, pb.move_log(), S)
+    assert ca[0].size() > 0 and ca[1].size() > 0 and ca[0].hits() > 0
+    evals_cold = pa.counters()["evals"]
+    again = games(ca, True)                        # the same games on the warm caches: fewer leaves reach the nets
+    assert again.counters()["evals"] < evals_cold
+    ra, _ = _sorted_log(*pa.move_log())
+    rb, _ = _sorted_log(*again.move_log())
+    assert np.array_equal(ra[:, :5], rb[:, :5])
+
+
 def test_pipeline_with_a_net_behind_one_group_and_random_seats_in_the_other():
     """the reference's baseline match (game_runner.py:2143-2182: the model against RandPlayer): group 1's seats use EvalType.RANDOM, so
     only group 0 has a ring and a net behind it; a per-seat Gumbel seat on top"""
