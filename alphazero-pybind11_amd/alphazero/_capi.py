@@ -8,7 +8,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libazmi.so")
+LIB_PATH = os.environ.get("AZMI_LIB") or os.path.join(os.path.dirname(_HERE), "libazmi.so")      # AZMI_LIB: another build of the same ABI (A/B timing of a kernel change on ONE box)
 
 AZMI_MAX_PLAYERS = 4
 AZMI_MAX_PERMS = 8

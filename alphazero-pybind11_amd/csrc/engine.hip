@@ -2163,3 +2163,11 @@ int azmi_mcts_query(azmi_mcts* m, uint32_t kind, float temp, uint32_t arg, const
 }
 
 }  // extern "C"
+
+#ifdef AZMI_BIG_PROF
+extern "C" int azmi_debug_big_prof(unsigned long long* out) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(azmi::g_big_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  unsigned long long z[16] = {};
+  return hipMemcpyToSymbol(HIP_SYMBOL(azmi::g_big_prof), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -27,6 +27,19 @@ namespace azmi {
 // (they need their own LDS scratch), its position history lives in HBM (ar.rep_list / ar.rep_path: one entry per ACTION, up
 // to thousands) instead of LDS, and it adds relative values, variants and multi-action turns.  Every difference is an
 // `if constexpr (kSG)` branch below; the Tafl instantiations compile to what they were.
+#ifdef AZMI_BIG_PROF
+// phase timing of the wide-game round (an experiment build: -DAZMI_BIG_PROF): ticks of the 100 MHz wall clock per phase, summed over
+// every wave; [0] load [1] process_result (+ move) [2] descent [3] move generation [4] shuffle [5] child records [6] leaf planes + probe
+// [7] store [8] rounds
+__device__ unsigned long long g_big_prof[16];
+#define AZB_PROF_MARK(i) do { const unsigned long long now_ = wall_clock64(); pf_[i] += now_ - pf_t_; pf_t_ = now_; } while (0)
+#define AZB_PROF_DECL do {} while (0)
+#define AZB_PROF_MEMBERS unsigned long long pf_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pf_t_ = 0;
+#else
+#define AZB_PROF_MARK(i) do {} while (0)
+#define AZB_PROF_DECL do {} while (0)
+#define AZB_PROF_MEMBERS
+#endif
 template <class GM> struct is_stargambit { static constexpr bool value = false; };
 template <> struct is_stargambit<StarGambit> { static constexpr bool value = true; };
 struct NoRulesScratch {};
@@ -37,7 +50,8 @@ template <class GM>
 struct BigScratch {  // per-wave LDS
   static constexpr int kRepLds = is_stargambit<GM>::value ? 1 : GM::MAX_TURNS + 2;
   uint16_t moves[GM::MAXK];
-  float f0[GM::MAXK], f1[GM::MAXK], f2[GM::MAXK];
+  alignas(16) float f0[GM::MAXK];     // (16-byte aligned: seq_sum_f0 reads it four floats at a time)
+  float f1[GM::MAXK], f2[GM::MAXK];
   uint32_t n[GM::MAXK];
   float dense[GM::M];
   uint64_t glist[kRepLds];  // game repetition list (since the last capture)
@@ -48,6 +62,7 @@ struct BigScratch {  // per-wave LDS
 #define AZB_SEL(arr, seat) ((seat) == 0 ? arr[0] : arr[P > 1 ? 1 : 0])
 template <class GM>
 struct BigSlot {
+  AZB_PROF_MEMBERS
   static_assert(GM::P == 2, "the wide-game engine is written for two-player games (first-visit value, resign entries)");
   static constexpr int G = 64, P = GM::P, M = GM::M, MAXK = GM::MAXK;
   static constexpr bool kSG = is_stargambit<GM>::value;
@@ -238,6 +253,7 @@ struct BigSlot {
                               uint32_t& c0_out, uint32_t& k_out) {
     const size_t tb = tree_base(seat);
     uint32_t base = 0;
+    AZB_PROF_DECL;
     if constexpr (kSG) {   // legal moves in ascending order from the dense bit map (dev_stargambit.h)
       GM::gen_valid(st, lane, sm.rules);
       base = GM::list_valid(lane, sm.rules, sm.moves, static_cast<uint32_t>(MAXK));
@@ -269,6 +285,7 @@ struct BigSlot {
     }
     const uint32_t k = base;
     sync();
+    AZB_PROF_MARK(3);
     // std::shuffle (stl_algo.h:3729-3792), sequential on lane 0's copy of the stream
     if (k > 1) {
       if (lane == 0) {
@@ -291,6 +308,7 @@ struct BigSlot {
       rng.state = static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32);
       sync();
     }
+    AZB_PROF_MARK(4);
     const uint32_t c0 = AZB_SEL(t_bump, seat);
     // the bump pointer lives in one half of the arena (k_compact ping-pongs between them)
     const uint32_t limit = ep.half_nodes ? ((c0 - 1) / ep.half_nodes + 1) * ep.half_nodes : ep.cap;
@@ -304,13 +322,29 @@ struct BigSlot {
     if (lane == 0) ar.META[tb + node] = meta_pack(c0, k, meta_mv(meta_keep), meta_player(meta_keep), meta_term(meta_keep));
     c0_out = c0; k_out = k;
     sync();
+    AZB_PROF_MARK(5);
     return true;
   }
 
   // in-order sum of sm.f0[0..k): every lane walks the same LDS words (broadcast reads), result uniform
+  // (the ADDS are a dependent chain by definition - ((f0[0] + f0[1]) + f0[2]) + ... -, the LDS reads are not: sixteen elements are
+  // asked for at once, four broadcast ds_read_b128, instead of one dependent read per element.  Round 4: 11.5 -> ~2 us of a
+  // Tawlbwrdd simulation's 78.  Elements at or beyond k are read - f0 is followed by f1 - and never added.)
   __device__ __forceinline__ float seq_sum_f0(uint32_t k) const {
+    static_assert(GM::MAXK % 16 == 0, "whole 16-element steps inside f0 / f1");
     float s = 0.0f;
-    for (uint32_t i = 0; i < k; ++i) s += sm.f0[i];
+    const float4* const p4 = reinterpret_cast<const float4*>(sm.f0);
+    for (uint32_t i = 0; i < k; i += 16) {
+      const float4 a = p4[i / 4], b = p4[i / 4 + 1], c = p4[i / 4 + 2], d = p4[i / 4 + 3];
+      const float v[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+      if (i + 16 <= k) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += v[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) if (i + j < k) s += v[j];
+      }
+    }
     return s;
   }
 
@@ -517,9 +551,11 @@ struct BigSlot {
       sm.f0[i] = n > 0 ? p : 0.0f;
     }
     sync();
+    AZB_PROF_MARK(12);
     // reference: seen_policy += c.policy only for visited children, in child order; adding the 0.0f of an
     // unvisited child leaves the running sum unchanged, so the masked in-order sum is identical
     const float seen = seq_sum_f0(k);
+    AZB_PROF_MARK(13);
     const float fpu_value = v_parent - fpu_reduction * sqrtf(seen);
     const float sqrt_n = sqrtf(static_cast<float>(n_parent));
     float best_u = -__builtin_inff();
@@ -531,6 +567,7 @@ struct BigSlot {
       if (u != u) u = (i == 0) ? __builtin_inff() : -__builtin_inff();
       if (u > best_u || best_i == 0xFFFFFFFFu) { best_u = u; best_i = i; }
     }
+    AZB_PROF_MARK(14);
     for (int off = 1; off < 64; off <<= 1) {
       const float ou = __shfl_xor(best_u, off, 64);
       const uint32_t oi = __shfl_xor(best_i, off, 64);
@@ -543,6 +580,7 @@ struct BigSlot {
   // ---- MCTS::find_leaf ------------------------------------------------------------------------------------------
   __device__ __forceinline__ bool find_leaf(uint32_t seat, typename GM::State& leaf, uint32_t& term) {
     sync();
+    AZB_PROF_DECL;
     const size_t tb = tree_base(seat);
     const uint32_t root = AZB_SEL(t_root, seat);
     cur = root; plen = 0;
@@ -571,15 +609,22 @@ struct BigSlot {
       if (gum_active && cur == root) best = gumbel_next_root_child(seat, tb, c0);
       else if (gum_active && seat_gumbel_full(seat)) best = gumbel_interior_select(seat, tb, c0, k, ar.V[tb + cur]);
       else best = select_child(tb, c0, k, ar.V[tb + cur], n, fpu);
+      AZB_PROF_MARK(9);
       cur = c0 + best;
       n = ar.N[tb + cur];
       meta = ar.META[tb + cur];
+#ifdef AZMI_BIG_PROF
+      asm volatile("s_waitcnt vmcnt(0)" :: "v"(n), "v"(meta) : "memory");
+#endif
+      AZB_PROF_MARK(10);
       if (!step_state(leaf, meta_mv(meta), path_list(), path_len, base_valid, glen)) { raise(64u); return false; }
+      AZB_PROF_MARK(11);
     }
     leaf_rep_len = path_len; leaf_base_valid = base_valid;
 #pragma unroll
     for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == seat) t_tld[p] += plen;
     term = meta_term(meta);
+    AZB_PROF_MARK(2);
     if (n == 0) {
       term = GM::terminal(leaf);
       const uint64_t keep = meta_pack(0, 0, meta_mv(meta), leaf.player, term);
@@ -815,7 +860,7 @@ struct BigSlot {
         ar.D[ri] = val[P];
       }
       ar.N[ri] = rn + 1;
-      ar.c_sims[slot] += 1;
+      atomicAdd(reinterpret_cast<unsigned long long*>(&ar.c_sims[slot]), 1ull);
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) if (static_cast<uint32_t>(p) == seat) t_depth[p] += 1;
@@ -1354,7 +1399,14 @@ __device__ __forceinline__ void round_big_body(const EngineParams& ep, const Eng
   const uint8_t st = ar.sstate[slot];
   if (st == kSlotDone || st == kSlotEnded) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; return; }
   BigSlot<GM> c(ep, ar, sm, slot, lane);
+#ifdef AZMI_BIG_PROF
+  c.pf_t_ = wall_clock64();
+#define AZB_CMARK(i) do { const unsigned long long now_ = wall_clock64(); c.pf_[i] += now_ - c.pf_t_; c.pf_t_ = now_; } while (0)
+#else
+#define AZB_CMARK(i) do {} while (0)
+#endif
   c.load();
+  AZB_CMARK(0);
   uint32_t inline_sims = 0, insert_key_set = 0;
   bool need_process = (st == kSlotWaitEval);
   if (!need_process) {
@@ -1374,6 +1426,7 @@ __device__ __forceinline__ void round_big_body(const EngineParams& ep, const Eng
     const uint32_t cp = c.gs.player;
     typename GM::State leaf;
     uint32_t term = 0;
+    AZB_CMARK(1);
     if (!c.find_leaf(cp, leaf, term)) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; c.store(kSlotDone); return; }
     const bool playout = kPlayout && term == 0 && c.seat_eval_playout(cp);   // (a terminal leaf's evaluation is never used)
     const bool needs_net = term == 0 && !c.seat_eval_random(cp) && !playout;
@@ -1381,15 +1434,19 @@ __device__ __forceinline__ void round_big_body(const EngineParams& ep, const Eng
     c.flags = (needs_net || playout) ? (c.flags | kFlagLeafNeedsNet) : (c.flags & ~kFlagLeafNeedsNet);
     if constexpr (kPlayout) { if (playout) c.playout_eval(leaf); }
     if (needs_net) {
-      const uint64_t key = c.emit_leaf(leaf);
       const uint32_t group = c.seat_group(cp);
+      // the eval list's ticket is one returning atomic on a word every wave of the launch adds to: without a cache (the leaf goes to
+      // the net for certain) it is drawn BEFORE the planes are written, so its round trip rides under their stores
+      uint32_t ticket = 0;
+      if (!ep.cache_on && lane == 0) ticket = atomicAdd(&ar.ctl->eval_count[group], 1u);
+      const uint64_t key = c.emit_leaf(leaf);
       const bool hit = ep.cache_on && c.cache_lookup(key, group);
       if (!hit) {
         if (lane == 0) {
-          ar.c_evals[slot] += 1;
-          if (ep.cache_on) ar.cache_keys[slot] = cache_key(key);
+          atomicAdd(reinterpret_cast<unsigned long long*>(&ar.c_evals[slot]), 1ull);     // (this wave is the cell's one writer: the same sum as load-add-store without the dependent load)
+          if (ep.cache_on) { ar.cache_keys[slot] = cache_key(key); ticket = atomicAdd(&ar.ctl->eval_count[group], 1u); }
           ar.leaf_group[slot] = static_cast<uint8_t>(group);
-          ar.eval_list[static_cast<size_t>(group) * ep.S + atomicAdd(&ar.ctl->eval_count[group], 1u)] = slot;
+          ar.eval_list[static_cast<size_t>(group) * ep.S + ticket] = slot;
         }
         insert_key_set = 1;
         break;
@@ -1399,7 +1456,14 @@ __device__ __forceinline__ void round_big_body(const EngineParams& ep, const Eng
     if (++inline_sims >= ep.max_inline) break;
   }
   if (ep.cache_on && !insert_key_set && lane == 0) ar.cache_keys[slot] = 0;
+  AZB_CMARK(6);
   c.store(kSlotWaitEval);
+  AZB_CMARK(7);
+#ifdef AZMI_BIG_PROF
+  c.pf_[8] = 1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) if (threadIdx.x == static_cast<uint32_t>(i)) atomicAdd(&g_big_prof[i], c.pf_[i]);
+#endif
 }
 
 template <class GM, bool kPlayout = false>

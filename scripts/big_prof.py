@@ -1,0 +1,37 @@
+"""phase timing of the wide-game round kernel (a -DAZMI_BIG_PROF build: AZMI_HIPCC_EXTRA=-DAZMI_BIG_PROF python -c 'import __graft_entry__ as g; g.build()'):
+Tawlbwrdd 2048 x 400 on 4 lock-step shards with the HIP net, ticks per phase summed over every wave / rounds"""
+import os, sys, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "alphazero-pybind11_amd"))
+import torch
+import alphazero as az
+from alphazero import torch_net, _capi
+import bench
+lib = _capi.lib if hasattr(_capi, "lib") else az.lib
+S, K = int(os.environ.get("S", 2048)), 4
+spec = torch_net.tawlbwrdd_spec()
+net = az.HipLeafNet(torch_net.random_init(spec, seed=0), spec)
+pms, sts = [], []
+for k in range(K):
+    pp = bench.selfplay_params(az, S // K, 400, 1 << 30, cache=0, gumbel=bool(os.environ.get("GUMBEL")))
+    pms.append(az.PlayManager(az.TawlbwrddGS(), pp, seed=11 + k)); sts.append(torch.cuda.Stream())
+sp = [s.cuda_stream for s in sts]
+az.run_rounds(pms, net, 1024, sp); torch.cuda.synchronize()
+out = (C.c_ulonglong * 16)()
+lib.azmi_debug_big_prof.restype = C.c_int; lib.azmi_debug_big_prof.argtypes = [C.c_void_p]
+lib.azmi_debug_big_prof(out)
+import time
+t0 = time.perf_counter()
+az.run_rounds(pms, net, 1024, sp); torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+lib.azmi_debug_big_prof(out)
+n = max(1, out[8])
+names = ["load", "process_result(+move)", "descent (rest: entry, Gumbel init, exit)", "move generation", "shuffle", "child records", "planes + probe", "store"]
+tot = 0.0
+for i, nm in enumerate(names):
+    us = out[i] / n / 100.0; tot += us
+    print("%-24s %7.2f us per wave-round" % (nm, us))
+for i, nm in ((12, "descent: children -> LDS"), (13, "descent: in-order seen sum"), (14, "descent: scores"), (9, "descent: arg-max reduce"), (10, "descent: N / META of the chosen child"), (11, "descent: step_state")):
+    us = out[i] / n / 100.0; tot += us
+    print("%-40s %7.2f us per wave-round" % (nm, us))
+print("sum %.1f us; %d wave-rounds in %.2f s = %.2f M simulations/s" % (tot, n, dt, n / dt / 1e6))
