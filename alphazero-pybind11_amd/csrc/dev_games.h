@@ -124,6 +124,37 @@ struct Connect4 {
 // =====================================================================================================
 namespace azmi {
 
+// ---- rook slides on a 121-bit board without walking squares (round 4) -------------------------------------------------------------
+// The occupancy of the piece's row / column as a W-bit word (the row: one 128-bit shift; the column: H single-bit picks), then the
+// squares the piece can reach along it: everything between the piece and the nearest blocker on either side (count-trailing /
+// leading-zeros on the blockers above / below it).  Branch-free and the same ~100 instructions for every lane; the square-by-square
+// walk it replaces ran up to ten steps of ~30 instructions in each of four directions and as long as the wavefront's busiest lane.
+template <int W_>
+__host__ __device__ __forceinline__ uint32_t az_row_bits(uint64_t lo, uint64_t hi, int h) {
+  const uint32_t sh = static_cast<uint32_t>(h * W_);
+  const uint64_t v = sh == 0 ? lo : sh < 64 ? (lo >> sh) | (hi << (64 - sh)) : hi >> (sh - 64);
+  return static_cast<uint32_t>(v) & ((1u << W_) - 1u);
+}
+template <int W_, int H_>
+__host__ __device__ __forceinline__ uint32_t az_col_bits(uint64_t lo, uint64_t hi, int w) {
+  uint32_t c = 0;
+#pragma unroll
+  for (int t = 0; t < H_; ++t) {
+    const uint32_t sq = static_cast<uint32_t>(t * W_ + w);
+    c |= static_cast<uint32_t>(((sq < 64 ? lo >> sq : hi >> (sq - 64)) & 1ULL)) << t;
+  }
+  return c;
+}
+// squares of a line of n that a piece on `pos` slides to, given the line's blockers (the piece's own bit may be set: it is masked out)
+__host__ __device__ __forceinline__ uint32_t az_ray_mask(uint32_t blockers, int pos, int n) {
+  const uint32_t below = (1u << pos) - 1u;
+  const uint32_t above = ((1u << n) - 1u) & ~((2u << pos) - 1u);
+  const uint32_t up = blockers & above, dn = blockers & below;
+  const uint32_t right = up ? (above & ((1u << __builtin_ctz(up)) - 1u)) : above;
+  const uint32_t left = dn ? (below & ~((2u << (31 - __builtin_clz(dn))) - 1u)) : below;
+  return left | right;
+}
+
 struct Tawlbwrdd {
   static constexpr int kGameId = 1;
   static constexpr bool kRelative = false;     // relative_values(), game_state.h:114
@@ -176,12 +207,9 @@ struct Tawlbwrdd {
   // 22-bit target mask of the piece on sq: bits 0..10 = new_w (row slides), bits 11..21 = new_h
   __host__ __device__ static uint32_t slide_mask(const State& s, uint32_t sq) {
     const int h = sq / W, w = sq % W;
-    uint32_t m = 0;
-    for (int t = w + 1; empty_at(s, h, t); ++t) m |= 1u << t;
-    for (int t = w - 1; empty_at(s, h, t); --t) m |= 1u << t;
-    for (int t = h + 1; empty_at(s, t, w); ++t) m |= 1u << (W + t);
-    for (int t = h - 1; empty_at(s, t, w); --t) m |= 1u << (W + t);
-    return m;
+    uint64_t lo = s.def[0] | s.atk[0], hi = s.def[1] | s.atk[1];
+    if (s.king != kNoKing) { if (s.king < 64) lo |= 1ULL << s.king; else hi |= 1ULL << (s.king - 64); }
+    return az_ray_mask(az_row_bits<W>(lo, hi, h), w, W) | (az_ray_mask(az_col_bits<W, H>(lo, hi, w), h, H) << W);
   }
   __host__ __device__ static bool has_valid_moves(const State& s) {  // tawlbwrdd_gs.cc:142-174
     for (uint32_t sq = 0; sq < SQ; ++sq) {
@@ -344,15 +372,20 @@ struct TaflX {
     return !occupied(s, h * W + w);
   }
   // 2N-bit target mask of the piece on sq: bits 0..N-1 = new_w (row slides), bits N..2N-1 = new_h
+  // (is_valid_square: a corner stops everyone but the king, whatever stands on it; the empty throne lets a non-king piece through
+  // but not land: not a blocker, its bit is cleared from the landing squares)
   __host__ __device__ __forceinline__ static uint32_t slide_mask(const State& s, uint32_t sq) {
     const int h = sq / W, w = sq % W;
     const bool k = s.king == sq;
-    uint32_t m = 0;
-    for (int t = w + 1; valid_square(s, k, h, t); ++t) { if (h == T && t == T && !k) continue; m |= 1u << t; }
-    for (int t = w - 1; valid_square(s, k, h, t); --t) { if (h == T && t == T && !k) continue; m |= 1u << t; }
-    for (int t = h + 1; valid_square(s, k, t, w); ++t) { if (t == T && w == T && !k) continue; m |= 1u << (W + t); }
-    for (int t = h - 1; valid_square(s, k, t, w); --t) { if (t == T && w == T && !k) continue; m |= 1u << (W + t); }
-    return m;
+    uint64_t lo = s.def[0] | s.atk[0], hi = s.def[1] | s.atk[1];
+    if (s.king != kNoKing) { if (s.king < 64) lo |= 1ULL << s.king; else hi |= 1ULL << (s.king - 64); }
+    constexpr uint32_t ends = 1u | (1u << (N - 1));
+    uint32_t rowb = az_row_bits<W>(lo, hi, h), colb = az_col_bits<W, H>(lo, hi, w);
+    if (k) { rowb &= (h == 0 || h == H - 1) ? ~ends : ~0u; colb &= (w == 0 || w == W - 1) ? ~ends : ~0u; }   // (a corner is the king's to land on)
+    else { rowb |= (h == 0 || h == H - 1) ? ends : 0u; colb |= (w == 0 || w == W - 1) ? ends : 0u; }
+    uint32_t rm = az_ray_mask(rowb, w, W), cm = az_ray_mask(colb, h, H);
+    if (!k) { if (h == T) rm &= ~(1u << T); if (w == T) cm &= ~(1u << T); }
+    return rm | (cm << W);
   }
   __host__ __device__ __forceinline__ static bool has_valid_moves(const State& s) {  // brandubh_gs.cc:156-213 / opentafl_gs.cc:155-212
     for (uint32_t sq = 0; sq < static_cast<uint32_t>(SQ); ++sq)

@@ -40,6 +40,16 @@ __device__ unsigned long long g_big_prof[16];
 #define AZB_PROF_DECL do {} while (0)
 #define AZB_PROF_MEMBERS
 #endif
+// pcg32 is an LCG: the state after j draws is A_j * s0 + C_j (A_0 = 1, C_0 = 0; A_{j+1} = A_j * mult, C_{j+1} = C_j * mult + inc), so
+// lane j can make draw j of a std::shuffle by itself (expand_node)
+struct PcgJumpTable {
+  uint64_t a[260], c[260];
+  constexpr PcgJumpTable() : a{}, c{} {
+    uint64_t A = 1, C = 0;
+    for (int j = 0; j < 260; ++j) { a[j] = A; c[j] = C; A = A * Pcg32::kMult; C = C * Pcg32::kMult + Pcg32::kInc; }
+  }
+};
+__device__ const PcgJumpTable kPcgJump{};
 template <class GM> struct is_stargambit { static constexpr bool value = false; };
 template <> struct is_stargambit<StarGambit> { static constexpr bool value = true; };
 struct NoRulesScratch {};
@@ -286,8 +296,52 @@ struct BigSlot {
     const uint32_t k = base;
     sync();
     AZB_PROF_MARK(3);
-    // std::shuffle (stl_algo.h:3729-3792), sequential on lane 0's copy of the stream
+    // std::shuffle (stl_algo.h:3729-3792): for i = 1 .. k-1 in pairs, ONE draw x in [0, (i+1)(i+2)) gives the two swap partners
+    // x / (i+2), x % (i+2) (an even k first spends one draw on i = 1 alone).  The draws are independent of the swaps, and draw j only
+    // needs the stream advanced j times, which is a multiply-add (kPcgJump): every lane makes the draws of its pairs - state, output
+    // function, Lemire's multiply, the division - side by side, and lane 0 is left with the swaps alone (round 4: 9.5 -> ~4 us of a
+    // Tawlbwrdd simulation).  Lemire's rejection (probability range / 2^32 per draw, ~2e-4 per expansion) would shift every later
+    // draw: any lane that meets its precondition sends the whole expansion down the sequential path below.
+    bool shuffled = false;
+    static_assert(GM::MAXK <= 512, "the jump table holds 260 draws");
     if (k > 1) {
+      const uint64_t s0 = rng.state;
+      const uint32_t d0 = (k & 1u) == 0 ? 1u : 0u, i0 = 1u + d0, np = (k - i0) >> 1;
+      bool redo = false;
+      for (uint32_t j = lane; j < np; j += G) {
+        const uint32_t i = i0 + 2u * j, b1 = i + 2u, range = (i + 1u) * b1;
+        const uint64_t old = kPcgJump.a[d0 + j] * s0 + kPcgJump.c[d0 + j];
+        const uint32_t xs = static_cast<uint32_t>(((old >> 18u) ^ old) >> 27u), rot = static_cast<uint32_t>(old >> 59u);
+        const uint32_t out = (xs >> rot) | (xs << ((32u - rot) & 31u));
+        const uint64_t product = static_cast<uint64_t>(out) * static_cast<uint64_t>(range);
+        if (static_cast<uint32_t>(product) < range) redo = true;
+        const uint32_t x = static_cast<uint32_t>(product >> 32);
+        sm.n[j] = (x / b1) | ((x % b1) << 16);
+      }
+      if (__ballot(redo) == 0ull) {
+        sync();
+        if (lane == 0) {
+          uint32_t i = 1;
+          if (d0) {       // (range 2: Lemire's threshold is 0, no rejection)
+            const uint64_t old = s0;
+            const uint32_t xs = static_cast<uint32_t>(((old >> 18u) ^ old) >> 27u), rot = static_cast<uint32_t>(old >> 59u);
+            const uint32_t out = (xs >> rot) | (xs << ((32u - rot) & 31u));
+            const uint32_t j = static_cast<uint32_t>((static_cast<uint64_t>(out) * 2ull) >> 32);
+            const uint16_t t = sm.moves[i]; sm.moves[i] = sm.moves[j]; sm.moves[j] = t;
+            ++i;
+          }
+          for (uint32_t j = 0; j < np; ++j) {
+            const uint32_t pk = sm.n[j], p0 = pk & 0xFFFFu, p1 = pk >> 16;
+            uint16_t t = sm.moves[i]; sm.moves[i] = sm.moves[p0]; sm.moves[p0] = t; ++i;
+            t = sm.moves[i]; sm.moves[i] = sm.moves[p1]; sm.moves[p1] = t; ++i;
+          }
+        }
+        rng.state = kPcgJump.a[d0 + np] * s0 + kPcgJump.c[d0 + np];
+        shuffled = true;
+        sync();
+      }
+    }
+    if (k > 1 && !shuffled) {
       if (lane == 0) {
         uint32_t i = 1;
         if ((k & 1u) == 0) {
@@ -609,7 +663,7 @@ struct BigSlot {
       if (gum_active && cur == root) best = gumbel_next_root_child(seat, tb, c0);
       else if (gum_active && seat_gumbel_full(seat)) best = gumbel_interior_select(seat, tb, c0, k, ar.V[tb + cur]);
       else best = select_child(tb, c0, k, ar.V[tb + cur], n, fpu);
-      AZB_PROF_MARK(9);
+      AZB_PROF_MARK(14);
       cur = c0 + best;
       n = ar.N[tb + cur];
       meta = ar.META[tb + cur];
@@ -1439,7 +1493,9 @@ __device__ __forceinline__ void round_big_body(const EngineParams& ep, const Eng
       // the net for certain) it is drawn BEFORE the planes are written, so its round trip rides under their stores
       uint32_t ticket = 0;
       if (!ep.cache_on && lane == 0) ticket = atomicAdd(&ar.ctl->eval_count[group], 1u);
+      AZB_CMARK(12 + 3);     // [15]: from the end of the expansion to here (terminal test of the leaf's flags, the ticket's issue)
       const uint64_t key = c.emit_leaf(leaf);
+      AZB_CMARK(9);          // [9]: planes + key
       const bool hit = ep.cache_on && c.cache_lookup(key, group);
       if (!hit) {
         if (lane == 0) {

@@ -26,12 +26,12 @@ az.run_rounds(pms, net, 1024, sp); torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 lib.azmi_debug_big_prof(out)
 n = max(1, out[8])
-names = ["load", "process_result(+move)", "descent (rest: entry, Gumbel init, exit)", "move generation", "shuffle", "child records", "planes + probe", "store"]
+names = ["load", "process_result(+move)", "descent (rest: entry, Gumbel init, exit)", "move generation", "shuffle", "child records", "list entry, exit", "store"]
 tot = 0.0
 for i, nm in enumerate(names):
     us = out[i] / n / 100.0; tot += us
     print("%-24s %7.2f us per wave-round" % (nm, us))
-for i, nm in ((12, "descent: children -> LDS"), (13, "descent: in-order seen sum"), (14, "descent: scores"), (9, "descent: arg-max reduce"), (10, "descent: N / META of the chosen child"), (11, "descent: step_state")):
+for i, nm in ((12, "descent: children -> LDS"), (13, "descent: in-order seen sum"), (14, "descent: scores + arg-max"), (9, "planes + key"), (10, "descent: N / META of the chosen child"), (11, "descent: step_state"), (15, "expansion end -> planes start")):
     us = out[i] / n / 100.0; tot += us
     print("%-40s %7.2f us per wave-round" % (nm, us))
 print("sum %.1f us; %d wave-rounds in %.2f s = %.2f M simulations/s" % (tot, n, dt, n / dt / 1e6))
