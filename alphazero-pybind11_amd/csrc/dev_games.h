@@ -211,13 +211,31 @@ struct Tawlbwrdd {
     if (s.king != kNoKing) { if (s.king < 64) lo |= 1ULL << s.king; else hi |= 1ULL << (s.king - 64); }
     return az_ray_mask(az_row_bits<W>(lo, hi, h), w, W) | (az_ray_mask(az_col_bits<W, H>(lo, hi, w), h, H) << W);
   }
-  __host__ __device__ static bool has_valid_moves(const State& s) {  // tawlbwrdd_gs.cc:142-174
-    for (uint32_t sq = 0; sq < SQ; ++sq) {
-      if (!own_piece(s, s.player, sq)) continue;
-      const int h = sq / W, w = sq % W;
-      if (empty_at(s, h, w + 1) || empty_at(s, h, w - 1) || empty_at(s, h + 1, w) || empty_at(s, h - 1, w)) return true;
+  // tawlbwrdd_gs.cc:142-174: some piece of the side to move has an empty orthogonal neighbour.  On the bitboards: the mover's
+  // pieces shifted one square east / west (without the wrap from one row's end to the next row's start) / south / north, against
+  // the empty squares (round 4: the square-by-square scan was ~500 instructions of every simulation's terminal test).
+  __host__ __device__ static bool has_valid_moves(const State& s) {
+    uint64_t olo = s.def[0] | s.atk[0], ohi = s.def[1] | s.atk[1];
+    uint64_t mlo = s.player == 0 ? s.atk[0] : s.def[0], mhi = s.player == 0 ? s.atk[1] : s.def[1];
+    if (s.king != kNoKing) {
+      const uint64_t kl = s.king < 64 ? 1ULL << s.king : 0ULL, kh = s.king < 64 ? 0ULL : 1ULL << (s.king - 64);
+      olo |= kl; ohi |= kh;
+      if (s.player == 1) { mlo |= kl; mhi |= kh; }
     }
-    return false;
+    // columns 0 and 10 of the 121-bit board (bit sq = h * 11 + w): constants after unrolling
+    uint64_t col0lo = 0, col0hi = 0, col10lo = 0, col10hi = 0;
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh) {
+      const int a = hh * W, b = hh * W + W - 1;
+      if (a < 64) col0lo |= 1ULL << a; else col0hi |= 1ULL << (a - 64);
+      if (b < 64) col10lo |= 1ULL << b; else col10hi |= 1ULL << (b - 64);
+    }
+    const uint64_t elo = ~olo, ehi = ~ohi & ((1ULL << (SQ - 64)) - 1ULL);       // empty squares of the board
+    const uint64_t east_lo = (mlo << 1) & ~col0lo, east_hi = ((mhi << 1) | (mlo >> 63)) & ~col0hi;
+    const uint64_t west_lo = ((mlo >> 1) | (mhi << 63)) & ~col10lo, west_hi = (mhi >> 1) & ~col10hi;
+    const uint64_t south_lo = mlo << W, south_hi = (mhi << W) | (mlo >> (64 - W));
+    const uint64_t north_lo = (mlo >> W) | (mhi << (64 - W)), north_hi = mhi >> W;
+    return (((east_lo | west_lo | south_lo | north_lo) & elo) | ((east_hi | west_hi | south_hi | north_hi) & ehi)) != 0;
   }
   __host__ __device__ static void remove_at(State& s, uint32_t sq) {
     clrb(s.def, sq); clrb(s.atk, sq);
@@ -278,6 +296,22 @@ struct Tawlbwrdd {
     if (!has_valid_moves(s)) return 1 + (s.player ^ 1u);
     if (s.turn >= static_cast<uint32_t>(MAX_TURNS)) return 3;
     return 0;
+  }
+  // the canonical tensor of a leaf by one wavefront, plane by plane: the three piece planes from the bitboards, the four flag planes
+  // as fills (canonical_at below, element by element, spent a division and a switch on each of the 847 entries)
+  __device__ __forceinline__ static void write_canonical_wave(const State& s, float* row, uint32_t lane) {
+    const float fl[4] = {s.player == 0 ? 1.0f : 0.0f, s.player == 1 ? 1.0f : 0.0f, (s.rep == 1 || s.rep > 2) ? 1.0f : 0.0f, s.rep >= 2 ? 1.0f : 0.0f};
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const uint32_t sq = it * 64 + lane;
+      if (sq < static_cast<uint32_t>(SQ)) {
+        row[sq] = s.king == sq ? 1.0f : 0.0f;
+        row[SQ + sq] = bit(s.def, sq) ? 1.0f : 0.0f;
+        row[2 * SQ + sq] = bit(s.atk, sq) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) row[(3 + p) * SQ + sq] = fl[p];
+      }
+    }
   }
   // tawlbwrdd_gs.cc:399-453
   __host__ __device__ static float canonical_at(const State& s, uint32_t e) {
@@ -516,6 +550,24 @@ struct TaflX {
       case 5: return (s.rep == 1 || s.rep > 2) ? 1.0f : 0.0f;
       case 6: return s.rep >= 2 ? 1.0f : 0.0f;
       default: return static_cast<float>(s.turn) / static_cast<float>(MAX_TURNS);   // opentafl_gs.cc:574-579
+    }
+  }
+  // (the same tensor by one wavefront, plane by plane: Tawlbwrdd::write_canonical_wave)
+  __device__ __forceinline__ static void write_canonical_wave(const State& s, float* row, uint32_t lane) {
+    float fl[C - 3];
+    fl[0] = s.player == 0 ? 1.0f : 0.0f; fl[1] = s.player == 1 ? 1.0f : 0.0f;
+    fl[2] = (s.rep == 1 || s.rep > 2) ? 1.0f : 0.0f; fl[3] = s.rep >= 2 ? 1.0f : 0.0f;
+    if constexpr (C > 7) fl[4] = static_cast<float>(s.turn) / static_cast<float>(MAX_TURNS);
+#pragma unroll
+    for (int it = 0; it < (SQ + 63) / 64; ++it) {
+      const uint32_t sq = it * 64 + lane;
+      if (sq < static_cast<uint32_t>(SQ)) {
+        row[sq] = s.king == sq ? 1.0f : 0.0f;
+        row[SQ + sq] = bit(s.def, sq) ? 1.0f : 0.0f;
+        row[2 * SQ + sq] = bit(s.atk, sq) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int p = 0; p < C - 3; ++p) row[(3 + p) * SQ + sq] = fl[p];
+      }
     }
   }
 };

@@ -269,28 +269,40 @@ struct BigSlot {
       base = GM::list_valid(lane, sm.rules, sm.moves, static_cast<uint32_t>(MAXK));
       if (base > static_cast<uint32_t>(MAXK)) { raise(8u); return false; }
     } else {
-    // move generation: lane handles squares lane and lane + 64
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const uint32_t sq = half * 64 + lane;
-      uint32_t mask = 0;
-      if (sq < static_cast<uint32_t>(GM::SQ) && GM::own_piece(st, st.player, sq)) mask = GM::slide_mask(st, sq);
-      const uint32_t cnt = __builtin_popcount(mask);
-      uint32_t incl = cnt;  // inclusive wave scan
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_up(incl, off, 64);
-        if (lane >= static_cast<uint32_t>(off)) incl += o;
+    // move generation.  The mover's pieces are compacted first - piece j in ascending square order goes to lane j (two ballots = the
+    // mover's bitboard words; a lane's rank is a population count) - so every lane computes at most ONE slide mask and the wave
+    // makes one prefix scan (round 4: the kernel used to walk squares lane and lane + 64 in two passes of mask + scan + list)
+    {
+      const uint32_t sqa = lane, sqb = 64u + lane;
+      const bool owna = sqa < static_cast<uint32_t>(GM::SQ) && GM::own_piece(st, st.player, sqa);
+      const bool ownb = sqb < static_cast<uint32_t>(GM::SQ) && GM::own_piece(st, st.player, sqb);
+      const uint64_t ba = __ballot(owna), bb = __ballot(ownb);
+      const uint32_t na = static_cast<uint32_t>(__popcll(ba)), npieces = na + static_cast<uint32_t>(__popcll(bb));
+      const uint64_t below = (1ull << lane) - 1ull;
+      if (owna) sm.n[__popcll(ba & below)] = sqa;
+      if (ownb) sm.n[na + __popcll(bb & below)] = sqb;
+      sync();
+      for (uint32_t pbase = 0; pbase < npieces; pbase += G) {       // (one turn: a side has at most 24 pieces; a hand-built board may have more)
+        const bool on = pbase + lane < npieces;
+        const uint32_t sq = on ? sm.n[pbase + lane] : 0u;
+        const uint32_t mask = on ? GM::slide_mask(st, sq) : 0u;
+        const uint32_t cnt = __builtin_popcount(mask);
+        uint32_t incl = cnt;  // inclusive wave scan
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t o = __shfl_up(incl, off, 64);
+          if (lane >= static_cast<uint32_t>(off)) incl += o;
+        }
+        uint32_t pos = base + incl - cnt;
+        const uint32_t total = __shfl(incl, 63, 64);
+        if (base + total > static_cast<uint32_t>(MAXK)) { raise(8u); return false; }
+        uint32_t m = mask;
+        while (m) {
+          const uint32_t b = __builtin_ctz(m);
+          m &= m - 1;
+          sm.moves[pos++] = static_cast<uint16_t>(sq * (GM::W + GM::H) + b);
+        }
+        base += total;
       }
-      uint32_t pos = base + incl - cnt;
-      const uint32_t total = __shfl(incl, 63, 64);
-      if (base + total > static_cast<uint32_t>(MAXK)) { raise(8u); return false; }
-      uint32_t m = mask;
-      while (m) {
-        const uint32_t b = __builtin_ctz(m);
-        m &= m - 1;
-        sm.moves[pos++] = static_cast<uint16_t>(sq * (GM::W + GM::H) + b);
-      }
-      base += total;
     }
     }
     const uint32_t k = base;
@@ -681,6 +693,9 @@ struct BigSlot {
     AZB_PROF_MARK(2);
     if (n == 0) {
       term = GM::terminal(leaf);
+#ifdef AZMI_BIG_PROF_TERMINAL
+      AZB_PROF_MARK(0);      // (experiment: the terminal test's share lands in [0] "load")
+#endif
       const uint64_t keep = meta_pack(0, 0, meta_mv(meta), leaf.player, term);
       uint32_t c0, k;
       if (!expand_node(seat, cur, leaf, keep, c0, k)) return false;
@@ -1412,7 +1427,7 @@ struct BigSlot {
       GM::write_canonical(leaf, row, lane, sm.rules);
       key = GM::key(leaf, lane);
     } else {
-      for (uint32_t e = lane; e < static_cast<uint32_t>(GM::CANON); e += G) row[e] = GM::canonical_at(leaf, e);
+      GM::write_canonical_wave(leaf, row, lane);
       key = GM::key(leaf);
     }
     if (lane == 0) ar.leaf_key[slot] = key;
