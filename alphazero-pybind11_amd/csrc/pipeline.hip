@@ -797,7 +797,11 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
     // ---- an answer token: the slot is back once req_seq shows the token's number; its granules become the slot's (v, pi) rows
     if (my_slot != kNoSlot && tok_seq != 0u) {
       while (g_ld(ar.req_seq + my_slot) != tok_seq) {
-        if (wall_clock64() - t_start > pa.cap_ticks) { if (lane == 0) atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTimeout)); my_slot = kNoSlot; break; }
+        if (wall_clock64() - t_start > pa.cap_ticks) {
+          if (lane == 0 && atomicAdd(&pc->dbg[0], 1u) == 0u) { pc->dbg[1] = my_slot; pc->dbg[2] = tok_seq; pc->dbg[3] = g_ld(ar.req_seq + my_slot); pc->dbg[4] = 0xAAAAu; pc->dbg[5] = ar.sstate[my_slot]; pc->dbg[6] = ar.flags[my_slot]; }
+          if (lane == 0) atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTimeout));
+          my_slot = kNoSlot; break;
+        }
         __builtin_amdgcn_s_sleep(2);
       }
     }
@@ -814,7 +818,11 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
 #pragma unroll
         for (int i = 1; i < 8; i <<= 1) okg &= static_cast<uint32_t>(__shfl_xor(static_cast<int>(okg), i, 8));
         if (okg) { answered = true; break; }
-        if (wall_clock64() - t_start > pa.cap_ticks) { if (lane == 0) atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTimeout)); my_slot = kNoSlot; break; }
+        if (wall_clock64() - t_start > pa.cap_ticks) {
+          if (lane == 0 && atomicAdd(&pc->dbg[0], 1u) == 0u) { pc->dbg[1] = my_slot; pc->dbg[2] = tok_seq; pc->dbg[3] = static_cast<uint32_t>(g0 >> 32); pc->dbg[4] = 0xBBBBu; pc->dbg[5] = static_cast<uint32_t>(g1 >> 32); pc->dbg[6] = g_ld(ar.req_seq + my_slot); }
+          if (lane == 0) atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTimeout));
+          my_slot = kNoSlot; break;
+        }
         __builtin_amdgcn_s_sleep(2);
       }
       if (answered) {
