@@ -1295,7 +1295,7 @@ int pipe_create(azmi_pm* pm, size_t tile_lds) {
   pa.min_active = getenv("AZMI_PIPE_MIN_ACTIVE") ? static_cast<uint32_t>(std::max(0, atoi(getenv("AZMI_PIPE_MIN_ACTIVE")))) : 0u;
   // net side: a workgroup draws a 6-request window (the 6-board tile: capacity) when at least big_at requests wait in the ring, else a
   // 3-request window (the 3-board tile: 39 us instead of 60 alone - with 4096 slots a slot's wait for its answer is what is short)
-  pa.big_at = getenv("AZMI_PIPE_BIG_AT") ? static_cast<uint32_t>(std::max(0, atoi(getenv("AZMI_PIPE_BIG_AT")))) : 48u;
+  pa.big_at = getenv("AZMI_PIPE_BIG_AT") ? static_cast<uint32_t>(std::max(0, atoi(getenv("AZMI_PIPE_BIG_AT")))) : 96u;      // (same-box A/B at 4096 slots: 48 -> 100.0, 96 / 128 / 192 -> 102.4 M simulations/s; 16384 slots: no difference)
   pa.take_wait = getenv("AZMI_PIPE_TAKE_WAIT") ? static_cast<uint32_t>(std::max(0, atoi(getenv("AZMI_PIPE_TAKE_WAIT")))) : 0u;
   (void)tile_lds;
   AZMI_HIP_TRY(hipStreamCreateWithFlags(&ps->net_stream, hipStreamNonBlocking));
