@@ -94,7 +94,8 @@ struct PipeEpoch {        // an allocation of its own, zeroed before every epoch
   uint32_t tree_late_n, net_late_n;   // calibration launches: workgroups that only started when the others had left
   uint32_t lost;          // ring positions a net workgroup gave up on in this epoch (their requests were overwritten a lap later before
                           // it could look: the workgroup had been switched out): k_pipe_settle re-queues those slots, no error
-  uint32_t pad1[16];
+  uint32_t svc_arrived, svc_late_n;   // conveyor: its service workgroups that started / that only started when the others had left (calibration)
+  uint32_t pad1[14];
 };
 static_assert(sizeof(PipeEpoch) == 256, "memset block: a multiple of 16 bytes");
 

@@ -15,6 +15,7 @@
 #include <mutex>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "../../include/azmi.h"
 #include "engine_host.h"
@@ -22,6 +23,7 @@
 #include "engine_kernels.h"
 #include "leafnet_c4.h"
 #include "pipe_types.h"
+#include "conveyor_c4.h"
 
 using namespace azmi;
 
@@ -1165,6 +1167,48 @@ __global__ void k_pair_wait(uint32_t* flag) {
 }
 __global__ void k_pair_set(uint32_t* flag) { g_st(flag, 1u); }
 
+// ---- the conveyor (conveyor_c4.h): its service kernel, and the launch-order helper --------------------------------------------------------
+namespace cvn = azmi_net_dev::cv;
+struct C4KeyFn {      // Connect4::key of a packed position (what k_pipe_net computes for the answer table)
+  __device__ unsigned long long operator()(unsigned long long b0, unsigned long long b1, uint32_t pl) const {
+    Connect4::State s_; s_.bb[0] = b0; s_.bb[1] = b1; s_.player = pl; s_.turn = 0;
+    return Connect4::key(s_);
+  }
+};
+// census of a calibration launch (pipe_calibrate): the workgroup announces itself, holds its place until `hold` ticks after the
+// epoch's first workgroup and leaves; returns true in that case
+__device__ __forceinline__ bool cv_census(PipeEpoch* pe, uint32_t hold, uint32_t* arrived, uint32_t* late_n) {
+  const uint64_t t_start = wall_clock64();
+  if (threadIdx.x == 0) {
+    unsigned long long t0 = atomicCAS(&pe->t0, 0ull, static_cast<unsigned long long>(t_start));
+    if (t0 == 0ull) t0 = t_start;
+    atomicMax(&pe->net_late, static_cast<uint32_t>(t_start > t0 ? t_start - t0 : 0ull));
+    atomicAdd(arrived, 1u);
+    if (hold != 0u && t_start > t0 && t_start - t0 >= hold) atomicAdd(late_n, 1u);
+  }
+  if (hold == 0u) return false;
+  __syncthreads();
+  const unsigned long long t0 = g_ld(&pe->t0);
+  while (wall_clock64() < t0 + hold) __builtin_amdgcn_s_sleep(32);
+  return true;
+}
+__global__ __launch_bounds__(256, 1) void k_cv_line_pipe(cvn::CvArgs a, PipeEpoch* pe, uint32_t hold) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_cvl[];
+  if (cv_census(pe, hold, &pe->net_arrived, &pe->net_late_n)) return;
+  cvn::line_wg(a, lds_cvl);
+}
+__global__ __launch_bounds__(cvn::SVC_THREADS, 2) void k_cv_service(cvn::CvArgs a, cvn::SvcPipe sp, PipeEpoch* pe, uint32_t hold) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds_cvs[];
+  if (cv_census(pe, hold, &pe->svc_arrived, &pe->svc_late_n)) return;
+  cvn::service_wg<C4KeyFn, 4, 16>(a, sp, lds_cvs, C4KeyFn{});
+}
+// the tree kernel is launched behind this one: the conv workgroups (a whole CU each) take their places first, the tree workgroups
+// pack into what is left (two per CU).  Gives up after 0.5 ms: placement is speed, never correctness
+__global__ void k_cv_wait_started(PipeEpoch* pe, uint32_t want) {
+  const uint64_t t0 = wall_clock64();
+  while (g_ld(&pe->net_arrived) < want && wall_clock64() - t0 < 50000ull) __builtin_amdgcn_s_sleep(32);
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------------------------
 struct PipeState {
   PipeArrays pa{};
@@ -1190,11 +1234,20 @@ struct PipeState {
   bool balance = false;
   unsigned long long bal_sims = 0, bal_boards = 0;
   uint32_t lost_seen = 0;           // PipeCtl::lost_total already reported
+  // the conveyor (conveyor_c4.h): the net side as lines of weight-stationary conv workgroups + one service workgroup per line
+  bool cv_on = false;               // this call runs it (else: the tile kernel k_pipe_net)
+  hipStream_t svc_stream = nullptr;
+  hipEvent_t ev_svc = nullptr;
+  uint32_t cv_lines = 0, cv_lines_alloc = 0, cv_nwg = 0, cv_heads = 2;
+  uint32_t* cv_xh = nullptr; uint8_t* cv_xt = nullptr; uint8_t* cv_xs = nullptr; uint32_t* cv_meta = nullptr; unsigned long long* cv_stat = nullptr;
+  bool cv_calibrated = false;
 };
 void pipe_state_free(PipeState* p) {
   if (!p) return;
   for (void* q : p->allocs) (void)hipFree(q);
   if (p->net_stream) (void)hipStreamDestroy(p->net_stream);
+  if (p->svc_stream) (void)hipStreamDestroy(p->svc_stream);
+  if (p->ev_svc) (void)hipEventDestroy(p->ev_svc);
   for (hipStream_t q : p->parked) (void)hipStreamDestroy(q);
   if (p->ev_go) (void)hipEventDestroy(p->ev_go);
   if (p->ev_net) (void)hipEventDestroy(p->ev_net);
@@ -1368,6 +1421,122 @@ int pipe_pair_streams(PipeState* ps, hipStream_t st) {
                         "the pipeline needs its tree and net kernels on the chip together - use azmi_run_rounds");
 }
 
+// ---- the conveyor's host side ---------------------------------------------------------------------------------------------------------
+// When the net side can be the conveyor (conveyor_c4.h): the bf16 tier, one model group, an even number of residual blocks (a conv
+// workgroup = two blocks).  AZMI_PIPE_NET=tiles keeps the tile kernel (k_pipe_net), =conveyor insists (an error where it cannot run).
+bool cv_eligible(const azmi_pm* pm, const PipePlan& plan) {
+  if (const char* e = getenv("AZMI_PIPE_NET")) if (strcmp(e, "tiles") == 0) return false;
+  const azmi_net_dev::NetDesc& nd = plan.view[0].nd;
+  return !plan.tree_only && plan.kind == 1 && plan.net_groups == 1u && pm->ep.num_groups == 1u && plan.view[0].x3 == 0 && nd.depth >= 2 && nd.depth % 2 == 0;
+}
+uint32_t cv_default_lines(uint32_t cus, uint32_t nwg, uint32_t tree_wgs) {
+  // CUs: a conv workgroup each, two service workgroups per CU (registers), two tree workgroups per CU
+  uint32_t lines = 1;
+  while ((lines + 1u) * nwg + (lines + 2u) / 2u + (tree_wgs + 1u) / 2u <= cus) ++lines;
+  return lines;
+}
+int cv_setup(azmi_pm* pm, PipeState* ps, const azmi_net_c4_view& view) {
+  const uint32_t nwg = static_cast<uint32_t>(view.nd.depth) / 2u;
+  hipDeviceProp_t prop;
+  AZMI_HIP_TRY(hipGetDeviceProperties(&prop, pm->device));
+  const uint32_t cus = static_cast<uint32_t>(prop.multiProcessorCount);
+  if (!ps->svc_stream) {
+    AZMI_HIP_TRY(hipStreamCreateWithFlags(&ps->svc_stream, hipStreamNonBlocking));
+    AZMI_HIP_TRY(hipEventCreateWithFlags(&ps->ev_svc, hipEventDisableTiming));
+    AZMI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cv_line_pipe), hipFuncAttributeMaxDynamicSharedMemorySize, cvn::LINE_LDS_BYTES));
+    AZMI_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cv_service), hipFuncAttributeMaxDynamicSharedMemorySize, cvn::SVC_LDS_BYTES));
+  }
+  const uint32_t want_alloc = std::max<uint32_t>(1u, cus / nwg);
+  if (ps->cv_nwg != nwg || ps->cv_lines_alloc < want_alloc) {
+    // (buffers of an earlier net shape stay in ps->allocs until the engine goes: a change of depth on one engine is rare)
+    const size_t rings = static_cast<size_t>(want_alloc) * (nwg + 1u);
+    int rc = pipe_alloc(ps, ps->cv_xh, rings * 128);
+    if (rc == AZMI_OK) rc = pipe_alloc(ps, ps->cv_xt, rings * cvn::X_T);
+    if (rc == AZMI_OK) rc = pipe_alloc(ps, ps->cv_xs, rings * cvn::X_S);
+    if (rc == AZMI_OK) rc = pipe_alloc(ps, ps->cv_meta, static_cast<size_t>(want_alloc) * cvn::MGRP * 32);
+    if (rc == AZMI_OK && !ps->cv_stat) rc = pipe_alloc(ps, ps->cv_stat, 16);
+    if (rc != AZMI_OK) return rc;
+    ps->cv_nwg = nwg; ps->cv_lines_alloc = want_alloc; ps->cv_calibrated = false;
+    ps->cv_lines = 0;
+  }
+  if (ps->cv_lines == 0) {
+    uint32_t lines = cv_default_lines(cus, nwg, ps->tree_wgs);
+    if (const char* e = getenv("AZMI_CV_LINES")) lines = static_cast<uint32_t>(std::max(1, atoi(e)));
+    ps->cv_lines = std::min(lines, ps->cv_lines_alloc);
+    ps->cv_heads = getenv("AZMI_CV_HEADS") ? static_cast<uint32_t>(std::min(2, std::max(1, atoi(getenv("AZMI_CV_HEADS"))))) : 2u;
+  }
+  return AZMI_OK;
+}
+cvn::CvArgs cv_args(const PipeState* ps, const azmi_net_c4_view& view, const PipeArrays& pa) {
+  cvn::CvArgs a{};
+  a.nd = view.nd; a.np = view.np;
+  a.xh = ps->cv_xh; a.xt = ps->cv_xt; a.xs = ps->cv_xs; a.meta = ps->cv_meta;
+  a.lines = ps->cv_lines; a.nwg = ps->cv_nwg;
+  a.err = &pa.ctl->err; a.stop = &pa.ep->stop; a.cap_ticks = pa.cap_ticks; a.stat = ps->cv_stat;
+  return a;
+}
+cvn::SvcPipe cv_svc(const PipeState* ps, const PipeArrays& pa) {
+  cvn::SvcPipe sp{};
+  sp.ring = pa.ring; sp.head = &pa.ctl->head; sp.tail = &pa.ctl->tail;
+  sp.stop = &pa.ep->stop; sp.tree_done = &pa.ep->tree_done; sp.tree_arrived = &pa.ep->tree_arrived;
+  sp.res = pa.res; sp.l0 = pa.l0; sp.l0_mask = pa.l0_mask;
+  sp.rring = pa.rring; sp.rshift = pa.rshift; sp.n_tree_wgs = pa.n_tree_wgs; sp.wg_rtail = reinterpret_cast<uint32_t*>(pa.wg);
+  sp.tiles = &pa.ctl->tiles; sp.tile_boards = &pa.ctl->tile_boards; sp.lost = &pa.ep->lost; sp.lost_total = &pa.ctl->lost_total;
+  sp.dbg = pa.ctl->dbg; sp.n_heads = ps->cv_heads;
+  return sp;
+}
+// one epoch's conveyor launches: the ring headers are zeroed on `st` (ahead of ev_go), the conv lines go to net_stream, the service
+// workgroups to svc_stream; both streams are joined back into `st` by the caller (ev_net, ev_svc)
+int cv_launch(PipeState* ps, const azmi_net_c4_view& view, const PipeArrays& pa, uint32_t hold) {
+  const cvn::CvArgs a = cv_args(ps, view, pa);
+  k_cv_line_pipe<<<ps->cv_lines * ps->cv_nwg, 256, cvn::LINE_LDS_BYTES, ps->net_stream>>>(a, pa.ep, hold);
+  AZMI_HIP_TRY(hipGetLastError());
+  k_cv_service<<<ps->cv_lines, cvn::SVC_THREADS, cvn::SVC_LDS_BYTES, ps->svc_stream>>>(a, cv_svc(ps, pa), pa.ep, hold);
+  AZMI_HIP_TRY(hipGetLastError());
+  return AZMI_OK;
+}
+int cv_zero_headers(PipeState* ps, hipStream_t st) {
+  AZMI_HIP_TRY(hipMemsetAsync(ps->cv_xh, 0, static_cast<size_t>(ps->cv_lines) * (ps->cv_nwg + 1u) * 512u, st));
+  return AZMI_OK;
+}
+void pipe_launch_tree(azmi_pm* pm, PipeState* ps, const PipeArrays& pa, hipStream_t st, bool prof);
+// Measures how many LINES run beside the tree workgroups (pipe_calibrate's census, for the conveyor): every workgroup of the three
+// kernels holds its place; a conv workgroup that the chip has no CU for starts late and is counted, and the line count gives way.
+int cv_calibrate(azmi_pm* pm, PipeState* ps, hipStream_t st, const azmi_net_c4_view& view) {
+  if (ps->cv_calibrated || getenv("AZMI_PIPE_NO_CALIBRATE")) { ps->cv_calibrated = true; return AZMI_OK; }
+  PipeArrays pa = ps->pa;
+  pa.census_hold = 100000u;
+  for (int attempt = 0; attempt < 24; ++attempt) {
+    AZMI_HIP_TRY(hipMemsetAsync(pa.ep, 0, sizeof(PipeEpoch), st));
+    { const int rc = cv_zero_headers(ps, st); if (rc != AZMI_OK) return rc; }
+    AZMI_HIP_TRY(hipEventRecord(ps->ev_go, st));
+    AZMI_HIP_TRY(hipStreamWaitEvent(ps->net_stream, ps->ev_go, 0));
+    AZMI_HIP_TRY(hipStreamWaitEvent(ps->svc_stream, ps->ev_go, 0));
+    { const int rc = cv_launch(ps, view, pa, pa.census_hold); if (rc != AZMI_OK) return rc; }
+    k_cv_wait_started<<<1, 1, 0, st>>>(pa.ep, ps->cv_lines * ps->cv_nwg);
+    pipe_launch_tree(pm, ps, pa, st, false);
+    AZMI_HIP_TRY(hipGetLastError());
+    AZMI_HIP_TRY(hipEventRecord(ps->ev_net, ps->net_stream));
+    AZMI_HIP_TRY(hipEventRecord(ps->ev_svc, ps->svc_stream));
+    AZMI_HIP_TRY(hipStreamWaitEvent(st, ps->ev_net, 0));
+    AZMI_HIP_TRY(hipStreamWaitEvent(st, ps->ev_svc, 0));
+    PipeEpoch he;
+    AZMI_HIP_TRY(hipMemcpyAsync(&he, pa.ep, sizeof(he), hipMemcpyDeviceToHost, st));
+    AZMI_HIP_TRY(hipStreamSynchronize(st));
+    ps->calib_rounds = static_cast<uint32_t>(attempt) + 1u;
+    const uint32_t late = he.tree_late_n + he.net_late_n + he.svc_late_n;
+    if (late == 0u && he.tree_arrived == ps->tree_wgs && he.net_arrived == ps->cv_lines * ps->cv_nwg && he.svc_arrived == ps->cv_lines) {
+      ps->cv_calibrated = true;
+      return AZMI_OK;
+    }
+    if (ps->cv_lines <= 1u) break;
+    const uint32_t give = std::max<uint32_t>(1u, (late + ps->cv_nwg - 1u) / ps->cv_nwg);
+    ps->cv_lines = ps->cv_lines > give ? ps->cv_lines - give : 1u;
+  }
+  return azmi_host_fail(AZMI_ERR_STATE, "azmi_run_pipeline: the chip does not hold %u tree workgroups beside one conveyor line (another tenant on the GPU? no third "
+                        "hardware queue?); AZMI_PIPE_NET=tiles runs the tile kernel", ps->tree_wgs);
+}
+
 // Measures how many net workgroups run BESIDE the tree workgroups: both persistent kernels are launched as they are in an epoch, with
 // PipeArrays::census_hold set - every workgroup that gets a place holds it until 1 ms after the first one started (far longer than the
 // two launches are apart) and leaves; one that the chip has no place for starts only then, finds itself late and is counted.  The net side gives up as many workgroups as came late (tree workgroups that came
@@ -1400,6 +1569,14 @@ int pipe_calibrate(azmi_pm* pm, PipeState* ps, hipStream_t st, const azmi_net_c4
   }
   return azmi_host_fail(AZMI_ERR_STATE, "azmi_run_pipeline: the chip does not hold %u tree workgroups beside one net workgroup (another tenant on the GPU? "
                         "AZMI_PIPE_TREE_WGS too large?); use azmi_run_rounds", ps->tree_wgs);
+}
+
+void pipe_launch_tree(azmi_pm* pm, PipeState* ps, const PipeArrays& pa, hipStream_t st, bool prof) {
+  if (ps->kind == 2) k_pipe_tree_generic<Connect4, 256><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
+  else if (pm->ep.gumbel_on) k_pipe_tree<Connect4, 256, false, true, true><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
+  else if (pa.n_groups > 1u) k_pipe_tree<Connect4, 256, false, true><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
+  else if (prof) k_pipe_tree<Connect4, 256, true><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
+  else k_pipe_tree<Connect4, 256, false><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
 }
 
 }  // namespace
@@ -1521,7 +1698,22 @@ static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_ne
   }
   if (!tree_only) { const int rc = pipe_pair_streams(ps, st); if (rc != AZMI_OK) return rc; }
   if (!tree_only) { const int rc = pipe_size_net(pm, ps, view); if (rc != AZMI_OK) return rc; }
-  if (!tree_only) { const int rc = pipe_calibrate(pm, ps, st, view); if (rc != AZMI_OK) return rc; }
+  // the net side: the conveyor where it can run (conveyor_c4.h), else the tile kernel
+  ps->cv_on = cv_eligible(pm, plan);
+  if (const char* e = getenv("AZMI_PIPE_NET")) if (strcmp(e, "conveyor") == 0 && !ps->cv_on && !tree_only)
+    return azmi_host_fail(AZMI_ERR_STATE, "AZMI_PIPE_NET=conveyor: the conveyor runs the bf16 tier behind one model group with an even number of residual blocks");
+  if (ps->cv_on) {
+    if (ps->balance) { ps->tree_wgs = ps->tree_wgs_default; pa.n_tree_wgs = ps->tree_wgs; }      // (the 512-place balance rule is the tile kernel's)
+    pa.cap_ticks = static_cast<unsigned long long>((getenv("AZMI_PIPE_CAP_MS") ? atof(getenv("AZMI_PIPE_CAP_MS")) : 250.0) * 1e5);
+    int rc = cv_setup(pm, ps, view);
+    if (rc == AZMI_OK) rc = cv_calibrate(pm, ps, st, view);
+    if (rc != AZMI_OK) {
+      if (getenv("AZMI_PIPE_NET")) return rc;
+      fprintf(stderr, "azmi_run_pipeline: the conveyor does not run here (%s); the tile kernel takes the net side\n", azmi_last_error());
+      ps->cv_on = false;
+    }
+  }
+  if (!tree_only && !ps->cv_on) { const int rc = pipe_calibrate(pm, ps, st, view); if (rc != AZMI_OK) return rc; }
   // the insert log holds an epoch's answers: at most one per simulation, in practice a third of them
   // (the quota is checked between passes: an epoch overshoots it by what the passes under way still finish)
   const uint64_t want_log = pm->ep.cache_on ? std::min<uint64_t>(std::min<uint64_t>(sims_per_epoch, 1024ull * pm->ep.S) + 2ull * pm->ep.S + static_cast<uint64_t>(ps->tree_wgs) * 32u * (pa.max_inline + 1u), 1ull << 24) : 0ull;
@@ -1588,11 +1780,23 @@ static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_ne
   const auto host_t0 = std::chrono::steady_clock::now();       // what the host spends enqueueing the epochs (it runs ahead of the GPU)
   for (uint32_t e = 0; e < epochs; ++e) {
     AZMI_HIP_TRY(hipMemsetAsync(pa.ep, 0, sizeof(PipeEpoch), st));
+    if (ps->cv_on) { rc = cv_zero_headers(ps, st); if (rc != AZMI_OK) return rc; }
     k_pipe_seed<<<settle_blocks, 256, 0, st>>>(pm->ep, pm->ar, pa);
     AZMI_HIP_TRY(hipGetLastError());
     if (!tree_only) {
       AZMI_HIP_TRY(hipEventRecord(ps->ev_go, st));
       AZMI_HIP_TRY(hipStreamWaitEvent(ps->net_stream, ps->ev_go, 0));
+      if (ps->cv_on) AZMI_HIP_TRY(hipStreamWaitEvent(ps->svc_stream, ps->ev_go, 0));
+    }
+    if (ps->cv_on) {      // the conv workgroups take their CUs first (k_cv_wait_started), the tree workgroups pack into the rest
+      AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 0], ps->net_stream));
+      rc = cv_launch(ps, view, pa, 0u);
+      if (rc != AZMI_OK) return rc;
+      AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 1], ps->net_stream));
+      AZMI_HIP_TRY(hipEventRecord(ps->ev_net, ps->net_stream));
+      AZMI_HIP_TRY(hipEventRecord(ps->ev_svc, ps->svc_stream));
+      k_cv_wait_started<<<1, 1, 0, st>>>(pa.ep, ps->cv_lines * ps->cv_nwg);
+      AZMI_HIP_TRY(hipGetLastError());
     }
     // the tree kernel goes first: its workgroups take their places per shader engine, the net kernel is sized for what is left
     AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 2], st));
@@ -1607,13 +1811,17 @@ static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_ne
       k_pipe_cache_insert<<<2048, 256, 0, st>>>(pm->ar, pa, 0u);
       AZMI_HIP_TRY(hipGetLastError());
     }
-    if (!tree_only) {
+    if (!tree_only && !ps->cv_on) {
       AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 0], ps->net_stream));
       rc = pipe_launch_net(ps, view, net_mode, ps->net_wgs, ps->net_stream, pa);
       if (rc != AZMI_OK) return rc;
       AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 1], ps->net_stream));
       AZMI_HIP_TRY(hipEventRecord(ps->ev_net, ps->net_stream));
       AZMI_HIP_TRY(hipStreamWaitEvent(st, ps->ev_net, 0));
+    }
+    if (ps->cv_on) {
+      AZMI_HIP_TRY(hipStreamWaitEvent(st, ps->ev_net, 0));
+      AZMI_HIP_TRY(hipStreamWaitEvent(st, ps->ev_svc, 0));
     }
     k_pipe_settle<<<settle_blocks, 256, 0, st>>>(pm->ep, pm->ar, pa);
     AZMI_HIP_TRY(hipGetLastError());
@@ -1650,10 +1858,10 @@ static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_ne
     fprintf(stderr, "azmi_run_pipeline: %u request(s) were given up by the net side and sent again (a net workgroup fell more than half a ring behind)\n", hc.lost_total - ps->lost_seen);
     ps->lost_seen = hc.lost_total;
   }
-  if (!tree_only && !hc.err) pipe_balance(ps, hc);       // (takes effect with the next call's first epoch)
+  if (!tree_only && !hc.err && !ps->cv_on) pipe_balance(ps, hc);       // (takes effect with the next call's first epoch)
   if (out_stats) {
     out_stats[0] = hc.tiles; out_stats[1] = hc.tile_boards; out_stats[2] = he.sims; out_stats[3] = he.tree_arrived;
-    out_stats[4] = he.net_arrived; out_stats[5] = he.ins_count; out_stats[6] = ps->net_wgs; out_stats[7] = ps->tree_wgs;
+    out_stats[4] = he.net_arrived; out_stats[5] = he.ins_count; out_stats[6] = ps->cv_on ? ps->cv_lines : ps->net_wgs; out_stats[7] = ps->tree_wgs;
     out_stats[8] = he.tree_late / 100u; out_stats[9] = he.net_late / 100u;
     double net_us = 0.0, tree_us = 0.0;
     for (uint32_t e = 0; e < epochs; ++e) {
@@ -1779,12 +1987,28 @@ extern "C" int azmi_debug_pipe_net_bench(azmi_pm* pm, azmi_net* net, uint32_t n,
   AZMI_HIP_TRY(hipEventCreate(&e0)); AZMI_HIP_TRY(hipEventCreate(&e1));
   float total = 0.0f;
   const uint32_t wgs = net_wgs ? net_wgs : ps->net_wgs;
+  if (mode == 3) {      // the conveyor: net_wgs = lines (0: as many as the chip holds)
+    if (view.x3 || view.nd.depth < 2 || view.nd.depth % 2) return azmi_host_fail(AZMI_ERR_STATE, "the conveyor runs the bf16 tier with an even number of residual blocks");
+    { const int rc = cv_setup(pm, ps, view); if (rc != AZMI_OK) return rc; }
+    if (net_wgs) ps->cv_lines = std::min(net_wgs, ps->cv_lines_alloc);
+    else { hipDeviceProp_t prop; AZMI_HIP_TRY(hipGetDeviceProperties(&prop, pm->device)); ps->cv_lines = std::min(ps->cv_lines_alloc, cv_default_lines(static_cast<uint32_t>(prop.multiProcessorCount), ps->cv_nwg, 0u)); }
+  }
   for (uint32_t r = 0; r < reps + 1; ++r) {
     AZMI_HIP_TRY(hipMemsetAsync(pa.ep, 0, sizeof(PipeEpoch), st));
+    if (mode == 3) { const int rc = cv_zero_headers(ps, st); if (rc != AZMI_OK) return rc; }
     k_pipe_fill<<<(n + 255) / 256, 256, 0, st>>>(pa, n, pm->ep.S, 1234 + r);
     k_pipe_fill_done<<<1, 1, 0, st>>>(pa, n);
     AZMI_HIP_TRY(hipEventRecord(e0, st));
-    { const int rc = pipe_launch_net(ps, view, mode, wgs, st, pa); if (rc != AZMI_OK) return rc; }
+    if (mode == 3) {
+      AZMI_HIP_TRY(hipEventRecord(ps->ev_go, st));
+      AZMI_HIP_TRY(hipStreamWaitEvent(ps->net_stream, ps->ev_go, 0));
+      AZMI_HIP_TRY(hipStreamWaitEvent(ps->svc_stream, ps->ev_go, 0));
+      { const int rc = cv_launch(ps, view, pa, 0u); if (rc != AZMI_OK) return rc; }
+      AZMI_HIP_TRY(hipEventRecord(ps->ev_net, ps->net_stream));
+      AZMI_HIP_TRY(hipEventRecord(ps->ev_svc, ps->svc_stream));
+      AZMI_HIP_TRY(hipStreamWaitEvent(st, ps->ev_net, 0));
+      AZMI_HIP_TRY(hipStreamWaitEvent(st, ps->ev_svc, 0));
+    } else { const int rc = pipe_launch_net(ps, view, mode, wgs, st, pa); if (rc != AZMI_OK) return rc; }
     AZMI_HIP_TRY(hipEventRecord(e1, st));
     k_pipe_head_reset<<<1, 1, 0, st>>>(pa);                   // (head = tail for the next drain; the READY tokens of the synthetic answers are dropped)
     AZMI_HIP_TRY(hipStreamSynchronize(st));
@@ -1799,6 +2023,68 @@ extern "C" int azmi_debug_pipe_net_bench(azmi_pm* pm, azmi_net* net, uint32_t n,
   *ms_out = total / static_cast<float>(reps);
   PipeCtl hc;
   AZMI_HIP_TRY(hipMemcpy(&hc, pa.ctl, sizeof(hc), hipMemcpyDeviceToHost));
-  if (hc.err) return azmi_host_fail(AZMI_ERR_STATE, "pipeline error mask 0x%x in the net drain", hc.err);
+  if (hc.err) {
+    (void)hipMemset(&pa.ctl->err, 0, sizeof(uint32_t));
+    return azmi_host_fail(AZMI_ERR_STATE, "pipeline error mask 0x%x in the net drain", hc.err);
+  }
+  return AZMI_OK;
+}
+
+// The net side's ANSWERS for `n` synthetic positions (n <= the engine's slots; position i -> slot i): the request ring is filled from
+// `seed` (k_pipe_fill), the net side drains it once - conveyor != 0: the conveyor with `lines` lines (0: the default), else the tile
+// kernel (tile selection 0) -, out[i * 10 + k] = entry k of slot i's result granules (pi[0..7) then v[0..3)), out_seq[i] = the sequence
+// number they carry (i + 1 when the slot was answered).  tests/test_gpu_conveyor.py compares the two paths bit for bit.
+extern "C" int azmi_debug_pipe_net_answers(azmi_pm* pm, azmi_net* net, uint32_t n, uint64_t seed, int conveyor, uint32_t lines, float* out, uint32_t* out_seq) {
+  if (!pm || !net || !out || !out_seq) return azmi_host_fail(AZMI_ERR_INVALID, "null argument");
+  std::lock_guard<std::recursive_mutex> lock_(pm->mu);
+  azmi_net* nets_[2] = {net, net};
+  const PipePlan plan_ = pipe_plan(pm, nets_, 2);
+  if (plan_.kind == 0 || plan_.tree_only) return azmi_host_fail(AZMI_ERR_STATE, "not a pipeline engine");
+  const azmi_net_c4_view view = plan_.view[0];
+  if (n > pm->ep.S || n > kPipeRing) return azmi_host_fail(AZMI_ERR_INVALID, "at most %u positions", pm->ep.S);
+  AZMI_HIP_TRY(hipSetDevice(pm->device));
+  if (!pm->pipe) { const int rc = pipe_create(pm, azmi_net_dev::c4::TileBig::LDS_BYTES); if (rc != AZMI_OK) return rc; }
+  PipeState* ps = pm->pipe;
+  PipeArrays pa = ps->pa;
+  { const int rc = pipe_size_net(pm, ps, view); if (rc != AZMI_OK) return rc; }
+  pa.cap_ticks = 25000000ull;
+  pa.l0 = nullptr;
+  hipStream_t st = pm->stream;
+  { const int rc = pipe_pair_streams(ps, st); if (rc != AZMI_OK) return rc; }
+  if (conveyor) {
+    if (view.x3 || view.nd.depth < 2 || view.nd.depth % 2) return azmi_host_fail(AZMI_ERR_STATE, "the conveyor runs the bf16 tier with an even number of residual blocks");
+    { const int rc = cv_setup(pm, ps, view); if (rc != AZMI_OK) return rc; }
+    if (lines) ps->cv_lines = std::min(lines, ps->cv_lines_alloc);
+  }
+  AZMI_HIP_TRY(hipMemsetAsync(pa.res, 0, sizeof(unsigned long long) * static_cast<size_t>(pm->ep.S) * kResStride, st));
+  AZMI_HIP_TRY(hipMemsetAsync(pa.ep, 0, sizeof(PipeEpoch), st));
+  if (conveyor) { const int rc = cv_zero_headers(ps, st); if (rc != AZMI_OK) return rc; }
+  k_pipe_fill<<<(n + 255) / 256, 256, 0, st>>>(pa, n, pm->ep.S, seed);
+  k_pipe_fill_done<<<1, 1, 0, st>>>(pa, n);
+  if (conveyor) {
+    AZMI_HIP_TRY(hipEventRecord(ps->ev_go, st));
+    AZMI_HIP_TRY(hipStreamWaitEvent(ps->net_stream, ps->ev_go, 0));
+    AZMI_HIP_TRY(hipStreamWaitEvent(ps->svc_stream, ps->ev_go, 0));
+    { const int rc = cv_launch(ps, view, pa, 0u); if (rc != AZMI_OK) return rc; }
+    AZMI_HIP_TRY(hipEventRecord(ps->ev_net, ps->net_stream));
+    AZMI_HIP_TRY(hipEventRecord(ps->ev_svc, ps->svc_stream));
+    AZMI_HIP_TRY(hipStreamWaitEvent(st, ps->ev_net, 0));
+    AZMI_HIP_TRY(hipStreamWaitEvent(st, ps->ev_svc, 0));
+  } else { const int rc = pipe_launch_net(ps, view, 0, ps->net_wgs, st, pa); if (rc != AZMI_OK) return rc; }
+  k_pipe_head_reset<<<1, 1, 0, st>>>(pa);
+  std::vector<unsigned long long> hres(static_cast<size_t>(n) * kResStride);
+  AZMI_HIP_TRY(hipMemcpyAsync(hres.data(), pa.res, hres.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  AZMI_HIP_TRY(hipMemsetAsync(pa.res, 0, sizeof(unsigned long long) * static_cast<size_t>(pm->ep.S) * kResStride, st));
+  PipeCtl hc;
+  AZMI_HIP_TRY(hipMemcpyAsync(&hc, pa.ctl, sizeof(hc), hipMemcpyDeviceToHost, st));
+  AZMI_HIP_TRY(hipStreamSynchronize(st));
+  for (uint32_t i = 0; i < n; ++i) {
+    out_seq[i] = static_cast<uint32_t>(hres[static_cast<size_t>(i) * kResStride] >> 32);
+    for (uint32_t k = 0; k < 10; ++k) { const uint32_t bits = static_cast<uint32_t>(hres[static_cast<size_t>(i) * kResStride + k]); memcpy(out + static_cast<size_t>(i) * 10 + k, &bits, 4); }
+  }
+  if (hc.err) {
+    AZMI_HIP_TRY(hipMemset(&pa.ctl->err, 0, sizeof(uint32_t)));
+    return azmi_host_fail(AZMI_ERR_STATE, "pipeline error mask 0x%x in the net drain (dbg %u %u %u %u %u %u)", hc.err, hc.dbg[8], hc.dbg[9], hc.dbg[10], hc.dbg[11], hc.dbg[12], hc.dbg[13]);
+  }
   return AZMI_OK;
 }

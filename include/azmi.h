@@ -463,6 +463,11 @@ int azmi_pipeline_supported_groups(azmi_pm* pm, azmi_net* const* nets, uint32_t 
  * `net_wgs` workgroups (0 = the pipeline's own count) and tile selection `mode` (0 = 3- and 6-board tiles, 1 = 6-board, 2 =
  * 3-board); *ms_out = milliseconds per drain.  Timing only (scripts/pipe_net_timing.py -> profiles/). */
 int azmi_debug_pipe_net_bench(azmi_pm* pm, azmi_net* net, uint32_t n, uint32_t reps, uint32_t net_wgs, int mode, float* ms_out);
+/* diagnostics: the net side's ANSWERS for `n` synthetic positions (n <= the engine's concurrent games; position i is asked for slot i,
+ * sequence number i + 1), drained once by the conveyor (conveyor != 0, csrc/conveyor_c4.h; `lines` lines, 0 = its default; mode 3 of
+ * azmi_debug_pipe_net_bench times it, net_wgs = lines) or by the tile kernel: out[10 i + k] = pi[k] (k < 7), v[k - 7] of position i,
+ * out_seq[i] = the sequence number its result granules carry.  The two paths answer bit for bit alike (tests/test_gpu_conveyor.py). */
+int azmi_debug_pipe_net_answers(azmi_pm* pm, azmi_net* net, uint32_t n, uint64_t seed, int conveyor, uint32_t lines, float* out, uint32_t* out_seq);
 /* diagnostics: out[0] = answers the tree side consumed in the last epoch of the last azmi_run_pipeline call (its insert log), out[1] =
  * those whose key is in the log more than once (evaluations an insert at answer time - PlayManager::update_inferences,
  * play_manager.cc:631-640 - or a table of requests in flight would have saved), out[2] = of those, twins within 4096 log entries */
