@@ -44,7 +44,8 @@ constexpr int RING_BYTES = 8 * PLANE;                          // 20,480
 constexpr int RES_BYTES = RNT * 4096;                          // residual ring: fp32 accumulator images [n-tile][m tile][lane][16 B]
 constexpr int LDS_RINGS = 0, LDS_RES = 4 * RING_BYTES, LDS_TAPS = LDS_RES + RES_BYTES, LDS_CTR = LDS_TAPS + 512;
 constexpr int LDS_AFF = LDS_CTR + 128;                         // a1 | b1 of the block a conv2 wave feeds: [2 waves][2][64] floats
-constexpr int LINE_LDS_BYTES = LDS_AFF + 1024;                 // 116,352: one conv workgroup per CU
+constexpr int LDS_RESIN = LDS_AFF + 1024;                      // the residual images that arrive from the workgroup before (LDS-DMA by wave 0)
+constexpr int LINE_LDS_BYTES = LDS_RESIN + RES_BYTES;          // 149,120: one conv workgroup per CU
 static_assert(PLANE % 256 == 0, "plane stride");
 // cross-workgroup ring (HBM): a header (all headers in one block: one memset per epoch), bf16 plane images [XNT][2048], fp32
 // accumulator images [XNT][4096]
@@ -69,10 +70,11 @@ struct CvArgs {
   uint8_t* xs;                // [lines][nwg + 1][X_S] stream images
   uint32_t* meta;             // [lines][MGRP][32]
   uint32_t lines, nwg;
+  uint32_t dbg_flags;         // timing experiments (wrong answers): bit 0 = wave 0 stages nothing from HBM
   uint32_t* err;              // PipeCtl::err (sticky)
   uint32_t* stop;             // PipeEpoch::stop
   unsigned long long cap_ticks;
-  unsigned long long* stat;   // [0] conv-wave body n-tiles, [1] ... drained n-tiles, [2] stem groups, [3] stem boards, [4] head groups, [5..] ticks
+  unsigned long long* stat;   // [0] conv-wave n-tiles, [1] of those drained (epilogue on its own), [2] stem groups, [3] boards, [4] head groups; 100 MHz ticks: [5..9) conv waves by role waiting for input, [9..13) for output room, [13] stems claiming, [14] stems waiting for room, [15] heads waiting, [16..20) conv-wave lifetimes by role, [20] stem, [21] head lifetimes
 };
 
 __device__ __forceinline__ size_t x_index(const CvArgs& a, uint32_t line, uint32_t b) { return static_cast<size_t>(line) * (a.nwg + 1u) + b; }
@@ -93,6 +95,15 @@ __device__ __forceinline__ void mfma_a_init(f32x4& acc, const u32x4& wa, const b
   asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(acc) : "a"(wa), "v"(b), "v"(c));
 }
 
+// 64 lanes x 16 B from per-lane global addresses straight into LDS at the wave-uniform `dst_lds` (+ lane * 16), L1 bypassed (sc1: the
+// bytes were written by another CU); no register destination - counted by the issuing wave's vmcnt like any load
+__device__ __forceinline__ void dma16_sc1(const uint8_t* src_lane, uint32_t dst_lds_) {
+  const uint32_t dst_lds = __builtin_amdgcn_readfirstlane(dst_lds_);
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src_lane), "s"(dst_lds) : "memory");
+}
+
 // ---- one conv wavefront ------------------------------------------------------------------------------------------------------------
 // ROLE = the wave's index in its workgroup = its layer there: 0 conv1 of block 2c (input staged from HBM), 1 conv2 of block 2c
 // (residual from HBM), 2 conv1 of block 2c + 1, 3 conv2 of block 2c + 1 (residual from the LDS residual ring, output to HBM).
@@ -101,7 +112,7 @@ template <int ROLE, bool LAST>
 __device__ __forceinline__ void conv_wave(const CvArgs& a, uint8_t* const lds, const uint32_t line, const uint32_t cwg) {
   constexpr bool IN_X = ROLE == 0;                 // input planes staged from the cross-workgroup ring
   constexpr bool EPI_B = (ROLE & 1) != 0;          // conv2: the stream out (fp32) + relu(a1 s + b1) of the NEXT block as planes
-  constexpr bool RES_X = ROLE == 1, RES_L = ROLE == 3;
+  constexpr bool RES_L = ROLE == 1 || ROLE == 3;     // the stream comes in through an LDS ring: ROLE 1 the one wave 0 fills from HBM, ROLE 3 the one wave 1 writes
   constexpr bool OUT_X = ROLE == 3;
   constexpr int PD = 2;                            // B fragments are read this many k-steps ahead (three buffers: 18 k-steps leave them in place)
   const int lane = threadIdx.x & 63, col = lane & 15, quad = lane >> 4;
@@ -109,18 +120,27 @@ __device__ __forceinline__ void conv_wave(const CvArgs& a, uint8_t* const lds, c
   (void)lds0;
   uint8_t* const in = lds + LDS_RINGS + ROLE * RING_BYTES;
   uint8_t* const out = lds + LDS_RINGS + (ROLE < 3 ? ROLE + 1 : 0) * RING_BYTES;
-  uint8_t* const res = lds + LDS_RES;
-  volatile uint32_t* const ctr = reinterpret_cast<volatile uint32_t*>(lds + LDS_CTR);
+  uint8_t* const res = lds + LDS_RES;                                   // written by ROLE 1, read by ROLE 3
+  uint8_t* const resin = lds + LDS_RESIN;                                // filled by ROLE 0 (DMA), read by ROLE 1
+  const uint8_t* const res_rd = ROLE == 1 ? resin : res;
+  constexpr int RES_P = ROLE == 1 ? 0 : 2, RES_C = ROLE == 1 ? 9 : 8;    // counters: images present (= ring 0 staged / ring 2 written), images consumed
+  const uint32_t resin_lds = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>((c4::lptr_t)resin)));
+  (void)resin_lds; (void)res_rd;
+  // (an LDS pointer by TYPE: through a generic pointer a volatile access compiles to flat_load / flat_store, which count on vmcnt AND
+  // lgkmcnt - every look at a counter then drains all the fragment reads in flight)
+  typedef volatile __attribute__((address_space(3))) uint32_t* lctr_t;
+  const lctr_t ctr = (lctr_t)(lds + LDS_CTR);
   // counters: P[i] = ctr[i] n-tiles present in ring i (i = 0: staged by wave 0), C[i] = ctr[4 + i] n-tiles of ring i consumed by wave i,
   // ctr[8] = residual ring consumed (wave 3), ctr[12 + i] = END: ring i's producer has delivered its last n-tile
   const size_t xi = x_index(a, line, cwg);
+  const uint8_t* const xin_s = a.xs + xi * X_S + lane * 16;
+  (void)xin_s;
   uint32_t* const xin_h = a.xh + xi * 128;
   uint32_t* const xout_h = a.xh + (xi + 1) * 128;
   uint8_t* const xout_t = a.xt + (xi + 1) * X_T;
   const auto r_xin_t = __builtin_amdgcn_make_buffer_rsrc(a.xt + xi * X_T, 0, X_T, 0x00020000);
-  const auto r_xin_s = __builtin_amdgcn_make_buffer_rsrc(a.xs + xi * X_S, 0, X_S, 0x00020000);
   const auto r_xout_s = __builtin_amdgcn_make_buffer_rsrc(a.xs + (xi + 1) * X_S, 0, X_S, 0x00020000);
-  (void)r_xin_t; (void)r_xin_s; (void)r_xout_s; (void)xin_h; (void)xout_h; (void)xout_t; (void)res;
+  (void)r_xin_t; (void)r_xout_s; (void)xin_h; (void)xout_h; (void)xout_t; (void)res;
 
   // ---- the layer's weights and parameters ----------------------------------------------------------------------------------------
   const uint32_t block = 2u * cwg + (ROLE >> 1);
@@ -160,7 +180,7 @@ __device__ __forceinline__ void conv_wave(const CvArgs& a, uint8_t* const lds, c
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   f32x4 eaA = {0.f, 0.f, 0.f, 0.f}, ebA = eaA, eaB = eaA, ebB = eaA;      // a1 / b1 of the m tile the epilogue is at (A: even m, B: odd m)
-  auto aff_load = [&](int m) {
+  auto aff_load = [&](int m) __attribute__((always_inline)) {
     if constexpr (EPI_B && !(LAST && ROLE == 3)) {
       if (m & 1) { eaB = *reinterpret_cast<const f32x4*>(aff + m * 16 + quad * 4); ebB = *reinterpret_cast<const f32x4*>(aff + CH + m * 16 + quad * 4); }
       else { eaA = *reinterpret_cast<const f32x4*>(aff + m * 16 + quad * 4); ebA = *reinterpret_cast<const f32x4*>(aff + CH + m * 16 + quad * 4); }
@@ -179,11 +199,11 @@ __device__ __forceinline__ void conv_wave(const CvArgs& a, uint8_t* const lds, c
   const uint32_t outbase = (quad >> 1) * PLANE + GUARD * 16 + col * 16 + (quad & 1) * 8;     // the lane's 8 bytes of ring n-tile 0, plane quad / 2 (+ 2 mt planes)
   const int dup_lo = col < 8 ? RPIX * 16 : 0, dup_hi = col >= 8 ? -RPIX * 16 : 0;                 // guard copies of ring n-tile 0's first / n-tile 7's last 8 pixels
 
-  auto read_b = [&](const uint32_t (&addr)[9], int ks) -> bf16x8 {
+  auto read_b = [&](const uint32_t (&addr)[9], int ks) __attribute__((always_inline)) -> bf16x8 {
     const int tap = ks >> 1, off = (tap / 3 - 1) * BW + (tap % 3 - 1);
     return *reinterpret_cast<const bf16x8*>(in + addr[tap] + (off * 16 + 128 + (ks & 1) * 4 * PLANE));
   };
-  auto taps_all = [&](uint32_t k, uint32_t (&addr)[9]) {
+  auto taps_all = [&](uint32_t k, uint32_t (&addr)[9]) __attribute__((always_inline)) {
     const uint32_t tm = mtab[(k & 7u) * 16u];
     const uint32_t pb = lanebase + (k & 7u) * 256u;
 #pragma unroll
@@ -198,35 +218,40 @@ __device__ __forceinline__ void conv_wave(const CvArgs& a, uint8_t* const lds, c
   uint32_t xprod = 0;                 // ROLE 0: the cross ring's producer count as last read
   bool stg_pending = false;           // ROLE 0: the planes of n-tile `staged` are on their way into `stg`
   u32x4 stg[2];
-  auto present = [&]() -> uint32_t { if constexpr (IN_X) return staged; else return uni(ctr[ROLE]); };
-  auto need_of = [&](uint32_t k) -> uint32_t { return (k & 7u) == 7u ? k + 1u : k + 2u; };
+  auto present = [&]() __attribute__((always_inline)) -> uint32_t { if constexpr (IN_X) return staged; else return uni(ctr[ROLE]); };
+  auto need_of = [&](uint32_t k) __attribute__((always_inline)) -> uint32_t { return (k & 7u) == 7u ? k + 1u : k + 2u; };
   // ROLE 0: one n-tile of planes from the cross ring into ring 0 (two 1 KB pieces: planes 0-3 and 4-7, this lane's pixel lane & 15)
-  auto stage_load = [&](uint32_t k) {
+  auto stage_load = [&](uint32_t k) __attribute__((always_inline)) {
     if constexpr (IN_X) {
+      if (a.dbg_flags & 1u) return;
+      // the stream's fp32 image straight into the residual-in ring (four 1 KB pieces, no registers), then the planes: loads return in
+      // order, so when the planes are in `stg` the image has landed
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) dma16_sc1(xin_s + (k % XNT) * 4096u + mt * 1024u, resin_lds + (k & 7u) * 4096u + mt * 1024u);
 #pragma unroll
       for (int i = 0; i < 2; ++i) stg[i] = __builtin_amdgcn_raw_buffer_load_b128(r_xin_t, (k % XNT) * 2048u + i * 1024u + lane * 16u, 0, 16);
     }
   };
-  auto stage_write = [&](uint32_t k) {
+  auto stage_write = [&](uint32_t k) __attribute__((always_inline)) {
     if constexpr (IN_X) {
       const uint32_t j = k & 7u;
-      const int dup = j == 0u ? dup_lo : (j == 7u ? dup_hi : 0);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        uint8_t* p = lds + LDS_RINGS + (i * 4 + quad) * PLANE + GUARD * 16 + (j * 16 + col) * 16;
-        *reinterpret_cast<u32x4*>(p) = stg[i];
-        *reinterpret_cast<u32x4*>(p + dup) = stg[i];
+      uint8_t* p = lds + LDS_RINGS + quad * PLANE + GUARD * 16 + (j * 16 + col) * 16;
+      *reinterpret_cast<u32x4*>(p) = stg[0];
+      *reinterpret_cast<u32x4*>(p + 4 * PLANE) = stg[1];
+      if (j == 0u || j == 7u) {         // guard copies: ring n-tile 0's first / n-tile 7's last eight pixels
+        const int dup = j == 0u ? dup_lo : dup_hi;
+        if (dup != 0) { *reinterpret_cast<u32x4*>(p + dup) = stg[0]; *reinterpret_cast<u32x4*>(p + 4 * PLANE + dup) = stg[1]; }
       }
     }
   };
 
   // ---- output side -----------------------------------------------------------------------------------------------------------------------
   uint32_t xcons = 0;                 // ROLE 3: the cross ring's consumer count as last read
-  auto xcons_load = [&]() -> uint32_t {
+  auto xcons_load = [&]() __attribute__((always_inline)) -> uint32_t {
     return uni(min(ld_sc1(xout_h + XH_CONS_T), ld_sc1(xout_h + XH_CONS_S)));
   };
   // space for the output of n-tile k: ring slots (LDS: the consumer is past k - RNT + 2, guard copies included; HBM: past k - XNT)
-  auto space_for = [&](uint32_t k, bool refresh) -> bool {
+  auto space_for = [&](uint32_t k, bool refresh) __attribute__((always_inline)) -> bool {
     if constexpr (OUT_X) {
       if (refresh) xcons = xcons_load();
       return static_cast<int32_t>(k - xcons) < XNT;
@@ -237,7 +262,7 @@ __device__ __forceinline__ void conv_wave(const CvArgs& a, uint8_t* const lds, c
     }
   };
   // the four values (channels mt * 16 + quad * 4 ..) of the lane's pixel of n-tile k, as two packed bf16 pairs, into the output planes
-  auto store_act = [&](uint32_t k, int mt, uint32_t p0, uint32_t p1) {
+  auto store_act = [&](uint32_t k, int mt, uint32_t p0, uint32_t p1) __attribute__((always_inline)) {
     if constexpr (OUT_X) {
       if constexpr (!LAST) {
         typedef __attribute__((address_space(1))) unsigned long long gu64;
@@ -246,13 +271,15 @@ __device__ __forceinline__ void conv_wave(const CvArgs& a, uint8_t* const lds, c
       }
     } else {
       const uint32_t j = k & 7u;
-      const int dup = j == 0u ? dup_lo : (j == 7u ? dup_hi : 0);
       uint8_t* p = out + outbase + j * 256u + mt * 2 * PLANE;
       *reinterpret_cast<u32x2*>(p) = u32x2{p0, p1};
-      *reinterpret_cast<u32x2*>(p + dup) = u32x2{p0, p1};
+      if (j == 0u || j == 7u) {         // guard copies: ring n-tile 0's first / n-tile 7's last eight pixels
+        const int dup = j == 0u ? dup_lo : dup_hi;
+        if (dup != 0) *reinterpret_cast<u32x2*>(p + dup) = u32x2{p0, p1};
+      }
     }
   };
-  auto store_res = [&](uint32_t k, int mt, const f32x4& v) {
+  auto store_res = [&](uint32_t k, int mt, const f32x4& v) __attribute__((always_inline)) {
     if constexpr (OUT_X) {
       u32x4 u; u[0] = __float_as_uint(v[0]); u[1] = __float_as_uint(v[1]); u[2] = __float_as_uint(v[2]); u[3] = __float_as_uint(v[3]);
       __builtin_amdgcn_raw_buffer_store_b128(u, r_xout_s, (k % XNT) * 4096u + mt * 1024u + lane * 16u, 0, 16);
@@ -262,41 +289,32 @@ __device__ __forceinline__ void conv_wave(const CvArgs& a, uint8_t* const lds, c
   };
   constexpr int X_STORES = OUT_X ? (LAST ? 4 : 8) : 0;       // HBM stores of one n-tile's epilogue
   // n-tiles 0 .. k are out (LDS: the stores above are ahead of this one in the wave's LDS queue; HBM: the caller has drained them)
-  auto publish = [&](uint32_t k) {
+  auto publish = [&](uint32_t k) __attribute__((always_inline)) {
     if constexpr (OUT_X) st_sc1(xout_h + XH_PROD, k + 1u);
     else ctr[ROLE + 1] = k + 1u;
   };
 
   // ---- the residual stream as the accumulators' initial value -----------------------------------------------------------------------
   uint32_t rl = 0;                    // residual images requested so far (n-tiles 0 .. rl - 1)
-  auto res_load = [&](uint32_t k, f32x4 (&r)[4]) {
-    if constexpr (RES_X) {
+  auto res_load = [&](uint32_t k, f32x4 (&r)[4]) __attribute__((always_inline)) {
+    if constexpr (RES_L) {
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r_xin_s, (k % XNT) * 4096u + mt * 1024u + lane * 16u, 0, 16);
-        r[mt] = f32x4{__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3])};
-      }
-    } else if constexpr (RES_L) {
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) r[mt] = *reinterpret_cast<const f32x4*>(res + (k & 7u) * 4096u + mt * 1024u + lane * 16u);
+      for (int mt = 0; mt < 4; ++mt) r[mt] = *reinterpret_cast<const f32x4*>(res_rd + (k & 7u) * 4096u + mt * 1024u + lane * 16u);
     }
   };
-  // is n-tile n's residual image there?  (HBM: wave 0 has staged n's planes, and the producer publishes both together; LDS: wave 1's count)
-  auto res_there = [&](uint32_t n) -> bool {
-    if constexpr (RES_X) return static_cast<int32_t>(uni(ctr[0]) - n) > 0;
-    else return static_cast<int32_t>(uni(ctr[2]) - n) > 0;
-  };
+  // is n-tile n's residual image there?  (ROLE 1: wave 0 has staged n - planes and image land together; ROLE 3: wave 1's count)
+  auto res_there = [&](uint32_t n) __attribute__((always_inline)) -> bool { return static_cast<int32_t>(uni(ctr[RES_P]) - n) > 0; };
 
   // ---- epilogue of one n-tile (the tile's expressions: leafnet_c4.h, residual block loop) ----------------------------------------
   float ev[16]; uint32_t pk[8];
-  auto epi_value = [&](const f32x4 (&acc)[4], int v) {          // value v = (mt, r) = (v / 4, v % 4)
+  auto epi_value = [&](const f32x4 (&acc)[4], int v) __attribute__((always_inline)) {          // value v = (mt, r) = (v / 4, v % 4)
     const int mt = v >> 2, r = v & 3;
     float x = acc[mt][r];
     if constexpr (EPI_B && !(LAST && ROLE == 3)) x = (mt & 1) ? eaB[r] * x + ebB[r] : eaA[r] * x + ebA[r];
     asm("v_max_f32 %0, 0, %1" : "=v"(ev[v]) : "v"(x));
   };
-  auto epi_pack = [&](int pair) { asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[pair]) : "v"(ev[2 * pair]), "v"(ev[2 * pair + 1])); };
-  auto epilogue_all = [&](uint32_t k, const f32x4 (&acc)[4]) {
+  auto epi_pack = [&](int pair) __attribute__((always_inline)) { asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk[pair]) : "v"(ev[2 * pair]), "v"(ev[2 * pair + 1])); };
+  auto epilogue_all = [&](uint32_t k, const f32x4 (&acc)[4]) __attribute__((always_inline)) {
     asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");           // the last MFMAs' results (asm: the compiler pads nothing)
 #pragma unroll
     for (int v = 0; v < 16; ++v) { if ((v & 3) == 0) aff_load(v >> 2); epi_value(acc, v); }
@@ -318,18 +336,19 @@ __device__ __forceinline__ void conv_wave(const CvArgs& a, uint8_t* const lds, c
   bf16x8 b[PD + 1];
   static_assert(18 % (PD + 1) == 0, "the fragment buffers stay in place from n-tile to n-tile");
   f32x4 accA[4], accB[4], rinA[4], rinB[4];
-  unsigned long long n_body = 0, n_drain = 0;
+  unsigned long long n_body = 0, n_drain = 0, t_wait_in = 0, t_wait_out = 0, t_go = 0, n_go = 0;
   bool failed = false;
 
   // one n-tile: 72 MFMAs into `acc`; every gap carries at most a few other instructions (a lone wave issues in order): the B read of
   // k-step ks + PD, the epilogue of n-tile k - 1 (`accp`), the tap bases and first reads of n-tile k + 1, staging / residual traffic.
   // WITH_PREV: n-tile k - 1's epilogue is pending.  Returns: go straight on with k + 1 (its input is there, k's output has room).
   // rin = the residual image of n-tile k (and, once consumed, the buffer of k + 2's), rin_next = that of k + 1.
-  auto body = [&](auto with_prev_tag, f32x4 (&acc)[4], f32x4 (&accp)[4], f32x4 (&rin)[4], f32x4 (&rin_next)[4], uint32_t (&addr)[9], uint32_t (&addr_n)[9]) -> bool {
+  auto body = [&](auto with_prev_tag, f32x4 (&acc)[4], f32x4 (&accp)[4], f32x4 (&rin)[4], f32x4 (&rin_next)[4], uint32_t (&addr)[9], uint32_t (&addr_n)[9]) __attribute__((always_inline)) -> bool {
     constexpr bool WITH_PREV = decltype(with_prev_tag)::value;
     uint32_t tm_next = 0, pb_n = 0, p_in = 0, xc_new = 0;
+    uint32_t v_pin = 0, v_room = 0, v_room2 = 0, v_resp = 0, v_c9 = 0;      // counters, read a few k-steps before they are looked at
     bool room = false, xc_asked = false;
-    (void)rin_next; (void)xc_new; (void)xc_asked;
+    (void)rin_next; (void)xc_new; (void)xc_asked; (void)v_pin; (void)v_room; (void)v_room2; (void)v_resp; (void)v_c9;
 #pragma unroll
     for (int ks = 0; ks < 18; ++ks) {
       const bf16x8 bc = b[ks % (PD + 1)];
@@ -343,14 +362,20 @@ __device__ __forceinline__ void conv_wave(const CvArgs& a, uint8_t* const lds, c
         if (mt == 0) {
           if (ks + PD < 18) b[(ks + PD) % (PD + 1)] = read_b(addr, ks + PD);
           else b[(ks + PD) % (PD + 1)] = read_b(addr_n, ks + PD - 18);
-          if (ks == 9) p_in = present();
+          if (ks == 5) {
+            if constexpr (!IN_X) v_pin = ctr[ROLE];
+            if constexpr (!OUT_X) v_room = ctr[4 + ROLE + 1];
+            if constexpr (ROLE == 1) v_room2 = ctr[8];
+            if constexpr (RES_L) v_resp = ctr[RES_P];
+            if constexpr (IN_X) v_c9 = ctr[9];
+          }
+          if (ks == 9) { if constexpr (IN_X) p_in = staged; else p_in = uni(v_pin); }
           if constexpr (WITH_PREV) { if (ks == 2 || ks == 6 || ks == 10) aff_load((ks + 2) >> 2); }
           if (ks == 16) aff_load(0);
         } else if (mt == 1) {
           if constexpr (WITH_PREV) { if (ks < 16) epi_value(accp, ks); }
-          if constexpr (IN_X) { if (ks == 16) st_sc1(xin_h + XH_CONS_T, staged); }
-          if constexpr (RES_X) { if (ks == 16) st_sc1(xin_h + XH_CONS_S, k + 1u); }
-          if constexpr (RES_L) { if (ks == 16) ctr[8] = k + 1u; }
+          if constexpr (IN_X) { if (ks == 16) { st_sc1(xin_h + XH_CONS_T, staged); st_sc1(xin_h + XH_CONS_S, staged); } }
+          if constexpr (RES_L) { if (ks == 16) ctr[RES_C] = k + 1u; }
           if (ks == 17) ctr[4 + ROLE] = k;           // n-tiles before k are no longer read (k - 1's last reads are long out)
         } else if (mt == 2) {
           if constexpr (WITH_PREV) { if (ks < 16 && (ks & 1)) epi_pack(ks >> 1); }
@@ -359,7 +384,7 @@ __device__ __forceinline__ void conv_wave(const CvArgs& a, uint8_t* const lds, c
             // land in the ring, the producer's count is read, the next n-tile's planes are requested
             if (ks == 6) { if (stg_pending) { stage_write(staged); staged += 1u; ctr[0] = staged; stg_pending = false; } }
             if (ks == 0) { if (static_cast<int32_t>(xprod - staged) <= 1) xprod = uni(ld_sc1(xin_h + XH_PROD)); }
-            if (ks == 12) { if (static_cast<int32_t>(xprod - staged) > 0 && static_cast<int32_t>(staged - k) <= RNT - 2) { stage_load(staged); stg_pending = true; } }
+            if (ks == 7) { if (static_cast<int32_t>(xprod - staged) > 0 && static_cast<int32_t>(staged - k) <= RNT - 2 && static_cast<int32_t>(staged - uni(v_c9)) < RNT) { stage_load(staged); stg_pending = true; } }
           }
           if constexpr (OUT_X) {
             if (ks == 0) { if (static_cast<int32_t>(k - xcons) >= XNT / 2) { xc_new = xcons_load(); xc_asked = true; } }
@@ -376,28 +401,27 @@ __device__ __forceinline__ void conv_wave(const CvArgs& a, uint8_t* const lds, c
               if constexpr (!(LAST && ROLE == 3)) store_act(k - 1u, m, pk[2 * m], pk[2 * m + 1]);
               if (ks == 15) {
                 if constexpr (OUT_X) {
-                  // everything but this body's stores is done: n-tile k - 2 (stored a body ago) is whole
-                  if constexpr (X_STORES == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                  if (k >= 2u) publish(k - 2u);
+                  // write-through stores take longer than an n-tile: the count moves three n-tiles behind the stores - everything but
+                  // the stores (and counts) of this body and the two before it is done, so n-tile k - 4 is whole
+                  if constexpr (X_STORES == 8) asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+                  if (k >= 4u) publish(k - 4u);
                 } else publish(k - 1u);
               }
             }
           } else if (what == -5) {
-            if constexpr (OUT_X) { if (xc_asked) xcons = xc_new; }
-            room = space_for(k, false);
+            if constexpr (OUT_X) { if (xc_asked) xcons = xc_new; room = space_for(k, false); }
+            else {
+              uint32_t c = v_room;
+              if constexpr (ROLE == 1) c = min(c, v_room2);
+              room = static_cast<int32_t>(k - uni(c)) <= RNT - 2;
+            }
           } else if (what >= 0) {
             uint32_t sel;
             asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(sel) : "v"(tm_next), "i"(what));
             asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(addr_n[what]) : "v"(sel), "v"(pb_n), "v"(zb[what]));
           }
-          // the residual images ahead: HBM two n-tiles ahead (k + 2 goes into k's buffer, free since the first MFMAs), LDS one
-          if constexpr (RES_X) {
-            if (ks == 1 || ks == 5) {
-              if (rl == k + 1u) { if (res_there(rl)) { res_load(rl, rin_next); rl += 1u; } }
-              else if (rl == k + 2u) { if (res_there(rl)) { res_load(rl, rin); rl += 1u; } }
-            }
-          }
-          if constexpr (RES_L) { if (ks == 14) { if (rl == k + 1u && res_there(rl)) { res_load(rl, rin_next); rl += 1u; } } }
+          // the residual image of the next n-tile
+          if constexpr (RES_L) { if (ks == 14) { if (rl == k + 1u && static_cast<int32_t>(uni(v_resp) - rl) > 0) { res_load(rl, rin_next); rl += 1u; } } }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -408,15 +432,16 @@ __device__ __forceinline__ void conv_wave(const CvArgs& a, uint8_t* const lds, c
   for (;;) {
     // ---- wait for n-tile k's input (and stage, ROLE 0) ---------------------------------------------------------------------------
     bool end = false;
+    const unsigned long long tw0 = wall100();
     for (uint32_t spins = 0;; ++spins) {
       if constexpr (IN_X) {
         if (stg_pending) { stage_write(staged); staged += 1u; stg_pending = false; }
         xprod = uni(ld_sc1(xin_h + XH_PROD));
-        while (static_cast<int32_t>(xprod - staged) > 0 && static_cast<int32_t>(staged - k) <= RNT - 2) {
+        while (static_cast<int32_t>(xprod - staged) > 0 && static_cast<int32_t>(staged - k) <= RNT - 2 && static_cast<int32_t>(staged - uni(ctr[9])) < RNT) {
           stage_load(staged); stage_write(staged); staged += 1u;
         }
         ctr[0] = staged;
-        st_sc1(xin_h + XH_CONS_T, staged);
+        st_sc1(xin_h + XH_CONS_T, staged); st_sc1(xin_h + XH_CONS_S, staged);
       }
       const uint32_t p = present();
       if (static_cast<int32_t>(p - need_of(k)) >= 0) break;
@@ -430,6 +455,7 @@ __device__ __forceinline__ void conv_wave(const CvArgs& a, uint8_t* const lds, c
       }
       __builtin_amdgcn_s_sleep(kSpinSleep);
     }
+    t_wait_in += wall100() - tw0;
     if (end || failed) break;
     // ---- prologue: tap bases and the first B fragments of n-tile k, the residual image ---------------------------------------------
     if (k & 1u) { taps_all(k, addrB);
@@ -439,17 +465,20 @@ __device__ __forceinline__ void conv_wave(const CvArgs& a, uint8_t* const lds, c
 #pragma unroll
       for (int i = 0; i < PD; ++i) b[i] = read_b(addrA, i);
     }
-    if constexpr (RES_X || RES_L) { if (rl == k) { if (k & 1u) res_load(k, rinB); else res_load(k, rinA); rl = k + 1u; } }
+    if constexpr (RES_L) { if (rl == k) { if (k & 1u) res_load(k, rinB); else res_load(k, rinA); rl = k + 1u; } }
     // ---- run: n-tile after n-tile while the input is there and the output has room -----------------------------------------------
     bool go = (k & 1u) ? body(std::false_type{}, accB, accA, rinB, rinA, addrB, addrA) : body(std::false_type{}, accA, accB, rinA, rinB, addrA, addrB);
     n_body += 1;
     while (go) {
+      const unsigned long long tg0 = (a.dbg_flags & 2u) ? wall100() : 0ull;
       k += 1u;
-      if constexpr (RES_X || RES_L) { if (rl == k) { if (k & 1u) res_load(k, rinB); else res_load(k, rinA); rl = k + 1u; } }      // (not requested ahead: a round trip in the open, rare)
+      if constexpr (RES_L) { if (rl == k) { if (k & 1u) res_load(k, rinB); else res_load(k, rinA); rl = k + 1u; } }      // (not read ahead: an LDS round trip in the open, rare)
       go = (k & 1u) ? body(std::true_type{}, accB, accA, rinB, rinA, addrB, addrA) : body(std::true_type{}, accA, accB, rinA, rinB, addrA, addrB);
       n_body += 1;
+      if (a.dbg_flags & 2u) { t_go += wall100() - tg0; n_go += 1; }
     }
     // ---- drain: n-tile k's epilogue on its own ------------------------------------------------------------------------------------
+    const unsigned long long tw1 = wall100();
     for (uint32_t spins = 0; !space_for(k, true); ++spins) {
       if ((spins & 63u) == 63u) {
         if (uni(ld_sc1(a.err)) != 0u) { failed = true; break; }
@@ -457,6 +486,7 @@ __device__ __forceinline__ void conv_wave(const CvArgs& a, uint8_t* const lds, c
       }
       __builtin_amdgcn_s_sleep(kSpinSleep);
     }
+    t_wait_out += wall100() - tw1;
     if (failed) break;
     if (k & 1u) epilogue_all(k, accB); else epilogue_all(k, accA);
     n_drain += 1;
@@ -467,8 +497,12 @@ __device__ __forceinline__ void conv_wave(const CvArgs& a, uint8_t* const lds, c
   if constexpr (OUT_X) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st_sc1(xout_h + XH_PROD, k); st_sc1(xout_h + XH_END, failed ? 2u : 1u); }
   else { ctr[ROLE + 1] = k; ctr[12 + ROLE + 1] = 1u; }
   ctr[4 + ROLE] = k;
-  if constexpr (RES_L) ctr[8] = k;
-  if (lane == 0 && a.stat) { atomicAdd(a.stat + 0, n_body); atomicAdd(a.stat + 1, n_drain); }
+  if constexpr (RES_L) ctr[RES_C] = k;
+  if (lane == 0 && a.stat) {
+    atomicAdd(a.stat + 0, n_body); atomicAdd(a.stat + 1, n_drain);
+    atomicAdd(a.stat + 5 + ROLE, t_wait_in); atomicAdd(a.stat + 9 + ROLE, t_wait_out); atomicAdd(a.stat + 16 + ROLE, wall100() - t_start);
+    atomicAdd(a.stat + 22 + ROLE, t_go); atomicAdd(a.stat + 26 + ROLE, n_go);
+  }
 }
 
 template <bool LAST>
@@ -556,12 +590,13 @@ __device__ __forceinline__ void stem_wave(const CvArgs& a, const SvcPipe& sp, ui
   constexpr uint64_t kPatienceTicks = 150;
   uint32_t w0 = 0, wn = 0, wdone = 0;       // the window: GB ring positions drawn with one fetch-add, served as their requests arrive
   uint32_t k = 0, grp = 0;                  // n-tiles, groups sent
-  unsigned long long n_boards = 0;
+  unsigned long long n_boards = 0, t_claim = 0, t_room = 0;
   bool failed = false;
   for (;;) {
     // ---- claim up to three requests (k_pipe_net's window rule) --------------------------------------------------------------------
     uint32_t n = 0, sl_ = 0xFFFFFFFFu, sq = 0, pl = 0;
     unsigned long long b0 = 0, b1 = 0;
+    const unsigned long long tc0 = wall100();
     {
       uint64_t t_first = 0, t_empty = 0;
       uint32_t final_looks = 0;
@@ -622,6 +657,7 @@ __device__ __forceinline__ void stem_wave(const CvArgs& a, const SvcPipe& sp, ui
         __builtin_amdgcn_s_sleep(16);
       }
     }
+    t_claim += wall100() - tc0;
     if (n == 0u) break;
     wdone += n;
     // ---- the group's boards: packed positions into LDS, metadata for the head wave ------------------------------------------------
@@ -639,6 +675,7 @@ __device__ __forceinline__ void stem_wave(const CvArgs& a, const SvcPipe& sp, ui
     if (lane == 0) { atomicAdd(sp.tiles, 1ull); atomicAdd(sp.tile_boards, static_cast<unsigned long long>(n)); }
     n_boards += n;
     // ---- room in X0 for eight more n-tiles ----------------------------------------------------------------------------------------------
+    const unsigned long long tr0 = wall100();
     for (uint32_t spins = 0;; ++spins) {
       const uint32_t c = uni(min(ld_sc1(xh + XH_CONS_T), ld_sc1(xh + XH_CONS_S)));
       if (static_cast<int32_t>(k + GT - c) <= XNT) break;
@@ -648,6 +685,7 @@ __device__ __forceinline__ void stem_wave(const CvArgs& a, const SvcPipe& sp, ui
       }
       __builtin_amdgcn_s_sleep(kSpinSleep);
     }
+    t_room += wall100() - tr0;
     if (failed) break;
     // ---- the stem convolution, n-tile by n-tile (leafnet_c4.h, PIPE stem: the im2col operand straight from the stone bits) ---------
     for (uint32_t j = 0; j < GT; ++j, ++k) {
@@ -657,7 +695,7 @@ __device__ __forceinline__ void stem_wave(const CvArgs& a, const SvcPipe& sp, ui
       const unsigned long long s0 = bbs[bd], s1 = bbs[4 + bd];
       const uint32_t plr = pls[bd];
       const uint32_t one2 = plr == 0u ? 0x3F80u : 0u, one3 = plr == 1u ? 0x3F80u : 0u;
-      auto tap_words = [&](int tap, uint32_t& e01, uint32_t& on) {       // (ci 0, ci 1) and (ci 2, ci 3) of one tap, as bf16 pairs
+      auto tap_words = [&](int tap, uint32_t& e01, uint32_t& on) __attribute__((always_inline)) {       // (ci 0, ci 1) and (ci 2, ci 3) of one tap, as bf16 pairs
         const int dh = ((tap * 11) >> 5) - 1, dw = tap - 3 * ((tap * 11) >> 5) - 1;
         const int hh = h + dh, ww = w + dw;
         const bool ok = tap < 9 && bd < GB && hh >= 0 && hh < BH && ww >= 0 && ww < BW;
@@ -697,9 +735,10 @@ __device__ __forceinline__ void stem_wave(const CvArgs& a, const SvcPipe& sp, ui
         typedef __attribute__((address_space(1))) unsigned long long gu64;
         __hip_atomic_store((gu64*)(xt + (k % XNT) * 2048u + (mt * 2 + (quad >> 1)) * 256u + col * 16u + (quad & 1) * 8u), ob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      // n-tile k - 1 (stored one turn ago) is whole once everything but this turn's eight stores is done
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      st_sc1(xh + XH_PROD, k);
+      // the count moves two n-tiles behind the stores (write-through stores take longer than a turn): everything but this turn's and
+      // the last turn's stores (and the last count) is done
+      asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+      if (k >= 1u) st_sc1(xh + XH_PROD, k - 1u);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     st_sc1(xh + XH_PROD, k);
@@ -708,7 +747,10 @@ __device__ __forceinline__ void stem_wave(const CvArgs& a, const SvcPipe& sp, ui
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   st_sc1(xh + XH_PROD, k);
   st_sc1(xh + XH_END, failed ? 2u : 1u);
-  if (lane == 0 && a.stat) { atomicAdd(a.stat + 2, static_cast<unsigned long long>(grp)); atomicAdd(a.stat + 3, n_boards); }
+  if (lane == 0 && a.stat) {
+    atomicAdd(a.stat + 2, static_cast<unsigned long long>(grp)); atomicAdd(a.stat + 3, n_boards);
+    atomicAdd(a.stat + 13, t_claim); atomicAdd(a.stat + 14, t_room); atomicAdd(a.stat + 20, wall100() - t_start);
+  }
 }
 
 // ---- head --------------------------------------------------------------------------------------------------------------------------------
@@ -753,18 +795,22 @@ __device__ __forceinline__ void head_wave(const CvArgs& a, const SvcPipe& sp, ui
   if (nh == 1u && lane == 0) st_sc1(xh + XH_CONS_T, 0x7FFFFFF0u);          // (no second head wave: its counter never holds the producer back)
   if (lane == 0) st_sc1(my_cons, which * GT);                                 // I need nothing below my first group
   const unsigned long long t_start = wall100();
-  unsigned long long n_groups = 0;
+  unsigned long long n_groups = 0, t_hwait = 0;
   bool failed = false;
   for (uint32_t g = which;; g += nh) {
     const uint32_t k0 = g * GT;
     float pa_[4] = {0.f, 0.f, 0.f, 0.f};       // the pool's four running sums of (board in flight, channel lane & 31)
-    bool over = false;
+    bool over = false, have_next = false;
+    f32x4 svn[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int j = 0; j < GT; ++j) {
       const uint32_t k = k0 + j;
-      // ---- wait for n-tile k of the stream ------------------------------------------------------------------------------------------
+      // ---- wait for n-tile k of the stream; its image was requested while the n-tile before was worked on when it was there already,
+      // and the next one's is requested now (an HBM round trip per n-tile in the open made a group take 19 us) ---------------------------
+      const unsigned long long th0 = wall100();
+      uint32_t pr = 0;
       for (uint32_t spins = 0;; ++spins) {
-        const uint32_t pr = uni(ld_sc1(xh + XH_PROD));
+        pr = uni(ld_sc1(xh + XH_PROD));
         if (static_cast<int32_t>(pr - k) > 0) break;
         if (uni(ld_sc1(xh + XH_END)) != 0u && uni(ld_sc1(xh + XH_PROD)) == pr) { over = true; break; }
         if ((spins & 63u) == 63u) {
@@ -773,13 +819,27 @@ __device__ __forceinline__ void head_wave(const CvArgs& a, const SvcPipe& sp, ui
         }
         __builtin_amdgcn_s_sleep(kSpinSleep);
       }
+      t_hwait += wall100() - th0;
       if (over || failed) break;
       // ---- h = relu(conv1x1(s) + bh): the stream's n-tile as bf16 operand planes (scratch), two k-steps x four m tiles ------------
       f32x4 sv[4];
+      if (!have_next) {
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r_xs, (k % XNT) * 4096u + mt * 1024u + lane * 16u, 0, 16);
-        sv[mt] = f32x4{__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3])};
+        for (int mt = 0; mt < 4; ++mt) {
+          const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r_xs, (k % XNT) * 4096u + mt * 1024u + lane * 16u, 0, 16);
+          sv[mt] = f32x4{__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3])};
+        }
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) sv[mt] = svn[mt];
+      }
+      have_next = j + 1 < GT && static_cast<int32_t>(pr - (k + 1u)) > 0;
+      if (have_next) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r_xs, ((k + 1u) % XNT) * 4096u + mt * 1024u + lane * 16u, 0, 16);
+          svn[mt] = f32x4{__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3])};
+        }
       }
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
@@ -853,14 +913,14 @@ __device__ __forceinline__ void head_wave(const CvArgs& a, const SvcPipe& sp, ui
       static_assert(PIX % PC == 0, "whole chunks");
       bf16x8 wA[PC][2], wB[PC][2];
       f32x4 run[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-      auto wload = [&](int c, bf16x8 (&w)[PC][2]) {
+      auto wload = [&](int c, bf16x8 (&w)[PC][2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PC; ++i) {
           w[i][0] = *reinterpret_cast<const bf16x8*>(wp + ((c * PC + i) * 2) * WFRAG_BYTES);
           w[i][1] = *reinterpret_cast<const bf16x8*>(wp + ((c * PC + i) * 2 + 1) * WFRAG_BYTES);
         }
       };
-      auto wmul = [&](int c, const bf16x8 (&w)[PC][2]) {
+      auto wmul = [&](int c, const bf16x8 (&w)[PC][2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PC; ++i) {
           const int pz = c * PC + i;
@@ -901,14 +961,14 @@ __device__ __forceinline__ void head_wave(const CvArgs& a, const SvcPipe& sp, ui
       asm volatile("" : "+v"(w1), "+v"(b1));
       constexpr int TC = 4;
       f32x4 fA[TC][3], fB[TC][3];
-      auto floadt = [&](int t0, f32x4 (&f)[TC][3]) {
+      auto floadt = [&](int t0, f32x4 (&f)[TC][3]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
           const int t = t0 + i < ntile ? t0 + i : 0;
           f[i][0] = w1[(t * 2 + 0) * 64]; f[i][1] = w1[(t * 2 + 1) * 64]; f[i][2] = *reinterpret_cast<const f32x4*>(b1 + t * 16);
         }
       };
-      auto fmul = [&](int t0, const f32x4 (&f)[TC][3]) {
+      auto fmul = [&](int t0, const f32x4 (&f)[TC][3]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
           const int t = t0 + i;
@@ -996,7 +1056,7 @@ __device__ __forceinline__ void head_wave(const CvArgs& a, const SvcPipe& sp, ui
     n_groups += 1;
   }
   if (lane == 0) st_sc1(my_cons, 0x7FFFFFF0u);
-  if (lane == 0 && a.stat) atomicAdd(a.stat + 4, n_groups);
+  if (lane == 0 && a.stat) { atomicAdd(a.stat + 4, n_groups); atomicAdd(a.stat + 15, t_hwait); atomicAdd(a.stat + 21, wall100() - t_start); }
 }
 
 // grid = lines workgroups of 192 threads: wave 0 = the line's stem, waves 1 / 2 = its head waves

@@ -1423,9 +1423,11 @@ int pipe_pair_streams(PipeState* ps, hipStream_t st) {
 
 // ---- the conveyor's host side ---------------------------------------------------------------------------------------------------------
 // When the net side can be the conveyor (conveyor_c4.h): the bf16 tier, one model group, an even number of residual blocks (a conv
-// workgroup = two blocks).  AZMI_PIPE_NET=tiles keeps the tile kernel (k_pipe_net), =conveyor insists (an error where it cannot run).
+// workgroup = two blocks).  Round 5: opt-in (AZMI_PIPE_NET=conveyor; an error where it cannot run) - bit for bit the tile kernel's
+// answers, but at 0.25 of the MFMA peak alone on the chip against the tile kernel's 0.45 (DESIGN section 4.5b says what is missing).
 bool cv_eligible(const azmi_pm* pm, const PipePlan& plan) {
-  if (const char* e = getenv("AZMI_PIPE_NET")) if (strcmp(e, "tiles") == 0) return false;
+  const char* e = getenv("AZMI_PIPE_NET");
+  if (!e || strcmp(e, "conveyor") != 0) return false;
   const azmi_net_dev::NetDesc& nd = plan.view[0].nd;
   return !plan.tree_only && plan.kind == 1 && plan.net_groups == 1u && pm->ep.num_groups == 1u && plan.view[0].x3 == 0 && nd.depth >= 2 && nd.depth % 2 == 0;
 }
@@ -1454,7 +1456,7 @@ int cv_setup(azmi_pm* pm, PipeState* ps, const azmi_net_c4_view& view) {
     if (rc == AZMI_OK) rc = pipe_alloc(ps, ps->cv_xt, rings * cvn::X_T);
     if (rc == AZMI_OK) rc = pipe_alloc(ps, ps->cv_xs, rings * cvn::X_S);
     if (rc == AZMI_OK) rc = pipe_alloc(ps, ps->cv_meta, static_cast<size_t>(want_alloc) * cvn::MGRP * 32);
-    if (rc == AZMI_OK && !ps->cv_stat) rc = pipe_alloc(ps, ps->cv_stat, 16);
+    if (rc == AZMI_OK && !ps->cv_stat) rc = pipe_alloc(ps, ps->cv_stat, 32);
     if (rc != AZMI_OK) return rc;
     ps->cv_nwg = nwg; ps->cv_lines_alloc = want_alloc; ps->cv_calibrated = false;
     ps->cv_lines = 0;
@@ -1472,6 +1474,7 @@ cvn::CvArgs cv_args(const PipeState* ps, const azmi_net_c4_view& view, const Pip
   a.nd = view.nd; a.np = view.np;
   a.xh = ps->cv_xh; a.xt = ps->cv_xt; a.xs = ps->cv_xs; a.meta = ps->cv_meta;
   a.lines = ps->cv_lines; a.nwg = ps->cv_nwg;
+  a.dbg_flags = getenv("AZMI_CV_DBG") ? static_cast<uint32_t>(atoi(getenv("AZMI_CV_DBG"))) : 0u;
   a.err = &pa.ctl->err; a.stop = &pa.ep->stop; a.cap_ticks = pa.cap_ticks; a.stat = ps->cv_stat;
   return a;
 }
@@ -2017,6 +2020,20 @@ extern "C" int azmi_debug_pipe_net_bench(azmi_pm* pm, azmi_net* net, uint32_t n,
     if (r > 0) total += ms;
   }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (mode == 3 && getenv("AZMI_CV_STAT")) {
+    unsigned long long h[32];
+    AZMI_HIP_TRY(hipMemcpy(h, ps->cv_stat, sizeof(h), hipMemcpyDeviceToHost));
+    AZMI_HIP_TRY(hipMemset(ps->cv_stat, 0, sizeof(h)));
+    fprintf(stderr, "conveyor stat (%u lines, %u drains): conv n-tiles %llu (drained %llu), stem groups %llu boards %llu, head groups %llu | per wave, us: "
+            "conv wait-in %.0f %.0f %.0f %.0f wait-out %.0f %.0f %.0f %.0f life %.0f | stem claim %.0f room %.0f life %.0f | head wait %.0f life %.0f\n",
+            ps->cv_lines, reps + 1, h[0], h[1], h[2], h[3], h[4],
+            h[5] * 0.01 / (ps->cv_lines * ps->cv_nwg), h[6] * 0.01 / (ps->cv_lines * ps->cv_nwg), h[7] * 0.01 / (ps->cv_lines * ps->cv_nwg), h[8] * 0.01 / (ps->cv_lines * ps->cv_nwg),
+            h[9] * 0.01 / (ps->cv_lines * ps->cv_nwg), h[10] * 0.01 / (ps->cv_lines * ps->cv_nwg), h[11] * 0.01 / (ps->cv_lines * ps->cv_nwg), h[12] * 0.01 / (ps->cv_lines * ps->cv_nwg),
+            h[16] * 0.01 / (ps->cv_lines * ps->cv_nwg), h[13] * 0.01 / ps->cv_lines, h[14] * 0.01 / ps->cv_lines, h[20] * 0.01 / ps->cv_lines,
+            h[15] * 0.01 / (ps->cv_lines * ps->cv_heads), h[21] * 0.01 / (ps->cv_lines * ps->cv_heads));
+    if (h[26]) fprintf(stderr, "  back-to-back n-tiles, ns each by role: %.0f %.0f %.0f %.0f (of %llu %llu %llu %llu)\n", 10.0 * h[22] / std::max(1ull, h[26]), 10.0 * h[23] / std::max(1ull, h[27]),
+                       10.0 * h[24] / std::max(1ull, h[28]), 10.0 * h[25] / std::max(1ull, h[29]), h[26], h[27], h[28], h[29]);
+  }
   // the synthetic answers carry sequence numbers a real request of the same slot could draw later: wipe the granules
   AZMI_HIP_TRY(hipMemsetAsync(pa.res, 0, sizeof(unsigned long long) * static_cast<size_t>(pm->ep.S) * kResStride, st));
   AZMI_HIP_TRY(hipStreamSynchronize(st));

@@ -42,3 +42,27 @@ def test_conveyor_answers_bit_for_bit_like_the_tile_kernel(depth, n, lines):
     assert len(bad) == 0, f"{len(bad)} of {n} positions differ, first {bad[:5]}: {got[bad[0]]} vs {want[bad[0]]}"
     # and they are what the plain launch of the tile answers (the whole-batch kernel behind HipLeafNet.process)
     assert abs(float(got[:, :7].sum(1).mean()) - 1.0) < 1e-5 and abs(float(got[:, 7:].sum(1).mean()) - 1.0) < 1e-5
+
+
+def test_the_pipeline_on_the_conveyor_plays_the_lockstep_engines_games(monkeypatch):
+    """AZMI_PIPE_NET=conveyor: the asynchronous pipeline with the conveyor as its net side (three kernels side by side: tree, conv
+    lines, service) plays, move for move and visit count for visit count, what the lock-step engine plays."""
+    import alphazero as az
+    from alphazero import torch_net
+    from test_gpu_pipeline import _pipeline_games, _lockstep_games, _sorted_log
+    from test_gpu_t3_nn_in_the_loop import _selfplay_params
+    monkeypatch.setenv("AZMI_PIPE_NET", "conveyor")
+    monkeypatch.setenv("AZMI_CV_LINES", "8")
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=21), spec)
+    S, seed = 128, 9001
+    pp = _selfplay_params(az, S, 100, cache=1 << 16)
+    pa, (ra, ca), stats = _pipeline_games(az, pp, seed, hip, sims_per_epoch=S * 40)
+    monkeypatch.delenv("AZMI_PIPE_NET")
+    pb, (rb, cb) = _lockstep_games(az, pp, seed, hip)
+    assert pa.games_completed() == pb.games_completed() == S
+    ra, ca = _sorted_log(ra, ca)
+    rb, cb = _sorted_log(rb, cb)
+    assert np.array_equal(ra, rb), "moves / pcg32 positions differ between the conveyor pipeline and the lock-step engine"
+    assert np.array_equal(ca, cb), "visit counts differ"
+    assert stats["tiles"] > 0 and stats["net_wgs"] == 8
