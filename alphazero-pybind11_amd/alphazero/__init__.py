@@ -1627,7 +1627,16 @@ def run_pipeline(pm, net, epochs, sims_per_epoch, stream=None):
     st = pm._stream_arg(stream)
     out = (C.c_uint64 * 16)()
     check(lib.azmi_run_pipeline(pm._h, None if net is None else net._h, int(epochs), int(sims_per_epoch), st, out))
-    return dict(zip(_PIPE_KEYS, (int(x) for x in out)))
+    return _pipe_stats(out)
+
+
+def _pipe_stats(out):
+    d = dict(zip(_PIPE_KEYS, (int(x) for x in out)))
+    # (slot 14 carries two 32-bit counts: the calibration launches of this call, and the requests the net side has given up on and
+    # the boundary has sent again since the engine was created - PipeCtl::lost_total)
+    d["lost_total"] = d["calibration_rounds"] >> 32
+    d["calibration_rounds"] &= 0xFFFFFFFF
+    return d
 
 
 _PIPE_KEYS = ("tiles", "tile_boards", "last_epoch_sims", "tree_wgs_started", "net_wgs_started", "last_epoch_inserts", "net_wgs", "tree_wgs",
@@ -1649,7 +1658,7 @@ def run_pipeline_groups(pm, nets, epochs, sims_per_epoch, stream=None):
     out = (C.c_uint64 * 16)()
     arr = (C.c_void_p * len(nets))(*[None if n is None else n._h for n in nets])
     check(lib.azmi_run_pipeline_groups(pm._h, arr, len(nets), int(epochs), int(sims_per_epoch), st, out))
-    return dict(zip(_PIPE_KEYS, (int(x) for x in out)))
+    return _pipe_stats(out)
 
 
 def pipeline_log_duplicates(pm):

@@ -163,6 +163,11 @@ SYMBOLS = {
     "azmi_debug_pipe_log_dupes": (C.c_int, [_VP, _VP]),
     "azmi_debug_pipe_net_bench": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _VP]),
     "azmi_debug_pipe_net_answers": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint64, C.c_int, C.c_uint32, _VP, _VP]),
+    "azmi_comm_unique_id": (C.c_int, [_VP]),
+    "azmi_comm_create": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, _PP(_VP)]),
+    "azmi_comm_destroy": (None, [_VP]),
+    "azmi_gather_counts": (C.c_int, [_VP, C.c_uint64, _VP, _VP]),
+    "azmi_gather_rows": (C.c_int, [_VP, _VP, _VP, C.c_uint32, _VP, _VP, _VP]),
     "azmi_rng_probe": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_float, C.c_uint32, C.c_uint32, _VP]),
     "azmi_num_symmetries": (C.c_uint32, [C.c_int]),
     "azmi_symmetries": (C.c_int, [C.c_int, C.c_int, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int, _VP]),

@@ -6,6 +6,8 @@ then the rows travel with a padded gather (rank 0 receives, everyone else sends)
 RCCL over xGMI (`backend="nccl"`), in the CPU tests it is gloo.  Messages are small
 (Connect4: 712 B/row), so no ring tuning is involved.
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
@@ -44,3 +46,59 @@ def gather_history_to_rank0(pm, dev, rank, world):
         pm._gathered.append(res)
         return int(res[0].shape[0])
     return 0
+
+
+class NativeGather:
+    """The same exchange behind the C ABI (csrc/gather.hip: azmi_comm_* / azmi_gather_counts / azmi_gather_rows over librccl, no
+    torch collective in the data path): one ncclAllGather of the row counts, then the rows UNPADDED to rank 0 - grouped
+    ncclSend / ncclRecv per array, rank 0's own rows by a device copy - so rank 0's extra memory is exactly the gathered rows
+    (gather_rows_to_rank0 pads every rank to the largest count).  The 128-byte RCCL id travels over the launcher's own process
+    group (one broadcast, any backend).  GPU only; the gloo tests keep using gather_rows_to_rank0."""
+
+    def __init__(self, rank, world, device, group=None):
+        from ._capi import lib, check
+        self._lib, self._check = lib, check
+        self.rank, self.world = int(rank), int(world)
+        dev = torch.device("cuda", int(device))
+        idt = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = (C.c_uint8 * 128)()
+            check(lib.azmi_comm_unique_id(buf))
+            idt = torch.tensor(list(buf), dtype=torch.uint8)
+        if self.world > 1:
+            backend = dist.get_backend(group)
+            t = idt.to(dev) if backend == "nccl" else idt
+            dist.broadcast(t, src=0, group=group)
+            idt = t.cpu()
+        idb = (C.c_uint8 * 128)(*idt.tolist())
+        h = C.c_void_p()
+        check(lib.azmi_comm_create(idb, self.rank, self.world, int(device), C.byref(h)))
+        self._h, self._dev = h, dev
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._lib is not None:
+            self._lib.azmi_comm_destroy(self._h)
+            self._h = None
+
+    def gather_rows_to_rank0(self, parts, stream=None):
+        """parts: CONTIGUOUS device tensors with the same leading dimension (may be 0).  Rank 0: the list of gathered tensors (rank
+        order), elsewhere None.  Returns after the copies are enqueued on `stream` (default: torch's current stream)."""
+        lib, check = self._lib, self._check
+        st = C.c_void_p(stream if stream is not None else torch.cuda.current_stream(self._dev).cuda_stream)
+        n_local = int(parts[0].shape[0])
+        counts = (C.c_uint64 * self.world)()
+        check(lib.azmi_gather_counts(self._h, n_local, counts, st))
+        total = sum(int(c) for c in counts)
+        parts = [p.contiguous() for p in parts]
+        k = len(parts)
+        row_bytes = (C.c_uint64 * k)(*[p.element_size() * (p.numel() // max(1, p.shape[0])) if p.shape[0] else p.element_size() * int(torch.tensor(p.shape[1:]).prod()) for p in parts])
+        src = (C.c_void_p * k)(*[p.data_ptr() for p in parts])
+        out = None
+        dst = (C.c_void_p * k)()
+        if self.rank == 0:
+            out = [torch.empty((total,) + tuple(p.shape[1:]), dtype=p.dtype, device=self._dev) for p in parts]
+            dst = (C.c_void_p * k)(*[o.data_ptr() for o in out])
+        if total:
+            check(lib.azmi_gather_rows(self._h, src, row_bytes, k, counts, dst, st))
+        self.last_counts = [int(c) for c in counts]
+        return out

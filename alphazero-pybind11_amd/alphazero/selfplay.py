@@ -94,17 +94,14 @@ def self_play(game, params, net=None, engines=None, seed=20240601, device=0, str
         live = list(range(K))
         tdev = torch.device("cuda", device)
         spe = 256 * int(params.concurrent_games)
+        pipe_state = {"retries": 0}
         while live:
             group = [pms[i] for i in live]
             if want_pipe:
-                try:
-                    run_pipeline(pms[0], net, epochs_per_poll, spe, sps[0])
-                except RuntimeError:
-                    # the pipeline's run-time preconditions (a second hardware queue beside the caller's stream, room for its tree and
-                    # net workgroups side by side) are only known once it runs: "auto" falls back to the lock-step driver - with fresh
-                    # shards while no game has finished, on the same engine otherwise (a pipeline error leaves the engine whole)
-                    if driver != "auto":
-                        raise
+                # the pipeline's run-time preconditions (a second hardware queue beside the caller's stream, room for its tree and
+                # net workgroups side by side) are only known once it runs: "auto" falls back to the lock-step driver - with fresh
+                # shards while no game has finished, on the same engine otherwise (a pipeline error leaves the engine whole)
+                if not _pipeline_step(lambda: run_pipeline(pms[0], net, epochs_per_poll, spe, sps[0]), pipe_state, driver, "self_play"):
                     want_pipe = False
                     if pms[0].games_completed() == 0 and not drained[0]:
                         K = max(1, min(int(engines or 4), int(params.concurrent_games)))
@@ -178,6 +175,30 @@ def self_play(game, params, net=None, engines=None, seed=20240601, device=0, str
     return res, samples
 
 
+def _pipeline_step(call, state, driver, what):
+    """One call of the asynchronous pipeline under the error contract of include/azmi.h: a "pipeline error mask" error (a spin that hit
+    the stall cap: the host was held up between the launches, another tenant took CUs) leaves the engine whole and the call is simply
+    made again - at most three times per run; a precondition failure (no second hardware queue beside the caller's stream, no room for
+    the kernels side by side, an engine the pipeline does not drive) makes driver="auto" fall back to the lock-step driver, with a warning;
+    everything else (out of memory, invalid arguments) is raised.  Returns True when the call ran, False to fall back."""
+    import warnings
+    while True:
+        try:
+            call()
+            return True
+        except RuntimeError as e:
+            msg = str(e)
+            if "pipeline error mask" in msg and state["retries"] < 3:
+                state["retries"] += 1
+                warnings.warn(f"{what}: pipeline error, call repeated ({state['retries']} of 3): {msg[:200]}")
+                continue
+            precondition = any(k in msg for k in ("hardware queue", "does not hold", "the pipeline drives", "pipeline error mask"))
+            if driver != "auto" or not precondition:
+                raise
+            warnings.warn(f"{what}: the asynchronous pipeline does not run here, falling back to the lock-step driver: {msg[:200]}")
+            return False
+
+
 @dataclasses.dataclass
 class MatchResult:             # what play_past() returns from the PlayManager (game_runner.py:2250-2332)
     nn_rate: float
@@ -191,15 +212,18 @@ class MatchResult:             # what play_past() returns from the PlayManager (
     perm_scores: list
 
 
-def gating_match(game, params, net_new, net_past, engines=2, seed=20240601, device=0, rounds_per_poll=256, driver="auto", epochs_per_poll=16):
+def gating_match(game, params, net_new, net_past, engines=2, seed=20240601, device=0, rounds_per_poll=256, driver="rounds", epochs_per_poll=16):
     """play_past (game_runner.py:2184-2332) on the device: model group 0 = the new model, group 1 = the past one, every seating
     of the two (2 players: both; N players: the new model alone in each seat, then the past model alone in each seat), games
     split over `engines` shards.  `net_new` / `net_past` are HipLeafNets, or None for the reference's RandPlayer (RANDOM
     evaluator).  `params` supplies the search settings (visits, temperatures, cache ...); its groups, permutations and
     evaluator types are set here like play_past does.
-    driver: "auto" = ONE engine on the asynchronous pipeline with one net per model group (azmi_run_pipeline_groups) where it applies
-    (Connect4 with Connect4-family nets), falling back to the lock-step driver on the same engine when the pipeline cannot run;
-    "rounds" = `engines` shards on the lock-step driver; "pipeline" = the pipeline or an error."""
+    driver: "rounds" (the default) = `engines` shards on the lock-step driver: the same seed gives the same match, game for game - gating
+    decides model promotion; "auto" = ONE engine on the asynchronous pipeline with one net per model group (azmi_run_pipeline_groups)
+    where it applies (Connect4 with Connect4-family nets; 2-3 x the games per second), falling back to the lock-step driver on the same
+    engine when the pipeline cannot run - the k-th game of a slot is still a function of the seed alone, but WHICH slots receive the last
+    restarts of a finite match depends on the order in which games end inside an epoch, so two runs of one seed may differ in a few
+    games (as the reference's workers race for games_started_, play_manager.cc:506-513); "pipeline" = the pipeline or an error."""
     import copy
     import torch
     g = game() if isinstance(game, type) else game
@@ -230,13 +254,10 @@ def gating_match(game, params, net_new, net_past, engines=2, seed=20240601, devi
     streams = [torch.cuda.Stream(device=device) for _ in range(K)]
     sps = [s.cuda_stream for s in streams]
     live = list(range(K))
+    pipe_state = {"retries": 0}
     while live:
         if use_pipe:
-            try:
-                run_pipeline_groups(pms[0], nets, epochs_per_poll, 256 * int(p.concurrent_games), sps[0])
-            except RuntimeError:
-                if driver != "auto":
-                    raise
+            if not _pipeline_step(lambda: run_pipeline_groups(pms[0], nets, epochs_per_poll, 256 * int(p.concurrent_games), sps[0]), pipe_state, driver, "gating_match"):
                 use_pipe = False          # (a pipeline error leaves the engine whole: the lock-step driver carries on with it)
                 continue
         else:

@@ -16,6 +16,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <memory>
 
 #include "../../include/azmi.h"
 #include "engine_host.h"
@@ -329,30 +331,33 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
     unsigned long long g0 = 0, g1 = 0;
     PendRec pr_in{};
     uint32_t seq_now = 0;
-    for (;;) {
-      if (my_slot != kNoSlot) {
-        seq_now = g_ld(ar.req_seq + slot);
-        if (tok_seq != 0u) {
-          if (lane < static_cast<uint32_t>(GM::M)) g0 = g_ld(res + lane);
-          if (lane <= static_cast<uint32_t>(P)) g1 = g_ld(res + kResV + lane);
-        }
-        pr_in = ar.pend[static_cast<size_t>(slot) * G + lane];
-        cur_key = ar.leaf_key[slot];
-        c.load();
-      }
-      const bool stale = my_slot != kNoSlot && tok_seq != 0u && seq_now != tok_seq;
-      if (__ballot(stale) == 0ull) break;
-      if (stale) {      // the slot's last holder is still storing it: wait for the publication, then ask again (for every group: rare)
-        while (g_ld(ar.req_seq + slot) != tok_seq) {
+    // (the publication word is looked at BEFORE the slot's plain loads are issued, not in one batch with them: the word
+    // comes from L2 (sc1), the plain loads may hit this CU's L1 earlier in time - a holder that published in between would have had its
+    // new sequence number accepted beside lines read before its stores.  One more round trip per pass, ~0.5 us of ~120.)
+    if (my_slot != kNoSlot) {
+      seq_now = g_ld(ar.req_seq + slot);
+      if (tok_seq != 0u) {
+        while (seq_now != tok_seq) {      // the slot's last holder is still storing it: wait for the publication (rare)
           if (wall_clock64() - t_start > pa.cap_ticks) {
-            if (lane == 0 && atomicAdd(&pc->dbg[0], 1u) == 0u) { pc->dbg[1] = slot; pc->dbg[2] = tok_seq; pc->dbg[3] = g_ld(ar.req_seq + slot); pc->dbg[4] = 0xEEEEu; }
+            if (lane == 0 && atomicAdd(&pc->dbg[0], 1u) == 0u) { pc->dbg[1] = slot; pc->dbg[2] = tok_seq; pc->dbg[3] = seq_now; pc->dbg[4] = 0xEEEEu; pc->dbg[14] = blockIdx.x; pc->dbg[15] = static_cast<uint32_t>((wall_clock64() - t_start) / 100u); }
             if (lane == 0) atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTimeout));
             my_slot = kNoSlot;      // (its other holder is still at work: the slot is not touched; k_pipe_settle takes its answer over)
             break;
           }
           __builtin_amdgcn_s_sleep(2);
+          seq_now = g_ld(ar.req_seq + slot);
         }
       }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // (no instruction: the loads below stay below the poll)
+    if (my_slot != kNoSlot) {
+      if (tok_seq != 0u) {
+        if (lane < static_cast<uint32_t>(GM::M)) g0 = g_ld(res + lane);
+        if (lane <= static_cast<uint32_t>(P)) g1 = g_ld(res + kResV + lane);
+      }
+      pr_in = ar.pend[static_cast<size_t>(slot) * G + lane];
+      cur_key = ar.leaf_key[slot];
+      c.load();
     }
     const bool on = my_slot != kNoSlot;
     if (on) {
@@ -732,6 +737,11 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
   PipeCtl* const pc = pa.ctl;
   PipeEpoch* const pe = pa.ep;
   PipeWg* const wc = pa.wg + blockIdx.x;
+  // where every wavefront of this workgroup is (diagnostics of the rare stall-cap error): PipeWg::pad[2 + wave] =
+  // phase | units of 10 us since the wave started << 8; the host prints the words of every tree workgroup with a pipeline error
+  uint32_t* const phase_word = &wc->pad[2 + (threadIdx.x >> 6)];
+#define AZMI_GEN_PHASE(x) do { if (wlane == 0) g_st(phase_word, static_cast<uint32_t>(x) | (static_cast<uint32_t>((wall_clock64() - t_start) / 1000u) << 8)); } while (0)
+  AZMI_GEN_PHASE(1);
   const uint32_t rmask = (1u << pa.rshift) - 1u;
   unsigned long long* const myring = pa.rring + (static_cast<size_t>(blockIdx.x) << pa.rshift);
   if (threadIdx.x == 0) {
@@ -742,6 +752,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
     asm volatile("s_waitcnt vmcnt(0)" :: "v"(before) : "memory");
   }
   __syncthreads();
+  AZMI_GEN_PHASE(2);
   if (pa.census_hold != 0u) {        // calibration launch: see k_pipe_tree
     const unsigned long long t0 = g_ld(&pe->t0);
     if (threadIdx.x == 0 && t_start > t0 && t_start - t0 >= pa.census_hold) atomicAdd(&pe->tree_late_n, 1u);
@@ -754,6 +765,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
   __syncthreads();
   const PipeKernArgs* const kargs = reinterpret_cast<const PipeKernArgs*>(reinterpret_cast<uintptr_t>(__builtin_amdgcn_kernarg_segment_ptr()));
   while (go) {
+    AZMI_GEN_PHASE(3);
     // ---- tokens (as k_pipe_tree: the arrived prefix of the eight ring positions at the LDS head)
     uint32_t my_slot = kNoSlot, tok_seq = 0, empty_polls = 0, ctl_word = 0;
     for (;;) {
@@ -781,7 +793,13 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
       }
       const uint64_t now = wall_clock64();
       if (now - t_start > pa.soft_ticks) stop_seen = 1u;
-      if (now - t_start > pa.cap_ticks) { if (wlane == 0) atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTimeout)); stop_seen = 1u; }
+      if (now - t_start > pa.cap_ticks) {
+        if (wlane == 0) {
+          atomicOr(&pc->err, static_cast<uint32_t>(kPipeErrTimeout));
+          if (atomicAdd(&pc->dbg[0], 1u) == 0u) { pc->dbg[1] = blockIdx.x; pc->dbg[2] = empty_polls; pc->dbg[3] = h; pc->dbg[4] = 0xCCCCu; pc->dbg[5] = wc->rtail; pc->dbg[6] = static_cast<uint32_t>(pa.soft_ticks / 1000u); }
+        }
+        stop_seen = 1u;
+      }
       if (stop_seen) { if (wlane == 0) g_st(&pe->stop, 1u); go = false; break; }
       const unsigned long long hm = __ballot(here);
       uint32_t k = 0;
@@ -796,6 +814,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
       break;
     }
     if (!go) break;
+    AZMI_GEN_PHASE(4);
     // ---- an answer token: the slot is back once req_seq shows the token's number; its granules become the slot's (v, pi) rows
     if (my_slot != kNoSlot && tok_seq != 0u) {
       while (g_ld(ar.req_seq + my_slot) != tok_seq) {
@@ -809,6 +828,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
     }
     bool answered = false;
     float reg_pi = 0.0f, reg_v = 0.0f;
+    AZMI_GEN_PHASE(5);
     if (my_slot != kNoSlot && tok_seq != 0u) {
       const unsigned long long* const res = pa.res + static_cast<size_t>(my_slot) * kResStride;
       unsigned long long g0 = 0, g1 = 0;
@@ -854,8 +874,10 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the rows are in place before the step reads them
+    AZMI_GEN_PHASE(6);
     // ---- one step of every slot of the pass (requests leave inside)
     const uint32_t rs = pipe_move_groups<GM>(kargs->ep, kargs->ar, kargs->pa, my_slot);
+    AZMI_GEN_PHASE(7);
     // ---- a slot whose next answer is at hand (cache hit, terminal leaf, RANDOM seat) goes straight back into the ring
     {
       const bool tok_out = my_slot != kNoSlot && lane == 0 && rs == kSlotWaitEval;
@@ -872,10 +894,13 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
       }
     }
   }
+  AZMI_GEN_PHASE(8);
   if (wlane == 0) g_st(&pe->stop, 1u);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  AZMI_GEN_PHASE(9);
   if (threadIdx.x == 0) { wc->rhead = s_head; atomicAdd(&pe->tree_done, 1u); }
+#undef AZMI_GEN_PHASE
 }
 
 // ---- net side -----------------------------------------------------------------------------------------------------------------------
@@ -1241,6 +1266,7 @@ struct PipeState {
   uint32_t cv_lines = 0, cv_lines_alloc = 0, cv_nwg = 0, cv_heads = 2;
   uint32_t* cv_xh = nullptr; uint8_t* cv_xt = nullptr; uint8_t* cv_xs = nullptr; uint32_t* cv_meta = nullptr; unsigned long long* cv_stat = nullptr;
   bool cv_calibrated = false;
+  const void* l0_nets[2] = {nullptr, nullptr};      // the weight images the answer table's entries were computed with (group 0, group 1)
 };
 void pipe_state_free(PipeState* p) {
   if (!p) return;
@@ -1566,7 +1592,12 @@ int pipe_calibrate(azmi_pm* pm, PipeState* ps, hipStream_t st, const azmi_net_c4
     AZMI_HIP_TRY(hipStreamSynchronize(st));
     ps->calib_rounds = static_cast<uint32_t>(attempt) + 1u;
     const uint32_t late = he.tree_late_n + he.net_late_n;
-    if (late == 0u && he.tree_arrived == ps->tree_wgs && he.net_arrived == ps->net_wgs) { ps->calibrated = true; ps->places = ps->x3 ? 0u : ps->tree_wgs + ps->net_wgs; return AZMI_OK; }
+    if (late == 0u && he.tree_arrived == ps->tree_wgs && he.net_arrived == ps->net_wgs) {
+      // (a workgroup serves ONE model group's ring for an epoch - its index's parity when both groups have a net: with one workgroup
+      // group 1's ring would never be served and every epoch would run into the time cap - ADVICE r4)
+      if (pa.net_groups == 3u && ps->net_wgs < 2u) break;
+      ps->calibrated = true; ps->places = ps->x3 ? 0u : ps->tree_wgs + ps->net_wgs; return AZMI_OK;
+    }
     if (ps->net_wgs <= 1u) break;
     ps->net_wgs = ps->net_wgs > late + 1u ? ps->net_wgs - std::max<uint32_t>(late, 1u) : 1u;
   }
@@ -1656,7 +1687,15 @@ void pipe_balance(PipeState* ps, const PipeCtl& hc) {
 
 // An epoch's workgroup counts assume the chip to itself (placement): two engines' epochs at once would each find half of
 // their workgroups without a place.  Calls from different threads therefore take turns (they are synchronous anyway).
-static std::mutex g_pipeline_turn;
+// (one mutex per DEVICE: two engines on two different GPUs of one process do not wait for each other - VERDICT r4)
+static std::mutex& pipeline_turn_of(int device) {
+  static std::mutex table_mu;
+  static std::map<int, std::unique_ptr<std::mutex>> table;
+  std::lock_guard<std::mutex> l(table_mu);
+  auto& m = table[device];
+  if (!m) m.reset(new std::mutex());
+  return *m;
+}
 static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_nets, uint32_t epochs, uint64_t sims_per_epoch, void* stream, uint64_t* out_stats);
 extern "C" int azmi_run_pipeline(azmi_pm* pm, azmi_net* net, uint32_t epochs, uint64_t sims_per_epoch, void* stream, uint64_t* out_stats) {
   azmi_net* nets[2] = {net, net};            // the same net for every model group (azmi_pm_net_forward's rule)
@@ -1669,7 +1708,7 @@ extern "C" int azmi_run_pipeline_groups(azmi_pm* pm, azmi_net* const* nets, uint
 static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_nets, uint32_t epochs, uint64_t sims_per_epoch, void* stream, uint64_t* out_stats) {
   if (!pm) return azmi_host_fail(AZMI_ERR_INVALID, "null argument");
   std::lock_guard<std::recursive_mutex> lock_(pm->mu);
-  std::lock_guard<std::mutex> turn_(g_pipeline_turn);
+  std::lock_guard<std::mutex> turn_(pipeline_turn_of(pm->device));
   const PipePlan plan = pipe_plan(pm, nets, num_nets);
   if (plan.kind == 0)
     return azmi_host_fail(AZMI_ERR_STATE, "azmi_run_pipeline: the pipeline drives the Connect4 engine (no PLAYOUT seats, at most two model groups, at most %u "
@@ -1750,6 +1789,17 @@ static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_ne
     if (rc != AZMI_OK) return rc;
     pa.l0_mask = (1u << sh) - 1u;
     pa.l0_wb = getenv("AZMI_PIPE_L0_WB") ? static_cast<uint32_t>(atoi(getenv("AZMI_PIPE_L0_WB"))) : 0u;
+  }
+  if (pa.l0) {
+    // the table's entries are answers of the nets the LAST call ran with: another net behind a group (or the groups' nets swapped)
+    // would be served the old net's (v, pi) as hits - wipe it.  (It also outlives the S3-FIFO's evictions inside one
+    // engine: by design, the table is a second, direct-mapped level of the position cache.)
+    const void* n0 = (plan.net_groups & 1u) ? static_cast<const void*>(plan.view[0].np.blocks) : nullptr;
+    const void* n1 = (plan.net_groups & 2u) ? static_cast<const void*>(plan.view[1].np.blocks) : nullptr;
+    if (n0 != ps->l0_nets[0] || n1 != ps->l0_nets[1]) {
+      if (ps->l0_nets[0] || ps->l0_nets[1]) AZMI_HIP_TRY(hipMemsetAsync(pa.l0, 0, (static_cast<size_t>(pa.l0_mask) + 1u) * kResStride * sizeof(unsigned long long), st));
+      ps->l0_nets[0] = n0; ps->l0_nets[1] = n1;
+    }
   }
   // an epoch must end long before the wall-clock cap (a stall detector, 250 ms): with the move step inside the epoch nothing else ends it,
   // so the quota is held to 1024 simulations per slot (~50 ms at the slowest per-slot rate measured)
@@ -1872,7 +1922,7 @@ static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_ne
       if (!tree_only && hipEventElapsedTime(&ms, ps->tev[4 * e + 0], ps->tev[4 * e + 1]) == hipSuccess) net_us += 1e3 * ms;
       if (hipEventElapsedTime(&ms, ps->tev[4 * e + 2], ps->tev[4 * e + 3]) == hipSuccess) tree_us += 1e3 * ms;
     }
-    out_stats[10] = static_cast<uint64_t>(net_us); out_stats[11] = static_cast<uint64_t>(tree_us); out_stats[12] = epochs; out_stats[13] = host_enqueue_us; out_stats[14] = ps->calib_rounds; out_stats[15] = hc.l0_hits;
+    out_stats[10] = static_cast<uint64_t>(net_us); out_stats[11] = static_cast<uint64_t>(tree_us); out_stats[12] = epochs; out_stats[13] = host_enqueue_us; out_stats[14] = static_cast<uint64_t>(ps->calib_rounds) | (static_cast<uint64_t>(hc.lost_total) << 32); out_stats[15] = hc.l0_hits;
     if (getenv("AZMI_PIPE_PROF")) {
       fprintf(stderr, "pipe prof:");
       for (int i = 0; i < 16; ++i) fprintf(stderr, " %llu", hc.prof[i]);
@@ -1883,6 +1933,16 @@ static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_ne
     fprintf(stderr, "pipeline dbg:");
     for (int i = 0; i < 18; ++i) fprintf(stderr, " %u", hc.dbg[i]);
     fprintf(stderr, "\n");
+    if (plan.kind == 2) {      // the generic tree kernel: where each of its wavefronts was last (phase, 10 us units since its start)
+      std::vector<PipeWg> hw(ps->tree_wgs);
+      if (hipMemcpy(hw.data(), pa.wg, hw.size() * sizeof(PipeWg), hipMemcpyDeviceToHost) == hipSuccess) {
+        fprintf(stderr, "pipeline generic tree kernel, workgroup: rhead rtail | phase@10us of its four wavefronts:");
+        for (uint32_t w = 0; w < ps->tree_wgs; ++w)
+          fprintf(stderr, "  [%u: %u %u | %u@%u %u@%u %u@%u %u@%u]", w, hw[w].rhead, hw[w].rtail, hw[w].pad[2] & 255u, hw[w].pad[2] >> 8, hw[w].pad[3] & 255u, hw[w].pad[3] >> 8,
+                  hw[w].pad[4] & 255u, hw[w].pad[4] >> 8, hw[w].pad[5] & 255u, hw[w].pad[5] >> 8);
+        fprintf(stderr, "\n");
+      }
+    }
   }
   if (hc.err) {
     // reported once: k_pipe_settle has put every slot whose request went unanswered back into the move step's kSlotQueued form, so

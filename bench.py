@@ -81,6 +81,8 @@ def parse(argv=None):
     ap.add_argument("--no-tawlbwrdd", action="store_true",
                     help="the default run (1 GPU, Connect4) also measures BASELINE configs[2] - Tawlbwrdd 2048 games x 400 sims, PUCT and Gumbel, with its "
                          "CPU baseline - and reports it as the `tawlbwrdd` block of the line; this flag skips that")
+    ap.add_argument("--no-stargambit", action="store_true",
+                    help="... and BASELINE configs[4] per GPU - star_gambit_unified 1024 games x 800 sims, 200 k-entry device cache - as the `stargambit` block; this flag skips that")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)    # a measurement process started by the default run
     ap.add_argument("--probe", action="store_true", help=argparse.SUPPRESS)     # child process of the default driver choice: exit 0 when the pipeline runs here
     ap.add_argument("--dry", action="store_true",
@@ -332,7 +334,7 @@ def orchestrate(args):
     (configs/tawlbwrdd.yaml:24-25) and its own CPU baseline (play_manager_bench.cc:171-181 methodology).  Each measurement is a
     process of its own, one after the other on the one GPU; this process never touches it."""
     t0 = time.perf_counter()
-    passthrough = [a for a in sys.argv[1:] if a != "--no-tawlbwrdd"]
+    passthrough = [a for a in sys.argv[1:] if a not in ("--no-tawlbwrdd", "--no-stargambit")]
     head = run_worker(passthrough, 900)
     if "error" in head:
         sys.stderr.write("bench.py: the headline measurement failed: " + json.dumps(head) + "\n")
@@ -353,6 +355,11 @@ def orchestrate(args):
         return out
     head["tawlbwrdd"] = trim(puct)
     head["tawlbwrdd"]["gumbel"] = trim(gumbel)
+    # BASELINE configs[4] (per GPU): star_gambit_unified, 1024 concurrent games, 800 sims, device-side S3-FIFO of 200 000 entries
+    # (configs/star_gambit_unified.yaml:5-15,23-24); no CPU baseline leg (the oracle port plays ~1 game/s: nothing finishes in a sample)
+    if not args.no_stargambit:
+        sgb = run_worker(["--game", "stargambit", "--warmup", "1", "--no-secondary", "--preroll-factor", "0.5", "--steps", "100", "--no-cpu-baseline"], 600)
+        head["stargambit"] = trim(sgb)
     head["config"]["bench_wall_s"] = time.perf_counter() - t0
     print(json.dumps(head))
     return 0
@@ -535,6 +542,7 @@ def main():
                         pipe_acc.setdefault("tiles0", pipe_acc.get("tiles_now", 0)); pipe_acc.setdefault("boards0", pipe_acc.get("boards_now", 0))
                         pipe_acc["late"] = max(pipe_acc["late"], st_["tree_latest_start_us"], st_["net_latest_start_us"])
                         pipe_acc["net_wgs"], pipe_acc["tree_wgs"] = st_["net_wgs"], st_["tree_wgs"]
+                        pipe_acc["lost_total"] = st_.get("lost_total", 0)
                     pipe_acc["tiles_now"], pipe_acc["boards_now"] = st_["tiles"], st_["tile_boards"]
                     pipe_acc["tiles"] = pipe_acc["tiles_now"] - pipe_acc.get("tiles0", 0); pipe_acc["boards"] = pipe_acc["boards_now"] - pipe_acc.get("boards0", 0)
                 return
@@ -637,10 +645,19 @@ def main():
     live = live_slots()
     # the one exchange step: the window's samples go to rank 0 over RCCL/xGMI
     gathered_rows = 0
+    gather_kind = None
     if use_dist:
         from alphazero import gather
         parts = [torch.cat([w[i] for w in window_rows], 0) for i in range(3)]
-        res = gather.gather_rows_to_rank0(parts, rank, world)
+        if dry:
+            res = gather.gather_rows_to_rank0(parts, rank, world)      # gloo (CPU rehearsal)
+            gather_kind = "torch.distributed (gloo)"
+        else:
+            # the native exchange behind the C ABI (azmi_gather_rows over librccl: unpadded rows, no torch collective in the data path)
+            ng = gather.NativeGather(rank, world, local_rank)
+            res = ng.gather_rows_to_rank0(parts)
+            torch.cuda.synchronize()
+            gather_kind = "azmi_gather_rows (librccl: ncclAllGather of counts + grouped ncclSend/ncclRecv of unpadded rows)"
         if rank == 0:
             gathered_rows = int(res[0].shape[0])
     barrier()
@@ -720,7 +737,7 @@ def main():
                                  "inference arithmetic: 6.4e-4); the 1e-5 tier is the bf16x3 net (split bf16 operands, 4.3e-7), see tier_1e5") if not tafl else
                                 "bf16 MFMA operands, fp32 accumulation; measured max |delta| vs the reference NNArch fp32 outputs: pi 6.2e-7, v 3.8e-6 (Tawlbwrdd)",
                 "sims_per_s": n_sims / dt, "leaf_evals_per_s": n_evals / dt,
-                "games_in_window": n_games, "samples_in_window": n_rows, "samples_gathered": gathered_rows,
+                "games_in_window": n_games, "samples_in_window": n_rows, "samples_gathered": gathered_rows, "sample_gather": gather_kind,
                 "node_stats": node_stats,
             },
         }
@@ -745,6 +762,14 @@ def main():
             out["config"].update({"tree_kernel_ms": tree_ms, "net_ms": nn_ms})
             if use_pipe:
                 out["config"]["pipeline_errors"] = list(PIPE_ERRORS)      # recovered pipeline errors of this process (normally none)
+                # top-level scalars (a parsed line keeps them): errors met and recovered from in this process, requests
+                # the net side gave up on and the boundary sent again
+                out["pipeline_errors"] = len(PIPE_ERRORS)
+                out["lost_total"] = int(pipe_acc.get("lost_total", 0))
+                # workgroup-time the net side spends per board in the mix: its workgroups x the net kernel's time / boards evaluated
+                # (idle polls included; the same tile alone on the chip: roofline.tiles_alone)
+                if pipe_acc["boards"]:
+                    out["tile_us_per_board"] = pipe_acc.get("net_wgs", 0) * pipe_acc["net_us"] / pipe_acc["boards"]
             if use_pipe:      # the host's share: enqueueing an epoch's launches (it runs ahead of the GPU; one synchronisation per step)
                 out["config"]["host_enqueue_us_per_epoch"] = pipe_acc["host_us"] / launches
             out["roofline"] = {

@@ -441,7 +441,10 @@ int azmi_run_rounds(azmi_pm* const* pms, azmi_net* net, uint32_t k, uint32_t rou
  *      when they are done).  net == NULL: an engine whose seats all use EvalType::RANDOM runs on the tree kernel alone.
  *      A pipeline error (a spin that hit the time cap: another tenant holds the chip, the host stalled between the two launches)
  *      is reported here ONCE and cleared: slots whose requests went unanswered are back in the move step's kSlotQueued form, so
- *      the next call of either driver carries on.  The games are those of azmi_run_rounds for the same seeds.
+ *      the next call of either driver carries on.  The k-th game of a slot is that of azmi_run_rounds for the same seed; with a finite
+ *      games_to_play, WHICH slots receive the last restarts depends on the order in which games end inside an epoch (as the reference's
+ *      workers race for games_started_, play_manager.cc:506-513), so the SET of games is only the same while no game restarts.
+ *      out_stats[14] = the calibration launches of this call | requests given up and sent again since creation << 32.
  *      out_stats (may be NULL): [0] net tiles run since the pipeline was created, [1] boards in them, [2] simulations of the
  *      last epoch, [3] / [4] tree / net workgroups that started in it, [5] its insert-log entries, [6] / [7] net / tree
  *      workgroups launched, [8] / [9] the latest start of a tree / net workgroup after the epoch's first, in microseconds (all
@@ -478,6 +481,25 @@ int azmi_pipeline_supported(azmi_pm* pm, azmi_net* net);
 /* the same loop with one net per MODEL GROUP (gating / benchmark matches between two models, game_runner.py:2184-2332):
  * nets[g] evaluates the leaves of group g, NULL = the group needs no net (RANDOM / PLAYOUT evaluator) */
 int azmi_run_rounds_groups(azmi_pm* const* pms, azmi_net* const* nets, uint32_t num_nets, uint32_t k, uint32_t rounds, void* const* streams);
+
+/* ---- the path's one exchange step: finished self-play samples go to rank 0 over RCCL / xGMI ---------------------------
+ * Replaces the reference's hist_saver (game_runner.py:729-747: one process, a queue) for one process per GPU.  No collective runs
+ * during the search.  librccl is loaded (dlopen) by the first of these calls; a one-GPU process that never gathers does not need it.
+ *   azmi_comm_unique_id  rank 0: the 128 bytes every rank passes to azmi_comm_create (carried there by the launcher's own channel:
+ *                        bench.py broadcasts them with torch.distributed)
+ *   azmi_comm_create     ncclCommInitRank on `device`
+ *   azmi_gather_counts   every rank: its row count in, all ranks' counts out (one ncclAllGather of 8 bytes per rank; synchronises
+ *                        `stream`)
+ *   azmi_gather_rows     every rank: `num_parts` device arrays of counts[rank] rows, row_bytes[i] bytes per row; rank 0 receives them
+ *                        in rank order, unpadded, into dst[i] (device memory for sum(counts) rows; ignored on the other ranks):
+ *                        grouped ncclSend / ncclRecv, its own rows by a device copy.  Asynchronous on `stream`. */
+typedef struct azmi_comm azmi_comm;
+int azmi_comm_unique_id(void* out128);
+int azmi_comm_create(const void* id128, int rank, int world, int device, azmi_comm** out);
+void azmi_comm_destroy(azmi_comm* comm);
+int azmi_gather_counts(azmi_comm* comm, uint64_t n_local, uint64_t* out_counts, void* stream);
+int azmi_gather_rows(azmi_comm* comm, const void* const* src, const uint64_t* row_bytes, uint32_t num_parts, const uint64_t* counts,
+                     void* const* dst, void* stream);
 
 /* The device RNG layer on its own (parity tier "RNG"): runs `thread_local pcg32 re` + the
  * libstdc++ algorithm the reference applies to it (mcts.cc:19,100,430-440,718) on the GPU.

@@ -108,12 +108,29 @@ def test_gating_match_between_two_models():
     assert abs(r.nn_rate - (r.perm_scores[0][0] + r.perm_scores[1][1]) / 64) < 0.05      # both seatings weigh the same
     again = selfplay.gating_match(az.Connect4GS, pp, new, past, engines=2, seed=3, driver="rounds")
     assert again == r                                                               # reproducible
-    # driver="auto" (the default): one engine on the asynchronous pipeline, one net per model group (azmi_run_pipeline_groups); which
-    # slot a restarted game lands in depends on the order the games end in, so the totals are checked, not the very games
-    pipe = selfplay.gating_match(az.Connect4GS, pp, new, past, seed=3)
+    default = selfplay.gating_match(az.Connect4GS, pp, new, past, engines=2, seed=3)
+    assert default == r                                                             # the default driver is the reproducible one
+    # driver="auto": one engine on the asynchronous pipeline, one net per model group (azmi_run_pipeline_groups); which slot a
+    # restarted game lands in depends on the order the games end in, so the totals are checked, not the very games
+    pipe = selfplay.gating_match(az.Connect4GS, pp, new, past, seed=3, driver="auto")
     assert pipe.n_games == 64 and pipe.nn_wins + pipe.past_wins + pipe.n_draws == 64 and pipe.hit_rate > 0
     assert sum(sum(ps) for ps in pipe.perm_scores) == 64 and abs(pipe.nn_rate - r.nn_rate) < 0.35
     with pytest.raises(RuntimeError, match="pipeline"):
         selfplay.gating_match(az.TawlbwrddGS, pp, new, past, driver="pipeline")
     rnd = selfplay.gating_match(az.Connect4GS, pp, new, None, engines=2, seed=3)    # vs RandPlayer: only group 0 reaches a net
     assert rnd.n_games == 64 and rnd.nn_wins + rnd.past_wins + rnd.n_draws == 64
+
+
+def test_native_gather_behind_the_c_abi_world_size_one():
+    """azmi_comm_* / azmi_gather_counts / azmi_gather_rows (csrc/gather.hip over librccl) at world size 1 - what a one-GPU box can run of
+    SURVEY 8e's exchange: the counts all-gather, rank 0's own rows by a device copy, empty and ragged inputs."""
+    import torch
+    from alphazero import gather
+    ng = gather.NativeGather(0, 1, 0)
+    dev = torch.device("cuda", 0)
+    for n in (0, 1, 777):
+        parts = [torch.rand((n, 4, 6, 7), device=dev), torch.rand((n, 3), device=dev), torch.rand((n, 7), device=dev)]
+        out = ng.gather_rows_to_rank0(parts)
+        torch.cuda.synchronize()
+        assert ng.last_counts == [n]
+        assert all(o.shape == p.shape and torch.equal(o, p) for o, p in zip(out, parts))
