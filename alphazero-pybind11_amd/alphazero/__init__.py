@@ -1635,7 +1635,8 @@ def _pipe_stats(out):
     # (slot 14 carries two 32-bit counts: the calibration launches of this call, and the requests the net side has given up on and
     # the boundary has sent again since the engine was created - PipeCtl::lost_total)
     d["lost_total"] = d["calibration_rounds"] >> 32
-    d["calibration_rounds"] &= 0xFFFFFFFF
+    d["freezes"] = (d["calibration_rounds"] >> 8) & 0xFFFFFF      # polling wavefronts that stood still for > 2 ms since creation (credited, not errors)
+    d["calibration_rounds"] &= 0xFF
     return d
 
 

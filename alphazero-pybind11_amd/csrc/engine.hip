@@ -135,18 +135,21 @@ int launch_round(azmi_pm* pm, hipStream_t st, bool defer_moves = false) {
     case AZMI_GAME_TAWLBWRDD:
       launch_pre_round<Tawlbwrdd>(pm, st);
       if (pm->any_playout) k_round_big<Tawlbwrdd, true><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
+      else if (pm->big_split) { k_round_big_sim<Tawlbwrdd><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar); k_round_big_move<Tawlbwrdd><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar); }
       else k_round_big_o2<Tawlbwrdd><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
       if (pm->ep.half_nodes) k_compact<Tawlbwrdd><<<std::min(pm->ep.S * pm->gi.P, kCompactBlocks), 256, 0, st>>>(pm->ep, pm->ar, pm->ep.S * pm->gi.P);
       break;
     case AZMI_GAME_BRANDUBH:
       launch_pre_round<Brandubh>(pm, st);
       if (pm->any_playout) k_round_big<Brandubh, true><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
+      else if (pm->big_split) { k_round_big_sim<Brandubh><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar); k_round_big_move<Brandubh><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar); }
       else k_round_big_o2<Brandubh><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
       if (pm->ep.half_nodes) k_compact<Brandubh><<<std::min(pm->ep.S * pm->gi.P, kCompactBlocks), 256, 0, st>>>(pm->ep, pm->ar, pm->ep.S * pm->gi.P);
       break;
     case AZMI_GAME_OPENTAFL:
       launch_pre_round<OpenTafl>(pm, st);
       if (pm->any_playout) k_round_big<OpenTafl, true><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
+      else if (pm->big_split) { k_round_big_sim<OpenTafl><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar); k_round_big_move<OpenTafl><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar); }
       else k_round_big_o2<OpenTafl><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
       if (pm->ep.half_nodes) k_compact<OpenTafl><<<std::min(pm->ep.S * pm->gi.P, kCompactBlocks), 256, 0, st>>>(pm->ep, pm->ar, pm->ep.S * pm->gi.P);
       break;
@@ -824,6 +827,7 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
   pm->nn_groups = seats.nn_groups;
   pm->any_playout = seats.any_playout;
   pm->split_rounds = game == AZMI_GAME_CONNECT4 && !seats.any_gumbel && !seats.any_playout && getenv("AZMI_NO_SPLIT") == nullptr;
+  pm->big_split = (game == AZMI_GAME_TAWLBWRDD || game == AZMI_GAME_BRANDUBH || game == AZMI_GAME_OPENTAFL) && !seats.any_playout && getenv("AZMI_NO_BIG_SPLIT") == nullptr;
   ep.cpuct = params->cpuct; ep.start_temp = params->start_temp; ep.final_temp = params->final_temp;
   ep.half_life = params->temp_decay_half_life;
   ep.n_half_life_v = 0;

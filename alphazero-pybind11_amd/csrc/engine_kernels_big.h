@@ -1460,13 +1460,30 @@ struct BigSlot {
 };
 
 // One round for every slot of a wide-node game: one wavefront (= one workgroup) per slot.
-template <class GM, bool kPlayout>
+// MODE 0: the whole round.  MODE 1 / 2 (round 5): the round SPLIT like the Connect4 engine's - 1 = every slot, but a
+// slot whose next backup completes a search (the move behind it: temperature, resignation, the history row, re-rooting, the game
+// step, the game's end) or whose game has to start is LISTED (ar.mover_list) and left untouched; 2 = the listed slots alone, the
+// whole round for them, launched right behind (their new leaves join the same round's eval list).  The rare, register-hungry steps
+// no longer size the kernel every slot runs: at two waves per SIMD the Tafl kernel held 256 registers + 71 spilled (288 B of scratch
+// per lane, 72 % of its HBM writes); without make_move / start_game it fits.
+template <class GM, bool kPlayout, int MODE = 0>
 __device__ __forceinline__ void round_big_body(const EngineParams& ep, const EngineArrays& ar, BigScratch<GM>& sm) {
-  const uint32_t slot = blockIdx.x, lane = threadIdx.x;
+  uint32_t slot = blockIdx.x;
+  const uint32_t lane = threadIdx.x;
+  if constexpr (MODE == 2) {
+    if (slot >= ar.ctl->mover_count) return;
+    slot = ar.mover_list[slot];
+  }
   if (slot >= ep.S) return;
   if (ar.ctl->stop) return;
   const uint8_t st = ar.sstate[slot];
   if (st == kSlotDone || st == kSlotEnded) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; return; }
+  if constexpr (MODE == 1) {
+    if (st != kSlotWaitEval) {      // kSlotFresh / kSlotRestart: a game start is the move step's
+      if (lane == 0) { if (ep.cache_on) ar.cache_keys[slot] = 0; ar.mover_list[atomicAdd(&ar.ctl->mover_count, 1u)] = slot; }
+      return;
+    }
+  }
   BigSlot<GM> c(ep, ar, sm, slot, lane);
 #ifdef AZMI_BIG_PROF
   c.pf_t_ = wall_clock64();
@@ -1478,18 +1495,33 @@ __device__ __forceinline__ void round_big_body(const EngineParams& ep, const Eng
   AZB_CMARK(0);
   uint32_t inline_sims = 0, insert_key_set = 0;
   bool need_process = (st == kSlotWaitEval);
-  if (!need_process) {
-    c.start_game(); c.draw_capped(); c.set_gumbel_target();
-    if (ep.gumbel_on && st == kSlotRestart && !ep.tree_reuse) c.set_gumbel_num_sims(c.gs.player, 0);   // see k_round
+  if constexpr (MODE == 2) c.flags &= ~kFlagListed;
+  if constexpr (MODE != 1) {
+    if (!need_process) {
+      c.start_game(); c.draw_capped(); c.set_gumbel_target();
+      if (ep.gumbel_on && st == kSlotRestart && !ep.tree_reuse) c.set_gumbel_num_sims(c.gs.player, 0);   // see k_round
+    }
   }
   for (;;) {
     if (need_process) {
       const uint32_t cp = c.gs.player;
       const bool noise = c.seat_eps(cp) > 0 && !(c.flags & kFlagCapped);
-      c.process_result(cp, (c.flags & kFlagLeafNeedsNet) != 0, noise);
       const uint32_t goal = (c.flags & kFlagCapped) ? c.seat_cap_visits(cp) : c.seat_visits(cp);
-      if (((cp == 0) ? c.t_depth[0] : c.t_depth[GM::P > 1 ? 1 : 0]) >= goal) {
-        if (c.make_move(cp)) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; c.store(kSlotEnded); return; }
+      if constexpr (MODE == 1) {
+        // process_result adds one to the seat's simulation count: this backup completes the search - the slot goes, as it stands
+        // (answers of cache hits of this round already backed up), to the move step
+        if (((cp == 0) ? c.t_depth[0] : c.t_depth[GM::P > 1 ? 1 : 0]) + 1u >= goal) {
+          c.flags |= kFlagListed;
+          if (lane == 0) { if (ep.cache_on) ar.cache_keys[slot] = 0; ar.mover_list[atomicAdd(&ar.ctl->mover_count, 1u)] = slot; }
+          c.store(kSlotWaitEval);
+          return;
+        }
+      }
+      c.process_result(cp, (c.flags & kFlagLeafNeedsNet) != 0, noise);
+      if constexpr (MODE != 1) {
+        if (((cp == 0) ? c.t_depth[0] : c.t_depth[GM::P > 1 ? 1 : 0]) >= goal) {
+          if (c.make_move(cp)) { if (ep.cache_on && lane == 0) ar.cache_keys[slot] = 0; c.store(kSlotEnded); return; }
+        }
       }
     }
     const uint32_t cp = c.gs.player;
@@ -1550,6 +1582,18 @@ template <class GM, bool kPlayout = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_round_big_o2(EngineParams ep, EngineArrays ar) {
   __shared__ BigScratch<GM> sm;
   round_big_body<GM, kPlayout>(ep, ar, sm);
+}
+// The split round (round_big_body MODE 1 / 2): the lean kernel over every slot at two waves per SIMD, then the move step over the
+// slots it listed (one wave per SIMD, the whole register file; a few slots per round: one move per seat_visits simulations)
+template <class GM>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_round_big_sim(EngineParams ep, EngineArrays ar) {
+  __shared__ BigScratch<GM> sm;
+  round_big_body<GM, false, 1>(ep, ar, sm);
+}
+template <class GM>
+__global__ __launch_bounds__(64) void k_round_big_move(EngineParams ep, EngineArrays ar) {
+  __shared__ BigScratch<GM> sm;
+  round_big_body<GM, false, 2>(ep, ar, sm);
 }
 
 // Arena compaction for wide games: copies the subtree under the current root into the idle half of the

@@ -38,6 +38,21 @@ __device__ __forceinline__ void g_st(uint32_t* p, uint32_t v) { __hip_atomic_sto
 
 
 enum : uint32_t { kGrpIdle = 0, kGrpReady = 1, kGrpWait = 2, kGrpPush = 3 };
+// A FREEZE: two looks at the wall clock by one polling wavefront more than 2 ms apart.  No iteration of a polling loop takes that
+// long on its own - the loops load a few words and sleep a microsecond -: the wavefront, and with it the chip, stood still (round 5:
+// the stall-cap error of round 4, one in ~30,000 epochs, was every wavefront of both kernels spanning > 190 ms in ONE iteration - the
+// GPU's own scheduler had switched the process's queues out, profiles/r5_repro_generic.txt).  The time caps are stall detectors for
+// THIS code's protocol, so a freeze is credited: the wavefront's start time moves by the gap, the freeze is counted
+// (PipeCtl::prof[14], longest gap in prof[15]) and reported with the call's statistics, not as an error.
+constexpr uint64_t kFreezeTicks = 200000ull;
+__device__ __forceinline__ void pipe_freeze_credit(PipeCtl* pc, uint64_t now, uint64_t& t_last, uint64_t& t_start, bool leader) {
+  const uint64_t gap = now - t_last;
+  if (gap > kFreezeTicks) {
+    t_start += gap;
+    if (leader) { atomicAdd(&pc->prof[14], 1ull); atomicMax(&pc->prof[15], static_cast<unsigned long long>(gap)); }
+  }
+  t_last = now;
+}
 constexpr uint64_t kMask48 = (1ull << 48) - 1;
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 
@@ -180,7 +195,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
   const EngineArrays& ar = ka.ar;
   const PipeArrays& pa = ka.pa;
   const uint32_t wlane = threadIdx.x & 63u, grp = wlane >> 3, lane = wlane & 7u;
-  const uint64_t t_start = wall_clock64();
+  uint64_t t_start = wall_clock64(), t_last = t_start;      // (t_start moves by what a freeze takes: pipe_freeze_credit)
   PipeCtl* const pc = pa.ctl;
   PipeEpoch* const pe = pa.ep;
   PipeWg* const wc = pa.wg + blockIdx.x;
@@ -248,6 +263,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
         if (w >= thr || w + d >= ep.S) stop_seen = 1u;
       }
       const uint64_t now = wall_clock64();
+      pipe_freeze_credit(pc, now, t_last, t_start, wlane == 0);
       // an epoch that runs long (a cold cache sends every leaf to the net: 16384 slots x 256 simulations take > 200 ms then) simply
       // ends at a quarter of the cap; the cap itself is the stall detector
       if (now - t_start > pa.soft_ticks) stop_seen = 1u;
@@ -733,7 +749,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
   const EngineArrays& ar = ka.ar;
   const PipeArrays& pa = ka.pa;
   const uint32_t wlane = threadIdx.x & 63u, grp = wlane >> 3, lane = wlane & 7u;
-  const uint64_t t_start = wall_clock64();
+  uint64_t t_start = wall_clock64(), t_last = t_start;
   PipeCtl* const pc = pa.ctl;
   PipeEpoch* const pe = pa.ep;
   PipeWg* const wc = pa.wg + blockIdx.x;
@@ -792,6 +808,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
         if (w >= thr || w + d >= ep.S) stop_seen = 1u;
       }
       const uint64_t now = wall_clock64();
+      pipe_freeze_credit(pc, now, t_last, t_start, wlane == 0);
       if (now - t_start > pa.soft_ticks) stop_seen = 1u;
       if (now - t_start > pa.cap_ticks) {
         if (wlane == 0) {
@@ -927,7 +944,7 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
   uint32_t* const xs = reinterpret_cast<uint32_t*>(lds_pipe + TBig::LDS_BYTES);
   static_assert(TBig::LDS_BYTES >= TSmall::LDS_BYTES && (X3 ? 1 : 2) * (TBig::LDS_BYTES + kPipeXs) <= 160 * 1024, "two workgroups per CU (X3: one)");
   const uint32_t tid = threadIdx.x;
-  const uint64_t t_start = wall_clock64();
+  uint64_t t_start = wall_clock64(), t_last = t_start;      // (wave 0's copy moves by what a freeze takes)
   PipeCtl* const pc = pa.ctl;
   PipeEpoch* const pe = pa.ep;
   const uint32_t mg = pa.net_groups == 3u ? (blockIdx.x & 1u) : (pa.net_groups == 2u ? 1u : 0u);      // this workgroup's model group
@@ -996,6 +1013,7 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
         const uint32_t hm = static_cast<uint32_t>(__ballot(here)) & 0xFFu;
         const uint32_t k = static_cast<uint32_t>(__builtin_ctz(~hm));          // arrived prefix of the window's rest
         const uint64_t now = wall_clock64();
+        pipe_freeze_credit(pc, now, t_last, t_start, tid == 0);
         if (k == left) { n = k; break; }
         if (k != 0u) {
           if (t_first == 0) t_first = now;
@@ -1267,12 +1285,18 @@ struct PipeState {
   uint32_t* cv_xh = nullptr; uint8_t* cv_xt = nullptr; uint8_t* cv_xs = nullptr; uint32_t* cv_meta = nullptr; unsigned long long* cv_stat = nullptr;
   bool cv_calibrated = false;
   const void* l0_nets[2] = {nullptr, nullptr};      // the weight images the answer table's entries were computed with (group 0, group 1)
+  // CU split (AZMI_PIPE_CU_SPLIT=T): the tree kernel on a stream masked to T CUs, the net kernel on the others
+  uint32_t cu_split = 0, cu_total = 0;
+  hipStream_t tree_stream = nullptr;
+  hipEvent_t ev_tree = nullptr;
 };
 void pipe_state_free(PipeState* p) {
   if (!p) return;
   for (void* q : p->allocs) (void)hipFree(q);
   if (p->net_stream) (void)hipStreamDestroy(p->net_stream);
   if (p->svc_stream) (void)hipStreamDestroy(p->svc_stream);
+  if (p->tree_stream) (void)hipStreamDestroy(p->tree_stream);
+  if (p->ev_tree) (void)hipEventDestroy(p->ev_tree);
   if (p->ev_svc) (void)hipEventDestroy(p->ev_svc);
   for (hipStream_t q : p->parked) (void)hipStreamDestroy(q);
   if (p->ev_go) (void)hipEventDestroy(p->ev_go);
@@ -1319,6 +1343,18 @@ struct PipePlan {
   azmi_net_c4_view view[2]{};         // view[g] of group g's net (view[1] = view[0] when group 1 has none)
 };
 int pipe_size_net(azmi_pm* pm, PipeState* ps, const azmi_net_c4_view& view);
+
+// a stream for one side of the pipeline: plain, or - with the CU split on - masked to the side's CUs (bit i of the mask = CU i as the
+// runtime numbers them; which physical CUs those are is nothing this code assumes: the two masks are disjoint, the census measures
+// what fits)
+int pipe_make_stream(PipeState* ps, hipStream_t* out, bool tree_side) {
+  if (ps->cu_split == 0u) { AZMI_HIP_TRY(hipStreamCreateWithFlags(out, hipStreamNonBlocking)); return AZMI_OK; }
+  std::vector<uint32_t> mask((ps->cu_total + 31u) / 32u, 0u);
+  for (uint32_t cu = 0; cu < ps->cu_total; ++cu)
+    if ((cu < ps->cu_split) == tree_side) mask[cu / 32u] |= 1u << (cu % 32u);
+  AZMI_HIP_TRY(hipExtStreamCreateWithCUMask(out, static_cast<uint32_t>(mask.size()), mask.data()));
+  return AZMI_OK;
+}
 
 uint32_t pipe_tree_wgs_for(uint32_t S) {
   // tree workgroups: a slot lives in ONE workgroup for an epoch (its home), so a workgroup's 32 lane-groups serve S / workgroups
@@ -1377,7 +1413,20 @@ int pipe_create(azmi_pm* pm, size_t tile_lds) {
   pa.big_at = getenv("AZMI_PIPE_BIG_AT") ? static_cast<uint32_t>(std::max(0, atoi(getenv("AZMI_PIPE_BIG_AT")))) : 96u;      // (same-box A/B at 4096 slots: 48 -> 100.0, 96 / 128 / 192 -> 102.4 M simulations/s; 16384 slots: no difference)
   pa.take_wait = getenv("AZMI_PIPE_TAKE_WAIT") ? static_cast<uint32_t>(std::max(0, atoi(getenv("AZMI_PIPE_TAKE_WAIT")))) : 0u;
   (void)tile_lds;
-  AZMI_HIP_TRY(hipStreamCreateWithFlags(&ps->net_stream, hipStreamNonBlocking));
+  if (const char* e = getenv("AZMI_PIPE_CU_SPLIT")) {
+    hipDeviceProp_t prop;
+    AZMI_HIP_TRY(hipGetDeviceProperties(&prop, pm->device));
+    ps->cu_total = static_cast<uint32_t>(prop.multiProcessorCount);
+    ps->cu_split = static_cast<uint32_t>(std::max(0, std::min(atoi(e), static_cast<int>(ps->cu_total) - 1)));
+    if (ps->cu_split) {
+      { const int rc2 = pipe_make_stream(ps, &ps->tree_stream, true); if (rc2 != AZMI_OK) return rc2; }
+      AZMI_HIP_TRY(hipEventCreateWithFlags(&ps->ev_tree, hipEventDisableTiming));
+      // two tree workgroups per CU (256 registers x 4 wavefronts each)
+      if (!getenv("AZMI_PIPE_TREE_WGS")) { ps->tree_wgs = ps->tree_wgs_default = std::min(ps->tree_wgs_alloc, 2u * ps->cu_split); pa.n_tree_wgs = ps->tree_wgs; }
+      ps->balance = false;
+    }
+  }
+  { const int rc2 = pipe_make_stream(ps, &ps->net_stream, false); if (rc2 != AZMI_OK) return rc2; }
   AZMI_HIP_TRY(hipEventCreateWithFlags(&ps->ev_go, hipEventDisableTiming));
   AZMI_HIP_TRY(hipEventCreateWithFlags(&ps->ev_net, hipEventDisableTiming));
   guard.p = nullptr;
@@ -1400,7 +1449,7 @@ int pipe_size_net(azmi_pm* pm, PipeState* ps, const azmi_net_c4_view& view) {
   AZMI_HIP_TRY(hipGetDeviceProperties(&prop, pm->device));
   int per_cu = 0;
   AZMI_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(pipe_net_fn(0, x3)), 256, ps->lds_bytes));
-  uint32_t net = static_cast<uint32_t>(std::max(1, per_cu)) * static_cast<uint32_t>(prop.multiProcessorCount);
+  uint32_t net = static_cast<uint32_t>(std::max(1, per_cu)) * (static_cast<uint32_t>(prop.multiProcessorCount) - ps->cu_split);
   if (const char* e = getenv("AZMI_PIPE_NET_WGS")) net = static_cast<uint32_t>(atoi(e));
   ps->net_wgs = std::max<uint32_t>(1u, net);
   ps->calibrated = false;
@@ -1441,7 +1490,7 @@ int pipe_pair_streams(PipeState* ps, hipStream_t st) {
     if (h[1] == 0u) { ps->paired = true; ps->paired_with = st; return AZMI_OK; }
     ps->parked.push_back(ps->net_stream);          // shares st's hardware queue
     ps->net_stream = nullptr;
-    AZMI_HIP_TRY(hipStreamCreateWithFlags(&ps->net_stream, hipStreamNonBlocking));
+    { const int rc2 = pipe_make_stream(ps, &ps->net_stream, false); if (rc2 != AZMI_OK) return rc2; }
   }
   return azmi_host_fail(AZMI_ERR_STATE, "azmi_run_pipeline: no second stream runs beside the caller's (one hardware queue? GPU_MAX_HW_QUEUES); "
                         "the pipeline needs its tree and net kernels on the chip together - use azmi_run_rounds");
@@ -1579,11 +1628,10 @@ int pipe_calibrate(azmi_pm* pm, PipeState* ps, hipStream_t st, const azmi_net_c4
     AZMI_HIP_TRY(hipMemsetAsync(pa.ep, 0, sizeof(PipeEpoch), st));
     AZMI_HIP_TRY(hipEventRecord(ps->ev_go, st));
     AZMI_HIP_TRY(hipStreamWaitEvent(ps->net_stream, ps->ev_go, 0));
-    if (ps->kind == 2) k_pipe_tree_generic<Connect4, 256><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
-    else if (pm->ep.gumbel_on) k_pipe_tree<Connect4, 256, false, true, true><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
-    else if (pa.n_groups > 1u) k_pipe_tree<Connect4, 256, false, true><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
-    else k_pipe_tree<Connect4, 256, false><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
+    if (ps->tree_stream) AZMI_HIP_TRY(hipStreamWaitEvent(ps->tree_stream, ps->ev_go, 0));
+    pipe_launch_tree(pm, ps, pa, ps->tree_stream ? ps->tree_stream : st, false);
     AZMI_HIP_TRY(hipGetLastError());
+    if (ps->tree_stream) { AZMI_HIP_TRY(hipEventRecord(ps->ev_tree, ps->tree_stream)); AZMI_HIP_TRY(hipStreamWaitEvent(st, ps->ev_tree, 0)); }
     { const int rc = pipe_launch_net(ps, view, 0, ps->net_wgs, ps->net_stream, pa); if (rc != AZMI_OK) return rc; }
     AZMI_HIP_TRY(hipEventRecord(ps->ev_net, ps->net_stream));
     AZMI_HIP_TRY(hipStreamWaitEvent(st, ps->ev_net, 0));
@@ -1852,14 +1900,14 @@ static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_ne
       AZMI_HIP_TRY(hipGetLastError());
     }
     // the tree kernel goes first: its workgroups take their places per shader engine, the net kernel is sized for what is left
-    AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 2], st));
-    if (plan.kind == 2) k_pipe_tree_generic<Connect4, 256><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
-    else if (pm->ep.gumbel_on) k_pipe_tree<Connect4, 256, false, true, true><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
-    else if (pa.n_groups > 1u) k_pipe_tree<Connect4, 256, false, true><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
-    else if (prof) k_pipe_tree<Connect4, 256, true><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
-    else k_pipe_tree<Connect4, 256, false><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
+    // (CU split: on its own stream, masked to the tree side's CUs; the caller's stream waits for it)
+    hipStream_t ts = ps->tree_stream && !tree_only ? ps->tree_stream : st;
+    if (ts != st) AZMI_HIP_TRY(hipStreamWaitEvent(ts, ps->ev_go, 0));
+    AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 2], ts));
+    pipe_launch_tree(pm, ps, pa, ts, prof);
     AZMI_HIP_TRY(hipGetLastError());
-    AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 3], st));
+    AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 3], ts));
+    if (ts != st) { AZMI_HIP_TRY(hipEventRecord(ps->ev_tree, ts)); AZMI_HIP_TRY(hipStreamWaitEvent(st, ps->ev_tree, 0)); }
     if (pm->ep.cache_on) {      // behind the tree kernel, beside the net side's last tiles
       k_pipe_cache_insert<<<2048, 256, 0, st>>>(pm->ar, pa, 0u);
       AZMI_HIP_TRY(hipGetLastError());
@@ -1922,7 +1970,7 @@ static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_ne
       if (!tree_only && hipEventElapsedTime(&ms, ps->tev[4 * e + 0], ps->tev[4 * e + 1]) == hipSuccess) net_us += 1e3 * ms;
       if (hipEventElapsedTime(&ms, ps->tev[4 * e + 2], ps->tev[4 * e + 3]) == hipSuccess) tree_us += 1e3 * ms;
     }
-    out_stats[10] = static_cast<uint64_t>(net_us); out_stats[11] = static_cast<uint64_t>(tree_us); out_stats[12] = epochs; out_stats[13] = host_enqueue_us; out_stats[14] = static_cast<uint64_t>(ps->calib_rounds) | (static_cast<uint64_t>(hc.lost_total) << 32); out_stats[15] = hc.l0_hits;
+    out_stats[10] = static_cast<uint64_t>(net_us); out_stats[11] = static_cast<uint64_t>(tree_us); out_stats[12] = epochs; out_stats[13] = host_enqueue_us; out_stats[14] = static_cast<uint64_t>(ps->calib_rounds & 0xFFu) | (static_cast<uint64_t>(std::min<unsigned long long>(hc.prof[14], 0xFFFFFFull)) << 8) | (static_cast<uint64_t>(hc.lost_total) << 32); out_stats[15] = hc.l0_hits;
     if (getenv("AZMI_PIPE_PROF")) {
       fprintf(stderr, "pipe prof:");
       for (int i = 0; i < 16; ++i) fprintf(stderr, " %llu", hc.prof[i]);

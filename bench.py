@@ -542,7 +542,7 @@ def main():
                         pipe_acc.setdefault("tiles0", pipe_acc.get("tiles_now", 0)); pipe_acc.setdefault("boards0", pipe_acc.get("boards_now", 0))
                         pipe_acc["late"] = max(pipe_acc["late"], st_["tree_latest_start_us"], st_["net_latest_start_us"])
                         pipe_acc["net_wgs"], pipe_acc["tree_wgs"] = st_["net_wgs"], st_["tree_wgs"]
-                        pipe_acc["lost_total"] = st_.get("lost_total", 0)
+                        pipe_acc["lost_total"] = st_.get("lost_total", 0); pipe_acc["freezes"] = st_.get("freezes", 0)
                     pipe_acc["tiles_now"], pipe_acc["boards_now"] = st_["tiles"], st_["tile_boards"]
                     pipe_acc["tiles"] = pipe_acc["tiles_now"] - pipe_acc.get("tiles0", 0); pipe_acc["boards"] = pipe_acc["boards_now"] - pipe_acc.get("boards0", 0)
                 return
@@ -766,6 +766,7 @@ def main():
                 # the net side gave up on and the boundary sent again
                 out["pipeline_errors"] = len(PIPE_ERRORS)
                 out["lost_total"] = int(pipe_acc.get("lost_total", 0))
+                out["pipeline_freezes"] = int(pipe_acc.get("freezes", 0))      # polling wavefronts that stood still > 2 ms (the GPU's scheduler; credited, not errors)
                 # workgroup-time the net side spends per board in the mix: its workgroups x the net kernel's time / boards evaluated
                 # (idle polls included; the same tile alone on the chip: roofline.tiles_alone)
                 if pipe_acc["boards"]:

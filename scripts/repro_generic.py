@@ -18,13 +18,15 @@ for it in range(N):
     pm = az.PlayManager(az.Connect4GS(), pp, seed=949 + it, log_moves=True)
     st = torch.cuda.Stream()
     n = 0
+    stats = None
     try:
         while pm.remaining_games() > 0 and n < 4000:
-            az.run_pipeline_groups(pm, [net], 4, S * 16, st.cuda_stream); n += 1
+            stats = az.run_pipeline_groups(pm, [net], 4, S * 16, st.cuda_stream); n += 1
             if pm.poll(st.cuda_stream)[1] == 0: break
     except RuntimeError as e:
         print("iteration %d call %d: %s" % (it, n, str(e)[:900]), flush=True)
         break
     torch.cuda.synchronize()
-    if it % 10 == 0: print("iteration", it, "ok", pm.games_completed(), flush=True)
+    if stats and stats.get("freezes"): print("iteration %d: %d freeze(s) credited (wavefronts that stood still > 2 ms), %d calls, no error" % (it, stats["freezes"], n), flush=True)
+    if it % 50 == 0: print("iteration", it, "ok", pm.games_completed(), flush=True)
 print("done")

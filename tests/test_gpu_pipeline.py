@@ -258,9 +258,10 @@ def test_generic_tree_kernel_plays_the_same_games(monkeypatch, shape):
         pp.seat_gumbel_enabled = [[1, 0], [0, 0]]
     pa, la, _ = _groups_pipeline_games(az, pp, seed, nets, S * 16)
     monkeypatch.setenv("AZMI_PIPE_GENERIC", "1")
-    # (round 4: this kernel met a stall-cap error once in ~3000 calls - cause not found, the kernel prints what it waited for; the
-    # error is recoverable by contract, and the games are compared all the same)
-    pb, lb, stats = _groups_pipeline_games(az, pp, seed, nets, S * 16, recovered_errors=2)
+    # (round 4 met a stall-cap error here once in ~3000 calls and tolerated it; round 5 found it - every wavefront of both kernels stood
+    # still for ~200 ms inside ONE poll: the GPU's scheduler, not the protocol - and credits such freezes against the caps
+    # (pipe_freeze_credit, profiles/r5_repro_generic.txt): the test is strict again)
+    pb, lb, stats = _groups_pipeline_games(az, pp, seed, nets, S * 16)
     monkeypatch.delenv("AZMI_PIPE_GENERIC")
     _same_games(pa, la, pb, lb, S)
     pc, lc = _groups_lockstep_games(az, pp, seed, nets)
