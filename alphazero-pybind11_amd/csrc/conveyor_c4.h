@@ -451,7 +451,7 @@ __device__ __forceinline__ void conv_wave(const CvArgs& a, uint8_t* const lds, c
       if (e) { end = static_cast<int32_t>(p - k) <= 0; break; }
       if ((spins & 63u) == 63u) {
         if (uni(ld_sc1(a.err)) != 0u) { failed = true; break; }
-        if (wall100() - t_start > a.cap_ticks + a.cap_ticks / 2u) { atomicOr(a.err, 64u); st_sc1(a.stop, 1u); failed = true; break; }
+        if (wall100() - t_start > 8u * a.cap_ticks) { atomicOr(a.err, 64u); st_sc1(a.stop, 1u); failed = true; break; }
       }
       __builtin_amdgcn_s_sleep(kSpinSleep);
     }
@@ -482,7 +482,7 @@ __device__ __forceinline__ void conv_wave(const CvArgs& a, uint8_t* const lds, c
     for (uint32_t spins = 0; !space_for(k, true); ++spins) {
       if ((spins & 63u) == 63u) {
         if (uni(ld_sc1(a.err)) != 0u) { failed = true; break; }
-        if (wall100() - t_start > a.cap_ticks + a.cap_ticks / 2u) { atomicOr(a.err, 64u); st_sc1(a.stop, 1u); failed = true; break; }
+        if (wall100() - t_start > 8u * a.cap_ticks) { atomicOr(a.err, 64u); st_sc1(a.stop, 1u); failed = true; break; }
       }
       __builtin_amdgcn_s_sleep(kSpinSleep);
     }
@@ -640,7 +640,7 @@ __device__ __forceinline__ void stem_wave(const CvArgs& a, const SvcPipe& sp, ui
             if (static_cast<int32_t>(t2 - (w0 + wdone)) <= 0) over = 1;
             else if (++final_looks >= 2u) stale = 1;
           }
-          if (!over && now - t_start > a.cap_ticks + a.cap_ticks / 4 && (ld_sc1(sp.tree_arrived) != 0u || now - t_start > 4u * a.cap_ticks)) {
+          if (!over && now - t_start > 8u * a.cap_ticks) {
             if (atomicAdd(&sp.dbg[7], 1u) == 0u) {
               sp.dbg[8] = ld_sc1(sp.stop); sp.dbg[9] = ld_sc1(sp.tree_done); sp.dbg[10] = ld_sc1(sp.tree_arrived);
               sp.dbg[11] = ld_sc1(sp.tail); sp.dbg[12] = w0 + wdone; sp.dbg[13] = static_cast<uint32_t>((now - t_start) / 1000u);
@@ -681,7 +681,7 @@ __device__ __forceinline__ void stem_wave(const CvArgs& a, const SvcPipe& sp, ui
       if (static_cast<int32_t>(k + GT - c) <= XNT) break;
       if ((spins & 63u) == 63u) {
         if (uni(ld_sc1(a.err)) != 0u) { failed = true; break; }
-        if (wall100() - t_start > a.cap_ticks + a.cap_ticks / 2u) { atomicOr(a.err, 64u); st_sc1(sp.stop, 1u); failed = true; break; }
+        if (wall100() - t_start > 8u * a.cap_ticks) { atomicOr(a.err, 64u); st_sc1(sp.stop, 1u); failed = true; break; }
       }
       __builtin_amdgcn_s_sleep(kSpinSleep);
     }
@@ -815,7 +815,7 @@ __device__ __forceinline__ void head_wave(const CvArgs& a, const SvcPipe& sp, ui
         if (uni(ld_sc1(xh + XH_END)) != 0u && uni(ld_sc1(xh + XH_PROD)) == pr) { over = true; break; }
         if ((spins & 63u) == 63u) {
           if (uni(ld_sc1(a.err)) != 0u) { failed = true; break; }
-          if (wall100() - t_start > a.cap_ticks + a.cap_ticks / 2u) { atomicOr(a.err, 64u); st_sc1(sp.stop, 1u); failed = true; break; }
+          if (wall100() - t_start > 8u * a.cap_ticks) { atomicOr(a.err, 64u); st_sc1(sp.stop, 1u); failed = true; break; }
         }
         __builtin_amdgcn_s_sleep(kSpinSleep);
       }

@@ -1042,7 +1042,10 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
           // the stall detector: cap x 1.25 once the tree side is there; while no tree workgroup has started yet (the host was held up
           // between the two launches, the tree kernel waits for a place) four caps - long enough for any scheduling hiccup, short
           // enough that a launch that never comes is an error and not a hang
-          if (!over && now - t_start > pa.cap_ticks + pa.cap_ticks / 4 && (g_ld(&pe->tree_arrived) != 0u || now - t_start > 4u * pa.cap_ticks)) {
+          // (round 5: EIGHT caps.  The cap is the tree side's stall detector; the net side only waits for the tree side, and the GPU's
+          // scheduler was seen to switch the tree kernel's queue out for > 300 ms while this kernel kept running
+          // (profiles/r5_repro_generic.txt: the tree wavefronts credit such a freeze and finish normally, this side must outwait it))
+          if (!over && now - t_start > 8u * pa.cap_ticks) {
             // (what the stalled workgroup saw, for the error message: dbg[8..14) = stop, tree workgroups done / arrived, ring tail,
             // the window position it waits at, 10 us units since its start)
             if (atomicAdd(&pc->dbg[7], 1u) == 0u) {
@@ -2003,10 +2006,12 @@ static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_ne
     return azmi_host_fail(AZMI_ERR_STATE, "pipeline error mask 0x%x (1 a spin hit the epoch's time cap, 2 a ring entry never arrived, 4 a result tag "
                           "did not match, 8 insert log full, 16 cache lock, 32 slots, 64 the net side hit the time cap); census: %u of %u tree and %u of %u net workgroups started; "
                           "last epoch: head %u tail %u sims %llu ended %u dead %u stop %u tree_done %u tiles %llu boards %llu; latest tree / net workgroup start %u / %u us; "
-                          "first time-out saw: slot %u seq %u / %u; net side: stop %u tree done %u of %u tail %u window at %u after %u0 us",
+                          "first time-out saw: slot %u seq %u / %u; net side: stop %u tree done %u of %u tail %u window at %u after %u0 us; "
+                          "wavefronts that stood still > 2 ms (not one instruction between two looks at the clock) so far: %llu, the longest for %.1f ms",
                           hc.err, he.tree_arrived, ps->tree_wgs, he.net_arrived, ps->net_wgs, hc.head, hc.tail, he.sims, he.ended, he.dead, he.stop,
                           he.tree_done, hc.tiles, hc.tile_boards, he.tree_late / 100u, he.net_late / 100u,
-                          hc.dbg[1], hc.dbg[2], hc.dbg[3], hc.dbg[8], hc.dbg[9], hc.dbg[10], hc.dbg[11], hc.dbg[12], hc.dbg[13]);
+                          hc.dbg[1], hc.dbg[2], hc.dbg[3], hc.dbg[8], hc.dbg[9], hc.dbg[10], hc.dbg[11], hc.dbg[12], hc.dbg[13],
+                          static_cast<unsigned long long>(hc.prof[14]), static_cast<double>(hc.prof[15]) * 1e-5);
   if (hc.err && getenv("AZMI_PIPE_DEBUG")) {
     fprintf(stderr, "pipeline dbg:");
     for (int i = 0; i < 18; ++i) fprintf(stderr, " %u", hc.dbg[i]);

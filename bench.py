@@ -822,10 +822,10 @@ def main():
                     "note": "latency-bound, not bandwidth-bound: one simulation is a chain of dependent memory round trips; "
                             "the figure to watch is the per-launch time (profiles/)"}
             # HBM-side traffic: not measurable from inside the process; taken from the committed rocprofv3 --pmc summaries of THIS
-            # round (profiles/r4_*: every row carries the commit it was collected at; a file of another round is not read), per
+            # round (profiles/r5_*: every row carries the commit it was collected at; a file of another round is not read), per
             # launch, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on gfx950 (the tree
             # kernel's 32-byte record reads are calibrated instead: FETCH_SIZE = TCC_EA0_RDREQ x 64 B there, profiles/r4_pmc_tree.csv)
-            RND = "r4"
+            RND = "r5"
             suffix = "_stargambit" if sg else "_tawlbwrdd" if tafl else ""
             pmc_net = os.path.join(ROOT, "profiles", f"{RND}_pmc_traffic{suffix}.csv")
             pmc_tree = os.path.join(ROOT, "profiles", f"{RND}_pmc_tree.csv")

@@ -1,10 +1,10 @@
 #!/bin/bash
 # average duration of a net tile INSIDE the pipeline (beside the tree kernel): prof[8] = ticks the net workgroups spent in tiles, prof[7] = ticks waiting
 cd "$(dirname "$0")/.."
-AZMI_PIPE_PROF=1 CACHE=128000000 BLOCKS=6 E=100 timeout -k 10 300 python scripts/pipe_bench.py > gpurun_out/r4_tile_in_mix.txt 2>&1
-python - <<'PY' >> gpurun_out/r4_tile_in_mix.txt
+AZMI_PIPE_PROF=1 CACHE=128000000 BLOCKS=6 E=100 timeout -k 10 300 python scripts/pipe_bench.py > gpurun_out/r5_tile_in_mix.txt 2>&1
+python - <<'PY' >> gpurun_out/r5_tile_in_mix.txt
 import re
-L = open('gpurun_out/r4_tile_in_mix.txt').read().splitlines()
+L = open('gpurun_out/r5_tile_in_mix.txt').read().splitlines()
 prof = [list(map(int, l.split(':')[1].split())) for l in L if l.startswith('pipe prof:')]
 print('calls with prof lines:', len(prof))
 a, b = prof[-4], prof[-1]
