@@ -186,15 +186,18 @@ __device__ __attribute__((noinline)) uint32_t pipe_move_groups(const EngineParam
 // gumbel_next_root_child) and - gumbel_full - at interior nodes (gumbel_interior_select): both are SlotCtx's own functions, called
 // from the descent below; the Gumbel state of a search (g, survivors, phase) is initialised by the move step's first descent
 // (find_leaf's lazy init), so a search whose state is not there yet is handed to the move step.  Built with TWO.
+#ifndef AZMI_TREE_MINB
+#define AZMI_TREE_MINB 2          // workgroups of k_pipe_tree per CU the register budget is set for (experiment builds: 3, 4)
+#endif
 template <class GM, int NT, bool PROF, bool TWO = false, bool GUM = false>
-__global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
+__global__ __launch_bounds__(NT, AZMI_TREE_MINB) void k_pipe_tree(PipeKernArgs ka) {
   constexpr int G = GM::GROUP;
   constexpr int P = GM::P;
   static_assert(P == 2 && G == 8 && GM::M == 7, "written for Connect4's 8-lane groups");
   const EngineParams& ep = ka.ep;
   const EngineArrays& ar = ka.ar;
   const PipeArrays& pa = ka.pa;
-  const uint32_t wlane = threadIdx.x & 63u, grp = wlane >> 3, lane = wlane & 7u;
+  const uint32_t wlane = threadIdx.x & 63u, grp = wlane >> 3, lane0 = wlane & 7u;
   uint64_t t_start = wall_clock64(), t_last = t_start;      // (t_start moves by what a freeze takes: pipe_freeze_credit)
   PipeCtl* const pc = pa.ctl;
   PipeEpoch* const pe = pa.ep;
@@ -230,10 +233,15 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree(PipeKernArgs ka) {
   __syncthreads();
   uint64_t pf_pass = 0, pf_idle = 0, pf_n = 0, pf_act = 0, pf_polls = 0, pf_io = 0, pf_lvls = 0, pf_mv = 0;
   uint64_t pf_ph[5] = {0, 0, 0, 0, 0};     // per group (lane 0 counts): ticks in backup / descent / expansion / probe, simulations
-  SlotCtx<GM> c(ep, ar, 0u, lane);
+  SlotCtx<GM> c(ep, ar, 0u, lane0);
 
   while (go) {
     const uint64_t pf_t0 = PROF ? wall_clock64() : 0;
+    // (the lane number, opaque per pass: per-lane addresses - base + lane x stride of a dozen arrays - are then computed where they
+    // are used instead of being hoisted out of the epoch's loop into 64-bit registers that live for ever, and spill)
+    uint32_t lane = lane0;
+    asm volatile("" : "+v"(lane));
+    c.lane = lane;
     // ---- tokens for this pass: the arrived prefix of the eight ring positions at the head
     uint32_t my_slot = kNoSlot, tok_seq = 0, tok_move = 0, n_tok = 0, empty_polls = 0, ctl_word = 0;
     uint64_t t_seen = 0;
