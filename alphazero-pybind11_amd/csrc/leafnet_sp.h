@@ -76,10 +76,13 @@ struct Geo {
   static_assert(NT * 16 * 32 * 4 <= ACT_BYTES, "pooling scratch fits the activation planes");
   static_assert(NPIX * 32 * 4 <= RING_BYTES, "policy logits fit the ring");
 };
-using Geo11 = Geo<11, 11, 2, 4>;
+#ifndef AZMI_SP11_TBW
+#define AZMI_SP11_TBW 2        // boards per 11 x 11 tile (experiment builds: 1 - half the tile latency, two n-tiles per wave)
+#endif
+using Geo11 = Geo<11, 11, AZMI_SP11_TBW, 2 * AZMI_SP11_TBW>;
 using Geo7 = Geo<7, 7, 5, 4>;
 using Geo13 = Geo<13, 13, 1, 3>;
-using Geo11X3 = Geo<11, 11, 2, 4, 1>;
+using Geo11X3 = Geo<11, 11, AZMI_SP11_TBW, 2 * AZMI_SP11_TBW, 1>;
 using Geo7X3 = Geo<7, 7, 5, 4, 1>;
 using Geo13X3 = Geo<13, 13, 1, 3, 1>;
 
@@ -316,7 +319,7 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
       if (ks + 1 < NKS) {
         // issue order inside the k-step: MFMAs and one A fragment of the next k-step (x4: its first MFMAs need all four),
         // then MFMAs, the address arithmetic and the read of one B fragment (x NTW)
-        constexpr int MF_A = 2, MF_B = (NTW * MT - 4 * MF_A) / NTW;
+        constexpr int MF_A = NTW * MT >= 12 ? 2 : 1, MF_B = (NTW * MT - 4 * MF_A) / NTW;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, MF_A, 0);

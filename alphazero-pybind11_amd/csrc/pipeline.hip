@@ -951,7 +951,7 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
   // [24..30) player, then as u64: [0..6) stones of player 0, [8..14) stones of player 1
   uint32_t* const xs = reinterpret_cast<uint32_t*>(lds_pipe + TBig::LDS_BYTES);
   static_assert(TBig::LDS_BYTES >= TSmall::LDS_BYTES && (X3 ? 1 : 2) * (TBig::LDS_BYTES + kPipeXs) <= 160 * 1024, "two workgroups per CU (X3: one)");
-  const uint32_t tid = threadIdx.x;
+  const uint32_t tid0 = threadIdx.x;
   uint64_t t_start = wall_clock64(), t_last = t_start;      // (wave 0's copy moves by what a freeze takes)
   PipeCtl* const pc = pa.ctl;
   PipeEpoch* const pe = pa.ep;
@@ -959,7 +959,7 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
   uint32_t* const q_head = pipe_head_of(pc, mg);
   uint32_t* const q_tail = pipe_tail_of(pc, mg);
   const unsigned long long* const q_ring = pipe_ring_of(pa, mg);
-  if (tid == 0) {
+  if (tid0 == 0) {
     unsigned long long t0 = atomicCAS(&pe->t0, 0ull, static_cast<unsigned long long>(t_start));
     if (t0 == 0ull) t0 = t_start;
     atomicMax(&pe->net_late, static_cast<uint32_t>(t_start > t0 ? t_start - t0 : 0ull));
@@ -980,6 +980,8 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
   uint32_t w0 = 0, wn = 0, wdone = 0;        // window start, size, positions served (wave 0 keeps them; uniform)
   uint64_t pf_wait = 0, pf_tile = 0, pf_mark = wall_clock64();
   for (;;) {
+    uint32_t tid = tid0;      // (opaque per tile, as k_pipe_tree's lane number: per-thread addresses are not hoisted out of the epoch's loop)
+    asm volatile("" : "+v"(tid));
     __syncthreads();
     { const uint64_t nowp = wall_clock64(); pf_tile += nowp - pf_mark; pf_mark = nowp; }
     if (tid < 64) {        // wave 0 runs the claim; lanes 0..7 look at one ring entry each
@@ -1118,7 +1120,7 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
       pipe_push_token(pa, home, pos, static_cast<unsigned long long>(sl) | (static_cast<unsigned long long>(xs[16 + tid]) << 16));
     }
   }
-  if (tid == 0) { atomicAdd(&pc->prof[7], pf_wait); atomicAdd(&pc->prof[8], pf_tile); }
+  if (tid0 == 0) { atomicAdd(&pc->prof[7], pf_wait); atomicAdd(&pc->prof[8], pf_tile); }
 }
 
 // (the net kernel's time accounting is added by its thread 0 when it leaves)
