@@ -62,9 +62,10 @@ struct PipeCtl {          // zeroed when the pipeline is created; lives across e
   uint32_t tail; uint32_t pad1[31];             // ring tickets handed out to tree wavefronts (free-running)
   uint32_t head1; uint32_t pad4[31];            // the same two words for the request ring of model group 1 (the generic tree kernel
   uint32_t tail1; uint32_t pad5[31];            // routes a leaf to the ring of its seat's group: one net per group, play_past)
-  uint32_t pad6[32], pad7[32];                  // (round 3: the chip-wide READY / MOVE ring positions; now per workgroup, PipeWg)
-  uint32_t err;           // PipeErr bits, sticky: every pipeline kernel leaves at once when it is set
-  uint32_t pad2;
+  uint32_t err;           // PipeErr bits, sticky: every pipeline kernel leaves at once when it is set.  Polled by every waiting
+  uint32_t pad6[31];      // workgroup: a line of its own (round 5; it shared the line of the tile counters below)
+  uint32_t pad7[32];
+  uint32_t pad2a, pad2;
   unsigned long long tiles;         // net tiles run
   unsigned long long tile_boards;   // boards in them
   unsigned long long epochs;
@@ -79,25 +80,29 @@ struct PipeCtl {          // zeroed when the pipeline is created; lives across e
 };
 static_assert(sizeof(PipeCtl) == 1024, "eight lines");
 
-struct PipeEpoch {        // an allocation of its own, zeroed before every epoch (one memset)
-  unsigned long long sims; uint32_t pad0[30];   // simulations finished in this epoch
+struct PipeEpoch {        // an allocation of its own, zeroed before every epoch (one memset); three 128-byte lines by who touches them
+  unsigned long long sims; uint32_t pad0[30];   // simulations finished in this epoch (tree wavefronts add, their idle polls read)
+  // ---- line 1: words the net workgroups POLL while they wait (written a few times per epoch)
   unsigned long long t0;  // wall clock of the epoch's first workgroup
   uint32_t stop;          // the epoch is over: quota reached, enough slots wait for the move step, time cap passed, or an error
   uint32_t tree_done;     // tree workgroups that have stored their slots and left
   uint32_t tree_arrived, net_arrived;   // census: workgroups that started
+  uint32_t tree_late, net_late;   // census: the latest start of a tree / net workgroup, in 100 MHz ticks after the first workgroup of the epoch
+  uint32_t tree_late_n, net_late_n;   // calibration launches: workgroups that only started when the others had left
+  uint32_t svc_arrived, svc_late_n;   // conveyor: its service workgroups that started / that only started when the others had left (calibration)
+  uint32_t pad1[20];
+  // ---- line 2: words the tree wavefronts WRITE all the time (round 5: off the polled line - an atomic on a line that hundreds of idle
+  // workgroups read every microsecond waits behind them)
   uint32_t ins_count;     // entries of the insert log
   uint32_t ended;         // games that ended in this epoch: their slots idle until the boundary's k_assign restarts or retires them
   uint32_t dead;          // slots without a game when the epoch began (retired) or lost to an engine error
-  uint32_t tree_late, net_late;   // census: the latest start of a tree / net workgroup, in 100 MHz ticks after the first workgroup of the epoch
   uint32_t ins_done;      // insert-log entries already applied (the first insert launch runs while the net side drains)
   uint32_t moved;         // move steps run by the mover wavefronts in this epoch
-  uint32_t tree_late_n, net_late_n;   // calibration launches: workgroups that only started when the others had left
   uint32_t lost;          // ring positions a net workgroup gave up on in this epoch (their requests were overwritten a lap later before
                           // it could look: the workgroup had been switched out): k_pipe_settle re-queues those slots, no error
-  uint32_t svc_arrived, svc_late_n;   // conveyor: its service workgroups that started / that only started when the others had left (calibration)
-  uint32_t pad1[14];
+  uint32_t pad2[26];
 };
-static_assert(sizeof(PipeEpoch) == 256, "memset block: a multiple of 16 bytes");
+static_assert(sizeof(PipeEpoch) == 384, "memset block: three lines");
 
 struct PipeArrays {
   PipeCtl* ctl;

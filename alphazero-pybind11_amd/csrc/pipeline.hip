@@ -764,8 +764,13 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
   // where every wavefront of this workgroup is (diagnostics of the rare stall-cap error): PipeWg::pad[2 + wave] =
   // phase | units of 10 us since the wave started << 8; the host prints the words of every tree workgroup with a pipeline error
   uint32_t* const phase_word = &wc->pad[2 + (threadIdx.x >> 6)];
-#define AZMI_GEN_PHASE(x) do { if (wlane == 0) g_st(phase_word, static_cast<uint32_t>(x) | (static_cast<uint32_t>((wall_clock64() - t_start) / 1000u) << 8)); } while (0)
+  // (an epoch that starts with the error word already set - the epochs of a call that were enqueued behind the failing one - leaves
+  // the diagnostics of the failing epoch alone)
+  const bool diag_on = g_ld(&pc->err) == 0u;
+#define AZMI_GEN_PHASE(x) do { if (wlane == 0 && diag_on) g_st(phase_word, static_cast<uint32_t>(x) | (static_cast<uint32_t>((wall_clock64() - t_start) / 1000u) << 8)); } while (0)
   AZMI_GEN_PHASE(1);
+  // (when each wavefront of the workgroup ENTERED the kernel: the raw clock, low 32 bits - do the four start together?)
+  if (wlane == 0 && diag_on) g_st(&wc->pad[6 + (threadIdx.x >> 6)], static_cast<uint32_t>(t_start));
   const uint32_t rmask = (1u << pa.rshift) - 1u;
   unsigned long long* const myring = pa.rring + (static_cast<size_t>(blockIdx.x) << pa.rshift);
   if (threadIdx.x == 0) {
@@ -788,11 +793,16 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
   if (threadIdx.x == 0) s_head = wc->rhead;
   __syncthreads();
   const PipeKernArgs* const kargs = reinterpret_cast<const PipeKernArgs*>(reinterpret_cast<uintptr_t>(__builtin_amdgcn_kernarg_segment_ptr()));
+  uint64_t seg_max[3] = {0, 0, 0}, sg_prev = __builtin_amdgcn_s_memtime();
+  uint64_t ph_max[5] = {0, 0, 0, 0, 0};
+  uint64_t gap_rt = 0, gap_sq = 0, sq_last = __builtin_amdgcn_s_memtime();
+  uint32_t gap_where = 0, did_pass = 0, gap_polls = 0, total_polls = 0;
   while (go) {
     AZMI_GEN_PHASE(3);
     // ---- tokens (as k_pipe_tree: the arrived prefix of the eight ring positions at the LDS head)
     uint32_t my_slot = kNoSlot, tok_seq = 0, empty_polls = 0, ctl_word = 0;
     for (;;) {
+      const uint64_t sg0 = __builtin_amdgcn_s_memtime();
       const uint32_t h = __builtin_amdgcn_readfirstlane(*const_cast<volatile uint32_t*>(&s_head));
       unsigned long long tok = 0;
       bool here = false;
@@ -801,6 +811,9 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
         tok = g_ld(myring + (pos & rmask));
         here = (tok >> 48) == pipe_lap_tag_r(pos, pa.rshift);
       }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" :: "v"(tok) : "memory");
+      const uint64_t sg1 = __builtin_amdgcn_s_memtime();
+      if (sg1 - sg0 > seg_max[0]) seg_max[0] = sg1 - sg0;          // (diagnostics: LDS head + the token load)
       if ((empty_polls & 3u) == 0u) {
         ctl_word = 0;
         if (wlane == 7) ctl_word = g_ld(&pe->stop) | g_ld(&pc->err) | g_ld(&ar.ctl->stop);
@@ -808,6 +821,11 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
         else if (wlane == 23) ctl_word = g_ld(&pe->ended);
         else if (wlane == 31) ctl_word = g_ld(&pe->dead);
       }
+      asm volatile("s_waitcnt vmcnt(0)" :: "v"(ctl_word) : "memory");
+      const uint64_t sg2 = __builtin_amdgcn_s_memtime();
+      if (sg2 - sg1 > seg_max[1]) seg_max[1] = sg2 - sg1;          // (the control words)
+      if (sg0 - sg_prev > seg_max[2]) seg_max[2] = sg0 - sg_prev;  // (from the last look's control words to this look's start: the sleep, a pass)
+      sg_prev = sg2;
       uint32_t stop_seen = __builtin_amdgcn_readlane(ctl_word, 7) | __builtin_amdgcn_readlane(ctl_word, 15);
       {
         const uint32_t w = __builtin_amdgcn_readlane(ctl_word, 23), d = __builtin_amdgcn_readlane(ctl_word, 31);
@@ -816,6 +834,12 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
         if (w >= thr || w + d >= ep.S) stop_seen = 1u;
       }
       const uint64_t now = wall_clock64();
+      {   // diagnostics: the longest interval between two looks of this wavefront by the 100 MHz wall clock, the same interval by the SQ's
+          // own counter (s_memtime), and where the wavefront was in between (0: only this poll loop, 1: a pass)
+        const uint64_t sq_now = __builtin_amdgcn_s_memtime();
+        if (now - t_last > gap_rt) { gap_rt = now - t_last; gap_sq = sq_now - sq_last; gap_where = did_pass; gap_polls = total_polls; }
+        sq_last = sq_now; did_pass = 0u; ++total_polls;
+      }
       pipe_freeze_credit(pc, now, t_last, t_start, wlane == 0);
       if (now - t_start > pa.soft_ticks) stop_seen = 1u;
       if (now - t_start > pa.cap_ticks) {
@@ -839,6 +863,9 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
       break;
     }
     if (!go) break;
+    did_pass = 1u;
+    uint64_t ph_t = __builtin_amdgcn_s_memtime();
+#define AZMI_GEN_SEG(i) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); if (t_ - ph_t > ph_max[i]) ph_max[i] = t_ - ph_t; ph_t = t_; } while (0)
     AZMI_GEN_PHASE(4);
     // ---- an answer token: the slot is back once req_seq shows the token's number; its granules become the slot's (v, pi) rows
     if (my_slot != kNoSlot && tok_seq != 0u) {
@@ -853,6 +880,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
     }
     bool answered = false;
     float reg_pi = 0.0f, reg_v = 0.0f;
+    AZMI_GEN_SEG(0);      // the wait for the slot's publication word
     AZMI_GEN_PHASE(5);
     if (my_slot != kNoSlot && tok_seq != 0u) {
       const unsigned long long* const res = pa.res + static_cast<size_t>(my_slot) * kResStride;
@@ -880,6 +908,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
         if (lane == 0) ar.flags[my_slot] = ar.flags[my_slot] & static_cast<uint8_t>(~kFlagReqOut);
       }
     }
+    AZMI_GEN_SEG(1);      // the answer's granules
     if (ep.cache_on) {        // PlayManager::update_inferences -> insert_many: logged with the leaf's group, applied after the epoch
       const unsigned long long am = __ballot(answered && lane == 0);
       if (am) {
@@ -899,9 +928,11 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the rows are in place before the step reads them
+    AZMI_GEN_SEG(2);      // the insert-log ticket and the drain
     AZMI_GEN_PHASE(6);
     // ---- one step of every slot of the pass (requests leave inside)
     const uint32_t rs = pipe_move_groups<GM>(kargs->ep, kargs->ar, kargs->pa, my_slot);
+    AZMI_GEN_SEG(3);      // the steps themselves (round_slot, the requests)
     AZMI_GEN_PHASE(7);
     // ---- a slot whose next answer is at hand (cache hit, terminal leaf, RANDOM seat) goes straight back into the ring
     {
@@ -918,12 +949,19 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
         }
       }
     }
+    AZMI_GEN_SEG(4);      // the READY tokens
+#undef AZMI_GEN_SEG
   }
   AZMI_GEN_PHASE(8);
   if (wlane == 0) g_st(&pe->stop, 1u);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   AZMI_GEN_PHASE(9);
+  if (threadIdx.x == 0 && diag_on) {      // (wavefront 0's longest interval between two looks: 10 us units by the wall clock | by the SQ clock, raw ticks >> 10 | where | after how many polls)
+    for (int i = 0; i < 5; ++i) wc->pad[18 + i] = static_cast<uint32_t>(ph_max[i] >> 10);
+    wc->pad[15] = static_cast<uint32_t>(seg_max[0] >> 10); wc->pad[16] = static_cast<uint32_t>(seg_max[1] >> 10); wc->pad[17] = static_cast<uint32_t>(seg_max[2] >> 10);
+    wc->pad[10] = static_cast<uint32_t>(gap_rt / 1000u); wc->pad[11] = static_cast<uint32_t>(gap_sq >> 10); wc->pad[12] = gap_where; wc->pad[13] = gap_polls; wc->pad[14] = total_polls;
+  }
   if (threadIdx.x == 0) { wc->rhead = s_head; atomicAdd(&pe->tree_done, 1u); }
 #undef AZMI_GEN_PHASE
 }
@@ -991,6 +1029,7 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
       uint64_t t_first = 0;                  // when the first request of this pass was seen
       uint32_t final_looks = 0;              // empty looks at the window after the tree side had left
       uint64_t t_empty = 0;                  // when this claim first found nothing at its position
+      uint32_t empty_looks = 0;              // looks that found nothing (lane 0 counts)
       for (;;) {
         if (wdone == wn) {
           // the window's size follows the load (MODE 0): with a backlog of requests the 6-board tile (capacity: 28 M evaluations/s on
@@ -1032,7 +1071,7 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
         }
         // nothing there: is the epoch over?  stop is up (no tree workgroup that arrives from now on sends anything) and every
         // tree workgroup that did arrive has left: tail is final, and what lies at or beyond it never comes
-        uint32_t over = 0, stale = 0;
+        uint32_t over = 0, stale = 0, idle = 0;
         if (tid == 0) {
           // A position more than half a ring BEHIND the tail will never show this lap's tag again: its request was overwritten a lap
           // later before this workgroup could look (seen once in ~1e10 requests: the workgroup sat 2 laps behind - it had been
@@ -1040,8 +1079,12 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
           // (looked at only once this position has been empty for 0.5 ms: `tail` is the hottest word of the pipeline - every request
           // is a returning add on it - and 384 idle workgroups reading it on every poll slowed every request: the headline lost 12 %)
           if (t_empty == 0) t_empty = now;
+          if (now - t_empty > 2000ull) idle = 1;          // nothing for 20 us: poll slowly from here on (below)
           if (now - t_empty > 50000ull && static_cast<int32_t>(g_ld(q_tail) - (w0 + wdone)) > static_cast<int32_t>(kPipeRing / 2u)) stale = 1;
-          if (g_ld(&pc->err)) over = 1;
+          // (err and stop are looked at on every eighth empty look only - ~4 us: they matter when the epoch ends, the window's own
+          // ring entries, read above on every look, are what a request's latency depends on)
+          if ((empty_looks++ & 7u) != 0u) { /* not this time */ }
+          else if (g_ld(&pc->err)) over = 1;
           else if (g_ld(&pe->stop) != 0u && g_ld(&pe->tree_done) >= g_ld(&pe->tree_arrived)) {
             const uint32_t t2 = g_ld(q_tail);
             if (static_cast<int32_t>(t2 - (w0 + wdone)) <= 0) over = 1;
@@ -1052,10 +1095,11 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
           // the stall detector: cap x 1.25 once the tree side is there; while no tree workgroup has started yet (the host was held up
           // between the two launches, the tree kernel waits for a place) four caps - long enough for any scheduling hiccup, short
           // enough that a launch that never comes is an error and not a hang
-          // (round 5: EIGHT caps.  The cap is the tree side's stall detector; the net side only waits for the tree side, and the GPU's
-          // scheduler was seen to switch the tree kernel's queue out for > 300 ms while this kernel kept running
-          // (profiles/r5_repro_generic.txt: the tree wavefronts credit such a freeze and finish normally, this side must outwait it))
-          if (!over && now - t_start > 8u * pa.cap_ticks) {
+          // (round 5: FORTY caps = 10 s.  The cap is the tree side's stall detector; the net side only waits for the tree side, and the
+          // tree kernel's wavefronts were seen to stand still for 0.3 s (profiles/r5_repro_generic_freeze_credit.txt) and for more than
+          // 2 s (r5_repro_generic_8xcap.txt) while this kernel kept running: they credit such a freeze and finish normally, this side
+          // must outwait it; a tree kernel that never comes is still an error after 10 s, not a hang)
+          if (!over && now - t_start > 40u * pa.cap_ticks) {
             // (what the stalled workgroup saw, for the error message: dbg[8..14) = stop, tree workgroups done / arrived, ring tail,
             // the window position it waits at, 10 us units since its start)
             if (atomicAdd(&pc->dbg[7], 1u) == 0u) {
@@ -1071,7 +1115,15 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
           wdone = wn;          // (the next turn of the loop draws a new window)
           continue;
         }
-        __builtin_amdgcn_s_sleep(16);
+        // A workgroup that has found nothing for 20 us polls every ~14 us instead of every 0.5 us (7 us more latency for a request that
+        // arrives into an idle chip): idle persistent workgroups are not free - their polls share the control lines and the fabric with
+        // the tree side.  (Round 5: this alone did NOT end the seconds-long stalls of the tree wavefronts seen beside ~500 idle net
+        // workgroups - not launching them did: net_launch.)
+        if (__builtin_amdgcn_readfirstlane(idle)) {
+          __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
+        } else {
+          __builtin_amdgcn_s_sleep(16);
+        }
       }
       if (tid < 8) {
         const bool mine = tid < n;
@@ -1276,6 +1328,7 @@ struct PipeState {
   uint32_t* pair_flag = nullptr;
   hipEvent_t ev_go = nullptr, ev_net = nullptr;
   uint32_t net_wgs = 0, tree_wgs = 0, tree_block = 256;
+  uint32_t net_launch = 0;          // net workgroups an epoch really launches: net_wgs, held to what the engine's slots can keep busy
   std::vector<hipEvent_t> tev;      // timing events: four per epoch of a run (net kernel start / end, tree kernel start / end)
   size_t lds_bytes = 0;
   bool sized = false, x3 = false;   // pipe_size_net has run for a net of this precision tier
@@ -1890,6 +1943,11 @@ static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_ne
     AZMI_HIP_TRY(hipEventCreate(&ev));
     ps->tev.push_back(ev);
   }
+  // A slot has at most one request out and a tile takes three: more than S / 3 net workgroups (+ 8 of slack) can never all have work.
+  // A small engine therefore does not launch the ~500 the chip holds: idle persistent workgroups are not free - they poll - and
+  // the rare seconds-long stalls of the tree side were only ever seen with hundreds of them idle.
+  ps->net_launch = std::min<uint32_t>(ps->net_wgs, std::max<uint32_t>(8u, (pm->ep.S + 2u) / 3u + 8u));
+  if (getenv("AZMI_PIPE_NET_ALL")) ps->net_launch = ps->net_wgs;
   const bool prof = getenv("AZMI_PIPE_PROF") != nullptr;
   const auto host_t0 = std::chrono::steady_clock::now();       // what the host spends enqueueing the epochs (it runs ahead of the GPU)
   for (uint32_t e = 0; e < epochs; ++e) {
@@ -1927,7 +1985,7 @@ static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_ne
     }
     if (!tree_only && !ps->cv_on) {
       AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 0], ps->net_stream));
-      rc = pipe_launch_net(ps, view, net_mode, ps->net_wgs, ps->net_stream, pa);
+      rc = pipe_launch_net(ps, view, net_mode, ps->net_launch, ps->net_stream, pa);
       if (rc != AZMI_OK) return rc;
       AZMI_HIP_TRY(hipEventRecord(ps->tev[4 * e + 1], ps->net_stream));
       AZMI_HIP_TRY(hipEventRecord(ps->ev_net, ps->net_stream));
@@ -1975,7 +2033,7 @@ static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_ne
   if (!tree_only && !hc.err && !ps->cv_on) pipe_balance(ps, hc);       // (takes effect with the next call's first epoch)
   if (out_stats) {
     out_stats[0] = hc.tiles; out_stats[1] = hc.tile_boards; out_stats[2] = he.sims; out_stats[3] = he.tree_arrived;
-    out_stats[4] = he.net_arrived; out_stats[5] = he.ins_count; out_stats[6] = ps->cv_on ? ps->cv_lines : ps->net_wgs; out_stats[7] = ps->tree_wgs;
+    out_stats[4] = he.net_arrived; out_stats[5] = he.ins_count; out_stats[6] = ps->cv_on ? ps->cv_lines : ps->net_launch; out_stats[7] = ps->tree_wgs;
     out_stats[8] = he.tree_late / 100u; out_stats[9] = he.net_late / 100u;
     double net_us = 0.0, tree_us = 0.0;
     for (uint32_t e = 0; e < epochs; ++e) {
@@ -1997,10 +2055,17 @@ static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_ne
     if (plan.kind == 2) {      // the generic tree kernel: where each of its wavefronts was last (phase, 10 us units since its start)
       std::vector<PipeWg> hw(ps->tree_wgs);
       if (hipMemcpy(hw.data(), pa.wg, hw.size() * sizeof(PipeWg), hipMemcpyDeviceToHost) == hipSuccess) {
-        fprintf(stderr, "pipeline generic tree kernel, workgroup: rhead rtail | phase@10us of its four wavefronts:");
+        fprintf(stderr, "pipeline generic tree kernel, workgroup: rhead rtail | phase@10us of its four wavefronts | their entry times, us after wavefront 0's:");
         for (uint32_t w = 0; w < ps->tree_wgs; ++w)
-          fprintf(stderr, "  [%u: %u %u | %u@%u %u@%u %u@%u %u@%u]", w, hw[w].rhead, hw[w].rtail, hw[w].pad[2] & 255u, hw[w].pad[2] >> 8, hw[w].pad[3] & 255u, hw[w].pad[3] >> 8,
-                  hw[w].pad[4] & 255u, hw[w].pad[4] >> 8, hw[w].pad[5] & 255u, hw[w].pad[5] >> 8);
+          fprintf(stderr, "  [%u: %u %u | %u@%u %u@%u %u@%u %u@%u | %d %d %d]", w, hw[w].rhead, hw[w].rtail, hw[w].pad[2] & 255u, hw[w].pad[2] >> 8, hw[w].pad[3] & 255u, hw[w].pad[3] >> 8,
+                  hw[w].pad[4] & 255u, hw[w].pad[4] >> 8, hw[w].pad[5] & 255u, hw[w].pad[5] >> 8,
+                  static_cast<int32_t>(hw[w].pad[7] - hw[w].pad[6]) / 100, static_cast<int32_t>(hw[w].pad[8] - hw[w].pad[6]) / 100, static_cast<int32_t>(hw[w].pad[9] - hw[w].pad[6]) / 100);
+        fprintf(stderr, "\n  wavefront 0's longest interval between two looks: wall clock x10us | SQ clock >> 10 | 0 poll loop, 1 a pass | after polls | polls in all:");
+        for (uint32_t w = 0; w < ps->tree_wgs; ++w) fprintf(stderr, "  [%u: %u | %u | %u | %u | %u]", w, hw[w].pad[10], hw[w].pad[11], hw[w].pad[12], hw[w].pad[13], hw[w].pad[14]);
+        fprintf(stderr, "\n  longest phases of its passes (SQ clock >> 10): publication word | granules | log ticket + drain | steps + requests | tokens:");
+        for (uint32_t w = 0; w < ps->tree_wgs; ++w) fprintf(stderr, "  [%u: %u | %u | %u | %u | %u]", w, hw[w].pad[18], hw[w].pad[19], hw[w].pad[20], hw[w].pad[21], hw[w].pad[22]);
+        fprintf(stderr, "\n  its longest segments (SQ clock >> 10): token load | control words | between looks:");
+        for (uint32_t w = 0; w < ps->tree_wgs; ++w) fprintf(stderr, "  [%u: %u | %u | %u]", w, hw[w].pad[15], hw[w].pad[16], hw[w].pad[17]);
         fprintf(stderr, "\n");
       }
     }
@@ -2018,7 +2083,7 @@ static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_ne
                           "last epoch: head %u tail %u sims %llu ended %u dead %u stop %u tree_done %u tiles %llu boards %llu; latest tree / net workgroup start %u / %u us; "
                           "first time-out saw: slot %u seq %u / %u; net side: stop %u tree done %u of %u tail %u window at %u after %u0 us; "
                           "wavefronts that stood still > 2 ms (not one instruction between two looks at the clock) so far: %llu, the longest for %.1f ms",
-                          hc.err, he.tree_arrived, ps->tree_wgs, he.net_arrived, ps->net_wgs, hc.head, hc.tail, he.sims, he.ended, he.dead, he.stop,
+                          hc.err, he.tree_arrived, ps->tree_wgs, he.net_arrived, ps->net_launch, hc.head, hc.tail, he.sims, he.ended, he.dead, he.stop,
                           he.tree_done, hc.tiles, hc.tile_boards, he.tree_late / 100u, he.net_late / 100u,
                           hc.dbg[1], hc.dbg[2], hc.dbg[3], hc.dbg[8], hc.dbg[9], hc.dbg[10], hc.dbg[11], hc.dbg[12], hc.dbg[13],
                           static_cast<unsigned long long>(hc.prof[14]), static_cast<double>(hc.prof[15]) * 1e-5);

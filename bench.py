@@ -653,11 +653,24 @@ def main():
             res = gather.gather_rows_to_rank0(parts, rank, world)      # gloo (CPU rehearsal)
             gather_kind = "torch.distributed (gloo)"
         else:
-            # the native exchange behind the C ABI (azmi_gather_rows over librccl: unpadded rows, no torch collective in the data path)
-            ng = gather.NativeGather(rank, world, local_rank)
-            res = ng.gather_rows_to_rank0(parts)
-            torch.cuda.synchronize()
-            gather_kind = "azmi_gather_rows (librccl: ncclAllGather of counts + grouped ncclSend/ncclRecv of unpadded rows)"
+            # the native exchange behind the C ABI (azmi_gather_rows over librccl: unpadded rows, no torch collective in the data path).
+            # Every rank must take the same road: a rank whose communicator cannot be made (librccl missing, ...) says so, and then
+            # all of them gather through torch.distributed instead - the line names the road taken and why
+            ng, why = None, ""
+            try:
+                ng = gather.NativeGather(rank, world, local_rank)
+            except Exception as e:          # noqa: BLE001 (reported in the line, not swallowed)
+                why = str(e)[:160]
+            ok = torch.tensor([1.0 if ng is not None else 0.0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() > 0:
+                res = ng.gather_rows_to_rank0(parts)
+                torch.cuda.synchronize()
+                gather_kind = "azmi_gather_rows (librccl: ncclAllGather of counts + grouped ncclSend/ncclRecv of unpadded rows)"
+            else:
+                res = gather.gather_rows_to_rank0(parts, rank, world)
+                torch.cuda.synchronize()
+                gather_kind = "torch.distributed (nccl = RCCL); the native communicator could not be made on every rank" + (": " + why if why else "")
         if rank == 0:
             gathered_rows = int(res[0].shape[0])
     barrier()

@@ -20,8 +20,8 @@ for it in range(N):
     n = 0
     stats = None
     try:
-        while pm.remaining_games() > 0 and n < 4000:
-            stats = az.run_pipeline_groups(pm, [net], 4, S * 16, st.cuda_stream); n += 1
+        while pm.remaining_games() > 0 and n < 16000:
+            stats = az.run_pipeline_groups(pm, [net], int(os.environ.get("E", 4)), S * 16, st.cuda_stream); n += 1
             if pm.poll(st.cuda_stream)[1] == 0: break
     except RuntimeError as e:
         print("iteration %d call %d: %s" % (it, n, str(e)[:900]), flush=True)
