@@ -116,7 +116,7 @@ struct PipeArrays {
   unsigned long long* rring;  // [n_tree_wgs][1 << rshift] READY rings: {tag16 | seq32 | move | slot}
   PipeWg* wg;                 // [n_tree_wgs]
   uint32_t rshift;            // log2 of a READY ring's entries (>= twice the slots of a workgroup)
-  uint32_t big_at;            // net side, tile selection 0: a workgroup draws a 6-request window when at least this many requests wait in the ring (else 3); 0 = always 6
+  uint32_t big_at;            // net side, tile selection 0: 0 = always a 6-request window; 1 = 6 after a window that was complete at first look, else 3; >= 2: that, and at least this many requests waiting in the ring
   uint32_t census_hold;       // != 0: a calibration launch - every workgroup holds its place this many ticks and leaves (pipe_calibrate)
   uint32_t take_wait;         // ticks a wavefront that found fewer than kTreeWindow tokens waits for more before it starts its pass
   uint32_t max_inline;        // simulations a group may finish in one pass without the net (cache hits, terminal leaves) before its slot re-queues

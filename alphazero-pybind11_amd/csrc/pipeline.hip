@@ -1016,6 +1016,7 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
   // rest of the window is there - or, when a request is waiting, for a short patience only -, runs a tile over what
   // arrived, and draws a new window once this one is used up.  head therefore runs ahead of tail.
   uint32_t w0 = 0, wn = 0, wdone = 0;        // window start, size, positions served (wave 0 keeps them; uniform)
+  bool prev_full = false, first_look = false; // the last window drawn was complete when first looked at (a backlog); the next look is a window's first
   uint64_t pf_wait = 0, pf_tile = 0, pf_mark = wall_clock64();
   for (;;) {
     uint32_t tid = tid0;      // (opaque per tile, as k_pipe_tree's lane number: per-thread addresses are not hoisted out of the epoch's loop)
@@ -1035,13 +1036,22 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
           // the window's size follows the load (MODE 0): with a backlog of requests the 6-board tile (capacity: 28 M evaluations/s on
           // the chip's net places), with none - this workgroup is idle, and so are others - the 3-board tile (latency: 39 us alone
           // against 60; the slots, not the matrix cores, are what is short then)
+          // (round 4 asked the ring: 6 when at least big_at = 96 requests waited, from a load of head and one of tail per claim.  Those
+          // are the two hottest words of the pipeline - every request is a returning add on tail - and the two loads alone cost 2.7 % of
+          // the headline (always-3 with them against always-3 without).  Round 5: a workgroup whose LAST window was complete when it
+          // first looked at it has met a backlog itself - 6; one that had to wait for its requests - 3.  No load at all: +3.4 % on one
+          // box, profiles/r5_window_rule_ab.txt.  AZMI_PIPE_BIG_AT >= 2 brings the ring's count back as a second condition.)
           uint32_t h = 0, take = kMaxTake;
           if (MODE == 0 && pa.big_at != 0u) {
-            uint32_t hd = 0, tl = 0;
-            if (tid == 0) { hd = g_ld(q_head); tl = g_ld(q_tail); }
-            const int32_t backlog = static_cast<int32_t>(__builtin_amdgcn_readfirstlane(tl) - __builtin_amdgcn_readfirstlane(hd));
-            if (backlog < static_cast<int32_t>(pa.big_at)) take = 3u;
+            if (!prev_full) take = 3u;
+            else if (pa.big_at >= 2u) {
+              uint32_t hd = 0, tl = 0;
+              if (tid == 0) { hd = g_ld(q_head); tl = g_ld(q_tail); }
+              const int32_t backlog = static_cast<int32_t>(__builtin_amdgcn_readfirstlane(tl) - __builtin_amdgcn_readfirstlane(hd));
+              if (backlog < static_cast<int32_t>(pa.big_at)) take = 3u;
+            }
           }
+          first_look = true;
           if (tid == 0) h = atomicAdd(q_head, take);
           w0 = __builtin_amdgcn_readfirstlane(h); wn = take; wdone = 0;
         }
@@ -1061,6 +1071,7 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
         }
         const uint32_t hm = static_cast<uint32_t>(__ballot(here)) & 0xFFu;
         const uint32_t k = static_cast<uint32_t>(__builtin_ctz(~hm));          // arrived prefix of the window's rest
+        if (first_look) { prev_full = k == left; first_look = false; }
         const uint64_t now = wall_clock64();
         pipe_freeze_credit(pc, now, t_last, t_start, tid == 0);
         if (k == left) { n = k; break; }
@@ -1476,7 +1487,7 @@ int pipe_create(azmi_pm* pm, size_t tile_lds) {
   pa.min_active = getenv("AZMI_PIPE_MIN_ACTIVE") ? static_cast<uint32_t>(std::max(0, atoi(getenv("AZMI_PIPE_MIN_ACTIVE")))) : 0u;
   // net side: a workgroup draws a 6-request window (the 6-board tile: capacity) when at least big_at requests wait in the ring, else a
   // 3-request window (the 3-board tile: 39 us instead of 60 alone - with 4096 slots a slot's wait for its answer is what is short)
-  pa.big_at = getenv("AZMI_PIPE_BIG_AT") ? static_cast<uint32_t>(std::max(0, atoi(getenv("AZMI_PIPE_BIG_AT")))) : 96u;      // (same-box A/B at 4096 slots: 48 -> 100.0, 96 / 128 / 192 -> 102.4 M simulations/s; 16384 slots: no difference)
+  pa.big_at = getenv("AZMI_PIPE_BIG_AT") ? static_cast<uint32_t>(std::max(0, atoi(getenv("AZMI_PIPE_BIG_AT")))) : 1u;      // 1: the workgroup's own experience (round 5); round 4: 96      // (same-box A/B at 4096 slots: 48 -> 100.0, 96 / 128 / 192 -> 102.4 M simulations/s; 16384 slots: no difference)
   pa.take_wait = getenv("AZMI_PIPE_TAKE_WAIT") ? static_cast<uint32_t>(std::max(0, atoi(getenv("AZMI_PIPE_TAKE_WAIT")))) : 0u;
   (void)tile_lds;
   if (const char* e = getenv("AZMI_PIPE_CU_SPLIT")) {
