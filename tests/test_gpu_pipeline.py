@@ -520,6 +520,26 @@ def test_pipeline_holds_a_huge_epoch_quota_below_the_stall_cap():
     assert pm.games_completed() == S
 
 
+def test_a_small_engine_launches_no_more_net_workgroups_than_its_slots_can_keep_busy(monkeypatch):
+    """round 5: a slot has one request out at most and a tile takes three, so an epoch launches min(measured places, S / 3 + 8) net
+    workgroups - hundreds of idle persistent workgroups beside a few tree workgroups are what the seconds-long stalls of the tree side
+    needed; AZMI_PIPE_NET_ALL=1 launches them all (the games are the same either way)"""
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=31), spec)
+    S, seed = 96, 4242
+    pp = _selfplay_params(az, S, 60, cache=1 << 14)
+    pa, (ra, ca), stats = _pipeline_games(az, pp, seed, hip, sims_per_epoch=S * 40)
+    assert stats["net_wgs"] == (S + 2) // 3 + 8 and stats["net_wgs_started"] == stats["net_wgs"]
+    monkeypatch.setenv("AZMI_PIPE_NET_ALL", "1")
+    pb, (rb, cb), stats_all = _pipeline_games(az, pp, seed, hip, sims_per_epoch=S * 40)
+    monkeypatch.delenv("AZMI_PIPE_NET_ALL")
+    assert stats_all["net_wgs"] > 2 * stats["net_wgs"] and stats_all["net_wgs_started"] == stats_all["net_wgs"]
+    sa, sb = _sorted_log(ra, ca), _sorted_log(rb, cb)
+    assert np.array_equal(sa[0], sb[0]) and np.array_equal(sa[1], sb[1])
+
+
 def test_pipeline_follows_the_callers_stream_from_call_to_call():
     """the caller's stream changes between calls (two torch streams and the engine's own): the net-side stream is re-checked against
     each new partner (a shared hardware queue would serialise the two persistent kernels) and the games stay the lock-step engine's"""
