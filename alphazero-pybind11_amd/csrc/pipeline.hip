@@ -1347,6 +1347,7 @@ struct PipeState {
   azmi_net_dev::NetPtrs np1{};
   int kind = 0;                     // PipePlan::kind of the current call (which tree kernel)
   bool calibrated = false;          // net_wgs has been measured beside the tree workgroups (pipe_calibrate)
+  bool svc_paired = false; hipStream_t svc_paired_with = nullptr;      // the conveyor's service stream runs beside `svc_paired_with` and net_stream
   uint32_t calib_rounds = 0;
   // balance between the two sides (pipe_balance): rings are allocated for tree_wgs_alloc workgroups, `places` = tree + net workgroups
   // the chip was measured to hold, the cumulative counters are those of the previous call
@@ -1573,6 +1574,37 @@ int pipe_pair_streams(PipeState* ps, hipStream_t st) {
                         "the pipeline needs its tree and net kernels on the chip together - use azmi_run_rounds");
 }
 
+// The conveyor's service kernel is a THIRD persistent kernel: its stream must share a hardware queue with neither the caller's stream
+// nor net_stream (the runtime deals streams onto a few queues round-robin; a kernel queued behind a persistent one starts when the
+// epoch is over).  Same probe as above, against both partners; streams that fail are parked.
+int pipe_pair_svc(PipeState* ps, hipStream_t st) {
+  if (ps->svc_paired && ps->svc_paired_with == st) return AZMI_OK;
+  if (!ps->pair_flag) { const int rc = pipe_alloc(ps, ps->pair_flag, 4); if (rc != AZMI_OK) return rc; }
+  for (int attempt = 0; attempt < 12; ++attempt) {
+    bool ok = true;
+    for (hipStream_t partner : {st, ps->net_stream}) {
+      AZMI_HIP_TRY(hipMemsetAsync(ps->pair_flag, 0, 4 * sizeof(uint32_t), partner));
+      AZMI_HIP_TRY(hipEventRecord(ps->ev_go, partner));
+      AZMI_HIP_TRY(hipStreamWaitEvent(ps->svc_stream, ps->ev_go, 0));
+      k_pair_wait<<<1, 1, 0, partner>>>(ps->pair_flag);
+      AZMI_HIP_TRY(hipGetLastError());
+      k_pair_set<<<1, 1, 0, ps->svc_stream>>>(ps->pair_flag);
+      AZMI_HIP_TRY(hipGetLastError());
+      uint32_t h[2] = {0, 0};
+      AZMI_HIP_TRY(hipStreamSynchronize(ps->svc_stream));
+      AZMI_HIP_TRY(hipMemcpyAsync(h, ps->pair_flag, sizeof(h), hipMemcpyDeviceToHost, partner));
+      AZMI_HIP_TRY(hipStreamSynchronize(partner));
+      if (h[1] != 0u) { ok = false; break; }
+    }
+    if (ok) { ps->svc_paired = true; ps->svc_paired_with = st; return AZMI_OK; }
+    ps->parked.push_back(ps->svc_stream);
+    ps->svc_stream = nullptr;
+    AZMI_HIP_TRY(hipStreamCreateWithFlags(&ps->svc_stream, hipStreamNonBlocking));
+  }
+  return azmi_host_fail(AZMI_ERR_STATE, "azmi_run_pipeline: no third stream runs beside the caller's and the net side's (GPU_MAX_HW_QUEUES < 3?): the conveyor "
+                        "needs three kernels on the chip together; AZMI_PIPE_NET=tiles runs the tile kernel");
+}
+
 // ---- the conveyor's host side ---------------------------------------------------------------------------------------------------------
 // When the net side can be the conveyor (conveyor_c4.h): the bf16 tier, one model group, an even number of residual blocks (a conv
 // workgroup = two blocks).  Round 5: opt-in (AZMI_PIPE_NET=conveyor; an error where it cannot run) - bit for bit the tile kernel's
@@ -1584,9 +1616,11 @@ bool cv_eligible(const azmi_pm* pm, const PipePlan& plan) {
   return !plan.tree_only && plan.kind == 1 && plan.net_groups == 1u && pm->ep.num_groups == 1u && plan.view[0].x3 == 0 && nd.depth >= 2 && nd.depth % 2 == 0;
 }
 uint32_t cv_default_lines(uint32_t cus, uint32_t nwg, uint32_t tree_wgs) {
-  // CUs: a conv workgroup each, two service workgroups per CU (registers), two tree workgroups per CU
+  // CUs: a conv workgroup each (it takes its CU's registers whole), a service workgroup each (two would fit a CU, but the dispatcher
+  // deals them one per CU while CUs are free), two tree workgroups per CU - inside nine tenths of the chip: the three kernels' workgroups
+  // are dealt at the same time, and a conv workgroup needs a CU that nothing else has touched (cv_calibrate gives lines up from there)
   uint32_t lines = 1;
-  while ((lines + 1u) * nwg + (lines + 2u) / 2u + (tree_wgs + 1u) / 2u <= cus) ++lines;
+  while ((lines + 1u) * (nwg + 1u) + (tree_wgs + 1u) / 2u <= cus - cus / 10u) ++lines;
   return lines;
 }
 int cv_setup(azmi_pm* pm, PipeState* ps, const azmi_net_c4_view& view) {
@@ -1873,6 +1907,7 @@ static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_ne
     if (ps->balance) { ps->tree_wgs = ps->tree_wgs_default; pa.n_tree_wgs = ps->tree_wgs; }      // (the 512-place balance rule is the tile kernel's)
     pa.cap_ticks = static_cast<unsigned long long>((getenv("AZMI_PIPE_CAP_MS") ? atof(getenv("AZMI_PIPE_CAP_MS")) : 250.0) * 1e5);
     int rc = cv_setup(pm, ps, view);
+    if (rc == AZMI_OK) rc = pipe_pair_svc(ps, st);
     if (rc == AZMI_OK) rc = cv_calibrate(pm, ps, st, view);
     if (rc != AZMI_OK) {
       if (getenv("AZMI_PIPE_NET")) return rc;
