@@ -7,7 +7,7 @@ import torch
 import alphazero as az
 from alphazero import torch_net
 from test_gpu_t3_nn_in_the_loop import _selfplay_params
-os.environ["AZMI_PIPE_GENERIC"] = "1"
+if os.environ.get("FAST") != "1": os.environ["AZMI_PIPE_GENERIC"] = "1"      # FAST=1: the default tree kernel (its Gumbel build here) instead
 spec = torch_net.connect4_spec()
 net = az.HipLeafNet(torch_net.random_init(spec, seed=51), spec)
 N = int(os.environ.get("N", 60))
