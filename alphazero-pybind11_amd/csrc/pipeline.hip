@@ -1094,7 +1094,7 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
           if (now - t_empty > 50000ull && static_cast<int32_t>(g_ld(q_tail) - (w0 + wdone)) > static_cast<int32_t>(kPipeRing / 2u)) stale = 1;
           // (err and stop are looked at on every eighth empty look only - ~4 us: they matter when the epoch ends, the window's own
           // ring entries, read above on every look, are what a request's latency depends on)
-          if ((empty_looks++ & 7u) != 0u) { /* not this time */ }
+          if (idle == 0u && (empty_looks++ & 7u) != 0u) { /* not this time */ }      // (a workgroup in its slow poll looks every time: 14 us apart)
           else if (g_ld(&pc->err)) over = 1;
           else if (g_ld(&pe->stop) != 0u && g_ld(&pe->tree_done) >= g_ld(&pe->tree_arrived)) {
             const uint32_t t2 = g_ld(q_tail);
