@@ -444,9 +444,11 @@ int azmi_run_rounds(azmi_pm* const* pms, azmi_net* net, uint32_t k, uint32_t rou
  *      the next call of either driver carries on.  The k-th game of a slot is that of azmi_run_rounds for the same seed; with a finite
  *      games_to_play, WHICH slots receive the last restarts depends on the order in which games end inside an epoch (as the reference's
  *      workers race for games_started_, play_manager.cc:506-513), so the SET of games is only the same while no game restarts.
- *      out_stats[14] = the calibration launches of this call (bits 0-7) | freezes - polling wavefronts that stood still for more than
- *      2 ms: the GPU's scheduler had switched the process out; credited against the time caps, not errors - since creation (bits 8-31) |
- *      requests given up and sent again since creation (bits 32-63).
+ *      out_stats[14] = the calibration launches of this call (bits 0-7) | freezes - tree wavefronts that stood still for more than
+ *      2 ms between two looks of their poll loop (seen with hundreds of idle net workgroups beside a small engine);
+ *      credited against the time caps, not errors - since creation (bits 8-31) | requests given up and sent again since creation
+ *      (bits 32-63).  An epoch launches min(the measured places, S / 3 + 8) net workgroups: a slot has at most one request out and
+ *      a tile takes three.
  *      out_stats (may be NULL): [0] net tiles run since the pipeline was created, [1] boards in them, [2] simulations of the
  *      last epoch, [3] / [4] tree / net workgroups that started in it, [5] its insert-log entries, [6] / [7] net / tree
  *      workgroups launched, [8] / [9] the latest start of a tree / net workgroup after the epoch's first, in microseconds (all
