@@ -163,6 +163,7 @@ SYMBOLS = {
     "azmi_debug_pipe_log_dupes": (C.c_int, [_VP, _VP]),
     "azmi_debug_pipe_net_bench": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _VP]),
     "azmi_debug_pipe_net_answers": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint64, C.c_int, C.c_uint32, _VP, _VP]),
+    "azmi_comm_available": (C.c_int, []),
     "azmi_comm_unique_id": (C.c_int, [_VP]),
     "azmi_comm_create": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, _PP(_VP)]),
     "azmi_comm_destroy": (None, [_VP]),

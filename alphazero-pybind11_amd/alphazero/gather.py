@@ -7,6 +7,7 @@ RCCL over xGMI (`backend="nccl"`), in the CPU tests it is gloo.  Messages are sm
 (Connect4: 712 B/row), so no ring tuning is involved.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -60,17 +61,38 @@ class NativeGather:
         self._lib, self._check = lib, check
         self.rank, self.world = int(rank), int(world)
         dev = torch.device("cuda", int(device))
-        idt = torch.zeros(128, dtype=torch.uint8)
-        if self.rank == 0:
+        # Every rank runs the SAME sequence of collectives whatever fails where (rank 0 used to raise before the broadcast
+        # while the others waited in it): (1) rank 0 broadcasts {status byte | 128-byte id} - status 0 and a zeroed id when it could not
+        # make one; (2) a MIN all-reduce of "librccl loads here AND rank 0's id is good"; only when every rank said yes does any of them
+        # enter ncclCommInitRank (a rank missing there would strand the others inside it).  A failure raises on EVERY rank.
+        mine_ok, why = 1, ""
+        try:
+            if os.environ.get("AZMI_COMM_TEST_FAIL_RANK") == str(self.rank):      # test hook (tests/test_gather_gloo.py): this rank has no librccl
+                raise RuntimeError("librccl not found (forced by AZMI_COMM_TEST_FAIL_RANK)")
+            check(lib.azmi_comm_available())
+        except Exception as e:          # noqa: BLE001 (carried into the agreement below, then raised on every rank)
+            mine_ok, why = 0, str(e)[:160]
+        msg = torch.zeros(129, dtype=torch.uint8)
+        if self.rank == 0 and mine_ok:
             buf = (C.c_uint8 * 128)()
-            check(lib.azmi_comm_unique_id(buf))
-            idt = torch.tensor(list(buf), dtype=torch.uint8)
+            try:
+                check(lib.azmi_comm_unique_id(buf))
+                msg = torch.tensor([1] + list(buf), dtype=torch.uint8)
+            except Exception as e:      # noqa: BLE001
+                mine_ok, why = 0, str(e)[:160]
         if self.world > 1:
-            backend = dist.get_backend(group)
-            t = idt.to(dev) if backend == "nccl" else idt
+            on_dev = dist.get_backend(group) == "nccl"
+            t = msg.to(dev) if on_dev else msg
             dist.broadcast(t, src=0, group=group)
-            idt = t.cpu()
-        idb = (C.c_uint8 * 128)(*idt.tolist())
+            msg = t.cpu()
+            ok = torch.tensor([float(mine_ok and int(msg[0]) == 1)], device=dev if on_dev else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            all_ok = bool(ok.item() > 0.5)
+        else:
+            all_ok = bool(mine_ok and int(msg[0]) == 1)
+        if not all_ok:
+            raise RuntimeError("NativeGather: the RCCL communicator cannot be made on every rank" + (f" (rank {self.rank}: {why})" if why else ""))
+        idb = (C.c_uint8 * 128)(*msg[1:].tolist())
         h = C.c_void_p()
         check(lib.azmi_comm_create(idb, self.rank, self.world, int(device), C.byref(h)))
         self._h, self._dev = h, dev

@@ -36,6 +36,12 @@ class SelfPlayResult:          # the fields of game_runner.SelfPlayResult that c
     variant_game_counts: dict = dataclasses.field(default_factory=dict)
     variant_win_rates: dict = dataclasses.field(default_factory=dict)
     variant_metrics: dict = dataclasses.field(default_factory=dict)
+    # which driver played the games (a stall must show up as a failure or as a counted event, not as a slow run - VERDICT r5 item 7):
+    # driver_used "pipeline" | "rounds" | "none" (no net); pipeline_retries = pipeline calls repeated after a recovered pipeline error;
+    # fallbacks = 1 when driver="auto" gave the pipeline up in mid-run and the lock-step driver carried on
+    driver_used: str = "rounds"
+    pipeline_retries: int = 0
+    fallbacks: int = 0
 
 
 def _shard_params(params, k, K):
@@ -56,7 +62,7 @@ def shard_seed(seed, k):
 
 
 def self_play(game, params, net=None, engines=None, seed=20240601, device=0, streams=None, rounds_per_poll=512, data_folder=None,
-              iteration=0, data_save_size=30_000, driver="auto", epochs_per_poll=16):
+              iteration=0, data_save_size=30_000, driver="auto", epochs_per_poll=16, max_fallbacks=None):
     """Runs `params.games_to_play` self-play games of `game`; `net` is a HipLeafNet (or None when every seat evaluates with
     RANDOM / PLAYOUT).  Returns (SelfPlayResult, (canonical, v, pi)) with the samples as device tensors in shard order (numpy
     arrays without a net, since nothing else needs torch then).  With `data_folder` the samples are also written as the
@@ -64,7 +70,9 @@ def self_play(game, params, net=None, engines=None, seed=20240601, device=0, str
     driver: "pipeline" = ONE engine with every game on the asynchronous tree / net pipeline (azmi_run_pipeline: Connect4, PUCT or
     Gumbel seats, at most 16384 concurrent games), "rounds" = `engines` shards (default 4) on the lock-step round
     driver, "auto" = the pipeline where it applies.  The finished samples are taken out of the engines' rings at every poll
-    (the ring is bounded: a long stream would overflow it), like the reference's hist_saver drains its queue."""
+    (the ring is bounded: a long stream would overflow it), like the reference's hist_saver drains its queue.
+    max_fallbacks: None = "auto" may fall back to the lock-step driver (counted in SelfPlayResult.fallbacks, with a warning); 0 = a run
+    that would fall back raises instead (what a throughput measurement wants: a stall is a failure, not a slow run)."""
     want_pipe = driver in ("auto", "pipeline") and net is not None and (engines in (None, 1) or driver == "pipeline")
     if want_pipe:
         probe = PlayManager(game() if isinstance(game, type) else game, _shard_params(params, 0, 1), seed=shard_seed(seed, 0), device=device)
@@ -94,7 +102,7 @@ def self_play(game, params, net=None, engines=None, seed=20240601, device=0, str
         live = list(range(K))
         tdev = torch.device("cuda", device)
         spe = 256 * int(params.concurrent_games)
-        pipe_state = {"retries": 0}
+        pipe_state = {"retries": 0, "fallbacks": 0, "driver": "pipeline" if want_pipe else "rounds"}
         while live:
             group = [pms[i] for i in live]
             if want_pipe:
@@ -103,6 +111,9 @@ def self_play(game, params, net=None, engines=None, seed=20240601, device=0, str
                 # shards while no game has finished, on the same engine otherwise (a pipeline error leaves the engine whole)
                 if not _pipeline_step(lambda: run_pipeline(pms[0], net, epochs_per_poll, spe, sps[0]), pipe_state, driver, "self_play"):
                     want_pipe = False
+                    pipe_state["fallbacks"] += 1; pipe_state["driver"] = "rounds"
+                    if max_fallbacks is not None and pipe_state["fallbacks"] > int(max_fallbacks):
+                        raise RuntimeError("self_play: the asynchronous pipeline gave up on this run and max_fallbacks=%d forbids the lock-step fallback" % int(max_fallbacks))
                     if pms[0].games_completed() == 0 and not drained[0]:
                         K = max(1, min(int(engines or 4), int(params.concurrent_games)))
                         pms = [PlayManager(game() if isinstance(game, type) else game, _shard_params(params, k, K), seed=shard_seed(seed, k), device=device)
@@ -164,6 +175,10 @@ def self_play(game, params, net=None, engines=None, seed=20240601, device=0, str
             res.variant_metrics[vid] = dict(game_length=div(vs[0], vs[1]), avg_depth=div(vs[5], vs[3]), avg_entropy=div(vs[6], vs[3]),
                                             avg_mpt=div(vs[2], vs[0]), avg_vm=div(vs[9], vs[2]), fast_avg_depth=div(vs[7], vs[4]),
                                             fast_avg_entropy=div(vs[8], vs[4]))
+    if no_net:
+        res.driver_used = "none"
+    else:
+        res.driver_used, res.pipeline_retries, res.fallbacks = pipe_state["driver"], pipe_state["retries"], pipe_state["fallbacks"]
     res._pms = pms                      # keeps the engines (and the device memory behind `samples`) alive
     if data_folder is not None and n_samples:
         from . import history_io
@@ -210,6 +225,9 @@ class MatchResult:             # what play_past() returns from the PlayManager (
     past_wins: int
     n_draws: int
     perm_scores: list
+    driver_used: str = "rounds"      # as SelfPlayResult's
+    pipeline_retries: int = 0
+    fallbacks: int = 0
 
 
 def gating_match(game, params, net_new, net_past, engines=2, seed=20240601, device=0, rounds_per_poll=256, driver="rounds", epochs_per_poll=16):
@@ -254,11 +272,12 @@ def gating_match(game, params, net_new, net_past, engines=2, seed=20240601, devi
     streams = [torch.cuda.Stream(device=device) for _ in range(K)]
     sps = [s.cuda_stream for s in streams]
     live = list(range(K))
-    pipe_state = {"retries": 0}
+    pipe_state = {"retries": 0, "fallbacks": 0, "driver": "pipeline" if use_pipe else "rounds"}
     while live:
         if use_pipe:
             if not _pipeline_step(lambda: run_pipeline_groups(pms[0], nets, epochs_per_poll, 256 * int(p.concurrent_games), sps[0]), pipe_state, driver, "gating_match"):
                 use_pipe = False          # (a pipeline error leaves the engine whole: the lock-step driver carries on with it)
+                pipe_state["fallbacks"] += 1; pipe_state["driver"] = "rounds"
                 continue
         else:
             run_rounds_groups([pms[i] for i in live], nets, rounds_per_poll, [sps[i] for i in live])
@@ -284,4 +303,5 @@ def gating_match(game, params, net_new, net_past, engines=2, seed=20240601, devi
             sums[k2] = sums.get(k2, 0.0) + v
     return MatchResult(nn_rate=nn_rate / n_perms, draw_rate=draw_rate / n_perms, hit_rate=(float(cs[0]) / float(cs[0] + cs[1])) if cs[0] + cs[1] else 0.0,
                        game_length=(sums["game_length"] / sums["games"]) if sums["games"] else 0.0, n_games=n_games, nn_wins=nn_wins,
-                       past_wins=past_wins, n_draws=n_draws, perm_scores=[x.tolist() for x in perm_scores])
+                       past_wins=past_wins, n_draws=n_draws, perm_scores=[x.tolist() for x in perm_scores],
+                       driver_used=pipe_state["driver"], pipeline_retries=pipe_state["retries"], fallbacks=pipe_state["fallbacks"])

@@ -52,6 +52,10 @@ Rccl* rccl() {
 }
 #define AZMI_NCCL_TRY(expr) do { const ncclResult_t r_ = (expr); if (r_ != ncclSuccess) \
   return azmi_host_fail(AZMI_ERR_NO_DEVICE, "%s: %s", #expr, rccl()->GetErrorString(r_)); } while (0)
+// inside a ncclGroupStart block: the group is closed before the error leaves (a return without ncclGroupEnd would leave this thread
+// in group mode, and every later RCCL call of the process would be queued into a group nobody ends)
+#define AZMI_NCCL_TRY_IN_GROUP(expr) do { const ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { (void)rccl()->GroupEnd(); \
+  return azmi_host_fail(AZMI_ERR_NO_DEVICE, "%s: %s", #expr, rccl()->GetErrorString(r_)); } } while (0)
 }  // namespace
 
 struct azmi_comm {
@@ -61,6 +65,12 @@ struct azmi_comm {
 };
 
 extern "C" {
+
+int azmi_comm_available(void) {
+  Rccl* r = rccl();
+  if (!r->lib || !r->err.empty()) return azmi_host_fail(AZMI_ERR_NO_DEVICE, "%s", r->err.c_str());
+  return AZMI_OK;
+}
 
 int azmi_comm_unique_id(void* out128) {
   if (!out128) return azmi_host_fail(AZMI_ERR_INVALID, "null argument");
@@ -129,13 +139,13 @@ int azmi_gather_rows(azmi_comm* c, const void* const* src, const uint64_t* row_b
       uint64_t off = n_local * rb;
       AZMI_NCCL_TRY(r->GroupStart());
       for (int q = 1; q < c->world; ++q) {
-        if (counts[q]) AZMI_NCCL_TRY(r->Recv(d + off, counts[q] * rb, ncclUint8, q, c->comm, st));
+        if (counts[q]) AZMI_NCCL_TRY_IN_GROUP(r->Recv(d + off, counts[q] * rb, ncclUint8, q, c->comm, st));
         off += counts[q] * rb;
       }
       AZMI_NCCL_TRY(r->GroupEnd());
     } else if (n_local) {
       AZMI_NCCL_TRY(r->GroupStart());
-      AZMI_NCCL_TRY(r->Send(src[p], n_local * rb, ncclUint8, 0, c->comm, st));
+      AZMI_NCCL_TRY_IN_GROUP(r->Send(src[p], n_local * rb, ncclUint8, 0, c->comm, st));
       AZMI_NCCL_TRY(r->GroupEnd());
     }
   }

@@ -64,7 +64,10 @@ struct PipeCtl {          // zeroed when the pipeline is created; lives across e
   uint32_t tail1; uint32_t pad5[31];            // routes a leaf to the ring of its seat's group: one net per group, play_past)
   uint32_t err;           // PipeErr bits, sticky: every pipeline kernel leaves at once when it is set.  Polled by every waiting
   uint32_t pad6[31];      // workgroup: a line of its own (round 5; it shared the line of the tile counters below)
-  uint32_t pad7[32];
+  // freezes credited by pipe_freeze_credit (count, longest gap in ticks): words of their own (they shared prof[14] / [15]
+  // with the PROF build's level / move counters, so a profiled run reported garbage as freezes)
+  unsigned long long freezes, freeze_max;
+  uint32_t pad7[28];
   uint32_t pad2a, pad2;
   unsigned long long tiles;         // net tiles run
   unsigned long long tile_boards;   // boards in them
@@ -137,6 +140,7 @@ struct PipeArrays {
   uint32_t ins_cap;
   uint32_t* locks;            // [cache shards] insert locks of the position cache (0 = free)
   uint32_t n_tree_wgs;
+  uint32_t net_needed;            // net workgroups the slots can keep busy (S / 3 + 8): one with a higher index that sits idle beside a tree side that has arrived and makes no progress for 1.25 caps leaves (k_pipe_net)
   unsigned long long quota;       // simulations per epoch
   uint32_t idle_num;              // the epoch also ends when `ended` reaches idle_num / 1024 of the slots that have a game
   unsigned long long cap_ticks;   // hard time cap of an epoch in 100 MHz ticks (a stall detector: an error)

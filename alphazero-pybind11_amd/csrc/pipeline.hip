@@ -43,13 +43,14 @@ enum : uint32_t { kGrpIdle = 0, kGrpReady = 1, kGrpWait = 2, kGrpPush = 3 };
 // the stall-cap error of round 4, one in ~30,000 epochs, was every wavefront of both kernels spanning > 190 ms in ONE iteration - the
 // GPU's own scheduler had switched the process's queues out, profiles/r5_repro_generic.txt).  The time caps are stall detectors for
 // THIS code's protocol, so a freeze is credited: the wavefront's start time moves by the gap, the freeze is counted
-// (PipeCtl::prof[14], longest gap in prof[15]) and reported with the call's statistics, not as an error.
+// (PipeCtl::freezes, longest gap in PipeCtl::freeze_max) and reported with the call's statistics, not as an error.  Only a gap INSIDE
+// a poll loop counts: the first look after a pass (a slow pass is not a freeze) only sets the mark.
 constexpr uint64_t kFreezeTicks = 200000ull;
 __device__ __forceinline__ void pipe_freeze_credit(PipeCtl* pc, uint64_t now, uint64_t& t_last, uint64_t& t_start, bool leader) {
   const uint64_t gap = now - t_last;
   if (gap > kFreezeTicks) {
     t_start += gap;
-    if (leader) { atomicAdd(&pc->prof[14], 1ull); atomicMax(&pc->prof[15], static_cast<unsigned long long>(gap)); }
+    if (leader) { atomicAdd(&pc->freezes, 1ull); atomicMax(&pc->freeze_max, static_cast<unsigned long long>(gap)); }
   }
   t_last = now;
 }
@@ -245,6 +246,7 @@ __global__ __launch_bounds__(NT, AZMI_TREE_MINB) void k_pipe_tree(PipeKernArgs k
     // ---- tokens for this pass: the arrived prefix of the eight ring positions at the head
     uint32_t my_slot = kNoSlot, tok_seq = 0, tok_move = 0, n_tok = 0, empty_polls = 0, ctl_word = 0;
     uint64_t t_seen = 0;
+    bool fresh_pass = true;
     for (;;) {
       const uint32_t h = __builtin_amdgcn_readfirstlane(*const_cast<volatile uint32_t*>(&s_head));
       unsigned long long tok = 0;
@@ -271,7 +273,8 @@ __global__ __launch_bounds__(NT, AZMI_TREE_MINB) void k_pipe_tree(PipeKernArgs k
         if (w >= thr || w + d >= ep.S) stop_seen = 1u;
       }
       const uint64_t now = wall_clock64();
-      pipe_freeze_credit(pc, now, t_last, t_start, wlane == 0);
+      if (fresh_pass) { t_last = now; fresh_pass = false; }      // (the pass before this look is work, not a freeze)
+      else pipe_freeze_credit(pc, now, t_last, t_start, wlane == 0);
       // an epoch that runs long (a cold cache sends every leaf to the net: 16384 slots x 256 simulations take > 200 ms then) simply
       // ends at a quarter of the cap; the cap itself is the stall detector
       if (now - t_start > pa.soft_ticks) stop_seen = 1u;
@@ -750,7 +753,10 @@ __global__ __launch_bounds__(NT, AZMI_TREE_MINB) void k_pipe_tree(PipeKernArgs k
 // pipe_move_groups, into the ring of the leaf's group) or - when the answer is at hand - the slot's token back into the ring.  One
 // simulation per slot and pass instead of the fast kernel's several, but no round barrier: a slot waits for its own answer only.
 // Same rings, granules, home workgroups, epoch boundaries and exit conditions as k_pipe_tree.
-template <class GM, int NT>
+// DIAG (AZMI_PIPE_DIAG=1, a build of its own): round 5's instrumentation of the stall hunt - phase stamps, segment clocks, the longest
+// interval between two looks - written into PipeWg::pad (the line of rtail, the word net workgroups add to: hence not on by default,
+// ADVICE r5) with s_waitcnt fences around the poll loop's loads so that each segment can be clocked.
+template <class GM, int NT, bool DIAG = false>
 __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
   constexpr int P = GM::P;
   const EngineParams& ep = ka.ep;
@@ -766,11 +772,11 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
   uint32_t* const phase_word = &wc->pad[2 + (threadIdx.x >> 6)];
   // (an epoch that starts with the error word already set - the epochs of a call that were enqueued behind the failing one - leaves
   // the diagnostics of the failing epoch alone)
-  const bool diag_on = g_ld(&pc->err) == 0u;
-#define AZMI_GEN_PHASE(x) do { if (wlane == 0 && diag_on) g_st(phase_word, static_cast<uint32_t>(x) | (static_cast<uint32_t>((wall_clock64() - t_start) / 1000u) << 8)); } while (0)
+  const bool diag_on = DIAG && g_ld(&pc->err) == 0u;
+#define AZMI_GEN_PHASE(x) do { if (DIAG && wlane == 0 && diag_on) g_st(phase_word, static_cast<uint32_t>(x) | (static_cast<uint32_t>((wall_clock64() - t_start) / 1000u) << 8)); } while (0)
   AZMI_GEN_PHASE(1);
   // (when each wavefront of the workgroup ENTERED the kernel: the raw clock, low 32 bits - do the four start together?)
-  if (wlane == 0 && diag_on) g_st(&wc->pad[6 + (threadIdx.x >> 6)], static_cast<uint32_t>(t_start));
+  if (DIAG && wlane == 0 && diag_on) g_st(&wc->pad[6 + (threadIdx.x >> 6)], static_cast<uint32_t>(t_start));
   const uint32_t rmask = (1u << pa.rshift) - 1u;
   unsigned long long* const myring = pa.rring + (static_cast<size_t>(blockIdx.x) << pa.rshift);
   if (threadIdx.x == 0) {
@@ -793,16 +799,17 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
   if (threadIdx.x == 0) s_head = wc->rhead;
   __syncthreads();
   const PipeKernArgs* const kargs = reinterpret_cast<const PipeKernArgs*>(reinterpret_cast<uintptr_t>(__builtin_amdgcn_kernarg_segment_ptr()));
-  uint64_t seg_max[3] = {0, 0, 0}, sg_prev = __builtin_amdgcn_s_memtime();
+  uint64_t seg_max[3] = {0, 0, 0}, sg_prev = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
   uint64_t ph_max[5] = {0, 0, 0, 0, 0};
-  uint64_t gap_rt = 0, gap_sq = 0, sq_last = __builtin_amdgcn_s_memtime();
+  uint64_t gap_rt = 0, gap_sq = 0, sq_last = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
   uint32_t gap_where = 0, did_pass = 0, gap_polls = 0, total_polls = 0;
   while (go) {
     AZMI_GEN_PHASE(3);
     // ---- tokens (as k_pipe_tree: the arrived prefix of the eight ring positions at the LDS head)
     uint32_t my_slot = kNoSlot, tok_seq = 0, empty_polls = 0, ctl_word = 0;
+    bool fresh_pass = true;
     for (;;) {
-      const uint64_t sg0 = __builtin_amdgcn_s_memtime();
+      const uint64_t sg0 = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
       const uint32_t h = __builtin_amdgcn_readfirstlane(*const_cast<volatile uint32_t*>(&s_head));
       unsigned long long tok = 0;
       bool here = false;
@@ -811,9 +818,12 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
         tok = g_ld(myring + (pos & rmask));
         here = (tok >> 48) == pipe_lap_tag_r(pos, pa.rshift);
       }
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" :: "v"(tok) : "memory");
-      const uint64_t sg1 = __builtin_amdgcn_s_memtime();
-      if (sg1 - sg0 > seg_max[0]) seg_max[0] = sg1 - sg0;          // (diagnostics: LDS head + the token load)
+      uint64_t sg1 = 0;
+      if constexpr (DIAG) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" :: "v"(tok) : "memory");
+        sg1 = __builtin_amdgcn_s_memtime();
+        if (sg1 - sg0 > seg_max[0]) seg_max[0] = sg1 - sg0;          // (diagnostics: LDS head + the token load)
+      }
       if ((empty_polls & 3u) == 0u) {
         ctl_word = 0;
         if (wlane == 7) ctl_word = g_ld(&pe->stop) | g_ld(&pc->err) | g_ld(&ar.ctl->stop);
@@ -821,11 +831,13 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
         else if (wlane == 23) ctl_word = g_ld(&pe->ended);
         else if (wlane == 31) ctl_word = g_ld(&pe->dead);
       }
-      asm volatile("s_waitcnt vmcnt(0)" :: "v"(ctl_word) : "memory");
-      const uint64_t sg2 = __builtin_amdgcn_s_memtime();
-      if (sg2 - sg1 > seg_max[1]) seg_max[1] = sg2 - sg1;          // (the control words)
-      if (sg0 - sg_prev > seg_max[2]) seg_max[2] = sg0 - sg_prev;  // (from the last look's control words to this look's start: the sleep, a pass)
-      sg_prev = sg2;
+      if constexpr (DIAG) {
+        asm volatile("s_waitcnt vmcnt(0)" :: "v"(ctl_word) : "memory");
+        const uint64_t sg2 = __builtin_amdgcn_s_memtime();
+        if (sg2 - sg1 > seg_max[1]) seg_max[1] = sg2 - sg1;          // (the control words)
+        if (sg0 - sg_prev > seg_max[2]) seg_max[2] = sg0 - sg_prev;  // (from the last look's control words to this look's start: the sleep, a pass)
+        sg_prev = sg2;
+      }
       uint32_t stop_seen = __builtin_amdgcn_readlane(ctl_word, 7) | __builtin_amdgcn_readlane(ctl_word, 15);
       {
         const uint32_t w = __builtin_amdgcn_readlane(ctl_word, 23), d = __builtin_amdgcn_readlane(ctl_word, 31);
@@ -834,13 +846,14 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
         if (w >= thr || w + d >= ep.S) stop_seen = 1u;
       }
       const uint64_t now = wall_clock64();
-      {   // diagnostics: the longest interval between two looks of this wavefront by the 100 MHz wall clock, the same interval by the SQ's
+      if constexpr (DIAG) {   // diagnostics: the longest interval between two looks of this wavefront by the 100 MHz wall clock, the same interval by the SQ's
           // own counter (s_memtime), and where the wavefront was in between (0: only this poll loop, 1: a pass)
         const uint64_t sq_now = __builtin_amdgcn_s_memtime();
         if (now - t_last > gap_rt) { gap_rt = now - t_last; gap_sq = sq_now - sq_last; gap_where = did_pass; gap_polls = total_polls; }
         sq_last = sq_now; did_pass = 0u; ++total_polls;
       }
-      pipe_freeze_credit(pc, now, t_last, t_start, wlane == 0);
+      if (fresh_pass) { t_last = now; fresh_pass = false; }
+      else pipe_freeze_credit(pc, now, t_last, t_start, wlane == 0);
       if (now - t_start > pa.soft_ticks) stop_seen = 1u;
       if (now - t_start > pa.cap_ticks) {
         if (wlane == 0) {
@@ -864,8 +877,8 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
     }
     if (!go) break;
     did_pass = 1u;
-    uint64_t ph_t = __builtin_amdgcn_s_memtime();
-#define AZMI_GEN_SEG(i) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); if (t_ - ph_t > ph_max[i]) ph_max[i] = t_ - ph_t; ph_t = t_; } while (0)
+    uint64_t ph_t = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
+#define AZMI_GEN_SEG(i) do { if constexpr (DIAG) { const uint64_t t_ = __builtin_amdgcn_s_memtime(); if (t_ - ph_t > ph_max[i]) ph_max[i] = t_ - ph_t; ph_t = t_; } } while (0)
     AZMI_GEN_PHASE(4);
     // ---- an answer token: the slot is back once req_seq shows the token's number; its granules become the slot's (v, pi) rows
     if (my_slot != kNoSlot && tok_seq != 0u) {
@@ -957,7 +970,7 @@ __global__ __launch_bounds__(NT, 2) void k_pipe_tree_generic(PipeKernArgs ka) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   AZMI_GEN_PHASE(9);
-  if (threadIdx.x == 0 && diag_on) {      // (wavefront 0's longest interval between two looks: 10 us units by the wall clock | by the SQ clock, raw ticks >> 10 | where | after how many polls)
+  if (DIAG && threadIdx.x == 0 && diag_on) {      // (wavefront 0's longest interval between two looks: 10 us units by the wall clock | by the SQ clock, raw ticks >> 10 | where | after how many polls)
     for (int i = 0; i < 5; ++i) wc->pad[18 + i] = static_cast<uint32_t>(ph_max[i] >> 10);
     wc->pad[15] = static_cast<uint32_t>(seg_max[0] >> 10); wc->pad[16] = static_cast<uint32_t>(seg_max[1] >> 10); wc->pad[17] = static_cast<uint32_t>(seg_max[2] >> 10);
     wc->pad[10] = static_cast<uint32_t>(gap_rt / 1000u); wc->pad[11] = static_cast<uint32_t>(gap_sq >> 10); wc->pad[12] = gap_where; wc->pad[13] = gap_polls; wc->pad[14] = total_polls;
@@ -1031,6 +1044,7 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
       uint32_t final_looks = 0;              // empty looks at the window after the tree side had left
       uint64_t t_empty = 0;                  // when this claim first found nothing at its position
       uint32_t empty_looks = 0;              // looks that found nothing (lane 0 counts)
+      unsigned long long sims_seen = 0; uint64_t t_prog = 0;     // a surplus workgroup's view of the tree side's progress (its slow poll)
       for (;;) {
         if (wdone == wn) {
           // the window's size follows the load (MODE 0): with a backlog of requests the 6-board tile (capacity: 28 M evaluations/s on
@@ -1082,7 +1096,7 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
         }
         // nothing there: is the epoch over?  stop is up (no tree workgroup that arrives from now on sends anything) and every
         // tree workgroup that did arrive has left: tail is final, and what lies at or beyond it never comes
-        uint32_t over = 0, stale = 0, idle = 0;
+        uint32_t over = 0, stale = 0, idle = 0, leave = 0;
         if (tid == 0) {
           // A position more than half a ring BEHIND the tail will never show this lap's tag again: its request was overwritten a lap
           // later before this workgroup could look (seen once in ~1e10 requests: the workgroup sat 2 laps behind - it had been
@@ -1110,6 +1124,17 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
           // tree kernel's wavefronts were seen to stand still for 0.3 s (profiles/r5_repro_generic_freeze_credit.txt) and for more than
           // 2 s (r5_repro_generic_8xcap.txt) while this kernel kept running: they credit such a freeze and finish normally, this side
           // must outwait it; a tree kernel that never comes is still an error after 10 s, not a hang)
+          // (round 6, ADVICE r5: what round 5's captures showed is that tree wavefronts can stand still for as long as HUNDREDS of idle
+          // net workgroups stay resident beside them, and run on the moment those leave.  An epoch launches no more net workgroups than
+          // its slots can keep busy (net_launch), so this only arises under AZMI_PIPE_NET_ALL; there a workgroup the slots do not need
+          // (index >= net_needed) that has been idle, in its slow poll, beside a tree side that HAS arrived and whose simulation count
+          // has not moved for 1.25 caps gives its place back instead of outwaiting the freeze: its window is given up like a stale one
+          // (k_pipe_settle sends a request that still lands there again), no error.  The needed workgroups keep the long patience.)
+          if (idle != 0u && !over && blockIdx.x >= pa.net_needed) {
+            const unsigned long long s_now = g_ld(&pe->sims);
+            if (s_now != sims_seen || t_prog == 0) { sims_seen = s_now; t_prog = now; }
+            else if (g_ld(&pe->tree_arrived) != 0u && now - t_prog > pa.cap_ticks + (pa.cap_ticks >> 2)) { stale = 1; leave = 1; }
+          }
           if (!over && now - t_start > 40u * pa.cap_ticks) {
             // (what the stalled workgroup saw, for the error message: dbg[8..14) = stop, tree workgroups done / arrived, ring tail,
             // the window position it waits at, 10 us units since its start)
@@ -1124,6 +1149,7 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
         if (__builtin_amdgcn_readfirstlane(stale)) {
           if (tid == 0) { atomicAdd(&pe->lost, left); atomicAdd(&pc->lost_total, left); }
           wdone = wn;          // (the next turn of the loop draws a new window)
+          if (__builtin_amdgcn_readfirstlane(leave)) { n = 0; break; }      // a surplus workgroup gives its place back
           continue;
         }
         // A workgroup that has found nothing for 20 us polls every ~14 us instead of every 0.5 us (7 us more latency for a request that
@@ -1765,7 +1791,11 @@ int pipe_calibrate(azmi_pm* pm, PipeState* ps, hipStream_t st, const azmi_net_c4
 }
 
 void pipe_launch_tree(azmi_pm* pm, PipeState* ps, const PipeArrays& pa, hipStream_t st, bool prof) {
-  if (ps->kind == 2) k_pipe_tree_generic<Connect4, 256><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
+  if (ps->kind == 2) {
+    static const bool diag = getenv("AZMI_PIPE_DIAG") != nullptr;
+    if (diag) k_pipe_tree_generic<Connect4, 256, true><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
+    else k_pipe_tree_generic<Connect4, 256><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
+  }
   else if (pm->ep.gumbel_on) k_pipe_tree<Connect4, 256, false, true, true><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
   else if (pa.n_groups > 1u) k_pipe_tree<Connect4, 256, false, true><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
   else if (prof) k_pipe_tree<Connect4, 256, true><<<ps->tree_wgs, 256, 0, st>>>(PipeKernArgs{pm->ep, pm->ar, pa});
@@ -1964,6 +1994,7 @@ static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_ne
   // an epoch must end long before the wall-clock cap (a stall detector, 250 ms): with the move step inside the epoch nothing else ends it,
   // so the quota is held to 1024 simulations per slot (~50 ms at the slowest per-slot rate measured)
   pa.quota = std::min<uint64_t>(sims_per_epoch, 1024ull * pm->ep.S);
+  pa.net_needed = std::max<uint32_t>(8u, (pm->ep.S + 2u) / 3u + 8u);
   // an epoch also ends when this share of the slots waits for the move step (all of them: the start of a run)
   double idle_frac = 0.125;
   if (const char* e = getenv("AZMI_PIPE_IDLE_FRAC")) idle_frac = atof(e);
@@ -2087,7 +2118,7 @@ static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_ne
       if (!tree_only && hipEventElapsedTime(&ms, ps->tev[4 * e + 0], ps->tev[4 * e + 1]) == hipSuccess) net_us += 1e3 * ms;
       if (hipEventElapsedTime(&ms, ps->tev[4 * e + 2], ps->tev[4 * e + 3]) == hipSuccess) tree_us += 1e3 * ms;
     }
-    out_stats[10] = static_cast<uint64_t>(net_us); out_stats[11] = static_cast<uint64_t>(tree_us); out_stats[12] = epochs; out_stats[13] = host_enqueue_us; out_stats[14] = static_cast<uint64_t>(ps->calib_rounds & 0xFFu) | (static_cast<uint64_t>(std::min<unsigned long long>(hc.prof[14], 0xFFFFFFull)) << 8) | (static_cast<uint64_t>(hc.lost_total) << 32); out_stats[15] = hc.l0_hits;
+    out_stats[10] = static_cast<uint64_t>(net_us); out_stats[11] = static_cast<uint64_t>(tree_us); out_stats[12] = epochs; out_stats[13] = host_enqueue_us; out_stats[14] = static_cast<uint64_t>(ps->calib_rounds & 0xFFu) | (static_cast<uint64_t>(std::min<unsigned long long>(hc.freezes, 0xFFFFFFull)) << 8) | (static_cast<uint64_t>(hc.lost_total) << 32); out_stats[15] = hc.l0_hits;
     if (getenv("AZMI_PIPE_PROF")) {
       fprintf(stderr, "pipe prof:");
       for (int i = 0; i < 16; ++i) fprintf(stderr, " %llu", hc.prof[i]);
@@ -2132,7 +2163,7 @@ static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_ne
                           hc.err, he.tree_arrived, ps->tree_wgs, he.net_arrived, ps->net_launch, hc.head, hc.tail, he.sims, he.ended, he.dead, he.stop,
                           he.tree_done, hc.tiles, hc.tile_boards, he.tree_late / 100u, he.net_late / 100u,
                           hc.dbg[1], hc.dbg[2], hc.dbg[3], hc.dbg[8], hc.dbg[9], hc.dbg[10], hc.dbg[11], hc.dbg[12], hc.dbg[13],
-                          static_cast<unsigned long long>(hc.prof[14]), static_cast<double>(hc.prof[15]) * 1e-5);
+                          static_cast<unsigned long long>(hc.freezes), static_cast<double>(hc.freeze_max) * 1e-5);
   if (hc.err && getenv("AZMI_PIPE_DEBUG")) {
     fprintf(stderr, "pipeline dbg:");
     for (int i = 0; i < 18; ++i) fprintf(stderr, " %u", hc.dbg[i]);

@@ -449,6 +449,11 @@ int azmi_run_rounds(azmi_pm* const* pms, azmi_net* net, uint32_t k, uint32_t rou
  *      credited against the time caps, not errors - since creation (bits 8-31) | requests given up and sent again since creation
  *      (bits 32-63).  An epoch launches min(the measured places, S / 3 + 8) net workgroups: a slot has at most one request out and
  *      a tile takes three.
+ *      Worst case of ONE epoch: the tree side's stall detector is the 250 ms cap (AZMI_PIPE_CAP_MS); the net side only waits for
+ *      the tree side and outwaits it for 40 caps = 10 s before it raises error bit 64 itself - a tree kernel that never starts
+ *      (the host held up between the two launches, no place on the chip) is an error after 10 s, not a hang.  A net workgroup beyond
+ *      the S / 3 + 8 the slots can use (only launched under AZMI_PIPE_NET_ALL) that idles beside a tree side without progress for
+ *      1.25 caps leaves instead.
  *      out_stats (may be NULL): [0] net tiles run since the pipeline was created, [1] boards in them, [2] simulations of the
  *      last epoch, [3] / [4] tree / net workgroups that started in it, [5] its insert-log entries, [6] / [7] net / tree
  *      workgroups launched, [8] / [9] the latest start of a tree / net workgroup after the epoch's first, in microseconds (all
@@ -489,6 +494,9 @@ int azmi_run_rounds_groups(azmi_pm* const* pms, azmi_net* const* nets, uint32_t 
 /* ---- the path's one exchange step: finished self-play samples go to rank 0 over RCCL / xGMI ---------------------------
  * Replaces the reference's hist_saver (game_runner.py:729-747: one process, a queue) for one process per GPU.  No collective runs
  * during the search.  librccl is loaded (dlopen) by the first of these calls; a one-GPU process that never gathers does not need it.
+ *   azmi_comm_available  AZMI_OK when librccl and every entry point used here load in this process (no communicator is made): what
+ *                        the ranks agree on BEFORE any of them enters ncclCommInitRank - a rank that would fail there strands the
+ *                        others inside it
  *   azmi_comm_unique_id  rank 0: the 128 bytes every rank passes to azmi_comm_create (carried there by the launcher's own channel:
  *                        bench.py broadcasts them with torch.distributed)
  *   azmi_comm_create     ncclCommInitRank on `device`
@@ -498,6 +506,7 @@ int azmi_run_rounds_groups(azmi_pm* const* pms, azmi_net* const* nets, uint32_t 
  *                        in rank order, unpadded, into dst[i] (device memory for sum(counts) rows; ignored on the other ranks):
  *                        grouped ncclSend / ncclRecv, its own rows by a device copy.  Asynchronous on `stream`. */
 typedef struct azmi_comm azmi_comm;
+int azmi_comm_available(void);
 int azmi_comm_unique_id(void* out128);
 int azmi_comm_create(const void* id128, int rank, int world, int device, azmi_comm** out);
 void azmi_comm_destroy(azmi_comm* comm);

@@ -1,7 +1,7 @@
 """the persistent net kernel ALONE on a pre-filled request ring (azmi_debug_pipe_net_bench): the launch rocprofv3 --pmc can
 count.  Counter collection serialises dispatches, and an epoch of the pipeline needs its tree and net kernels co-resident, so
 the HBM-side traffic of k_pipe_net is taken here: N positions drained by the bench's workgroup count, bytes per position =
-counter / N (scripts/gpu_round3_profiles.sh)."""
+counter / N (scripts/gpu_round6_profiles.sh)."""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "alphazero-pybind11_amd"))

@@ -95,3 +95,41 @@ def test_gather_rows_and_statistics_world8():
     assert cmean == [float(r) for r in expect_owner] and v0 == [r + 0.5 for r in expect_owner]
     assert stats == [36.0 * i for i in range(32)]             # sum over ranks of (rank + 1) = 36
     assert tmax == 7.0
+
+
+def _worker_native_fail(rank, world, port, q, failing_rank):
+    """bench.py's road choice when the native communicator cannot be made on one rank (rank 0 raised before the broadcast
+    the others were waiting in, and the job hung): every rank must leave NativeGather with the same exception after the same
+    collectives, agree on the fallback, and gather through torch.distributed."""
+    sys.path.insert(0, os.path.join(ROOT, "alphazero-pybind11_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["AZMI_COMM_TEST_FAIL_RANK"] = str(failing_rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from alphazero import gather
+    ng, why = None, ""
+    try:
+        ng = gather.NativeGather(rank, world, 0)
+    except RuntimeError as e:
+        why = str(e)
+    ok = torch.tensor([1.0 if ng is not None else 0.0])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)                  # bench.py's agreement: same collective on every rank
+    rows = torch.full((2 + rank, 3), float(rank))
+    res = gather.gather_rows_to_rank0([rows], rank, world)     # the fallback road
+    q.put((rank, ng is None, "cannot be made on every rank" in why, ok.item(), None if res is None else tuple(res[0].shape)))
+    dist.destroy_process_group()
+
+
+def test_native_gather_failure_is_agreed_on_by_every_rank():
+    for failing_rank in (0, 1):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = 33500 + (os.getpid() % 2000) + failing_rank
+        procs = [ctx.Process(target=_worker_native_fail, args=(r, 2, port, q, failing_rank)) for r in range(2)]
+        for p in procs:
+            p.start()
+        outs = sorted(q.get(timeout=120) for _ in range(2))
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+        assert outs[0] == (0, True, True, 0.0, (5, 3)) and outs[1] == (1, True, True, 0.0, None), outs

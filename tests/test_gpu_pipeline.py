@@ -722,8 +722,15 @@ def test_self_play_auto_falls_back_when_the_pipeline_cannot_run(monkeypatch):
     monkeypatch.setenv("AZMI_PIPE_SOFT_MS", "1000")
     res, _ = selfplay.self_play(az.Connect4GS, pp, hip, seed=5)
     assert res.games == 96
+    # round 6: the change of driver is COUNTED in the result, and a caller that measures throughput can forbid it
+    assert res.fallbacks == 1 and res.driver_used == "rounds" and res.pipeline_retries == 3
+    with pytest.raises(RuntimeError, match="max_fallbacks"):
+        selfplay.self_play(az.Connect4GS, pp, hip, seed=5, max_fallbacks=0)
     with pytest.raises(RuntimeError, match="pipeline"):
         selfplay.self_play(az.Connect4GS, pp, hip, seed=5, driver="pipeline")
+    monkeypatch.delenv("AZMI_PIPE_CAP_MS"); monkeypatch.delenv("AZMI_PIPE_SOFT_MS")
+    ok, _ = selfplay.self_play(az.Connect4GS, pp, hip, seed=5)
+    assert ok.games == 96 and ok.fallbacks == 0 and ok.driver_used == "pipeline" and ok.pipeline_retries == 0
 
 
 def test_pipeline_runs_the_bf16x3_tier(oracle):
