@@ -396,8 +396,14 @@ struct TaflX {
   }
   __host__ __device__ __forceinline__ static bool corner(int h, int w) { return (h == 0 || h == H - 1) && (w == 0 || w == W - 1); }
   __host__ __device__ __forceinline__ static bool occupied(const State& s, uint32_t sq) { return bit(s.def, sq) || bit(s.atk, sq) || s.king == sq; }
+  // (by VALUE: written as `p == 0 ? bit(s.atk, sq) : bit(s.def, sq)` the two loads were merged into one load through a SELECT OF
+  // POINTERS with a run-time offset - the whole BigSlot object that holds the state then stays in memory, and with it the by-value
+  // kernel arguments it refers to: 1.2 KB of private scratch per lane and flat accesses in every OpenTafl kernel, rounds 2-5)
   __host__ __device__ __forceinline__ static bool own_piece(const State& s, uint32_t p, uint32_t sq) {
-    return p == 0 ? bit(s.atk, sq) : (bit(s.def, sq) || s.king == sq);
+    const uint64_t alo = s.atk[0], ahi = s.atk[1], dlo = s.def[0], dhi = s.def[1];
+    const uint64_t lo = p == 0 ? alo : dlo, hi = p == 0 ? ahi : dhi;
+    const bool on = (((sq < 64 ? lo : hi) >> (sq & 63)) & 1ULL) != 0;
+    return on || (p != 0 && s.king == sq);
   }
   // is_valid_square, brandubh_gs.cc:138-154 / opentafl_gs.cc:137-153
   __host__ __device__ __forceinline__ static bool valid_square(const State& s, bool is_king, int h, int w) {

@@ -1590,6 +1590,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void k_
   __shared__ BigScratch<GM> sm;
   round_big_body<GM, false, 1>(ep, ar, sm);
 }
+// (StarGambit, round 6: the same lean kernel with the whole register file - at two waves per SIMD its unit-per-lane rules spill)
+template <class GM>
+__global__ __launch_bounds__(64) void k_round_big_sim1(EngineParams ep, EngineArrays ar) {
+  __shared__ BigScratch<GM> sm;
+  round_big_body<GM, false, 1>(ep, ar, sm);
+}
 template <class GM>
 __global__ __launch_bounds__(64) void k_round_big_move(EngineParams ep, EngineArrays ar) {
   __shared__ BigScratch<GM> sm;

@@ -67,7 +67,8 @@ struct PipeCtl {          // zeroed when the pipeline is created; lives across e
   // freezes credited by pipe_freeze_credit (count, longest gap in ticks): words of their own (they shared prof[14] / [15]
   // with the PROF build's level / move counters, so a profiled run reported garbage as freezes)
   unsigned long long freezes, freeze_max;
-  uint32_t pad7[28];
+  unsigned long long tile_hist[6];  // net tiles by the boards they carried (1 .. 6): printed by AZMI_PIPE_PROF
+  uint32_t pad7[16];
   uint32_t pad2a, pad2;
   unsigned long long tiles;         // net tiles run
   unsigned long long tile_boards;   // boards in them

@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(256, 2) void k_pipe_net(azmi_net_dev::NetDesc nd, a
     { const uint64_t nowp = wall_clock64(); pf_wait += nowp - pf_mark; pf_mark = nowp; }
     const uint32_t n = xs[0];
     if (n == 0) break;
-    if (tid == 0) { atomicAdd(&pc->tiles, 1ull); atomicAdd(&pc->tile_boards, static_cast<unsigned long long>(n)); }
+    if (tid == 0) { atomicAdd(&pc->tiles, 1ull); atomicAdd(&pc->tile_boards, static_cast<unsigned long long>(n)); atomicAdd(&pc->tile_hist[(n - 1u) % 6u], 1ull); }
     __syncthreads();
     c4::PipeIO pio{pa.res, xs + 8, xs + 16, kResStride, kResV, pa.l0, xs + 96, reinterpret_cast<const unsigned long long*>(xs + 32) + 16,
                    reinterpret_cast<const unsigned long long*>(xs + 32), xs + 24};
@@ -2122,6 +2122,11 @@ static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_ne
     if (getenv("AZMI_PIPE_PROF")) {
       fprintf(stderr, "pipe prof:");
       for (int i = 0; i < 16; ++i) fprintf(stderr, " %llu", hc.prof[i]);
+      fprintf(stderr, "\n");
+    }
+    if (getenv("AZMI_PIPE_PROF") || getenv("AZMI_PIPE_HIST")) {
+      fprintf(stderr, "pipe tile hist (tiles of 1 .. 6 boards since creation):");
+      for (int i = 0; i < 6; ++i) fprintf(stderr, " %llu", hc.tile_hist[i]);
       fprintf(stderr, "\n");
     }
   }

@@ -8,13 +8,16 @@ import alphazero as az
 from alphazero import torch_net, _capi
 import bench
 lib = _capi.lib if hasattr(_capi, "lib") else az.lib
-S, K = int(os.environ.get("S", 2048)), 4
-spec = torch_net.tawlbwrdd_spec()
+GAME = os.environ.get("GAME", "tawlbwrdd")      # tawlbwrdd | stargambit | opentafl
+S, K = int(os.environ.get("S", 1024 if GAME == "stargambit" else 2048)), 4
+SIMS = int(os.environ.get("SIMS", 800 if GAME == "stargambit" else 400))
+spec = {"tawlbwrdd": torch_net.tawlbwrdd_spec, "stargambit": torch_net.stargambit_spec, "opentafl": torch_net.opentafl_spec}[GAME]()
+Game = {"tawlbwrdd": az.TawlbwrddGS, "stargambit": az.StarGambitUnifiedGS, "opentafl": az.OpenTaflGS}[GAME]
 net = az.HipLeafNet(torch_net.random_init(spec, seed=0), spec)
 pms, sts = [], []
 for k in range(K):
-    pp = bench.selfplay_params(az, S // K, 400, 1 << 30, cache=0, gumbel=bool(os.environ.get("GUMBEL")))
-    pms.append(az.PlayManager(az.TawlbwrddGS(), pp, seed=11 + k)); sts.append(torch.cuda.Stream())
+    pp = bench.selfplay_params(az, S // K, SIMS, 1 << 30, cache=(200_000 // K if GAME == "stargambit" else 0), gumbel=bool(os.environ.get("GUMBEL")))
+    pms.append(az.PlayManager(Game(), pp, seed=11 + k)); sts.append(torch.cuda.Stream())
 sp = [s.cuda_stream for s in sts]
 az.run_rounds(pms, net, 1024, sp); torch.cuda.synchronize()
 out = (C.c_ulonglong * 16)()

@@ -1,5 +1,6 @@
 """Writes tests/REFERENCE_TEST_COVERAGE.md: every TEST of the reference's C++ test files for the hot path
-(/root/reference/src/{mcts,play_manager,star_gambit_gs,star_gambit_unified_gs}_test.cc - read here as text, never shipped) mapped
+(/root/reference/src/{mcts,play_manager,star_gambit_gs,star_gambit_unified_gs,connect4_gs,opentafl_gs,brandubh_gs,tawlbwrdd_gs,
+s3fifo_cache,tafl_helper}_test.cc and the in-boundary cases of test_history.py / test_star_gambit_unified.py - read here as text, never shipped) mapped
 to the test of this repository that mirrors it, or to the reason it is not mirrored.  Run in the build container:
     python tests/make_reference_coverage.py
 The mapping below is the maintained part; the script fails when a reference TEST has no entry (a new reference test)."""
@@ -109,6 +110,70 @@ MAP = {
         "StarGambitUnifiedGS.Symmetry*": "tests/test_oracle_stargambit.py::test_mirror_symmetry_cases_of_the_reference + tests/test_gpu_stargambit.py::test_symmetries_on_the_device_equal_the_oracle",
         "StarGambitUnifiedGS.*": SG + "case_unified_shapes_and_remap (static constants, canonical shape, game-type channels, padding of the 11 x 11 variants, action / deploy remap against the plain games at every step of random games)",
     },
+    # ---- connect4_gs_test.cc (round 6: the files below were mirrored in code since rounds 1-3, but not in this ledger) -----------------
+    "connect4_gs_test.cc": {
+        "Connect4GS.Equals": "tests/test_gpu_gamestate.py::test_reference_connect4_gs_cases (==, != after a move, equal again after the same moves) on the device object",
+        "Connect4GS.Copy": "tests/test_gpu_gamestate.py::test_reference_connect4_gs_cases (copy() equal and independent) + test_connect4_from_board_ctor_and_pickle",
+        "Connect4GS.ValidMoves": "tests/test_oracle_pinned.py::test_connect4_valid_moves (oracle) + tests/test_gpu_gamestate.py::test_reference_connect4_gs_cases (device)",
+        "Connect4GS.PlayMove": "tests/test_oracle_pinned.py::test_connect4_play_move_stacks + tests/test_gpu_gamestate.py::test_reference_connect4_gs_cases",
+        "Connect4GS.WinState": "tests/test_oracle_pinned.py::test_connect4_win_states (the reference's boards: horizontal / vertical / both diagonals, draw, running) + tests/test_gpu_gamestate.py::test_reference_connect4_gs_cases",
+        "Connect4GS.Canonicalize": "tests/test_oracle_pinned.py::test_connect4_canonical + tests/test_gpu_gamestate.py::test_reference_connect4_gs_cases (planes 0 / 1 stones, 2 / 3 the player to move)",
+    },
+    # ---- opentafl_gs_test.cc: every TEST is one entry of tests/tafl_cases.py::OPENTAFL_CASES (same pieces, move and asserted cells / moves / score) ----
+    "opentafl_gs_test.cc": {
+        "OpenTaflGS.RepetitionCount": "tests/tafl_cases.py::OPENTAFL_REPETITION: tests/test_oracle_pinned.py::test_opentafl_rule_known_answers (oracle) + tests/test_gpu_tafl_family.py::test_opentafl_reference_rule_cases_on_device",
+        "OpenTaflGS.StartingPosition": "tests/test_oracle_pinned.py::test_opentafl_rule_known_answers (piece counts, king on the throne, attackers to move) + tests/test_gpu_tafl_family.py::test_opentafl_reference_rule_cases_on_device",
+        "OpenTaflGS.*": "tests/tafl_cases.py::OPENTAFL_CASES entry of the same name, run by tests/test_oracle_pinned.py::test_opentafl_rule_known_answers (oracle, CPU) and tests/test_gpu_tafl_family.py::test_opentafl_reference_rule_cases_on_device (the device object)",
+    },
+    "brandubh_gs_test.cc": {
+        "BrandubhGS.RepetitionCount": "tests/test_oracle_pinned.py::test_brandubh_known_answers + tests/test_gpu_tafl_family.py::test_brandubh_cases_on_device",
+    },
+    "tawlbwrdd_gs_test.cc": {
+        "TawlbwrddGS.RepetitionCount": "tests/test_oracle_pinned.py::test_tawlbwrdd_threefold_repetition + tests/test_gpu_gamestate.py::test_tawlbwrdd_object_walk_matches_oracle / test_a_reference_image_with_a_repetition_map_loads_and_counts_on",
+    },
+    # ---- s3fifo_cache_test.cc: tests/s3fifo_cases.py restates the single-threaded cases once; it runs on the oracle and on the device cache ----
+    "s3fifo_cache_test.cc": {
+        "S3FIFOCache.ConcurrentFindInsert": "not mirrored: a thread-safety test of the reference's mutexes; the device cache has no host threads (probes inside kernels are read-only, "
+                                            "batch inserts take the shard's lock: tests/test_gpu_cache.py::test_engine_with_cache_is_transparent / test_wide_game_engine_with_cache_is_transparent)",
+        "ShardedS3FIFOCache.ConcurrentInsertMany": "not mirrored: as ConcurrentFindInsert (the pipeline's concurrent inserts are covered by tests/test_gpu_pipeline.py::test_in_epoch_answer_table_is_transparent_and_saves_evaluations and the cache-transparency cases)",
+        "S3FIFOCache.CapacityZero": "tests/test_gpu_cache.py::test_playmanager_cache_counters_and_no_cache (max_cache_size = 0: no cache object, nothing stored) + tests/s3fifo_cases.py capacity_one for the smallest real cache",
+        "ShardedS3FIFOCache.*": "tests/s3fifo_cases.py::sharded_insert_distributes_and_stats_aggregate via tests/test_oracle_pinned.py::test_reference_s3fifo_cases_on_the_oracle and tests/test_gpu_cache.py::test_reference_s3fifo_cases_on_the_device_cache",
+        "S3FIFOCache.*": "tests/s3fifo_cases.py case of the same name (snake case), run by tests/test_oracle_pinned.py::test_reference_s3fifo_cases_on_the_oracle (CPU) and tests/test_gpu_cache.py::test_reference_s3fifo_cases_on_the_device_cache (device); op-by-op vs the oracle: test_device_cache_matches_oracle_op_by_op",
+    },
+    "tafl_helper_test.cc": {
+        "TaflHelper.Mirror": "tests/test_oracle_pinned.py::test_symmetry_mirror_known_answer (the reference's 5 x 5 tables) + tests/test_gpu_symmetries.py::test_reference_spot_tables_5x5 (device kernel)",
+        "TaflHelper.Rot90": "tests/test_oracle_pinned.py::test_symmetry_rot90_known_answer + tests/test_gpu_symmetries.py::test_reference_spot_tables_5x5",
+        "TaflHelper.EightSym": "tests/test_gpu_symmetries.py::test_reference_spot_tables_5x5 / test_group_properties_and_oracle (eight images, identity first)",
+        "TaflHelper.*": "tests/test_oracle_pinned.py::test_symmetry_group_properties (bijection, order 4 / 2, eight distinct permutations, geometric equivariance) + tests/test_gpu_symmetries.py::test_group_properties_and_oracle (n = 7, 11 on the device) + tests/test_gpu_tafl_family.py::test_symmetry_kernel_policy_permutation_equals_the_reference_move_maps",
+    },
+}
+
+# Python tests of the reference for this path (pytest functions; only the cases inside the boundary)
+PY_MAP = {
+    "test_history.py": {
+        "_range": (43, 160),      # the .ptz cases; the reservoir / chunk cases below line 160 belong to the training loop (out of scope)
+        "test_roundtrip_float32": "tests/test_history_io.py::test_store_mode_frame_layout_and_round_trip / test_history_triples_round_trip_in_the_reference_layout",
+        "test_roundtrip_integer_values": "tests/test_history_io.py::test_history_triples_round_trip_in_the_reference_layout (values survive bit for bit: the frames are stored, not quantised)",
+        "test_file_size_reduction": "not mirrored: a compression-ratio assertion on the reference's zstd level; history_io writes STORE-mode zstd frames (no compressor in this image) that the real decoder accepts: tests/test_history_io.py::test_store_frames_are_accepted_by_the_real_decoder_and_real_frames_are_read",
+        "test_ptz_extension": "tests/test_history_io.py::test_history_triples_round_trip_in_the_reference_layout (the triples are written as `IIII-BBBB-{canonical,v,pi}-ROWS.ptz`, the pattern glob_file_triples reads back)",
+        "test_empty_tensor_roundtrip": "tests/test_history_io.py::test_store_mode_frame_layout_and_round_trip (zero-row tensors)",
+        "test_hist_save_creates_ptz": "tests/test_gpu_selfplay_harness.py (self_play(data_folder=...) writes the triples) + tests/test_history_io.py::test_history_triples_round_trip_in_the_reference_layout",
+        "test_mixed_format_loading": "tests/test_history_io.py::test_store_frames_are_accepted_by_the_real_decoder_and_real_frames_are_read (frames of the real compressor are read back)",
+        "test_glob_file_triples": "tests/test_history_io.py::test_history_triples_round_trip_in_the_reference_layout (glob of the triples of an iteration)",
+        "test_glob_file_triples_multiple": "tests/test_history_io.py::test_history_triples_round_trip_in_the_reference_layout (several batches per iteration)",
+    },
+    "test_star_gambit_unified.py": {
+        "_range": (1, 10 ** 9),
+        "TestStaticInterface.*": "tests/stargambit_cases.py::case_unified_shapes_and_remap (NUM_MOVES 1709, CANONICAL_SHAPE 36 x 13 x 13, players, symmetries) on the oracle and the device objects",
+        "TestStaticInterface.test_registry_entries": "not mirrored: load_game.py's registry is the reference's config layer (out of scope); the classes it names exist: tests/test_gpu_gamestate.py / alphazero.StarGambit*GS",
+        "TestCanonicalObservation.*": "tests/stargambit_cases.py::case_unified_shapes_and_remap (game-type channels one-hot and broadcast, zero outer ring of the 11 x 11 variants, Battle's valid outer hexes)",
+        "TestActionRemapping.*": "tests/stargambit_cases.py::case_unified_shapes_and_remap (valid_moves size, no outer-ring moves, deploys at the unified offset, random games playable in both spaces)",
+        "TestVariantSelection.test_pinned*": "tests/stargambit_cases.py::case_unified_shapes_and_remap (pinned games of all four variants; the pinned subclasses of py_wrapper.cc:668-705)",
+        "TestVariantSelection.*": "tests/test_oracle_stargambit.py::test_variant_draw_rule_is_the_documented_one + tests/test_gpu_stargambit.py::test_variant_statistics_match_the_oracle (uniform and biased probabilities)",
+        "TestCopy.*": "tests/stargambit_cases.py::case_deploy_switches_player (copy equal / independent) via tests/test_gpu_gamestate.py",
+        "TestConfigIntegration.*": "not mirrored: config.py / load_game.py validation of the training configuration (out of scope, SURVEY 2); the engine-side knob (variant probabilities) is PlayParams / StarGambitUnifiedGS(probs=...): tests/test_gpu_stargambit.py::test_variant_statistics_match_the_oracle",
+        "TestComputeUnifiedProbs.*": "not mirrored: compute_unified_probs belongs to the training loop's sample balancing (game_runner.py, out of scope); its OUTPUT is the probs vector the boundary takes",
+    },
 }
 
 
@@ -147,6 +212,28 @@ def main():
                 mirrored += 1
             rows.append(f"| `{fname}:{ln}` {name} | {val} |")
         out += [f"## {fname}: {len(tests)} tests, {mirrored} mirrored, {len(tests) - mirrored} not mirrored (reason given)", "", "| reference test | mirrored by |", "|---|---|"] + rows + [""]
+    # the reference's Python tests inside the boundary
+    for fname, table in PY_MAP.items():
+        lo, hi = table["_range"]
+        tests, cls = [], None
+        for i, line in enumerate(open(os.path.join(REF, fname)), 1):
+            mc = re.match(r"class (\w+)", line)
+            if mc:
+                cls = mc.group(1)
+            m = re.match(r"(\s*)def (test_\w+)\(", line)
+            if m and lo <= i <= hi:
+                tests.append((i, f"{cls}.{m.group(2)}" if (m.group(1) and cls) else m.group(2)))
+        mirrored, rows = 0, []
+        for ln, name in tests:
+            val = lookup({k: v for k, v in table.items() if k != "_range"}, name)
+            if val is None:
+                missing.append(f"{fname}:{ln} {name}")
+                val = "UNMAPPED"
+            if not val.startswith("not mirrored"):
+                mirrored += 1
+            rows.append(f"| `{fname}:{ln}` {name} | {val} |")
+        out += [f"## {fname}" + (f" (lines {lo}-{hi}: the cases inside the boundary)" if hi < 10 ** 9 else "") + f": {len(tests)} tests, {mirrored} mirrored, {len(tests) - mirrored} not mirrored (reason given)", "",
+                "| reference test | mirrored by |", "|---|---|"] + rows + [""]
     if missing:
         sys.stderr.write("unmapped reference tests:\n  " + "\n  ".join(missing) + "\n")
         sys.exit(1)
