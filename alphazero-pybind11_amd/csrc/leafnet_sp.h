@@ -414,9 +414,17 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
         const int b = t >> 7, c = (t >> 2) & 31, part = t & 3;
         constexpr int per = (PIX + 3) / 4;
         const int p0 = part * per, p1 = (p0 + per < PIX) ? p0 + per : PIX;
+        // (round 6: the quarter's reads are all issued before the first add - as a loop with a run-time trip count it was 31
+        // dependent LDS round trips per half, 4 us of a 61 us Tawlbwrdd tile.  The sum is the same sum in the same order: the entries
+        // past the quarter's end are + 0.0f onto a sum of relu outputs)
         float acc = 0.0f;
-        if (b < TBW)
-          for (int p = p0; p < p1; ++p) acc += pool_buf[(b * PIX + p) * 32 + c];
+        if (b < TBW) {
+          float x[per];
+#pragma unroll
+          for (int i = 0; i < per; ++i) x[i] = (p0 + i < p1) ? pool_buf[(b * PIX + p0 + i) * 32 + c] : 0.0f;
+#pragma unroll
+          for (int i = 0; i < per; ++i) acc += x[i];
+        }
         const float s01 = acc + __shfl_xor(acc, 1, 64);
         out[half][it] = (s01 + __shfl_xor(s01, 2, 64)) / static_cast<float>(PIX);
       }
@@ -498,18 +506,55 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
     return;
   }
   barrier_lds();
-  for (int b = wave; b < TBW; b += NWV) {        // one wave per board: softmax = exp(log_softmax), neural_net.py:494,816
-    if (board0 + b >= batch) continue;
-    const uint32_t out_row = rows ? rows[board0 + b] : board0 + b;
-    const float* row = lg + b * M;
+  // softmax = exp(log_softmax), neural_net.py:494,816.  Round 6: every exponential is taken ONCE (it goes back into the logits' place in
+  // LDS and is scaled in the last pass; rounds 2-5 took it twice) and, where the tile has fewer boards than waves (11 x 11: two boards),
+  // a board's row is cut into PB contiguous parts, one wave each - the two 2662-entry rows of a Tawlbwrdd tile kept two of the four
+  // waves busy for 8.8 us of a 61 us tile (profiles/r6_sp_tile_timing.txt).  The maximum and the sum of a row are combined from the
+  // parts in part order, each part's sum in the order of rounds 2-5 (lane-strided, then the butterfly): a function of the row alone,
+  // wherever the board sits in its tile or batch.
+  constexpr int PB = (TBW < NWV && NWV % TBW == 0) ? NWV / TBW : 1;     // waves per board
+  if constexpr (PB > 1) {
+    float* const red = prm;                                   // [TBW][PB] maxima, then sums (the parameters are dead by now)
+    const int b = wave / PB, part = wave % PB;
+    const bool on = board0 + b < batch;
+    const int per = (M + PB - 1) / PB, e0 = part * per, e1 = (e0 + per < M) ? e0 + per : M;
+    float* const row = lg + b * M;
     float mx = -__builtin_inff();
-    for (int e = lane; e < M; e += 64) mx = fmaxf(mx, row[e]);
+    for (int e = e0 + lane; e < e1; e += 64) mx = fmaxf(mx, row[e]);
     for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if (lane == 0) red[wave] = mx;
+    barrier_lds();
+    mx = red[b * PB];
+#pragma unroll
+    for (int q = 1; q < PB; ++q) mx = fmaxf(mx, red[b * PB + q]);
     float sum = 0.0f;
-    for (int e = lane; e < M; e += 64) sum += expf(row[e] - mx);
+    for (int e = e0 + lane; e < e1; e += 64) { const float x = expf(row[e] - mx); row[e] = x; sum += x; }
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-    float* out = pi_out + static_cast<size_t>(out_row) * M;
-    for (int e = lane; e < M; e += 64) out[e] = expf(row[e] - mx) / sum;
+    barrier_lds();                                            // every wave has read the maxima
+    if (lane == 0) red[wave] = sum;
+    barrier_lds();
+    sum = red[b * PB];
+#pragma unroll
+    for (int q = 1; q < PB; ++q) sum += red[b * PB + q];
+    if (on) {
+      const uint32_t out_row = rows ? rows[board0 + b] : board0 + b;
+      float* out = pi_out + static_cast<size_t>(out_row) * M;
+      for (int e = e0 + lane; e < e1; e += 64) out[e] = row[e] / sum;
+    }
+  } else {
+    for (int b = wave; b < TBW; b += NWV) {        // one wave per board
+      if (board0 + b >= batch) continue;
+      const uint32_t out_row = rows ? rows[board0 + b] : board0 + b;
+      float* const row = lg + b * M;
+      float mx = -__builtin_inff();
+      for (int e = lane; e < M; e += 64) mx = fmaxf(mx, row[e]);
+      for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      float sum = 0.0f;
+      for (int e = lane; e < M; e += 64) { const float x = expf(row[e] - mx); row[e] = x; sum += x; }
+      for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+      float* out = pi_out + static_cast<size_t>(out_row) * M;
+      for (int e = lane; e < M; e += 64) out[e] = row[e] / sum;
+    }
   }
 }
 

@@ -991,7 +991,7 @@ def main():
                 # the tree phase of a wide game's shard-round is three launches (k_round_big_sim + k_round_big_move + k_compact; the
                 # one-kernel form k_round_big / k_round_big_o2 where the split is off): their bytes are SUMMED (the last
                 # matching row used to win, which was the move step alone)
-                tree_rows = ("k_round_big_sim<", "k_round_big_move<", "k_round_big<", "k_round_big_o2<", "k_compact<") if tafl else ("k_sim<", "k_round<azmi::Connect4")
+                tree_rows = ("k_round_big_sim<", "k_round_big_sim1<", "k_round_big_move<", "k_round_big<", "k_round_big_o2<", "k_compact<", "k_cache_insert<") if tafl else ("k_sim<", "k_round<azmi::Connect4")
                 tree_sum, tree_seen = 0.0, []
                 for line in open(pmc_net):
                     f = line.strip().split(",")
