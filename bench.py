@@ -248,8 +248,8 @@ def cpu_baseline(az, sims, seconds, S, hip_net, cache, threads=None, game="conne
     fn = C.cast(lib.azmi_net_eval_host, C.c_void_p).value
     out = {"unit": "games/s", "cores": threads, "kind": "port"}
     gid = orc.GAME_TAWLBWRDD if game == "tawlbwrdd" else orc.GAME_CONNECT4
-    gname = "Tawlbwrdd" if game == "tawlbwrdd" else "Connect4"
-    netname = "configs/tawlbwrdd.yaml net" if game == "tawlbwrdd" else "6b64c net"
+    gname = {"tawlbwrdd": "Tawlbwrdd", "stargambit": "star_gambit_unified"}.get(game, "Connect4")
+    netname = {"tawlbwrdd": "configs/tawlbwrdd.yaml net", "stargambit": "configs/star_gambit_unified.yaml net"}.get(game, "6b64c net")
 
     def leg(eval_kind, slots_total, nsims, secs, cache_total, nthreads):
         """one timed run: `nthreads` oracle PlayManagers side by side; returns (games/s, sims/s, evals/s) after warm-up"""
@@ -261,7 +261,9 @@ def cpu_baseline(az, sims, seconds, S, hip_net, cache, threads=None, game="conne
             pp.history_enabled = True
             if eval_kind == "random":
                 pp.eval_type = [1, 1]
-            pms.append(orc.PlayManager(gid, pp, 1000 + 7919 * t, per_slot_rng=False, record_moves=False))
+            if game == "stargambit":      # configs/star_gambit_unified.yaml: the four variants at equal probability, temperatures as the GPU run's
+                pp.start_temp, pp.final_temp, pp.temp_decay_half_life_by_variant = 1.2, 0.2, [3.0, 4.0, 5.0, 8.0]
+            pms.append(orc.PlayManager(orc.Game.sg_unified() if game == "stargambit" else gid, pp, 1000 + 7919 * t, per_slot_rng=False, record_moves=False))
         marks = []
 
         def snap():
@@ -286,8 +288,17 @@ def cpu_baseline(az, sims, seconds, S, hip_net, cache, threads=None, game="conne
         dt = t1 - t0
         return (g1 - g0) / dt, (s1 - s0) / dt, (e1 - e0) / dt, g1 - g0, dt
 
+    if hip_net is not None and game == "stargambit":
+        # (round 6: a short leg for configs[4] - the oracle port plays a StarGambit game in seconds, so the rate is the sample's
+        # simulations/s over the GPU run's simulations per game; a leg that cannot run leaves the RANDOM-evaluator figure below)
+        try:
+            g, s, e, n, dt = leg("nn", S, sims, seconds, cache, threads)
+        except Exception as ex:      # noqa: BLE001 (recorded in the line)
+            out["nn_leg_error"] = str(ex)[:160]
+            hip_net = None
     if hip_net is not None:
-        g, s, e, n, dt = leg("nn", S, sims, seconds, cache, threads)
+        if game != "stargambit":
+            g, s, e, n, dt = leg("nn", S, sims, seconds, cache, threads)
         out["value"] = g
         if n < 64 and sims_per_game:      # a long game does not finish inside a bounded sample: the rate follows from the simulations
             out["value"] = s / sims_per_game
@@ -303,9 +314,9 @@ def cpu_baseline(az, sims, seconds, S, hip_net, cache, threads=None, game="conne
     out["tree_only"] = {"games_per_s": g, "sims_per_s": s, "note": f"EvalType.RANDOM (no net), {threads} threads, {n} games in {dt:.1f}s"}
     out["tree_only_sims_per_s"] = s
     if "value" not in out:
-        out["value"] = g
+        out["value"] = g if (n >= 64 or not sims_per_game) else s / sims_per_game
         out["sims_per_s"] = s
-        out["sample"] = out["tree_only"]["note"]
+        out["sample"] = out["tree_only"]["note"] + (f"; value = simulations/s / {sims_per_game:.0f} simulations per game of the GPU run" if (n < 64 and sims_per_game) else "")
     if game != "connect4":
         return out
     # BASELINE configs[0]: Connect4, 64 concurrent games, 100 sims, one worker thread — the reference's own CPU-runnable case
@@ -383,9 +394,10 @@ def orchestrate(args):
     head["tawlbwrdd"] = trim(puct)
     head["tawlbwrdd"]["gumbel"] = trim(gumbel)
     # BASELINE configs[4] (per GPU): star_gambit_unified, 1024 concurrent games, 800 sims, device-side S3-FIFO of 200 000 entries
-    # (configs/star_gambit_unified.yaml:5-15,23-24); no CPU baseline leg (the oracle port plays ~1 game/s: nothing finishes in a sample)
+    # (configs/star_gambit_unified.yaml:5-15,23-24); round 6: a 10 s CPU leg (its rate = the sample's simulations/s over the GPU run's simulations per game)
     if not args.no_stargambit:
-        sgb = run_worker(["--game", "stargambit", "--warmup", "1", "--no-secondary", "--preroll-factor", "0.5", "--steps", "100", "--no-cpu-baseline"], 600)
+        sgb = run_worker(["--game", "stargambit", "--warmup", "1", "--no-secondary", "--preroll-factor", "0.5", "--steps", "100", "--cpu-seconds", "10"]
+                         + (["--no-cpu-baseline"] if args.no_cpu_baseline else []), 700)
         head["stargambit"] = trim(sgb)
     head["config"]["bench_wall_s"] = time.perf_counter() - t0
     flatten_line(head)
@@ -1087,10 +1099,10 @@ def main():
                         out["config"][name]["games_per_s"] = ((s1 - s0) / dt2) / (n_sims / n_games)
                         out["config"][name]["note"] += f"; games/s = this window's simulations/s / the headline's {n_sims / n_games:.0f} simulations per game (a cold-start window of {dt2:.1f}s)"
                     del pms2, tot2, run2
-            if world == 1 and not args.no_cpu_baseline and not sg and not args.gumbel:
+            if world == 1 and not args.no_cpu_baseline and not args.gumbel:
                 sys.stderr.write("bench.py: cpu baseline ...\n"); sys.stderr.flush()
                 # the reference's own cache size: 200 000 entries (config.py:197); Tawlbwrdd: off, as in its GPU run
-                out["cpu_baseline"] = cpu_baseline(az, sims, args.cpu_seconds, S, hip_net, 0 if tafl else 200_000, game="tawlbwrdd" if tafl else "connect4",
+                out["cpu_baseline"] = cpu_baseline(az, sims, args.cpu_seconds, S, hip_net, 200_000 if (sg or not tafl) else 0, game=args.game,
                                                    sims_per_game=(n_sims / n_games) if n_games else None)
         print(json.dumps(out))
     if use_dist:

@@ -27,8 +27,8 @@ MAP = {
         "MCTS.PuctInversionWithNoise": "tests/test_gpu_mcts_object.py::test_call_by_call_parity_with_oracle (noise configurations: priors after add_root_noise equal the oracle's, incl. the inversion)",
         "MCTS.RootFpuZero": "tests/test_gpu_mcts_object.py::test_reference_mcts_property_cases",
         "MCTS.PolicyTargetPruning": "tests/test_gpu_mcts_object.py::test_reference_mcts_property_cases",
-        "MCTS.ShapedDirichletDistribution": "statistical test of the noise distribution: not mirrored as statistics; the shaped-Dirichlet draws are pinned draw by draw instead (tests/test_gpu_rng.py gamma stream vs real libstdc++, tests/test_gpu_parity_connect4.py option tiers with shaped noise: pcg32 position after every move)",
-        "MCTS.ShapedDirichletAlphaDistribution": "as ShapedDirichletDistribution",
+        "MCTS.ShapedDirichletDistribution": "tests/test_gpu_mcts_object.py::test_reference_shaped_dirichlet_distribution_cases (round 6: the reference's assertions on the device object, shaped and uniform noise) + draw by draw: tests/test_gpu_rng.py gamma stream vs real libstdc++",
+        "MCTS.ShapedDirichletAlphaDistribution": "tests/test_gpu_mcts_object.py::test_reference_shaped_dirichlet_distribution_cases (400 seeds instead of 50 trials: every legal move noised in every trial, plus the noise's mean and variance against the symmetric-Dirichlet values)",
         "MCTS.PuctInversionGradual": "tests/test_gpu_mcts_object.py::test_call_by_call_parity_with_oracle (visit counts after every call equal the oracle's under noise)",
         "MCTS.TrainEvalSeparation": "tests/test_gpu_parity_connect4.py::test_playmanager_option_tiers (self_play on / off, eval_temp paths) - the PlayManager flags the case toggles",
         "MCTS.RawPolicyTemperatureInteraction": "tests/test_gpu_mcts_object.py::test_call_by_call_parity_with_oracle (root temperature configurations)",

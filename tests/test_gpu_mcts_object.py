@@ -316,6 +316,42 @@ def test_reference_mcts_property_cases(az):
     assert abs(nn.probs_pruned(1.0).sum() - 1) < 1e-5
 
 
+def test_reference_shaped_dirichlet_distribution_cases(az):
+    """mcts_test.cc:279-355 (ShapedDirichletDistribution, ShapedDirichletAlphaDistribution) on the device object - the one MCTS test of
+    the reference that was only covered draw by draw.  With no visits probs(1.0) returns the root's priors
+    (mcts.cc:575-591), i.e. the priors after add_root_noise (mcts.cc:403-441).  The reference's assertions - a valid distribution,
+    every legal move noised in every trial - and, beyond them, the noise's first two moments over 400 seeds: dumb_eval's uniform
+    policy makes every shaped alpha equal (shaped_sum = 0), so the noise is a symmetric Dirichlet(A / 7 each, A = NOISE_ALPHA_RATIO =
+    10.83) and a prior is 0.75 / 7 + 0.25 x Dir_i: mean 1 / 7, variance 0.25^2 x a (A - a) / (A^2 (A + 1)), a = A / 7."""
+    for shaped in (True, False):                                              # ShapedDirichletDistribution, :279-314
+        gs = az.Connect4GS()
+        m = az.MCTS(2, 2, 7, 0.25, 1.4, 0.0, False, False, shaped, seed=11)
+        leaf = m.find_leaf(gs); v, pi = az.dumb_eval(leaf); m.process_result(gs, v, pi, True)
+        p = m.probs(1.0)
+        assert (p >= 0).all() and abs(float(p.sum()) - 1.0) < 1e-4
+    gs = az.Connect4GS()                                                        # ShapedDirichletAlphaDistribution, :317-355
+    for mv in (3, 0, 3, 0):
+        gs.play_move(mv)
+    valid = gs.valid_moves()
+    trials = 400                                                                # (the reference: 50)
+    rows = []
+    for t in range(trials):
+        m = az.MCTS(2, 2, 7, 0.25, 1.4, 0.0, False, False, True, seed=1000 + t)
+        leaf = m.find_leaf(gs); v, pi = az.dumb_eval(leaf); m.process_result(gs, v, pi, True)
+        p = m.probs(1.0)
+        assert abs(float(p.sum()) - 1.0) < 1e-4 and (p >= 0).all()
+        assert ((p > 0) == (valid == 1)).all(), f"trial {t}: every legal move gets noise, no other move any mass"
+        rows.append(p)
+    x = np.stack(rows).astype(np.float64)
+    assert len({tuple(r) for r in x.round(7)}) == trials                        # 400 seeds, 400 different noise draws
+    A, eps = 10.83, 0.25
+    a = A / 7
+    var = eps * eps * a * (A - a) / (A * A * (A + 1))
+    se = (var / trials) ** 0.5
+    assert np.abs(x.mean(0) - 1.0 / 7).max() < 5 * se, (x.mean(0), se)
+    assert 0.75 * var < x.var(0).min() and x.var(0).max() < 1.3 * var, (x.var(0), var)
+
+
 def _gumbel_mcts(az, m, full=False, seed=7):                   # make_gumbel_mcts, :713-728
     return az.MCTS(2.0, 2, 7, 0.0, 1.0, 0.0, False, False, False, True, m, 50.0, 1.0, full, seed=seed)
 
