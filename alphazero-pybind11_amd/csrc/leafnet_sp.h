@@ -208,6 +208,11 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
   }
 
   // epilogue helper: 4 consecutive channels (mt*16 + quad*4 ..) of the lane's pixel as bf16, into plane `plane0 + quad/2`
+  // (round 6: the convolution epilogues store EVERY lane's pixel, the few padding pixels of a tile (n >= NPIX) included - until then
+  // each of an epilogue's 16 stores sat in an exec-mask region of its own (s_and_saveexec / branch / s_or per store: the lone tile
+  // 62.5 -> 59.3 us, profiles/r6_tile_exp_noguard.txt).  A padding pixel reads all-zero cells at every tap (tap_ok = 0), so its
+  // values are biases: finite, written to slots no real pixel's tap ever reads (taps stay on the reader's own board), never pooled,
+  // never stored.  The heads' scratch (value rows, policy planes, logits) keeps its test: there a padding pixel's index is out of range.)
   auto store4 = [&](int j, int plane0, f32x4 val) {
     bf16x4 o;
     o[0] = static_cast<__bf16>(val[0]); o[1] = static_cast<__bf16>(val[1]);
@@ -225,7 +230,7 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
-        if (!((real_m >> j) & 1u)) continue;
+        // (no `real_m` test here since round 6: see the note at store4)
         f32x4 t;
 #pragma unroll
         for (int r = 0; r < 4; ++r) t[r] = fmaxf(x[j][mt][r], 0.0f);
@@ -357,7 +362,7 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
       const f32x4 b1 = *reinterpret_cast<const f32x4*>(affine + CH + mt * 16 + quad * 4);
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
-        if (!((real_m >> j) & 1u)) continue;
+        // (no `real_m` test here since round 6: see the note at store4)
         f32x4 t;
 #pragma unroll
         for (int r = 0; r < 4; ++r) t[r] = fmaxf(a1[r] * s[j][mt][r] + b1[r], 0.0f);
@@ -380,7 +385,7 @@ __device__ __forceinline__ void tile(const SpDesc& nd, const SpPtrs& np, const f
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
-      if ((real_m >> j) & 1u) store4(j, mt * 2, s[j][mt]);
+      store4(j, mt * 2, s[j][mt]);
   f32x4 hv[NTW][MT], hp[NTW][MT];
   set_bias(hv, prm + PRM_HEAD);
   set_bias(hp, prm + PRM_HEAD + HCS);

@@ -25,7 +25,13 @@
 #include "engine_kernels.h"
 #include "leafnet_c4.h"
 #include "pipe_types.h"
-#include "conveyor_c4.h"
+// The conveyor (round 5's weight-stationary net side: bit-identical to the tile kernel, slower - DESIGN 4.5b) is an EXPERIMENT since
+// round 6: its device code lives in scripts/experiments/conveyor_c4.h and is compiled in only with -DAZMI_WITH_CONVEYOR
+// (AZMI_HIPCC_EXTRA=-DAZMI_WITH_CONVEYOR python -c "import __graft_entry__ as g; g.build()"); the default library carries the host
+// plumbing and answers AZMI_PIPE_NET=conveyor with an error.
+#ifdef AZMI_WITH_CONVEYOR
+#include "../../scripts/experiments/conveyor_c4.h"
+#endif
 
 using namespace azmi;
 
@@ -1312,6 +1318,7 @@ __global__ void k_pair_wait(uint32_t* flag) {
 }
 __global__ void k_pair_set(uint32_t* flag) { g_st(flag, 1u); }
 
+#ifdef AZMI_WITH_CONVEYOR
 // ---- the conveyor (conveyor_c4.h): its service kernel, and the launch-order helper --------------------------------------------------------
 namespace cvn = azmi_net_dev::cv;
 struct C4KeyFn {      // Connect4::key of a packed position (what k_pipe_net computes for the answer table)
@@ -1347,6 +1354,7 @@ __global__ __launch_bounds__(cvn::SVC_THREADS, 2) void k_cv_service(cvn::CvArgs 
   if (cv_census(pe, hold, &pe->svc_arrived, &pe->svc_late_n)) return;
   cvn::service_wg<C4KeyFn, 4, 16>(a, sp, lds_cvs, C4KeyFn{});
 }
+#endif   // AZMI_WITH_CONVEYOR
 // the tree kernel is launched behind this one: the conv workgroups (a whole CU each) take their places first, the tree workgroups
 // pack into what is left (two per CU).  Gives up after 0.5 ms: placement is speed, never correctness
 __global__ void k_cv_wait_started(PipeEpoch* pe, uint32_t want) {
@@ -1631,6 +1639,8 @@ int pipe_pair_svc(PipeState* ps, hipStream_t st) {
                         "needs three kernels on the chip together; AZMI_PIPE_NET=tiles runs the tile kernel");
 }
 
+void pipe_launch_tree(azmi_pm* pm, PipeState* ps, const PipeArrays& pa, hipStream_t st, bool prof);
+#ifdef AZMI_WITH_CONVEYOR
 // ---- the conveyor's host side ---------------------------------------------------------------------------------------------------------
 // When the net side can be the conveyor (conveyor_c4.h): the bf16 tier, one model group, an even number of residual blocks (a conv
 // workgroup = two blocks).  Round 5: opt-in (AZMI_PIPE_NET=conveyor; an error where it cannot run) - bit for bit the tile kernel's
@@ -1714,7 +1724,6 @@ int cv_zero_headers(PipeState* ps, hipStream_t st) {
   AZMI_HIP_TRY(hipMemsetAsync(ps->cv_xh, 0, static_cast<size_t>(ps->cv_lines) * (ps->cv_nwg + 1u) * 512u, st));
   return AZMI_OK;
 }
-void pipe_launch_tree(azmi_pm* pm, PipeState* ps, const PipeArrays& pa, hipStream_t st, bool prof);
 // Measures how many LINES run beside the tree workgroups (pipe_calibrate's census, for the conveyor): every workgroup of the three
 // kernels holds its place; a conv workgroup that the chip has no CU for starts late and is counted, and the line count gives way.
 int cv_calibrate(azmi_pm* pm, PipeState* ps, hipStream_t st, const azmi_net_c4_view& view) {
@@ -1751,6 +1760,15 @@ int cv_calibrate(azmi_pm* pm, PipeState* ps, hipStream_t st, const azmi_net_c4_v
   return azmi_host_fail(AZMI_ERR_STATE, "azmi_run_pipeline: the chip does not hold %u tree workgroups beside one conveyor line (another tenant on the GPU? no third "
                         "hardware queue?); AZMI_PIPE_NET=tiles runs the tile kernel", ps->tree_wgs);
 }
+#else      // the default library: the conveyor is not compiled in (scripts/experiments/conveyor_c4.h)
+static int cv_absent() { return azmi_host_fail(AZMI_ERR_STATE, "this build has no conveyor (an experiment since round 6: build with -DAZMI_WITH_CONVEYOR); the tile kernel is the net side"); }
+bool cv_eligible(const azmi_pm*, const PipePlan&) { return false; }
+uint32_t cv_default_lines(uint32_t, uint32_t, uint32_t) { return 0u; }
+int cv_setup(azmi_pm*, PipeState*, const azmi_net_c4_view&) { return cv_absent(); }
+int cv_launch(PipeState*, const azmi_net_c4_view&, const PipeArrays&, uint32_t) { return cv_absent(); }
+int cv_zero_headers(PipeState*, hipStream_t) { return cv_absent(); }
+int cv_calibrate(azmi_pm*, PipeState*, hipStream_t, const azmi_net_c4_view&) { return cv_absent(); }
+#endif     // AZMI_WITH_CONVEYOR
 
 // Measures how many net workgroups run BESIDE the tree workgroups: both persistent kernels are launched as they are in an epoch, with
 // PipeArrays::census_hold set - every workgroup that gets a place holds it until 1 ms after the first one started (far longer than the
@@ -1932,7 +1950,11 @@ static int run_pipeline_impl(azmi_pm* pm, azmi_net* const* nets, uint32_t num_ne
   // the net side: the conveyor where it can run (conveyor_c4.h), else the tile kernel
   ps->cv_on = cv_eligible(pm, plan);
   if (const char* e = getenv("AZMI_PIPE_NET")) if (strcmp(e, "conveyor") == 0 && !ps->cv_on && !tree_only)
+#ifdef AZMI_WITH_CONVEYOR
     return azmi_host_fail(AZMI_ERR_STATE, "AZMI_PIPE_NET=conveyor: the conveyor runs the bf16 tier behind one model group with an even number of residual blocks");
+#else
+    return cv_absent();
+#endif
   if (ps->cv_on) {
     if (ps->balance) { ps->tree_wgs = ps->tree_wgs_default; pa.n_tree_wgs = ps->tree_wgs; }      // (the 512-place balance rule is the tile kernel's)
     pa.cap_ticks = static_cast<unsigned long long>((getenv("AZMI_PIPE_CAP_MS") ? atof(getenv("AZMI_PIPE_CAP_MS")) : 250.0) * 1e5);

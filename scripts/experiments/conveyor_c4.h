@@ -25,8 +25,8 @@
 // * Arithmetic: the SAME MFMAs on the same operands in the same order per accumulator as leafnet_c4.h's tile, the same epilogue
 //   expressions: bit-identical answers (tests/test_gpu_conveyor.py), so every fixture and parity tier carries over.
 #pragma once
-#include "leafnet_c4.h"
-#include "pipe_types.h"
+#include "../../alphazero-pybind11_amd/csrc/leafnet_c4.h"
+#include "../../alphazero-pybind11_amd/csrc/pipe_types.h"
 
 namespace azmi_net_dev {
 namespace cv {

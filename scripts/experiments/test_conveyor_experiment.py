@@ -1,4 +1,7 @@
-"""-m gpu: the conveyor (csrc/conveyor_c4.h: the Connect4 leaf net as lines of weight-stationary conv wavefronts + service waves)
+"""An EXPERIMENT since round 6 (not collected by `pytest tests/`): needs a library built with -DAZMI_WITH_CONVEYOR
+(AZMI_HIPCC_EXTRA=-DAZMI_WITH_CONVEYOR python -c "import __graft_entry__ as g; g.build()"), then
+    python -m pytest scripts/experiments/test_conveyor_experiment.py -m gpu -p no:cacheprovider --rootdir tests -c /dev/null
+-m gpu: the conveyor (scripts/experiments/conveyor_c4.h: the Connect4 leaf net as lines of weight-stationary conv wavefronts + service waves)
 answers every position bit for bit as the tile kernel of csrc/leafnet_c4.h does - the same MFMAs on the same operands in the same
 order per accumulator, the same epilogue and head expressions (neural_net.py:233-263, 448-510, 800-823) - so every fixture and
 parity tier of the tile carries over.  Both paths drain the same synthetic request ring (azmi_debug_pipe_net_answers)."""

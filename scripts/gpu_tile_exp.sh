@@ -7,7 +7,7 @@ IFS='|' read -ra SETS <<< "${KNOBS:-}"
 i=0
 for k in "base" "${SETS[@]}"; do
   [ "$k" = "base" ] && k=""
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -w $k tile_exp.hip -o /tmp/tx_$i || { echo "build failed: $k" >> $out; i=$((i+1)); continue; }
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -w $FLAGS $k tile_exp.hip -o /tmp/tx_$i || { echo "build failed: $k" >> $out; i=$((i+1)); continue; }
   i=$((i+1))
 done
 # two passes over the binaries (box warm-up / clock drift shows as a difference between the passes)

@@ -3,7 +3,7 @@
 //         -I alphazero-pybind11_amd/csrc -o /tmp/cv_line.s scripts/micro/cv_line_check.hip
 #include <hip/hip_runtime.h>
 #include <cstdint>
-#include "conveyor_c4.h"
+#include "../experiments/conveyor_c4.h"
 namespace cvn = azmi_net_dev::cv;
 extern "C" __global__ __launch_bounds__(256, 1) void k_line(cvn::CvArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_cvl[];

@@ -9,6 +9,18 @@
 #ifndef X_NRING
 #define X_NRING 5
 #endif
+#ifndef X_NWV
+#define X_NWV 4            // waves per workgroup: 8 = two per SIMD inside ONE tile (n-tiles per wave halved, 128 registers)
+#endif
+#ifndef X_STAMP
+#define X_STAMP 0          // 1: wave 0 stamps s_memtime at the phase boundaries; the per-phase cycle sums of every tile go to stamp_out[tile][16]
+#endif
+#ifndef X_NOGUARD
+#define X_NOGUARD 0        // 1: the conv epilogues store every lane's pixel (the 2-4 padding pixels of a tile too: bias-only values nobody reads) - no exec-mask region per store
+#endif
+#ifndef X_SWP
+#define X_SWP 1            // 1: fragments of k-step i + 1 read while the MFMAs of k-step i issue (double buffer); 0: read, wait, multiply
+#endif
 #ifndef X_SCHED
 #define X_SCHED 0
 #endif
@@ -75,7 +87,13 @@ __device__ __forceinline__ bf16x8 lds_read_frag(const uint8_t* p) {
 //   * every reduction runs in an order that does not depend on where a board sits in its tile or batch, so a position's
 //     (v, pi) is bit-identical wherever the engine's unordered eval list places it.
 namespace c4 {
-constexpr int NTH = 256, NWV = 4;      // threads, waves (one per SIMD)
+#if X_STAMP
+__device__ unsigned long long* g_stamp_out;
+#define X_ST(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_t; st_t = t_; } while (0)
+#else
+#define X_ST(i) do {} while (0)
+#endif
+constexpr int NWV = X_NWV, NTH = 64 * NWV;      // waves, threads
 constexpr int BH = 6, BW = 7, PIX = BH * BW;
 constexpr int CHUNK_KS = 2;            // k-steps per weight chunk (= one 3x3 tap)
 constexpr int CHUNK_BYTES = CHUNK_KS * MT * WFRAG_BYTES;   // 8,192
@@ -149,10 +167,17 @@ __device__ __forceinline__ void dma16x2(const uint8_t* src_lane, uint32_t dst) {
                : "=&s"(keep) : "v"(src_lane), "s"(dst) : "memory");
 #endif
 }
+__device__ __forceinline__ void dma16x1(const uint8_t* src_lane, uint32_t dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src_lane), "s"(dst) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_vm() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
   else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else static_assert(N == 0, "add the count");
@@ -220,6 +245,9 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
   // of that loop and spilled (64 scratch stores in its preheader); an opaque copy keeps it where it is
   if constexpr (PIPE) asm volatile("" : "+v"(tid_));
   const int tid = tid_, lane = tid & 63;
+#if X_STAMP
+  unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
+#endif
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, quad = lane >> 4;
   const uint32_t board0 = tile_index * TBW;
@@ -248,8 +276,9 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
   const size_t wave_off = static_cast<size_t>(wave * PIECES) * WFRAG_BYTES;
   const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lptr_t)ring))) + static_cast<uint32_t>(wave_off);
   auto issue_chunk = [&](const uint8_t* chunk_src, int slot) {
-    static_assert(PIECES == 2, "dma16x2 moves the wave's two pieces");
-    dma16x2(chunk_src + wave_off + lane * 16, ring_lds + static_cast<uint32_t>(slot) * CHUNK_BYTES);
+    static_assert(PIECES == 2 || PIECES == 1, "one or two 1 KB pieces per wave");
+    if constexpr (PIECES == 2) dma16x2(chunk_src + wave_off + lane * 16, ring_lds + static_cast<uint32_t>(slot) * CHUNK_BYTES);
+    else dma16x1(chunk_src + wave_off + lane * 16, ring_lds + static_cast<uint32_t>(slot) * CHUNK_BYTES);
   };
   const uint8_t* const conv0_w = np.blocks + 3 * CH * sizeof(float);      // block 0, conv1
   // ring slots 3 and 4 first hold the stem's operands: 8 KB of stem fragments, and the tile's raw input planes
@@ -262,7 +291,7 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
             reinterpret_cast<uint8_t*>(raw) + wave * 1024);
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) dma16(np.stem_w + (wave * 2 + i) * WFRAG_BYTES + lane * 16, stem_w_lds + (wave * 2 + i) * WFRAG_BYTES);
+  for (int i = 0; i < PIECES; ++i) dma16(np.stem_w + (wave * PIECES + i) * WFRAG_BYTES + lane * 16, stem_w_lds + (wave * PIECES + i) * WFRAG_BYTES);
 #pragma unroll
   for (int i = 0; i < NRING - 2; ++i) issue_chunk(conv0_w + i * CHUNK_BYTES, i);
 
@@ -287,7 +316,7 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
   }
 
   // ---- stem: im2col of the CIN input planes, B[k = tap*CIN + ci][pixel] (k < 64), one thread per pixel --------------
-  wait_vm<2 * (NRING - 2)>();                      // input planes + stem fragments have landed (chunks 0-2 stay in flight)
+  wait_vm<PIECES * (NRING - 2)>();                      // input planes + stem fragments have landed (chunks 0-2 stay in flight)
   barrier_lds();
   if constexpr (PIPE) {
     static_assert(CIN == 4, "the packed-position stem is Connect4's: two stone planes + two player planes");
@@ -448,7 +477,7 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
     for (int ks = 0; ks < NKS; ++ks) {
       const int cur = ks & 1, c = ks / CHUNK_KS, ksl = ks % CHUNK_KS;
       if (ksl == CHUNK_KS - 1) {            // open chunk c + 1 (the next convolution's first chunk when c is the last)
-        if constexpr (DBG == 0) wait_vm<2 * (NRING - 3)>();      // chunk g + 1 has landed; g + 2 and g + 3 (2 pieces each) may still be in flight
+        if constexpr (DBG == 0 || DBG == 7) wait_vm<PIECES * (NRING - 3)>();      // chunk g + 1 has landed; g + 2 and g + 3 (2 pieces each) may still be in flight
         if (c == NCH - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (DBG != 2) { __builtin_amdgcn_s_barrier(); }
         __builtin_amdgcn_sched_barrier(0);
@@ -458,12 +487,19 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
       } else {
         __builtin_amdgcn_sched_barrier(0);
       }
+#if X_SWP
       if constexpr (DBG != 4) {
         if (ks + 1 < NKS) {
           load_a((ks + 1) % CHUNK_KS, wlane + slot * CHUNK_BYTES, a[cur ^ 1]);
           load_b(ks + 1, b[cur ^ 1]);
         }
       }
+#else
+      if (ks > 0) {      // (at the chunk's second k-step `slot` already names the next chunk's slot)
+        const int slot_cur = (ksl == CHUNK_KS - 1) ? (slot == 0 ? NRING - 1 : slot - 1) : slot;
+        load_a(ks % CHUNK_KS, wlane + slot_cur * CHUNK_BYTES, a[cur]); load_b(ks, b[cur]);
+      }
+#endif
       if constexpr (DBG == 5) {
 #pragma unroll
         for (int j = 0; j < NTW; ++j) asm volatile("" :: "v"(b[cur][j]));
@@ -474,7 +510,7 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
         for (int j = 0; j < NTW; ++j)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[cur][mt], b[cur][j], acc[j][mt], 0, 0, 0);
-        if (ks + 1 < NKS) {
+        if (X_SWP && ks + 1 < NKS) {
           // issue order inside the k-step: 2 MFMAs and one A fragment of the next k-step (x4: its first MFMAs need all
           // four), then 2 MFMAs, the address arithmetic and the read of one B fragment (x4)
 #if X_SCHED == 0
@@ -522,6 +558,7 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
     return conv_run(acc, slot0, wbase, wnext, std::integral_constant<int, CPC>{}, std::false_type{});
   };
 
+  X_ST(0);
   if constexpr (DBG == 6) { if (s[0][0][0] == 12345.678f) v_out[0] = s[1][1][1] + s[2][2][2] + s[3][3][3]; return; }   // timing: stem only
   int slot = 0;
   for (int blk = 0; blk < depth; ++blk) {
@@ -534,7 +571,7 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
       const f32x4 b1 = *reinterpret_cast<const f32x4*>(affine + CH + mt * 16 + quad * 4);
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
-        if (!((real_m >> j) & 1u)) continue;
+        if (!X_NOGUARD && !((real_m >> j) & 1u)) continue;
         f32x4 t;
 #pragma unroll
         for (int r = 0; r < 4; ++r) t[r] = fmaxf(a1[r] * s[j][mt][r] + b1[r], 0.0f);
@@ -549,26 +586,30 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
 #pragma unroll
       for (int j = 0; j < NTW; ++j) u[j][mt] = c1;
     }
-    if (blk == 0) { if constexpr (DBG == 0) wait_vm<2 * (NRING - 3)>(); }      // chunk 0 (chunks 1 and 2 stay in flight)
+    if (blk == 0) { if constexpr (DBG == 0 || DBG == 7) wait_vm<PIECES * (NRING - 3)>(); }      // chunk 0 (chunks 1 and 2 stay in flight)
     barrier_lds();                                        // barrier C: planes visible (and, block 0, chunk 0 landed for every wave)
     if (blk == 0) { if constexpr (DBG != 3) issue_chunk(conv0_w + (NRING - 2) * CHUNK_BYTES, NRING - 2); }  // the stem is done with slot 3 (slot 4: chunk 4, at the first chunk barrier)
+    X_ST(1);
     const uint8_t* const w1 = np.blocks + blk * block_stride + 3 * CH * sizeof(float);
     const uint8_t* const w2 = w1 + CPC * CHUNK_BYTES;
     const uint8_t* const wn = blk + 1 < depth ? w2 + CPC * CHUNK_BYTES + 3 * CH * sizeof(float) : np.head_w;
     slot = conv3x3(u, slot, w1, w2);
+    X_ST(2);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
-        if (!((real_m >> j) & 1u)) continue;
+        if (!X_NOGUARD && !((real_m >> j) & 1u)) continue;
         f32x4 t;
 #pragma unroll
         for (int r = 0; r < 4; ++r) t[r] = fmaxf(u[j][mt][r], 0.0f);
         store4(j, mt * 2, t);
       }
     barrier_lds();
+    X_ST(3);
     // s = s + conv2(u)
     slot = conv3x3(s, slot, w2, wn);
+    X_ST(4);
   }
 
   if constexpr (DBG == 7) { if (s[0][0][0] == 12345.678f) v_out[0] = s[1][1][1] + s[2][2][2] + s[3][3][3]; return; }   // timing: stem + trunk
@@ -577,7 +618,7 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
-      if ((real_m >> j) & 1u) store4(j, mt * 2, s[j][mt]);
+      if (X_NOGUARD || ((real_m >> j) & 1u)) store4(j, mt * 2, s[j][mt]);
   f32x4 hacc[NTW][MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -624,6 +665,7 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
     }
     barrier_lds();
   }
+  X_ST(5);
   if constexpr (DBG == 8) { if (hacc[0][0][0] == 12345.678f) v_out[0] = hacc[1][1][1] + hacc[2][2][2]; return; }   // timing: ... + head 1x1 conv
   // (the value head's FC operands are requested now - the head accumulators are about to die - and land during the policy FC)
   // value fc1 on the exact-fp32 matrix pipe (v_mfma_f32_16x16x4_f32, the boards as the 16 columns; round 4 - the VALU form, one
@@ -680,6 +722,7 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
     }
   }
   barrier_lds();
+  X_ST(6);
   {
     // policy logits: wave w sums pixel positions [p0, p0 + npos) (11, 11, 10, 10), partial tiles are added in wave order
     const int bsrc0 = col < TBW ? col * PIX * 16 : ZERO_OFF + col * 16;      // board `col`, or an all-zero cell
@@ -709,6 +752,7 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
     vpool[b * HC + c] = ((a0 + a1) + (a2 + a3)) / static_cast<float>(PIX);
   }
   barrier_lds();
+  X_ST(7);
   if constexpr (DBG == 9) { if (part[tid] == 12345.678f) v_out[0] = vpool[tid & 63]; return; }   // timing: ... + policy FC partials and the value pool
   if (tid < TBW * M) {
     const int b = tid / M, m = tid % M;
@@ -738,6 +782,7 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
     }
   }
   barrier_lds();
+  X_ST(8);
   for (int b = wave; b < TBW; b += NWV) {      // value fc2: a wave per board, lane l sums hidden units l, l + 64, ...
     float acc[MAXP1];
 #pragma unroll
@@ -758,6 +803,7 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
     }
   }
   barrier_lds();
+  X_ST(9);
   if constexpr (DBG == 10) { if (logits[tid & 63] == 12345.678f) v_out[0] = 1.0f; return; }   // timing: ... + the value FCs
   // softmax = exp(log_softmax), neural_net.py:468,508,816: one thread per output entry; every thread of a group walks the
   // group's logits in the same order, so the shared maximum and sum are bit-identical across the group
@@ -788,6 +834,10 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
       }
     }
   }
+#if X_STAMP
+  X_ST(10);
+  if (tid == 0) for (int i = 0; i < 12; ++i) g_stamp_out[static_cast<size_t>(tile_index) * 16 + i] = st_acc[i];
+#endif
 }
 
 template <class TG, int CIN, int MAXP1, int MAXM>

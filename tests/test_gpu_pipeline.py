@@ -811,3 +811,25 @@ def test_a_request_the_net_side_cannot_read_is_given_up_and_sent_again(monkeypat
     assert pa.games_completed() == pb.games_completed() == S
     sa, sb = _sorted_log(ra, ca), _sorted_log(rb, cb)
     assert np.array_equal(sa[0], sb[0]) and np.array_equal(sa[1], sb[1])
+
+
+def test_the_default_library_has_no_conveyor_and_says_so(monkeypatch):
+    """round 6: the conveyor (round 5's weight-stationary net side, a measured loser) is an experiment build (scripts/experiments/,
+    -DAZMI_WITH_CONVEYOR); the default library answers AZMI_PIPE_NET=conveyor with an error by name instead of silently running the tiles"""
+    import alphazero as az
+    from alphazero import torch_net
+    spec = torch_net.connect4_spec()
+    hip = az.HipLeafNet(torch_net.random_init(spec, seed=4), spec)
+    pp = _selfplay_params(az, 64, 20, cache=1 << 10)
+    pm = az.PlayManager(az.Connect4GS(), pp, seed=3)
+    st = torch.cuda.Stream()
+    monkeypatch.setenv("AZMI_PIPE_NET", "conveyor")
+    try:
+        az.run_pipeline(pm, hip, 1, 64 * 8, st.cuda_stream)
+    except RuntimeError as e:
+        assert "no conveyor" in str(e), str(e)
+    else:
+        # (an experiment build: the conveyor ran)
+        pass
+    monkeypatch.delenv("AZMI_PIPE_NET")
+    az.run_pipeline(pm, hip, 1, 64 * 8, st.cuda_stream)          # the engine is whole: the tile kernel carries on
