@@ -928,6 +928,24 @@ def main():
                 out["roofline"]["tiles_alone_frac"] = tf / MFMA_PEAK_TFLOPS      # (flat copies: a parsed line keeps scalars only)
                 out["roofline"]["tiles_alone_us_per_launch"] = us
                 del xr, vr, pr
+                # round 6: the same tile SUSTAINED - 18432 rows = 3072 six-board tiles = six rounds of workgroups per launch, so
+                # co-resident workgroups drift out of phase as the persistent ones of the pipeline do (one round of 512 tiles that start
+                # together keeps both workgroups of a CU in the same phase: stems, epilogues and heads coincide and the matrix pipe idles
+                # through them - DESIGN 4.5 (v))
+                xs = (torch.rand((18432,) + tuple(spec.in_shape), device=dev) < 0.3).float()
+                vs = torch.empty((18432, spec.num_players + 1), device=dev); ps_ = torch.empty((18432, spec.num_moves), device=dev)
+                for _ in range(5):
+                    hip_net.forward(xs, vs, ps_)
+                ea.record()
+                for _ in range(60):
+                    hip_net.forward(xs, vs, ps_)
+                eb.record(); torch.cuda.synchronize()
+                us2 = ea.elapsed_time(eb) * 1e3 / 60
+                tf2 = 18432 * flop_per_eval / us2 / 1e6
+                out["roofline"]["tiles_alone_sustained_frac"] = tf2 / MFMA_PEAK_TFLOPS
+                out["roofline"]["tiles_alone_sustained_us_per_launch"] = us2
+                out["roofline"]["tiles_alone_sustained_rows"] = 18432
+                del xs, vs, ps_
             if True:
                 # the second kernel of the path, the tree step (HBM side): algorithmic bytes per simulation from SURVEY §8d
                 # (select + backup + expand + state + canonical + eval rows: Connect4 1.3 KB with the measured depth 3.5 / 6.8
