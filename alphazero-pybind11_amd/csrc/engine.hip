@@ -156,7 +156,6 @@ int launch_round(azmi_pm* pm, hipStream_t st, bool defer_moves = false) {
     case AZMI_GAME_STARGAMBIT:
       launch_pre_round<StarGambit>(pm, st);
       if (pm->any_playout) k_round_big<StarGambit, true><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
-      else if (pm->big_split == 2) { k_round_big_sim<StarGambit><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar); k_round_big_move<StarGambit><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar); }
       else if (pm->big_split) { k_round_big_sim1<StarGambit><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar); k_round_big_move<StarGambit><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar); }
       else k_round_big<StarGambit><<<pm->ep.S, 64, 0, st>>>(pm->ep, pm->ar);
       if (pm->ep.half_nodes) k_compact<StarGambit><<<std::min(pm->ep.S * pm->gi.P, kCompactBlocks), 256, 0, st>>>(pm->ep, pm->ar, pm->ep.S * pm->gi.P);
@@ -830,8 +829,8 @@ int pm_create_impl(int game, const azmi_play_params* params, const azmi_engine_o
   pm->any_playout = seats.any_playout;
   pm->split_rounds = game == AZMI_GAME_CONNECT4 && !seats.any_gumbel && !seats.any_playout && getenv("AZMI_NO_SPLIT") == nullptr;
   pm->big_split = (game == AZMI_GAME_TAWLBWRDD || game == AZMI_GAME_BRANDUBH || game == AZMI_GAME_OPENTAFL || game == AZMI_GAME_STARGAMBIT) && !seats.any_playout && getenv("AZMI_NO_BIG_SPLIT") == nullptr;
-  // (StarGambit, round 6: the simulation kernel at one wave per SIMD by default; AZMI_SG_SIM_O2=1 holds it to 256 registers)
-  if (pm->big_split && game == AZMI_GAME_STARGAMBIT && getenv("AZMI_SG_SIM_O2")) pm->big_split = 2;
+  // (StarGambit, round 6: its simulation kernel keeps the whole register file - k_round_big_sim1, one wave per SIMD: held to 256
+  // registers it spills 232 of them)
   ep.cpuct = params->cpuct; ep.start_temp = params->start_temp; ep.final_temp = params->final_temp;
   ep.half_life = params->temp_decay_half_life;
   ep.n_half_life_v = 0;

@@ -53,7 +53,7 @@ struct azmi_pm {
   bool all_random = false;               // no seat needs a net (EvalType::RANDOM / PLAYOUT everywhere)
   bool any_playout = false;              // some seat uses EvalType::PLAYOUT
   uint32_t nn_groups = 0;                // bit g: a seat of model group g evaluates with the net
-  bool big_split = false;                // Tafl family, no PLAYOUT seats: k_round_big_sim + k_round_big_move instead of the one k_round_big_o2 (engine_kernels_big.h)
+  bool big_split = false;                // wide games, no PLAYOUT seats: k_round_big_sim (StarGambit: k_round_big_sim1) + k_round_big_move instead of the one-kernel round (engine_kernels_big.h)
   bool split_rounds = false;             // Connect4, plain PUCT seats: k_sim + move step instead of the one k_round (engine_kernels.h)
   bool max_inline_explicit = false;      // azmi_pm_options.max_inline was given (the pipeline then keeps it instead of its own default)
   std::vector<std::deque<uint32_t>> pending_g;   // host-buffer path: pending leaves per model group

@@ -86,7 +86,7 @@ rm -rf /tmp/kss
 echo "== pmc traffic, StarGambit round kernels"
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmcs_$ctr && mkdir -p /tmp/pmcs_$ctr
-  timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmcs_$ctr -o r -- python3 bench.py --worker --game stargambit --warmup 0 --no-secondary --preroll-factor 0.02 --no-cpu-baseline --steps 1 --rounds-per-step 64 --profile-window > gpurun_out/r6_pmcs_$ctr.log 2>&1 || { echo "stargambit pmc $ctr failed"; tail -5 gpurun_out/r6_pmcs_$ctr.log; }
+  timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmcs_$ctr -o r -- python3 bench.py --worker --game stargambit --warmup 0 --no-secondary --preroll-factor 0.002 --no-cpu-baseline --steps 1 --rounds-per-step 64 --profile-window > gpurun_out/r6_pmcs_$ctr.log 2>&1 || { echo "stargambit pmc $ctr failed"; tail -5 gpurun_out/r6_pmcs_$ctr.log; }
 done
 python3 - "$commit" <<'PY'
 import csv, glob, collections, sys
