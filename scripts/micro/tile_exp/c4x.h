@@ -18,6 +18,9 @@
 #ifndef X_NOGUARD
 #define X_NOGUARD 0        // 1: the conv epilogues store every lane's pixel (the 2-4 padding pixels of a tile too: bias-only values nobody reads) - no exec-mask region per store
 #endif
+#ifndef X_FMA
+#define X_FMA 0            // 1: the pre-activation affine of an epilogue as ONE fma per value (the library is built with -ffp-contract=off: a multiply and an add)
+#endif
 #ifndef X_SWP
 #define X_SWP 1            // 1: fragments of k-step i + 1 read while the MFMAs of k-step i issue (double buffer); 0: read, wait, multiply
 #endif
@@ -574,7 +577,7 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
         if (!X_NOGUARD && !((real_m >> j) & 1u)) continue;
         f32x4 t;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) t[r] = fmaxf(a1[r] * s[j][mt][r] + b1[r], 0.0f);
+        for (int r = 0; r < 4; ++r) t[r] = X_FMA ? fmaxf(__builtin_fmaf(a1[r], s[j][mt][r], b1[r]), 0.0f) : fmaxf(a1[r] * s[j][mt][r] + b1[r], 0.0f);
         store4(j, mt * 2, t);
       }
     }
