@@ -21,6 +21,9 @@
 #ifndef X_FMA
 #define X_FMA 0            // 1: the pre-activation affine of an epilogue as ONE fma per value (the library is built with -ffp-contract=off: a multiply and an add)
 #endif
+#ifndef X_STAGGER
+#define X_STAGGER 0        // shader cycles the second half of the grid (blockIdx >= gridDim / 2: with one round of 2 x CUs tiles, the CU partners of the first half) waits before it starts: deterministic anti-phase of the two workgroups of a CU
+#endif
 #ifndef X_SWP
 #define X_SWP 1            // 1: fragments of k-step i + 1 read while the MFMAs of k-step i issue (double buffer); 0: read, wait, multiply
 #endif
@@ -239,6 +242,9 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
   if (in_row >= max_rows) in_row = max_rows - 1;
   if (rows) { batch = *row_count; in_row = rows[in_row]; }
   if (tile_index * TBW >= batch) return;
+#if X_STAGGER
+  if (blockIdx.x >= gridDim.x / 2) { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); while (__builtin_amdgcn_s_memtime() - t0_ < X_STAGGER) __builtin_amdgcn_s_sleep(4); }
+#endif
   uint8_t* const act = lds + TG::ACT_OFF;
   uint8_t* const ring = lds + TG::RING_OFF;
   float* const prm = reinterpret_cast<float*>(lds + TG::RING_OFF + RING_BYTES);
