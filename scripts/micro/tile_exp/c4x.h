@@ -243,7 +243,11 @@ __device__ __forceinline__ void tile(const NetDesc& nd, const NetPtrs& np, const
   if (rows) { batch = *row_count; in_row = rows[in_row]; }
   if (tile_index * TBW >= batch) return;
 #if X_STAGGER
-  if (blockIdx.x >= gridDim.x / 2) { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); while (__builtin_amdgcn_s_memtime() - t0_ < X_STAGGER) __builtin_amdgcn_s_sleep(4); }
+  #ifndef X_STAGGER_WHO
+#define X_STAGGER_WHO 0      // which workgroups wait: 0 = the second half of the grid, 1 = odd block indices, 2 = odd (block index / 8) (XCD round-robin), 3 = the SIMD's second wave slot (HW_REG_HW_ID wave id bit 0)
+#endif
+  if (X_STAGGER_WHO == 0 ? blockIdx.x >= gridDim.x / 2 : X_STAGGER_WHO == 1 ? (blockIdx.x & 1u) != 0u : X_STAGGER_WHO == 2 ? ((blockIdx.x >> 3) & 1u) != 0u
+                         : (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1u) != 0u) { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); while (__builtin_amdgcn_s_memtime() - t0_ < X_STAGGER) __builtin_amdgcn_s_sleep(4); }
 #endif
   uint8_t* const act = lds + TG::ACT_OFF;
   uint8_t* const ring = lds + TG::RING_OFF;
