@@ -928,10 +928,9 @@ def main():
                 out["roofline"]["tiles_alone_frac"] = tf / MFMA_PEAK_TFLOPS      # (flat copies: a parsed line keeps scalars only)
                 out["roofline"]["tiles_alone_us_per_launch"] = us
                 del xr, vr, pr
-                # round 6: the same tile SUSTAINED - 18432 rows = 3072 six-board tiles = six rounds of workgroups per launch, so
-                # co-resident workgroups drift out of phase as the persistent ones of the pipeline do (one round of 512 tiles that start
-                # together keeps both workgroups of a CU in the same phase: stems, epilogues and heads coincide and the matrix pipe idles
-                # through them - DESIGN 4.5 (v))
+                # round 6: the same tile SUSTAINED - 18432 rows = 3072 six-board tiles = six rounds of workgroups per launch: the ramp
+                # (every workgroup's first weight chunks from a cold L2 at once) and the tail (a CU idles from its first finished tile to
+                # its last) of a one-round launch are amortised, as they are for the pipeline's persistent workgroups - DESIGN 4.5 (v)
                 xs = (torch.rand((18432,) + tuple(spec.in_shape), device=dev) < 0.3).float()
                 vs = torch.empty((18432, spec.num_players + 1), device=dev); ps_ = torch.empty((18432, spec.num_moves), device=dev)
                 for _ in range(5):
