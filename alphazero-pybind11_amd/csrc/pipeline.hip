@@ -1576,7 +1576,12 @@ int pipe_size_net(azmi_pm* pm, PipeState* ps, const azmi_net_c4_view& view) {
   return AZMI_OK;
 }
 int pipe_launch_net(PipeState* ps, const azmi_net_c4_view& view, int mode, uint32_t wgs, hipStream_t st, const PipeArrays& pa) {
-  pipe_net_fn(mode, ps->x3)<<<wgs, 256, ps->lds_bytes, st>>>(view.nd, view.np, ps->np1_valid ? ps->np1 : view.np, pa);
+  // AZMI_WHATIF_NET_DEPTH=n (a measurement knob, never a result: the answers are another net's): the tiles run n residual blocks
+  // instead of the net's - how much of the pipeline's rate is the tile's latency
+  azmi_net_dev::NetDesc nd = view.nd;
+  static const int whatif_depth = getenv("AZMI_WHATIF_NET_DEPTH") ? atoi(getenv("AZMI_WHATIF_NET_DEPTH")) : 0;
+  if (whatif_depth > 0 && whatif_depth < nd.depth) nd.depth = whatif_depth;
+  pipe_net_fn(mode, ps->x3)<<<wgs, 256, ps->lds_bytes, st>>>(nd, view.np, ps->np1_valid ? ps->np1 : view.np, pa);
   AZMI_HIP_TRY(hipGetLastError());
   return AZMI_OK;
 }
