@@ -3,6 +3,7 @@
   SHAPE=net_random       two model groups, a net behind group 0 and RANDOM seats in group 1 (the RandPlayer baseline match), 256 slots
   SHAPE=gumbel_two_nets  Gumbel roots, two different nets behind two model groups (play_past), 512 slots
   SHAPE=slots_16384      the headline engine with 16384 concurrent games (one group, PUCT)
+  SHAPE=headline         the bench's engine itself (4096 x 800, 128 M-entry cache), epochs of 256 simulations per slot
 A pipeline error RAISES (no retry here): the run stops at the first one and prints it.  Credited freezes, lost requests and every
 error are counted in the last line."""
 import os, sys, time
@@ -27,6 +28,10 @@ elif shape == "gumbel_two_nets":
     pp = bench.selfplay_params(az, S, sims, 1 << 30, cache=1 << 18, gumbel=True)
     pp.model_groups, pp.seat_perms = [0, 1], [[0, 1], [1, 0]]
     nets = [net0, az.HipLeafNet(torch_net.random_init(spec, seed=1), spec)]
+elif shape == "headline":          # the bench's own engine: 4096 x 800, 128 M-entry cache
+    S, sims, E, Q = 4096, 800, 4, 256
+    pp = bench.selfplay_params(az, S, sims, 1 << 30, cache=128_000_000)
+    nets = None
 else:
     S, sims, E, Q = 16384, 800, 2, 64
     pp = bench.selfplay_params(az, S, sims, 1 << 30, cache=32_000_000)
