@@ -117,6 +117,7 @@ PYBIND11_MODULE(azmi_pybind, m) {
       .def_readwrite("temp_decay_half_life_by_variant", &PlayParams::temp_decay_half_life_by_variant)
       .def_readwrite("model_groups", &PlayParams::model_groups);
 
+
   py::class_<AzmiPM>(m, "DevicePlayManager")
       .def(py::init<int, const PlayParams&, uint64_t>(), py::arg("game"), py::arg("params"), py::arg("seed") = 0)
       .def("play", [](AzmiPM& s) { if (azmi_pm_play(s.h, AZMI_STREAM_ENGINE)) fail(); }, py::call_guard<py::gil_scoped_release>())
@@ -149,6 +150,48 @@ PYBIND11_MODULE(azmi_pybind, m) {
              uint32_t d = 0, l = 0;
              if (azmi_pm_poll(s.h, AZMI_STREAM_ENGINE, &d, &l)) fail();
              return l; })
+      // ---- the rest of PlayManager's read-out and control surface (py_wrapper.cc:108-330; play_manager.h:170-366): one C-ABI call each
+      .def("stop", [](AzmiPM& s) { if (azmi_pm_stop(s.h)) fail(); })
+      .def("stopped", [](AzmiPM& s) { int o = 0; if (azmi_pm_stopped(s.h, &o)) fail(); return o != 0; })
+      .def("awaiting_inference_count", [](AzmiPM& s) { uint32_t a = 0, b = 0; if (azmi_pm_queue_counts(s.h, &a, &b)) fail(); return a; })
+      .def("awaiting_mcts_count", [](AzmiPM& s) { uint32_t a = 0, b = 0; if (azmi_pm_queue_counts(s.h, &a, &b)) fail(); return b; })
+      .def("resign_scores", [](AzmiPM& s) {
+             py::array_t<float> out(static_cast<py::ssize_t>(s.P + 1));
+             if (azmi_pm_resign_scores(s.h, out.mutable_data())) fail();
+             return out; })
+      .def("avg_game_length", [](AzmiPM& s) { float o[7]; if (azmi_pm_stats(s.h, o)) fail(); return o[0]; })
+      .def("avg_leaf_depth", [](AzmiPM& s) { float o[7]; if (azmi_pm_stats(s.h, o)) fail(); return o[1]; })
+      .def("avg_search_entropy", [](AzmiPM& s) { float o[7]; if (azmi_pm_stats(s.h, o)) fail(); return o[2]; })
+      .def("fast_avg_leaf_depth", [](AzmiPM& s) { float o[7]; if (azmi_pm_stats(s.h, o)) fail(); return o[3]; })
+      .def("fast_avg_search_entropy", [](AzmiPM& s) { float o[7]; if (azmi_pm_stats(s.h, o)) fail(); return o[4]; })
+      .def("avg_moves_per_turn", [](AzmiPM& s) { float o[7]; if (azmi_pm_stats(s.h, o)) fail(); return o[5]; })
+      .def("avg_valid_moves", [](AzmiPM& s) { float o[7]; if (azmi_pm_stats(s.h, o)) fail(); return o[6]; })
+      .def("stat_sums", [](AzmiPM& s) {           // the accumulators behind the averages, for exact aggregation over engines / ranks
+             py::array_t<double> out(10);
+             if (azmi_pm_stat_sums(s.h, out.mutable_data())) fail();
+             return out; })
+      .def("hist_count", [](AzmiPM& s) { uint64_t o[6]; if (azmi_pm_counters(s.h, o)) fail(); return o[4]; })
+      .def("simulations", [](AzmiPM& s) { uint64_t o[6]; if (azmi_pm_counters(s.h, o)) fail(); return o[0]; })
+      .def("leaf_evaluations", [](AzmiPM& s) { uint64_t o[6]; if (azmi_pm_counters(s.h, o)) fail(); return o[1]; })
+      .def("cache_hits", [](AzmiPM& s) { uint64_t o[6]; if (azmi_pm_cache_stats(s.h, o)) fail(); return o[0]; })
+      .def("cache_misses", [](AzmiPM& s) { uint64_t o[6]; if (azmi_pm_cache_stats(s.h, o)) fail(); return o[1]; })
+      .def("cache_evictions", [](AzmiPM& s) { uint64_t o[6]; if (azmi_pm_cache_stats(s.h, o)) fail(); return o[2]; })
+      .def("cache_reinserts", [](AzmiPM& s) { uint64_t o[6]; if (azmi_pm_cache_stats(s.h, o)) fail(); return o[3]; })
+      .def("cache_size", [](AzmiPM& s) { uint64_t o[6]; if (azmi_pm_cache_stats(s.h, o)) fail(); return o[4]; })
+      .def("cache_max_size", [](AzmiPM& s) { uint64_t o[6]; if (azmi_pm_cache_stats(s.h, o)) fail(); return o[5]; })
+      .def("num_model_groups", [](AzmiPM& s) { uint32_t g = 0, q = 0; if (azmi_pm_groups(s.h, &g, &q)) fail(); return g; })
+      .def("num_seat_perms", [](AzmiPM& s) { uint32_t g = 0, q = 0; if (azmi_pm_groups(s.h, &g, &q)) fail(); return q; })
+      .def("perm_scores", [](AzmiPM& s, uint32_t idx) {
+             py::array_t<float> out(static_cast<py::ssize_t>(s.P + 1));
+             uint32_t games = 0;
+             if (azmi_pm_perm_scores(s.h, idx, out.mutable_data(), &games)) fail();
+             return out; })
+      .def("perm_games_completed", [](AzmiPM& s, uint32_t idx) {
+             std::vector<float> tmp(s.P + 1);
+             uint32_t games = 0;
+             if (azmi_pm_perm_scores(s.h, idx, tmp.data(), &games)) fail();
+             return games; })
+      .def("num_tracked_variants", [](AzmiPM& s) { return azmi_pm_num_variants(s.h); })
       .def_property_readonly("num_players", [](const AzmiPM& s) { return s.P; })
       .def_property_readonly("num_moves", [](const AzmiPM& s) { return s.M; })
       .def_property_readonly("canonical_shape", [](const AzmiPM& s) { return py::make_tuple(s.chw[0], s.chw[1], s.chw[2]); });

@@ -14,7 +14,11 @@ def _mods():
 
 def test_compiled_module_loads_and_exposes_the_bound_surface():
     az, ap = _mods()
-    for name in ("play", "build_batch", "update_inferences", "build_history_batch", "scores", "games_completed", "remaining_games"):
+    for name in ("play", "build_batch", "update_inferences", "build_history_batch", "scores", "games_completed", "remaining_games",
+                 "stop", "stopped", "awaiting_inference_count", "awaiting_mcts_count", "resign_scores", "avg_game_length", "avg_leaf_depth",
+                 "avg_search_entropy", "fast_avg_leaf_depth", "fast_avg_search_entropy", "avg_moves_per_turn", "avg_valid_moves", "stat_sums",
+                 "hist_count", "cache_hits", "cache_misses", "cache_evictions", "cache_reinserts", "cache_size", "cache_max_size",
+                 "num_model_groups", "num_seat_perms", "perm_scores", "perm_games_completed", "num_tracked_variants"):
         assert hasattr(ap.DevicePlayManager, name), name
     p = ap.PlayParams()
     p.games_to_play, p.concurrent_games, p.mcts_visits, p.eval_type = 4, 4, [10, 10], [1, 1]
@@ -53,6 +57,17 @@ def test_random_evaluator_games_equal_the_ctypes_module():
     assert a.games_completed() == b.games_completed() == 32 and a.remaining_games() == 0
     assert np.array_equal(np.asarray(a.scores()), np.asarray(b.scores()))
     assert a.num_players == 2 and a.num_moves == 7 and a.canonical_shape == (4, 6, 7)
+    # the read-out surface: every getter of the compiled binding against the ctypes module's (same C ABI underneath)
+    for name in ("avg_game_length", "avg_leaf_depth", "avg_search_entropy", "fast_avg_leaf_depth", "fast_avg_search_entropy",
+                 "avg_moves_per_turn", "avg_valid_moves", "hist_count", "cache_hits", "cache_misses", "cache_evictions", "cache_reinserts",
+                 "cache_size", "cache_max_size", "num_model_groups", "num_seat_perms", "num_tracked_variants", "awaiting_inference_count",
+                 "awaiting_mcts_count", "stopped"):
+        assert getattr(a, name)() == getattr(b, name)(), name
+    assert np.array_equal(np.asarray(a.resign_scores()), np.asarray(b.resign_scores()))
+    assert np.array_equal(np.asarray(a.stat_sums()), np.asarray(list(b.stat_sums().values())))
+    for q in range(a.num_seat_perms()):
+        assert np.array_equal(np.asarray(a.perm_scores(q)), np.asarray(b.perm_scores(q))) and a.perm_games_completed(q) == b.perm_games_completed(q)
+    assert a.simulations() == b.counters()["sims"] and a.leaf_evaluations() == b.counters()["evals"]
 
 
 @pytest.mark.gpu
